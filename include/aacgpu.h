@@ -1,0 +1,210 @@
+/*
+ * aacgpu.h — C ABI of the MI355X-native AAC-LC synthesis engine.
+ *
+ * This library replaces ONE seam of audiocogs/aac.js: everything that
+ * `AACDecoder.prototype.process(elements)` does plus the channel interleave that
+ * follows it in `readChunk` (reference src/decoder.js:201-215, 218-404), i.e.
+ *
+ *     inverse quantisation      src/ics.js:222-227,244-256  (+ tables src/tables.js:168-191)
+ *     mid/side stereo           src/decoder.js:379-404
+ *     intensity stereo          src/decoder.js:337-376
+ *     TNS                       src/tns.js:105-177   (identity as the reference runs, see AACG_TNS_REFERENCE)
+ *     IMDCT + window + OLA      src/filter_bank.js:88-204, src/mdct.js:62-115, src/fft.js:105-192
+ *     interleave, /32768        src/decoder.js:203-215
+ *
+ * The serial part (ADTS demux, raw_data_block parse, Huffman) stays in the JavaScript
+ * host, exactly where the reference has it; the host hands batches of parsed
+ * elements ("units") across this ABI.  Plain C: pointers and sizes only, int status
+ * (0 = OK, <0 = error), no exceptions, no torch/HIP types in any signature.
+ *
+ * Vocabulary (follows the reference's data model):
+ *   channel-frame  one channel x one 1024-sample frame
+ *   unit           one syntactic element of one frame: SCE/LFE (1 channel,
+ *                  reference `processSingle`, decoder.js:250) or CPE (2 channels,
+ *                  `processPair`, decoder.js:285)
+ *   stream         one decoder instance's worth of state: the reference keeps
+ *                  `FilterBank.overlaps[ch]` (filter_bank.js:38-41) per decoder; the
+ *                  engine keeps it per (stream slot, channel) in HBM.
+ */
+#ifndef AACGPU_H
+#define AACGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AACG_ABI_VERSION 1
+
+#define AACG_FRAME_LEN      1024   /* decoder.js:86 frameLength                       */
+#define AACG_MAX_SECTIONS   120    /* ics.js:49 MAX_SECTIONS (bandTypes/scaleFactors) */
+#define AACG_MAX_CHANNELS   8
+#define AACG_RUN_FRAMES     8      /* frames per workgroup run        */
+
+/* ---- status codes ------------------------------------------------------------ */
+enum {
+    AACG_OK                 = 0,
+    AACG_ERR_INVALID_ARG    = -1,
+    AACG_ERR_NO_DEVICE      = -2,   /* no HIP device / HIP call failed                 */
+    AACG_ERR_OUT_OF_MEMORY  = -3,
+    AACG_ERR_CAPACITY       = -4,   /* batch larger than the engine was created for    */
+    AACG_ERR_UNSUPPORTED    = -5,   /* reference throws here too (pulse, gain, PNS...) */
+    AACG_ERR_LAYOUT_CHANGE  = -6,   /* element layout of a stream changes inside one batch */
+    AACG_ERR_STALE_PLAN     = -7    /* plan does not match the engine's overlap parity */
+};
+
+/* ---- window sequences, ics.js:44-47 ------------------------------------------- */
+enum {
+    AACG_ONLY_LONG_SEQUENCE   = 0,
+    AACG_LONG_START_SEQUENCE  = 1,
+    AACG_EIGHT_SHORT_SEQUENCE = 2,
+    AACG_LONG_STOP_SEQUENCE   = 3
+};
+
+/* ---- band types, ics.js:37-42 -------------------------------------------------- */
+enum {
+    AACG_ZERO_BT       = 0,
+    AACG_FIRST_PAIR_BT = 5,
+    AACG_ESC_BT        = 11,
+    AACG_NOISE_BT      = 13,
+    AACG_INTENSITY_BT2 = 14,
+    AACG_INTENSITY_BT  = 15
+};
+
+/* ---- what the host hands over for the spectrum ------------------------------------ */
+enum {
+    AACG_INPUT_SPEC_F32  = 0,  /* the spectrum exactly as FilterBank.process receives it
+                                  (filter_bank.js:88 `input`): f32[1024] per channel, dequantised,
+                                  MS/IS already applied by the host — the filterbank seam       */
+    AACG_INPUT_QUANT_I16 = 1   /* the integers Huffman.decodeSpectralData produced
+                                  (huffman.js:1462-1490), int16[1024] per channel, same index
+                                  order as ICStream.data, + aacg_band_meta per channel — the
+                                  process(elements) seam: dequant, MS and IS run on the device   */
+};
+
+/* ---- TNS behaviour ------------------------------------------------------------- */
+enum {
+    AACG_TNS_REFERENCE = 0     /* what aac.js executes: TNS.process leaves the data untouched
+                                  (tns.js:106,122 NaN loop bounds)         */
+};
+
+/* The ICSInfo fields the path reads (ics.js:270-314), one per channel, 16 bytes. */
+typedef struct aacg_chan_info {
+    uint8_t window_sequence;    /* info.windowSequence                                         */
+    uint8_t window_shape;       /* info.windowShape[1]: 0 sine, 1 KBD                          */
+    uint8_t window_shape_prev;  /* info.windowShape[0]; aac.js always has 0 here because it
+                                   builds a fresh ICSInfo per frame (decoder.js:145,153)       */
+    uint8_t max_sfb;            /* info.maxSFB                                                 */
+    uint8_t group_count;        /* info.groupCount (1 for long windows)                        */
+    uint8_t flags;              /* reserved (tnsPresent etc.), must be 0                       */
+    uint8_t reserved[2];
+    uint8_t group_len[8];       /* info.groupLength[g]                                         */
+} aacg_chan_info;
+
+#define AACG_UNIT_COMMON_WINDOW 0x01   /* cpe.commonWindow (cpe.js:43)  */
+#define AACG_UNIT_MASK_PRESENT  0x02   /* cpe.maskPresent  (cpe.js:47)  */
+
+/* One SCE/LFE/CPE of one frame, 64 bytes.  Units of one stream must be listed in
+ * decode order; units that share `stream` and `pcm_offset` form one frame.          */
+typedef struct aacg_unit_desc {
+    uint32_t stream;        /* stream slot: owner of the overlap state                         */
+    uint32_t pcm_offset;    /* float offset of this frame's [1024][n_out_ch] block in pcm_out  */
+    uint16_t channel;       /* first output channel of the element (decoder.js:233-247)        */
+    uint16_t n_out_ch;      /* channels per frame of this stream = interleave stride
+                               (config.chanConfig, decoder.js:219)                             */
+    uint8_t  n_ch;          /* 1 = SCE/LFE, 2 = CPE                                            */
+    uint8_t  flags;         /* AACG_UNIT_*                                                     */
+    uint16_t reserved0;
+    uint32_t coef_offset;   /* channel c's spectrum starts at (coef_offset + c) * 1024 elements */
+    uint32_t meta_offset;   /* channel c's aacg_band_meta is meta[meta_offset + c] (QUANT only) */
+    aacg_chan_info ch[2];   /* [0] = left / the single channel, [1] = right                    */
+    uint32_t reserved1[2];
+} aacg_unit_desc;
+
+/* Per-channel band side info for AACG_INPUT_QUANT_I16, 240 bytes: one 16-bit word per
+ * (group, sfb), index g*max_sfb + sfb exactly like ICStream.bandTypes / scaleFactors
+ * (ics.js:217).
+ *   bits 0..8   index into SCALEFACTOR_TABLE (tables.js:168-176), 0..427
+ *   bit  9      negate the looked-up value (noise bands store -SF, ics.js:159)
+ *   bit  10     ms_used[idx] (cpe.js:50-63); read from the LEFT channel's meta
+ *   bits 12..15 band type (ics.js:37-42)                                            */
+typedef struct aacg_band_meta {
+    uint16_t band[AACG_MAX_SECTIONS];
+} aacg_band_meta;
+
+#define AACG_META_SF_MASK   0x01FFu
+#define AACG_META_NEGATE    0x0200u
+#define AACG_META_MS_USED   0x0400u
+#define AACG_META_BT_SHIFT  12
+
+typedef struct aacg_config {
+    int32_t abi_version;       /* AACG_ABI_VERSION                                             */
+    int32_t device_ordinal;    /* HIP device                                                   */
+    int32_t sample_index;      /* config.sampleIndex (decoder.js:63); selects SWB tables, 3 = 48 kHz */
+    int32_t max_streams;       /* stream slots with overlap state                              */
+    int32_t max_channels;      /* channels per stream, <= AACG_MAX_CHANNELS                    */
+    int32_t max_batch_units;   /* capacity of the host-buffer path (aacg_decode_batch)         */
+    int32_t input_kind;        /* AACG_INPUT_*                                                 */
+    int32_t tns_mode;          /* AACG_TNS_*                                                   */
+} aacg_config;
+
+typedef struct aacg_engine aacg_engine;
+typedef struct aacg_plan   aacg_plan;
+
+/* ---- lifetime ------------------------------------------------------------------ */
+/* new FilterBank(false, channels) for every stream slot (filter_bank.js:24-44): builds the
+ * window / twiddle tables on the device and zeroes all overlap state.                  */
+int  aacg_create(const aacg_config* cfg, aacg_engine** out);
+void aacg_destroy(aacg_engine* e);
+const char* aacg_last_error(const aacg_engine* e);   /* text of the last failure            */
+int  aacg_abi_version(void);
+
+/* ---- overlap state (filter_bank.js:38-41) ------------------------------------------ */
+int aacg_reset_stream(aacg_engine* e, uint32_t stream);                       /* zero = new FilterBank */
+int aacg_get_overlap(aacg_engine* e, uint32_t stream, uint32_t channel, float* dst1024);
+int aacg_set_overlap(aacg_engine* e, uint32_t stream, uint32_t channel, const float* src1024);
+
+/* ---- the hot path, host buffers ---------------------------------------------------- */
+/* Synchronous equivalent of  process(elements) + interleave  for a whole batch:
+ * uploads units/coefficients, runs the kernels, downloads PCM.
+ *   coeffs  float[...] (SPEC_F32) or int16_t[...] (QUANT_I16), n_coef_blocks * 1024 elements
+ *   meta    aacg_band_meta[n_meta] or NULL (SPEC_F32)
+ *   pcm_out float[n_pcm_floats]; every frame block [1024][n_out_ch] is fully written
+ *           (channels no unit covers are zero, decoder.js:229-231), scale 1/32768.   */
+int aacg_decode_batch(aacg_engine* e,
+                      const aacg_unit_desc* units, uint32_t n_units,
+                      const void* coeffs, uint32_t n_coef_blocks,
+                      const aacg_band_meta* meta, uint32_t n_meta,
+                      float* pcm_out, size_t n_pcm_floats);
+
+/* ---- the hot path, device-resident ------------------------------------------------- */
+/* A plan is the uploaded unit table plus the run table the kernel walks.  It can be
+ * launched repeatedly: every launch continues the streams where the previous launch of
+ * the same plan left them (the next batch of the same shape).                          */
+int  aacg_plan_create(aacg_engine* e, const aacg_unit_desc* units, uint32_t n_units, aacg_plan** out);
+void aacg_plan_destroy(aacg_plan* p);
+/* Launch on `hip_stream` (a hipStream_t passed as void*, NULL = the engine's own stream);
+ * returns after enqueueing.  d_coeffs / d_meta / d_pcm are DEVICE pointers.            */
+int aacg_decode_device(aacg_engine* e, aacg_plan* p,
+                       const void* d_coeffs, const aacg_band_meta* d_meta,
+                       float* d_pcm, void* hip_stream);
+/* Spectral stage only (dequant + MS + IS): writes float[(coef_offset + c) * 1024 ...] so
+ * that tests can gate this stage bit-exact.  QUANT_I16 engines only.                   */
+int aacg_spectral_device(aacg_engine* e, aacg_plan* p,
+                         const void* d_coeffs, const aacg_band_meta* d_meta,
+                         float* d_spec_out, void* hip_stream);
+int aacg_synchronize(aacg_engine* e, void* hip_stream);
+
+/* ---- introspection used by bench/tests ------------------------------------------------ */
+/* Copies the engine's host-built tables (what the device kernels read) for table KATs.
+ * which: 0 IQ[8191], 1 SF[428], 2 sine1024, 3 kbd1024, 4 sine128, 5 kbd128               */
+int aacg_get_table(aacg_engine* e, int which, float* dst, size_t n);
+/* Name of the dominant kernel (for matching rocprofv3 rows).                            */
+const char* aacg_kernel_name(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AACGPU_H */

@@ -1,0 +1,598 @@
+/*
+ * aac_oracle.c — CPU restatement of aac.js's per-frame transform path (plain C).
+ *
+ * TEST INFRASTRUCTURE ONLY (see aac_oracle.h).  Parity status: PINNED against outputs of
+ * the reference itself (tests/golden, tests/test_oracle_golden.py): tables, FFT, IMDCT and
+ * the whole filterbank / dequant / MS / IS chain are reproduced bit-for-bit.
+ *
+ * Every function cites the reference file:line it follows.  Rounding model: all
+ * arithmetic in double, rounded to float exactly where the reference stores into a
+ * Float32Array.  Build: gcc -O2 -ffp-contract=off (an FMA-contracted build is a
+ * different function).
+ */
+#include "aac_oracle.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+
+/* ------------------------------------------------------------------------------------ */
+/* tables                                                                                 */
+/* ------------------------------------------------------------------------------------ */
+
+static int    g_ready;
+static float  g_iq[8191];             /* tables.js:182-191 */
+static float  g_sf[428];              /* tables.js:168-176 */
+static float  g_sine_long[1024], g_sine_short[128];   /* filter_bank.js:46-52,81-82 */
+static float  g_kbd_long[1024],  g_kbd_short[128];    /* filter_bank.js:54-79,83-84 */
+static float  g_roots_long[512][3];   /* fft.js:82-103 */
+static float  g_roots_short[64][2];   /* fft.js:59-80  */
+static double g_mdct_long[512][2];    /* mdct_tables.js:21-534  (N = 2048) */
+static double g_mdct_short[64][2];    /* mdct_tables.js:536-601 (N = 256)  */
+
+/* tables.js:34-155 as (width, repeat) runs; -1 terminates.  Index = sampleIndex 0..11. */
+static const int8_t SWB_LONG_RLE[12][32] = {
+    {4,14, 8,5, 12,5, 16,2, 24,1, 28,1, 36,1, 44,1, 64,11, -1},
+    {4,14, 8,5, 12,5, 16,2, 24,1, 28,1, 36,1, 44,1, 64,11, -1},
+    {4,14, 8,4, 12,3, 16,3, 20,1, 24,2, 28,1, 36,1, 40,18, -1},
+    {4,10, 8,7, 12,4, 16,2, 20,2, 24,2, 28,2, 32,19, 96,1, -1},
+    {4,10, 8,7, 12,4, 16,2, 20,2, 24,2, 28,2, 32,19, 96,1, -1},
+    {4,10, 8,7, 12,4, 16,2, 20,2, 24,2, 28,2, 32,22, -1},
+    {4,11, 8,10, 12,4, 16,3, 20,2, 24,2, 28,2, 32,1, 36,2, 40,1, 44,1, 48,1, 52,2, 64,5, -1},
+    {4,11, 8,10, 12,4, 16,3, 20,2, 24,2, 28,2, 32,1, 36,2, 40,1, 44,1, 48,1, 52,2, 64,5, -1},
+    {8,11, 12,9, 16,4, 20,3, 24,2, 28,2, 32,1, 36,1, 40,2, 44,1, 48,1, 52,1, 56,1, 60,1, 64,3, -1},
+    {8,11, 12,9, 16,4, 20,3, 24,2, 28,2, 32,1, 36,1, 40,2, 44,1, 48,1, 52,1, 56,1, 60,1, 64,3, -1},
+    {8,11, 12,9, 16,4, 20,3, 24,2, 28,2, 32,1, 36,1, 40,2, 44,1, 48,1, 52,1, 56,1, 60,1, 64,3, -1},
+    {12,13, 16,7, 20,4, 24,3, 28,2, 32,1, 36,2, 40,1, 44,1, 48,1, 52,1, 56,1, 60,1, 64,1, 80,1, -1},
+};
+static const int8_t SWB_SHORT_RLE[12][12] = {
+    {4,6, 8,3, 16,1, 28,1, 36,1, -1},
+    {4,6, 8,3, 16,1, 28,1, 36,1, -1},
+    {4,6, 8,3, 16,1, 28,1, 36,1, -1},
+    {4,5, 8,3, 12,3, 16,3, -1},
+    {4,5, 8,3, 12,3, 16,3, -1},
+    {4,5, 8,3, 12,3, 16,3, -1},
+    {4,7, 8,3, 12,2, 16,2, 20,1, -1},
+    {4,7, 8,3, 12,2, 16,2, 20,1, -1},
+    {4,8, 8,2, 12,2, 16,1, 20,2, -1},
+    {4,8, 8,2, 12,2, 16,1, 20,2, -1},
+    {4,8, 8,2, 12,2, 16,1, 20,2, -1},
+    {4,7, 8,4, 12,1, 16,1, 20,2, -1},
+};
+
+static uint16_t g_swb_long[12][64];
+static uint16_t g_swb_short[12][16];
+static int      g_swb_long_count[12], g_swb_short_count[12];
+
+static int expand_rle(const int8_t* rle, uint16_t* off)
+{
+    int n = 0, pos = 0;
+    off[0] = 0;
+    for (int i = 0; rle[i] >= 0; i += 2)
+        for (int r = 0; r < rle[i + 1]; r++) { pos += rle[i]; off[++n] = (uint16_t)pos; }
+    return n;
+}
+
+/* filter_bank.js:46-52 */
+static void gen_sine(float* d, int len)
+{
+    for (int i = 0; i < len; i++)
+        d[i] = (float)sin((i + 0.5) * (M_PI / (2.0 * len)));
+}
+
+/* filter_bank.js:54-79: note the running sum is read back from a Float32Array (f[n]),
+ * while `sum` itself stays double and gets +1 after the loop. */
+static void gen_kbd(float* out, double alpha, int len)
+{
+    double PIN = M_PI / len, sum = 0.0;
+    double alpha2 = (alpha * PIN) * (alpha * PIN);
+    float* f = (float*)malloc(sizeof(float) * (size_t)len);
+    for (int n = 0; n < len; n++) {
+        double tmp = (double)n * (double)(len - n) * alpha2, bessel = 1.0;
+        for (int j = 50; j > 0; j--)
+            bessel = bessel * tmp / (double)(j * j) + 1.0;
+        sum += bessel;
+        f[n] = (float)sum;
+    }
+    sum += 1.0;
+    for (int n = 0; n < len; n++)
+        out[n] = (float)sqrt((double)f[n] / sum);
+    free(f);
+}
+
+/* fft.js:82-103: every component goes through a Float32Array and is fed back. */
+static void gen_roots_long(float (*f)[3], int len)
+{
+    double t = 2.0 * M_PI / len, cosT = cos(t), sinT = sin(t);
+    f[0][0] = 1.0f; f[0][1] = 0.0f; f[0][2] = 0.0f;
+    for (int i = 1; i < len; i++) {
+        f[i][0] = (float)((double)f[i - 1][0] * cosT + (double)f[i - 1][2] * sinT);
+        f[i][2] = (float)((double)f[i - 1][2] * cosT - (double)f[i - 1][0] * sinT);
+        f[i][1] = -f[i][2];
+    }
+}
+
+/* fft.js:59-80: lastImag is a plain JS double. */
+static void gen_roots_short(float (*f)[2], int len)
+{
+    double t = 2.0 * M_PI / len, cosT = cos(t), sinT = sin(t), lastImag = 0.0;
+    f[0][0] = 1.0f; f[0][1] = 0.0f;
+    for (int i = 1; i < len; i++) {
+        f[i][0] = (float)((double)f[i - 1][0] * cosT + lastImag * sinT);
+        lastImag = lastImag * cosT - (double)f[i - 1][0] * sinT;
+        f[i][1] = (float)(-lastImag);
+    }
+}
+
+/* mdct_tables.js holds sqrt(2/N) * (cos, sin)(2*pi*(k + 1/8)/N) written with 15 decimals;
+ * the literal is what the reference computes with, so go through the same text form. */
+static double round15(double v)
+{
+    char txt[64];
+    snprintf(txt, sizeof txt, "%.15f", v);
+    return strtod(txt, NULL);
+}
+
+static void gen_mdct(double (*t)[2], int N)
+{
+    double scale = sqrt(2.0 / N);
+    for (int k = 0; k < N / 4; k++) {
+        double a = 2.0 * M_PI * (k + 0.125) / N;
+        t[k][0] = round15(scale * cos(a));
+        t[k][1] = round15(scale * sin(a));
+    }
+}
+
+void orc_init(void)
+{
+    if (g_ready) return;
+    for (int i = 0; i < 8191; i++) g_iq[i] = (float)pow((double)i, 4.0 / 3.0);   /* tables.js:186-188 */
+    for (int i = 0; i < 428; i++)  g_sf[i] = (float)pow(2.0, (i - 200) / 4.0);   /* tables.js:171-173 */
+    gen_sine(g_sine_long, 1024);
+    gen_sine(g_sine_short, 128);
+    gen_kbd(g_kbd_long, 4.0, 1024);      /* filter_bank.js:83 */
+    gen_kbd(g_kbd_short, 6.0, 128);      /* filter_bank.js:84 */
+    gen_roots_long(g_roots_long, 512);
+    gen_roots_short(g_roots_short, 64);
+    gen_mdct(g_mdct_long, 2048);
+    gen_mdct(g_mdct_short, 256);
+    for (int s = 0; s < 12; s++) {
+        g_swb_long_count[s]  = expand_rle(SWB_LONG_RLE[s],  g_swb_long[s]);
+        g_swb_short_count[s] = expand_rle(SWB_SHORT_RLE[s], g_swb_short[s]);
+    }
+    g_ready = 1;
+}
+
+size_t orc_get_table_f32(int which, float* dst, size_t n)
+{
+    const float* src; size_t cnt;
+    orc_init();
+    switch (which) {
+    case 0: src = g_iq;                 cnt = 8191;    break;
+    case 1: src = g_sf;                 cnt = 428;     break;
+    case 2: src = g_sine_long;          cnt = 1024;    break;
+    case 3: src = g_kbd_long;           cnt = 1024;    break;
+    case 4: src = g_sine_short;         cnt = 128;     break;
+    case 5: src = g_kbd_short;          cnt = 128;     break;
+    case 6: src = &g_roots_long[0][0];  cnt = 512 * 3; break;
+    case 7: src = &g_roots_short[0][0]; cnt = 64 * 2;  break;
+    default: return 0;
+    }
+    if (dst) memcpy(dst, src, sizeof(float) * (n < cnt ? n : cnt));
+    return cnt;
+}
+
+size_t orc_get_table_f64(int which, double* dst, size_t n)
+{
+    const double* src; size_t cnt;
+    orc_init();
+    switch (which) {
+    case 0: src = &g_mdct_long[0][0];  cnt = 512 * 2; break;
+    case 1: src = &g_mdct_short[0][0]; cnt = 64 * 2;  break;
+    default: return 0;
+    }
+    if (dst) memcpy(dst, src, sizeof(double) * (n < cnt ? n : cnt));
+    return cnt;
+}
+
+int orc_get_swb_offsets(int sample_index, int is_long, uint16_t* dst)
+{
+    orc_init();
+    if (sample_index < 0 || sample_index > 11) return 0;
+    int cnt = is_long ? g_swb_long_count[sample_index] : g_swb_short_count[sample_index];
+    memcpy(dst, is_long ? g_swb_long[sample_index] : g_swb_short[sample_index],
+           sizeof(uint16_t) * (size_t)(cnt + 1));
+    return cnt;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* FFT, fft.js:105-192 (forward = false: imOffset 1, scale 1)                            */
+/* ------------------------------------------------------------------------------------ */
+
+void orc_fft_inverse(int length, float* buf)
+{
+    float (*in)[2] = (float (*)[2])buf;
+    float rev[512][2];
+    orc_init();
+
+    /* bit-reversal, fft.js:113-125 */
+    int ii = 0;
+    for (int i = 0; i < length; i++) {
+        rev[i][0] = in[ii][0];
+        rev[i][1] = in[ii][1];
+        int k = length >> 1;
+        while (ii >= k && k > 0) { ii -= k; k >>= 1; }
+        ii += k;
+    }
+    for (int i = 0; i < length; i++) { in[i][0] = rev[i][0]; in[i][1] = rev[i][1]; }
+
+    /* bottom base-4 round, fft.js:140-170: every temporary lives in a Float32Array */
+    for (int i = 0; i < length; i += 4) {
+        float a0 = in[i][0] + in[i + 1][0],     a1 = in[i][1] + in[i + 1][1];
+        float b0 = in[i + 2][0] + in[i + 3][0], b1 = in[i + 2][1] + in[i + 3][1];
+        float c0 = in[i][0] - in[i + 1][0],     c1 = in[i][1] - in[i + 1][1];
+        float d0 = in[i + 2][0] - in[i + 3][0], d1 = in[i + 2][1] - in[i + 3][1];
+        in[i][0] = a0 + b0;     in[i][1] = a1 + b1;
+        in[i + 2][0] = a0 - b0; in[i + 2][1] = a1 - b1;
+        float e10 = c0 - d1, e11 = c1 + d0;
+        float e20 = c0 + d1, e21 = c1 - d0;
+        in[i + 1][0] = e10; in[i + 1][1] = e11;      /* !forward branch, fft.js:164-168 */
+        in[i + 3][0] = e20; in[i + 3][1] = e21;
+    }
+
+    /* iterations from bottom to top, fft.js:173-191: zRe/zIm are JS doubles */
+    for (int i = 4; i < length; i <<= 1) {
+        int shift = i << 1, m = length / shift;
+        for (int j = 0; j < length; j += shift) {
+            for (int k = 0; k < i; k++) {
+                int km = k * m;
+                double rootRe, rootIm;
+                if (length == 512) { rootRe = g_roots_long[km][0];  rootIm = g_roots_long[km][1]; }
+                else               { rootRe = g_roots_short[km][0]; rootIm = g_roots_short[km][1]; }
+                double xr = in[i + j + k][0], xi = in[i + j + k][1];
+                double zRe = xr * rootRe - xi * rootIm;
+                double zIm = xr * rootIm + xi * rootRe;
+                double lr = in[j + k][0], li = in[j + k][1];
+                in[i + j + k][0] = (float)(lr - zRe);
+                in[i + j + k][1] = (float)(li - zIm);
+                in[j + k][0] = (float)(lr + zRe);
+                in[j + k][1] = (float)(li + zIm);
+            }
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* IMDCT, mdct.js:62-115                                                                  */
+/* ------------------------------------------------------------------------------------ */
+
+void orc_imdct(int N, const float* input, float* output)
+{
+    int N2 = N >> 1, N4 = N >> 2, N8 = N >> 3;
+    float buf[512][2];
+    orc_init();
+    double (*sincos)[2] = (N == 2048) ? g_mdct_long : g_mdct_short;
+
+    /* pre-IFFT complex multiplication, mdct.js:73-76 */
+    for (int k = 0; k < N4; k++) {
+        double x0 = input[2 * k], x1 = input[N2 - 1 - 2 * k];
+        buf[k][1] = (float)((x0 * sincos[k][0]) + (x1 * sincos[k][1]));
+        buf[k][0] = (float)((x1 * sincos[k][0]) - (x0 * sincos[k][1]));
+    }
+
+    orc_fft_inverse(N4, &buf[0][0]);               /* mdct.js:79 */
+
+    /* post-IFFT complex multiplication, mdct.js:82-87 */
+    for (int k = 0; k < N4; k++) {
+        double t0 = buf[k][0], t1 = buf[k][1];
+        buf[k][1] = (float)((t1 * sincos[k][0]) + (t0 * sincos[k][1]));
+        buf[k][0] = (float)((t0 * sincos[k][0]) - (t1 * sincos[k][1]));
+    }
+
+    /* reordering, mdct.js:90-114 */
+    for (int k = 0; k < N8; k += 2) {
+        output[2 * k]     = buf[N8 + k][1];
+        output[2 + 2 * k] = buf[N8 + 1 + k][1];
+        output[1 + 2 * k] = -buf[N8 - 1 - k][0];
+        output[3 + 2 * k] = -buf[N8 - 2 - k][0];
+
+        output[N4 + 2 * k]     = buf[k][0];
+        output[N4 + 2 + 2 * k] = buf[1 + k][0];
+        output[N4 + 1 + 2 * k] = -buf[N4 - 1 - k][1];
+        output[N4 + 3 + 2 * k] = -buf[N4 - 2 - k][1];
+
+        output[N2 + 2 * k]     = buf[N8 + k][0];
+        output[N2 + 2 + 2 * k] = buf[N8 + 1 + k][0];
+        output[N2 + 1 + 2 * k] = -buf[N8 - 1 - k][1];
+        output[N2 + 3 + 2 * k] = -buf[N8 - 2 - k][1];
+
+        output[N2 + N4 + 2 * k]     = -buf[k][1];
+        output[N2 + N4 + 2 + 2 * k] = -buf[1 + k][1];
+        output[N2 + N4 + 1 + 2 * k] = buf[N4 - 1 - k][0];
+        output[N2 + N4 + 3 + 2 * k] = buf[N4 - 2 - k][0];
+    }
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* filterbank, filter_bank.js:88-204                                                      */
+/* ------------------------------------------------------------------------------------ */
+
+/* f32 store of  a + b*w  evaluated in double, filter_bank.js:110 etc. */
+static inline float madd(float a, float b, float w)
+{
+    return (float)((double)a + ((double)b * (double)w));
+}
+
+void orc_filterbank(int window_sequence, int window_shape, int window_shape_prev,
+                    const float* input, float* output, float* overlap)
+{
+    enum { length = 1024, shortLen = 128, mid = 448, trans = 64 };
+    float buf[2048];
+    orc_init();
+    const float* longWindows      = window_shape      ? g_kbd_long  : g_sine_long;
+    const float* shortWindows     = window_shape      ? g_kbd_short : g_sine_short;
+    const float* longWindowsPrev  = window_shape_prev ? g_kbd_long  : g_sine_long;
+    const float* shortWindowsPrev = window_shape_prev ? g_kbd_short : g_sine_short;
+
+    switch (window_sequence) {
+    case AACG_ONLY_LONG_SEQUENCE:                       /* filter_bank.js:105-118 */
+        orc_imdct(2048, input, buf);
+        for (int i = 0; i < length; i++)
+            output[i] = madd(overlap[i], buf[i], longWindowsPrev[i]);
+        for (int i = 0; i < length; i++)
+            overlap[i] = buf[length + i] * longWindows[length - 1 - i];
+        break;
+
+    case AACG_LONG_START_SEQUENCE:                      /* filter_bank.js:120-141 */
+        orc_imdct(2048, input, buf);
+        for (int i = 0; i < length; i++)
+            output[i] = madd(overlap[i], buf[i], longWindowsPrev[i]);
+        for (int i = 0; i < mid; i++)
+            overlap[i] = buf[length + i];
+        for (int i = 0; i < shortLen; i++)
+            overlap[mid + i] = buf[length + mid + i] * shortWindows[shortLen - i - 1];
+        for (int i = 0; i < mid; i++)
+            overlap[mid + shortLen + i] = 0.0f;
+        break;
+
+    case AACG_EIGHT_SHORT_SEQUENCE:                     /* filter_bank.js:143-178 */
+        for (int i = 0; i < 8; i++)
+            orc_imdct(256, input + i * shortLen, buf + 2 * i * shortLen);
+        for (int i = 0; i < mid; i++)
+            output[i] = overlap[i];
+        for (int i = 0; i < shortLen; i++) {
+            output[mid + i] = madd(overlap[mid + i], buf[i], shortWindowsPrev[i]);
+            for (int j = 1; j <= 4; j++) {
+                if (j == 4 && i >= trans) break;
+                /* ov + (b1*w1) + (b2*w2), left to right in double, filter_bank.js:155-160 */
+                double v = (double)overlap[mid + shortLen * j + i]
+                         + ((double)buf[shortLen * (2 * j - 1) + i] * (double)shortWindows[shortLen - 1 - i]);
+                v = v + ((double)buf[shortLen * 2 * j + i] * (double)shortWindows[i]);
+                output[mid + j * shortLen + i] = (float)v;
+            }
+        }
+        for (int i = 0; i < shortLen; i++) {
+            for (int j = 4; j <= 7; j++) {
+                if (j == 4 && i < trans) continue;
+                double v = ((double)buf[shortLen * (2 * j - 1) + i] * (double)shortWindows[shortLen - 1 - i])
+                         + ((double)buf[shortLen * 2 * j + i] * (double)shortWindows[i]);
+                overlap[mid + j * shortLen + i - length] = (float)v;
+            }
+            overlap[mid + 8 * shortLen + i - length] = buf[shortLen * 15 + i] * shortWindows[shortLen - 1 - i];
+        }
+        for (int i = 0; i < mid; i++)
+            overlap[mid + shortLen + i] = 0.0f;
+        break;
+
+    case AACG_LONG_STOP_SEQUENCE:                       /* filter_bank.js:180-202 */
+        orc_imdct(2048, input, buf);
+        for (int i = 0; i < mid; i++)
+            output[i] = overlap[i];
+        for (int i = 0; i < shortLen; i++)
+            output[mid + i] = madd(overlap[mid + i], buf[mid + i], shortWindowsPrev[i]);
+        for (int i = 0; i < mid; i++)
+            output[mid + shortLen + i] = overlap[mid + shortLen + i] + buf[mid + shortLen + i];
+        for (int i = 0; i < length; i++)
+            overlap[i] = buf[length + i] * longWindows[length - 1 - i];
+        break;
+    }
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* spectral reconstruction                                                                 */
+/* ------------------------------------------------------------------------------------ */
+
+static inline int meta_bt(uint16_t m)   { return m >> AACG_META_BT_SHIFT; }
+static inline float meta_sf(uint16_t m)
+{
+    float v = g_sf[m & AACG_META_SF_MASK];
+    return (m & AACG_META_NEGATE) ? -v : v;
+}
+
+static const uint16_t* swb_of(int sample_index, const aacg_chan_info* info)
+{
+    /* ics.js:301,307: swbOffsets chosen by window sequence */
+    return info->window_sequence == AACG_EIGHT_SHORT_SEQUENCE ? g_swb_short[sample_index]
+                                                              : g_swb_long[sample_index];
+}
+
+/* ics.js:203-261 with Huffman.decodeSpectralData replaced by the q[] array.  The
+ * reference starts from a fresh zeroed Float32Array (ics.js:29), so coefficients at and
+ * above swbOffsets[maxSFB] stay +0. */
+int orc_dequant(int sample_index, const aacg_chan_info* info, const aacg_band_meta* meta,
+                const int16_t* q, float* data)
+{
+    orc_init();
+    const uint16_t* offsets = swb_of(sample_index, info);
+    memset(data, 0, sizeof(float) * 1024);
+    int groupOff = 0, idx = 0;
+    for (int g = 0; g < info->group_count; g++) {
+        int groupLen = info->group_len[g];
+        for (int sfb = 0; sfb < info->max_sfb; sfb++, idx++) {
+            int hcb = meta_bt(meta->band[idx]);
+            int off = groupOff + offsets[sfb];
+            int width = offsets[sfb + 1] - offsets[sfb];
+            if (hcb == AACG_ZERO_BT || hcb == AACG_INTENSITY_BT || hcb == AACG_INTENSITY_BT2) {
+                for (int group = 0; group < groupLen; group++, off += 128)      /* ics.js:222-227 */
+                    for (int i = off; i < off + width; i++) data[i] = 0.0f;
+            } else if (hcb == AACG_NOISE_BT) {
+                return AACG_ERR_UNSUPPORTED;     /* ics.js:228-243 degenerates to NaN, SURVEY §8a row 4 */
+            } else {
+                float sf = meta_sf(meta->band[idx]);
+                for (int group = 0; group < groupLen; group++, off += 128) {    /* ics.js:244-256 */
+                    for (int k = 0; k < width; k++) {
+                        int v = q[off + k];
+                        float x;
+                        if (v > 0) x = (v < 8191) ? g_iq[v] : NAN;              /* IQ_TABLE[8191+] is undefined */
+                        else       x = (-v < 8191) ? -g_iq[-v] : NAN;           /* q == 0 gives -0, as in JS    */
+                        x = x * sf;
+                        data[off + k] = x;
+                    }
+                }
+            }
+        }
+        groupOff += groupLen << 7;
+    }
+    return AACG_OK;
+}
+
+/* decoder.js:379-404 */
+void orc_process_ms(int sample_index, const aacg_unit_desc* u,
+                    const aacg_band_meta* meta_l, const aacg_band_meta* meta_r,
+                    float* left, float* right)
+{
+    orc_init();
+    const aacg_chan_info* info = &u->ch[0];            /* element.left.info */
+    const uint16_t* offsets = swb_of(sample_index, info);
+    int groupOff = 0, idx = 0;
+    for (int g = 0; g < info->group_count; g++) {
+        for (int i = 0; i < info->max_sfb; i++, idx++) {
+            int used = (meta_l->band[idx] & AACG_META_MS_USED) != 0;
+            if (used && meta_bt(meta_l->band[idx]) < AACG_NOISE_BT && meta_bt(meta_r->band[idx]) < AACG_NOISE_BT) {
+                for (int w = 0; w < info->group_len[g]; w++) {
+                    int off = groupOff + w * 128 + offsets[i];
+                    for (int j = 0; j < offsets[i + 1] - offsets[i]; j++) {
+                        float t = left[off + j] - right[off + j];
+                        left[off + j] = left[off + j] + right[off + j];
+                        right[off + j] = t;
+                    }
+                }
+            }
+        }
+        groupOff += info->group_len[g] * 128;
+    }
+}
+
+/* decoder.js:337-376.  sectEnd only drives the iteration there; sections are runs of one
+ * band type (ics.js:83-116) so a per-band test is the same function. */
+void orc_process_is(int sample_index, const aacg_unit_desc* u,
+                    const aacg_band_meta* meta_l, const aacg_band_meta* meta_r,
+                    const float* left, float* right)
+{
+    orc_init();
+    const aacg_chan_info* info = &u->ch[1];            /* element.right.info */
+    const uint16_t* offsets = swb_of(sample_index, info);
+    int groupOff = 0, idx = 0;
+    for (int g = 0; g < info->group_count; g++) {
+        for (int i = 0; i < info->max_sfb; i++, idx++) {
+            int bt = meta_bt(meta_r->band[idx]);
+            if (bt == AACG_INTENSITY_BT || bt == AACG_INTENSITY_BT2) {
+                int c = (bt == AACG_INTENSITY_BT) ? 1 : -1;
+                if (u->flags & AACG_UNIT_MASK_PRESENT)
+                    c *= (meta_l->band[idx] & AACG_META_MS_USED) ? -1 : 1;
+                float scale = (float)c * meta_sf(meta_r->band[idx]);
+                for (int w = 0; w < info->group_len[g]; w++) {
+                    int off = groupOff + w * 128 + offsets[i];
+                    int len = offsets[i + 1] - offsets[i];
+                    for (int j = 0; j < len; j++)
+                        right[off + j] = left[off + j] * scale;
+                }
+            }
+        }
+        groupOff += info->group_len[g] * 128;
+    }
+}
+
+/* ics.js:234: randomState = (randomState * (1664525 + 1013904223)) | 0 — the product is
+ * formed in double (so it loses low bits) and then wrapped by ToInt32. */
+void orc_pns_sequence(int32_t* seq, int n)
+{
+    int32_t state = 0x1F2E3D4C;                       /* ics.js:31 */
+    for (int i = 0; i < n; i++) {
+        double p = (double)state * (double)(1664525 + 1013904223);
+        double m = fmod(trunc(p), 4294967296.0);       /* ToInt32 */
+        if (m < 0) m += 4294967296.0;
+        state = (int32_t)(uint32_t)m;
+        seq[i] = state;
+    }
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* process(elements) + interleave, decoder.js:201-215, 218-334                            */
+/* ------------------------------------------------------------------------------------ */
+
+int orc_decode_batch(int sample_index, int input_kind, int max_streams, int max_channels,
+                     const aacg_unit_desc* units, uint32_t n_units,
+                     const void* coeffs, const aacg_band_meta* meta,
+                     float* pcm_out, float* overlaps, float* spec_out)
+{
+    orc_init();
+    if (sample_index < 0 || sample_index > 11) return AACG_ERR_INVALID_ARG;
+    float data[2][1024], out[1024];
+    uint32_t prev_stream = 0xffffffffu, prev_off = 0xffffffffu;
+
+    for (uint32_t n = 0; n < n_units; n++) {
+        const aacg_unit_desc* u = &units[n];
+        if (u->n_ch < 1 || u->n_ch > 2 || (int)u->stream >= max_streams ||
+            u->channel + u->n_ch > max_channels || u->channel + u->n_ch > u->n_out_ch)
+            return AACG_ERR_INVALID_ARG;
+
+        /* decoder.js:229-231: every channel of a frame starts as zeros */
+        if (u->stream != prev_stream || u->pcm_offset != prev_off) {
+            memset(pcm_out + u->pcm_offset, 0, sizeof(float) * 1024u * u->n_out_ch);
+            prev_stream = u->stream; prev_off = u->pcm_offset;
+        }
+
+        const aacg_band_meta* ml = NULL; const aacg_band_meta* mr = NULL;
+        for (int c = 0; c < u->n_ch; c++) {
+            size_t base = ((size_t)u->coef_offset + (size_t)c) * 1024u;
+            if (input_kind == AACG_INPUT_SPEC_F32) {
+                memcpy(data[c], (const float*)coeffs + base, sizeof(float) * 1024);
+            } else {
+                const aacg_band_meta* m = &meta[u->meta_offset + (uint32_t)c];
+                int rc = orc_dequant(sample_index, &u->ch[c], m, (const int16_t*)coeffs + base, data[c]);
+                if (rc) return rc;
+                if (c == 0) ml = m; else mr = m;
+            }
+        }
+
+        if (u->n_ch == 2 && input_kind == AACG_INPUT_QUANT_I16) {
+            /* processPair, decoder.js:294-302 */
+            if ((u->flags & AACG_UNIT_COMMON_WINDOW) && (u->flags & AACG_UNIT_MASK_PRESENT))
+                orc_process_ms(sample_index, u, ml, mr, data[0], data[1]);
+            orc_process_is(sample_index, u, ml, mr, data[0], data[1]);
+        }
+        /* tns.process: no-op as the reference runs (tns.js:106,122); coupling: never applied
+         * (decoder.js:408,418).  SURVEY.md §8a rows 8, 9. */
+
+        for (int c = 0; c < u->n_ch; c++) {
+            int ch = u->channel + c;
+            float* ov = overlaps + ((size_t)u->stream * (size_t)max_channels + (size_t)ch) * 1024u;
+            if (spec_out)
+                memcpy(spec_out + ((size_t)u->coef_offset + (size_t)c) * 1024u, data[c], sizeof(float) * 1024);
+            /* filter_bank.process(info, data, this.data[channel], channel), decoder.js:269,318-319 */
+            orc_filterbank(u->ch[c].window_sequence, u->ch[c].window_shape, u->ch[c].window_shape_prev,
+                           data[c], out, ov);
+            /* interleave, decoder.js:209-213: output[j++] = data[i][k] / 32768 */
+            float* dst = pcm_out + u->pcm_offset + ch;
+            for (int k = 0; k < 1024; k++)
+                dst[(size_t)k * u->n_out_ch] = (float)((double)out[k] / 32768.0);
+        }
+    }
+    return AACG_OK;
+}

@@ -1,0 +1,115 @@
+"""ctypes wrapper around oracle/liboracle.so — the CPU checker (test infrastructure only)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+
+UNIT_DTYPE = np.dtype([
+    ("stream", "<u4"), ("pcm_offset", "<u4"), ("channel", "<u2"), ("n_out_ch", "<u2"),
+    ("n_ch", "u1"), ("flags", "u1"), ("reserved0", "<u2"), ("coef_offset", "<u4"), ("meta_offset", "<u4"),
+    ("ch", [("window_sequence", "u1"), ("window_shape", "u1"), ("window_shape_prev", "u1"), ("max_sfb", "u1"),
+            ("group_count", "u1"), ("flags", "u1"), ("reserved", "u1", (2,)), ("group_len", "u1", (8,))], (2,)),
+    ("reserved1", "<u4", (2,)),
+])
+assert UNIT_DTYPE.itemsize == 64
+
+
+def build(target="liboracle.so"):
+    subprocess.run(["make", "-C", ORACLE_DIR, target], check=True, stdout=subprocess.DEVNULL)
+    return os.path.join(ORACLE_DIR, target)
+
+
+class Oracle:
+    def __init__(self, path):
+        self.lib = L = C.CDLL(path)
+        L.orc_init.restype = None
+        L.orc_get_table_f32.restype = C.c_size_t
+        L.orc_get_table_f32.argtypes = [C.c_int, C.c_void_p, C.c_size_t]
+        L.orc_get_table_f64.restype = C.c_size_t
+        L.orc_get_table_f64.argtypes = [C.c_int, C.c_void_p, C.c_size_t]
+        L.orc_get_swb_offsets.argtypes = [C.c_int, C.c_int, C.c_void_p]
+        L.orc_fft_inverse.restype = None
+        L.orc_fft_inverse.argtypes = [C.c_int, C.c_void_p]
+        L.orc_imdct.restype = None
+        L.orc_imdct.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_filterbank.restype = None
+        L.orc_filterbank.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_pns_sequence.restype = None
+        L.orc_pns_sequence.argtypes = [C.c_void_p, C.c_int]
+        L.orc_decode_batch.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_uint32,
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_init()
+
+    def table_f32(self, which):
+        n = self.lib.orc_get_table_f32(which, None, 0)
+        a = np.empty(n, np.float32)
+        self.lib.orc_get_table_f32(which, a.ctypes.data, n)
+        return a
+
+    def table_f64(self, which):
+        n = self.lib.orc_get_table_f64(which, None, 0)
+        a = np.empty(n, np.float64)
+        self.lib.orc_get_table_f64(which, a.ctypes.data, n)
+        return a
+
+    def swb_offsets(self, sample_index, is_long):
+        a = np.zeros(64, np.uint16)
+        n = self.lib.orc_get_swb_offsets(sample_index, int(is_long), a.ctypes.data)
+        return a[:n + 1].copy()
+
+    def fft_inverse(self, x):
+        buf = np.ascontiguousarray(x, np.float32).copy()
+        self.lib.orc_fft_inverse(buf.shape[0], buf.ctypes.data)
+        return buf
+
+    def imdct(self, x):
+        x = np.ascontiguousarray(x, np.float32)
+        y = np.empty(2 * x.shape[0], np.float32)
+        self.lib.orc_imdct(2 * x.shape[0], x.ctypes.data, y.ctypes.data)
+        return y
+
+    def filterbank(self, seq, shape, shape_prev, x, overlap):
+        x = np.ascontiguousarray(x, np.float32)
+        out = np.empty(1024, np.float32)
+        self.lib.orc_filterbank(seq, shape, shape_prev, x.ctypes.data, out.ctypes.data, overlap.ctypes.data)
+        return out
+
+    def pns_sequence(self, n):
+        a = np.empty(n, np.int32)
+        self.lib.orc_pns_sequence(a.ctypes.data, n)
+        return a
+
+    def decode_batch(self, units, coeffs, meta, n_pcm_floats, overlaps, sample_index=3, want_spec=False):
+        """overlaps: float32 [max_streams, max_channels, 1024], updated in place."""
+        units = np.ascontiguousarray(units)
+        assert units.dtype == UNIT_DTYPE
+        coeffs = np.ascontiguousarray(coeffs)
+        kind = 1 if coeffs.dtype == np.int16 else 0
+        assert kind == 1 or coeffs.dtype == np.float32
+        if meta is not None:
+            meta = np.ascontiguousarray(meta, np.uint16)
+        pcm = np.full(n_pcm_floats, np.nan, np.float32)
+        spec = np.zeros(coeffs.size, np.float32) if want_spec else None
+        assert overlaps.dtype == np.float32 and overlaps.flags.c_contiguous
+        rc = self.lib.orc_decode_batch(sample_index, kind, overlaps.shape[0], overlaps.shape[1],
+                                       units.ctypes.data, len(units), coeffs.ctypes.data,
+                                       meta.ctypes.data if meta is not None else None,
+                                       pcm.ctypes.data, overlaps.ctypes.data,
+                                       spec.ctypes.data if want_spec else None)
+        if rc != 0:
+            raise RuntimeError("orc_decode_batch failed: %d" % rc)
+        return (pcm, spec.reshape(-1, 1024)) if want_spec else pcm
+
+
+_cached = None
+
+
+def load():
+    global _cached
+    if _cached is None:
+        _cached = Oracle(build())
+    return _cached
