@@ -1,0 +1,355 @@
+/*
+ * aacg_engine.hip — the C ABI of include/aacgpu.h on top of the gfx950 kernels.
+ *
+ * Replaces AACDecoder.prototype.process + the interleave of readChunk (reference
+ * src/decoder.js:201-215, 218-334) for batches of frames from many streams.  There is no
+ * CPU fallback: every entry point either runs the HIP kernels or returns an error.
+ */
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "aacg_kernels.h"
+#include "aacg_host.h"
+
+/* ---- kernels ----------------------------------------------------------------------- */
+/* 576 threads = 9 waves; 2 workgroups per CU (LDS 2 x 76.5 KiB) = 18 waves -> <= 96 VGPRs */
+extern "C" __global__ __launch_bounds__(AACG_WG_THREADS, 5)
+void aacg_imdct_run_quant(const aacg_kparams P) { imdct_run_body<AACG_INPUT_QUANT_I16>(P); }
+
+extern "C" __global__ __launch_bounds__(AACG_WG_THREADS, 5)
+void aacg_imdct_run_f32(const aacg_kparams P) { imdct_run_body<AACG_INPUT_SPEC_F32>(P); }
+
+extern "C" __global__ __launch_bounds__(64)
+void aacg_spectral(const aacg_kparams P) { spectral_body(P); }
+
+/* ---- engine ------------------------------------------------------------------------ */
+struct aacg_engine {
+    aacg_config cfg;
+    hipStream_t stream = nullptr;
+    aacg_tables* d_tab = nullptr;
+    float* d_overlap = nullptr;             /* [max_streams][max_channels][2][1024] */
+    std::vector<uint8_t> parity;            /* live buffer per (stream, channel) */
+    aacg_tables h_tab;
+    aacg_host_windows h_win;
+    /* scratch of the host-buffer path, grown on demand */
+    void*  d_coeffs = nullptr;  size_t coeffs_cap = 0;
+    aacg_band_meta* d_meta = nullptr; size_t meta_cap = 0;
+    float* d_pcm = nullptr;     size_t pcm_cap = 0;
+    std::string err;
+};
+
+struct aacg_plan {
+    aacg_engine* e;
+    aacg_plan_host h;
+    uint32_t n_units = 0;
+    aacg_unit_desc* d_units = nullptr;
+    aacg_run* d_runs = nullptr;
+    uint32_t launches = 0;
+};
+
+namespace {
+
+bool hip_ok(aacg_engine* e, hipError_t rc, const char* what)
+{
+    if (rc == hipSuccess) return true;
+    if (e) e->err = std::string(what) + ": " + hipGetErrorString(rc);
+    return false;
+}
+
+#define HIP_TRY(e, call, code) do { if (!hip_ok((e), (call), #call)) return (code); } while (0)
+
+size_t coef_elem_size(const aacg_engine* e) { return e->cfg.input_kind == AACG_INPUT_QUANT_I16 ? 2 : 4; }
+
+int grow(aacg_engine* e, void** p, size_t* cap, size_t need)
+{
+    if (need <= *cap) return AACG_OK;
+    if (*p) { (void)hipFree(*p); *p = nullptr; *cap = 0; }
+    HIP_TRY(e, hipMalloc(p, need), AACG_ERR_OUT_OF_MEMORY);
+    *cap = need;
+    return AACG_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int aacg_abi_version(void) { return AACG_ABI_VERSION; }
+
+const char* aacg_kernel_name(void) { return "aacg_imdct_run_quant"; }
+
+const char* aacg_last_error(const aacg_engine* e) { return e ? e->err.c_str() : "null engine"; }
+
+int aacg_create(const aacg_config* cfg, aacg_engine** out)
+{
+    if (!cfg || !out) return AACG_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (cfg->abi_version != AACG_ABI_VERSION || cfg->max_streams < 1 || cfg->max_channels < 1 ||
+        cfg->max_channels > AACG_MAX_CHANNELS || cfg->tns_mode != AACG_TNS_REFERENCE ||
+        (cfg->input_kind != AACG_INPUT_SPEC_F32 && cfg->input_kind != AACG_INPUT_QUANT_I16))
+        return AACG_ERR_INVALID_ARG;
+
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || cfg->device_ordinal < 0 || cfg->device_ordinal >= n_dev)
+        return AACG_ERR_NO_DEVICE;
+
+    aacg_engine* e = new (std::nothrow) aacg_engine();
+    if (!e) return AACG_ERR_OUT_OF_MEMORY;
+    e->cfg = *cfg;
+    int rc = aacg_build_tables(cfg->sample_index, &e->h_tab, &e->h_win);
+    if (rc) { delete e; return rc; }
+
+    const size_t ov_bytes = (size_t)cfg->max_streams * (size_t)cfg->max_channels * 2u * 1024u * sizeof(float);
+    if (!hip_ok(e, hipSetDevice(cfg->device_ordinal), "hipSetDevice") ||
+        !hip_ok(e, hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking), "hipStreamCreate") ||
+        !hip_ok(e, hipMalloc((void**)&e->d_tab, sizeof(aacg_tables)), "hipMalloc tables") ||
+        !hip_ok(e, hipMalloc((void**)&e->d_overlap, ov_bytes), "hipMalloc overlap") ||
+        !hip_ok(e, hipMemcpy(e->d_tab, &e->h_tab, sizeof(aacg_tables), hipMemcpyHostToDevice), "upload tables") ||
+        !hip_ok(e, hipMemset(e->d_overlap, 0, ov_bytes), "zero overlap") ||
+        /* 76.5 KiB of dynamic LDS per workgroup is above the 64 KiB default limit */
+        !hip_ok(e, hipFuncSetAttribute((const void*)aacg_imdct_run_quant, hipFuncAttributeMaxDynamicSharedMemorySize, AACG_WG_LDS_BYTES), "LDS attr") ||
+        !hip_ok(e, hipFuncSetAttribute((const void*)aacg_imdct_run_f32, hipFuncAttributeMaxDynamicSharedMemorySize, AACG_WG_LDS_BYTES), "LDS attr")) {
+        std::fprintf(stderr, "aacgpu: %s\n", e->err.c_str());
+        aacg_destroy(e);
+        return AACG_ERR_NO_DEVICE;
+    }
+    e->parity.assign((size_t)cfg->max_streams * (size_t)cfg->max_channels, 0);
+    *out = e;
+    return AACG_OK;
+}
+
+void aacg_destroy(aacg_engine* e)
+{
+    if (!e) return;
+    (void)hipSetDevice(e->cfg.device_ordinal);
+    (void)hipDeviceSynchronize();
+    if (e->d_tab) (void)hipFree(e->d_tab);
+    if (e->d_overlap) (void)hipFree(e->d_overlap);
+    if (e->d_coeffs) (void)hipFree(e->d_coeffs);
+    if (e->d_meta) (void)hipFree(e->d_meta);
+    if (e->d_pcm) (void)hipFree(e->d_pcm);
+    if (e->stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+}
+
+/* ---- overlap state ----------------------------------------------------------------- */
+static int ov_check(aacg_engine* e, uint32_t stream, uint32_t channel)
+{
+    if (!e) return AACG_ERR_INVALID_ARG;
+    if ((int)stream >= e->cfg.max_streams || (int)channel >= e->cfg.max_channels) {
+        e->err = "stream/channel out of range";
+        return AACG_ERR_INVALID_ARG;
+    }
+    HIP_TRY(e, hipSetDevice(e->cfg.device_ordinal), AACG_ERR_NO_DEVICE);
+    HIP_TRY(e, hipDeviceSynchronize(), AACG_ERR_NO_DEVICE);
+    return AACG_OK;
+}
+
+static float* ov_ptr(aacg_engine* e, uint32_t stream, uint32_t channel)
+{
+    const int p = e->parity[(size_t)stream * (size_t)e->cfg.max_channels + channel];
+    return e->d_overlap + aacg_ov_offset(e->cfg.max_channels, stream, channel, p);
+}
+
+int aacg_reset_stream(aacg_engine* e, uint32_t stream)
+{
+    int rc = ov_check(e, stream, 0);
+    if (rc) return rc;
+    for (int c = 0; c < e->cfg.max_channels; c++)
+        HIP_TRY(e, hipMemset(ov_ptr(e, stream, (uint32_t)c), 0, 4096), AACG_ERR_NO_DEVICE);
+    return AACG_OK;
+}
+
+int aacg_get_overlap(aacg_engine* e, uint32_t stream, uint32_t channel, float* dst)
+{
+    int rc = ov_check(e, stream, channel);
+    if (rc) return rc;
+    if (!dst) return AACG_ERR_INVALID_ARG;
+    HIP_TRY(e, hipMemcpy(dst, ov_ptr(e, stream, channel), 4096, hipMemcpyDeviceToHost), AACG_ERR_NO_DEVICE);
+    return AACG_OK;
+}
+
+int aacg_set_overlap(aacg_engine* e, uint32_t stream, uint32_t channel, const float* src)
+{
+    int rc = ov_check(e, stream, channel);
+    if (rc) return rc;
+    if (!src) return AACG_ERR_INVALID_ARG;
+    HIP_TRY(e, hipMemcpy(ov_ptr(e, stream, channel), src, 4096, hipMemcpyHostToDevice), AACG_ERR_NO_DEVICE);
+    return AACG_OK;
+}
+
+int aacg_get_table(aacg_engine* e, int which, float* dst, size_t n)
+{
+    if (!e || !dst) return AACG_ERR_INVALID_ARG;
+    const float* src; size_t cnt;
+    switch (which) {
+    case 0: src = e->h_tab.iq;           cnt = 8191; break;
+    case 1: src = e->h_tab.sf;           cnt = 428;  break;
+    case 2: src = e->h_win.sine_long;    cnt = 1024; break;
+    case 3: src = e->h_win.kbd_long;     cnt = 1024; break;
+    case 4: src = e->h_win.sine_short;   cnt = 128;  break;
+    case 5: src = e->h_win.kbd_short;    cnt = 128;  break;
+    default: return AACG_ERR_INVALID_ARG;
+    }
+    std::memcpy(dst, src, sizeof(float) * (n < cnt ? n : cnt));
+    return (int)cnt;
+}
+
+/* ---- plans ------------------------------------------------------------------------- */
+int aacg_plan_create(aacg_engine* e, const aacg_unit_desc* units, uint32_t n_units, aacg_plan** out)
+{
+    if (!e || !units || !n_units || !out) return AACG_ERR_INVALID_ARG;
+    *out = nullptr;
+    aacg_plan* p = new (std::nothrow) aacg_plan();
+    if (!p) return AACG_ERR_OUT_OF_MEMORY;
+    p->e = e;
+    p->n_units = n_units;
+    int rc = aacg_plan_build(units, n_units, e->cfg.sample_index, e->cfg.max_streams, e->cfg.max_channels,
+                             e->parity.data(), &p->h, &e->err);
+    if (rc) { delete p; return rc; }
+    const size_t ub = sizeof(aacg_unit_desc) * n_units, rb = sizeof(aacg_run) * p->h.runs.size();
+    if (!hip_ok(e, hipSetDevice(e->cfg.device_ordinal), "hipSetDevice") ||
+        !hip_ok(e, hipMalloc((void**)&p->d_units, ub), "hipMalloc units") ||
+        !hip_ok(e, hipMalloc((void**)&p->d_runs, rb), "hipMalloc runs") ||
+        !hip_ok(e, hipMemcpy(p->d_units, units, ub, hipMemcpyHostToDevice), "upload units") ||
+        !hip_ok(e, hipMemcpy(p->d_runs, p->h.runs.data(), rb, hipMemcpyHostToDevice), "upload runs")) {
+        aacg_plan_destroy(p);
+        return AACG_ERR_OUT_OF_MEMORY;
+    }
+    *out = p;
+    return AACG_OK;
+}
+
+void aacg_plan_destroy(aacg_plan* p)
+{
+    if (!p) return;
+    (void)hipSetDevice(p->e->cfg.device_ordinal);
+    if (p->d_units) (void)hipFree(p->d_units);
+    if (p->d_runs) (void)hipFree(p->d_runs);
+    delete p;
+}
+
+static int plan_check_parity(aacg_engine* e, const aacg_plan* p)
+{
+    const int flip = (int)(p->launches & 1u);
+    for (const aacg_chain& c : p->h.chains)
+        for (int k = 0; k < c.n_ch; k++)
+            if (e->parity[(size_t)c.stream * (size_t)e->cfg.max_channels + c.channel + k] != (c.parity[k] ^ flip)) {
+                e->err = "plan is stale: another plan advanced one of its streams";
+                return AACG_ERR_STALE_PLAN;
+            }
+    return AACG_OK;
+}
+
+int aacg_decode_device(aacg_engine* e, aacg_plan* p, const void* d_coeffs, const aacg_band_meta* d_meta,
+                       float* d_pcm, void* hip_stream)
+{
+    if (!e || !p || p->e != e || !d_coeffs || !d_pcm) return AACG_ERR_INVALID_ARG;
+    const bool quant = e->cfg.input_kind == AACG_INPUT_QUANT_I16;
+    if (quant && !d_meta) { e->err = "QUANT_I16 engine needs band meta"; return AACG_ERR_INVALID_ARG; }
+    int rc = plan_check_parity(e, p);
+    if (rc) return rc;
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : e->stream;
+    if (p->h.zero_fill)
+        HIP_TRY(e, hipMemsetAsync(d_pcm, 0, p->h.pcm_floats * sizeof(float), s), AACG_ERR_NO_DEVICE);
+
+    aacg_kparams P;
+    P.units = p->d_units; P.runs = p->d_runs; P.coeffs = d_coeffs; P.meta = d_meta; P.pcm = d_pcm;
+    P.overlap = e->d_overlap; P.spec_out = nullptr; P.tab = e->d_tab;
+    P.flip = (int32_t)(p->launches & 1u); P.n_runs = (int32_t)p->h.runs.size();
+    const dim3 grid((unsigned)p->h.runs.size()), block(AACG_WG_THREADS);
+    if (quant) hipLaunchKernelGGL(aacg_imdct_run_quant, grid, block, AACG_WG_LDS_BYTES, s, P);
+    else       hipLaunchKernelGGL(aacg_imdct_run_f32, grid, block, AACG_WG_LDS_BYTES, s, P);
+    HIP_TRY(e, hipGetLastError(), AACG_ERR_NO_DEVICE);
+
+    for (const aacg_chain& c : p->h.chains)
+        for (int k = 0; k < c.n_ch; k++)
+            e->parity[(size_t)c.stream * (size_t)e->cfg.max_channels + c.channel + k] ^= 1;
+    p->launches++;
+    return AACG_OK;
+}
+
+int aacg_spectral_device(aacg_engine* e, aacg_plan* p, const void* d_coeffs, const aacg_band_meta* d_meta,
+                         float* d_spec_out, void* hip_stream)
+{
+    if (!e || !p || p->e != e || !d_coeffs || !d_meta || !d_spec_out) return AACG_ERR_INVALID_ARG;
+    if (e->cfg.input_kind != AACG_INPUT_QUANT_I16) { e->err = "spectral stage needs a QUANT_I16 engine"; return AACG_ERR_INVALID_ARG; }
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : e->stream;
+    aacg_kparams P;
+    std::memset(&P, 0, sizeof P);
+    P.units = p->d_units; P.coeffs = d_coeffs; P.meta = d_meta; P.spec_out = d_spec_out; P.tab = e->d_tab;
+    hipLaunchKernelGGL(aacg_spectral, dim3(p->n_units), dim3(64), 1024 * 4 + 512, s, P);
+    HIP_TRY(e, hipGetLastError(), AACG_ERR_NO_DEVICE);
+    return AACG_OK;
+}
+
+int aacg_synchronize(aacg_engine* e, void* hip_stream)
+{
+    if (!e) return AACG_ERR_INVALID_ARG;
+    HIP_TRY(e, hipStreamSynchronize(hip_stream ? (hipStream_t)hip_stream : e->stream), AACG_ERR_NO_DEVICE);
+    return AACG_OK;
+}
+
+/* ---- host-buffer path: process(elements) + interleave for a batch ------------------- */
+int aacg_decode_batch(aacg_engine* e, const aacg_unit_desc* units, uint32_t n_units,
+                      const void* coeffs, uint32_t n_coef_blocks,
+                      const aacg_band_meta* meta, uint32_t n_meta,
+                      float* pcm_out, size_t n_pcm_floats)
+{
+    if (!e || !units || !n_units || !coeffs || !pcm_out) return AACG_ERR_INVALID_ARG;
+    const bool quant = e->cfg.input_kind == AACG_INPUT_QUANT_I16;
+    if (quant && !meta) { e->err = "QUANT_I16 engine needs band meta"; return AACG_ERR_INVALID_ARG; }
+    if (e->cfg.max_batch_units > 0 && (int)n_units > e->cfg.max_batch_units) {
+        e->err = "batch exceeds max_batch_units";
+        return AACG_ERR_CAPACITY;
+    }
+
+    aacg_plan* p = nullptr;
+    int rc = aacg_plan_create(e, units, n_units, &p);
+    if (rc) return rc;
+    if (p->h.coef_blocks > n_coef_blocks || (quant && p->h.meta_blocks > n_meta) || p->h.pcm_floats > n_pcm_floats) {
+        e->err = "a unit points outside the coefficient / meta / pcm buffers";
+        aacg_plan_destroy(p);
+        return AACG_ERR_INVALID_ARG;
+    }
+    if (quant) {
+        /* PNS bands: aac.js's generator degenerates to NaN output (ics.js:234,239);
+         * like the reference's other unsupported tools this is refused, not silently altered. */
+        for (uint32_t i = 0; i < n_units; i++)
+            for (int c = 0; c < units[i].n_ch; c++) {
+                const aacg_chan_info& ci = units[i].ch[c];
+                const aacg_band_meta& m = meta[units[i].meta_offset + (uint32_t)c];
+                for (int b = 0; b < ci.group_count * ci.max_sfb; b++)
+                    if ((m.band[b] >> AACG_META_BT_SHIFT) == AACG_NOISE_BT) {
+                        e->err = "NOISE_BT (PNS) band: not decodable by the reference either";
+                        aacg_plan_destroy(p);
+                        return AACG_ERR_UNSUPPORTED;
+                    }
+            }
+    }
+
+    const size_t cb = (size_t)n_coef_blocks * 1024u * coef_elem_size(e);
+    const size_t mb = quant ? (size_t)n_meta * sizeof(aacg_band_meta) : 0;
+    const size_t pb = n_pcm_floats * sizeof(float);
+    rc = grow(e, &e->d_coeffs, &e->coeffs_cap, cb);
+    if (!rc && quant) rc = grow(e, (void**)&e->d_meta, &e->meta_cap, mb);
+    if (!rc) rc = grow(e, (void**)&e->d_pcm, &e->pcm_cap, pb);
+    if (rc) { aacg_plan_destroy(p); return rc; }
+
+    bool ok = hip_ok(e, hipMemcpyAsync(e->d_coeffs, coeffs, cb, hipMemcpyHostToDevice, e->stream), "H2D coeffs");
+    if (ok && quant) ok = hip_ok(e, hipMemcpyAsync(e->d_meta, meta, mb, hipMemcpyHostToDevice, e->stream), "H2D meta");
+    if (ok) {
+        rc = aacg_decode_device(e, p, e->d_coeffs, e->d_meta, e->d_pcm, e->stream);
+        if (!rc) ok = hip_ok(e, hipMemcpyAsync(pcm_out, e->d_pcm, p->h.pcm_floats * sizeof(float), hipMemcpyDeviceToHost, e->stream), "D2H pcm") &&
+                      hip_ok(e, hipStreamSynchronize(e->stream), "sync");
+    }
+    aacg_plan_destroy(p);
+    if (rc) return rc;
+    return ok ? AACG_OK : AACG_ERR_NO_DEVICE;
+}
+
+}  // extern "C"

@@ -1,0 +1,54 @@
+/*
+ * aacg_host.h — host-side internals shared by the engine and (for CPU-only tests of the
+ * host logic) the lane emulator: table construction and the batch planner.  No HIP here.
+ */
+#ifndef AACG_HOST_H
+#define AACG_HOST_H
+
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "aacg_device.h"
+
+struct aacg_host_windows {
+    float sine_long[1024], kbd_long[1024], sine_short[128], kbd_short[128];
+};
+
+/* Fills *t for config.sampleIndex (decoder.js:63); hw (optional) receives the plain windows. */
+int aacg_build_tables(int sample_index, aacg_tables* t, aacg_host_windows* hw);
+/* SWB_OFFSET_1024/128[sample_index] (tables.js:34-155): writes count+1 offsets, returns count. */
+int aacg_swb_offsets(int sample_index, int is_long, int* dst);
+
+/* One (stream, element) sequence of consecutive frames inside a batch. */
+struct aacg_chain {
+    uint32_t stream;
+    uint16_t channel;
+    uint8_t  n_ch;
+    uint8_t  parity[2];     /* overlap buffer holding the chain's input state when the plan was built */
+    uint32_t first_run, n_runs;
+};
+
+struct aacg_plan_host {
+    std::vector<aacg_run>   runs;     /* in launch (block) order, XCD-aware */
+    std::vector<aacg_chain> chains;
+    bool     zero_fill = false;       /* some frame has a channel no unit writes (decoder.js:229-231) */
+    uint32_t coef_blocks = 0;         /* 1 + highest (coef_offset + c) referenced */
+    uint32_t meta_blocks = 0;
+    size_t   pcm_floats = 0;          /* 1 + highest PCM float written */
+};
+
+/* float offset of overlap buffer `parity` of (stream, channel) in the pool */
+static inline int32_t aacg_ov_offset(int max_channels, uint32_t stream, uint32_t channel, int parity)
+{
+    return (int32_t)((((size_t)stream * (size_t)max_channels + channel) * 2u + (unsigned)parity) * 1024u);
+}
+
+/* Validates the units and cuts them into runs.  parity: [max_streams * max_channels] current
+ * input buffer per (stream, channel), or NULL for all zero.  Returns AACG_OK or an error code
+ * with a message in *err. */
+int aacg_plan_build(const aacg_unit_desc* units, uint32_t n_units, int sample_index,
+                    int max_streams, int max_channels, const uint8_t* parity,
+                    aacg_plan_host* out, std::string* err);
+
+#endif

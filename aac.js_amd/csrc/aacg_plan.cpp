@@ -1,0 +1,160 @@
+/*
+ * aacg_plan.cpp — batch planner: turns the host's list of parsed elements ("units", the
+ * `elements` array of decoder.js:218 for many frames and streams) into workgroup runs.
+ *
+ * A chain is the sequence of frames of one element (same stream, same first channel, same
+ * width) inside the batch; the only cross-frame dependency of the path is the overlap
+ * buffer of each of its channels (filter_bank.js:38-41).  A chain is cut into runs of
+ * AACG_RUN_W frames; run 0 takes its incoming tail from the overlap state, every later run
+ * recomputes it from the previous frame's spectrum (no inter-workgroup communication).
+ */
+#include "aacg_host.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <map>
+
+namespace {
+
+struct stream_state {
+    bool     seen = false;
+    uint32_t cur_off = 0;      /* pcm_offset of the frame being assembled */
+    uint32_t frame = 0;        /* frame ordinal inside the batch */
+    uint32_t mask = 0;         /* channels covered in the current frame */
+    uint16_t n_out = 0;
+};
+
+struct open_chain {
+    std::vector<int32_t> units;
+    uint32_t last_frame;
+    uint8_t  n_ch;
+};
+
+int fail(std::string* err, int code, const char* fmt, long a = 0, long b = 0, long c = 0)
+{
+    if (err) {
+        char buf[256];
+        std::snprintf(buf, sizeof buf, fmt, a, b, c);
+        *err = buf;
+    }
+    return code;
+}
+
+}  // namespace
+
+int aacg_plan_build(const aacg_unit_desc* units, uint32_t n_units, int sample_index,
+                    int max_streams, int max_channels, const uint8_t* parity,
+                    aacg_plan_host* out, std::string* err)
+{
+    int swb[64];
+    const int n_long = aacg_swb_offsets(sample_index, 1, swb);
+    const int n_short = aacg_swb_offsets(sample_index, 0, swb);
+    if (!n_long) return fail(err, AACG_ERR_INVALID_ARG, "sample_index %ld out of range", sample_index);
+
+    *out = aacg_plan_host();
+    std::vector<stream_state> st((size_t)max_streams);
+    std::map<uint64_t, open_chain> open;                     /* key: stream << 16 | channel */
+
+    auto close_frame = [&](stream_state& s) {
+        if (s.seen && s.mask != ((1u << s.n_out) - 1u)) out->zero_fill = true;
+    };
+
+    for (uint32_t i = 0; i < n_units; i++) {
+        const aacg_unit_desc& u = units[i];
+        if (u.n_ch < 1 || u.n_ch > 2) return fail(err, AACG_ERR_INVALID_ARG, "unit %ld: n_ch %ld", i, u.n_ch);
+        if ((int)u.stream >= max_streams) return fail(err, AACG_ERR_CAPACITY, "unit %ld: stream %ld >= max_streams", i, u.stream);
+        if (u.n_out_ch < 1 || u.n_out_ch > max_channels || u.channel + u.n_ch > u.n_out_ch)
+            return fail(err, AACG_ERR_INVALID_ARG, "unit %ld: channel %ld does not fit %ld output channels", i, u.channel, u.n_out_ch);
+        for (int c = 0; c < u.n_ch; c++) {
+            const aacg_chan_info& ci = u.ch[c];
+            if (ci.window_sequence > 3 || ci.window_shape > 1 || ci.window_shape_prev > 1)
+                return fail(err, AACG_ERR_INVALID_ARG, "unit %ld ch %ld: bad window fields", i, c);
+            if (ci.window_sequence == AACG_EIGHT_SHORT_SEQUENCE) {
+                int sum = 0;
+                if (ci.group_count < 1 || ci.group_count > 8) return fail(err, AACG_ERR_INVALID_ARG, "unit %ld ch %ld: group_count", i, c);
+                for (int g = 0; g < ci.group_count; g++) sum += ci.group_len[g];
+                if (sum != 8) return fail(err, AACG_ERR_INVALID_ARG, "unit %ld ch %ld: group lengths sum to %ld, not 8", i, c, sum);
+                if (ci.max_sfb > n_short) return fail(err, AACG_ERR_INVALID_ARG, "unit %ld ch %ld: max_sfb %ld (short)", i, c, ci.max_sfb);
+            } else {
+                if (ci.group_count != 1 || ci.group_len[0] != 1) return fail(err, AACG_ERR_INVALID_ARG, "unit %ld ch %ld: long window needs one group of one", i, c);
+                if (ci.max_sfb > n_long) return fail(err, AACG_ERR_INVALID_ARG, "unit %ld ch %ld: max_sfb %ld (long)", i, c, ci.max_sfb);
+            }
+            if ((int)ci.group_count * (int)ci.max_sfb > AACG_MAX_SECTIONS)
+                return fail(err, AACG_ERR_INVALID_ARG, "unit %ld ch %ld: more than 120 bands", i, c);
+        }
+
+        stream_state& s = st[u.stream];
+        if (!s.seen) { s.seen = true; s.cur_off = u.pcm_offset; s.frame = 0; s.mask = 0; s.n_out = u.n_out_ch; }
+        else if (u.pcm_offset != s.cur_off) { close_frame(s); s.cur_off = u.pcm_offset; s.frame++; s.mask = 0; }
+        if (u.n_out_ch != s.n_out) return fail(err, AACG_ERR_LAYOUT_CHANGE, "unit %ld: stream %ld changes channel count inside a batch", i, u.stream);
+        const uint32_t bits = ((1u << u.n_ch) - 1u) << u.channel;
+        if (s.mask & bits) return fail(err, AACG_ERR_INVALID_ARG, "unit %ld: channel %ld written twice in one frame", i, u.channel);
+        s.mask |= bits;
+
+        const uint64_t key = ((uint64_t)u.stream << 16) | u.channel;
+        auto it = open.find(key);
+        if (it == open.end()) {
+            if (s.frame != 0) return fail(err, AACG_ERR_LAYOUT_CHANGE, "unit %ld: element at channel %ld appears mid-batch", i, u.channel);
+            open_chain oc; oc.last_frame = 0; oc.n_ch = u.n_ch; oc.units.push_back((int32_t)i);
+            open.emplace(key, std::move(oc));
+        } else {
+            open_chain& oc = it->second;
+            if (oc.n_ch != u.n_ch || oc.last_frame + 1 != s.frame)
+                return fail(err, AACG_ERR_LAYOUT_CHANGE, "unit %ld: element layout of stream %ld changes inside a batch", i, u.stream);
+            oc.last_frame = s.frame;
+            oc.units.push_back((int32_t)i);
+        }
+
+        out->coef_blocks = std::max(out->coef_blocks, u.coef_offset + u.n_ch);
+        out->meta_blocks = std::max(out->meta_blocks, u.meta_offset + u.n_ch);
+        out->pcm_floats = std::max(out->pcm_floats, (size_t)u.pcm_offset + 1024u * u.n_out_ch);
+    }
+    for (auto& s : st) close_frame(s);
+    /* every chain must reach its stream's last frame, or a later batch would chain onto a stale tail */
+    for (auto& kv : open)
+        if (kv.second.last_frame != st[(size_t)(kv.first >> 16)].frame)
+            return fail(err, AACG_ERR_LAYOUT_CHANGE, "stream %ld: element at channel %ld ends before the batch does",
+                        (long)(kv.first >> 16), (long)(kv.first & 0xffff));
+
+    /* chains -> runs, generated chain by chain */
+    std::vector<aacg_run> gen;
+    for (auto& kv : open) {
+        const open_chain& oc = kv.second;
+        aacg_chain ch;
+        ch.stream = (uint32_t)(kv.first >> 16);
+        ch.channel = (uint16_t)(kv.first & 0xffff);
+        ch.n_ch = oc.n_ch;
+        ch.first_run = (uint32_t)gen.size();
+        for (int c = 0; c < 2; c++)
+            ch.parity[c] = (parity && c < oc.n_ch) ? parity[(size_t)ch.stream * (size_t)max_channels + ch.channel + c] : 0;
+        const size_t n = oc.units.size();
+        for (size_t pos = 0; pos < n; pos += AACG_RUN_W) {
+            aacg_run r;
+            r.pred_unit = pos ? oc.units[pos - 1] : -1;
+            r.n_units = (int32_t)std::min<size_t>(AACG_RUN_W, n - pos);
+            for (int k = 0; k < AACG_RUN_W; k++) r.unit[k] = k < r.n_units ? oc.units[pos + k] : -1;
+            for (int c = 0; c < 2; c++) {
+                const uint32_t chn = ch.channel + (c < oc.n_ch ? c : 0);
+                r.ov_a[c] = aacg_ov_offset(max_channels, ch.stream, chn, ch.parity[c]);
+                r.ov_b[c] = aacg_ov_offset(max_channels, ch.stream, chn, ch.parity[c] ^ 1);
+            }
+            r.is_last = (pos + AACG_RUN_W >= n) ? 1 : 0;
+            r.reserved = 0;
+            gen.push_back(r);
+        }
+        ch.n_runs = (uint32_t)gen.size() - ch.first_run;
+        out->chains.push_back(ch);
+    }
+
+    /* XCD-aware block order: the dispatcher puts block b on XCD b % 8 (observed, speed only), and a
+     * run re-reads the last frame of the run before it; keep neighbours on one XCD's L2. */
+    const size_t R = gen.size();
+    out->runs.resize(R);
+    size_t i = 0;
+    for (size_t x = 0; x < 8 && x < R; x++) {
+        const size_t cnt = (R - 1 - x) / 8 + 1;
+        for (size_t s = 0; s < cnt; s++) out->runs[s * 8 + x] = gen[i++];
+    }
+    /* chain.first_run refers to generation order; the engine only needs counts, keep as is */
+    return AACG_OK;
+}

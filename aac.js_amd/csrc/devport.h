@@ -1,0 +1,64 @@
+/*
+ * devport.h — the handful of wavefront primitives the kernels are written against.
+ *
+ * Product build (hipcc, gfx950): thin wrappers over CDNA4 builtins — 64-lane wavefronts,
+ * ds_bpermute cross-lane moves, wave-scope LDS fences, workgroup barrier.
+ *
+ * tests/emu/ provides a second implementation of exactly these names on CPU threads
+ * (one thread per lane, barriers at the sync points) so the kernels' index choreography
+ * can be checked in the build container, which has no GPU.  That build is test
+ * infrastructure; the product library never contains it (AACG_EMU_BUILD is only defined
+ * by tests/emu/Makefile).
+ */
+#ifndef AACG_DEVPORT_H
+#define AACG_DEVPORT_H
+
+#ifdef AACG_EMU_BUILD
+#include "devport_emu.h"
+#else
+
+#include <hip/hip_runtime.h>
+
+#define DP_DEVICE __device__ __forceinline__
+#define DP_KERNEL(bounds_threads, bounds_waves) __global__ __launch_bounds__(bounds_threads, bounds_waves)
+
+typedef float2 dpf2;
+typedef float4 dpf4;
+
+DP_DEVICE int dp_lane()  { return (int)(threadIdx.x & 63u); }
+DP_DEVICE int dp_wave()  { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+DP_DEVICE int dp_block() { return (int)blockIdx.x; }
+/* make a wave-uniform value provably uniform (lets hipcc use scalar loads behind it) */
+DP_DEVICE int dp_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+/* LDS written by some lanes of this wave, read by others: order + complete the writes. */
+DP_DEVICE void dp_wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+DP_DEVICE void dp_block_sync() { __syncthreads(); }
+
+/* v[i] <- lane `src`'s v[i]  (ds_bpermute_b32; no LDS storage involved) */
+template <int N>
+DP_DEVICE void dp_shfl(float (&v)[N], int src)
+{
+#pragma unroll
+    for (int i = 0; i < N; i++) v[i] = __shfl(v[i], src, 64);
+}
+
+extern __shared__ __attribute__((aligned(16))) unsigned char dp_lds_raw[];
+DP_DEVICE unsigned char* dp_lds() { return dp_lds_raw; }
+
+DP_DEVICE float dp_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+/* hide a value from common-subexpression elimination: a table load behind it is re-issued
+ * (an L1 hit) instead of its result being held in VGPRs across the whole FFT */
+DP_DEVICE int dp_opaque(int v) { asm volatile("" : "+v"(v)); return v; }
+DP_DEVICE float dp_nan() { return __builtin_nanf(""); }
+/* keep the instruction scheduler from hoisting the next block's loads above this point
+ * (bounds the number of gathers in flight, i.e. VGPR pressure) */
+DP_DEVICE void dp_sched_fence() { __builtin_amdgcn_sched_barrier(0); }
+
+#endif /* AACG_EMU_BUILD */
+#endif

@@ -1,0 +1,183 @@
+"""ctypes binding of the C ABI in include/aacgpu.h (aac.js_amd/csrc/libaacgpu.so).
+
+Plumbing only: tests and bench.py drive the HIP path through exactly the entry points a
+JavaScript host binds over N-API.  There is no CPU fallback here: if the
+library is missing or no GPU is present, calls raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+LIB_PATH = os.path.join(ROOT, "aac.js_amd", "csrc", "libaacgpu.so")
+
+INPUT_SPEC_F32, INPUT_QUANT_I16 = 0, 1
+ERR_NAMES = {0: "OK", -1: "INVALID_ARG", -2: "NO_DEVICE", -3: "OUT_OF_MEMORY", -4: "CAPACITY",
+             -5: "UNSUPPORTED", -6: "LAYOUT_CHANGE", -7: "STALE_PLAN"}
+
+# every symbol include/aacgpu.h declares
+ABI_SYMBOLS = ["aacg_create", "aacg_destroy", "aacg_last_error", "aacg_abi_version", "aacg_reset_stream",
+               "aacg_get_overlap", "aacg_set_overlap", "aacg_decode_batch", "aacg_plan_create", "aacg_plan_destroy",
+               "aacg_decode_device", "aacg_spectral_device", "aacg_synchronize", "aacg_get_table", "aacg_kernel_name"]
+
+UNIT_DTYPE = np.dtype([
+    ("stream", "<u4"), ("pcm_offset", "<u4"), ("channel", "<u2"), ("n_out_ch", "<u2"),
+    ("n_ch", "u1"), ("flags", "u1"), ("reserved0", "<u2"), ("coef_offset", "<u4"), ("meta_offset", "<u4"),
+    ("ch", [("window_sequence", "u1"), ("window_shape", "u1"), ("window_shape_prev", "u1"), ("max_sfb", "u1"),
+            ("group_count", "u1"), ("flags", "u1"), ("reserved", "u1", (2,)), ("group_len", "u1", (8,))], (2,)),
+    ("reserved1", "<u4", (2,)),
+])
+assert UNIT_DTYPE.itemsize == 64
+
+
+class Config(C.Structure):
+    _fields_ = [("abi_version", C.c_int32), ("device_ordinal", C.c_int32), ("sample_index", C.c_int32),
+                ("max_streams", C.c_int32), ("max_channels", C.c_int32), ("max_batch_units", C.c_int32),
+                ("input_kind", C.c_int32), ("tns_mode", C.c_int32)]
+
+
+class AacgError(RuntimeError):
+    def __init__(self, code, msg):
+        RuntimeError.__init__(self, "aacgpu: %s (%d): %s" % (ERR_NAMES.get(code, "?"), code, msg))
+        self.code = code
+
+
+_lib = None
+
+
+def load_library(path=LIB_PATH):
+    """dlopen the C-ABI library.  Raises if it has not been built — never falls back."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(path):
+        raise RuntimeError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(hipcc --offload-arch=gfx950); there is no CPU fallback" % path)
+    L = C.CDLL(path)
+    L.aacg_abi_version.restype = C.c_int
+    L.aacg_kernel_name.restype = C.c_char_p
+    L.aacg_last_error.restype = C.c_char_p
+    L.aacg_last_error.argtypes = [C.c_void_p]
+    L.aacg_create.argtypes = [C.POINTER(Config), C.POINTER(C.c_void_p)]
+    L.aacg_destroy.argtypes = [C.c_void_p]
+    L.aacg_destroy.restype = None
+    L.aacg_reset_stream.argtypes = [C.c_void_p, C.c_uint32]
+    L.aacg_get_overlap.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+    L.aacg_set_overlap.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+    L.aacg_decode_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32,
+                                    C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t]
+    L.aacg_plan_create.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]
+    L.aacg_plan_destroy.argtypes = [C.c_void_p]
+    L.aacg_plan_destroy.restype = None
+    L.aacg_decode_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.aacg_spectral_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.aacg_synchronize.argtypes = [C.c_void_p, C.c_void_p]
+    L.aacg_get_table.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
+    _lib = L
+    return L
+
+
+class Plan:
+    def __init__(self, engine, handle, n_units):
+        self.engine, self.handle, self.n_units = engine, handle, n_units
+
+    def destroy(self):
+        if self.handle:
+            self.engine.lib.aacg_plan_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+class Engine:
+    """One engine per device (mirrors one FilterBank per decoder, for many streams at once)."""
+
+    def __init__(self, input_kind=INPUT_QUANT_I16, max_streams=1, max_channels=2, device=0, sample_index=3,
+                 max_batch_units=0):
+        self.lib = load_library()
+        cfg = Config(self.lib.aacg_abi_version(), device, sample_index, max_streams, max_channels, max_batch_units,
+                     input_kind, 0)
+        h = C.c_void_p()
+        rc = self.lib.aacg_create(C.byref(cfg), C.byref(h))
+        if rc:
+            raise AacgError(rc, "aacg_create failed (is a GPU visible?)")
+        self.handle = h
+        self.input_kind = input_kind
+        self.max_streams, self.max_channels = max_streams, max_channels
+
+    def close(self):
+        if self.handle:
+            self.lib.aacg_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc < 0:
+            raise AacgError(rc, self.lib.aacg_last_error(self.handle).decode())
+        return rc
+
+    # -- host-buffer path -----------------------------------------------------------------
+    def decode_batch(self, units, coeffs, meta, n_pcm_floats):
+        units = np.ascontiguousarray(units)
+        assert units.dtype == UNIT_DTYPE
+        coeffs = np.ascontiguousarray(coeffs)
+        assert coeffs.dtype == (np.int16 if self.input_kind == INPUT_QUANT_I16 else np.float32)
+        n_blocks = coeffs.size // 1024
+        if meta is not None:
+            meta = np.ascontiguousarray(meta, np.uint16)
+        pcm = np.full(n_pcm_floats, np.nan, np.float32)
+        self._check(self.lib.aacg_decode_batch(self.handle, units.ctypes.data, len(units), coeffs.ctypes.data, n_blocks,
+                                               meta.ctypes.data if meta is not None else None,
+                                               meta.size // 120 if meta is not None else 0, pcm.ctypes.data, pcm.size))
+        return pcm
+
+    # -- device-resident path -----------------------------------------------------------------
+    def plan(self, units):
+        units = np.ascontiguousarray(units)
+        assert units.dtype == UNIT_DTYPE
+        h = C.c_void_p()
+        self._check(self.lib.aacg_plan_create(self.handle, units.ctypes.data, len(units), C.byref(h)))
+        return Plan(self, h, len(units))
+
+    def decode_device(self, plan, d_coeffs, d_meta, d_pcm, stream=0):
+        """d_* are raw device addresses (e.g. torch.Tensor.data_ptr()); stream a hipStream_t handle or 0."""
+        self._check(self.lib.aacg_decode_device(self.handle, plan.handle, d_coeffs, d_meta, d_pcm, stream))
+
+    def spectral_device(self, plan, d_coeffs, d_meta, d_spec, stream=0):
+        self._check(self.lib.aacg_spectral_device(self.handle, plan.handle, d_coeffs, d_meta, d_spec, stream))
+
+    def synchronize(self, stream=0):
+        self._check(self.lib.aacg_synchronize(self.handle, stream))
+
+    # -- overlap state ------------------------------------------------------------------------
+    def get_overlap(self, stream, channel):
+        a = np.empty(1024, np.float32)
+        self._check(self.lib.aacg_get_overlap(self.handle, stream, channel, a.ctypes.data))
+        return a
+
+    def set_overlap(self, stream, channel, values):
+        a = np.ascontiguousarray(values, np.float32)
+        assert a.size == 1024
+        self._check(self.lib.aacg_set_overlap(self.handle, stream, channel, a.ctypes.data))
+
+    def reset_stream(self, stream):
+        self._check(self.lib.aacg_reset_stream(self.handle, stream))
+
+    def table(self, which):
+        n = self._check(self.lib.aacg_get_table(self.handle, which, np.empty(1, np.float32).ctypes.data, 0))
+        a = np.empty(n, np.float32)
+        self._check(self.lib.aacg_get_table(self.handle, which, a.ctypes.data, n))
+        return a
+
+    def kernel_name(self):
+        return self.lib.aacg_kernel_name().decode()

@@ -1,0 +1,107 @@
+"""Synthetic AAC-LC workloads: unit tables, quantised spectra and band side info
+for S streams x T consecutive frames, shaped like what the JavaScript host's parser emits.
+
+Layout conventions used by bench.py and the tests:
+  frame (s, t) -> frame index f = s * T + t
+  pcm_offset   = f * 1024 * C            coef/meta block of channel c = f * C + c
+"""
+import numpy as np
+
+from aacgpu import UNIT_DTYPE
+
+SWB_LONG_48 = np.concatenate([[0], np.cumsum([4] * 10 + [8] * 7 + [12] * 4 + [16] * 2 + [20] * 2 + [24] * 2 +
+                                              [28] * 2 + [32] * 19 + [96])])
+SWB_SHORT_48 = np.concatenate([[0], np.cumsum([4] * 5 + [8] * 3 + [12] * 3 + [16] * 3)])
+
+SEQ_PATTERN_MIX = [0, 0, 1, 2, 2, 3, 0, 0]          # config 3: ONLY_LONG, LONG_START, EIGHT_SHORT x2, LONG_STOP, ...
+
+
+def _band_of(offsets, n):
+    b = np.zeros(n, np.int64)
+    for i in range(len(offsets) - 1):
+        b[offsets[i]:offsets[i + 1]] = i
+    return b
+
+
+def make_batch(n_streams, n_frames, layout=("cpe",), mix=False, seed=0xAAC00002, intensity=False, frame_base=0,
+               stream_base=0):
+    """Returns dict(units, q (int16 [blocks,1024]), meta (uint16 [blocks,120]), C, n_pcm, n_frames_total).
+
+    mix=False: config 2 — all ONLY_LONG, KBD, maxSFB 49, common window, ms_used on even bands.
+    mix=True : config 3 — per-stream sequence pattern [0,0,1,2,2,3,0,0] phase-shifted by stream, shorts grouped
+               [3,4,1] with maxSFB 14, shapes alternating per frame.  frame_base continues the pattern across
+               consecutive batches of the same streams.
+    """
+    rng = np.random.default_rng(seed + 7919 * frame_base)
+    C = sum(2 if e == "cpe" else 1 for e in layout)
+    F = n_streams * n_frames
+    n_units = F * len(layout)
+    units = np.zeros(n_units, UNIT_DTYPE)
+    q = np.zeros((F * C, 1024), np.int16)
+    meta = np.zeros((F * C, 120), np.uint16)
+
+    s_idx = np.repeat(np.arange(n_streams), n_frames)
+    t_idx = np.tile(np.arange(n_frames), n_streams) + frame_base
+    if mix:
+        seq_f = np.array(SEQ_PATTERN_MIX)[(t_idx + s_idx) % 8]
+        shape_f = (t_idx & 1).astype(np.uint8)
+    else:
+        seq_f = np.zeros(F, np.int64)
+        shape_f = np.ones(F, np.uint8)
+
+    band_long, band_short = _band_of(SWB_LONG_48, 1024), _band_of(SWB_SHORT_48, 128)
+    k = np.arange(1024)
+    lam_long = 24.0 * np.exp(-k / 180.0)
+    lam_short = np.tile(24.0 * np.exp(-(np.arange(128) * 8) / 180.0), 8)
+    group_of_win = np.repeat([0, 1, 2], [3, 4, 1])
+
+    ui = 0
+    chan = 0
+    for e_i, e in enumerate(layout):
+        nc = 2 if e == "cpe" else 1
+        sel = np.arange(F) * len(layout) + e_i
+        u = units[sel]
+        u["stream"] = s_idx + stream_base
+        u["pcm_offset"] = np.arange(F, dtype=np.uint64) * 1024 * C
+        u["channel"] = chan
+        u["n_out_ch"] = C
+        u["n_ch"] = nc
+        u["flags"] = 3 if nc == 2 else 0          # common window + mask present
+        u["coef_offset"] = np.arange(F) * C + chan
+        u["meta_offset"] = np.arange(F) * C + chan
+        is_short = seq_f == 2
+        for c in range(nc):
+            u["ch"]["window_sequence"][:, c] = seq_f
+            u["ch"]["window_shape"][:, c] = shape_f
+            u["ch"]["max_sfb"][:, c] = np.where(is_short, 14, 49)
+            u["ch"]["group_count"][:, c] = np.where(is_short, 3, 1)
+            gl = np.zeros((F, 8), np.uint8)
+            gl[:, 0] = 1
+            gl[is_short, :3] = [3, 4, 1]
+            u["ch"]["group_len"][:, c] = gl
+        units[sel] = u
+
+        for c in range(nc):
+            blocks = np.arange(F) * C + chan + c
+            # two-sided geometric magnitudes with scale lambda(k)
+            lam = np.where(is_short[:, None], lam_short[None, :], lam_long[None, :])
+            mag = np.floor(rng.exponential(1.0, (F, 1024)) * lam * 0.5)
+            sign = rng.integers(0, 2, (F, 1024)) * 2 - 1
+            q[blocks] = np.clip(mag * sign, -8190, 8190).astype(np.int16)
+            # band side info: spectral codebooks 1..11, scalefactor index 140 +- 8, ms_used on even bands (left)
+            nb = np.where(is_short, 3 * 14, 49)
+            bt = rng.integers(1, 12, (F, 120)).astype(np.uint16)
+            sf = (140 + rng.integers(-8, 9, (F, 120))).astype(np.uint16)
+            if intensity and c == 1:
+                is_band = rng.random((F, 120)) < 0.15
+                bt = np.where(is_band, rng.integers(14, 16, (F, 120)), bt).astype(np.uint16)
+                sf = np.where(is_band, 200 + rng.integers(-20, 21, (F, 120)), sf).astype(np.uint16)
+            m = sf | (bt << 12)
+            if nc == 2 and c == 0:
+                sfb = np.where(is_short[:, None], np.arange(120)[None, :] % 14, np.arange(120)[None, :])
+                m = m | np.where(sfb % 2 == 0, 0x400, 0).astype(np.uint16)
+            m = np.where(np.arange(120)[None, :] < nb[:, None], m, 0).astype(np.uint16)
+            meta[blocks] = m
+        chan += nc
+        ui += 1
+    return dict(units=units, q=q, meta=meta, C=C, n_pcm=F * 1024 * C, n_frames_total=F)

@@ -1,0 +1,180 @@
+#!/usr/bin/env python3
+"""bench.py — AAC-LC 48 kHz stereo frames/sec of the hot path on MI355X (BASELINE.json metric).
+
+One step = one pass of the hot path (dequant + MS/IS -> IMDCT -> window -> overlap-add -> interleave)
+over one batch of BASELINE config 2: 256 streams x 16 consecutive frames = 4096 stereo ONLY_LONG
+frames (KBD, maxSFB 49, common window, ms_used on even bands), int16 quantised spectra + band side
+info resident in HBM, float PCM written to HBM.  Consecutive steps are consecutive batches of the
+same 256 streams (overlap state carried in the engine), rotating through NBUF distinct input/output
+buffer sets so that no step is served from the 256 MiB Infinity Cache.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--input quant|spec] [--workload cfg2|cfg3]
+
+N > 1: launched by torch.distributed.run, one rank per GPU; streams are sharded over ranks (every rank
+decodes its own 256 streams: weak scaling, no data-path collective; RCCL only carries the barrier and
+the max-over-ranks of the elapsed time).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "aac.js_amd", "python"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec peak (6.29 TB/s measured copy)
+STREAMS, FRAMES = 256, 16      # config 2: 4096 stereo frames per batch per GPU
+
+
+def algorithmic_bytes_per_stereo_frame(kind):
+    """per channel-frame 4096 B spectrum (f32) or 2048 B coefficients + 240 B band side
+    info (int16 path), 4096 B PCM out, + 8192/T B of overlap state (read + written once per chain)."""
+    per_cf = (4096 if kind == "spec" else 2048 + 240) + 4096 + 8192.0 / FRAMES
+    return 2 * per_cf
+
+
+def cpu_baseline(kind, mix, budget_s=12.0):
+    """The oracle (plain C restatement of the reference algorithm, bit-exact with aac.js) on ONE host core,
+    on a bounded sample of the same workload: batches of 4 streams x 16 frames until ~budget_s of CPU time."""
+    import numpy as np
+    import aacgpu_workload
+    import orc
+    o = orc.load()
+    wl = aacgpu_workload.make_batch(n_streams=4, n_frames=FRAMES, mix=mix, seed=0xAAC00002)
+    ov = np.zeros((4, 2, 1024), np.float32)
+    coeffs = wl["q"]
+    if kind == "spec":
+        _, coeffs = o.decode_batch(wl["units"], wl["q"], wl["meta"], wl["n_pcm"], ov, want_spec=True)
+    meta = wl["meta"] if kind == "quant" else None
+    o.decode_batch(wl["units"], coeffs, meta, wl["n_pcm"], ov)          # warm
+    frames, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < budget_s:
+        o.decode_batch(wl["units"], coeffs, meta, wl["n_pcm"], ov)
+        frames += wl["n_frames_total"]
+    dt = time.perf_counter() - t0
+    return {"value": frames / dt, "unit": "stereo frames/s", "cores": 1, "kind": "port",
+            "sample": "%d stereo frames (4 streams x 16-frame batches, same generator as the GPU workload) in %.1f s "
+                      "on 1 of %d host cores; oracle/aac_oracle.c, gcc -O2 -ffp-contract=off" % (frames, dt, os.cpu_count())}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=40)
+    ap.add_argument("--input", choices=["quant", "spec"], default="quant")
+    ap.add_argument("--workload", choices=["cfg2", "cfg3"], default="cfg2")
+    ap.add_argument("--nbuf", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import aacgpu
+    import aacgpu_workload
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node N" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    mix = args.workload == "cfg3"
+    kind = aacgpu.INPUT_QUANT_I16 if args.input == "quant" else aacgpu.INPUT_SPEC_F32
+    eng = aacgpu.Engine(kind, max_streams=STREAMS, max_channels=2, device=local)
+
+    # rank r owns streams [256 r, 256 r + 256): independent data per rank, same shape
+    base = aacgpu_workload.make_batch(n_streams=STREAMS, n_frames=FRAMES, mix=mix, seed=0xAAC00002 + 1000 * rank)
+    units = base["units"]
+    plan = eng.plan(units)
+    d_meta = torch.from_numpy(base["meta"].view(np.int16)).cuda() if args.input == "quant" else None
+    bufs = []
+    rng = np.random.default_rng(rank)
+    for b in range(args.nbuf):
+        q = base["q"] if b == 0 else np.roll(base["q"], 131 * b, axis=0) * rng.choice([-1, 1]).astype(np.int16)
+        if args.input == "quant":
+            d_in = torch.from_numpy(np.ascontiguousarray(q)).cuda()
+        else:
+            # filterbank seam: f32 spectra of matching magnitude (IQ * scalefactor of the same data)
+            x = np.sign(q) * np.abs(q.astype(np.float32)) ** (4.0 / 3.0) * 2.0 ** -15
+            d_in = torch.from_numpy(x.astype(np.float32)).cuda()
+        d_out = torch.empty(base["n_pcm"], dtype=torch.float32, device="cuda")
+        bufs.append((d_in, d_out))
+    stream = torch.cuda.current_stream().cuda_stream
+    meta_ptr = d_meta.data_ptr() if d_meta is not None else None
+
+    def step(i):
+        d_in, d_out = bufs[i % args.nbuf]
+        eng.decode_device(plan, d_in.data_ptr(), meta_ptr, d_out.data_ptr(), stream)
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    ev1.record()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = ev0.elapsed_time(ev1) / args.steps          # HIP events on the launch stream
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # sanity: the last output is finite and non-trivial (never part of the timed region)
+    out = bufs[(args.warmup + args.steps - 1) % args.nbuf][1]
+    ok = bool(torch.isfinite(out).all().item()) and float(out.abs().max().item()) > 0
+
+    frames_per_step = STREAMS * FRAMES
+    value = world * frames_per_step * args.steps / elapsed
+    abytes = algorithmic_bytes_per_stereo_frame(args.input) * frames_per_step
+    achieved = abytes / (kernel_ms * 1e-3) / 1e9
+    line = {
+        "metric": "AAC-LC 48 kHz stereo frames/sec per node + achieved HBM GB/s vs roofline",
+        "value": value, "unit": "stereo frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE config 2: batch of 4096 stereo LC frames (256 streams x 16 frames, ONLY_LONG_SEQUENCE, KBD)"
+                   if not mix else "BASELINE config 3: 4096 stereo frames, window-sequence mix [0,0,1,2,2,3,0,0], TNS identity",
+                   "input": "int16 quantised spectra + band side info (process(elements) seam)" if args.input == "quant"
+                   else "f32 spectra (FilterBank.process seam)",
+                   "streams_per_gpu": STREAMS, "frames_per_stream_per_step": FRAMES, "buffers_rotated": args.nbuf,
+                   "realtime_multiple": value / 46.875, "sharding": "streams over ranks, no data-path collective"},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "kernel": eng.kernel_name() if args.input == "quant" else "aacg_imdct_run_f32",
+                     "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": abytes},
+        "output_ok": ok,
+    }
+    if rank == 0 and not args.no_cpu_baseline and world == 1:
+        line["cpu_baseline"] = cpu_baseline(args.input, mix)
+    elif rank == 0:
+        line["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    plan.destroy()
+    eng.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

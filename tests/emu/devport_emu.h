@@ -1,0 +1,65 @@
+/*
+ * devport_emu.h — CPU stand-in for aac.js_amd/csrc/devport.h.  TEST INFRASTRUCTURE ONLY.
+ *
+ * Runs the very same kernel source (aacg_kernels.h) with one OS thread per lane:
+ * 64 threads form a wavefront, (W+1)*64 a workgroup; dp_wave_sync / dp_shfl / dp_block_sync
+ * are pthread barriers.  Lanes only interact at those points in the real kernel too, so an
+ * indexing, twiddle, windowing or hand-off mistake shows up here — in a container without a
+ * GPU (LDS is poisoned with NaN bits before every workgroup, so a read of a slot nobody wrote
+ * is visible too).  What it cannot show: compiler/hardware issues (the -m gpu tests do).
+ * Never compiled into the product library; selected by -DAACG_EMU_BUILD in tests/emu/Makefile.
+ */
+#ifndef AACG_DEVPORT_EMU_H
+#define AACG_DEVPORT_EMU_H
+
+#include <math.h>
+#include <pthread.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#define DP_DEVICE static inline
+#define DP_KERNEL(a, b)
+
+struct alignas(8)  dpf2 { float x, y; };
+struct alignas(16) dpf4 { float x, y, z, w; };
+
+struct emu_wave {
+    pthread_barrier_t bar;
+    float shfl[64][16];
+};
+struct emu_block {
+    pthread_barrier_t bar;
+    unsigned char* lds;
+    int block_id;
+};
+struct emu_lane_ctx {
+    int lane, wave;
+    emu_wave* w;
+    emu_block* b;
+};
+extern thread_local emu_lane_ctx g_emu;
+
+DP_DEVICE int dp_lane()  { return g_emu.lane; }
+DP_DEVICE int dp_wave()  { return g_emu.wave; }
+DP_DEVICE int dp_block() { return g_emu.b->block_id; }
+DP_DEVICE int dp_uniform(int v) { return v; }
+DP_DEVICE void dp_wave_sync()  { pthread_barrier_wait(&g_emu.w->bar); }
+DP_DEVICE void dp_block_sync() { pthread_barrier_wait(&g_emu.b->bar); }
+
+template <int N>
+DP_DEVICE void dp_shfl(float (&v)[N], int src)
+{
+    static_assert(N <= 16, "shuffle payload");
+    for (int i = 0; i < N; i++) g_emu.w->shfl[g_emu.lane][i] = v[i];
+    pthread_barrier_wait(&g_emu.w->bar);
+    for (int i = 0; i < N; i++) v[i] = g_emu.w->shfl[src][i];
+    pthread_barrier_wait(&g_emu.w->bar);
+}
+
+DP_DEVICE unsigned char* dp_lds() { return g_emu.b->lds; }
+DP_DEVICE float dp_fma(float a, float b, float c) { return fmaf(a, b, c); }
+DP_DEVICE float dp_nan() { return NAN; }
+DP_DEVICE int dp_opaque(int v) { return v; }
+DP_DEVICE void dp_sched_fence() {}
+
+#endif

@@ -1,0 +1,137 @@
+/*
+ * emu_lib.cpp — lane-lockstep CPU execution of the HIP kernels' source, for tests only.
+ * Exposes: table build, the real host planner, and "launch" of the run / spectral kernels.
+ */
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../aac.js_amd/csrc/aacg_kernels.h"
+#include "../../aac.js_amd/csrc/aacg_host.h"
+
+thread_local emu_lane_ctx g_emu;
+
+namespace {
+
+struct launch_arg {
+    emu_lane_ctx ctx;
+    const aacg_kparams* P;
+    int kind;     /* 0 f32 run, 1 quant run, 2 spectral */
+};
+
+void* lane_main(void* p)
+{
+    launch_arg* a = (launch_arg*)p;
+    g_emu = a->ctx;
+    if (a->kind == 0)      imdct_run_body<AACG_INPUT_SPEC_F32>(*a->P);
+    else if (a->kind == 1) imdct_run_body<AACG_INPUT_QUANT_I16>(*a->P);
+    else                   spectral_body(*a->P);
+    return nullptr;
+}
+
+void launch(const aacg_kparams& P, int kind, int grid, int waves, size_t lds_bytes)
+{
+    const int threads = waves * 64;
+    std::vector<emu_wave> wv((size_t)waves);
+    std::vector<launch_arg> args((size_t)threads);
+    std::vector<pthread_t> tid((size_t)threads);
+    unsigned char* lds = (unsigned char*)aligned_alloc(64, lds_bytes);
+    pthread_attr_t attr;
+    pthread_attr_init(&attr);
+    pthread_attr_setstacksize(&attr, 256 * 1024);
+    for (int b = 0; b < grid; b++) {
+        emu_block blk;
+        blk.lds = lds;
+        blk.block_id = b;
+        std::memset(lds, 0xff, lds_bytes);             /* NaN pattern: reads of unwritten LDS show up */
+        pthread_barrier_init(&blk.bar, nullptr, (unsigned)threads);
+        for (int w = 0; w < waves; w++) pthread_barrier_init(&wv[(size_t)w].bar, nullptr, 64);
+        for (int t = 0; t < threads; t++) {
+            args[(size_t)t].ctx = emu_lane_ctx{t & 63, t >> 6, &wv[(size_t)(t >> 6)], &blk};
+            args[(size_t)t].P = &P;
+            args[(size_t)t].kind = kind;
+            pthread_create(&tid[(size_t)t], &attr, lane_main, &args[(size_t)t]);
+        }
+        for (int t = 0; t < threads; t++) pthread_join(tid[(size_t)t], nullptr);
+        for (int w = 0; w < waves; w++) pthread_barrier_destroy(&wv[(size_t)w].bar);
+        pthread_barrier_destroy(&blk.bar);
+    }
+    pthread_attr_destroy(&attr);
+    free(lds);
+}
+
+aacg_tables g_tab;
+int g_tab_index = -1;
+std::string g_err;
+
+}  // namespace
+
+extern "C" {
+
+const char* emu_last_error() { return g_err.c_str(); }
+
+int emu_get_windows(int sample_index, float* dst /* 1024+1024+128+128 */)
+{
+    aacg_tables t; aacg_host_windows w;
+    int rc = aacg_build_tables(sample_index, &t, &w);
+    if (rc) return rc;
+    std::memcpy(dst, w.sine_long, 4096); std::memcpy(dst + 1024, w.kbd_long, 4096);
+    std::memcpy(dst + 2048, w.sine_short, 512); std::memcpy(dst + 2176, w.kbd_short, 512);
+    return 0;
+}
+
+int emu_get_iq_sf(float* iq /* 8192 */, float* sf /* 428 */)
+{
+    aacg_tables t;
+    int rc = aacg_build_tables(3, &t, nullptr);
+    if (rc) return rc;
+    std::memcpy(iq, t.iq, sizeof t.iq); std::memcpy(sf, t.sf, 428 * 4);
+    return 0;
+}
+
+/* plan only: returns number of runs (or <0); fills counts for inspection */
+int emu_plan(const aacg_unit_desc* units, uint32_t n_units, int sample_index, int max_streams, int max_channels,
+             const uint8_t* parity, aacg_run* runs_out, uint32_t runs_cap, int32_t* info /* zero_fill, n_chains, coef_blocks, meta_blocks */)
+{
+    aacg_plan_host ph;
+    int rc = aacg_plan_build(units, n_units, sample_index, max_streams, max_channels, parity, &ph, &g_err);
+    if (rc) return rc;
+    if (runs_out) for (size_t i = 0; i < ph.runs.size() && i < runs_cap; i++) runs_out[i] = ph.runs[i];
+    if (info) { info[0] = ph.zero_fill; info[1] = (int32_t)ph.chains.size(); info[2] = (int32_t)ph.coef_blocks; info[3] = (int32_t)ph.meta_blocks; }
+    return (int)ph.runs.size();
+}
+
+/* full path: plan + "launch".  overlap_pool: [max_streams][max_channels][2][1024]; parity: [max_streams*max_channels], updated. */
+int emu_decode(int input_kind, int sample_index, int max_streams, int max_channels,
+               const aacg_unit_desc* units, uint32_t n_units, const void* coeffs, const aacg_band_meta* meta,
+               float* pcm, size_t n_pcm_floats, float* overlap_pool, uint8_t* parity)
+{
+    if (g_tab_index != sample_index) { int rc = aacg_build_tables(sample_index, &g_tab, nullptr); if (rc) return rc; g_tab_index = sample_index; }
+    aacg_plan_host ph;
+    int rc = aacg_plan_build(units, n_units, sample_index, max_streams, max_channels, parity, &ph, &g_err);
+    if (rc) return rc;
+    if (ph.pcm_floats > n_pcm_floats) { g_err = "pcm buffer too small"; return AACG_ERR_CAPACITY; }
+    if (ph.zero_fill) std::memset(pcm, 0, n_pcm_floats * sizeof(float));
+    aacg_kparams P;
+    std::memset(&P, 0, sizeof P);
+    P.units = units; P.runs = ph.runs.data(); P.coeffs = coeffs; P.meta = meta; P.pcm = pcm;
+    P.overlap = overlap_pool; P.tab = &g_tab; P.flip = 0; P.n_runs = (int32_t)ph.runs.size();
+    launch(P, input_kind == AACG_INPUT_QUANT_I16 ? 1 : 0, (int)ph.runs.size(), AACG_WG_WAVES, AACG_WG_LDS_BYTES);
+    for (auto& c : ph.chains)
+        for (int k = 0; k < c.n_ch; k++) parity[(size_t)c.stream * (size_t)max_channels + c.channel + k] ^= 1;
+    return AACG_OK;
+}
+
+int emu_spectral(int sample_index, const aacg_unit_desc* units, uint32_t n_units,
+                 const void* coeffs, const aacg_band_meta* meta, float* spec_out)
+{
+    if (g_tab_index != sample_index) { int rc = aacg_build_tables(sample_index, &g_tab, nullptr); if (rc) return rc; g_tab_index = sample_index; }
+    aacg_kparams P;
+    std::memset(&P, 0, sizeof P);
+    P.units = units; P.coeffs = coeffs; P.meta = meta; P.spec_out = spec_out; P.tab = &g_tab;
+    launch(P, 2, (int)n_units, 1, 1024 * 4 + 512);
+    return AACG_OK;
+}
+
+}  // extern "C"

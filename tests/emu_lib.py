@@ -1,0 +1,79 @@
+"""ctypes wrapper for tests/emu/libaacg_emu.so — the kernels' source run lane-by-lane on CPU threads
+(test infrastructure; see tests/emu/devport_emu.h)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+import orc
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+RUN_DTYPE = np.dtype([("pred_unit", "<i4"), ("n_units", "<i4"), ("unit", "<i4", (8,)),
+                      ("ov_a", "<i4", (2,)), ("ov_b", "<i4", (2,)), ("is_last", "<i4"), ("reserved", "<i4")])
+
+
+class Emu:
+    def __init__(self, target="libaacg_emu.so"):
+        subprocess.run(["make", "-C", os.path.join(HERE, "emu"), target], check=True, stdout=subprocess.DEVNULL)
+        self.lib = L = C.CDLL(os.path.join(HERE, "emu", target))
+        L.emu_last_error.restype = C.c_char_p
+        L.emu_decode.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,
+                                 C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+        L.emu_spectral.argtypes = [C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.emu_plan.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+        L.emu_get_windows.argtypes = [C.c_int, C.c_void_p]
+        L.emu_get_iq_sf.argtypes = [C.c_void_p, C.c_void_p]
+
+    def error(self):
+        return self.lib.emu_last_error().decode()
+
+    def decode(self, units, coeffs, meta, n_pcm, pool, parity, sample_index=3):
+        units = np.ascontiguousarray(units)
+        coeffs = np.ascontiguousarray(coeffs)
+        kind = 1 if coeffs.dtype == np.int16 else 0
+        meta = np.ascontiguousarray(meta, np.uint16) if meta is not None else None
+        pcm = np.full(n_pcm, np.nan, np.float32)
+        rc = self.lib.emu_decode(kind, sample_index, pool.shape[0], pool.shape[1], units.ctypes.data, len(units),
+                                 coeffs.ctypes.data, meta.ctypes.data if meta is not None else None,
+                                 pcm.ctypes.data, n_pcm, pool.ctypes.data, parity.ctypes.data)
+        if rc:
+            raise RuntimeError("emu_decode rc=%d: %s" % (rc, self.error()))
+        return pcm
+
+    def spectral(self, units, q, meta, sample_index=3):
+        units = np.ascontiguousarray(units)
+        q = np.ascontiguousarray(q, np.int16)
+        meta = np.ascontiguousarray(meta, np.uint16)
+        spec = np.zeros(q.shape, np.float32)
+        rc = self.lib.emu_spectral(sample_index, units.ctypes.data, len(units), q.ctypes.data, meta.ctypes.data, spec.ctypes.data)
+        assert rc == 0
+        return spec
+
+    def plan(self, units, max_streams, max_channels, parity=None, sample_index=3):
+        units = np.ascontiguousarray(units)
+        runs = np.zeros(len(units) + 8, RUN_DTYPE)
+        info = np.zeros(4, np.int32)
+        n = self.lib.emu_plan(units.ctypes.data, len(units), sample_index, max_streams, max_channels,
+                              parity.ctypes.data if parity is not None else None, runs.ctypes.data, len(runs), info.ctypes.data)
+        return n, runs[:max(n, 0)], info
+
+    def windows(self, sample_index=3):
+        a = np.zeros(2304, np.float32)
+        assert self.lib.emu_get_windows(sample_index, a.ctypes.data) == 0
+        return a[:1024], a[1024:2048], a[2048:2176], a[2176:]
+
+    def iq_sf(self):
+        iq = np.zeros(8192, np.float32); sf = np.zeros(428, np.float32)
+        assert self.lib.emu_get_iq_sf(iq.ctypes.data, sf.ctypes.data) == 0
+        return iq, sf
+
+
+def pool_current(pool, parity):
+    """[S][C][1024] view of the live overlap buffers."""
+    S, Cn = pool.shape[:2]
+    out = np.empty((S, Cn, 1024), np.float32)
+    for s in range(S):
+        for c in range(Cn):
+            out[s, c] = pool[s, c, parity[s * Cn + c]]
+    return out

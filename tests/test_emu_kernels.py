@@ -1,0 +1,171 @@
+"""The kernels' source (aac.js_amd/csrc/aacg_kernels.h) executed lane-by-lane on CPU threads
+(tests/emu) against the reference's golden vectors and the oracle.  This is the CPU-side check of
+the wavefront choreography — lane maps, radix-8 stages, LDS transposes, mirror shuffles, window/OLA,
+run hand-off, planner — since the build container has no GPU.  The same comparisons run against
+the real HIP build in test_gpu_parity.py.
+"""
+import numpy as np
+import pytest
+
+import emu_lib
+import orc
+
+RMS_TOL = 1e-5          # internal gate; BASELINE.json's bound is 1e-4 RMS on [-1,1) PCM
+
+
+@pytest.fixture(scope="module")
+def emu():
+    return emu_lib.Emu()
+
+
+def rms(a, b):
+    d = np.asarray(a, np.float64).ravel() - np.asarray(b, np.float64).ravel()
+    return float(np.sqrt(np.mean(d * d)))
+
+
+def test_tables_match_reference(emu, golden):
+    sl, kl, ss, ks = emu.windows()
+    for got, name in ((sl, "tables.sine_long"), (kl, "tables.kbd_long"), (ss, "tables.sine_short"), (ks, "tables.kbd_short")):
+        assert np.array_equal(got.view(np.uint32), golden[name].view(np.uint32)), name
+    iq, sf = emu.iq_sf()
+    assert np.array_equal(iq[:8191].view(np.uint32), golden["tables.iq"].view(np.uint32))
+    assert np.isnan(iq[8191])
+    assert np.array_equal(sf.view(np.uint32), golden["tables.sf"].view(np.uint32))
+
+
+SCENARIOS = ["scn_stereo", "scn_split", "scn_7ch", "scn_mono"]
+
+
+@pytest.mark.parametrize("name", SCENARIOS)
+@pytest.mark.parametrize("inp", ["q", "spec"])
+def test_scenarios_vs_reference(emu, golden, name, inp):
+    units = golden[name + ".units"].view(orc.UNIT_DTYPE).ravel()
+    ref = golden[name + ".pcm"]
+    C = ref.shape[2]
+    pool = np.zeros((1, C, 2, 1024), np.float32)
+    par = np.zeros(C, np.uint8)
+    pcm = emu.decode(units, golden[name + "." + inp], golden[name + ".meta"] if inp == "q" else None, ref.size, pool, par)
+    assert not np.isnan(pcm).any()
+    assert rms(pcm, ref) < RMS_TOL
+    ov = emu_lib.pool_current(pool, par)[0]
+    scale = max(1.0, float(np.abs(golden[name + ".overlap"]).max()))
+    assert np.abs(ov - golden[name + ".overlap"]).max() / scale < 1e-5
+
+
+@pytest.mark.parametrize("name", SCENARIOS)
+def test_spectral_stage_bit_exact(emu, golden, name):
+    """dequant + MS + IS are integer lookups and single fp32 operations: bit-exact (SURVEY §8a rows 3,6,7)."""
+    units = golden[name + ".units"].view(orc.UNIT_DTYPE).ravel()
+    spec = emu.spectral(units, golden[name + ".q"], golden[name + ".meta"])
+    assert np.array_equal(spec.view(np.uint32), golden[name + ".spec"].view(np.uint32))
+
+
+def test_cfg1(emu, golden):
+    units = np.zeros(1, orc.UNIT_DTYPE)
+    units["n_out_ch"] = 1
+    units["n_ch"] = 1
+    units["ch"]["max_sfb"][0, 0] = 49
+    units["ch"]["group_count"][0, 0] = 1
+    units["ch"]["group_len"][0, 0, 0] = 1
+    pool = np.zeros((1, 1, 2, 1024), np.float32)
+    par = np.zeros(1, np.uint8)
+    pcm = emu.decode(units, golden["cfg1.spec"], None, 1024, pool, par)
+    assert rms(pcm, golden["cfg1.pcm"]) < RMS_TOL
+
+
+def test_batches_chain_like_one_long_batch(emu, golden, oracle):
+    """Splitting a stream into consecutive batches (state through the double-buffered overlap pool)
+    gives the same PCM as one batch; runs longer than AACG_RUN_FRAMES recompute their predecessor."""
+    name = "scn_stereo"
+    units = golden[name + ".units"].view(orc.UNIT_DTYPE).ravel().copy()
+    ref = golden[name + ".pcm"]
+    pool = np.zeros((1, 2, 2, 1024), np.float32)
+    par = np.zeros(2, np.uint8)
+    got = np.empty(ref.size, np.float32)
+    for lo, hi in ((0, 5), (5, 6), (6, 18)):                    # 5 + 1 + 12 frames (12 > 8: two runs)
+        u = units[lo:hi].copy()
+        base = int(u["pcm_offset"][0])
+        u["pcm_offset"] -= base
+        cb = int(u["coef_offset"][0])
+        u["coef_offset"] -= cb
+        u["meta_offset"] -= cb
+        pcm = emu.decode(u, golden[name + ".q"][cb:cb + 2 * (hi - lo)], golden[name + ".meta"][cb:cb + 2 * (hi - lo)],
+                         (hi - lo) * 2048, pool, par)
+        got[base:base + pcm.size] = pcm
+    assert rms(got, ref) < RMS_TOL
+
+
+def _workload(**kw):
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "aac.js_amd", "python"))
+    import aacgpu_workload
+    return aacgpu_workload.make_batch(**kw)
+
+
+@pytest.mark.parametrize("mix,layout,intensity", [(False, ("cpe",), False), (True, ("cpe",), True),
+                                                  (True, ("cpe", "cpe", "cpe", "sce"), False), (True, ("sce",), False)])
+def test_synthetic_multistream_vs_oracle(emu, oracle, mix, layout, intensity):
+    """BASELINE configs 2/3/5 at reduced size: several streams x 11 frames (two runs per chain)."""
+    S, T = 3, 11
+    wl = _workload(n_streams=S, n_frames=T, layout=layout, mix=mix, intensity=intensity, seed=1234)
+    C = wl["C"]
+    ov = np.zeros((S, C, 1024), np.float32)
+    ref, spec_ref = oracle.decode_batch(wl["units"], wl["q"], wl["meta"], wl["n_pcm"], ov, want_spec=True)
+    pool = np.zeros((S, C, 2, 1024), np.float32)
+    par = np.zeros(S * C, np.uint8)
+    pcm = emu.decode(wl["units"], wl["q"], wl["meta"], wl["n_pcm"], pool, par)
+    assert rms(pcm, ref) < RMS_TOL
+    assert np.abs(emu_lib.pool_current(pool, par) - ov).max() < 1e-5 * max(1.0, np.abs(ov).max())
+    spec = emu.spectral(wl["units"], wl["q"], wl["meta"])
+    assert np.array_equal(spec.view(np.uint32), spec_ref.view(np.uint32))
+    # filterbank seam on the same data
+    pool[:] = 0
+    par[:] = 0
+    pcm2 = emu.decode(wl["units"], spec_ref, None, wl["n_pcm"], pool, par)
+    assert rms(pcm2, ref) < RMS_TOL
+
+
+def test_planner_runs(emu):
+    wl = _workload(n_streams=5, n_frames=19)
+    n, runs, info = emu.plan(wl["units"], 5, 2)
+    assert n == 5 * 3 and info[1] == 5 and info[0] == 0       # 19 frames = 8 + 8 + 3 per chain
+    seen = np.zeros(len(wl["units"]), int)
+    for r in runs:
+        ids = r["unit"][:r["n_units"]]
+        assert (np.diff(ids) == 1).all()                       # consecutive frames of one stream
+        seen[ids] += 1
+        first = ids[0] % 19 == 0
+        assert (r["pred_unit"] == -1) == first and (first or r["pred_unit"] == ids[0] - 1)
+        assert r["is_last"] == (ids[-1] % 19 == 18)
+    assert (seen == 1).all()
+    # consecutive runs of one chain sit 8 blocks apart (same XCD under the observed b % 8 dispatch)
+    pos = {int(r["unit"][0]): i for i, r in enumerate(runs)}
+    assert sum((pos[s * 19 + 8] - pos[s * 19]) % 8 == 0 for s in range(5)) >= 3
+
+
+def test_planner_rejects_bad_input(emu):
+    wl = _workload(n_streams=1, n_frames=3)
+    u = wl["units"].copy()
+    u["ch"]["window_sequence"][1, 0] = 2                       # short with long grouping
+    assert emu.plan(u, 1, 2)[0] == -1
+    u = wl["units"].copy()
+    u["n_ch"][2] = 1                                           # layout change mid-batch
+    assert emu.plan(u, 1, 2)[0] == -6
+    u = wl["units"].copy()
+    u["stream"][0] = 7
+    assert emu.plan(u, 1, 2)[0] == -4
+    u = wl["units"].copy()
+    u["ch"]["max_sfb"][0, 1] = 50
+    assert emu.plan(u, 1, 2)[0] == -1
+
+
+def test_uncovered_channels_are_zero(emu):
+    """decoder.js:229-231: channels no element writes stay zero."""
+    wl = _workload(n_streams=1, n_frames=2, layout=("sce",))
+    u = wl["units"].copy()
+    u["n_out_ch"] = 2
+    u["pcm_offset"] = np.arange(2) * 2048
+    pool = np.zeros((1, 2, 2, 1024), np.float32)
+    par = np.zeros(2, np.uint8)
+    pcm = emu.decode(u, wl["q"], wl["meta"], 4096, pool, par).reshape(2, 1024, 2)
+    assert (pcm[:, :, 1] == 0).all() and np.abs(pcm[:, :, 0]).max() > 0

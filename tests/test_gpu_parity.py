@@ -1,0 +1,241 @@
+"""Parity tests proper: the HIP path, called through the C ABI, against (a) the golden vectors the
+REFERENCE produced and (b) the oracle on seeded synthetic batches.  All need a real MI355X.
+
+Tolerances: spectral stage (dequant, MS, IS) bit-exact; PCM RMS error <= 1e-5 on the [-1,1) scale
+(BASELINE.json allows 1e-4); overlap state within 1e-5 relative to its peak.
+"""
+import numpy as np
+import pytest
+
+import aacgpu
+import aacgpu_workload
+import orc
+
+pytestmark = pytest.mark.gpu
+RMS_TOL = 1e-5
+
+
+def rms(a, b):
+    d = np.asarray(a, np.float64).ravel() - np.asarray(b, np.float64).ravel()
+    return float(np.sqrt(np.mean(d * d)))
+
+
+def overlaps(eng, S, C):
+    return np.stack([[eng.get_overlap(s, c) for c in range(C)] for s in range(S)])
+
+
+SCENARIOS = ["scn_stereo", "scn_split", "scn_7ch", "scn_mono"]
+
+
+def test_native_library_is_loaded(engine_lib):
+    assert engine_lib.aacg_kernel_name().decode() == "aacg_imdct_run_quant"
+    maps = open("/proc/self/maps").read()
+    assert "libaacgpu.so" in maps
+
+
+def test_tables_match_reference(golden):
+    eng = aacgpu.Engine(aacgpu.INPUT_SPEC_F32, 1, 1)
+    for which, name in ((0, "tables.iq"), (1, "tables.sf"), (2, "tables.sine_long"), (3, "tables.kbd_long"),
+                        (4, "tables.sine_short"), (5, "tables.kbd_short")):
+        assert np.array_equal(eng.table(which).view(np.uint32), golden[name].view(np.uint32)), name
+    eng.close()
+
+
+@pytest.mark.parametrize("name", SCENARIOS)
+@pytest.mark.parametrize("inp", ["q", "spec"])
+def test_scenarios_vs_reference(golden, name, inp):
+    """Multi-frame scenarios the reference decoded through its own readChunk(): all window sequences and
+    transitions, both shapes, MS, IS, zero bands, grouped shorts, split windows, 7 channels, mono."""
+    units = golden[name + ".units"].view(aacgpu.UNIT_DTYPE).ravel()
+    ref = golden[name + ".pcm"]
+    C = ref.shape[2]
+    kind = aacgpu.INPUT_QUANT_I16 if inp == "q" else aacgpu.INPUT_SPEC_F32
+    eng = aacgpu.Engine(kind, max_streams=1, max_channels=C)
+    pcm = eng.decode_batch(units, golden[name + "." + inp], golden[name + ".meta"] if inp == "q" else None, ref.size)
+    assert not np.isnan(pcm).any()
+    assert rms(pcm, ref) < RMS_TOL
+    ov = overlaps(eng, 1, C)[0]
+    scale = max(1.0, float(np.abs(golden[name + ".overlap"]).max()))
+    assert np.abs(ov - golden[name + ".overlap"]).max() / scale < 1e-5
+    eng.close()
+
+
+def test_cfg1_mono_long_frame(golden):
+    """BASELINE config 1."""
+    units = np.zeros(1, aacgpu.UNIT_DTYPE)
+    units["n_out_ch"] = 1
+    units["n_ch"] = 1
+    units["ch"]["max_sfb"][0, 0] = 49
+    units["ch"]["group_count"][0, 0] = 1
+    units["ch"]["group_len"][0, 0, 0] = 1
+    eng = aacgpu.Engine(aacgpu.INPUT_SPEC_F32, 1, 1)
+    pcm = eng.decode_batch(units, golden["cfg1.spec"], None, 1024)
+    assert rms(pcm, golden["cfg1.pcm"]) < RMS_TOL
+    assert np.abs(eng.get_overlap(0, 0) - golden["cfg1.overlap"][0]).max() < 1e-4
+    eng.close()
+
+
+def _torch():
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+@pytest.mark.parametrize("name", SCENARIOS)
+def test_spectral_stage_bit_exact(golden, name):
+    torch = _torch()
+    units = golden[name + ".units"].view(aacgpu.UNIT_DTYPE).ravel()
+    C = golden[name + ".pcm"].shape[2]
+    eng = aacgpu.Engine(aacgpu.INPUT_QUANT_I16, 1, C)
+    plan = eng.plan(units)
+    dq = torch.from_numpy(golden[name + ".q"]).cuda()
+    dm = torch.from_numpy(golden[name + ".meta"].view(np.int16)).cuda()
+    ds = torch.zeros(dq.shape, dtype=torch.float32, device="cuda")
+    eng.spectral_device(plan, dq.data_ptr(), dm.data_ptr(), ds.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    spec = ds.cpu().numpy()
+    assert np.array_equal(spec.view(np.uint32), golden[name + ".spec"].view(np.uint32))
+    plan.destroy()
+    eng.close()
+
+
+@pytest.mark.parametrize("mix,layout,intensity", [(False, ("cpe",), False), (True, ("cpe",), True),
+                                                  (True, ("cpe", "cpe", "cpe", "sce"), False), (True, ("sce",), False)])
+def test_synthetic_vs_oracle(oracle, mix, layout, intensity):
+    """BASELINE configs 2/3/5 at a size the oracle finishes in seconds: 16 streams x 24 frames."""
+    S, T = 16, 24
+    wl = aacgpu_workload.make_batch(n_streams=S, n_frames=T, layout=layout, mix=mix, intensity=intensity, seed=4321)
+    C = wl["C"]
+    ov = np.zeros((S, C, 1024), np.float32)
+    ref, spec_ref = oracle.decode_batch(wl["units"], wl["q"], wl["meta"], wl["n_pcm"], ov, want_spec=True)
+    eng = aacgpu.Engine(aacgpu.INPUT_QUANT_I16, S, C)
+    pcm = eng.decode_batch(wl["units"], wl["q"], wl["meta"], wl["n_pcm"])
+    assert rms(pcm, ref) < RMS_TOL
+    assert np.abs(overlaps(eng, S, C) - ov).max() < 1e-5 * max(1.0, float(np.abs(ov).max()))
+    eng.close()
+    eng = aacgpu.Engine(aacgpu.INPUT_SPEC_F32, S, C)
+    pcm = eng.decode_batch(wl["units"], spec_ref, None, wl["n_pcm"])
+    assert rms(pcm, ref) < RMS_TOL
+    eng.close()
+
+
+def test_consecutive_batches_equal_one_batch(oracle):
+    """Stream state lives in the engine: T frames as 3 batches == one batch == the oracle."""
+    S, T = 4, 21
+    wl = aacgpu_workload.make_batch(n_streams=S, n_frames=T, mix=True, seed=77)
+    ov = np.zeros((S, 2, 1024), np.float32)
+    ref = oracle.decode_batch(wl["units"], wl["q"], wl["meta"], wl["n_pcm"], ov).reshape(S, T, 2048)
+    eng = aacgpu.Engine(aacgpu.INPUT_QUANT_I16, S, 2)
+    units = wl["units"].reshape(S, T)
+    got = np.empty((S, T, 2048), np.float32)
+    for lo, hi in ((0, 9), (9, 10), (10, 21)):
+        u = units[:, lo:hi].copy()
+        n = hi - lo
+        u["pcm_offset"] = (np.arange(S)[:, None] * n + np.arange(n)[None, :]) * 2048
+        pcm = eng.decode_batch(u.ravel(), wl["q"], wl["meta"], S * n * 2048)
+        got[:, lo:hi] = pcm.reshape(S, n, 2048)
+    assert rms(got, ref) < RMS_TOL
+    eng.close()
+
+
+def test_plan_reuse_device_path(oracle):
+    """A plan launched repeatedly continues the streams (double-buffered overlap, flip per launch); a second
+    plan on the same streams makes the first one stale."""
+    torch = _torch()
+    S, T = 8, 16
+    eng = aacgpu.Engine(aacgpu.INPUT_QUANT_I16, S, 2)
+    wls = [aacgpu_workload.make_batch(n_streams=S, n_frames=T, mix=True, seed=5, frame_base=T * i) for i in range(3)]
+    plan = eng.plan(wls[0]["units"])                       # same shape for every batch? sequences differ -> per-batch plans
+    ov = np.zeros((S, 2, 1024), np.float32)
+    stream = torch.cuda.current_stream().cuda_stream
+    # identical side info three times (only the coefficients change): one plan, three launches
+    for i in range(3):
+        q = wls[i]["q"]
+        ref = oracle.decode_batch(wls[0]["units"], q, wls[0]["meta"], wls[0]["n_pcm"], ov)
+        dq = torch.from_numpy(q).cuda()
+        dm = torch.from_numpy(wls[0]["meta"].view(np.int16)).cuda()
+        dp = torch.empty(wls[0]["n_pcm"], dtype=torch.float32, device="cuda")
+        eng.decode_device(plan, dq.data_ptr(), dm.data_ptr(), dp.data_ptr(), stream)
+        torch.cuda.synchronize()
+        assert rms(dp.cpu().numpy(), ref) < RMS_TOL, i
+    assert np.abs(overlaps(eng, S, 2) - ov).max() < 1e-5 * max(1.0, float(np.abs(ov).max()))
+    plan2 = eng.plan(wls[0]["units"])
+    dq = torch.from_numpy(wls[0]["q"]).cuda()
+    dm = torch.from_numpy(wls[0]["meta"].view(np.int16)).cuda()
+    dp = torch.empty(wls[0]["n_pcm"], dtype=torch.float32, device="cuda")
+    eng.decode_device(plan2, dq.data_ptr(), dm.data_ptr(), dp.data_ptr(), stream)
+    with pytest.raises(aacgpu.AacgError) as ei:
+        eng.decode_device(plan, dq.data_ptr(), dm.data_ptr(), dp.data_ptr(), stream)
+    assert ei.value.code == -7
+    torch.cuda.synchronize()
+    plan.destroy()
+    plan2.destroy()
+    eng.close()
+
+
+def test_overlap_set_get_reset():
+    eng = aacgpu.Engine(aacgpu.INPUT_SPEC_F32, 2, 2)
+    v = np.arange(1024, dtype=np.float32)
+    eng.set_overlap(1, 1, v)
+    assert np.array_equal(eng.get_overlap(1, 1), v)
+    assert not eng.get_overlap(1, 0).any()
+    # overlap is what the next frame starts from: a zero spectrum frame outputs overlap / 32768 (ONLY_LONG)
+    wl = aacgpu_workload.make_batch(n_streams=2, n_frames=1)
+    pcm = eng.decode_batch(wl["units"], np.zeros((4, 1024), np.float32), None, wl["n_pcm"]).reshape(2, 1024, 2)
+    assert np.allclose(pcm[1, :, 1], v / 32768.0, rtol=0, atol=1e-7)
+    eng.set_overlap(1, 1, v)
+    eng.reset_stream(1)
+    assert not eng.get_overlap(1, 1).any()
+    eng.close()
+
+
+def test_full_size_properties():
+    """BASELINE config 2 at full size (256 streams x 16 frames = 4096 stereo frames), checked through
+    size-independent properties: linearity of the filterbank seam, and TDAC — a frame's first-half
+    output plus the previous tail reconstructs, so decoding frames one batch at a time equals decoding
+    them in one batch bit-for-bit."""
+    S, T = 256, 16
+    wl = aacgpu_workload.make_batch(n_streams=S, n_frames=T, seed=2)
+    rng = np.random.default_rng(0)
+    a = (rng.standard_normal((S * T * 2, 1024)) * 100).astype(np.float32)
+    b = (rng.standard_normal((S * T * 2, 1024)) * 100).astype(np.float32)
+
+    def run(x):
+        eng = aacgpu.Engine(aacgpu.INPUT_SPEC_F32, S, 2)
+        out = eng.decode_batch(wl["units"], x, None, wl["n_pcm"])
+        eng.close()
+        return out
+
+    pa, pb, pab = run(a), run(b), run((a + b).astype(np.float32))
+    assert not np.isnan(pab).any()
+    scale = float(np.sqrt(np.mean(pab.astype(np.float64) ** 2)))
+    assert rms(pa.astype(np.float64) + pb, pab) < 2e-6 * max(scale, 1e-3) + 1e-7
+    # one batch of 16 frames == 16 batches of 1 frame, bit for bit (same kernels, state through HBM)
+    eng = aacgpu.Engine(aacgpu.INPUT_SPEC_F32, S, 2)
+    units = wl["units"].reshape(S, T)
+    got = np.empty((S, T, 2048), np.float32)
+    for t in range(T):
+        u = units[:, t].copy()
+        u["pcm_offset"] = np.arange(S) * 2048
+        got[:, t] = eng.decode_batch(u, a, None, S * 2048).reshape(S, 2048)
+    eng.close()
+    d = np.abs(got.ravel() - pa)
+    assert d.max() <= 1e-6 * max(1.0, float(np.abs(pa).max()))
+
+
+def test_errors():
+    eng = aacgpu.Engine(aacgpu.INPUT_QUANT_I16, 1, 2)
+    wl = aacgpu_workload.make_batch(n_streams=1, n_frames=2)
+    meta = wl["meta"].copy()
+    meta[0, 3] = (13 << 12) | 150                         # NOISE_BT: the reference cannot decode it either
+    with pytest.raises(aacgpu.AacgError) as ei:
+        eng.decode_batch(wl["units"], wl["q"], meta, wl["n_pcm"])
+    assert ei.value.code == -5
+    u = wl["units"].copy()
+    u["stream"] = 3
+    with pytest.raises(aacgpu.AacgError) as ei:
+        eng.decode_batch(u, wl["q"], wl["meta"], wl["n_pcm"])
+    assert ei.value.code == -4
+    with pytest.raises(aacgpu.AacgError):
+        eng.decode_batch(wl["units"], wl["q"], wl["meta"], 100)          # pcm buffer too small
+    eng.close()
