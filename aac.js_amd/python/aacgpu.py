@@ -46,6 +46,26 @@ class AacgError(RuntimeError):
 _lib = None
 
 
+def _share_hip_runtime_with_torch():
+    """PyTorch wheels bundle their own libamdhip64.so.7.  One process must use ONE HIP runtime, or device
+    pointers from torch are foreign to this library: if torch is installed (bench/tests use it for device
+    memory and streams) map its runtime first, so that libaacgpu.so's NEEDED libamdhip64.so.7 resolves to
+    the same copy whether torch is imported before or after.  Without torch the system ROCm runtime is used."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    spec = importlib.util.find_spec("torch")
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load_library(path=LIB_PATH):
     """dlopen the C-ABI library.  Raises if it has not been built — never falls back."""
     global _lib
@@ -54,6 +74,7 @@ def load_library(path=LIB_PATH):
     if not os.path.exists(path):
         raise RuntimeError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(hipcc --offload-arch=gfx950); there is no CPU fallback" % path)
+    _share_hip_runtime_with_torch()
     L = C.CDLL(path)
     L.aacg_abi_version.restype = C.c_int
     L.aacg_kernel_name.restype = C.c_char_p

@@ -88,10 +88,10 @@ def make_batch(n_streams, n_frames, layout=("cpe",), mix=False, seed=0xAAC00002,
             mag = np.floor(rng.exponential(1.0, (F, 1024)) * lam * 0.5)
             sign = rng.integers(0, 2, (F, 1024)) * 2 - 1
             q[blocks] = np.clip(mag * sign, -8190, 8190).astype(np.int16)
-            # band side info: spectral codebooks 1..11, scalefactor index 140 +- 8, ms_used on even bands (left)
+            # band side info: spectral codebooks 1..11, scalefactor index 248 +- 8, ms_used on even bands (left)
             nb = np.where(is_short, 3 * 14, 49)
             bt = rng.integers(1, 12, (F, 120)).astype(np.uint16)
-            sf = (140 + rng.integers(-8, 9, (F, 120))).astype(np.uint16)
+            sf = (248 + rng.integers(-8, 9, (F, 120))).astype(np.uint16)      # 2^(12 +- 2): PCM near -17 dBFS
             if intensity and c == 1:
                 is_band = rng.random((F, 120)) < 0.15
                 bt = np.where(is_band, rng.integers(14, 16, (F, 120)), bt).astype(np.uint16)

@@ -220,7 +220,7 @@ function randomChannel(rng, seq, shape, opts) {
             for (let i = 0; i < run; i++, k++) {
                 bandTypes[g * maxSFB + k] = bt;
                 // normal bands: offset[0]-100+200 (ics.js:166); intensity: 200-clamp (ics.js:141-145)
-                sfIdx[g * maxSFB + k] = (bt === 14 || bt === 15) ? 160 + rng.below(80) : (bt === 0 ? 0 : 150 + rng.below(70));
+                sfIdx[g * maxSFB + k] = (bt === 14 || bt === 15) ? 188 + rng.below(24) : (bt === 0 ? 0 : 200 + rng.below(30));   // PCM lands near -15 dBFS
             }
         }
     }
@@ -404,14 +404,14 @@ function scenario(name, seed, nFrames, layout, seqPattern, opts) {
     put(name + '.overlap', ov, [C, 1024]);
 }
 
-// F7 / config 1: one mono ONLY_LONG sine frame, spectrum 1000*u*exp(-k/200) (SURVEY.md §8d)
+// F7 / config 1: one mono ONLY_LONG sine frame, spectrum 1200000*u*exp(-k/200) (SURVEY.md §8d)
 {
     const dec = makeDecoder(1);
     const rng = new Rng(0xAAC00001);
     const ics = new ICStream(dec.config);
     ics.info.windowSequence = 0; ics.info.windowShape[1] = 0; ics.info.groupCount = 1; ics.info.groupLength[0] = 1;
     ics.info.maxSFB = 49; ics.info.windowCount = 1; ics.info.swbOffsets = tables.SWB_OFFSET_1024[SAMPLE_INDEX]; ics.info.swbCount = 49;
-    for (let k = 0; k < 1024; k++) ics.data[k] = 1000 * rng.unit() * Math.exp(-k / 200);
+    for (let k = 0; k < 1024; k++) ics.data[k] = 1200000 * rng.unit() * Math.exp(-k / 200);
     const spec = Float32Array.from(ics.data);
     dec.process = function () { return AACDecoder.prototype.process.call(this, [ics]); };
     const pcm = dec.readChunk();
