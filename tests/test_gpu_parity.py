@@ -80,7 +80,8 @@ def test_cfg1_mono_long_frame(golden):
     eng = aacgpu.Engine(aacgpu.INPUT_SPEC_F32, 1, 1)
     pcm = eng.decode_batch(units, golden["cfg1.spec"], None, 1024)
     assert rms(pcm, golden["cfg1.pcm"]) < RMS_TOL
-    assert np.abs(eng.get_overlap(0, 0) - golden["cfg1.overlap"][0]).max() < 1e-4
+    ref_ov = golden["cfg1.overlap"][0]
+    assert np.abs(eng.get_overlap(0, 0) - ref_ov).max() < 1e-5 * float(np.abs(ref_ov).max())
     eng.close()
 
 
