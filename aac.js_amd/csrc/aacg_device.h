@@ -8,47 +8,66 @@
 #include <stdint.h>
 #include "../../include/aacgpu.h"
 
-#define AACG_RUN_W        AACG_RUN_FRAMES          /* frames per run = working waves per workgroup */
-#define AACG_WG_WAVES     (AACG_RUN_W + 1)         /* + wave 0: predecessor tail                    */
+#define AACG_RUN_W        AACG_RUN_FRAMES          /* waves per workgroup = frames per first run of a chain */
+#define AACG_WG_WAVES     AACG_RUN_W
 #define AACG_WG_THREADS   (AACG_WG_WAVES * 64)
-
-/* LDS per wave: tail[0] (1024 f32) + max(tail[1], FFT exchange scratch 576 complex) */
-#define AACG_SCRATCH_C2   576                      /* 8 rows x 72 = 64 lanes x 9 (padded)          */
-#define AACG_SLOT_FLOATS  (1024 + 2 * AACG_SCRATCH_C2)
-#define AACG_SLOT_BYTES   (AACG_SLOT_FLOATS * 4)
-#define AACG_WG_LDS_BYTES (AACG_WG_WAVES * AACG_SLOT_BYTES)
 
 struct aacg_c2 { float re, im; };
 
-/* All constant tables, one device allocation (~61 KiB); most waves touch ~12 KiB of it
- * (ONLY_LONG: sincos_long, tw512, tw64, one head window, one tail window), which stays
- * resident in the 32 KiB vector L1 of each CU. */
+/* ---- constant tables ---------------------------------------------------------------- */
+/* One device allocation; every workgroup copies the part its kernel needs into LDS once
+ * (16-byte loads, L2-resident) and all 16 waves read it from there: the per-wave table
+ * traffic never touches the vector-memory pipeline.  Offsets in floats. */
 struct aacg_tables {
-    /* mdct.js:73-87 twiddles sqrt(2/N) * (cos, sin)(2*pi*(k + 1/8)/N), f32 */
-    aacg_c2 sincos_long[512];
-    aacg_c2 sincos_short[64];
+    /* mdct.js:73-87 rotation sqrt(2/N) * (cos, sin)(2*pi*(k + 1/8)/N), k = l + 64 j stored [j][l] */
+    aacg_c2 sincos_long[8][64];
     /* radix-8 inter-stage twiddles e^{+2*pi*i*l*q/512}, [q-1][l], and e^{+2*pi*i*g*r/64}, [r-1][g] */
     aacg_c2 tw512[7][64];
     aacg_c2 tw64[7][8];
-    /* effective 1024-sample windows of the long sequences (filter_bank.js:105-141,180-202), natural order:
-     * head_win[(stop ? 2 : 0) + shape_prev][n]  multiplies IMDCT output n       (first half)
-     * tail_win[(start ? 2 : 0) + shape][n]      multiplies IMDCT output 1024+n  (second half) */
-    float head_win[4][1024];
-    float tail_win[4][1024];
-    float short_win[2][128];          /* SINE_128, KBD_128 (filter_bank.js:82,84) */
-    float iq[8192];                   /* IQ_TABLE (tables.js:182-191); [8191] = NaN like the JS out-of-range read */
-    float sf[512];                    /* SCALEFACTOR_TABLE (tables.js:168-176), 428 used */
+    aacg_c2 sincos_short[8][8];       /* N = 256, k = g + 8 j stored [j][g] */
+    float win_long[2][1024];          /* SINE_1024, KBD_1024 (filter_bank.js:81,83) */
+    float win_short[2][128];          /* SINE_128,  KBD_128  (filter_bank.js:82,84) */
+    /* ---- end of the part the f32 kernel stages (AACG_TAB_F32_FLOATS) ---- */
+    float sf[432];                    /* SCALEFACTOR_TABLE (tables.js:168-176), 428 used */
+    float iq_small[512];              /* IQ_TABLE[0..511] (tables.js:182-191): the common magnitudes */
     uint8_t band_of_long[1024];       /* coefficient -> sfb for this sample_index (tables.js:34-155) */
     uint8_t band_of_short[128];
+    /* ---- end of the part the quant kernel stages (AACG_TAB_QUANT_FLOATS) ---- */
+    float iq[8192];                   /* full IQ_TABLE, global; [8191] = NaN like the JS out-of-range read */
 };
 
-/* One workgroup's work: up to AACG_RUN_W consecutive frames of one element of one stream. */
+#define AACG_TAB_OFF_SINCOS_LONG  0
+#define AACG_TAB_OFF_TW512        (AACG_TAB_OFF_SINCOS_LONG + 8 * 64 * 2)
+#define AACG_TAB_OFF_TW64         (AACG_TAB_OFF_TW512 + 7 * 64 * 2)
+#define AACG_TAB_OFF_SINCOS_SHORT (AACG_TAB_OFF_TW64 + 7 * 8 * 2)
+#define AACG_TAB_OFF_WIN_LONG     (AACG_TAB_OFF_SINCOS_SHORT + 8 * 8 * 2)
+#define AACG_TAB_OFF_WIN_SHORT    (AACG_TAB_OFF_WIN_LONG + 2 * 1024)
+#define AACG_TAB_F32_FLOATS       (AACG_TAB_OFF_WIN_SHORT + 2 * 128)
+#define AACG_TAB_OFF_SF           AACG_TAB_F32_FLOATS
+#define AACG_TAB_OFF_IQ_SMALL     (AACG_TAB_OFF_SF + 432)
+#define AACG_TAB_OFF_BAND_LONG    (AACG_TAB_OFF_IQ_SMALL + 512)
+#define AACG_TAB_OFF_BAND_SHORT   (AACG_TAB_OFF_BAND_LONG + 256)
+#define AACG_TAB_QUANT_FLOATS     (AACG_TAB_OFF_BAND_SHORT + 32)
+
+/* ---- LDS map of the run kernel -------------------------------------------------------- */
+/* [tables][slot 0] ... [slot 15]; slot = tail[0] (1024 f32) | tail[1] = work area (1152 f32):
+ * the work area holds, in turn, the staged spectrum (natural order), the FFT transposes
+ * (576 complex, padded) and finally the second channel's tail. */
+#define AACG_WORK_FLOATS  1152
+#define AACG_SLOT_FLOATS  (1024 + AACG_WORK_FLOATS)
+#define AACG_LDS_FLOATS(tab_floats) ((tab_floats) + AACG_WG_WAVES * AACG_SLOT_FLOATS)
+#define AACG_LDS_BYTES_F32    (4 * AACG_LDS_FLOATS(AACG_TAB_F32_FLOATS))
+#define AACG_LDS_BYTES_QUANT  (4 * AACG_LDS_FLOATS(AACG_TAB_QUANT_FLOATS))
+
+/* One workgroup's work: consecutive frames of one element of one stream.  The first run of a
+ * chain holds up to 16 units (wave w = unit w, wave 0 starts from the overlap state); a later
+ * run holds up to 15 units in waves 1..15 and wave 0 recomputes the tail of pred_unit. */
 struct aacg_run {
-    int32_t pred_unit;                /* unit whose tail feeds unit[0]; -1: take it from overlap state */
+    int32_t pred_unit;                /* -1: first run of its chain */
     int32_t n_units;
     int32_t unit[AACG_RUN_W];
-    /* The chain's overlap state is double-buffered (a run that reads it and the run that
-     * writes it are different workgroups of one launch): float offsets of the two buffers
+    /* The chain's overlap state is double-buffered (the run that reads it and the run that
+     * writes it can be different workgroups of one launch): float offsets of the two buffers
      * per channel.  Launch parity `flip` selects in = flip ? b : a, out = flip ? a : b.   */
     int32_t ov_a[2];
     int32_t ov_b[2];
@@ -65,7 +84,7 @@ struct aacg_kparams {
     float*                overlap;    /* overlap pool */
     float*                spec_out;   /* spectral-only kernel */
     const aacg_tables*    tab;
-    int32_t               flip;       /* 0/1: swap ov_in and ov_out (plan reuse, see aacg_engine.hip) */
+    int32_t               flip;       /* 0/1: swap ov_a and ov_b (plan reuse, see aacg_engine.hip) */
     int32_t               n_runs;
 };
 

@@ -17,15 +17,17 @@
 #include "aacg_host.h"
 
 /* ---- kernels ----------------------------------------------------------------------- */
-/* 576 threads = 9 waves; 2 workgroups per CU (LDS 2 x 76.5 KiB) = 18 waves -> <= 96 VGPRs */
-extern "C" __global__ __launch_bounds__(AACG_WG_THREADS, 5)
+/* 1024 threads = 16 waves, one workgroup per CU: 4 waves per SIMD -> 128 VGPRs per lane */
+extern "C" __global__ __launch_bounds__(AACG_WG_THREADS)
 void aacg_imdct_run_quant(const aacg_kparams P) { imdct_run_body<AACG_INPUT_QUANT_I16>(P); }
 
-extern "C" __global__ __launch_bounds__(AACG_WG_THREADS, 5)
+extern "C" __global__ __launch_bounds__(AACG_WG_THREADS)
 void aacg_imdct_run_f32(const aacg_kparams P) { imdct_run_body<AACG_INPUT_SPEC_F32>(P); }
 
-extern "C" __global__ __launch_bounds__(64)
-void aacg_spectral(const aacg_kparams P) { spectral_body(P); }
+extern "C" __global__ __launch_bounds__(AACG_WG_THREADS)
+void aacg_spectral(const aacg_kparams P, int n_units) { spectral_body(P, n_units); }
+
+#define AACG_LDS_BYTES_SPECTRAL ((AACG_TAB_QUANT_FLOATS + AACG_WG_WAVES * 512) * 4)
 
 /* ---- engine ------------------------------------------------------------------------ */
 struct aacg_engine {
@@ -110,9 +112,10 @@ int aacg_create(const aacg_config* cfg, aacg_engine** out)
         !hip_ok(e, hipMalloc((void**)&e->d_overlap, ov_bytes), "hipMalloc overlap") ||
         !hip_ok(e, hipMemcpy(e->d_tab, &e->h_tab, sizeof(aacg_tables), hipMemcpyHostToDevice), "upload tables") ||
         !hip_ok(e, hipMemset(e->d_overlap, 0, ov_bytes), "zero overlap") ||
-        /* 76.5 KiB of dynamic LDS per workgroup is above the 64 KiB default limit */
-        !hip_ok(e, hipFuncSetAttribute((const void*)aacg_imdct_run_quant, hipFuncAttributeMaxDynamicSharedMemorySize, AACG_WG_LDS_BYTES), "LDS attr") ||
-        !hip_ok(e, hipFuncSetAttribute((const void*)aacg_imdct_run_f32, hipFuncAttributeMaxDynamicSharedMemorySize, AACG_WG_LDS_BYTES), "LDS attr")) {
+        /* ~158 KiB of dynamic LDS per workgroup is above the 64 KiB default limit */
+        !hip_ok(e, hipFuncSetAttribute((const void*)aacg_imdct_run_quant, hipFuncAttributeMaxDynamicSharedMemorySize, AACG_LDS_BYTES_QUANT), "LDS attr") ||
+        !hip_ok(e, hipFuncSetAttribute((const void*)aacg_imdct_run_f32, hipFuncAttributeMaxDynamicSharedMemorySize, AACG_LDS_BYTES_F32), "LDS attr") ||
+        !hip_ok(e, hipFuncSetAttribute((const void*)aacg_spectral, hipFuncAttributeMaxDynamicSharedMemorySize, AACG_LDS_BYTES_SPECTRAL), "LDS attr")) {
         std::fprintf(stderr, "aacgpu: %s\n", e->err.c_str());
         aacg_destroy(e);
         return AACG_ERR_NO_DEVICE;
@@ -215,7 +218,7 @@ int aacg_plan_create(aacg_engine* e, const aacg_unit_desc* units, uint32_t n_uni
     if (!hip_ok(e, hipSetDevice(e->cfg.device_ordinal), "hipSetDevice") ||
         !hip_ok(e, hipMalloc((void**)&p->d_units, ub), "hipMalloc units") ||
         !hip_ok(e, hipMalloc((void**)&p->d_runs, rb), "hipMalloc runs") ||
-        !hip_ok(e, hipMemcpy(p->d_units, units, ub, hipMemcpyHostToDevice), "upload units") ||
+        !hip_ok(e, hipMemcpy(p->d_units, p->h.units.data(), ub, hipMemcpyHostToDevice), "upload units") ||
         !hip_ok(e, hipMemcpy(p->d_runs, p->h.runs.data(), rb, hipMemcpyHostToDevice), "upload runs")) {
         aacg_plan_destroy(p);
         return AACG_ERR_OUT_OF_MEMORY;
@@ -262,8 +265,8 @@ int aacg_decode_device(aacg_engine* e, aacg_plan* p, const void* d_coeffs, const
     P.overlap = e->d_overlap; P.spec_out = nullptr; P.tab = e->d_tab;
     P.flip = (int32_t)(p->launches & 1u); P.n_runs = (int32_t)p->h.runs.size();
     const dim3 grid((unsigned)p->h.runs.size()), block(AACG_WG_THREADS);
-    if (quant) hipLaunchKernelGGL(aacg_imdct_run_quant, grid, block, AACG_WG_LDS_BYTES, s, P);
-    else       hipLaunchKernelGGL(aacg_imdct_run_f32, grid, block, AACG_WG_LDS_BYTES, s, P);
+    if (quant) hipLaunchKernelGGL(aacg_imdct_run_quant, grid, block, AACG_LDS_BYTES_QUANT, s, P);
+    else       hipLaunchKernelGGL(aacg_imdct_run_f32, grid, block, AACG_LDS_BYTES_F32, s, P);
     HIP_TRY(e, hipGetLastError(), AACG_ERR_NO_DEVICE);
 
     for (const aacg_chain& c : p->h.chains)
@@ -282,7 +285,8 @@ int aacg_spectral_device(aacg_engine* e, aacg_plan* p, const void* d_coeffs, con
     aacg_kparams P;
     std::memset(&P, 0, sizeof P);
     P.units = p->d_units; P.coeffs = d_coeffs; P.meta = d_meta; P.spec_out = d_spec_out; P.tab = e->d_tab;
-    hipLaunchKernelGGL(aacg_spectral, dim3(p->n_units), dim3(64), 1024 * 4 + 512, s, P);
+    hipLaunchKernelGGL(aacg_spectral, dim3((p->n_units + AACG_WG_WAVES - 1) / AACG_WG_WAVES), dim3(AACG_WG_THREADS),
+                       AACG_LDS_BYTES_SPECTRAL, s, P, (int)p->n_units);
     HIP_TRY(e, hipGetLastError(), AACG_ERR_NO_DEVICE);
     return AACG_OK;
 }

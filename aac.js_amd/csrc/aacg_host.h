@@ -30,6 +30,7 @@ struct aacg_chain {
 };
 
 struct aacg_plan_host {
+    std::vector<aacg_unit_desc> units;  /* device copy: reserved1[c] = group-of-window map of channel c */
     std::vector<aacg_run>   runs;     /* in launch (block) order, XCD-aware */
     std::vector<aacg_chain> chains;
     bool     zero_fill = false;       /* some frame has a channel no unit writes (decoder.js:229-231) */

@@ -5,18 +5,22 @@
  *   wave       = one unit (SCE/LFE/CPE) of one frame: both channels of a CPE live in one
  *                wave, so MS/IS are register-local and stereo PCM leaves as 16-byte
  *                (L,R,L,R) stores, 1 KiB contiguous per wave instruction.
- *   workgroup  = one run: up to AACG_RUN_W consecutive frames of that element + wave 0,
- *                which supplies the tail feeding the first frame (recomputed from the
- *                previous frame's spectrum, or copied from the overlap state in HBM).
- *                Tails travel wave -> wave through LDS; one workgroup barrier per run.
- *   IMDCT      = N/4-point complex inverse FFT between two twiddle passes (the algorithm
- *                class of mdct.js:62-115), here as radix-8 register butterflies with two
- *                LDS transposes (512 = 8x8x8) or one (64 = 8x8 per short window), natural
- *                order in and out, so no bit-reversal pass (fft.js:113-137) exists at all.
+ *   workgroup  = 16 waves = one run: consecutive frames of one element of one stream, one
+ *                workgroup per CU (128 VGPRs per lane, ~158 KiB of LDS).  Tails travel
+ *                wave -> wave through LDS with one workgroup barrier; the first frame of a
+ *                chain starts from the overlap state in HBM, a later run's wave 0 recomputes
+ *                the tail of the frame before it (no inter-workgroup communication).
+ *   tables     = rotation/twiddle/window (and dequant) tables are copied into LDS once per
+ *                workgroup; per-wave table reads never use the vector-memory pipeline.
+ *   HBM        = spectra in with 16-byte loads in natural order, redistributed to the FFT
+ *                lane map through LDS; PCM out with 16-byte stores.
+ *   IMDCT      = N/4-point complex inverse FFT between two rotations (the algorithm class of
+ *                mdct.js:62-115) as radix-8 register butterflies with two LDS transposes
+ *                (512 = 8x8x8) or one (64 = 8x8 per short window); natural order in and out,
+ *                so no bit-reversal pass (fft.js:113-137) exists.
  *
  * Lane maps.  Long: lane l, element j holds index l + 64 j.  Short: lane (w = l>>3, g = l&7),
- * element j holds index g + 8 j of window w.  Both FFTs return to the map they start in,
- * so pre- and post-twiddle use the same sincos registers.
+ * element j holds index g + 8 j of window w.
  */
 #ifndef AACG_KERNELS_H
 #define AACG_KERNELS_H
@@ -29,7 +33,7 @@ struct cpx { float re, im; };
 DP_DEVICE cpx c_add(cpx a, cpx b) { cpx r; r.re = a.re + b.re; r.im = a.im + b.im; return r; }
 DP_DEVICE cpx c_sub(cpx a, cpx b) { cpx r; r.re = a.re - b.re; r.im = a.im - b.im; return r; }
 DP_DEVICE cpx c_muli(cpx a)       { cpx r; r.re = -a.im; r.im = a.re; return r; }            /* i * a */
-DP_DEVICE cpx c_mul(cpx a, aacg_c2 w)
+DP_DEVICE cpx c_mul(cpx a, cpx w)
 {
     cpx r;
     r.re = dp_fma(a.re, w.re, -(a.im * w.im));
@@ -71,89 +75,123 @@ DP_DEVICE cpx lds_get(const float* base, int idx)
     cpx v; v.re = t.x; v.im = t.y; return v;
 }
 
-/* array position of the (even, odd) coefficient pair held by (lane, j) */
-DP_DEVICE int pair_pos(int lane, int j, int cls)
+/* ------------------------------------------------------------------------------------ */
+/* table staging: global (L2) -> LDS, once per workgroup                                   */
+/* ------------------------------------------------------------------------------------ */
+DP_DEVICE void stage_tables(const aacg_tables* T, float* lds, int n_floats)
 {
-    return cls ? (((lane >> 3) << 7) + ((lane & 7) << 1) + (j << 4))      /* short: 128 w + 2 g + 16 j */
-               : ((lane << 1) + (j << 7));                                /* long : 2 l + 128 j        */
+    const dpf4* src = (const dpf4*)T;
+    dpf4* dst = (dpf4*)lds;
+    const int n4 = n_floats >> 2;
+    for (int i = dp_tid(); i < n4; i += AACG_WG_THREADS) dst[i] = src[i];
 }
 
 /* ------------------------------------------------------------------------------------ */
-/* long windows: IMDCT-2048 + window, filter_bank.js:105-141,180-202 / mdct.js:62-115      */
+/* windows of the long sequences, filter_bank.js:105-141,180-202                           */
 /* ------------------------------------------------------------------------------------ */
-/* xe[j] = X[2k], xo[j] = X[2k+1] for k = l + 64 j.  Writes the windowed second half to
- * tail[0..1023] (LDS, natural order) and returns the windowed first half at
- * n = 2 l + 128 m (hx[m]) and n + 1 (hy[m]).                                             */
-DP_DEVICE void long_channel(const aacg_tables* T, int seq, int shape, int shape_prev, bool want_head,
-                            const float (&xe)[8], const float (&xo)[8],
-                            float* scratch, float* tail, float (&hx)[8], float (&hy)[8])
+/* (w[n], w[n+1]) multiplying IMDCT output n, n+1 of the first half (n even). */
+DP_DEVICE dpf2 head_window(const float* tab, int seq, int shape_prev, int n)
+{
+    const float* wl = tab + AACG_TAB_OFF_WIN_LONG + 1024 * shape_prev;
+    if (seq != AACG_LONG_STOP_SEQUENCE) return *(const dpf2*)(wl + n);      /* filter_bank.js:109-111,124-126 */
+    /* LONG_STOP: 0 | previous-shape short window | 1   (filter_bank.js:185-195) */
+    const float* ws = tab + AACG_TAB_OFF_WIN_SHORT + 128 * shape_prev;
+    int i = n - 448; i = i < 0 ? 0 : (i > 126 ? 126 : i);
+    dpf2 v = *(const dpf2*)(ws + i);
+    if (n < 448) { v.x = 0.0f; v.y = 0.0f; }
+    if (n >= 576) { v.x = 1.0f; v.y = 1.0f; }
+    return v;
+}
+/* (w[n], w[n+1]) multiplying IMDCT output 1024 + n, 1024 + n + 1 (n even). */
+DP_DEVICE dpf2 tail_window(const float* tab, int seq, int shape, int n)
+{
+    dpf2 v, r;
+    if (seq != AACG_LONG_START_SEQUENCE) {                                   /* reversed long window, filter_bank.js:114-116 */
+        v = *(const dpf2*)(tab + AACG_TAB_OFF_WIN_LONG + 1024 * shape + 1022 - n);
+        r.x = v.y; r.y = v.x;
+        return r;
+    }
+    /* LONG_START: 1 | reversed short window | 0   (filter_bank.js:129-139) */
+    int i = 574 - n; i = i < 0 ? 0 : (i > 126 ? 126 : i);
+    v = *(const dpf2*)(tab + AACG_TAB_OFF_WIN_SHORT + 128 * shape + i);
+    r.x = v.y; r.y = v.x;
+    if (n < 448) { r.x = 1.0f; r.y = 1.0f; }
+    if (n >= 576) { r.x = 0.0f; r.y = 0.0f; }
+    return r;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* long windows: IMDCT-2048 + window, mdct.js:62-115 + filter_bank.js                      */
+/* ------------------------------------------------------------------------------------ */
+/* work[0..1023] holds the spectrum in natural order on entry and is reused for the FFT
+ * transposes.  Writes the windowed second half to tail[0..1023] (natural order; tail may
+ * alias work) and returns the windowed first half at n = 2 l + 128 m (hx[m]), n + 1 (hy[m]). */
+DP_DEVICE void long_channel(const float* tab, int seq, int shape, int shape_prev, bool want_head,
+                            float* work, float* tail, float (&hx)[8], float (&hy)[8])
 {
     const int l = dp_lane();
+    const float* sincos = tab + AACG_TAB_OFF_SINCOS_LONG;
 
-    /* X[N/2-1-2k] lives in lane 63-l as its odd value of element 7-j (mdct.js:74-75) */
-    float o[8];
-#pragma unroll
-    for (int j = 0; j < 8; j++) o[j] = xo[7 - j];
-    dp_shfl(o, 63 - l);
-
+    /* k = l + 64 j:  X[2k] and X[N/2-1-2k] (mdct.js:74-75) */
     cpx z[8];
 #pragma unroll
     for (int j = 0; j < 8; j++) {
-        const aacg_c2 sc = T->sincos_long[l + 64 * j];
-        z[j].im = dp_fma(xe[j], sc.re, o[j] * sc.im);                /* mdct.js:74 */
-        z[j].re = dp_fma(o[j], sc.re, -(xe[j] * sc.im));             /* mdct.js:75 */
+        const dpf2 a = *(const dpf2*)(work + 2 * l + 128 * j);
+        const dpf2 b = *(const dpf2*)(work + 1022 - 2 * l - 128 * j);
+        const cpx sc = lds_get(sincos, 64 * j + l);
+        z[j].im = dp_fma(a.x, sc.re, b.y * sc.im);                   /* mdct.js:74 */
+        z[j].re = dp_fma(b.y, sc.re, -(a.x * sc.im));                /* mdct.js:75 */
     }
+    dp_wave_sync();
 
     /* 512-point inverse FFT, unscaled (fft.js with forward = false) */
     radix8_inv(z);                                    /* over j (stride 64)       */
 #pragma unroll
-    for (int q = 1; q < 8; q++) z[q] = c_mul(z[q], T->tw512[q - 1][l]);
+    for (int q = 1; q < 8; q++) z[q] = c_mul(z[q], lds_get(tab + AACG_TAB_OFF_TW512, 64 * (q - 1) + l));
 #pragma unroll
-    for (int q = 0; q < 8; q++) lds_put(scratch, q * 72 + l, z[q]);
+    for (int q = 0; q < 8; q++) lds_put(work, q * 72 + l, z[q]);
     dp_wave_sync();
     const int l0 = l & 7, qq = l >> 3;
 #pragma unroll
-    for (int j = 0; j < 8; j++) z[j] = lds_get(scratch, qq * 72 + l0 + 8 * j);
+    for (int j = 0; j < 8; j++) z[j] = lds_get(work, qq * 72 + l0 + 8 * j);
     dp_wave_sync();
     radix8_inv(z);                                    /* over l1 (stride 8)       */
 #pragma unroll
-    for (int r = 1; r < 8; r++) z[r] = c_mul(z[r], T->tw64[r - 1][l0]);
+    for (int r = 1; r < 8; r++) z[r] = c_mul(z[r], lds_get(tab + AACG_TAB_OFF_TW64, 8 * (r - 1) + l0));
 #pragma unroll
-    for (int r = 0; r < 8; r++) lds_put(scratch, (qq + 8 * r) * 9 + l0, z[r]);
+    for (int r = 0; r < 8; r++) lds_put(work, (qq + 8 * r) * 9 + l0, z[r]);
     dp_wave_sync();
 #pragma unroll
-    for (int i = 0; i < 8; i++) z[i] = lds_get(scratch, l * 9 + i);
+    for (int i = 0; i < 8; i++) z[i] = lds_get(work, l * 9 + i);
     dp_wave_sync();
     radix8_inv(z);                                    /* over l0; lane l now holds Z[l + 64 r] */
 
     /* post-IFFT rotation (mdct.js:82-87), then fetch the mirror lane's values for the reorder */
     float m[16];
-    const int lk = dp_opaque(l);                      /* same table entries as the pre-twiddle: re-read, not held */
 #pragma unroll
     for (int r = 0; r < 8; r++) {
-        const aacg_c2 sc = T->sincos_long[lk + 64 * r];
+        const cpx sc = lds_get(sincos, 64 * r + l);
         m[r]     = dp_fma(z[r].re, sc.re, -(z[r].im * sc.im));
         m[8 + r] = dp_fma(z[r].im, sc.re, z[r].re * sc.im);
     }
     float R[8], I[8];
 #pragma unroll
     for (int r = 0; r < 8; r++) { R[r] = m[r]; I[r] = m[8 + r]; }
-    dp_shfl(m, 63 - l);                               /* m[r] = re[511 - k'], m[8+r] = im[..] of the mirror */
+    dp_shfl(m, 63 - l);                               /* m[r] = re, m[8+r] = im of the mirror lane */
 
     /* reorder (mdct.js:90-114) fused with the window (filter_bank.js:109-116 etc.) */
-    const float* hw = T->head_win[(seq == AACG_LONG_STOP_SEQUENCE ? 2 : 0) + shape_prev];
-    const float* tw = T->tail_win[(seq == AACG_LONG_START_SEQUENCE ? 2 : 0) + shape];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const int n = 2 * l + 128 * j;
         if (want_head) {
-            dpf2 w0 = *(const dpf2*)(hw + n), w1 = *(const dpf2*)(hw + n + 512);
+            const dpf2 w0 = head_window(tab, seq, shape_prev, n), w1 = head_window(tab, seq, shape_prev, n + 512);
             hx[j]     = I[j + 4] * w0.x;              /* y[2k]        =  im[N/8 + k]     */
             hy[j]     = -m[3 - j] * w0.y;             /* y[2k+1]      = -re[N/8 - 1 - k] */
             hx[j + 4] = R[j] * w1.x;                  /* y[N/4+2k]    =  re[k]           */
             hy[j + 4] = -m[8 + 7 - j] * w1.y;         /* y[N/4+2k+1]  = -im[N/4 - 1 - k] */
         }
-        dpf2 v0 = *(const dpf2*)(tw + n), v1 = *(const dpf2*)(tw + n + 512), t;
+        const dpf2 v0 = tail_window(tab, seq, shape, n), v1 = tail_window(tab, seq, shape, n + 512);
+        dpf2 t;
         t.x = R[j + 4] * v0.x;                        /* y[N/2+2k]    =  re[N/8 + k]     */
         t.y = -m[8 + 3 - j] * v0.y;                   /* y[N/2+2k+1]  = -im[N/8 - 1 - k] */
         *(dpf2*)(tail + n) = t;
@@ -170,43 +208,39 @@ DP_DEVICE void long_channel(const aacg_tables* T, int seq, int shape, int shape_
  * blocks placed at frame position 448 + p:   out[448+p] = ov[448+p] + s[p]  (p < 576),
  * new overlap[p-576] = s[p] (p >= 576), new overlap[576..1023] = 0.  Returns s at
  * p = 128 w + 2 g + 16 m (hx[m]) and p + 1 (hy[m]); only p < 576 is meaningful there.   */
-DP_DEVICE void short_channel(const aacg_tables* T, int shape, int shape_prev, bool want_head,
-                             const float (&xe)[8], const float (&xo)[8],
-                             float* scratch, float* tail, float (&hx)[8], float (&hy)[8])
+DP_DEVICE void short_channel(const float* tab, int shape, int shape_prev,
+                             float* work, float* tail, float (&hx)[8], float (&hy)[8])
 {
     const int l = dp_lane(), w = l >> 3, g = l & 7;
-    (void)want_head;
-
-    float o[8];
-#pragma unroll
-    for (int j = 0; j < 8; j++) o[j] = xo[7 - j];
-    dp_shfl(o, l ^ 7);                                /* X_w[127 - 2k] from lane (w, 7-g) */
+    const float* sincos = tab + AACG_TAB_OFF_SINCOS_SHORT;
 
     cpx z[8];
 #pragma unroll
     for (int j = 0; j < 8; j++) {
-        const aacg_c2 sc = T->sincos_short[g + 8 * j];
-        z[j].im = dp_fma(xe[j], sc.re, o[j] * sc.im);
-        z[j].re = dp_fma(o[j], sc.re, -(xe[j] * sc.im));
+        const dpf2 a = *(const dpf2*)(work + 128 * w + 2 * g + 16 * j);          /* X_w[2k], k = g + 8 j */
+        const dpf2 b = *(const dpf2*)(work + 128 * w + 126 - 2 * g - 16 * j);    /* .y = X_w[127 - 2k]   */
+        const cpx sc = lds_get(sincos, 8 * j + g);
+        z[j].im = dp_fma(a.x, sc.re, b.y * sc.im);
+        z[j].re = dp_fma(b.y, sc.re, -(a.x * sc.im));
     }
+    dp_wave_sync();
 
     /* 64-point inverse FFT per window: 8 lanes x 8 points */
     radix8_inv(z);
 #pragma unroll
-    for (int q = 1; q < 8; q++) z[q] = c_mul(z[q], T->tw64[q - 1][g]);
+    for (int q = 1; q < 8; q++) z[q] = c_mul(z[q], lds_get(tab + AACG_TAB_OFF_TW64, 8 * (q - 1) + g));
 #pragma unroll
-    for (int q = 0; q < 8; q++) lds_put(scratch, (8 * w + q) * 9 + g, z[q]);
+    for (int q = 0; q < 8; q++) lds_put(work, (8 * w + q) * 9 + g, z[q]);
     dp_wave_sync();
 #pragma unroll
-    for (int i = 0; i < 8; i++) z[i] = lds_get(scratch, l * 9 + i);
+    for (int i = 0; i < 8; i++) z[i] = lds_get(work, l * 9 + i);
     dp_wave_sync();
     radix8_inv(z);                                    /* lane (w, q) holds Z_w[q + 8 r] */
 
     float m[16];
-    const int gk = dp_opaque(g);
 #pragma unroll
     for (int r = 0; r < 8; r++) {
-        const aacg_c2 sc = T->sincos_short[gk + 8 * r];
+        const cpx sc = lds_get(sincos, 8 * r + g);
         m[r]     = dp_fma(z[r].re, sc.re, -(z[r].im * sc.im));
         m[8 + r] = dp_fma(z[r].im, sc.re, z[r].re * sc.im);
     }
@@ -216,20 +250,22 @@ DP_DEVICE void short_channel(const aacg_tables* T, int shape, int shape_prev, bo
     dp_shfl(m, l ^ 7);
 
     /* window each block: head with W[i] (block 0: previous shape), tail with W[127-i] */
-    const float* ws = T->short_win[shape];
-    const float* wh = (w == 0) ? T->short_win[shape_prev] : ws;
+    const float* ws = tab + AACG_TAB_OFF_WIN_SHORT + 128 * shape;
+    const float* wh = (w == 0) ? tab + AACG_TAB_OFF_WIN_SHORT + 128 * shape_prev : ws;
     float hd[16], tl[16];                             /* [m] = position i = 2g+16m, [8+m] = i+1 */
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const int i = 2 * g + 16 * j;
-        hd[j]         = I[j + 4] * wh[i];             /* y[2k]       */
-        hd[8 + j]     = -m[3 - j] * wh[i + 1];        /* y[2k+1]     */
-        hd[j + 4]     = R[j] * wh[i + 64];            /* y[64+2k]    */
-        hd[8 + j + 4] = -m[8 + 7 - j] * wh[i + 65];   /* y[64+2k+1]  */
-        tl[j]         = R[j + 4] * ws[127 - i];       /* y[128+2k]   */
-        tl[8 + j]     = -m[8 + 3 - j] * ws[126 - i];  /* y[128+2k+1] */
-        tl[j + 4]     = -I[j] * ws[63 - i];           /* y[192+2k]   */
-        tl[8 + j + 4] = m[7 - j] * ws[62 - i];        /* y[192+2k+1] */
+        const dpf2 h0 = *(const dpf2*)(wh + i), h1 = *(const dpf2*)(wh + i + 64);
+        const dpf2 t0 = *(const dpf2*)(ws + 126 - i), t1 = *(const dpf2*)(ws + 62 - i);
+        hd[j]         = I[j + 4] * h0.x;              /* y[2k]       */
+        hd[8 + j]     = -m[3 - j] * h0.y;             /* y[2k+1]     */
+        hd[j + 4]     = R[j] * h1.x;                  /* y[64+2k]    */
+        hd[8 + j + 4] = -m[8 + 7 - j] * h1.y;         /* y[64+2k+1]  */
+        tl[j]         = R[j + 4] * t0.y;              /* y[128+2k]   * W[127-i] */
+        tl[8 + j]     = -m[8 + 3 - j] * t0.x;         /* y[128+2k+1] * W[126-i] */
+        tl[j + 4]     = -I[j] * t1.y;                 /* y[192+2k]   * W[63-i]  */
+        tl[8 + j + 4] = m[7 - j] * t1.x;              /* y[192+2k+1] * W[62-i]  */
     }
     /* s[128 w + i] = tail of block w-1 + head of block w (filter_bank.js:155-160) */
     float pt[16];
@@ -256,210 +292,246 @@ DP_DEVICE void short_channel(const aacg_tables* T, int shape, int shape_prev, bo
     }
 }
 
+/* IMDCT + window of one channel whose spectrum sits in `work` (natural order). */
+DP_DEVICE void filter_channel(const float* tab, const aacg_chan_info* ci, bool want_head,
+                              float* work, float* tail, float (&hx)[8], float (&hy)[8])
+{
+    if (ci->window_sequence == AACG_EIGHT_SHORT_SEQUENCE)
+        short_channel(tab, ci->window_shape, ci->window_shape_prev, work, tail, hx, hy);
+    else
+        long_channel(tab, ci->window_sequence, ci->window_shape, ci->window_shape_prev, want_head, work, tail, hx, hy);
+}
+
 /* ------------------------------------------------------------------------------------ */
 /* spectral reconstruction: dequant (ics.js:222-227,244-256), MS (decoder.js:379-404),       */
-/* IS (decoder.js:337-376)                                                                 */
+/* IS (decoder.js:337-376) in natural order: lane l owns coefficients 8 l + 512 i + 0..7     */
 /* ------------------------------------------------------------------------------------ */
+#define AACG_BF_MS      0x010         /* band flags kept in LDS: bits 0..3 band type, bit 4 ms_used */
+
+/* Per-wave band table in LDS (in the work area, before the spectrum is staged):
+ * scale[c][128] f32 at bt + 0 / + 128, flags[c][128] i32 at bt + 256 / + 384. */
+DP_DEVICE void prepare_bands(const float* tab, const aacg_band_meta* meta, int n_ch, float* bt)
+{
+    const int lane = dp_lane();
+    for (int c = 0; c < n_ch; c++) {
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int b = lane + 64 * h;
+            if (b < AACG_MAX_SECTIONS) {
+                const unsigned wd = meta[c].band[b];
+                float sf = tab[AACG_TAB_OFF_SF + (wd & AACG_META_SF_MASK)];
+                if (wd & AACG_META_NEGATE) sf = -sf;
+                bt[c * 128 + b] = sf;
+                ((int*)bt)[256 + c * 128 + b] = (int)(wd >> AACG_META_BT_SHIFT) | ((wd & AACG_META_MS_USED) ? AACG_BF_MS : 0);
+            }
+        }
+    }
+}
+
 struct chan_ctx {
-    int cls;            /* 1 = EIGHT_SHORT lane map */
+    int cls;            /* 1 = EIGHT_SHORT */
     int max_sfb;
-    int group_count;
-    int cum[7];         /* prefix sums of group_len: window w is in group #{i : w >= cum[i]} */
+    unsigned gmap;      /* 4 bits per window: its group (planner-filled, aacg_unit_desc.reserved1) */
 };
 
-DP_DEVICE void load_ctx(const aacg_chan_info* ci, chan_ctx& cc)
+/* index g*maxSFB + sfb of the band holding array position pos (ics.js:217); -1 if sfb >= maxSFB */
+DP_DEVICE int band_index(const float* tab, const chan_ctx& cc, int pos)
 {
-    cc.cls = (ci->window_sequence == AACG_EIGHT_SHORT_SEQUENCE) ? 1 : 0;
-    cc.max_sfb = ci->max_sfb;
-    cc.group_count = ci->group_count;
-    int acc = 0;
-#pragma unroll
-    for (int i = 0; i < 7; i++) { acc += ci->group_len[i]; cc.cum[i] = acc; }
-}
-
-/* index g*maxSFB + sfb of the band holding array position pos (ics.js:217), coded = sfb < maxSFB */
-DP_DEVICE int band_index(const aacg_tables* T, const chan_ctx& cc, int pos, bool& coded)
-{
+    const unsigned char* bl = (const unsigned char*)(tab + AACG_TAB_OFF_BAND_LONG);
+    const unsigned char* bs = (const unsigned char*)(tab + AACG_TAB_OFF_BAND_SHORT);
     int sfb, g = 0;
-    if (cc.cls) {
-        sfb = T->band_of_short[pos & 127];
-        const int w = pos >> 7;
-#pragma unroll
-        for (int i = 0; i < 7; i++) g += (i + 1 < cc.group_count && w >= cc.cum[i]) ? 1 : 0;
-    } else {
-        sfb = T->band_of_long[pos];
-    }
-    coded = sfb < cc.max_sfb;
-    return coded ? g * cc.max_sfb + sfb : 0;
+    if (cc.cls) { sfb = bs[pos & 127]; g = (int)((cc.gmap >> (4 * (pos >> 7))) & 15u); }
+    else        { sfb = bl[pos]; }
+    return sfb < cc.max_sfb ? g * cc.max_sfb + sfb : -1;
 }
 
-DP_DEVICE float meta_scale(const aacg_tables* T, unsigned mword)
-{
-    float sf = T->sf[mword & AACG_META_SF_MASK];
-    return (mword & AACG_META_NEGATE) ? -sf : sf;
-}
-
-DP_DEVICE float dequant_one(const aacg_tables* T, int q, float sf)
+DP_DEVICE float dequant_one(const float* tab, const aacg_tables* T, int q, float sf)
 {
     int a = q < 0 ? -q : q;
-    a = a > 8191 ? 8191 : a;                          /* IQ_TABLE[8191..] is undefined in JS -> NaN */
-    const float v = T->iq[a];
+    float v;
+    if (a < 512) v = tab[AACG_TAB_OFF_IQ_SMALL + a];
+    else         v = T->iq[a > 8191 ? 8191 : a];      /* rare; IQ_TABLE[8191..] is undefined in JS -> NaN */
     return (q > 0 ? v : -v) * sf;                     /* q == 0 gives -0 like ics.js:251 */
 }
 
-DP_DEVICE void dequant_pair(const aacg_tables* T, unsigned mword, bool coded, int packed,
-                            float& x0, float& x1)
+/* four coefficients packed as two dwords of int16 pairs */
+DP_DEVICE void dequant4(const float* tab, const aacg_tables* T, int bflags, float sf, int p01, int p23, float (&x)[4])
 {
-    const int bt = (int)(mword >> AACG_META_BT_SHIFT);
-    if (!coded || bt == AACG_ZERO_BT || bt >= AACG_NOISE_BT) {    /* ZERO / INTENSITY -> +0 (ics.js:222-227); NOISE: see DESIGN.md */
-        x0 = 0.0f; x1 = 0.0f;
+    const int bt = bflags & 15;
+    if (bflags < 0 || bt == AACG_ZERO_BT || bt >= AACG_NOISE_BT) {   /* uncoded / ZERO / INTENSITY -> +0 (ics.js:222-227); NOISE: DESIGN.md */
+        x[0] = x[1] = x[2] = x[3] = 0.0f;
         return;
     }
-    const float sf = meta_scale(T, mword);
-    x0 = dequant_one(T, (int)(short)(packed & 0xffff), sf);
-    x1 = dequant_one(T, packed >> 16, sf);
+    x[0] = dequant_one(tab, T, (int)(short)(p01 & 0xffff), sf);
+    x[1] = dequant_one(tab, T, p01 >> 16, sf);
+    x[2] = dequant_one(tab, T, (int)(short)(p23 & 0xffff), sf);
+    x[3] = dequant_one(tab, T, p23 >> 16, sf);
 }
 
-/* Fills (xe0, xo0) and, for a CPE, (xe1, xo1): the pair at pair_pos(lane, j, cls_c) of each
- * channel after dequant, MS and IS. */
-DP_DEVICE void spectral_quant(const aacg_kparams& P, const aacg_unit_desc* u, int n_ch,
-                              const chan_ctx& ccL, const chan_ctx& ccR, float* scratch,
-                              float (&xe0)[8], float (&xo0)[8], float (&xe1)[8], float (&xo1)[8])
+/* Produces xl / xr[16]: element 8 i + e is coefficient 8 lane + 512 i + e of the left / right
+ * (or single) channel after dequant, MS and IS. */
+DP_DEVICE void spectral_quant(const aacg_kparams& P, const float* tab, const aacg_unit_desc* u, int n_ch,
+                              float* bt, float (&xl)[16], float (&xr)[16])
 {
-    const aacg_tables* T = P.tab;
     const int lane = dp_lane();
     const int16_t* q0 = (const int16_t*)P.coeffs + (size_t)u->coef_offset * 1024u;
-    const aacg_band_meta* mL = P.meta + u->meta_offset;
+    chan_ctx ccL, ccR;
+    ccL.cls = u->ch[0].window_sequence == AACG_EIGHT_SHORT_SEQUENCE; ccL.max_sfb = u->ch[0].max_sfb; ccL.gmap = u->reserved1[0];
+    ccR.cls = u->ch[1].window_sequence == AACG_EIGHT_SHORT_SEQUENCE; ccR.max_sfb = u->ch[1].max_sfb; ccR.gmap = u->reserved1[1];
 
-    if (n_ch == 1) {
+    /* issue the coefficient loads first (16 bytes per lane), then build the band table while they fly */
+    dpi4 ql[2], qr[2];
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const int pos = pair_pos(lane, j, ccL.cls);
-            bool coded; const int idx = band_index(T, ccL, pos, coded);
-            dequant_pair(T, mL->band[idx], coded, *(const int*)(q0 + pos), xe0[j], xo0[j]);
-        }
-        return;
+    for (int i = 0; i < 2; i++) {
+        ql[i] = *(const dpi4*)(q0 + 8 * lane + 512 * i);
+        if (n_ch == 2) qr[i] = *(const dpi4*)(q0 + 1024 + 8 * lane + 512 * i);
+        else           { qr[i].x = qr[i].y = qr[i].z = qr[i].w = 0; }
     }
-
-    const aacg_band_meta* mR = mL + 1;
-    const int16_t* q1 = q0 + 1024;
-    const bool common = (u->flags & AACG_UNIT_COMMON_WINDOW) != 0;
-    const bool mask   = (u->flags & AACG_UNIT_MASK_PRESENT) != 0;
-
-    if (ccL.cls == ccR.cls) {
-        /* both channels on the same lane map: MS and IS are register-local */
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const int pos = pair_pos(lane, j, ccL.cls);
-            bool codedL, codedR;
-            const int idxL = band_index(T, ccL, pos, codedL);
-            const int idxR = band_index(T, ccR, pos, codedR);
-            const unsigned wL = mL->band[idxL], wR = mR->band[idxR];
-            float a0, a1, b0, b1;
-            dequant_pair(T, wL, codedL, *(const int*)(q0 + pos), a0, a1);
-            dequant_pair(T, wR, codedR, *(const int*)(q1 + pos), b0, b1);
-            /* decoder.js:295-296,393: MS needs commonWindow && maskPresent && ms_used && both band types < NOISE */
-            if (common && mask && codedL && (wL & AACG_META_MS_USED) &&
-                (wL >> AACG_META_BT_SHIFT) < AACG_NOISE_BT && (wR >> AACG_META_BT_SHIFT) < AACG_NOISE_BT) {
-                const float t0 = a0 - b0, t1 = a1 - b1;
-                a0 = a0 + b0; a1 = a1 + b1;
-                b0 = t0; b1 = t1;
-            }
-            /* decoder.js:353-368: right = left * (c * sfR) on intensity bands of the right channel */
-            const int btR = (int)(wR >> AACG_META_BT_SHIFT);
-            if (codedR && btR >= AACG_INTENSITY_BT2) {
-                float scale = meta_scale(T, wR);
-                bool neg = (btR == AACG_INTENSITY_BT2);
-                if (mask && (mL->band[idxR] & AACG_META_MS_USED)) neg = !neg;
-                scale = neg ? -scale : scale;
-                b0 = a0 * scale; b1 = a1 * scale;
-            }
-            xe0[j] = a0; xo0[j] = a1; xe1[j] = b0; xo1[j] = b1;
-            if (j & 1) dp_sched_fence();
-        }
-        return;
-    }
-
-    /* L and R on different lane maps (no common window, one of them EIGHT_SHORT): MS cannot
-     * apply (decoder.js:295); IS reads the left spectrum at the right channel's positions,
-     * staged through LDS in natural order. */
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-        const int pos = pair_pos(lane, j, ccL.cls);
-        bool coded; const int idx = band_index(T, ccL, pos, coded);
-        dequant_pair(T, mL->band[idx], coded, *(const int*)(q0 + pos), xe0[j], xo0[j]);
-        dpf2 t; t.x = xe0[j]; t.y = xo0[j];
-        *(dpf2*)(scratch + pos) = t;
-    }
+    prepare_bands(tab, P.meta + u->meta_offset, n_ch, bt);
     dp_wave_sync();
+
+    const bool ms_on = n_ch == 2 && (u->flags & AACG_UNIT_COMMON_WINDOW) && (u->flags & AACG_UNIT_MASK_PRESENT);
+    const bool mask  = (u->flags & AACG_UNIT_MASK_PRESENT) != 0;
+    const int* bf = (const int*)bt + 256;
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
-        const int pos = pair_pos(lane, j, ccR.cls);
-        bool coded; const int idx = band_index(T, ccR, pos, coded);
-        const unsigned wR = mR->band[idx];
-        dequant_pair(T, wR, coded, *(const int*)(q1 + pos), xe1[j], xo1[j]);
-        const int btR = (int)(wR >> AACG_META_BT_SHIFT);
-        if (coded && btR >= AACG_INTENSITY_BT2) {
-            float scale = meta_scale(T, wR);
-            bool neg = (btR == AACG_INTENSITY_BT2);
-            if (mask && (mL->band[idx] & AACG_META_MS_USED)) neg = !neg;
-            scale = neg ? -scale : scale;
-            const dpf2 lv = *(const dpf2*)(scratch + pos);
-            xe1[j] = lv.x * scale; xo1[j] = lv.y * scale;
+    for (int i = 0; i < 2; i++) {
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int pos = 8 * lane + 512 * i + 4 * h;
+            const int idxL = band_index(tab, ccL, pos);
+            const int fL = idxL < 0 ? -1 : bf[idxL];
+            const float sL = idxL < 0 ? 0.0f : bt[idxL];
+            float a[4], b[4];
+            dequant4(tab, P.tab, fL, sL, h ? ql[i].z : ql[i].x, h ? ql[i].w : ql[i].y, a);
+            if (n_ch == 2) {
+                const int idxR = band_index(tab, ccR, pos);
+                const int fR = idxR < 0 ? -1 : bf[128 + idxR];
+                const float sR = idxR < 0 ? 0.0f : bt[128 + idxR];
+                dequant4(tab, P.tab, fR, sR, h ? qr[i].z : qr[i].x, h ? qr[i].w : qr[i].y, b);
+                /* decoder.js:295-296,393: MS needs commonWindow && maskPresent && ms_used[idx] && both band types < NOISE
+                 * (idx from the left channel's grid; with a common window it is the right channel's too) */
+                if (ms_on && idxL >= 0 && (fL & AACG_BF_MS) && (fL & 15) < AACG_NOISE_BT && (bf[128 + idxL] & 15) < AACG_NOISE_BT) {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) { const float t = a[e] - b[e]; a[e] = a[e] + b[e]; b[e] = t; }
+                }
+                /* decoder.js:353-368: right = left * (c * sfR) on the right channel's intensity bands */
+                if (idxR >= 0 && (fR & 15) >= AACG_INTENSITY_BT2) {
+                    bool neg = (fR & 15) == AACG_INTENSITY_BT2;
+                    if (mask && (bf[idxR] & AACG_BF_MS)) neg = !neg;
+                    const float scale = neg ? -sR : sR;
+#pragma unroll
+                    for (int e = 0; e < 4; e++) b[e] = a[e] * scale;
+                }
+            } else {
+                b[0] = b[1] = b[2] = b[3] = 0.0f;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; e++) { xl[8 * i + 4 * h + e] = a[e]; xr[8 * i + 4 * h + e] = b[e]; }
         }
     }
-    dp_wave_sync();
+    dp_wave_sync();                                    /* band table dead: the work area may be overwritten */
 }
 
-DP_DEVICE void load_f32(const float* x, int cls, float (&xe)[8], float (&xo)[8])
+/* registers (natural order, 8 lane + 512 i + e) -> work[0..1023] */
+DP_DEVICE void stage_nat8(const float (&x)[16], float* work)
 {
     const int lane = dp_lane();
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
-        const dpf2 v = *(const dpf2*)(x + pair_pos(lane, j, cls));
-        xe[j] = v.x; xo[j] = v.y;
+    for (int i = 0; i < 2; i++) {
+        dpf4 a, b;
+        a.x = x[8 * i]; a.y = x[8 * i + 1]; a.z = x[8 * i + 2]; a.w = x[8 * i + 3];
+        b.x = x[8 * i + 4]; b.y = x[8 * i + 5]; b.z = x[8 * i + 6]; b.w = x[8 * i + 7];
+        *(dpf4*)(work + 8 * lane + 512 * i) = a;
+        *(dpf4*)(work + 8 * lane + 512 * i + 4) = b;
     }
+    dp_wave_sync();
 }
 
-/* IMDCT + window of one channel: tail -> LDS, windowed head -> registers */
-DP_DEVICE void filter_channel(const aacg_tables* T, const aacg_chan_info* ci, int cls, bool want_head,
-                              const float (&xe)[8], const float (&xo)[8],
-                              float* scratch, float* tail, float (&hx)[8], float (&hy)[8])
-{
-    if (cls) short_channel(T, ci->window_shape, ci->window_shape_prev, want_head, xe, xo, scratch, tail, hx, hy);
-    else     long_channel(T, ci->window_sequence, ci->window_shape, ci->window_shape_prev, want_head, xe, xo, scratch, tail, hx, hy);
-}
-
-/* out = (overlap + head) / 32768 for one channel, scalar stores at stride C (decoder.js:209-213) */
-DP_DEVICE void store_channel(const float* pv, float* dst, int C, int cls, const float (&hx)[8], const float (&hy)[8])
+/* ------------------------------------------------------------------------------------ */
+/* epilogue: out = (overlap + head) / 32768, interleaved (filter_bank.js + decoder.js:203-215) */
+/* ------------------------------------------------------------------------------------ */
+/* prev: the two incoming tails (channel c at prev + c * stride), in LDS or in HBM. */
+DP_DEVICE void epilogue(const float* prev, int stride, const aacg_unit_desc* u, int n_ch, int cls0, int cls1,
+                        float* pcm_base, const float (&hx0)[8], const float (&hy0)[8],
+                        const float (&hx1)[8], const float (&hy1)[8])
 {
     const int lane = dp_lane(), w = lane >> 3, g = lane & 7;
-    const float S = 1.0f / 32768.0f;
-    if (!cls) {
+    const float S = 1.0f / 32768.0f;                   /* decoder.js:211 */
+    const int C = u->n_out_ch;
+    float* pcm = pcm_base + u->pcm_offset + u->channel;
+
+    if (n_ch == 2 && C == 2 && cls0 == cls1 && ((u->pcm_offset | u->channel) & 3) == 0) {
+        /* stereo fast path: (L[n], R[n], L[n+1], R[n+1]) = 16 bytes per lane */
+        if (!cls0) {
 #pragma unroll
-        for (int m = 0; m < 8; m++) {
-            const int n = 2 * lane + 128 * m;
-            const dpf2 a = *(const dpf2*)(pv + n);
-            dst[(size_t)n * C]       = (a.x + hx[m]) * S;
-            dst[(size_t)(n + 1) * C] = (a.y + hy[m]) * S;
-        }
-    } else {
+            for (int m = 0; m < 8; m++) {
+                const int n = 2 * lane + 128 * m;
+                const dpf2 a = *(const dpf2*)(prev + n), b = *(const dpf2*)(prev + stride + n);
+                dpf4 o;
+                o.x = (a.x + hx0[m]) * S; o.y = (b.x + hx1[m]) * S;
+                o.z = (a.y + hy0[m]) * S; o.w = (b.y + hy1[m]) * S;
+                *(dpf4*)(pcm + 2 * n) = o;
+            }
+        } else {
 #pragma unroll
-        for (int m = 0; m < 8; m++) {
-            if (w < 4 || (w == 4 && m < 4)) {
-                const int n = 448 + 128 * w + 2 * g + 16 * m;
-                const dpf2 a = *(const dpf2*)(pv + n);
-                dst[(size_t)n * C]       = (a.x + hx[m]) * S;
-                dst[(size_t)(n + 1) * C] = (a.y + hy[m]) * S;
+            for (int m = 0; m < 8; m++) {
+                if (w < 4 || (w == 4 && m < 4)) {
+                    const int n = 448 + 128 * w + 2 * g + 16 * m;
+                    const dpf2 a = *(const dpf2*)(prev + n), b = *(const dpf2*)(prev + stride + n);
+                    dpf4 o;
+                    o.x = (a.x + hx0[m]) * S; o.y = (b.x + hx1[m]) * S;
+                    o.z = (a.y + hy0[m]) * S; o.w = (b.y + hy1[m]) * S;
+                    *(dpf4*)(pcm + 2 * n) = o;
+                }
+            }
+#pragma unroll
+            for (int t4 = 0; t4 < 4; t4++) {           /* out[0..447] = overlap (filter_bank.js:149-151) */
+                const int n = 2 * lane + 128 * t4;
+                if (n < 448) {
+                    const dpf2 a = *(const dpf2*)(prev + n), b = *(const dpf2*)(prev + stride + n);
+                    dpf4 o; o.x = a.x * S; o.y = b.x * S; o.z = a.y * S; o.w = b.y * S;
+                    *(dpf4*)(pcm + 2 * n) = o;
+                }
             }
         }
+        return;
+    }
+
 #pragma unroll
-        for (int t4 = 0; t4 < 4; t4++) {               /* out[0..447] = overlap (filter_bank.js:149-151) */
-            const int n = 2 * lane + 128 * t4;
-            if (n < 448) {
-                const dpf2 a = *(const dpf2*)(pv + n);
-                dst[(size_t)n * C]       = a.x * S;
-                dst[(size_t)(n + 1) * C] = a.y * S;
+    for (int c = 0; c < 2; c++) {
+        if (c < n_ch) {
+            const float* pv = prev + c * stride;
+            float* dst = pcm + c;
+            const int cls = c ? cls1 : cls0;
+            const float (&hx)[8] = c ? hx1 : hx0;
+            const float (&hy)[8] = c ? hy1 : hy0;
+            if (!cls) {
+#pragma unroll
+                for (int m = 0; m < 8; m++) {
+                    const int n = 2 * lane + 128 * m;
+                    const dpf2 a = *(const dpf2*)(pv + n);
+                    dst[(size_t)n * C]       = (a.x + hx[m]) * S;
+                    dst[(size_t)(n + 1) * C] = (a.y + hy[m]) * S;
+                }
+            } else {
+#pragma unroll
+                for (int m = 0; m < 8; m++) {
+                    if (w < 4 || (w == 4 && m < 4)) {
+                        const int n = 448 + 128 * w + 2 * g + 16 * m;
+                        const dpf2 a = *(const dpf2*)(pv + n);
+                        dst[(size_t)n * C]       = (a.x + hx[m]) * S;
+                        dst[(size_t)(n + 1) * C] = (a.y + hy[m]) * S;
+                    }
+                }
+#pragma unroll
+                for (int t4 = 0; t4 < 4; t4++) {
+                    const int n = 2 * lane + 128 * t4;
+                    if (n < 448) {
+                        const dpf2 a = *(const dpf2*)(pv + n);
+                        dst[(size_t)n * C]       = a.x * S;
+                        dst[(size_t)(n + 1) * C] = a.y * S;
+                    }
+                }
             }
         }
     }
@@ -471,115 +543,93 @@ DP_DEVICE void store_channel(const float* pv, float* dst, int C, int cls, const 
 template <int KIND>
 DP_DEVICE void imdct_run_body(const aacg_kparams& P)
 {
+    const int TAB_FLOATS = (KIND == AACG_INPUT_QUANT_I16) ? AACG_TAB_QUANT_FLOATS : AACG_TAB_F32_FLOATS;
     const int lane = dp_lane(), wave = dp_wave();
     const aacg_run* run = P.runs + dp_block();
     float* lds = (float*)dp_lds();
-    float* slot = lds + wave * AACG_SLOT_FLOATS;       /* tail[0] | tail[1] = FFT scratch */
-    float* scratch = slot + 1024;
+    const float* tab = lds;
+    float* slots = lds + TAB_FLOATS;
+    float* slot = slots + wave * AACG_SLOT_FLOATS;     /* tail[0] | tail[1] = work area */
+    float* work = slot + 1024;
 
     const int n_units = run->n_units;
+    const bool has_pred = run->pred_unit >= 0;
     int ui = -1;
-    if (wave == 0) ui = run->pred_unit;
-    else if (wave - 1 < n_units) ui = run->unit[wave - 1];
+    if (has_pred) { if (wave == 0) ui = run->pred_unit; else if (wave - 1 < n_units) ui = run->unit[wave - 1]; }
+    else          { if (wave < n_units) ui = run->unit[wave]; }
     ui = dp_uniform(ui);
+    const bool is_pred_wave = has_pred && wave == 0;
 
     float hx0[8], hy0[8], hx1[8], hy1[8];
     const aacg_unit_desc* u = P.units;
     int n_ch = 0, cls0 = 0, cls1 = 0;
 
-    if (ui >= 0) {
-        u = P.units + ui;
-        n_ch = u->n_ch;
-        const bool want_head = wave != 0;
-        /* TNS between here and the filterbank: identity as the reference runs (tns.js:106,122) */
-        if (KIND == AACG_INPUT_QUANT_I16) {
-            chan_ctx ccL, ccR;
-            load_ctx(&u->ch[0], ccL);
-            load_ctx(&u->ch[1], ccR);
-            cls0 = ccL.cls; cls1 = ccR.cls;
-            float xe0[8], xo0[8], xe1[8], xo1[8];
-            spectral_quant(P, u, n_ch, ccL, ccR, scratch, xe0, xo0, xe1, xo1);
-            filter_channel(P.tab, &u->ch[0], cls0, want_head, xe0, xo0, scratch, slot, hx0, hy0);
-            if (n_ch == 2) {
-                dp_wave_sync();                        /* tail[1] aliases the FFT scratch */
-                filter_channel(P.tab, &u->ch[1], cls1, want_head, xe1, xo1, scratch, slot + 1024, hx1, hy1);
-            }
-        } else {
-            const float* x = (const float*)P.coeffs + (size_t)u->coef_offset * 1024u;
+    if (KIND == AACG_INPUT_QUANT_I16) {
+        float xl[16], xr[16];
+        stage_tables(P.tab, lds, TAB_FLOATS);
+        dp_block_sync();                               /* dequant needs the SF / IQ / band tables */
+        if (ui >= 0) {
+            u = P.units + ui;
+            n_ch = u->n_ch;
             cls0 = u->ch[0].window_sequence == AACG_EIGHT_SHORT_SEQUENCE;
             cls1 = u->ch[1].window_sequence == AACG_EIGHT_SHORT_SEQUENCE;
-            float xe0[8], xo0[8], xe1[8], xo1[8];
-            load_f32(x, cls0, xe0, xo0);
-            if (n_ch == 2) load_f32(x + 1024, cls1, xe1, xo1);
-            filter_channel(P.tab, &u->ch[0], cls0, want_head, xe0, xo0, scratch, slot, hx0, hy0);
+            spectral_quant(P, tab, u, n_ch, work, xl, xr);
+            /* TNS would run here: identity as the reference executes it (tns.js:106,122) */
+            stage_nat8(xl, work);
+            filter_channel(tab, &u->ch[0], !is_pred_wave, work, slot, hx0, hy0);
             if (n_ch == 2) {
                 dp_wave_sync();
-                filter_channel(P.tab, &u->ch[1], cls1, want_head, xe1, xo1, scratch, slot + 1024, hx1, hy1);
+                stage_nat8(xr, work);
+                filter_channel(tab, &u->ch[1], !is_pred_wave, work, work, hx1, hy1);
             }
         }
-    } else if (wave == 0) {
-        /* first run of its chain in this launch: the tail comes from the overlap state
-         * (filter_bank.js:38-41, `overlap = this.overlaps[channel]`) */
-        const aacg_unit_desc* u0 = P.units + run->unit[0];
-        const int nc = u0->n_ch;
-        for (int c = 0; c < nc; c++) {
-            const float* src = P.overlap + (P.flip ? run->ov_b[c] : run->ov_a[c]);
+    } else {
+        /* spectra: 16-byte loads in natural order, issued before the table copy so both fly together */
+        dpf4 xa[4], xb[4];
+        if (ui >= 0) {
+            u = P.units + ui;
+            n_ch = u->n_ch;
+            cls0 = u->ch[0].window_sequence == AACG_EIGHT_SHORT_SEQUENCE;
+            cls1 = u->ch[1].window_sequence == AACG_EIGHT_SHORT_SEQUENCE;
+            const float* x = (const float*)P.coeffs + (size_t)u->coef_offset * 1024u;
 #pragma unroll
-            for (int i = 0; i < 4; i++)
-                *(dpf4*)(slot + c * 1024 + 4 * lane + 256 * i) = *(const dpf4*)(src + 4 * lane + 256 * i);
+            for (int i = 0; i < 4; i++) {
+                xa[i] = *(const dpf4*)(x + 4 * lane + 256 * i);
+                if (n_ch == 2) xb[i] = *(const dpf4*)(x + 1024 + 4 * lane + 256 * i);
+            }
+        }
+        stage_tables(P.tab, lds, TAB_FLOATS);
+        dp_block_sync();
+        if (ui >= 0) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) *(dpf4*)(work + 4 * lane + 256 * i) = xa[i];
+            dp_wave_sync();
+            filter_channel(tab, &u->ch[0], !is_pred_wave, work, slot, hx0, hy0);
+            if (n_ch == 2) {
+                dp_wave_sync();
+#pragma unroll
+                for (int i = 0; i < 4; i++) *(dpf4*)(work + 4 * lane + 256 * i) = xb[i];
+                dp_wave_sync();
+                filter_channel(tab, &u->ch[1], !is_pred_wave, work, work, hx1, hy1);
+            }
         }
     }
 
-    dp_block_sync();
+    dp_block_sync();                                   /* every wave's tails are in its slot */
 
-    if (wave >= 1 && ui >= 0) {
-        const float* prev = lds + (wave - 1) * AACG_SLOT_FLOATS;
-        const float S = 1.0f / 32768.0f;               /* decoder.js:211 */
-        const int C = u->n_out_ch;
-        float* pcm = P.pcm + u->pcm_offset + u->channel;
-        const int w = lane >> 3, g = lane & 7;
-
-        if (n_ch == 2 && C == 2 && cls0 == cls1 && ((u->pcm_offset | u->channel) & 3) == 0) {
-            /* stereo fast path: (L[n], R[n], L[n+1], R[n+1]) = 16 bytes per lane */
-            if (!cls0) {
-#pragma unroll
-                for (int m = 0; m < 8; m++) {
-                    const int n = 2 * lane + 128 * m;
-                    const dpf2 a = *(const dpf2*)(prev + n), b = *(const dpf2*)(prev + 1024 + n);
-                    dpf4 o;
-                    o.x = (a.x + hx0[m]) * S; o.y = (b.x + hx1[m]) * S;
-                    o.z = (a.y + hy0[m]) * S; o.w = (b.y + hy1[m]) * S;
-                    *(dpf4*)(pcm + 2 * n) = o;
-                }
-            } else {
-#pragma unroll
-                for (int m = 0; m < 8; m++) {
-                    if (w < 4 || (w == 4 && m < 4)) {
-                        const int n = 448 + 128 * w + 2 * g + 16 * m;
-                        const dpf2 a = *(const dpf2*)(prev + n), b = *(const dpf2*)(prev + 1024 + n);
-                        dpf4 o;
-                        o.x = (a.x + hx0[m]) * S; o.y = (b.x + hx1[m]) * S;
-                        o.z = (a.y + hy0[m]) * S; o.w = (b.y + hy1[m]) * S;
-                        *(dpf4*)(pcm + 2 * n) = o;
-                    }
-                }
-#pragma unroll
-                for (int t4 = 0; t4 < 4; t4++) {       /* out[0..447] = overlap (filter_bank.js:149-151) */
-                    const int n = 2 * lane + 128 * t4;
-                    if (n < 448) {
-                        const dpf2 a = *(const dpf2*)(prev + n), b = *(const dpf2*)(prev + 1024 + n);
-                        dpf4 o; o.x = a.x * S; o.y = b.x * S; o.z = a.y * S; o.w = b.y * S;
-                        *(dpf4*)(pcm + 2 * n) = o;
-                    }
-                }
-            }
+    if (ui >= 0 && !is_pred_wave) {
+        if (wave == 0) {
+            /* first frame of its chain in this launch: overlap state from HBM
+             * (filter_bank.js:38-41, `overlap = this.overlaps[channel]`) */
+            const float* ov0 = P.overlap + (P.flip ? run->ov_b[0] : run->ov_a[0]);
+            const float* ov1 = P.overlap + (P.flip ? run->ov_b[1] : run->ov_a[1]);
+            epilogue(ov0, (int)(ov1 - ov0), u, n_ch, cls0, cls1, P.pcm, hx0, hy0, hx1, hy1);
         } else {
-            store_channel(prev, pcm, C, cls0, hx0, hy0);
-            if (n_ch == 2) store_channel(prev + 1024, pcm + 1, C, cls1, hx1, hy1);
+            epilogue(slot - AACG_SLOT_FLOATS, 1024, u, n_ch, cls0, cls1, P.pcm, hx0, hy0, hx1, hy1);
         }
-
         /* the chain's last frame in this launch: its tail is the new overlap state */
-        if (wave == n_units && run->is_last) {
+        const int last_wave = has_pred ? n_units : n_units - 1;
+        if (wave == last_wave && run->is_last) {
             for (int c = 0; c < n_ch; c++) {
                 float* dstov = P.overlap + (P.flip ? run->ov_a[c] : run->ov_b[c]);
 #pragma unroll
@@ -590,29 +640,34 @@ DP_DEVICE void imdct_run_body(const aacg_kparams& P)
     }
 }
 
-/* Spectral stage alone (one wave per unit): spec_out in ICStream.data order. */
-DP_DEVICE void spectral_body(const aacg_kparams& P)
+/* Spectral stage alone (16 units per workgroup, one wave each): spec_out in ICStream.data order. */
+DP_DEVICE void spectral_body(const aacg_kparams& P, int n_units)
 {
-    const int lane = dp_lane();
-    const aacg_unit_desc* u = P.units + dp_block();
-    float* scratch = (float*)dp_lds();
-    chan_ctx ccL, ccR;
-    load_ctx(&u->ch[0], ccL);
-    load_ctx(&u->ch[1], ccR);
+    const int lane = dp_lane(), wave = dp_wave();
+    float* lds = (float*)dp_lds();
+    const float* tab = lds;
+    float* bt = lds + AACG_TAB_QUANT_FLOATS + wave * 512;
+    stage_tables(P.tab, lds, AACG_TAB_QUANT_FLOATS);
+    dp_block_sync();
+    const int ui = dp_block() * AACG_WG_WAVES + wave;
+    if (ui >= n_units) return;
+    const aacg_unit_desc* u = P.units + ui;
     const int n_ch = u->n_ch;
-    float xe0[8], xo0[8], xe1[8], xo1[8];
-    spectral_quant(P, u, n_ch, ccL, ccR, scratch, xe0, xo0, xe1, xo1);
+    float xl[16], xr[16];
+    spectral_quant(P, tab, u, n_ch, bt, xl, xr);
     float* out = P.spec_out + (size_t)u->coef_offset * 1024u;
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
-        dpf2 t; t.x = xe0[j]; t.y = xo0[j];
-        *(dpf2*)(out + pair_pos(lane, j, ccL.cls)) = t;
-    }
-    if (n_ch == 2) {
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            dpf2 t; t.x = xe1[j]; t.y = xo1[j];
-            *(dpf2*)(out + 1024 + pair_pos(lane, j, ccR.cls)) = t;
+    for (int i = 0; i < 2; i++) {
+        dpf4 a, b;
+        a.x = xl[8 * i]; a.y = xl[8 * i + 1]; a.z = xl[8 * i + 2]; a.w = xl[8 * i + 3];
+        b.x = xl[8 * i + 4]; b.y = xl[8 * i + 5]; b.z = xl[8 * i + 6]; b.w = xl[8 * i + 7];
+        *(dpf4*)(out + 8 * lane + 512 * i) = a;
+        *(dpf4*)(out + 8 * lane + 512 * i + 4) = b;
+        if (n_ch == 2) {
+            a.x = xr[8 * i]; a.y = xr[8 * i + 1]; a.z = xr[8 * i + 2]; a.w = xr[8 * i + 3];
+            b.x = xr[8 * i + 4]; b.y = xr[8 * i + 5]; b.z = xr[8 * i + 6]; b.w = xr[8 * i + 7];
+            *(dpf4*)(out + 1024 + 8 * lane + 512 * i) = a;
+            *(dpf4*)(out + 1024 + 8 * lane + 512 * i + 4) = b;
         }
     }
 }

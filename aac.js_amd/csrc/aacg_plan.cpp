@@ -4,9 +4,10 @@
  *
  * A chain is the sequence of frames of one element (same stream, same first channel, same
  * width) inside the batch; the only cross-frame dependency of the path is the overlap
- * buffer of each of its channels (filter_bank.js:38-41).  A chain is cut into runs of
- * AACG_RUN_W frames; run 0 takes its incoming tail from the overlap state, every later run
- * recomputes it from the previous frame's spectrum (no inter-workgroup communication).
+ * buffer of each of its channels (filter_bank.js:38-41).  A chain is cut into runs: the
+ * first holds up to AACG_RUN_W frames and takes its incoming tail from the overlap state;
+ * every later run holds up to AACG_RUN_W - 1 frames and recomputes the tail of the frame
+ * before it from that frame's spectrum (no inter-workgroup communication).
  */
 #include "aacg_host.h"
 
@@ -105,6 +106,19 @@ int aacg_plan_build(const aacg_unit_desc* units, uint32_t n_units, int sample_in
             oc.units.push_back((int32_t)i);
         }
 
+        /* device copy with the group-of-window map: 4 bits per window (ics.js:288-296 grouping) */
+        aacg_unit_desc du = u;
+        for (int c = 0; c < 2; c++) {
+            uint32_t gmap = 0;
+            if (c < u.n_ch && u.ch[c].window_sequence == AACG_EIGHT_SHORT_SEQUENCE) {
+                int w = 0;
+                for (int g = 0; g < u.ch[c].group_count; g++)
+                    for (int k = 0; k < u.ch[c].group_len[g] && w < 8; k++, w++) gmap |= (uint32_t)g << (4 * w);
+            }
+            du.reserved1[c] = gmap;
+        }
+        out->units.push_back(du);
+
         out->coef_blocks = std::max(out->coef_blocks, u.coef_offset + u.n_ch);
         out->meta_blocks = std::max(out->meta_blocks, u.meta_offset + u.n_ch);
         out->pcm_floats = std::max(out->pcm_floats, (size_t)u.pcm_offset + 1024u * u.n_out_ch);
@@ -128,17 +142,19 @@ int aacg_plan_build(const aacg_unit_desc* units, uint32_t n_units, int sample_in
         for (int c = 0; c < 2; c++)
             ch.parity[c] = (parity && c < oc.n_ch) ? parity[(size_t)ch.stream * (size_t)max_channels + ch.channel + c] : 0;
         const size_t n = oc.units.size();
-        for (size_t pos = 0; pos < n; pos += AACG_RUN_W) {
+        for (size_t pos = 0; pos < n;) {
             aacg_run r;
+            const size_t cap = pos ? AACG_RUN_W - 1 : AACG_RUN_W;        /* wave 0 of a later run recomputes its predecessor */
             r.pred_unit = pos ? oc.units[pos - 1] : -1;
-            r.n_units = (int32_t)std::min<size_t>(AACG_RUN_W, n - pos);
+            r.n_units = (int32_t)std::min<size_t>(cap, n - pos);
             for (int k = 0; k < AACG_RUN_W; k++) r.unit[k] = k < r.n_units ? oc.units[pos + k] : -1;
             for (int c = 0; c < 2; c++) {
                 const uint32_t chn = ch.channel + (c < oc.n_ch ? c : 0);
                 r.ov_a[c] = aacg_ov_offset(max_channels, ch.stream, chn, ch.parity[c]);
                 r.ov_b[c] = aacg_ov_offset(max_channels, ch.stream, chn, ch.parity[c] ^ 1);
             }
-            r.is_last = (pos + AACG_RUN_W >= n) ? 1 : 0;
+            pos += (size_t)r.n_units;
+            r.is_last = pos >= n ? 1 : 0;
             r.reserved = 0;
             gen.push_back(r);
         }

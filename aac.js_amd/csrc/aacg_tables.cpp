@@ -11,6 +11,7 @@
 #include "aacg_host.h"
 
 #include <cmath>
+#include <cstddef>
 #include <cstring>
 #include <limits>
 #include <vector>
@@ -97,15 +98,15 @@ int aacg_build_tables(int sample_index, aacg_tables* t, aacg_host_windows* hw)
     if (sample_index < 0 || sample_index > 11) return AACG_ERR_INVALID_ARG;
     std::memset(t, 0, sizeof *t);
 
-    for (int k = 0; k < 512; k++) {
+    for (int k = 0; k < 512; k++) {                 /* k = l + 64 j stored [j][l] */
         const double a = 2.0 * kPi * (k + 0.125) / 2048.0, s = std::sqrt(2.0 / 2048.0);
-        t->sincos_long[k].re = (float)(s * std::cos(a));
-        t->sincos_long[k].im = (float)(s * std::sin(a));
+        t->sincos_long[k >> 6][k & 63].re = (float)(s * std::cos(a));
+        t->sincos_long[k >> 6][k & 63].im = (float)(s * std::sin(a));
     }
-    for (int k = 0; k < 64; k++) {
+    for (int k = 0; k < 64; k++) {                  /* k = g + 8 j stored [j][g] */
         const double a = 2.0 * kPi * (k + 0.125) / 256.0, s = std::sqrt(2.0 / 256.0);
-        t->sincos_short[k].re = (float)(s * std::cos(a));
-        t->sincos_short[k].im = (float)(s * std::sin(a));
+        t->sincos_short[k >> 3][k & 7].re = (float)(s * std::cos(a));
+        t->sincos_short[k >> 3][k & 7].im = (float)(s * std::sin(a));
     }
     for (int q = 1; q < 8; q++) {
         for (int l = 0; l < 64; l++) {
@@ -126,25 +127,14 @@ int aacg_build_tables(int sample_index, aacg_tables* t, aacg_host_windows* hw)
     kbd_window(w.kbd_long, 4.0, 1024);       /* filter_bank.js:83 */
     kbd_window(w.kbd_short, 6.0, 128);       /* filter_bank.js:84 */
     if (hw) *hw = w;
-
-    for (int shape = 0; shape < 2; shape++) {
-        const float* wl = shape ? w.kbd_long : w.sine_long;
-        const float* wsh = shape ? w.kbd_short : w.sine_short;
-        std::memcpy(t->short_win[shape], wsh, sizeof(float) * 128);
-        for (int n = 0; n < 1024; n++) {
-            /* ONLY_LONG / LONG_START first half (filter_bank.js:109-111,124-126) */
-            t->head_win[shape][n] = wl[n];
-            /* LONG_STOP first half: 0 | short window | 1 (filter_bank.js:185-195) */
-            t->head_win[2 + shape][n] = n < 448 ? 0.0f : (n < 576 ? wsh[n - 448] : 1.0f);
-            /* ONLY_LONG / LONG_STOP second half, reversed window (filter_bank.js:114-116,198-200) */
-            t->tail_win[shape][n] = wl[1023 - n];
-            /* LONG_START second half: 1 | reversed short window | 0 (filter_bank.js:129-139) */
-            t->tail_win[2 + shape][n] = n < 448 ? 1.0f : (n < 576 ? wsh[127 - (n - 448)] : 0.0f);
-        }
-    }
+    std::memcpy(t->win_long[0], w.sine_long, sizeof w.sine_long);
+    std::memcpy(t->win_long[1], w.kbd_long, sizeof w.kbd_long);
+    std::memcpy(t->win_short[0], w.sine_short, sizeof w.sine_short);
+    std::memcpy(t->win_short[1], w.kbd_short, sizeof w.kbd_short);
 
     for (int i = 0; i < 8191; i++) t->iq[i] = (float)std::pow((double)i, 4.0 / 3.0);
     t->iq[8191] = std::numeric_limits<float>::quiet_NaN();
+    std::memcpy(t->iq_small, t->iq, sizeof t->iq_small);
     for (int i = 0; i < 428; i++) t->sf[i] = (float)std::pow(2.0, (i - 200) / 4.0);
 
     std::vector<int> off;
@@ -154,5 +144,16 @@ int aacg_build_tables(int sample_index, aacg_tables* t, aacg_host_windows* hw)
     n = expand(kSwbShort[sample_index], off);
     for (int b = 0; b < n; b++)
         for (int k = off[b]; k < off[b + 1]; k++) t->band_of_short[k] = (uint8_t)b;
+    static_assert(offsetof(aacg_tables, tw512) == 4 * AACG_TAB_OFF_TW512, "table map");
+    static_assert(offsetof(aacg_tables, tw64) == 4 * AACG_TAB_OFF_TW64, "table map");
+    static_assert(offsetof(aacg_tables, sincos_short) == 4 * AACG_TAB_OFF_SINCOS_SHORT, "table map");
+    static_assert(offsetof(aacg_tables, win_long) == 4 * AACG_TAB_OFF_WIN_LONG, "table map");
+    static_assert(offsetof(aacg_tables, win_short) == 4 * AACG_TAB_OFF_WIN_SHORT, "table map");
+    static_assert(offsetof(aacg_tables, sf) == 4 * AACG_TAB_OFF_SF, "table map");
+    static_assert(offsetof(aacg_tables, iq_small) == 4 * AACG_TAB_OFF_IQ_SMALL, "table map");
+    static_assert(offsetof(aacg_tables, band_of_long) == 4 * AACG_TAB_OFF_BAND_LONG, "table map");
+    static_assert(offsetof(aacg_tables, band_of_short) == 4 * AACG_TAB_OFF_BAND_SHORT, "table map");
+    static_assert(offsetof(aacg_tables, iq) == 4 * AACG_TAB_QUANT_FLOATS, "table map");
+    static_assert(AACG_LDS_BYTES_QUANT <= 160 * 1024, "LDS budget of one CU");
     return AACG_OK;
 }

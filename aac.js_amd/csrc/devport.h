@@ -24,7 +24,9 @@
 
 typedef float2 dpf2;
 typedef float4 dpf4;
+typedef int4   dpi4;
 
+DP_DEVICE int dp_tid()   { return (int)threadIdx.x; }
 DP_DEVICE int dp_lane()  { return (int)(threadIdx.x & 63u); }
 DP_DEVICE int dp_wave()  { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 DP_DEVICE int dp_block() { return (int)blockIdx.x; }

@@ -41,7 +41,7 @@ extern "C" {
 #define AACG_FRAME_LEN      1024   /* decoder.js:86 frameLength                       */
 #define AACG_MAX_SECTIONS   120    /* ics.js:49 MAX_SECTIONS (bandTypes/scaleFactors) */
 #define AACG_MAX_CHANNELS   8
-#define AACG_RUN_FRAMES     8      /* frames per workgroup run        */
+#define AACG_RUN_FRAMES     16     /* frames per workgroup run        */
 
 /* ---- status codes ------------------------------------------------------------ */
 enum {

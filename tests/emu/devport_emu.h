@@ -22,6 +22,7 @@
 
 struct alignas(8)  dpf2 { float x, y; };
 struct alignas(16) dpf4 { float x, y, z, w; };
+struct alignas(16) dpi4 { int x, y, z, w; };
 
 struct emu_wave {
     pthread_barrier_t bar;
@@ -39,6 +40,7 @@ struct emu_lane_ctx {
 };
 extern thread_local emu_lane_ctx g_emu;
 
+DP_DEVICE int dp_tid()   { return g_emu.wave * 64 + g_emu.lane; }
 DP_DEVICE int dp_lane()  { return g_emu.lane; }
 DP_DEVICE int dp_wave()  { return g_emu.wave; }
 DP_DEVICE int dp_block() { return g_emu.b->block_id; }

@@ -18,6 +18,7 @@ struct launch_arg {
     emu_lane_ctx ctx;
     const aacg_kparams* P;
     int kind;     /* 0 f32 run, 1 quant run, 2 spectral */
+    int n_units;
 };
 
 void* lane_main(void* p)
@@ -26,11 +27,11 @@ void* lane_main(void* p)
     g_emu = a->ctx;
     if (a->kind == 0)      imdct_run_body<AACG_INPUT_SPEC_F32>(*a->P);
     else if (a->kind == 1) imdct_run_body<AACG_INPUT_QUANT_I16>(*a->P);
-    else                   spectral_body(*a->P);
+    else                   spectral_body(*a->P, a->n_units);
     return nullptr;
 }
 
-void launch(const aacg_kparams& P, int kind, int grid, int waves, size_t lds_bytes)
+void launch(const aacg_kparams& P, int kind, int grid, int waves, size_t lds_bytes, int n_units = 0)
 {
     const int threads = waves * 64;
     std::vector<emu_wave> wv((size_t)waves);
@@ -51,6 +52,7 @@ void launch(const aacg_kparams& P, int kind, int grid, int waves, size_t lds_byt
             args[(size_t)t].ctx = emu_lane_ctx{t & 63, t >> 6, &wv[(size_t)(t >> 6)], &blk};
             args[(size_t)t].P = &P;
             args[(size_t)t].kind = kind;
+            args[(size_t)t].n_units = n_units;
             pthread_create(&tid[(size_t)t], &attr, lane_main, &args[(size_t)t]);
         }
         for (int t = 0; t < threads; t++) pthread_join(tid[(size_t)t], nullptr);
@@ -115,9 +117,10 @@ int emu_decode(int input_kind, int sample_index, int max_streams, int max_channe
     if (ph.zero_fill) std::memset(pcm, 0, n_pcm_floats * sizeof(float));
     aacg_kparams P;
     std::memset(&P, 0, sizeof P);
-    P.units = units; P.runs = ph.runs.data(); P.coeffs = coeffs; P.meta = meta; P.pcm = pcm;
+    P.units = ph.units.data(); P.runs = ph.runs.data(); P.coeffs = coeffs; P.meta = meta; P.pcm = pcm;
     P.overlap = overlap_pool; P.tab = &g_tab; P.flip = 0; P.n_runs = (int32_t)ph.runs.size();
-    launch(P, input_kind == AACG_INPUT_QUANT_I16 ? 1 : 0, (int)ph.runs.size(), AACG_WG_WAVES, AACG_WG_LDS_BYTES);
+    launch(P, input_kind == AACG_INPUT_QUANT_I16 ? 1 : 0, (int)ph.runs.size(), AACG_WG_WAVES,
+           input_kind == AACG_INPUT_QUANT_I16 ? AACG_LDS_BYTES_QUANT : AACG_LDS_BYTES_F32);
     for (auto& c : ph.chains)
         for (int k = 0; k < c.n_ch; k++) parity[(size_t)c.stream * (size_t)max_channels + c.channel + k] ^= 1;
     return AACG_OK;
@@ -127,10 +130,14 @@ int emu_spectral(int sample_index, const aacg_unit_desc* units, uint32_t n_units
                  const void* coeffs, const aacg_band_meta* meta, float* spec_out)
 {
     if (g_tab_index != sample_index) { int rc = aacg_build_tables(sample_index, &g_tab, nullptr); if (rc) return rc; g_tab_index = sample_index; }
+    aacg_plan_host ph;
+    int rc = aacg_plan_build(units, n_units, sample_index, 1 << 16, 8, nullptr, &ph, &g_err);
+    if (rc) return rc;
     aacg_kparams P;
     std::memset(&P, 0, sizeof P);
-    P.units = units; P.coeffs = coeffs; P.meta = meta; P.spec_out = spec_out; P.tab = &g_tab;
-    launch(P, 2, (int)n_units, 1, 1024 * 4 + 512);
+    P.units = ph.units.data(); P.coeffs = coeffs; P.meta = meta; P.spec_out = spec_out; P.tab = &g_tab;
+    launch(P, 2, (int)((n_units + AACG_WG_WAVES - 1) / AACG_WG_WAVES), AACG_WG_WAVES,
+           (AACG_TAB_QUANT_FLOATS + AACG_WG_WAVES * 512) * 4, (int)n_units);
     return AACG_OK;
 }
 

@@ -9,7 +9,7 @@ import numpy as np
 import orc
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-RUN_DTYPE = np.dtype([("pred_unit", "<i4"), ("n_units", "<i4"), ("unit", "<i4", (8,)),
+RUN_DTYPE = np.dtype([("pred_unit", "<i4"), ("n_units", "<i4"), ("unit", "<i4", (16,)),
                       ("ov_a", "<i4", (2,)), ("ov_b", "<i4", (2,)), ("is_last", "<i4"), ("reserved", "<i4")])
 
 
