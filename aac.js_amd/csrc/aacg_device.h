@@ -50,11 +50,11 @@ struct aacg_tables {
 #define AACG_TAB_QUANT_FLOATS     (AACG_TAB_OFF_BAND_SHORT + 32)
 
 /* ---- LDS map of the run kernel -------------------------------------------------------- */
-/* [tables][slot 0] ... [slot 15]; slot = tail[0] (1024 f32) | tail[1] = work area (1152 f32):
- * the work area holds, in turn, the staged spectrum (natural order), the FFT transposes
- * (576 complex, padded) and finally the second channel's tail. */
-#define AACG_WORK_FLOATS  1152
-#define AACG_SLOT_FLOATS  (1024 + AACG_WORK_FLOATS)
+/* [tables][slot 0] ... [slot 15]; slot = two 1024-float areas, one per channel.  An area
+ * holds, in turn, the channel's staged spectrum (natural order), its FFT transposes
+ * (512 complex, XOR-swizzled instead of padded) and finally its windowed tail, which the
+ * next wave reads after the workgroup barrier. */
+#define AACG_SLOT_FLOATS  2048
 #define AACG_LDS_FLOATS(tab_floats) ((tab_floats) + AACG_WG_WAVES * AACG_SLOT_FLOATS)
 #define AACG_LDS_BYTES_F32    (4 * AACG_LDS_FLOATS(AACG_TAB_F32_FLOATS))
 #define AACG_LDS_BYTES_QUANT  (4 * AACG_LDS_FLOATS(AACG_TAB_QUANT_FLOATS))
@@ -86,6 +86,7 @@ struct aacg_kparams {
     const aacg_tables*    tab;
     int32_t               flip;       /* 0/1: swap ov_a and ov_b (plan reuse, see aacg_engine.hip) */
     int32_t               n_runs;
+    int32_t               ablate;     /* profiling only (env AACG_ABLATE): 1 skip IMDCT, 2 skip PCM stores, 4 skip spectrum loads */
 };
 
 #endif

@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -42,6 +43,7 @@ struct aacg_engine {
     void*  d_coeffs = nullptr;  size_t coeffs_cap = 0;
     aacg_band_meta* d_meta = nullptr; size_t meta_cap = 0;
     float* d_pcm = nullptr;     size_t pcm_cap = 0;
+    int ablate = 0;                         /* profiling knob, env AACG_ABLATE (see aacg_device.h); 0 in normal use */
     std::string err;
 };
 
@@ -121,6 +123,7 @@ int aacg_create(const aacg_config* cfg, aacg_engine** out)
         return AACG_ERR_NO_DEVICE;
     }
     e->parity.assign((size_t)cfg->max_streams * (size_t)cfg->max_channels, 0);
+    if (const char* a = std::getenv("AACG_ABLATE")) e->ablate = std::atoi(a);
     *out = e;
     return AACG_OK;
 }
@@ -264,6 +267,7 @@ int aacg_decode_device(aacg_engine* e, aacg_plan* p, const void* d_coeffs, const
     P.units = p->d_units; P.runs = p->d_runs; P.coeffs = d_coeffs; P.meta = d_meta; P.pcm = d_pcm;
     P.overlap = e->d_overlap; P.spec_out = nullptr; P.tab = e->d_tab;
     P.flip = (int32_t)(p->launches & 1u); P.n_runs = (int32_t)p->h.runs.size();
+    P.ablate = e->ablate;
     const dim3 grid((unsigned)p->h.runs.size()), block(AACG_WG_THREADS);
     if (quant) hipLaunchKernelGGL(aacg_imdct_run_quant, grid, block, AACG_LDS_BYTES_QUANT, s, P);
     else       hipLaunchKernelGGL(aacg_imdct_run_f32, grid, block, AACG_LDS_BYTES_F32, s, P);
