@@ -10,7 +10,8 @@ import os
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-LIB_PATH = os.path.join(ROOT, "aac.js_amd", "csrc", "libaacgpu.so")
+# AACGPU_LIB: A/B another build of the same ABI (tools/ab.sh); default is the in-tree build
+LIB_PATH = os.environ.get("AACGPU_LIB") or os.path.join(ROOT, "aac.js_amd", "csrc", "libaacgpu.so")
 
 INPUT_SPEC_F32, INPUT_QUANT_I16 = 0, 1
 ERR_NAMES = {0: "OK", -1: "INVALID_ARG", -2: "NO_DEVICE", -3: "OUT_OF_MEMORY", -4: "CAPACITY",
