@@ -440,27 +440,35 @@ DP_DEVICE int band_index(const float* tab, const chan_ctx& cc, int pos)
     return sfb < cc.max_sfb ? g * cc.max_sfb + sfb : -1;
 }
 
-DP_DEVICE float dequant_one(const float* tab, const aacg_tables* T, int q, float sf)
+/* |q|^(4/3) * sign(q) * sf for four coefficients packed as two dwords of int16 pairs, branch-free:
+ * magnitudes below 512 come from the LDS copy of IQ_TABLE; `big` collects the magnitudes so that the
+ * caller can patch the rare larger ones afterwards.  q == 0 gives -0 like ics.js:251; an uncoded,
+ * ZERO or INTENSITY band gives +0 (ics.js:222-227). */
+DP_DEVICE void dequant4(const float* tab, bool live, float sf, int p01, int p23, float (&x)[4], int& big)
 {
-    int a = q < 0 ? -q : q;
-    float v;
-    if (a < 512) v = tab[AACG_TAB_OFF_IQ_SMALL + a];
-    else         v = T->iq[a > 8191 ? 8191 : a];      /* rare; IQ_TABLE[8191..] is undefined in JS -> NaN */
-    return (q > 0 ? v : -v) * sf;                     /* q == 0 gives -0 like ics.js:251 */
+    const int q[4] = {(int)(short)(p01 & 0xffff), p01 >> 16, (int)(short)(p23 & 0xffff), p23 >> 16};
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        const int a = q[e] < 0 ? -q[e] : q[e];
+        big |= a;
+        const float v = tab[AACG_TAB_OFF_IQ_SMALL + (a > 511 ? 511 : a)];
+        const float sv = q[e] > 0 ? v : -v;
+        x[e] = live ? sv * sf : 0.0f;
+    }
 }
 
-/* four coefficients packed as two dwords of int16 pairs */
-DP_DEVICE void dequant4(const float* tab, const aacg_tables* T, int bflags, float sf, int p01, int p23, float (&x)[4])
+/* the rare magnitudes >= 512: full IQ_TABLE in global memory; [8191] = NaN like the JS out-of-range read */
+DP_DEVICE void dequant4_big(const aacg_tables* T, bool live, float sf, int p01, int p23, float (&x)[4])
 {
-    const int bt = bflags & 15;
-    if (bflags < 0 || bt == AACG_ZERO_BT || bt >= AACG_NOISE_BT) {   /* uncoded / ZERO / INTENSITY -> +0 (ics.js:222-227); NOISE: DESIGN.md */
-        x[0] = x[1] = x[2] = x[3] = 0.0f;
-        return;
+    const int q[4] = {(int)(short)(p01 & 0xffff), p01 >> 16, (int)(short)(p23 & 0xffff), p23 >> 16};
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        const int a = q[e] < 0 ? -q[e] : q[e];
+        if (live && a >= 512) {
+            const float v = T->iq[a > 8191 ? 8191 : a];
+            x[e] = (q[e] > 0 ? v : -v) * sf;
+        }
     }
-    x[0] = dequant_one(tab, T, (int)(short)(p01 & 0xffff), sf);
-    x[1] = dequant_one(tab, T, p01 >> 16, sf);
-    x[2] = dequant_one(tab, T, (int)(short)(p23 & 0xffff), sf);
-    x[3] = dequant_one(tab, T, p23 >> 16, sf);
 }
 
 /* Produces xl / xr[16]: element 8 i + e is coefficient 8 lane + 512 i + e of the left / right
@@ -485,46 +493,72 @@ DP_DEVICE void spectral_quant(const aacg_kparams& P, const float* tab, const aac
     prepare_bands(tab, P.meta + u->meta_offset, n_ch, bt);
     dp_wave_sync();
 
-    const bool ms_on = n_ch == 2 && (u->flags & AACG_UNIT_COMMON_WINDOW) && (u->flags & AACG_UNIT_MASK_PRESENT);
+    const bool two = n_ch == 2;
+    const bool ms_on = two && (u->flags & AACG_UNIT_COMMON_WINDOW) && (u->flags & AACG_UNIT_MASK_PRESENT);
     const bool mask  = (u->flags & AACG_UNIT_MASK_PRESENT) != 0;
     const int* bf = (const int*)bt + 256;
+
+    /* per 4-coefficient group (bands are multiples of 4 wide): what MS / IS need later */
+    bool  g_ms[4], g_is[4];
+    float g_isc[4];
+    bool  liveL[4], liveR[4];
+    float sfL[4], sfR[4];
+    int big = 0;
 #pragma unroll
-    for (int i = 0; i < 2; i++) {
+    for (int k = 0; k < 4; k++) {
+        const int i = k >> 1, h = k & 1;
+        const int pos = 8 * lane + 512 * i + 4 * h;
+        const int idxL = band_index(tab, ccL, pos);
+        const int iL = idxL < 0 ? 0 : idxL;
+        const int fL = bf[iL];
+        const int btL = fL & 15;
+        liveL[k] = idxL >= 0 && btL != AACG_ZERO_BT && btL < AACG_NOISE_BT;
+        sfL[k] = bt[iL];
+        dequant4(tab, liveL[k], sfL[k], h ? ql[i].z : ql[i].x, h ? ql[i].w : ql[i].y, *(float (*)[4])&xl[4 * k], big);
+
+        const int idxR = band_index(tab, ccR, pos);
+        const int iR = idxR < 0 ? 0 : idxR;
+        const int fR = bf[128 + iR];
+        const int btR = fR & 15;
+        liveR[k] = two && idxR >= 0 && btR != AACG_ZERO_BT && btR < AACG_NOISE_BT;
+        sfR[k] = bt[128 + iR];
+        dequant4(tab, liveR[k], sfR[k], h ? qr[i].z : qr[i].x, h ? qr[i].w : qr[i].y, *(float (*)[4])&xr[4 * k], big);
+
+        /* decoder.js:295-296,393: MS needs commonWindow && maskPresent && ms_used[idx] && both band types < NOISE
+         * (idx on the left channel's grid; with a common window it is the right channel's too) */
+        g_ms[k] = ms_on && idxL >= 0 && (fL & AACG_BF_MS) && btL < AACG_NOISE_BT && (bf[128 + iL] & 15) < AACG_NOISE_BT;
+        /* decoder.js:353-368: right = left * (c * sfR) on the right channel's intensity bands */
+        g_is[k] = two && idxR >= 0 && btR >= AACG_INTENSITY_BT2;
+        bool neg = btR == AACG_INTENSITY_BT2;
+        if (mask && (bf[iR] & AACG_BF_MS)) neg = !neg;
+        g_isc[k] = neg ? -sfR[k] : sfR[k];
+    }
+
+    if (dp_any(big >= 512)) {                          /* escape-coded magnitudes: rare */
 #pragma unroll
-        for (int h = 0; h < 2; h++) {
-            const int pos = 8 * lane + 512 * i + 4 * h;
-            const int idxL = band_index(tab, ccL, pos);
-            const int fL = idxL < 0 ? -1 : bf[idxL];
-            const float sL = idxL < 0 ? 0.0f : bt[idxL];
-            float a[4], b[4];
-            dequant4(tab, P.tab, fL, sL, h ? ql[i].z : ql[i].x, h ? ql[i].w : ql[i].y, a);
-            if (n_ch == 2) {
-                const int idxR = band_index(tab, ccR, pos);
-                const int fR = idxR < 0 ? -1 : bf[128 + idxR];
-                const float sR = idxR < 0 ? 0.0f : bt[128 + idxR];
-                dequant4(tab, P.tab, fR, sR, h ? qr[i].z : qr[i].x, h ? qr[i].w : qr[i].y, b);
-                /* decoder.js:295-296,393: MS needs commonWindow && maskPresent && ms_used[idx] && both band types < NOISE
-                 * (idx from the left channel's grid; with a common window it is the right channel's too) */
-                if (ms_on && idxL >= 0 && (fL & AACG_BF_MS) && (fL & 15) < AACG_NOISE_BT && (bf[128 + idxL] & 15) < AACG_NOISE_BT) {
-#pragma unroll
-                    for (int e = 0; e < 4; e++) { const float t = a[e] - b[e]; a[e] = a[e] + b[e]; b[e] = t; }
-                }
-                /* decoder.js:353-368: right = left * (c * sfR) on the right channel's intensity bands */
-                if (idxR >= 0 && (fR & 15) >= AACG_INTENSITY_BT2) {
-                    bool neg = (fR & 15) == AACG_INTENSITY_BT2;
-                    if (mask && (bf[idxR] & AACG_BF_MS)) neg = !neg;
-                    const float scale = neg ? -sR : sR;
-#pragma unroll
-                    for (int e = 0; e < 4; e++) b[e] = a[e] * scale;
-                }
-            } else {
-                b[0] = b[1] = b[2] = b[3] = 0.0f;
-            }
-#pragma unroll
-            for (int e = 0; e < 4; e++) { xl[8 * i + 4 * h + e] = a[e]; xr[8 * i + 4 * h + e] = b[e]; }
+        for (int k = 0; k < 4; k++) {
+            const int i = k >> 1, h = k & 1;
+            dequant4_big(P.tab, liveL[k], sfL[k], h ? ql[i].z : ql[i].x, h ? ql[i].w : ql[i].y, *(float (*)[4])&xl[4 * k]);
+            dequant4_big(P.tab, liveR[k], sfR[k], h ? qr[i].z : qr[i].x, h ? qr[i].w : qr[i].y, *(float (*)[4])&xr[4 * k]);
         }
     }
-    dp_wave_sync();                                    /* band table dead: the work area may be overwritten */
+
+    if (two) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                float a = xl[4 * k + e], b = xr[4 * k + e];
+                const float sum = a + b, dif = a - b;
+                a = g_ms[k] ? sum : a;
+                b = g_ms[k] ? dif : b;
+                const float is = a * g_isc[k];
+                b = g_is[k] ? is : b;
+                xl[4 * k + e] = a; xr[4 * k + e] = b;
+            }
+        }
+    }
+    dp_wave_sync();                                    /* band table dead: the area may be overwritten */
 }
 
 /* registers (natural order, 8 lane + 512 i + e) -> work[0..1023] */

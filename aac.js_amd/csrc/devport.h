@@ -54,6 +54,8 @@ extern __shared__ __attribute__((aligned(16))) unsigned char dp_lds_raw[];
 DP_DEVICE unsigned char* dp_lds() { return dp_lds_raw; }
 
 DP_DEVICE float dp_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+/* true in every lane if the predicate holds in any lane of the wave */
+DP_DEVICE bool dp_any(bool p) { return __any(p) != 0; }
 /* hide a value from common-subexpression elimination: a table load behind it is re-issued
  * (an L1 hit) instead of its result being held in VGPRs across the whole FFT */
 DP_DEVICE int dp_opaque(int v) { asm volatile("" : "+v"(v)); return v; }

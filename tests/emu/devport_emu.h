@@ -58,6 +58,16 @@ DP_DEVICE void dp_shfl(float (&v)[N], int src)
     pthread_barrier_wait(&g_emu.w->bar);
 }
 
+DP_DEVICE bool dp_any(bool p)
+{
+    g_emu.w->shfl[g_emu.lane][0] = p ? 1.0f : 0.0f;
+    pthread_barrier_wait(&g_emu.w->bar);
+    bool r = false;
+    for (int i = 0; i < 64; i++) r = r || g_emu.w->shfl[i][0] != 0.0f;
+    pthread_barrier_wait(&g_emu.w->bar);
+    return r;
+}
+
 DP_DEVICE unsigned char* dp_lds() { return g_emu.b->lds; }
 DP_DEVICE float dp_fma(float a, float b, float c) { return fmaf(a, b, c); }
 DP_DEVICE float dp_nan() { return NAN; }
