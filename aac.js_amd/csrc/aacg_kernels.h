@@ -78,12 +78,29 @@ DP_DEVICE cpx lds_get(const float* base, int idx)
 /* ------------------------------------------------------------------------------------ */
 /* table staging: global (L2) -> LDS, once per workgroup                                   */
 /* ------------------------------------------------------------------------------------ */
-DP_DEVICE void stage_tables(const aacg_tables* T, float* lds, int n_floats)
+/* Split in two so that the table loads are issued BEFORE the wave's own spectrum loads: vector
+ * loads return in order, so the LDS copy (which waits for the table data only) does not wait for
+ * the spectrum, and the spectrum keeps flying across the workgroup barrier. */
+DP_DEVICE void stage_tables_load(const aacg_tables* T, int n_floats, dpf4& t0, dpf4& t1)
 {
     const dpf4* src = (const dpf4*)T;
+    const int n4 = n_floats >> 2, tid = dp_tid();
+    const int i1 = tid + AACG_WG_THREADS;
+    t0 = src[tid < n4 ? tid : n4 - 1];                 /* clamped: unconditional loads, conditional stores */
+    t1 = src[i1 < n4 ? i1 : n4 - 1];
+}
+DP_DEVICE void stage_tables_store(float* lds, int n_floats, const dpf4& t0, const dpf4& t1)
+{
     dpf4* dst = (dpf4*)lds;
-    const int n4 = n_floats >> 2;
-    for (int i = dp_tid(); i < n4; i += AACG_WG_THREADS) dst[i] = src[i];
+    const int n4 = n_floats >> 2, tid = dp_tid();
+    if (tid < n4) dst[tid] = t0;
+    if (tid + AACG_WG_THREADS < n4) dst[tid + AACG_WG_THREADS] = t1;
+}
+DP_DEVICE void stage_tables(const aacg_tables* T, float* lds, int n_floats)
+{
+    dpf4 t0, t1;
+    stage_tables_load(T, n_floats, t0, t1);
+    stage_tables_store(lds, n_floats, t0, t1);
 }
 
 /* ------------------------------------------------------------------------------------ */
@@ -405,19 +422,45 @@ DP_DEVICE void filter_unit(const float* tab, const aacg_unit_desc* u, int n_ch, 
 
 /* Per-wave band table in LDS (in the work area, before the spectrum is staged):
  * scale[c][128] f32 at bt + 0 / + 128, flags[c][128] i32 at bt + 256 / + 384. */
-DP_DEVICE void prepare_bands(const float* tab, const aacg_band_meta* meta, int n_ch, float* bt)
+struct quant_regs { dpi4 ql[2], qr[2]; unsigned mw[2][2]; };
+
+/* the unit's quantised spectra (16 bytes per lane per load) and raw band words, issued early */
+DP_DEVICE void quant_load(const aacg_kparams& P, const aacg_unit_desc* u, int n_ch, quant_regs& r)
 {
     const int lane = dp_lane();
-    for (int c = 0; c < n_ch; c++) {
+    const int16_t* q0 = (const int16_t*)P.coeffs + (size_t)u->coef_offset * 1024u;
+    const aacg_band_meta* meta = P.meta + u->meta_offset;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        r.ql[i] = *(const dpi4*)(q0 + 8 * lane + 512 * i);
+        if (n_ch == 2) r.qr[i] = *(const dpi4*)(q0 + 1024 + 8 * lane + 512 * i);
+        else           { r.qr[i].x = r.qr[i].y = r.qr[i].z = r.qr[i].w = 0; }
+    }
+#pragma unroll
+    for (int c = 0; c < 2; c++)
 #pragma unroll
         for (int h = 0; h < 2; h++) {
             const int b = lane + 64 * h;
-            if (b < AACG_MAX_SECTIONS) {
-                const unsigned wd = meta[c].band[b];
-                float sf = tab[AACG_TAB_OFF_SF + (wd & AACG_META_SF_MASK)];
-                if (wd & AACG_META_NEGATE) sf = -sf;
-                bt[c * 128 + b] = sf;
-                ((int*)bt)[256 + c * 128 + b] = (int)(wd >> AACG_META_BT_SHIFT) | ((wd & AACG_META_MS_USED) ? AACG_BF_MS : 0);
+            r.mw[c][h] = (c < n_ch && b < AACG_MAX_SECTIONS) ? meta[c].band[b] : 0u;
+        }
+}
+
+DP_DEVICE void prepare_bands(const float* tab, const quant_regs& r, int n_ch, float* bt)
+{
+    const int lane = dp_lane();
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        if (c < n_ch) {
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int b = lane + 64 * h;
+                if (b < AACG_MAX_SECTIONS) {
+                    const unsigned wd = r.mw[c][h];
+                    float sf = tab[AACG_TAB_OFF_SF + (wd & AACG_META_SF_MASK)];
+                    if (wd & AACG_META_NEGATE) sf = -sf;
+                    bt[c * 128 + b] = sf;
+                    ((int*)bt)[256 + c * 128 + b] = (int)(wd >> AACG_META_BT_SHIFT) | ((wd & AACG_META_MS_USED) ? AACG_BF_MS : 0);
+                }
             }
         }
     }
@@ -474,23 +517,16 @@ DP_DEVICE void dequant4_big(const aacg_tables* T, bool live, float sf, int p01, 
 /* Produces xl / xr[16]: element 8 i + e is coefficient 8 lane + 512 i + e of the left / right
  * (or single) channel after dequant, MS and IS. */
 DP_DEVICE void spectral_quant(const aacg_kparams& P, const float* tab, const aacg_unit_desc* u, int n_ch,
-                              float* bt, float (&xl)[16], float (&xr)[16])
+                              const quant_regs& qreg, float* bt, float (&xl)[16], float (&xr)[16])
 {
     const int lane = dp_lane();
-    const int16_t* q0 = (const int16_t*)P.coeffs + (size_t)u->coef_offset * 1024u;
     chan_ctx ccL, ccR;
     ccL.cls = u->ch[0].window_sequence == AACG_EIGHT_SHORT_SEQUENCE; ccL.max_sfb = u->ch[0].max_sfb; ccL.gmap = u->reserved1[0];
     ccR.cls = u->ch[1].window_sequence == AACG_EIGHT_SHORT_SEQUENCE; ccR.max_sfb = u->ch[1].max_sfb; ccR.gmap = u->reserved1[1];
 
-    /* issue the coefficient loads first (16 bytes per lane), then build the band table while they fly */
-    dpi4 ql[2], qr[2];
-#pragma unroll
-    for (int i = 0; i < 2; i++) {
-        ql[i] = *(const dpi4*)(q0 + 8 * lane + 512 * i);
-        if (n_ch == 2) qr[i] = *(const dpi4*)(q0 + 1024 + 8 * lane + 512 * i);
-        else           { qr[i].x = qr[i].y = qr[i].z = qr[i].w = 0; }
-    }
-    prepare_bands(tab, P.meta + u->meta_offset, n_ch, bt);
+    const dpi4 (&ql)[2] = qreg.ql;
+    const dpi4 (&qr)[2] = qreg.qr;
+    prepare_bands(tab, qreg, n_ch, bt);
     dp_wave_sync();
 
     const bool two = n_ch == 2;
@@ -678,6 +714,7 @@ DP_DEVICE void imdct_run_body(const aacg_kparams& P)
     const float* tab = lds;
     float* slots = lds + TAB_FLOATS;
     float* slot = slots + wave * AACG_SLOT_FLOATS;     /* area of channel 0 | area of channel 1 */
+    int* flags = (int*)(slots + AACG_WG_WAVES * AACG_SLOT_FLOATS);
 
     const int n_units = run->n_units;
     const bool has_pred = run->pred_unit >= 0;
@@ -687,63 +724,65 @@ DP_DEVICE void imdct_run_body(const aacg_kparams& P)
     ui = dp_uniform(ui);
     const bool is_pred_wave = has_pred && wave == 0;
 
-    float hx0[8], hy0[8], hx1[8], hy1[8];
-    const aacg_unit_desc* u = P.units;
-    int n_ch = 0, cls0 = 0, cls1 = 0;
+    /* Earlier frames get the higher issue priority: they finish first and their PCM stores overlap
+     * the later waves' arithmetic.  A wave only ever waits for the wave before it, whose priority is
+     * never lower, so a spinning consumer cannot starve its producer. */
+    dp_setprio(3 - (wave >> 2));
 
-    if (KIND == AACG_INPUT_QUANT_I16) {
-        float xl[16], xr[16];
-        stage_tables(P.tab, lds, TAB_FLOATS);
-        dp_block_sync();                               /* dequant needs the SF / IQ / band tables */
-        if (ui >= 0) {
-            u = P.units + ui;
-            n_ch = u->n_ch;
-            cls0 = u->ch[0].window_sequence == AACG_EIGHT_SHORT_SEQUENCE;
-            cls1 = u->ch[1].window_sequence == AACG_EIGHT_SHORT_SEQUENCE;
-            spectral_quant(P, tab, u, n_ch, slot + 1024, xl, xr);
+    float hx0[8], hy0[8], hx1[8], hy1[8];
+    const aacg_unit_desc* u = P.units + (ui >= 0 ? ui : 0);
+    const int n_ch = ui >= 0 ? u->n_ch : 0;
+    const int cls0 = u->ch[0].window_sequence == AACG_EIGHT_SHORT_SEQUENCE;
+    const int cls1 = u->ch[1].window_sequence == AACG_EIGHT_SHORT_SEQUENCE;
+
+    /* loads: tables first, then this wave's spectrum; only the tables are waited for before the barrier */
+    dpf4 tr0, tr1;
+    stage_tables_load(P.tab, TAB_FLOATS, tr0, tr1);
+    quant_regs qreg;
+    dpf4 xa[4], xb[4];
+    if (ui >= 0) {
+        if (KIND == AACG_INPUT_QUANT_I16) {
+            quant_load(P, u, n_ch, qreg);
+        } else if (!(P.ablate & 4)) {
+            const float* x = (const float*)P.coeffs + (size_t)u->coef_offset * 1024u;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                xa[i] = *(const dpf4*)(x + 4 * lane + 256 * i);
+                if (n_ch == 2) xb[i] = *(const dpf4*)(x + 1024 + 4 * lane + 256 * i);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; i++) { xa[i].x = xa[i].y = xa[i].z = xa[i].w = (float)lane; xb[i] = xa[i]; }
+        }
+    }
+    stage_tables_store(lds, TAB_FLOATS, tr0, tr1);
+    if (lane == 0) flags[wave] = 0;
+    dp_block_sync();                                   /* tables and flags are in LDS */
+
+    if (ui >= 0 && (P.ablate & 1) && KIND != AACG_INPUT_QUANT_I16) {
+#pragma unroll
+        for (int m = 0; m < 8; m++) { hx0[m] = xa[m & 3].x; hy0[m] = xa[m & 3].y; hx1[m] = xb[m & 3].z; hy1[m] = xb[m & 3].w; }
+    } else if (ui >= 0) {
+        if (KIND == AACG_INPUT_QUANT_I16) {
+            float xl[16], xr[16];
+            spectral_quant(P, tab, u, n_ch, qreg, slot + 1024, xl, xr);
             /* TNS would run here: identity as the reference executes it (tns.js:106,122) */
             stage_nat8(xl, slot);
             if (n_ch == 2) stage_nat8(xr, slot + 1024);
-            dp_wave_sync();
-            filter_unit(tab, u, n_ch, !is_pred_wave, slot, hx0, hy0, hx1, hy1);
-        }
-    } else {
-        /* spectra: 16-byte loads in natural order, issued before the table copy so both fly together */
-        dpf4 xa[4], xb[4];
-        if (ui >= 0) {
-            u = P.units + ui;
-            n_ch = u->n_ch;
-            cls0 = u->ch[0].window_sequence == AACG_EIGHT_SHORT_SEQUENCE;
-            cls1 = u->ch[1].window_sequence == AACG_EIGHT_SHORT_SEQUENCE;
-            const float* x = (const float*)P.coeffs + (size_t)u->coef_offset * 1024u;
-            if (!(P.ablate & 4)) {
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    xa[i] = *(const dpf4*)(x + 4 * lane + 256 * i);
-                    if (n_ch == 2) xb[i] = *(const dpf4*)(x + 1024 + 4 * lane + 256 * i);
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < 4; i++) { xa[i].x = xa[i].y = xa[i].z = xa[i].w = (float)lane; xb[i] = xa[i]; }
-            }
-        }
-        stage_tables(P.tab, lds, TAB_FLOATS);
-        dp_block_sync();
-        if (ui >= 0 && (P.ablate & 1)) {
-#pragma unroll
-            for (int m = 0; m < 8; m++) { hx0[m] = xa[m & 3].x; hy0[m] = xa[m & 3].y; hx1[m] = xb[m & 3].z; hy1[m] = xb[m & 3].w; }
-        } else if (ui >= 0) {
+        } else {
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 *(dpf4*)(slot + 4 * lane + 256 * i) = xa[i];
                 if (n_ch == 2) *(dpf4*)(slot + 1024 + 4 * lane + 256 * i) = xb[i];
             }
-            dp_wave_sync();
-            filter_unit(tab, u, n_ch, !is_pred_wave, slot, hx0, hy0, hx1, hy1);
         }
+        dp_wave_sync();
+        filter_unit(tab, u, n_ch, !is_pred_wave, slot, hx0, hy0, hx1, hy1);
     }
 
-    dp_block_sync();                                   /* every wave's tails are in its slot */
+    /* this wave's tails are complete in its slot: release them to the next wave */
+    dp_wave_sync();
+    if (lane == 0) dp_flag_set(&flags[wave], 1);
 
     if (ui >= 0 && !is_pred_wave && (P.ablate & 2)) {
         /* profiling: keep the values live without storing 8 KiB of PCM */
@@ -759,6 +798,7 @@ DP_DEVICE void imdct_run_body(const aacg_kparams& P)
             const float* ov1 = P.overlap + (P.flip ? run->ov_b[1] : run->ov_a[1]);
             epilogue(ov0, (int)(ov1 - ov0), u, n_ch, cls0, cls1, P.pcm, hx0, hy0, hx1, hy1);
         } else {
+            dp_flag_wait(&flags[wave - 1], 1);         /* the previous frame's tails (acquire) */
             epilogue(slot - AACG_SLOT_FLOATS, 1024, u, n_ch, cls0, cls1, P.pcm, hx0, hy0, hx1, hy1);
         }
         /* the chain's last frame in this launch: its tail is the new overlap state */
@@ -788,7 +828,9 @@ DP_DEVICE void spectral_body(const aacg_kparams& P, int n_units)
     const aacg_unit_desc* u = P.units + ui;
     const int n_ch = u->n_ch;
     float xl[16], xr[16];
-    spectral_quant(P, tab, u, n_ch, bt, xl, xr);
+    quant_regs qreg;
+    quant_load(P, u, n_ch, qreg);
+    spectral_quant(P, tab, u, n_ch, qreg, bt, xl, xr);
     float* out = P.spec_out + (size_t)u->coef_offset * 1024u;
 #pragma unroll
     for (int i = 0; i < 2; i++) {

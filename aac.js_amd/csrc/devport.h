@@ -42,6 +42,22 @@ DP_DEVICE void dp_wave_sync()
 }
 DP_DEVICE void dp_block_sync() { __syncthreads(); }
 
+/* wave -> wave hand-off inside one workgroup through an LDS word (all waves of a workgroup are
+ * resident, the producer never waits on its consumer).  Release/acquire at workgroup scope. */
+DP_DEVICE void dp_flag_set(int* flag, int v) { __hip_atomic_store(flag, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+DP_DEVICE void dp_flag_wait(int* flag, int v)
+{
+    while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != v) __builtin_amdgcn_s_sleep(2);
+}
+/* issue priority of this wave on its SIMD (0..3); s_setprio takes an immediate */
+DP_DEVICE void dp_setprio(int p)
+{
+    if (p >= 3) __builtin_amdgcn_s_setprio(3);
+    else if (p == 2) __builtin_amdgcn_s_setprio(2);
+    else if (p == 1) __builtin_amdgcn_s_setprio(1);
+    else __builtin_amdgcn_s_setprio(0);
+}
+
 /* v[i] <- lane `src`'s v[i]  (ds_bpermute_b32; no LDS storage involved) */
 template <int N>
 DP_DEVICE void dp_shfl(float (&v)[N], int src)

@@ -14,6 +14,7 @@
 
 #include <math.h>
 #include <pthread.h>
+#include <sched.h>
 #include <stdint.h>
 #include <stddef.h>
 
@@ -47,6 +48,9 @@ DP_DEVICE int dp_block() { return g_emu.b->block_id; }
 DP_DEVICE int dp_uniform(int v) { return v; }
 DP_DEVICE void dp_wave_sync()  { pthread_barrier_wait(&g_emu.w->bar); }
 DP_DEVICE void dp_block_sync() { pthread_barrier_wait(&g_emu.b->bar); }
+DP_DEVICE void dp_flag_set(int* flag, int v) { __atomic_store_n(flag, v, __ATOMIC_RELEASE); }
+DP_DEVICE void dp_flag_wait(int* flag, int v) { while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != v) sched_yield(); }
+DP_DEVICE void dp_setprio(int) {}
 
 template <int N>
 DP_DEVICE void dp_shfl(float (&v)[N], int src)
