@@ -1,0 +1,205 @@
+/*
+ * aac.js_amd/js — JavaScript host of the MI355X AAC-LC synthesis engine.
+ *
+ * Keeps the serial work where aac.js has it (ADTS demux, raw_data_block parse, Huffman: CPU,
+ * JavaScript) and hands batches of parsed elements across the N-API layer (../napi) to the HIP
+ * kernels, while presenting the Aurora.js decoder plugin surface of the reference
+ * (src/decoder.js:29-216): init(), setCookie(buffer), readChunk() -> interleaved Float32Array.
+ *
+ * Own code throughout; nothing is imported from the reference.
+ */
+'use strict';
+const path = require('path');
+
+const INPUT_SPEC_F32 = 0, INPUT_QUANT_I16 = 1;
+const UNIT_BYTES = 64, META_WORDS = 120, FRAME = 1024;
+const SAMPLE_RATES = [96000, 88200, 64000, 48000, 44100, 32000, 24000, 22050, 16000, 12000, 11025, 8000, 7350];
+
+let addon = null;
+function loadAddon() {
+    if (addon) return addon;
+    addon = require(path.join(__dirname, '..', 'napi', 'aacgpu_napi.node'));
+    // fails loudly if the HIP library was not built: there is no CPU fallback in the product path
+    addon.load(process.env.AACGPU_LIB || path.join(__dirname, '..', 'csrc', 'libaacgpu.so'));
+    return addon;
+}
+
+/* ---- unit table packing: mirrors aacg_unit_desc / aacg_band_meta in include/aacgpu.h ---------- */
+function packChanInfo(view, off, ch) {
+    view.setUint8(off + 0, ch.windowSequence);
+    view.setUint8(off + 1, ch.windowShape);
+    view.setUint8(off + 2, ch.windowShapePrev | 0);   // aac.js always has 0 here (fresh ICSInfo per frame)
+    view.setUint8(off + 3, ch.maxSFB);
+    view.setUint8(off + 4, ch.groupLength.length);
+    for (let g = 0; g < ch.groupLength.length; g++) view.setUint8(off + 8 + g, ch.groupLength[g]);
+}
+
+/* units: [{stream, pcmOffset, channel, nOutCh, coefOffset, metaOffset, commonWindow, maskPresent, ch: [info, info?]}] */
+function packUnits(units) {
+    const buf = new ArrayBuffer(UNIT_BYTES * units.length), view = new DataView(buf);
+    units.forEach(function (u, i) {
+        const o = UNIT_BYTES * i;
+        view.setUint32(o + 0, u.stream, true);
+        view.setUint32(o + 4, u.pcmOffset, true);
+        view.setUint16(o + 8, u.channel, true);
+        view.setUint16(o + 10, u.nOutCh, true);
+        view.setUint8(o + 12, u.ch.length);
+        view.setUint8(o + 13, (u.commonWindow ? 1 : 0) | (u.maskPresent ? 2 : 0));
+        view.setUint32(o + 16, u.coefOffset, true);
+        view.setUint32(o + 20, u.metaOffset, true);
+        packChanInfo(view, o + 24, u.ch[0]);
+        if (u.ch.length > 1) packChanInfo(view, o + 40, u.ch[1]);
+    });
+    return new Uint8Array(buf);
+}
+
+function unpackUnits(bytes) {
+    const view = new DataView(bytes.buffer, bytes.byteOffset, bytes.byteLength), out = [];
+    function chan(off) {
+        const n = view.getUint8(off + 4), gl = [];
+        for (let g = 0; g < n; g++) gl.push(view.getUint8(off + 8 + g));
+        return { windowSequence: view.getUint8(off), windowShape: view.getUint8(off + 1), windowShapePrev: view.getUint8(off + 2),
+                 maxSFB: view.getUint8(off + 3), groupLength: gl };
+    }
+    for (let o = 0; o < bytes.byteLength; o += UNIT_BYTES) {
+        const nCh = view.getUint8(o + 12), flags = view.getUint8(o + 13);
+        const u = { stream: view.getUint32(o, true), pcmOffset: view.getUint32(o + 4, true), channel: view.getUint16(o + 8, true),
+                    nOutCh: view.getUint16(o + 10, true), coefOffset: view.getUint32(o + 16, true), metaOffset: view.getUint32(o + 20, true),
+                    commonWindow: !!(flags & 1), maskPresent: !!(flags & 2), ch: [chan(o + 24)] };
+        if (nCh > 1) u.ch.push(chan(o + 40));
+        out.push(u);
+    }
+    return out;
+}
+
+/* one 16-bit word per (group, sfb): sf index | negate<<9 | ms_used<<10 | bandType<<12 */
+function packBandWord(bandType, sfIndex, negate, msUsed) {
+    return (sfIndex & 0x1ff) | (negate ? 0x200 : 0) | (msUsed ? 0x400 : 0) | ((bandType & 15) << 12);
+}
+
+/* ---- engine wrapper ---------------------------------------------------------------------------- */
+function Engine(opts) {
+    opts = opts || {};
+    this.addon = loadAddon();
+    this.inputKind = opts.inputKind === undefined ? INPUT_QUANT_I16 : opts.inputKind;
+    this.handle = this.addon.create({ deviceOrdinal: opts.deviceOrdinal | 0, sampleIndex: opts.sampleIndex === undefined ? 3 : opts.sampleIndex,
+                                      maxStreams: opts.maxStreams || 1, maxChannels: opts.maxChannels || 2,
+                                      maxBatchUnits: opts.maxBatchUnits | 0, inputKind: this.inputKind });
+}
+Engine.prototype.decodeBatch = function (units, coeffs, meta, pcm) {
+    return this.addon.decodeBatch(this.handle, units, coeffs, meta || null, pcm);   // throws on error
+};
+Engine.prototype.resetStream = function (s) { this.addon.resetStream(this.handle, s); };
+Engine.prototype.getOverlap = function (s, c) { return this.addon.getOverlap(this.handle, s, c, new Float32Array(FRAME)); };
+Engine.prototype.setOverlap = function (s, c, v) { this.addon.setOverlap(this.handle, s, c, v); };
+
+/* ---- minimal MSB-first bit reader (for setCookie; the frame parser brings its own stream) ------- */
+function BitReader(bytes) { this.bytes = bytes; this.pos = 0; }
+BitReader.prototype.read = function (n) {
+    let v = 0;
+    for (let i = 0; i < n; i++, this.pos++) {
+        if ((this.pos >> 3) >= this.bytes.length) throw new Error('Insufficient data');
+        v = (v * 2) + ((this.bytes[this.pos >> 3] >> (7 - (this.pos & 7))) & 1);
+    }
+    return v;
+};
+BitReader.prototype.advance = function (n) { this.pos += n; };
+
+/*
+ * GpuAACDecoder — the plugin surface of aac.js's AACDecoder (src/decoder.js:49-216) on top of the engine.
+ *
+ *   init()                 format.floatingPoint = true                       (decoder.js:49-51)
+ *   setCookie(buffer)      AudioSpecificConfig -> this.config, channelsPerFrame; allocates the stream's
+ *                          filterbank state = resets the engine's stream slot  (decoder.js:53-113)
+ *   readChunk()            one frame of interleaved Float32Array(1024 * channels) in [-1, 1), or throws
+ *
+ * The serial bitstream parse is delegated to `frontend.parseFrame(decoder)`, which must return
+ *   { elements: [{ type: 'sce'|'lfe'|'cpe', commonWindow, maskPresent, ch: [chanInfo...] }],
+ *     q: Int16Array(1024 * nCh), meta: Uint16Array(120 * nCh) }        (channel order = element order)
+ * or null when no complete frame is buffered.  To batch without changing the surface, readChunk parses
+ * ahead every complete frame already buffered (up to `lookahead`), submits ONE batch, returns frame 0 and
+ * serves the rest from a queue; overlap state is only advanced by frames that parsed completely, as in
+ * the reference where process() runs after align() (decoder.js:200-201).
+ */
+function GpuAACDecoder(opts) {
+    opts = opts || {};
+    this.format = opts.format || {};
+    this.frontend = opts.frontend || null;
+    this.engine = opts.engine || null;
+    this.stream = opts.stream | 0;           // engine stream slot of this decoder instance
+    this.lookahead = opts.lookahead || 16;
+    this.queue = [];
+}
+GpuAACDecoder.prototype.init = function () { this.format.floatingPoint = true; };
+
+GpuAACDecoder.prototype.setCookie = function (buffer) {
+    const bytes = buffer.data || buffer, s = new BitReader(bytes), cfg = this.config = {};
+    cfg.profile = s.read(5);
+    if (cfg.profile === 31) cfg.profile = 32 + s.read(6);
+    cfg.sampleIndex = s.read(4);
+    if (cfg.sampleIndex === 0x0f) {
+        cfg.sampleRate = s.read(24);
+        const i = SAMPLE_RATES.indexOf(cfg.sampleRate);
+        if (i >= 0) cfg.sampleIndex = i;
+    } else {
+        cfg.sampleRate = SAMPLE_RATES[cfg.sampleIndex];
+    }
+    cfg.chanConfig = s.read(4);
+    this.format.channelsPerFrame = cfg.chanConfig;
+    if (cfg.profile !== 1 && cfg.profile !== 2 && cfg.profile !== 4)
+        throw new Error('AAC profile ' + cfg.profile + ' not supported.');
+    if (s.read(1)) throw new Error('frameLengthFlag not supported');
+    cfg.frameLength = FRAME;
+    if (s.read(1)) s.advance(14);
+    if (s.read(1)) { if (cfg.profile > 16) s.advance(3); s.advance(1); }
+    if (cfg.chanConfig === 0) throw new Error('PCE unimplemented');
+    if (!this.engine)
+        this.engine = new Engine({ sampleIndex: cfg.sampleIndex, maxStreams: this.stream + 1, maxChannels: cfg.chanConfig, inputKind: INPUT_QUANT_I16 });
+    this.engine.resetStream(this.stream);    // new FilterBank(false, chanConfig): zeroed overlaps (filter_bank.js:38-41)
+};
+
+/* elements of one parsed frame -> unit records; channel indices assigned in element order, elements beyond
+ * chanConfig channels dropped (decoder.js:233-247) */
+GpuAACDecoder.prototype.unitsOfFrame = function (frame, frameSlot, blockBase) {
+    const C = this.config.chanConfig, units = [];
+    let channel = 0, block = blockBase;
+    for (const e of frame.elements) {
+        const n = e.type === 'cpe' ? 2 : 1;
+        if (channel >= C) break;
+        if (e.gainPresent) throw new Error('Gain control not implemented');
+        units.push({ stream: this.stream, pcmOffset: frameSlot * FRAME * C, channel: channel, nOutCh: C, coefOffset: block, metaOffset: block,
+                     commonWindow: !!e.commonWindow, maskPresent: !!e.maskPresent, ch: e.ch });
+        channel += n; block += n;
+    }
+    return units;
+};
+
+GpuAACDecoder.prototype.readChunk = function () {
+    if (this.queue.length) return this.queue.shift();
+    if (this.config.profile === 1) throw new Error('Main prediction unimplemented');
+    if (this.config.profile === 4) throw new Error('LTP prediction unimplemented');
+    const C = this.config.chanConfig, frames = [];
+    while (frames.length < this.lookahead) {
+        let f = null;
+        try { f = this.frontend.parseFrame(this); } catch (err) { if (!frames.length) throw err; break; }   // underflow ends look-ahead
+        if (!f) break;
+        frames.push(f);
+    }
+    if (!frames.length) return null;
+    let nBlocks = 0;
+    for (const f of frames) nBlocks += f.q.length / FRAME;
+    const q = new Int16Array(nBlocks * FRAME), meta = new Uint16Array(nBlocks * META_WORDS);
+    let units = [], block = 0;
+    frames.forEach((f, slot) => {
+        units = units.concat(this.unitsOfFrame(f, slot, block));
+        q.set(f.q, block * FRAME); meta.set(f.meta, block * META_WORDS);
+        block += f.q.length / FRAME;
+    });
+    const pcm = new Float32Array(frames.length * FRAME * C);
+    this.engine.decodeBatch(packUnits(units), q, meta, pcm);
+    for (let i = 0; i < frames.length; i++) this.queue.push(pcm.slice(i * FRAME * C, (i + 1) * FRAME * C));   // caller owns each array
+    return this.queue.shift();
+};
+
+module.exports = { Engine, GpuAACDecoder, BitReader, packUnits, unpackUnits, packBandWord,
+                   INPUT_SPEC_F32, INPUT_QUANT_I16, UNIT_BYTES, META_WORDS, SAMPLE_RATES };

@@ -1,0 +1,192 @@
+/*
+ * aacgpu_napi.c — N-API (node_api.h, N-API <= v8) binding of the C ABI in include/aacgpu.h.
+ *
+ * This is the FFI layer the JavaScript host (aac.js_amd/js) uses in place of the reference's
+ * in-process  this.process(elements) + interleave  (src/decoder.js:201-215).  The addon itself is
+ * plain C (gcc); it dlopen()s libaacgpu.so, so it builds on machines without hipcc and fails
+ * loudly at load time if the HIP library is absent.  Non-zero status codes become thrown Errors,
+ * the convention Aurora's Decoder.decode() already expects from readChunk.
+ */
+#include <node_api.h>
+
+#include <dlfcn.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../include/aacgpu.h"
+
+static struct {
+    void* dl;
+    int  (*create)(const aacg_config*, aacg_engine**);
+    void (*destroy)(aacg_engine*);
+    const char* (*last_error)(const aacg_engine*);
+    int  (*abi_version)(void);
+    int  (*reset_stream)(aacg_engine*, uint32_t);
+    int  (*get_overlap)(aacg_engine*, uint32_t, uint32_t, float*);
+    int  (*set_overlap)(aacg_engine*, uint32_t, uint32_t, const float*);
+    int  (*decode_batch)(aacg_engine*, const aacg_unit_desc*, uint32_t, const void*, uint32_t,
+                         const aacg_band_meta*, uint32_t, float*, size_t);
+} L;
+
+#define CHECK(env, call) do { if ((call) != napi_ok) { napi_throw_error((env), NULL, "aacgpu: N-API call failed: " #call); return NULL; } } while (0)
+
+static napi_value fail(napi_env env, aacg_engine* e, int rc, const char* what)
+{
+    char msg[512];
+    snprintf(msg, sizeof msg, "aacgpu: %s failed (%d): %s", what, rc, e && L.last_error ? L.last_error(e) : "");
+    napi_throw_error(env, NULL, msg);
+    return NULL;
+}
+
+static int load_lib(napi_env env, const char* path)
+{
+    if (L.dl) return 1;
+    L.dl = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+    if (!L.dl) {
+        char msg[1024];
+        snprintf(msg, sizeof msg, "aacgpu: cannot load %s: %s (build it with hipcc --offload-arch=gfx950; there is no CPU fallback)", path, dlerror());
+        napi_throw_error(env, NULL, msg);
+        return 0;
+    }
+#define SYM(field, name) do { *(void**)&L.field = dlsym(L.dl, name); if (!L.field) { napi_throw_error(env, NULL, "aacgpu: missing symbol " name); return 0; } } while (0)
+    SYM(create, "aacg_create"); SYM(destroy, "aacg_destroy"); SYM(last_error, "aacg_last_error");
+    SYM(abi_version, "aacg_abi_version"); SYM(reset_stream, "aacg_reset_stream");
+    SYM(get_overlap, "aacg_get_overlap"); SYM(set_overlap, "aacg_set_overlap"); SYM(decode_batch, "aacg_decode_batch");
+#undef SYM
+    return 1;
+}
+
+static int get_i32(napi_env env, napi_value obj, const char* key, int32_t dflt)
+{
+    napi_value v; bool has = false; int32_t out = dflt;
+    if (napi_has_named_property(env, obj, key, &has) == napi_ok && has &&
+        napi_get_named_property(env, obj, key, &v) == napi_ok) napi_get_value_int32(env, v, &out);
+    return out;
+}
+
+static void engine_finalize(napi_env env, void* data, void* hint)
+{
+    (void)env; (void)hint;
+    if (data && L.destroy) L.destroy((aacg_engine*)data);
+}
+
+/* load(path) -> abi version */
+static napi_value js_load(napi_env env, napi_callback_info info)
+{
+    size_t argc = 1; napi_value argv[1]; char path[2048]; size_t n = 0; napi_value out;
+    CHECK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    CHECK(env, napi_get_value_string_utf8(env, argv[0], path, sizeof path, &n));
+    if (!load_lib(env, path)) return NULL;
+    CHECK(env, napi_create_int32(env, L.abi_version(), &out));
+    return out;
+}
+
+/* create({deviceOrdinal, sampleIndex, maxStreams, maxChannels, maxBatchUnits, inputKind}) -> external */
+static napi_value js_create(napi_env env, napi_callback_info info)
+{
+    size_t argc = 1; napi_value argv[1], out;
+    CHECK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    if (!L.dl) { napi_throw_error(env, NULL, "aacgpu: call load(path) first"); return NULL; }
+    aacg_config cfg;
+    memset(&cfg, 0, sizeof cfg);
+    cfg.abi_version = AACG_ABI_VERSION;
+    cfg.device_ordinal = get_i32(env, argv[0], "deviceOrdinal", 0);
+    cfg.sample_index = get_i32(env, argv[0], "sampleIndex", 3);
+    cfg.max_streams = get_i32(env, argv[0], "maxStreams", 1);
+    cfg.max_channels = get_i32(env, argv[0], "maxChannels", 2);
+    cfg.max_batch_units = get_i32(env, argv[0], "maxBatchUnits", 0);
+    cfg.input_kind = get_i32(env, argv[0], "inputKind", AACG_INPUT_QUANT_I16);
+    cfg.tns_mode = AACG_TNS_REFERENCE;
+    aacg_engine* e = NULL;
+    int rc = L.create(&cfg, &e);
+    if (rc) return fail(env, NULL, rc, "aacg_create (is a GPU visible?)");
+    CHECK(env, napi_create_external(env, e, engine_finalize, NULL, &out));
+    return out;
+}
+
+static aacg_engine* engine_of(napi_env env, napi_value v)
+{
+    void* p = NULL;
+    if (napi_get_value_external(env, v, &p) != napi_ok || !p) { napi_throw_error(env, NULL, "aacgpu: bad engine handle"); return NULL; }
+    return (aacg_engine*)p;
+}
+
+static int typed(napi_env env, napi_value v, napi_typedarray_type* type, size_t* len, void** data)
+{
+    napi_value ab; size_t off;
+    return napi_get_typedarray_info(env, v, type, len, data, &ab, &off) == napi_ok;
+}
+
+/* decodeBatch(engine, units:Uint8Array(64*n), coeffs:Int16Array|Float32Array, meta:Uint16Array|null, pcm:Float32Array) */
+static napi_value js_decode_batch(napi_env env, napi_callback_info info)
+{
+    size_t argc = 5; napi_value argv[5];
+    CHECK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    aacg_engine* e = engine_of(env, argv[0]);
+    if (!e) return NULL;
+    napi_typedarray_type tu, tc, tm, tp; size_t nu, nc, nm = 0, np; void *du, *dc, *dm = NULL, *dp;
+    if (!typed(env, argv[1], &tu, &nu, &du) || tu != napi_uint8_array || nu % sizeof(aacg_unit_desc)) {
+        napi_throw_type_error(env, NULL, "units must be a Uint8Array of 64-byte aacg_unit_desc records"); return NULL; }
+    if (!typed(env, argv[2], &tc, &nc, &dc) || (tc != napi_int16_array && tc != napi_float32_array) || nc % 1024) {
+        napi_throw_type_error(env, NULL, "coeffs must be an Int16Array or Float32Array, a multiple of 1024 long"); return NULL; }
+    napi_valuetype vt;
+    CHECK(env, napi_typeof(env, argv[3], &vt));
+    if (vt != napi_null && vt != napi_undefined) {
+        if (!typed(env, argv[3], &tm, &nm, &dm) || tm != napi_uint16_array || nm % AACG_MAX_SECTIONS) {
+            napi_throw_type_error(env, NULL, "meta must be a Uint16Array of 120-word aacg_band_meta records"); return NULL; }
+    }
+    if (!typed(env, argv[4], &tp, &np, &dp) || tp != napi_float32_array) {
+        napi_throw_type_error(env, NULL, "pcm must be a Float32Array"); return NULL; }
+    int rc = L.decode_batch(e, (const aacg_unit_desc*)du, (uint32_t)(nu / sizeof(aacg_unit_desc)), dc, (uint32_t)(nc / 1024),
+                            (const aacg_band_meta*)dm, (uint32_t)(nm / AACG_MAX_SECTIONS), (float*)dp, np);
+    if (rc) return fail(env, e, rc, "aacg_decode_batch");
+    return argv[4];
+}
+
+static napi_value js_reset_stream(napi_env env, napi_callback_info info)
+{
+    size_t argc = 2; napi_value argv[2]; uint32_t s = 0;
+    CHECK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    aacg_engine* e = engine_of(env, argv[0]);
+    if (!e) return NULL;
+    napi_get_value_uint32(env, argv[1], &s);
+    int rc = L.reset_stream(e, s);
+    if (rc) return fail(env, e, rc, "aacg_reset_stream");
+    return NULL;
+}
+
+/* getOverlap(engine, stream, channel, Float32Array(1024)) / setOverlap(...) */
+static napi_value overlap_io(napi_env env, napi_callback_info info, int set)
+{
+    size_t argc = 4; napi_value argv[4]; uint32_t s = 0, c = 0;
+    CHECK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    aacg_engine* e = engine_of(env, argv[0]);
+    if (!e) return NULL;
+    napi_get_value_uint32(env, argv[1], &s);
+    napi_get_value_uint32(env, argv[2], &c);
+    napi_typedarray_type t; size_t n; void* d;
+    if (!typed(env, argv[3], &t, &n, &d) || t != napi_float32_array || n != 1024) {
+        napi_throw_type_error(env, NULL, "overlap buffer must be a Float32Array(1024)"); return NULL; }
+    int rc = set ? L.set_overlap(e, s, c, (const float*)d) : L.get_overlap(e, s, c, (float*)d);
+    if (rc) return fail(env, e, rc, set ? "aacg_set_overlap" : "aacg_get_overlap");
+    return argv[3];
+}
+static napi_value js_get_overlap(napi_env env, napi_callback_info info) { return overlap_io(env, info, 0); }
+static napi_value js_set_overlap(napi_env env, napi_callback_info info) { return overlap_io(env, info, 1); }
+
+static napi_value init(napi_env env, napi_value exports)
+{
+    napi_property_descriptor props[] = {
+        {"load", NULL, js_load, NULL, NULL, NULL, napi_default, NULL},
+        {"create", NULL, js_create, NULL, NULL, NULL, napi_default, NULL},
+        {"decodeBatch", NULL, js_decode_batch, NULL, NULL, NULL, napi_default, NULL},
+        {"resetStream", NULL, js_reset_stream, NULL, NULL, NULL, napi_default, NULL},
+        {"getOverlap", NULL, js_get_overlap, NULL, NULL, NULL, napi_default, NULL},
+        {"setOverlap", NULL, js_set_overlap, NULL, NULL, NULL, napi_default, NULL},
+    };
+    napi_define_properties(env, exports, sizeof props / sizeof props[0], props);
+    return exports;
+}
+
+NAPI_MODULE(NODE_GYP_MODULE_NAME, init)

@@ -1,0 +1,86 @@
+#!/usr/bin/env node
+/* Node-side tests of the JavaScript host.  `node tests/js/test_host.js cpu` needs no GPU;
+ * `... gpu` drives the engine through the N-API addon against the golden vectors. */
+'use strict';
+const fs = require('fs'), path = require('path'), assert = require('assert');
+const root = path.join(__dirname, '..', '..');
+const host = require(path.join(root, 'aac.js_amd', 'js'));
+
+function loadGolden() {
+    const man = JSON.parse(fs.readFileSync(path.join(root, 'tests', 'golden', 'golden.json')));
+    const blob = fs.readFileSync(path.join(root, 'tests', 'golden', 'golden.bin'));
+    const T = { f4: Float32Array, f8: Float64Array, i4: Int32Array, i2: Int16Array, u2: Uint16Array, u1: Uint8Array };
+    const out = {};
+    for (const name of Object.keys(man.arrays)) {
+        const a = man.arrays[name], n = a.shape.reduce((x, y) => x * y, 1), Ty = T[a.dtype];
+        const copy = new Uint8Array(n * Ty.BYTES_PER_ELEMENT);
+        copy.set(blob.subarray(a.offset, a.offset + copy.length));
+        out[name] = new Ty(copy.buffer);
+    }
+    return out;
+}
+function rms(a, b) { let s = 0; for (let i = 0; i < a.length; i++) s += (a[i] - b[i]) * (a[i] - b[i]); return Math.sqrt(s / a.length); }
+
+const mode = process.argv[2] || 'cpu';
+const g = loadGolden();
+
+// unit packing round-trips the records the reference-derived fixtures hold
+for (const name of ['scn_stereo', 'scn_7ch', 'scn_split', 'scn_mono']) {
+    const bytes = g[name + '.units'];
+    const again = host.packUnits(host.unpackUnits(bytes));
+    assert.deepStrictEqual(Buffer.from(again), Buffer.from(bytes), name + ': packUnits(unpackUnits(x)) != x');
+}
+assert.strictEqual(host.packBandWord(15, 200, false, true), (15 << 12) | 0x400 | 200);
+
+// setCookie: 2-byte AudioSpecificConfig as the ADTS demuxer synthesises it (adts_demuxer.js:67-70): LC, 48 kHz, stereo
+{
+    const dec = new host.GpuAACDecoder({ engine: { resetStream: function () {} } });
+    dec.init();
+    assert.strictEqual(dec.format.floatingPoint, true);
+    dec.setCookie(new Uint8Array([(2 << 3) | (3 >> 1), ((3 & 1) << 7) | (2 << 3)]));
+    assert.deepStrictEqual([dec.config.profile, dec.config.sampleIndex, dec.config.sampleRate, dec.config.chanConfig, dec.config.frameLength],
+                           [2, 3, 48000, 2, 1024]);
+    assert.strictEqual(dec.format.channelsPerFrame, 2);
+    assert.throws(() => dec.setCookie(new Uint8Array([(5 << 3) | 1, 0x90])), /not supported/);
+}
+console.log('host cpu tests ok');
+if (mode !== 'gpu') process.exit(0);
+
+// ---- GPU: raw batch through the addon, then the plugin surface with look-ahead ------------------
+for (const name of ['scn_stereo', 'scn_7ch']) {
+    const C = name === 'scn_7ch' ? 7 : 2, ref = g[name + '.pcm'];
+    const eng = new host.Engine({ maxStreams: 1, maxChannels: C });
+    const pcm = new Float32Array(ref.length);
+    eng.decodeBatch(g[name + '.units'], g[name + '.q'], g[name + '.meta'], pcm);
+    const e = rms(pcm, ref);
+    assert.ok(e < 1e-5, name + ' rms ' + e);
+    console.log(name, 'decodeBatch rms', e.toExponential(3));
+}
+{
+    // readChunk(): frames arrive one at a time from a front end; look-ahead 5 batches them
+    const name = 'scn_stereo', units = host.unpackUnits(g[name + '.units']), ref = g[name + '.pcm'];
+    let t = 0, avail = 0;
+    const frontend = { parseFrame: function () {
+        if (t >= units.length || t >= avail) return null;
+        const u = units[t], q = g[name + '.q'].subarray(2048 * t, 2048 * (t + 1)), meta = g[name + '.meta'].subarray(240 * t, 240 * (t + 1));
+        t++;
+        return { elements: [{ type: 'cpe', commonWindow: u.commonWindow, maskPresent: u.maskPresent, ch: u.ch }], q: q, meta: meta };
+    } };
+    const dec = new host.GpuAACDecoder({ frontend: frontend, lookahead: 5 });
+    dec.init();
+    dec.setCookie(new Uint8Array([(2 << 3) | (3 >> 1), ((3 & 1) << 7) | (2 << 3)]));
+    let worst = 0, got = 0;
+    for (const burst of [1, 7, 3, 7]) {          // data arrives in bursts: 18 frames in total
+        avail += burst;
+        for (let out; (out = dec.readChunk()) !== null; got++) {
+            assert.strictEqual(out.length, 2048);
+            worst = Math.max(worst, rms(out, ref.subarray(2048 * got, 2048 * (got + 1))));
+        }
+    }
+    assert.strictEqual(got, 18);
+    assert.ok(worst < 1e-5, 'readChunk rms ' + worst);
+    console.log('readChunk x18 worst frame rms', worst.toExponential(3));
+    // error convention: a bad batch throws, like the reference's throw new Error(...)
+    assert.throws(() => dec.engine.decodeBatch(g[name + '.units'], new Int16Array(1024), g[name + '.meta'], new Float32Array(2048)), /aacgpu/);
+}
+console.log('host gpu tests ok');

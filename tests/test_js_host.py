@@ -1,0 +1,42 @@
+"""The JavaScript host (aac.js_amd/js) and its N-API addon, driven under Node like Aurora would."""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NODE = shutil.which("node")
+needs_node = pytest.mark.skipif(NODE is None or not os.path.exists("/usr/include/node/node_api.h"),
+                                reason="node / node_api.h not present on this machine")
+
+
+def build_addon():
+    subprocess.run(["make", "-C", os.path.join(ROOT, "aac.js_amd", "napi")], check=True, stdout=subprocess.DEVNULL,
+                   stderr=subprocess.DEVNULL)
+
+
+@needs_node
+def test_host_cpu():
+    """Unit packing matches the reference-derived records byte for byte; setCookie parses the ASC."""
+    build_addon()
+    r = subprocess.run([NODE, os.path.join(ROOT, "tests", "js", "test_host.js"), "cpu"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "host cpu tests ok" in r.stdout, r.stdout + r.stderr
+
+
+@needs_node
+def test_addon_fails_loudly_without_library():
+    build_addon()
+    code = ("const a=require(%r); try{a.load('/nonexistent/libaacgpu.so'); console.log('loaded')}"
+            "catch(e){console.log('refused: '+e.message)}") % os.path.join(ROOT, "aac.js_amd", "napi", "aacgpu_napi.node")
+    r = subprocess.run([NODE, "-e", code], capture_output=True, text=True, timeout=60)
+    assert "refused" in r.stdout and "no CPU fallback" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+@needs_node
+def test_host_gpu():
+    """decodeBatch through N-API and GpuAACDecoder.readChunk() with look-ahead, against the golden PCM."""
+    build_addon()
+    r = subprocess.run([NODE, os.path.join(ROOT, "tests", "js", "test_host.js"), "gpu"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "host gpu tests ok" in r.stdout, r.stdout + r.stderr
