@@ -35,6 +35,22 @@ def algorithmic_bytes_per_stereo_frame(kind):
     return 2 * per_cf
 
 
+def measured_traffic(kind):
+    """HBM bytes per launch from the PMC counters (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, separate rocprofv3
+    --pmc passes of this same command, tools/prof.sh); bench.py cannot run the profiler on itself, so the
+    committed summary of the latest round under profiles/ is quoted.  None if there is none."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+    if not files:
+        return None, None
+    try:
+        with open(files[-1]) as f:
+            d = json.load(f)
+        return float(d[kind]["traffic_bytes"]), os.path.relpath(files[-1], ROOT)
+    except (KeyError, ValueError, OSError):
+        return None, None
+
+
 def cpu_baseline(kind, mix, budget_s=12.0):
     """The oracle (plain C restatement of the reference algorithm, bit-exact with aac.js) on ONE host core,
     on a bounded sample of the same workload: batches of 4 streams x 16 frames until ~budget_s of CPU time."""
@@ -151,6 +167,7 @@ def main():
     value = world * frames_per_step * args.steps / elapsed
     abytes = algorithmic_bytes_per_stereo_frame(args.input) * frames_per_step
     achieved = abytes / (kernel_ms * 1e-3) / 1e9
+    traffic, traffic_src = measured_traffic(args.input) if not mix else (None, None)
     line = {
         "metric": "AAC-LC 48 kHz stereo frames/sec per node + achieved HBM GB/s vs roofline",
         "value": value, "unit": "stereo frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -163,7 +180,7 @@ def main():
                    "streams_per_gpu": STREAMS, "frames_per_stream_per_step": FRAMES, "buffers_rotated": args.nbuf,
                    "realtime_multiple": value / 46.875, "sharding": "streams over ranks, no data-path collective"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                      "kernel": eng.kernel_name() if args.input == "quant" else "aacg_imdct_run_f32",
                      "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": abytes},
         "output_ok": ok,
