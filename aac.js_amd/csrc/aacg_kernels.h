@@ -375,42 +375,235 @@ DP_DEVICE void short_channels(const float* tab, const chan_par (&cp)[NC],
     }
 }
 
-/* IMDCT + window of the unit's channels, whose spectra sit in the slot's areas (natural order):
- * both channels together when they are on the same lane map, one after the other otherwise. */
-DP_DEVICE void filter_unit(const float* tab, const aacg_unit_desc* u, int n_ch, bool want_head, float* slot,
-                           float (&hx0)[8], float (&hy0)[8], float (&hx1)[8], float (&hy1)[8])
+/* staging swizzle of the pair planes (defined with the staging helpers below) */
+DP_DEVICE int stg(int k);
+
+/* ------------------------------------------------------------------------------------ */
+/* CPE with both channels on the same lane map: (left, right) packed arithmetic            */
+/* ------------------------------------------------------------------------------------ */
+/* Every quantity is a dpv2 = (left, right); one v_pk_*_f32 per operation, no shuffles, and the
+ * rotation / twiddle / window factors are shared.  LDS elements are 16 bytes (reL, reR, imL, imR),
+ * so a transpose takes half the LDS instructions of two planar ones.
+ *
+ * Slot layout (2048 floats): the staged spectra as two planes of (L,R) pairs, E[k] = X[2k] at
+ * pair index k and O[k] = X[2k+1] at 512 + k; then the transposes (512 x 16 B); then the
+ * windowed tails interleaved, pair index n = (tailL[n], tailR[n]). */
+struct cpx2 { dpv2 re, im; };
+
+DP_DEVICE dpv2 v2(float a, float b) { dpv2 r; r[0] = a; r[1] = b; return r; }
+DP_DEVICE dpv2 v2s(float s) { dpv2 r; r[0] = s; r[1] = s; return r; }
+DP_DEVICE cpx2 c2_add(cpx2 a, cpx2 b) { cpx2 r; r.re = a.re + b.re; r.im = a.im + b.im; return r; }
+DP_DEVICE cpx2 c2_sub(cpx2 a, cpx2 b) { cpx2 r; r.re = a.re - b.re; r.im = a.im - b.im; return r; }
+DP_DEVICE cpx2 c2_muli(cpx2 a) { cpx2 r; r.re = -a.im; r.im = a.re; return r; }
+DP_DEVICE cpx2 c2_mul(cpx2 a, cpx w)
 {
-    chan_par p0, p1;
-    p0.seq = u->ch[0].window_sequence; p0.shape = u->ch[0].window_shape; p0.shape_prev = u->ch[0].window_shape_prev;
-    p1.seq = u->ch[1].window_sequence; p1.shape = u->ch[1].window_shape; p1.shape_prev = u->ch[1].window_shape_prev;
-    const bool s0 = p0.seq == AACG_EIGHT_SHORT_SEQUENCE, s1 = p1.seq == AACG_EIGHT_SHORT_SEQUENCE;
-    if (n_ch == 2 && s0 == s1) {
-        const chan_par cp[2] = {p0, p1};
-        float* const area[2] = {slot, slot + 1024};
-        float hx[2][8], hy[2][8];
-        if (s0) short_channels<2>(tab, cp, area, hx, hy);
-        else    long_channels<2>(tab, cp, want_head, area, hx, hy);
+    cpx2 r;
+    const dpv2 wr = v2s(w.re), wi = v2s(w.im);
+    r.re = a.re * wr - a.im * wi;
+    r.im = a.re * wi + a.im * wr;
+    return r;
+}
+
+DP_DEVICE void radix8_inv2(cpx2 (&x)[8])
+{
+    const dpv2 h = v2s(0.70710678118654752440f);
+    cpx2 a0 = c2_add(x[0], x[4]), a1 = c2_sub(x[0], x[4]);
+    cpx2 a2 = c2_add(x[2], x[6]), a3 = c2_sub(x[2], x[6]);
+    cpx2 a4 = c2_add(x[1], x[5]), a5 = c2_sub(x[1], x[5]);
+    cpx2 a6 = c2_add(x[3], x[7]), a7 = c2_sub(x[3], x[7]);
+    cpx2 e0 = c2_add(a0, a2), e2 = c2_sub(a0, a2);
+    cpx2 ia3 = c2_muli(a3), ia7 = c2_muli(a7);
+    cpx2 e1 = c2_add(a1, ia3), e3 = c2_sub(a1, ia3);
+    cpx2 o0 = c2_add(a4, a6), o2 = c2_sub(a4, a6);
+    cpx2 o1 = c2_add(a5, ia7), o3 = c2_sub(a5, ia7);
+    cpx2 t1, t2, t3;
+    t1.re = (o1.re - o1.im) * h;  t1.im = (o1.re + o1.im) * h;
+    t2 = c2_muli(o2);
+    t3.re = -(o3.re + o3.im) * h; t3.im = (o3.re - o3.im) * h;
+    x[0] = c2_add(e0, o0); x[4] = c2_sub(e0, o0);
+    x[1] = c2_add(e1, t1); x[5] = c2_sub(e1, t1);
+    x[2] = c2_add(e2, t2); x[6] = c2_sub(e2, t2);
+    x[3] = c2_add(e3, t3); x[7] = c2_sub(e3, t3);
+}
+
+/* 16-byte transposes: slot indices chosen so that ds_write_b128 (8-lane groups, 8 slots) and
+ * ds_read_b128 (the four 16-lane groups of MI355X_MICROARCH.md §LDS, 16 slots) are conflict-free */
+DP_DEVICE int pch1(int q, int l)     { return 64 * q + (l ^ (((q >> 1) & 1) << 3)); }
+DP_DEVICE int pch2(int row, int col) { return 8 * row + (col ^ ((row >> 1) & 7)); }
+DP_DEVICE void lds_put2(float* base, int slot, cpx2 v)
+{
+    dpf4 t; t.x = v.re[0]; t.y = v.re[1]; t.z = v.im[0]; t.w = v.im[1];
+    *(dpf4*)(base + 4 * slot) = t;
+}
+DP_DEVICE cpx2 lds_get2(const float* base, int slot)
+{
+    const dpf4 t = *(const dpf4*)(base + 4 * slot);
+    cpx2 v; v.re = v2(t.x, t.y); v.im = v2(t.z, t.w); return v;
+}
+DP_DEVICE dpv2 lds_pair(const float* base, int pair_index)
+{
+    const dpf2 t = *(const dpf2*)(base + 2 * pair_index);
+    return v2(t.x, t.y);
+}
+
+/* mirror-lane exchange of 8 (L,R) complex values: m*[r] <- lane `src`'s value */
+DP_DEVICE void shfl_pairs(const dpv2 (&R)[8], const dpv2 (&I)[8], int src, dpv2 (&mR)[8], dpv2 (&mI)[8])
+{
+    float a[16], b[16];
 #pragma unroll
-        for (int m = 0; m < 8; m++) { hx0[m] = hx[0][m]; hy0[m] = hy[0][m]; hx1[m] = hx[1][m]; hy1[m] = hy[1][m]; }
-        return;
+    for (int r = 0; r < 8; r++) { a[r] = R[r][0]; a[8 + r] = R[r][1]; b[r] = I[r][0]; b[8 + r] = I[r][1]; }
+    dp_shfl(a, src);
+    dp_shfl(b, src);
+#pragma unroll
+    for (int r = 0; r < 8; r++) { mR[r] = v2(a[r], a[8 + r]); mI[r] = v2(b[r], b[8 + r]); }
+}
+
+/* Long windows, both channels (they share sequence and shapes: one ICSInfo, cpe.js:44, or equal by value). */
+DP_DEVICE void long_pair(const float* tab, const chan_par& cp, bool want_head, float* slot,
+                         dpv2 (&hx)[8], dpv2 (&hy)[8])
+{
+    const int l = dp_lane();
+    const float* sincos = tab + AACG_TAB_OFF_SINCOS_LONG;
+
+    cpx2 z[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const cpx sc = lds_get(sincos, 64 * j + l);
+        const dpv2 xe = lds_pair(slot, stg(l + 64 * j));                  /* X[2k],        k = l + 64 j */
+        const dpv2 xo = lds_pair(slot, 512 + stg(511 - l - 64 * j));      /* X[1023 - 2k]               */
+        z[j].im = xe * v2s(sc.re) + xo * v2s(sc.im);                 /* mdct.js:74 */
+        z[j].re = xo * v2s(sc.re) - xe * v2s(sc.im);                 /* mdct.js:75 */
     }
-    {
-        const chan_par cp[1] = {p0};
-        float* const area[1] = {slot};
-        float hx[1][8], hy[1][8];
-        if (s0) short_channels<1>(tab, cp, area, hx, hy);
-        else    long_channels<1>(tab, cp, want_head, area, hx, hy);
+    dp_wave_sync();
+
+    radix8_inv2(z);
 #pragma unroll
-        for (int m = 0; m < 8; m++) { hx0[m] = hx[0][m]; hy0[m] = hy[0][m]; }
+    for (int q = 1; q < 8; q++) z[q] = c2_mul(z[q], lds_get(tab + AACG_TAB_OFF_TW512, 64 * (q - 1) + l));
+#pragma unroll
+    for (int q = 0; q < 8; q++) lds_put2(slot, pch1(q, l), z[q]);
+    dp_wave_sync();
+    const int l0 = l & 7, qq = l >> 3;
+#pragma unroll
+    for (int j = 0; j < 8; j++) z[j] = lds_get2(slot, pch1(qq, l0 + 8 * j));
+    dp_wave_sync();
+    radix8_inv2(z);
+#pragma unroll
+    for (int r = 1; r < 8; r++) z[r] = c2_mul(z[r], lds_get(tab + AACG_TAB_OFF_TW64, 8 * (r - 1) + l0));
+#pragma unroll
+    for (int r = 0; r < 8; r++) lds_put2(slot, pch2(qq + 8 * r, l0), z[r]);
+    dp_wave_sync();
+#pragma unroll
+    for (int i = 0; i < 8; i++) z[i] = lds_get2(slot, pch2(l, i));
+    dp_wave_sync();
+    radix8_inv2(z);
+
+    dpv2 R[8], I[8], mR[8], mI[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const cpx sc = lds_get(sincos, 64 * r + l);
+        R[r] = z[r].re * v2s(sc.re) - z[r].im * v2s(sc.im);          /* mdct.js:82-87 */
+        I[r] = z[r].im * v2s(sc.re) + z[r].re * v2s(sc.im);
     }
-    if (n_ch == 2) {
-        const chan_par cp[1] = {p1};
-        float* const area[1] = {slot + 1024};
-        float hx[1][8], hy[1][8];
-        if (s1) short_channels<1>(tab, cp, area, hx, hy);
-        else    long_channels<1>(tab, cp, want_head, area, hx, hy);
+    shfl_pairs(R, I, 63 - l, mR, mI);
+
 #pragma unroll
-        for (int m = 0; m < 8; m++) { hx1[m] = hx[0][m]; hy1[m] = hy[0][m]; }
+    for (int j = 0; j < 4; j++) {
+        const int n = 2 * l + 128 * j;
+        if (want_head) {
+            const dpf2 w0 = head_window(tab, cp.seq, cp.shape_prev, n), w1 = head_window(tab, cp.seq, cp.shape_prev, n + 512);
+            hx[j]     = I[j + 4] * v2s(w0.x);
+            hy[j]     = -mR[3 - j] * v2s(w0.y);
+            hx[j + 4] = R[j] * v2s(w1.x);
+            hy[j + 4] = -mI[7 - j] * v2s(w1.y);
+        }
+        const dpf2 v0 = tail_window(tab, cp.seq, cp.shape, n), v1 = tail_window(tab, cp.seq, cp.shape, n + 512);
+        const dpv2 t0 = R[j + 4] * v2s(v0.x), t1 = -mI[3 - j] * v2s(v0.y);
+        const dpv2 t2 = -I[j] * v2s(v1.x),    t3 = mR[7 - j] * v2s(v1.y);
+        dpf4 o;
+        o.x = t0[0]; o.y = t0[1]; o.z = t1[0]; o.w = t1[1];
+        *(dpf4*)(slot + 2 * n) = o;                                   /* (tailL[n], tailR[n], tailL[n+1], tailR[n+1]) */
+        o.x = t2[0]; o.y = t2[1]; o.z = t3[0]; o.w = t3[1];
+        *(dpf4*)(slot + 2 * (n + 512)) = o;
+    }
+}
+
+/* EIGHT_SHORT, both channels. */
+DP_DEVICE void short_pair(const float* tab, const chan_par& cp, float* slot, dpv2 (&hx)[8], dpv2 (&hy)[8])
+{
+    const int l = dp_lane(), w = l >> 3, g = l & 7;
+    const float* sincos = tab + AACG_TAB_OFF_SINCOS_SHORT;
+
+    cpx2 z[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const cpx sc = lds_get(sincos, 8 * j + g);
+        const dpv2 xe = lds_pair(slot, stg(64 * w + g + 8 * j));                 /* X_w[2k], k = g + 8 j */
+        const dpv2 xo = lds_pair(slot, 512 + stg(64 * w + 63 - g - 8 * j));      /* X_w[127 - 2k]        */
+        z[j].im = xe * v2s(sc.re) + xo * v2s(sc.im);
+        z[j].re = xo * v2s(sc.re) - xe * v2s(sc.im);
+    }
+    dp_wave_sync();
+
+    radix8_inv2(z);
+#pragma unroll
+    for (int q = 1; q < 8; q++) z[q] = c2_mul(z[q], lds_get(tab + AACG_TAB_OFF_TW64, 8 * (q - 1) + g));
+#pragma unroll
+    for (int q = 0; q < 8; q++) lds_put2(slot, pch2(8 * w + q, g), z[q]);
+    dp_wave_sync();
+#pragma unroll
+    for (int i = 0; i < 8; i++) z[i] = lds_get2(slot, pch2(l, i));
+    dp_wave_sync();
+    radix8_inv2(z);
+
+    dpv2 R[8], I[8], mR[8], mI[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const cpx sc = lds_get(sincos, 8 * r + g);
+        R[r] = z[r].re * v2s(sc.re) - z[r].im * v2s(sc.im);
+        I[r] = z[r].im * v2s(sc.re) + z[r].re * v2s(sc.im);
+    }
+    shfl_pairs(R, I, l ^ 7, mR, mI);
+
+    const float* ws = tab + AACG_TAB_OFF_WIN_SHORT + 128 * cp.shape;
+    const float* wh = (w == 0) ? tab + AACG_TAB_OFF_WIN_SHORT + 128 * cp.shape_prev : ws;
+    dpv2 hd[16], tl[16];                               /* [m] = position i = 2g+16m, [8+m] = i+1 */
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int i = 2 * g + 16 * j;
+        const dpf2 h0 = *(const dpf2*)(wh + i), h1 = *(const dpf2*)(wh + i + 64);
+        const dpf2 t0 = *(const dpf2*)(ws + 126 - i), t1 = *(const dpf2*)(ws + 62 - i);
+        hd[j]         = I[j + 4] * v2s(h0.x);
+        hd[8 + j]     = -mR[3 - j] * v2s(h0.y);
+        hd[j + 4]     = R[j] * v2s(h1.x);
+        hd[8 + j + 4] = -mI[7 - j] * v2s(h1.y);
+        tl[j]         = R[j + 4] * v2s(t0.y);
+        tl[8 + j]     = -mI[3 - j] * v2s(t0.x);
+        tl[j + 4]     = -I[j] * v2s(t1.y);
+        tl[8 + j + 4] = mR[7 - j] * v2s(t1.x);
+    }
+    /* s[128 w + i] = tail of block w-1 + head of block w (filter_bank.js:155-160) */
+    float pa[16], pb[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) { pa[i] = tl[i][0]; pb[i] = tl[i][1]; }
+    dp_shfl(pa, (l - 8) & 63);
+    dp_shfl(pb, (l - 8) & 63);
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        hx[i] = (w == 0 ? v2s(0.0f) : v2(pa[i], pb[i])) + hd[i];
+        hy[i] = (w == 0 ? v2s(0.0f) : v2(pa[8 + i], pb[8 + i])) + hd[8 + i];
+    }
+
+    /* second half of s -> new overlap, interleaved (filter_bank.js:164-176) */
+#pragma unroll
+    for (int mm = 0; mm < 8; mm++) {
+        const int p = 128 * w + 2 * g + 16 * mm;
+        if (p >= 576) { dpf4 o; o.x = hx[mm][0]; o.y = hx[mm][1]; o.z = hy[mm][0]; o.w = hy[mm][1]; *(dpf4*)(slot + 2 * (p - 576)) = o; }
+        if (w == 7)   { dpf4 o; o.x = tl[mm][0]; o.y = tl[mm][1]; o.z = tl[8 + mm][0]; o.w = tl[8 + mm][1]; *(dpf4*)(slot + 2 * (448 + 2 * g + 16 * mm)) = o; }
+    }
+#pragma unroll
+    for (int t4 = 0; t4 < 4; t4++) {
+        const int n = 576 + 2 * l + 128 * t4;
+        if (n < 1024) { dpf4 zz; zz.x = zz.y = zz.z = zz.w = 0.0f; *(dpf4*)(slot + 2 * n) = zz; }
     }
 }
 
@@ -597,8 +790,15 @@ DP_DEVICE void spectral_quant(const aacg_kparams& P, const float* tab, const aac
     dp_wave_sync();                                    /* band table dead: the area may be overwritten */
 }
 
-/* registers (natural order, 8 lane + 512 i + e) -> work[0..1023] */
-DP_DEVICE void stage_nat8(const float (&x)[16], float* work)
+/* ------------------------------------------------------------------------------------ */
+/* staging: spectra -> LDS                                                                 */
+/* ------------------------------------------------------------------------------------ */
+/* pair planes: pair index k of X[2k] (E plane, at 0) / X[2k+1] (O plane, at 512); the XOR keeps both the
+ * long (l + 64 j) and the short (64 w + g + 8 j) read patterns conflict-free */
+DP_DEVICE int stg(int k) { return k ^ (((k >> 6) & 3) << 3); }
+
+/* registers in natural order (8 lane + 512 i + e) -> planar area[0..1023] */
+DP_DEVICE void stage_nat8(const float (&x)[16], float* area)
 {
     const int lane = dp_lane();
 #pragma unroll
@@ -606,16 +806,112 @@ DP_DEVICE void stage_nat8(const float (&x)[16], float* work)
         dpf4 a, b;
         a.x = x[8 * i]; a.y = x[8 * i + 1]; a.z = x[8 * i + 2]; a.w = x[8 * i + 3];
         b.x = x[8 * i + 4]; b.y = x[8 * i + 5]; b.z = x[8 * i + 6]; b.w = x[8 * i + 7];
-        *(dpf4*)(work + 8 * lane + 512 * i) = a;
-        *(dpf4*)(work + 8 * lane + 512 * i + 4) = b;
+        *(dpf4*)(area + 8 * lane + 512 * i) = a;
+        *(dpf4*)(area + 8 * lane + 512 * i + 4) = b;
+    }
+}
+/* the same for a CPE on the pair path: (L,R) pairs into the E / O planes */
+DP_DEVICE void stage_pair_nat8(const float (&xl)[16], const float (&xr)[16], float* slot)
+{
+    const int lane = dp_lane();
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int k = 4 * lane + 256 * i + 2 * h, e = 8 * i + 4 * h;
+            dpf4 ev, od;
+            ev.x = xl[e];     ev.y = xr[e];     ev.z = xl[e + 2]; ev.w = xr[e + 2];
+            od.x = xl[e + 1]; od.y = xr[e + 1]; od.z = xl[e + 3]; od.w = xr[e + 3];
+            *(dpf4*)(slot + 2 * stg(k)) = ev;
+            *(dpf4*)(slot + 2 * (512 + stg(k))) = od;
+        }
+    }
+}
+/* f32 spectra as loaded (float4 at 4 lane + 256 i per channel) */
+DP_DEVICE void stage_pair_f32(const dpf4 (&xa)[4], const dpf4 (&xb)[4], float* slot)
+{
+    const int lane = dp_lane();
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int k = 2 * lane + 128 * i;
+        dpf4 ev, od;
+        ev.x = xa[i].x; ev.y = xb[i].x; ev.z = xa[i].z; ev.w = xb[i].z;
+        od.x = xa[i].y; od.y = xb[i].y; od.z = xa[i].w; od.w = xb[i].w;
+        *(dpf4*)(slot + 2 * stg(k)) = ev;
+        *(dpf4*)(slot + 2 * (512 + stg(k))) = od;
+    }
+}
+
+/* IMDCT + window of a unit whose spectra are staged in its slot.  CPE tails always end up
+ * interleaved (pair index n = (tailL[n], tailR[n])); a single channel's tail is planar. */
+DP_DEVICE void filter_unit(const float* tab, const aacg_unit_desc* u, int n_ch, bool pair_path, bool want_head, float* slot,
+                           float (&hx0)[8], float (&hy0)[8], float (&hx1)[8], float (&hy1)[8])
+{
+    chan_par p0, p1;
+    p0.seq = u->ch[0].window_sequence; p0.shape = u->ch[0].window_shape; p0.shape_prev = u->ch[0].window_shape_prev;
+    p1.seq = u->ch[1].window_sequence; p1.shape = u->ch[1].window_shape; p1.shape_prev = u->ch[1].window_shape_prev;
+    const bool s0 = p0.seq == AACG_EIGHT_SHORT_SEQUENCE, s1 = p1.seq == AACG_EIGHT_SHORT_SEQUENCE;
+    if (pair_path) {
+        dpv2 hx[8], hy[8];
+        if (s0) short_pair(tab, p0, slot, hx, hy);
+        else    long_pair(tab, p0, want_head, slot, hx, hy);
+#pragma unroll
+        for (int m = 0; m < 8; m++) { hx0[m] = hx[m][0]; hx1[m] = hx[m][1]; hy0[m] = hy[m][0]; hy1[m] = hy[m][1]; }
+        return;
+    }
+    {
+        const chan_par cp[1] = {p0};
+        float* const area[1] = {slot};
+        float hx[1][8], hy[1][8];
+        if (s0) short_channels<1>(tab, cp, area, hx, hy);
+        else    long_channels<1>(tab, cp, want_head, area, hx, hy);
+#pragma unroll
+        for (int m = 0; m < 8; m++) { hx0[m] = hx[0][m]; hy0[m] = hy[0][m]; }
+    }
+    if (n_ch == 2) {
+        const chan_par cp[1] = {p1};
+        float* const area[1] = {slot + 1024};
+        float hx[1][8], hy[1][8];
+        if (s1) short_channels<1>(tab, cp, area, hx, hy);
+        else    long_channels<1>(tab, cp, want_head, area, hx, hy);
+#pragma unroll
+        for (int m = 0; m < 8; m++) { hx1[m] = hx[0][m]; hy1[m] = hy[0][m]; }
+        /* two planar tails -> the interleaved form the next wave expects */
+        const int lane = dp_lane();
+        dpf4 a[4], b[4];
+        dp_wave_sync();
+#pragma unroll
+        for (int i = 0; i < 4; i++) { a[i] = *(const dpf4*)(slot + 4 * lane + 256 * i); b[i] = *(const dpf4*)(slot + 1024 + 4 * lane + 256 * i); }
+        dp_wave_sync();
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            dpf4 o;
+            o.x = a[i].x; o.y = b[i].x; o.z = a[i].y; o.w = b[i].y;
+            *(dpf4*)(slot + 2 * (4 * lane + 256 * i)) = o;
+            o.x = a[i].z; o.y = b[i].z; o.z = a[i].w; o.w = b[i].w;
+            *(dpf4*)(slot + 2 * (4 * lane + 256 * i) + 4) = o;
+        }
     }
 }
 
 /* ------------------------------------------------------------------------------------ */
 /* epilogue: out = (overlap + head) / 32768, interleaved (filter_bank.js + decoder.js:203-215) */
 /* ------------------------------------------------------------------------------------ */
-/* prev: the two incoming tails (channel c at prev + c * stride), in LDS or in HBM. */
-DP_DEVICE void epilogue(const float* prev, int stride, const aacg_unit_desc* u, int n_ch, int cls0, int cls1,
+/* (ov0[n], ov1[n], ov0[n+1], ov1[n+1]) of the incoming tails: FROM_LDS: the previous wave's slot
+ * (interleaved for a CPE, planar for one channel); else the overlap state in HBM (planar). */
+template <bool FROM_LDS>
+DP_DEVICE dpf4 incoming(const float* p0, const float* p1, int n_ch, int n)
+{
+    dpf4 r;
+    if (FROM_LDS && n_ch == 2) return *(const dpf4*)(p0 + 2 * n);
+    const dpf2 a = *(const dpf2*)(p0 + n);
+    r.x = a.x; r.z = a.y; r.y = 0.0f; r.w = 0.0f;
+    if (n_ch == 2) { const dpf2 b = *(const dpf2*)(p1 + n); r.y = b.x; r.w = b.y; }
+    return r;
+}
+
+template <bool FROM_LDS>
+DP_DEVICE void epilogue(const float* p0, const float* p1, const aacg_unit_desc* u, int n_ch, int cls0, int cls1,
                         float* pcm_base, const float (&hx0)[8], const float (&hy0)[8],
                         const float (&hx1)[8], const float (&hy1)[8])
 {
@@ -630,10 +926,10 @@ DP_DEVICE void epilogue(const float* prev, int stride, const aacg_unit_desc* u, 
 #pragma unroll
             for (int m = 0; m < 8; m++) {
                 const int n = 2 * lane + 128 * m;
-                const dpf2 a = *(const dpf2*)(prev + n), b = *(const dpf2*)(prev + stride + n);
+                const dpf4 v = incoming<FROM_LDS>(p0, p1, 2, n);
                 dpf4 o;
-                o.x = (a.x + hx0[m]) * S; o.y = (b.x + hx1[m]) * S;
-                o.z = (a.y + hy0[m]) * S; o.w = (b.y + hy1[m]) * S;
+                o.x = (v.x + hx0[m]) * S; o.y = (v.y + hx1[m]) * S;
+                o.z = (v.z + hy0[m]) * S; o.w = (v.w + hy1[m]) * S;
                 *(dpf4*)(pcm + 2 * n) = o;
             }
         } else {
@@ -641,10 +937,10 @@ DP_DEVICE void epilogue(const float* prev, int stride, const aacg_unit_desc* u, 
             for (int m = 0; m < 8; m++) {
                 if (w < 4 || (w == 4 && m < 4)) {
                     const int n = 448 + 128 * w + 2 * g + 16 * m;
-                    const dpf2 a = *(const dpf2*)(prev + n), b = *(const dpf2*)(prev + stride + n);
+                    const dpf4 v = incoming<FROM_LDS>(p0, p1, 2, n);
                     dpf4 o;
-                    o.x = (a.x + hx0[m]) * S; o.y = (b.x + hx1[m]) * S;
-                    o.z = (a.y + hy0[m]) * S; o.w = (b.y + hy1[m]) * S;
+                    o.x = (v.x + hx0[m]) * S; o.y = (v.y + hx1[m]) * S;
+                    o.z = (v.z + hy0[m]) * S; o.w = (v.w + hy1[m]) * S;
                     *(dpf4*)(pcm + 2 * n) = o;
                 }
             }
@@ -652,8 +948,8 @@ DP_DEVICE void epilogue(const float* prev, int stride, const aacg_unit_desc* u, 
             for (int t4 = 0; t4 < 4; t4++) {           /* out[0..447] = overlap (filter_bank.js:149-151) */
                 const int n = 2 * lane + 128 * t4;
                 if (n < 448) {
-                    const dpf2 a = *(const dpf2*)(prev + n), b = *(const dpf2*)(prev + stride + n);
-                    dpf4 o; o.x = a.x * S; o.y = b.x * S; o.z = a.y * S; o.w = b.y * S;
+                    const dpf4 v = incoming<FROM_LDS>(p0, p1, 2, n);
+                    dpf4 o; o.x = v.x * S; o.y = v.y * S; o.z = v.z * S; o.w = v.w * S;
                     *(dpf4*)(pcm + 2 * n) = o;
                 }
             }
@@ -661,10 +957,10 @@ DP_DEVICE void epilogue(const float* prev, int stride, const aacg_unit_desc* u, 
         return;
     }
 
+    /* any channel count / mixed lane maps: scalar stores at stride C */
 #pragma unroll
     for (int c = 0; c < 2; c++) {
         if (c < n_ch) {
-            const float* pv = prev + c * stride;
             float* dst = pcm + c;
             const int cls = c ? cls1 : cls0;
             const float (&hx)[8] = c ? hx1 : hx0;
@@ -673,27 +969,27 @@ DP_DEVICE void epilogue(const float* prev, int stride, const aacg_unit_desc* u, 
 #pragma unroll
                 for (int m = 0; m < 8; m++) {
                     const int n = 2 * lane + 128 * m;
-                    const dpf2 a = *(const dpf2*)(pv + n);
-                    dst[(size_t)n * C]       = (a.x + hx[m]) * S;
-                    dst[(size_t)(n + 1) * C] = (a.y + hy[m]) * S;
+                    const dpf4 v = incoming<FROM_LDS>(p0, p1, n_ch, n);
+                    dst[(size_t)n * C]       = ((c ? v.y : v.x) + hx[m]) * S;
+                    dst[(size_t)(n + 1) * C] = ((c ? v.w : v.z) + hy[m]) * S;
                 }
             } else {
 #pragma unroll
                 for (int m = 0; m < 8; m++) {
                     if (w < 4 || (w == 4 && m < 4)) {
                         const int n = 448 + 128 * w + 2 * g + 16 * m;
-                        const dpf2 a = *(const dpf2*)(pv + n);
-                        dst[(size_t)n * C]       = (a.x + hx[m]) * S;
-                        dst[(size_t)(n + 1) * C] = (a.y + hy[m]) * S;
+                        const dpf4 v = incoming<FROM_LDS>(p0, p1, n_ch, n);
+                        dst[(size_t)n * C]       = ((c ? v.y : v.x) + hx[m]) * S;
+                        dst[(size_t)(n + 1) * C] = ((c ? v.w : v.z) + hy[m]) * S;
                     }
                 }
 #pragma unroll
                 for (int t4 = 0; t4 < 4; t4++) {
                     const int n = 2 * lane + 128 * t4;
                     if (n < 448) {
-                        const dpf2 a = *(const dpf2*)(pv + n);
-                        dst[(size_t)n * C]       = a.x * S;
-                        dst[(size_t)(n + 1) * C] = a.y * S;
+                        const dpf4 v = incoming<FROM_LDS>(p0, p1, n_ch, n);
+                        dst[(size_t)n * C]       = (c ? v.y : v.x) * S;
+                        dst[(size_t)(n + 1) * C] = (c ? v.w : v.z) * S;
                     }
                 }
             }
@@ -713,7 +1009,7 @@ DP_DEVICE void imdct_run_body(const aacg_kparams& P)
     float* lds = (float*)dp_lds();
     const float* tab = lds;
     float* slots = lds + TAB_FLOATS;
-    float* slot = slots + wave * AACG_SLOT_FLOATS;     /* area of channel 0 | area of channel 1 */
+    float* slot = slots + wave * AACG_SLOT_FLOATS;
     int* flags = (int*)(slots + AACG_WG_WAVES * AACG_SLOT_FLOATS);
 
     const int n_units = run->n_units;
@@ -734,6 +1030,10 @@ DP_DEVICE void imdct_run_body(const aacg_kparams& P)
     const int n_ch = ui >= 0 ? u->n_ch : 0;
     const int cls0 = u->ch[0].window_sequence == AACG_EIGHT_SHORT_SEQUENCE;
     const int cls1 = u->ch[1].window_sequence == AACG_EIGHT_SHORT_SEQUENCE;
+    const bool pair_path = n_ch == 2 && cls0 == cls1 &&
+                           u->ch[0].window_sequence == u->ch[1].window_sequence &&
+                           u->ch[0].window_shape == u->ch[1].window_shape &&
+                           u->ch[0].window_shape_prev == u->ch[1].window_shape_prev;
 
     /* loads: tables first, then this wave's spectrum; only the tables are waited for before the barrier */
     dpf4 tr0, tr1;
@@ -767,17 +1067,20 @@ DP_DEVICE void imdct_run_body(const aacg_kparams& P)
             float xl[16], xr[16];
             spectral_quant(P, tab, u, n_ch, qreg, slot + 1024, xl, xr);
             /* TNS would run here: identity as the reference executes it (tns.js:106,122) */
-            stage_nat8(xl, slot);
-            if (n_ch == 2) stage_nat8(xr, slot + 1024);
+            if (pair_path) stage_pair_nat8(xl, xr, slot);
+            else { stage_nat8(xl, slot); if (n_ch == 2) stage_nat8(xr, slot + 1024); }
         } else {
+            if (pair_path) stage_pair_f32(xa, xb, slot);
+            else {
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                *(dpf4*)(slot + 4 * lane + 256 * i) = xa[i];
-                if (n_ch == 2) *(dpf4*)(slot + 1024 + 4 * lane + 256 * i) = xb[i];
+                for (int i = 0; i < 4; i++) {
+                    *(dpf4*)(slot + 4 * lane + 256 * i) = xa[i];
+                    if (n_ch == 2) *(dpf4*)(slot + 1024 + 4 * lane + 256 * i) = xb[i];
+                }
             }
         }
         dp_wave_sync();
-        filter_unit(tab, u, n_ch, !is_pred_wave, slot, hx0, hy0, hx1, hy1);
+        filter_unit(tab, u, n_ch, pair_path, !is_pred_wave, slot, hx0, hy0, hx1, hy1);
     }
 
     /* this wave's tails are complete in its slot: release them to the next wave */
@@ -796,19 +1099,29 @@ DP_DEVICE void imdct_run_body(const aacg_kparams& P)
              * (filter_bank.js:38-41, `overlap = this.overlaps[channel]`) */
             const float* ov0 = P.overlap + (P.flip ? run->ov_b[0] : run->ov_a[0]);
             const float* ov1 = P.overlap + (P.flip ? run->ov_b[1] : run->ov_a[1]);
-            epilogue(ov0, (int)(ov1 - ov0), u, n_ch, cls0, cls1, P.pcm, hx0, hy0, hx1, hy1);
+            epilogue<false>(ov0, ov1, u, n_ch, cls0, cls1, P.pcm, hx0, hy0, hx1, hy1);
         } else {
             dp_flag_wait(&flags[wave - 1], 1);         /* the previous frame's tails (acquire) */
-            epilogue(slot - AACG_SLOT_FLOATS, 1024, u, n_ch, cls0, cls1, P.pcm, hx0, hy0, hx1, hy1);
+            epilogue<true>(slot - AACG_SLOT_FLOATS, slot - AACG_SLOT_FLOATS, u, n_ch, cls0, cls1, P.pcm, hx0, hy0, hx1, hy1);
         }
-        /* the chain's last frame in this launch: its tail is the new overlap state */
+        /* the chain's last frame in this launch: its tail is the new overlap state (planar in HBM) */
         const int last_wave = has_pred ? n_units : n_units - 1;
         if (wave == last_wave && run->is_last) {
-            for (int c = 0; c < n_ch; c++) {
-                float* dstov = P.overlap + (P.flip ? run->ov_a[c] : run->ov_b[c]);
+            float* d0 = P.overlap + (P.flip ? run->ov_a[0] : run->ov_b[0]);
+            float* d1 = P.overlap + (P.flip ? run->ov_a[1] : run->ov_b[1]);
 #pragma unroll
-                for (int i = 0; i < 4; i++)
-                    *(dpf4*)(dstov + 4 * lane + 256 * i) = *(const dpf4*)(slot + c * 1024 + 4 * lane + 256 * i);
+            for (int i = 0; i < 4; i++) {
+                const int n = 4 * lane + 256 * i;
+                if (n_ch == 2) {
+                    const dpf4 a = *(const dpf4*)(slot + 2 * n), b = *(const dpf4*)(slot + 2 * n + 4);
+                    dpf4 l4, r4;
+                    l4.x = a.x; l4.y = a.z; l4.z = b.x; l4.w = b.z;
+                    r4.x = a.y; r4.y = a.w; r4.z = b.y; r4.w = b.w;
+                    *(dpf4*)(d0 + n) = l4;
+                    *(dpf4*)(d1 + n) = r4;
+                } else {
+                    *(dpf4*)(d0 + n) = *(const dpf4*)(slot + n);
+                }
             }
         }
     }

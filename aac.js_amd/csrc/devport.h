@@ -25,6 +25,8 @@
 typedef float2 dpf2;
 typedef float4 dpf4;
 typedef int4   dpi4;
+/* (left, right) channel pair: every arithmetic op on it is one v_pk_*_f32 */
+typedef float dpv2 __attribute__((ext_vector_type(2)));
 
 DP_DEVICE int dp_tid()   { return (int)threadIdx.x; }
 DP_DEVICE int dp_lane()  { return (int)(threadIdx.x & 63u); }
