@@ -43,6 +43,7 @@ struct aacg_engine {
     void*  d_coeffs = nullptr;  size_t coeffs_cap = 0;
     aacg_band_meta* d_meta = nullptr; size_t meta_cap = 0;
     float* d_pcm = nullptr;     size_t pcm_cap = 0;
+    void* d_trace = nullptr;                /* profiling: per-wave phase timestamps when (ablate & 16) */
     int ablate = 0;                         /* profiling knob, env AACG_ABLATE (see aacg_device.h); 0 in normal use */
     std::string err;
 };
@@ -124,6 +125,7 @@ int aacg_create(const aacg_config* cfg, aacg_engine** out)
     }
     e->parity.assign((size_t)cfg->max_streams * (size_t)cfg->max_channels, 0);
     if (const char* a = std::getenv("AACG_ABLATE")) e->ablate = std::atoi(a);
+    if ((e->ablate & 16) && hipMalloc(&e->d_trace, 1u << 22) == hipSuccess) (void)hipMemset(e->d_trace, 0, 1u << 22);
     *out = e;
     return AACG_OK;
 }
@@ -199,6 +201,11 @@ int aacg_get_table(aacg_engine* e, int which, float* dst, size_t n)
     case 3: src = e->h_win.kbd_long;     cnt = 1024; break;
     case 4: src = e->h_win.sine_short;   cnt = 128;  break;
     case 5: src = e->h_win.kbd_short;    cnt = 128;  break;
+    case 100:                                  /* profiling: raw phase-timestamp buffer of the last launch */
+        if (!e->d_trace) return AACG_ERR_INVALID_ARG;
+        (void)hipDeviceSynchronize();
+        (void)hipMemcpy(dst, e->d_trace, sizeof(float) * (n < (1u << 20) ? n : (1u << 20)), hipMemcpyDeviceToHost);
+        return (int)(1u << 20);
     default: return AACG_ERR_INVALID_ARG;
     }
     std::memcpy(dst, src, sizeof(float) * (n < cnt ? n : cnt));
@@ -267,7 +274,8 @@ int aacg_decode_device(aacg_engine* e, aacg_plan* p, const void* d_coeffs, const
     P.units = p->d_units; P.runs = p->d_runs; P.coeffs = d_coeffs; P.meta = d_meta; P.pcm = d_pcm;
     P.overlap = e->d_overlap; P.spec_out = nullptr; P.tab = e->d_tab;
     P.flip = (int32_t)(p->launches & 1u); P.n_runs = (int32_t)p->h.runs.size();
-    P.ablate = e->ablate;
+    P.ablate = e->d_trace ? e->ablate : (e->ablate & ~16);
+    if (e->d_trace) P.spec_out = (float*)e->d_trace;
     const dim3 grid((unsigned)p->h.runs.size()), block(AACG_WG_THREADS);
     if (quant) hipLaunchKernelGGL(aacg_imdct_run_quant, grid, block, AACG_LDS_BYTES_QUANT, s, P);
     else       hipLaunchKernelGGL(aacg_imdct_run_f32, grid, block, AACG_LDS_BYTES_F32, s, P);

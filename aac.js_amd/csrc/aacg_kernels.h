@@ -76,6 +76,34 @@ DP_DEVICE cpx lds_get(const float* base, int idx)
 }
 
 /* ------------------------------------------------------------------------------------ */
+/* unit descriptor: fetched as 16 scalar dwords (the address is wave-uniform), unpacked with    */
+/* SALU bit operations — byte-wide field reads would each be a vector-memory round trip          */
+/* ------------------------------------------------------------------------------------ */
+struct unit_view {
+    uint32_t pcm_offset, coef_offset, meta_offset;
+    int channel, n_out_ch, n_ch, flags;
+    int seq[2], shape[2], shape_prev[2], max_sfb[2];
+    uint32_t gmap[2];           /* 4 bits per window: its group (planner-filled reserved1[]) */
+};
+DP_DEVICE unit_view load_unit(const aacg_unit_desc* u)
+{
+    const uint32_t* w = (const uint32_t*)u;
+    unit_view v;
+    const uint32_t w2 = w[2], w3 = w[3];
+    v.pcm_offset = w[1]; v.coef_offset = w[4]; v.meta_offset = w[5];
+    v.channel = (int)(w2 & 0xffffu); v.n_out_ch = (int)(w2 >> 16);
+    v.n_ch = (int)(w3 & 0xffu); v.flags = (int)((w3 >> 8) & 0xffu);
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        const uint32_t ci = w[6 + 4 * c];
+        v.seq[c] = (int)(ci & 0xffu); v.shape[c] = (int)((ci >> 8) & 0xffu);
+        v.shape_prev[c] = (int)((ci >> 16) & 0xffu); v.max_sfb[c] = (int)(ci >> 24);
+        v.gmap[c] = w[14 + c];
+    }
+    return v;
+}
+
+/* ------------------------------------------------------------------------------------ */
 /* table staging: global (L2) -> LDS, once per workgroup                                   */
 /* ------------------------------------------------------------------------------------ */
 /* Split in two so that the table loads are issued BEFORE the wave's own spectrum loads: vector
@@ -618,24 +646,23 @@ DP_DEVICE void short_pair(const float* tab, const chan_par& cp, float* slot, dpv
 struct quant_regs { dpi4 ql[2], qr[2]; unsigned mw[2][2]; };
 
 /* the unit's quantised spectra (16 bytes per lane per load) and raw band words, issued early */
-DP_DEVICE void quant_load(const aacg_kparams& P, const aacg_unit_desc* u, int n_ch, quant_regs& r)
+DP_DEVICE void quant_load(const aacg_kparams& P, const unit_view& u, int n_ch, quant_regs& r)
 {
     const int lane = dp_lane();
-    const int16_t* q0 = (const int16_t*)P.coeffs + (size_t)u->coef_offset * 1024u;
-    const aacg_band_meta* meta = P.meta + u->meta_offset;
+    const int16_t* q0 = (const int16_t*)P.coeffs + (size_t)u.coef_offset * 1024u;
+    const aacg_band_meta* meta = P.meta + u.meta_offset;
+    /* unconditional loads (a single channel reads its own block twice): no per-load branches, so the
+     * compiler keeps all of them in flight together */
+    const int16_t* q1 = q0 + (n_ch == 2 ? 1024 : 0);
+    const aacg_band_meta* m1 = meta + (n_ch == 2 ? 1 : 0);
+    const int b1 = lane + 64 < AACG_MAX_SECTIONS ? lane + 64 : AACG_MAX_SECTIONS - 1;
 #pragma unroll
     for (int i = 0; i < 2; i++) {
         r.ql[i] = *(const dpi4*)(q0 + 8 * lane + 512 * i);
-        if (n_ch == 2) r.qr[i] = *(const dpi4*)(q0 + 1024 + 8 * lane + 512 * i);
-        else           { r.qr[i].x = r.qr[i].y = r.qr[i].z = r.qr[i].w = 0; }
+        r.qr[i] = *(const dpi4*)(q1 + 8 * lane + 512 * i);
     }
-#pragma unroll
-    for (int c = 0; c < 2; c++)
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-            const int b = lane + 64 * h;
-            r.mw[c][h] = (c < n_ch && b < AACG_MAX_SECTIONS) ? meta[c].band[b] : 0u;
-        }
+    r.mw[0][0] = meta->band[lane]; r.mw[0][1] = meta->band[b1];
+    r.mw[1][0] = m1->band[lane];   r.mw[1][1] = m1->band[b1];
 }
 
 DP_DEVICE void prepare_bands(const float* tab, const quant_regs& r, int n_ch, float* bt)
@@ -709,13 +736,13 @@ DP_DEVICE void dequant4_big(const aacg_tables* T, bool live, float sf, int p01, 
 
 /* Produces xl / xr[16]: element 8 i + e is coefficient 8 lane + 512 i + e of the left / right
  * (or single) channel after dequant, MS and IS. */
-DP_DEVICE void spectral_quant(const aacg_kparams& P, const float* tab, const aacg_unit_desc* u, int n_ch,
+DP_DEVICE void spectral_quant(const aacg_kparams& P, const float* tab, const unit_view& u, int n_ch,
                               const quant_regs& qreg, float* bt, float (&xl)[16], float (&xr)[16])
 {
     const int lane = dp_lane();
     chan_ctx ccL, ccR;
-    ccL.cls = u->ch[0].window_sequence == AACG_EIGHT_SHORT_SEQUENCE; ccL.max_sfb = u->ch[0].max_sfb; ccL.gmap = u->reserved1[0];
-    ccR.cls = u->ch[1].window_sequence == AACG_EIGHT_SHORT_SEQUENCE; ccR.max_sfb = u->ch[1].max_sfb; ccR.gmap = u->reserved1[1];
+    ccL.cls = u.seq[0] == AACG_EIGHT_SHORT_SEQUENCE; ccL.max_sfb = u.max_sfb[0]; ccL.gmap = u.gmap[0];
+    ccR.cls = u.seq[1] == AACG_EIGHT_SHORT_SEQUENCE; ccR.max_sfb = u.max_sfb[1]; ccR.gmap = u.gmap[1];
 
     const dpi4 (&ql)[2] = qreg.ql;
     const dpi4 (&qr)[2] = qreg.qr;
@@ -723,8 +750,8 @@ DP_DEVICE void spectral_quant(const aacg_kparams& P, const float* tab, const aac
     dp_wave_sync();
 
     const bool two = n_ch == 2;
-    const bool ms_on = two && (u->flags & AACG_UNIT_COMMON_WINDOW) && (u->flags & AACG_UNIT_MASK_PRESENT);
-    const bool mask  = (u->flags & AACG_UNIT_MASK_PRESENT) != 0;
+    const bool ms_on = two && (u.flags & AACG_UNIT_COMMON_WINDOW) && (u.flags & AACG_UNIT_MASK_PRESENT);
+    const bool mask  = (u.flags & AACG_UNIT_MASK_PRESENT) != 0;
     const int* bf = (const int*)bt + 256;
 
     /* per 4-coefficient group (bands are multiples of 4 wide): what MS / IS need later */
@@ -844,12 +871,12 @@ DP_DEVICE void stage_pair_f32(const dpf4 (&xa)[4], const dpf4 (&xb)[4], float* s
 
 /* IMDCT + window of a unit whose spectra are staged in its slot.  CPE tails always end up
  * interleaved (pair index n = (tailL[n], tailR[n])); a single channel's tail is planar. */
-DP_DEVICE void filter_unit(const float* tab, const aacg_unit_desc* u, int n_ch, bool pair_path, bool want_head, float* slot,
+DP_DEVICE void filter_unit(const float* tab, const unit_view& u, int n_ch, bool pair_path, bool want_head, float* slot,
                            float (&hx0)[8], float (&hy0)[8], float (&hx1)[8], float (&hy1)[8])
 {
     chan_par p0, p1;
-    p0.seq = u->ch[0].window_sequence; p0.shape = u->ch[0].window_shape; p0.shape_prev = u->ch[0].window_shape_prev;
-    p1.seq = u->ch[1].window_sequence; p1.shape = u->ch[1].window_shape; p1.shape_prev = u->ch[1].window_shape_prev;
+    p0.seq = u.seq[0]; p0.shape = u.shape[0]; p0.shape_prev = u.shape_prev[0];
+    p1.seq = u.seq[1]; p1.shape = u.shape[1]; p1.shape_prev = u.shape_prev[1];
     const bool s0 = p0.seq == AACG_EIGHT_SHORT_SEQUENCE, s1 = p1.seq == AACG_EIGHT_SHORT_SEQUENCE;
     if (pair_path) {
         dpv2 hx[8], hy[8];
@@ -911,16 +938,16 @@ DP_DEVICE dpf4 incoming(const float* p0, const float* p1, int n_ch, int n)
 }
 
 template <bool FROM_LDS>
-DP_DEVICE void epilogue(const float* p0, const float* p1, const aacg_unit_desc* u, int n_ch, int cls0, int cls1,
+DP_DEVICE void epilogue(const float* p0, const float* p1, const unit_view& u, int n_ch, int cls0, int cls1,
                         float* pcm_base, const float (&hx0)[8], const float (&hy0)[8],
                         const float (&hx1)[8], const float (&hy1)[8])
 {
     const int lane = dp_lane(), w = lane >> 3, g = lane & 7;
     const float S = 1.0f / 32768.0f;                   /* decoder.js:211 */
-    const int C = u->n_out_ch;
-    float* pcm = pcm_base + u->pcm_offset + u->channel;
+    const int C = u.n_out_ch;
+    float* pcm = pcm_base + u.pcm_offset + u.channel;
 
-    if (n_ch == 2 && C == 2 && cls0 == cls1 && ((u->pcm_offset | u->channel) & 3) == 0) {
+    if (n_ch == 2 && C == 2 && cls0 == cls1 && ((u.pcm_offset | (uint32_t)u.channel) & 3u) == 0) {
         /* stereo fast path: (L[n], R[n], L[n+1], R[n+1]) = 16 bytes per lane */
         if (!cls0) {
 #pragma unroll
@@ -1012,6 +1039,11 @@ DP_DEVICE void imdct_run_body(const aacg_kparams& P)
     float* slot = slots + wave * AACG_SLOT_FLOATS;
     int* flags = (int*)(slots + AACG_WG_WAVES * AACG_SLOT_FLOATS);
 
+    /* the table loads go first: everything behind them in the vector-memory queue may stay in flight
+     * while the tables are copied to LDS */
+    dpf4 tr0, tr1;
+    stage_tables_load(P.tab, TAB_FLOATS, tr0, tr1);
+
     const int n_units = run->n_units;
     const bool has_pred = run->pred_unit >= 0;
     int ui = -1;
@@ -1020,44 +1052,39 @@ DP_DEVICE void imdct_run_body(const aacg_kparams& P)
     ui = dp_uniform(ui);
     const bool is_pred_wave = has_pred && wave == 0;
 
+    float hx0[8], hy0[8], hx1[8], hy1[8];
+    /* scalar loads: nothing that may clobber memory (stores, clock reads) precedes them */
+    const unit_view u = load_unit(P.units + (ui >= 0 ? ui : 0));
     /* Earlier frames get the higher issue priority: they finish first and their PCM stores overlap
      * the later waves' arithmetic.  A wave only ever waits for the wave before it, whose priority is
      * never lower, so a spinning consumer cannot starve its producer. */
     dp_setprio(3 - (wave >> 2));
+    const unsigned long long t_start = (P.ablate & 16) ? dp_clock() : 0;
+    unsigned long long* trace = (P.ablate & 16) ? (unsigned long long*)P.spec_out + ((size_t)dp_block() * AACG_WG_WAVES + wave) * 8 : nullptr;
+    if (trace && lane == 0) trace[0] = t_start;
+    const int n_ch = ui >= 0 ? u.n_ch : 0;
+    const int cls0 = u.seq[0] == AACG_EIGHT_SHORT_SEQUENCE;
+    const int cls1 = u.seq[1] == AACG_EIGHT_SHORT_SEQUENCE;
+    const bool pair_path = n_ch == 2 && u.seq[0] == u.seq[1] && u.shape[0] == u.shape[1] && u.shape_prev[0] == u.shape_prev[1];
 
-    float hx0[8], hy0[8], hx1[8], hy1[8];
-    const aacg_unit_desc* u = P.units + (ui >= 0 ? ui : 0);
-    const int n_ch = ui >= 0 ? u->n_ch : 0;
-    const int cls0 = u->ch[0].window_sequence == AACG_EIGHT_SHORT_SEQUENCE;
-    const int cls1 = u->ch[1].window_sequence == AACG_EIGHT_SHORT_SEQUENCE;
-    const bool pair_path = n_ch == 2 && cls0 == cls1 &&
-                           u->ch[0].window_sequence == u->ch[1].window_sequence &&
-                           u->ch[0].window_shape == u->ch[1].window_shape &&
-                           u->ch[0].window_shape_prev == u->ch[1].window_shape_prev;
-
-    /* loads: tables first, then this wave's spectrum; only the tables are waited for before the barrier */
-    dpf4 tr0, tr1;
-    stage_tables_load(P.tab, TAB_FLOATS, tr0, tr1);
+    /* This wave's spectrum: only the tables are waited for before the barrier.  All loads are
+     * unconditional (an idle wave of a short run re-reads unit 0 and ignores it; a single channel reads
+     * its block twice): a load under a condition makes hipcc wait vmcnt(0) at the join, which would
+     * serialise the HBM round trips. */
     quant_regs qreg;
     dpf4 xa[4], xb[4];
-    if (ui >= 0) {
-        if (KIND == AACG_INPUT_QUANT_I16) {
-            quant_load(P, u, n_ch, qreg);
-        } else if (!(P.ablate & 4)) {
-            const float* x = (const float*)P.coeffs + (size_t)u->coef_offset * 1024u;
+    if (KIND == AACG_INPUT_QUANT_I16) {
+        quant_load(P, u, u.n_ch, qreg);
+    } else {
+        const float* x = (const float*)P.coeffs + (size_t)u.coef_offset * 1024u;
+        const float* x1 = x + (u.n_ch == 2 ? 1024 : 0);
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                xa[i] = *(const dpf4*)(x + 4 * lane + 256 * i);
-                if (n_ch == 2) xb[i] = *(const dpf4*)(x + 1024 + 4 * lane + 256 * i);
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < 4; i++) { xa[i].x = xa[i].y = xa[i].z = xa[i].w = (float)lane; xb[i] = xa[i]; }
-        }
+        for (int i = 0; i < 4; i++) { xa[i] = *(const dpf4*)(x + 4 * lane + 256 * i); xb[i] = *(const dpf4*)(x1 + 4 * lane + 256 * i); }
     }
     stage_tables_store(lds, TAB_FLOATS, tr0, tr1);
     if (lane == 0) flags[wave] = 0;
-    dp_block_sync();                                   /* tables and flags are in LDS */
+    dp_block_sync_lds();                               /* tables and flags are in LDS; the spectrum loads keep flying */
+    if (trace && lane == 0) trace[1] = dp_clock();
 
     if (ui >= 0 && (P.ablate & 1) && KIND != AACG_INPUT_QUANT_I16) {
 #pragma unroll
@@ -1065,6 +1092,15 @@ DP_DEVICE void imdct_run_body(const aacg_kparams& P)
     } else if (ui >= 0) {
         if (KIND == AACG_INPUT_QUANT_I16) {
             float xl[16], xr[16];
+            if (P.ablate & 8) {                        /* profiling: no dequant / MS / IS arithmetic */
+#pragma unroll
+                for (int i = 0; i < 2; i++) {
+                    xl[8 * i] = (float)qreg.ql[i].x; xl[8 * i + 1] = (float)qreg.ql[i].y; xl[8 * i + 2] = (float)qreg.ql[i].z; xl[8 * i + 3] = (float)qreg.ql[i].w;
+                    xl[8 * i + 4] = xl[8 * i]; xl[8 * i + 5] = xl[8 * i + 1]; xl[8 * i + 6] = xl[8 * i + 2]; xl[8 * i + 7] = xl[8 * i + 3];
+                    xr[8 * i] = (float)qreg.qr[i].x; xr[8 * i + 1] = (float)qreg.qr[i].y; xr[8 * i + 2] = (float)qreg.qr[i].z; xr[8 * i + 3] = (float)qreg.qr[i].w;
+                    xr[8 * i + 4] = xr[8 * i]; xr[8 * i + 5] = xr[8 * i + 1]; xr[8 * i + 6] = xr[8 * i + 2]; xr[8 * i + 7] = xr[8 * i + 3];
+                }
+            } else
             spectral_quant(P, tab, u, n_ch, qreg, slot + 1024, xl, xr);
             /* TNS would run here: identity as the reference executes it (tns.js:106,122) */
             if (pair_path) stage_pair_nat8(xl, xr, slot);
@@ -1080,12 +1116,14 @@ DP_DEVICE void imdct_run_body(const aacg_kparams& P)
             }
         }
         dp_wave_sync();
+        if (trace && lane == 0) trace[2] = dp_clock();     /* spectrum arrived and staged */
         filter_unit(tab, u, n_ch, pair_path, !is_pred_wave, slot, hx0, hy0, hx1, hy1);
     }
 
     /* this wave's tails are complete in its slot: release them to the next wave */
     dp_wave_sync();
     if (lane == 0) dp_flag_set(&flags[wave], 1);
+    if (trace && lane == 0) trace[3] = dp_clock();         /* IMDCT done, tail released */
 
     if (ui >= 0 && !is_pred_wave && (P.ablate & 2)) {
         /* profiling: keep the values live without storing 8 KiB of PCM */
@@ -1102,8 +1140,10 @@ DP_DEVICE void imdct_run_body(const aacg_kparams& P)
             epilogue<false>(ov0, ov1, u, n_ch, cls0, cls1, P.pcm, hx0, hy0, hx1, hy1);
         } else {
             dp_flag_wait(&flags[wave - 1], 1);         /* the previous frame's tails (acquire) */
+            if (trace && lane == 0) trace[4] = dp_clock();
             epilogue<true>(slot - AACG_SLOT_FLOATS, slot - AACG_SLOT_FLOATS, u, n_ch, cls0, cls1, P.pcm, hx0, hy0, hx1, hy1);
         }
+        if (trace && lane == 0) trace[5] = dp_clock();     /* PCM stores issued */
         /* the chain's last frame in this launch: its tail is the new overlap state (planar in HBM) */
         const int last_wave = has_pred ? n_units : n_units - 1;
         if (wave == last_wave && run->is_last) {
@@ -1138,13 +1178,13 @@ DP_DEVICE void spectral_body(const aacg_kparams& P, int n_units)
     dp_block_sync();
     const int ui = dp_block() * AACG_WG_WAVES + wave;
     if (ui >= n_units) return;
-    const aacg_unit_desc* u = P.units + ui;
-    const int n_ch = u->n_ch;
+    const unit_view u = load_unit(P.units + dp_uniform(ui));
+    const int n_ch = u.n_ch;
     float xl[16], xr[16];
     quant_regs qreg;
     quant_load(P, u, n_ch, qreg);
     spectral_quant(P, tab, u, n_ch, qreg, bt, xl, xr);
-    float* out = P.spec_out + (size_t)u->coef_offset * 1024u;
+    float* out = P.spec_out + (size_t)u.coef_offset * 1024u;
 #pragma unroll
     for (int i = 0; i < 2; i++) {
         dpf4 a, b;

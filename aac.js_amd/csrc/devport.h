@@ -43,6 +43,13 @@ DP_DEVICE void dp_wave_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 DP_DEVICE void dp_block_sync() { __syncthreads(); }
+/* Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the vector-memory
+ * counter (vmcnt(0)), i.e. it would make every wave wait for its in-flight HBM loads; here the
+ * loads keep flying across the barrier and are waited for where their data is first used. */
+DP_DEVICE void dp_block_sync_lds()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
 
 /* wave -> wave hand-off inside one workgroup through an LDS word (all waves of a workgroup are
  * resident, the producer never waits on its consumer).  Release/acquire at workgroup scope. */
@@ -77,6 +84,8 @@ DP_DEVICE bool dp_any(bool p) { return __any(p) != 0; }
 /* hide a value from common-subexpression elimination: a table load behind it is re-issued
  * (an L1 hit) instead of its result being held in VGPRs across the whole FFT */
 DP_DEVICE int dp_opaque(int v) { asm volatile("" : "+v"(v)); return v; }
+/* constant-rate (100 MHz) wall clock, same time base on every CU: phase timelines for profiling */
+DP_DEVICE unsigned long long dp_clock() { return wall_clock64(); }
 DP_DEVICE float dp_nan() { return __builtin_nanf(""); }
 /* keep the instruction scheduler from hoisting the next block's loads above this point
  * (bounds the number of gathers in flight, i.e. VGPR pressure) */

@@ -49,6 +49,7 @@ DP_DEVICE int dp_block() { return g_emu.b->block_id; }
 DP_DEVICE int dp_uniform(int v) { return v; }
 DP_DEVICE void dp_wave_sync()  { pthread_barrier_wait(&g_emu.w->bar); }
 DP_DEVICE void dp_block_sync() { pthread_barrier_wait(&g_emu.b->bar); }
+DP_DEVICE void dp_block_sync_lds() { pthread_barrier_wait(&g_emu.b->bar); }
 DP_DEVICE void dp_flag_set(int* flag, int v) { __atomic_store_n(flag, v, __ATOMIC_RELEASE); }
 DP_DEVICE void dp_flag_wait(int* flag, int v) { while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != v) sched_yield(); }
 DP_DEVICE void dp_setprio(int) {}
@@ -75,6 +76,7 @@ DP_DEVICE bool dp_any(bool p)
 
 DP_DEVICE unsigned char* dp_lds() { return g_emu.b->lds; }
 DP_DEVICE float dp_fma(float a, float b, float c) { return fmaf(a, b, c); }
+DP_DEVICE unsigned long long dp_clock() { return 0; }
 DP_DEVICE float dp_nan() { return NAN; }
 DP_DEVICE int dp_opaque(int v) { return v; }
 DP_DEVICE void dp_sched_fence() {}
