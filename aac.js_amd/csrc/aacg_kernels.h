@@ -957,7 +957,7 @@ DP_DEVICE void epilogue(const float* p0, const float* p1, const unit_view& u, in
                 dpf4 o;
                 o.x = (v.x + hx0[m]) * S; o.y = (v.y + hx1[m]) * S;
                 o.z = (v.z + hy0[m]) * S; o.w = (v.w + hy1[m]) * S;
-                *(dpf4*)(pcm + 2 * n) = o;
+                dp_store_nt((dpf4*)(pcm + 2 * n), o);
             }
         } else {
 #pragma unroll
@@ -968,7 +968,7 @@ DP_DEVICE void epilogue(const float* p0, const float* p1, const unit_view& u, in
                     dpf4 o;
                     o.x = (v.x + hx0[m]) * S; o.y = (v.y + hx1[m]) * S;
                     o.z = (v.z + hy0[m]) * S; o.w = (v.w + hy1[m]) * S;
-                    *(dpf4*)(pcm + 2 * n) = o;
+                    dp_store_nt((dpf4*)(pcm + 2 * n), o);
                 }
             }
 #pragma unroll
@@ -977,7 +977,7 @@ DP_DEVICE void epilogue(const float* p0, const float* p1, const unit_view& u, in
                 if (n < 448) {
                     const dpf4 v = incoming<FROM_LDS>(p0, p1, 2, n);
                     dpf4 o; o.x = v.x * S; o.y = v.y * S; o.z = v.z * S; o.w = v.w * S;
-                    *(dpf4*)(pcm + 2 * n) = o;
+                    dp_store_nt((dpf4*)(pcm + 2 * n), o);
                 }
             }
         }

@@ -84,6 +84,25 @@ DP_DEVICE bool dp_any(bool p) { return __any(p) != 0; }
 /* hide a value from common-subexpression elimination: a table load behind it is re-issued
  * (an L1 hit) instead of its result being held in VGPRs across the whole FFT */
 DP_DEVICE int dp_opaque(int v) { asm volatile("" : "+v"(v)); return v; }
+/* streaming (non-temporal) 16-byte accesses: PCM is written once and never re-read by the kernel,
+ * spectra are read once */
+typedef float dp_nv4 __attribute__((ext_vector_type(4)));
+DP_DEVICE void dp_store_nt(dpf4* p, dpf4 v)
+{
+    dp_nv4 t; t[0] = v.x; t[1] = v.y; t[2] = v.z; t[3] = v.w;
+    __builtin_nontemporal_store(t, (dp_nv4*)p);
+}
+typedef int dp_ni4 __attribute__((ext_vector_type(4)));
+DP_DEVICE dpi4 dp_load_nt_i4(const dpi4* p)
+{
+    const dp_ni4 t = __builtin_nontemporal_load((const dp_ni4*)p);
+    dpi4 v; v.x = t[0]; v.y = t[1]; v.z = t[2]; v.w = t[3]; return v;
+}
+DP_DEVICE dpf4 dp_load_nt(const dpf4* p)
+{
+    const dp_nv4 t = __builtin_nontemporal_load((const dp_nv4*)p);
+    dpf4 v; v.x = t[0]; v.y = t[1]; v.z = t[2]; v.w = t[3]; return v;
+}
 /* constant-rate (100 MHz) wall clock, same time base on every CU: phase timelines for profiling */
 DP_DEVICE unsigned long long dp_clock() { return wall_clock64(); }
 DP_DEVICE float dp_nan() { return __builtin_nanf(""); }

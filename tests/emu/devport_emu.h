@@ -76,6 +76,9 @@ DP_DEVICE bool dp_any(bool p)
 
 DP_DEVICE unsigned char* dp_lds() { return g_emu.b->lds; }
 DP_DEVICE float dp_fma(float a, float b, float c) { return fmaf(a, b, c); }
+DP_DEVICE void dp_store_nt(dpf4* p, dpf4 v) { *p = v; }
+DP_DEVICE dpf4 dp_load_nt(const dpf4* p) { return *p; }
+DP_DEVICE dpi4 dp_load_nt_i4(const dpi4* p) { return *p; }
 DP_DEVICE unsigned long long dp_clock() { return 0; }
 DP_DEVICE float dp_nan() { return NAN; }
 DP_DEVICE int dp_opaque(int v) { return v; }
