@@ -1058,7 +1058,7 @@ DP_DEVICE void imdct_run_body(const aacg_kparams& P)
     /* Earlier frames get the higher issue priority: they finish first and their PCM stores overlap
      * the later waves' arithmetic.  A wave only ever waits for the wave before it, whose priority is
      * never lower, so a spinning consumer cannot starve its producer. */
-    dp_setprio(3 - (wave >> 2));
+    if (P.ablate & 64) dp_setprio(0); else if (P.ablate & 32) dp_setprio(1 - (wave >> 3)); else dp_setprio(3 - (wave >> 2));
     const unsigned long long t_start = (P.ablate & 16) ? dp_clock() : 0;
     unsigned long long* trace = (P.ablate & 16) ? (unsigned long long*)P.spec_out + ((size_t)dp_block() * AACG_WG_WAVES + wave) * 8 : nullptr;
     if (trace && lane == 0) trace[0] = t_start;
