@@ -29,7 +29,8 @@ struct aacg_tables {
     float win_short[2][128];          /* SINE_128,  KBD_128  (filter_bank.js:82,84) */
     /* ---- end of the part the f32 kernel stages (AACG_TAB_F32_FLOATS) ---- */
     float sf[432];                    /* SCALEFACTOR_TABLE (tables.js:168-176), 428 used */
-    float iq_small[512];              /* IQ_TABLE[0..511] (tables.js:182-191): the common magnitudes */
+    float iq_signed[1024];            /* sign(q) * IQ_TABLE[|q|] for q = -512..511 at [q + 512] (tables.js:182-191, ics.js:251:
+                                         q = 0 gives -0); larger magnitudes take the full table below */
     uint8_t band_of_long[1024];       /* coefficient -> sfb for this sample_index (tables.js:34-155) */
     uint8_t band_of_short[128];
     /* ---- end of the part the quant kernel stages (AACG_TAB_QUANT_FLOATS) ---- */
@@ -45,7 +46,7 @@ struct aacg_tables {
 #define AACG_TAB_F32_FLOATS       (AACG_TAB_OFF_WIN_SHORT + 2 * 128)
 #define AACG_TAB_OFF_SF           AACG_TAB_F32_FLOATS
 #define AACG_TAB_OFF_IQ_SMALL     (AACG_TAB_OFF_SF + 432)
-#define AACG_TAB_OFF_BAND_LONG    (AACG_TAB_OFF_IQ_SMALL + 512)
+#define AACG_TAB_OFF_BAND_LONG    (AACG_TAB_OFF_IQ_SMALL + 1024)
 #define AACG_TAB_OFF_BAND_SHORT   (AACG_TAB_OFF_BAND_LONG + 256)
 #define AACG_TAB_QUANT_FLOATS     (AACG_TAB_OFF_BAND_SHORT + 32)
 

@@ -703,31 +703,32 @@ DP_DEVICE int band_index(const float* tab, const chan_ctx& cc, int pos)
     return sfb < cc.max_sfb ? g * cc.max_sfb + sfb : -1;
 }
 
-/* |q|^(4/3) * sign(q) * sf for four coefficients packed as two dwords of int16 pairs, branch-free:
- * magnitudes below 512 come from the LDS copy of IQ_TABLE; `big` collects the magnitudes so that the
- * caller can patch the rare larger ones afterwards.  q == 0 gives -0 like ics.js:251; an uncoded,
- * ZERO or INTENSITY band gives +0 (ics.js:222-227). */
-DP_DEVICE void dequant4(const float* tab, bool live, float sf, int p01, int p23, float (&x)[4], int& big)
+/* sign(q) |q|^(4/3) sf for four coefficients packed as two dwords of int16 pairs, branch-free: one
+ * LDS lookup in the signed table (q = -512..511) per coefficient; `oor` collects q + 512 so that the
+ * caller can detect and patch the rare larger magnitudes afterwards.  q == 0 gives -0 like ics.js:251;
+ * an uncoded, ZERO or INTENSITY band gives +0 (ics.js:222-227). */
+DP_DEVICE void dequant4(const float* tab, bool live, float sf, int p01, int p23, float (&x)[4], int& oor)
 {
     const int q[4] = {(int)(short)(p01 & 0xffff), p01 >> 16, (int)(short)(p23 & 0xffff), p23 >> 16};
 #pragma unroll
     for (int e = 0; e < 4; e++) {
-        const int a = q[e] < 0 ? -q[e] : q[e];
-        big |= a;
-        const float v = tab[AACG_TAB_OFF_IQ_SMALL + (a > 511 ? 511 : a)];
-        const float sv = q[e] > 0 ? v : -v;
-        x[e] = live ? sv * sf : 0.0f;
+        const int t = q[e] + 512;
+        oor |= t;
+        const int idx = t < 0 ? 0 : (t > 1023 ? 1023 : t);
+        const float v = tab[AACG_TAB_OFF_IQ_SMALL + idx];
+        x[e] = live ? v * sf : 0.0f;
     }
 }
 
-/* the rare magnitudes >= 512: full IQ_TABLE in global memory; [8191] = NaN like the JS out-of-range read */
+/* the rare magnitudes outside the LDS table: full IQ_TABLE in global memory; [8191] = NaN like the JS
+ * out-of-range read */
 DP_DEVICE void dequant4_big(const aacg_tables* T, bool live, float sf, int p01, int p23, float (&x)[4])
 {
     const int q[4] = {(int)(short)(p01 & 0xffff), p01 >> 16, (int)(short)(p23 & 0xffff), p23 >> 16};
 #pragma unroll
     for (int e = 0; e < 4; e++) {
         const int a = q[e] < 0 ? -q[e] : q[e];
-        if (live && a >= 512) {
+        if (live && ((q[e] + 512) & ~1023)) {
             const float v = T->iq[a > 8191 ? 8191 : a];
             x[e] = (q[e] > 0 ? v : -v) * sf;
         }
@@ -790,7 +791,7 @@ DP_DEVICE void spectral_quant(const aacg_kparams& P, const float* tab, const uni
         g_isc[k] = neg ? -sfR[k] : sfR[k];
     }
 
-    if (dp_any(big >= 512)) {                          /* escape-coded magnitudes: rare */
+    if (dp_any((big & ~1023) != 0)) {                  /* escape-coded magnitudes: rare */
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const int i = k >> 1, h = k & 1;

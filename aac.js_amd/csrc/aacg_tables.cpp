@@ -134,7 +134,7 @@ int aacg_build_tables(int sample_index, aacg_tables* t, aacg_host_windows* hw)
 
     for (int i = 0; i < 8191; i++) t->iq[i] = (float)std::pow((double)i, 4.0 / 3.0);
     t->iq[8191] = std::numeric_limits<float>::quiet_NaN();
-    std::memcpy(t->iq_small, t->iq, sizeof t->iq_small);
+    for (int q = -512; q < 512; q++) t->iq_signed[q + 512] = q > 0 ? t->iq[q] : -t->iq[-q];
     for (int i = 0; i < 428; i++) t->sf[i] = (float)std::pow(2.0, (i - 200) / 4.0);
 
     std::vector<int> off;
@@ -150,7 +150,7 @@ int aacg_build_tables(int sample_index, aacg_tables* t, aacg_host_windows* hw)
     static_assert(offsetof(aacg_tables, win_long) == 4 * AACG_TAB_OFF_WIN_LONG, "table map");
     static_assert(offsetof(aacg_tables, win_short) == 4 * AACG_TAB_OFF_WIN_SHORT, "table map");
     static_assert(offsetof(aacg_tables, sf) == 4 * AACG_TAB_OFF_SF, "table map");
-    static_assert(offsetof(aacg_tables, iq_small) == 4 * AACG_TAB_OFF_IQ_SMALL, "table map");
+    static_assert(offsetof(aacg_tables, iq_signed) == 4 * AACG_TAB_OFF_IQ_SMALL, "table map");
     static_assert(offsetof(aacg_tables, band_of_long) == 4 * AACG_TAB_OFF_BAND_LONG, "table map");
     static_assert(offsetof(aacg_tables, band_of_short) == 4 * AACG_TAB_OFF_BAND_SHORT, "table map");
     static_assert(offsetof(aacg_tables, iq) == 4 * AACG_TAB_QUANT_FLOATS, "table map");
