@@ -39,10 +39,20 @@ struct aacg_engine {
     std::vector<uint8_t> parity;            /* live buffer per (stream, channel) */
     aacg_tables h_tab;
     aacg_host_windows h_win;
-    /* scratch of the host-buffer path, grown on demand */
-    void*  d_coeffs = nullptr;  size_t coeffs_cap = 0;
-    aacg_band_meta* d_meta = nullptr; size_t meta_cap = 0;
-    float* d_pcm = nullptr;     size_t pcm_cap = 0;
+    /* host-buffer path: two pipeline slots (stream + device buffers grown on demand) */
+    struct slot_t {
+        hipStream_t stream = nullptr;
+        hipEvent_t done = nullptr, kernel_done = nullptr;
+        bool busy = false;
+        void* d_units = nullptr;  size_t units_cap = 0;
+        void* d_runs = nullptr;   size_t runs_cap = 0;
+        void* d_coeffs = nullptr; size_t coeffs_cap = 0;
+        void* d_meta = nullptr;   size_t meta_cap = 0;
+        void* d_pcm = nullptr;    size_t pcm_cap = 0;
+        aacg_plan_host h;
+    } slot[2];
+    uint64_t submitted = 0;
+    hipEvent_t last_kernel = nullptr;       /* completion of the most recently submitted batch's kernel */
     void* d_trace = nullptr;                /* profiling: per-wave phase timestamps when (ablate & 16) */
     int ablate = 0;                         /* profiling knob, env AACG_ABLATE (see aacg_device.h); 0 in normal use */
     std::string err;
@@ -76,6 +86,26 @@ int grow(aacg_engine* e, void** p, size_t* cap, size_t need)
     if (*p) { (void)hipFree(*p); *p = nullptr; *cap = 0; }
     HIP_TRY(e, hipMalloc(p, need), AACG_ERR_OUT_OF_MEMORY);
     *cap = need;
+    return AACG_OK;
+}
+
+/* enqueue the run kernel for a planned batch (device pointers) */
+int launch_run(aacg_engine* e, const aacg_unit_desc* d_units, const aacg_run* d_runs, const aacg_plan_host& h,
+               const void* d_coeffs, const aacg_band_meta* d_meta, float* d_pcm, int flip, hipStream_t s)
+{
+    const bool quant = e->cfg.input_kind == AACG_INPUT_QUANT_I16;
+    if (h.zero_fill)
+        HIP_TRY(e, hipMemsetAsync(d_pcm, 0, h.pcm_floats * sizeof(float), s), AACG_ERR_NO_DEVICE);
+    aacg_kparams P;
+    P.units = d_units; P.runs = d_runs; P.coeffs = d_coeffs; P.meta = d_meta; P.pcm = d_pcm;
+    P.overlap = e->d_overlap; P.spec_out = nullptr; P.tab = e->d_tab;
+    P.flip = flip; P.n_runs = (int32_t)h.runs.size();
+    P.ablate = e->d_trace ? e->ablate : (e->ablate & ~16);
+    if (e->d_trace) P.spec_out = (float*)e->d_trace;
+    const dim3 grid((unsigned)h.runs.size()), block(AACG_WG_THREADS);
+    if (quant) hipLaunchKernelGGL(aacg_imdct_run_quant, grid, block, AACG_LDS_BYTES_QUANT, s, P);
+    else       hipLaunchKernelGGL(aacg_imdct_run_f32, grid, block, AACG_LDS_BYTES_F32, s, P);
+    HIP_TRY(e, hipGetLastError(), AACG_ERR_NO_DEVICE);
     return AACG_OK;
 }
 
@@ -137,9 +167,13 @@ void aacg_destroy(aacg_engine* e)
     (void)hipDeviceSynchronize();
     if (e->d_tab) (void)hipFree(e->d_tab);
     if (e->d_overlap) (void)hipFree(e->d_overlap);
-    if (e->d_coeffs) (void)hipFree(e->d_coeffs);
-    if (e->d_meta) (void)hipFree(e->d_meta);
-    if (e->d_pcm) (void)hipFree(e->d_pcm);
+    for (auto& sl : e->slot) {
+        for (void* p : {sl.d_units, sl.d_runs, sl.d_coeffs, sl.d_meta, sl.d_pcm}) if (p) (void)hipFree(p);
+        if (sl.done) (void)hipEventDestroy(sl.done);
+        if (sl.kernel_done) (void)hipEventDestroy(sl.kernel_done);
+        if (sl.stream) (void)hipStreamDestroy(sl.stream);
+    }
+    if (e->d_trace) (void)hipFree(e->d_trace);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }
@@ -267,19 +301,8 @@ int aacg_decode_device(aacg_engine* e, aacg_plan* p, const void* d_coeffs, const
     int rc = plan_check_parity(e, p);
     if (rc) return rc;
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : e->stream;
-    if (p->h.zero_fill)
-        HIP_TRY(e, hipMemsetAsync(d_pcm, 0, p->h.pcm_floats * sizeof(float), s), AACG_ERR_NO_DEVICE);
-
-    aacg_kparams P;
-    P.units = p->d_units; P.runs = p->d_runs; P.coeffs = d_coeffs; P.meta = d_meta; P.pcm = d_pcm;
-    P.overlap = e->d_overlap; P.spec_out = nullptr; P.tab = e->d_tab;
-    P.flip = (int32_t)(p->launches & 1u); P.n_runs = (int32_t)p->h.runs.size();
-    P.ablate = e->d_trace ? e->ablate : (e->ablate & ~16);
-    if (e->d_trace) P.spec_out = (float*)e->d_trace;
-    const dim3 grid((unsigned)p->h.runs.size()), block(AACG_WG_THREADS);
-    if (quant) hipLaunchKernelGGL(aacg_imdct_run_quant, grid, block, AACG_LDS_BYTES_QUANT, s, P);
-    else       hipLaunchKernelGGL(aacg_imdct_run_f32, grid, block, AACG_LDS_BYTES_F32, s, P);
-    HIP_TRY(e, hipGetLastError(), AACG_ERR_NO_DEVICE);
+    rc = launch_run(e, p->d_units, p->d_runs, p->h, d_coeffs, d_meta, d_pcm, (int)(p->launches & 1u), s);
+    if (rc) return rc;
 
     for (const aacg_chain& c : p->h.chains)
         for (int k = 0; k < c.n_ch; k++)
@@ -311,25 +334,54 @@ int aacg_synchronize(aacg_engine* e, void* hip_stream)
 }
 
 /* ---- host-buffer path: process(elements) + interleave for a batch ------------------- */
-int aacg_decode_batch(aacg_engine* e, const aacg_unit_desc* units, uint32_t n_units,
-                      const void* coeffs, uint32_t n_coef_blocks,
-                      const aacg_band_meta* meta, uint32_t n_meta,
-                      float* pcm_out, size_t n_pcm_floats)
+void* aacg_host_alloc(size_t bytes)
 {
-    if (!e || !units || !n_units || !coeffs || !pcm_out) return AACG_ERR_INVALID_ARG;
+    void* p = nullptr;
+    return hipHostMalloc(&p, bytes, hipHostMallocDefault) == hipSuccess ? p : nullptr;
+}
+void aacg_host_free(void* p) { if (p) (void)hipHostFree(p); }
+
+int aacg_wait(aacg_engine* e, uint64_t ticket)
+{
+    if (!e || ticket == 0 || ticket > e->submitted) return AACG_ERR_INVALID_ARG;
+    aacg_engine::slot_t& sl = e->slot[(ticket - 1) & 1];
+    if (sl.busy) {
+        HIP_TRY(e, hipEventSynchronize(sl.done), AACG_ERR_NO_DEVICE);
+        sl.busy = false;
+    }
+    return AACG_OK;
+}
+
+int aacg_submit(aacg_engine* e, const aacg_unit_desc* units, uint32_t n_units,
+                const void* coeffs, uint32_t n_coef_blocks,
+                const aacg_band_meta* meta, uint32_t n_meta,
+                float* pcm_out, size_t n_pcm_floats, uint64_t* ticket)
+{
+    if (!e || !units || !n_units || !coeffs || !pcm_out || !ticket) return AACG_ERR_INVALID_ARG;
     const bool quant = e->cfg.input_kind == AACG_INPUT_QUANT_I16;
     if (quant && !meta) { e->err = "QUANT_I16 engine needs band meta"; return AACG_ERR_INVALID_ARG; }
     if (e->cfg.max_batch_units > 0 && (int)n_units > e->cfg.max_batch_units) {
         e->err = "batch exceeds max_batch_units";
         return AACG_ERR_CAPACITY;
     }
+    HIP_TRY(e, hipSetDevice(e->cfg.device_ordinal), AACG_ERR_NO_DEVICE);
+    aacg_engine::slot_t& sl = e->slot[e->submitted & 1];
+    if (sl.busy) {                                     /* the batch two submissions ago was never waited for */
+        HIP_TRY(e, hipEventSynchronize(sl.done), AACG_ERR_NO_DEVICE);
+        sl.busy = false;
+    }
+    if (!sl.stream) {
+        HIP_TRY(e, hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking), AACG_ERR_NO_DEVICE);
+        HIP_TRY(e, hipEventCreateWithFlags(&sl.done, hipEventDisableTiming), AACG_ERR_NO_DEVICE);
+        HIP_TRY(e, hipEventCreateWithFlags(&sl.kernel_done, hipEventDisableTiming), AACG_ERR_NO_DEVICE);
+    }
 
-    aacg_plan* p = nullptr;
-    int rc = aacg_plan_create(e, units, n_units, &p);
+    int rc = aacg_plan_build(units, n_units, e->cfg.sample_index, e->cfg.max_streams, e->cfg.max_channels,
+                             e->parity.data(), &sl.h, &e->err);
     if (rc) return rc;
-    if (p->h.coef_blocks > n_coef_blocks || (quant && p->h.meta_blocks > n_meta) || p->h.pcm_floats > n_pcm_floats) {
+    const aacg_plan_host& h = sl.h;
+    if (h.coef_blocks > n_coef_blocks || (quant && h.meta_blocks > n_meta) || h.pcm_floats > n_pcm_floats) {
         e->err = "a unit points outside the coefficient / meta / pcm buffers";
-        aacg_plan_destroy(p);
         return AACG_ERR_INVALID_ARG;
     }
     if (quant) {
@@ -342,30 +394,54 @@ int aacg_decode_batch(aacg_engine* e, const aacg_unit_desc* units, uint32_t n_un
                 for (int b = 0; b < ci.group_count * ci.max_sfb; b++)
                     if ((m.band[b] >> AACG_META_BT_SHIFT) == AACG_NOISE_BT) {
                         e->err = "NOISE_BT (PNS) band: not decodable by the reference either";
-                        aacg_plan_destroy(p);
                         return AACG_ERR_UNSUPPORTED;
                     }
             }
     }
 
+    const size_t ub = sizeof(aacg_unit_desc) * h.units.size(), rb = sizeof(aacg_run) * h.runs.size();
     const size_t cb = (size_t)n_coef_blocks * 1024u * coef_elem_size(e);
     const size_t mb = quant ? (size_t)n_meta * sizeof(aacg_band_meta) : 0;
-    const size_t pb = n_pcm_floats * sizeof(float);
-    rc = grow(e, &e->d_coeffs, &e->coeffs_cap, cb);
-    if (!rc && quant) rc = grow(e, (void**)&e->d_meta, &e->meta_cap, mb);
-    if (!rc) rc = grow(e, (void**)&e->d_pcm, &e->pcm_cap, pb);
-    if (rc) { aacg_plan_destroy(p); return rc; }
+    const size_t pb = h.pcm_floats * sizeof(float);
+    if ((rc = grow(e, &sl.d_units, &sl.units_cap, ub)) || (rc = grow(e, &sl.d_runs, &sl.runs_cap, rb)) ||
+        (rc = grow(e, &sl.d_coeffs, &sl.coeffs_cap, cb)) || (quant && (rc = grow(e, &sl.d_meta, &sl.meta_cap, mb))) ||
+        (rc = grow(e, &sl.d_pcm, &sl.pcm_cap, pb)))
+        return rc;
 
-    bool ok = hip_ok(e, hipMemcpyAsync(e->d_coeffs, coeffs, cb, hipMemcpyHostToDevice, e->stream), "H2D coeffs");
-    if (ok && quant) ok = hip_ok(e, hipMemcpyAsync(e->d_meta, meta, mb, hipMemcpyHostToDevice, e->stream), "H2D meta");
-    if (ok) {
-        rc = aacg_decode_device(e, p, e->d_coeffs, e->d_meta, e->d_pcm, e->stream);
-        if (!rc) ok = hip_ok(e, hipMemcpyAsync(pcm_out, e->d_pcm, p->h.pcm_floats * sizeof(float), hipMemcpyDeviceToHost, e->stream), "D2H pcm") &&
-                      hip_ok(e, hipStreamSynchronize(e->stream), "sync");
-    }
-    aacg_plan_destroy(p);
+    hipStream_t s = sl.stream;
+    HIP_TRY(e, hipMemcpyAsync(sl.d_units, h.units.data(), ub, hipMemcpyHostToDevice, s), AACG_ERR_NO_DEVICE);
+    HIP_TRY(e, hipMemcpyAsync(sl.d_runs, h.runs.data(), rb, hipMemcpyHostToDevice, s), AACG_ERR_NO_DEVICE);
+    HIP_TRY(e, hipMemcpyAsync(sl.d_coeffs, coeffs, cb, hipMemcpyHostToDevice, s), AACG_ERR_NO_DEVICE);
+    if (quant) HIP_TRY(e, hipMemcpyAsync(sl.d_meta, meta, mb, hipMemcpyHostToDevice, s), AACG_ERR_NO_DEVICE);
+    /* kernels chain through the overlap state: this one starts after the previous batch's kernel,
+     * while its uploads above overlapped it */
+    if (e->last_kernel) HIP_TRY(e, hipStreamWaitEvent(s, e->last_kernel, 0), AACG_ERR_NO_DEVICE);
+    rc = launch_run(e, (const aacg_unit_desc*)sl.d_units, (const aacg_run*)sl.d_runs, h, sl.d_coeffs,
+                    (const aacg_band_meta*)sl.d_meta, (float*)sl.d_pcm, 0, s);
     if (rc) return rc;
-    return ok ? AACG_OK : AACG_ERR_NO_DEVICE;
+    HIP_TRY(e, hipEventRecord(sl.kernel_done, s), AACG_ERR_NO_DEVICE);
+    e->last_kernel = sl.kernel_done;
+    HIP_TRY(e, hipMemcpyAsync(pcm_out, sl.d_pcm, pb, hipMemcpyDeviceToHost, s), AACG_ERR_NO_DEVICE);
+    HIP_TRY(e, hipEventRecord(sl.done, s), AACG_ERR_NO_DEVICE);
+    sl.busy = true;
+
+    for (const aacg_chain& c : h.chains)
+        for (int k = 0; k < c.n_ch; k++)
+            e->parity[(size_t)c.stream * (size_t)e->cfg.max_channels + c.channel + k] ^= 1;
+    *ticket = ++e->submitted;
+    return AACG_OK;
+}
+
+/* Synchronous form: process(elements) + interleave for a whole batch. */
+int aacg_decode_batch(aacg_engine* e, const aacg_unit_desc* units, uint32_t n_units,
+                      const void* coeffs, uint32_t n_coef_blocks,
+                      const aacg_band_meta* meta, uint32_t n_meta,
+                      float* pcm_out, size_t n_pcm_floats)
+{
+    uint64_t t = 0;
+    int rc = aacg_submit(e, units, n_units, coeffs, n_coef_blocks, meta, n_meta, pcm_out, n_pcm_floats, &t);
+    if (rc) return rc;
+    return aacg_wait(e, t);
 }
 
 }  // extern "C"

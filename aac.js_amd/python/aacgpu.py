@@ -19,7 +19,8 @@ ERR_NAMES = {0: "OK", -1: "INVALID_ARG", -2: "NO_DEVICE", -3: "OUT_OF_MEMORY", -
 
 # every symbol include/aacgpu.h declares
 ABI_SYMBOLS = ["aacg_create", "aacg_destroy", "aacg_last_error", "aacg_abi_version", "aacg_reset_stream",
-               "aacg_get_overlap", "aacg_set_overlap", "aacg_decode_batch", "aacg_plan_create", "aacg_plan_destroy",
+               "aacg_get_overlap", "aacg_set_overlap", "aacg_decode_batch", "aacg_submit", "aacg_wait",
+               "aacg_host_alloc", "aacg_host_free", "aacg_plan_create", "aacg_plan_destroy",
                "aacg_decode_device", "aacg_spectral_device", "aacg_synchronize", "aacg_get_table", "aacg_kernel_name"]
 
 UNIT_DTYPE = np.dtype([
@@ -89,6 +90,13 @@ def load_library(path=LIB_PATH):
     L.aacg_set_overlap.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
     L.aacg_decode_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32,
                                     C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t]
+    L.aacg_submit.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32,
+                              C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64)]
+    L.aacg_wait.argtypes = [C.c_void_p, C.c_uint64]
+    L.aacg_host_alloc.restype = C.c_void_p
+    L.aacg_host_alloc.argtypes = [C.c_size_t]
+    L.aacg_host_free.restype = None
+    L.aacg_host_free.argtypes = [C.c_void_p]
     L.aacg_plan_create.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]
     L.aacg_plan_destroy.argtypes = [C.c_void_p]
     L.aacg_plan_destroy.restype = None
@@ -162,6 +170,30 @@ class Engine:
                                                meta.ctypes.data if meta is not None else None,
                                                meta.size // 120 if meta is not None else 0, pcm.ctypes.data, pcm.size))
         return pcm
+
+    def submit(self, units, coeffs, meta, pcm):
+        """Asynchronous decode_batch into the caller's `pcm` array (keep every array alive until wait)."""
+        assert units.dtype == UNIT_DTYPE and units.flags.c_contiguous and coeffs.flags.c_contiguous and pcm.flags.c_contiguous
+        t = C.c_uint64()
+        self._check(self.lib.aacg_submit(self.handle, units.ctypes.data, len(units), coeffs.ctypes.data, coeffs.size // 1024,
+                                         meta.ctypes.data if meta is not None else None,
+                                         meta.size // 120 if meta is not None else 0, pcm.ctypes.data, pcm.size, C.byref(t)))
+        return t.value
+
+    def wait(self, ticket):
+        self._check(self.lib.aacg_wait(self.handle, ticket))
+
+    def pinned(self, shape, dtype):
+        """numpy array over page-locked host memory (aacg_host_alloc): transfers from/to it are asynchronous."""
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p = self.lib.aacg_host_alloc(n)
+        if not p:
+            raise AacgError(-3, "aacg_host_alloc failed")
+        buf = (C.c_char * n).from_address(p)
+        a = np.frombuffer(buf, dtype=dtype).reshape(shape)
+        self._pinned = getattr(self, "_pinned", [])
+        self._pinned.append(p)
+        return a
 
     # -- device-resident path -----------------------------------------------------------------
     def plan(self, units):

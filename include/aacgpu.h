@@ -179,6 +179,22 @@ int aacg_decode_batch(aacg_engine* e,
                       const aacg_band_meta* meta, uint32_t n_meta,
                       float* pcm_out, size_t n_pcm_floats);
 
+/* Asynchronous pair of the same call, for pipelining: aacg_submit enqueues upload, kernels and
+ * download of one batch on one of two internal HIP streams and returns a ticket; aacg_wait blocks
+ * until that batch's pcm_out is complete.  Two batches may be in flight: the PCIe transfers of one
+ * overlap the kernels of the other, while the kernels themselves run in submission order (they
+ * chain through the overlap state).  Buffers must stay valid until the wait; transfers are truly
+ * asynchronous only from/to pinned memory (aacg_host_alloc).  Tickets must be waited in order. */
+int aacg_submit(aacg_engine* e,
+                const aacg_unit_desc* units, uint32_t n_units,
+                const void* coeffs, uint32_t n_coef_blocks,
+                const aacg_band_meta* meta, uint32_t n_meta,
+                float* pcm_out, size_t n_pcm_floats, uint64_t* ticket);
+int aacg_wait(aacg_engine* e, uint64_t ticket);
+/* Pinned (page-locked) host memory for the calls above: hipHostMalloc / hipHostFree. */
+void* aacg_host_alloc(size_t bytes);
+void  aacg_host_free(void* p);
+
 /* ---- the hot path, device-resident ------------------------------------------------- */
 /* A plan is the uploaded unit table plus the run table the kernel walks.  It can be
  * launched repeatedly: every launch continues the streams where the previous launch of

@@ -253,3 +253,37 @@ def test_errors():
     with pytest.raises(aacgpu.AacgError):
         eng.decode_batch(wl["units"], wl["q"], wl["meta"], 100)          # pcm buffer too small
     eng.close()
+
+
+def test_pipelined_submit_wait(oracle):
+    """aacg_submit / aacg_wait: two batches in flight on two streams, pinned buffers; kernels stay in
+    submission order (they chain through the overlap state), so 6 pipelined batches == one 48-frame batch."""
+    S, T, NB = 8, 8, 6
+    eng = aacgpu.Engine(aacgpu.INPUT_QUANT_I16, S, 2)
+    wl = aacgpu_workload.make_batch(n_streams=S, n_frames=T * NB, mix=True, intensity=True, seed=31)
+    ov = np.zeros((S, 2, 1024), np.float32)
+    ref = oracle.decode_batch(wl["units"], wl["q"], wl["meta"], wl["n_pcm"], ov).reshape(S, T * NB, 2048)
+    units = wl["units"].reshape(S, T * NB)
+    bufs, tickets = [], []
+    for b in range(NB):
+        u = units[:, b * T:(b + 1) * T].copy()
+        u["pcm_offset"] = (np.arange(S)[:, None] * T + np.arange(T)[None, :]) * 2048
+        blocks = (u["coef_offset"].ravel()[:, None] + np.arange(2)[None, :]).ravel()
+        q = eng.pinned((S * T * 2, 1024), np.int16)
+        m = eng.pinned((S * T * 2, 120), np.uint16)
+        q[:] = wl["q"][blocks]
+        m[:] = wl["meta"][blocks]
+        u["coef_offset"] = np.arange(S * T).reshape(S, T) * 2
+        u["meta_offset"] = u["coef_offset"]
+        pcm = eng.pinned((S * T * 2048,), np.float32)
+        pcm[:] = np.nan
+        uu = np.ascontiguousarray(u.ravel())
+        bufs.append((uu, q, m, pcm))
+        tickets.append(eng.submit(uu, q, m, pcm))
+        if b >= 1:
+            eng.wait(tickets[b - 1])                       # keep two in flight
+    eng.wait(tickets[-1])
+    got = np.stack([bufs[b][3].reshape(S, T, 2048) for b in range(NB)], axis=1).reshape(S, NB * T, 2048)
+    assert rms(got, ref) < RMS_TOL
+    assert np.abs(overlaps(eng, S, 2) - ov).max() < 1e-5 * max(1.0, float(np.abs(ov).max()))
+    eng.close()
