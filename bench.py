@@ -70,9 +70,25 @@ def cpu_baseline(kind, mix, budget_s=12.0):
         o.decode_batch(wl["units"], coeffs, meta, wl["n_pcm"], ov)
         frames += wl["n_frames_total"]
     dt = time.perf_counter() - t0
-    return {"value": frames / dt, "unit": "stereo frames/s", "cores": 1, "kind": "port",
-            "sample": "%d stereo frames (4 streams x 16-frame batches, same generator as the GPU workload) in %.1f s "
-                      "on 1 of %d host cores; oracle/aac_oracle.c, gcc -O2 -ffp-contract=off" % (frames, dt, os.cpu_count())}
+    out = {"value": frames / dt, "unit": "stereo frames/s", "cores": 1, "kind": "port",
+           "sample": "%d stereo frames (4 streams x 16-frame batches, same generator as the GPU workload) in %.1f s "
+                     "on 1 of %d host cores; oracle/aac_oracle.c, gcc -O2 -ffp-contract=off" % (frames, dt, os.cpu_count())}
+    # the same path as plain JavaScript under Node, the stand-in for "aac.js's own Node path" (the reference cannot
+    # travel to the GPU box); in the build container the real aac.js ran process()+interleave at 0.55x this port's rate
+    # 
+    import shutil
+    import subprocess
+    node = shutil.which("node")
+    if node and not mix and kind == "quant":
+        try:
+            r = subprocess.run([node, os.path.join(ROOT, "oracle", "js", "aac_port.js"), "bench", "5"],
+                               capture_output=True, text=True, timeout=60)
+            js = json.loads(r.stdout.strip().splitlines()[-1])
+            out["js_port"] = {"value": js["frames_per_s"], "unit": "stereo frames/s", "cores": 1, "node": js["node"],
+                              "sample": "%d frames in %.1f s, oracle/js/aac_port.js" % (js["frames"], js["seconds"])}
+        except Exception as exc:                        # baseline extra only; never fails the bench
+            out["js_port"] = {"error": str(exc)[:200]}
+    return out
 
 
 def main():
@@ -81,7 +97,7 @@ def main():
     ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--warmup", type=int, default=40)
     ap.add_argument("--input", choices=["quant", "spec"], default="quant")
-    ap.add_argument("--workload", choices=["cfg2", "cfg3"], default="cfg2")
+    ap.add_argument("--workload", choices=["cfg2", "cfg3", "cfg4", "cfg5"], default="cfg2")
     ap.add_argument("--nbuf", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -105,12 +121,18 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
-    mix = args.workload == "cfg3"
+    # cfg2 (the metric's configuration) / cfg3: 256 streams x 16 frames; cfg4: 32 streams x 128 frames per GPU
+    # (chains of 9 runs: later runs recompute their predecessor's tail); cfg5: 3 CPE + LFE = 7 channels per frame
+    mix = args.workload in ("cfg3", "cfg4", "cfg5")
+    n_streams, n_frames = (32, 128) if args.workload == "cfg4" else (STREAMS, FRAMES)
+    layout = ("cpe", "cpe", "cpe", "sce") if args.workload == "cfg5" else ("cpe",)
+    n_chan = 7 if args.workload == "cfg5" else 2
     kind = aacgpu.INPUT_QUANT_I16 if args.input == "quant" else aacgpu.INPUT_SPEC_F32
-    eng = aacgpu.Engine(kind, max_streams=STREAMS, max_channels=2, device=local)
+    eng = aacgpu.Engine(kind, max_streams=n_streams, max_channels=n_chan, device=local)
 
-    # rank r owns streams [256 r, 256 r + 256): independent data per rank, same shape
-    base = aacgpu_workload.make_batch(n_streams=STREAMS, n_frames=FRAMES, mix=mix, seed=0xAAC00002 + 1000 * rank)
+    # rank r owns its own streams: independent data per rank, same shape
+    base = aacgpu_workload.make_batch(n_streams=n_streams, n_frames=n_frames, mix=mix, layout=layout,
+                                      seed=0xAAC00002 + 1000 * rank)
     units = base["units"]
     plan = eng.plan(units)
     d_meta = torch.from_numpy(base["meta"].view(np.int16)).cuda() if args.input == "quant" else None
@@ -164,21 +186,24 @@ def main():
     out = bufs[(args.warmup + args.steps - 1) % args.nbuf][1]
     ok = bool(torch.isfinite(out).all().item()) and float(out.abs().max().item()) > 0
 
-    frames_per_step = STREAMS * FRAMES
+    frames_per_step = n_streams * n_frames
     value = world * frames_per_step * args.steps / elapsed
-    abytes = algorithmic_bytes_per_stereo_frame(args.input) * frames_per_step
+    # cfg5: 7 channel-frames per frame instead of 2; cfg4: overlap state once per 128 frames
+    abytes = algorithmic_bytes_per_stereo_frame(args.input) * frames_per_step * (n_chan / 2.0)
     achieved = abytes / (kernel_ms * 1e-3) / 1e9
-    traffic, traffic_src = measured_traffic(args.input) if not mix else (None, None)
+    traffic, traffic_src = measured_traffic(args.input) if args.workload == "cfg2" else (None, None)
     line = {
         "metric": "AAC-LC 48 kHz stereo frames/sec per node + achieved HBM GB/s vs roofline",
         "value": value, "unit": "stereo frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "BASELINE config 2: batch of 4096 stereo LC frames (256 streams x 16 frames, ONLY_LONG_SEQUENCE, KBD)"
-                   if not mix else "BASELINE config 3: 4096 stereo frames, window-sequence mix [0,0,1,2,2,3,0,0], TNS identity",
+        "config": {"workload": {"cfg2": "BASELINE config 2: batch of 4096 stereo LC frames (256 streams x 16 frames, ONLY_LONG_SEQUENCE, KBD)",
+                                "cfg3": "BASELINE config 3: 4096 stereo frames, window-sequence mix [0,0,1,2,2,3,0,0], TNS identity",
+                                "cfg4": "BASELINE config 4 shape per GPU: 32 streams x 128 frames, config-3 mix",
+                                "cfg5": "BASELINE config 5 shape per GPU: 4096 frames of 3 CPE + LFE (7 channels), config-3 mix"}[args.workload],
                    "input": "int16 quantised spectra + band side info (process(elements) seam)" if args.input == "quant"
                    else "f32 spectra (FilterBank.process seam)",
-                   "streams_per_gpu": STREAMS, "frames_per_stream_per_step": FRAMES, "buffers_rotated": args.nbuf,
+                   "streams_per_gpu": n_streams, "frames_per_stream_per_step": n_frames, "buffers_rotated": args.nbuf,
                    "realtime_multiple": value / 46.875, "sharding": "streams over ranks, no data-path collective"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,

@@ -40,3 +40,13 @@ def test_host_gpu():
     build_addon()
     r = subprocess.run([NODE, os.path.join(ROOT, "tests", "js", "test_host.js"), "gpu"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "host gpu tests ok" in r.stdout, r.stdout + r.stderr
+
+
+@needs_node
+def test_js_port_matches_golden():
+    """oracle/js/aac_port.js (the JavaScript CPU baseline) reproduces the reference's PCM on the ONLY_LONG frames."""
+    import json
+    r = subprocess.run([NODE, os.path.join(ROOT, "oracle", "js", "aac_port.js"), "check", os.path.join(ROOT, "tests", "golden")],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert json.loads(r.stdout)["rms"] < 1e-6
