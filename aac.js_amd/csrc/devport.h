@@ -58,6 +58,8 @@ DP_DEVICE void dp_flag_wait(int* flag, int v)
 {
     while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != v) __builtin_amdgcn_s_sleep(2);
 }
+/* park this wave for about n x 64 cycles */
+DP_DEVICE void dp_sleep(int n) { for (int i = 0; i < n; i++) __builtin_amdgcn_s_sleep(1); }
 /* issue priority of this wave on its SIMD (0..3); s_setprio takes an immediate */
 DP_DEVICE void dp_setprio(int p)
 {

@@ -53,6 +53,7 @@ DP_DEVICE void dp_block_sync_lds() { pthread_barrier_wait(&g_emu.b->bar); }
 DP_DEVICE void dp_flag_set(int* flag, int v) { __atomic_store_n(flag, v, __ATOMIC_RELEASE); }
 DP_DEVICE void dp_flag_wait(int* flag, int v) { while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != v) sched_yield(); }
 DP_DEVICE void dp_setprio(int) {}
+DP_DEVICE void dp_sleep(int) {}
 
 template <int N>
 DP_DEVICE void dp_shfl(float (&v)[N], int src)
