@@ -180,3 +180,36 @@ def test_uncovered_channels_are_zero(emu):
     par = np.zeros(2, np.uint8)
     pcm = emu.decode(u, wl["q"], wl["meta"], 4096, pool, par).reshape(2, 1024, 2)
     assert (pcm[:, :, 1] == 0).all() and np.abs(pcm[:, :, 0]).max() > 0
+
+
+def test_ragged_streams_and_eight_channels(emu, oracle):
+    """Chains of different lengths in one batch (1, 3, 17, 33 frames: up to three runs) and an 8-channel layout."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "aac.js_amd", "python"))
+    import aacgpu_workload
+    counts = [3, 17, 1, 33]
+    parts = [aacgpu_workload.make_batch(n_streams=1, n_frames=T, mix=True, intensity=True, seed=50 + s, stream_base=s)
+             for s, T in enumerate(counts)]
+    units = np.concatenate([p["units"] for p in parts])
+    q = np.concatenate([p["q"] for p in parts])
+    meta = np.concatenate([p["meta"] for p in parts])
+    off = np.concatenate([np.full(c, b) for c, b in zip(counts, np.cumsum([0] + counts[:-1]))])
+    units["pcm_offset"] += (off * 2048).astype(np.uint32)
+    units["coef_offset"] += (off * 2).astype(np.uint32)
+    units["meta_offset"] += (off * 2).astype(np.uint32)
+    n_pcm = sum(counts) * 2048
+    ov = np.zeros((4, 2, 1024), np.float32)
+    ref = oracle.decode_batch(units, q, meta, n_pcm, ov)
+    pool = np.zeros((4, 2, 2, 1024), np.float32)
+    par = np.zeros(8, np.uint8)
+    pcm = emu.decode(units, q, meta, n_pcm, pool, par)
+    assert rms(pcm, ref) < RMS_TOL
+    assert np.abs(emu_lib.pool_current(pool, par) - ov).max() < 1e-5 * max(1.0, np.abs(ov).max())
+
+    wl = aacgpu_workload.make_batch(n_streams=1, n_frames=3, layout=("cpe", "sce", "cpe", "cpe", "sce"), mix=True, seed=77)
+    ov = np.zeros((1, 8, 1024), np.float32)
+    ref = oracle.decode_batch(wl["units"], wl["q"], wl["meta"], wl["n_pcm"], ov)
+    pool = np.zeros((1, 8, 2, 1024), np.float32)
+    par = np.zeros(8, np.uint8)
+    pcm = emu.decode(wl["units"], wl["q"], wl["meta"], wl["n_pcm"], pool, par)
+    assert rms(pcm, ref) < RMS_TOL

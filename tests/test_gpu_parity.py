@@ -287,3 +287,117 @@ def test_pipelined_submit_wait(oracle):
     assert rms(got, ref) < RMS_TOL
     assert np.abs(overlaps(eng, S, 2) - ov).max() < 1e-5 * max(1.0, float(np.abs(ov).max()))
     eng.close()
+
+
+def _ragged_batch(seed=5):
+    """Streams with different frame counts, units of different streams interleaved in the list (decode order only has
+    to hold per stream)."""
+    counts = [3, 17, 1, 33, 16, 2]
+    parts = []
+    for s, T in enumerate(counts):
+        wl = aacgpu_workload.make_batch(n_streams=1, n_frames=T, mix=True, intensity=(s % 2 == 0), seed=seed + s, stream_base=s)
+        parts.append(wl)
+    n_frames = sum(counts)
+    units = np.concatenate([p["units"] for p in parts])
+    q = np.concatenate([p["q"] for p in parts])
+    meta = np.concatenate([p["meta"] for p in parts])
+    base = np.cumsum([0] + counts[:-1])
+    off = np.concatenate([np.full(c, b) for c, b in zip(counts, base)])
+    units["pcm_offset"] += (off * 2048).astype(np.uint32)
+    units["coef_offset"] += (off * 2).astype(np.uint32)
+    units["meta_offset"] += (off * 2).astype(np.uint32)
+    # interleave streams round-robin while keeping each stream's own order
+    order, cursors = [], [0] * len(counts)
+    starts = list(base)
+    while len(order) < n_frames:
+        for s, T in enumerate(counts):
+            if cursors[s] < T:
+                order.append(starts[s] + cursors[s])
+                cursors[s] += 1
+    return units[np.array(order)], q, meta, n_frames * 2048, len(counts)
+
+
+def test_ragged_interleaved_streams(oracle):
+    units, q, meta, n_pcm, S = _ragged_batch()
+    ov = np.zeros((S, 2, 1024), np.float32)
+    ref = oracle.decode_batch(units, q, meta, n_pcm, ov)
+    eng = aacgpu.Engine(aacgpu.INPUT_QUANT_I16, S, 2)
+    pcm = eng.decode_batch(units, q, meta, n_pcm)
+    assert rms(pcm, ref) < RMS_TOL
+    assert np.abs(overlaps(eng, S, 2) - ov).max() < 1e-5 * max(1.0, float(np.abs(ov).max()))
+    eng.close()
+
+
+def test_extremes(oracle):
+    """Maximum band counts and group counts, eight channels, escape magnitudes up to 8190, |q| >= 8191 -> NaN like the
+    reference's out-of-range IQ_TABLE read, all-zero band types -> silence with overlap flushed, empty batch refused."""
+    S = 1
+    wl = aacgpu_workload.make_batch(n_streams=S, n_frames=6, layout=("cpe", "cpe", "cpe", "cpe"), mix=True, seed=9)
+    u, q, meta = wl["units"].copy(), wl["q"].copy(), wl["meta"].copy()
+    assert u["n_out_ch"][0] == 8
+    short = u["ch"]["window_sequence"][:, 0] == 2
+    for c in range(2):                                         # eight groups of one window, maxSFB 14
+        gl = u["ch"]["group_len"][:, c].copy()
+        gl[short] = 1
+        u["ch"]["group_len"][:, c] = gl
+        u["ch"]["group_count"][short, c] = 8
+    bt = np.full(120, 11 << 12, np.uint16) | 236                # every band escape-coded
+    for i in np.nonzero(short)[0]:
+        meta[u["meta_offset"][i]] = np.where(np.arange(120) < 112, bt | 0x400, 0)
+        meta[u["meta_offset"][i] + 1] = np.where(np.arange(120) < 112, bt, 0)
+    q[::7, ::13] = 8190
+    q[3::11, 5::17] = -8190
+    ov = np.zeros((S, 8, 1024), np.float32)
+    ref = oracle.decode_batch(u, q, meta, wl["n_pcm"], ov)
+    eng = aacgpu.Engine(aacgpu.INPUT_QUANT_I16, S, 8)
+    pcm = eng.decode_batch(u, q, meta, wl["n_pcm"])
+    assert np.isfinite(ref).all() and rms(pcm, ref) < 1e-4     # |PCM| is in the thousands here: relative gate does the work
+    # |q| = 8191 and beyond: NaN in exactly the frames (and their successors through the overlap) where the oracle has NaN
+    q2 = q.copy()
+    q2[int(u["coef_offset"][8]), 40] = 8191
+    q2[int(u["coef_offset"][12]) + 1, 7] = -32768
+    ov[:] = 0
+    ref2 = oracle.decode_batch(u, q2, meta, wl["n_pcm"], ov)
+    eng.reset_stream(0)
+    pcm2 = eng.decode_batch(u, q2, meta, wl["n_pcm"])
+    assert np.isnan(ref2).any() and np.array_equal(np.isnan(pcm2), np.isnan(ref2))
+    ok = ~np.isnan(ref2)
+    assert rms(pcm2[ok], ref2[ok]) < 1e-4
+    # all bands ZERO_BT: output is the flushed overlap, then exact silence
+    eng.reset_stream(0)
+    eng.decode_batch(u, q, meta, wl["n_pcm"])
+    zmeta = np.zeros_like(meta)
+    first = eng.decode_batch(u, q, zmeta, wl["n_pcm"]).reshape(6, 1024, 8)
+    assert np.abs(first[0]).max() > 0 and not first[2:].any()
+    # empty batch
+    with pytest.raises(aacgpu.AacgError) as ei:
+        eng.decode_batch(u[:0], q, meta, wl["n_pcm"])
+    assert ei.value.code == -1
+    eng.close()
+
+
+def test_many_streams_multi_round(oracle):
+    """2048 streams x 16 frames (8 batches' worth, 2048 workgroups: many rounds per CU); the oracle checks a sample of
+    the streams (streams are independent) and a checksum of checksums guards the rest against cross-talk."""
+    S, T = 2048, 16
+    wl = aacgpu_workload.make_batch(n_streams=S, n_frames=T, mix=True, seed=123)
+    eng = aacgpu.Engine(aacgpu.INPUT_QUANT_I16, S, 2)
+    pcm = eng.decode_batch(wl["units"], wl["q"], wl["meta"], wl["n_pcm"]).reshape(S, T * 2048)
+    assert np.isfinite(pcm).all()
+    units = wl["units"].reshape(S, T)
+    for s in (0, 1, 255, 256, 1023, 2047):
+        u = units[s].copy()
+        u["stream"] = 0
+        ov = np.zeros((1, 2, 1024), np.float32)
+        ref = oracle.decode_batch(u, wl["q"], wl["meta"], wl["n_pcm"], ov)[s * T * 2048:(s + 1) * T * 2048]
+        assert rms(pcm[s], ref) < RMS_TOL
+        assert np.abs(overlaps(eng, s + 1, 2)[s] - ov[0]).max() < 1e-5 * max(1.0, float(np.abs(ov).max()))
+    # decoding again in two halves (streams 0..1023, 1024..2047) from a fresh engine gives bit-identical PCM
+    eng2 = aacgpu.Engine(aacgpu.INPUT_QUANT_I16, S, 2)
+    half = S * T // 2
+    a = eng2.decode_batch(wl["units"][:half], wl["q"], wl["meta"], wl["n_pcm"])[:half * 2048]
+    ub = wl["units"][half:].copy()
+    b = eng2.decode_batch(ub, wl["q"], wl["meta"], wl["n_pcm"])[half * 2048:]
+    assert np.array_equal(np.concatenate([a, b]).view(np.uint32), pcm.ravel().view(np.uint32))
+    eng.close()
+    eng2.close()
