@@ -49,6 +49,10 @@ struct aacg_engine {
         void* d_coeffs = nullptr; size_t coeffs_cap = 0;
         void* d_meta = nullptr;   size_t meta_cap = 0;
         void* d_pcm = nullptr;    size_t pcm_cap = 0;
+        /* page-locked staging for callers that pass ordinary (pageable) memory */
+        void* h_in = nullptr;     size_t h_in_cap = 0;
+        void* h_pcm = nullptr;    size_t h_pcm_cap = 0;
+        float* user_pcm = nullptr; size_t user_pcm_bytes = 0;   /* copy-back target at aacg_wait, or null */
         aacg_plan_host h;
     } slot[2];
     uint64_t submitted = 0;
@@ -87,6 +91,23 @@ int grow(aacg_engine* e, void** p, size_t* cap, size_t need)
     HIP_TRY(e, hipMalloc(p, need), AACG_ERR_OUT_OF_MEMORY);
     *cap = need;
     return AACG_OK;
+}
+
+int grow_host(aacg_engine* e, void** p, size_t* cap, size_t need)
+{
+    if (need <= *cap) return AACG_OK;
+    if (*p) { (void)hipHostFree(*p); *p = nullptr; *cap = 0; }
+    HIP_TRY(e, hipHostMalloc(p, need, hipHostMallocDefault), AACG_ERR_OUT_OF_MEMORY);
+    *cap = need;
+    return AACG_OK;
+}
+
+/* true if the runtime knows this host pointer as page-locked (hipHostMalloc / hipHostRegister) */
+bool is_pinned(const void* p)
+{
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return a.type == hipMemoryTypeHost;
 }
 
 /* enqueue the run kernel for a planned batch (device pointers) */
@@ -169,6 +190,8 @@ void aacg_destroy(aacg_engine* e)
     if (e->d_overlap) (void)hipFree(e->d_overlap);
     for (auto& sl : e->slot) {
         for (void* p : {sl.d_units, sl.d_runs, sl.d_coeffs, sl.d_meta, sl.d_pcm}) if (p) (void)hipFree(p);
+        if (sl.h_in) (void)hipHostFree(sl.h_in);
+        if (sl.h_pcm) (void)hipHostFree(sl.h_pcm);
         if (sl.done) (void)hipEventDestroy(sl.done);
         if (sl.kernel_done) (void)hipEventDestroy(sl.kernel_done);
         if (sl.stream) (void)hipStreamDestroy(sl.stream);
@@ -348,6 +371,7 @@ int aacg_wait(aacg_engine* e, uint64_t ticket)
     if (sl.busy) {
         HIP_TRY(e, hipEventSynchronize(sl.done), AACG_ERR_NO_DEVICE);
         sl.busy = false;
+        if (sl.user_pcm) { std::memcpy(sl.user_pcm, sl.h_pcm, sl.user_pcm_bytes); sl.user_pcm = nullptr; }
     }
     return AACG_OK;
 }
@@ -367,8 +391,8 @@ int aacg_submit(aacg_engine* e, const aacg_unit_desc* units, uint32_t n_units,
     HIP_TRY(e, hipSetDevice(e->cfg.device_ordinal), AACG_ERR_NO_DEVICE);
     aacg_engine::slot_t& sl = e->slot[e->submitted & 1];
     if (sl.busy) {                                     /* the batch two submissions ago was never waited for */
-        HIP_TRY(e, hipEventSynchronize(sl.done), AACG_ERR_NO_DEVICE);
-        sl.busy = false;
+        int wrc = aacg_wait(e, e->submitted - 1);
+        if (wrc) return wrc;
     }
     if (!sl.stream) {
         HIP_TRY(e, hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking), AACG_ERR_NO_DEVICE);
@@ -408,11 +432,31 @@ int aacg_submit(aacg_engine* e, const aacg_unit_desc* units, uint32_t n_units,
         (rc = grow(e, &sl.d_pcm, &sl.pcm_cap, pb)))
         return rc;
 
+    /* Ordinary (pageable) caller memory goes through the slot's page-locked staging buffers (one host
+     * memcpy each way, then truly asynchronous DMA); page-locked caller memory is used in place. */
     hipStream_t s = sl.stream;
+    const void* src_coeffs = coeffs;
+    const void* src_meta = meta;
+    if (!is_pinned(coeffs) || (quant && !is_pinned(meta))) {
+        const size_t mb_al = (cb + 255) & ~(size_t)255;
+        if ((rc = grow_host(e, &sl.h_in, &sl.h_in_cap, mb_al + mb))) return rc;
+        std::memcpy(sl.h_in, coeffs, cb);
+        if (quant) std::memcpy((char*)sl.h_in + mb_al, meta, mb);
+        src_coeffs = sl.h_in;
+        src_meta = (char*)sl.h_in + mb_al;
+    }
+    float* dst_pcm = pcm_out;
+    sl.user_pcm = nullptr;
+    if (!is_pinned(pcm_out)) {
+        if ((rc = grow_host(e, &sl.h_pcm, &sl.h_pcm_cap, pb))) return rc;
+        dst_pcm = (float*)sl.h_pcm;
+        sl.user_pcm = pcm_out;
+        sl.user_pcm_bytes = pb;
+    }
     HIP_TRY(e, hipMemcpyAsync(sl.d_units, h.units.data(), ub, hipMemcpyHostToDevice, s), AACG_ERR_NO_DEVICE);
     HIP_TRY(e, hipMemcpyAsync(sl.d_runs, h.runs.data(), rb, hipMemcpyHostToDevice, s), AACG_ERR_NO_DEVICE);
-    HIP_TRY(e, hipMemcpyAsync(sl.d_coeffs, coeffs, cb, hipMemcpyHostToDevice, s), AACG_ERR_NO_DEVICE);
-    if (quant) HIP_TRY(e, hipMemcpyAsync(sl.d_meta, meta, mb, hipMemcpyHostToDevice, s), AACG_ERR_NO_DEVICE);
+    HIP_TRY(e, hipMemcpyAsync(sl.d_coeffs, src_coeffs, cb, hipMemcpyHostToDevice, s), AACG_ERR_NO_DEVICE);
+    if (quant) HIP_TRY(e, hipMemcpyAsync(sl.d_meta, src_meta, mb, hipMemcpyHostToDevice, s), AACG_ERR_NO_DEVICE);
     /* kernels chain through the overlap state: this one starts after the previous batch's kernel,
      * while its uploads above overlapped it */
     if (e->last_kernel) HIP_TRY(e, hipStreamWaitEvent(s, e->last_kernel, 0), AACG_ERR_NO_DEVICE);
@@ -421,7 +465,7 @@ int aacg_submit(aacg_engine* e, const aacg_unit_desc* units, uint32_t n_units,
     if (rc) return rc;
     HIP_TRY(e, hipEventRecord(sl.kernel_done, s), AACG_ERR_NO_DEVICE);
     e->last_kernel = sl.kernel_done;
-    HIP_TRY(e, hipMemcpyAsync(pcm_out, sl.d_pcm, pb, hipMemcpyDeviceToHost, s), AACG_ERR_NO_DEVICE);
+    HIP_TRY(e, hipMemcpyAsync(dst_pcm, sl.d_pcm, pb, hipMemcpyDeviceToHost, s), AACG_ERR_NO_DEVICE);
     HIP_TRY(e, hipEventRecord(sl.done, s), AACG_ERR_NO_DEVICE);
     sl.busy = true;
 

@@ -128,6 +128,11 @@ function GpuAACDecoder(opts) {
     this.engine = opts.engine || null;
     this.stream = opts.stream | 0;           // engine stream slot of this decoder instance
     this.lookahead = opts.lookahead || 16;
+    /* aac.js always windows the first half of a frame with the SINE shape, because it builds a fresh ICSInfo
+     * per frame and so loses windowShape[0] (decoder.js:145,153; SURVEY.md 9.1).  false (default) reproduces
+     * that; true carries the previous frame's shape per channel as the standard prescribes. */
+    this.carryWindowShape = !!opts.carryWindowShape;
+    this.prevShape = [];
     this.queue = [];
 }
 GpuAACDecoder.prototype.init = function () { this.format.floatingPoint = true; };
@@ -167,6 +172,10 @@ GpuAACDecoder.prototype.unitsOfFrame = function (frame, frameSlot, blockBase) {
         const n = e.type === 'cpe' ? 2 : 1;
         if (channel >= C) break;
         if (e.gainPresent) throw new Error('Gain control not implemented');
+        for (let c = 0; c < n; c++) {
+            e.ch[c].windowShapePrev = this.carryWindowShape ? (this.prevShape[channel + c] | 0) : 0;
+            this.prevShape[channel + c] = e.ch[c].windowShape;
+        }
         units.push({ stream: this.stream, pcmOffset: frameSlot * FRAME * C, channel: channel, nOutCh: C, coefOffset: block, metaOffset: block,
                      commonWindow: !!e.commonWindow, maskPresent: !!e.maskPresent, ch: e.ch });
         channel += n; block += n;
