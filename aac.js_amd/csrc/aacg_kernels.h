@@ -996,7 +996,41 @@ DP_DEVICE void epilogue(const float* p0, const float* p1, const unit_view& u, in
         return;
     }
 
-    /* any channel count / mixed lane maps: scalar stores at stride C */
+    if (n_ch == 2 && cls0 == cls1) {
+        /* a CPE inside a wider frame (5.1 etc.): (L[n], R[n]) are adjacent, one 8-byte store per sample
+         * (4-byte aligned when the channel count is odd) */
+        if (!cls0) {
+#pragma unroll
+            for (int m = 0; m < 8; m++) {
+                const int n = 2 * lane + 128 * m;
+                const dpf4 v = incoming<FROM_LDS>(p0, p1, 2, n);
+                dp_store2_u(pcm + (size_t)n * C, (v.x + hx0[m]) * S, (v.y + hx1[m]) * S);
+                dp_store2_u(pcm + (size_t)(n + 1) * C, (v.z + hy0[m]) * S, (v.w + hy1[m]) * S);
+            }
+        } else {
+#pragma unroll
+            for (int m = 0; m < 8; m++) {
+                if (w < 4 || (w == 4 && m < 4)) {
+                    const int n = 448 + 128 * w + 2 * g + 16 * m;
+                    const dpf4 v = incoming<FROM_LDS>(p0, p1, 2, n);
+                    dp_store2_u(pcm + (size_t)n * C, (v.x + hx0[m]) * S, (v.y + hx1[m]) * S);
+                    dp_store2_u(pcm + (size_t)(n + 1) * C, (v.z + hy0[m]) * S, (v.w + hy1[m]) * S);
+                }
+            }
+#pragma unroll
+            for (int t4 = 0; t4 < 4; t4++) {
+                const int n = 2 * lane + 128 * t4;
+                if (n < 448) {
+                    const dpf4 v = incoming<FROM_LDS>(p0, p1, 2, n);
+                    dp_store2_u(pcm + (size_t)n * C, v.x * S, v.y * S);
+                    dp_store2_u(pcm + (size_t)(n + 1) * C, v.z * S, v.w * S);
+                }
+            }
+        }
+        return;
+    }
+
+    /* single channels / mixed lane maps: scalar stores at stride C */
 #pragma unroll
     for (int c = 0; c < 2; c++) {
         if (c < n_ch) {

@@ -105,6 +105,10 @@ DP_DEVICE dpf4 dp_load_nt(const dpf4* p)
     const dp_nv4 t = __builtin_nontemporal_load((const dp_nv4*)p);
     dpf4 v; v.x = t[0]; v.y = t[1]; v.z = t[2]; v.w = t[3]; return v;
 }
+/* two adjacent floats at an address that is only 4-byte aligned (odd channel counts): one
+ * global_store_dwordx2 — gfx950 runs in unaligned-access mode, and the type says align 4 */
+typedef float dp_f2u __attribute__((ext_vector_type(2), aligned(4)));
+DP_DEVICE void dp_store2_u(float* p, float a, float b) { dp_f2u v; v[0] = a; v[1] = b; *(dp_f2u*)p = v; }
 /* constant-rate (100 MHz) wall clock, same time base on every CU: phase timelines for profiling */
 DP_DEVICE unsigned long long dp_clock() { return wall_clock64(); }
 DP_DEVICE float dp_nan() { return __builtin_nanf(""); }

@@ -80,6 +80,7 @@ DP_DEVICE float dp_fma(float a, float b, float c) { return fmaf(a, b, c); }
 DP_DEVICE void dp_store_nt(dpf4* p, dpf4 v) { *p = v; }
 DP_DEVICE dpf4 dp_load_nt(const dpf4* p) { return *p; }
 DP_DEVICE dpi4 dp_load_nt_i4(const dpi4* p) { return *p; }
+DP_DEVICE void dp_store2_u(float* p, float a, float b) { p[0] = a; p[1] = b; }
 DP_DEVICE unsigned long long dp_clock() { return 0; }
 DP_DEVICE float dp_nan() { return NAN; }
 DP_DEVICE int dp_opaque(int v) { return v; }
