@@ -33,7 +33,7 @@ static struct {
 
 static napi_value fail(napi_env env, aacg_engine* e, int rc, const char* what)
 {
-    char msg[512];
+    char msg[1024];
     snprintf(msg, sizeof msg, "aacgpu: %s failed (%d): %s", what, rc, e && L.last_error ? L.last_error(e) : "");
     napi_throw_error(env, NULL, msg);
     return NULL;
