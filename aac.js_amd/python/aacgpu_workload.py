@@ -105,3 +105,78 @@ def make_batch(n_streams, n_frames, layout=("cpe",), mix=False, seed=0xAAC00002,
         chan += nc
         ui += 1
     return dict(units=units, q=q, meta=meta, C=C, n_pcm=F * 1024 * C, n_frames_total=F)
+
+
+GROUPINGS = [[8], [3, 4, 1], [1] * 8, [2, 6], [4, 4], [1, 7], [2, 2, 2, 2], [1, 1, 6]]
+
+
+def random_batch(seed, n_streams=3, max_frames=20):
+    """Fuzz workload: per stream a random channel layout and frame count; per frame and element random window
+    sequences (any order, also illegal transitions: the filterbank is defined for all of them), shapes, previous
+    shapes, maxSFB, short-window groupings, common / split windows, band types (zero, codebooks, escape, intensity),
+    MS masks (none / per band / all), scalefactors, and quantised values including escape-range magnitudes."""
+    rng = np.random.default_rng(seed)
+    band_long, band_short = _band_of(SWB_LONG_48, 1024), _band_of(SWB_SHORT_48, 128)
+    units, qs, metas = [], [], []
+    block = 0
+    pcm = 0
+    max_c = 0
+    for s in range(n_streams):
+        layout = [("cpe",), ("sce",), ("cpe", "sce"), ("sce", "cpe", "cpe", "sce"), ("cpe", "cpe", "cpe", "cpe")][rng.integers(0, 5)]
+        C = sum(2 if e == "cpe" else 1 for e in layout)
+        max_c = max(max_c, C)
+        T = int(rng.integers(1, max_frames + 1))
+        for t in range(T):
+            chan = 0
+            for e in layout:
+                nc = 2 if e == "cpe" else 1
+                u = np.zeros(1, UNIT_DTYPE)
+                u["stream"] = s
+                u["pcm_offset"] = pcm
+                u["channel"] = chan
+                u["n_out_ch"] = C
+                u["n_ch"] = nc
+                u["coef_offset"] = block
+                u["meta_offset"] = block
+                common = nc == 2 and rng.random() < 0.8
+                mask_mode = int(rng.integers(0, 4)) if common else 0      # 0 none, 1/2 per band, 3 all
+                u["flags"] = (1 if common else 0) | (2 if mask_mode else 0)
+                infos = []
+                for c in range(nc):
+                    if c == 1 and common:
+                        infos.append(infos[0])
+                        continue
+                    seq = int(rng.integers(0, 4))
+                    gl = GROUPINGS[rng.integers(0, len(GROUPINGS))] if seq == 2 else [1]
+                    infos.append(dict(seq=seq, shape=int(rng.integers(0, 2)), prev=int(rng.integers(0, 2)),
+                                      max_sfb=int(rng.integers(0, 15)) if seq == 2 else int(rng.integers(0, 50)), gl=gl))
+                for c, inf in enumerate(infos):
+                    u["ch"]["window_sequence"][0, c] = inf["seq"]
+                    u["ch"]["window_shape"][0, c] = inf["shape"]
+                    u["ch"]["window_shape_prev"][0, c] = inf["prev"]
+                    u["ch"]["max_sfb"][0, c] = inf["max_sfb"]
+                    u["ch"]["group_count"][0, c] = len(inf["gl"])
+                    u["ch"]["group_len"][0, c, :len(inf["gl"])] = inf["gl"]
+                    nb = len(inf["gl"]) * inf["max_sfb"]
+                    bt = rng.choice([0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 11], size=120).astype(np.uint16)
+                    sfi = (232 + rng.integers(-12, 13, 120)).astype(np.uint16)
+                    if c == 1:
+                        isb = rng.random(120) < 0.2
+                        bt = np.where(isb, rng.integers(14, 16, 120), bt).astype(np.uint16)
+                        sfi = np.where(isb, 200 + rng.integers(-16, 17, 120), sfi).astype(np.uint16)
+                    m = sfi | (bt << 12)
+                    if c == 0 and mask_mode:
+                        used = np.ones(120, bool) if mask_mode == 3 else rng.random(120) < 0.5
+                        m = m | np.where(used, 0x400, 0).astype(np.uint16)
+                    m = np.where(np.arange(120) < nb, m, rng.integers(0, 65536, 120) & 0xCFFF).astype(np.uint16)   # junk beyond nb, never NOISE
+                    metas.append(m)
+                    lam = np.tile(24.0 * np.exp(-(np.arange(128) * 8) / 180.0), 8) if inf["seq"] == 2 else 24.0 * np.exp(-np.arange(1024) / 180.0)
+                    qq = np.floor(rng.exponential(1.0, 1024) * lam * 0.5) * (rng.integers(0, 2, 1024) * 2 - 1)
+                    big = rng.random(1024) < 0.004
+                    qq = np.where(big, rng.integers(-8190, 8191, 1024), qq)
+                    qs.append(np.clip(qq, -8190, 8190).astype(np.int16))
+                units.append(u)
+                block += nc
+                chan += nc
+            pcm += 1024 * C
+    return dict(units=np.concatenate(units), q=np.stack(qs), meta=np.stack(metas), n_pcm=pcm, n_streams=n_streams, max_channels=max_c)

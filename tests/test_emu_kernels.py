@@ -213,3 +213,22 @@ def test_ragged_streams_and_eight_channels(emu, oracle):
     par = np.zeros(8, np.uint8)
     pcm = emu.decode(wl["units"], wl["q"], wl["meta"], wl["n_pcm"], pool, par)
     assert rms(pcm, ref) < RMS_TOL
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_fuzz_vs_oracle(emu, oracle, seed):
+    """Random layouts, sequences, shapes (also previous shapes), groupings, band types, masks: emulated kernels vs oracle."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "aac.js_amd", "python"))
+    import aacgpu_workload
+    wl = aacgpu_workload.random_batch(seed, n_streams=2, max_frames=6)
+    S, C = wl["n_streams"], wl["max_channels"]
+    ov = np.zeros((S, C, 1024), np.float32)
+    ref, spec_ref = oracle.decode_batch(wl["units"], wl["q"], wl["meta"], wl["n_pcm"], ov, want_spec=True)
+    pool = np.zeros((S, C, 2, 1024), np.float32)
+    par = np.zeros(S * C, np.uint8)
+    pcm = emu.decode(wl["units"], wl["q"], wl["meta"], wl["n_pcm"], pool, par)
+    rms(pcm, ref)
+    assert np.abs(emu_lib.pool_current(pool, par) - ov).max() < 1e-5 * max(1.0, np.abs(ov).max())
+    spec = emu.spectral(wl["units"], wl["q"], wl["meta"])
+    assert np.array_equal(spec.view(np.uint32), spec_ref.view(np.uint32))

@@ -402,3 +402,18 @@ def test_many_streams_multi_round(oracle):
     assert np.array_equal(np.concatenate([a, b]).view(np.uint32), pcm.ravel().view(np.uint32))
     eng.close()
     eng2.close()
+
+
+@pytest.mark.parametrize("seed", list(range(100, 124)))
+def test_fuzz_vs_oracle(oracle, seed):
+    """24 random batches: random channel layouts (1..8 channels), frame counts, window sequences in any order, both
+    shapes and previous shapes, groupings, maxSFB (also 0), common / split windows, band types, MS masks, escapes."""
+    wl = aacgpu_workload.random_batch(seed, n_streams=4, max_frames=40)
+    S, C = wl["n_streams"], wl["max_channels"]
+    ov = np.zeros((S, C, 1024), np.float32)
+    ref = oracle.decode_batch(wl["units"], wl["q"], wl["meta"], wl["n_pcm"], ov)
+    eng = aacgpu.Engine(aacgpu.INPUT_QUANT_I16, S, C)
+    pcm = eng.decode_batch(wl["units"], wl["q"], wl["meta"], wl["n_pcm"])
+    rms(pcm, ref)
+    assert np.abs(overlaps(eng, S, C) - ov).max() < 1e-5 * max(1.0, float(np.abs(ov).max()))
+    eng.close()
