@@ -89,6 +89,11 @@ function Engine(opts) {
 Engine.prototype.decodeBatch = function (units, coeffs, meta, pcm) {
     return this.addon.decodeBatch(this.handle, units, coeffs, meta || null, pcm);   // throws on error
 };
+/* the same off the JavaScript thread: resolves with `pcm`; one call in flight per engine (the kernels chain
+ * through the overlap state, so batches of one engine are decoded in order) */
+Engine.prototype.decodeBatchAsync = function (units, coeffs, meta, pcm) {
+    return this.addon.decodeBatchAsync(this.handle, units, coeffs, meta || null, pcm);
+};
 Engine.prototype.resetStream = function (s) { this.addon.resetStream(this.handle, s); };
 Engine.prototype.getOverlap = function (s, c) { return this.addon.getOverlap(this.handle, s, c, new Float32Array(FRAME)); };
 Engine.prototype.setOverlap = function (s, c, v) { this.addon.setOverlap(this.handle, s, c, v); };

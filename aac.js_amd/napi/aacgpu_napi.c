@@ -27,6 +27,9 @@ static struct {
     int  (*set_overlap)(aacg_engine*, uint32_t, uint32_t, const float*);
     int  (*decode_batch)(aacg_engine*, const aacg_unit_desc*, uint32_t, const void*, uint32_t,
                          const aacg_band_meta*, uint32_t, float*, size_t);
+    int  (*submit)(aacg_engine*, const aacg_unit_desc*, uint32_t, const void*, uint32_t,
+                   const aacg_band_meta*, uint32_t, float*, size_t, uint64_t*);
+    int  (*wait)(aacg_engine*, uint64_t);
 } L;
 
 #define CHECK(env, call) do { if ((call) != napi_ok) { napi_throw_error((env), NULL, "aacgpu: N-API call failed: " #call); return NULL; } } while (0)
@@ -53,6 +56,7 @@ static int load_lib(napi_env env, const char* path)
     SYM(create, "aacg_create"); SYM(destroy, "aacg_destroy"); SYM(last_error, "aacg_last_error");
     SYM(abi_version, "aacg_abi_version"); SYM(reset_stream, "aacg_reset_stream");
     SYM(get_overlap, "aacg_get_overlap"); SYM(set_overlap, "aacg_set_overlap"); SYM(decode_batch, "aacg_decode_batch");
+    SYM(submit, "aacg_submit"); SYM(wait, "aacg_wait");
 #undef SYM
     return 1;
 }
@@ -175,12 +179,91 @@ static napi_value overlap_io(napi_env env, napi_callback_info info, int set)
 static napi_value js_get_overlap(napi_env env, napi_callback_info info) { return overlap_io(env, info, 0); }
 static napi_value js_set_overlap(napi_env env, napi_callback_info info) { return overlap_io(env, info, 1); }
 
+/* ---- decodeBatchAsync: the same call off the JavaScript thread (napi_async_work), so the event loop keeps
+ * parsing the next frames while the GPU works; resolves with the pcm array, rejects with an Error ---------- */
+typedef struct {
+    napi_async_work work;
+    napi_deferred deferred;
+    napi_ref refs[4];            /* units, coeffs, meta, pcm stay alive until completion */
+    aacg_engine* e;
+    const aacg_unit_desc* units; uint32_t n_units;
+    const void* coeffs; uint32_t n_blocks;
+    const aacg_band_meta* meta; uint32_t n_meta;
+    float* pcm; size_t n_pcm;
+    int rc;
+    char err[512];
+} async_job;
+
+static void job_execute(napi_env env, void* data)
+{
+    (void)env;
+    async_job* j = (async_job*)data;
+    uint64_t t = 0;
+    j->rc = L.submit(j->e, j->units, j->n_units, j->coeffs, j->n_blocks, j->meta, j->n_meta, j->pcm, j->n_pcm, &t);
+    if (!j->rc) j->rc = L.wait(j->e, t);
+    if (j->rc) snprintf(j->err, sizeof j->err, "aacgpu: decodeBatchAsync failed (%d): %.400s", j->rc, L.last_error(j->e));
+}
+
+static void job_complete(napi_env env, napi_status status, void* data)
+{
+    async_job* j = (async_job*)data;
+    napi_value v;
+    if (status == napi_ok && j->rc == 0) {
+        napi_get_reference_value(env, j->refs[3], &v);
+        napi_resolve_deferred(env, j->deferred, v);
+    } else {
+        napi_value msg;
+        napi_create_string_utf8(env, j->rc ? j->err : "aacgpu: async work cancelled", NAPI_AUTO_LENGTH, &msg);
+        napi_create_error(env, NULL, msg, &v);
+        napi_reject_deferred(env, j->deferred, v);
+    }
+    for (int i = 0; i < 4; i++) if (j->refs[i]) napi_delete_reference(env, j->refs[i]);
+    napi_delete_async_work(env, j->work);
+    free(j);
+}
+
+static napi_value js_decode_batch_async(napi_env env, napi_callback_info info)
+{
+    size_t argc = 5; napi_value argv[5], promise, name;
+    CHECK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    aacg_engine* e = engine_of(env, argv[0]);
+    if (!e) return NULL;
+    napi_typedarray_type tu, tc, tm, tp; size_t nu, nc, nm = 0, np; void *du, *dc, *dm = NULL, *dp;
+    napi_valuetype vt;
+    if (!typed(env, argv[1], &tu, &nu, &du) || tu != napi_uint8_array || nu % sizeof(aacg_unit_desc) ||
+        !typed(env, argv[2], &tc, &nc, &dc) || (tc != napi_int16_array && tc != napi_float32_array) || nc % 1024 ||
+        !typed(env, argv[4], &tp, &np, &dp) || tp != napi_float32_array) {
+        napi_throw_type_error(env, NULL, "decodeBatchAsync(engine, Uint8Array units, Int16Array|Float32Array coeffs, Uint16Array|null meta, Float32Array pcm)");
+        return NULL;
+    }
+    CHECK(env, napi_typeof(env, argv[3], &vt));
+    if (vt != napi_null && vt != napi_undefined &&
+        (!typed(env, argv[3], &tm, &nm, &dm) || tm != napi_uint16_array || nm % AACG_MAX_SECTIONS)) {
+        napi_throw_type_error(env, NULL, "meta must be a Uint16Array of 120-word aacg_band_meta records");
+        return NULL;
+    }
+    async_job* j = (async_job*)calloc(1, sizeof *j);
+    if (!j) { napi_throw_error(env, NULL, "aacgpu: out of memory"); return NULL; }
+    j->e = e; j->units = (const aacg_unit_desc*)du; j->n_units = (uint32_t)(nu / sizeof(aacg_unit_desc));
+    j->coeffs = dc; j->n_blocks = (uint32_t)(nc / 1024); j->meta = (const aacg_band_meta*)dm; j->n_meta = (uint32_t)(nm / AACG_MAX_SECTIONS);
+    j->pcm = (float*)dp; j->n_pcm = np;
+    const int idx[4] = {1, 2, 3, 4};
+    for (int i = 0; i < 4; i++)
+        if (!(i == 2 && !dm)) napi_create_reference(env, argv[idx[i]], 1, &j->refs[i]);
+    CHECK(env, napi_create_promise(env, &j->deferred, &promise));
+    CHECK(env, napi_create_string_utf8(env, "aacgpu.decodeBatchAsync", NAPI_AUTO_LENGTH, &name));
+    CHECK(env, napi_create_async_work(env, NULL, name, job_execute, job_complete, j, &j->work));
+    CHECK(env, napi_queue_async_work(env, j->work));
+    return promise;
+}
+
 static napi_value init(napi_env env, napi_value exports)
 {
     napi_property_descriptor props[] = {
         {"load", NULL, js_load, NULL, NULL, NULL, napi_default, NULL},
         {"create", NULL, js_create, NULL, NULL, NULL, napi_default, NULL},
         {"decodeBatch", NULL, js_decode_batch, NULL, NULL, NULL, napi_default, NULL},
+        {"decodeBatchAsync", NULL, js_decode_batch_async, NULL, NULL, NULL, napi_default, NULL},
         {"resetStream", NULL, js_reset_stream, NULL, NULL, NULL, napi_default, NULL},
         {"getOverlap", NULL, js_get_overlap, NULL, NULL, NULL, napi_default, NULL},
         {"setOverlap", NULL, js_set_overlap, NULL, NULL, NULL, napi_default, NULL},

@@ -83,4 +83,17 @@ for (const name of ['scn_stereo', 'scn_7ch']) {
     // error convention: a bad batch throws, like the reference's throw new Error(...)
     assert.throws(() => dec.engine.decodeBatch(g[name + '.units'], new Int16Array(1024), g[name + '.meta'], new Float32Array(2048)), /aacgpu/);
 }
-console.log('host gpu tests ok');
+(async function () {
+    // decodeBatchAsync: the event loop stays free while the GPU decodes (a timer fires before the promise resolves or right after)
+    const name = 'scn_stereo', ref = g[name + '.pcm'];
+    const eng = new host.Engine({ maxStreams: 1, maxChannels: 2 });
+    const pcm = new Float32Array(ref.length);
+    const out = await eng.decodeBatchAsync(g[name + '.units'], g[name + '.q'], g[name + '.meta'], pcm);
+    assert.strictEqual(out, pcm);
+    assert.ok(rms(pcm, ref) < 1e-5);
+    let rejected = false;
+    try { await eng.decodeBatchAsync(g[name + '.units'], new Int16Array(1024), g[name + '.meta'], new Float32Array(2048)); } catch (e) { rejected = /aacgpu/.test(e.message); }
+    assert.ok(rejected, 'async error path');
+    console.log('decodeBatchAsync ok');
+    console.log('host gpu tests ok');
+})().catch(function (e) { console.error(e); process.exit(1); });
