@@ -60,6 +60,24 @@ struct aacg_tables {
 #define AACG_LDS_BYTES_F32    (4 * AACG_LDS_FLOATS(AACG_TAB_F32_FLOATS))
 #define AACG_LDS_BYTES_QUANT  (4 * AACG_LDS_FLOATS(AACG_TAB_QUANT_FLOATS))
 
+/* Device copy of a unit: the ABI record plus what the planner derives from it. */
+struct aacg_dev_unit {
+    aacg_unit_desc d;
+    uint32_t gmap[2];                 /* per channel: group of window w in bits 4w..4w+3 (ics.js:288-296 grouping) */
+    uint32_t pad[2];
+};
+
+/* Device form of one channel's TNS side info (AACG_TNS_SPEC): per filter slot the sample range and the
+ * direct-form coefficients, both derived on the host exactly as tns.js:111-152 derives them.  Long windows
+ * use slots 0..2, EIGHT_SHORT uses slot w for window w; order 0 = empty slot. */
+struct aacg_dev_tns {
+    int32_t start[8];                 /* first sample filtered, absolute index in ICStream.data order (includes w * 128) */
+    int32_t size[8];                  /* number of samples; multiple of 4 */
+    int32_t inc[8];                   /* +1 upwards, -1 downwards */
+    int32_t order[8];
+    float   lpc[8][AACG_TNS_MAX_ORDER];
+};
+
 /* One workgroup's work: consecutive frames of one element of one stream.  The first run of a
  * chain holds up to 16 units (wave w = unit w, wave 0 starts from the overlap state); a later
  * run holds up to 15 units in waves 1..15 and wave 0 recomputes the tail of pred_unit. */
@@ -77,10 +95,11 @@ struct aacg_run {
 };
 
 struct aacg_kparams {
-    const aacg_unit_desc* units;
+    const aacg_dev_unit*  units;
     const aacg_run*       runs;
     const void*           coeffs;     /* float or int16_t, per input kind */
     const aacg_band_meta* meta;
+    const aacg_dev_tns*   tns;        /* AACG_TNS_SPEC: indexed like aacg_unit_desc.tns_offset + c; else null */
     float*                pcm;
     float*                overlap;    /* overlap pool */
     float*                spec_out;   /* spectral-only kernel */

@@ -20,10 +20,18 @@
 /* ---- kernels ----------------------------------------------------------------------- */
 /* 1024 threads = 16 waves, one workgroup per CU: 4 waves per SIMD -> 128 VGPRs per lane */
 extern "C" __global__ __launch_bounds__(AACG_WG_THREADS)
-void aacg_imdct_run_quant(const aacg_kparams P) { imdct_run_body<AACG_INPUT_QUANT_I16>(P); }
+void aacg_imdct_run_quant(const aacg_kparams P) { imdct_run_body<AACG_INPUT_QUANT_I16, false>(P); }
 
 extern "C" __global__ __launch_bounds__(AACG_WG_THREADS)
-void aacg_imdct_run_f32(const aacg_kparams P) { imdct_run_body<AACG_INPUT_SPEC_F32>(P); }
+void aacg_imdct_run_f32(const aacg_kparams P) { imdct_run_body<AACG_INPUT_SPEC_F32, false>(P); }
+
+/* AACG_TNS_SPEC batches that carry TNS side info: the same bodies with the TNS stage compiled in (kept out
+ * of the kernels above so that their register allocation is untouched) */
+extern "C" __global__ __launch_bounds__(AACG_WG_THREADS)
+void aacg_imdct_run_quant_tns(const aacg_kparams P) { imdct_run_body<AACG_INPUT_QUANT_I16, true>(P); }
+
+extern "C" __global__ __launch_bounds__(AACG_WG_THREADS)
+void aacg_imdct_run_f32_tns(const aacg_kparams P) { imdct_run_body<AACG_INPUT_SPEC_F32, true>(P); }
 
 extern "C" __global__ __launch_bounds__(AACG_WG_THREADS)
 void aacg_spectral(const aacg_kparams P, int n_units) { spectral_body(P, n_units); }
@@ -48,6 +56,7 @@ struct aacg_engine {
         void* d_runs = nullptr;   size_t runs_cap = 0;
         void* d_coeffs = nullptr; size_t coeffs_cap = 0;
         void* d_meta = nullptr;   size_t meta_cap = 0;
+        void* d_tns = nullptr;    size_t tns_cap = 0;
         void* d_pcm = nullptr;    size_t pcm_cap = 0;
         /* page-locked staging for callers that pass ordinary (pageable) memory */
         void* h_in = nullptr;     size_t h_in_cap = 0;
@@ -66,8 +75,9 @@ struct aacg_plan {
     aacg_engine* e;
     aacg_plan_host h;
     uint32_t n_units = 0;
-    aacg_unit_desc* d_units = nullptr;
+    aacg_dev_unit* d_units = nullptr;
     aacg_run* d_runs = nullptr;
+    aacg_dev_tns* d_tns = nullptr;
     uint32_t launches = 0;
 };
 
@@ -111,21 +121,28 @@ bool is_pinned(const void* p)
 }
 
 /* enqueue the run kernel for a planned batch (device pointers) */
-int launch_run(aacg_engine* e, const aacg_unit_desc* d_units, const aacg_run* d_runs, const aacg_plan_host& h,
-               const void* d_coeffs, const aacg_band_meta* d_meta, float* d_pcm, int flip, hipStream_t s)
+int launch_run(aacg_engine* e, const aacg_dev_unit* d_units, const aacg_run* d_runs, const aacg_dev_tns* d_tns,
+               const aacg_plan_host& h, const void* d_coeffs, const aacg_band_meta* d_meta, float* d_pcm, int flip,
+               hipStream_t s)
 {
     const bool quant = e->cfg.input_kind == AACG_INPUT_QUANT_I16;
     if (h.zero_fill)
         HIP_TRY(e, hipMemsetAsync(d_pcm, 0, h.pcm_floats * sizeof(float), s), AACG_ERR_NO_DEVICE);
     aacg_kparams P;
     P.units = d_units; P.runs = d_runs; P.coeffs = d_coeffs; P.meta = d_meta; P.pcm = d_pcm;
+    P.tns = h.any_tns ? d_tns : nullptr;
     P.overlap = e->d_overlap; P.spec_out = nullptr; P.tab = e->d_tab;
     P.flip = flip; P.n_runs = (int32_t)h.runs.size();
     P.ablate = e->d_trace ? e->ablate : (e->ablate & ~16);
     if (e->d_trace) P.spec_out = (float*)e->d_trace;
     const dim3 grid((unsigned)h.runs.size()), block(AACG_WG_THREADS);
-    if (quant) hipLaunchKernelGGL(aacg_imdct_run_quant, grid, block, AACG_LDS_BYTES_QUANT, s, P);
-    else       hipLaunchKernelGGL(aacg_imdct_run_f32, grid, block, AACG_LDS_BYTES_F32, s, P);
+    if (P.tns) {
+        if (quant) hipLaunchKernelGGL(aacg_imdct_run_quant_tns, grid, block, AACG_LDS_BYTES_QUANT, s, P);
+        else       hipLaunchKernelGGL(aacg_imdct_run_f32_tns, grid, block, AACG_LDS_BYTES_F32, s, P);
+    } else {
+        if (quant) hipLaunchKernelGGL(aacg_imdct_run_quant, grid, block, AACG_LDS_BYTES_QUANT, s, P);
+        else       hipLaunchKernelGGL(aacg_imdct_run_f32, grid, block, AACG_LDS_BYTES_F32, s, P);
+    }
     HIP_TRY(e, hipGetLastError(), AACG_ERR_NO_DEVICE);
     return AACG_OK;
 }
@@ -145,7 +162,7 @@ int aacg_create(const aacg_config* cfg, aacg_engine** out)
     if (!cfg || !out) return AACG_ERR_INVALID_ARG;
     *out = nullptr;
     if (cfg->abi_version != AACG_ABI_VERSION || cfg->max_streams < 1 || cfg->max_channels < 1 ||
-        cfg->max_channels > AACG_MAX_CHANNELS || cfg->tns_mode != AACG_TNS_REFERENCE ||
+        cfg->max_channels > AACG_MAX_CHANNELS || (cfg->tns_mode != AACG_TNS_REFERENCE && cfg->tns_mode != AACG_TNS_SPEC) ||
         (cfg->input_kind != AACG_INPUT_SPEC_F32 && cfg->input_kind != AACG_INPUT_QUANT_I16))
         return AACG_ERR_INVALID_ARG;
 
@@ -169,6 +186,8 @@ int aacg_create(const aacg_config* cfg, aacg_engine** out)
         /* ~158 KiB of dynamic LDS per workgroup is above the 64 KiB default limit */
         !hip_ok(e, hipFuncSetAttribute((const void*)aacg_imdct_run_quant, hipFuncAttributeMaxDynamicSharedMemorySize, AACG_LDS_BYTES_QUANT), "LDS attr") ||
         !hip_ok(e, hipFuncSetAttribute((const void*)aacg_imdct_run_f32, hipFuncAttributeMaxDynamicSharedMemorySize, AACG_LDS_BYTES_F32), "LDS attr") ||
+        !hip_ok(e, hipFuncSetAttribute((const void*)aacg_imdct_run_quant_tns, hipFuncAttributeMaxDynamicSharedMemorySize, AACG_LDS_BYTES_QUANT), "LDS attr") ||
+        !hip_ok(e, hipFuncSetAttribute((const void*)aacg_imdct_run_f32_tns, hipFuncAttributeMaxDynamicSharedMemorySize, AACG_LDS_BYTES_F32), "LDS attr") ||
         !hip_ok(e, hipFuncSetAttribute((const void*)aacg_spectral, hipFuncAttributeMaxDynamicSharedMemorySize, AACG_LDS_BYTES_SPECTRAL), "LDS attr")) {
         std::fprintf(stderr, "aacgpu: %s\n", e->err.c_str());
         aacg_destroy(e);
@@ -189,7 +208,7 @@ void aacg_destroy(aacg_engine* e)
     if (e->d_tab) (void)hipFree(e->d_tab);
     if (e->d_overlap) (void)hipFree(e->d_overlap);
     for (auto& sl : e->slot) {
-        for (void* p : {sl.d_units, sl.d_runs, sl.d_coeffs, sl.d_meta, sl.d_pcm}) if (p) (void)hipFree(p);
+        for (void* p : {sl.d_units, sl.d_runs, sl.d_coeffs, sl.d_meta, sl.d_tns, sl.d_pcm}) if (p) (void)hipFree(p);
         if (sl.h_in) (void)hipHostFree(sl.h_in);
         if (sl.h_pcm) (void)hipHostFree(sl.h_pcm);
         if (sl.done) (void)hipEventDestroy(sl.done);
@@ -272,21 +291,31 @@ int aacg_get_table(aacg_engine* e, int which, float* dst, size_t n)
 /* ---- plans ------------------------------------------------------------------------- */
 int aacg_plan_create(aacg_engine* e, const aacg_unit_desc* units, uint32_t n_units, aacg_plan** out)
 {
+    return aacg_plan_create_tns(e, units, n_units, nullptr, 0, out);
+}
+
+int aacg_plan_create_tns(aacg_engine* e, const aacg_unit_desc* units, uint32_t n_units,
+                         const aacg_tns_info* tns, uint32_t n_tns, aacg_plan** out)
+{
     if (!e || !units || !n_units || !out) return AACG_ERR_INVALID_ARG;
+    if (e->cfg.tns_mode != AACG_TNS_SPEC) { tns = nullptr; n_tns = 0; }   /* REFERENCE mode: TNS is the identity */
     *out = nullptr;
     aacg_plan* p = new (std::nothrow) aacg_plan();
     if (!p) return AACG_ERR_OUT_OF_MEMORY;
     p->e = e;
     p->n_units = n_units;
     int rc = aacg_plan_build(units, n_units, e->cfg.sample_index, e->cfg.max_streams, e->cfg.max_channels,
-                             e->parity.data(), &p->h, &e->err);
+                             e->parity.data(), &p->h, &e->err, tns, n_tns);
     if (rc) { delete p; return rc; }
-    const size_t ub = sizeof(aacg_unit_desc) * n_units, rb = sizeof(aacg_run) * p->h.runs.size();
+    const size_t ub = sizeof(aacg_dev_unit) * n_units, rb = sizeof(aacg_run) * p->h.runs.size();
+    const size_t tb = sizeof(aacg_dev_tns) * p->h.tns.size();
     if (!hip_ok(e, hipSetDevice(e->cfg.device_ordinal), "hipSetDevice") ||
         !hip_ok(e, hipMalloc((void**)&p->d_units, ub), "hipMalloc units") ||
         !hip_ok(e, hipMalloc((void**)&p->d_runs, rb), "hipMalloc runs") ||
         !hip_ok(e, hipMemcpy(p->d_units, p->h.units.data(), ub, hipMemcpyHostToDevice), "upload units") ||
-        !hip_ok(e, hipMemcpy(p->d_runs, p->h.runs.data(), rb, hipMemcpyHostToDevice), "upload runs")) {
+        !hip_ok(e, hipMemcpy(p->d_runs, p->h.runs.data(), rb, hipMemcpyHostToDevice), "upload runs") ||
+        (tb && (!hip_ok(e, hipMalloc((void**)&p->d_tns, tb), "hipMalloc tns") ||
+                !hip_ok(e, hipMemcpy(p->d_tns, p->h.tns.data(), tb, hipMemcpyHostToDevice), "upload tns")))) {
         aacg_plan_destroy(p);
         return AACG_ERR_OUT_OF_MEMORY;
     }
@@ -300,6 +329,7 @@ void aacg_plan_destroy(aacg_plan* p)
     (void)hipSetDevice(p->e->cfg.device_ordinal);
     if (p->d_units) (void)hipFree(p->d_units);
     if (p->d_runs) (void)hipFree(p->d_runs);
+    if (p->d_tns) (void)hipFree(p->d_tns);
     delete p;
 }
 
@@ -324,7 +354,7 @@ int aacg_decode_device(aacg_engine* e, aacg_plan* p, const void* d_coeffs, const
     int rc = plan_check_parity(e, p);
     if (rc) return rc;
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : e->stream;
-    rc = launch_run(e, p->d_units, p->d_runs, p->h, d_coeffs, d_meta, d_pcm, (int)(p->launches & 1u), s);
+    rc = launch_run(e, p->d_units, p->d_runs, p->d_tns, p->h, d_coeffs, d_meta, d_pcm, (int)(p->launches & 1u), s);
     if (rc) return rc;
 
     for (const aacg_chain& c : p->h.chains)
@@ -381,7 +411,17 @@ int aacg_submit(aacg_engine* e, const aacg_unit_desc* units, uint32_t n_units,
                 const aacg_band_meta* meta, uint32_t n_meta,
                 float* pcm_out, size_t n_pcm_floats, uint64_t* ticket)
 {
+    return aacg_submit_tns(e, units, n_units, coeffs, n_coef_blocks, meta, n_meta, nullptr, 0, pcm_out, n_pcm_floats, ticket);
+}
+
+int aacg_submit_tns(aacg_engine* e, const aacg_unit_desc* units, uint32_t n_units,
+                    const void* coeffs, uint32_t n_coef_blocks,
+                    const aacg_band_meta* meta, uint32_t n_meta,
+                    const aacg_tns_info* tns, uint32_t n_tns,
+                    float* pcm_out, size_t n_pcm_floats, uint64_t* ticket)
+{
     if (!e || !units || !n_units || !coeffs || !pcm_out || !ticket) return AACG_ERR_INVALID_ARG;
+    if (e->cfg.tns_mode != AACG_TNS_SPEC) { tns = nullptr; n_tns = 0; }   /* REFERENCE mode: TNS is the identity */
     const bool quant = e->cfg.input_kind == AACG_INPUT_QUANT_I16;
     if (quant && !meta) { e->err = "QUANT_I16 engine needs band meta"; return AACG_ERR_INVALID_ARG; }
     if (e->cfg.max_batch_units > 0 && (int)n_units > e->cfg.max_batch_units) {
@@ -401,7 +441,7 @@ int aacg_submit(aacg_engine* e, const aacg_unit_desc* units, uint32_t n_units,
     }
 
     int rc = aacg_plan_build(units, n_units, e->cfg.sample_index, e->cfg.max_streams, e->cfg.max_channels,
-                             e->parity.data(), &sl.h, &e->err);
+                             e->parity.data(), &sl.h, &e->err, tns, n_tns);
     if (rc) return rc;
     const aacg_plan_host& h = sl.h;
     if (h.coef_blocks > n_coef_blocks || (quant && h.meta_blocks > n_meta) || h.pcm_floats > n_pcm_floats) {
@@ -423,13 +463,14 @@ int aacg_submit(aacg_engine* e, const aacg_unit_desc* units, uint32_t n_units,
             }
     }
 
-    const size_t ub = sizeof(aacg_unit_desc) * h.units.size(), rb = sizeof(aacg_run) * h.runs.size();
+    const size_t ub = sizeof(aacg_dev_unit) * h.units.size(), rb = sizeof(aacg_run) * h.runs.size();
+    const size_t tb = sizeof(aacg_dev_tns) * h.tns.size();
     const size_t cb = (size_t)n_coef_blocks * 1024u * coef_elem_size(e);
     const size_t mb = quant ? (size_t)n_meta * sizeof(aacg_band_meta) : 0;
     const size_t pb = h.pcm_floats * sizeof(float);
     if ((rc = grow(e, &sl.d_units, &sl.units_cap, ub)) || (rc = grow(e, &sl.d_runs, &sl.runs_cap, rb)) ||
         (rc = grow(e, &sl.d_coeffs, &sl.coeffs_cap, cb)) || (quant && (rc = grow(e, &sl.d_meta, &sl.meta_cap, mb))) ||
-        (rc = grow(e, &sl.d_pcm, &sl.pcm_cap, pb)))
+        (tb && (rc = grow(e, &sl.d_tns, &sl.tns_cap, tb))) || (rc = grow(e, &sl.d_pcm, &sl.pcm_cap, pb)))
         return rc;
 
     /* Ordinary (pageable) caller memory goes through the slot's page-locked staging buffers (one host
@@ -455,12 +496,13 @@ int aacg_submit(aacg_engine* e, const aacg_unit_desc* units, uint32_t n_units,
     }
     HIP_TRY(e, hipMemcpyAsync(sl.d_units, h.units.data(), ub, hipMemcpyHostToDevice, s), AACG_ERR_NO_DEVICE);
     HIP_TRY(e, hipMemcpyAsync(sl.d_runs, h.runs.data(), rb, hipMemcpyHostToDevice, s), AACG_ERR_NO_DEVICE);
+    if (tb) HIP_TRY(e, hipMemcpyAsync(sl.d_tns, h.tns.data(), tb, hipMemcpyHostToDevice, s), AACG_ERR_NO_DEVICE);
     HIP_TRY(e, hipMemcpyAsync(sl.d_coeffs, src_coeffs, cb, hipMemcpyHostToDevice, s), AACG_ERR_NO_DEVICE);
     if (quant) HIP_TRY(e, hipMemcpyAsync(sl.d_meta, src_meta, mb, hipMemcpyHostToDevice, s), AACG_ERR_NO_DEVICE);
     /* kernels chain through the overlap state: this one starts after the previous batch's kernel,
      * while its uploads above overlapped it */
     if (e->last_kernel) HIP_TRY(e, hipStreamWaitEvent(s, e->last_kernel, 0), AACG_ERR_NO_DEVICE);
-    rc = launch_run(e, (const aacg_unit_desc*)sl.d_units, (const aacg_run*)sl.d_runs, h, sl.d_coeffs,
+    rc = launch_run(e, (const aacg_dev_unit*)sl.d_units, (const aacg_run*)sl.d_runs, (const aacg_dev_tns*)sl.d_tns, h, sl.d_coeffs,
                     (const aacg_band_meta*)sl.d_meta, (float*)sl.d_pcm, 0, s);
     if (rc) return rc;
     HIP_TRY(e, hipEventRecord(sl.kernel_done, s), AACG_ERR_NO_DEVICE);
@@ -482,8 +524,17 @@ int aacg_decode_batch(aacg_engine* e, const aacg_unit_desc* units, uint32_t n_un
                       const aacg_band_meta* meta, uint32_t n_meta,
                       float* pcm_out, size_t n_pcm_floats)
 {
+    return aacg_decode_batch_tns(e, units, n_units, coeffs, n_coef_blocks, meta, n_meta, nullptr, 0, pcm_out, n_pcm_floats);
+}
+
+int aacg_decode_batch_tns(aacg_engine* e, const aacg_unit_desc* units, uint32_t n_units,
+                          const void* coeffs, uint32_t n_coef_blocks,
+                          const aacg_band_meta* meta, uint32_t n_meta,
+                          const aacg_tns_info* tns, uint32_t n_tns,
+                          float* pcm_out, size_t n_pcm_floats)
+{
     uint64_t t = 0;
-    int rc = aacg_submit(e, units, n_units, coeffs, n_coef_blocks, meta, n_meta, pcm_out, n_pcm_floats, &t);
+    int rc = aacg_submit_tns(e, units, n_units, coeffs, n_coef_blocks, meta, n_meta, tns, n_tns, pcm_out, n_pcm_floats, &t);
     if (rc) return rc;
     return aacg_wait(e, t);
 }

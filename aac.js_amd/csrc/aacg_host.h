@@ -30,7 +30,9 @@ struct aacg_chain {
 };
 
 struct aacg_plan_host {
-    std::vector<aacg_unit_desc> units;  /* device copy: reserved1[c] = group-of-window map of channel c */
+    std::vector<aacg_dev_unit> units;   /* device copy of the units */
+    std::vector<aacg_dev_tns>  tns;     /* device form of the TNS side info (AACG_TNS_SPEC), same indexing as the input */
+    bool     any_tns = false;         /* some channel has AACG_CHAN_TNS_PRESENT and TNS records were given */
     std::vector<aacg_run>   runs;     /* in launch (block) order, XCD-aware */
     std::vector<aacg_chain> chains;
     bool     zero_fill = false;       /* some frame has a channel no unit writes (decoder.js:229-231) */
@@ -50,6 +52,11 @@ static inline int32_t aacg_ov_offset(int max_channels, uint32_t stream, uint32_t
  * with a message in *err. */
 int aacg_plan_build(const aacg_unit_desc* units, uint32_t n_units, int sample_index,
                     int max_streams, int max_channels, const uint8_t* parity,
-                    aacg_plan_host* out, std::string* err);
+                    aacg_plan_host* out, std::string* err,
+                    const aacg_tns_info* tns = nullptr, uint32_t n_tns = 0);
+
+/* tns.js:111-152: per-filter sample range and LPC coefficients of one channel (float32 stores as in the
+ * reference's Float32Array lpc).  Returns AACG_OK or AACG_ERR_UNSUPPORTED (order > 12). */
+int aacg_tns_prepare(int sample_index, const aacg_chan_info* info, const aacg_tns_info* in, aacg_dev_tns* out);
 
 #endif

@@ -80,12 +80,12 @@ DP_DEVICE cpx lds_get(const float* base, int idx)
 /* SALU bit operations — byte-wide field reads would each be a vector-memory round trip          */
 /* ------------------------------------------------------------------------------------ */
 struct unit_view {
-    uint32_t pcm_offset, coef_offset, meta_offset;
+    uint32_t pcm_offset, coef_offset, meta_offset, tns_offset;
     int channel, n_out_ch, n_ch, flags;
-    int seq[2], shape[2], shape_prev[2], max_sfb[2];
-    uint32_t gmap[2];           /* 4 bits per window: its group (planner-filled reserved1[]) */
+    int seq[2], shape[2], shape_prev[2], max_sfb[2], tns[2];
+    uint32_t gmap[2];           /* 4 bits per window: its group (planner-filled) */
 };
-DP_DEVICE unit_view load_unit(const aacg_unit_desc* u)
+DP_DEVICE unit_view load_unit(const aacg_dev_unit* u)
 {
     const uint32_t* w = (const uint32_t*)u;
     unit_view v;
@@ -95,11 +95,13 @@ DP_DEVICE unit_view load_unit(const aacg_unit_desc* u)
     v.n_ch = (int)(w3 & 0xffu); v.flags = (int)((w3 >> 8) & 0xffu);
 #pragma unroll
     for (int c = 0; c < 2; c++) {
-        const uint32_t ci = w[6 + 4 * c];
+        const uint32_t ci = w[6 + 4 * c], cj = w[7 + 4 * c];
         v.seq[c] = (int)(ci & 0xffu); v.shape[c] = (int)((ci >> 8) & 0xffu);
         v.shape_prev[c] = (int)((ci >> 16) & 0xffu); v.max_sfb[c] = (int)(ci >> 24);
-        v.gmap[c] = w[14 + c];
+        v.tns[c] = (int)((cj >> 8) & AACG_CHAN_TNS_PRESENT);         /* aacg_chan_info.flags */
+        v.gmap[c] = w[16 + c];
     }
+    v.tns_offset = w[14];
     return v;
 }
 
@@ -881,6 +883,199 @@ DP_DEVICE void stage_pair_f32(const dpf4 (&xa)[4], const dpf4 (&xb)[4], float* s
     }
 }
 
+/* ------------------------------------------------------------------------------------ */
+/* AACG_TNS_SPEC: the all-pole filter tns.js:155-163 was meant to run, as a block scan       */
+/* ------------------------------------------------------------------------------------ */
+/* y[m] = x[m] - sum_{k=1..min(m,order)} lpc[k-1] y[m-k] over `size` samples in processing order
+ * (position = start + inc * m).  A serial recurrence per (window, filter); here every lane takes a
+ * block of 16 consecutive samples and the blocks of one filter are chained by a scan:
+ *   1. zero-state response of the block, whose last P outputs form c_b;
+ *   2. the block's state transition is the same P x P matrix M = A^16 for every block (A = companion
+ *      matrix of the filter); lane i builds column i by running the homogeneous recurrence 16 steps from
+ *      e_i; M^2, M^4, ... by distributed squaring through LDS;
+ *   3. Hillis-Steele scan over the blocks of the filter: v_b <- M^(2^k) v_(b-2^k) + v_b;
+ *   4. the block is recomputed from its true incoming state v_(b-1) and written back.
+ * SB = lanes (blocks) per filter: 64 for a long window (one filter at a time), 8 for EIGHT_SHORT (lane group w
+ * runs the filter of window w, all eight in parallel).  P = largest order handled (coefficients beyond `order`
+ * are zero).  area: the channel's spectrum in ICStream.data order; scratch: P * P doubles per filter. */
+template <int SB, int P>
+DP_DEVICE_NOINLINE void tns_pass(float* area, float* scratch, int start, int size, int inc, int order, const float* lpc_src)
+{
+    const int lane = dp_lane(), b = lane & (SB - 1), seg = lane / SB;
+    /* scan levels: log2 of the number of blocks the (longest) filter spans */
+    const int n_blocks = (size + 15) >> 4;
+    const int LEVELS = (SB == 64) ? (n_blocks > 1 ? 32 - __builtin_clz((unsigned)(n_blocks - 1)) : 0) : 3;
+    double* mbuf = (double*)scratch + seg * P * P;     /* [row][col]; <= 4 KiB over the wave */
+
+    float lpc[P];
+#pragma unroll
+    for (int k = 0; k < P; k++) lpc[k] = (k < order) ? lpc_src[k] : 0.0f;
+
+    /* this lane's block, in processing order */
+    const int m0 = 16 * b;
+    const int n_valid = order > 0 ? (size - m0 < 0 ? 0 : (size - m0 > 16 ? 16 : size - m0)) : 0;
+    const float* blk = area + (inc > 0 ? start + m0 : start - m0 - 3);   /* chunk c at blk + 4 c inc */
+    auto load_block = [&](float (&x)[16]) {
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            dpf4 t; t.x = t.y = t.z = t.w = 0.0f;
+            if (4 * c < n_valid) t = *(const dpf4*)(blk + 4 * c * inc);
+            if (inc > 0) { x[4 * c] = t.x; x[4 * c + 1] = t.y; x[4 * c + 2] = t.z; x[4 * c + 3] = t.w; }
+            else         { x[4 * c] = t.w; x[4 * c + 1] = t.z; x[4 * c + 2] = t.y; x[4 * c + 3] = t.x; }
+        }
+    };
+
+    /* 1. zero-state response (float32, tap by tap like tns.js:160); only its last P outputs are kept */
+    double v[P];
+    {
+        float x[16], y[16];
+        load_block(x);
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            float acc = x[j];
+#pragma unroll
+            for (int k = 1; k <= P; k++) if (k <= j) acc = dp_fma(-lpc[k - 1], y[j - k], acc);
+            y[j] = acc;
+        }
+#pragma unroll
+        for (int k = 0; k < P; k++) v[k] = (double)y[15 - k];
+    }
+
+    /* 2. M = A^16 in double precision: lane i < P of the filter runs the homogeneous recurrence from e_i.
+     * The block transitions are where a near-unstable filter (reflection coefficients close to 1) would lose
+     * accuracy in float32; in double the state that enters a block is as good as the serial evaluation's. */
+    if (b < P) {
+        double s[P];
+#pragma unroll
+        for (int k = 0; k < P; k++) s[k] = (k == b) ? 1.0 : 0.0;
+#pragma unroll
+        for (int step = 0; step < 16; step++) {
+            double acc = 0.0;
+#pragma unroll
+            for (int k = 0; k < P; k++) acc = dp_fma(-(double)lpc[k], s[k], acc);
+#pragma unroll
+            for (int k = P - 1; k > 0; k--) s[k] = s[k - 1];
+            s[0] = acc;
+        }
+#pragma unroll
+        for (int r = 0; r < P; r++) mbuf[r * P + b] = s[r];
+    }
+    dp_wave_sync();
+
+    /* 3. scan: after level k, v holds the state behind a zero-initial-state run of up to 2^(k+1) blocks ending
+     * here; the matrix is squared in place between levels (M, M^2, M^4, ...) */
+    constexpr int EPL = (P * P + SB - 1) / SB;         /* matrix entries per lane when squaring */
+#pragma unroll 1
+    for (int lev = 0; lev < LEVELS; lev++) {
+        double pv[P];
+#pragma unroll
+        for (int k = 0; k < P; k++) pv[k] = v[k];
+        dp_shfl(pv, (lane - (1 << lev)) & 63);
+        if (b >= (1 << lev)) {
+#pragma unroll
+            for (int r = 0; r < P; r++) {
+                double acc = v[r];
+#pragma unroll
+                for (int t = 0; t < P; t++) acc = dp_fma(mbuf[r * P + t], pv[t], acc);
+                v[r] = acc;
+                dp_sched_fence();                      /* keep the next row's LDS reads from being hoisted */
+            }
+        }
+        if (lev + 1 < LEVELS) {
+            double sq[EPL];
+#pragma unroll
+            for (int q = 0; q < EPL; q++) {
+                const int e = b + q * SB, r = e / P, c = e % P;
+                double acc = 0.0;
+                if (e < P * P) {
+#pragma unroll
+                    for (int t = 0; t < P; t++) acc = dp_fma(mbuf[r * P + t], mbuf[t * P + c], acc);
+                }
+                sq[q] = acc;
+                dp_sched_fence();
+            }
+            dp_wave_sync();                            /* every lane has read the old matrix */
+#pragma unroll
+            for (int q = 0; q < EPL; q++) if (b + q * SB < P * P) mbuf[b + q * SB] = sq[q];
+            dp_wave_sync();
+        }
+    }
+    dp_shfl(v, (lane - 1) & 63);
+    float s_in[P];
+#pragma unroll
+    for (int k = 0; k < P; k++) s_in[k] = (b == 0) ? 0.0f : (float)v[k];
+
+    /* 4. the block from its true incoming state (s_in[k] = y[-1-k]), same arithmetic as step 1; the block is
+     * read again rather than held in registers across the scan */
+    float x[16], y[16];
+    load_block(x);
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        float acc = x[j];
+#pragma unroll
+        for (int k = 1; k <= P; k++) acc = dp_fma(-lpc[k - 1], (k <= j) ? y[j - k] : s_in[k - j - 1], acc);
+        y[j] = acc;
+    }
+    dp_wave_sync();                                    /* every lane has read the matrix / its block */
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        if (4 * c < n_valid) {
+            dpf4 t;
+            if (inc > 0) { t.x = y[4 * c]; t.y = y[4 * c + 1]; t.z = y[4 * c + 2]; t.w = y[4 * c + 3]; }
+            else         { t.w = y[4 * c]; t.z = y[4 * c + 1]; t.y = y[4 * c + 2]; t.x = y[4 * c + 3]; }
+            *(dpf4*)(const_cast<float*>(blk) + 4 * c * inc) = t;
+        }
+    }
+    dp_wave_sync();
+}
+
+/* All TNS filters of one channel, in place on `area` (ICStream.data order); `scratch` holds the block-transition
+ * matrices.  Callers stage the spectrum, sync the wave, call this, and read it back. */
+DP_DEVICE void tns_area(const aacg_dev_tns* rec, bool is_short, float* area, float* scratch)
+{
+    if (is_short) {
+        const int w = dp_lane() >> 3;                  /* lane group w filters window w */
+        tns_pass<8, 8>(area, scratch, rec->start[w], rec->size[w], rec->inc[w], rec->order[w], rec->lpc[w]);
+    } else {
+        for (int f = 0; f < 3; f++) {                  /* up to three filters, disjoint band ranges (tns.js:119-124) */
+            const int order = rec->order[f];           /* wave-uniform: the matrix work goes with the square of P */
+            if (order <= 0) continue;
+            if (order <= 4)      tns_pass<64, 4>(area, scratch, rec->start[f], rec->size[f], rec->inc[f], order, rec->lpc[f]);
+            else if (order <= 8) tns_pass<64, 8>(area, scratch, rec->start[f], rec->size[f], rec->inc[f], order, rec->lpc[f]);
+            else                 tns_pass<64, AACG_TNS_MAX_ORDER>(area, scratch, rec->start[f], rec->size[f], rec->inc[f], order, rec->lpc[f]);
+        }
+    }
+}
+
+/* ... on the natural-order registers of the QUANT path (8 lane + 512 i + e) */
+DP_DEVICE void tns_channel(const aacg_dev_tns* rec, bool is_short, float* area, float* scratch, float (&x)[16])
+{
+    const int lane = dp_lane();
+    stage_nat8(x, area);
+    dp_wave_sync();
+    tns_area(rec, is_short, area, scratch);
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const dpf4 a = *(const dpf4*)(area + 8 * lane + 512 * i), b = *(const dpf4*)(area + 8 * lane + 512 * i + 4);
+        x[8 * i] = a.x; x[8 * i + 1] = a.y; x[8 * i + 2] = a.z; x[8 * i + 3] = a.w;
+        x[8 * i + 4] = b.x; x[8 * i + 5] = b.y; x[8 * i + 6] = b.z; x[8 * i + 7] = b.w;
+    }
+    dp_wave_sync();
+}
+
+/* ... on the load registers of the SPEC_F32 path (4 lane + 256 i) */
+DP_DEVICE void tns_channel(const aacg_dev_tns* rec, bool is_short, float* area, float* scratch, dpf4 (&x)[4])
+{
+    const int lane = dp_lane();
+#pragma unroll
+    for (int i = 0; i < 4; i++) *(dpf4*)(area + 4 * lane + 256 * i) = x[i];
+    dp_wave_sync();
+    tns_area(rec, is_short, area, scratch);
+#pragma unroll
+    for (int i = 0; i < 4; i++) x[i] = *(const dpf4*)(area + 4 * lane + 256 * i);
+    dp_wave_sync();
+}
+
 /* IMDCT + window of a unit whose spectra are staged in its slot.  CPE tails always end up
  * interleaved (pair index n = (tailL[n], tailR[n])); a single channel's tail is planar. */
 DP_DEVICE void filter_unit(const float* tab, const unit_view& u, int n_ch, bool pair_path, bool want_head, float* slot,
@@ -1073,7 +1268,7 @@ DP_DEVICE void epilogue(const float* p0, const float* p1, const unit_view& u, in
 /* ------------------------------------------------------------------------------------ */
 /* one run per workgroup                                                                   */
 /* ------------------------------------------------------------------------------------ */
-template <int KIND>
+template <int KIND, bool TNS>
 DP_DEVICE void imdct_run_body(const aacg_kparams& P)
 {
     const int TAB_FLOATS = (KIND == AACG_INPUT_QUANT_I16) ? AACG_TAB_QUANT_FLOATS : AACG_TAB_F32_FLOATS;
@@ -1163,10 +1358,19 @@ DP_DEVICE void imdct_run_body(const aacg_kparams& P)
                 }
             } else
             spectral_quant(P, tab, u, n_ch, qreg, slot + 1024, xl, xr);
-            /* TNS would run here: identity as the reference executes it (tns.js:106,122) */
+            /* TNS runs here (decoder.js:309-313): identity as the reference executes it (tns.js:106,122);
+             * AACG_TNS_SPEC engines apply the filter it was meant to be */
+            if (TNS && P.tns) {
+                if (u.tns[0]) tns_channel(P.tns + u.tns_offset, cls0 != 0, slot, slot + 1024, xl);
+                if (n_ch == 2 && u.tns[1]) tns_channel(P.tns + u.tns_offset + 1, cls1 != 0, slot + 1024, slot, xr);
+            }
             if (pair_path) stage_pair_nat8(xl, xr, slot);
             else { stage_nat8(xl, slot); if (n_ch == 2) stage_nat8(xr, slot + 1024); }
         } else {
+            if (TNS && P.tns) {
+                if (u.tns[0]) tns_channel(P.tns + u.tns_offset, cls0 != 0, slot, slot + 1024, xa);
+                if (n_ch == 2 && u.tns[1]) tns_channel(P.tns + u.tns_offset + 1, cls1 != 0, slot + 1024, slot, xb);
+            }
             if (pair_path) stage_pair_f32(xa, xb, slot);
             else {
 #pragma unroll

@@ -13,6 +13,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstring>
 #include <map>
 
 namespace {
@@ -43,9 +44,63 @@ int fail(std::string* err, int code, const char* fmt, long a = 0, long b = 0, lo
 
 }  // namespace
 
+/* TNS_MAX_BANDS_1024 / _128 (tns.js:65-66; ISO/IEC 14496-3 Table 4.138) by sampleIndex */
+static const uint8_t kTnsMaxBandsLong[13]  = {31, 31, 34, 40, 42, 51, 46, 46, 42, 42, 42, 39, 39};
+static const uint8_t kTnsMaxBandsShort[13] = {9, 9, 10, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14};
+
+int aacg_tns_prepare(int sample_index, const aacg_chan_info* info, const aacg_tns_info* in, aacg_dev_tns* out)
+{
+    std::memset(out, 0, sizeof *out);
+    const bool is_short = info->window_sequence == AACG_EIGHT_SHORT_SEQUENCE;
+    int swb[64];
+    const int swb_count = aacg_swb_offsets(sample_index, is_short ? 0 : 1, swb);
+    /* tns.js:106 intends min(maxBands, maxSFB); the short-window table is the documented deviation of SPEC mode */
+    const int max_bands = is_short ? kTnsMaxBandsShort[sample_index] : kTnsMaxBandsLong[sample_index];
+    const int mmm = std::min<int>(max_bands, info->max_sfb);
+    const int n_win = is_short ? 8 : 1;
+    for (int w = 0; w < n_win; w++) {
+        int bottom = swb_count;                                      /* tns.js:112 */
+        const int nf = in->n_filt[w];
+        if (nf > (is_short ? 1 : 3)) return AACG_ERR_INVALID_ARG;
+        for (int f = 0; f < nf; f++) {
+            const aacg_tns_filter& tf = in->filt[is_short ? w : f];
+            const int slot = is_short ? w : f;
+            const int top = bottom;                                  /* tns.js:121-123 */
+            bottom = std::max(0, top - (int)tf.length);
+            const int order = tf.order;
+            if (order == 0) continue;
+            /* AAC-LC limits: 12 for long windows, 7 for short ones (3-bit field, tns.js:47) */
+            if (order > (is_short ? 8 : AACG_TNS_MAX_ORDER)) return AACG_ERR_UNSUPPORTED;
+            float lpc[AACG_TNS_MAX_ORDER];
+            for (int i = 0; i < order; i++) {                        /* tns.js:128-140, Float32Array stores */
+                const float r = -tf.coef[i];
+                lpc[i] = r;
+                for (int j = 0, len = (i + 1) >> 1; j < len; j++) {
+                    const float fj = lpc[j], b = lpc[i - 1 - j];
+                    lpc[j] = (float)((double)fj + (double)r * (double)b);
+                    lpc[i - 1 - j] = (float)((double)b + (double)r * (double)fj);
+                }
+            }
+            int start = swb[std::min(bottom, mmm)];                  /* tns.js:142-152 */
+            const int end = swb[std::min(top, mmm)];
+            const int size = end - start;
+            if (size <= 0) continue;
+            int inc = 1;
+            if (tf.direction) { inc = -1; start = end - 1; }
+            out->start[slot] = start + w * 128;
+            out->size[slot] = size;
+            out->inc[slot] = inc;
+            out->order[slot] = order;
+            for (int i = 0; i < order; i++) out->lpc[slot][i] = lpc[i];
+        }
+    }
+    return AACG_OK;
+}
+
 int aacg_plan_build(const aacg_unit_desc* units, uint32_t n_units, int sample_index,
                     int max_streams, int max_channels, const uint8_t* parity,
-                    aacg_plan_host* out, std::string* err)
+                    aacg_plan_host* out, std::string* err,
+                    const aacg_tns_info* tns, uint32_t n_tns)
 {
     int swb[64];
     const int n_long = aacg_swb_offsets(sample_index, 1, swb);
@@ -107,7 +162,9 @@ int aacg_plan_build(const aacg_unit_desc* units, uint32_t n_units, int sample_in
         }
 
         /* device copy with the group-of-window map: 4 bits per window (ics.js:288-296 grouping) */
-        aacg_unit_desc du = u;
+        aacg_dev_unit du;
+        std::memset(&du, 0, sizeof du);
+        du.d = u;
         for (int c = 0; c < 2; c++) {
             uint32_t gmap = 0;
             if (c < u.n_ch && u.ch[c].window_sequence == AACG_EIGHT_SHORT_SEQUENCE) {
@@ -115,7 +172,16 @@ int aacg_plan_build(const aacg_unit_desc* units, uint32_t n_units, int sample_in
                 for (int g = 0; g < u.ch[c].group_count; g++)
                     for (int k = 0; k < u.ch[c].group_len[g] && w < 8; k++, w++) gmap |= (uint32_t)g << (4 * w);
             }
-            du.reserved1[c] = gmap;
+            du.gmap[c] = gmap;
+            if (!tns) du.d.ch[c].flags &= (uint8_t)~AACG_CHAN_TNS_PRESENT;       /* no records: nothing to apply */
+            if (tns && c < u.n_ch && (u.ch[c].flags & AACG_CHAN_TNS_PRESENT)) {
+                const uint32_t ti = u.tns_offset + (uint32_t)c;
+                if (ti >= n_tns) return fail(err, AACG_ERR_INVALID_ARG, "unit %ld ch %ld: tns_offset outside the TNS array", i, c);
+                if (out->tns.size() < n_tns) out->tns.resize(n_tns);
+                int trc = aacg_tns_prepare(sample_index, &u.ch[c], &tns[ti], &out->tns[ti]);
+                if (trc) return fail(err, trc, "unit %ld ch %ld: TNS filter order > 12 or too many filters", i, c);
+                out->any_tns = true;
+            }
         }
         out->units.push_back(du);
 

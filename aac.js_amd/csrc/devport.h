@@ -20,6 +20,7 @@
 #include <hip/hip_runtime.h>
 
 #define DP_DEVICE __device__ __forceinline__
+#define DP_DEVICE_NOINLINE static __device__ __attribute__((noinline))
 #define DP_KERNEL(bounds_threads, bounds_waves) __global__ __launch_bounds__(bounds_threads, bounds_waves)
 
 typedef float2 dpf2;
@@ -77,10 +78,18 @@ DP_DEVICE void dp_shfl(float (&v)[N], int src)
     for (int i = 0; i < N; i++) v[i] = __shfl(v[i], src, 64);
 }
 
+template <int N>
+DP_DEVICE void dp_shfl(double (&v)[N], int src)
+{
+#pragma unroll
+    for (int i = 0; i < N; i++) v[i] = __shfl(v[i], src, 64);
+}
+
 extern __shared__ __attribute__((aligned(16))) unsigned char dp_lds_raw[];
 DP_DEVICE unsigned char* dp_lds() { return dp_lds_raw; }
 
 DP_DEVICE float dp_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+DP_DEVICE double dp_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
 /* true in every lane if the predicate holds in any lane of the wave */
 DP_DEVICE bool dp_any(bool p) { return __any(p) != 0; }
 /* hide a value from common-subexpression elimination: a table load behind it is re-issued

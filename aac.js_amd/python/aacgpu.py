@@ -20,6 +20,7 @@ ERR_NAMES = {0: "OK", -1: "INVALID_ARG", -2: "NO_DEVICE", -3: "OUT_OF_MEMORY", -
 # every symbol include/aacgpu.h declares
 ABI_SYMBOLS = ["aacg_create", "aacg_destroy", "aacg_last_error", "aacg_abi_version", "aacg_reset_stream",
                "aacg_get_overlap", "aacg_set_overlap", "aacg_decode_batch", "aacg_submit", "aacg_wait",
+               "aacg_decode_batch_tns", "aacg_submit_tns", "aacg_plan_create_tns",
                "aacg_host_alloc", "aacg_host_free", "aacg_plan_create", "aacg_plan_destroy",
                "aacg_decode_device", "aacg_spectral_device", "aacg_synchronize", "aacg_get_table", "aacg_kernel_name"]
 
@@ -28,9 +29,18 @@ UNIT_DTYPE = np.dtype([
     ("n_ch", "u1"), ("flags", "u1"), ("reserved0", "<u2"), ("coef_offset", "<u4"), ("meta_offset", "<u4"),
     ("ch", [("window_sequence", "u1"), ("window_shape", "u1"), ("window_shape_prev", "u1"), ("max_sfb", "u1"),
             ("group_count", "u1"), ("flags", "u1"), ("reserved", "u1", (2,)), ("group_len", "u1", (8,))], (2,)),
-    ("reserved1", "<u4", (2,)),
+    ("tns_offset", "<u4"), ("reserved1", "<u4"),
 ])
 assert UNIT_DTYPE.itemsize == 64
+
+# aacg_tns_info: one per channel with CHAN_TNS_PRESENT (TNS_SPEC engines)
+TNS_DTYPE = np.dtype([
+    ("n_filt", "u1", (8,)),
+    ("filt", [("length", "u1"), ("order", "u1"), ("direction", "u1"), ("reserved", "u1"), ("coef", "<f4", (12,))], (8,)),
+])
+assert TNS_DTYPE.itemsize == 424
+TNS_REFERENCE, TNS_SPEC = 0, 1
+CHAN_TNS_PRESENT = 0x01
 
 
 class Config(C.Structure):
@@ -92,6 +102,12 @@ def load_library(path=LIB_PATH):
                                     C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t]
     L.aacg_submit.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32,
                               C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64)]
+    L.aacg_decode_batch_tns.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32,
+                                        C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t]
+    L.aacg_submit_tns.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32,
+                                  C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t,
+                                  C.POINTER(C.c_uint64)]
+    L.aacg_plan_create_tns.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]
     L.aacg_wait.argtypes = [C.c_void_p, C.c_uint64]
     L.aacg_host_alloc.restype = C.c_void_p
     L.aacg_host_alloc.argtypes = [C.c_size_t]
@@ -128,10 +144,10 @@ class Engine:
     """One engine per device (mirrors one FilterBank per decoder, for many streams at once)."""
 
     def __init__(self, input_kind=INPUT_QUANT_I16, max_streams=1, max_channels=2, device=0, sample_index=3,
-                 max_batch_units=0):
+                 max_batch_units=0, tns_mode=TNS_REFERENCE):
         self.lib = load_library()
         cfg = Config(self.lib.aacg_abi_version(), device, sample_index, max_streams, max_channels, max_batch_units,
-                     input_kind, 0)
+                     input_kind, tns_mode)
         h = C.c_void_p()
         rc = self.lib.aacg_create(C.byref(cfg), C.byref(h))
         if rc:
@@ -157,7 +173,7 @@ class Engine:
         return rc
 
     # -- host-buffer path -----------------------------------------------------------------
-    def decode_batch(self, units, coeffs, meta, n_pcm_floats):
+    def decode_batch(self, units, coeffs, meta, n_pcm_floats, tns=None):
         units = np.ascontiguousarray(units)
         assert units.dtype == UNIT_DTYPE
         coeffs = np.ascontiguousarray(coeffs)
@@ -166,15 +182,30 @@ class Engine:
         if meta is not None:
             meta = np.ascontiguousarray(meta, np.uint16)
         pcm = np.full(n_pcm_floats, np.nan, np.float32)
+        if tns is not None:
+            tns = np.ascontiguousarray(tns)
+            assert tns.dtype == TNS_DTYPE
+            self._check(self.lib.aacg_decode_batch_tns(self.handle, units.ctypes.data, len(units), coeffs.ctypes.data, n_blocks,
+                                                       meta.ctypes.data if meta is not None else None,
+                                                       meta.size // 120 if meta is not None else 0,
+                                                       tns.ctypes.data, len(tns), pcm.ctypes.data, pcm.size))
+            return pcm
         self._check(self.lib.aacg_decode_batch(self.handle, units.ctypes.data, len(units), coeffs.ctypes.data, n_blocks,
                                                meta.ctypes.data if meta is not None else None,
                                                meta.size // 120 if meta is not None else 0, pcm.ctypes.data, pcm.size))
         return pcm
 
-    def submit(self, units, coeffs, meta, pcm):
+    def submit(self, units, coeffs, meta, pcm, tns=None):
         """Asynchronous decode_batch into the caller's `pcm` array (keep every array alive until wait)."""
         assert units.dtype == UNIT_DTYPE and units.flags.c_contiguous and coeffs.flags.c_contiguous and pcm.flags.c_contiguous
         t = C.c_uint64()
+        if tns is not None:
+            assert tns.dtype == TNS_DTYPE and tns.flags.c_contiguous
+            self._check(self.lib.aacg_submit_tns(self.handle, units.ctypes.data, len(units), coeffs.ctypes.data, coeffs.size // 1024,
+                                                 meta.ctypes.data if meta is not None else None,
+                                                 meta.size // 120 if meta is not None else 0,
+                                                 tns.ctypes.data, len(tns), pcm.ctypes.data, pcm.size, C.byref(t)))
+            return t.value
         self._check(self.lib.aacg_submit(self.handle, units.ctypes.data, len(units), coeffs.ctypes.data, coeffs.size // 1024,
                                          meta.ctypes.data if meta is not None else None,
                                          meta.size // 120 if meta is not None else 0, pcm.ctypes.data, pcm.size, C.byref(t)))
@@ -196,10 +227,15 @@ class Engine:
         return a
 
     # -- device-resident path -----------------------------------------------------------------
-    def plan(self, units):
+    def plan(self, units, tns=None):
         units = np.ascontiguousarray(units)
         assert units.dtype == UNIT_DTYPE
         h = C.c_void_p()
+        if tns is not None:
+            tns = np.ascontiguousarray(tns)
+            assert tns.dtype == TNS_DTYPE
+            self._check(self.lib.aacg_plan_create_tns(self.handle, units.ctypes.data, len(units), tns.ctypes.data, len(tns), C.byref(h)))
+            return Plan(self, h, len(units))
         self._check(self.lib.aacg_plan_create(self.handle, units.ctypes.data, len(units), C.byref(h)))
         return Plan(self, h, len(units))
 

@@ -180,3 +180,58 @@ def random_batch(seed, n_streams=3, max_frames=20):
                 chan += nc
             pcm += 1024 * C
     return dict(units=np.concatenate(units), q=np.stack(qs), meta=np.stack(metas), n_pcm=pcm, n_streams=n_streams, max_channels=max_c)
+
+
+# ---- TNS side info (AACG_TNS_SPEC) -------------------------------------------------------------------
+def tns_coef_table(res_bits, compress):
+    """The values a parser looks up for a `res_bits`-bit (3 or 4) TNS coefficient field, `compress` dropping the
+    top bit (ISO/IEC 14496-3 4.6.9.3: sin(q / iqfac), with the sign convention of tns.js:49-63)."""
+    n = 1 << (res_bits - compress)
+    out = np.zeros(n, np.float32)
+    iqfac = ((1 << (res_bits - 1)) - 0.5) / (np.pi / 2)
+    iqfac_m = ((1 << (res_bits - 1)) + 0.5) / (np.pi / 2)
+    for i in range(n):
+        s = i - n if i >= n // 2 else i               # two's complement field
+        out[i] = np.float32(-np.sin(s / (iqfac if s >= 0 else iqfac_m)))
+    return out
+
+
+def add_tns(batch, seed=0x7115, p_channel=0.6, max_order_long=12, max_order_short=7, wild=False):
+    """Adds TNS side info to a batch from make_batch / random_batch: returns (units copy with CHAN_TNS_PRESENT
+    and tns_offset set, TNS_DTYPE array).  Long windows get 1..3 filters, short windows 0..1 per window,
+    lengths / orders / directions random, coefficients from the 3- and 4-bit tables.  The reflection
+    coefficients decay with their index, as an encoder's do (|k_i| <= max(0.25, 0.98 * 0.75^i)); wild=True draws
+    every one from the full table instead, which yields near-unstable filters with gains of 100 and more."""
+    from aacgpu import TNS_DTYPE, CHAN_TNS_PRESENT
+    rng = np.random.default_rng(seed)
+    units = batch["units"].copy()
+    recs = []
+    for i in range(len(units)):
+        u = units[i]
+        n_ch = int(u["n_ch"])
+        has = [rng.random() < p_channel for _ in range(n_ch)]
+        if not any(has):
+            continue
+        units[i]["tns_offset"] = len(recs)             # n_ch consecutive records, unused ones stay empty
+        for c in range(n_ch):
+            rec = np.zeros((), TNS_DTYPE)
+            if has[c]:
+                short = int(u["ch"][c]["window_sequence"]) == 2
+                res = int(rng.integers(3, 5))
+                for w in range(8 if short else 1):
+                    nf = int(rng.integers(0, 2)) if short else int(rng.integers(1, 4))
+                    rec["n_filt"][w] = nf
+                    for f in range(nf):
+                        slot = w if short else f
+                        order = int(rng.integers(0, (max_order_short if short else max_order_long) + 1))
+                        tab = tns_coef_table(res, int(rng.integers(0, 2)))
+                        rec["filt"][slot]["length"] = int(rng.integers(0, 16 if short else 50))
+                        rec["filt"][slot]["order"] = order
+                        rec["filt"][slot]["direction"] = int(rng.integers(0, 2))
+                        for k in range(order):
+                            ok = tab if wild else tab[np.abs(tab) <= max(0.25, 0.98 * 0.75 ** k)]
+                            rec["filt"][slot]["coef"][k] = ok[rng.integers(0, len(ok))]
+                units[i]["ch"][c]["flags"] |= CHAN_TNS_PRESENT
+            recs.append(rec)
+    tns = np.array(recs, TNS_DTYPE) if recs else np.zeros(1, TNS_DTYPE)
+    return units, tns

@@ -8,7 +8,7 @@ info resident in HBM, float PCM written to HBM.  Consecutive steps are consecuti
 same 256 streams (overlap state carried in the engine), rotating through NBUF distinct input/output
 buffer sets so that no step is served from the 256 MiB Infinity Cache.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--input quant|spec] [--workload cfg2|cfg3]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--input quant|spec] [--workload cfg2|cfg3|cfg4|cfg5] [--tns reference|spec]
 
 N > 1: launched by torch.distributed.run, one rank per GPU; streams are sharded over ranks (every rank
 decodes its own 256 streams: weak scaling, no data-path collective; RCCL only carries the barrier and
@@ -98,6 +98,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=40)
     ap.add_argument("--input", choices=["quant", "spec"], default="quant")
     ap.add_argument("--workload", choices=["cfg2", "cfg3", "cfg4", "cfg5"], default="cfg2")
+    ap.add_argument("--tns", choices=["reference", "spec"], default="reference",
+                    help="spec: AACG_TNS_SPEC engine with TNS side info on ~60 %% of the channels (supplementary; "
+                         "the reference's TNS is the identity, which is what the headline figure measures)")
     ap.add_argument("--nbuf", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pipelines", type=int, default=1, choices=[1, 2],
@@ -130,17 +133,20 @@ def main():
     layout = ("cpe", "cpe", "cpe", "sce") if args.workload == "cfg5" else ("cpe",)
     n_chan = 7 if args.workload == "cfg5" else 2
     kind = aacgpu.INPUT_QUANT_I16 if args.input == "quant" else aacgpu.INPUT_SPEC_F32
-    eng = aacgpu.Engine(kind, max_streams=n_streams * args.pipelines, max_channels=n_chan, device=local)
+    eng = aacgpu.Engine(kind, max_streams=n_streams * args.pipelines, max_channels=n_chan, device=local,
+                        tns_mode=aacgpu.TNS_SPEC if args.tns == "spec" else aacgpu.TNS_REFERENCE)
 
     # rank r owns its own streams: independent data per rank, same shape
     base = aacgpu_workload.make_batch(n_streams=n_streams, n_frames=n_frames, mix=mix, layout=layout,
                                       seed=0xAAC00002 + 1000 * rank)
-    units = base["units"]
+    units, tns = base["units"], None
+    if args.tns == "spec":
+        units, tns = aacgpu_workload.add_tns(base, seed=0x7115 + rank)
     plans = []
     for pl in range(args.pipelines):               # pipeline p owns stream slots [p * n_streams, (p + 1) * n_streams)
         up = units.copy()
         up["stream"] += pl * n_streams
-        plans.append(eng.plan(up))
+        plans.append(eng.plan(up, tns=tns))
     plan = plans[0]
     d_meta = torch.from_numpy(base["meta"].view(np.int16)).cuda() if args.input == "quant" else None
     bufs = []
@@ -215,10 +221,11 @@ def main():
                    "input": "int16 quantised spectra + band side info (process(elements) seam)" if args.input == "quant"
                    else "f32 spectra (FilterBank.process seam)",
                    "streams_per_gpu": n_streams, "frames_per_stream_per_step": n_frames, "buffers_rotated": args.nbuf,
-                   "realtime_multiple": value / 46.875, "sharding": "streams over ranks, no data-path collective", "pipelines": args.pipelines},
+                   "realtime_multiple": value / 46.875, "sharding": "streams over ranks, no data-path collective", "pipelines": args.pipelines,
+                   "tns": "identity, as the reference executes it" if tns is None else "AACG_TNS_SPEC, filters on ~60 % of the channels"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                     "kernel": eng.kernel_name() if args.input == "quant" else "aacg_imdct_run_f32",
+                     "kernel": (eng.kernel_name() if args.input == "quant" else "aacg_imdct_run_f32") + ("_tns" if tns is not None else ""),
                      "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": abytes},
         "output_ok": ok,
     }

@@ -86,9 +86,30 @@ enum {
 
 /* ---- TNS behaviour ------------------------------------------------------------- */
 enum {
-    AACG_TNS_REFERENCE = 0     /* what aac.js executes: TNS.process leaves the data untouched
-                                  (tns.js:106,122 NaN loop bounds)         */
+    AACG_TNS_REFERENCE = 0,    /* what aac.js executes: TNS.process leaves the data untouched
+                                  (tns.js:106,122 NaN loop bounds); TNS side
+                                  info, if any, is ignored                                       */
+    AACG_TNS_SPEC      = 1     /* what tns.js:105-177 was meant to do (and a standard decoder does):
+                                  the all-pole filter of its `decode` branch (tns.js:155-163) over the
+                                  band range of every filter, per window.  Not aac.js behaviour: an
+                                  explicit, separately tested mode                                 */
 };
+
+/* ---- TNS side info (AACG_TNS_SPEC), the fields of the reference's TNS object (tns.js:22-44) ---- */
+#define AACG_TNS_MAX_ORDER 12  /* AAC-LC limit; tns.js:84 accepts up to 20, orders 13..20 are refused */
+typedef struct aacg_tns_filter {
+    uint8_t length;            /* tns.length[w][filt], in scalefactor bands                    */
+    uint8_t order;             /* tns.order[w][filt]; 0 = filter absent                        */
+    uint8_t direction;         /* tns.direction[w][filt]: 1 = downwards                        */
+    uint8_t reserved;
+    float   coef[AACG_TNS_MAX_ORDER];   /* tns.coef[w][filt][i] as looked up from TNS_TABLES (tns.js:89-97) */
+} aacg_tns_filter;
+/* One per channel that has AACG_CHAN_TNS_PRESENT.  Long windows: n_filt[0] <= 3 filters in filt[0..2];
+ * EIGHT_SHORT: window w has n_filt[w] <= 1 filter in filt[w] (bit widths of tns.js:47-48).   */
+typedef struct aacg_tns_info {
+    uint8_t n_filt[8];
+    aacg_tns_filter filt[8];
+} aacg_tns_info;
 
 /* The ICSInfo fields the path reads (ics.js:270-314), one per channel, 16 bytes. */
 typedef struct aacg_chan_info {
@@ -98,11 +119,12 @@ typedef struct aacg_chan_info {
                                    builds a fresh ICSInfo per frame (decoder.js:145,153)       */
     uint8_t max_sfb;            /* info.maxSFB                                                 */
     uint8_t group_count;        /* info.groupCount (1 for long windows)                        */
-    uint8_t flags;              /* reserved (tnsPresent etc.), must be 0                       */
+    uint8_t flags;              /* AACG_CHAN_*                                                 */
     uint8_t reserved[2];
     uint8_t group_len[8];       /* info.groupLength[g]                                         */
 } aacg_chan_info;
 
+#define AACG_CHAN_TNS_PRESENT    0x01   /* ics.tnsPresent (ics.js:71); only read in AACG_TNS_SPEC mode */
 #define AACG_UNIT_COMMON_WINDOW 0x01   /* cpe.commonWindow (cpe.js:43)  */
 #define AACG_UNIT_MASK_PRESENT  0x02   /* cpe.maskPresent  (cpe.js:47)  */
 
@@ -120,7 +142,8 @@ typedef struct aacg_unit_desc {
     uint32_t coef_offset;   /* channel c's spectrum starts at (coef_offset + c) * 1024 elements */
     uint32_t meta_offset;   /* channel c's aacg_band_meta is meta[meta_offset + c] (QUANT only) */
     aacg_chan_info ch[2];   /* [0] = left / the single channel, [1] = right                    */
-    uint32_t reserved1[2];
+    uint32_t tns_offset;    /* channel c's aacg_tns_info is tns[tns_offset + c] (if TNS present)  */
+    uint32_t reserved1;
 } aacg_unit_desc;
 
 /* Per-channel band side info for AACG_INPUT_QUANT_I16, 240 bytes: one 16-bit word per
@@ -191,6 +214,19 @@ int aacg_submit(aacg_engine* e,
                 const aacg_band_meta* meta, uint32_t n_meta,
                 float* pcm_out, size_t n_pcm_floats, uint64_t* ticket);
 int aacg_wait(aacg_engine* e, uint64_t ticket);
+/* The same three calls with TNS side info (AACG_TNS_SPEC engines; tns may be NULL otherwise). */
+int aacg_decode_batch_tns(aacg_engine* e,
+                          const aacg_unit_desc* units, uint32_t n_units,
+                          const void* coeffs, uint32_t n_coef_blocks,
+                          const aacg_band_meta* meta, uint32_t n_meta,
+                          const aacg_tns_info* tns, uint32_t n_tns,
+                          float* pcm_out, size_t n_pcm_floats);
+int aacg_submit_tns(aacg_engine* e,
+                    const aacg_unit_desc* units, uint32_t n_units,
+                    const void* coeffs, uint32_t n_coef_blocks,
+                    const aacg_band_meta* meta, uint32_t n_meta,
+                    const aacg_tns_info* tns, uint32_t n_tns,
+                    float* pcm_out, size_t n_pcm_floats, uint64_t* ticket);
 /* Pinned (page-locked) host memory for the calls above: hipHostMalloc / hipHostFree. */
 void* aacg_host_alloc(size_t bytes);
 void  aacg_host_free(void* p);
@@ -200,6 +236,9 @@ void  aacg_host_free(void* p);
  * launched repeatedly: every launch continues the streams where the previous launch of
  * the same plan left them (the next batch of the same shape).                          */
 int  aacg_plan_create(aacg_engine* e, const aacg_unit_desc* units, uint32_t n_units, aacg_plan** out);
+/* with TNS side info (host pointer; becomes part of the plan like the unit table) */
+int  aacg_plan_create_tns(aacg_engine* e, const aacg_unit_desc* units, uint32_t n_units,
+                          const aacg_tns_info* tns, uint32_t n_tns, aacg_plan** out);
 void aacg_plan_destroy(aacg_plan* p);
 /* Launch on `hip_stream` (a hipStream_t passed as void*, NULL = the engine's own stream);
  * returns after enqueueing.  d_coeffs / d_meta / d_pcm are DEVICE pointers.            */

@@ -518,6 +518,55 @@ void orc_process_is(int sample_index, const aacg_unit_desc* u,
     }
 }
 
+/* tns.js:65-66 */
+static const int TNS_MAX_BANDS_1024[13] = {31, 31, 34, 40, 42, 51, 46, 46, 42, 42, 42, 39, 39};
+static const int TNS_MAX_BANDS_128[13]  = {9, 9, 10, 14, 14, 14, 14, 14, 14, 14, 14, 14, 14};
+
+/* tns.js:105-177 with the two slips repaired (`ics.maxSFB` -> `info.maxSFB`, `tmp - length` -> `top - length`)
+ * and decode = true; see the header for the status of this function. */
+int orc_tns_spec(int sample_index, const aacg_chan_info* info, const aacg_tns_info* tns, float* data)
+{
+    orc_init();
+    const int is_short = info->window_sequence == AACG_EIGHT_SHORT_SEQUENCE;
+    const uint16_t* swbOffsets = swb_of(sample_index, info);
+    const int swbCount = is_short ? g_swb_short_count[sample_index] : g_swb_long_count[sample_index];
+    const int maxBands = is_short ? TNS_MAX_BANDS_128[sample_index] : TNS_MAX_BANDS_1024[sample_index];
+    const int mmm = maxBands < info->max_sfb ? maxBands : info->max_sfb;          /* tns.js:106 */
+    const int windowCount = is_short ? 8 : 1;
+    float lpc[20];
+    for (int w = 0; w < windowCount; w++) {
+        int bottom = swbCount;                                                    /* tns.js:112 */
+        for (int filt = 0; filt < tns->n_filt[w]; filt++) {
+            const aacg_tns_filter* f = &tns->filt[is_short ? w : filt];
+            int top = bottom;
+            bottom = top - f->length; if (bottom < 0) bottom = 0;                  /* tns.js:121-123 */
+            const int order = f->order;
+            if (order == 0) continue;
+            if (order > AACG_TNS_MAX_ORDER) return AACG_ERR_UNSUPPORTED;
+            for (int i = 0; i < order; i++) {                                     /* tns.js:128-140 */
+                const float r = -f->coef[i];
+                lpc[i] = r;
+                for (int j = 0, len = (i + 1) >> 1; j < len; j++) {
+                    const float ff = lpc[j], b = lpc[i - 1 - j];
+                    lpc[j] = (float)((double)ff + (double)r * (double)b);
+                    lpc[i - 1 - j] = (float)((double)b + (double)r * (double)ff);
+                }
+            }
+            int start = swbOffsets[bottom < mmm ? bottom : mmm];                  /* tns.js:142-146 */
+            const int end = swbOffsets[top < mmm ? top : mmm];
+            const int size = end - start;
+            int inc = 1;
+            if (size <= 0) continue;
+            if (f->direction) { inc = -1; start = end - 1; }                       /* tns.js:148-151 */
+            start += w * 128;
+            for (int m = 0; m < size; m++, start += inc)                           /* tns.js:155-163 */
+                for (int i = 1; i <= (m < order ? m : order); i++)
+                    data[start] = (float)((double)data[start] - (double)data[start - i * inc] * (double)lpc[i - 1]);
+        }
+    }
+    return AACG_OK;
+}
+
 /* ics.js:234: randomState = (randomState * (1664525 + 1013904223)) | 0 — the product is
  * formed in double (so it loses low bits) and then wrapped by ToInt32. */
 void orc_pns_sequence(int32_t* seq, int n)
@@ -540,6 +589,16 @@ int orc_decode_batch(int sample_index, int input_kind, int max_streams, int max_
                      const aacg_unit_desc* units, uint32_t n_units,
                      const void* coeffs, const aacg_band_meta* meta,
                      float* pcm_out, float* overlaps, float* spec_out)
+{
+    return orc_decode_batch_tns(sample_index, input_kind, max_streams, max_channels, units, n_units, coeffs, meta,
+                                NULL, AACG_TNS_REFERENCE, pcm_out, overlaps, spec_out);
+}
+
+int orc_decode_batch_tns(int sample_index, int input_kind, int max_streams, int max_channels,
+                         const aacg_unit_desc* units, uint32_t n_units,
+                         const void* coeffs, const aacg_band_meta* meta,
+                         const aacg_tns_info* tns, int tns_mode,
+                         float* pcm_out, float* overlaps, float* spec_out)
 {
     orc_init();
     if (sample_index < 0 || sample_index > 11) return AACG_ERR_INVALID_ARG;
@@ -578,7 +637,14 @@ int orc_decode_batch(int sample_index, int input_kind, int max_streams, int max_
             orc_process_is(sample_index, u, ml, mr, data[0], data[1]);
         }
         /* tns.process: no-op as the reference runs (tns.js:106,122); coupling: never applied
-         * (decoder.js:408,418).  SURVEY.md §8a rows 8, 9. */
+         * (decoder.js:408,418).  SURVEY.md §8a rows 8, 9.  AACG_TNS_SPEC: the intended filter, after MS/IS
+         * (decoder.js:309-313). */
+        if (tns && tns_mode == AACG_TNS_SPEC)
+            for (int c = 0; c < u->n_ch; c++)
+                if (u->ch[c].flags & AACG_CHAN_TNS_PRESENT) {
+                    int rc = orc_tns_spec(sample_index, &u->ch[c], &tns[u->tns_offset + (uint32_t)c], data[c]);
+                    if (rc) return rc;
+                }
 
         for (int c = 0; c < u->n_ch; c++) {
             int ch = u->channel + c;

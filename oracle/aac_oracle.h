@@ -60,6 +60,13 @@ void orc_process_ms(int sample_index, const aacg_unit_desc* u,
 void orc_process_is(int sample_index, const aacg_unit_desc* u,
                     const aacg_band_meta* meta_l, const aacg_band_meta* meta_r,
                     const float* left, float* right);
+/* AACG_TNS_SPEC: tns.js:105-177 as it was meant to run (the reference never executes it):
+ * `mmm = min(maxBands, info.maxSFB)`, `bottom = max(0, top - length)`, the all-pole `decode` branch (:155-163),
+ * float32 stores as in the reference's typed arrays; short windows use TNS_MAX_BANDS_128 (tns.js:66).
+ * NOT pinned by the reference (there is no reference behaviour to pin to); tests cross-check it against an
+ * independent double-precision direct form. */
+int orc_tns_spec(int sample_index, const aacg_chan_info* info, const aacg_tns_info* tns, float* data);
+
 /* PNS generator exactly as written (ics.js:234): fills seq[n] starting from 0x1F2E3D4C. */
 void orc_pns_sequence(int32_t* seq, int n);
 
@@ -71,6 +78,12 @@ int orc_decode_batch(int sample_index, int input_kind, int max_streams, int max_
                      const aacg_unit_desc* units, uint32_t n_units,
                      const void* coeffs, const aacg_band_meta* meta,
                      float* pcm_out, float* overlaps, float* spec_out);
+/* the same with TNS side info: tns == NULL or tns_mode == AACG_TNS_REFERENCE leaves the spectrum untouched */
+int orc_decode_batch_tns(int sample_index, int input_kind, int max_streams, int max_channels,
+                         const aacg_unit_desc* units, uint32_t n_units,
+                         const void* coeffs, const aacg_band_meta* meta,
+                         const aacg_tns_info* tns, int tns_mode,
+                         float* pcm_out, float* overlaps, float* spec_out);
 
 #ifdef __cplusplus
 }

@@ -19,6 +19,7 @@
 #include <stddef.h>
 
 #define DP_DEVICE static inline
+#define DP_DEVICE_NOINLINE static
 #define DP_KERNEL(a, b)
 
 struct alignas(8)  dpf2 { float x, y; };
@@ -29,6 +30,7 @@ typedef float dpv2 __attribute__((vector_size(8)));
 struct emu_wave {
     pthread_barrier_t bar;
     float shfl[64][16];
+    double shfl_d[64][16];
 };
 struct emu_block {
     pthread_barrier_t bar;
@@ -65,6 +67,16 @@ DP_DEVICE void dp_shfl(float (&v)[N], int src)
     pthread_barrier_wait(&g_emu.w->bar);
 }
 
+template <int N>
+DP_DEVICE void dp_shfl(double (&v)[N], int src)
+{
+    static_assert(N <= 16, "shuffle payload");
+    for (int i = 0; i < N; i++) g_emu.w->shfl_d[g_emu.lane][i] = v[i];
+    pthread_barrier_wait(&g_emu.w->bar);
+    for (int i = 0; i < N; i++) v[i] = g_emu.w->shfl_d[src][i];
+    pthread_barrier_wait(&g_emu.w->bar);
+}
+
 DP_DEVICE bool dp_any(bool p)
 {
     g_emu.w->shfl[g_emu.lane][0] = p ? 1.0f : 0.0f;
@@ -77,6 +89,7 @@ DP_DEVICE bool dp_any(bool p)
 
 DP_DEVICE unsigned char* dp_lds() { return g_emu.b->lds; }
 DP_DEVICE float dp_fma(float a, float b, float c) { return fmaf(a, b, c); }
+DP_DEVICE double dp_fma(double a, double b, double c) { return fma(a, b, c); }
 DP_DEVICE void dp_store_nt(dpf4* p, dpf4 v) { *p = v; }
 DP_DEVICE dpf4 dp_load_nt(const dpf4* p) { return *p; }
 DP_DEVICE dpi4 dp_load_nt_i4(const dpi4* p) { return *p; }

@@ -25,8 +25,8 @@ void* lane_main(void* p)
 {
     launch_arg* a = (launch_arg*)p;
     g_emu = a->ctx;
-    if (a->kind == 0)      imdct_run_body<AACG_INPUT_SPEC_F32>(*a->P);
-    else if (a->kind == 1) imdct_run_body<AACG_INPUT_QUANT_I16>(*a->P);
+    if (a->kind == 0)      imdct_run_body<AACG_INPUT_SPEC_F32, true>(*a->P);
+    else if (a->kind == 1) imdct_run_body<AACG_INPUT_QUANT_I16, true>(*a->P);
     else                   spectral_body(*a->P, a->n_units);
     return nullptr;
 }
@@ -105,13 +105,28 @@ int emu_plan(const aacg_unit_desc* units, uint32_t n_units, int sample_index, in
 }
 
 /* full path: plan + "launch".  overlap_pool: [max_streams][max_channels][2][1024]; parity: [max_streams*max_channels], updated. */
+int emu_decode_tns(int input_kind, int sample_index, int max_streams, int max_channels,
+                   const aacg_unit_desc* units, uint32_t n_units, const void* coeffs, const aacg_band_meta* meta,
+                   const aacg_tns_info* tns, uint32_t n_tns,
+                   float* pcm, size_t n_pcm_floats, float* overlap_pool, uint8_t* parity);
+
 int emu_decode(int input_kind, int sample_index, int max_streams, int max_channels,
                const aacg_unit_desc* units, uint32_t n_units, const void* coeffs, const aacg_band_meta* meta,
                float* pcm, size_t n_pcm_floats, float* overlap_pool, uint8_t* parity)
 {
+    return emu_decode_tns(input_kind, sample_index, max_streams, max_channels, units, n_units, coeffs, meta,
+                          nullptr, 0, pcm, n_pcm_floats, overlap_pool, parity);
+}
+
+/* tns != NULL: AACG_TNS_SPEC */
+int emu_decode_tns(int input_kind, int sample_index, int max_streams, int max_channels,
+                   const aacg_unit_desc* units, uint32_t n_units, const void* coeffs, const aacg_band_meta* meta,
+                   const aacg_tns_info* tns, uint32_t n_tns,
+                   float* pcm, size_t n_pcm_floats, float* overlap_pool, uint8_t* parity)
+{
     if (g_tab_index != sample_index) { int rc = aacg_build_tables(sample_index, &g_tab, nullptr); if (rc) return rc; g_tab_index = sample_index; }
     aacg_plan_host ph;
-    int rc = aacg_plan_build(units, n_units, sample_index, max_streams, max_channels, parity, &ph, &g_err);
+    int rc = aacg_plan_build(units, n_units, sample_index, max_streams, max_channels, parity, &ph, &g_err, tns, n_tns);
     if (rc) return rc;
     if (ph.pcm_floats > n_pcm_floats) { g_err = "pcm buffer too small"; return AACG_ERR_CAPACITY; }
     if (ph.zero_fill) std::memset(pcm, 0, n_pcm_floats * sizeof(float));
@@ -119,6 +134,7 @@ int emu_decode(int input_kind, int sample_index, int max_streams, int max_channe
     std::memset(&P, 0, sizeof P);
     P.units = ph.units.data(); P.runs = ph.runs.data(); P.coeffs = coeffs; P.meta = meta; P.pcm = pcm;
     P.overlap = overlap_pool; P.tab = &g_tab; P.flip = 0; P.n_runs = (int32_t)ph.runs.size();
+    P.tns = ph.any_tns ? ph.tns.data() : nullptr;
     launch(P, input_kind == AACG_INPUT_QUANT_I16 ? 1 : 0, (int)ph.runs.size(), AACG_WG_WAVES,
            input_kind == AACG_INPUT_QUANT_I16 ? AACG_LDS_BYTES_QUANT : AACG_LDS_BYTES_F32);
     for (auto& c : ph.chains)

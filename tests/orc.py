@@ -13,9 +13,15 @@ UNIT_DTYPE = np.dtype([
     ("n_ch", "u1"), ("flags", "u1"), ("reserved0", "<u2"), ("coef_offset", "<u4"), ("meta_offset", "<u4"),
     ("ch", [("window_sequence", "u1"), ("window_shape", "u1"), ("window_shape_prev", "u1"), ("max_sfb", "u1"),
             ("group_count", "u1"), ("flags", "u1"), ("reserved", "u1", (2,)), ("group_len", "u1", (8,))], (2,)),
-    ("reserved1", "<u4", (2,)),
+    ("tns_offset", "<u4"), ("reserved1", "<u4"),
 ])
 assert UNIT_DTYPE.itemsize == 64
+TNS_DTYPE = np.dtype([
+    ("n_filt", "u1", (8,)),
+    ("filt", [("length", "u1"), ("order", "u1"), ("direction", "u1"), ("reserved", "u1"), ("coef", "<f4", (12,))], (8,)),
+])
+assert TNS_DTYPE.itemsize == 424
+CHAN_INFO_DTYPE = UNIT_DTYPE["ch"].base
 
 
 def build(target="liboracle.so"):
@@ -42,6 +48,9 @@ class Oracle:
         L.orc_pns_sequence.argtypes = [C.c_void_p, C.c_int]
         L.orc_decode_batch.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_uint32,
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_decode_batch_tns.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_uint32,
+                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_tns_spec.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_init()
 
     def table_f32(self, which):
@@ -83,8 +92,19 @@ class Oracle:
         self.lib.orc_pns_sequence(a.ctypes.data, n)
         return a
 
-    def decode_batch(self, units, coeffs, meta, n_pcm_floats, overlaps, sample_index=3, want_spec=False):
-        """overlaps: float32 [max_streams, max_channels, 1024], updated in place."""
+    def tns_spec(self, info, tns, data, sample_index=3):
+        """AACG_TNS_SPEC on one channel: info a CHAN_INFO_DTYPE scalar, tns a TNS_DTYPE scalar; returns filtered copy."""
+        info = np.array(info, CHAN_INFO_DTYPE).reshape(1)
+        tns = np.array(tns, TNS_DTYPE).reshape(1)
+        out = np.array(data, np.float32).copy()
+        assert out.size == 1024
+        rc = self.lib.orc_tns_spec(sample_index, info.ctypes.data, tns.ctypes.data, out.ctypes.data)
+        if rc != 0:
+            raise RuntimeError("orc_tns_spec failed: %d" % rc)
+        return out
+
+    def decode_batch(self, units, coeffs, meta, n_pcm_floats, overlaps, sample_index=3, want_spec=False, tns=None):
+        """overlaps: float32 [max_streams, max_channels, 1024], updated in place.  tns: TNS_DTYPE array -> AACG_TNS_SPEC."""
         units = np.ascontiguousarray(units)
         assert units.dtype == UNIT_DTYPE
         coeffs = np.ascontiguousarray(coeffs)
@@ -95,11 +115,15 @@ class Oracle:
         pcm = np.full(n_pcm_floats, np.nan, np.float32)
         spec = np.zeros(coeffs.size, np.float32) if want_spec else None
         assert overlaps.dtype == np.float32 and overlaps.flags.c_contiguous
-        rc = self.lib.orc_decode_batch(sample_index, kind, overlaps.shape[0], overlaps.shape[1],
-                                       units.ctypes.data, len(units), coeffs.ctypes.data,
-                                       meta.ctypes.data if meta is not None else None,
-                                       pcm.ctypes.data, overlaps.ctypes.data,
-                                       spec.ctypes.data if want_spec else None)
+        if tns is not None:
+            tns = np.ascontiguousarray(tns)
+            assert tns.dtype == TNS_DTYPE
+        rc = self.lib.orc_decode_batch_tns(sample_index, kind, overlaps.shape[0], overlaps.shape[1],
+                                           units.ctypes.data, len(units), coeffs.ctypes.data,
+                                           meta.ctypes.data if meta is not None else None,
+                                           tns.ctypes.data if tns is not None else None, 1 if tns is not None else 0,
+                                           pcm.ctypes.data, overlaps.ctypes.data,
+                                           spec.ctypes.data if want_spec else None)
         if rc != 0:
             raise RuntimeError("orc_decode_batch failed: %d" % rc)
         return (pcm, spec.reshape(-1, 1024)) if want_spec else pcm

@@ -1,0 +1,329 @@
+"""AACG_TNS_SPEC: the all-pole filter tns.js:105-177 was meant to run.
+
+aac.js itself never executes it (NaN loop bounds, tns.js:106,122), so there is no reference output to
+pin to: PARITY UNPINNED BY THE REFERENCE for this mode.  The oracle's restatement (orc_tns_spec) is
+instead checked against an independent double-precision direct form written from ISO/IEC 14496-3
+4.6.9.3 below, and the kernels (block scan, different summation order) against the oracle within a
+stated tolerance.  The default mode (AACG_TNS_REFERENCE) must ignore TNS side info bit for bit.
+"""
+import numpy as np
+import pytest
+
+import aacgpu_workload as W
+import emu_lib
+import orc
+
+# 48 kHz tables (ISO/IEC 14496-3 Tables 4.129/4.130, 4.138)
+TNS_MAX_BANDS = {False: 40, True: 14}
+
+# Filtered spectra vs the float64 direct form.  The recursion amplifies the float32 store rounding (and the
+# float32 rounding of the LPC coefficients, tns.js:39) by up to the square of the filter's gain, and random
+# reflection coefficients of order 12 reach gains of 30+: the forward bound scales accordingly, and the
+# well-conditioned statement (the output satisfies the recurrence to float32 rounding) is checked separately.
+ORACLE_REL_TOL = 3e-6
+# Kernel (block scan) vs oracle (sample-serial), relative to the PCM signal RMS.  Inside a 16-sample block the
+# kernel uses the oracle's arithmetic; the state entering a block comes from the scan (block transitions in
+# double precision), so it differs from the oracle's float32-rounded history by that rounding times the filter's
+# gain.  Measured: ~1.5e-6 (the IMDCT's own level) with encoder-like filters; with near-unstable random filters
+# <= 3e-5, where the oracle itself is up to 7e-4 from the float64 evaluation.
+KERNEL_REL_TOL = 5e-6
+KERNEL_REL_TOL_WILD = 1e-3     # filters no encoder emits (PCM peaks of 1e4 on the [-1,1) scale): add_tns(wild=True)
+
+
+def direct_form(info, rec, data, want_filters=False):
+    """ISO/IEC 14496-3 4.6.9.3 tns_decode_frame in float64, one channel, spectrum in ICStream.data order."""
+    short = int(info["window_sequence"]) == 2
+    swb = W.SWB_SHORT_48 if short else W.SWB_LONG_48
+    n_swb = len(swb) - 1
+    mmm = min(TNS_MAX_BANDS[short], int(info["max_sfb"]))
+    out = np.array(data, np.float64)
+    filters = []
+    for w in range(8 if short else 1):
+        bottom = n_swb
+        for f in range(int(rec["n_filt"][w])):
+            flt = rec["filt"][w if short else f]
+            top = bottom
+            bottom = max(top - int(flt["length"]), 0)
+            order = int(flt["order"])
+            if order == 0:
+                continue
+            # tns_decode_coef: reflection -> direct form (the tables of tns.js:49-63 hold -sin(), hence the sign)
+            k = -flt["coef"][:order].astype(np.float64)
+            a = np.zeros(order + 1)
+            a[0] = 1.0
+            for m in range(1, order + 1):
+                b = a.copy()
+                for i in range(1, m):
+                    b[i] = a[i] + k[m - 1] * a[m - i]
+                b[m] = k[m - 1]
+                a = b
+            start, end = int(swb[min(bottom, mmm)]), int(swb[min(top, mmm)])
+            size = end - start
+            if size <= 0:
+                continue
+            inc = 1
+            if int(flt["direction"]):
+                inc, start = -1, end - 1
+            pos = w * 128 + start
+            filters.append((pos, size, inc, a))
+            hist = []
+            for m in range(size):
+                y = out[pos]
+                for j in range(1, min(m, order) + 1):
+                    y -= a[j] * hist[-j]
+                out[pos] = y
+                hist.append(y)
+                pos += inc
+    return (out, filters) if want_filters else out
+
+
+def _random_channel(rng, short):
+    info = np.zeros((), orc.CHAN_INFO_DTYPE)
+    info["window_sequence"] = 2 if short else int(rng.choice([0, 1, 3]))
+    info["max_sfb"] = int(rng.integers(1, 15)) if short else int(rng.integers(1, 50))
+    info["group_count"] = 1
+    info["group_len"][0] = 8 if short else 1
+    unit = np.zeros(1, orc.UNIT_DTYPE)
+    unit["n_ch"] = 1
+    unit["ch"][0][0] = info
+    return info, unit
+
+
+@pytest.mark.parametrize("short", [False, True])
+def test_oracle_tns_matches_iso_direct_form(oracle, short):
+    rng = np.random.default_rng(77 + short)
+    worst = 0.0
+    for trial in range(40):
+        info, unit = _random_channel(rng, short)
+        units, tns = W.add_tns(dict(units=unit), seed=1000 * short + trial, p_channel=1.0, wild=trial % 2 == 1)
+        data = (rng.standard_normal(1024) * 1000).astype(np.float32)
+        got = oracle.tns_spec(info, tns[0], data)
+        want, filters = direct_form(info, tns[0], data, want_filters=True)
+        err = np.sqrt(np.mean((got - want) ** 2))
+        sig = np.sqrt(np.mean(want ** 2))
+        gain = max(1.0, sig / np.sqrt(np.mean(data.astype(np.float64) ** 2)))
+        worst = max(worst, err / sig / gain ** 2)
+        # samples outside every filter's range are untouched, bit for bit
+        same = want == data.astype(np.float64)
+        assert np.array_equal(got[same].view(np.uint32), data[same].view(np.uint32))
+        # backward check: x[m] = y[m] + sum a[k] y[m-k] holds to a few float32 roundings of the terms
+        y = got.astype(np.float64)
+        for pos, size, inc, a in filters:
+            idx = pos + inc * np.arange(size)
+            for m in range(size):
+                k = np.arange(1, min(m, len(a) - 1) + 1)
+                terms = a[k] * y[idx[m - k]]
+                resid = y[idx[m]] + terms.sum() - np.float64(data[idx[m]])
+                bound = 2.0 ** -23 * (abs(y[idx[m]]) + np.abs(terms).sum()) * 2 + 1e-30
+                assert abs(resid) <= bound, (trial, m, resid, bound)
+    assert worst < ORACLE_REL_TOL, worst
+
+
+def test_oracle_tns_edge_cases(oracle):
+    info, unit = _random_channel(np.random.default_rng(1), False)
+    info["max_sfb"] = 49
+    data = np.arange(1024, dtype=np.float32) - 300
+    rec = np.zeros((), orc.TNS_DTYPE)
+    # no filters / order 0 / zero length: identity
+    assert np.array_equal(oracle.tns_spec(info, rec, data), data)
+    rec["n_filt"][0] = 2
+    rec["filt"][0]["length"] = 20
+    rec["filt"][1]["length"] = 0
+    rec["filt"][1]["order"] = 5
+    rec["filt"][1]["coef"][:5] = 0.5
+    assert np.array_equal(oracle.tns_spec(info, rec, data), data)
+    # order-1 filter, upwards over the top 9 bands (40 = TNS_MAX_BANDS caps `top`): y[m] = x[m] + c y[m-1]
+    rec = np.zeros((), orc.TNS_DTYPE)
+    rec["n_filt"][0] = 1
+    rec["filt"][0]["length"] = 18           # bands 31..48 -> clipped to 31..39
+    rec["filt"][0]["order"] = 1
+    rec["filt"][0]["coef"][0] = 0.5         # lpc[0] = -0.5
+    got = oracle.tns_spec(info, rec, data)
+    lo, hi = int(W.SWB_LONG_48[31]), int(W.SWB_LONG_48[40])
+    want = data.copy()
+    for n in range(lo + 1, hi):
+        want[n] = np.float32(np.float64(data[n]) + 0.5 * np.float64(want[n - 1]))
+    assert np.array_equal(got, want)
+    # downwards: the mirror image
+    rec["filt"][0]["direction"] = 1
+    got = oracle.tns_spec(info, rec, data)
+    want = data.copy()
+    for n in range(hi - 2, lo - 1, -1):
+        want[n] = np.float32(np.float64(data[n]) + 0.5 * np.float64(want[n + 1]))
+    assert np.array_equal(got, want)
+
+
+def _decode_pair(oracle, wl, tns, units=None):
+    units = wl["units"] if units is None else units
+    S = wl.get("n_streams", int(units["stream"].max()) + 1)
+    C = wl.get("max_channels", wl.get("C"))
+    ov = np.zeros((S, C, 1024), np.float32)
+    ref = oracle.decode_batch(units, wl["q"], wl["meta"], wl["n_pcm"], ov, tns=tns)
+    return ref, ov, S, C
+
+
+def test_reference_mode_ignores_tns_side_info(oracle):
+    wl = W.random_batch(5, n_streams=2, max_frames=4)
+    units, tns = W.add_tns(wl, seed=5)
+    plain, ov0, S, C = _decode_pair(oracle, wl, None)
+    flagged, ov1, _, _ = _decode_pair(oracle, wl, None, units=units)     # flags set, REFERENCE mode
+    assert np.array_equal(plain.view(np.uint32), flagged.view(np.uint32))
+    spec, _, _, _ = _decode_pair(oracle, wl, tns, units=units)
+    assert not np.array_equal(plain, spec)                               # SPEC mode does change the output
+
+
+@pytest.fixture(scope="module")
+def emu():
+    return emu_lib.Emu()
+
+
+def _rel(a, b):
+    a = np.asarray(a, np.float64).ravel()
+    b = np.asarray(b, np.float64).ravel()
+    return float(np.sqrt(np.mean((a - b) ** 2)) / max(np.sqrt(np.mean(b * b)), 1e-30))
+
+
+@pytest.mark.parametrize("seed,wild", [(11, False), (12, False), (13, False), (13, True)])
+def test_emulated_kernels_tns_vs_oracle(emu, oracle, seed, wild):
+    """Random layouts / sequences with TNS on ~60 % of the channels: block-scan kernels vs the oracle."""
+    wl = W.random_batch(seed, n_streams=2, max_frames=5)
+    units, tns = W.add_tns(wl, seed=seed, wild=wild)
+    ref, ov, S, C = _decode_pair(oracle, wl, tns, units=units)
+    pool = np.zeros((S, C, 2, 1024), np.float32)
+    par = np.zeros(S * C, np.uint8)
+    pcm = emu.decode(units, wl["q"], wl["meta"], wl["n_pcm"], pool, par, tns=tns)
+    tol = KERNEL_REL_TOL_WILD if wild else KERNEL_REL_TOL
+    assert _rel(pcm, ref) < tol
+    assert _rel(emu_lib.pool_current(pool, par), ov) < tol
+    # without records the flags are inert (REFERENCE behaviour), bit-identical to the unflagged batch
+    pool[:] = 0
+    par[:] = 0
+    a = emu.decode(units, wl["q"], wl["meta"], wl["n_pcm"], pool, par)
+    pool[:] = 0
+    par[:] = 0
+    b = emu.decode(wl["units"], wl["q"], wl["meta"], wl["n_pcm"], pool, par)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def test_emulated_kernels_tns_f32_seam(emu, oracle):
+    """SPEC_F32 input (filterbank seam): TNS runs on the caller's spectrum."""
+    wl = W.make_batch(n_streams=2, n_frames=5, mix=True, seed=99)
+    units, tns = W.add_tns(wl, seed=3, p_channel=0.8)
+    ov = np.zeros((2, 2, 1024), np.float32)
+    _, spec = oracle.decode_batch(wl["units"], wl["q"], wl["meta"], wl["n_pcm"], ov, want_spec=True)
+    ov[:] = 0
+    ref = oracle.decode_batch(units, spec, None, wl["n_pcm"], ov, tns=tns)
+    ov2 = np.zeros_like(ov)
+    ref_q = oracle.decode_batch(units, wl["q"], wl["meta"], wl["n_pcm"], ov2, tns=tns)
+    assert np.array_equal(ref.view(np.uint32), ref_q.view(np.uint32))    # both seams agree in the oracle
+    pool = np.zeros((2, 2, 2, 1024), np.float32)
+    par = np.zeros(4, np.uint8)
+    pcm = emu.decode(units, spec, None, wl["n_pcm"], pool, par, tns=tns)
+    assert _rel(pcm, ref) < KERNEL_REL_TOL
+
+
+def test_planner_rejects_bad_tns(emu):
+    wl = W.make_batch(n_streams=1, n_frames=2, seed=1)
+    units, tns = W.add_tns(wl, seed=1, p_channel=1.0)
+    pool = np.zeros((1, 2, 2, 1024), np.float32)
+    par = np.zeros(2, np.uint8)
+    bad = units.copy()
+    bad["tns_offset"][1] = len(tns)                   # points outside the array
+    with pytest.raises(RuntimeError, match="tns_offset"):
+        emu.decode(bad, wl["q"], wl["meta"], wl["n_pcm"], pool, par, tns=tns)
+    t2 = tns.copy()
+    t2[0]["n_filt"][0] = 1
+    t2[0]["filt"][0]["order"] = 13                     # above the AAC-LC limit
+    with pytest.raises(RuntimeError, match="rc=-5"):
+        emu.decode(units, wl["q"], wl["meta"], wl["n_pcm"], pool, par, tns=t2)
+
+
+# ---- the HIP path (needs a real MI355X) -----------------------------------------------------------------
+def _gpu_overlaps(eng, S, C):
+    return np.stack([[eng.get_overlap(s, c) for c in range(C)] for s in range(S)])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,wild", [(201, False), (202, False), (203, False), (204, False), (205, True), (206, True)])
+def test_gpu_tns_fuzz_vs_oracle(oracle, seed, wild):
+    import aacgpu
+    wl = W.random_batch(seed, n_streams=4, max_frames=20)
+    units, tns = W.add_tns(wl, seed=seed, wild=wild)
+    ref, ov, S, C = _decode_pair(oracle, wl, tns, units=units)
+    eng = aacgpu.Engine(aacgpu.INPUT_QUANT_I16, S, C, tns_mode=aacgpu.TNS_SPEC)
+    pcm = eng.decode_batch(units, wl["q"], wl["meta"], wl["n_pcm"], tns=tns)
+    tol = KERNEL_REL_TOL_WILD if wild else KERNEL_REL_TOL
+    assert _rel(pcm, ref) < tol
+    assert _rel(_gpu_overlaps(eng, S, C), ov) < tol
+    eng.close()
+    # REFERENCE-mode engine: side info and flags are ignored, bit-identical to the plain batch
+    eng = aacgpu.Engine(aacgpu.INPUT_QUANT_I16, S, C)
+    a = eng.decode_batch(units, wl["q"], wl["meta"], wl["n_pcm"], tns=tns)
+    eng.close()
+    eng = aacgpu.Engine(aacgpu.INPUT_QUANT_I16, S, C)
+    b = eng.decode_batch(wl["units"], wl["q"], wl["meta"], wl["n_pcm"])
+    eng.close()
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("layout", [("cpe",), ("cpe", "cpe", "cpe", "sce")])
+def test_gpu_tns_cfg3_both_seams(oracle, layout):
+    """BASELINE config 3 ("mixed window sequences, TNS on") at reduced size, through both input seams and
+    through the device-resident plan path."""
+    import aacgpu
+    import torch
+    S, T = 6, 19
+    wl = W.make_batch(n_streams=S, n_frames=T, layout=layout, mix=True, intensity=True, seed=77)
+    C = wl["C"]
+    units, tns = W.add_tns(wl, seed=7, p_channel=0.7)
+    ov = np.zeros((S, C, 1024), np.float32)
+    _, spec = oracle.decode_batch(wl["units"], wl["q"], wl["meta"], wl["n_pcm"], ov, want_spec=True)
+    ov[:] = 0
+    ref = oracle.decode_batch(units, wl["q"], wl["meta"], wl["n_pcm"], ov, tns=tns)
+
+    eng = aacgpu.Engine(aacgpu.INPUT_SPEC_F32, S, C, tns_mode=aacgpu.TNS_SPEC)
+    pcm = eng.decode_batch(units, spec, None, wl["n_pcm"], tns=tns)
+    assert _rel(pcm, ref) < KERNEL_REL_TOL
+    assert _rel(_gpu_overlaps(eng, S, C), ov) < KERNEL_REL_TOL
+    eng.close()
+
+    eng = aacgpu.Engine(aacgpu.INPUT_QUANT_I16, S, C, tns_mode=aacgpu.TNS_SPEC)
+    plan = eng.plan(units, tns=tns)
+    dq = torch.from_numpy(wl["q"]).cuda()
+    dm = torch.from_numpy(wl["meta"].view(np.int16)).cuda()
+    dp = torch.zeros(wl["n_pcm"], dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    eng.decode_device(plan, dq.data_ptr(), dm.data_ptr(), dp.data_ptr(), 0)
+    eng.synchronize()
+    assert _rel(dp.cpu().numpy(), ref) < KERNEL_REL_TOL
+    assert _rel(_gpu_overlaps(eng, S, C), ov) < KERNEL_REL_TOL
+    plan.destroy()
+    eng.close()
+
+
+@pytest.mark.gpu
+def test_gpu_tns_errors():
+    import aacgpu
+    wl = W.make_batch(n_streams=1, n_frames=2, seed=1)
+    units, tns = W.add_tns(wl, seed=1, p_channel=1.0)
+    eng = aacgpu.Engine(aacgpu.INPUT_QUANT_I16, 1, 2, tns_mode=aacgpu.TNS_SPEC)
+    t2 = tns.copy()
+    t2[0]["n_filt"][0] = 1
+    t2[0]["filt"][0]["order"] = 13
+    with pytest.raises(aacgpu.AacgError) as ei:
+        eng.decode_batch(units, wl["q"], wl["meta"], wl["n_pcm"], tns=t2)
+    assert ei.value.code == -5
+    bad = units.copy()
+    bad["tns_offset"][1] = len(tns)
+    with pytest.raises(aacgpu.AacgError) as ei:
+        eng.decode_batch(bad, wl["q"], wl["meta"], wl["n_pcm"], tns=tns)
+    assert ei.value.code == -1
+    # flags without records: nothing to apply, decodes like a plain batch
+    a = eng.decode_batch(units, wl["q"], wl["meta"], wl["n_pcm"])
+    eng.reset_stream(0)
+    b = eng.decode_batch(wl["units"], wl["q"], wl["meta"], wl["n_pcm"])
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    eng.close()
+    with pytest.raises(aacgpu.AacgError):
+        aacgpu.Engine(aacgpu.INPUT_QUANT_I16, 1, 2, tns_mode=2)
