@@ -12,7 +12,8 @@
 const path = require('path');
 
 const INPUT_SPEC_F32 = 0, INPUT_QUANT_I16 = 1;
-const UNIT_BYTES = 64, META_WORDS = 120, FRAME = 1024;
+const UNIT_BYTES = 64, META_WORDS = 120, FRAME = 1024, TNS_BYTES = 424, TNS_MAX_ORDER = 12;
+const TNS_REFERENCE = 0, TNS_SPEC = 1;
 const SAMPLE_RATES = [96000, 88200, 64000, 48000, 44100, 32000, 24000, 22050, 16000, 12000, 11025, 8000, 7350];
 
 let addon = null;
@@ -31,6 +32,7 @@ function packChanInfo(view, off, ch) {
     view.setUint8(off + 2, ch.windowShapePrev | 0);   // aac.js always has 0 here (fresh ICSInfo per frame)
     view.setUint8(off + 3, ch.maxSFB);
     view.setUint8(off + 4, ch.groupLength.length);
+    view.setUint8(off + 5, ch.tns ? 1 : 0);           // AACG_CHAN_TNS_PRESENT (only read by TNS_SPEC engines)
     for (let g = 0; g < ch.groupLength.length; g++) view.setUint8(off + 8 + g, ch.groupLength[g]);
 }
 
@@ -49,6 +51,33 @@ function packUnits(units) {
         view.setUint32(o + 20, u.metaOffset, true);
         packChanInfo(view, o + 24, u.ch[0]);
         if (u.ch.length > 1) packChanInfo(view, o + 40, u.ch[1]);
+        view.setUint32(o + 56, u.tnsOffset >>> 0, true);
+    });
+    return new Uint8Array(buf);
+}
+
+/* TNS side info -> aacg_tns_info records.  `list` holds one entry per channel slot, in the shape of the
+ * reference's TNS object (tns.js:22-44: nFilt[w], length[w][filt], order[w][filt], direction[w][filt],
+ * coef[w][filt][i]) plus `short` (EIGHT_SHORT_SEQUENCE), or null for a channel without TNS.  Long windows
+ * put filter f of window 0 in slot f, short windows put window w's single filter in slot w. */
+function packTns(list) {
+    const buf = new ArrayBuffer(TNS_BYTES * Math.max(1, list.length)), view = new DataView(buf);
+    list.forEach(function (t, i) {
+        if (!t) return;
+        const o = TNS_BYTES * i, nWin = t.short ? 8 : 1;
+        for (let w = 0; w < nWin; w++) {
+            const nf = t.nFilt[w] | 0;
+            if (nf > (t.short ? 1 : 3)) throw new Error('TNS filter count out of range: ' + nf);
+            view.setUint8(o + w, nf);
+            for (let f = 0; f < nf; f++) {
+                const fo = o + 8 + 52 * (t.short ? w : f), order = t.order[w][f] | 0;
+                if (order > TNS_MAX_ORDER) throw new Error('TNS filter out of range: ' + order);   // tns.js:84-85 allows 20
+                view.setUint8(fo, t.length[w][f]);
+                view.setUint8(fo + 1, order);
+                view.setUint8(fo + 2, t.direction[w][f] ? 1 : 0);
+                for (let k = 0; k < order; k++) view.setFloat32(fo + 4 + 4 * k, t.coef[w][f][k], true);
+            }
+        }
     });
     return new Uint8Array(buf);
 }
@@ -84,15 +113,17 @@ function Engine(opts) {
     this.inputKind = opts.inputKind === undefined ? INPUT_QUANT_I16 : opts.inputKind;
     this.handle = this.addon.create({ deviceOrdinal: opts.deviceOrdinal | 0, sampleIndex: opts.sampleIndex === undefined ? 3 : opts.sampleIndex,
                                       maxStreams: opts.maxStreams || 1, maxChannels: opts.maxChannels || 2,
-                                      maxBatchUnits: opts.maxBatchUnits | 0, inputKind: this.inputKind });
+                                      maxBatchUnits: opts.maxBatchUnits | 0, inputKind: this.inputKind,
+                                      tnsMode: opts.tnsMode | 0 });
 }
-Engine.prototype.decodeBatch = function (units, coeffs, meta, pcm) {
-    return this.addon.decodeBatch(this.handle, units, coeffs, meta || null, pcm);   // throws on error
+/* tns: packTns(...) records for TNS_SPEC engines, else omitted */
+Engine.prototype.decodeBatch = function (units, coeffs, meta, pcm, tns) {
+    return this.addon.decodeBatch(this.handle, units, coeffs, meta || null, pcm, tns || null);   // throws on error
 };
 /* the same off the JavaScript thread: resolves with `pcm`; one call in flight per engine (the kernels chain
  * through the overlap state, so batches of one engine are decoded in order) */
-Engine.prototype.decodeBatchAsync = function (units, coeffs, meta, pcm) {
-    return this.addon.decodeBatchAsync(this.handle, units, coeffs, meta || null, pcm);
+Engine.prototype.decodeBatchAsync = function (units, coeffs, meta, pcm, tns) {
+    return this.addon.decodeBatchAsync(this.handle, units, coeffs, meta || null, pcm, tns || null);
 };
 Engine.prototype.resetStream = function (s) { this.addon.resetStream(this.handle, s); };
 Engine.prototype.getOverlap = function (s, c) { return this.addon.getOverlap(this.handle, s, c, new Float32Array(FRAME)); };
@@ -137,6 +168,10 @@ function GpuAACDecoder(opts) {
      * per frame and so loses windowShape[0] (decoder.js:145,153; SURVEY.md 9.1).  false (default) reproduces
      * that; true carries the previous frame's shape per channel as the standard prescribes. */
     this.carryWindowShape = !!opts.carryWindowShape;
+    /* aac.js's TNS.process leaves the spectrum untouched (NaN loop bounds, tns.js:106,122).  TNS_REFERENCE
+     * (default) reproduces that; TNS_SPEC applies the filter, taking each channel's side info from
+     * chanInfo.tns (an object shaped like the reference's TNS instance, tns.js:22-44). */
+    this.tnsMode = opts.tnsMode | 0;
     this.prevShape = [];
     this.queue = [];
 }
@@ -164,13 +199,14 @@ GpuAACDecoder.prototype.setCookie = function (buffer) {
     if (s.read(1)) { if (cfg.profile > 16) s.advance(3); s.advance(1); }
     if (cfg.chanConfig === 0) throw new Error('PCE unimplemented');
     if (!this.engine)
-        this.engine = new Engine({ sampleIndex: cfg.sampleIndex, maxStreams: this.stream + 1, maxChannels: cfg.chanConfig, inputKind: INPUT_QUANT_I16 });
+        this.engine = new Engine({ sampleIndex: cfg.sampleIndex, maxStreams: this.stream + 1, maxChannels: cfg.chanConfig, inputKind: INPUT_QUANT_I16,
+                                   tnsMode: this.tnsMode });
     this.engine.resetStream(this.stream);    // new FilterBank(false, chanConfig): zeroed overlaps (filter_bank.js:38-41)
 };
 
 /* elements of one parsed frame -> unit records; channel indices assigned in element order, elements beyond
  * chanConfig channels dropped (decoder.js:233-247) */
-GpuAACDecoder.prototype.unitsOfFrame = function (frame, frameSlot, blockBase) {
+GpuAACDecoder.prototype.unitsOfFrame = function (frame, frameSlot, blockBase, tnsList) {
     const C = this.config.chanConfig, units = [];
     let channel = 0, block = blockBase;
     for (const e of frame.elements) {
@@ -181,8 +217,16 @@ GpuAACDecoder.prototype.unitsOfFrame = function (frame, frameSlot, blockBase) {
             e.ch[c].windowShapePrev = this.carryWindowShape ? (this.prevShape[channel + c] | 0) : 0;
             this.prevShape[channel + c] = e.ch[c].windowShape;
         }
+        let tnsOffset = 0;
+        if (tnsList && e.ch.some(function (c) { return !!c.tns; })) {       // ics.tnsPresent (ics.js:71), TNS_SPEC engines only
+            tnsOffset = tnsList.length;
+            for (let c = 0; c < n; c++) {
+                if (e.ch[c].tns) e.ch[c].tns.short = e.ch[c].windowSequence === 2;
+                tnsList.push(e.ch[c].tns || null);
+            }
+        }
         units.push({ stream: this.stream, pcmOffset: frameSlot * FRAME * C, channel: channel, nOutCh: C, coefOffset: block, metaOffset: block,
-                     commonWindow: !!e.commonWindow, maskPresent: !!e.maskPresent, ch: e.ch });
+                     commonWindow: !!e.commonWindow, maskPresent: !!e.maskPresent, ch: e.ch, tnsOffset: tnsOffset });
         channel += n; block += n;
     }
     return units;
@@ -204,16 +248,17 @@ GpuAACDecoder.prototype.readChunk = function () {
     for (const f of frames) nBlocks += f.q.length / FRAME;
     const q = new Int16Array(nBlocks * FRAME), meta = new Uint16Array(nBlocks * META_WORDS);
     let units = [], block = 0;
+    const tnsList = this.tnsMode === TNS_SPEC ? [] : null;
     frames.forEach((f, slot) => {
-        units = units.concat(this.unitsOfFrame(f, slot, block));
+        units = units.concat(this.unitsOfFrame(f, slot, block, tnsList));
         q.set(f.q, block * FRAME); meta.set(f.meta, block * META_WORDS);
         block += f.q.length / FRAME;
     });
     const pcm = new Float32Array(frames.length * FRAME * C);
-    this.engine.decodeBatch(packUnits(units), q, meta, pcm);
+    this.engine.decodeBatch(packUnits(units), q, meta, pcm, tnsList && tnsList.length ? packTns(tnsList) : null);
     for (let i = 0; i < frames.length; i++) this.queue.push(pcm.slice(i * FRAME * C, (i + 1) * FRAME * C));   // caller owns each array
     return this.queue.shift();
 };
 
-module.exports = { Engine, GpuAACDecoder, BitReader, packUnits, unpackUnits, packBandWord,
-                   INPUT_SPEC_F32, INPUT_QUANT_I16, UNIT_BYTES, META_WORDS, SAMPLE_RATES };
+module.exports = { Engine, GpuAACDecoder, BitReader, packUnits, unpackUnits, packBandWord, packTns,
+                   INPUT_SPEC_F32, INPUT_QUANT_I16, TNS_REFERENCE, TNS_SPEC, UNIT_BYTES, META_WORDS, TNS_BYTES, SAMPLE_RATES };

@@ -30,6 +30,10 @@ static struct {
     int  (*submit)(aacg_engine*, const aacg_unit_desc*, uint32_t, const void*, uint32_t,
                    const aacg_band_meta*, uint32_t, float*, size_t, uint64_t*);
     int  (*wait)(aacg_engine*, uint64_t);
+    int  (*decode_batch_tns)(aacg_engine*, const aacg_unit_desc*, uint32_t, const void*, uint32_t,
+                             const aacg_band_meta*, uint32_t, const aacg_tns_info*, uint32_t, float*, size_t);
+    int  (*submit_tns)(aacg_engine*, const aacg_unit_desc*, uint32_t, const void*, uint32_t,
+                       const aacg_band_meta*, uint32_t, const aacg_tns_info*, uint32_t, float*, size_t, uint64_t*);
 } L;
 
 #define CHECK(env, call) do { if ((call) != napi_ok) { napi_throw_error((env), NULL, "aacgpu: N-API call failed: " #call); return NULL; } } while (0)
@@ -57,6 +61,7 @@ static int load_lib(napi_env env, const char* path)
     SYM(abi_version, "aacg_abi_version"); SYM(reset_stream, "aacg_reset_stream");
     SYM(get_overlap, "aacg_get_overlap"); SYM(set_overlap, "aacg_set_overlap"); SYM(decode_batch, "aacg_decode_batch");
     SYM(submit, "aacg_submit"); SYM(wait, "aacg_wait");
+    SYM(decode_batch_tns, "aacg_decode_batch_tns"); SYM(submit_tns, "aacg_submit_tns");
 #undef SYM
     return 1;
 }
@@ -101,7 +106,7 @@ static napi_value js_create(napi_env env, napi_callback_info info)
     cfg.max_channels = get_i32(env, argv[0], "maxChannels", 2);
     cfg.max_batch_units = get_i32(env, argv[0], "maxBatchUnits", 0);
     cfg.input_kind = get_i32(env, argv[0], "inputKind", AACG_INPUT_QUANT_I16);
-    cfg.tns_mode = AACG_TNS_REFERENCE;
+    cfg.tns_mode = get_i32(env, argv[0], "tnsMode", AACG_TNS_REFERENCE);
     aacg_engine* e = NULL;
     int rc = L.create(&cfg, &e);
     if (rc) return fail(env, NULL, rc, "aacg_create (is a GPU visible?)");
@@ -122,11 +127,31 @@ static int typed(napi_env env, napi_value v, napi_typedarray_type* type, size_t*
     return napi_get_typedarray_info(env, v, type, len, data, &ab, &off) == napi_ok;
 }
 
-/* decodeBatch(engine, units:Uint8Array(64*n), coeffs:Int16Array|Float32Array, meta:Uint16Array|null, pcm:Float32Array) */
+/* optional trailing argument: tns:Uint8Array of aacg_tns_info records (AACG_TNS_SPEC engines); 1 ok, 0 thrown */
+static int optional_tns(napi_env env, size_t argc, napi_value* argv, size_t at, void** data, size_t* count)
+{
+    *data = NULL; *count = 0;
+    if (argc <= at) return 1;
+    napi_valuetype vt;
+    if (napi_typeof(env, argv[at], &vt) != napi_ok) return 0;
+    if (vt == napi_null || vt == napi_undefined) return 1;
+    napi_typedarray_type tt; size_t nt;
+    if (!typed(env, argv[at], &tt, &nt, data) || tt != napi_uint8_array || nt % sizeof(aacg_tns_info)) {
+        napi_throw_type_error(env, NULL, "tns must be a Uint8Array of 424-byte aacg_tns_info records");
+        return 0;
+    }
+    *count = nt / sizeof(aacg_tns_info);
+    return 1;
+}
+
+/* decodeBatch(engine, units:Uint8Array(64*n), coeffs:Int16Array|Float32Array, meta:Uint16Array|null, pcm:Float32Array
+ *             [, tns:Uint8Array(424*m)]) */
 static napi_value js_decode_batch(napi_env env, napi_callback_info info)
 {
-    size_t argc = 5; napi_value argv[5];
+    size_t argc = 6; napi_value argv[6];
     CHECK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    void* dt; size_t nt;
+    if (!optional_tns(env, argc, argv, 5, &dt, &nt)) return NULL;
     aacg_engine* e = engine_of(env, argv[0]);
     if (!e) return NULL;
     napi_typedarray_type tu, tc, tm, tp; size_t nu, nc, nm = 0, np; void *du, *dc, *dm = NULL, *dp;
@@ -142,8 +167,9 @@ static napi_value js_decode_batch(napi_env env, napi_callback_info info)
     }
     if (!typed(env, argv[4], &tp, &np, &dp) || tp != napi_float32_array) {
         napi_throw_type_error(env, NULL, "pcm must be a Float32Array"); return NULL; }
-    int rc = L.decode_batch(e, (const aacg_unit_desc*)du, (uint32_t)(nu / sizeof(aacg_unit_desc)), dc, (uint32_t)(nc / 1024),
-                            (const aacg_band_meta*)dm, (uint32_t)(nm / AACG_MAX_SECTIONS), (float*)dp, np);
+    int rc = L.decode_batch_tns(e, (const aacg_unit_desc*)du, (uint32_t)(nu / sizeof(aacg_unit_desc)), dc, (uint32_t)(nc / 1024),
+                                (const aacg_band_meta*)dm, (uint32_t)(nm / AACG_MAX_SECTIONS),
+                                (const aacg_tns_info*)dt, (uint32_t)nt, (float*)dp, np);
     if (rc) return fail(env, e, rc, "aacg_decode_batch");
     return argv[4];
 }
@@ -184,7 +210,8 @@ static napi_value js_set_overlap(napi_env env, napi_callback_info info) { return
 typedef struct {
     napi_async_work work;
     napi_deferred deferred;
-    napi_ref refs[4];            /* units, coeffs, meta, pcm stay alive until completion */
+    napi_ref refs[5];            /* units, coeffs, meta, pcm, tns stay alive until completion */
+    const aacg_tns_info* tns; uint32_t n_tns;
     aacg_engine* e;
     const aacg_unit_desc* units; uint32_t n_units;
     const void* coeffs; uint32_t n_blocks;
@@ -199,7 +226,8 @@ static void job_execute(napi_env env, void* data)
     (void)env;
     async_job* j = (async_job*)data;
     uint64_t t = 0;
-    j->rc = L.submit(j->e, j->units, j->n_units, j->coeffs, j->n_blocks, j->meta, j->n_meta, j->pcm, j->n_pcm, &t);
+    j->rc = L.submit_tns(j->e, j->units, j->n_units, j->coeffs, j->n_blocks, j->meta, j->n_meta, j->tns, j->n_tns,
+                         j->pcm, j->n_pcm, &t);
     if (!j->rc) j->rc = L.wait(j->e, t);
     if (j->rc) snprintf(j->err, sizeof j->err, "aacgpu: decodeBatchAsync failed (%d): %.400s", j->rc, L.last_error(j->e));
 }
@@ -217,15 +245,17 @@ static void job_complete(napi_env env, napi_status status, void* data)
         napi_create_error(env, NULL, msg, &v);
         napi_reject_deferred(env, j->deferred, v);
     }
-    for (int i = 0; i < 4; i++) if (j->refs[i]) napi_delete_reference(env, j->refs[i]);
+    for (int i = 0; i < 5; i++) if (j->refs[i]) napi_delete_reference(env, j->refs[i]);
     napi_delete_async_work(env, j->work);
     free(j);
 }
 
 static napi_value js_decode_batch_async(napi_env env, napi_callback_info info)
 {
-    size_t argc = 5; napi_value argv[5], promise, name;
+    size_t argc = 6; napi_value argv[6], promise, name;
     CHECK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    void* dt; size_t nt;
+    if (!optional_tns(env, argc, argv, 5, &dt, &nt)) return NULL;
     aacg_engine* e = engine_of(env, argv[0]);
     if (!e) return NULL;
     napi_typedarray_type tu, tc, tm, tp; size_t nu, nc, nm = 0, np; void *du, *dc, *dm = NULL, *dp;
@@ -247,6 +277,8 @@ static napi_value js_decode_batch_async(napi_env env, napi_callback_info info)
     j->e = e; j->units = (const aacg_unit_desc*)du; j->n_units = (uint32_t)(nu / sizeof(aacg_unit_desc));
     j->coeffs = dc; j->n_blocks = (uint32_t)(nc / 1024); j->meta = (const aacg_band_meta*)dm; j->n_meta = (uint32_t)(nm / AACG_MAX_SECTIONS);
     j->pcm = (float*)dp; j->n_pcm = np;
+    j->tns = (const aacg_tns_info*)dt; j->n_tns = (uint32_t)nt;
+    if (dt) napi_create_reference(env, argv[5], 1, &j->refs[4]);
     const int idx[4] = {1, 2, 3, 4};
     for (int i = 0; i < 4; i++)
         if (!(i == 2 && !dm)) napi_create_reference(env, argv[idx[i]], 1, &j->refs[i]);

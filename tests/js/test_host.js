@@ -43,6 +43,30 @@ assert.strictEqual(host.packBandWord(15, 200, false, true), (15 << 12) | 0x400 |
     assert.strictEqual(dec.format.channelsPerFrame, 2);
     assert.throws(() => dec.setCookie(new Uint8Array([(5 << 3) | 1, 0x90])), /not supported/);
 }
+// TNS side info: aacg_tns_info layout (include/aacgpu.h): n_filt[8], then 8 x {length, order, direction, pad, coef[12]}
+const tnsLong = { short: false, nFilt: [2], length: [[20, 9]], order: [[3, 1]], direction: [[false, true]],
+                  coef: [[new Float32Array([0.5, -0.25, 0.125]), new Float32Array([-0.4338837])]] };
+{
+    const tnsShort = { short: true, nFilt: [0, 1, 0, 0, 0, 0, 0, 1], length: [[], [7], [], [], [], [], [], [5]], order: [[], [2], [], [], [], [], [], [0]],
+                       direction: [[], [true], [], [], [], [], [], [false]], coef: [[], [new Float32Array([0.25, 0.75])], [], [], [], [], [], [new Float32Array(0)]] };
+    const bytes = host.packTns([tnsLong, null, tnsShort]);
+    assert.strictEqual(bytes.length, 3 * host.TNS_BYTES);
+    const v = new DataView(bytes.buffer);
+    assert.deepStrictEqual([v.getUint8(0), v.getUint8(8), v.getUint8(9), v.getUint8(10), v.getUint8(60), v.getUint8(61), v.getUint8(62)],
+                           [2, 20, 3, 0, 9, 1, 1]);
+    assert.strictEqual(v.getFloat32(12 + 4, true), -0.25);
+    assert.strictEqual(v.getFloat32(64, true), Math.fround(-0.4338837));
+    for (let i = host.TNS_BYTES; i < 2 * host.TNS_BYTES; i++) assert.strictEqual(bytes[i], 0);       // channel without TNS
+    const o = 2 * host.TNS_BYTES;
+    assert.deepStrictEqual([v.getUint8(o + 1), v.getUint8(o + 7), v.getUint8(o + 8 + 52), v.getUint8(o + 8 + 52 + 1), v.getUint8(o + 8 + 52 + 2)], [1, 1, 7, 2, 1]);
+    assert.strictEqual(v.getFloat32(o + 8 + 52 + 8, true), 0.75);
+    assert.throws(() => host.packTns([{ short: false, nFilt: [1], length: [[1]], order: [[13]], direction: [[0]], coef: [[new Float32Array(13)]] }]), /out of range/);
+    // unit records carry the flag and the record index
+    const u = host.unpackUnits(g['scn_stereo.units'])[0];
+    u.ch[1].tns = tnsLong; u.tnsOffset = 6;
+    const ub = host.packUnits([u]);
+    assert.deepStrictEqual([ub[24 + 5], ub[40 + 5], new DataView(ub.buffer).getUint32(56, true)], [0, 1, 6]);
+}
 console.log('host cpu tests ok');
 if (mode !== 'gpu') process.exit(0);
 
@@ -82,6 +106,23 @@ for (const name of ['scn_stereo', 'scn_7ch']) {
     console.log('readChunk x18 worst frame rms', worst.toExponential(3));
     // error convention: a bad batch throws, like the reference's throw new Error(...)
     assert.throws(() => dec.engine.decodeBatch(g[name + '.units'], new Int16Array(1024), g[name + '.meta'], new Float32Array(2048)), /aacgpu/);
+}
+{
+    // TNS_SPEC engine: side info reaches the kernels; a TNS_REFERENCE engine ignores it (numerical parity: tests/test_tns_spec.py)
+    const name = 'scn_stereo', ref = g[name + '.pcm'], units = host.unpackUnits(g[name + '.units']);
+    const list = [];
+    units.forEach(function (u, i) {
+        if (u.ch[0].windowSequence === 2) return;
+        u.ch[0].tns = tnsLong; u.tnsOffset = list.length; list.push(tnsLong, null);
+    });
+    const ub = host.packUnits(units), tb = host.packTns(list);
+    const plain = new host.Engine({ maxStreams: 1, maxChannels: 2 }), a = new Float32Array(ref.length);
+    plain.decodeBatch(ub, g[name + '.q'], g[name + '.meta'], a, tb);
+    assert.ok(rms(a, ref) < 1e-5, 'TNS_REFERENCE engine must ignore TNS side info');
+    const spec = new host.Engine({ maxStreams: 1, maxChannels: 2, tnsMode: host.TNS_SPEC }), b = new Float32Array(ref.length);
+    spec.decodeBatch(ub, g[name + '.q'], g[name + '.meta'], b, tb);
+    assert.ok(b.every(Number.isFinite) && rms(b, ref) > 1e-4, 'TNS_SPEC engine must apply the filters');
+    console.log('tns side info ok, rms vs identity', rms(b, ref).toExponential(3));
 }
 (async function () {
     // decodeBatchAsync: the event loop stays free while the GPU decodes (a timer fires before the promise resolves or right after)
