@@ -652,10 +652,17 @@ DP_DEVICE void short_pair(const float* tab, const chan_par& cp, float* slot, dpv
 /* spectral reconstruction: dequant (ics.js:222-227,244-256), MS (decoder.js:379-404),       */
 /* IS (decoder.js:337-376) in natural order: lane l owns coefficients 8 l + 512 i + 0..7     */
 /* ------------------------------------------------------------------------------------ */
-#define AACG_BF_MS      0x010         /* band flags kept in LDS: bits 0..3 band type, bit 4 ms_used */
-
-/* Per-wave band table in LDS (in the work area, before the spectrum is staged):
- * scale[c][128] f32 at bt + 0 / + 128, flags[c][128] i32 at bt + 256 / + 384. */
+/* Per-wave band records in LDS (in the work area, before the spectrum is staged): for channel c and band
+ * index b = g * maxSFB + sfb (ics.js:217) two words at bt + 256 c + 2 b:
+ *   val   = the band's scale (sf, sign applied) if the band carries coefficients; the intensity scale
+ *           +-sf (decoder.js:353-368) on an intensity band of the right channel; else 0
+ *   flags = bit 31: the band carries coefficients (band type 1..12);  bit 0: left channel: MS applies to
+ *           this band (decoder.js:295-296,393); right channel: intensity band
+ * Everything that depends only on the band is decided here once (two bands per lane) instead of once per
+ * coefficient group.  Record 127 is the "no band" record (sfb >= maxSFB): dead, no MS, no IS. */
+#define AACG_BR_LIVE    0x80000000u
+#define AACG_BR_FLAG    0x00000001u
+#define AACG_BR_NONE    127
 struct quant_regs { dpi4 ql[2], qr[2]; unsigned mw[2][2]; };
 
 /* the unit's quantised spectra (16 bytes per lane per load) and raw band words, issued early */
@@ -678,60 +685,88 @@ DP_DEVICE void quant_load(const aacg_kparams& P, const unit_view& u, int n_ch, q
     r.mw[1][0] = m1->band[lane];   r.mw[1][1] = m1->band[b1];
 }
 
-DP_DEVICE void prepare_bands(const float* tab, const quant_regs& r, int n_ch, float* bt)
+DP_DEVICE void prepare_bands(const float* tab, const quant_regs& r, bool two, bool ms_on, bool mask, float* bt)
 {
     const int lane = dp_lane();
+    unsigned* bw = (unsigned*)bt;
 #pragma unroll
-    for (int c = 0; c < 2; c++) {
-        if (c < n_ch) {
-#pragma unroll
-            for (int h = 0; h < 2; h++) {
-                const int b = lane + 64 * h;
-                if (b < AACG_MAX_SECTIONS) {
-                    const unsigned wd = r.mw[c][h];
-                    float sf = tab[AACG_TAB_OFF_SF + (wd & AACG_META_SF_MASK)];
-                    if (wd & AACG_META_NEGATE) sf = -sf;
-                    bt[c * 128 + b] = sf;
-                    ((int*)bt)[256 + c * 128 + b] = (int)(wd >> AACG_META_BT_SHIFT) | ((wd & AACG_META_MS_USED) ? AACG_BF_MS : 0);
-                }
-            }
-        }
+    for (int h = 0; h < 2; h++) {
+        const int b = lane + 64 * h;
+        const bool coded = b < AACG_MAX_SECTIONS;      /* the rest (incl. AACG_BR_NONE) are empty records */
+        const unsigned wl = r.mw[0][h], wr = r.mw[1][h];
+        const int tl = (int)(wl >> AACG_META_BT_SHIFT), tr = (int)(wr >> AACG_META_BT_SHIFT);
+        float sl = tab[AACG_TAB_OFF_SF + (wl & AACG_META_SF_MASK)];
+        float sr = tab[AACG_TAB_OFF_SF + (wr & AACG_META_SF_MASK)];
+        if (wl & AACG_META_NEGATE) sl = -sl;
+        if (wr & AACG_META_NEGATE) sr = -sr;
+        const bool live_l = coded && tl != AACG_ZERO_BT && tl < AACG_NOISE_BT;
+        const bool live_r = coded && two && tr != AACG_ZERO_BT && tr < AACG_NOISE_BT;
+        /* decoder.js:295-296,393: MS needs commonWindow && maskPresent && ms_used[idx] && both band types < NOISE */
+        const bool ms = coded && ms_on && (wl & AACG_META_MS_USED) && tl < AACG_NOISE_BT && tr < AACG_NOISE_BT;
+        /* decoder.js:353-368: right = left * (c * sf) on the right channel's intensity bands; c = -1 for
+         * INTENSITY_BT2, flipped again where the mask is present and ms_used is set */
+        const bool is = coded && two && tr >= AACG_INTENSITY_BT2;
+        bool neg = tr == AACG_INTENSITY_BT2;
+        if (mask && (wl & AACG_META_MS_USED)) neg = !neg;
+        dpf2 rl, rr;
+        rl.x = live_l ? sl : 0.0f;
+        rl.y = __builtin_bit_cast(float, (live_l ? AACG_BR_LIVE : 0u) | (ms ? AACG_BR_FLAG : 0u));
+        rr.x = live_r ? sr : (is ? (neg ? -sr : sr) : 0.0f);
+        rr.y = __builtin_bit_cast(float, (live_r ? AACG_BR_LIVE : 0u) | (is ? AACG_BR_FLAG : 0u));
+        *(dpf2*)(bw + 2 * b) = rl;
+        *(dpf2*)(bw + 256 + 2 * b) = rr;
     }
 }
 
 struct chan_ctx {
     int cls;            /* 1 = EIGHT_SHORT */
     int max_sfb;
-    unsigned gmap;      /* 4 bits per window: its group (planner-filled, aacg_unit_desc.reserved1) */
+    unsigned gmap;      /* 4 bits per window: its group (planner-filled) */
 };
 
-/* index g*maxSFB + sfb of the band holding array position pos (ics.js:217); -1 if sfb >= maxSFB */
-DP_DEVICE int band_index(const float* tab, const chan_ctx& cc, int pos)
+/* Band record indices of the four 4-coefficient groups a lane owns (k = 2 i + h: positions
+ * 8 lane + 512 i + 4 h): the band maps hold one byte per coefficient, so one 8-byte read covers the two
+ * groups of an i.  AACG_BR_NONE if sfb >= maxSFB. */
+DP_DEVICE void band_indices(const float* tab, const chan_ctx& cc, int (&idx)[4])
 {
-    const unsigned char* bl = (const unsigned char*)(tab + AACG_TAB_OFF_BAND_LONG);
-    const unsigned char* bs = (const unsigned char*)(tab + AACG_TAB_OFF_BAND_SHORT);
-    int sfb, g = 0;
-    if (cc.cls) { sfb = bs[pos & 127]; g = (int)((cc.gmap >> (4 * (pos >> 7))) & 15u); }
-    else        { sfb = bl[pos]; }
-    return sfb < cc.max_sfb ? g * cc.max_sfb + sfb : -1;
-}
-
-/* sign(q) |q|^(4/3) sf for four coefficients packed as two dwords of int16 pairs, branch-free: one
- * LDS lookup in the signed table (q = -512..511) per coefficient; `oor` collects q + 512 so that the
- * caller can detect and patch the rare larger magnitudes afterwards.  q == 0 gives -0 like ics.js:251;
- * an uncoded, ZERO or INTENSITY band gives +0 (ics.js:222-227). */
-DP_DEVICE void dequant4(const float* tab, bool live, float sf, int p01, int p23, float (&x)[4], int& oor)
-{
-    const int q[4] = {(int)(short)(p01 & 0xffff), p01 >> 16, (int)(short)(p23 & 0xffff), p23 >> 16};
+    const int lane = dp_lane();
+    if (cc.cls) {
+        /* pos & 127 does not depend on i; window = pos >> 7 = lane / 16 + 4 i */
+        const dpf2 m = *(const dpf2*)((const unsigned char*)(tab + AACG_TAB_OFF_BAND_SHORT) + ((8 * lane) & 127));
+        const int s0 = (int)(__builtin_bit_cast(unsigned, m.x) & 0xffu), s1 = (int)(__builtin_bit_cast(unsigned, m.y) & 0xffu);
 #pragma unroll
-    for (int e = 0; e < 4; e++) {
-        const int t = q[e] + 512;
-        oor |= t;
-        const int idx = t < 0 ? 0 : (t > 1023 ? 1023 : t);
-        const float v = tab[AACG_TAB_OFF_IQ_SMALL + idx];
-        x[e] = live ? v * sf : 0.0f;
+        for (int i = 0; i < 2; i++) {
+            const int g = (int)((cc.gmap >> (4 * ((lane >> 4) + 4 * i))) & 15u);
+            idx[2 * i]     = s0 < cc.max_sfb ? g * cc.max_sfb + s0 : AACG_BR_NONE;
+            idx[2 * i + 1] = s1 < cc.max_sfb ? g * cc.max_sfb + s1 : AACG_BR_NONE;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const dpf2 m = *(const dpf2*)((const unsigned char*)(tab + AACG_TAB_OFF_BAND_LONG) + 8 * lane + 512 * i);
+            const int s0 = (int)(__builtin_bit_cast(unsigned, m.x) & 0xffu), s1 = (int)(__builtin_bit_cast(unsigned, m.y) & 0xffu);
+            idx[2 * i]     = s0 < cc.max_sfb ? s0 : AACG_BR_NONE;
+            idx[2 * i + 1] = s1 < cc.max_sfb ? s1 : AACG_BR_NONE;
+        }
     }
 }
+
+/* sign(q) |q|^(4/3) sf for four coefficients packed as two dwords of int16 pairs, branch-free and without
+ * unpacking: v_mad_i32_i16 turns each half straight into the LDS byte address of its entry in the signed
+ * table (q = -512..511, `iq0` = address of the q = 0 entry), one fused multiply-add applies the scalefactor.
+ *   live band:  x = IQ[q] * sf + (-0)   (q == 0 gives -0 like ics.js:251: the table holds -0 there)
+ *   dead band:  x = IQ[q] * 0  + (+0) = +0   (uncoded, ZERO or INTENSITY band, ics.js:222-227)
+ * Larger magnitudes read some other LDS word (or 0 outside the allocation); `oor` collects the packed
+ * q + 512 so that the caller can detect them afterwards and patch those elements (dequant4_big). */
+DP_DEVICE void dequant4(int iq0, float sf_eff, float z_eff, int p01, int p23, float (&x)[4], int& oor)
+{
+    oor |= dp_pk_add_u16(p01, 0x02000200) | dp_pk_add_u16(p23, 0x02000200);
+    x[0] = dp_fma(dp_lds_read_f32(dp_mad4_i16_lo(p01, iq0)), sf_eff, z_eff);
+    x[1] = dp_fma(dp_lds_read_f32(dp_mad4_i16_hi(p01, iq0)), sf_eff, z_eff);
+    x[2] = dp_fma(dp_lds_read_f32(dp_mad4_i16_lo(p23, iq0)), sf_eff, z_eff);
+    x[3] = dp_fma(dp_lds_read_f32(dp_mad4_i16_hi(p23, iq0)), sf_eff, z_eff);
+}
+#define AACG_OOR_MASK ((int)0xFC00FC00)                /* some q + 512 outside 0..1023 */
 
 /* the rare magnitudes outside the LDS table: full IQ_TABLE in global memory; [8191] = NaN like the JS
  * out-of-range read */
@@ -741,9 +776,9 @@ DP_DEVICE void dequant4_big(const aacg_tables* T, bool live, float sf, int p01, 
 #pragma unroll
     for (int e = 0; e < 4; e++) {
         const int a = q[e] < 0 ? -q[e] : q[e];
-        if (live && ((q[e] + 512) & ~1023)) {
+        if ((q[e] + 512) & ~1023) {
             const float v = T->iq[a > 8191 ? 8191 : a];
-            x[e] = (q[e] > 0 ? v : -v) * sf;
+            x[e] = live ? (q[e] > 0 ? v : -v) * sf : 0.0f;
         }
     }
 }
@@ -753,58 +788,50 @@ DP_DEVICE void dequant4_big(const aacg_tables* T, bool live, float sf, int p01, 
 DP_DEVICE void spectral_quant(const aacg_kparams& P, const float* tab, const unit_view& u, int n_ch,
                               const quant_regs& qreg, float* bt, float (&xl)[16], float (&xr)[16])
 {
-    const int lane = dp_lane();
     chan_ctx ccL, ccR;
     ccL.cls = u.seq[0] == AACG_EIGHT_SHORT_SEQUENCE; ccL.max_sfb = u.max_sfb[0]; ccL.gmap = u.gmap[0];
     ccR.cls = u.seq[1] == AACG_EIGHT_SHORT_SEQUENCE; ccR.max_sfb = u.max_sfb[1]; ccR.gmap = u.gmap[1];
 
     const dpi4 (&ql)[2] = qreg.ql;
     const dpi4 (&qr)[2] = qreg.qr;
-    prepare_bands(tab, qreg, n_ch, bt);
-    dp_wave_sync();
-
     const bool two = n_ch == 2;
     const bool ms_on = two && (u.flags & AACG_UNIT_COMMON_WINDOW) && (u.flags & AACG_UNIT_MASK_PRESENT);
     const bool mask  = (u.flags & AACG_UNIT_MASK_PRESENT) != 0;
-    const int* bf = (const int*)bt + 256;
+    prepare_bands(tab, qreg, two, ms_on, mask, bt);
+    int idxL[4], idxR[4];
+    band_indices(tab, ccL, idxL);
+    band_indices(tab, ccR, idxR);
+    dp_wave_sync();
 
-    /* per 4-coefficient group (bands are multiples of 4 wide): what MS / IS need later */
-    bool  g_ms[4], g_is[4];
-    float g_isc[4];
-    bool  liveL[4], liveR[4];
-    float sfL[4], sfR[4];
+    /* per 4-coefficient group (bands are multiples of 4 wide): the band records of both channels, all loads
+     * unconditional and independent of each other */
+    dpf2 recL[4], recR[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        recL[k] = *(const dpf2*)(bt + 2 * idxL[k]);
+        recR[k] = *(const dpf2*)(bt + 256 + 2 * idxR[k]);
+    }
+    bool  g_ms[4], g_is[4], liveL[4], liveR[4];
+    float g_isc[4], sfL[4], sfR[4];
     int big = 0;
+    const int iq0 = dp_lds_addr(tab + AACG_TAB_OFF_IQ_SMALL + 512);
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const int i = k >> 1, h = k & 1;
-        const int pos = 8 * lane + 512 * i + 4 * h;
-        const int idxL = band_index(tab, ccL, pos);
-        const int iL = idxL < 0 ? 0 : idxL;
-        const int fL = bf[iL];
-        const int btL = fL & 15;
-        liveL[k] = idxL >= 0 && btL != AACG_ZERO_BT && btL < AACG_NOISE_BT;
-        sfL[k] = bt[iL];
-        dequant4(tab, liveL[k], sfL[k], h ? ql[i].z : ql[i].x, h ? ql[i].w : ql[i].y, *(float (*)[4])&xl[4 * k], big);
-
-        const int idxR = band_index(tab, ccR, pos);
-        const int iR = idxR < 0 ? 0 : idxR;
-        const int fR = bf[128 + iR];
-        const int btR = fR & 15;
-        liveR[k] = two && idxR >= 0 && btR != AACG_ZERO_BT && btR < AACG_NOISE_BT;
-        sfR[k] = bt[128 + iR];
-        dequant4(tab, liveR[k], sfR[k], h ? qr[i].z : qr[i].x, h ? qr[i].w : qr[i].y, *(float (*)[4])&xr[4 * k], big);
-
-        /* decoder.js:295-296,393: MS needs commonWindow && maskPresent && ms_used[idx] && both band types < NOISE
-         * (idx on the left channel's grid; with a common window it is the right channel's too) */
-        g_ms[k] = ms_on && idxL >= 0 && (fL & AACG_BF_MS) && btL < AACG_NOISE_BT && (bf[128 + iL] & 15) < AACG_NOISE_BT;
-        /* decoder.js:353-368: right = left * (c * sfR) on the right channel's intensity bands */
-        g_is[k] = two && idxR >= 0 && btR >= AACG_INTENSITY_BT2;
-        bool neg = btR == AACG_INTENSITY_BT2;
-        if (mask && (bf[iR] & AACG_BF_MS)) neg = !neg;
-        g_isc[k] = neg ? -sfR[k] : sfR[k];
+        const unsigned fl = __builtin_bit_cast(unsigned, recL[k].y), fr = __builtin_bit_cast(unsigned, recR[k].y);
+        g_ms[k] = (fl & AACG_BR_FLAG) != 0;
+        g_is[k] = (fr & AACG_BR_FLAG) != 0;
+        liveL[k] = (fl & AACG_BR_LIVE) != 0;
+        liveR[k] = (fr & AACG_BR_LIVE) != 0;
+        sfL[k] = recL[k].x;
+        g_isc[k] = recR[k].x;
+        sfR[k] = g_is[k] ? 0.0f : recR[k].x;
+        /* the addend is -0 on a band that carries coefficients, +0 elsewhere: the flag's sign bit */
+        dequant4(iq0, sfL[k], __builtin_bit_cast(float, fl & AACG_BR_LIVE), h ? ql[i].z : ql[i].x, h ? ql[i].w : ql[i].y, *(float (*)[4])&xl[4 * k], big);
+        dequant4(iq0, sfR[k], __builtin_bit_cast(float, fr & AACG_BR_LIVE), h ? qr[i].z : qr[i].x, h ? qr[i].w : qr[i].y, *(float (*)[4])&xr[4 * k], big);
     }
 
-    if (dp_any((big & ~1023) != 0)) {                  /* escape-coded magnitudes: rare */
+    if (dp_any((big & AACG_OOR_MASK) != 0)) {          /* escape-coded magnitudes: rare */
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const int i = k >> 1, h = k & 1;
@@ -814,17 +841,27 @@ DP_DEVICE void spectral_quant(const aacg_kparams& P, const float* tab, const uni
     }
 
     if (two) {
+        /* wave-uniform skips: most frames carry no intensity bands, many no MS */
+        if (dp_any(g_ms[0] || g_ms[1] || g_ms[2] || g_ms[3])) {
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
+            for (int k = 0; k < 4; k++) {
 #pragma unroll
-            for (int e = 0; e < 4; e++) {
-                float a = xl[4 * k + e], b = xr[4 * k + e];
-                const float sum = a + b, dif = a - b;
-                a = g_ms[k] ? sum : a;
-                b = g_ms[k] ? dif : b;
-                const float is = a * g_isc[k];
-                b = g_is[k] ? is : b;
-                xl[4 * k + e] = a; xr[4 * k + e] = b;
+                for (int e = 0; e < 4; e++) {
+                    const float a = xl[4 * k + e], b = xr[4 * k + e];
+                    const float sum = a + b, dif = a - b;
+                    xl[4 * k + e] = g_ms[k] ? sum : a;
+                    xr[4 * k + e] = g_ms[k] ? dif : b;
+                }
+            }
+        }
+        if (dp_any(g_is[0] || g_is[1] || g_is[2] || g_is[3])) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const float is = xl[4 * k + e] * g_isc[k];
+                    xr[4 * k + e] = g_is[k] ? is : xr[4 * k + e];
+                }
             }
         }
     }

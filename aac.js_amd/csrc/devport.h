@@ -88,6 +88,18 @@ DP_DEVICE void dp_shfl(double (&v)[N], int src)
 extern __shared__ __attribute__((aligned(16))) unsigned char dp_lds_raw[];
 DP_DEVICE unsigned char* dp_lds() { return dp_lds_raw; }
 
+/* LDS byte addresses as integers (table gathers): ds_read_b32 on a computed address.  A read outside the
+ * workgroup's allocation returns 0 (the LDS has no fault path). */
+DP_DEVICE int dp_lds_addr(const void* p) { return (int)(uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)p; }
+DP_DEVICE float dp_lds_read_f32(int a) { return *(__attribute__((address_space(3))) const float*)(uintptr_t)(uint32_t)a; }
+/* (int16 half of p) * 4 + add in one VALU instruction: sign extension, scaling and the table base at once */
+DP_DEVICE int dp_mad4_i16_lo(int p, int add) { int r; asm("v_mad_i32_i16 %0, %1, 4, %2" : "=v"(r) : "v"(p), "s"(add)); return r; }
+DP_DEVICE int dp_mad4_i16_hi(int p, int add) { int r; asm("v_mad_i32_i16 %0, %1, 4, %2 op_sel:[1,0,0,0]" : "=v"(r) : "v"(p), "s"(add)); return r; }
+typedef unsigned short dp_u16x2 __attribute__((ext_vector_type(2)));
+DP_DEVICE int dp_pk_add_u16(int a, int b)
+{
+    return __builtin_bit_cast(int, (dp_u16x2)(__builtin_bit_cast(dp_u16x2, a) + __builtin_bit_cast(dp_u16x2, b)));
+}
 DP_DEVICE float dp_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 DP_DEVICE double dp_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
 /* true in every lane if the predicate holds in any lane of the wave */

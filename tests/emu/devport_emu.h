@@ -16,6 +16,7 @@
 #include <pthread.h>
 #include <sched.h>
 #include <stdint.h>
+#include <string.h>
 #include <stddef.h>
 
 #define DP_DEVICE static inline
@@ -35,6 +36,7 @@ struct emu_wave {
 struct emu_block {
     pthread_barrier_t bar;
     unsigned char* lds;
+    size_t lds_bytes;
     int block_id;
 };
 struct emu_lane_ctx {
@@ -88,6 +90,21 @@ DP_DEVICE bool dp_any(bool p)
 }
 
 DP_DEVICE unsigned char* dp_lds() { return g_emu.b->lds; }
+/* LDS byte addresses as integers (table gathers); a read outside the workgroup's allocation returns 0 */
+DP_DEVICE int dp_lds_addr(const void* p) { return (int)((const unsigned char*)p - g_emu.b->lds); }
+DP_DEVICE float dp_lds_read_f32(int a)
+{
+    if (a < 0 || (size_t)a + 4 > g_emu.b->lds_bytes) return 0.0f;
+    float v; memcpy(&v, g_emu.b->lds + a, 4); return v;
+}
+/* (int16 half of p) * 4 + add */
+DP_DEVICE int dp_mad4_i16_lo(int p, int add) { return (int)(short)(p & 0xffff) * 4 + add; }
+DP_DEVICE int dp_mad4_i16_hi(int p, int add) { return (p >> 16) * 4 + add; }
+DP_DEVICE int dp_pk_add_u16(int a, int b)
+{
+    const unsigned lo = ((unsigned)a + (unsigned)b) & 0xffffu, hi = (((unsigned)a >> 16) + ((unsigned)b >> 16)) & 0xffffu;
+    return (int)(lo | (hi << 16));
+}
 DP_DEVICE float dp_fma(float a, float b, float c) { return fmaf(a, b, c); }
 DP_DEVICE double dp_fma(double a, double b, double c) { return fma(a, b, c); }
 DP_DEVICE void dp_store_nt(dpf4* p, dpf4 v) { *p = v; }

@@ -44,6 +44,7 @@ void launch(const aacg_kparams& P, int kind, int grid, int waves, size_t lds_byt
     for (int b = 0; b < grid; b++) {
         emu_block blk;
         blk.lds = lds;
+        blk.lds_bytes = lds_bytes;
         blk.block_id = b;
         std::memset(lds, 0xff, lds_bytes);             /* NaN pattern: reads of unwritten LDS show up */
         pthread_barrier_init(&blk.bar, nullptr, (unsigned)threads);
