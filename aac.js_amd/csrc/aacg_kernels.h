@@ -171,7 +171,9 @@ DP_DEVICE dpf2 tail_window(const float* tab, int seq, int shape, int n)
  * (LONG_STOP first 448 samples, LONG_START last 448): the reference copies / zeroes there instead of
  * multiplying (filter_bank.js:129-139,185-188), so a NaN or Inf in the spectrum must not leak through.
  * Real window samples are never 0, so the test is exact; `guard` is wave-uniform (only START / STOP). */
-DP_DEVICE float wmul(float x, float w, bool guard) { return (guard && w == 0.0f) ? 0.0f : x * w; }
+/* The products are formed unconditionally; the fix-up sits behind a wave-uniform branch that only START / STOP
+ * frames take (dp_keep_branch() stops the compiler from turning it back into per-element selects). */
+DP_DEVICE void wfix(float& r, float w) { r = (w == 0.0f) ? 0.0f : r; }
 
 /* ------------------------------------------------------------------------------------ */
 /* LDS transposes between radix-8 stages: 512 complex per channel, XOR-swizzled so that the   */
@@ -281,21 +283,29 @@ DP_DEVICE void long_channels(const float* tab, const chan_par (&cp)[NC], bool wa
                 const dpf2 w0 = head_window(tab, cp[c].seq, cp[c].shape_prev, n);
                 const dpf2 w1 = head_window(tab, cp[c].seq, cp[c].shape_prev, n + 512);
                 const bool gh = cp[c].seq == AACG_LONG_STOP_SEQUENCE;
-                hx[c][j]     = wmul(I[c][j + 4], w0.x, gh);    /* y[2k]        =  im[N/8 + k]     */
-                hy[c][j]     = wmul(-m[3 - j], w0.y, gh);      /* y[2k+1]      = -re[N/8 - 1 - k] */
-                hx[c][j + 4] = wmul(R[c][j], w1.x, gh);        /* y[N/4+2k]    =  re[k]           */
-                hy[c][j + 4] = wmul(-m[8 + 7 - j], w1.y, gh);  /* y[N/4+2k+1]  = -im[N/4 - 1 - k] */
+                hx[c][j]     = I[c][j + 4] * w0.x;             /* y[2k]        =  im[N/8 + k]     */
+                hy[c][j]     = -m[3 - j] * w0.y;               /* y[2k+1]      = -re[N/8 - 1 - k] */
+                hx[c][j + 4] = R[c][j] * w1.x;                 /* y[N/4+2k]    =  re[k]           */
+                hy[c][j + 4] = -m[8 + 7 - j] * w1.y;           /* y[N/4+2k+1]  = -im[N/4 - 1 - k] */
+                if (gh) {
+                    dp_keep_branch();
+                    wfix(hx[c][j], w0.x); wfix(hy[c][j], w0.y); wfix(hx[c][j + 4], w1.x); wfix(hy[c][j + 4], w1.y);
+                }
             }
             const dpf2 v0 = tail_window(tab, cp[c].seq, cp[c].shape, n);
             const dpf2 v1 = tail_window(tab, cp[c].seq, cp[c].shape, n + 512);
-            dpf2 t;
+            dpf2 t, t2;
             const bool gt = cp[c].seq == AACG_LONG_START_SEQUENCE;
-            t.x = wmul(R[c][j + 4], v0.x, gt);        /* y[N/2+2k]    =  re[N/8 + k]     */
-            t.y = wmul(-m[8 + 3 - j], v0.y, gt);      /* y[N/2+2k+1]  = -im[N/8 - 1 - k] */
+            t.x = R[c][j + 4] * v0.x;                 /* y[N/2+2k]    =  re[N/8 + k]     */
+            t.y = -m[8 + 3 - j] * v0.y;               /* y[N/2+2k+1]  = -im[N/8 - 1 - k] */
+            t2.x = -I[c][j] * v1.x;                   /* y[3N/4+2k]   = -im[k]           */
+            t2.y = m[7 - j] * v1.y;                   /* y[3N/4+2k+1] =  re[N/4 - 1 - k] */
+            if (gt) {
+                dp_keep_branch();
+                wfix(t.x, v0.x); wfix(t.y, v0.y); wfix(t2.x, v1.x); wfix(t2.y, v1.y);
+            }
             *(dpf2*)(area[c] + n) = t;
-            t.x = wmul(-I[c][j], v1.x, gt);           /* y[3N/4+2k]   = -im[k]           */
-            t.y = wmul(m[7 - j], v1.y, gt);           /* y[3N/4+2k+1] =  re[N/4 - 1 - k] */
-            *(dpf2*)(area[c] + n + 512) = t;
+            *(dpf2*)(area[c] + n + 512) = t2;
         }
     }
 }
@@ -430,7 +440,7 @@ struct cpx2 { dpv2 re, im; };
 
 DP_DEVICE dpv2 v2(float a, float b) { dpv2 r; r[0] = a; r[1] = b; return r; }
 DP_DEVICE dpv2 v2s(float s) { dpv2 r; r[0] = s; r[1] = s; return r; }
-DP_DEVICE dpv2 wmul2(dpv2 x, float w, bool guard) { return (guard && w == 0.0f) ? v2s(0.0f) : x * v2s(w); }
+DP_DEVICE void wfix2(dpv2& r, float w) { r = (w == 0.0f) ? v2s(0.0f) : r; }
 DP_DEVICE cpx2 c2_add(cpx2 a, cpx2 b) { cpx2 r; r.re = a.re + b.re; r.im = a.im + b.im; return r; }
 DP_DEVICE cpx2 c2_sub(cpx2 a, cpx2 b) { cpx2 r; r.re = a.re - b.re; r.im = a.im - b.im; return r; }
 DP_DEVICE cpx2 c2_muli(cpx2 a) { cpx2 r; r.re = -a.im; r.im = a.re; return r; }
@@ -551,15 +561,23 @@ DP_DEVICE void long_pair(const float* tab, const chan_par& cp, bool want_head, f
         if (want_head) {
             const dpf2 w0 = head_window(tab, cp.seq, cp.shape_prev, n), w1 = head_window(tab, cp.seq, cp.shape_prev, n + 512);
             const bool gh = cp.seq == AACG_LONG_STOP_SEQUENCE;
-            hx[j]     = wmul2(I[j + 4], w0.x, gh);
-            hy[j]     = wmul2(-mR[3 - j], w0.y, gh);
-            hx[j + 4] = wmul2(R[j], w1.x, gh);
-            hy[j + 4] = wmul2(-mI[7 - j], w1.y, gh);
+            hx[j]     = I[j + 4] * v2s(w0.x);
+            hy[j]     = -mR[3 - j] * v2s(w0.y);
+            hx[j + 4] = R[j] * v2s(w1.x);
+            hy[j + 4] = -mI[7 - j] * v2s(w1.y);
+            if (gh) {
+                dp_keep_branch();
+                wfix2(hx[j], w0.x); wfix2(hy[j], w0.y); wfix2(hx[j + 4], w1.x); wfix2(hy[j + 4], w1.y);
+            }
         }
         const dpf2 v0 = tail_window(tab, cp.seq, cp.shape, n), v1 = tail_window(tab, cp.seq, cp.shape, n + 512);
         const bool gt = cp.seq == AACG_LONG_START_SEQUENCE;
-        const dpv2 t0 = wmul2(R[j + 4], v0.x, gt), t1 = wmul2(-mI[3 - j], v0.y, gt);
-        const dpv2 t2 = wmul2(-I[j], v1.x, gt),    t3 = wmul2(mR[7 - j], v1.y, gt);
+        dpv2 t0 = R[j + 4] * v2s(v0.x), t1 = -mI[3 - j] * v2s(v0.y);
+        dpv2 t2 = -I[j] * v2s(v1.x),    t3 = mR[7 - j] * v2s(v1.y);
+        if (gt) {
+            dp_keep_branch();
+            wfix2(t0, v0.x); wfix2(t1, v0.y); wfix2(t2, v1.x); wfix2(t3, v1.y);
+        }
         dpf4 o;
         o.x = t0[0]; o.y = t0[1]; o.z = t1[0]; o.w = t1[1];
         *(dpf4*)(slot + 2 * n) = o;                                   /* (tailL[n], tailR[n], tailL[n+1], tailR[n+1]) */

@@ -110,10 +110,25 @@ DP_DEVICE int dp_opaque(int v) { asm volatile("" : "+v"(v)); return v; }
 /* streaming (non-temporal) 16-byte accesses: PCM is written once and never re-read by the kernel,
  * spectra are read once */
 typedef float dp_nv4 __attribute__((ext_vector_type(4)));
+#ifndef AACG_STORE_MODE
+#define AACG_STORE_MODE 0
+#endif
 DP_DEVICE void dp_store_nt(dpf4* p, dpf4 v)
 {
     dp_nv4 t; t[0] = v.x; t[1] = v.y; t[2] = v.z; t[3] = v.w;
+#if AACG_STORE_MODE == 0
     __builtin_nontemporal_store(t, (dp_nv4*)p);
+#elif AACG_STORE_MODE == 1
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(p), "v"(t) : "memory");
+#elif AACG_STORE_MODE == 2
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" :: "v"(p), "v"(t) : "memory");
+#elif AACG_STORE_MODE == 3
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(t) : "memory");
+#elif AACG_STORE_MODE == 4
+    asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" :: "v"(p), "v"(t) : "memory");
+#else
+    *(dp_nv4*)p = t;
+#endif
 }
 typedef int dp_ni4 __attribute__((ext_vector_type(4)));
 DP_DEVICE dpi4 dp_load_nt_i4(const dpi4* p)
@@ -135,6 +150,8 @@ DP_DEVICE unsigned long long dp_clock() { return wall_clock64(); }
 DP_DEVICE float dp_nan() { return __builtin_nanf(""); }
 /* keep the instruction scheduler from hoisting the next block's loads above this point
  * (bounds the number of gathers in flight, i.e. VGPR pressure) */
+/* inside a block guarded by a wave-uniform condition: keeps it a real (scalar) branch */
+DP_DEVICE void dp_keep_branch() { asm volatile(""); }
 DP_DEVICE void dp_sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 
 #endif /* AACG_EMU_BUILD */

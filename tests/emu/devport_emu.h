@@ -114,6 +114,7 @@ DP_DEVICE void dp_store2_u(float* p, float a, float b) { p[0] = a; p[1] = b; }
 DP_DEVICE unsigned long long dp_clock() { return 0; }
 DP_DEVICE float dp_nan() { return NAN; }
 DP_DEVICE int dp_opaque(int v) { return v; }
+DP_DEVICE void dp_keep_branch() {}
 DP_DEVICE void dp_sched_fence() {}
 
 #endif

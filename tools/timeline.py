@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.join(ROOT, "aac.js_amd", "python"))
 import numpy as np, torch, aacgpu, aacgpu_workload
 
 kind = sys.argv[1] if len(sys.argv) > 1 else "quant"
-S, T = 256, 16
+S, T = 256, int(os.environ.get("TL_FRAMES", "16"))
 eng = aacgpu.Engine(aacgpu.INPUT_QUANT_I16 if kind == "quant" else aacgpu.INPUT_SPEC_F32, S, 2)
 wl = aacgpu_workload.make_batch(S, T)
 plan = eng.plan(wl["units"])
@@ -22,11 +22,11 @@ for _ in range(5):
 eng.synchronize()
 raw = np.zeros(1 << 20, np.float32)
 eng._check(eng.lib.aacg_get_table(eng.handle, 100, raw.ctypes.data, raw.size))
-t = raw.view(np.uint64)[: 256 * 16 * 8].reshape(256, 16, 8).astype(np.float64) * 0.01     # 100 MHz ticks -> us
+t = raw.view(np.uint64)[: 256 * 16 * 8].reshape(256, 16, 8)[:, :T].astype(np.float64) * 0.01     # 100 MHz ticks -> us
 t0 = t[:, :, 0].min()
 names = ["start", "tables+barrier", "spectrum staged", "imdct done", "prev tail seen", "stores issued"]
 print("phase (us since first wave start): median over workgroups, by wave")
-for w in range(16):
+for w in range(min(16, T)):
     row = [np.median(t[:, w, k] - t0) for k in range(6)]
     print("wave %2d: " % w + "  ".join("%s %6.2f" % (names[k][:14], row[k]) for k in range(6)))
 print("kernel span (last stores issued - first start): %.2f us; start skew across WGs: %.2f us" % ((t[:, :, 5].max() - t0), t[:, :, 0].max() - t0))
