@@ -555,6 +555,31 @@ DP_DEVICE void long_pair(const float* tab, const chan_par& cp, bool want_head, f
     }
     shfl_pairs(R, I, 63 - l, mR, mI);
 
+    if (cp.seq == AACG_ONLY_LONG_SEQUENCE) {
+        /* the common case as straight-line code: with no branch between them the sixteen window reads are all
+         * issued behind the mirror shuffles instead of one LDS round trip each (filter_bank.js:109-116) */
+        dp_keep_branch();
+        const float* wh = tab + AACG_TAB_OFF_WIN_LONG + 1024 * cp.shape_prev;
+        const float* wt = tab + AACG_TAB_OFF_WIN_LONG + 1024 * cp.shape;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int n = 2 * l + 128 * j;
+            const dpf2 w0 = *(const dpf2*)(wh + n), w1 = *(const dpf2*)(wh + n + 512);
+            const dpf2 r0 = *(const dpf2*)(wt + 1022 - n), r1 = *(const dpf2*)(wt + 510 - n);   /* reversed: (w[1023-n-1], w[1023-n]) */
+            hx[j]     = I[j + 4] * v2s(w0.x);
+            hy[j]     = -mR[3 - j] * v2s(w0.y);
+            hx[j + 4] = R[j] * v2s(w1.x);
+            hy[j + 4] = -mI[7 - j] * v2s(w1.y);
+            const dpv2 t0 = R[j + 4] * v2s(r0.y), t1 = -mI[3 - j] * v2s(r0.x);
+            const dpv2 t2 = -I[j] * v2s(r1.y),    t3 = mR[7 - j] * v2s(r1.x);
+            dpf4 o;
+            o.x = t0[0]; o.y = t0[1]; o.z = t1[0]; o.w = t1[1];
+            *(dpf4*)(slot + 2 * n) = o;
+            o.x = t2[0]; o.y = t2[1]; o.z = t3[0]; o.w = t3[1];
+            *(dpf4*)(slot + 2 * (n + 512)) = o;
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const int n = 2 * l + 128 * j;
