@@ -556,8 +556,9 @@ DP_DEVICE void long_pair(const float* tab, const chan_par& cp, bool want_head, f
     shfl_pairs(R, I, 63 - l, mR, mI);
 
     if (cp.seq == AACG_ONLY_LONG_SEQUENCE) {
-        /* the common case as straight-line code: with no branch between them the sixteen window reads are all
-         * issued behind the mirror shuffles instead of one LDS round trip each (filter_bank.js:109-116) */
+        /* the common case as straight-line code: with no branch between them the window reads of an iteration
+         * are issued together instead of one LDS round trip each (filter_bank.js:109-116).  Reading all sixteen
+         * ahead of the first tail store was measured too: no faster, and 4 more VGPRs. */
         dp_keep_branch();
         const float* wh = tab + AACG_TAB_OFF_WIN_LONG + 1024 * cp.shape_prev;
         const float* wt = tab + AACG_TAB_OFF_WIN_LONG + 1024 * cp.shape;
@@ -565,7 +566,7 @@ DP_DEVICE void long_pair(const float* tab, const chan_par& cp, bool want_head, f
         for (int j = 0; j < 4; j++) {
             const int n = 2 * l + 128 * j;
             const dpf2 w0 = *(const dpf2*)(wh + n), w1 = *(const dpf2*)(wh + n + 512);
-            const dpf2 r0 = *(const dpf2*)(wt + 1022 - n), r1 = *(const dpf2*)(wt + 510 - n);   /* reversed: (w[1023-n-1], w[1023-n]) */
+            const dpf2 r0 = *(const dpf2*)(wt + 1022 - n), r1 = *(const dpf2*)(wt + 510 - n);   /* reversed: (w[1022-n], w[1023-n]) */
             hx[j]     = I[j + 4] * v2s(w0.x);
             hy[j]     = -mR[3 - j] * v2s(w0.y);
             hx[j + 4] = R[j] * v2s(w1.x);
@@ -728,7 +729,44 @@ DP_DEVICE void quant_load(const aacg_kparams& P, const unit_view& u, int n_ch, q
     r.mw[1][0] = m1->band[lane];   r.mw[1][1] = m1->band[b1];
 }
 
-DP_DEVICE void prepare_bands(const float* tab, const quant_regs& r, bool two, bool ms_on, bool mask, float* bt)
+struct chan_ctx {
+    int cls;            /* 1 = EIGHT_SHORT */
+    int max_sfb;
+    unsigned gmap;      /* 4 bits per window: its group (planner-filled) */
+};
+
+/* The raw band-map bytes a lane needs for its four 4-coefficient groups (k = 2 i + h: positions
+ * 8 lane + 512 i + 4 h).  The maps hold one byte per coefficient, so one 8-byte read covers the two groups of
+ * an i; both the long and the short map are read unconditionally (no branch between the loads). */
+struct band_raw { dpf2 lng[2], sht; };
+DP_DEVICE void band_raw_load(const float* tab, band_raw& r)
+{
+    const int lane = dp_lane();
+    const unsigned char* bl = (const unsigned char*)(tab + AACG_TAB_OFF_BAND_LONG);
+    const unsigned char* bs = (const unsigned char*)(tab + AACG_TAB_OFF_BAND_SHORT);
+    r.lng[0] = *(const dpf2*)(bl + 8 * lane);
+    r.lng[1] = *(const dpf2*)(bl + 8 * lane + 512);
+    r.sht = *(const dpf2*)(bs + ((8 * lane) & 127));   /* pos & 127 does not depend on i */
+}
+/* Band record indices g * maxSFB + sfb (ics.js:217); AACG_BR_NONE if sfb >= maxSFB. */
+DP_DEVICE void band_indices(const band_raw& r, const chan_ctx& cc, int (&idx)[4])
+{
+    const int lane = dp_lane();
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const dpf2 m = cc.cls ? r.sht : r.lng[i];
+        const int s0 = (int)(__builtin_bit_cast(unsigned, m.x) & 0xffu), s1 = (int)(__builtin_bit_cast(unsigned, m.y) & 0xffu);
+        /* short: window = pos >> 7 = lane / 16 + 4 i, its group from the map; long: group 0 */
+        const int g = cc.cls ? (int)((cc.gmap >> (4 * ((lane >> 4) + 4 * i))) & 15u) : 0;
+        idx[2 * i]     = s0 < cc.max_sfb ? g * cc.max_sfb + s0 : AACG_BR_NONE;
+        idx[2 * i + 1] = s1 < cc.max_sfb ? g * cc.max_sfb + s1 : AACG_BR_NONE;
+    }
+}
+
+/* Band records of both channels, two bands per lane; sl / sr: the bands' SF-table entries, loaded by the
+ * caller together with the band maps.  Bit operations instead of && / ||: no short-circuit branches. */
+DP_DEVICE void prepare_bands(const quant_regs& r, const float (&sl_in)[2], const float (&sr_in)[2],
+                             bool two, bool ms_on, bool mask, float* bt)
 {
     const int lane = dp_lane();
     unsigned* bw = (unsigned*)bt;
@@ -738,19 +776,17 @@ DP_DEVICE void prepare_bands(const float* tab, const quant_regs& r, bool two, bo
         const bool coded = b < AACG_MAX_SECTIONS;      /* the rest (incl. AACG_BR_NONE) are empty records */
         const unsigned wl = r.mw[0][h], wr = r.mw[1][h];
         const int tl = (int)(wl >> AACG_META_BT_SHIFT), tr = (int)(wr >> AACG_META_BT_SHIFT);
-        float sl = tab[AACG_TAB_OFF_SF + (wl & AACG_META_SF_MASK)];
-        float sr = tab[AACG_TAB_OFF_SF + (wr & AACG_META_SF_MASK)];
-        if (wl & AACG_META_NEGATE) sl = -sl;
-        if (wr & AACG_META_NEGATE) sr = -sr;
-        const bool live_l = coded && tl != AACG_ZERO_BT && tl < AACG_NOISE_BT;
-        const bool live_r = coded && two && tr != AACG_ZERO_BT && tr < AACG_NOISE_BT;
+        const float sl = (wl & AACG_META_NEGATE) ? -sl_in[h] : sl_in[h];
+        const float sr = (wr & AACG_META_NEGATE) ? -sr_in[h] : sr_in[h];
+        const bool ms_used = (wl & AACG_META_MS_USED) != 0;
+        const bool live_l = coded & (tl != AACG_ZERO_BT) & (tl < AACG_NOISE_BT);
+        const bool live_r = coded & two & (tr != AACG_ZERO_BT) & (tr < AACG_NOISE_BT);
         /* decoder.js:295-296,393: MS needs commonWindow && maskPresent && ms_used[idx] && both band types < NOISE */
-        const bool ms = coded && ms_on && (wl & AACG_META_MS_USED) && tl < AACG_NOISE_BT && tr < AACG_NOISE_BT;
+        const bool ms = coded & ms_on & ms_used & (tl < AACG_NOISE_BT) & (tr < AACG_NOISE_BT);
         /* decoder.js:353-368: right = left * (c * sf) on the right channel's intensity bands; c = -1 for
          * INTENSITY_BT2, flipped again where the mask is present and ms_used is set */
-        const bool is = coded && two && tr >= AACG_INTENSITY_BT2;
-        bool neg = tr == AACG_INTENSITY_BT2;
-        if (mask && (wl & AACG_META_MS_USED)) neg = !neg;
+        const bool is = coded & two & (tr >= AACG_INTENSITY_BT2);
+        const bool neg = (tr == AACG_INTENSITY_BT2) ^ (mask & ms_used);
         dpf2 rl, rr;
         rl.x = live_l ? sl : 0.0f;
         rl.y = __builtin_bit_cast(float, (live_l ? AACG_BR_LIVE : 0u) | (ms ? AACG_BR_FLAG : 0u));
@@ -758,39 +794,6 @@ DP_DEVICE void prepare_bands(const float* tab, const quant_regs& r, bool two, bo
         rr.y = __builtin_bit_cast(float, (live_r ? AACG_BR_LIVE : 0u) | (is ? AACG_BR_FLAG : 0u));
         *(dpf2*)(bw + 2 * b) = rl;
         *(dpf2*)(bw + 256 + 2 * b) = rr;
-    }
-}
-
-struct chan_ctx {
-    int cls;            /* 1 = EIGHT_SHORT */
-    int max_sfb;
-    unsigned gmap;      /* 4 bits per window: its group (planner-filled) */
-};
-
-/* Band record indices of the four 4-coefficient groups a lane owns (k = 2 i + h: positions
- * 8 lane + 512 i + 4 h): the band maps hold one byte per coefficient, so one 8-byte read covers the two
- * groups of an i.  AACG_BR_NONE if sfb >= maxSFB. */
-DP_DEVICE void band_indices(const float* tab, const chan_ctx& cc, int (&idx)[4])
-{
-    const int lane = dp_lane();
-    if (cc.cls) {
-        /* pos & 127 does not depend on i; window = pos >> 7 = lane / 16 + 4 i */
-        const dpf2 m = *(const dpf2*)((const unsigned char*)(tab + AACG_TAB_OFF_BAND_SHORT) + ((8 * lane) & 127));
-        const int s0 = (int)(__builtin_bit_cast(unsigned, m.x) & 0xffu), s1 = (int)(__builtin_bit_cast(unsigned, m.y) & 0xffu);
-#pragma unroll
-        for (int i = 0; i < 2; i++) {
-            const int g = (int)((cc.gmap >> (4 * ((lane >> 4) + 4 * i))) & 15u);
-            idx[2 * i]     = s0 < cc.max_sfb ? g * cc.max_sfb + s0 : AACG_BR_NONE;
-            idx[2 * i + 1] = s1 < cc.max_sfb ? g * cc.max_sfb + s1 : AACG_BR_NONE;
-        }
-    } else {
-#pragma unroll
-        for (int i = 0; i < 2; i++) {
-            const dpf2 m = *(const dpf2*)((const unsigned char*)(tab + AACG_TAB_OFF_BAND_LONG) + 8 * lane + 512 * i);
-            const int s0 = (int)(__builtin_bit_cast(unsigned, m.x) & 0xffu), s1 = (int)(__builtin_bit_cast(unsigned, m.y) & 0xffu);
-            idx[2 * i]     = s0 < cc.max_sfb ? s0 : AACG_BR_NONE;
-            idx[2 * i + 1] = s1 < cc.max_sfb ? s1 : AACG_BR_NONE;
-        }
     }
 }
 
@@ -840,10 +843,19 @@ DP_DEVICE void spectral_quant(const aacg_kparams& P, const float* tab, const uni
     const bool two = n_ch == 2;
     const bool ms_on = two && (u.flags & AACG_UNIT_COMMON_WINDOW) && (u.flags & AACG_UNIT_MASK_PRESENT);
     const bool mask  = (u.flags & AACG_UNIT_MASK_PRESENT) != 0;
-    prepare_bands(tab, qreg, two, ms_on, mask, bt);
+    /* one batch of independent LDS reads: the four SF-table entries of this lane's two bands and the band maps */
+    float sl[2], sr[2];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        sl[h] = tab[AACG_TAB_OFF_SF + (qreg.mw[0][h] & AACG_META_SF_MASK)];
+        sr[h] = tab[AACG_TAB_OFF_SF + (qreg.mw[1][h] & AACG_META_SF_MASK)];
+    }
+    band_raw braw;
+    band_raw_load(tab, braw);
+    prepare_bands(qreg, sl, sr, two, ms_on, mask, bt);
     int idxL[4], idxR[4];
-    band_indices(tab, ccL, idxL);
-    band_indices(tab, ccR, idxR);
+    band_indices(braw, ccL, idxL);
+    band_indices(braw, ccR, idxR);
     dp_wave_sync();
 
     /* per 4-coefficient group (bands are multiples of 4 wide): the band records of both channels, all loads
