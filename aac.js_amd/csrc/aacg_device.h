@@ -102,6 +102,7 @@ struct aacg_kparams {
     const aacg_dev_tns*   tns;        /* AACG_TNS_SPEC: indexed like aacg_unit_desc.tns_offset + c; else null */
     float*                pcm;
     float*                overlap;    /* overlap pool */
+    float*                scratch;    /* [n_runs][2048]: parked predecessor tails of double-duty runs */
     float*                spec_out;   /* spectral-only kernel */
     const aacg_tables*    tab;
     int32_t               flip;       /* 0/1: swap ov_a and ov_b (plan reuse, see aacg_engine.hip) */

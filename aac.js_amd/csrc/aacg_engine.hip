@@ -25,13 +25,11 @@ void aacg_imdct_run_quant(const aacg_kparams P) { imdct_run_body<AACG_INPUT_QUAN
 extern "C" __global__ __launch_bounds__(AACG_WG_THREADS)
 void aacg_imdct_run_f32(const aacg_kparams P) { imdct_run_body<AACG_INPUT_SPEC_F32, false>(P); }
 
-/* AACG_TNS_SPEC batches that carry TNS side info: the same bodies with the TNS stage compiled in (kept out
- * of the kernels above so that their register allocation is untouched) */
-extern "C" __global__ __launch_bounds__(AACG_WG_THREADS)
-void aacg_imdct_run_quant_tns(const aacg_kparams P) { imdct_run_body<AACG_INPUT_QUANT_I16, true>(P); }
-
-extern "C" __global__ __launch_bounds__(AACG_WG_THREADS)
-void aacg_imdct_run_f32_tns(const aacg_kparams P) { imdct_run_body<AACG_INPUT_SPEC_F32, true>(P); }
+/* The variants (_dd: plans with full later runs, whose first wave does double duty; _tns: AACG_TNS_SPEC batches
+ * with TNS side info) live in aacg_engine_ext.hip: their own code object, so that adding to them never moves the
+ * two kernels above. */
+int aacg_ext_set_lds_limits(void);
+void aacg_ext_launch(bool quant, bool tns, dim3 grid, dim3 block, hipStream_t s, const aacg_kparams& P);
 
 extern "C" __global__ __launch_bounds__(AACG_WG_THREADS)
 void aacg_spectral(const aacg_kparams P, int n_units) { spectral_body(P, n_units); }
@@ -57,6 +55,7 @@ struct aacg_engine {
         void* d_coeffs = nullptr; size_t coeffs_cap = 0;
         void* d_meta = nullptr;   size_t meta_cap = 0;
         void* d_tns = nullptr;    size_t tns_cap = 0;
+        void* d_scratch = nullptr; size_t scratch_cap = 0;
         void* d_pcm = nullptr;    size_t pcm_cap = 0;
         /* page-locked staging for callers that pass ordinary (pageable) memory */
         void* h_in = nullptr;     size_t h_in_cap = 0;
@@ -78,6 +77,7 @@ struct aacg_plan {
     aacg_dev_unit* d_units = nullptr;
     aacg_run* d_runs = nullptr;
     aacg_dev_tns* d_tns = nullptr;
+    float* d_scratch = nullptr;             /* parked predecessor tails of double-duty runs */
     uint32_t launches = 0;
 };
 
@@ -122,7 +122,7 @@ bool is_pinned(const void* p)
 
 /* enqueue the run kernel for a planned batch (device pointers) */
 int launch_run(aacg_engine* e, const aacg_dev_unit* d_units, const aacg_run* d_runs, const aacg_dev_tns* d_tns,
-               const aacg_plan_host& h, const void* d_coeffs, const aacg_band_meta* d_meta, float* d_pcm, int flip,
+               float* d_scratch, const aacg_plan_host& h, const void* d_coeffs, const aacg_band_meta* d_meta, float* d_pcm, int flip,
                hipStream_t s)
 {
     const bool quant = e->cfg.input_kind == AACG_INPUT_QUANT_I16;
@@ -131,14 +131,14 @@ int launch_run(aacg_engine* e, const aacg_dev_unit* d_units, const aacg_run* d_r
     aacg_kparams P;
     P.units = d_units; P.runs = d_runs; P.coeffs = d_coeffs; P.meta = d_meta; P.pcm = d_pcm;
     P.tns = h.any_tns ? d_tns : nullptr;
+    P.scratch = d_scratch;
     P.overlap = e->d_overlap; P.spec_out = nullptr; P.tab = e->d_tab;
     P.flip = flip; P.n_runs = (int32_t)h.runs.size();
     P.ablate = e->d_trace ? e->ablate : (e->ablate & ~16);
     if (e->d_trace) P.spec_out = (float*)e->d_trace;
     const dim3 grid((unsigned)h.runs.size()), block(AACG_WG_THREADS);
-    if (P.tns) {
-        if (quant) hipLaunchKernelGGL(aacg_imdct_run_quant_tns, grid, block, AACG_LDS_BYTES_QUANT, s, P);
-        else       hipLaunchKernelGGL(aacg_imdct_run_f32_tns, grid, block, AACG_LDS_BYTES_F32, s, P);
+    if (P.tns || h.needs_scratch) {
+        aacg_ext_launch(quant, P.tns != nullptr, grid, block, s, P);
     } else {
         if (quant) hipLaunchKernelGGL(aacg_imdct_run_quant, grid, block, AACG_LDS_BYTES_QUANT, s, P);
         else       hipLaunchKernelGGL(aacg_imdct_run_f32, grid, block, AACG_LDS_BYTES_F32, s, P);
@@ -186,8 +186,7 @@ int aacg_create(const aacg_config* cfg, aacg_engine** out)
         /* ~158 KiB of dynamic LDS per workgroup is above the 64 KiB default limit */
         !hip_ok(e, hipFuncSetAttribute((const void*)aacg_imdct_run_quant, hipFuncAttributeMaxDynamicSharedMemorySize, AACG_LDS_BYTES_QUANT), "LDS attr") ||
         !hip_ok(e, hipFuncSetAttribute((const void*)aacg_imdct_run_f32, hipFuncAttributeMaxDynamicSharedMemorySize, AACG_LDS_BYTES_F32), "LDS attr") ||
-        !hip_ok(e, hipFuncSetAttribute((const void*)aacg_imdct_run_quant_tns, hipFuncAttributeMaxDynamicSharedMemorySize, AACG_LDS_BYTES_QUANT), "LDS attr") ||
-        !hip_ok(e, hipFuncSetAttribute((const void*)aacg_imdct_run_f32_tns, hipFuncAttributeMaxDynamicSharedMemorySize, AACG_LDS_BYTES_F32), "LDS attr") ||
+        aacg_ext_set_lds_limits() != 0 ||
         !hip_ok(e, hipFuncSetAttribute((const void*)aacg_spectral, hipFuncAttributeMaxDynamicSharedMemorySize, AACG_LDS_BYTES_SPECTRAL), "LDS attr")) {
         std::fprintf(stderr, "aacgpu: %s\n", e->err.c_str());
         aacg_destroy(e);
@@ -208,7 +207,7 @@ void aacg_destroy(aacg_engine* e)
     if (e->d_tab) (void)hipFree(e->d_tab);
     if (e->d_overlap) (void)hipFree(e->d_overlap);
     for (auto& sl : e->slot) {
-        for (void* p : {sl.d_units, sl.d_runs, sl.d_coeffs, sl.d_meta, sl.d_tns, sl.d_pcm}) if (p) (void)hipFree(p);
+        for (void* p : {sl.d_units, sl.d_runs, sl.d_coeffs, sl.d_meta, sl.d_tns, sl.d_scratch, sl.d_pcm}) if (p) (void)hipFree(p);
         if (sl.h_in) (void)hipHostFree(sl.h_in);
         if (sl.h_pcm) (void)hipHostFree(sl.h_pcm);
         if (sl.done) (void)hipEventDestroy(sl.done);
@@ -309,13 +308,15 @@ int aacg_plan_create_tns(aacg_engine* e, const aacg_unit_desc* units, uint32_t n
     if (rc) { delete p; return rc; }
     const size_t ub = sizeof(aacg_dev_unit) * n_units, rb = sizeof(aacg_run) * p->h.runs.size();
     const size_t tb = sizeof(aacg_dev_tns) * p->h.tns.size();
+    const size_t sb = p->h.needs_scratch ? p->h.runs.size() * AACG_SLOT_FLOATS * sizeof(float) : 0;
     if (!hip_ok(e, hipSetDevice(e->cfg.device_ordinal), "hipSetDevice") ||
         !hip_ok(e, hipMalloc((void**)&p->d_units, ub), "hipMalloc units") ||
         !hip_ok(e, hipMalloc((void**)&p->d_runs, rb), "hipMalloc runs") ||
         !hip_ok(e, hipMemcpy(p->d_units, p->h.units.data(), ub, hipMemcpyHostToDevice), "upload units") ||
         !hip_ok(e, hipMemcpy(p->d_runs, p->h.runs.data(), rb, hipMemcpyHostToDevice), "upload runs") ||
         (tb && (!hip_ok(e, hipMalloc((void**)&p->d_tns, tb), "hipMalloc tns") ||
-                !hip_ok(e, hipMemcpy(p->d_tns, p->h.tns.data(), tb, hipMemcpyHostToDevice), "upload tns")))) {
+                !hip_ok(e, hipMemcpy(p->d_tns, p->h.tns.data(), tb, hipMemcpyHostToDevice), "upload tns"))) ||
+        (sb && !hip_ok(e, hipMalloc((void**)&p->d_scratch, sb), "hipMalloc scratch"))) {
         aacg_plan_destroy(p);
         return AACG_ERR_OUT_OF_MEMORY;
     }
@@ -330,6 +331,7 @@ void aacg_plan_destroy(aacg_plan* p)
     if (p->d_units) (void)hipFree(p->d_units);
     if (p->d_runs) (void)hipFree(p->d_runs);
     if (p->d_tns) (void)hipFree(p->d_tns);
+    if (p->d_scratch) (void)hipFree(p->d_scratch);
     delete p;
 }
 
@@ -354,7 +356,7 @@ int aacg_decode_device(aacg_engine* e, aacg_plan* p, const void* d_coeffs, const
     int rc = plan_check_parity(e, p);
     if (rc) return rc;
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : e->stream;
-    rc = launch_run(e, p->d_units, p->d_runs, p->d_tns, p->h, d_coeffs, d_meta, d_pcm, (int)(p->launches & 1u), s);
+    rc = launch_run(e, p->d_units, p->d_runs, p->d_tns, p->d_scratch, p->h, d_coeffs, d_meta, d_pcm, (int)(p->launches & 1u), s);
     if (rc) return rc;
 
     for (const aacg_chain& c : p->h.chains)
@@ -465,12 +467,13 @@ int aacg_submit_tns(aacg_engine* e, const aacg_unit_desc* units, uint32_t n_unit
 
     const size_t ub = sizeof(aacg_dev_unit) * h.units.size(), rb = sizeof(aacg_run) * h.runs.size();
     const size_t tb = sizeof(aacg_dev_tns) * h.tns.size();
+    const size_t sb = h.needs_scratch ? h.runs.size() * AACG_SLOT_FLOATS * sizeof(float) : 0;
     const size_t cb = (size_t)n_coef_blocks * 1024u * coef_elem_size(e);
     const size_t mb = quant ? (size_t)n_meta * sizeof(aacg_band_meta) : 0;
     const size_t pb = h.pcm_floats * sizeof(float);
     if ((rc = grow(e, &sl.d_units, &sl.units_cap, ub)) || (rc = grow(e, &sl.d_runs, &sl.runs_cap, rb)) ||
         (rc = grow(e, &sl.d_coeffs, &sl.coeffs_cap, cb)) || (quant && (rc = grow(e, &sl.d_meta, &sl.meta_cap, mb))) ||
-        (tb && (rc = grow(e, &sl.d_tns, &sl.tns_cap, tb))) || (rc = grow(e, &sl.d_pcm, &sl.pcm_cap, pb)))
+        (tb && (rc = grow(e, &sl.d_tns, &sl.tns_cap, tb))) || (sb && (rc = grow(e, &sl.d_scratch, &sl.scratch_cap, sb))) || (rc = grow(e, &sl.d_pcm, &sl.pcm_cap, pb)))
         return rc;
 
     /* Ordinary (pageable) caller memory goes through the slot's page-locked staging buffers (one host
@@ -502,7 +505,8 @@ int aacg_submit_tns(aacg_engine* e, const aacg_unit_desc* units, uint32_t n_unit
     /* kernels chain through the overlap state: this one starts after the previous batch's kernel,
      * while its uploads above overlapped it */
     if (e->last_kernel) HIP_TRY(e, hipStreamWaitEvent(s, e->last_kernel, 0), AACG_ERR_NO_DEVICE);
-    rc = launch_run(e, (const aacg_dev_unit*)sl.d_units, (const aacg_run*)sl.d_runs, (const aacg_dev_tns*)sl.d_tns, h, sl.d_coeffs,
+    rc = launch_run(e, (const aacg_dev_unit*)sl.d_units, (const aacg_run*)sl.d_runs, (const aacg_dev_tns*)sl.d_tns,
+                    (float*)sl.d_scratch, h, sl.d_coeffs,
                     (const aacg_band_meta*)sl.d_meta, (float*)sl.d_pcm, 0, s);
     if (rc) return rc;
     HIP_TRY(e, hipEventRecord(sl.kernel_done, s), AACG_ERR_NO_DEVICE);

@@ -1,0 +1,45 @@
+/*
+ * aacg_engine_ext.hip — the run kernel's variants (see aacg_engine.hip): separate translation unit, separate
+ * code object.  MI355X (gfx950) only.
+ */
+#include <hip/hip_runtime.h>
+
+#include "aacg_kernels.h"
+
+/* Variants of aacg_imdct_run_quant / _f32:
+ *   _dd : plans with full later runs (chains longer than 16 frames), whose first wave does double duty;
+ *   _tns: AACG_TNS_SPEC batches that carry TNS side info (also handles double duty). */
+extern "C" __global__ __launch_bounds__(AACG_WG_THREADS)
+void aacg_imdct_run_quant_dd(const aacg_kparams P) { imdct_run_body_dd<AACG_INPUT_QUANT_I16, false>(P); }
+
+extern "C" __global__ __launch_bounds__(AACG_WG_THREADS)
+void aacg_imdct_run_f32_dd(const aacg_kparams P) { imdct_run_body_dd<AACG_INPUT_SPEC_F32, false>(P); }
+
+extern "C" __global__ __launch_bounds__(AACG_WG_THREADS)
+void aacg_imdct_run_quant_tns(const aacg_kparams P) { imdct_run_body_dd<AACG_INPUT_QUANT_I16, true>(P); }
+
+extern "C" __global__ __launch_bounds__(AACG_WG_THREADS)
+void aacg_imdct_run_f32_tns(const aacg_kparams P) { imdct_run_body_dd<AACG_INPUT_SPEC_F32, true>(P); }
+
+
+int aacg_ext_set_lds_limits(void)
+{
+    /* ~158 KiB of dynamic LDS per workgroup is above the 64 KiB default limit */
+    hipError_t rc = hipSuccess;
+    if (rc == hipSuccess) rc = hipFuncSetAttribute((const void*)aacg_imdct_run_quant_dd, hipFuncAttributeMaxDynamicSharedMemorySize, AACG_LDS_BYTES_QUANT);
+    if (rc == hipSuccess) rc = hipFuncSetAttribute((const void*)aacg_imdct_run_f32_dd, hipFuncAttributeMaxDynamicSharedMemorySize, AACG_LDS_BYTES_F32);
+    if (rc == hipSuccess) rc = hipFuncSetAttribute((const void*)aacg_imdct_run_quant_tns, hipFuncAttributeMaxDynamicSharedMemorySize, AACG_LDS_BYTES_QUANT);
+    if (rc == hipSuccess) rc = hipFuncSetAttribute((const void*)aacg_imdct_run_f32_tns, hipFuncAttributeMaxDynamicSharedMemorySize, AACG_LDS_BYTES_F32);
+    return rc == hipSuccess ? 0 : -1;
+}
+
+void aacg_ext_launch(bool quant, bool tns, dim3 grid, dim3 block, hipStream_t s, const aacg_kparams& P)
+{
+    if (tns) {
+        if (quant) hipLaunchKernelGGL(aacg_imdct_run_quant_tns, grid, block, AACG_LDS_BYTES_QUANT, s, P);
+        else       hipLaunchKernelGGL(aacg_imdct_run_f32_tns, grid, block, AACG_LDS_BYTES_F32, s, P);
+    } else {
+        if (quant) hipLaunchKernelGGL(aacg_imdct_run_quant_dd, grid, block, AACG_LDS_BYTES_QUANT, s, P);
+        else       hipLaunchKernelGGL(aacg_imdct_run_f32_dd, grid, block, AACG_LDS_BYTES_F32, s, P);
+    }
+}

@@ -33,6 +33,7 @@ struct aacg_plan_host {
     std::vector<aacg_dev_unit> units;   /* device copy of the units */
     std::vector<aacg_dev_tns>  tns;     /* device form of the TNS side info (AACG_TNS_SPEC), same indexing as the input */
     bool     any_tns = false;         /* some channel has AACG_CHAN_TNS_PRESENT and TNS records were given */
+    bool     needs_scratch = false;   /* some later run holds 16 frames: its first wave parks the predecessor's tails */
     std::vector<aacg_run>   runs;     /* in launch (block) order, XCD-aware */
     std::vector<aacg_chain> chains;
     bool     zero_fill = false;       /* some frame has a channel no unit writes (decoder.js:229-231) */

@@ -208,9 +208,18 @@ int aacg_plan_build(const aacg_unit_desc* units, uint32_t n_units, int sample_in
         for (int c = 0; c < 2; c++)
             ch.parity[c] = (parity && c < oc.n_ch) ? parity[(size_t)ch.stream * (size_t)max_channels + ch.channel + c] : 0;
         const size_t n = oc.units.size();
+        /* The first run takes 16 frames.  A later run recomputes the tail of the frame before it: with up to 15
+         * frames a wave of its own does that, a full run of 16 gives its first wave double duty (one IMDCT more in
+         * series).  Use as few double-duty runs as it takes to reach the minimum number of runs. */
+        size_t n_full = 0;
+        if (n > AACG_RUN_W) {
+            const size_t rem = n - AACG_RUN_W, later = (rem + AACG_RUN_W - 1) / AACG_RUN_W;
+            n_full = rem > later * (AACG_RUN_W - 1) ? rem - later * (AACG_RUN_W - 1) : 0;
+        }
         for (size_t pos = 0; pos < n;) {
             aacg_run r;
-            const size_t cap = pos ? AACG_RUN_W - 1 : AACG_RUN_W;        /* wave 0 of a later run recomputes its predecessor */
+            size_t cap = AACG_RUN_W;
+            if (pos) { if (n_full) n_full--; else cap = AACG_RUN_W - 1; }
             r.pred_unit = pos ? oc.units[pos - 1] : -1;
             r.n_units = (int32_t)std::min<size_t>(cap, n - pos);
             for (int k = 0; k < AACG_RUN_W; k++) r.unit[k] = k < r.n_units ? oc.units[pos + k] : -1;
@@ -219,6 +228,7 @@ int aacg_plan_build(const aacg_unit_desc* units, uint32_t n_units, int sample_in
                 r.ov_a[c] = aacg_ov_offset(max_channels, ch.stream, chn, ch.parity[c]);
                 r.ov_b[c] = aacg_ov_offset(max_channels, ch.stream, chn, ch.parity[c] ^ 1);
             }
+            if (pos && r.n_units == AACG_RUN_W) out->needs_scratch = true;
             pos += (size_t)r.n_units;
             r.is_last = pos >= n ? 1 : 0;
             r.reserved = 0;

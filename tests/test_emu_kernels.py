@@ -232,3 +232,28 @@ def test_fuzz_vs_oracle(emu, oracle, seed):
     assert np.abs(emu_lib.pool_current(pool, par) - ov).max() < 1e-5 * max(1.0, np.abs(ov).max())
     spec = emu.spectral(wl["units"], wl["q"], wl["meta"])
     assert np.array_equal(spec.view(np.uint32), spec_ref.view(np.uint32))
+
+
+@pytest.mark.parametrize("T,want", [(31, [16, 15]), (32, [16, 16]), (33, [16, 15, 2]), (48, [16, 16, 16])])
+def test_long_chains_double_duty(emu, oracle, T, want):
+    """Chains longer than a run: a later run recomputes its predecessor's tail — in a wave of its own when it
+    holds up to 15 frames, by its first wave doing double duty when a full 16 keeps the number of runs minimal."""
+    wl = _workload(n_streams=1, n_frames=T, mix=True, intensity=True, seed=T)
+    n, runs, info = emu.plan(wl["units"], 1, 2)
+    assert sorted((int(r["n_units"]) for r in runs), reverse=True) == want
+    assert sum(int(r["pred_unit"]) >= 0 for r in runs) == len(want) - 1
+    ov = np.zeros((1, 2, 1024), np.float32)
+    ref = oracle.decode_batch(wl["units"], wl["q"], wl["meta"], wl["n_pcm"], ov)
+    pool = np.zeros((1, 2, 2, 1024), np.float32)
+    par = np.zeros(2, np.uint8)
+    pcm = emu.decode(wl["units"], wl["q"], wl["meta"], wl["n_pcm"], pool, par)
+    assert rms(pcm, ref) < RMS_TOL
+    assert np.abs(emu_lib.pool_current(pool, par) - ov).max() < 1e-5 * max(1.0, np.abs(ov).max())
+    # f32 seam, single channel element as well
+    wl = _workload(n_streams=1, n_frames=T, layout=("sce",), mix=True, seed=T + 1)
+    ov = np.zeros((1, 1, 1024), np.float32)
+    ref, spec = oracle.decode_batch(wl["units"], wl["q"], wl["meta"], wl["n_pcm"], ov, want_spec=True)
+    pool = np.zeros((1, 1, 2, 1024), np.float32)
+    par = np.zeros(1, np.uint8)
+    pcm = emu.decode(wl["units"], spec, None, wl["n_pcm"], pool, par)
+    assert rms(pcm, ref) < RMS_TOL

@@ -417,3 +417,26 @@ def test_fuzz_vs_oracle(oracle, seed):
     rms(pcm, ref)
     assert np.abs(overlaps(eng, S, C) - ov).max() < 1e-5 * max(1.0, float(np.abs(ov).max()))
     eng.close()
+
+
+@pytest.mark.parametrize("T", [32, 47, 128])
+def test_long_chains_double_duty(oracle, T):
+    """BASELINE config 4 shape (few streams, long chains): later runs of 16 frames whose first wave recomputes the
+    predecessor's tail before its own frame; also through a reused plan (flip) and the f32 seam."""
+    S = 6
+    wl = aacgpu_workload.make_batch(n_streams=S, n_frames=T, mix=True, intensity=True, seed=900 + T)
+    ov = np.zeros((S, 2, 1024), np.float32)
+    ref, spec = oracle.decode_batch(wl["units"], wl["q"], wl["meta"], wl["n_pcm"], ov, want_spec=True)
+    eng = aacgpu.Engine(aacgpu.INPUT_QUANT_I16, S, 2)
+    pcm = eng.decode_batch(wl["units"], wl["q"], wl["meta"], wl["n_pcm"])
+    assert rms(pcm, ref) < RMS_TOL
+    assert np.abs(overlaps(eng, S, 2) - ov).max() < 1e-5 * max(1.0, float(np.abs(ov).max()))
+    # the next batch of the same shape continues the streams
+    ref2 = oracle.decode_batch(wl["units"], wl["q"], wl["meta"], wl["n_pcm"], ov)
+    pcm2 = eng.decode_batch(wl["units"], wl["q"], wl["meta"], wl["n_pcm"])
+    assert rms(pcm2, ref2) < RMS_TOL
+    eng.close()
+    eng = aacgpu.Engine(aacgpu.INPUT_SPEC_F32, S, 2)
+    pcm = eng.decode_batch(wl["units"], spec, None, wl["n_pcm"])
+    assert rms(pcm, ref) < RMS_TOL
+    eng.close()

@@ -30,3 +30,18 @@ for w in range(min(16, T)):
     row = [np.median(t[:, w, k] - t0) for k in range(6)]
     print("wave %2d: " % w + "  ".join("%s %6.2f" % (names[k][:14], row[k]) for k in range(6)))
 print("kernel span (last stores issued - first start): %.2f us; start skew across WGs: %.2f us" % ((t[:, :, 5].max() - t0), t[:, :, 0].max() - t0))
+
+# distribution over workgroups: where do the stragglers come from?
+end = t[:, :, 5].max(axis=1) - t0                     # last stores issued per workgroup
+start = t[:, :, 0].min(axis=1) - t0
+print("per-workgroup end (last stores issued): " + "  ".join("p%d %.2f" % (q, np.percentile(end, q)) for q in (0, 10, 50, 90, 99, 100)))
+print("per-workgroup duration: " + "  ".join("p%d %.2f" % (q, np.percentile(end - start, q)) for q in (0, 10, 50, 90, 99, 100)))
+for x in range(8):
+    sel = np.arange(256) % 8 == x                     # blockIdx -> XCD round-robin
+    print("XCD %d: start %.2f..%.2f  end median %.2f max %.2f" % (x, start[sel].min(), start[sel].max(), np.median(end[sel]), end[sel].max()))
+late = np.argsort(end)[-8:]
+print("latest workgroups:", [(int(i), round(float(start[i]), 2), round(float(end[i]), 2)) for i in late])
+for k, nm in enumerate(names):
+    if k in (4,): continue
+    v = t[:, :, k] - t0
+    print("%-16s all waves: p50 %.2f p90 %.2f p99 %.2f max %.2f" % (nm, *(np.percentile(v, q) for q in (50, 90, 99)), v.max()))
