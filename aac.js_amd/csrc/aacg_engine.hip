@@ -131,7 +131,7 @@ int launch_run(aacg_engine* e, const aacg_dev_unit* d_units, const aacg_run* d_r
     aacg_kparams P;
     P.units = d_units; P.runs = d_runs; P.coeffs = d_coeffs; P.meta = d_meta; P.pcm = d_pcm;
     P.tns = h.any_tns ? d_tns : nullptr;
-    P.scratch = d_scratch;
+    P.scratch = h.needs_scratch ? d_scratch : nullptr;
     P.overlap = e->d_overlap; P.spec_out = nullptr; P.tab = e->d_tab;
     P.flip = flip; P.n_runs = (int32_t)h.runs.size();
     P.ablate = e->d_trace ? e->ablate : (e->ablate & ~16);

@@ -8,18 +8,18 @@
 
 /* Variants of aacg_imdct_run_quant / _f32:
  *   _dd : plans with full later runs (chains longer than 16 frames), whose first wave does double duty;
- *   _tns: AACG_TNS_SPEC batches that carry TNS side info (also handles double duty). */
+ *   _tns: AACG_TNS_SPEC batches that carry TNS side info (the planner gives those no full later runs). */
 extern "C" __global__ __launch_bounds__(AACG_WG_THREADS)
-void aacg_imdct_run_quant_dd(const aacg_kparams P) { imdct_run_body_dd<AACG_INPUT_QUANT_I16, false>(P); }
+void aacg_imdct_run_quant_dd(const aacg_kparams P) { imdct_run_body_dd<AACG_INPUT_QUANT_I16>(P); }
 
 extern "C" __global__ __launch_bounds__(AACG_WG_THREADS)
-void aacg_imdct_run_f32_dd(const aacg_kparams P) { imdct_run_body_dd<AACG_INPUT_SPEC_F32, false>(P); }
+void aacg_imdct_run_f32_dd(const aacg_kparams P) { imdct_run_body_dd<AACG_INPUT_SPEC_F32>(P); }
 
 extern "C" __global__ __launch_bounds__(AACG_WG_THREADS)
-void aacg_imdct_run_quant_tns(const aacg_kparams P) { imdct_run_body_dd<AACG_INPUT_QUANT_I16, true>(P); }
+void aacg_imdct_run_quant_tns(const aacg_kparams P) { imdct_run_body<AACG_INPUT_QUANT_I16, true>(P); }
 
 extern "C" __global__ __launch_bounds__(AACG_WG_THREADS)
-void aacg_imdct_run_f32_tns(const aacg_kparams P) { imdct_run_body_dd<AACG_INPUT_SPEC_F32, true>(P); }
+void aacg_imdct_run_f32_tns(const aacg_kparams P) { imdct_run_body<AACG_INPUT_SPEC_F32, true>(P); }
 
 
 int aacg_ext_set_lds_limits(void)

@@ -991,7 +991,7 @@ DP_DEVICE void stage_pair_f32(const dpf4 (&xa)[4], const dpf4 (&xb)[4], float* s
  * runs the filter of window w, all eight in parallel).  P = largest order handled (coefficients beyond `order`
  * are zero).  area: the channel's spectrum in ICStream.data order; scratch: P * P doubles per filter. */
 template <int SB, int P>
-DP_DEVICE_NOINLINE void tns_pass(float* area, float* scratch, int start, int size, int inc, int order, const float* lpc_src)
+DP_DEVICE void tns_pass(float* area, float* scratch, int start, int size, int inc, int order, const float* lpc_src)
 {
     const int lane = dp_lane(), b = lane & (SB - 1), seg = lane / SB;
     /* scan levels: log2 of the number of blocks the (longest) filter spans */
@@ -1527,17 +1527,17 @@ DP_DEVICE void imdct_run_body(const aacg_kparams& P)
 /* ------------------------------------------------------------------------------------ */
 /* one run per workgroup, with double duty                                                 */
 /* ------------------------------------------------------------------------------------ */
-/* The run body again, for plans that contain full later runs (chains longer than 16 frames) and for the TNS
- * variants.  A later run of a chain starts from the tail of the frame before it, which another workgroup owns,
+/* The run body again, for plans that contain full later runs (chains longer than 16 frames).  A later run of a chain starts from the tail of the frame before it, which another workgroup owns,
  * so it recomputes that frame's IMDCT.  With up to 15 frames a wave of its own does that (imdct_run_body above
- * handles it as well); a full run of 16 gives its first wave double duty: first the predecessor, whose tails it
+ * handles it as well, and is what the TNS variants use); a full run of 16 gives its first wave double duty: first the predecessor, whose tails it
  * parks in a scratch area in global memory, then its own frame, which takes its overlap from there.
  * Kept as a second function on purpose: the same source instantiated without the second pass compiles to a run
  * body that is 0.8 us slower on config 2 than the one above (interleaved A/B, 16.8 vs 16.0 us), and a non-inlined
  * predecessor pass costs config 4 more than it saves (29 vs 23 us).  The stages themselves are shared. */
-template <int KIND, bool TNS>
+template <int KIND>
 DP_DEVICE void imdct_run_body_dd(const aacg_kparams& P)
 {
+    constexpr bool TNS = false;                        /* TNS batches get no full later runs (aacg_plan.cpp) */
     const int TAB_FLOATS = (KIND == AACG_INPUT_QUANT_I16) ? AACG_TAB_QUANT_FLOATS : AACG_TAB_F32_FLOATS;
     const int lane = dp_lane(), wave = dp_wave();
     const aacg_run* run = P.runs + dp_block();

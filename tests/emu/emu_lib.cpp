@@ -25,8 +25,10 @@ void* lane_main(void* p)
 {
     launch_arg* a = (launch_arg*)p;
     g_emu = a->ctx;
-    if (a->kind == 0)      imdct_run_body_dd<AACG_INPUT_SPEC_F32, true>(*a->P);
-    else if (a->kind == 1) imdct_run_body_dd<AACG_INPUT_QUANT_I16, true>(*a->P);
+    /* the same dispatch as the engine's launch_run: tns variant / double-duty variant / plain */
+    const bool dd = a->P->scratch != nullptr, tns = a->P->tns != nullptr;
+    if (a->kind == 0)      { if (tns) imdct_run_body<AACG_INPUT_SPEC_F32, true>(*a->P); else if (dd) imdct_run_body_dd<AACG_INPUT_SPEC_F32>(*a->P); else imdct_run_body<AACG_INPUT_SPEC_F32, false>(*a->P); }
+    else if (a->kind == 1) { if (tns) imdct_run_body<AACG_INPUT_QUANT_I16, true>(*a->P); else if (dd) imdct_run_body_dd<AACG_INPUT_QUANT_I16>(*a->P); else imdct_run_body<AACG_INPUT_QUANT_I16, false>(*a->P); }
     else                   spectral_body(*a->P, a->n_units);
     return nullptr;
 }
@@ -137,7 +139,7 @@ int emu_decode_tns(int input_kind, int sample_index, int max_streams, int max_ch
     P.overlap = overlap_pool; P.tab = &g_tab; P.flip = 0; P.n_runs = (int32_t)ph.runs.size();
     P.tns = ph.any_tns ? ph.tns.data() : nullptr;
     std::vector<float> scratch(ph.needs_scratch ? ph.runs.size() * AACG_SLOT_FLOATS : 1, 0.0f);
-    P.scratch = scratch.data();
+    P.scratch = ph.needs_scratch ? scratch.data() : nullptr;
     launch(P, input_kind == AACG_INPUT_QUANT_I16 ? 1 : 0, (int)ph.runs.size(), AACG_WG_WAVES,
            input_kind == AACG_INPUT_QUANT_I16 ? AACG_LDS_BYTES_QUANT : AACG_LDS_BYTES_F32);
     for (auto& c : ph.chains)

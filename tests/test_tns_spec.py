@@ -327,3 +327,32 @@ def test_gpu_tns_errors():
     eng.close()
     with pytest.raises(aacgpu.AacgError):
         aacgpu.Engine(aacgpu.INPUT_QUANT_I16, 1, 2, tns_mode=2)
+
+
+def test_emulated_tns_long_chain(emu, oracle):
+    """A chain longer than a run with TNS side info: the planner gives TNS batches no full later runs (the TNS
+    kernel variants have no double-duty pass), so 32 frames are 16 + 15 + 1."""
+    wl = W.make_batch(n_streams=1, n_frames=32, mix=True, seed=5)
+    units, tns = W.add_tns(wl, seed=9)
+    ov = np.zeros((1, 2, 1024), np.float32)
+    ref = oracle.decode_batch(units, wl["q"], wl["meta"], wl["n_pcm"], ov, tns=tns)
+    pool = np.zeros((1, 2, 2, 1024), np.float32)
+    par = np.zeros(2, np.uint8)
+    pcm = emu.decode(units, wl["q"], wl["meta"], wl["n_pcm"], pool, par, tns=tns)
+    assert _rel(pcm, ref) < KERNEL_REL_TOL
+    assert _rel(emu_lib.pool_current(pool, par), ov) < KERNEL_REL_TOL
+
+
+@pytest.mark.gpu
+def test_gpu_tns_long_chain(oracle):
+    import aacgpu
+    S, T = 3, 40
+    wl = W.make_batch(n_streams=S, n_frames=T, mix=True, intensity=True, seed=6)
+    units, tns = W.add_tns(wl, seed=10)
+    ov = np.zeros((S, 2, 1024), np.float32)
+    ref = oracle.decode_batch(units, wl["q"], wl["meta"], wl["n_pcm"], ov, tns=tns)
+    eng = aacgpu.Engine(aacgpu.INPUT_QUANT_I16, S, 2, tns_mode=aacgpu.TNS_SPEC)
+    pcm = eng.decode_batch(units, wl["q"], wl["meta"], wl["n_pcm"], tns=tns)
+    assert _rel(pcm, ref) < KERNEL_REL_TOL
+    assert _rel(_gpu_overlaps(eng, S, 2), ov) < KERNEL_REL_TOL
+    eng.close()
