@@ -507,6 +507,37 @@ DP_DEVICE void shfl_pairs(const dpv2 (&R)[8], const dpv2 (&I)[8], int src, dpv2 
     for (int r = 0; r < 8; r++) { mR[r] = v2(a[r], a[8 + r]); mI[r] = v2(b[r], b[8 + r]); }
 }
 
+/* window + reorder of the long pair path for one window sequence (mdct.js:90-114 fused with
+ * filter_bank.js:109-141,180-202); tails interleaved into the slot */
+template <int SEQ>
+DP_DEVICE void long_pair_window(const float* tab, const chan_par& cp, bool want_head, float* slot,
+                                const dpv2 (&R)[8], const dpv2 (&I)[8], const dpv2 (&mR)[8], const dpv2 (&mI)[8],
+                                dpv2 (&hx)[8], dpv2 (&hy)[8])
+{
+    const int l = dp_lane();
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int n = 2 * l + 128 * j;
+        const dpf2 w0 = head_window(tab, SEQ, cp.shape_prev, n), w1 = head_window(tab, SEQ, cp.shape_prev, n + 512);
+        const dpf2 v0 = tail_window(tab, SEQ, cp.shape, n), v1 = tail_window(tab, SEQ, cp.shape, n + 512);
+        if (want_head) {
+            hx[j]     = I[j + 4] * v2s(w0.x);
+            hy[j]     = -mR[3 - j] * v2s(w0.y);
+            hx[j + 4] = R[j] * v2s(w1.x);
+            hy[j + 4] = -mI[7 - j] * v2s(w1.y);
+            if (SEQ == AACG_LONG_STOP_SEQUENCE) { wfix2(hx[j], w0.x); wfix2(hy[j], w0.y); wfix2(hx[j + 4], w1.x); wfix2(hy[j + 4], w1.y); }
+        }
+        dpv2 t0 = R[j + 4] * v2s(v0.x), t1 = -mI[3 - j] * v2s(v0.y);
+        dpv2 t2 = -I[j] * v2s(v1.x),    t3 = mR[7 - j] * v2s(v1.y);
+        if (SEQ == AACG_LONG_START_SEQUENCE) { wfix2(t0, v0.x); wfix2(t1, v0.y); wfix2(t2, v1.x); wfix2(t3, v1.y); }
+        dpf4 o;
+        o.x = t0[0]; o.y = t0[1]; o.z = t1[0]; o.w = t1[1];
+        *(dpf4*)(slot + 2 * n) = o;                                   /* (tailL[n], tailR[n], tailL[n+1], tailR[n+1]) */
+        o.x = t2[0]; o.y = t2[1]; o.z = t3[0]; o.w = t3[1];
+        *(dpf4*)(slot + 2 * (n + 512)) = o;
+    }
+}
+
 /* Long windows, both channels (they share sequence and shapes: one ICSInfo, cpe.js:44, or equal by value). */
 DP_DEVICE void long_pair(const float* tab, const chan_par& cp, bool want_head, float* slot,
                          dpv2 (&hx)[8], dpv2 (&hy)[8])
@@ -581,35 +612,10 @@ DP_DEVICE void long_pair(const float* tab, const chan_par& cp, bool want_head, f
         }
         return;
     }
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const int n = 2 * l + 128 * j;
-        if (want_head) {
-            const dpf2 w0 = head_window(tab, cp.seq, cp.shape_prev, n), w1 = head_window(tab, cp.seq, cp.shape_prev, n + 512);
-            const bool gh = cp.seq == AACG_LONG_STOP_SEQUENCE;
-            hx[j]     = I[j + 4] * v2s(w0.x);
-            hy[j]     = -mR[3 - j] * v2s(w0.y);
-            hx[j + 4] = R[j] * v2s(w1.x);
-            hy[j + 4] = -mI[7 - j] * v2s(w1.y);
-            if (gh) {
-                dp_keep_branch();
-                wfix2(hx[j], w0.x); wfix2(hy[j], w0.y); wfix2(hx[j + 4], w1.x); wfix2(hy[j + 4], w1.y);
-            }
-        }
-        const dpf2 v0 = tail_window(tab, cp.seq, cp.shape, n), v1 = tail_window(tab, cp.seq, cp.shape, n + 512);
-        const bool gt = cp.seq == AACG_LONG_START_SEQUENCE;
-        dpv2 t0 = R[j + 4] * v2s(v0.x), t1 = -mI[3 - j] * v2s(v0.y);
-        dpv2 t2 = -I[j] * v2s(v1.x),    t3 = mR[7 - j] * v2s(v1.y);
-        if (gt) {
-            dp_keep_branch();
-            wfix2(t0, v0.x); wfix2(t1, v0.y); wfix2(t2, v1.x); wfix2(t3, v1.y);
-        }
-        dpf4 o;
-        o.x = t0[0]; o.y = t0[1]; o.z = t1[0]; o.w = t1[1];
-        *(dpf4*)(slot + 2 * n) = o;                                   /* (tailL[n], tailR[n], tailL[n+1], tailR[n+1]) */
-        o.x = t2[0]; o.y = t2[1]; o.z = t3[0]; o.w = t3[1];
-        *(dpf4*)(slot + 2 * (n + 512)) = o;
-    }
+    /* LONG_START / LONG_STOP: the same loop with the sequence as a compile-time constant, so that the branches
+     * inside head_window / tail_window fold and each iteration's window reads are issued together */
+    if (cp.seq == AACG_LONG_START_SEQUENCE) long_pair_window<AACG_LONG_START_SEQUENCE>(tab, cp, want_head, slot, R, I, mR, mI, hx, hy);
+    else                                    long_pair_window<AACG_LONG_STOP_SEQUENCE>(tab, cp, want_head, slot, R, I, mR, mI, hx, hy);
 }
 
 /* EIGHT_SHORT, both channels. */
