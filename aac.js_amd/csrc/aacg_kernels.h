@@ -193,6 +193,36 @@ struct chan_par { int seq, shape, shape_prev; };
  * c's spectrum in natural order on entry, is reused for its FFT transposes and receives its
  * windowed second half (natural order).  Returns the windowed first half at n = 2 l + 128 m
  * (hx[c][m]) and n + 1 (hy[c][m]). */
+/* window + reorder of one planar long channel for one window sequence; m[r] = re, m[8+r] = im of lane 63 - l */
+template <int SEQ>
+DP_DEVICE void long_planar_window(const float* tab, const chan_par& cp, bool want_head, float* area,
+                                  const float (&R)[8], const float (&I)[8], const float (&m)[16],
+                                  float (&hx)[8], float (&hy)[8])
+{
+    const int l = dp_lane();
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int n = 2 * l + 128 * j;
+        const dpf2 w0 = head_window(tab, SEQ, cp.shape_prev, n), w1 = head_window(tab, SEQ, cp.shape_prev, n + 512);
+        const dpf2 v0 = tail_window(tab, SEQ, cp.shape, n), v1 = tail_window(tab, SEQ, cp.shape, n + 512);
+        if (want_head) {
+            hx[j]     = I[j + 4] * w0.x;              /* y[2k]        =  im[N/8 + k]     */
+            hy[j]     = -m[3 - j] * w0.y;             /* y[2k+1]      = -re[N/8 - 1 - k] */
+            hx[j + 4] = R[j] * w1.x;                  /* y[N/4+2k]    =  re[k]           */
+            hy[j + 4] = -m[8 + 7 - j] * w1.y;         /* y[N/4+2k+1]  = -im[N/4 - 1 - k] */
+            if (SEQ == AACG_LONG_STOP_SEQUENCE) { wfix(hx[j], w0.x); wfix(hy[j], w0.y); wfix(hx[j + 4], w1.x); wfix(hy[j + 4], w1.y); }
+        }
+        dpf2 t, t2;
+        t.x = R[j + 4] * v0.x;                        /* y[N/2+2k]    =  re[N/8 + k]     */
+        t.y = -m[8 + 3 - j] * v0.y;                   /* y[N/2+2k+1]  = -im[N/8 - 1 - k] */
+        t2.x = -I[j] * v1.x;                          /* y[3N/4+2k]   = -im[k]           */
+        t2.y = m[7 - j] * v1.y;                       /* y[3N/4+2k+1] =  re[N/4 - 1 - k] */
+        if (SEQ == AACG_LONG_START_SEQUENCE) { wfix(t.x, v0.x); wfix(t.y, v0.y); wfix(t2.x, v1.x); wfix(t2.y, v1.y); }
+        *(dpf2*)(area + n) = t;
+        *(dpf2*)(area + n + 512) = t2;
+    }
+}
+
 template <int NC>
 DP_DEVICE void long_channels(const float* tab, const chan_par (&cp)[NC], bool want_head,
                              float* const (&area)[NC], float (&hx)[NC][8], float (&hy)[NC][8])
@@ -275,48 +305,13 @@ DP_DEVICE void long_channels(const float* tab, const chan_par (&cp)[NC], bool wa
 #pragma unroll
         for (int r = 0; r < 8; r++) { m[r] = R[c][r]; m[8 + r] = I[c][r]; }
         dp_shfl(m, 63 - l);
-        /* reorder (mdct.js:90-114) fused with the window (filter_bank.js:109-116 etc.) */
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int n = 2 * l + 128 * j;
-            if (want_head) {
-                const dpf2 w0 = head_window(tab, cp[c].seq, cp[c].shape_prev, n);
-                const dpf2 w1 = head_window(tab, cp[c].seq, cp[c].shape_prev, n + 512);
-                const bool gh = cp[c].seq == AACG_LONG_STOP_SEQUENCE;
-                hx[c][j]     = I[c][j + 4] * w0.x;             /* y[2k]        =  im[N/8 + k]     */
-                hy[c][j]     = -m[3 - j] * w0.y;               /* y[2k+1]      = -re[N/8 - 1 - k] */
-                hx[c][j + 4] = R[c][j] * w1.x;                 /* y[N/4+2k]    =  re[k]           */
-                hy[c][j + 4] = -m[8 + 7 - j] * w1.y;           /* y[N/4+2k+1]  = -im[N/4 - 1 - k] */
-                if (gh) {
-                    dp_keep_branch();
-                    wfix(hx[c][j], w0.x); wfix(hy[c][j], w0.y); wfix(hx[c][j + 4], w1.x); wfix(hy[c][j + 4], w1.y);
-                }
-            }
-            const dpf2 v0 = tail_window(tab, cp[c].seq, cp[c].shape, n);
-            const dpf2 v1 = tail_window(tab, cp[c].seq, cp[c].shape, n + 512);
-            dpf2 t, t2;
-            const bool gt = cp[c].seq == AACG_LONG_START_SEQUENCE;
-            t.x = R[c][j + 4] * v0.x;                 /* y[N/2+2k]    =  re[N/8 + k]     */
-            t.y = -m[8 + 3 - j] * v0.y;               /* y[N/2+2k+1]  = -im[N/8 - 1 - k] */
-            t2.x = -I[c][j] * v1.x;                   /* y[3N/4+2k]   = -im[k]           */
-            t2.y = m[7 - j] * v1.y;                   /* y[3N/4+2k+1] =  re[N/4 - 1 - k] */
-            if (gt) {
-                dp_keep_branch();
-                wfix(t.x, v0.x); wfix(t.y, v0.y); wfix(t2.x, v1.x); wfix(t2.y, v1.y);
-            }
-            *(dpf2*)(area[c] + n) = t;
-            *(dpf2*)(area[c] + n + 512) = t2;
-        }
+        /* reorder (mdct.js:90-114) fused with the window (filter_bank.js:109-116 etc.), with the sequence as a
+         * compile-time constant: the branches inside head_window / tail_window fold, the reads go out together */
+        if (cp[c].seq == AACG_ONLY_LONG_SEQUENCE)       long_planar_window<AACG_ONLY_LONG_SEQUENCE>(tab, cp[c], want_head, area[c], R[c], I[c], m, hx[c], hy[c]);
+        else if (cp[c].seq == AACG_LONG_START_SEQUENCE) long_planar_window<AACG_LONG_START_SEQUENCE>(tab, cp[c], want_head, area[c], R[c], I[c], m, hx[c], hy[c]);
+        else                                            long_planar_window<AACG_LONG_STOP_SEQUENCE>(tab, cp[c], want_head, area[c], R[c], I[c], m, hx[c], hy[c]);
     }
 }
-
-/* ------------------------------------------------------------------------------------ */
-/* EIGHT_SHORT_SEQUENCE: 8 x IMDCT-256 + window + inner overlap-add, filter_bank.js:143-178 */
-/* ------------------------------------------------------------------------------------ */
-/* Lane group w handles window w.  With s[p], p = 0..1151, the windowed sum of the eight
- * blocks placed at frame position 448 + p:   out[448+p] = ov[448+p] + s[p]  (p < 576),
- * new overlap[p-576] = s[p] (p >= 576), new overlap[576..1023] = 0.  Returns s at
- * p = 128 w + 2 g + 16 m (hx[c][m]) and p + 1 (hy[c][m]); only p < 576 is meaningful there. */
 template <int NC>
 DP_DEVICE void short_channels(const float* tab, const chan_par (&cp)[NC],
                               float* const (&area)[NC], float (&hx)[NC][8], float (&hy)[NC][8])
