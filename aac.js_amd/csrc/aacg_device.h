@@ -102,12 +102,13 @@ struct aacg_kparams {
     const aacg_dev_tns*   tns;        /* AACG_TNS_SPEC: indexed like aacg_unit_desc.tns_offset + c; else null */
     float*                pcm;
     float*                overlap;    /* overlap pool */
-    float*                scratch;    /* [n_runs][2048]: parked predecessor tails of double-duty runs */
     float*                spec_out;   /* spectral-only kernel */
     const aacg_tables*    tab;
     int32_t               flip;       /* 0/1: swap ov_a and ov_b (plan reuse, see aacg_engine.hip) */
     int32_t               n_runs;
     int32_t               ablate;     /* profiling only (env AACG_ABLATE): 1 skip IMDCT, 2 skip PCM stores, 4 skip spectrum loads */
+    int32_t               reserved;
+    float*                scratch;    /* [n_runs][2048]: parked predecessor tails of double-duty runs (last: the plain kernels never load it) */
 };
 
 #endif

@@ -1250,13 +1250,16 @@ DP_DEVICE void epilogue(const float* p0, const float* p1, const unit_view& u, in
     if (n_ch == 2 && C == 2 && cls0 == cls1 && ((u.pcm_offset | (uint32_t)u.channel) & 3u) == 0) {
         /* stereo fast path: (L[n], R[n], L[n+1], R[n+1]) = 16 bytes per lane */
         if (!cls0) {
+            /* all eight reads of the incoming tails first: one LDS (or HBM) round trip, not one per store */
+            dpf4 v[8];
+#pragma unroll
+            for (int m = 0; m < 8; m++) v[m] = incoming<FROM_LDS>(p0, p1, 2, 2 * lane + 128 * m);
 #pragma unroll
             for (int m = 0; m < 8; m++) {
                 const int n = 2 * lane + 128 * m;
-                const dpf4 v = incoming<FROM_LDS>(p0, p1, 2, n);
                 dpf4 o;
-                o.x = (v.x + hx0[m]) * S; o.y = (v.y + hx1[m]) * S;
-                o.z = (v.z + hy0[m]) * S; o.w = (v.w + hy1[m]) * S;
+                o.x = (v[m].x + hx0[m]) * S; o.y = (v[m].y + hx1[m]) * S;
+                o.z = (v[m].z + hy0[m]) * S; o.w = (v[m].w + hy1[m]) * S;
                 dp_store_nt((dpf4*)(pcm + 2 * n), o);
             }
         } else {

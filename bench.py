@@ -94,8 +94,10 @@ def cpu_baseline(kind, mix, budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=400)
-    ap.add_argument("--warmup", type=int, default=40)
+    ap.add_argument("--steps", type=int, default=20000)
+    ap.add_argument("--warmup", type=int, default=2000)
+    ap.add_argument("--precondition-ms", type=float, default=300.0,
+                    help="untimed load before the warm-up steps so that the GPU is at its steady clocks (0 = none)")
     ap.add_argument("--input", choices=["quant", "spec"], default="quant")
     ap.add_argument("--workload", choices=["cfg2", "cfg3", "cfg4", "cfg5"], default="cfg2")
     ap.add_argument("--tns", choices=["reference", "spec"], default="reference",
@@ -174,8 +176,19 @@ def main():
         pl = i % args.pipelines
         eng.decode_device(plans[pl], d_in.data_ptr(), meta_ptr, d_out.data_ptr(), tstreams[pl].cuda_stream)
 
+    # The GPU reaches its steady clocks only after tens of milliseconds of load: a 4096-frame step takes ~15 us,
+    # so a few hundred warm-up steps are over before the clocks have ramped (measured: 15.9 us per step after 40
+    # warm-up steps, 14.2 us after 4000).  Untimed preconditioning, reported in the JSON line; then the W warm-up
+    # steps of the contract; the timed region is exactly K steps.
+    n_pre = 0
+    t_pre = time.perf_counter()
+    while (time.perf_counter() - t_pre) * 1e3 < args.precondition_ms:
+        for _ in range(256):
+            step(n_pre)
+            n_pre += 1
+        torch.cuda.synchronize()
     for i in range(args.warmup):
-        step(i)
+        step(n_pre + i)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -184,7 +197,7 @@ def main():
     t0 = time.perf_counter()
     ev0.record()
     for i in range(args.steps):
-        step(args.warmup + i)
+        step(n_pre + args.warmup + i)
     for extra in tstreams[1:]:
         tstream.wait_stream(extra)                        # the closing event sees every pipeline
     ev1.record()
@@ -200,7 +213,7 @@ def main():
         elapsed = float(t.item())
 
     # sanity: the last output is finite and non-trivial (never part of the timed region)
-    out = bufs[(args.warmup + args.steps - 1) % args.nbuf][1]
+    out = bufs[(n_pre + args.warmup + args.steps - 1) % args.nbuf][1]
     ok = bool(torch.isfinite(out).all().item()) and float(out.abs().max().item()) > 0
 
     frames_per_step = n_streams * n_frames
@@ -222,6 +235,7 @@ def main():
                    else "f32 spectra (FilterBank.process seam)",
                    "streams_per_gpu": n_streams, "frames_per_stream_per_step": n_frames, "buffers_rotated": args.nbuf,
                    "realtime_multiple": value / 46.875, "sharding": "streams over ranks, no data-path collective", "pipelines": args.pipelines,
+                   "preconditioning": "%d untimed steps (%.0f ms of load) before the warm-up steps: steady GPU clocks" % (n_pre, args.precondition_ms),
                    "tns": "identity, as the reference executes it" if tns is None else "AACG_TNS_SPEC, filters on ~60 % of the channels"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,

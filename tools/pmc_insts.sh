@@ -7,7 +7,7 @@ for lib in "$@"; do
   OUT=$R/gpurun_out/pmc_insts/$lib
   mkdir -p $OUT
   AACGPU_LIB=$R/aac.js_amd/csrc/variants/$lib rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_BUSY_CYCLES \
-      --output-format csv -d $OUT -- python3 $R/bench.py --steps 40 --warmup 10 --no-cpu-baseline $ARGS > $OUT/log.txt 2>&1
+      --output-format csv -d $OUT -- python3 $R/bench.py --steps 40 --warmup 10 --precondition-ms 0 --no-cpu-baseline $ARGS > $OUT/log.txt 2>&1
   python3 - $OUT $lib <<'PY'
 import sys, glob, csv, collections
 out, lib = sys.argv[1], sys.argv[2]
