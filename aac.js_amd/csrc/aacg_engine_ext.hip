@@ -6,20 +6,19 @@
 
 #include "aacg_kernels.h"
 
+/* aacg_engine_tns.hip */
+int aacg_tns_set_lds_limits(void);
+void aacg_tns_launch(bool quant, dim3 grid, dim3 block, hipStream_t s, const aacg_kparams& P);
+
 /* Variants of aacg_imdct_run_quant / _f32:
  *   _dd : plans with full later runs (chains longer than 16 frames), whose first wave does double duty;
- *   _tns: AACG_TNS_SPEC batches that carry TNS side info (the planner gives those no full later runs). */
+ *   (_tns, for AACG_TNS_SPEC batches that carry TNS side info, is in aacg_engine_tns.hip) */
 extern "C" __global__ __launch_bounds__(AACG_WG_THREADS)
 void aacg_imdct_run_quant_dd(const aacg_kparams P) { imdct_run_body_dd<AACG_INPUT_QUANT_I16>(P); }
 
 extern "C" __global__ __launch_bounds__(AACG_WG_THREADS)
 void aacg_imdct_run_f32_dd(const aacg_kparams P) { imdct_run_body_dd<AACG_INPUT_SPEC_F32>(P); }
 
-extern "C" __global__ __launch_bounds__(AACG_WG_THREADS)
-void aacg_imdct_run_quant_tns(const aacg_kparams P) { imdct_run_body<AACG_INPUT_QUANT_I16, true>(P); }
-
-extern "C" __global__ __launch_bounds__(AACG_WG_THREADS)
-void aacg_imdct_run_f32_tns(const aacg_kparams P) { imdct_run_body<AACG_INPUT_SPEC_F32, true>(P); }
 
 
 int aacg_ext_set_lds_limits(void)
@@ -28,16 +27,14 @@ int aacg_ext_set_lds_limits(void)
     hipError_t rc = hipSuccess;
     if (rc == hipSuccess) rc = hipFuncSetAttribute((const void*)aacg_imdct_run_quant_dd, hipFuncAttributeMaxDynamicSharedMemorySize, AACG_LDS_BYTES_QUANT);
     if (rc == hipSuccess) rc = hipFuncSetAttribute((const void*)aacg_imdct_run_f32_dd, hipFuncAttributeMaxDynamicSharedMemorySize, AACG_LDS_BYTES_F32);
-    if (rc == hipSuccess) rc = hipFuncSetAttribute((const void*)aacg_imdct_run_quant_tns, hipFuncAttributeMaxDynamicSharedMemorySize, AACG_LDS_BYTES_QUANT);
-    if (rc == hipSuccess) rc = hipFuncSetAttribute((const void*)aacg_imdct_run_f32_tns, hipFuncAttributeMaxDynamicSharedMemorySize, AACG_LDS_BYTES_F32);
+    if (rc == hipSuccess && aacg_tns_set_lds_limits() != 0) rc = hipErrorUnknown;
     return rc == hipSuccess ? 0 : -1;
 }
 
 void aacg_ext_launch(bool quant, bool tns, dim3 grid, dim3 block, hipStream_t s, const aacg_kparams& P)
 {
     if (tns) {
-        if (quant) hipLaunchKernelGGL(aacg_imdct_run_quant_tns, grid, block, AACG_LDS_BYTES_QUANT, s, P);
-        else       hipLaunchKernelGGL(aacg_imdct_run_f32_tns, grid, block, AACG_LDS_BYTES_F32, s, P);
+        aacg_tns_launch(quant, grid, block, s, P);
     } else {
         if (quant) hipLaunchKernelGGL(aacg_imdct_run_quant_dd, grid, block, AACG_LDS_BYTES_QUANT, s, P);
         else       hipLaunchKernelGGL(aacg_imdct_run_f32_dd, grid, block, AACG_LDS_BYTES_F32, s, P);

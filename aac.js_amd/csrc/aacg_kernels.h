@@ -1413,12 +1413,13 @@ DP_DEVICE void imdct_run_body(const aacg_kparams& P)
     const float* xsrc = (const float*)P.coeffs + (size_t)u.coef_offset * 1024u;
     const float* xsrc1 = xsrc + (u.n_ch == 2 ? 1024 : 0);
     /* Load staggering (measured: -1 us on the f32 path).  The first four frames of the run (the highest-
-     * priority waves, one per SIMD) request their spectra first and alone: the table barrier below is only
+     * priority waves, one per SIMD; two on the int16 path, where a sweep of 0..8 early waves at steady clocks
+     * gave 14.5 / 14.2 / 13.5 / 13.9 / 14.1 / - / - / - / 14.8 us) request their spectra first and alone: the table barrier below is only
      * released once their data has landed (the loads sit under a condition, so hipcc waits for them at the
      * join), and only then do the other twelve waves issue their requests.  The first group therefore sees
      * its data after ~1.7 us instead of queueing behind the whole chip's 33 MB, and the later groups' data
      * arrives while the SIMD is still busy with the earlier ones. */
-    const bool early = wave < 4 || (P.ablate & 128);
+    const bool early = wave < (KIND == AACG_INPUT_QUANT_I16 ? 2 : 4) || (P.ablate & 128);
     if (early) {
         if (KIND == AACG_INPUT_QUANT_I16) quant_load(P, u, u.n_ch, qreg);
         else {
@@ -1619,12 +1620,13 @@ DP_DEVICE void imdct_run_body_dd(const aacg_kparams& P)
         }
     };
     /* Load staggering (measured: -1 us on the f32 path).  The first four frames of the run (the highest-
-     * priority waves, one per SIMD) request their spectra first and alone: the table barrier below is only
+     * priority waves, one per SIMD; two on the int16 path, where a sweep of 0..8 early waves at steady clocks
+     * gave 14.5 / 14.2 / 13.5 / 13.9 / 14.1 / - / - / - / 14.8 us) request their spectra first and alone: the table barrier below is only
      * released once their data has landed (the loads sit under a condition, so hipcc waits for them at the
      * join), and only then do the other twelve waves issue their requests.  The first group therefore sees
      * its data after ~1.7 us instead of queueing behind the whole chip's 33 MB, and the later groups' data
      * arrives while the SIMD is still busy with the earlier ones. */
-    const bool early = wave < 4 || (P.ablate & 128);
+    const bool early = wave < (KIND == AACG_INPUT_QUANT_I16 ? 2 : 4) || (P.ablate & 128);
     if (early) issue_loads();
     stage_tables_store(lds, TAB_FLOATS, tr0, tr1);
     if (lane == 0) flags[wave] = 0;
