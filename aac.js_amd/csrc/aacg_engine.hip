@@ -43,6 +43,7 @@ struct aacg_engine {
     aacg_tables* d_tab = nullptr;
     float* d_overlap = nullptr;             /* [max_streams][max_channels][2][1024] */
     std::vector<uint8_t> parity;            /* live buffer per (stream, channel) */
+    uint64_t epoch = 0;                     /* bumped whenever `parity` changes: lets a relaunched plan skip its check */
     aacg_tables h_tab;
     aacg_host_windows h_win;
     /* host-buffer path: two pipeline slots (stream + device buffers grown on demand) */
@@ -78,6 +79,7 @@ struct aacg_plan {
     aacg_run* d_runs = nullptr;
     aacg_dev_tns* d_tns = nullptr;
     float* d_scratch = nullptr;             /* parked predecessor tails of double-duty runs */
+    uint64_t seen_epoch = ~0ull;            /* engine epoch right after this plan's last launch */
     uint32_t launches = 0;
 };
 
@@ -353,7 +355,8 @@ int aacg_decode_device(aacg_engine* e, aacg_plan* p, const void* d_coeffs, const
     if (!e || !p || p->e != e || !d_coeffs || !d_pcm) return AACG_ERR_INVALID_ARG;
     const bool quant = e->cfg.input_kind == AACG_INPUT_QUANT_I16;
     if (quant && !d_meta) { e->err = "QUANT_I16 engine needs band meta"; return AACG_ERR_INVALID_ARG; }
-    int rc = plan_check_parity(e, p);
+    /* relaunched back to back (nothing else advanced any stream since): the per-chain check is known to pass */
+    int rc = p->seen_epoch == e->epoch ? AACG_OK : plan_check_parity(e, p);
     if (rc) return rc;
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : e->stream;
     rc = launch_run(e, p->d_units, p->d_runs, p->d_tns, p->d_scratch, p->h, d_coeffs, d_meta, d_pcm, (int)(p->launches & 1u), s);
@@ -363,6 +366,7 @@ int aacg_decode_device(aacg_engine* e, aacg_plan* p, const void* d_coeffs, const
         for (int k = 0; k < c.n_ch; k++)
             e->parity[(size_t)c.stream * (size_t)e->cfg.max_channels + c.channel + k] ^= 1;
     p->launches++;
+    p->seen_epoch = ++e->epoch;
     return AACG_OK;
 }
 
@@ -518,6 +522,7 @@ int aacg_submit_tns(aacg_engine* e, const aacg_unit_desc* units, uint32_t n_unit
     for (const aacg_chain& c : h.chains)
         for (int k = 0; k < c.n_ch; k++)
             e->parity[(size_t)c.stream * (size_t)e->cfg.max_channels + c.channel + k] ^= 1;
+    e->epoch++;
     *ticket = ++e->submitted;
     return AACG_OK;
 }

@@ -198,6 +198,7 @@ def main():
     ev0.record()
     for i in range(args.steps):
         step(n_pre + args.warmup + i)
+    t_issued = time.perf_counter() - t0                   # host time to enqueue the K launches
     for extra in tstreams[1:]:
         tstream.wait_stream(extra)                        # the closing event sees every pipeline
     ev1.record()
@@ -240,7 +241,8 @@ def main():
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                      "kernel": (eng.kernel_name() if args.input == "quant" else "aacg_imdct_run_f32") + ("_tns" if tns is not None else ""),
-                     "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": abytes},
+                     "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": abytes,
+                     "host_enqueue_us_per_step": t_issued / args.steps * 1e6},
         "output_ok": ok,
     }
     if rank == 0 and not args.no_cpu_baseline and world == 1:
