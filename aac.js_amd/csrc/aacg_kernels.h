@@ -808,10 +808,13 @@ DP_DEVICE void prepare_bands(const quant_regs& r, const float (&sl_in)[2], const
 DP_DEVICE void dequant4(int iq0, float sf_eff, float z_eff, int p01, int p23, float (&x)[4], int& oor)
 {
     oor |= dp_pk_add_u16(p01, 0x02000200) | dp_pk_add_u16(p23, 0x02000200);
-    x[0] = dp_fma(dp_lds_read_f32(dp_mad4_i16_lo(p01, iq0)), sf_eff, z_eff);
-    x[1] = dp_fma(dp_lds_read_f32(dp_mad4_i16_hi(p01, iq0)), sf_eff, z_eff);
-    x[2] = dp_fma(dp_lds_read_f32(dp_mad4_i16_lo(p23, iq0)), sf_eff, z_eff);
-    x[3] = dp_fma(dp_lds_read_f32(dp_mad4_i16_hi(p23, iq0)), sf_eff, z_eff);
+    dpv2 a, b, sf, z;
+    a[0] = dp_lds_read_f32(dp_mad4_i16_lo(p01, iq0)); a[1] = dp_lds_read_f32(dp_mad4_i16_hi(p01, iq0));
+    b[0] = dp_lds_read_f32(dp_mad4_i16_lo(p23, iq0)); b[1] = dp_lds_read_f32(dp_mad4_i16_hi(p23, iq0));
+    sf[0] = sf[1] = sf_eff; z[0] = z[1] = z_eff;
+    a = dp_fma2(a, sf, z);                             /* v_pk_fma_f32: two coefficients per instruction */
+    b = dp_fma2(b, sf, z);
+    x[0] = a[0]; x[1] = a[1]; x[2] = b[0]; x[3] = b[1];
 }
 #define AACG_OOR_MASK ((int)0xFC00FC00)                /* some q + 512 outside 0..1023 */
 
@@ -902,11 +905,15 @@ DP_DEVICE void spectral_quant(const aacg_kparams& P, const float* tab, const uni
 #pragma unroll
             for (int k = 0; k < 4; k++) {
 #pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    const float a = xl[4 * k + e], b = xr[4 * k + e];
-                    const float sum = a + b, dif = a - b;
-                    xl[4 * k + e] = g_ms[k] ? sum : a;
-                    xr[4 * k + e] = g_ms[k] ? dif : b;
+                for (int e = 0; e < 4; e += 2) {       /* sums and differences two at a time (v_pk_add_f32) */
+                    dpv2 a, b;
+                    a[0] = xl[4 * k + e]; a[1] = xl[4 * k + e + 1];
+                    b[0] = xr[4 * k + e]; b[1] = xr[4 * k + e + 1];
+                    const dpv2 sum = a + b, dif = a - b;
+                    xl[4 * k + e]     = g_ms[k] ? sum[0] : a[0];
+                    xl[4 * k + e + 1] = g_ms[k] ? sum[1] : a[1];
+                    xr[4 * k + e]     = g_ms[k] ? dif[0] : b[0];
+                    xr[4 * k + e + 1] = g_ms[k] ? dif[1] : b[1];
                 }
             }
         }

@@ -102,6 +102,7 @@ DP_DEVICE int dp_pk_add_u16(int a, int b)
 }
 DP_DEVICE float dp_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 DP_DEVICE double dp_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+DP_DEVICE dpv2 dp_fma2(dpv2 a, dpv2 b, dpv2 c) { return __builtin_elementwise_fma(a, b, c); }
 /* true in every lane if the predicate holds in any lane of the wave */
 DP_DEVICE bool dp_any(bool p) { return __any(p) != 0; }
 /* hide a value from common-subexpression elimination: a table load behind it is re-issued

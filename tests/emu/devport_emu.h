@@ -107,6 +107,7 @@ DP_DEVICE int dp_pk_add_u16(int a, int b)
 }
 DP_DEVICE float dp_fma(float a, float b, float c) { return fmaf(a, b, c); }
 DP_DEVICE double dp_fma(double a, double b, double c) { return fma(a, b, c); }
+DP_DEVICE dpv2 dp_fma2(dpv2 a, dpv2 b, dpv2 c) { dpv2 r; r[0] = fmaf(a[0], b[0], c[0]); r[1] = fmaf(a[1], b[1], c[1]); return r; }
 DP_DEVICE void dp_store_nt(dpf4* p, dpf4 v) { *p = v; }
 DP_DEVICE dpf4 dp_load_nt(const dpf4* p) { return *p; }
 DP_DEVICE dpi4 dp_load_nt_i4(const dpi4* p) { return *p; }
