@@ -67,6 +67,53 @@ const tnsLong = { short: false, nFilt: [2], length: [[20, 9]], order: [[3, 1]], 
     const ub = host.packUnits([u]);
     assert.deepStrictEqual([ub[24 + 5], ub[40 + 5], new DataView(ub.buffer).getUint32(56, true)], [0, 1, 6]);
 }
+// ADTS framing (aac.js_amd/js/adts.js): headers built here bit by bit from the field layout
+{
+    const adts = require(path.join(__dirname, '..', '..', 'aac.js_amd', 'js', 'adts.js'));
+    const header = function (profile, sr, ch, frameLength, crc) {
+        const bits = [];
+        const put = function (v, n) { for (let i = n - 1; i >= 0; i--) bits.push((v >> i) & 1); };
+        put(0xfff, 12); put(0, 1); put(0, 2); put(crc ? 0 : 1, 1); put(profile - 1, 2); put(sr, 4); put(0, 1); put(ch, 3);
+        put(0, 4); put(frameLength, 13); put(0x7ff, 11); put(0, 2);
+        if (crc) put(0xbeef, 16);
+        const b = new Uint8Array(bits.length / 8);
+        bits.forEach(function (x, i) { b[i >> 3] |= x << (7 - (i & 7)); });
+        return b;
+    };
+    const frame = function (profile, sr, ch, payload, crc) {
+        const h = header(profile, sr, ch, (crc ? 9 : 7) + payload, crc), f = new Uint8Array(h.length + payload);
+        f.set(h); for (let i = h.length; i < f.length; i++) f[i] = (i * 37) & 0x7f;          // never looks like a syncword
+        return f;
+    };
+    const h = adts.readHeader(new host.BitReader(header(2, 3, 2, 345, false)));
+    assert.deepStrictEqual(h, { profile: 2, samplingIndex: 3, chanConfig: 2, frameLength: 345, numFrames: 1, headerBytes: 7 });
+    const r = new host.BitReader(header(2, 4, 6, 100, true));
+    assert.strictEqual(adts.readHeader(r).headerBytes, 9);
+    assert.strictEqual(r.pos, 72);                                                           // the CRC is consumed too
+    assert.throws(() => adts.readHeader(new host.BitReader(new Uint8Array([0xff, 0xe1, 0, 0, 0, 0, 0]))), /Invalid ADTS header/);
+    // the synthesised cookie parses back to the same configuration (adts_demuxer.js:66-70 -> decoder.js:53-113)
+    const dec = new host.GpuAACDecoder({ engine: { resetStream: function () {} } });
+    dec.setCookie(adts.cookie(h));
+    assert.deepStrictEqual([dec.config.profile, dec.config.sampleIndex, dec.config.chanConfig], [2, 3, 2]);
+    // probe: syncword at an even offset only, like the reference's readUInt16 loop
+    assert.strictEqual(adts.probe(frame(2, 3, 2, 20, false)), true);
+    assert.strictEqual(adts.probe(new Uint8Array([0, 0xff, 0xf1, 0, 0, 0])), false);
+    assert.strictEqual(adts.probe(new Uint8Array([0, 0, 0xff, 0xf1, 0, 0])), true);
+    assert.strictEqual(adts.probe(new Uint8Array([1, 2, 3, 4])), false);
+    // frames(): complete frames only
+    const f1 = frame(2, 3, 2, 50, false), f2 = frame(2, 3, 2, 70, true), f3 = frame(2, 3, 2, 30, false);
+    const buf = new Uint8Array(f1.length + f2.length + f3.length - 5);
+    buf.set(f1); buf.set(f2, f1.length); buf.set(f3.subarray(0, f3.length - 5), f1.length + f2.length);
+    const fr = adts.frames(buf);
+    assert.deepStrictEqual(fr.map(function (x) { return [x.offset, x.length]; }), [[0, 57], [57, 79]]);
+    // demuxer events: format, cookie, data — once, then data only
+    const ev = [];
+    const dm = new adts.AdtsDemuxer(function (name, payload) { ev.push([name, payload]); });
+    dm.push(f1); dm.push(f2);
+    assert.deepStrictEqual(ev.map(function (e) { return e[0]; }), ['format', 'cookie', 'data', 'data']);
+    assert.deepStrictEqual(ev[0][1], { formatID: 'aac ', sampleRate: 48000, channelsPerFrame: 2, bitsPerChannel: 16 });
+    assert.deepStrictEqual(Array.from(ev[1][1]), [17, 144]);
+}
 console.log('host cpu tests ok');
 if (mode !== 'gpu') process.exit(0);
 
