@@ -106,6 +106,17 @@ function packBandWord(bandType, sfIndex, negate, msUsed) {
     return (sfIndex & 0x1ff) | (negate ? 0x200 : 0) | (msUsed ? 0x400 : 0) | ((bandType & 15) << 12);
 }
 
+/* Pulse data (ics.js:175-201 parses it; ics.js:263-265 then throws 'TODO: add pulse data').  The standard's rule
+ * (ISO/IEC 14496-3 4.6.3.3) works on the quantised integers, i.e. on this seam's input: coefficient
+ * pulseOffset[i] moves away from zero by pulseAmp[i] (long windows only).  q: the channel's Int16Array(1024). */
+function applyPulses(q, pulseOffset, pulseAmp) {
+    for (let i = 0; i < pulseOffset.length; i++) {
+        const k = pulseOffset[i];
+        if (k > 1023) throw new Error('Pulse offset out of range: ' + k);       // ics.js:192-198
+        q[k] += q[k] > 0 ? pulseAmp[i] : -pulseAmp[i];
+    }
+}
+
 /* ---- engine wrapper ---------------------------------------------------------------------------- */
 function Engine(opts) {
     opts = opts || {};
@@ -172,6 +183,9 @@ function GpuAACDecoder(opts) {
      * (default) reproduces that; TNS_SPEC applies the filter, taking each channel's side info from
      * chanInfo.tns (an object shaped like the reference's TNS instance, tns.js:22-44). */
     this.tnsMode = opts.tnsMode | 0;
+    /* chanInfo.pulse = { offset: [...], amp: [...] } (ics.pulseOffset / pulseAmp): aac.js throws 'TODO: add pulse
+     * data' on such a frame (ics.js:263-265); applyPulses: true adds them to the quantised spectrum instead. */
+    this.applyPulses = !!opts.applyPulses;
     this.prevShape = [];
     this.queue = [];
 }
@@ -216,6 +230,10 @@ GpuAACDecoder.prototype.unitsOfFrame = function (frame, frameSlot, blockBase, tn
         for (let c = 0; c < n; c++) {
             e.ch[c].windowShapePrev = this.carryWindowShape ? (this.prevShape[channel + c] | 0) : 0;
             this.prevShape[channel + c] = e.ch[c].windowShape;
+            if (e.ch[c].pulse) {
+                if (!this.applyPulses) throw new Error('TODO: add pulse data');
+                applyPulses(frame.q.subarray(FRAME * (block - blockBase + c), FRAME * (block - blockBase + c + 1)), e.ch[c].pulse.offset, e.ch[c].pulse.amp);
+            }
         }
         let tnsOffset = 0;
         if (tnsList && e.ch.some(function (c) { return !!c.tns; })) {       // ics.tnsPresent (ics.js:71), TNS_SPEC engines only
@@ -260,5 +278,5 @@ GpuAACDecoder.prototype.readChunk = function () {
     return this.queue.shift();
 };
 
-module.exports = { Engine, GpuAACDecoder, BitReader, packUnits, unpackUnits, packBandWord, packTns,
+module.exports = { Engine, GpuAACDecoder, BitReader, packUnits, unpackUnits, packBandWord, packTns, applyPulses,
                    INPUT_SPEC_F32, INPUT_QUANT_I16, TNS_REFERENCE, TNS_SPEC, UNIT_BYTES, META_WORDS, TNS_BYTES, SAMPLE_RATES };

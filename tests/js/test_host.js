@@ -67,6 +67,24 @@ const tnsLong = { short: false, nFilt: [2], length: [[20, 9]], order: [[3, 1]], 
     const ub = host.packUnits([u]);
     assert.deepStrictEqual([ub[24 + 5], ub[40 + 5], new DataView(ub.buffer).getUint32(56, true)], [0, 1, 6]);
 }
+// pulse data: away from zero on the quantised integers; the reference's behaviour (throw) is the default
+{
+    const q = new Int16Array(1024); q[10] = 3; q[11] = -2; q[40] = 0;
+    host.applyPulses(q, [10, 11, 40], [5, 7, 1]);
+    assert.deepStrictEqual([q[10], q[11], q[40]], [8, -9, -1]);                // q == 0 moves down, like the standard's `else` branch
+    assert.throws(() => host.applyPulses(q, [1024], [1]), /Pulse offset out of range/);
+    const mk = function (applyPulses) {
+        const fq = new Int16Array(2048); fq[1024 + 7] = 4;
+        const dec = new host.GpuAACDecoder({ engine: { resetStream: function () {} }, applyPulses: applyPulses });
+        dec.setCookie(new Uint8Array([(2 << 3) | (3 >> 1), ((3 & 1) << 7) | (2 << 3)]));
+        const ch = function (pulse) { return { windowSequence: 0, windowShape: 1, maxSFB: 49, groupLength: [1], pulse: pulse }; };
+        const frame = { elements: [{ type: 'cpe', commonWindow: true, maskPresent: false, ch: [ch(null), ch({ offset: [7], amp: [3] })] }], q: fq, meta: new Uint16Array(240) };
+        dec.unitsOfFrame(frame, 0, 0, null);
+        return fq[1024 + 7];
+    };
+    assert.strictEqual(mk(true), 7);
+    assert.throws(() => mk(false), /TODO: add pulse data/);
+}
 // ADTS framing (aac.js_amd/js/adts.js): headers built here bit by bit from the field layout
 {
     const adts = require(path.join(__dirname, '..', '..', 'aac.js_amd', 'js', 'adts.js'));
