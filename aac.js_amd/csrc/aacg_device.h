@@ -78,6 +78,16 @@ struct aacg_dev_tns {
     float   lpc[8][AACG_TNS_MAX_ORDER];
 };
 
+/* AACG_PNS_SPEC: the noise generator's whole sequence (it restarts for every channel of every frame, so it is a
+ * fixed table), the running sum of its squares (a band-window's energy is a difference of two entries) and the
+ * scalefactor-band offsets of the engine's sample rate.  Global memory, read only where a band is NOISE_BT. */
+struct aacg_pns_tables {
+    float    rnd[1024];               /* rnd[p] = (float)state after p + 1 steps of state * 1664525 + 1013904223 from 0x1F2E3D4C */
+    double   esum[1028];              /* esum[p] = sum of rnd[i]^2 for i < p, p = 0..1024 */
+    uint16_t swb_long[64];            /* swbOffsets of the long / short window (tables.js:34-155), [swbCount] = 1024 / 128 */
+    uint16_t swb_short[16];
+};
+
 /* One workgroup's work: consecutive frames of one element of one stream.  The first run of a
  * chain holds up to 16 units (wave w = unit w, wave 0 starts from the overlap state); a later
  * run holds up to 15 units in waves 1..15 and wave 0 recomputes the tail of pred_unit. */
@@ -109,6 +119,7 @@ struct aacg_kparams {
     int32_t               ablate;     /* profiling only (env AACG_ABLATE): 1 skip IMDCT, 2 skip PCM stores, 4 skip spectrum loads */
     int32_t               reserved;
     float*                scratch;    /* [n_runs][2048]: parked predecessor tails of double-duty runs (last: the plain kernels never load it) */
+    const aacg_pns_tables* pns;       /* AACG_PNS_SPEC: the spectral stage's noise tables */
 };
 
 #endif

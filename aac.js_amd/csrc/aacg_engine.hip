@@ -30,6 +30,9 @@ void aacg_imdct_run_f32(const aacg_kparams P) { imdct_run_body<AACG_INPUT_SPEC_F
  * two kernels above. */
 int aacg_ext_set_lds_limits(void);
 void aacg_ext_launch(bool quant, bool tns, dim3 grid, dim3 block, hipStream_t s, const aacg_kparams& P);
+/* aacg_engine_pns.hip: the spectral stage with PNS (AACG_PNS_SPEC), quantised input -> f32 spectra */
+int aacg_pns_set_lds_limits(void);
+void aacg_pns_launch(int n_units, hipStream_t s, const aacg_kparams& P);
 
 extern "C" __global__ __launch_bounds__(AACG_WG_THREADS)
 void aacg_spectral(const aacg_kparams P, int n_units) { spectral_body(P, n_units); }
@@ -41,6 +44,7 @@ struct aacg_engine {
     aacg_config cfg;
     hipStream_t stream = nullptr;
     aacg_tables* d_tab = nullptr;
+    aacg_pns_tables* d_pns = nullptr;       /* AACG_PNS_SPEC */
     float* d_overlap = nullptr;             /* [max_streams][max_channels][2][1024] */
     std::vector<uint8_t> parity;            /* live buffer per (stream, channel) */
     uint64_t epoch = 0;                     /* bumped whenever `parity` changes: lets a relaunched plan skip its check */
@@ -57,6 +61,7 @@ struct aacg_engine {
         void* d_meta = nullptr;   size_t meta_cap = 0;
         void* d_tns = nullptr;    size_t tns_cap = 0;
         void* d_scratch = nullptr; size_t scratch_cap = 0;
+        void* d_spec = nullptr;   size_t spec_cap = 0;       /* PNS route: f32 spectra between the two kernels */
         void* d_pcm = nullptr;    size_t pcm_cap = 0;
         /* page-locked staging for callers that pass ordinary (pageable) memory */
         void* h_in = nullptr;     size_t h_in_cap = 0;
@@ -79,6 +84,7 @@ struct aacg_plan {
     aacg_run* d_runs = nullptr;
     aacg_dev_tns* d_tns = nullptr;
     float* d_scratch = nullptr;             /* parked predecessor tails of double-duty runs */
+    float* d_spec = nullptr;                /* PNS route: f32 spectra between the two kernels */
     uint64_t seen_epoch = ~0ull;            /* engine epoch right after this plan's last launch */
     uint32_t launches = 0;
 };
@@ -124,21 +130,30 @@ bool is_pinned(const void* p)
 
 /* enqueue the run kernel for a planned batch (device pointers) */
 int launch_run(aacg_engine* e, const aacg_dev_unit* d_units, const aacg_run* d_runs, const aacg_dev_tns* d_tns,
-               float* d_scratch, const aacg_plan_host& h, const void* d_coeffs, const aacg_band_meta* d_meta, float* d_pcm, int flip,
-               hipStream_t s)
+               float* d_scratch, float* d_spec, const aacg_plan_host& h, const void* d_coeffs, const aacg_band_meta* d_meta,
+               float* d_pcm, int flip, hipStream_t s)
 {
-    const bool quant = e->cfg.input_kind == AACG_INPUT_QUANT_I16;
+    bool quant = e->cfg.input_kind == AACG_INPUT_QUANT_I16;
     if (h.zero_fill)
         HIP_TRY(e, hipMemsetAsync(d_pcm, 0, h.pcm_floats * sizeof(float), s), AACG_ERR_NO_DEVICE);
     aacg_kparams P;
     P.units = d_units; P.runs = d_runs; P.coeffs = d_coeffs; P.meta = d_meta; P.pcm = d_pcm;
     P.tns = h.any_tns ? d_tns : nullptr;
     P.scratch = h.needs_scratch ? d_scratch : nullptr;
+    P.pns = nullptr;
     P.overlap = e->d_overlap; P.spec_out = nullptr; P.tab = e->d_tab;
     P.flip = flip; P.n_runs = (int32_t)h.runs.size();
     P.ablate = e->d_trace ? e->ablate : (e->ablate & ~16);
     if (e->d_trace) P.spec_out = (float*)e->d_trace;
     const dim3 grid((unsigned)h.runs.size()), block(AACG_WG_THREADS);
+    if (quant && h.any_pns) {
+        /* AACG_PNS_SPEC: dequant + MS + IS + noise bands to f32 spectra, which the f32 run kernel takes from there */
+        float* trace_or_null = P.spec_out;
+        P.spec_out = d_spec; P.pns = e->d_pns;
+        aacg_pns_launch((int)h.units.size(), s, P);
+        P.spec_out = trace_or_null; P.coeffs = d_spec; P.meta = nullptr;
+        quant = false;
+    }
     if (P.tns || h.needs_scratch) {
         aacg_ext_launch(quant, P.tns != nullptr, grid, block, s, P);
     } else {
@@ -165,6 +180,8 @@ int aacg_create(const aacg_config* cfg, aacg_engine** out)
     *out = nullptr;
     if (cfg->abi_version != AACG_ABI_VERSION || cfg->max_streams < 1 || cfg->max_channels < 1 ||
         cfg->max_channels > AACG_MAX_CHANNELS || (cfg->tns_mode != AACG_TNS_REFERENCE && cfg->tns_mode != AACG_TNS_SPEC) ||
+        (cfg->pns_mode != AACG_PNS_REFERENCE && cfg->pns_mode != AACG_PNS_SPEC) ||
+        (cfg->pns_mode == AACG_PNS_SPEC && cfg->input_kind != AACG_INPUT_QUANT_I16) ||
         (cfg->input_kind != AACG_INPUT_SPEC_F32 && cfg->input_kind != AACG_INPUT_QUANT_I16))
         return AACG_ERR_INVALID_ARG;
 
@@ -188,13 +205,21 @@ int aacg_create(const aacg_config* cfg, aacg_engine** out)
         /* ~158 KiB of dynamic LDS per workgroup is above the 64 KiB default limit */
         !hip_ok(e, hipFuncSetAttribute((const void*)aacg_imdct_run_quant, hipFuncAttributeMaxDynamicSharedMemorySize, AACG_LDS_BYTES_QUANT), "LDS attr") ||
         !hip_ok(e, hipFuncSetAttribute((const void*)aacg_imdct_run_f32, hipFuncAttributeMaxDynamicSharedMemorySize, AACG_LDS_BYTES_F32), "LDS attr") ||
-        aacg_ext_set_lds_limits() != 0 ||
+        aacg_ext_set_lds_limits() != 0 || aacg_pns_set_lds_limits() != 0 ||
         !hip_ok(e, hipFuncSetAttribute((const void*)aacg_spectral, hipFuncAttributeMaxDynamicSharedMemorySize, AACG_LDS_BYTES_SPECTRAL), "LDS attr")) {
         std::fprintf(stderr, "aacgpu: %s\n", e->err.c_str());
         aacg_destroy(e);
         return AACG_ERR_NO_DEVICE;
     }
     e->parity.assign((size_t)cfg->max_streams * (size_t)cfg->max_channels, 0);
+    if (cfg->pns_mode == AACG_PNS_SPEC) {
+        aacg_pns_tables* pt = new (std::nothrow) aacg_pns_tables;
+        const bool ok = pt && aacg_build_pns_tables(cfg->sample_index, pt) == AACG_OK &&
+                        hip_ok(e, hipMalloc((void**)&e->d_pns, sizeof *pt), "hipMalloc pns tables") &&
+                        hip_ok(e, hipMemcpy(e->d_pns, pt, sizeof *pt, hipMemcpyHostToDevice), "upload pns tables");
+        delete pt;
+        if (!ok) { aacg_destroy(e); return AACG_ERR_OUT_OF_MEMORY; }
+    }
     if (const char* a = std::getenv("AACG_ABLATE")) e->ablate = std::atoi(a);
     if ((e->ablate & 16) && hipMalloc(&e->d_trace, 1u << 22) == hipSuccess) (void)hipMemset(e->d_trace, 0, 1u << 22);
     *out = e;
@@ -207,9 +232,10 @@ void aacg_destroy(aacg_engine* e)
     (void)hipSetDevice(e->cfg.device_ordinal);
     (void)hipDeviceSynchronize();
     if (e->d_tab) (void)hipFree(e->d_tab);
+    if (e->d_pns) (void)hipFree(e->d_pns);
     if (e->d_overlap) (void)hipFree(e->d_overlap);
     for (auto& sl : e->slot) {
-        for (void* p : {sl.d_units, sl.d_runs, sl.d_coeffs, sl.d_meta, sl.d_tns, sl.d_scratch, sl.d_pcm}) if (p) (void)hipFree(p);
+        for (void* p : {sl.d_units, sl.d_runs, sl.d_coeffs, sl.d_meta, sl.d_tns, sl.d_scratch, sl.d_spec, sl.d_pcm}) if (p) (void)hipFree(p);
         if (sl.h_in) (void)hipHostFree(sl.h_in);
         if (sl.h_pcm) (void)hipHostFree(sl.h_pcm);
         if (sl.done) (void)hipEventDestroy(sl.done);
@@ -308,7 +334,13 @@ int aacg_plan_create_tns(aacg_engine* e, const aacg_unit_desc* units, uint32_t n
     int rc = aacg_plan_build(units, n_units, e->cfg.sample_index, e->cfg.max_streams, e->cfg.max_channels,
                              e->parity.data(), &p->h, &e->err, tns, n_tns);
     if (rc) { delete p; return rc; }
+    if (p->h.any_pns && e->cfg.pns_mode != AACG_PNS_SPEC) {
+        e->err = "a unit carries AACG_UNIT_HAS_PNS: NOISE_BT bands are not decodable by the reference either (AACG_PNS_SPEC engines fill them)";
+        delete p;
+        return AACG_ERR_UNSUPPORTED;
+    }
     const size_t ub = sizeof(aacg_dev_unit) * n_units, rb = sizeof(aacg_run) * p->h.runs.size();
+    const size_t xb = p->h.any_pns ? (size_t)p->h.coef_blocks * 1024u * sizeof(float) : 0;
     const size_t tb = sizeof(aacg_dev_tns) * p->h.tns.size();
     const size_t sb = p->h.needs_scratch ? p->h.runs.size() * AACG_SLOT_FLOATS * sizeof(float) : 0;
     if (!hip_ok(e, hipSetDevice(e->cfg.device_ordinal), "hipSetDevice") ||
@@ -318,7 +350,8 @@ int aacg_plan_create_tns(aacg_engine* e, const aacg_unit_desc* units, uint32_t n
         !hip_ok(e, hipMemcpy(p->d_runs, p->h.runs.data(), rb, hipMemcpyHostToDevice), "upload runs") ||
         (tb && (!hip_ok(e, hipMalloc((void**)&p->d_tns, tb), "hipMalloc tns") ||
                 !hip_ok(e, hipMemcpy(p->d_tns, p->h.tns.data(), tb, hipMemcpyHostToDevice), "upload tns"))) ||
-        (sb && !hip_ok(e, hipMalloc((void**)&p->d_scratch, sb), "hipMalloc scratch"))) {
+        (sb && !hip_ok(e, hipMalloc((void**)&p->d_scratch, sb), "hipMalloc scratch")) ||
+        (xb && !hip_ok(e, hipMalloc((void**)&p->d_spec, xb), "hipMalloc spectra"))) {
         aacg_plan_destroy(p);
         return AACG_ERR_OUT_OF_MEMORY;
     }
@@ -334,6 +367,7 @@ void aacg_plan_destroy(aacg_plan* p)
     if (p->d_runs) (void)hipFree(p->d_runs);
     if (p->d_tns) (void)hipFree(p->d_tns);
     if (p->d_scratch) (void)hipFree(p->d_scratch);
+    if (p->d_spec) (void)hipFree(p->d_spec);
     delete p;
 }
 
@@ -359,7 +393,7 @@ int aacg_decode_device(aacg_engine* e, aacg_plan* p, const void* d_coeffs, const
     int rc = p->seen_epoch == e->epoch ? AACG_OK : plan_check_parity(e, p);
     if (rc) return rc;
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : e->stream;
-    rc = launch_run(e, p->d_units, p->d_runs, p->d_tns, p->d_scratch, p->h, d_coeffs, d_meta, d_pcm, (int)(p->launches & 1u), s);
+    rc = launch_run(e, p->d_units, p->d_runs, p->d_tns, p->d_scratch, p->d_spec, p->h, d_coeffs, d_meta, d_pcm, (int)(p->launches & 1u), s);
     if (rc) return rc;
 
     for (const aacg_chain& c : p->h.chains)
@@ -463,21 +497,32 @@ int aacg_submit_tns(aacg_engine* e, const aacg_unit_desc* units, uint32_t n_unit
                 const aacg_band_meta& m = meta[units[i].meta_offset + (uint32_t)c];
                 for (int b = 0; b < ci.group_count * ci.max_sfb; b++)
                     if ((m.band[b] >> AACG_META_BT_SHIFT) == AACG_NOISE_BT) {
-                        e->err = "NOISE_BT (PNS) band: not decodable by the reference either";
-                        return AACG_ERR_UNSUPPORTED;
+                        if (e->cfg.pns_mode != AACG_PNS_SPEC) {
+                            e->err = "NOISE_BT (PNS) band: not decodable by the reference either";
+                            return AACG_ERR_UNSUPPORTED;
+                        }
+                        if (!(units[i].flags & AACG_UNIT_HAS_PNS)) {
+                            e->err = "a unit has a NOISE_BT band but not AACG_UNIT_HAS_PNS";
+                            return AACG_ERR_INVALID_ARG;
+                        }
                     }
             }
+        if (h.any_pns && e->cfg.pns_mode != AACG_PNS_SPEC) {
+            e->err = "a unit carries AACG_UNIT_HAS_PNS: NOISE_BT bands are not decodable by the reference either";
+            return AACG_ERR_UNSUPPORTED;
+        }
     }
 
     const size_t ub = sizeof(aacg_dev_unit) * h.units.size(), rb = sizeof(aacg_run) * h.runs.size();
     const size_t tb = sizeof(aacg_dev_tns) * h.tns.size();
     const size_t sb = h.needs_scratch ? h.runs.size() * AACG_SLOT_FLOATS * sizeof(float) : 0;
+    const size_t xb = h.any_pns ? (size_t)n_coef_blocks * 1024u * sizeof(float) : 0;
     const size_t cb = (size_t)n_coef_blocks * 1024u * coef_elem_size(e);
     const size_t mb = quant ? (size_t)n_meta * sizeof(aacg_band_meta) : 0;
     const size_t pb = h.pcm_floats * sizeof(float);
     if ((rc = grow(e, &sl.d_units, &sl.units_cap, ub)) || (rc = grow(e, &sl.d_runs, &sl.runs_cap, rb)) ||
         (rc = grow(e, &sl.d_coeffs, &sl.coeffs_cap, cb)) || (quant && (rc = grow(e, &sl.d_meta, &sl.meta_cap, mb))) ||
-        (tb && (rc = grow(e, &sl.d_tns, &sl.tns_cap, tb))) || (sb && (rc = grow(e, &sl.d_scratch, &sl.scratch_cap, sb))) || (rc = grow(e, &sl.d_pcm, &sl.pcm_cap, pb)))
+        (tb && (rc = grow(e, &sl.d_tns, &sl.tns_cap, tb))) || (sb && (rc = grow(e, &sl.d_scratch, &sl.scratch_cap, sb))) || (xb && (rc = grow(e, &sl.d_spec, &sl.spec_cap, xb))) || (rc = grow(e, &sl.d_pcm, &sl.pcm_cap, pb)))
         return rc;
 
     /* Ordinary (pageable) caller memory goes through the slot's page-locked staging buffers (one host
@@ -510,7 +555,7 @@ int aacg_submit_tns(aacg_engine* e, const aacg_unit_desc* units, uint32_t n_unit
      * while its uploads above overlapped it */
     if (e->last_kernel) HIP_TRY(e, hipStreamWaitEvent(s, e->last_kernel, 0), AACG_ERR_NO_DEVICE);
     rc = launch_run(e, (const aacg_dev_unit*)sl.d_units, (const aacg_run*)sl.d_runs, (const aacg_dev_tns*)sl.d_tns,
-                    (float*)sl.d_scratch, h, sl.d_coeffs,
+                    (float*)sl.d_scratch, (float*)sl.d_spec, h, sl.d_coeffs,
                     (const aacg_band_meta*)sl.d_meta, (float*)sl.d_pcm, 0, s);
     if (rc) return rc;
     HIP_TRY(e, hipEventRecord(sl.kernel_done, s), AACG_ERR_NO_DEVICE);

@@ -17,6 +17,7 @@ struct aacg_host_windows {
 
 /* Fills *t for config.sampleIndex (decoder.js:63); hw (optional) receives the plain windows. */
 int aacg_build_tables(int sample_index, aacg_tables* t, aacg_host_windows* hw);
+int aacg_build_pns_tables(int sample_index, aacg_pns_tables* t);
 /* SWB_OFFSET_1024/128[sample_index] (tables.js:34-155): writes count+1 offsets, returns count. */
 int aacg_swb_offsets(int sample_index, int is_long, int* dst);
 
@@ -33,6 +34,7 @@ struct aacg_plan_host {
     std::vector<aacg_dev_unit> units;   /* device copy of the units */
     std::vector<aacg_dev_tns>  tns;     /* device form of the TNS side info (AACG_TNS_SPEC), same indexing as the input */
     bool     any_tns = false;         /* some channel has AACG_CHAN_TNS_PRESENT and TNS records were given */
+    bool     any_pns = false;         /* some unit carries AACG_UNIT_HAS_PNS */
     bool     needs_scratch = false;   /* some later run holds 16 frames: its first wave parks the predecessor's tails */
     std::vector<aacg_run>   runs;     /* in launch (block) order, XCD-aware */
     std::vector<aacg_chain> chains;

@@ -833,8 +833,89 @@ DP_DEVICE void dequant4_big(const aacg_tables* T, bool live, float sf, int p01, 
     }
 }
 
+/* ------------------------------------------------------------------------------------ */
+/* AACG_PNS_SPEC: NOISE_BT bands as ics.js:228-243 was meant to fill them                     */
+/* ------------------------------------------------------------------------------------ */
+/* exclusive prefix sum over the wave's 128 band slots: two values per lane (slots lane and lane + 64) */
+DP_DEVICE void wave_excl_scan2(int& v0, int& v1)
+{
+    const int lane = dp_lane();
+    int in0 = v0, in1 = v1;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        float t[2] = {__builtin_bit_cast(float, in0), __builtin_bit_cast(float, in1)};
+        dp_shfl(t, (lane - d) & 63);
+        if (lane >= d) { in0 += __builtin_bit_cast(int, t[0]); in1 += __builtin_bit_cast(int, t[1]); }
+    }
+    float tot[1] = {__builtin_bit_cast(float, in0)};   /* inclusive sums; lane 63 holds the first half's total */
+    dp_shfl(tot, 63);
+    v0 = in0 - v0;
+    v1 = in1 - v1 + __builtin_bit_cast(int, tot[0]);
+}
+
+/* One channel's noise bands, in place on the natural-order registers x (8 lane + 512 i + e).  The reference's
+ * generator restarts for every channel of every frame (fresh ICStream, decoder.js:145,153), so draw number p is
+ * the table entry rnd[p]; a band-window takes `width` consecutive draws, in the order of ics.js:214-243 (group,
+ * band, window of the group, coefficient), and is scaled to sf / sqrt(sum of squares).  nb: LDS scratch, 256 ints. */
+DP_DEVICE void pns_channel(const aacg_pns_tables* T, const float* tab, const chan_ctx& cc, const unsigned (&mw)[2],
+                           int* nb, float (&x)[16])
+{
+    const int lane = dp_lane();
+    const uint16_t* swb = cc.cls ? T->swb_short : T->swb_long;
+    /* windows per group, and each window's rank inside its group, from the 4-bit-per-window group map */
+    auto group_len = [&](int g) { int n = 0; for (int w = 0; w < 8; w++) n += (cc.cls && ((cc.gmap >> (4 * w)) & 15u) == (unsigned)g) ? 1 : 0; return cc.cls ? n : 1; };
+    /* 1. draws per band slot, exclusive prefix sum -> first draw of every band; kept with the noise scale */
+    int cnt[2]; bool noise[2];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const int b = lane + 64 * h;
+        const unsigned wd = mw[h];
+        noise[h] = b < AACG_MAX_SECTIONS && (int)(wd >> AACG_META_BT_SHIFT) == AACG_NOISE_BT && cc.max_sfb > 0;
+        const int g = cc.max_sfb > 0 ? b / cc.max_sfb : 0, sfb = cc.max_sfb > 0 ? b % cc.max_sfb : 0;
+        cnt[h] = noise[h] ? group_len(g) * ((int)swb[sfb + 1] - (int)swb[sfb]) : 0;
+    }
+    int first[2] = {cnt[0], cnt[1]};
+    wave_excl_scan2(first[0], first[1]);
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const int b = lane + 64 * h;
+        nb[b] = noise[h] ? first[h] : -1;
+        float sf = tab[AACG_TAB_OFF_SF + (mw[h] & AACG_META_SF_MASK)];
+        if (mw[h] & AACG_META_NEGATE) sf = -sf;
+        ((float*)nb)[128 + b] = sf;
+    }
+    dp_wave_sync();
+    /* 2. this lane's four 4-coefficient groups */
+    band_raw braw;
+    band_raw_load(tab, braw);
+    int idx[4];
+    band_indices(braw, cc, idx);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int i = k >> 1, h = k & 1;
+        const int pos = 8 * lane + 512 * i + 4 * h;
+        const int p_band = idx[k] == AACG_BR_NONE ? -1 : nb[idx[k]];
+        if (p_band >= 0) {
+            const int w = cc.cls ? pos >> 7 : 0;
+            const int g = cc.cls ? (int)((cc.gmap >> (4 * w)) & 15u) : 0;
+            int rank = 0;                               /* windows of the same group before this one */
+            for (int v = 0; v < 8; v++) rank += (cc.cls && v < w && ((cc.gmap >> (4 * v)) & 15u) == (unsigned)g) ? 1 : 0;
+            const int sfb = idx[k] - g * cc.max_sfb;
+            const int width = (int)swb[sfb + 1] - (int)swb[sfb];
+            const int pw = p_band + rank * width;       /* first draw of this band-window */
+            const int k0 = (cc.cls ? (pos & 127) : pos) - (int)swb[sfb];
+            const double energy = T->esum[pw + width] - T->esum[pw];
+            const double scale = (double)((const float*)nb)[128 + idx[k]] / __builtin_sqrt(energy);
+#pragma unroll
+            for (int e = 0; e < 4; e++) x[4 * k + e] = (float)((double)T->rnd[(pw + k0 + e) & 1023] * scale);
+        }
+    }
+    dp_wave_sync();
+}
+
 /* Produces xl / xr[16]: element 8 i + e is coefficient 8 lane + 512 i + e of the left / right
  * (or single) channel after dequant, MS and IS. */
+template <bool PNS = false>
 DP_DEVICE void spectral_quant(const aacg_kparams& P, const float* tab, const unit_view& u, int n_ch,
                               const quant_regs& qreg, float* bt, float (&xl)[16], float (&xr)[16])
 {
@@ -899,6 +980,13 @@ DP_DEVICE void spectral_quant(const aacg_kparams& P, const float* tab, const uni
         }
     }
 
+    if (PNS && (u.flags & AACG_UNIT_HAS_PNS)) {
+        /* the noise bands come before MS / IS like everything decodeSpectralData produces: an intensity band of
+         * the right channel copies whatever the left channel holds there (decoder.js:353-368), noise included.
+         * bt + 512: scratch behind the band records (the PNS kernel gives every wave 1024 floats) */
+        pns_channel(P.pns, tab, ccL, qreg.mw[0], (int*)(bt + 512), xl);
+        if (two) pns_channel(P.pns, tab, ccR, qreg.mw[1], (int*)(bt + 512), xr);
+    }
     if (two) {
         /* wave-uniform skips: most frames carry no intensity bands, many no MS */
         if (dp_any(g_ms[0] || g_ms[1] || g_ms[2] || g_ms[3])) {
@@ -1733,6 +1821,41 @@ DP_DEVICE void imdct_run_body_dd(const aacg_kparams& P)
         const int last_wave = (has_pred && !dd) ? n_units : n_units - 1;
         if (wave == last_wave && run->is_last)
             save_tails(P.overlap + (P.flip ? run->ov_a[0] : run->ov_b[0]), P.overlap + (P.flip ? run->ov_a[1] : run->ov_b[1]));
+    }
+}
+
+/* The spectral stage with PNS (16 units per workgroup, one wave each): dequant, MS, IS as in the run kernel, then
+ * the noise bands; f32 spectra in ICStream.data order to spec_out, which the f32 run kernel then consumes. */
+DP_DEVICE void spectral_pns_body(const aacg_kparams& P, int n_units)
+{
+    const int lane = dp_lane(), wave = dp_wave();
+    float* lds = (float*)dp_lds();
+    const float* tab = lds;
+    float* bt = lds + AACG_TAB_QUANT_FLOATS + wave * 1024;
+    stage_tables(P.tab, lds, AACG_TAB_QUANT_FLOATS);
+    dp_block_sync();
+    const int ui = dp_block() * AACG_WG_WAVES + wave;
+    if (ui >= n_units) return;
+    const unit_view u = load_unit(P.units + dp_uniform(ui));
+    const int n_ch = u.n_ch;
+    float xl[16], xr[16];
+    quant_regs qreg;
+    quant_load(P, u, n_ch, qreg);
+    spectral_quant<true>(P, tab, u, n_ch, qreg, bt, xl, xr);
+    float* out = P.spec_out + (size_t)u.coef_offset * 1024u;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        dpf4 a, b;
+        a.x = xl[8 * i]; a.y = xl[8 * i + 1]; a.z = xl[8 * i + 2]; a.w = xl[8 * i + 3];
+        b.x = xl[8 * i + 4]; b.y = xl[8 * i + 5]; b.z = xl[8 * i + 6]; b.w = xl[8 * i + 7];
+        *(dpf4*)(out + 8 * lane + 512 * i) = a;
+        *(dpf4*)(out + 8 * lane + 512 * i + 4) = b;
+        if (n_ch == 2) {
+            a.x = xr[8 * i]; a.y = xr[8 * i + 1]; a.z = xr[8 * i + 2]; a.w = xr[8 * i + 3];
+            b.x = xr[8 * i + 4]; b.y = xr[8 * i + 5]; b.z = xr[8 * i + 6]; b.w = xr[8 * i + 7];
+            *(dpf4*)(out + 1024 + 8 * lane + 512 * i) = a;
+            *(dpf4*)(out + 1024 + 8 * lane + 512 * i + 4) = b;
+        }
     }
 }
 

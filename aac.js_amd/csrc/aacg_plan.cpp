@@ -117,6 +117,7 @@ int aacg_plan_build(const aacg_unit_desc* units, uint32_t n_units, int sample_in
 
     for (uint32_t i = 0; i < n_units; i++) {
         const aacg_unit_desc& u = units[i];
+        if (u.flags & AACG_UNIT_HAS_PNS) out->any_pns = true;
         if (u.n_ch < 1 || u.n_ch > 2) return fail(err, AACG_ERR_INVALID_ARG, "unit %ld: n_ch %ld", i, u.n_ch);
         if ((int)u.stream >= max_streams) return fail(err, AACG_ERR_CAPACITY, "unit %ld: stream %ld >= max_streams", i, u.stream);
         if (u.n_out_ch < 1 || u.n_out_ch > max_channels || u.channel + u.n_ch > u.n_out_ch)

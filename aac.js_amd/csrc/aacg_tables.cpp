@@ -157,3 +157,25 @@ int aacg_build_tables(int sample_index, aacg_tables* t, aacg_host_windows* hw)
     static_assert(AACG_LDS_BYTES_QUANT <= 160 * 1024, "LDS budget of one CU");
     return AACG_OK;
 }
+
+/* AACG_PNS_SPEC: the generator's sequence, the running sum of its squares, the band offsets (ics.js:228-243). */
+int aacg_build_pns_tables(int sample_index, aacg_pns_tables* t)
+{
+    if (sample_index < 0 || sample_index > 11) return AACG_ERR_INVALID_ARG;
+    std::memset(t, 0, sizeof *t);
+    uint32_t state = 0x1F2E3D4Cu;                       /* ics.js:31 */
+    double sum = 0.0;
+    for (int p = 0; p < 1024; p++) {
+        state = state * 1664525u + 1013904223u;         /* the intended recurrence, wrapping like |0 */
+        t->rnd[p] = (float)(int32_t)state;
+        t->esum[p] = sum;
+        sum += (double)t->rnd[p] * (double)t->rnd[p];
+    }
+    t->esum[1024] = sum;
+    int off[64];
+    int n = aacg_swb_offsets(sample_index, 1, off);
+    for (int i = 0; i <= n && i < 64; i++) t->swb_long[i] = (uint16_t)off[i];
+    n = aacg_swb_offsets(sample_index, 0, off);
+    for (int i = 0; i <= n && i < 16; i++) t->swb_short[i] = (uint16_t)off[i];
+    return AACG_OK;
+}

@@ -13,7 +13,7 @@ const path = require('path');
 
 const INPUT_SPEC_F32 = 0, INPUT_QUANT_I16 = 1;
 const UNIT_BYTES = 64, META_WORDS = 120, FRAME = 1024, TNS_BYTES = 424, TNS_MAX_ORDER = 12;
-const TNS_REFERENCE = 0, TNS_SPEC = 1;
+const TNS_REFERENCE = 0, TNS_SPEC = 1, PNS_REFERENCE = 0, PNS_SPEC = 1;
 const SAMPLE_RATES = [96000, 88200, 64000, 48000, 44100, 32000, 24000, 22050, 16000, 12000, 11025, 8000, 7350];
 
 let addon = null;
@@ -46,7 +46,7 @@ function packUnits(units) {
         view.setUint16(o + 8, u.channel, true);
         view.setUint16(o + 10, u.nOutCh, true);
         view.setUint8(o + 12, u.ch.length);
-        view.setUint8(o + 13, (u.commonWindow ? 1 : 0) | (u.maskPresent ? 2 : 0));
+        view.setUint8(o + 13, (u.commonWindow ? 1 : 0) | (u.maskPresent ? 2 : 0) | (u.hasPns ? 4 : 0));   // AACG_UNIT_*
         view.setUint32(o + 16, u.coefOffset, true);
         view.setUint32(o + 20, u.metaOffset, true);
         packChanInfo(view, o + 24, u.ch[0]);
@@ -94,7 +94,7 @@ function unpackUnits(bytes) {
         const nCh = view.getUint8(o + 12), flags = view.getUint8(o + 13);
         const u = { stream: view.getUint32(o, true), pcmOffset: view.getUint32(o + 4, true), channel: view.getUint16(o + 8, true),
                     nOutCh: view.getUint16(o + 10, true), coefOffset: view.getUint32(o + 16, true), metaOffset: view.getUint32(o + 20, true),
-                    commonWindow: !!(flags & 1), maskPresent: !!(flags & 2), ch: [chan(o + 24)] };
+                    commonWindow: !!(flags & 1), maskPresent: !!(flags & 2), hasPns: !!(flags & 4), ch: [chan(o + 24)] };
         if (nCh > 1) u.ch.push(chan(o + 40));
         out.push(u);
     }
@@ -125,7 +125,7 @@ function Engine(opts) {
     this.handle = this.addon.create({ deviceOrdinal: opts.deviceOrdinal | 0, sampleIndex: opts.sampleIndex === undefined ? 3 : opts.sampleIndex,
                                       maxStreams: opts.maxStreams || 1, maxChannels: opts.maxChannels || 2,
                                       maxBatchUnits: opts.maxBatchUnits | 0, inputKind: this.inputKind,
-                                      tnsMode: opts.tnsMode | 0 });
+                                      tnsMode: opts.tnsMode | 0, pnsMode: opts.pnsMode | 0 });
 }
 /* tns: packTns(...) records for TNS_SPEC engines, else omitted */
 Engine.prototype.decodeBatch = function (units, coeffs, meta, pcm, tns) {
@@ -183,6 +183,9 @@ function GpuAACDecoder(opts) {
      * (default) reproduces that; TNS_SPEC applies the filter, taking each channel's side info from
      * chanInfo.tns (an object shaped like the reference's TNS instance, tns.js:22-44). */
     this.tnsMode = opts.tnsMode | 0;
+    /* PNS_REFERENCE (default): a frame with NOISE_BT bands (element.hasPns) is refused, aac.js produces NaN there
+     * (ics.js:234,239); PNS_SPEC fills the bands as ics.js:228-243 was meant to */
+    this.pnsMode = opts.pnsMode | 0;
     /* chanInfo.pulse = { offset: [...], amp: [...] } (ics.pulseOffset / pulseAmp): aac.js throws 'TODO: add pulse
      * data' on such a frame (ics.js:263-265); applyPulses: true adds them to the quantised spectrum instead. */
     this.applyPulses = !!opts.applyPulses;
@@ -214,7 +217,7 @@ GpuAACDecoder.prototype.setCookie = function (buffer) {
     if (cfg.chanConfig === 0) throw new Error('PCE unimplemented');
     if (!this.engine)
         this.engine = new Engine({ sampleIndex: cfg.sampleIndex, maxStreams: this.stream + 1, maxChannels: cfg.chanConfig, inputKind: INPUT_QUANT_I16,
-                                   tnsMode: this.tnsMode });
+                                   tnsMode: this.tnsMode, pnsMode: this.pnsMode });
     this.engine.resetStream(this.stream);    // new FilterBank(false, chanConfig): zeroed overlaps (filter_bank.js:38-41)
 };
 
@@ -244,7 +247,7 @@ GpuAACDecoder.prototype.unitsOfFrame = function (frame, frameSlot, blockBase, tn
             }
         }
         units.push({ stream: this.stream, pcmOffset: frameSlot * FRAME * C, channel: channel, nOutCh: C, coefOffset: block, metaOffset: block,
-                     commonWindow: !!e.commonWindow, maskPresent: !!e.maskPresent, ch: e.ch, tnsOffset: tnsOffset });
+                     commonWindow: !!e.commonWindow, maskPresent: !!e.maskPresent, hasPns: !!e.hasPns, ch: e.ch, tnsOffset: tnsOffset });
         channel += n; block += n;
     }
     return units;
@@ -279,4 +282,4 @@ GpuAACDecoder.prototype.readChunk = function () {
 };
 
 module.exports = { Engine, GpuAACDecoder, BitReader, packUnits, unpackUnits, packBandWord, packTns, applyPulses,
-                   INPUT_SPEC_F32, INPUT_QUANT_I16, TNS_REFERENCE, TNS_SPEC, UNIT_BYTES, META_WORDS, TNS_BYTES, SAMPLE_RATES };
+                   INPUT_SPEC_F32, INPUT_QUANT_I16, TNS_REFERENCE, TNS_SPEC, PNS_REFERENCE, PNS_SPEC, UNIT_BYTES, META_WORDS, TNS_BYTES, SAMPLE_RATES };

@@ -107,6 +107,7 @@ static napi_value js_create(napi_env env, napi_callback_info info)
     cfg.max_batch_units = get_i32(env, argv[0], "maxBatchUnits", 0);
     cfg.input_kind = get_i32(env, argv[0], "inputKind", AACG_INPUT_QUANT_I16);
     cfg.tns_mode = get_i32(env, argv[0], "tnsMode", AACG_TNS_REFERENCE);
+    cfg.pns_mode = get_i32(env, argv[0], "pnsMode", AACG_PNS_REFERENCE);
     aacg_engine* e = NULL;
     int rc = L.create(&cfg, &e);
     if (rc) return fail(env, NULL, rc, "aacg_create (is a GPU visible?)");

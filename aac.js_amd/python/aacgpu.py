@@ -40,13 +40,15 @@ TNS_DTYPE = np.dtype([
 ])
 assert TNS_DTYPE.itemsize == 424
 TNS_REFERENCE, TNS_SPEC = 0, 1
+PNS_REFERENCE, PNS_SPEC = 0, 1
+UNIT_COMMON_WINDOW, UNIT_MASK_PRESENT, UNIT_HAS_PNS = 1, 2, 4
 CHAN_TNS_PRESENT = 0x01
 
 
 class Config(C.Structure):
     _fields_ = [("abi_version", C.c_int32), ("device_ordinal", C.c_int32), ("sample_index", C.c_int32),
                 ("max_streams", C.c_int32), ("max_channels", C.c_int32), ("max_batch_units", C.c_int32),
-                ("input_kind", C.c_int32), ("tns_mode", C.c_int32)]
+                ("input_kind", C.c_int32), ("tns_mode", C.c_int32), ("pns_mode", C.c_int32)]
 
 
 class AacgError(RuntimeError):
@@ -144,10 +146,10 @@ class Engine:
     """One engine per device (mirrors one FilterBank per decoder, for many streams at once)."""
 
     def __init__(self, input_kind=INPUT_QUANT_I16, max_streams=1, max_channels=2, device=0, sample_index=3,
-                 max_batch_units=0, tns_mode=TNS_REFERENCE):
+                 max_batch_units=0, tns_mode=TNS_REFERENCE, pns_mode=PNS_REFERENCE):
         self.lib = load_library()
         cfg = Config(self.lib.aacg_abi_version(), device, sample_index, max_streams, max_channels, max_batch_units,
-                     input_kind, tns_mode)
+                     input_kind, tns_mode, pns_mode)
         h = C.c_void_p()
         rc = self.lib.aacg_create(C.byref(cfg), C.byref(h))
         if rc:

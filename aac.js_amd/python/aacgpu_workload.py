@@ -235,3 +235,30 @@ def add_tns(batch, seed=0x7115, p_channel=0.6, max_order_long=12, max_order_shor
             recs.append(rec)
     tns = np.array(recs, TNS_DTYPE) if recs else np.zeros(1, TNS_DTYPE)
     return units, tns
+
+
+# ---- perceptual noise substitution (AACG_PNS_SPEC) ----------------------------------------------------
+def add_pns(batch, seed=0x9125, p_unit=0.7, p_band=0.25):
+    """Turns random coded bands into NOISE_BT bands (band type 13, the scalefactor word = the band's energy
+    scalefactor, here 2^((sf - 200) / 4) around the level of the other bands) and flags the units
+    (UNIT_HAS_PNS).  Returns (units copy, meta copy); the quantised values of those bands are left as they are —
+    a parser never delivers any, and the engine must not read them."""
+    from aacgpu import UNIT_HAS_PNS
+    rng = np.random.default_rng(seed)
+    units, meta = batch["units"].copy(), batch["meta"].copy()
+    for i in range(len(units)):
+        if rng.random() >= p_unit:
+            continue
+        hit = False
+        for c in range(int(units[i]["n_ch"])):
+            ci = units[i]["ch"][c]
+            nb = int(ci["group_count"]) * int(ci["max_sfb"])
+            m = meta[int(units[i]["meta_offset"]) + c]
+            for b in range(nb):
+                bt = int(m[b]) >> 12
+                if 1 <= bt <= 11 and rng.random() < p_band:
+                    m[b] = (13 << 12) | (m[b] & 0x0400) | int(260 + rng.integers(-12, 13))     # keeps ms_used, drops negate
+                    hit = True
+        if hit:
+            units[i]["flags"] |= UNIT_HAS_PNS
+    return units, meta

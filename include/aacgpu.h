@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define AACG_ABI_VERSION 1
+#define AACG_ABI_VERSION 2
 
 #define AACG_FRAME_LEN      1024   /* decoder.js:86 frameLength                       */
 #define AACG_MAX_SECTIONS   120    /* ics.js:49 MAX_SECTIONS (bandTypes/scaleFactors) */
@@ -95,6 +95,18 @@ enum {
                                   explicit, separately tested mode                                 */
 };
 
+/* ---- PNS behaviour ------------------------------------------------------------- */
+enum {
+    AACG_PNS_REFERENCE = 0,    /* NOISE_BT bands are refused (AACG_ERR_UNSUPPORTED): aac.js's generator
+                                  degenerates to NaN output after 11 draws (ics.js:234,239, SURVEY.md
+                                  §8a row 4), there is no reference behaviour to reproduce            */
+    AACG_PNS_SPEC      = 1     /* what ics.js:228-243 was meant to do: the generator
+                                  state * 1664525 + 1013904223, restarted for every channel of every
+                                  frame as the reference's fresh ICStream does, values normalised to the
+                                  band's energy scalefactor per window.  Not aac.js behaviour: an explicit,
+                                  separately tested mode (QUANT_I16 engines; units flag AACG_UNIT_HAS_PNS) */
+};
+
 /* ---- TNS side info (AACG_TNS_SPEC), the fields of the reference's TNS object (tns.js:22-44) ---- */
 #define AACG_TNS_MAX_ORDER 12  /* AAC-LC limit; tns.js:84 accepts up to 20, orders 13..20 are refused */
 typedef struct aacg_tns_filter {
@@ -127,6 +139,9 @@ typedef struct aacg_chan_info {
 #define AACG_CHAN_TNS_PRESENT    0x01   /* ics.tnsPresent (ics.js:71); only read in AACG_TNS_SPEC mode */
 #define AACG_UNIT_COMMON_WINDOW 0x01   /* cpe.commonWindow (cpe.js:43)  */
 #define AACG_UNIT_MASK_PRESENT  0x02   /* cpe.maskPresent  (cpe.js:47)  */
+#define AACG_UNIT_HAS_PNS       0x04   /* some band of the unit is NOISE_BT (the parser knows, ics.js:84-121):
+                                          AACG_PNS_SPEC engines route such batches through the PNS stage,
+                                          AACG_PNS_REFERENCE engines refuse them                          */
 
 /* One SCE/LFE/CPE of one frame, 64 bytes.  Units of one stream must be listed in
  * decode order; units that share `stream` and `pcm_offset` form one frame.          */
@@ -171,6 +186,7 @@ typedef struct aacg_config {
     int32_t max_batch_units;   /* capacity of the host-buffer path (aacg_decode_batch)         */
     int32_t input_kind;        /* AACG_INPUT_*                                                 */
     int32_t tns_mode;          /* AACG_TNS_*                                                   */
+    int32_t pns_mode;          /* AACG_PNS_* (ABI version 2)                                   */
 } aacg_config;
 
 typedef struct aacg_engine aacg_engine;

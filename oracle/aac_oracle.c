@@ -427,7 +427,19 @@ static const uint16_t* swb_of(int sample_index, const aacg_chan_info* info)
 int orc_dequant(int sample_index, const aacg_chan_info* info, const aacg_band_meta* meta,
                 const int16_t* q, float* data)
 {
+    return orc_dequant_pns(sample_index, info, meta, q, AACG_PNS_REFERENCE, data);
+}
+
+/* pns_mode == AACG_PNS_SPEC: NOISE_BT bands as ics.js:228-243 was meant to fill them — the generator
+ * `randomState = randomState * 1664525 + 1013904223` (ics.js:234 misplaces a parenthesis and degenerates),
+ * restarted at 0x1F2E3D4C for every channel of every frame because the reference builds a fresh ICStream per
+ * frame (decoder.js:145,153), values normalised to the band's energy scalefactor per window.  NOT pinned by the
+ * reference (it never produces this output); tests check it against an independent numpy restatement. */
+int orc_dequant_pns(int sample_index, const aacg_chan_info* info, const aacg_band_meta* meta,
+                    const int16_t* q, int pns_mode, float* data)
+{
     orc_init();
+    int32_t randomState = 0x1F2E3D4C;                                            /* ics.js:31 */
     const uint16_t* offsets = swb_of(sample_index, info);
     memset(data, 0, sizeof(float) * 1024);
     int groupOff = 0, idx = 0;
@@ -441,7 +453,19 @@ int orc_dequant(int sample_index, const aacg_chan_info* info, const aacg_band_me
                 for (int group = 0; group < groupLen; group++, off += 128)      /* ics.js:222-227 */
                     for (int i = off; i < off + width; i++) data[i] = 0.0f;
             } else if (hcb == AACG_NOISE_BT) {
-                return AACG_ERR_UNSUPPORTED;     /* ics.js:228-243 degenerates to NaN, SURVEY §8a row 4 */
+                if (pns_mode != AACG_PNS_SPEC)
+                    return AACG_ERR_UNSUPPORTED; /* ics.js:228-243 degenerates to NaN, SURVEY §8a row 4 */
+                const float sf = meta_sf(meta->band[idx]);
+                for (int group = 0; group < groupLen; group++, off += 128) {    /* ics.js:230-242, repaired */
+                    double energy = 0.0;
+                    for (int k = 0; k < width; k++) {
+                        randomState = (int32_t)((uint32_t)randomState * 1664525u + 1013904223u);
+                        data[off + k] = (float)randomState;
+                        energy += (double)data[off + k] * (double)data[off + k];
+                    }
+                    const double scale = (double)sf / sqrt(energy);
+                    for (int k = 0; k < width; k++) data[off + k] = (float)((double)data[off + k] * scale);
+                }
             } else {
                 float sf = meta_sf(meta->band[idx]);
                 for (int group = 0; group < groupLen; group++, off += 128) {    /* ics.js:244-256 */
@@ -600,6 +624,16 @@ int orc_decode_batch_tns(int sample_index, int input_kind, int max_streams, int 
                          const aacg_tns_info* tns, int tns_mode,
                          float* pcm_out, float* overlaps, float* spec_out)
 {
+    return orc_decode_batch_ex(sample_index, input_kind, max_streams, max_channels, units, n_units, coeffs, meta,
+                               tns, tns_mode, AACG_PNS_REFERENCE, pcm_out, overlaps, spec_out);
+}
+
+int orc_decode_batch_ex(int sample_index, int input_kind, int max_streams, int max_channels,
+                        const aacg_unit_desc* units, uint32_t n_units,
+                        const void* coeffs, const aacg_band_meta* meta,
+                        const aacg_tns_info* tns, int tns_mode, int pns_mode,
+                        float* pcm_out, float* overlaps, float* spec_out)
+{
     orc_init();
     if (sample_index < 0 || sample_index > 11) return AACG_ERR_INVALID_ARG;
     float data[2][1024], out[1024];
@@ -624,7 +658,7 @@ int orc_decode_batch_tns(int sample_index, int input_kind, int max_streams, int 
                 memcpy(data[c], (const float*)coeffs + base, sizeof(float) * 1024);
             } else {
                 const aacg_band_meta* m = &meta[u->meta_offset + (uint32_t)c];
-                int rc = orc_dequant(sample_index, &u->ch[c], m, (const int16_t*)coeffs + base, data[c]);
+                int rc = orc_dequant_pns(sample_index, &u->ch[c], m, (const int16_t*)coeffs + base, pns_mode, data[c]);
                 if (rc) return rc;
                 if (c == 0) ml = m; else mr = m;
             }

@@ -78,6 +78,16 @@ int orc_decode_batch(int sample_index, int input_kind, int max_streams, int max_
                      const aacg_unit_desc* units, uint32_t n_units,
                      const void* coeffs, const aacg_band_meta* meta,
                      float* pcm_out, float* overlaps, float* spec_out);
+/* dequant with a PNS mode (AACG_PNS_SPEC: noise bands as ics.js:228-243 was meant to fill them; unpinned) */
+int orc_dequant_pns(int sample_index, const aacg_chan_info* info, const aacg_band_meta* meta,
+                    const int16_t* q, int pns_mode, float* data);
+/* all modes */
+int orc_decode_batch_ex(int sample_index, int input_kind, int max_streams, int max_channels,
+                        const aacg_unit_desc* units, uint32_t n_units,
+                        const void* coeffs, const aacg_band_meta* meta,
+                        const aacg_tns_info* tns, int tns_mode, int pns_mode,
+                        float* pcm_out, float* overlaps, float* spec_out);
+
 /* the same with TNS side info: tns == NULL or tns_mode == AACG_TNS_REFERENCE leaves the spectrum untouched */
 int orc_decode_batch_tns(int sample_index, int input_kind, int max_streams, int max_channels,
                          const aacg_unit_desc* units, uint32_t n_units,

@@ -29,6 +29,7 @@ void* lane_main(void* p)
     const bool dd = a->P->scratch != nullptr, tns = a->P->tns != nullptr;
     if (a->kind == 0)      { if (tns) imdct_run_body<AACG_INPUT_SPEC_F32, true>(*a->P); else if (dd) imdct_run_body_dd<AACG_INPUT_SPEC_F32>(*a->P); else imdct_run_body<AACG_INPUT_SPEC_F32, false>(*a->P); }
     else if (a->kind == 1) { if (tns) imdct_run_body<AACG_INPUT_QUANT_I16, true>(*a->P); else if (dd) imdct_run_body_dd<AACG_INPUT_QUANT_I16>(*a->P); else imdct_run_body<AACG_INPUT_QUANT_I16, false>(*a->P); }
+    else if (a->kind == 3) spectral_pns_body(*a->P, a->n_units);
     else                   spectral_body(*a->P, a->n_units);
     return nullptr;
 }
@@ -112,6 +113,10 @@ int emu_decode_tns(int input_kind, int sample_index, int max_streams, int max_ch
                    const aacg_unit_desc* units, uint32_t n_units, const void* coeffs, const aacg_band_meta* meta,
                    const aacg_tns_info* tns, uint32_t n_tns,
                    float* pcm, size_t n_pcm_floats, float* overlap_pool, uint8_t* parity);
+int emu_decode_ex(int input_kind, int sample_index, int max_streams, int max_channels,
+                  const aacg_unit_desc* units, uint32_t n_units, const void* coeffs, const aacg_band_meta* meta,
+                  const aacg_tns_info* tns, uint32_t n_tns, int pns_mode,
+                  float* pcm, size_t n_pcm_floats, float* overlap_pool, uint8_t* parity);
 
 int emu_decode(int input_kind, int sample_index, int max_streams, int max_channels,
                const aacg_unit_desc* units, uint32_t n_units, const void* coeffs, const aacg_band_meta* meta,
@@ -127,6 +132,16 @@ int emu_decode_tns(int input_kind, int sample_index, int max_streams, int max_ch
                    const aacg_tns_info* tns, uint32_t n_tns,
                    float* pcm, size_t n_pcm_floats, float* overlap_pool, uint8_t* parity)
 {
+    return emu_decode_ex(input_kind, sample_index, max_streams, max_channels, units, n_units, coeffs, meta, tns, n_tns,
+                         AACG_PNS_REFERENCE, pcm, n_pcm_floats, overlap_pool, parity);
+}
+
+/* pns_mode == AACG_PNS_SPEC: batches with AACG_UNIT_HAS_PNS units take the engine's two-kernel route */
+int emu_decode_ex(int input_kind, int sample_index, int max_streams, int max_channels,
+                  const aacg_unit_desc* units, uint32_t n_units, const void* coeffs, const aacg_band_meta* meta,
+                  const aacg_tns_info* tns, uint32_t n_tns, int pns_mode,
+                  float* pcm, size_t n_pcm_floats, float* overlap_pool, uint8_t* parity)
+{
     if (g_tab_index != sample_index) { int rc = aacg_build_tables(sample_index, &g_tab, nullptr); if (rc) return rc; g_tab_index = sample_index; }
     aacg_plan_host ph;
     int rc = aacg_plan_build(units, n_units, sample_index, max_streams, max_channels, parity, &ph, &g_err, tns, n_tns);
@@ -140,6 +155,19 @@ int emu_decode_tns(int input_kind, int sample_index, int max_streams, int max_ch
     P.tns = ph.any_tns ? ph.tns.data() : nullptr;
     std::vector<float> scratch(ph.needs_scratch ? ph.runs.size() * AACG_SLOT_FLOATS : 1, 0.0f);
     P.scratch = ph.needs_scratch ? scratch.data() : nullptr;
+    std::vector<float> spec;
+    static aacg_pns_tables pns_tab;
+    if (ph.any_pns) {
+        if (pns_mode != AACG_PNS_SPEC || input_kind != AACG_INPUT_QUANT_I16) { g_err = "PNS unit in a batch without AACG_PNS_SPEC"; return AACG_ERR_UNSUPPORTED; }
+        aacg_build_pns_tables(sample_index, &pns_tab);
+        spec.assign((size_t)ph.coef_blocks * 1024u, 0.0f);
+        aacg_kparams Q = P;
+        Q.spec_out = spec.data(); Q.pns = &pns_tab;
+        launch(Q, 3, (int)((n_units + AACG_WG_WAVES - 1) / AACG_WG_WAVES), AACG_WG_WAVES,
+               (AACG_TAB_QUANT_FLOATS + AACG_WG_WAVES * 1024) * 4, (int)n_units);
+        P.coeffs = spec.data(); P.meta = nullptr;
+        input_kind = AACG_INPUT_SPEC_F32;
+    }
     launch(P, input_kind == AACG_INPUT_QUANT_I16 ? 1 : 0, (int)ph.runs.size(), AACG_WG_WAVES,
            input_kind == AACG_INPUT_QUANT_I16 ? AACG_LDS_BYTES_QUANT : AACG_LDS_BYTES_F32);
     for (auto& c : ph.chains)

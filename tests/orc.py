@@ -50,6 +50,8 @@ class Oracle:
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_decode_batch_tns.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_uint32,
                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_decode_batch_ex.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_uint32,
+                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_tns_spec.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_init()
 
@@ -103,7 +105,7 @@ class Oracle:
             raise RuntimeError("orc_tns_spec failed: %d" % rc)
         return out
 
-    def decode_batch(self, units, coeffs, meta, n_pcm_floats, overlaps, sample_index=3, want_spec=False, tns=None):
+    def decode_batch(self, units, coeffs, meta, n_pcm_floats, overlaps, sample_index=3, want_spec=False, tns=None, pns=False):
         """overlaps: float32 [max_streams, max_channels, 1024], updated in place.  tns: TNS_DTYPE array -> AACG_TNS_SPEC."""
         units = np.ascontiguousarray(units)
         assert units.dtype == UNIT_DTYPE
@@ -118,12 +120,13 @@ class Oracle:
         if tns is not None:
             tns = np.ascontiguousarray(tns)
             assert tns.dtype == TNS_DTYPE
-        rc = self.lib.orc_decode_batch_tns(sample_index, kind, overlaps.shape[0], overlaps.shape[1],
-                                           units.ctypes.data, len(units), coeffs.ctypes.data,
-                                           meta.ctypes.data if meta is not None else None,
-                                           tns.ctypes.data if tns is not None else None, 1 if tns is not None else 0,
-                                           pcm.ctypes.data, overlaps.ctypes.data,
-                                           spec.ctypes.data if want_spec else None)
+        rc = self.lib.orc_decode_batch_ex(sample_index, kind, overlaps.shape[0], overlaps.shape[1],
+                                          units.ctypes.data, len(units), coeffs.ctypes.data,
+                                          meta.ctypes.data if meta is not None else None,
+                                          tns.ctypes.data if tns is not None else None, 1 if tns is not None else 0,
+                                          1 if pns else 0,
+                                          pcm.ctypes.data, overlaps.ctypes.data,
+                                          spec.ctypes.data if want_spec else None)
         if rc != 0:
             raise RuntimeError("orc_decode_batch failed: %d" % rc)
         return (pcm, spec.reshape(-1, 1024)) if want_spec else pcm
