@@ -440,3 +440,22 @@ def test_long_chains_double_duty(oracle, T):
     pcm = eng.decode_batch(wl["units"], spec, None, wl["n_pcm"])
     assert rms(pcm, ref) < RMS_TOL
     eng.close()
+
+
+@pytest.mark.parametrize("sample_index,max_long", [(5, 49), (6, 47), (8, 43), (0, 41)])
+def test_other_sample_rates(oracle, sample_index, max_long):
+    """Band tables of other sampling rates (tables.js:34-155) through the real engine: 32, 24, 16, 96 kHz."""
+    wl = aacgpu_workload.random_batch(600 + sample_index, n_streams=3, max_frames=12)
+    units = wl["units"].copy()
+    for i in range(len(units)):
+        for c in range(2):
+            short = int(units[i]["ch"][c]["window_sequence"]) == 2
+            units[i]["ch"][c]["max_sfb"] = min(int(units[i]["ch"][c]["max_sfb"]), 12 if short else max_long)
+    S, C = wl["n_streams"], wl["max_channels"]
+    ov = np.zeros((S, C, 1024), np.float32)
+    ref = oracle.decode_batch(units, wl["q"], wl["meta"], wl["n_pcm"], ov, sample_index=sample_index)
+    eng = aacgpu.Engine(aacgpu.INPUT_QUANT_I16, S, C, sample_index=sample_index)
+    pcm = eng.decode_batch(units, wl["q"], wl["meta"], wl["n_pcm"])
+    rms(pcm, ref)
+    assert np.abs(overlaps(eng, S, C) - ov).max() < 1e-5 * max(1.0, float(np.abs(ov).max()))
+    eng.close()
