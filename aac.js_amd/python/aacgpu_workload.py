@@ -5,6 +5,8 @@ Layout conventions used by bench.py and the tests:
   frame (s, t) -> frame index f = s * T + t
   pcm_offset   = f * 1024 * C            coef/meta block of channel c = f * C + c
 """
+import os
+
 import numpy as np
 
 from aacgpu import UNIT_DTYPE
@@ -43,7 +45,8 @@ def make_batch(n_streams, n_frames, layout=("cpe",), mix=False, seed=0xAAC00002,
     s_idx = np.repeat(np.arange(n_streams), n_frames)
     t_idx = np.tile(np.arange(n_frames), n_streams) + frame_base
     if mix:
-        seq_f = np.array(SEQ_PATTERN_MIX)[(t_idx + s_idx) % 8]
+        pattern = [int(c) for c in os.environ.get("AACG_SEQ_PATTERN", "")] or SEQ_PATTERN_MIX      # diagnostic override, e.g. 22222222
+        seq_f = np.array(pattern)[(t_idx + s_idx) % len(pattern)]
         shape_f = (t_idx & 1).astype(np.uint8)
     else:
         seq_f = np.zeros(F, np.int64)
