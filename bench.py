@@ -10,6 +10,11 @@ buffer sets so that no step is served from the 256 MiB Infinity Cache.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--input quant|spec] [--workload cfg2|cfg3|cfg4|cfg5] [--tns reference|spec]
 
+Timing: W untimed warm-up steps, then exactly K timed steps between barrier + synchronize on both sides; the
+kernel time comes from HIP events on the launch stream.  A step takes ~13 us, so before the warm-up the GPU is
+loaded for --precondition-ms (default 300 ms, untimed, reported as config.preconditioning): a few hundred steps
+are over before the clocks have ramped, and the same kernel then measures 12 % slower.
+
 N > 1: launched by torch.distributed.run, one rank per GPU; streams are sharded over ranks (every rank
 decodes its own 256 streams: weak scaling, no data-path collective; RCCL only carries the barrier and
 the max-over-ranks of the elapsed time).
