@@ -23,18 +23,33 @@ while time.time() - t0 < budget:
         wl = W.make_batch(n_streams=S, n_frames=int(rng.integers(1, 71)), layout=layout, mix=True, intensity=bool(rng.integers(0, 2)), seed=seed)
         C = wl["C"]
     ov = np.zeros((S, C, 1024), np.float32)
-    eng = aacgpu.Engine(aacgpu.INPUT_QUANT_I16, S, C)
-    engf = aacgpu.Engine(aacgpu.INPUT_SPEC_F32, S, C)
+    # a third of the batches exercise the optional modes: TNS SPEC (encoder-like filters), PNS SPEC, or both
+    mode = int(rng.integers(0, 6))
+    use_tns, use_pns = mode in (1, 3), mode in (2, 3)
+    units, meta, tns = wl["units"], wl["meta"], None
+    if use_pns:
+        units, meta = W.add_pns(dict(units=units, meta=meta), seed=seed)
+    if use_tns:
+        units, tns = W.add_tns(dict(units=units), seed=seed)
+    wl = dict(wl, units=units, meta=meta)
+    eng = aacgpu.Engine(aacgpu.INPUT_QUANT_I16, S, C, tns_mode=int(use_tns), pns_mode=int(use_pns))
+    engf = aacgpu.Engine(aacgpu.INPUT_SPEC_F32, S, C, tns_mode=int(use_tns))
     for rep in range(int(rng.integers(1, 4))):                 # consecutive batches of the same streams
-        ref, spec = o.decode_batch(wl["units"], wl["q"], wl["meta"], wl["n_pcm"], ov, want_spec=True)
+        ov_in = ov.copy()
+        ref, spec = o.decode_batch(units, wl["q"], meta, wl["n_pcm"], ov, want_spec=True, tns=tns, pns=use_pns)
+        if use_tns:                                            # spec_out is post-TNS: the f32 seam needs the pre-TNS spectrum
+            _, spec = o.decode_batch(units, wl["q"], meta, wl["n_pcm"], ov_in.copy(), want_spec=True, pns=use_pns)
         sig = float(np.sqrt(np.mean(ref.astype(np.float64) ** 2))) + 1e-12
-        for e, x, m in ((eng, wl["q"], wl["meta"]), (engf, spec, None)):
-            pcm = e.decode_batch(wl["units"], x, m, wl["n_pcm"])
+        for e, x, m in ((eng, wl["q"], meta), (engf, spec, None)):
+            pcm = e.decode_batch(units, x, m, wl["n_pcm"], tns=tns)
             err = float(np.sqrt(np.mean((pcm.astype(np.float64) - ref) ** 2))) / sig
             worst = max(worst, err)
-            assert np.array_equal(np.isnan(pcm), np.isnan(ref)) and err < 5e-6, (seed, rep, err)
+            # TNS SPEC: block scan vs serial evaluation differ by rounding x filter gain; a single frame (and with it the
+            # overlap state) can be 1e-5 off where the batch average is 1e-6 (tests/test_tns_spec.py)
+            assert np.array_equal(np.isnan(pcm), np.isnan(ref)) and err < (2e-5 if use_tns else 5e-6), (seed, rep, mode, err)
         got = np.stack([[eng.get_overlap(s, c) for c in range(C)] for s in range(S)])
-        assert np.abs(got - ov).max() <= 1e-5 * max(1.0, float(np.abs(ov).max())), (seed, rep)
+        ov_err = float(np.sqrt(np.mean((got.astype(np.float64) - ov) ** 2))) / (float(np.sqrt(np.mean(ov.astype(np.float64) ** 2))) + 1e-12)
+        assert ov_err < (1e-4 if use_tns else 5e-6), (seed, rep, mode, ov_err)
         n_batches += 1; n_frames += len(wl["units"])
     eng.close(); engf.close()
 print("soak ok: %d batches, %d units, worst relative rms error %.2e, %.0f s" % (n_batches, n_frames, worst, time.time() - t0))
