@@ -20,19 +20,19 @@
 /* ---- kernels ----------------------------------------------------------------------- */
 /* 1024 threads = 16 waves, one workgroup per CU: 4 waves per SIMD -> 128 VGPRs per lane */
 extern "C" __global__ __launch_bounds__(AACG_WG_THREADS)
-void aacg_imdct_run_quant(const aacg_kparams P) { imdct_run_body<AACG_INPUT_QUANT_I16, false>(P); }
+void aacg_imdct_run_quant(const aacg_kparams P) { imdct_run_body<AACG_INPUT_QUANT_I16>(P); }
 
 extern "C" __global__ __launch_bounds__(AACG_WG_THREADS)
-void aacg_imdct_run_f32(const aacg_kparams P) { imdct_run_body<AACG_INPUT_SPEC_F32, false>(P); }
+void aacg_imdct_run_f32(const aacg_kparams P) { imdct_run_body<AACG_INPUT_SPEC_F32>(P); }
 
-/* The variants (_dd: plans with full later runs, whose first wave does double duty; _tns: AACG_TNS_SPEC batches
- * with TNS side info) live in aacg_engine_ext.hip: their own code object, so that adding to them never moves the
- * two kernels above. */
+/* The variant for plans with full later runs (_dd: their first wave does double duty) lives in aacg_engine_ext.hip,
+ * the optional TNS / PNS stages in aacg_engine_spectral.hip: their own code objects, so that adding to them never
+ * moves the two kernels above. */
 int aacg_ext_set_lds_limits(void);
-void aacg_ext_launch(bool quant, bool tns, dim3 grid, dim3 block, hipStream_t s, const aacg_kparams& P);
-/* aacg_engine_pns.hip: the spectral stage with PNS (AACG_PNS_SPEC), quantised input -> f32 spectra */
-int aacg_pns_set_lds_limits(void);
-void aacg_pns_launch(int n_units, hipStream_t s, const aacg_kparams& P);
+void aacg_ext_launch(bool quant, dim3 grid, dim3 block, hipStream_t s, const aacg_kparams& P);
+/* aacg_engine_spectral.hip: the optional stages (AACG_PNS_SPEC noise bands, AACG_TNS_SPEC filters) -> f32 spectra */
+int aacg_spectral_ex_set_lds_limits(void);
+void aacg_spectral_ex_launch(bool quant, int n_units, hipStream_t s, const aacg_kparams& P);
 
 extern "C" __global__ __launch_bounds__(AACG_WG_THREADS)
 void aacg_spectral(const aacg_kparams P, int n_units) { spectral_body(P, n_units); }
@@ -146,16 +146,16 @@ int launch_run(aacg_engine* e, const aacg_dev_unit* d_units, const aacg_run* d_r
     P.ablate = e->d_trace ? e->ablate : (e->ablate & ~16);
     if (e->d_trace) P.spec_out = (float*)e->d_trace;
     const dim3 grid((unsigned)h.runs.size()), block(AACG_WG_THREADS);
-    if (quant && h.any_pns) {
-        /* AACG_PNS_SPEC: dequant + MS + IS + noise bands to f32 spectra, which the f32 run kernel takes from there */
+    if (h.any_tns || (quant && h.any_pns)) {
+        /* optional stages first (noise bands, TNS filters): f32 spectra, which the f32 run kernel takes from there */
         float* trace_or_null = P.spec_out;
         P.spec_out = d_spec; P.pns = e->d_pns;
-        aacg_pns_launch((int)h.units.size(), s, P);
-        P.spec_out = trace_or_null; P.coeffs = d_spec; P.meta = nullptr;
+        aacg_spectral_ex_launch(quant, (int)h.units.size(), s, P);
+        P.spec_out = trace_or_null; P.coeffs = d_spec; P.meta = nullptr; P.tns = nullptr;
         quant = false;
     }
-    if (P.tns || h.needs_scratch) {
-        aacg_ext_launch(quant, P.tns != nullptr, grid, block, s, P);
+    if (h.needs_scratch) {
+        aacg_ext_launch(quant, grid, block, s, P);
     } else {
         if (quant) hipLaunchKernelGGL(aacg_imdct_run_quant, grid, block, AACG_LDS_BYTES_QUANT, s, P);
         else       hipLaunchKernelGGL(aacg_imdct_run_f32, grid, block, AACG_LDS_BYTES_F32, s, P);
@@ -205,7 +205,7 @@ int aacg_create(const aacg_config* cfg, aacg_engine** out)
         /* ~158 KiB of dynamic LDS per workgroup is above the 64 KiB default limit */
         !hip_ok(e, hipFuncSetAttribute((const void*)aacg_imdct_run_quant, hipFuncAttributeMaxDynamicSharedMemorySize, AACG_LDS_BYTES_QUANT), "LDS attr") ||
         !hip_ok(e, hipFuncSetAttribute((const void*)aacg_imdct_run_f32, hipFuncAttributeMaxDynamicSharedMemorySize, AACG_LDS_BYTES_F32), "LDS attr") ||
-        aacg_ext_set_lds_limits() != 0 || aacg_pns_set_lds_limits() != 0 ||
+        aacg_ext_set_lds_limits() != 0 || aacg_spectral_ex_set_lds_limits() != 0 ||
         !hip_ok(e, hipFuncSetAttribute((const void*)aacg_spectral, hipFuncAttributeMaxDynamicSharedMemorySize, AACG_LDS_BYTES_SPECTRAL), "LDS attr")) {
         std::fprintf(stderr, "aacgpu: %s\n", e->err.c_str());
         aacg_destroy(e);
@@ -340,7 +340,7 @@ int aacg_plan_create_tns(aacg_engine* e, const aacg_unit_desc* units, uint32_t n
         return AACG_ERR_UNSUPPORTED;
     }
     const size_t ub = sizeof(aacg_dev_unit) * n_units, rb = sizeof(aacg_run) * p->h.runs.size();
-    const size_t xb = p->h.any_pns ? (size_t)p->h.coef_blocks * 1024u * sizeof(float) : 0;
+    const size_t xb = (p->h.any_pns || p->h.any_tns) ? (size_t)p->h.coef_blocks * 1024u * sizeof(float) : 0;
     const size_t tb = sizeof(aacg_dev_tns) * p->h.tns.size();
     const size_t sb = p->h.needs_scratch ? p->h.runs.size() * AACG_SLOT_FLOATS * sizeof(float) : 0;
     if (!hip_ok(e, hipSetDevice(e->cfg.device_ordinal), "hipSetDevice") ||
@@ -516,7 +516,7 @@ int aacg_submit_tns(aacg_engine* e, const aacg_unit_desc* units, uint32_t n_unit
     const size_t ub = sizeof(aacg_dev_unit) * h.units.size(), rb = sizeof(aacg_run) * h.runs.size();
     const size_t tb = sizeof(aacg_dev_tns) * h.tns.size();
     const size_t sb = h.needs_scratch ? h.runs.size() * AACG_SLOT_FLOATS * sizeof(float) : 0;
-    const size_t xb = h.any_pns ? (size_t)n_coef_blocks * 1024u * sizeof(float) : 0;
+    const size_t xb = (h.any_pns || h.any_tns) ? (size_t)n_coef_blocks * 1024u * sizeof(float) : 0;
     const size_t cb = (size_t)n_coef_blocks * 1024u * coef_elem_size(e);
     const size_t mb = quant ? (size_t)n_meta * sizeof(aacg_band_meta) : 0;
     const size_t pb = h.pcm_floats * sizeof(float);

@@ -6,13 +6,10 @@
 
 #include "aacg_kernels.h"
 
-/* aacg_engine_tns.hip */
-int aacg_tns_set_lds_limits(void);
-void aacg_tns_launch(bool quant, dim3 grid, dim3 block, hipStream_t s, const aacg_kparams& P);
 
 /* Variants of aacg_imdct_run_quant / _f32:
  *   _dd : plans with full later runs (chains longer than 16 frames), whose first wave does double duty;
- *   (_tns, for AACG_TNS_SPEC batches that carry TNS side info, is in aacg_engine_tns.hip) */
+ * (the optional TNS / PNS stages are a kernel of their own, aacg_engine_spectral.hip) */
 extern "C" __global__ __launch_bounds__(AACG_WG_THREADS)
 void aacg_imdct_run_quant_dd(const aacg_kparams P) { imdct_run_body_dd<AACG_INPUT_QUANT_I16>(P); }
 
@@ -27,16 +24,11 @@ int aacg_ext_set_lds_limits(void)
     hipError_t rc = hipSuccess;
     if (rc == hipSuccess) rc = hipFuncSetAttribute((const void*)aacg_imdct_run_quant_dd, hipFuncAttributeMaxDynamicSharedMemorySize, AACG_LDS_BYTES_QUANT);
     if (rc == hipSuccess) rc = hipFuncSetAttribute((const void*)aacg_imdct_run_f32_dd, hipFuncAttributeMaxDynamicSharedMemorySize, AACG_LDS_BYTES_F32);
-    if (rc == hipSuccess && aacg_tns_set_lds_limits() != 0) rc = hipErrorUnknown;
     return rc == hipSuccess ? 0 : -1;
 }
 
-void aacg_ext_launch(bool quant, bool tns, dim3 grid, dim3 block, hipStream_t s, const aacg_kparams& P)
+void aacg_ext_launch(bool quant, dim3 grid, dim3 block, hipStream_t s, const aacg_kparams& P)
 {
-    if (tns) {
-        aacg_tns_launch(quant, grid, block, s, P);
-    } else {
-        if (quant) hipLaunchKernelGGL(aacg_imdct_run_quant_dd, grid, block, AACG_LDS_BYTES_QUANT, s, P);
-        else       hipLaunchKernelGGL(aacg_imdct_run_f32_dd, grid, block, AACG_LDS_BYTES_F32, s, P);
-    }
+    if (quant) hipLaunchKernelGGL(aacg_imdct_run_quant_dd, grid, block, AACG_LDS_BYTES_QUANT, s, P);
+    else       hipLaunchKernelGGL(aacg_imdct_run_f32_dd, grid, block, AACG_LDS_BYTES_F32, s, P);
 }

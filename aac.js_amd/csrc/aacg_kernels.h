@@ -1251,19 +1251,6 @@ DP_DEVICE void tns_channel(const aacg_dev_tns* rec, bool is_short, float* area, 
     dp_wave_sync();
 }
 
-/* ... on the load registers of the SPEC_F32 path (4 lane + 256 i) */
-DP_DEVICE void tns_channel(const aacg_dev_tns* rec, bool is_short, float* area, float* scratch, dpf4 (&x)[4])
-{
-    const int lane = dp_lane();
-#pragma unroll
-    for (int i = 0; i < 4; i++) *(dpf4*)(area + 4 * lane + 256 * i) = x[i];
-    dp_wave_sync();
-    tns_area(rec, is_short, area, scratch);
-#pragma unroll
-    for (int i = 0; i < 4; i++) x[i] = *(const dpf4*)(area + 4 * lane + 256 * i);
-    dp_wave_sync();
-}
-
 /* IMDCT + window of a unit whose spectra are staged in its slot.  CPE tails always end up
  * interleaved (pair index n = (tailL[n], tailR[n])); a single channel's tail is planar. */
 DP_DEVICE void filter_unit(const float* tab, const unit_view& u, int n_ch, bool pair_path, bool want_head, float* slot,
@@ -1459,7 +1446,7 @@ DP_DEVICE void epilogue(const float* p0, const float* p1, const unit_view& u, in
 /* ------------------------------------------------------------------------------------ */
 /* one run per workgroup                                                                   */
 /* ------------------------------------------------------------------------------------ */
-template <int KIND, bool TNS>
+template <int KIND>
 DP_DEVICE void imdct_run_body(const aacg_kparams& P)
 {
     const int TAB_FLOATS = (KIND == AACG_INPUT_QUANT_I16) ? AACG_TAB_QUANT_FLOATS : AACG_TAB_F32_FLOATS;
@@ -1550,19 +1537,12 @@ DP_DEVICE void imdct_run_body(const aacg_kparams& P)
                 }
             } else
             spectral_quant(P, tab, u, n_ch, qreg, slot + 1024, xl, xr);
-            /* TNS runs here (decoder.js:309-313): identity as the reference executes it (tns.js:106,122);
-             * AACG_TNS_SPEC engines apply the filter it was meant to be */
-            if (TNS && P.tns) {
-                if (u.tns[0]) tns_channel(P.tns + u.tns_offset, cls0 != 0, slot, slot + 1024, xl);
-                if (n_ch == 2 && u.tns[1]) tns_channel(P.tns + u.tns_offset + 1, cls1 != 0, slot + 1024, slot, xr);
-            }
+            /* TNS would run here (decoder.js:309-313): identity as the reference executes it (tns.js:106,122).
+             * AACG_TNS_SPEC batches never reach this kernel with quantised input: spectral_ex_body applies the filter
+             * and hands f32 spectra to the f32 run kernel. */
             if (pair_path) stage_pair_nat8(xl, xr, slot);
             else { stage_nat8(xl, slot); if (n_ch == 2) stage_nat8(xr, slot + 1024); }
         } else {
-            if (TNS && P.tns) {
-                if (u.tns[0]) tns_channel(P.tns + u.tns_offset, cls0 != 0, slot, slot + 1024, xa);
-                if (n_ch == 2 && u.tns[1]) tns_channel(P.tns + u.tns_offset + 1, cls1 != 0, slot + 1024, slot, xb);
-            }
             if (pair_path) stage_pair_f32(xa, xb, slot);
             else {
 #pragma unroll
@@ -1629,7 +1609,7 @@ DP_DEVICE void imdct_run_body(const aacg_kparams& P)
 /* ------------------------------------------------------------------------------------ */
 /* The run body again, for plans that contain full later runs (chains longer than 16 frames).  A later run of a chain starts from the tail of the frame before it, which another workgroup owns,
  * so it recomputes that frame's IMDCT.  With up to 15 frames a wave of its own does that (imdct_run_body above
- * handles it as well, and is what the TNS variants use); a full run of 16 gives its first wave double duty: first the predecessor, whose tails it
+ * handles it as well); a full run of 16 gives its first wave double duty: first the predecessor, whose tails it
  * parks in a scratch area in global memory, then its own frame, which takes its overlap from there.
  * Kept as a second function on purpose: the same source instantiated without the second pass compiles to a run
  * body that is 0.8 us slower on config 2 than the one above (interleaved A/B, 16.8 vs 16.0 us), and a non-inlined
@@ -1637,7 +1617,6 @@ DP_DEVICE void imdct_run_body(const aacg_kparams& P)
 template <int KIND>
 DP_DEVICE void imdct_run_body_dd(const aacg_kparams& P)
 {
-    constexpr bool TNS = false;                        /* TNS batches get no full later runs (aacg_plan.cpp) */
     const int TAB_FLOATS = (KIND == AACG_INPUT_QUANT_I16) ? AACG_TAB_QUANT_FLOATS : AACG_TAB_F32_FLOATS;
     const int lane = dp_lane(), wave = dp_wave();
     const aacg_run* run = P.runs + dp_block();
@@ -1749,19 +1728,12 @@ DP_DEVICE void imdct_run_body_dd(const aacg_kparams& P)
                 }
             } else
             spectral_quant(P, tab, u, n_ch, qreg, slot + 1024, xl, xr);
-            /* TNS runs here (decoder.js:309-313): identity as the reference executes it (tns.js:106,122);
-             * AACG_TNS_SPEC engines apply the filter it was meant to be */
-            if (TNS && P.tns) {
-                if (u.tns[0]) tns_channel(P.tns + u.tns_offset, cls0 != 0, slot, slot + 1024, xl);
-                if (n_ch == 2 && u.tns[1]) tns_channel(P.tns + u.tns_offset + 1, cls1 != 0, slot + 1024, slot, xr);
-            }
+            /* TNS would run here (decoder.js:309-313): identity as the reference executes it (tns.js:106,122).
+             * AACG_TNS_SPEC batches never reach this kernel with quantised input: spectral_ex_body applies the filter
+             * and hands f32 spectra to the f32 run kernel. */
             if (pair_path) stage_pair_nat8(xl, xr, slot);
             else { stage_nat8(xl, slot); if (n_ch == 2) stage_nat8(xr, slot + 1024); }
         } else {
-            if (TNS && P.tns) {
-                if (u.tns[0]) tns_channel(P.tns + u.tns_offset, cls0 != 0, slot, slot + 1024, xa);
-                if (n_ch == 2 && u.tns[1]) tns_channel(P.tns + u.tns_offset + 1, cls1 != 0, slot + 1024, slot, xb);
-            }
             if (pair_path) stage_pair_f32(xa, xb, slot);
             else {
 #pragma unroll
@@ -1824,24 +1796,50 @@ DP_DEVICE void imdct_run_body_dd(const aacg_kparams& P)
     }
 }
 
-/* The spectral stage with PNS (16 units per workgroup, one wave each): dequant, MS, IS as in the run kernel, then
- * the noise bands; f32 spectra in ICStream.data order to spec_out, which the f32 run kernel then consumes. */
-DP_DEVICE void spectral_pns_body(const aacg_kparams& P, int n_units)
+/* The optional stages as a kernel of their own (16 units per workgroup, one wave each), so that the run kernels
+ * never carry them: quantised input -> dequantisation, noise bands (AACG_PNS_SPEC), MS / IS, then the TNS filters
+ * (AACG_TNS_SPEC); f32 input -> the TNS filters only.  f32 spectra in ICStream.data order to spec_out, which the
+ * f32 run kernel then consumes.  Per wave 2048 floats of LDS: band records and PNS scratch first, then the TNS
+ * work area of one channel and the block matrices in the other half. */
+template <int KIND>
+DP_DEVICE void spectral_ex_body(const aacg_kparams& P, int n_units)
 {
+    const int TAB_FLOATS = (KIND == AACG_INPUT_QUANT_I16) ? AACG_TAB_QUANT_FLOATS : 0;
     const int lane = dp_lane(), wave = dp_wave();
     float* lds = (float*)dp_lds();
     const float* tab = lds;
-    float* bt = lds + AACG_TAB_QUANT_FLOATS + wave * 1024;
-    stage_tables(P.tab, lds, AACG_TAB_QUANT_FLOATS);
-    dp_block_sync();
+    float* slot = lds + TAB_FLOATS + wave * AACG_SLOT_FLOATS;
+    if (KIND == AACG_INPUT_QUANT_I16) {
+        stage_tables(P.tab, lds, AACG_TAB_QUANT_FLOATS);
+        dp_block_sync();
+    }
     const int ui = dp_block() * AACG_WG_WAVES + wave;
     if (ui >= n_units) return;
     const unit_view u = load_unit(P.units + dp_uniform(ui));
     const int n_ch = u.n_ch;
     float xl[16], xr[16];
-    quant_regs qreg;
-    quant_load(P, u, n_ch, qreg);
-    spectral_quant<true>(P, tab, u, n_ch, qreg, bt, xl, xr);
+    if (KIND == AACG_INPUT_QUANT_I16) {
+        quant_regs qreg;
+        quant_load(P, u, n_ch, qreg);
+        spectral_quant<true>(P, tab, u, n_ch, qreg, slot, xl, xr);
+    } else {
+        const float* x0 = (const float*)P.coeffs + (size_t)u.coef_offset * 1024u;
+        const float* x1 = x0 + (n_ch == 2 ? 1024 : 0);
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const dpf4 a = *(const dpf4*)(x0 + 8 * lane + 512 * i), b = *(const dpf4*)(x0 + 8 * lane + 512 * i + 4);
+            const dpf4 c = *(const dpf4*)(x1 + 8 * lane + 512 * i), d = *(const dpf4*)(x1 + 8 * lane + 512 * i + 4);
+            xl[8 * i] = a.x; xl[8 * i + 1] = a.y; xl[8 * i + 2] = a.z; xl[8 * i + 3] = a.w;
+            xl[8 * i + 4] = b.x; xl[8 * i + 5] = b.y; xl[8 * i + 6] = b.z; xl[8 * i + 7] = b.w;
+            xr[8 * i] = c.x; xr[8 * i + 1] = c.y; xr[8 * i + 2] = c.z; xr[8 * i + 3] = c.w;
+            xr[8 * i + 4] = d.x; xr[8 * i + 5] = d.y; xr[8 * i + 6] = d.z; xr[8 * i + 7] = d.w;
+        }
+    }
+    /* tns.process (decoder.js:309-313) as it was meant to run, after MS / IS */
+    if (P.tns) {
+        if (u.tns[0]) tns_channel(P.tns + u.tns_offset, u.seq[0] == AACG_EIGHT_SHORT_SEQUENCE, slot, slot + 1024, xl);
+        if (n_ch == 2 && u.tns[1]) tns_channel(P.tns + u.tns_offset + 1, u.seq[1] == AACG_EIGHT_SHORT_SEQUENCE, slot + 1024, slot, xr);
+    }
     float* out = P.spec_out + (size_t)u.coef_offset * 1024u;
 #pragma unroll
     for (int i = 0; i < 2; i++) {

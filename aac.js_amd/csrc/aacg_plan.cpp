@@ -213,7 +213,7 @@ int aacg_plan_build(const aacg_unit_desc* units, uint32_t n_units, int sample_in
          * frames a wave of its own does that, a full run of 16 gives its first wave double duty (one IMDCT more in
          * series).  Use as few double-duty runs as it takes to reach the minimum number of runs. */
         size_t n_full = 0;
-        if (n > AACG_RUN_W && !tns) {                  /* the TNS kernel variants have no double-duty pass */
+        if (n > AACG_RUN_W) {
             const size_t rem = n - AACG_RUN_W, later = (rem + AACG_RUN_W - 1) / AACG_RUN_W;
             n_full = rem > later * (AACG_RUN_W - 1) ? rem - later * (AACG_RUN_W - 1) : 0;
         }

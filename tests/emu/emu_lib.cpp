@@ -25,11 +25,12 @@ void* lane_main(void* p)
 {
     launch_arg* a = (launch_arg*)p;
     g_emu = a->ctx;
-    /* the same dispatch as the engine's launch_run: tns variant / double-duty variant / plain */
-    const bool dd = a->P->scratch != nullptr, tns = a->P->tns != nullptr;
-    if (a->kind == 0)      { if (tns) imdct_run_body<AACG_INPUT_SPEC_F32, true>(*a->P); else if (dd) imdct_run_body_dd<AACG_INPUT_SPEC_F32>(*a->P); else imdct_run_body<AACG_INPUT_SPEC_F32, false>(*a->P); }
-    else if (a->kind == 1) { if (tns) imdct_run_body<AACG_INPUT_QUANT_I16, true>(*a->P); else if (dd) imdct_run_body_dd<AACG_INPUT_QUANT_I16>(*a->P); else imdct_run_body<AACG_INPUT_QUANT_I16, false>(*a->P); }
-    else if (a->kind == 3) spectral_pns_body(*a->P, a->n_units);
+    /* the same dispatch as the engine's launch_run: double-duty variant / plain; kinds 3, 4: the optional-stage kernel */
+    const bool dd = a->P->scratch != nullptr;
+    if (a->kind == 0)      { if (dd) imdct_run_body_dd<AACG_INPUT_SPEC_F32>(*a->P); else imdct_run_body<AACG_INPUT_SPEC_F32>(*a->P); }
+    else if (a->kind == 1) { if (dd) imdct_run_body_dd<AACG_INPUT_QUANT_I16>(*a->P); else imdct_run_body<AACG_INPUT_QUANT_I16>(*a->P); }
+    else if (a->kind == 3) spectral_ex_body<AACG_INPUT_QUANT_I16>(*a->P, a->n_units);
+    else if (a->kind == 4) spectral_ex_body<AACG_INPUT_SPEC_F32>(*a->P, a->n_units);
     else                   spectral_body(*a->P, a->n_units);
     return nullptr;
 }
@@ -157,15 +158,16 @@ int emu_decode_ex(int input_kind, int sample_index, int max_streams, int max_cha
     P.scratch = ph.needs_scratch ? scratch.data() : nullptr;
     std::vector<float> spec;
     static aacg_pns_tables pns_tab;
-    if (ph.any_pns) {
-        if (pns_mode != AACG_PNS_SPEC || input_kind != AACG_INPUT_QUANT_I16) { g_err = "PNS unit in a batch without AACG_PNS_SPEC"; return AACG_ERR_UNSUPPORTED; }
+    if (ph.any_pns && (pns_mode != AACG_PNS_SPEC || input_kind != AACG_INPUT_QUANT_I16)) { g_err = "PNS unit in a batch without AACG_PNS_SPEC"; return AACG_ERR_UNSUPPORTED; }
+    if (ph.any_pns || ph.any_tns) {                     /* the engine's two-kernel route */
+        const bool quant = input_kind == AACG_INPUT_QUANT_I16;
         aacg_build_pns_tables(sample_index, &pns_tab);
         spec.assign((size_t)ph.coef_blocks * 1024u, 0.0f);
         aacg_kparams Q = P;
         Q.spec_out = spec.data(); Q.pns = &pns_tab;
-        launch(Q, 3, (int)((n_units + AACG_WG_WAVES - 1) / AACG_WG_WAVES), AACG_WG_WAVES,
-               (AACG_TAB_QUANT_FLOATS + AACG_WG_WAVES * 1024) * 4, (int)n_units);
-        P.coeffs = spec.data(); P.meta = nullptr;
+        launch(Q, quant ? 3 : 4, (int)((n_units + AACG_WG_WAVES - 1) / AACG_WG_WAVES), AACG_WG_WAVES,
+               ((quant ? AACG_TAB_QUANT_FLOATS : 0) + AACG_WG_WAVES * AACG_SLOT_FLOATS) * 4, (int)n_units);
+        P.coeffs = spec.data(); P.meta = nullptr; P.tns = nullptr;
         input_kind = AACG_INPUT_SPEC_F32;
     }
     launch(P, input_kind == AACG_INPUT_QUANT_I16 ? 1 : 0, (int)ph.runs.size(), AACG_WG_WAVES,

@@ -330,8 +330,8 @@ def test_gpu_tns_errors():
 
 
 def test_emulated_tns_long_chain(emu, oracle):
-    """A chain longer than a run with TNS side info: the planner gives TNS batches no full later runs (the TNS
-    kernel variants have no double-duty pass), so 32 frames are 16 + 15 + 1."""
+    """A chain longer than a run with TNS side info: the TNS stage is a kernel of its own, so the run kernel's
+    double-duty variant (16 + 16 frames) applies as for any other batch."""
     wl = W.make_batch(n_streams=1, n_frames=32, mix=True, seed=5)
     units, tns = W.add_tns(wl, seed=9)
     ov = np.zeros((1, 2, 1024), np.float32)
