@@ -245,7 +245,8 @@ def main():
                    "tns": "identity, as the reference executes it" if tns is None else "AACG_TNS_SPEC, filters on ~60 % of the channels"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                     "kernel": (eng.kernel_name() if args.input == "quant" else "aacg_imdct_run_f32") + ("_tns" if tns is not None else ""),
+                     "kernel": ("aacg_spectral_ex_%s + aacg_imdct_run_f32" % ("quant" if args.input == "quant" else "f32")) if tns is not None
+                               else (eng.kernel_name() if args.input == "quant" else "aacg_imdct_run_f32"),
                      "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": abytes,
                      "host_enqueue_us_per_step": t_issued / args.steps * 1e6},
         "output_ok": ok,
