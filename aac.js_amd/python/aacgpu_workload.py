@@ -265,3 +265,30 @@ def add_pns(batch, seed=0x9125, p_unit=0.7, p_band=0.25):
         if hit:
             units[i]["flags"] |= UNIT_HAS_PNS
     return units, meta
+
+
+def add_tns_config3(batch, seed=0xAAC00003):
+    """TNS side info on every channel-frame — long windows one filter of order 12 over 20
+    bands, EIGHT_SHORT one filter of order 7 per window (over all 14 bands here); directions alternate, reflection
+    coefficients from the 4-bit table with the decaying envelope of add_tns."""
+    from aacgpu import TNS_DTYPE, CHAN_TNS_PRESENT
+    rng = np.random.default_rng(seed)
+    units = batch["units"].copy()
+    tab = tns_coef_table(4, 0)
+    recs = []
+    for i in range(len(units)):
+        units[i]["tns_offset"] = len(recs)
+        for c in range(int(units[i]["n_ch"])):
+            rec = np.zeros((), TNS_DTYPE)
+            short = int(units[i]["ch"][c]["window_sequence"]) == 2
+            for w in range(8 if short else 1):
+                rec["n_filt"][w] = 1
+                f = rec["filt"][w]
+                order = 7 if short else 12
+                f["length"], f["order"], f["direction"] = (14 if short else 20), order, (i + c + w) & 1
+                for k in range(order):
+                    ok = tab[np.abs(tab) <= max(0.25, 0.98 * 0.75 ** k)]
+                    f["coef"][k] = ok[rng.integers(0, len(ok))]
+            units[i]["ch"][c]["flags"] |= CHAN_TNS_PRESENT
+            recs.append(rec)
+    return units, np.array(recs, TNS_DTYPE)

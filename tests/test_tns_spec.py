@@ -356,3 +356,16 @@ def test_gpu_tns_long_chain(oracle):
     assert _rel(pcm, ref) < KERNEL_REL_TOL
     assert _rel(_gpu_overlaps(eng, S, 2), ov) < KERNEL_REL_TOL
     eng.close()
+
+
+def test_config3_tns_workload(emu, oracle):
+    """a filter on every channel-frame (long: order 12 over 20 bands; short: order 7 per window)."""
+    wl = W.make_batch(n_streams=2, n_frames=9, mix=True, seed=3)
+    units, tns = W.add_tns_config3(wl)
+    assert len(tns) == 2 * len(units) and all(int(u["ch"][c]["flags"]) & 1 for u in units for c in range(2))
+    ov = np.zeros((2, 2, 1024), np.float32)
+    ref = oracle.decode_batch(units, wl["q"], wl["meta"], wl["n_pcm"], ov, tns=tns)
+    pool = np.zeros((2, 2, 2, 1024), np.float32)
+    par = np.zeros(4, np.uint8)
+    pcm = emu.decode(units, wl["q"], wl["meta"], wl["n_pcm"], pool, par, tns=tns)
+    assert _rel(pcm, ref) < KERNEL_REL_TOL
