@@ -20,7 +20,6 @@
 #include <hip/hip_runtime.h>
 
 #define DP_DEVICE __device__ __forceinline__
-#define DP_DEVICE_NOINLINE static __device__ __attribute__((noinline))
 #define DP_KERNEL(bounds_threads, bounds_waves) __global__ __launch_bounds__(bounds_threads, bounds_waves)
 
 typedef float2 dpf2;
@@ -59,8 +58,6 @@ DP_DEVICE void dp_flag_wait(int* flag, int v)
 {
     while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != v) __builtin_amdgcn_s_sleep(2);
 }
-/* park this wave for about n x 64 cycles */
-DP_DEVICE void dp_sleep(int n) { for (int i = 0; i < n; i++) __builtin_amdgcn_s_sleep(1); }
 /* issue priority of this wave on its SIMD (0..3); s_setprio takes an immediate */
 DP_DEVICE void dp_setprio(int p)
 {
@@ -105,9 +102,6 @@ DP_DEVICE double dp_fma(double a, double b, double c) { return __builtin_fma(a, 
 DP_DEVICE dpv2 dp_fma2(dpv2 a, dpv2 b, dpv2 c) { return __builtin_elementwise_fma(a, b, c); }
 /* true in every lane if the predicate holds in any lane of the wave */
 DP_DEVICE bool dp_any(bool p) { return __any(p) != 0; }
-/* hide a value from common-subexpression elimination: a table load behind it is re-issued
- * (an L1 hit) instead of its result being held in VGPRs across the whole FFT */
-DP_DEVICE int dp_opaque(int v) { asm volatile("" : "+v"(v)); return v; }
 /* streaming (non-temporal) 16-byte accesses: PCM is written once and never re-read by the kernel,
  * spectra are read once */
 typedef float dp_nv4 __attribute__((ext_vector_type(4)));
@@ -131,24 +125,12 @@ DP_DEVICE void dp_store_nt(dpf4* p, dpf4 v)
     *(dp_nv4*)p = t;
 #endif
 }
-typedef int dp_ni4 __attribute__((ext_vector_type(4)));
-DP_DEVICE dpi4 dp_load_nt_i4(const dpi4* p)
-{
-    const dp_ni4 t = __builtin_nontemporal_load((const dp_ni4*)p);
-    dpi4 v; v.x = t[0]; v.y = t[1]; v.z = t[2]; v.w = t[3]; return v;
-}
-DP_DEVICE dpf4 dp_load_nt(const dpf4* p)
-{
-    const dp_nv4 t = __builtin_nontemporal_load((const dp_nv4*)p);
-    dpf4 v; v.x = t[0]; v.y = t[1]; v.z = t[2]; v.w = t[3]; return v;
-}
 /* two adjacent floats at an address that is only 4-byte aligned (odd channel counts): one
  * global_store_dwordx2 — gfx950 runs in unaligned-access mode, and the type says align 4 */
 typedef float dp_f2u __attribute__((ext_vector_type(2), aligned(4)));
 DP_DEVICE void dp_store2_u(float* p, float a, float b) { dp_f2u v; v[0] = a; v[1] = b; *(dp_f2u*)p = v; }
 /* constant-rate (100 MHz) wall clock, same time base on every CU: phase timelines for profiling */
 DP_DEVICE unsigned long long dp_clock() { return wall_clock64(); }
-DP_DEVICE float dp_nan() { return __builtin_nanf(""); }
 /* keep the instruction scheduler from hoisting the next block's loads above this point
  * (bounds the number of gathers in flight, i.e. VGPR pressure) */
 /* inside a block guarded by a wave-uniform condition: keeps it a real (scalar) branch */

@@ -20,7 +20,6 @@
 #include <stddef.h>
 
 #define DP_DEVICE static inline
-#define DP_DEVICE_NOINLINE static
 #define DP_KERNEL(a, b)
 
 struct alignas(8)  dpf2 { float x, y; };
@@ -57,7 +56,6 @@ DP_DEVICE void dp_block_sync_lds() { pthread_barrier_wait(&g_emu.b->bar); }
 DP_DEVICE void dp_flag_set(int* flag, int v) { __atomic_store_n(flag, v, __ATOMIC_RELEASE); }
 DP_DEVICE void dp_flag_wait(int* flag, int v) { while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != v) sched_yield(); }
 DP_DEVICE void dp_setprio(int) {}
-DP_DEVICE void dp_sleep(int) {}
 
 template <int N>
 DP_DEVICE void dp_shfl(float (&v)[N], int src)
@@ -109,12 +107,8 @@ DP_DEVICE float dp_fma(float a, float b, float c) { return fmaf(a, b, c); }
 DP_DEVICE double dp_fma(double a, double b, double c) { return fma(a, b, c); }
 DP_DEVICE dpv2 dp_fma2(dpv2 a, dpv2 b, dpv2 c) { dpv2 r; r[0] = fmaf(a[0], b[0], c[0]); r[1] = fmaf(a[1], b[1], c[1]); return r; }
 DP_DEVICE void dp_store_nt(dpf4* p, dpf4 v) { *p = v; }
-DP_DEVICE dpf4 dp_load_nt(const dpf4* p) { return *p; }
-DP_DEVICE dpi4 dp_load_nt_i4(const dpi4* p) { return *p; }
 DP_DEVICE void dp_store2_u(float* p, float a, float b) { p[0] = a; p[1] = b; }
 DP_DEVICE unsigned long long dp_clock() { return 0; }
-DP_DEVICE float dp_nan() { return NAN; }
-DP_DEVICE int dp_opaque(int v) { return v; }
 DP_DEVICE void dp_keep_branch() {}
 DP_DEVICE void dp_sched_fence() {}
 
