@@ -7,9 +7,13 @@
  *                (L,R,L,R) stores, 1 KiB contiguous per wave instruction.
  *   workgroup  = 16 waves = one run: consecutive frames of one element of one stream, one
  *                workgroup per CU (128 VGPRs per lane, ~158 KiB of LDS).  Tails travel
- *                wave -> wave through LDS with one workgroup barrier; the first frame of a
- *                chain starts from the overlap state in HBM, a later run's wave 0 recomputes
- *                the tail of the frame before it (no inter-workgroup communication).
+ *                wave -> wave through LDS, released by one LDS flag per wave (no workgroup
+ *                barrier on the hand-off); the first frame of a chain starts from the overlap
+ *                state in HBM, a later run recomputes the tail of the frame before it (a wave
+ *                of its own, or double duty of its first wave; no inter-workgroup communication).
+ *   optional   = AACG_TNS_SPEC filters and AACG_PNS_SPEC noise bands run in a kernel of their own
+ *                (spectral_ex_body) that hands f32 spectra to the f32 run kernel: the run kernels
+ *                never carry them.
  *   tables     = rotation/twiddle/window (and dequant) tables are copied into LDS once per
  *                workgroup; per-wave table reads never use the vector-memory pipeline.
  *   HBM        = spectra in with 16-byte loads in natural order, redistributed to the FFT
