@@ -104,6 +104,25 @@ struct aacg_run {
     int32_t reserved;
 };
 
+/* Frame-major run (multichannel streams: n_out_ch > 2 with several elements per frame): one workgroup holds
+ * F consecutive frames x the E elements of a frame, wave w = f * E + e.  A wave takes its predecessor's tail from
+ * wave w - E; the E waves of a frame put their PCM into an LDS staging area in the stream's interleaved layout
+ * and the whole workgroup stores it as full lines (a wave on its own can only write its 1-2 channels of every
+ * sample: 8-byte pieces at a stride of n_out_ch floats).  A later run's frame-0 waves do double duty. */
+#define AACG_FM_MAX_ELEMENTS 8
+#define AACG_FM_HALF         512      /* samples staged per round */
+struct aacg_fm_run {
+    int32_t n_elem, n_frames;         /* E, F: E * F <= 16 */
+    int32_t has_pred, is_last;
+    int32_t n_out_ch, stage_off;      /* stage_off: float offset of the staging area behind the slots */
+    int32_t reserved[2];
+    int32_t unit[AACG_RUN_W];         /* wave w = f * E + e; -1 = idle */
+    int32_t slot_off[AACG_RUN_W];     /* float offset of wave w's slot in the slot area (CPE 2048, single channel 1536) */
+    int32_t pred[AACG_FM_MAX_ELEMENTS];
+    int32_t ov_a[AACG_FM_MAX_ELEMENTS][2];
+    int32_t ov_b[AACG_FM_MAX_ELEMENTS][2];
+};
+
 struct aacg_kparams {
     const aacg_dev_unit*  units;
     const aacg_run*       runs;
@@ -120,6 +139,7 @@ struct aacg_kparams {
     int32_t               reserved;
     float*                scratch;    /* [n_runs][2048]: parked predecessor tails of double-duty runs (last: the plain kernels never load it) */
     const aacg_pns_tables* pns;       /* AACG_PNS_SPEC: the spectral stage's noise tables */
+    const aacg_fm_run*    fm_runs;    /* frame-major runs (their own kernel) */
 };
 
 #endif

@@ -1861,6 +1861,213 @@ DP_DEVICE void spectral_ex_body(const aacg_kparams& P, int n_units)
     }
 }
 
+/* ------------------------------------------------------------------------------------ */
+/* frame-major runs: multichannel streams                                                   */
+/* ------------------------------------------------------------------------------------ */
+/* One sample pair of one channel into the staging area, if it lies in the half being staged. */
+DP_DEVICE void fm_emit(float* stage, int half, int C, int ch, int n, float v0, float v1)
+{
+    if ((n >> 9) == half) {
+        stage[(n & 511) * C + ch] = v0;
+        stage[((n + 1) & 511) * C + ch] = v1;
+    }
+}
+
+/* out = (overlap + head) / 32768 of one unit for the samples of one half, into the staging area in the stream's
+ * interleaved layout (filter_bank.js + decoder.js:203-215); the counterpart of epilogue<>. */
+template <bool FROM_LDS>
+DP_DEVICE void fm_stage_unit(const float* p0, const float* p1, const unit_view& u, int n_ch, int cls0, int cls1,
+                             float* stage, int half, const float (&hx0)[8], const float (&hy0)[8],
+                             const float (&hx1)[8], const float (&hy1)[8])
+{
+    const int lane = dp_lane(), w = lane >> 3, g = lane & 7;
+    const float S = 1.0f / 32768.0f;                   /* decoder.js:211 */
+    const int C = u.n_out_ch;
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        if (c < n_ch) {
+            const int cls = c ? cls1 : cls0;
+            const float (&hx)[8] = c ? hx1 : hx0;
+            const float (&hy)[8] = c ? hy1 : hy0;
+            const int ch = u.channel + c;
+            if (!cls) {
+#pragma unroll
+                for (int m = 0; m < 8; m++) {
+                    if ((m >> 2) == half) {            /* n = 2 lane + 128 m: m picks the half */
+                        const int n = 2 * lane + 128 * m;
+                        const dpf4 v = incoming<FROM_LDS>(p0, p1, n_ch, n);
+                        fm_emit(stage, half, C, ch, n, ((c ? v.y : v.x) + hx[m]) * S, ((c ? v.w : v.z) + hy[m]) * S);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int m = 0; m < 8; m++) {
+                    if (w < 4 || (w == 4 && m < 4)) {
+                        const int n = 448 + 128 * w + 2 * g + 16 * m;
+                        if ((n >> 9) == half) {
+                            const dpf4 v = incoming<FROM_LDS>(p0, p1, n_ch, n);
+                            fm_emit(stage, half, C, ch, n, ((c ? v.y : v.x) + hx[m]) * S, ((c ? v.w : v.z) + hy[m]) * S);
+                        }
+                    }
+                }
+                if (half == 0) {
+#pragma unroll
+                    for (int t4 = 0; t4 < 4; t4++) {   /* out[0..447] = overlap (filter_bank.js:149-151) */
+                        const int n = 2 * lane + 128 * t4;
+                        if (n < 448) {
+                            const dpf4 v = incoming<FROM_LDS>(p0, p1, n_ch, n);
+                            fm_emit(stage, half, C, ch, n, (c ? v.y : v.x) * S, (c ? v.w : v.z) * S);
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+/* The run body for frame-major runs (aacg_fm_run, aacg_device.h).  Same stages as imdct_run_body_dd; what differs:
+ * the predecessor is wave - E, slots have per-wave offsets, frame-0 waves of a later run do the double duty, and the
+ * epilogue goes through the staging area: per frame and half, the frame's waves stage their PCM, a workgroup
+ * barrier, every thread stores 16 contiguous bytes, a second barrier. */
+template <int KIND>
+DP_DEVICE void imdct_run_body_fm(const aacg_kparams& P)
+{
+    const int TAB_FLOATS = (KIND == AACG_INPUT_QUANT_I16) ? AACG_TAB_QUANT_FLOATS : AACG_TAB_F32_FLOATS;
+    const int lane = dp_lane(), wave = dp_wave();
+    const aacg_fm_run* run = P.fm_runs + dp_block();
+    float* lds = (float*)dp_lds();
+    const float* tab = lds;
+    float* slots = lds + TAB_FLOATS;
+    const int E = run->n_elem, F = run->n_frames, C = run->n_out_ch;
+    int* flags = (int*)(slots + run->stage_off + AACG_FM_HALF * C);
+    float* stage = slots + run->stage_off;
+    float* slot = slots + run->slot_off[wave];
+
+    dpf4 tr0, tr1;
+    stage_tables_load(P.tab, TAB_FLOATS, tr0, tr1);
+
+    int my_f = 0;                                       /* wave / E without a divide */
+    for (int k = 1; k < AACG_WG_WAVES; k++) my_f += (k * E <= wave) ? 1 : 0;
+    const int my_e = wave - my_f * E;
+    const bool active = my_f < F;
+    const bool has_pred = run->has_pred != 0;
+    int ui = active ? run->unit[wave] : -1;
+    ui = dp_uniform(ui);
+    const int n_pass = (active && has_pred && my_f == 0) ? 2 : 1;
+    float* scratch = P.scratch + ((size_t)dp_block() * AACG_FM_MAX_ELEMENTS + (size_t)my_e) * AACG_SLOT_FLOATS;
+
+    float hx0[8], hy0[8], hx1[8], hy1[8];
+    unit_view u = load_unit(P.units + (n_pass == 2 ? run->pred[my_e] : (ui >= 0 ? ui : 0)));
+    dp_setprio(my_f < 3 ? 3 - my_f : 0);
+    int n_ch = ui >= 0 ? u.n_ch : 0;
+    int cls0 = u.seq[0] == AACG_EIGHT_SHORT_SEQUENCE;
+    int cls1 = u.seq[1] == AACG_EIGHT_SHORT_SEQUENCE;
+    bool pair_path = n_ch == 2 && u.seq[0] == u.seq[1] && u.shape[0] == u.shape[1] && u.shape_prev[0] == u.shape_prev[1];
+
+    quant_regs qreg;
+    dpf4 xa[4], xb[4];
+    auto issue_loads = [&]() {
+        if (KIND == AACG_INPUT_QUANT_I16) quant_load(P, u, u.n_ch, qreg);
+        else {
+            const float* xsrc = (const float*)P.coeffs + (size_t)u.coef_offset * 1024u;
+            const float* xsrc1 = xsrc + (u.n_ch == 2 ? 1024 : 0);
+#pragma unroll
+            for (int i = 0; i < 4; i++) { xa[i] = *(const dpf4*)(xsrc + 4 * lane + 256 * i); xb[i] = *(const dpf4*)(xsrc1 + 4 * lane + 256 * i); }
+        }
+    };
+    auto save_tails = [&](float* d0, float* d1) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int n = 4 * lane + 256 * i;
+            if (n_ch == 2) {
+                const dpf4 a = *(const dpf4*)(slot + 2 * n), b = *(const dpf4*)(slot + 2 * n + 4);
+                dpf4 l4, r4;
+                l4.x = a.x; l4.y = a.z; l4.z = b.x; l4.w = b.z;
+                r4.x = a.y; r4.y = a.w; r4.z = b.y; r4.w = b.w;
+                *(dpf4*)(d0 + n) = l4;
+                *(dpf4*)(d1 + n) = r4;
+            } else {
+                *(dpf4*)(d0 + n) = *(const dpf4*)(slot + n);
+            }
+        }
+    };
+    const bool early = wave < E || (P.ablate & 128);    /* the first frame's waves */
+    if (early) issue_loads();
+    stage_tables_store(lds, TAB_FLOATS, tr0, tr1);
+    if (lane == 0) flags[wave] = 0;
+    dp_block_sync_lds();
+    if (!early) issue_loads();
+
+    auto front = [&](bool want_head) {
+        if (KIND == AACG_INPUT_QUANT_I16) {
+            float xl[16], xr[16];
+            spectral_quant(P, tab, u, n_ch, qreg, slot + 1024, xl, xr);
+            if (pair_path) stage_pair_nat8(xl, xr, slot);
+            else { stage_nat8(xl, slot); if (n_ch == 2) stage_nat8(xr, slot + 1024); }
+        } else {
+            if (pair_path) stage_pair_f32(xa, xb, slot);
+            else {
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    *(dpf4*)(slot + 4 * lane + 256 * i) = xa[i];
+                    if (n_ch == 2) *(dpf4*)(slot + 1024 + 4 * lane + 256 * i) = xb[i];
+                }
+            }
+        }
+        dp_wave_sync();
+        filter_unit(tab, u, n_ch, pair_path, want_head, slot, hx0, hy0, hx1, hy1);
+    };
+
+    if (ui >= 0) front(n_pass == 1);
+    if (n_pass == 2) {
+        dp_keep_branch();
+        dp_wave_sync();
+        save_tails(scratch, scratch + 1024);
+        u = load_unit(P.units + ui);
+        n_ch = u.n_ch;
+        cls0 = u.seq[0] == AACG_EIGHT_SHORT_SEQUENCE;
+        cls1 = u.seq[1] == AACG_EIGHT_SHORT_SEQUENCE;
+        pair_path = n_ch == 2 && u.seq[0] == u.seq[1] && u.shape[0] == u.shape[1] && u.shape_prev[0] == u.shape_prev[1];
+        issue_loads();
+        dp_wave_sync();
+        front(true);
+    }
+
+    dp_wave_sync();
+    if (lane == 0) dp_flag_set(&flags[wave], 1);
+
+    /* epilogue through the staging area, frame by frame, half by half */
+#pragma unroll 1
+    for (int f = 0; f < F; f++) {
+        const uint32_t frame_pcm = P.units[run->unit[f * E]].d.pcm_offset;
+#pragma unroll 1
+        for (int half = 0; half < 2; half++) {
+            if (active && my_f == f && ui >= 0) {
+                if (my_f == 0) {
+                    const float* ov0 = n_pass == 2 ? scratch : P.overlap + (P.flip ? run->ov_b[my_e][0] : run->ov_a[my_e][0]);
+                    const float* ov1 = n_pass == 2 ? scratch + 1024 : P.overlap + (P.flip ? run->ov_b[my_e][1] : run->ov_a[my_e][1]);
+                    fm_stage_unit<false>(ov0, ov1, u, n_ch, cls0, cls1, stage, half, hx0, hy0, hx1, hy1);
+                } else {
+                    if (half == 0) dp_flag_wait(&flags[wave - E], 1);
+                    const float* prev = slots + run->slot_off[wave - E];
+                    fm_stage_unit<true>(prev, prev, u, n_ch, cls0, cls1, stage, half, hx0, hy0, hx1, hy1);
+                }
+            }
+            dp_block_sync_lds();
+            {
+                const int n4 = (AACG_FM_HALF * C) >> 2;    /* 16-byte pieces of this half: C * 128 */
+                float* dst = P.pcm + frame_pcm + (size_t)half * AACG_FM_HALF * C;
+                for (int i = dp_tid(); i < n4; i += AACG_WG_THREADS) dp_store_nt((dpf4*)(dst + 4 * i), *(const dpf4*)(stage + 4 * i));
+            }
+            dp_block_sync_lds();
+        }
+    }
+
+    /* the last frame of a chain's last run: its tails are the new overlap state (planar in HBM) */
+    if (active && ui >= 0 && my_f == F - 1 && run->is_last)
+        save_tails(P.overlap + (P.flip ? run->ov_a[my_e][0] : run->ov_b[my_e][0]), P.overlap + (P.flip ? run->ov_a[my_e][1] : run->ov_b[my_e][1]));
+}
+
 /* Spectral stage alone (16 units per workgroup, one wave each): spec_out in ICStream.data order. */
 DP_DEVICE void spectral_body(const aacg_kparams& P, int n_units)
 {

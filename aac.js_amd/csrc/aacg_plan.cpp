@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <map>
 
 namespace {
@@ -24,6 +25,9 @@ struct stream_state {
     uint32_t frame = 0;        /* frame ordinal inside the batch */
     uint32_t mask = 0;         /* channels covered in the current frame */
     uint16_t n_out = 0;
+    bool     holes = false;    /* some frame leaves a channel unwritten */
+    bool     aligned = true;   /* every pcm_offset is a multiple of 4 floats */
+    uint32_t n_chains = 0;
 };
 
 struct open_chain {
@@ -112,7 +116,7 @@ int aacg_plan_build(const aacg_unit_desc* units, uint32_t n_units, int sample_in
     std::map<uint64_t, open_chain> open;                     /* key: stream << 16 | channel */
 
     auto close_frame = [&](stream_state& s) {
-        if (s.seen && s.mask != ((1u << s.n_out) - 1u)) out->zero_fill = true;
+        if (s.seen && s.mask != ((1u << s.n_out) - 1u)) { out->zero_fill = true; s.holes = true; }
     };
 
     for (uint32_t i = 0; i < n_units; i++) {
@@ -144,6 +148,7 @@ int aacg_plan_build(const aacg_unit_desc* units, uint32_t n_units, int sample_in
         if (!s.seen) { s.seen = true; s.cur_off = u.pcm_offset; s.frame = 0; s.mask = 0; s.n_out = u.n_out_ch; }
         else if (u.pcm_offset != s.cur_off) { close_frame(s); s.cur_off = u.pcm_offset; s.frame++; s.mask = 0; }
         if (u.n_out_ch != s.n_out) return fail(err, AACG_ERR_LAYOUT_CHANGE, "unit %ld: stream %ld changes channel count inside a batch", i, u.stream);
+        if (u.pcm_offset & 3u) s.aligned = false;
         const uint32_t bits = ((1u << u.n_ch) - 1u) << u.channel;
         if (s.mask & bits) return fail(err, AACG_ERR_INVALID_ARG, "unit %ld: channel %ld written twice in one frame", i, u.channel);
         s.mask |= bits;
@@ -154,6 +159,7 @@ int aacg_plan_build(const aacg_unit_desc* units, uint32_t n_units, int sample_in
             if (s.frame != 0) return fail(err, AACG_ERR_LAYOUT_CHANGE, "unit %ld: element at channel %ld appears mid-batch", i, u.channel);
             open_chain oc; oc.last_frame = 0; oc.n_ch = u.n_ch; oc.units.push_back((int32_t)i);
             open.emplace(key, std::move(oc));
+            s.n_chains++;
         } else {
             open_chain& oc = it->second;
             if (oc.n_ch != u.n_ch || oc.last_frame + 1 != s.frame)
@@ -197,6 +203,64 @@ int aacg_plan_build(const aacg_unit_desc* units, uint32_t n_units, int sample_in
             return fail(err, AACG_ERR_LAYOUT_CHANGE, "stream %ld: element at channel %ld ends before the batch does",
                         (long)(kv.first >> 16), (long)(kv.first & 0xffff));
 
+    /* Multichannel streams go frame-major (aacg_fm_run): all elements of a frame in one workgroup, so that the PCM
+     * can be interleaved in LDS and stored as full lines.  Needs every channel of every frame written (the staging
+     * area is stored as it is), 16-byte aligned frames, 2..8 elements.  Opt-in for now (AACG_FM=1 in the environment):
+     * correct, but with workgroup barriers around every staging round it is slower than element-major runs. */
+    static const bool fm_enabled = [] { const char* v = std::getenv("AACG_FM"); return v && v[0] == '1'; }();
+    auto is_fm = [&](uint32_t stream) {
+        const stream_state& s = st[stream];
+        return fm_enabled && s.n_out > 2 && s.n_chains >= 2 && s.n_chains <= AACG_FM_MAX_ELEMENTS && !s.holes && s.aligned;
+    };
+    {
+        std::map<uint32_t, std::vector<uint64_t>> by_stream;       /* chains of a stream, by channel */
+        for (auto& kv : open) if (is_fm((uint32_t)(kv.first >> 16))) by_stream[(uint32_t)(kv.first >> 16)].push_back(kv.first);
+        for (auto& sv : by_stream) {
+            const uint32_t stream = sv.first;
+            const int E = (int)sv.second.size(), C = st[stream].n_out;
+            /* frames per run: as many as the waves and the LDS allow (slots of a frame + staging + flags; the larger,
+             * quantised-input table set is assumed) */
+            int frame_floats = 0;
+            for (int e = 0; e < E; e++) frame_floats += open[sv.second[(size_t)e]].n_ch == 2 ? AACG_SLOT_FLOATS : 1536;
+            const int budget = 160 * 1024 / 4 - AACG_TAB_QUANT_FLOATS - AACG_FM_HALF * C - AACG_RUN_W;
+            const int F = std::min(AACG_RUN_W / E, budget / frame_floats);      /* >= 1: E <= 8 frames of <= 2048 floats */
+            const size_t n = open[sv.second[0]].units.size();
+            for (size_t t0 = 0; t0 < n; t0 += (size_t)F) {
+                aacg_fm_run r;
+                std::memset(&r, 0, sizeof r);
+                r.n_elem = E; r.n_frames = (int32_t)std::min<size_t>((size_t)F, n - t0);
+                r.has_pred = t0 ? 1 : 0; r.is_last = t0 + (size_t)F >= n ? 1 : 0; r.n_out_ch = C;
+                for (int w = 0; w < AACG_RUN_W; w++) r.unit[w] = -1;
+                int off = 0;
+                for (int f = 0; f < F; f++)
+                    for (int e = 0; e < E; e++) {
+                        const open_chain& oc = open[sv.second[(size_t)e]];
+                        const int w = f * E + e;
+                        r.slot_off[w] = off;
+                        off += oc.n_ch == 2 ? AACG_SLOT_FLOATS : 1536;
+                        if (f < r.n_frames) r.unit[w] = oc.units[t0 + (size_t)f];
+                    }
+                for (int w = F * E; w < AACG_RUN_W; w++) r.slot_off[w] = 0;    /* idle waves never touch their slot */
+                r.stage_off = off;
+                for (int e = 0; e < E; e++) {
+                    const uint64_t key = sv.second[(size_t)e];
+                    const open_chain& oc = open[key];
+                    const uint32_t channel = (uint32_t)(key & 0xffff);
+                    r.pred[e] = t0 ? oc.units[t0 - 1] : -1;
+                    for (int c = 0; c < 2; c++) {
+                        const uint32_t chn = channel + (c < oc.n_ch ? c : 0);
+                        const int par = parity ? parity[(size_t)stream * (size_t)max_channels + chn] : 0;
+                        r.ov_a[e][c] = aacg_ov_offset(max_channels, stream, chn, par);
+                        r.ov_b[e][c] = aacg_ov_offset(max_channels, stream, chn, par ^ 1);
+                    }
+                }
+                out->fm_lds_floats = std::max(out->fm_lds_floats, (uint32_t)(off + AACG_FM_HALF * C + AACG_RUN_W));
+                if (r.has_pred) out->fm_needs_scratch = true;
+                out->fm_runs.push_back(r);
+            }
+        }
+    }
+
     /* chains -> runs, generated chain by chain */
     std::vector<aacg_run> gen;
     for (auto& kv : open) {
@@ -208,6 +272,11 @@ int aacg_plan_build(const aacg_unit_desc* units, uint32_t n_units, int sample_in
         ch.first_run = (uint32_t)gen.size();
         for (int c = 0; c < 2; c++)
             ch.parity[c] = (parity && c < oc.n_ch) ? parity[(size_t)ch.stream * (size_t)max_channels + ch.channel + c] : 0;
+        if (is_fm(ch.stream)) {                            /* its runs are in fm_runs; the chain record keeps the parity bookkeeping */
+            ch.n_runs = 0;
+            out->chains.push_back(ch);
+            continue;
+        }
         const size_t n = oc.units.size();
         /* The first run takes 16 frames.  A later run recomputes the tail of the frame before it: with up to 15
          * frames a wave of its own does that, a full run of 16 gives its first wave double duty (one IMDCT more in
