@@ -281,5 +281,12 @@ GpuAACDecoder.prototype.readChunk = function () {
     return this.queue.shift();
 };
 
+/* bytes from the demuxer ('data' events of AdtsDemuxer / an MP4 demuxer's samples) to the front end */
+GpuAACDecoder.prototype.feed = function (bytes) { this.frontend.push(bytes.data || bytes); };
+GpuAACDecoder.prototype.feedPacket = function (bytes) { this.frontend.pushPacket(bytes.data || bytes); };
+
 module.exports = { Engine, GpuAACDecoder, BitReader, packUnits, unpackUnits, packBandWord, packTns, applyPulses,
                    INPUT_SPEC_F32, INPUT_QUANT_I16, TNS_REFERENCE, TNS_SPEC, PNS_REFERENCE, PNS_SPEC, UNIT_BYTES, META_WORDS, TNS_BYTES, SAMPLE_RATES };
+/* the bitstream front end and its pieces (loaded on first use: they require this module themselves) */
+for (const [name, file] of [['FrontEnd', './frontend.js'], ['codebooks', './codebooks.js'], ['adts', './adts.js'], ['BitStream', './bits.js']])
+    Object.defineProperty(module.exports, name, { enumerable: true, get: function () { const m = require(file); return m[name] || m; } });

@@ -1,0 +1,365 @@
+#!/usr/bin/env node
+/*
+ * Tests of the bitstream front end (aac.js_amd/js/{bits,codebooks,frontend}.js).
+ *
+ *   node tests/js/test_frontend.js [outdir]
+ *
+ * Needs a Huffman provider (the code words are not in this repository): $AACG_HUFFMAN_MODULE, or the reference
+ * checkout of the build container.  Without one the script prints SKIP and exits 0.
+ *
+ *  1. codebooks: the provider's prefix trees are walked, the lookup tables decode every code word back
+ *  2. writer -> FrontEnd round trips: every field the synthetic writer (aac_writer.js) put into a stream comes
+ *     back bit-exactly — all window sequences, groupings, section escapes, the three scalefactor classes,
+ *     M/S masks, pulse and TNS side info, DSE / FIL / CCE elements in between, ADTS with and without CRC, raw
+ *     packets, several sample rates and channel layouts; the reference's error messages for malformed input
+ *  3. with the reference checkout present: the same bytes go through the reference's own readChunk()
+ *     (decoder.js:125-216, its real Bitstream calls, Huffman, ICS, CPE, CCE parsers), and what it parsed
+ *     (window info, band types, scalefactors, every quantised integer) must equal what FrontEnd produced;
+ *     its PCM is written to `outdir` next to the engine inputs FrontEnd + GpuAACDecoder produced, for
+ *     tests/test_frontend.py to decode through the oracle / the emulated kernels / the GPU.
+ */
+'use strict';
+const fs = require('fs'), path = require('path'), assert = require('assert');
+const root = path.join(__dirname, '..', '..');
+const host = require(path.join(root, 'aac.js_amd', 'js'));
+const adts = require(path.join(root, 'aac.js_amd', 'js', 'adts.js'));
+const { BitStream } = require(path.join(root, 'aac.js_amd', 'js', 'bits.js'));
+const codebooks = require(path.join(root, 'aac.js_amd', 'js', 'codebooks.js'));
+const { FrontEnd, swbOffsets, tnsCoefTable } = require(path.join(root, 'aac.js_amd', 'js', 'frontend.js'));
+const { Writer, BitWriter, Rng } = require('./aac_writer.js');
+
+const REF = '/root/reference/src/';
+const haveRef = fs.existsSync(REF + 'decoder.js');
+let provider = null;
+if (process.env.AACG_HUFFMAN_MODULE) provider = require(process.env.AACG_HUFFMAN_MODULE);
+else if (haveRef) provider = require(REF + 'huffman.js');
+if (!provider) { console.log('SKIP: no Huffman provider'); process.exit(0); }
+const outdir = process.argv[2] || null;
+
+/* ---- 0. bit reader ------------------------------------------------------------------------------------ */
+{
+    const w = new BitWriter(), rng = new Rng(7), items = [];
+    for (let i = 0; i < 2000; i++) { const n = 1 + rng.below(32), v = rng.next() % Math.pow(2, n); items.push([v, n]); w.put(v, n); }
+    const bytes = w.bytes(), r = new BitStream(bytes);
+    for (const [v, n] of items) { assert.strictEqual(r.peek(n), v); assert.strictEqual(r.read(n), v); }
+    r.align();
+    assert.strictEqual(r.pos, bytes.length * 8);
+    assert.throws(() => r.read(1), /Insufficient data/);
+    assert.strictEqual(r.peek(9), 0);                                  // peeking past the end sees zeros
+}
+
+/* ---- 1. codebooks --------------------------------------------------------------------------------------- */
+const cb = codebooks.fromProvider(provider);
+{
+    const again = codebooks.fromTables(JSON.parse(JSON.stringify(cb.toTables())));
+    for (let book = 0; book <= 11; book++) {
+        const ent = book ? cb.tables.spectral[book - 1] : cb.tables.sf;
+        ent.forEach(function (e, sym) {
+            const w = new BitWriter();
+            w.put(e[1], e[0]); w.put(0x2AAAAA, 22);                    // something after the code word
+            for (const c of [cb, again]) {
+                const r = new BitStream(w.bytes());
+                assert.strictEqual(c.symbol(r, book), sym, 'book ' + book + ' symbol ' + sym);
+                assert.strictEqual(r.pos, e[0]);
+            }
+        });
+    }
+    assert.throws(() => codebooks.fromProvider({}), /provider lacks/);
+    assert.throws(() => codebooks.fromTables({ sf: cb.tables.sf.slice(1), spectral: cb.tables.spectral }), /entries/);
+}
+if (haveRef) {                                                           // own tables by formula vs the reference's listings
+    const tables = require(REF + 'tables.js');
+    for (let si = 0; si < 12; si++) {
+        assert.deepStrictEqual(Array.from(swbOffsets(si, false)), Array.from(tables.SWB_OFFSET_1024[si]), 'long offsets ' + si);
+        assert.deepStrictEqual(Array.from(swbOffsets(si, true)), Array.from(tables.SWB_OFFSET_128[si]), 'short offsets ' + si);
+    }
+}
+
+/* ---- helpers -------------------------------------------------------------------------------------------- */
+function layoutChannels(layout) { return layout.reduce(function (a, e) { return a + (e === 'cpe' ? 2 : e === 'sce' || e === 'lfe' ? 1 : 0); }, 0); }
+
+/* one random frame for `layout` (element kinds, e.g. ['cpe'] or ['sce','dse','cpe','fil','cce','lfe']) */
+function randomFrame(wr, rng, layout, seqOf, o) {
+    const elements = [];
+    layout.forEach(function (kind, ei) {
+        const id = rng.below(16);
+        if (kind === 'sce' || kind === 'lfe') {
+            elements.push({ type: kind, id: id, ch: [wr.randomChannel(rng, { seq: seqOf(ei), tns: o.tns && rng.chance(0.5), pulse: o.pulse && rng.chance(0.5), allowPNS: o.pns })] });
+        } else if (kind === 'cpe') {
+            const common = !o.noCommon && rng.below(5) !== 0;
+            const L = wr.randomChannel(rng, { seq: seqOf(ei), tns: o.tns && rng.chance(0.5), pulse: o.pulse && rng.chance(0.4), allowPNS: o.pns });
+            const R = wr.randomChannel(rng, { seq: seqOf(ei + 3), template: common ? L : null, allowIS: true, tns: o.tns && rng.chance(0.5), pulse: o.pulse && rng.chance(0.4), allowPNS: o.pns });
+            const e = { type: 'cpe', id: id, commonWindow: common, mask: common ? rng.below(3) : 0, ch: [L, R] };
+            if (e.mask === 1) { e.msUsed = []; for (let i = 0; i < L.groupLen.length * L.maxSFB; i++) e.msUsed.push(rng.below(2)); }
+            elements.push(e);
+        } else if (kind === 'dse') {
+            const bytes = [];
+            for (let i = rng.chance(0.2) ? 255 + rng.below(40) : rng.below(40); i > 0; i--) bytes.push(rng.below(256));
+            elements.push({ type: 'dse', id: id, align: rng.below(2) === 1, bytes: bytes });
+        } else if (kind === 'fil') {
+            elements.push({ type: 'fil', count: rng.chance(0.3) ? 15 + rng.below(60) : rng.below(15) });
+        } else if (kind === 'cce') {
+            const targets = [], lists = [];
+            for (let i = 1 + rng.below(3); i > 0; i--) {
+                const t = { pair: rng.below(2) === 1, id: rng.below(16), sel: rng.below(4) };
+                targets.push(t); lists.push(0);
+                if (t.pair && t.sel === 3) lists.push(0);
+            }
+            lists.shift();                                             // the first gain list is implicit
+            const ch = wr.randomChannel(rng, { seq: seqOf(ei) });
+            if (o.cceNoZero) for (let i = 0; i < ch.bandTypes.length; i++) if (ch.bandTypes[i] === 0) { ch.bandTypes[i] = 11; ch.sf[i] = ch.globalGain; ch.split[i] = 1; }
+            if (o.cceNoZero) fixScalefactors(ch);
+            elements.push({ type: 'cce', id: id, point: o.ccePoint === undefined ? rng.below(4) : o.ccePoint, targets: targets, sign: rng.below(2), scale: rng.below(4), ch: [ch],
+                            quirks: o.quirks !== false,
+                            lists: lists.map(function () { return { cge: rng.below(2), common: rng.below(21) - 10, steps: [rng.below(9) - 4, rng.below(9) - 4, 0] }; }) });
+        }
+    });
+    return elements;
+}
+/* after band types were edited: make the spectrum-class scalefactors a valid differential chain again */
+function fixScalefactors(ch) {
+    let spec = ch.globalGain;
+    for (let i = 0; i < ch.bandTypes.length; i++)
+        if (ch.bandTypes[i] >= 1 && ch.bandTypes[i] <= 11) { if (Math.abs(ch.sf[i] - spec) > 60) ch.sf[i] = spec; spec = ch.sf[i]; }
+}
+
+/* what the engine input must be for a written channel */
+function expectedMeta(ch, msUsed) {
+    const m = new Uint16Array(120);
+    for (let i = 0; i < ch.groupLen.length * ch.maxSFB; i++) {
+        const bt = ch.bandTypes[i];
+        let w = bt << 12;
+        if (bt >= 14) w |= 200 - Math.min(Math.max(ch.sf[i], -155), 100);
+        else if (bt === 13) w |= (200 + Math.min(Math.max(ch.sf[i], -100), 155)) | 0x200;
+        else if (bt) w |= ch.sf[i] + 100;
+        if (msUsed && msUsed[i]) w |= 0x400;
+        m[i] = w;
+    }
+    return m;
+}
+function expectedTns(ch) {
+    const short = ch.seq === 2, t = { nFilt: [], length: [], order: [], direction: [], coef: [] };
+    for (let w = 0; w < (short ? 8 : 1); w++) {
+        const list = ch.tns.filt[w];
+        t.nFilt.push(list.length);
+        t.length.push(list.map(function (f) { return f.length; }));
+        t.order.push(list.map(function (f) { return f.order; }));
+        t.direction.push(list.map(function (f) { return f.order ? f.direction : false; }));
+        t.coef.push(list.map(function (f) { const tab = tnsCoefTable(ch.tns.res[w] + 3, f.compress); return Float32Array.from(f.field.slice(0, f.order), function (i) { return tab[i]; }); }));
+    }
+    return t;
+}
+function checkChannel(got, ch, where) {
+    assert.deepStrictEqual([got.windowSequence, got.windowShape, got.maxSFB, got.groupLength], [ch.seq, ch.shape, ch.maxSFB, ch.groupLen], where + ': ics_info');
+    if (ch.pulse) assert.deepStrictEqual(got.pulse, { offset: ch.pulse.offset, amp: ch.pulse.amp }, where + ': pulse');
+    else assert.strictEqual(got.pulse, undefined, where + ': pulse');
+    if (ch.tns) assert.deepStrictEqual(got.tns, expectedTns(ch), where + ': tns');
+    else assert.strictEqual(got.tns, undefined, where + ': tns');
+    assert.strictEqual(got.hasPns, Array.prototype.some.call(ch.bandTypes, function (b) { return b === 13; }), where + ': hasPns');
+}
+function checkFrame(frame, elements, where) {
+    const audio = elements.filter(function (e) { return e.type === 'sce' || e.type === 'lfe' || e.type === 'cpe'; });
+    assert.strictEqual(frame.elements.length, audio.length, where + ': element count');
+    let block = 0;
+    audio.forEach(function (e, i) {
+        const got = frame.elements[i], w = where + ' element ' + i;
+        assert.strictEqual(got.type, e.type, w); assert.strictEqual(got.id, e.id, w + ': id');
+        assert.strictEqual(got.commonWindow, !!e.commonWindow, w + ': common_window');
+        assert.strictEqual(got.maskPresent, e.type === 'cpe' && !!e.mask, w + ': ms_mask_present');
+        e.ch.forEach(function (ch, c) {
+            checkChannel(got.ch[c], ch, w + ' ch ' + c);
+            const ms = c === 0 && e.mask ? (e.mask === 2 ? new Array(120).fill(1) : e.msUsed) : null;
+            assert.deepStrictEqual(frame.meta.subarray(block * 120, block * 120 + 120), expectedMeta(ch, ms), w + ' ch ' + c + ': band words');
+            assert.deepStrictEqual(frame.q.subarray(block * 1024, block * 1024 + 1024), ch.q, w + ' ch ' + c + ': quantised spectrum');
+            block++;
+        });
+    });
+    assert.strictEqual(frame.q.length, block * 1024);
+}
+
+/* ---- 2. writer -> FrontEnd ----------------------------------------------------------------------------- */
+const PATTERN = [0, 0, 1, 2, 2, 3, 0, 1, 2, 3, 0, 0, 1, 3, 2, 0, 3, 1];
+const CASES = [
+    { name: 'stereo48', si: 3, layout: ['cpe'], frames: 18, o: { tns: true } },
+    { name: 'mono44', si: 4, layout: ['sce'], frames: 9, o: { tns: true, pulse: true, pns: true } },
+    { name: 'split16', si: 8, layout: ['cpe'], frames: 8, o: { noCommon: true, pulse: true } },
+    { name: 'five1_48', si: 3, layout: ['sce', 'cpe', 'dse', 'cpe', 'fil', 'lfe'], frames: 6, o: { tns: true, pns: true } },
+    { name: 'surround48', si: 3, layout: ['sce', 'cpe', 'dse', 'cpe', 'fil', 'lfe'], frames: 5, o: { tns: true } },
+    { name: 'mono22', si: 7, layout: ['sce'], frames: 7, o: {} },
+    { name: 'extras8k', si: 11, layout: ['fil', 'dse', 'cpe', 'cce', 'dse', 'fil'], frames: 6, o: { cceNoZero: true, ccePoint: 1 } },
+    { name: 'cce96', si: 0, layout: ['cce', 'sce', 'cce', 'cpe'], frames: 6, o: {} },
+    { name: 'cce_spec', si: 5, layout: ['cce', 'cpe', 'cce'], frames: 5, o: { quirks: false } },
+];
+let nFrames = 0;
+for (const c of CASES) {
+    const wr = new Writer(cb, c.si), rng = new Rng(0xF00D ^ (c.si * 7919) ^ c.frames), C = layoutChannels(c.layout);
+    const fe = new FrontEnd({ codebooks: cb, referenceQuirks: c.o.quirks !== false }), config = { sampleIndex: c.si, chanConfig: C };
+    const written = [];
+    for (let t = 0; t < c.frames; t++) {
+        const elements = randomFrame(wr, rng, c.layout, function (ei) { return PATTERN[(t + ei) % PATTERN.length]; }, c.o);
+        written.push(elements);
+        if (t % 3 === 2) fe.pushPacket(wr.rawDataBlock(elements));                       // an MP4-style sample
+        else if (t % 3 === 1) fe.pushPacket(wr.adtsFrame(elements, C & 7, { crc: true }));   // a packet that carries its ADTS header
+        else {
+            const bytes = wr.adtsFrame(elements, C & 7, { crc: t % 2 === 0 });
+            fe.push(bytes.subarray(0, 5));                                               // arrives in pieces: no frame until complete
+            assert.strictEqual(fe.parseFrame({ config: config }), null);
+            fe.push(bytes.subarray(5, bytes.length - 1));
+            assert.strictEqual(fe.parseFrame({ config: config }), null);
+            fe.push(bytes.subarray(bytes.length - 1));
+        }
+        checkFrame(fe.parseFrame({ config: config }), elements, c.name + ' frame ' + t);
+        nFrames++;
+    }
+    assert.strictEqual(fe.parseFrame({ config: config }), null);
+    c.written = written;
+}
+
+/* malformed input: the reference's messages */
+{
+    const wr = new Writer(cb, 3), rng = new Rng(99), config = { sampleIndex: 3, chanConfig: 1 };
+    function parse(bytes) { const fe = new FrontEnd({ codebooks: cb }); fe.pushPacket(bytes); return fe.parseFrame({ config: config }); }
+    function element(mutate) { const ch = wr.randomChannel(rng, { seq: 0 }); mutate(ch); return [{ type: 'sce', id: 0, ch: [ch] }]; }
+    assert.throws(() => parse(wr.rawDataBlock(element(function (ch) { ch.bandTypes.fill(12); }))), /Invalid band type: 12/);
+    assert.throws(() => parse(wr.rawDataBlock(element(function (ch) { ch.gainControl = true; }))), /TODO: decode gain control\/SSR/);
+    assert.throws(() => parse(wr.rawDataBlock([{ type: 'pce', id: 0 }])), /TODO: PCE_ELEMENT/);
+    {   // max_sfb beyond the 49 bands of 48 kHz
+        const w = new BitWriter();
+        w.put(0, 3); w.put(0, 4); w.put(100, 8); w.put(0, 1); w.put(0, 2); w.put(0, 1); w.put(50, 6); w.put(0, 1);
+        assert.throws(() => parse(w.bytes()), /maxSFB out of range/);
+    }
+    {   // a section that runs past max_sfb
+        const w = new BitWriter();
+        w.put(0, 3); w.put(0, 4); w.put(100, 8); w.put(0, 1); w.put(0, 2); w.put(0, 1); w.put(10, 6); w.put(0, 1); w.put(1, 4); w.put(11, 5);
+        assert.throws(() => parse(w.bytes()), /Too many bands \(11 > 10\)/);
+    }
+    {   // predictor_data_present
+        const w = new BitWriter();
+        w.put(0, 3); w.put(0, 4); w.put(100, 8); w.put(0, 1); w.put(0, 2); w.put(0, 1); w.put(10, 6); w.put(1, 1);
+        assert.throws(() => parse(w.bytes()), /Prediction not implemented\./);
+    }
+    {   // pulse data in a short-window frame
+        const ch = wr.randomChannel(rng, { seq: 2 });
+        ch.pulse = { swb: 0, offset: [1], amp: [1] };
+        assert.throws(() => parse(wr.rawDataBlock([{ type: 'sce', id: 0, ch: [ch] }])), /Pulse tool not allowed in eight short sequence\./);
+    }
+    {   // truncated frame
+        const bytes = wr.rawDataBlock(element(function () {}));
+        assert.throws(() => parse(bytes.subarray(0, bytes.length >> 1)), /Insufficient data/);
+    }
+    const fe = new FrontEnd({ codebooks: cb });
+    fe.push(new Uint8Array([1, 2, 3, 4, 5, 6, 7, 8]));
+    assert.throws(() => fe.parseFrame({ config: config }), /Invalid ADTS header\./);
+    assert.throws(() => new FrontEnd({ huffman: {} }), /provider lacks/);
+}
+
+/* ---- 3. the same bytes through the reference ---------------------------------------------------------- */
+let compared = 0;
+if (haveRef) {
+    process.env.NODE_PATH = path.join(root, 'tests', 'golden', 'gen', 'stubs');
+    require('module').Module._initPaths();
+    const AACDecoder = require(REF + 'decoder.js'), FilterBank = require(REF + 'filter_bank.js'), refTables = require(REF + 'tables.js');
+    const refHuffman = require(REF + 'huffman.js');
+    let ints = null;
+    const inner = refHuffman.decodeSpectralData;
+    refHuffman.decodeSpectralData = function (stream, book, data, off) {               // ics.js:247 calls through the module object
+        inner.call(this, stream, book, data, off);
+        for (let j = 0; j < (book < 5 ? 4 : 2); j++) ints.push(data[off + j]);
+    };
+    const manifest = [];
+    for (const c of CASES) {
+        if (c.o.quirks === false) continue;                    // standard-syntax coupling elements: the reference parses those differently
+        const wr = new Writer(cb, c.si), C = layoutChannels(c.layout), usable = !c.o.pns && !c.o.pulse;
+        const ref = new AACDecoder();
+        ref.format = {};
+        ref.config = { profile: 2, sampleIndex: c.si, sampleRate: host.SAMPLE_RATES[c.si], chanConfig: C, frameLength: 1024 };
+        ref.filter_bank = new FilterBank(false, C);
+        let refElements = null;
+        ref.process = function (elements) { refElements = elements; if (usable) AACDecoder.prototype.process.call(this, elements); else this.data = []; };
+
+        /* mine: the whole stream through GpuAACDecoder.readChunk with an engine that records its input */
+        const captured = {}, fe = new FrontEnd({ codebooks: cb });
+        const engine = { resetStream: function () {}, decodeBatch: function (units, q, meta, pcm, tns) { captured.units = units; captured.q = q; captured.meta = meta; captured.tns = tns; } };
+        const dec = new host.GpuAACDecoder({ engine: engine, frontend: fe, lookahead: c.frames, applyPulses: false });
+        dec.config = { profile: 2, sampleIndex: c.si, chanConfig: C };
+        const frames = c.written.map(function (elements) { return wr.adtsFrame(elements, C & 7); });
+        const refPcm = new Float32Array(c.frames * C * 1024), mine = [];
+        frames.forEach(function (bytes, t) {
+            const fe1 = new FrontEnd({ codebooks: cb });
+            fe1.push(bytes);
+            const f = fe1.parseFrame(dec);
+            mine.push(f);
+            ints = [];
+            ref.bitstream = new BitStream(bytes);
+            let pcm = null;
+            try { pcm = ref.readChunk(); } catch (e) { if (!/TODO: add pulse data/.test(e.message)) throw e; }
+            if (pcm && usable) refPcm.set(pcm, t * C * 1024);
+            if (pcm) assert.strictEqual(ref.bitstream.pos, bytes.length * 8, c.name + ': the reference did not end on the frame boundary');
+            if (!pcm) return;                                   // the reference gave up on pulse data: nothing to compare
+            /* element by element */
+            let block = 0;
+            assert.strictEqual(refElements.length, f.elements.length);
+            refElements.forEach(function (re, i) {
+                const me = f.elements[i], chans = re.left ? [re.left, re.right] : [re];
+                if (re.left) { assert.strictEqual(!!re.commonWindow, me.commonWindow); assert.strictEqual(!!re.maskPresent, me.maskPresent); }
+                assert.strictEqual(re.id, me.id);
+                chans.forEach(function (ics, ci) {
+                    const mc = me.ch[ci], info = ics.info, nb = info.groupCount * info.maxSFB, words = f.meta.subarray(block * 120, block * 120 + 120);
+                    assert.deepStrictEqual([info.windowSequence, info.windowShape[1], info.maxSFB, Array.from(info.groupLength.subarray(0, info.groupCount))],
+                                           [mc.windowSequence, mc.windowShape, mc.maxSFB, mc.groupLength], c.name + ': ics_info');
+                    for (let b = 0; b < nb; b++) {
+                        assert.strictEqual(ics.bandTypes[b], words[b] >>> 12, c.name + ': band type');
+                        const sf = ics.bandTypes[b] ? refTables.SCALEFACTOR_TABLE[words[b] & 0x1ff] * (words[b] & 0x200 ? -1 : 1) : 0;
+                        assert.strictEqual(ics.scaleFactors[b], sf, c.name + ': scalefactor of band ' + b);
+                        if (re.left && ci === 0 && re.maskPresent) assert.strictEqual(!!re.ms_used[b], !!(words[b] & 0x400), c.name + ': ms_used');
+                    }
+                    assert.strictEqual(!!ics.tnsPresent, !!mc.tns);
+                    if (mc.tns)
+                        for (let w = 0; w < info.windowCount; w++) {
+                            assert.strictEqual(ics.tns.nFilt[w], mc.tns.nFilt[w]);
+                            for (let fi = 0; fi < mc.tns.nFilt[w]; fi++) {
+                                assert.deepStrictEqual([ics.tns.length[w][fi], ics.tns.order[w][fi]], [mc.tns.length[w][fi], mc.tns.order[w][fi]]);
+                                if (mc.tns.order[w][fi]) assert.strictEqual(!!ics.tns.direction[w][fi], mc.tns.direction[w][fi]);
+                                for (let k = 0; k < mc.tns.order[w][fi]; k++)
+                                    assert.ok(Math.abs(ics.tns.coef[w][fi][k] - mc.tns.coef[w][fi][k]) < 1e-7, c.name + ': TNS coefficient');   // 8-digit listing vs formula
+                            }
+                        }
+                    block++;
+                });
+            });
+            /* every integer the reference's Huffman decoder returned, in its order (ics.js:212-258) */
+            const want = [];
+            let b0 = 0;
+            f.elements.forEach(function (me) {
+                me.ch.forEach(function (mc) {
+                    const off = swbOffsets(c.si, mc.windowSequence === 2), q = f.q.subarray(b0 * 1024, b0 * 1024 + 1024), words = f.meta.subarray(b0 * 120);
+                    for (let g = 0, groupOff = 0; g < mc.groupLength.length; groupOff += mc.groupLength[g] * 128, g++)
+                        for (let sfb = 0; sfb < mc.maxSFB; sfb++) {
+                            const bt = words[g * mc.maxSFB + sfb] >>> 12;
+                            if (bt === 0 || bt >= 13) continue;
+                            for (let w = 0; w < mc.groupLength[g]; w++) for (let k = off[sfb]; k < off[sfb + 1]; k++) want.push(q[groupOff + w * 128 + k]);
+                        }
+                    b0++;
+                });
+            });
+            /* coupling elements' integers are in the reference's log too but not in mine: compare the audio ones only
+             * when the layout has no CCE */
+            if (c.layout.indexOf('cce') < 0) assert.deepStrictEqual(ints, want, c.name + ' frame ' + t + ': Huffman output');
+            compared++;
+        });
+        if (!usable || !outdir) continue;
+        /* the whole stream through the plugin surface */
+        for (const bytes of frames) fe.push(bytes);
+        dec.engine = engine;
+        dec.readChunk();
+        fs.mkdirSync(outdir, { recursive: true });
+        fs.writeFileSync(path.join(outdir, c.name + '.aac'), Buffer.concat(frames.map(function (b) { return Buffer.from(b); })));
+        fs.writeFileSync(path.join(outdir, c.name + '.units'), Buffer.from(captured.units));
+        fs.writeFileSync(path.join(outdir, c.name + '.q'), Buffer.from(captured.q.buffer));
+        fs.writeFileSync(path.join(outdir, c.name + '.meta'), Buffer.from(captured.meta.buffer));
+        fs.writeFileSync(path.join(outdir, c.name + '.refpcm'), Buffer.from(refPcm.buffer));
+        manifest.push({ name: c.name, sampleIndex: c.si, channels: C, frames: c.frames });
+    }
+    if (outdir) fs.writeFileSync(path.join(outdir, 'manifest.json'), JSON.stringify(manifest));
+}
+console.log('frontend tests passed: ' + nFrames + ' frames round-tripped, ' + compared + ' compared with the reference');
