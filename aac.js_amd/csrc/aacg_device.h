@@ -142,4 +142,32 @@ struct aacg_kparams {
     const aacg_fm_run*    fm_runs;    /* frame-major runs (their own kernel) */
 };
 
+/* ---- device front end (aacg_parse.h) ------------------------------------------------------------ */
+#define AACG_PARSE_WG_THREADS 256
+#define AACG_PARSE_L1_BITS    9
+#define AACG_PARSE_LUT_WORDS  12288     /* 12 first-level tables of 512 + the second-level tables */
+/* lut entry: bits 0..4 code length; bit 5 clear: bits 8..31 payload (scalefactor book: the value; spectral books:
+ * values as 6-bit two's-complement fields);  bit 5 set: bits 0..4 = extra bits, bits 8..31 = index of a
+ * second-level table */
+typedef struct aacg_parse_tables {
+    uint32_t lut[AACG_PARSE_LUT_WORDS];
+    uint32_t lut_words;
+    uint16_t swb_long[64];
+    uint16_t swb_short[16];
+    uint32_t n_swb_long, n_swb_short;
+    float    tns_coef[4][16];           /* [2 * coef_compress + coef_res][field] (tns.js:50-63) */
+} aacg_parse_tables;
+
+typedef struct aacg_parse_params {
+    const uint32_t* bytes;
+    const aacg_parse_frame* frames;
+    const aacg_parse_tables* tab;
+    aacg_unit_desc* units;
+    int16_t* q;
+    aacg_band_meta* meta;
+    aacg_tns_info* tns;
+    aacg_parse_result* results;
+    uint32_t n_frames, max_units, max_channels, options;
+} aacg_parse_params;
+
 #endif

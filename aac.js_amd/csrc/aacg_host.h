@@ -65,4 +65,9 @@ int aacg_plan_build(const aacg_unit_desc* units, uint32_t n_units, int sample_in
  * reference's Float32Array lpc).  Returns AACG_OK or AACG_ERR_UNSUPPORTED (order > 12). */
 int aacg_tns_prepare(int sample_index, const aacg_chan_info* info, const aacg_tns_info* in, aacg_dev_tns* out);
 
+/* Device front end: lookup tables from the caller's (length, code word, values) lists; every book is checked to be
+ * a complete prefix code of the standard's alphabet size.  Returns AACG_OK or AACG_ERR_INVALID_ARG / _CAPACITY. */
+int aacg_parse_build_tables(int sample_index, const aacg_code_entry* entries, const uint32_t counts[12],
+                            aacg_parse_tables* out, std::string* err);
+
 #endif

@@ -1,0 +1,158 @@
+/*
+ * aacg_parser.hip — the device front end behind include/aacgpu.h's aacg_parser_* / aacg_parse_* entry points:
+ * the kernel (one lane per frame, aacg_parse.h) and its host plumbing.  Independent of aacg_engine: it shares
+ * record formats with it, no state.
+ */
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "aacg_parse.h"
+#include "aacg_host.h"
+
+extern "C" DP_KERNEL(AACG_PARSE_WG_THREADS, 1)
+void aacg_parse_frames(const aacg_parse_params P) { aacg_parse::parse_body(P); }
+
+struct aacg_parser {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    aacg_parse_tables* d_tab = nullptr;
+    size_t lds_bytes = 0;
+    /* device staging of aacg_parse_batch, grown on demand */
+    void* d_buf[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t cap[7] = {0, 0, 0, 0, 0, 0, 0};
+    std::string err;
+};
+
+namespace {
+
+int fail(aacg_parser* p, int rc, const std::string& m) { if (p) p->err = m; return rc; }
+int hip_fail(aacg_parser* p, hipError_t e, const char* what) { return fail(p, AACG_ERR_NO_DEVICE, std::string(what) + ": " + hipGetErrorString(e)); }
+#define HIPCHECK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return hip_fail(p, e_, #call); } while (0)
+
+int grow(aacg_parser* p, int i, size_t bytes)
+{
+    if (bytes <= p->cap[i]) return AACG_OK;
+    if (p->d_buf[i]) (void)hipFree(p->d_buf[i]);
+    p->d_buf[i] = nullptr; p->cap[i] = 0;
+    if (hipMalloc(&p->d_buf[i], bytes) != hipSuccess) return fail(p, AACG_ERR_OUT_OF_MEMORY, "hipMalloc failed");
+    p->cap[i] = bytes;
+    return AACG_OK;
+}
+
+int launch(aacg_parser* p, const aacg_parse_params& P, hipStream_t s)
+{
+    HIPCHECK(hipMemsetAsync(P.q, 0, (size_t)P.n_frames * P.max_channels * 1024u * sizeof(int16_t), s));
+    if (P.tns) HIPCHECK(hipMemsetAsync(P.tns, 0, (size_t)P.n_frames * P.max_channels * sizeof(aacg_tns_info), s));
+    const unsigned grid = (P.n_frames + AACG_PARSE_WG_THREADS - 1) / AACG_PARSE_WG_THREADS;
+    hipLaunchKernelGGL(aacg_parse_frames, dim3(grid), dim3(AACG_PARSE_WG_THREADS), p->lds_bytes, s, P);
+    HIPCHECK(hipGetLastError());
+    return AACG_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* aacg_parse_kernel_name(void) { return "aacg_parse_frames"; }
+const char* aacg_parser_last_error(const aacg_parser* p) { return p ? p->err.c_str() : "null parser"; }
+
+const char* aacg_parse_status_string(int status)
+{
+    static const char* const text[] = {
+        "ok", "Insufficient data", "Invalid band type: 12", "Too many bands", "Scalefactor out of range",
+        "Pulse tool not allowed in eight short sequence.", "Pulse SWB or offset out of range", "TODO: add pulse data",
+        "TNS filter out of range", "Prediction not implemented.", "TODO: decode gain control/SSR", "TODO: PCE_ELEMENT",
+        "maxSFB out of range", "Reserved ms mask type: 3", "Huffman: escape sequence too long",
+        "more elements or channels in the frame than allowed for" };
+    return status >= 0 && status < (int)(sizeof text / sizeof *text) ? text[status] : "unknown status";
+}
+
+int aacg_parser_create(int device_ordinal, int sample_index, const aacg_code_entry* entries, const uint32_t counts[12], aacg_parser** out)
+{
+    if (!out) return AACG_ERR_INVALID_ARG;
+    *out = nullptr;
+    aacg_parser* p = new aacg_parser;
+    p->device = device_ordinal;
+    std::vector<aacg_parse_tables> tab(1);
+    int rc = aacg_parse_build_tables(sample_index, entries, counts, tab.data(), &p->err);
+    if (rc == AACG_OK && hipSetDevice(device_ordinal) != hipSuccess) rc = fail(p, AACG_ERR_NO_DEVICE, "hipSetDevice failed");
+    if (rc == AACG_OK) {
+        p->lds_bytes = (size_t)tab[0].lut_words * 4u + 160u + (size_t)AACG_MAX_SECTIONS * AACG_PARSE_WG_THREADS;
+        if (hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking) != hipSuccess ||
+            hipMalloc((void**)&p->d_tab, sizeof(aacg_parse_tables)) != hipSuccess ||
+            hipMemcpy(p->d_tab, tab.data(), sizeof(aacg_parse_tables), hipMemcpyHostToDevice) != hipSuccess ||
+            hipFuncSetAttribute((const void*)aacg_parse_frames, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_bytes) != hipSuccess)
+            rc = fail(p, AACG_ERR_NO_DEVICE, "HIP setup of the parser failed");
+    }
+    /* on failure the object is still returned, so that aacg_parser_last_error() can say why */
+    *out = p;
+    return rc;
+}
+
+void aacg_parser_destroy(aacg_parser* p)
+{
+    if (!p) return;
+    for (int i = 0; i < 7; i++) if (p->d_buf[i]) (void)hipFree(p->d_buf[i]);
+    if (p->d_tab) (void)hipFree(p->d_tab);
+    if (p->stream) (void)hipStreamDestroy(p->stream);
+    delete p;
+}
+
+int aacg_parse_device(aacg_parser* p, const void* d_bytes, const aacg_parse_frame* d_frames, uint32_t n_frames,
+                      uint32_t max_units, uint32_t max_channels, uint32_t options,
+                      aacg_unit_desc* d_units, int16_t* d_q, aacg_band_meta* d_meta, aacg_tns_info* d_tns,
+                      aacg_parse_result* d_results, void* hip_stream)
+{
+    if (!p || !p->d_tab) return AACG_ERR_INVALID_ARG;
+    if (!n_frames) return AACG_OK;
+    if (!d_bytes || !d_frames || !d_units || !d_q || !d_meta || !d_results || !max_units || !max_channels || ((uintptr_t)d_bytes & 3u))
+        return fail(p, AACG_ERR_INVALID_ARG, "aacg_parse_device: null or misaligned argument");
+    HIPCHECK(hipSetDevice(p->device));
+    aacg_parse_params P;
+    P.bytes = (const uint32_t*)d_bytes; P.frames = d_frames; P.tab = p->d_tab; P.units = d_units; P.q = d_q; P.meta = d_meta;
+    P.tns = d_tns; P.results = d_results; P.n_frames = n_frames; P.max_units = max_units; P.max_channels = max_channels; P.options = options;
+    return launch(p, P, hip_stream ? (hipStream_t)hip_stream : p->stream);
+}
+
+int aacg_parse_batch(aacg_parser* p, const uint8_t* bytes, size_t n_bytes, const aacg_parse_frame* frames, uint32_t n_frames,
+                     uint32_t max_units, uint32_t max_channels, uint32_t options,
+                     aacg_unit_desc* units, int16_t* q, aacg_band_meta* meta, aacg_tns_info* tns, aacg_parse_result* results)
+{
+    if (!p || !p->d_tab) return AACG_ERR_INVALID_ARG;
+    if (!n_frames) return AACG_OK;
+    if (!bytes || !frames || !units || !q || !meta || !results || !max_units || !max_channels)
+        return fail(p, AACG_ERR_INVALID_ARG, "aacg_parse_batch: null argument");
+    for (uint32_t f = 0; f < n_frames; f++)
+        if ((size_t)frames[f].byte_offset + frames[f].byte_length > n_bytes) return fail(p, AACG_ERR_INVALID_ARG, "frame " + std::to_string(f) + " lies outside the byte buffer");
+    HIPCHECK(hipSetDevice(p->device));
+    const size_t padded = (n_bytes + 3u) / 4u * 4u + 8u, blocks = (size_t)n_frames * max_channels;
+    const size_t sizes[7] = { padded, n_frames * sizeof(aacg_parse_frame), (size_t)n_frames * max_units * sizeof(aacg_unit_desc),
+                              blocks * 1024u * sizeof(int16_t), blocks * sizeof(aacg_band_meta), tns ? blocks * sizeof(aacg_tns_info) : 0,
+                              n_frames * sizeof(aacg_parse_result) };
+    for (int i = 0; i < 7; i++) { int rc = sizes[i] ? grow(p, i, sizes[i]) : AACG_OK; if (rc) return rc; }
+    hipStream_t s = p->stream;
+    HIPCHECK(hipMemsetAsync((char*)p->d_buf[0] + padded - 12u, 0, 12u, s));
+    HIPCHECK(hipMemcpyAsync(p->d_buf[0], bytes, n_bytes, hipMemcpyHostToDevice, s));
+    HIPCHECK(hipMemcpyAsync(p->d_buf[1], frames, sizes[1], hipMemcpyHostToDevice, s));
+    HIPCHECK(hipMemsetAsync(p->d_buf[2], 0, sizes[2], s));
+    HIPCHECK(hipMemsetAsync(p->d_buf[4], 0, sizes[4], s));
+    aacg_parse_params P;
+    P.bytes = (const uint32_t*)p->d_buf[0]; P.frames = (const aacg_parse_frame*)p->d_buf[1]; P.tab = p->d_tab;
+    P.units = (aacg_unit_desc*)p->d_buf[2]; P.q = (int16_t*)p->d_buf[3]; P.meta = (aacg_band_meta*)p->d_buf[4];
+    P.tns = tns ? (aacg_tns_info*)p->d_buf[5] : nullptr; P.results = (aacg_parse_result*)p->d_buf[6];
+    P.n_frames = n_frames; P.max_units = max_units; P.max_channels = max_channels; P.options = options;
+    int rc = launch(p, P, s);
+    if (rc) return rc;
+    HIPCHECK(hipMemcpyAsync(units, p->d_buf[2], sizes[2], hipMemcpyDeviceToHost, s));
+    HIPCHECK(hipMemcpyAsync(q, p->d_buf[3], sizes[3], hipMemcpyDeviceToHost, s));
+    HIPCHECK(hipMemcpyAsync(meta, p->d_buf[4], sizes[4], hipMemcpyDeviceToHost, s));
+    if (tns) HIPCHECK(hipMemcpyAsync(tns, p->d_buf[5], sizes[5], hipMemcpyDeviceToHost, s));
+    HIPCHECK(hipMemcpyAsync(results, p->d_buf[6], sizes[6], hipMemcpyDeviceToHost, s));
+    HIPCHECK(hipStreamSynchronize(s));
+    return AACG_OK;
+}
+
+}  // extern "C"

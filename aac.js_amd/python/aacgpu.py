@@ -22,7 +22,9 @@ ABI_SYMBOLS = ["aacg_create", "aacg_destroy", "aacg_last_error", "aacg_abi_versi
                "aacg_get_overlap", "aacg_set_overlap", "aacg_decode_batch", "aacg_submit", "aacg_wait",
                "aacg_decode_batch_tns", "aacg_submit_tns", "aacg_plan_create_tns",
                "aacg_host_alloc", "aacg_host_free", "aacg_plan_create", "aacg_plan_destroy",
-               "aacg_decode_device", "aacg_spectral_device", "aacg_synchronize", "aacg_get_table", "aacg_kernel_name"]
+               "aacg_decode_device", "aacg_spectral_device", "aacg_synchronize", "aacg_get_table", "aacg_kernel_name",
+               "aacg_parser_create", "aacg_parser_destroy", "aacg_parser_last_error", "aacg_parse_status_string",
+               "aacg_parse_batch", "aacg_parse_device", "aacg_parse_kernel_name"]
 
 UNIT_DTYPE = np.dtype([
     ("stream", "<u4"), ("pcm_offset", "<u4"), ("channel", "<u2"), ("n_out_ch", "<u2"),
@@ -122,8 +124,85 @@ def load_library(path=LIB_PATH):
     L.aacg_spectral_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.aacg_synchronize.argtypes = [C.c_void_p, C.c_void_p]
     L.aacg_get_table.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
+    L.aacg_parser_create.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]
+    L.aacg_parser_destroy.argtypes = [C.c_void_p]
+    L.aacg_parser_destroy.restype = None
+    L.aacg_parser_last_error.argtypes = [C.c_void_p]
+    L.aacg_parser_last_error.restype = C.c_char_p
+    L.aacg_parse_status_string.argtypes = [C.c_int]
+    L.aacg_parse_status_string.restype = C.c_char_p
+    L.aacg_parse_kernel_name.restype = C.c_char_p
+    L.aacg_parse_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.aacg_parse_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     _lib = L
     return L
+
+
+# ---- device front end (aacg_parser_*, include/aacgpu.h) -------------------------------------------------
+CODE_ENTRY_DTYPE = np.dtype([("code", "<u4"), ("len", "u1"), ("v", "i1", (4,)), ("reserved", "u1", (3,))])
+PARSE_FRAME_DTYPE = np.dtype([("byte_offset", "<u4"), ("byte_length", "<u4")])
+PARSE_RESULT_DTYPE = np.dtype([("status", "u1"), ("n_units", "u1"), ("n_channels", "u1"), ("flags", "u1"), ("bits_used", "<u4")])
+META_DTYPE = np.dtype(("<u2", (120,)))
+PARSE_APPLY_PULSES, PARSE_REFERENCE_QUIRKS = 1, 2
+
+
+def alloc_parse_outputs(n_frames, max_units, max_channels, want_tns):
+    blocks = n_frames * max_channels
+    return {"units": np.zeros(n_frames * max_units, UNIT_DTYPE), "q": np.zeros((blocks, 1024), np.int16),
+            "meta": np.zeros((blocks, 120), np.uint16), "tns": np.zeros(blocks, TNS_DTYPE) if want_tns else None,
+            "results": np.zeros(n_frames, PARSE_RESULT_DTYPE)}
+
+
+class Parser:
+    """aacg_parser: one GPU lane parses one frame.  entries / counts: the 12 codebooks as CODE_ENTRY_DTYPE records."""
+
+    def __init__(self, entries, counts, sample_index=3, device=0):
+        self.lib = load_library()
+        entries = np.ascontiguousarray(entries)
+        counts = np.ascontiguousarray(counts, np.uint32)
+        assert entries.dtype == CODE_ENTRY_DTYPE and counts.size == 12
+        h = C.c_void_p()
+        rc = self.lib.aacg_parser_create(device, sample_index, entries.ctypes.data, counts.ctypes.data, C.byref(h))
+        self.handle = h
+        if rc != 0:
+            msg = self.lib.aacg_parser_last_error(h).decode() if h else "aacg_parser_create failed"
+            self.close()
+            raise AacgError(rc, msg)
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.aacg_parser_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise AacgError(rc, self.lib.aacg_parser_last_error(self.handle).decode())
+
+    def parse_batch(self, data, frames, max_units, max_channels, options=PARSE_REFERENCE_QUIRKS, want_tns=False):
+        data = np.ascontiguousarray(data, np.uint8)
+        frames = np.ascontiguousarray(frames)
+        assert frames.dtype == PARSE_FRAME_DTYPE
+        out = alloc_parse_outputs(len(frames), max_units, max_channels, want_tns)
+        self._check(self.lib.aacg_parse_batch(self.handle, data.ctypes.data, data.size, frames.ctypes.data, len(frames), max_units, max_channels,
+                                              options, out["units"].ctypes.data, out["q"].ctypes.data, out["meta"].ctypes.data,
+                                              out["tns"].ctypes.data if want_tns else None, out["results"].ctypes.data))
+        return out
+
+    def parse_device(self, d_bytes, d_frames, n_frames, max_units, max_channels, options, d_units, d_q, d_meta, d_tns, d_results, stream=0):
+        """Device pointers (ints); asynchronous on `stream`."""
+        self._check(self.lib.aacg_parse_device(self.handle, d_bytes, d_frames, n_frames, max_units, max_channels, options,
+                                               d_units, d_q, d_meta, d_tns, d_results, stream))
+
+    def status_string(self, status):
+        return self.lib.aacg_parse_status_string(int(status)).decode()
 
 
 class Plan:

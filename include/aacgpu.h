@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define AACG_ABI_VERSION 2
+#define AACG_ABI_VERSION 3
 
 #define AACG_FRAME_LEN      1024   /* decoder.js:86 frameLength                       */
 #define AACG_MAX_SECTIONS   120    /* ics.js:49 MAX_SECTIONS (bandTypes/scaleFactors) */
@@ -274,6 +274,96 @@ int aacg_synchronize(aacg_engine* e, void* hip_stream);
 int aacg_get_table(aacg_engine* e, int which, float* dst, size_t n);
 /* Name of the dominant kernel (for matching rocprofv3 rows).                            */
 const char* aacg_kernel_name(void);
+
+
+/* ---- the bitstream front end on the device (optional; independent of aacg_engine) ---------------
+ * One GPU lane parses one frame: what aac.js does serially per frame between `stream.peek(12)` and
+ * `this.process(elements)` (decoder.js:126-201 element loop, ics.js:56-201,279-314, cpe.js:37-75,
+ * tns.js:68-103, cce.js:45-119 parse-and-discard, huffman.js:1425-1490) for a whole batch of frames at
+ * once, writing the records aacg_decode_* / aacg_plan_create* take.  The host keeps what is trivial and
+ * serial: finding frame boundaries (ADTS frame_length, MP4 sample sizes) and numbering streams.
+ *
+ * The Huffman code words are not part of this library.  The caller supplies the 12 codebooks as
+ * (length, code word, values) lists — book 0 = scalefactors (v[0] = 0..120, huffman.js HCB_SF), books
+ * 1..11 = spectral (huffman.js HCB1..HCB11; v[0..3] for books 1-4, v[0..1] for 5-11; magnitudes for the
+ * unsigned books 3,4,7..11) — e.g. as aac.js_amd/js/codebooks.js obtains them from a provider.        */
+typedef struct aacg_code_entry {
+    uint32_t code;             /* the code word, right-aligned                                     */
+    uint8_t  len;              /* its length in bits, 1..24                                        */
+    int8_t   v[4];
+    uint8_t  reserved[3];
+} aacg_code_entry;
+
+typedef struct aacg_parse_frame {
+    uint32_t byte_offset;      /* of the frame in `bytes`: an ADTS frame (header included, decoder.js:129-130)
+                                  or a bare raw_data_block                                         */
+    uint32_t byte_length;
+} aacg_parse_frame;
+
+enum {                         /* aacg_parse_result.status; the reference's message for each in
+                                  aacg_parse_status_string()                                       */
+    AACG_PARSE_OK = 0,
+    AACG_PARSE_INSUFFICIENT_DATA = 1,  /* the frame ended inside an element (AV.Bitstream underflow)   */
+    AACG_PARSE_BAND_TYPE = 2,          /* ics.js:96  'Invalid band type: 12'                            */
+    AACG_PARSE_TOO_MANY_BANDS = 3,     /* ics.js:105 'Too many bands'                                   */
+    AACG_PARSE_SCALEFACTOR = 4,        /* ics.js:165 'Scalefactor out of range' (also below -100, where
+                                          the reference reads outside its table)                        */
+    AACG_PARSE_PULSE_IN_SHORT = 5,     /* ics.js:65  'Pulse tool not allowed in eight short sequence.'  */
+    AACG_PARSE_PULSE_RANGE = 6,        /* ics.js:180,193,198 'Pulse SWB / offset out of range'          */
+    AACG_PARSE_PULSE_DATA = 7,         /* ics.js:264 'TODO: add pulse data' (without AACG_PARSE_APPLY_PULSES) */
+    AACG_PARSE_TNS_ORDER = 8,          /* tns.js:85  'TNS filter out of range' (> 20; > 12 when TNS records
+                                          are requested, AACG_TNS_MAX_ORDER)                            */
+    AACG_PARSE_PREDICTION = 9,         /* ics.js:318 'Prediction not implemented.'                      */
+    AACG_PARSE_GAIN_CONTROL = 10,      /* ics.js:76  'TODO: decode gain control/SSR'                    */
+    AACG_PARSE_PCE = 11,               /* decoder.js:184 'TODO: PCE_ELEMENT'                            */
+    AACG_PARSE_MAX_SFB = 12,           /* max_sfb beyond the sampling rate's band count (the reference reads
+                                          outside its offset table)                                     */
+    AACG_PARSE_MS_MASK = 13,           /* cpe.js:66  'Reserved ms mask type: 3'                         */
+    AACG_PARSE_ESCAPE = 14,            /* escape sequence longer than the standard's 13 bits            */
+    AACG_PARSE_CAPACITY = 15           /* more elements / channels in the frame than the caller allowed */
+};
+#define AACG_PARSE_APPLY_PULSES      0x1u   /* add pulse data to the spectrum (ISO/IEC 14496-3 4.6.3.3) instead
+                                               of failing the frame as the reference does              */
+#define AACG_PARSE_REFERENCE_QUIRKS  0x2u   /* coupling channel elements consume the bits cce.js consumes
+                                               (AFTER_IMDCT never matches, the band index only steps on coded
+                                               bands) rather than the standard's syntax                  */
+#define AACG_PARSE_HAS_PNS 0x1
+#define AACG_PARSE_HAS_TNS 0x2
+typedef struct aacg_parse_result {
+    uint8_t  status;           /* AACG_PARSE_*; a failed frame's output records are unspecified    */
+    uint8_t  n_units;          /* SCE/LFE/CPE elements found = records written for this frame      */
+    uint8_t  n_channels;
+    uint8_t  flags;            /* AACG_PARSE_HAS_*                                                 */
+    uint32_t bits_used;        /* consumed from byte_offset on, byte-aligned at the end            */
+} aacg_parse_result;
+
+typedef struct aacg_parser aacg_parser;
+/* counts[b] entries of book b, concatenated in `entries`; every book must be a complete prefix code.  */
+int aacg_parser_create(int device_ordinal, int sample_index, const aacg_code_entry* entries,
+                       const uint32_t counts[12], aacg_parser** out);
+void aacg_parser_destroy(aacg_parser* p);
+const char* aacg_parser_last_error(const aacg_parser* p);
+const char* aacg_parse_status_string(int status);
+
+/* Frame f's element e lands in units[f * max_units + e]; its channels in q / meta / tns block
+ * f * max_channels + (running channel index), which is what the record's coef_offset / meta_offset /
+ * tns_offset say.  Left for the caller to fill before decoding: stream, pcm_offset, n_out_ch
+ * (window_shape_prev is written as 0, as aac.js has it).  reserved0 carries (element type << 4) | id.
+ * tns may be NULL: TNS side info is then consumed and dropped (AACG_TNS_REFERENCE engines).
+ *
+ * aacg_parse_batch: host pointers, returns when the results are there.
+ * aacg_parse_device: DEVICE pointers, asynchronous on hip_stream; d_bytes 4-byte aligned with >= 8 readable
+ * bytes after the last frame; zero-fills d_q (and d_tns) itself.                                        */
+int aacg_parse_batch(aacg_parser* p, const uint8_t* bytes, size_t n_bytes,
+                     const aacg_parse_frame* frames, uint32_t n_frames,
+                     uint32_t max_units, uint32_t max_channels, uint32_t options,
+                     aacg_unit_desc* units, int16_t* q, aacg_band_meta* meta, aacg_tns_info* tns,
+                     aacg_parse_result* results);
+int aacg_parse_device(aacg_parser* p, const void* d_bytes, const aacg_parse_frame* d_frames, uint32_t n_frames,
+                      uint32_t max_units, uint32_t max_channels, uint32_t options,
+                      aacg_unit_desc* d_units, int16_t* d_q, aacg_band_meta* d_meta, aacg_tns_info* d_tns,
+                      aacg_parse_result* d_results, void* hip_stream);
+const char* aacg_parse_kernel_name(void);
 
 #ifdef __cplusplus
 }

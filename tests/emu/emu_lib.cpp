@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "../../aac.js_amd/csrc/aacg_kernels.h"
+#include "../../aac.js_amd/csrc/aacg_parse.h"
 #include "../../aac.js_amd/csrc/aacg_host.h"
 
 thread_local emu_lane_ctx g_emu;
@@ -18,8 +19,9 @@ namespace {
 struct launch_arg {
     emu_lane_ctx ctx;
     const aacg_kparams* P;
-    int kind;     /* 0 f32 run, 1 quant run, 2 spectral */
+    int kind;     /* 0 f32 run, 1 quant run, 2 spectral, 3/4 optional stages, 5/6 frame-major, 7 front end */
     int n_units;
+    const aacg_parse_params* PP;
 };
 
 void* lane_main(void* p)
@@ -27,6 +29,7 @@ void* lane_main(void* p)
     launch_arg* a = (launch_arg*)p;
     g_emu = a->ctx;
     /* the same dispatch as the engine's launch_run: double-duty variant / plain; kinds 3, 4: the optional-stage kernel */
+    if (a->kind == 7) { aacg_parse::parse_body(*a->PP); return nullptr; }
     const bool dd = a->P->scratch != nullptr;
     if (a->kind == 0)      { if (dd) imdct_run_body_dd<AACG_INPUT_SPEC_F32>(*a->P); else imdct_run_body<AACG_INPUT_SPEC_F32>(*a->P); }
     else if (a->kind == 1) { if (dd) imdct_run_body_dd<AACG_INPUT_QUANT_I16>(*a->P); else imdct_run_body<AACG_INPUT_QUANT_I16>(*a->P); }
@@ -38,7 +41,7 @@ void* lane_main(void* p)
     return nullptr;
 }
 
-void launch(const aacg_kparams& P, int kind, int grid, int waves, size_t lds_bytes, int n_units = 0)
+void launch(const aacg_kparams& P, int kind, int grid, int waves, size_t lds_bytes, int n_units = 0, const aacg_parse_params* PP = nullptr)
 {
     const int threads = waves * 64;
     std::vector<emu_wave> wv((size_t)waves);
@@ -61,6 +64,7 @@ void launch(const aacg_kparams& P, int kind, int grid, int waves, size_t lds_byt
             args[(size_t)t].P = &P;
             args[(size_t)t].kind = kind;
             args[(size_t)t].n_units = n_units;
+            args[(size_t)t].PP = PP;
             pthread_create(&tid[(size_t)t], &attr, lane_main, &args[(size_t)t]);
         }
         for (int t = 0; t < threads; t++) pthread_join(tid[(size_t)t], nullptr);
@@ -201,6 +205,32 @@ int emu_spectral(int sample_index, const aacg_unit_desc* units, uint32_t n_units
     P.units = ph.units.data(); P.coeffs = coeffs; P.meta = meta; P.spec_out = spec_out; P.tab = &g_tab;
     launch(P, 2, (int)((n_units + AACG_WG_WAVES - 1) / AACG_WG_WAVES), AACG_WG_WAVES,
            (AACG_TAB_QUANT_FLOATS + AACG_WG_WAVES * 512) * 4, (int)n_units);
+    return AACG_OK;
+}
+
+/* the device front end (aacg_parse.h) on host memory: same arguments as aacg_parse_batch */
+int emu_parse(int sample_index, const aacg_code_entry* entries, const uint32_t* counts,
+              const uint8_t* bytes, size_t n_bytes, const aacg_parse_frame* frames, uint32_t n_frames,
+              uint32_t max_units, uint32_t max_channels, uint32_t options,
+              aacg_unit_desc* units, int16_t* q, aacg_band_meta* meta, aacg_tns_info* tns, aacg_parse_result* results)
+{
+    static aacg_parse_tables tab;
+    int rc = aacg_parse_build_tables(sample_index, entries, counts, &tab, &g_err);
+    if (rc) return rc;
+    std::vector<uint32_t> padded((n_bytes + 3) / 4 + 2, 0u);
+    std::memcpy(padded.data(), bytes, n_bytes);
+    const size_t blocks = (size_t)n_frames * max_channels;
+    std::memset(units, 0, (size_t)n_frames * max_units * sizeof *units);
+    std::memset(q, 0, blocks * 1024 * sizeof *q);
+    std::memset(meta, 0, blocks * sizeof *meta);
+    if (tns) std::memset(tns, 0, blocks * sizeof *tns);
+    aacg_parse_params PP;
+    PP.bytes = padded.data(); PP.frames = frames; PP.tab = &tab; PP.units = units; PP.q = q; PP.meta = meta; PP.tns = tns; PP.results = results;
+    PP.n_frames = n_frames; PP.max_units = max_units; PP.max_channels = max_channels; PP.options = options;
+    aacg_kparams none;
+    std::memset(&none, 0, sizeof none);
+    launch(none, 7, (int)((n_frames + AACG_PARSE_WG_THREADS - 1) / AACG_PARSE_WG_THREADS), AACG_PARSE_WG_THREADS / 64,
+           (size_t)tab.lut_words * 4 + 160 + (size_t)AACG_MAX_SECTIONS * AACG_PARSE_WG_THREADS, 0, &PP);
     return AACG_OK;
 }
 

@@ -84,3 +84,22 @@ def pool_current(pool, parity):
         for c in range(Cn):
             out[s, c] = pool[s, c, parity[s * Cn + c]]
     return out
+
+
+def emu_parse(emu, sample_index, entries, counts, data, frames, max_units, max_channels, options, want_tns):
+    """The device front end's kernel source (aacg_parse.h) run on the CPU: same outputs as aacgpu.Parser.parse_batch."""
+    import aacgpu
+    data = np.ascontiguousarray(data, np.uint8)
+    frames = np.ascontiguousarray(frames)
+    entries = np.ascontiguousarray(entries)
+    counts = np.ascontiguousarray(counts, np.uint32)
+    out = aacgpu.alloc_parse_outputs(len(frames), max_units, max_channels, want_tns)
+    f = emu.lib.emu_parse
+    f.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    rc = f(sample_index, entries.ctypes.data, counts.ctypes.data, data.ctypes.data, data.size, frames.ctypes.data, len(frames),
+           max_units, max_channels, options, out["units"].ctypes.data, out["q"].ctypes.data, out["meta"].ctypes.data,
+           out["tns"].ctypes.data if want_tns else None, out["results"].ctypes.data)
+    if rc:
+        raise RuntimeError("emu_parse rc=%d: %s" % (rc, emu.error()))
+    return out
