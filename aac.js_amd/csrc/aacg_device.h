@@ -143,9 +143,13 @@ struct aacg_kparams {
 };
 
 /* ---- device front end (aacg_parse.h) ------------------------------------------------------------ */
-#define AACG_PARSE_WG_THREADS 256
+#define AACG_PARSE_WG_SMALL   256      /* frames staged in LDS: shortest time per frame */
+#define AACG_PARSE_WG_LARGE   1024     /* frames read in place, 16 waves per CU: highest rate on large batches */
 #define AACG_PARSE_L1_BITS    9
 #define AACG_PARSE_LUT_WORDS  12288     /* 12 first-level tables of 512 + the second-level tables */
+#define AACG_PARSE_PAD_BYTES  32        /* readable bytes required after the last frame (look-ahead + 16-byte staging) */
+/* LDS of a workgroup: tables, band columns, allocator word, then the arena */
+#define AACG_PARSE_LDS_FIXED(lut_words, threads) ((size_t)(lut_words) * 4u + 160u + (size_t)AACG_MAX_SECTIONS * (threads) + 16u)
 /* lut entry: bits 0..4 code length; bit 5 clear: bits 8..31 payload (scalefactor book: the value; spectral books:
  * values as 6-bit two's-complement fields);  bit 5 set: bits 0..4 = extra bits, bits 8..31 = index of a
  * second-level table */
@@ -168,6 +172,8 @@ typedef struct aacg_parse_params {
     aacg_tns_info* tns;
     aacg_parse_result* results;
     uint32_t n_frames, max_units, max_channels, options;
+    uint32_t arena_bytes;      /* LDS left for staging the frames' bytes */
+    uint32_t wg_threads;
 } aacg_parse_params;
 
 #endif

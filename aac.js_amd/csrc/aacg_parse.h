@@ -30,7 +30,9 @@
 namespace aacg_parse {
 
 struct bit_reader {
-    const uint32_t* base;      /* the whole byte buffer as big-endian dwords */
+    int lds;                   /* LDS byte address of the frame's staged bytes (big-endian dwords), or -1: */
+    const uint32_t* glb;       /* ... read in place.  Kept apart so that the staged case compiles to ds_read: a flat or
+                                  global load would wait on vmcnt, i.e. for every spectrum store issued before it */
     uint32_t pos, end;         /* absolute bit positions */
     uint32_t cached;           /* dword index held in w */
     uint64_t w;
@@ -39,9 +41,9 @@ struct bit_reader {
 
 DP_DEVICE uint32_t be32(uint32_t v) { return __builtin_bswap32(v); }
 
-DP_DEVICE void br_open(bit_reader& r, const uint32_t* base, uint32_t byte_offset, uint32_t byte_length)
+DP_DEVICE void br_open(bit_reader& r, int lds, const uint32_t* glb, uint32_t byte_offset, uint32_t byte_length)
 {
-    r.base = base; r.pos = byte_offset * 8u; r.end = r.pos + byte_length * 8u;
+    r.lds = lds; r.glb = glb; r.pos = byte_offset * 8u; r.end = r.pos + byte_length * 8u;
     r.cached = 0xffffffffu; r.w = 0; r.status = AACG_PARSE_OK;
 }
 
@@ -50,7 +52,8 @@ DP_DEVICE uint32_t br_peek(bit_reader& r, int n)
 {
     const uint32_t i = r.pos >> 5;
     if (i != r.cached) {
-        r.w = ((uint64_t)be32(r.base[i]) << 32) | be32(r.base[i + 1]);
+        if (r.lds >= 0) r.w = ((uint64_t)be32(dp_lds_read_u32(r.lds + 4 * (int)i)) << 32) | be32(dp_lds_read_u32(r.lds + 4 * (int)i + 4));
+        else       r.w = ((uint64_t)be32(r.glb[i]) << 32) | be32(r.glb[i + 1]);
         r.cached = i;
     }
     return (uint32_t)((r.w << (r.pos & 31u)) >> (64 - n));
@@ -74,15 +77,34 @@ DP_DEVICE uint32_t br_read(bit_reader& r, int n)
 
 DP_DEVICE void br_fail(bit_reader& r, int code) { if (!r.status) r.status = code; }
 
-/* next code word of `book`: returns the entry's 24-bit payload */
-DP_DEVICE uint32_t huff(bit_reader& r, const uint32_t* lut, int book)
+/* the next 32 bits, for a code word and its sign bits in one look */
+DP_DEVICE uint32_t br_peek32(bit_reader& r)
 {
-    if (r.status) return 0;
-    uint32_t e = lut[book * (1 << AACG_PARSE_L1_BITS) + (int)br_peek(r, AACG_PARSE_L1_BITS)];
+    const uint32_t i = r.pos >> 5;
+    if (i != r.cached) {
+        if (r.lds >= 0) r.w = ((uint64_t)be32(dp_lds_read_u32(r.lds + 4 * (int)i)) << 32) | be32(dp_lds_read_u32(r.lds + 4 * (int)i + 4));
+        else       r.w = ((uint64_t)be32(r.glb[i]) << 32) | be32(r.glb[i + 1]);
+        r.cached = i;
+    }
+    return (uint32_t)((r.w << (r.pos & 31u)) >> 32);
+}
+
+/* entry of the code word at the top of `win` */
+DP_DEVICE uint32_t lut_entry(int lut, int book, uint32_t win)
+{
+    uint32_t e = dp_lds_read_u32(lut + 4 * (book * (1 << AACG_PARSE_L1_BITS) + (int)(win >> (32 - AACG_PARSE_L1_BITS))));
     if (e & 0x20u) {
         const int extra = (int)(e & 31u);
-        e = lut[(e >> 8) + (br_peek(r, AACG_PARSE_L1_BITS + extra) & ((1u << extra) - 1u))];
+        e = dp_lds_read_u32(lut + 4 * (int)((e >> 8) + ((win >> (32 - AACG_PARSE_L1_BITS - extra)) & ((1u << extra) - 1u))));
     }
+    return e;
+}
+
+/* next code word of `book`: returns the entry's 24-bit payload */
+DP_DEVICE uint32_t huff(bit_reader& r, int lut, int book)
+{
+    if (r.status) return 0;
+    const uint32_t e = lut_entry(lut, book, br_peek32(r));
     br_skip(r, e & 31u);
     return r.status ? 0u : e >> 8;
 }
@@ -97,11 +119,14 @@ DP_DEVICE int group_len(const ics_info& i, int g) { return (int)((i.group_len >>
 
 struct lane_ctx {
     const aacg_parse_params* P;
-    const uint32_t* lut;       /* LDS */
-    const uint16_t* swb_long;  /* LDS */
-    const uint16_t* swb_short; /* LDS */
-    unsigned char* bands;      /* LDS, this lane's byte column: bands[idx * stride] = band type | ms_used << 7 */
+    /* LDS byte addresses (explicit ds_read / ds_write through devport, never a flat access) */
+    int lut;
+    int swb_long, swb_short;   /* uint16 offsets */
+    int bands;                 /* this lane's byte column: byte idx * stride = band type | ms_used << 7 */
     int stride;
+    unsigned char* arena;      /* the workgroup's frames are staged here as far as they fit */
+    int* arena_top;
+    int arena_bytes;
 };
 
 /* ics_info (ics.js:279-314) */
@@ -162,11 +187,13 @@ struct ics_out {
     aacg_chan_info* chan;
 };
 
-/* individual_channel_stream (ics.js:56-201).  shared != nullptr: common_window.  Returns flags: 1 noise bands, 2 TNS */
-DP_DEVICE int parse_ics(bit_reader& r, const lane_ctx& c, const ics_info* shared, ics_info& info, const ics_out& o, bool keep_ms)
+/* individual_channel_stream (ics.js:56-201).  have_info: common_window, `info` was read by the caller.
+ * Returns flags: 1 noise bands, 2 TNS.  (info travels by reference to a plain local: a pointer chosen at run time
+ * would put it in scratch memory, and every scratch access waits for the spectrum stores before it.) */
+DP_DEVICE int parse_ics(bit_reader& r, const lane_ctx& c, bool have_info, ics_info& info, const ics_out& o, bool keep_ms)
 {
     const int global_gain = (int)br_read(r, 8);
-    if (shared) info = *shared; else parse_ics_info(r, c, info);
+    if (!have_info) parse_ics_info(r, c, info);
     if (r.status) return 0;
     const int groups = info.groups, max_sfb = info.max_sfb, nb = groups * max_sfb, S = c.stride;
     const bool is_short = info.seq == 2;
@@ -181,7 +208,7 @@ DP_DEVICE int parse_ics(bit_reader& r, const lane_ctx& c, const ics_info* shared
             while ((incr = (int)br_read(r, len_bits)) == esc && !r.status) end += incr;
             end += incr;
             if (end > max_sfb) { br_fail(r, AACG_PARSE_TOO_MANY_BANDS); break; }
-            for (; k < end; k++, idx++) c.bands[idx * S] = (unsigned char)((keep_ms ? c.bands[idx * S] & 0x80 : 0) | bt);
+            for (; k < end; k++, idx++) dp_lds_write_u8(c.bands + idx * S, (keep_ms ? dp_lds_read_u8(c.bands + idx * S) & 0x80u : 0u) | (uint32_t)bt);
         }
     if (r.status) return 0;
 
@@ -189,7 +216,7 @@ DP_DEVICE int parse_ics(bit_reader& r, const lane_ctx& c, const ics_info* shared
     int sf_spec = global_gain, sf_noise = global_gain - 90, sf_int = 0, flags = 0;
     bool first_noise = true;
     for (int idx = 0; idx < nb && !r.status; idx++) {
-        const int b = c.bands[idx * S], bt = b & 15;
+        const int b = (int)dp_lds_read_u8(c.bands + idx * S), bt = b & 15;
         int word = bt << 12;
         if (bt == 0) {
         } else if (bt >= 14) {
@@ -212,18 +239,19 @@ DP_DEVICE int parse_ics(bit_reader& r, const lane_ctx& c, const ics_info* shared
 
     /* pulse_data (ics.js:175-201): kept in registers until the spectrum is there */
     int n_pulse = 0;
-    uint32_t pulse_at[4] = {0, 0, 0, 0}, pulse_amp = 0;
+    uint64_t pulse_at = 0;         /* 4 x 16 bits */
+    uint32_t pulse_amp = 0;        /* 4 x 4 bits */
     if (br_read(r, 1)) {
         if (is_short) br_fail(r, AACG_PARSE_PULSE_IN_SHORT);
         n_pulse = (int)br_read(r, 2) + 1;
         const int swb = (int)br_read(r, 6);
         if (swb >= info.n_swb) br_fail(r, AACG_PARSE_PULSE_RANGE);
-        uint32_t at = r.status ? 0u : c.swb_long[swb];
+        uint32_t at = r.status ? 0u : dp_lds_read_u16(c.swb_long + 2 * swb);
         for (int i = 0; i < 4; i++)
             if (i < n_pulse) {
                 at += br_read(r, 5);
                 if (at > 1023u) br_fail(r, AACG_PARSE_PULSE_RANGE);
-                pulse_at[i] = at;
+                pulse_at |= (uint64_t)(at & 1023u) << (16 * i);
                 pulse_amp |= br_read(r, 4) << (4 * i);
             }
         if (!(c.P->options & AACG_PARSE_APPLY_PULSES)) br_fail(r, AACG_PARSE_PULSE_DATA);
@@ -240,55 +268,76 @@ DP_DEVICE int parse_ics(bit_reader& r, const lane_ctx& c, const ics_info* shared
         for (int g = 0; g < 8; g++) o.chan->group_len[g] = (uint8_t)(g < groups ? group_len(info, g) : 0);
     }
 
-    /* spectral_data (ics.js:203-261 without the dequantisation) */
-    const uint16_t* off = is_short ? c.swb_short : c.swb_long;
-    for (int g = 0, idx = 0, group_off = 0; g < groups && !r.status; g++) {
-        const int glen = group_len(info, g);
-        for (int sfb = 0; sfb < max_sfb && !r.status; sfb++, idx++) {
-            const int bt = c.bands[idx * S] & 15;
-            if (bt == 0 || bt >= 13) continue;
-            const int lo = group_off + off[sfb], hi = group_off + off[sfb + 1];
-            for (int w = 0; w < glen && !r.status; w++) {
-                if (bt < 5) {
-                    const bool sgn = bt >= 3;
-                    for (int k = lo + w * 128; k < hi + w * 128 && !r.status; k += 4) {
-                        const uint32_t p = huff(r, c.lut, bt);
-                        int v[4];
-                        for (int j = 0; j < 4; j++) { v[j] = field6(p, j); if (sgn && v[j] && br_read(r, 1)) v[j] = -v[j]; }
-                        if (o.q) {
-                            uint32_t* d = (uint32_t*)(o.q + k);
-                            d[0] = (uint32_t)(v[0] & 0xffff) | ((uint32_t)v[1] << 16);
-                            d[1] = (uint32_t)(v[2] & 0xffff) | ((uint32_t)v[3] << 16);
-                        }
+    /* spectral_data (ics.js:203-261 without the dequantisation).  ONE loop per lane, one code word or one step of
+     * the (group, band, window) walk per trip: written as the reference's four nested loops, a wave would run every
+     * level for as many trips as its slowest lane needs at that level — the product of the maxima instead of the
+     * maximum of the sums.  Quads and pairs share the body (a pair's fields 2, 3 are zero and take no sign bits). */
+    if (nb > 0) {
+        const int off = is_short ? c.swb_short : c.swb_long;
+        int g = 0, sfb = -1, idx = -1, glen = group_len(info, 0), w = glen, group_off = 0;
+        int k = 0, hi = 0, bt = 0, lo0 = 0, hi0 = 0;
+        uint32_t sgn = 0;
+        while (!r.status) {
+            if (k >= hi) {
+                if (++w >= glen) {
+                    w = 0; sfb++; idx++;
+                    if (sfb >= max_sfb) {
+                        sfb = 0; group_off += glen * 128;
+                        if (++g >= groups) break;
+                        glen = group_len(info, g);
                     }
-                } else {
-                    const bool sgn = bt >= 7;
-                    for (int k = lo + w * 128; k < hi + w * 128 && !r.status; k += 2) {
-                        const uint32_t p = huff(r, c.lut, bt);
-                        int v[2];
-                        for (int j = 0; j < 2; j++) { v[j] = field6(p, j); if (sgn && v[j] && br_read(r, 1)) v[j] = -v[j]; }
-                        if (bt == 11)
-                            for (int j = 0; j < 2; j++) {
-                                if (v[j] != 16 && v[j] != -16) continue;
-                                int n = 4;
-                                while (br_read(r, 1)) n++;
-                                if (n > 12) { br_fail(r, AACG_PARSE_ESCAPE); break; }
-                                const int mag = (1 << n) + (int)br_read(r, n);
-                                v[j] = v[j] < 0 ? -mag : mag;
-                            }
-                        if (o.q) *(uint32_t*)(o.q + k) = (uint32_t)(v[0] & 0xffff) | ((uint32_t)v[1] << 16);
-                    }
+                    bt = (int)dp_lds_read_u8(c.bands + idx * S) & 15;
+                    if (bt == 0 || bt >= 13) { w = glen; continue; }           /* nothing coded: on to the next band */
+                    lo0 = (int)dp_lds_read_u16(off + 2 * sfb); hi0 = (int)dp_lds_read_u16(off + 2 * sfb + 2);
+                    sgn = (bt >= 7 || bt == 3 || bt == 4) ? 1u : 0u;
+                }
+                k = group_off + w * 128 + lo0; hi = group_off + w * 128 + hi0;
+                continue;
+            }
+            const uint32_t win = br_peek32(r), e = lut_entry(c.lut, bt, win), p = e >> 8;
+            uint32_t len = e & 31u, sb = win << len;                         /* sign bits follow the code word: <= 19 + 4 bits */
+            int v0 = field6(p, 0), v1 = field6(p, 1), v2 = field6(p, 2), v3 = field6(p, 3);
+            {   /* one sign bit per non-zero value of an unsigned book, in order; branch-free: the lanes of a wave
+                 * hold different values, every `if` here would run both ways */
+                const uint32_t n0 = sgn & (uint32_t)(v0 != 0), n1 = sgn & (uint32_t)(v1 != 0), n2 = sgn & (uint32_t)(v2 != 0), n3 = sgn & (uint32_t)(v3 != 0);
+                const int s0 = -(int)((sb >> 31) & n0); sb <<= n0;
+                const int s1 = -(int)((sb >> 31) & n1); sb <<= n1;
+                const int s2 = -(int)((sb >> 31) & n2); sb <<= n2;
+                const int s3 = -(int)((sb >> 31) & n3);
+                v0 = (v0 ^ s0) - s0; v1 = (v1 ^ s1) - s1; v2 = (v2 ^ s2) - s2; v3 = (v3 ^ s3) - s3;
+                len += n0 + n1 + n2 + n3;
+            }
+            br_skip(r, len);
+            if (bt == 11) {
+                if (v0 == 16 || v0 == -16) {
+                    int n = 4;
+                    while (br_read(r, 1)) n++;
+                    if (n > 12) br_fail(r, AACG_PARSE_ESCAPE);
+                    const int mag = (1 << (n & 15)) + (int)br_read(r, n & 15);
+                    v0 = v0 < 0 ? -mag : mag;
+                }
+                if (v1 == 16 || v1 == -16) {
+                    int n = 4;
+                    while (br_read(r, 1)) n++;
+                    if (n > 12) br_fail(r, AACG_PARSE_ESCAPE);
+                    const int mag = (1 << (n & 15)) + (int)br_read(r, n & 15);
+                    v1 = v1 < 0 ? -mag : mag;
                 }
             }
+            if (o.q && !r.status) {
+                uint32_t* d = (uint32_t*)(o.q + k);
+                d[0] = (uint32_t)(v0 & 0xffff) | ((uint32_t)v1 << 16);
+                if (bt < 5) d[1] = (uint32_t)(v2 & 0xffff) | ((uint32_t)v3 << 16);
+            }
+            k += bt < 5 ? 4 : 2;
         }
-        group_off += glen * 128;
     }
     if (r.status) return 0;
     if (o.q)
         for (int i = 0; i < 4; i++)
             if (i < n_pulse) {
-                const int amp = (int)((pulse_amp >> (4 * i)) & 15u), v = o.q[pulse_at[i]];
-                o.q[pulse_at[i]] = (int16_t)(v > 0 ? v + amp : v - amp);
+                const int amp = (int)((pulse_amp >> (4 * i)) & 15u), at = (int)((pulse_at >> (16 * i)) & 1023u), v = o.q[at];
+                o.q[at] = (int16_t)(v > 0 ? v + amp : v - amp);
             }
     return flags;
 }
@@ -309,7 +358,7 @@ DP_DEVICE void parse_cce(bit_reader& r, const lane_ctx& c)
     br_skip(r, 3);
     ics_info info;
     const ics_out none = {nullptr, nullptr, nullptr, nullptr};
-    parse_ics(r, c, nullptr, info, none, false);
+    parse_ics(r, c, false, info, none, false);
     if (r.status) return;
     const bool quirks = (c.P->options & AACG_PARSE_REFERENCE_QUIRKS) != 0, after = !quirks && point == 3;
     const int nb = info.groups * info.max_sfb;
@@ -321,7 +370,7 @@ DP_DEVICE void parse_cce(bit_reader& r, const lane_ctx& c)
         }
         if (after) continue;
         for (int b = 0, idx = 0; b < nb && !r.status; b++) {
-            const bool coded = (c.bands[(quirks ? idx : b) * c.stride] & 15) != 0;
+            const bool coded = (dp_lds_read_u8(c.bands + (quirks ? idx : b) * c.stride) & 15u) != 0;
             if (coded && cge == 0) huff(r, c.lut, 0);
             if (coded) idx++;
         }
@@ -332,8 +381,21 @@ DP_DEVICE void parse_cce(bit_reader& r, const lane_ctx& c)
 DP_DEVICE void parse_frame(const lane_ctx& c, uint32_t frame)
 {
     const aacg_parse_params& P = *c.P;
+    /* The frame's bytes go to LDS first (16-byte pieces, 8 bytes of look-ahead included): a lane that fetched its
+     * bit string from global memory as it went would make the whole wave wait for a load at nearly every code word,
+     * because some lane always needs its next word.  A frame that does not fit any more is read in place. */
+    const uint32_t off = P.frames[frame].byte_offset, len = P.frames[frame].byte_length;
+    const uint32_t first = off & ~15u, span = ((off + len + 8u + 15u) & ~15u) - first;
+    const unsigned char* src = (const unsigned char*)P.bytes + first;
+    int staged = -1;
+    const int slot = dp_lds_atomic_add(c.arena_top, (int)span);
+    if (slot >= 0 && slot + (int)span <= c.arena_bytes) {
+        dpi4* dst = (dpi4*)(c.arena + slot);
+        for (uint32_t k = 0; k < span / 16u; k++) dst[k] = ((const dpi4*)src)[k];
+        staged = dp_lds_addr(dst);
+    }
     bit_reader r;
-    br_open(r, P.bytes, P.frames[frame].byte_offset, P.frames[frame].byte_length);
+    br_open(r, staged, (const uint32_t*)src, off - first, len);
     const uint32_t start = r.pos;
     if (r.end - r.pos >= 56 && br_peek(r, 12) == 0xfffu) {           /* ADTS header (adts_demuxer.js:28-52) */
         br_skip(r, 15);
@@ -352,24 +414,24 @@ DP_DEVICE void parse_frame(const lane_ctx& c, uint32_t frame)
             if (n_units >= (int)P.max_units || channel + n_ch > (int)P.max_channels) over = true;
             const uint32_t block = frame * P.max_channels + (uint32_t)channel;
             aacg_unit_desc* u = over ? nullptr : &P.units[frame * P.max_units + (uint32_t)n_units];
-            ics_info left, right;
+            ics_info info;
             int unit_flags = 0, fl = 0;
             bool ms = false;
             if (n_ch == 2 && br_read(r, 1)) {
                 unit_flags |= AACG_UNIT_COMMON_WINDOW;
-                parse_ics_info(r, c, left);
+                parse_ics_info(r, c, info);
                 const int mask = (int)br_read(r, 2);
                 if (mask == 3) br_fail(r, AACG_PARSE_MS_MASK);
                 if (mask && !r.status) {
                     unit_flags |= AACG_UNIT_MASK_PRESENT;
                     ms = true;
-                    for (int i = 0; i < left.groups * left.max_sfb; i++) c.bands[i * c.stride] = (unsigned char)((mask == 2 ? 1u : br_read(r, 1)) << 7);
+                    for (int i = 0; i < info.groups * info.max_sfb; i++) dp_lds_write_u8(c.bands + i * c.stride, (mask == 2 ? 1u : br_read(r, 1)) << 7);
                 }
             }
             for (int k = 0; k < n_ch && !r.status; k++) {
                 const ics_out none = {nullptr, nullptr, nullptr, nullptr};
                 const ics_out o = over ? none : ics_out{ P.q + (size_t)(block + k) * 1024u, P.meta[block + k].band, P.tns ? &P.tns[block + k] : nullptr, &u->ch[k] };
-                fl |= parse_ics(r, c, (unit_flags & AACG_UNIT_COMMON_WINDOW) ? &left : nullptr, k ? right : left, o, ms && k == 0);
+                fl |= parse_ics(r, c, (unit_flags & AACG_UNIT_COMMON_WINDOW) != 0, info, o, ms && k == 0);
             }
             if (r.status) break;
             if (over) continue;
@@ -402,20 +464,23 @@ DP_DEVICE void parse_frame(const lane_ctx& c, uint32_t frame)
     res->bits_used = r.pos - start;
 }
 
-/* kernel body: workgroup of AACG_PARSE_WG_THREADS lanes, lane t of block b parses frame b * threads + t */
+/* kernel body: workgroup of P.wg_threads lanes, lane t of block b parses frame b * threads + t */
 DP_DEVICE void parse_body(const aacg_parse_params& P)
 {
     uint32_t* lds = (uint32_t*)dp_lds();
     const aacg_parse_tables* T = P.tab;
-    const int tid = dp_tid(), words = (int)T->lut_words;
-    for (int i = tid; i < words; i += AACG_PARSE_WG_THREADS) lds[i] = T->lut[i];
+    const int tid = dp_tid(), words = (int)T->lut_words, threads = (int)P.wg_threads;
+    for (int i = tid; i < words; i += threads) lds[i] = T->lut[i];
     uint16_t* swb = (uint16_t*)(lds + words);
-    for (int i = tid; i < 64 + 16; i += AACG_PARSE_WG_THREADS) swb[i] = i < 64 ? T->swb_long[i] : T->swb_short[i - 64];
+    for (int i = tid; i < 64 + 16; i += threads) swb[i] = i < 64 ? T->swb_long[i] : T->swb_short[i - 64];
     unsigned char* bands = (unsigned char*)(swb + 80);
+    int* top = (int*)(bands + AACG_MAX_SECTIONS * threads);
+    unsigned char* arena = (unsigned char*)(top + 4);
+    if (tid == 0) *top = 0;
     dp_block_sync();
-    const uint32_t frame = (uint32_t)dp_block() * AACG_PARSE_WG_THREADS + (uint32_t)tid;
+    const uint32_t frame = (uint32_t)dp_block() * (uint32_t)threads + (uint32_t)tid;
     if (frame >= P.n_frames) return;
-    const lane_ctx c = { &P, lds, swb, swb + 64, bands + tid, AACG_PARSE_WG_THREADS };
+    const lane_ctx c = { &P, dp_lds_addr(lds), dp_lds_addr(swb), dp_lds_addr(swb + 64), dp_lds_addr(bands + tid), threads, arena, top, (int)P.arena_bytes };
     parse_frame(c, frame);
 }
 

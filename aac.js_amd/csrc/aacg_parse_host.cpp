@@ -88,6 +88,6 @@ int aacg_parse_build_tables(int sample_index, const aacg_code_entry* entries, co
             next += 1u << extra;
         }
     }
-    out->lut_words = next;
+    out->lut_words = (next + 3u) & ~3u;            /* keeps what follows in LDS 16-byte aligned */
     return AACG_OK;
 }

@@ -5,6 +5,7 @@
  */
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -12,7 +13,7 @@
 #include "aacg_parse.h"
 #include "aacg_host.h"
 
-extern "C" DP_KERNEL(AACG_PARSE_WG_THREADS, 1)
+extern "C" DP_KERNEL(AACG_PARSE_WG_LARGE, 1)
 void aacg_parse_frames(const aacg_parse_params P) { aacg_parse::parse_body(P); }
 
 struct aacg_parser {
@@ -20,6 +21,8 @@ struct aacg_parser {
     hipStream_t stream = nullptr;
     aacg_parse_tables* d_tab = nullptr;
     size_t lds_bytes = 0;
+    uint32_t lut_words = 0;
+    int n_cus = 256;
     /* device staging of aacg_parse_batch, grown on demand */
     void* d_buf[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     size_t cap[7] = {0, 0, 0, 0, 0, 0, 0};
@@ -42,12 +45,19 @@ int grow(aacg_parser* p, int i, size_t bytes)
     return AACG_OK;
 }
 
-int launch(aacg_parser* p, const aacg_parse_params& P, hipStream_t s)
+int launch(aacg_parser* p, aacg_parse_params& P, hipStream_t s)
 {
+    /* up to one small workgroup per CU: stage the frames in LDS; beyond that the rate matters more than the time per
+     * frame, and 16 waves per CU reading in place overlap what one wave per SIMD cannot (AACG_PARSE_WG overrides) */
+    const char* env = std::getenv("AACG_PARSE_WG");
+    P.wg_threads = env ? (uint32_t)std::atoi(env) : (P.n_frames <= (uint32_t)p->n_cus * AACG_PARSE_WG_SMALL ? AACG_PARSE_WG_SMALL : P.n_frames <= (uint32_t)p->n_cus * 512u ? 512u : AACG_PARSE_WG_LARGE);
+    if (P.wg_threads != AACG_PARSE_WG_SMALL && P.wg_threads != 512 && P.wg_threads != AACG_PARSE_WG_LARGE) return fail(p, AACG_ERR_INVALID_ARG, "AACG_PARSE_WG must be 256, 512 or 1024");
+    while (AACG_PARSE_LDS_FIXED(p->lut_words, P.wg_threads) > p->lds_bytes) P.wg_threads /= 2;      /* very large tables */
+    P.arena_bytes = (uint32_t)(p->lds_bytes - AACG_PARSE_LDS_FIXED(p->lut_words, P.wg_threads));
     HIPCHECK(hipMemsetAsync(P.q, 0, (size_t)P.n_frames * P.max_channels * 1024u * sizeof(int16_t), s));
     if (P.tns) HIPCHECK(hipMemsetAsync(P.tns, 0, (size_t)P.n_frames * P.max_channels * sizeof(aacg_tns_info), s));
-    const unsigned grid = (P.n_frames + AACG_PARSE_WG_THREADS - 1) / AACG_PARSE_WG_THREADS;
-    hipLaunchKernelGGL(aacg_parse_frames, dim3(grid), dim3(AACG_PARSE_WG_THREADS), p->lds_bytes, s, P);
+    const unsigned grid = (P.n_frames + P.wg_threads - 1) / P.wg_threads;
+    hipLaunchKernelGGL(aacg_parse_frames, dim3(grid), dim3(P.wg_threads), p->lds_bytes, s, P);
     HIPCHECK(hipGetLastError());
     return AACG_OK;
 }
@@ -80,7 +90,10 @@ int aacg_parser_create(int device_ordinal, int sample_index, const aacg_code_ent
     int rc = aacg_parse_build_tables(sample_index, entries, counts, tab.data(), &p->err);
     if (rc == AACG_OK && hipSetDevice(device_ordinal) != hipSuccess) rc = fail(p, AACG_ERR_NO_DEVICE, "hipSetDevice failed");
     if (rc == AACG_OK) {
-        p->lds_bytes = (size_t)tab[0].lut_words * 4u + 160u + (size_t)AACG_MAX_SECTIONS * AACG_PARSE_WG_THREADS;
+        p->lds_bytes = 160u * 1024u;                 /* one workgroup per CU: what the tables leave is the frames' staging arena */
+        p->lut_words = tab[0].lut_words;
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device_ordinal) == hipSuccess && prop.multiProcessorCount > 0) p->n_cus = prop.multiProcessorCount;
         if (hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking) != hipSuccess ||
             hipMalloc((void**)&p->d_tab, sizeof(aacg_parse_tables)) != hipSuccess ||
             hipMemcpy(p->d_tab, tab.data(), sizeof(aacg_parse_tables), hipMemcpyHostToDevice) != hipSuccess ||
@@ -108,7 +121,7 @@ int aacg_parse_device(aacg_parser* p, const void* d_bytes, const aacg_parse_fram
 {
     if (!p || !p->d_tab) return AACG_ERR_INVALID_ARG;
     if (!n_frames) return AACG_OK;
-    if (!d_bytes || !d_frames || !d_units || !d_q || !d_meta || !d_results || !max_units || !max_channels || ((uintptr_t)d_bytes & 3u))
+    if (!d_bytes || !d_frames || !d_units || !d_q || !d_meta || !d_results || !max_units || !max_channels || ((uintptr_t)d_bytes & 15u))
         return fail(p, AACG_ERR_INVALID_ARG, "aacg_parse_device: null or misaligned argument");
     HIPCHECK(hipSetDevice(p->device));
     aacg_parse_params P;
@@ -128,13 +141,13 @@ int aacg_parse_batch(aacg_parser* p, const uint8_t* bytes, size_t n_bytes, const
     for (uint32_t f = 0; f < n_frames; f++)
         if ((size_t)frames[f].byte_offset + frames[f].byte_length > n_bytes) return fail(p, AACG_ERR_INVALID_ARG, "frame " + std::to_string(f) + " lies outside the byte buffer");
     HIPCHECK(hipSetDevice(p->device));
-    const size_t padded = (n_bytes + 3u) / 4u * 4u + 8u, blocks = (size_t)n_frames * max_channels;
+    const size_t padded = (n_bytes + 15u) / 16u * 16u + AACG_PARSE_PAD_BYTES, blocks = (size_t)n_frames * max_channels;
     const size_t sizes[7] = { padded, n_frames * sizeof(aacg_parse_frame), (size_t)n_frames * max_units * sizeof(aacg_unit_desc),
                               blocks * 1024u * sizeof(int16_t), blocks * sizeof(aacg_band_meta), tns ? blocks * sizeof(aacg_tns_info) : 0,
                               n_frames * sizeof(aacg_parse_result) };
     for (int i = 0; i < 7; i++) { int rc = sizes[i] ? grow(p, i, sizes[i]) : AACG_OK; if (rc) return rc; }
     hipStream_t s = p->stream;
-    HIPCHECK(hipMemsetAsync((char*)p->d_buf[0] + padded - 12u, 0, 12u, s));
+    HIPCHECK(hipMemsetAsync((char*)p->d_buf[0] + padded - (AACG_PARSE_PAD_BYTES + 16u), 0, AACG_PARSE_PAD_BYTES + 16u, s));
     HIPCHECK(hipMemcpyAsync(p->d_buf[0], bytes, n_bytes, hipMemcpyHostToDevice, s));
     HIPCHECK(hipMemcpyAsync(p->d_buf[1], frames, sizes[1], hipMemcpyHostToDevice, s));
     HIPCHECK(hipMemsetAsync(p->d_buf[2], 0, sizes[2], s));

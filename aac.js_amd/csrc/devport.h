@@ -89,6 +89,10 @@ DP_DEVICE unsigned char* dp_lds() { return dp_lds_raw; }
  * workgroup's allocation returns 0 (the LDS has no fault path). */
 DP_DEVICE int dp_lds_addr(const void* p) { return (int)(uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)p; }
 DP_DEVICE float dp_lds_read_f32(int a) { return *(__attribute__((address_space(3))) const float*)(uintptr_t)(uint32_t)a; }
+DP_DEVICE uint32_t dp_lds_read_u32(int a) { return *(__attribute__((address_space(3))) const uint32_t*)(uintptr_t)(uint32_t)a; }
+DP_DEVICE uint32_t dp_lds_read_u16(int a) { return *(__attribute__((address_space(3))) const uint16_t*)(uintptr_t)(uint32_t)a; }
+DP_DEVICE uint32_t dp_lds_read_u8(int a) { return *(__attribute__((address_space(3))) const uint8_t*)(uintptr_t)(uint32_t)a; }
+DP_DEVICE void dp_lds_write_u8(int a, uint32_t v) { *(__attribute__((address_space(3))) uint8_t*)(uintptr_t)(uint32_t)a = (uint8_t)v; }
 /* (int16 half of p) * 4 + add in one VALU instruction: sign extension, scaling and the table base at once */
 DP_DEVICE int dp_mad4_i16_lo(int p, int add) { int r; asm("v_mad_i32_i16 %0, %1, 4, %2" : "=v"(r) : "v"(p), "s"(add)); return r; }
 DP_DEVICE int dp_mad4_i16_hi(int p, int add) { int r; asm("v_mad_i32_i16 %0, %1, 4, %2 op_sel:[1,0,0,0]" : "=v"(r) : "v"(p), "s"(add)); return r; }
@@ -101,6 +105,9 @@ DP_DEVICE float dp_fma(float a, float b, float c) { return __builtin_fmaf(a, b, 
 DP_DEVICE double dp_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
 DP_DEVICE dpv2 dp_fma2(dpv2 a, dpv2 b, dpv2 c) { return __builtin_elementwise_fma(a, b, c); }
 /* true in every lane if the predicate holds in any lane of the wave */
+/* LDS bump allocation: returns the old value */
+DP_DEVICE int dp_lds_atomic_add(int* p, int v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
 DP_DEVICE bool dp_any(bool p) { return __any(p) != 0; }
 /* streaming (non-temporal) 16-byte accesses: PCM is written once and never re-read by the kernel,
  * spectra are read once */

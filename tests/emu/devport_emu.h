@@ -77,6 +77,8 @@ DP_DEVICE void dp_shfl(double (&v)[N], int src)
     pthread_barrier_wait(&g_emu.w->bar);
 }
 
+DP_DEVICE int dp_lds_atomic_add(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+
 DP_DEVICE bool dp_any(bool p)
 {
     g_emu.w->shfl[g_emu.lane][0] = p ? 1.0f : 0.0f;
@@ -95,6 +97,10 @@ DP_DEVICE float dp_lds_read_f32(int a)
     if (a < 0 || (size_t)a + 4 > g_emu.b->lds_bytes) return 0.0f;
     float v; memcpy(&v, g_emu.b->lds + a, 4); return v;
 }
+DP_DEVICE uint32_t dp_lds_read_u32(int a) { uint32_t v; memcpy(&v, g_emu.b->lds + a, 4); return v; }
+DP_DEVICE uint32_t dp_lds_read_u16(int a) { uint16_t v; memcpy(&v, g_emu.b->lds + a, 2); return v; }
+DP_DEVICE uint32_t dp_lds_read_u8(int a) { return g_emu.b->lds[a]; }
+DP_DEVICE void dp_lds_write_u8(int a, uint32_t v) { g_emu.b->lds[a] = (unsigned char)v; }
 /* (int16 half of p) * 4 + add */
 DP_DEVICE int dp_mad4_i16_lo(int p, int add) { return (int)(short)(p & 0xffff) * 4 + add; }
 DP_DEVICE int dp_mad4_i16_hi(int p, int add) { return (p >> 16) * 4 + add; }

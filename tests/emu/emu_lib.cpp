@@ -217,7 +217,7 @@ int emu_parse(int sample_index, const aacg_code_entry* entries, const uint32_t* 
     static aacg_parse_tables tab;
     int rc = aacg_parse_build_tables(sample_index, entries, counts, &tab, &g_err);
     if (rc) return rc;
-    std::vector<uint32_t> padded((n_bytes + 3) / 4 + 2, 0u);
+    std::vector<uint32_t> padded((n_bytes + 15) / 16 * 4 + AACG_PARSE_PAD_BYTES / 4 + 4, 0u);
     std::memcpy(padded.data(), bytes, n_bytes);
     const size_t blocks = (size_t)n_frames * max_channels;
     std::memset(units, 0, (size_t)n_frames * max_units * sizeof *units);
@@ -227,10 +227,15 @@ int emu_parse(int sample_index, const aacg_code_entry* entries, const uint32_t* 
     aacg_parse_params PP;
     PP.bytes = padded.data(); PP.frames = frames; PP.tab = &tab; PP.units = units; PP.q = q; PP.meta = meta; PP.tns = tns; PP.results = results;
     PP.n_frames = n_frames; PP.max_units = max_units; PP.max_channels = max_channels; PP.options = options;
+    /* AACG_EMU_ARENA: a small staging arena sends most frames down the read-in-place path */
+    PP.wg_threads = AACG_PARSE_WG_SMALL;
+    const size_t fixed = AACG_PARSE_LDS_FIXED(tab.lut_words, PP.wg_threads);
+    const char* env = std::getenv("AACG_EMU_ARENA");
+    PP.arena_bytes = env ? (uint32_t)std::atoi(env) : (uint32_t)(160 * 1024 - fixed);
     aacg_kparams none;
     std::memset(&none, 0, sizeof none);
-    launch(none, 7, (int)((n_frames + AACG_PARSE_WG_THREADS - 1) / AACG_PARSE_WG_THREADS), AACG_PARSE_WG_THREADS / 64,
-           (size_t)tab.lut_words * 4 + 160 + (size_t)AACG_MAX_SECTIONS * AACG_PARSE_WG_THREADS, 0, &PP);
+    launch(none, 7, (int)((n_frames + PP.wg_threads - 1) / PP.wg_threads), (int)PP.wg_threads / 64,
+           fixed + PP.arena_bytes, 0, &PP);
     return AACG_OK;
 }
 

@@ -86,6 +86,12 @@ def test_emulated_kernel_synthetic_codebooks(synthetic):
     assert run_emulated(synthetic) >= 10
 
 
+def test_emulated_kernel_reads_in_place_when_lds_is_full(synthetic, monkeypatch):
+    """Frames that do not fit the LDS staging arena are parsed from global memory: same results."""
+    monkeypatch.setenv("AACG_EMU_ARENA", "2048")
+    assert run_emulated(synthetic) >= 10
+
+
 def test_emulated_kernel_real_codebooks(tmp_path):
     """Build container only: the same with the code words the reference checkout supplies."""
     assert run_emulated(make_cases(tmp_path, "provider")) >= 10

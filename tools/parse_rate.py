@@ -38,9 +38,9 @@ def main():
     data = np.fromfile(os.path.join(d, "stereo600.bytes"), np.uint8)
     frames = np.fromfile(os.path.join(d, "stereo600.frames"), aacgpu.PARSE_FRAME_DTYPE)
     reps = (a.frames + len(frames) - 1) // len(frames)
-    pad = (-len(data)) % 4
+    pad = (-len(data)) % 16
     one = np.concatenate([data, np.zeros(pad, np.uint8)])
-    big = np.concatenate([np.tile(one, reps), np.zeros(8, np.uint8)])
+    big = np.concatenate([np.tile(one, reps), np.zeros(32, np.uint8)])
     table = np.tile(frames, reps)
     table["byte_offset"] += np.repeat(np.arange(reps, dtype=np.uint32) * len(one), len(frames))
     table = table[:a.frames]
