@@ -162,6 +162,22 @@ Codebooks.prototype.spectral = function (bits, book, q, off) {
 
 Codebooks.prototype.toTables = function () { return this.tables; };
 
+/* the books as aacg_code_entry records (include/aacgpu.h: u32 code, u8 len, i8 v[4], 3 pad) for aacg_parser_create */
+Codebooks.prototype.toEntryRecords = function () {
+    const books = [this.tables.sf].concat(this.tables.spectral), counts = new Uint32Array(12);
+    let n = 0;
+    books.forEach(function (b, i) { counts[i] = b.length; n += b.length; });
+    const entries = new Uint8Array(12 * n), view = new DataView(entries.buffer);
+    let o = 0;
+    for (const b of books)
+        for (const e of b) {
+            view.setUint32(o, e[1], true); view.setUint8(o + 4, e[0]);
+            for (let j = 0; j < e.length - 2; j++) view.setInt8(o + 5 + j, e[2 + j]);
+            o += 12;
+        }
+    return { entries: entries, counts: counts };
+};
+
 function fromTables(t) {
     if (!t || !Array.isArray(t.sf) || !Array.isArray(t.spectral) || t.spectral.length !== 11) throw new Error('codebooks: malformed table object');
     return new Codebooks(t);

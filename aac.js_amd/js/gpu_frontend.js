@@ -1,0 +1,99 @@
+/*
+ * aac.js_amd/js/gpu_frontend.js — the front end with the parsing on the GPU (aacg_parser_*, include/aacgpu.h).
+ *
+ * Same interface as FrontEnd (frontend.js): push() ADTS bytes / pushPacket() raw_data_blocks, parseFrame(decoder)
+ * -> { elements, q, meta } or null, throwing the reference's message for a malformed frame when that frame is
+ * reached.  What differs is where the work happens: every complete frame already buffered (up to `batch`) is handed
+ * to the device in ONE aacg_parse_batch call — one GPU lane per frame — and the frames are then served from the
+ * result.  JavaScript only finds the frame boundaries (ADTS frame_length / sample sizes).
+ * The code words come from ./codebooks.js, as for FrontEnd.  There is no CPU fallback: without the HIP library the
+ * constructor throws.
+ */
+'use strict';
+const host = require('./index.js');
+const codebooks = require('./codebooks.js');
+const adts = require('./adts.js');
+
+const FRAME = 1024, META_WORDS = 120, UNIT_BYTES = 64, TNS_BYTES = 424;
+const APPLY_PULSES = 1, REFERENCE_QUIRKS = 2;
+const TYPE_NAME = { 0: 'sce', 1: 'cpe', 3: 'lfe' };
+
+function GpuFrontEnd(opts) {
+    opts = opts || {};
+    this.addon = host.loadAddon();
+    this.cb = codebooks.load(opts);
+    this.deviceOrdinal = opts.deviceOrdinal | 0;
+    this.batch = opts.batch || 4096;               // frames per launch
+    this.maxUnits = opts.maxUnits || 8;            // elements / channels allowed per frame
+    this.maxChannels = opts.maxChannels || 8;
+    this.wantTns = !!opts.wantTns;                 // deliver TNS side info (AACG_TNS_SPEC decoders)
+    this.options = (opts.applyPulses ? APPLY_PULSES : 0) | (opts.referenceQuirks !== false ? REFERENCE_QUIRKS : 0);
+    this.parser = null; this.sampleIndex = -1;
+    this.buf = new Uint8Array(0); this.packets = []; this.queue = [];
+}
+
+GpuFrontEnd.prototype.push = function (bytes) {
+    if (!this.buf.length) { this.buf = bytes; return; }
+    const joined = new Uint8Array(this.buf.length + bytes.length);
+    joined.set(this.buf); joined.set(bytes, this.buf.length);
+    this.buf = joined;
+};
+GpuFrontEnd.prototype.pushPacket = function (bytes) { this.packets.push(bytes); };
+
+/* parse everything that is complete: fills this.queue with frame objects or Error objects */
+GpuFrontEnd.prototype.fill = function (config) {
+    if (!this.parser || this.sampleIndex !== config.sampleIndex) {
+        const rec = this.cb.toEntryRecords();
+        this.parser = this.addon.parserCreate({ deviceOrdinal: this.deviceOrdinal, sampleIndex: config.sampleIndex }, rec.entries, rec.counts);
+        this.sampleIndex = config.sampleIndex;
+    }
+    let bytes, table;
+    if (this.packets.length) {
+        const take = this.packets.splice(0, this.batch);
+        let total = 0;
+        for (const p of take) total += p.length;
+        bytes = new Uint8Array(total); table = new Uint32Array(2 * take.length);
+        let at = 0;
+        take.forEach(function (p, i) { bytes.set(p, at); table[2 * i] = at; table[2 * i + 1] = p.length; at += p.length; });
+    } else {
+        const list = adts.frames(this.buf).slice(0, this.batch);
+        if (!list.length) {
+            if (this.buf.length >= 7) adts.readHeader(new host.BitReader(this.buf));      // throws 'Invalid ADTS header.' on garbage
+            return;
+        }
+        const end = list[list.length - 1].offset + list[list.length - 1].length;
+        bytes = this.buf.subarray(0, end); this.buf = this.buf.subarray(end);
+        table = new Uint32Array(2 * list.length);
+        list.forEach(function (f, i) { table[2 * i] = f.offset; table[2 * i + 1] = f.length; });
+    }
+    const n = table.length / 2, U = this.maxUnits, C = this.maxChannels;
+    const units = new Uint8Array(n * U * UNIT_BYTES), q = new Int16Array(n * C * FRAME), meta = new Uint16Array(n * C * META_WORDS);
+    const tns = this.wantTns ? new Uint8Array(n * C * TNS_BYTES) : null, results = new Uint8Array(8 * n);
+    this.addon.parseBatch(this.parser, bytes, table, U, C, this.options, units, q, meta, tns, results);
+    for (let f = 0; f < n; f++) {
+        const status = results[8 * f], nUnits = results[8 * f + 1], nCh = results[8 * f + 2];
+        if (status) { this.queue.push(new Error(this.addon.parseStatusString(status))); continue; }
+        const frame = { elements: [], q: q.slice(f * C * FRAME, (f * C + nCh) * FRAME), meta: meta.slice(f * C * META_WORDS, (f * C + nCh) * META_WORDS) };
+        for (const u of host.unpackUnits(units.subarray(f * U * UNIT_BYTES, (f * U + nUnits) * UNIT_BYTES))) {
+            const e = { type: TYPE_NAME[u.tag >> 4], id: u.tag & 15, commonWindow: u.commonWindow, maskPresent: u.maskPresent, hasPns: u.hasPns, ch: [] };
+            u.ch.forEach(function (c, k) {
+                const chan = { windowSequence: c.windowSequence, windowShape: c.windowShape, maxSFB: c.maxSFB, groupLength: c.groupLength, hasPns: u.hasPns };
+                if (c.tnsPresent && tns) chan.tns = host.unpackTns(tns, u.coefOffset + k, c.windowSequence === 2);
+                else if (c.tnsPresent) chan.tns = null;             // present in the stream, dropped (AACG_TNS_REFERENCE)
+                e.ch.push(chan);
+            });
+            frame.elements.push(e);
+        }
+        this.queue.push(frame);
+    }
+};
+
+GpuFrontEnd.prototype.parseFrame = function (decoder) {
+    if (!this.queue.length) this.fill(decoder.config);
+    if (!this.queue.length) return null;
+    const f = this.queue.shift();
+    if (f instanceof Error) throw f;
+    return f;
+};
+
+module.exports = { GpuFrontEnd };

@@ -82,19 +82,36 @@ function packTns(list) {
     return new Uint8Array(buf);
 }
 
+/* one aacg_tns_info record back into the shape of the reference's TNS object (the inverse of packTns) */
+function unpackTns(bytes, index, short) {
+    const view = new DataView(bytes.buffer, bytes.byteOffset + TNS_BYTES * index, TNS_BYTES), nWin = short ? 8 : 1;
+    const t = { short: short, nFilt: [], length: [], order: [], direction: [], coef: [] };
+    for (let w = 0; w < nWin; w++) {
+        const nf = view.getUint8(w);
+        t.nFilt.push(nf); t.length.push([]); t.order.push([]); t.direction.push([]); t.coef.push([]);
+        for (let f = 0; f < nf; f++) {
+            const fo = 8 + 52 * (short ? w : f), order = view.getUint8(fo + 1), coef = new Float32Array(order);
+            for (let k = 0; k < order; k++) coef[k] = view.getFloat32(fo + 4 + 4 * k, true);
+            t.length[w].push(view.getUint8(fo)); t.order[w].push(order); t.direction[w].push(!!view.getUint8(fo + 2)); t.coef[w].push(coef);
+        }
+    }
+    return t;
+}
+
 function unpackUnits(bytes) {
     const view = new DataView(bytes.buffer, bytes.byteOffset, bytes.byteLength), out = [];
     function chan(off) {
         const n = view.getUint8(off + 4), gl = [];
         for (let g = 0; g < n; g++) gl.push(view.getUint8(off + 8 + g));
         return { windowSequence: view.getUint8(off), windowShape: view.getUint8(off + 1), windowShapePrev: view.getUint8(off + 2),
-                 maxSFB: view.getUint8(off + 3), groupLength: gl };
+                 maxSFB: view.getUint8(off + 3), groupLength: gl, tnsPresent: !!(view.getUint8(off + 5) & 1) };
     }
     for (let o = 0; o < bytes.byteLength; o += UNIT_BYTES) {
         const nCh = view.getUint8(o + 12), flags = view.getUint8(o + 13);
         const u = { stream: view.getUint32(o, true), pcmOffset: view.getUint32(o + 4, true), channel: view.getUint16(o + 8, true),
                     nOutCh: view.getUint16(o + 10, true), coefOffset: view.getUint32(o + 16, true), metaOffset: view.getUint32(o + 20, true),
-                    commonWindow: !!(flags & 1), maskPresent: !!(flags & 2), hasPns: !!(flags & 4), ch: [chan(o + 24)] };
+                    commonWindow: !!(flags & 1), maskPresent: !!(flags & 2), hasPns: !!(flags & 4), ch: [chan(o + 24)],
+                    tnsOffset: view.getUint32(o + 56, true), tag: view.getUint16(o + 14, true) };
         if (nCh > 1) u.ch.push(chan(o + 40));
         out.push(u);
     }
@@ -285,8 +302,8 @@ GpuAACDecoder.prototype.readChunk = function () {
 GpuAACDecoder.prototype.feed = function (bytes) { this.frontend.push(bytes.data || bytes); };
 GpuAACDecoder.prototype.feedPacket = function (bytes) { this.frontend.pushPacket(bytes.data || bytes); };
 
-module.exports = { Engine, GpuAACDecoder, BitReader, packUnits, unpackUnits, packBandWord, packTns, applyPulses,
+module.exports = { Engine, GpuAACDecoder, BitReader, packUnits, unpackUnits, packBandWord, packTns, unpackTns, applyPulses, loadAddon,
                    INPUT_SPEC_F32, INPUT_QUANT_I16, TNS_REFERENCE, TNS_SPEC, PNS_REFERENCE, PNS_SPEC, UNIT_BYTES, META_WORDS, TNS_BYTES, SAMPLE_RATES };
 /* the bitstream front end and its pieces (loaded on first use: they require this module themselves) */
-for (const [name, file] of [['FrontEnd', './frontend.js'], ['codebooks', './codebooks.js'], ['adts', './adts.js'], ['BitStream', './bits.js']])
+for (const [name, file] of [['FrontEnd', './frontend.js'], ['GpuFrontEnd', './gpu_frontend.js'], ['codebooks', './codebooks.js'], ['adts', './adts.js'], ['BitStream', './bits.js']])
     Object.defineProperty(module.exports, name, { enumerable: true, get: function () { const m = require(file); return m[name] || m; } });

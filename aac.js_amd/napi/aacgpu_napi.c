@@ -34,6 +34,12 @@ static struct {
                              const aacg_band_meta*, uint32_t, const aacg_tns_info*, uint32_t, float*, size_t);
     int  (*submit_tns)(aacg_engine*, const aacg_unit_desc*, uint32_t, const void*, uint32_t,
                        const aacg_band_meta*, uint32_t, const aacg_tns_info*, uint32_t, float*, size_t, uint64_t*);
+    int  (*parser_create)(int, int, const aacg_code_entry*, const uint32_t*, aacg_parser**);
+    void (*parser_destroy)(aacg_parser*);
+    const char* (*parser_last_error)(const aacg_parser*);
+    const char* (*parse_status_string)(int);
+    int  (*parse_batch)(aacg_parser*, const uint8_t*, size_t, const aacg_parse_frame*, uint32_t, uint32_t, uint32_t, uint32_t,
+                        aacg_unit_desc*, int16_t*, aacg_band_meta*, aacg_tns_info*, aacg_parse_result*);
 } L;
 
 #define CHECK(env, call) do { if ((call) != napi_ok) { napi_throw_error((env), NULL, "aacgpu: N-API call failed: " #call); return NULL; } } while (0)
@@ -62,6 +68,8 @@ static int load_lib(napi_env env, const char* path)
     SYM(get_overlap, "aacg_get_overlap"); SYM(set_overlap, "aacg_set_overlap"); SYM(decode_batch, "aacg_decode_batch");
     SYM(submit, "aacg_submit"); SYM(wait, "aacg_wait");
     SYM(decode_batch_tns, "aacg_decode_batch_tns"); SYM(submit_tns, "aacg_submit_tns");
+    SYM(parser_create, "aacg_parser_create"); SYM(parser_destroy, "aacg_parser_destroy"); SYM(parser_last_error, "aacg_parser_last_error");
+    SYM(parse_status_string, "aacg_parse_status_string"); SYM(parse_batch, "aacg_parse_batch");
 #undef SYM
     return 1;
 }
@@ -290,6 +298,85 @@ static napi_value js_decode_batch_async(napi_env env, napi_callback_info info)
     return promise;
 }
 
+/* ---- device front end (aacg_parser_*) ------------------------------------------------------------------ */
+static void parser_finalize(napi_env env, void* data, void* hint)
+{
+    (void)env; (void)hint;
+    if (data && L.parser_destroy) L.parser_destroy((aacg_parser*)data);
+}
+
+/* parserCreate({deviceOrdinal, sampleIndex}, entries:Uint8Array(12*n) of aacg_code_entry, counts:Uint32Array(12)) -> external */
+static napi_value js_parser_create(napi_env env, napi_callback_info info)
+{
+    size_t argc = 3; napi_value argv[3], out;
+    CHECK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    if (!L.dl) { napi_throw_error(env, NULL, "aacgpu: call load(path) first"); return NULL; }
+    napi_typedarray_type te, tc; size_t ne, nc; void *de, *dc;
+    if (!typed(env, argv[1], &te, &ne, &de) || te != napi_uint8_array || ne % sizeof(aacg_code_entry) ||
+        !typed(env, argv[2], &tc, &nc, &dc) || tc != napi_uint32_array || nc != 12) {
+        napi_throw_type_error(env, NULL, "parserCreate(opts, entries:Uint8Array of 12-byte aacg_code_entry, counts:Uint32Array(12))"); return NULL; }
+    size_t total = 0;
+    for (int b = 0; b < 12; b++) total += ((const uint32_t*)dc)[b];
+    if (total * sizeof(aacg_code_entry) != ne) { napi_throw_type_error(env, NULL, "counts do not add up to the number of entries"); return NULL; }
+    aacg_parser* p = NULL;
+    int rc = L.parser_create(get_i32(env, argv[0], "deviceOrdinal", 0), get_i32(env, argv[0], "sampleIndex", 3),
+                             (const aacg_code_entry*)de, (const uint32_t*)dc, &p);
+    if (rc) {
+        char msg[1024];
+        snprintf(msg, sizeof msg, "aacgpu: aacg_parser_create failed (%d): %s", rc, p ? L.parser_last_error(p) : "");
+        if (p) L.parser_destroy(p);
+        napi_throw_error(env, NULL, msg);
+        return NULL;
+    }
+    CHECK(env, napi_create_external(env, p, parser_finalize, NULL, &out));
+    return out;
+}
+
+/* parseBatch(parser, bytes:Uint8Array, frames:Uint32Array(2*n) [offset, length]..., maxUnits, maxChannels, options,
+ *            units:Uint8Array(64*n*maxUnits), q:Int16Array(1024*n*maxChannels), meta:Uint16Array(120*n*maxChannels),
+ *            tns:Uint8Array(424*n*maxChannels)|null, results:Uint8Array(8*n)) */
+static napi_value js_parse_batch(napi_env env, napi_callback_info info)
+{
+    size_t argc = 11; napi_value argv[11];
+    CHECK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    void* pv = NULL;
+    if (argc < 11 || napi_get_value_external(env, argv[0], &pv) != napi_ok || !pv) { napi_throw_error(env, NULL, "aacgpu: bad parser handle"); return NULL; }
+    aacg_parser* p = (aacg_parser*)pv;
+    napi_typedarray_type t; size_t nb, nf, nu, nq, nm, nr; void *db, *df, *du, *dq, *dm, *dr, *dt; size_t nt;
+    uint32_t max_units = 0, max_ch = 0, options = 0;
+    napi_get_value_uint32(env, argv[3], &max_units); napi_get_value_uint32(env, argv[4], &max_ch); napi_get_value_uint32(env, argv[5], &options);
+    if (!typed(env, argv[1], &t, &nb, &db) || t != napi_uint8_array || !typed(env, argv[2], &t, &nf, &df) || t != napi_uint32_array || (nf & 1)) {
+        napi_throw_type_error(env, NULL, "parseBatch: bytes must be a Uint8Array, frames a Uint32Array of (offset, length) pairs"); return NULL; }
+    const size_t n = nf / 2;
+    if (!typed(env, argv[6], &t, &nu, &du) || t != napi_uint8_array || nu != n * max_units * sizeof(aacg_unit_desc) ||
+        !typed(env, argv[7], &t, &nq, &dq) || t != napi_int16_array || nq != n * max_ch * 1024 ||
+        !typed(env, argv[8], &t, &nm, &dm) || t != napi_uint16_array || nm != n * max_ch * AACG_MAX_SECTIONS ||
+        !typed(env, argv[10], &t, &nr, &dr) || t != napi_uint8_array || nr != n * sizeof(aacg_parse_result)) {
+        napi_throw_type_error(env, NULL, "parseBatch: output arrays do not have the sizes n * maxUnits / maxChannels imply"); return NULL; }
+    if (!optional_tns(env, argc, argv, 9, &dt, &nt)) return NULL;
+    if (dt && nt != n * max_ch) { napi_throw_type_error(env, NULL, "parseBatch: tns must hold n * maxChannels records"); return NULL; }
+    int rc = L.parse_batch(p, (const uint8_t*)db, nb, (const aacg_parse_frame*)df, (uint32_t)n, max_units, max_ch, options,
+                           (aacg_unit_desc*)du, (int16_t*)dq, (aacg_band_meta*)dm, (aacg_tns_info*)dt, (aacg_parse_result*)dr);
+    if (rc) {
+        char msg[1024];
+        snprintf(msg, sizeof msg, "aacgpu: aacg_parse_batch failed (%d): %s", rc, L.parser_last_error(p));
+        napi_throw_error(env, NULL, msg);
+        return NULL;
+    }
+    return argv[10];
+}
+
+/* parseStatusString(code) -> the reference's message for a per-frame status */
+static napi_value js_parse_status_string(napi_env env, napi_callback_info info)
+{
+    size_t argc = 1; napi_value argv[1], out; int32_t code = 0;
+    CHECK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    if (!L.dl) { napi_throw_error(env, NULL, "aacgpu: call load(path) first"); return NULL; }
+    napi_get_value_int32(env, argv[0], &code);
+    CHECK(env, napi_create_string_utf8(env, L.parse_status_string(code), NAPI_AUTO_LENGTH, &out));
+    return out;
+}
+
 static napi_value init(napi_env env, napi_value exports)
 {
     napi_property_descriptor props[] = {
@@ -300,6 +387,9 @@ static napi_value init(napi_env env, napi_value exports)
         {"resetStream", NULL, js_reset_stream, NULL, NULL, NULL, napi_default, NULL},
         {"getOverlap", NULL, js_get_overlap, NULL, NULL, NULL, napi_default, NULL},
         {"setOverlap", NULL, js_set_overlap, NULL, NULL, NULL, napi_default, NULL},
+        {"parserCreate", NULL, js_parser_create, NULL, NULL, NULL, napi_default, NULL},
+        {"parseBatch", NULL, js_parse_batch, NULL, NULL, NULL, napi_default, NULL},
+        {"parseStatusString", NULL, js_parse_status_string, NULL, NULL, NULL, napi_default, NULL},
     };
     napi_define_properties(env, exports, sizeof props / sizeof props[0], props);
     return exports;

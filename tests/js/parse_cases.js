@@ -33,21 +33,11 @@ if (mode === 'provider') {
 } else cb = codebooks.fromTables(synthTables(0xC0DE));
 fs.mkdirSync(outdir, { recursive: true });
 
-/* the codebooks as aacg_code_entry records: u32 code, u8 len, i8 v[4], 3 pad = 12 bytes */
+/* the codebooks as aacg_code_entry records */
 {
-    const books = [cb.tables.sf].concat(cb.tables.spectral), counts = new Uint32Array(12);
-    let n = 0;
-    books.forEach(function (b, i) { counts[i] = b.length; n += b.length; });
-    const buf = Buffer.alloc(12 * n);
-    let o = 0;
-    for (const b of books)
-        for (const e of b) {
-            buf.writeUInt32LE(e[1], o); buf.writeUInt8(e[0], o + 4);
-            for (let j = 0; j < e.length - 2; j++) buf.writeInt8(e[2 + j], o + 5 + j);
-            o += 12;
-        }
-    fs.writeFileSync(path.join(outdir, 'codebooks.entries'), buf);
-    fs.writeFileSync(path.join(outdir, 'codebooks.counts'), Buffer.from(counts.buffer));
+    const rec = cb.toEntryRecords();
+    fs.writeFileSync(path.join(outdir, 'codebooks.entries'), Buffer.from(rec.entries));
+    fs.writeFileSync(path.join(outdir, 'codebooks.counts'), Buffer.from(rec.counts.buffer));
 }
 
 const STATUS = [[/Insufficient data/, 1], [/Invalid band type/, 2], [/Too many bands/, 3], [/Scalefactor out of range/, 4], [/Pulse tool not allowed/, 5],

@@ -189,6 +189,56 @@ for (const name of ['scn_stereo', 'scn_7ch']) {
     assert.ok(b.every(Number.isFinite) && rms(b, ref) > 1e-4, 'TNS_SPEC engine must apply the filters');
     console.log('tns side info ok, rms vs identity', rms(b, ref).toExponential(3));
 }
+{
+    // GpuFrontEnd: the same frames parsed on the device and by the JavaScript front end (stand-in codebooks: the box has no
+    // code words), then decoded through GpuAACDecoder.readChunk with either front end: identical frame objects, identical PCM
+    const codebooks = require(path.join(root, 'aac.js_amd', 'js', 'codebooks.js'));
+    const { Writer, Rng } = require('./aac_writer.js'), { randomFrame, PATTERN } = require('./stream_cases.js'), { synthTables } = require('./synth_codebooks.js');
+    const cb = codebooks.fromTables(synthTables(0xC0DE)), wr = new Writer(cb, 3), rng = new Rng(0x6F0);
+    const frames = [];
+    for (let t = 0; t < 40; t++) frames.push(wr.adtsFrame(randomFrame(wr, rng, ['cpe'], function () { return PATTERN[t % PATTERN.length]; }, { tns: t % 3 === 0 }), 2, { crc: t % 2 === 1 }));
+    const bad = frames[7].slice(); bad[9] ^= 0x5a; bad[15] ^= 0xff;      // a damaged frame: both front ends must agree on what happens
+    const stream = Buffer.concat(frames.map(function (b) { return Buffer.from(b); }));
+    const cpu = new host.FrontEnd({ codebooks: cb }), gpu = new host.GpuFrontEnd({ codebooks: cb, wantTns: true, batch: 16 });
+    const config = { sampleIndex: 3 };
+    cpu.push(new Uint8Array(stream)); gpu.push(new Uint8Array(stream));
+    cpu.pushPacket(bad); gpu.pushPacket(bad);
+    let n = 0;
+    for (;;) {
+        let a = null, b = null, ea = null, eb = null;
+        try { a = cpu.parseFrame({ config: config }); } catch (e) { ea = e.message.replace(/[:(].*$/, ''); }
+        try { b = gpu.parseFrame({ config: config }); } catch (e) { eb = e.message.replace(/[:(].*$/, ''); }
+        assert.strictEqual(eb, ea, 'frame ' + n + ': error behaviour');
+        if (!a && !ea) { assert.strictEqual(b, null); break; }
+        if (a) {
+            assert.deepStrictEqual(b.q, a.q, 'frame ' + n + ': spectrum'); assert.deepStrictEqual(b.meta, a.meta, 'frame ' + n + ': band words');
+            assert.strictEqual(b.elements.length, a.elements.length);
+            a.elements.forEach(function (e, i) {
+                const x = b.elements[i];
+                assert.deepStrictEqual([x.type, x.id, x.commonWindow, x.maskPresent, x.hasPns], [e.type, e.id, e.commonWindow, e.maskPresent, e.hasPns]);
+                e.ch.forEach(function (c, k) {
+                    assert.deepStrictEqual([x.ch[k].windowSequence, x.ch[k].windowShape, x.ch[k].maxSFB, x.ch[k].groupLength], [c.windowSequence, c.windowShape, c.maxSFB, c.groupLength]);
+                    assert.strictEqual(!!x.ch[k].tns, !!c.tns);
+                    if (c.tns) { c.tns.short = c.windowSequence === 2; assert.deepStrictEqual(host.packTns([x.ch[k].tns]), host.packTns([c.tns]), 'frame ' + n + ': TNS side info'); }
+                });
+            });
+        }
+        n++;
+    }
+    assert.strictEqual(n, 41);
+    const pcm = [];
+    for (const Front of [host.FrontEnd, host.GpuFrontEnd]) {
+        const dec = new host.GpuAACDecoder({ frontend: new Front({ codebooks: cb }), lookahead: 64 });
+        dec.init(); dec.setCookie(new Uint8Array([(2 << 3) | (3 >> 1), ((3 & 1) << 7) | (2 << 3)]));
+        dec.feed(new Uint8Array(stream));
+        const out = [];
+        for (let chunk; (chunk = dec.readChunk()) !== null;) out.push(chunk);
+        assert.strictEqual(out.length, 40);
+        pcm.push(out);
+    }
+    for (let t = 0; t < 40; t++) assert.deepStrictEqual(pcm[1][t], pcm[0][t], 'frame ' + t + ': PCM');
+    console.log('GpuFrontEnd ok: 41 frames parsed on the device, 40 decoded');
+}
 (async function () {
     // decodeBatchAsync: the event loop stays free while the GPU decodes (a timer fires before the promise resolves or right after)
     const name = 'scn_stereo', ref = g[name + '.pcm'];
