@@ -206,8 +206,8 @@ for (const name of ['scn_stereo', 'scn_7ch']) {
     let n = 0;
     for (;;) {
         let a = null, b = null, ea = null, eb = null;
-        try { a = cpu.parseFrame({ config: config }); } catch (e) { ea = e.message.replace(/[:(].*$/, ''); }
-        try { b = gpu.parseFrame({ config: config }); } catch (e) { eb = e.message.replace(/[:(].*$/, ''); }
+        try { a = cpu.parseFrame({ config: config }); } catch (e) { ea = e.message.replace(/\s*[:(].*$/, ''); }
+        try { b = gpu.parseFrame({ config: config }); } catch (e) { eb = e.message.replace(/\s*[:(].*$/, ''); }
         assert.strictEqual(eb, ea, 'frame ' + n + ': error behaviour');
         if (!a && !ea) { assert.strictEqual(b, null); break; }
         if (a) {
