@@ -28,6 +28,9 @@ struct stream_state {
     bool     holes = false;    /* some frame leaves a channel unwritten */
     bool     aligned = true;   /* every pcm_offset is a multiple of 4 floats */
     uint32_t n_chains = 0;
+    /* the stream's first chains by channel: spares the per-unit map lookup (map nodes do not move) */
+    struct open_chain* chain[4] = {nullptr, nullptr, nullptr, nullptr};
+    uint16_t chain_channel[4] = {0, 0, 0, 0};
 };
 
 struct open_chain {
@@ -112,6 +115,7 @@ int aacg_plan_build(const aacg_unit_desc* units, uint32_t n_units, int sample_in
     if (!n_long) return fail(err, AACG_ERR_INVALID_ARG, "sample_index %ld out of range", sample_index);
 
     *out = aacg_plan_host();
+    out->units.reserve(n_units);
     std::vector<stream_state> st((size_t)max_streams);
     std::map<uint64_t, open_chain> open;                     /* key: stream << 16 | channel */
 
@@ -154,14 +158,18 @@ int aacg_plan_build(const aacg_unit_desc* units, uint32_t n_units, int sample_in
         s.mask |= bits;
 
         const uint64_t key = ((uint64_t)u.stream << 16) | u.channel;
-        auto it = open.find(key);
-        if (it == open.end()) {
+        open_chain* found = nullptr;
+        const uint32_t cached = std::min<uint32_t>(s.n_chains, 4u);
+        for (uint32_t k = 0; k < cached; k++) if (s.chain_channel[k] == u.channel) { found = s.chain[k]; break; }
+        if (!found && s.n_chains > 4u) { auto it = open.find(key); if (it != open.end()) found = &it->second; }
+        if (!found) {
             if (s.frame != 0) return fail(err, AACG_ERR_LAYOUT_CHANGE, "unit %ld: element at channel %ld appears mid-batch", i, u.channel);
-            open_chain oc; oc.last_frame = 0; oc.n_ch = u.n_ch; oc.units.push_back((int32_t)i);
-            open.emplace(key, std::move(oc));
+            open_chain oc; oc.last_frame = 0; oc.n_ch = u.n_ch; oc.units.reserve(16); oc.units.push_back((int32_t)i);
+            auto at = open.emplace(key, std::move(oc)).first;
+            if (s.n_chains < 4u) { s.chain[s.n_chains] = &at->second; s.chain_channel[s.n_chains] = u.channel; }
             s.n_chains++;
         } else {
-            open_chain& oc = it->second;
+            open_chain& oc = *found;
             if (oc.n_ch != u.n_ch || oc.last_frame + 1 != s.frame)
                 return fail(err, AACG_ERR_LAYOUT_CHANGE, "unit %ld: element layout of stream %ld changes inside a batch", i, u.stream);
             oc.last_frame = s.frame;
