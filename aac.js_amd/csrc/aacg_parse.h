@@ -37,6 +37,8 @@ struct bit_reader {
     uint32_t cached;           /* dword index held in w */
     uint64_t w;
     int status;
+    int deferred;              /* a refusal that only counts if the rest of the frame parses: pulse data without
+                                  AACG_PARSE_APPLY_PULSES, a TNS order the records cannot hold */
 };
 
 DP_DEVICE uint32_t be32(uint32_t v) { return __builtin_bswap32(v); }
@@ -44,7 +46,7 @@ DP_DEVICE uint32_t be32(uint32_t v) { return __builtin_bswap32(v); }
 DP_DEVICE void br_open(bit_reader& r, int lds, const uint32_t* glb, uint32_t byte_offset, uint32_t byte_length)
 {
     r.lds = lds; r.glb = glb; r.pos = byte_offset * 8u; r.end = r.pos + byte_length * 8u;
-    r.cached = 0xffffffffu; r.w = 0; r.status = AACG_PARSE_OK;
+    r.cached = 0xffffffffu; r.w = 0; r.status = AACG_PARSE_OK; r.deferred = 0;
 }
 
 /* n = 1..32 bits at the current position (zeros past the end of the buffer's padding are the host's job) */
@@ -166,8 +168,8 @@ DP_DEVICE void parse_tns(bit_reader& r, const lane_ctx& c, const ics_info& info,
         for (int f = 0; f < nf && !r.status; f++) {
             const int length = (int)br_read(r, len_bits), order = (int)br_read(r, ord_bits);
             if (order > 20) { br_fail(r, AACG_PARSE_TNS_ORDER); return; }
-            if (out && order > AACG_TNS_MAX_ORDER) { br_fail(r, AACG_PARSE_TNS_ORDER); return; }
-            aacg_tns_filter* flt = out ? &out->filt[is_short ? w : f] : nullptr;
+            if (out && order > AACG_TNS_MAX_ORDER && !r.deferred) r.deferred = AACG_PARSE_TNS_ORDER;
+            aacg_tns_filter* flt = out && order <= AACG_TNS_MAX_ORDER ? &out->filt[is_short ? w : f] : nullptr;
             if (flt) { flt->length = (uint8_t)length; flt->order = (uint8_t)order; flt->direction = 0; flt->reserved = 0; }
             if (!order) continue;
             const int direction = (int)br_read(r, 1), compress = (int)br_read(r, 1), width = res + 3 - compress;
@@ -254,7 +256,7 @@ DP_DEVICE int parse_ics(bit_reader& r, const lane_ctx& c, bool have_info, ics_in
                 pulse_at |= (uint64_t)(at & 1023u) << (16 * i);
                 pulse_amp |= br_read(r, 4) << (4 * i);
             }
-        if (!(c.P->options & AACG_PARSE_APPLY_PULSES)) br_fail(r, AACG_PARSE_PULSE_DATA);
+        if (!(c.P->options & AACG_PARSE_APPLY_PULSES) && !r.deferred) r.deferred = AACG_PARSE_PULSE_DATA;
     }
 
     if (br_read(r, 1)) { parse_tns(r, c, info, o.tns); flags |= 2; }
@@ -457,6 +459,7 @@ DP_DEVICE void parse_frame(const lane_ctx& c, uint32_t frame)
         }
     }
     if (!r.status) br_skip(r, (0u - r.pos) & 7u);
+    if (r.deferred) br_fail(r, r.deferred);
     if (over) br_fail(r, AACG_PARSE_CAPACITY);
     aacg_parse_result* res = &P.results[frame];
     res->status = (uint8_t)r.status; res->n_units = (uint8_t)(r.status ? 0 : n_units); res->n_channels = (uint8_t)(r.status ? 0 : channel);

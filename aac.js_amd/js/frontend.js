@@ -325,7 +325,7 @@ FrontEnd.prototype.parseRawDataBlock = function (bits, config) {
     const q = new Int16Array(n), meta = new Uint16Array(n / FRAME * META_WORDS);
     n = 0;
     for (const p of parts) { q.set(p[0], n); meta.set(p[1], n / FRAME * META_WORDS); n += p[0].length; }
-    return { elements: elements, q: q, meta: meta };
+    return { elements: elements, q: q, meta: meta, bitsUsed: bits.pos };     // bitsUsed: from the start of the frame's bytes, byte-aligned
 };
 
 /* next complete frame, or null.  `decoder.config` supplies sampleIndex (set by setCookie). */

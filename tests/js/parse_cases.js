@@ -95,7 +95,7 @@ function emit(name, frames, o) {
         units.forEach(function (u, i) { packed[i * host.UNIT_BYTES + 14] = u.tag; });            // reserved0: (element type << 4) | id
         unitBytes.set(packed, f * o.maxUnits * host.UNIT_BYTES);
         results.writeUInt8(units.length, 8 * f + 1); results.writeUInt8(channel, 8 * f + 2); results.writeUInt8(flags, 8 * f + 3);
-        results.writeUInt32LE(bytes.length * 8, 8 * f + 4);
+        results.writeUInt32LE(frame.bitsUsed, 8 * f + 4);
     });
     const w = function (ext, data) { fs.writeFileSync(path.join(outdir, name + ext), data); };
     w('.bytes', Buffer.concat(chunks)); w('.frames', Buffer.from(table.buffer)); w('.units', Buffer.from(unitBytes));
@@ -146,6 +146,25 @@ for (const c of CASES) {
     frames.push(wr.rawDataBlock([{ type: 'sce', id: 0, ch: [wr.randomChannel(rng, { seq: 0 })] }, { type: 'sce', id: 1, ch: [wr.randomChannel(rng, { seq: 0 })] }]));   // 15: two elements, one allowed
     frames.push(good());
     emit('malformed', frames, { si: 3, maxUnits: 1, maxCh: 1, applyPulses: true });
+}
+/* garbage in: random bytes, and valid frames with bits flipped — whatever the JavaScript parser makes of them (which
+ * status, and for the frames that still parse, which records), the device parser must make the same of them */
+{
+    const wr = new Writer(cb, 4), rng = new Rng(0xBADF00D), frames = [];
+    for (let t = 0; t < 200; t++) {
+        const b = new Uint8Array(20 + rng.below(700));
+        for (let i = 0; i < b.length; i++) b[i] = rng.below(256);
+        if (t % 4 === 0) b[0] &= 0x1f;                            // starts like an SCE: gets further into the syntax
+        if (t % 4 === 1) { b[0] = 0x20 | (b[0] & 0x1f); }         // starts like a CPE
+        frames.push(b);
+    }
+    for (let t = 0; t < 300; t++) {
+        const layout = t % 3 === 0 ? ['sce'] : t % 3 === 1 ? ['cpe'] : ['sce', 'cpe'];
+        const b = wr.rawDataBlock(randomFrame(wr, rng, layout, function (ei) { return PATTERN[(t + ei) % PATTERN.length]; }, { tns: true, pns: true, pulse: t % 5 === 0 })).slice();
+        for (let flips = 1 + rng.below(3); flips > 0; flips--) b[rng.below(b.length)] ^= 1 << rng.below(8);
+        frames.push(b);
+    }
+    emit('fuzz', frames, { si: 4, maxUnits: 2, maxCh: 3, applyPulses: true, wantTns: true });
 }
 fs.writeFileSync(path.join(outdir, 'manifest.json'), JSON.stringify(manifest));
 console.log('parse cases written: ' + manifest.length + ' (' + mode + ' codebooks)');

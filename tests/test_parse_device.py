@@ -92,6 +92,19 @@ def test_emulated_kernel_reads_in_place_when_lds_is_full(synthetic, monkeypatch)
     assert run_emulated(synthetic) >= 10
 
 
+def test_kernel_source_under_address_sanitizer(synthetic):
+    """Garbage frames and every other case with exactly-sized buffers under ASan: no access outside what the ABI promises."""
+    emu_dir = os.path.join(ROOT, "tests", "emu")
+    subprocess.run(["make", "-C", emu_dir, "asan_parse"], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    for case in json.load(open(os.path.join(synthetic, "manifest.json"))):
+        if case["name"] not in ("fuzz", "malformed", "five1_48", "mono44", "extras8k"):
+            continue
+        r = subprocess.run([os.path.join(emu_dir, "asan_parse"), synthetic, case["name"], str(case["sampleIndex"]), str(case["maxUnits"]),
+                            str(case["maxChannels"]), str(case["options"]), "1" if case["wantTns"] else "0"],
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "asan_parse" in r.stdout, r.stdout + r.stderr[-2000:]
+
+
 def test_emulated_kernel_real_codebooks(tmp_path):
     """Build container only: the same with the code words the reference checkout supplies."""
     assert run_emulated(make_cases(tmp_path, "provider")) >= 10
