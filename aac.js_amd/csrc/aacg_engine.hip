@@ -74,6 +74,10 @@ struct aacg_engine {
         float* user_pcm = nullptr; size_t user_pcm_bytes = 0;   /* copy-back target at aacg_wait, or null */
         aacg_plan_host h;
     } slot[2];
+    /* plans: device buffers come from a free list and are filled by asynchronous copies on `upload`, so that creating
+     * or destroying a plan does not wait for kernels that are running (hipMalloc / hipMemcpy / hipFree would) */
+    hipStream_t upload = nullptr;
+    std::vector<std::pair<void*, size_t>> pool;
     uint64_t submitted = 0;
     hipEvent_t last_kernel = nullptr;       /* completion of the most recently submitted batch's kernel */
     void* d_trace = nullptr;                /* profiling: per-wave phase timestamps when (ablate & 16) */
@@ -91,6 +95,11 @@ struct aacg_plan {
     aacg_dev_tns* d_tns = nullptr;
     float* d_scratch = nullptr;             /* parked predecessor tails of double-duty runs */
     float* d_spec = nullptr;                /* PNS route: f32 spectra between the two kernels */
+    size_t bytes[6] = {0, 0, 0, 0, 0, 0};   /* sizes of the six buffers above, for the engine's free list */
+    hipEvent_t uploaded = nullptr;          /* the tables are on the device */
+    hipEvent_t last_use = nullptr;          /* recorded at destruction on last_stream: everything launched with this plan */
+    hipStream_t last_stream = nullptr;      /* stream of the most recent launch (no per-launch event: it costs 3 us per step) */
+    bool used = false;
     uint64_t seen_epoch = ~0ull;            /* engine epoch right after this plan's last launch */
     uint32_t launches = 0;
 };
@@ -107,6 +116,31 @@ bool hip_ok(aacg_engine* e, hipError_t rc, const char* what)
 #define HIP_TRY(e, call, code) do { if (!hip_ok((e), (call), #call)) return (code); } while (0)
 
 size_t coef_elem_size(const aacg_engine* e) { return e->cfg.input_kind == AACG_INPUT_QUANT_I16 ? 2 : 4; }
+
+/* smallest free block that fits without wasting more than half of it, else a new allocation */
+void* pool_take(aacg_engine* e, size_t bytes, size_t* got)
+{
+    size_t best = e->pool.size();
+    for (size_t i = 0; i < e->pool.size(); i++)
+        if (e->pool[i].second >= bytes && e->pool[i].second <= 2 * bytes + 4096 && (best == e->pool.size() || e->pool[i].second < e->pool[best].second)) best = i;
+    if (best != e->pool.size()) {
+        void* p = e->pool[best].first;
+        *got = e->pool[best].second;
+        e->pool.erase(e->pool.begin() + (long)best);
+        return p;
+    }
+    void* p = nullptr;
+    if (!hip_ok(e, hipMalloc(&p, bytes), "hipMalloc (plan)")) return nullptr;
+    *got = bytes;
+    return p;
+}
+
+void pool_give(aacg_engine* e, void* p, size_t bytes)
+{
+    if (!p) return;
+    if (e->pool.size() >= 48) { (void)hipFree(e->pool.front().first); e->pool.erase(e->pool.begin()); }
+    e->pool.emplace_back(p, bytes);
+}
 
 int grow(aacg_engine* e, void** p, size_t* cap, size_t need)
 {
@@ -211,6 +245,7 @@ int aacg_create(const aacg_config* cfg, aacg_engine** out)
     const size_t ov_bytes = (size_t)cfg->max_streams * (size_t)cfg->max_channels * 2u * 1024u * sizeof(float);
     if (!hip_ok(e, hipSetDevice(cfg->device_ordinal), "hipSetDevice") ||
         !hip_ok(e, hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking), "hipStreamCreate") ||
+        !hip_ok(e, hipStreamCreateWithFlags(&e->upload, hipStreamNonBlocking), "hipStreamCreate") ||
         !hip_ok(e, hipMalloc((void**)&e->d_tab, sizeof(aacg_tables)), "hipMalloc tables") ||
         !hip_ok(e, hipMalloc((void**)&e->d_overlap, ov_bytes), "hipMalloc overlap") ||
         !hip_ok(e, hipMemcpy(e->d_tab, &e->h_tab, sizeof(aacg_tables), hipMemcpyHostToDevice), "upload tables") ||
@@ -256,6 +291,8 @@ void aacg_destroy(aacg_engine* e)
         if (sl.stream) (void)hipStreamDestroy(sl.stream);
     }
     if (e->d_trace) (void)hipFree(e->d_trace);
+    for (auto& b : e->pool) (void)hipFree(b.first);
+    if (e->upload) (void)hipStreamDestroy(e->upload);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }
@@ -358,17 +395,20 @@ int aacg_plan_create_tns(aacg_engine* e, const aacg_unit_desc* units, uint32_t n
     const size_t tb = sizeof(aacg_dev_tns) * p->h.tns.size();
     const size_t sb = std::max(p->h.needs_scratch ? p->h.runs.size() * AACG_SLOT_FLOATS * sizeof(float) : 0,
                                p->h.fm_needs_scratch ? p->h.fm_runs.size() * AACG_FM_MAX_ELEMENTS * AACG_SLOT_FLOATS * sizeof(float) : 0);
-    if (!hip_ok(e, hipSetDevice(e->cfg.device_ordinal), "hipSetDevice") ||
-        !hip_ok(e, hipMalloc((void**)&p->d_units, ub), "hipMalloc units") ||
-        (rb && !hip_ok(e, hipMalloc((void**)&p->d_runs, rb), "hipMalloc runs")) ||
-        (fb && (!hip_ok(e, hipMalloc((void**)&p->d_fm_runs, fb), "hipMalloc fm runs") ||
-                !hip_ok(e, hipMemcpy(p->d_fm_runs, p->h.fm_runs.data(), fb, hipMemcpyHostToDevice), "upload fm runs"))) ||
-        !hip_ok(e, hipMemcpy(p->d_units, p->h.units.data(), ub, hipMemcpyHostToDevice), "upload units") ||
-        (rb && !hip_ok(e, hipMemcpy(p->d_runs, p->h.runs.data(), rb, hipMemcpyHostToDevice), "upload runs")) ||
-        (tb && (!hip_ok(e, hipMalloc((void**)&p->d_tns, tb), "hipMalloc tns") ||
-                !hip_ok(e, hipMemcpy(p->d_tns, p->h.tns.data(), tb, hipMemcpyHostToDevice), "upload tns"))) ||
-        (sb && !hip_ok(e, hipMalloc((void**)&p->d_scratch, sb), "hipMalloc scratch")) ||
-        (xb && !hip_ok(e, hipMalloc((void**)&p->d_spec, xb), "hipMalloc spectra"))) {
+    bool ok = hip_ok(e, hipSetDevice(e->cfg.device_ordinal), "hipSetDevice") &&
+              hip_ok(e, hipEventCreateWithFlags(&p->uploaded, hipEventDisableTiming), "hipEventCreate") &&
+              hip_ok(e, hipEventCreateWithFlags(&p->last_use, hipEventDisableTiming), "hipEventCreate");
+    const size_t want[6] = {ub, rb, fb, tb, sb, xb};
+    void** const slot[6] = {(void**)&p->d_units, (void**)&p->d_runs, (void**)&p->d_fm_runs, (void**)&p->d_tns, (void**)&p->d_scratch, (void**)&p->d_spec};
+    const void* const src[6] = {p->h.units.data(), p->h.runs.data(), p->h.fm_runs.data(), p->h.tns.data(), nullptr, nullptr};
+    for (int i = 0; i < 6 && ok; i++) {
+        if (!want[i]) continue;
+        *slot[i] = pool_take(e, want[i], &p->bytes[i]);
+        ok = *slot[i] != nullptr &&
+             (!src[i] || hip_ok(e, hipMemcpyAsync(*slot[i], src[i], want[i], hipMemcpyHostToDevice, e->upload), "upload plan tables"));
+    }
+    ok = ok && hip_ok(e, hipEventRecord(p->uploaded, e->upload), "hipEventRecord");
+    if (!ok) {
         aacg_plan_destroy(p);
         return AACG_ERR_OUT_OF_MEMORY;
     }
@@ -379,13 +419,20 @@ int aacg_plan_create_tns(aacg_engine* e, const aacg_unit_desc* units, uint32_t n
 void aacg_plan_destroy(aacg_plan* p)
 {
     if (!p) return;
-    (void)hipSetDevice(p->e->cfg.device_ordinal);
-    if (p->d_units) (void)hipFree(p->d_units);
-    if (p->d_runs) (void)hipFree(p->d_runs);
-    if (p->d_fm_runs) (void)hipFree(p->d_fm_runs);
-    if (p->d_tns) (void)hipFree(p->d_tns);
-    if (p->d_scratch) (void)hipFree(p->d_scratch);
-    if (p->d_spec) (void)hipFree(p->d_spec);
+    aacg_engine* e = p->e;
+    (void)hipSetDevice(e->cfg.device_ordinal);
+    /* the buffers go back to the free list: wait for the copies into them and for the last kernel that reads them
+     * (two events, not the whole device) */
+    if (p->uploaded) { (void)hipEventSynchronize(p->uploaded); (void)hipEventDestroy(p->uploaded); }
+    if (p->last_use) {
+        if (p->used) {
+            if (hipEventRecord(p->last_use, p->last_stream) == hipSuccess) (void)hipEventSynchronize(p->last_use);
+            else { (void)hipGetLastError(); (void)hipDeviceSynchronize(); }        /* the stream is gone: wait for everything */
+        }
+        (void)hipEventDestroy(p->last_use);
+    }
+    void* const ptr[6] = {p->d_units, p->d_runs, p->d_fm_runs, p->d_tns, p->d_scratch, p->d_spec};
+    for (int i = 0; i < 6; i++) pool_give(e, ptr[i], p->bytes[i]);
     delete p;
 }
 
@@ -411,8 +458,11 @@ int aacg_decode_device(aacg_engine* e, aacg_plan* p, const void* d_coeffs, const
     int rc = p->seen_epoch == e->epoch ? AACG_OK : plan_check_parity(e, p);
     if (rc) return rc;
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : e->stream;
+    if (!p->used) HIP_TRY(e, hipStreamWaitEvent(s, p->uploaded, 0), AACG_ERR_NO_DEVICE);
     rc = launch_run(e, p->d_units, p->d_runs, p->d_fm_runs, p->d_tns, p->d_scratch, p->d_spec, p->h, d_coeffs, d_meta, d_pcm, (int)(p->launches & 1u), s);
     if (rc) return rc;
+    p->last_stream = s;
+    p->used = true;
 
     for (const aacg_chain& c : p->h.chains)
         for (int k = 0; k < c.n_ch; k++)
@@ -431,9 +481,12 @@ int aacg_spectral_device(aacg_engine* e, aacg_plan* p, const void* d_coeffs, con
     aacg_kparams P;
     std::memset(&P, 0, sizeof P);
     P.units = p->d_units; P.coeffs = d_coeffs; P.meta = d_meta; P.spec_out = d_spec_out; P.tab = e->d_tab;
+    HIP_TRY(e, hipStreamWaitEvent(s, p->uploaded, 0), AACG_ERR_NO_DEVICE);
     hipLaunchKernelGGL(aacg_spectral, dim3((p->n_units + AACG_WG_WAVES - 1) / AACG_WG_WAVES), dim3(AACG_WG_THREADS),
                        AACG_LDS_BYTES_SPECTRAL, s, P, (int)p->n_units);
     HIP_TRY(e, hipGetLastError(), AACG_ERR_NO_DEVICE);
+    p->last_stream = s;
+    p->used = true;
     return AACG_OK;
 }
 
