@@ -186,6 +186,47 @@ def test_plan_reuse_device_path(oracle):
     eng.close()
 
 
+def test_plans_come_and_go_while_kernels_run(oracle):
+    """Plan buffers are recycled through the engine's free list and filled by asynchronous copies: plans of changing size,
+    created and destroyed without any synchronisation in between, launched on two streams — every batch still equals the
+    oracle (a recycled buffer overwritten while a kernel still reads it, or read before its upload landed, would not)."""
+    torch = _torch()
+    rng = np.random.default_rng(77)
+    S = 6
+    eng = aacgpu.Engine(aacgpu.INPUT_QUANT_I16, 2 * S, 2)
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    ov = [np.zeros((2 * S, 2, 1024), np.float32) for _ in range(2)]          # slot k owns streams k*S .. k*S+S-1
+    pending = []                                                              # (plan, device buffers, reference, slot)
+    checked = 0
+    for it in range(40):
+        k = it & 1
+        wl = aacgpu_workload.make_batch(n_streams=int(rng.integers(1, S + 1)), n_frames=int(rng.integers(1, 40)), mix=True, seed=1000 + it,
+                                        stream_base=k * S)
+        full = np.zeros((2 * S, 2, 1024), np.float32)
+        full[:] = ov[k]
+        ref = oracle.decode_batch(wl["units"], wl["q"], wl["meta"], wl["n_pcm"], full)
+        ov[k] = full
+        with torch.cuda.stream(streams[k]):
+            dq = torch.from_numpy(wl["q"]).cuda(non_blocking=True)
+            dm = torch.from_numpy(wl["meta"].view(np.int16)).cuda(non_blocking=True)
+            dp = torch.empty(wl["n_pcm"], dtype=torch.float32, device="cuda")
+        plan = eng.plan(wl["units"])
+        eng.decode_device(plan, dq.data_ptr(), dm.data_ptr(), dp.data_ptr(), streams[k].cuda_stream)
+        pending.append((plan, (dq, dm, dp), ref, k))
+        if len(pending) > 2:                                                  # retire the oldest: its kernel may still be running
+            old_plan, bufs, old_ref, ok = pending.pop(0)
+            old_plan.destroy()
+            streams[ok].synchronize()
+            assert rms(bufs[2].cpu().numpy(), old_ref) < RMS_TOL, it
+            checked += 1
+    torch.cuda.synchronize()
+    for old_plan, bufs, old_ref, ok in pending:
+        assert rms(bufs[2].cpu().numpy(), old_ref) < RMS_TOL
+        old_plan.destroy()
+    assert checked == 38
+    eng.close()
+
+
 def test_overlap_set_get_reset():
     eng = aacgpu.Engine(aacgpu.INPUT_SPEC_F32, 2, 2)
     v = np.arange(1024, dtype=np.float32)
