@@ -292,3 +292,60 @@ def add_tns_config3(batch, seed=0xAAC00003):
             units[i]["ch"][c]["flags"] |= CHAN_TNS_PRESENT
             recs.append(rec)
     return units, np.array(recs, TNS_DTYPE)
+
+
+# ---- device front end: stand-in codebooks and a hand-assembled frame (smoke test, no Node needed) -------------------
+def standin_codebooks():
+    """The 12 codebooks' alphabets (ISO/IEC 14496-3 4.A.1) with the simplest complete prefix code over each: the first
+    2^(k+1) - n symbols get k bits, the rest k + 1 (k = floor(log2 n)), canonical assignment.  Not the standard's code
+    words (those are not in this repository); a parser does not care.  Returns (entries, counts)."""
+    import itertools
+    from aacgpu import CODE_ENTRY_DTYPE
+    books = [[(i,) for i in range(121)]]
+    for lo, hi, dim in ((-1, 1, 4), (-1, 1, 4), (0, 2, 4), (0, 2, 4), (-4, 4, 2), (-4, 4, 2), (0, 7, 2), (0, 7, 2), (0, 12, 2), (0, 12, 2), (0, 16, 2)):
+        books.append(list(itertools.product(range(lo, hi + 1), repeat=dim)))
+    entries = np.zeros(sum(len(b) for b in books), CODE_ENTRY_DTYPE)
+    counts = np.array([len(b) for b in books], np.uint32)
+    at = 0
+    for b in books:
+        n = len(b)
+        k = n.bit_length() - 1
+        short = (2 << k) - n if n != (1 << k) else n
+        code, prev = 0, k
+        for i, v in enumerate(b):
+            length = k if i < short else k + 1
+            code <<= length - prev
+            prev = length
+            entries[at]["code"], entries[at]["len"] = code, length
+            entries[at]["v"][:len(v)] = v
+            code += 1
+            at += 1
+    return entries, counts
+
+
+def tiny_frame(entries, counts, pairs=((1, -2), (0, 3), (-4, 4), (0, 0))):
+    """One raw_data_block: an SCE, ONLY_LONG, two scalefactor bands coded with book 5 (signed pairs), scalefactor steps 0.
+    Returns (bytes, expected first coefficients, expected band word)."""
+    start = [0] + [int(x) for x in np.cumsum(counts)]
+    def code(book, values):
+        for e in entries[start[book]:start[book + 1]]:
+            if tuple(e["v"][:len(values)]) == tuple(values):
+                return int(e["code"]), int(e["len"])
+        raise KeyError(values)
+    bits = []
+    def put(v, n):
+        bits.extend((v >> (n - 1 - i)) & 1 for i in range(n))
+    put(0, 3); put(0, 4)                                  # SCE, tag 0
+    put(100, 8)                                           # global_gain
+    put(0, 1); put(0, 2); put(0, 1); put(2, 6); put(0, 1)  # ics_info: ONLY_LONG, sine, max_sfb 2, no prediction
+    put(5, 4); put(2, 5)                                  # one section: book 5 over both bands
+    for _ in range(2):
+        put(*code(0, (60,)))                              # scalefactor step 0: 100 -> table index 200
+    put(0, 1); put(0, 1); put(0, 1)                       # no pulse, TNS, gain control
+    for p in pairs:
+        put(*code(5, p))
+    put(7, 3)                                             # END
+    while len(bits) % 8:
+        bits.append(0)
+    data = np.packbits(np.array(bits, np.uint8))
+    return data, np.array([v for p in pairs for v in p], np.int16), (5 << 12) | 200
