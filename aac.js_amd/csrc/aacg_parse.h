@@ -184,7 +184,7 @@ DP_DEVICE void parse_tns(bit_reader& r, const lane_ctx& c, const ics_info& info,
 
 struct ics_out {
     int16_t* q;                /* this channel's 1024 values (pre-zeroed), or nullptr: parse and drop */
-    uint16_t* meta;            /* this channel's 120 band words */
+    uint16_t* meta;            /* this channel's 120 band words (pre-zeroed: only the coded ones are written) */
     aacg_tns_info* tns;        /* or nullptr */
     aacg_chan_info* chan;
 };
@@ -237,7 +237,6 @@ DP_DEVICE int parse_ics(bit_reader& r, const lane_ctx& c, bool have_info, ics_in
         if (b & 0x80) word |= AACG_META_MS_USED;
         if (o.meta) o.meta[idx] = (uint16_t)word;
     }
-    if (o.meta) for (int idx = nb; idx < AACG_MAX_SECTIONS; idx++) o.meta[idx] = 0;
 
     /* pulse_data (ics.js:175-201): kept in registers until the spectrum is there */
     int n_pulse = 0;
@@ -281,20 +280,23 @@ DP_DEVICE int parse_ics(bit_reader& r, const lane_ctx& c, bool have_info, ics_in
         uint32_t sgn = 0;
         while (!r.status) {
             if (k >= hi) {
-                if (++w >= glen) {
+                bool done = false;
+                for (;;) {                                                  /* to the next coded (band, window) */
+                    if (++w < glen) break;
                     w = 0; sfb++; idx++;
                     if (sfb >= max_sfb) {
                         sfb = 0; group_off += glen * 128;
-                        if (++g >= groups) break;
+                        if (++g >= groups) { done = true; break; }
                         glen = group_len(info, g);
                     }
                     bt = (int)dp_lds_read_u8(c.bands + idx * S) & 15;
-                    if (bt == 0 || bt >= 13) { w = glen; continue; }           /* nothing coded: on to the next band */
+                    if (bt == 0 || bt >= 13) { w = glen; continue; }           /* nothing coded here */
                     lo0 = (int)dp_lds_read_u16(off + 2 * sfb); hi0 = (int)dp_lds_read_u16(off + 2 * sfb + 2);
                     sgn = (bt >= 7 || bt == 3 || bt == 4) ? 1u : 0u;
+                    break;
                 }
-                k = group_off + w * 128 + lo0; hi = group_off + w * 128 + hi0;
-                continue;
+                if (done) break;
+                k = group_off + w * 128 + lo0; hi = group_off + w * 128 + hi0;      /* bands are >= 4 wide: k < hi, decode in this trip */
             }
             const uint32_t win = br_peek32(r), e = lut_entry(c.lut, bt, win), p = e >> 8;
             uint32_t len = e & 31u, sb = win << len;                         /* sign bits follow the code word: <= 19 + 4 bits */

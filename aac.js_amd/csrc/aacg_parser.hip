@@ -55,6 +55,7 @@ int launch(aacg_parser* p, aacg_parse_params& P, hipStream_t s)
     while (AACG_PARSE_LDS_FIXED(p->lut_words, P.wg_threads) > p->lds_bytes) P.wg_threads /= 2;      /* very large tables */
     P.arena_bytes = (uint32_t)(p->lds_bytes - AACG_PARSE_LDS_FIXED(p->lut_words, P.wg_threads));
     HIPCHECK(hipMemsetAsync(P.q, 0, (size_t)P.n_frames * P.max_channels * 1024u * sizeof(int16_t), s));
+    HIPCHECK(hipMemsetAsync(P.meta, 0, (size_t)P.n_frames * P.max_channels * sizeof(aacg_band_meta), s));
     if (P.tns) HIPCHECK(hipMemsetAsync(P.tns, 0, (size_t)P.n_frames * P.max_channels * sizeof(aacg_tns_info), s));
     const unsigned grid = (P.n_frames + P.wg_threads - 1) / P.wg_threads;
     hipLaunchKernelGGL(aacg_parse_frames, dim3(grid), dim3(P.wg_threads), p->lds_bytes, s, P);
@@ -151,7 +152,6 @@ int aacg_parse_batch(aacg_parser* p, const uint8_t* bytes, size_t n_bytes, const
     HIPCHECK(hipMemcpyAsync(p->d_buf[0], bytes, n_bytes, hipMemcpyHostToDevice, s));
     HIPCHECK(hipMemcpyAsync(p->d_buf[1], frames, sizes[1], hipMemcpyHostToDevice, s));
     HIPCHECK(hipMemsetAsync(p->d_buf[2], 0, sizes[2], s));
-    HIPCHECK(hipMemsetAsync(p->d_buf[4], 0, sizes[4], s));
     aacg_parse_params P;
     P.bytes = (const uint32_t*)p->d_buf[0]; P.frames = (const aacg_parse_frame*)p->d_buf[1]; P.tab = p->d_tab;
     P.units = (aacg_unit_desc*)p->d_buf[2]; P.q = (int16_t*)p->d_buf[3]; P.meta = (aacg_band_meta*)p->d_buf[4];

@@ -353,7 +353,7 @@ const char* aacg_parse_status_string(int status);
  *
  * aacg_parse_batch: host pointers, returns when the results are there.
  * aacg_parse_device: DEVICE pointers, asynchronous on hip_stream; d_bytes 16-byte aligned with >= 32 readable
- * bytes after the last frame; zero-fills d_q (and d_tns) itself.                                        */
+ * bytes after the last frame; zero-fills d_q, d_meta (and d_tns) itself.                                        */
 int aacg_parse_batch(aacg_parser* p, const uint8_t* bytes, size_t n_bytes,
                      const aacg_parse_frame* frames, uint32_t n_frames,
                      uint32_t max_units, uint32_t max_channels, uint32_t options,
