@@ -147,6 +147,7 @@ struct aacg_kparams {
 #define AACG_PARSE_WG_LARGE   1024     /* frames read in place, 16 waves per CU: highest rate on large batches */
 #define AACG_PARSE_L1_BITS    9
 #define AACG_PARSE_LUT_WORDS  12288     /* 12 first-level tables of 512 + the second-level tables */
+#define AACG_PARSE_BUCKETS    1024      /* frame lengths in 8-byte steps, for the lane order */
 #define AACG_PARSE_PAD_BYTES  32        /* readable bytes required after the last frame (look-ahead + 16-byte staging) */
 /* LDS of a workgroup: tables, band columns, allocator word, then the arena */
 #define AACG_PARSE_LDS_FIXED(lut_words, threads) ((size_t)(lut_words) * 4u + 160u + (size_t)AACG_MAX_SECTIONS * (threads) + 16u)
@@ -174,6 +175,7 @@ typedef struct aacg_parse_params {
     uint32_t n_frames, max_units, max_channels, options;
     uint32_t arena_bytes;      /* LDS left for staging the frames' bytes */
     uint32_t wg_threads;
+    const uint32_t* order;     /* lane i parses frame order[i] (frames of similar length share a wave), or NULL: frame i */
 } aacg_parse_params;
 
 #endif

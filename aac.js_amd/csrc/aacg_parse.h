@@ -469,7 +469,8 @@ DP_DEVICE void parse_frame(const lane_ctx& c, uint32_t frame)
     res->bits_used = r.pos - start;
 }
 
-/* kernel body: workgroup of P.wg_threads lanes, lane t of block b parses frame b * threads + t */
+/* kernel body: workgroup of P.wg_threads lanes; lane t of block b parses frame order[b * threads + t].  A wave takes as
+ * long as its longest frame, so the launcher orders the frames by length (longest first): neighbours finish together. */
 DP_DEVICE void parse_body(const aacg_parse_params& P)
 {
     uint32_t* lds = (uint32_t*)dp_lds();
@@ -483,8 +484,9 @@ DP_DEVICE void parse_body(const aacg_parse_params& P)
     unsigned char* arena = (unsigned char*)(top + 4);
     if (tid == 0) *top = 0;
     dp_block_sync();
-    const uint32_t frame = (uint32_t)dp_block() * (uint32_t)threads + (uint32_t)tid;
-    if (frame >= P.n_frames) return;
+    const uint32_t lane = (uint32_t)dp_block() * (uint32_t)threads + (uint32_t)tid;
+    if (lane >= P.n_frames) return;
+    const uint32_t frame = P.order ? P.order[lane] : lane;
     const lane_ctx c = { &P, dp_lds_addr(lds), dp_lds_addr(swb), dp_lds_addr(swb + 64), dp_lds_addr(bands + tid), threads, arena, top, (int)P.arena_bytes };
     parse_frame(c, frame);
 }

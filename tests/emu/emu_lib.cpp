@@ -229,6 +229,11 @@ int emu_parse(int sample_index, const aacg_code_entry* entries, const uint32_t* 
     PP.n_frames = n_frames; PP.max_units = max_units; PP.max_channels = max_channels; PP.options = options;
     /* AACG_EMU_ARENA: a small staging arena sends most frames down the read-in-place path */
     PP.wg_threads = AACG_PARSE_WG_SMALL;
+    /* the launcher's lane order: frames by length, longest first (a host sort here, a counting sort on the device) */
+    std::vector<uint32_t> order(n_frames);
+    for (uint32_t i = 0; i < n_frames; i++) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return frames[a].byte_length > frames[b].byte_length; });
+    PP.order = n_frames > 64 ? order.data() : nullptr;
     const size_t fixed = AACG_PARSE_LDS_FIXED(tab.lut_words, PP.wg_threads);
     const char* env = std::getenv("AACG_EMU_ARENA");
     PP.arena_bytes = env ? (uint32_t)std::atoi(env) : (uint32_t)(160 * 1024 - fixed);
