@@ -35,6 +35,8 @@ void aacg_ext_launch(bool quant, dim3 grid, dim3 block, hipStream_t s, const aac
 /* aacg_engine_fm.hip: frame-major runs of multichannel streams */
 int aacg_fm_set_lds_limits(void);
 int aacg_fm_launch(bool quant, unsigned n_runs, unsigned lds_floats, hipStream_t s, const aacg_kparams& P);
+void aacg_refresh_launch(aacg_dev_unit* units, const aacg_unit_desc* parsed, const aacg_parse_result* results, uint32_t n_units,
+                         uint32_t max_units, int refuse_pns, uint32_t* refused, hipStream_t s);
 int aacg_spectral_ex_set_lds_limits(void);
 void aacg_spectral_ex_launch(bool quant, int n_units, hipStream_t s, const aacg_kparams& P);
 
@@ -469,6 +471,25 @@ int aacg_decode_device(aacg_engine* e, aacg_plan* p, const void* d_coeffs, const
             e->parity[(size_t)c.stream * (size_t)e->cfg.max_channels + c.channel + k] ^= 1;
     p->launches++;
     p->seen_epoch = ++e->epoch;
+    return AACG_OK;
+}
+
+/* The plan's device unit records take what the parser found (device to device); the run tables stay. */
+int aacg_plan_refresh_from_parse(aacg_engine* e, aacg_plan* p, const aacg_unit_desc* d_parsed_units,
+                                 const aacg_parse_result* d_results, uint32_t max_units, uint32_t* d_refused, void* hip_stream)
+{
+    if (!e || !p || p->e != e || !d_parsed_units || !d_results || !max_units || !d_refused) return AACG_ERR_INVALID_ARG;
+    if (e->cfg.input_kind != AACG_INPUT_QUANT_I16) { e->err = "aacg_plan_refresh_from_parse needs a QUANT_I16 engine"; return AACG_ERR_INVALID_ARG; }
+    if (p->h.any_tns || p->h.any_pns || e->cfg.tns_mode == AACG_TNS_SPEC) {
+        e->err = "aacg_plan_refresh_from_parse: TNS records / noise tables are prepared on the host, such plans are rebuilt per batch";
+        return AACG_ERR_UNSUPPORTED;
+    }
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : e->stream;
+    HIP_TRY(e, hipStreamWaitEvent(s, p->uploaded, 0), AACG_ERR_NO_DEVICE);
+    aacg_refresh_launch(p->d_units, d_parsed_units, d_results, p->n_units, max_units, 1, d_refused, s);
+    HIP_TRY(e, hipGetLastError(), AACG_ERR_NO_DEVICE);
+    p->last_stream = s;
+    p->used = true;
     return AACG_OK;
 }
 

@@ -24,7 +24,7 @@ ABI_SYMBOLS = ["aacg_create", "aacg_destroy", "aacg_last_error", "aacg_abi_versi
                "aacg_host_alloc", "aacg_host_free", "aacg_plan_create", "aacg_plan_destroy",
                "aacg_decode_device", "aacg_spectral_device", "aacg_synchronize", "aacg_get_table", "aacg_kernel_name",
                "aacg_parser_create", "aacg_parser_destroy", "aacg_parser_last_error", "aacg_parse_status_string",
-               "aacg_parse_batch", "aacg_parse_device", "aacg_parse_kernel_name"]
+               "aacg_parse_batch", "aacg_parse_device", "aacg_parse_kernel_name", "aacg_plan_refresh_from_parse"]
 
 UNIT_DTYPE = np.dtype([
     ("stream", "<u4"), ("pcm_offset", "<u4"), ("channel", "<u2"), ("n_out_ch", "<u2"),
@@ -134,6 +134,7 @@ def load_library(path=LIB_PATH):
     L.aacg_parse_kernel_name.restype = C.c_char_p
     L.aacg_parse_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.aacg_plan_refresh_from_parse.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
     L.aacg_parse_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     _lib = L
@@ -323,6 +324,10 @@ class Engine:
     def decode_device(self, plan, d_coeffs, d_meta, d_pcm, stream=0):
         """d_* are raw device addresses (e.g. torch.Tensor.data_ptr()); stream a hipStream_t handle or 0."""
         self._check(self.lib.aacg_decode_device(self.handle, plan.handle, d_coeffs, d_meta, d_pcm, stream))
+
+    def plan_refresh_from_parse(self, plan, d_parsed_units, d_results, max_units, d_refused, stream=0):
+        """Device pointers: the plan's unit records take what aacg_parse_device wrote (run tables unchanged)."""
+        self._check(self.lib.aacg_plan_refresh_from_parse(self.handle, plan.handle, d_parsed_units, d_results, max_units, d_refused, stream))
 
     def spectral_device(self, plan, d_coeffs, d_meta, d_spec, stream=0):
         self._check(self.lib.aacg_spectral_device(self.handle, plan.handle, d_coeffs, d_meta, d_spec, stream))

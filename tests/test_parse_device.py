@@ -165,3 +165,91 @@ def test_gpu_bytes_to_pcm(synthetic, oracle):
     assert sig > 1e-3 and float(np.sqrt(np.mean(d * d))) <= 5e-6 * sig
     eng.close()
     p.close()
+
+
+def _silent(units):
+    units["flags"] = 0
+    units["ch"] = np.zeros((), units.dtype["ch"])
+    units["ch"]["group_count"] = 1
+    units["ch"]["group_len"][..., 0] = 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,layout", [("stereo600", [(2, 0)]), ("fuzz", [(1, 0), (2, 1)])])
+def test_gpu_plan_refresh_from_parse(synthetic, oracle, name, layout):
+    """Parser -> transform without the host in between: a plan built once from the streams' structure, its device unit
+    records rewritten from aacg_parse_device's output (aacg_plan_refresh_from_parse), equals parsing to the host and
+    planning there — including the frames that become silent (refused by the parser, wrong element, noise bands)."""
+    import torch
+    entries, counts = codebooks(synthetic)
+    case = [c for c in json.load(open(os.path.join(synthetic, "manifest.json"))) if c["name"] == name][0]
+    data, frames, _ = load_case(synthetic, case)
+    U, Ch, n = case["maxUnits"], case["maxChannels"], len(frames)
+    assert U == len(layout)
+    C = sum(k for k, _ in layout)
+    F = 10                                                     # frames per stream
+    n = n // F * F
+    frames = frames[:n]
+    S = n // F
+    p = aacgpu.Parser(entries, counts, sample_index=case["sampleIndex"])
+    host = p.parse_batch(data, frames, U, Ch, case["options"], False)
+    # the plan's skeleton: structure only
+    skel = np.zeros(n * U, aacgpu.UNIT_DTYPE)
+    _silent(skel)
+    f = np.repeat(np.arange(n, dtype=np.uint32), U)
+    skel["stream"] = f // F
+    skel["pcm_offset"] = (f % F) * (1024 * C) + (f // F) * (F * 1024 * C)
+    skel["n_out_ch"] = C
+    skel["n_ch"] = np.tile(np.array([k for k, _ in layout], np.uint8), n)
+    skel["channel"] = np.tile(np.array([c for _, c in layout], np.uint16), n)
+    skel["coef_offset"] = skel["meta_offset"] = f * Ch + skel["channel"]
+    # host reference: the parsed records where they fit the skeleton, silent units elsewhere (the rule of the refresh kernel)
+    ref_units = skel.copy()
+    got = host["units"]
+    res = np.repeat(host["results"], U)
+    e = np.tile(np.arange(U), n)
+    ok = (res["status"] == 0) & (e < res["n_units"]) & (got["n_ch"] == skel["n_ch"]) & (got["channel"] == skel["channel"]) & ((got["flags"] & 4) == 0)
+    ref_units["flags"][ok] = got["flags"][ok]
+    ch = got["ch"][ok].copy()
+    ch["flags"] = 0
+    ref_units["ch"][ok] = ch
+    ref_units["coef_offset"] = got["coef_offset"]
+    ref_units["meta_offset"] = got["meta_offset"]
+    bad = ~ok
+    ref_units["coef_offset"][bad] = skel["coef_offset"][bad]     # a refused frame's offsets are whatever the parser left: unused, max_sfb is 0
+    ref_units["meta_offset"][bad] = skel["meta_offset"][bad]
+    ov = np.zeros((S, C, 1024), np.float32)
+    ref = oracle.decode_batch(ref_units, host["q"], host["meta"], n * 1024 * C, ov, sample_index=case["sampleIndex"])
+    # device path
+    dev = torch.device("cuda:0")
+    t = lambda arr: torch.from_numpy(np.ascontiguousarray(arr).view(np.uint8).reshape(-1)).to(dev)
+    pad = np.concatenate([data, np.zeros((-len(data)) % 16 + 32, np.uint8)])
+    d_bytes, d_frames = t(pad), t(frames)
+    d_units = torch.zeros(n * U * 64, dtype=torch.uint8, device=dev)
+    d_q = torch.zeros(n * Ch * 1024, dtype=torch.int16, device=dev)
+    d_meta = torch.zeros(n * Ch * 120, dtype=torch.int16, device=dev)
+    d_res = torch.zeros(n * 8, dtype=torch.uint8, device=dev)
+    d_pcm = torch.zeros(n * 1024 * C, dtype=torch.float32, device=dev)
+    d_refused = torch.zeros(1, dtype=torch.int32, device=dev)
+    side = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    eng = aacgpu.Engine(aacgpu.INPUT_QUANT_I16, max_streams=S, max_channels=C, sample_index=case["sampleIndex"])
+    plan = eng.plan(skel)
+    p.parse_device(d_bytes.data_ptr(), d_frames.data_ptr(), n, U, Ch, case["options"], d_units.data_ptr(), d_q.data_ptr(), d_meta.data_ptr(),
+                   None, d_res.data_ptr(), side.cuda_stream)
+    eng.plan_refresh_from_parse(plan, d_units.data_ptr(), d_res.data_ptr(), U, d_refused.data_ptr(), side.cuda_stream)
+    eng.decode_device(plan, d_q.data_ptr(), d_meta.data_ptr(), d_pcm.data_ptr(), side.cuda_stream)
+    side.synchronize()
+    assert int(d_refused.cpu()[0]) == int(bad.sum())
+    if name == "stereo600":
+        assert not bad.any()
+    else:
+        assert bad.any() and ok.any()
+    pcm = d_pcm.cpu().numpy()
+    assert np.isfinite(pcm).all()
+    d = pcm.astype(np.float64) - ref
+    sig = float(np.sqrt(np.mean(ref.astype(np.float64) ** 2)))
+    assert sig > 1e-4 and float(np.sqrt(np.mean(d * d))) <= 5e-6 * sig + 1e-9
+    plan.destroy()
+    eng.close()
+    p.close()
