@@ -22,11 +22,18 @@ __device__ __forceinline__ uint32_t length_bucket(uint32_t bytes)
     const uint32_t k = bytes >> 3;
     return AACG_PARSE_BUCKETS - 1u - (k < AACG_PARSE_BUCKETS ? k : AACG_PARSE_BUCKETS - 1u);
 }
+/* one frame per thread; the buckets are counted in LDS first: frames cluster in a few hundred buckets, and 64 k global
+ * atomics on those took 70 us per pass */
 extern "C" __global__ __launch_bounds__(256)
 void aacg_parse_order_count(const aacg_parse_frame* frames, uint32_t n, uint32_t* hist)
 {
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
-        atomicAdd(&hist[length_bucket(frames[i].byte_length)], 1u);
+    __shared__ uint32_t cnt[AACG_PARSE_BUCKETS];
+    for (uint32_t b = threadIdx.x; b < AACG_PARSE_BUCKETS; b += 256u) cnt[b] = 0;
+    __syncthreads();
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n) atomicAdd(&cnt[length_bucket(frames[i].byte_length)], 1u);
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < AACG_PARSE_BUCKETS; b += 256u) if (cnt[b]) atomicAdd(&hist[b], cnt[b]);
 }
 extern "C" __global__ __launch_bounds__(AACG_PARSE_BUCKETS)
 void aacg_parse_order_scan(uint32_t* hist)
@@ -46,8 +53,16 @@ void aacg_parse_order_scan(uint32_t* hist)
 extern "C" __global__ __launch_bounds__(256)
 void aacg_parse_order_fill(const aacg_parse_frame* frames, uint32_t n, uint32_t* next, uint32_t* order)
 {
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
-        order[atomicAdd(&next[length_bucket(frames[i].byte_length)], 1u)] = i;
+    __shared__ uint32_t cnt[AACG_PARSE_BUCKETS];          /* the block's frames per bucket, then where its share starts */
+    for (uint32_t b = threadIdx.x; b < AACG_PARSE_BUCKETS; b += 256u) cnt[b] = 0;
+    __syncthreads();
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    uint32_t bucket = 0, rank = 0;
+    if (i < n) { bucket = length_bucket(frames[i].byte_length); rank = atomicAdd(&cnt[bucket], 1u); }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < AACG_PARSE_BUCKETS; b += 256u) if (cnt[b]) cnt[b] = atomicAdd(&next[b], cnt[b]);
+    __syncthreads();
+    if (i < n) order[cnt[bucket] + rank] = i;
 }
 
 struct aacg_parser {
@@ -107,7 +122,7 @@ int launch(aacg_parser* p, aacg_parse_params& P, hipStream_t s)
             p->order_cap = need;
         }
         uint32_t* hist = p->d_order + P.n_frames;
-        const unsigned blocks = (P.n_frames + 255u) / 256u < 1024u ? (P.n_frames + 255u) / 256u : 1024u;
+        const unsigned blocks = (P.n_frames + 255u) / 256u;
         HIPCHECK(hipMemsetAsync(hist, 0, AACG_PARSE_BUCKETS * sizeof(uint32_t), s));
         hipLaunchKernelGGL(aacg_parse_order_count, dim3(blocks), dim3(256), 0, s, P.frames, P.n_frames, hist);
         hipLaunchKernelGGL(aacg_parse_order_scan, dim3(1), dim3(AACG_PARSE_BUCKETS), 0, s, hist);
