@@ -221,7 +221,8 @@ int aacg_parse_batch(aacg_parser* p, const uint8_t* bytes, size_t n_bytes, const
                               n_frames * sizeof(aacg_parse_result) };
     for (int i = 0; i < 7; i++) { int rc = sizes[i] ? grow(p, i, sizes[i]) : AACG_OK; if (rc) return rc; }
     hipStream_t s = p->stream;
-    HIPCHECK(hipMemsetAsync((char*)p->d_buf[0] + padded - (AACG_PARSE_PAD_BYTES + 16u), 0, AACG_PARSE_PAD_BYTES + 16u, s));
+    const size_t tail = padded < AACG_PARSE_PAD_BYTES + 16u ? padded : AACG_PARSE_PAD_BYTES + 16u;      /* zeros behind the last byte */
+    HIPCHECK(hipMemsetAsync((char*)p->d_buf[0] + padded - tail, 0, tail, s));
     HIPCHECK(hipMemcpyAsync(p->d_buf[0], bytes, n_bytes, hipMemcpyHostToDevice, s));
     HIPCHECK(hipMemcpyAsync(p->d_buf[1], frames, sizes[1], hipMemcpyHostToDevice, s));
     HIPCHECK(hipMemsetAsync(p->d_buf[2], 0, sizes[2], s));
