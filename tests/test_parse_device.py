@@ -167,6 +167,40 @@ def test_gpu_bytes_to_pcm(synthetic, oracle):
     p.close()
 
 
+@pytest.mark.gpu
+def test_gpu_parser_edge_cases():
+    """Empty batch, empty frame, a frame outside the buffer, a one-byte buffer, more elements than allowed for."""
+    import aacgpu_workload
+    entries, counts = aacgpu_workload.standin_codebooks()
+    data, want_q, want_word = aacgpu_workload.tiny_frame(entries, counts)
+    p = aacgpu.Parser(entries, counts, sample_index=3)
+    none = p.parse_batch(data, np.zeros(0, aacgpu.PARSE_FRAME_DTYPE), 1, 1)
+    assert len(none["results"]) == 0
+    frames = np.zeros(4, aacgpu.PARSE_FRAME_DTYPE)
+    frames["byte_offset"] = [0, 3, 0, len(data) - 1]
+    frames["byte_length"] = [len(data), 0, 2, 1]                 # whole frame, empty, truncated twice
+    out = p.parse_batch(data, frames, 1, 1)
+    assert list(out["results"]["status"]) == [0, 1, 1, 1]
+    assert np.array_equal(out["q"][0][:len(want_q)], want_q) and int(out["meta"][0][0]) == want_word
+    assert not out["q"][1:].any()
+    one = p.parse_batch(np.array([0xff], np.uint8), np.array([(0, 1)], aacgpu.PARSE_FRAME_DTYPE), 1, 1)     # END straight away: a frame without elements
+    assert int(one["results"]["status"][0]) == 0 and int(one["results"]["n_units"][0]) == 0 and int(one["results"]["bits_used"][0]) == 8
+    outside = np.array([(len(data) - 2, 8)], aacgpu.PARSE_FRAME_DTYPE)
+    with pytest.raises(aacgpu.AacgError) as ei:
+        p.parse_batch(data, outside, 1, 1)
+    assert ei.value.code == -1
+    twice = np.concatenate([data, np.zeros(1, np.uint8), data])  # the second copy at an odd offset
+    frames2 = np.array([(0, len(data)), (len(data) + 1, len(data))], aacgpu.PARSE_FRAME_DTYPE)
+    both = p.parse_batch(twice, frames2, 1, 1)
+    assert not both["results"]["status"].any() and np.array_equal(both["q"][0], both["q"][1]) and np.array_equal(both["q"][1][:len(want_q)], want_q)
+    p.close()
+    bad = entries.copy()
+    bad["len"][200] += 1
+    with pytest.raises(aacgpu.AacgError) as ei:
+        aacgpu.Parser(bad, counts, sample_index=3)
+    assert ei.value.code == -1 and "prefix code" in str(ei.value)
+
+
 def _silent(units):
     units["flags"] = 0
     units["ch"] = np.zeros((), units.dtype["ch"])
