@@ -23,6 +23,7 @@ const { randomFrame, layoutChannels, CASES, PATTERN } = require('./stream_cases.
 const { synthTables } = require('./synth_codebooks.js');
 
 const outdir = process.argv[2], mode = process.argv[3] || 'synthetic';
+const SALT = parseInt(process.env.AACG_CASE_SEED || '0', 10) >>> 0;      // other streams of the same kinds (tools/soak_parse.py)
 if (!outdir) { console.error('usage: parse_cases.js <outdir> [synthetic|provider]'); process.exit(2); }
 let cb;
 if (mode === 'provider') {
@@ -107,7 +108,7 @@ function emit(name, frames, o) {
 
 /* the stream cases of test_frontend.js, ADTS / ADTS+CRC / bare raw_data_block in turn */
 for (const c of CASES) {
-    const wr = new Writer(cb, c.si), rng = new Rng(0xF00D ^ (c.si * 7919) ^ c.frames), C = layoutChannels(c.layout), frames = [];
+    const wr = new Writer(cb, c.si), rng = new Rng((0xF00D ^ (c.si * 7919) ^ c.frames ^ SALT) >>> 0), C = layoutChannels(c.layout), frames = [];
     for (let t = 0; t < c.frames; t++) {
         const elements = randomFrame(wr, rng, c.layout, function (ei) { return PATTERN[(t + ei) % PATTERN.length]; }, c.o);
         frames.push(t % 3 === 2 ? wr.rawDataBlock(elements) : wr.adtsFrame(elements, C & 7, { crc: t % 3 === 1 }));
@@ -119,7 +120,7 @@ for (const c of CASES) {
 
 /* a larger batch: more frames than one workgroup has lanes */
 {
-    const wr = new Writer(cb, 3), rng = new Rng(0xB16), frames = [];
+    const wr = new Writer(cb, 3), rng = new Rng((0xB16 ^ SALT) >>> 0), frames = [];
     for (let t = 0; t < 600; t++) frames.push(wr.adtsFrame(randomFrame(wr, rng, ['cpe'], function () { return PATTERN[t % PATTERN.length]; }, { tns: t % 4 === 0 }), 2));
     emit('stereo600', frames, { si: 3, maxUnits: 1, maxCh: 2, wantTns: true });
 }
@@ -150,7 +151,7 @@ for (const c of CASES) {
 /* garbage in: random bytes, and valid frames with bits flipped — whatever the JavaScript parser makes of them (which
  * status, and for the frames that still parse, which records), the device parser must make the same of them */
 {
-    const wr = new Writer(cb, 4), rng = new Rng(0xBADF00D), frames = [];
+    const wr = new Writer(cb, 4), rng = new Rng((0xBADF00D ^ SALT) >>> 0), frames = [];
     for (let t = 0; t < 200; t++) {
         const b = new Uint8Array(20 + rng.below(700));
         for (let i = 0; i < b.length; i++) b[i] = rng.below(256);
