@@ -277,7 +277,7 @@ DP_DEVICE int parse_ics(bit_reader& r, const lane_ctx& c, bool have_info, ics_in
         const int off = is_short ? c.swb_short : c.swb_long;
         int g = 0, sfb = -1, idx = -1, glen = group_len(info, 0), w = glen, group_off = 0;
         int k = 0, hi = 0, bt = 0, lo0 = 0, hi0 = 0;
-        uint32_t sgn = 0;
+        uint32_t sgn = 0, held = 0;
         while (!r.status) {
             if (k >= hi) {
                 bool done = false;
@@ -328,11 +328,14 @@ DP_DEVICE int parse_ics(bit_reader& r, const lane_ctx& c, bool have_info, ics_in
                     v1 = v1 < 0 ? -mag : mag;
                 }
             }
+            /* always 8 bytes per store: a quad as it is, a pair together with its neighbour (runs start on multiples of 4
+             * and are multiples of 4 wide, so pairs come in twos) — half the write requests, the ceiling of large batches */
+            const uint32_t lo = (uint32_t)(v0 & 0xffff) | ((uint32_t)v1 << 16);
             if (o.q && !r.status) {
-                uint32_t* d = (uint32_t*)(o.q + k);
-                d[0] = (uint32_t)(v0 & 0xffff) | ((uint32_t)v1 << 16);
-                if (bt < 5) d[1] = (uint32_t)(v2 & 0xffff) | ((uint32_t)v3 << 16);
+                if (bt < 5) { dpu2 d; d.x = lo; d.y = (uint32_t)(v2 & 0xffff) | ((uint32_t)v3 << 16); *(dpu2*)(o.q + k) = d; }
+                else if (k & 2) { dpu2 d; d.x = held; d.y = lo; *(dpu2*)(o.q + k - 2) = d; }
             }
+            held = lo;
             k += bt < 5 ? 4 : 2;
         }
     }

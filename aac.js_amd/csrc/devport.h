@@ -25,6 +25,7 @@
 typedef float2 dpf2;
 typedef float4 dpf4;
 typedef int4   dpi4;
+typedef uint2  dpu2;
 /* (left, right) channel pair: every arithmetic op on it is one v_pk_*_f32 */
 typedef float dpv2 __attribute__((ext_vector_type(2)));
 

@@ -25,6 +25,7 @@
 struct alignas(8)  dpf2 { float x, y; };
 struct alignas(16) dpf4 { float x, y, z, w; };
 struct alignas(16) dpi4 { int x, y, z, w; };
+struct alignas(8)  dpu2 { uint32_t x, y; };
 typedef float dpv2 __attribute__((vector_size(8)));
 
 struct emu_wave {
