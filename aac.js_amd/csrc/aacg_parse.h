@@ -312,7 +312,7 @@ DP_DEVICE int parse_ics(bit_reader& r, const lane_ctx& c, bool have_info, ics_in
                 len += n0 + n1 + n2 + n3;
             }
             br_skip(r, len);
-            if (bt == 11) {
+            if (bt == 11 && (((v0 + 16) & ~32) == 0 || ((v1 + 16) & ~32) == 0)) {      /* |v| == 16: escape sequences follow, v0's first */
                 if (v0 == 16 || v0 == -16) {
                     int n = 4;
                     while (br_read(r, 1)) n++;

@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--real", action="store_true")
+    ap.add_argument("--uniform", action="store_true", help="only the frames within 10 %% of the median length (a constant-bit-rate stream)")
     ap.add_argument("--decode", action="store_true", help="also time parse + plan-reuse decode of the same batch")
     a = ap.parse_args()
     import torch
@@ -37,6 +38,9 @@ def main():
     counts = np.fromfile(os.path.join(d, "codebooks.counts"), np.uint32)
     data = np.fromfile(os.path.join(d, "stereo600.bytes"), np.uint8)
     frames = np.fromfile(os.path.join(d, "stereo600.frames"), aacgpu.PARSE_FRAME_DTYPE)
+    if a.uniform:
+        med = float(np.median(frames["byte_length"]))
+        frames = frames[(frames["byte_length"] > 0.9 * med) & (frames["byte_length"] < 1.1 * med)]
     reps = (a.frames + len(frames) - 1) // len(frames)
     pad = (-len(data)) % 16
     one = np.concatenate([data, np.zeros(pad, np.uint8)])
