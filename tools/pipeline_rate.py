@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--streams", type=int, default=4096)
     ap.add_argument("--frames", type=int, default=16)
     ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--uniform", action="store_true", help="only the frames within 10 %% of the median length (a constant-bit-rate stream)")
     ap.add_argument("--resident", action="store_true", help="one plan for all batches, its unit records refreshed on the device: no host work per batch")
     ap.add_argument("--overlap", action="store_true", help="two batches in flight: the host plans batch N while the GPU parses batch N+1")
     a = ap.parse_args()
@@ -37,6 +38,9 @@ def main():
     counts = np.fromfile(os.path.join(d, "codebooks.counts"), np.uint32)
     data = np.fromfile(os.path.join(d, "stereo600.bytes"), np.uint8)
     frames = np.fromfile(os.path.join(d, "stereo600.frames"), aacgpu.PARSE_FRAME_DTYPE)
+    if a.uniform:
+        med = float(np.median(frames["byte_length"]))
+        frames = frames[(frames["byte_length"] > 0.9 * med) & (frames["byte_length"] < 1.1 * med)]
     n = a.streams * a.frames
     reps = (n + len(frames) - 1) // len(frames)
     one = np.concatenate([data, np.zeros((-len(data)) % 16, np.uint8)])
