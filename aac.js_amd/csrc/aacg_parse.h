@@ -473,7 +473,8 @@ DP_DEVICE void parse_frame(const lane_ctx& c, uint32_t frame)
 }
 
 /* kernel body: workgroup of P.wg_threads lanes; lane t of block b parses frame order[b * threads + t].  A wave takes as
- * long as its longest frame, so the launcher orders the frames by length (longest first): neighbours finish together. */
+ * long as its longest frame, so the launcher sorts the frames by length and deals the sorted 64-frame pieces out to the
+ * workgroups in turn: the lanes of a wave finish together, and every CU gets long and short waves alike. */
 DP_DEVICE void parse_body(const aacg_parse_params& P)
 {
     uint32_t* lds = (uint32_t*)dp_lds();
@@ -488,8 +489,8 @@ DP_DEVICE void parse_body(const aacg_parse_params& P)
     if (tid == 0) *top = 0;
     dp_block_sync();
     const uint32_t lane = (uint32_t)dp_block() * (uint32_t)threads + (uint32_t)tid;
-    if (lane >= P.n_frames) return;
-    const uint32_t frame = P.order ? P.order[lane] : lane;
+    const uint32_t frame = P.order ? P.order[lane] : lane;       /* the order covers every lane of the grid; 0xffffffff = idle */
+    if (frame >= P.n_frames) return;
     const lane_ctx c = { &P, dp_lds_addr(lds), dp_lds_addr(swb), dp_lds_addr(swb + 64), dp_lds_addr(bands + tid), threads, arena, top, (int)P.arena_bytes };
     parse_frame(c, frame);
 }

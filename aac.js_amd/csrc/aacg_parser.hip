@@ -51,7 +51,7 @@ void aacg_parse_order_scan(uint32_t* hist)
     hist[t] = sum[t] - mine;                               /* exclusive: where the bucket starts */
 }
 extern "C" __global__ __launch_bounds__(256)
-void aacg_parse_order_fill(const aacg_parse_frame* frames, uint32_t n, uint32_t* next, uint32_t* order)
+void aacg_parse_order_fill(const aacg_parse_frame* frames, uint32_t n, uint32_t* next, uint32_t* order, uint32_t n_wg, uint32_t waves_per_wg)
 {
     __shared__ uint32_t cnt[AACG_PARSE_BUCKETS];          /* the block's frames per bucket, then where its share starts */
     for (uint32_t b = threadIdx.x; b < AACG_PARSE_BUCKETS; b += 256u) cnt[b] = 0;
@@ -62,7 +62,11 @@ void aacg_parse_order_fill(const aacg_parse_frame* frames, uint32_t n, uint32_t*
     __syncthreads();
     for (uint32_t b = threadIdx.x; b < AACG_PARSE_BUCKETS; b += 256u) if (cnt[b]) cnt[b] = atomicAdd(&next[b], cnt[b]);
     __syncthreads();
-    if (i < n) order[cnt[bucket] + rank] = i;
+    if (i < n) {
+        /* sorted position -> lane: piece c of 64 neighbours becomes wave c / n_wg of workgroup c % n_wg */
+        const uint32_t pos = cnt[bucket] + rank, piece = pos >> 6;
+        order[((piece % n_wg) * waves_per_wg + piece / n_wg) * 64u + (pos & 63u)] = i;
+    }
 }
 
 struct aacg_parser {
@@ -108,28 +112,28 @@ int launch(aacg_parser* p, aacg_parse_params& P, hipStream_t s)
     HIPCHECK(hipMemsetAsync(P.q, 0, (size_t)P.n_frames * P.max_channels * 1024u * sizeof(int16_t), s));
     HIPCHECK(hipMemsetAsync(P.meta, 0, (size_t)P.n_frames * P.max_channels * sizeof(aacg_band_meta), s));
     if (P.tns) HIPCHECK(hipMemsetAsync(P.tns, 0, (size_t)P.n_frames * P.max_channels * sizeof(aacg_tns_info), s));
-    /* frames of similar length into the same wave (AACG_PARSE_SORT=0: in table order).  Measured with frame lengths
-     * spread 44..1186 bytes: 16 k frames 1.40 -> 0.92 ms, 64 k 1.36 -> 1.05, 128 k 1.68 -> 1.52; with the 1024-lane
-     * workgroups of larger batches it loses (256 k: 2.49 -> 3.03 ms), so those keep the table order */
+    /* Frames of similar length into the same wave, and long and short waves onto every CU alike (AACG_PARSE_SORT=0: table
+     * order).  Measured with frame lengths spread 44..1186 bytes: 16 k frames 1.40 -> 0.89 ms, 64 k 1.36 -> 0.94. */
     static const bool sort_enabled = [] { const char* v = std::getenv("AACG_PARSE_SORT"); return !(v && v[0] == '0'); }();
+    const unsigned grid = (P.n_frames + P.wg_threads - 1) / P.wg_threads;
     P.order = nullptr;
-    if (sort_enabled && P.n_frames > 64u && P.wg_threads < AACG_PARSE_WG_LARGE) {
-        const size_t need = (size_t)P.n_frames + AACG_PARSE_BUCKETS;
+    if (sort_enabled && P.n_frames > 64u) {
+        const size_t lanes = (size_t)grid * P.wg_threads, need = lanes + AACG_PARSE_BUCKETS;
         if (need > p->order_cap) {
             if (p->d_order) (void)hipFree(p->d_order);
             p->d_order = nullptr; p->order_cap = 0;
             if (hipMalloc((void**)&p->d_order, need * sizeof(uint32_t)) != hipSuccess) return fail(p, AACG_ERR_OUT_OF_MEMORY, "hipMalloc failed");
             p->order_cap = need;
         }
-        uint32_t* hist = p->d_order + P.n_frames;
+        uint32_t* hist = p->d_order + lanes;
         const unsigned blocks = (P.n_frames + 255u) / 256u;
+        HIPCHECK(hipMemsetAsync(p->d_order, 0xff, lanes * sizeof(uint32_t), s));
         HIPCHECK(hipMemsetAsync(hist, 0, AACG_PARSE_BUCKETS * sizeof(uint32_t), s));
         hipLaunchKernelGGL(aacg_parse_order_count, dim3(blocks), dim3(256), 0, s, P.frames, P.n_frames, hist);
         hipLaunchKernelGGL(aacg_parse_order_scan, dim3(1), dim3(AACG_PARSE_BUCKETS), 0, s, hist);
-        hipLaunchKernelGGL(aacg_parse_order_fill, dim3(blocks), dim3(256), 0, s, P.frames, P.n_frames, hist, p->d_order);
+        hipLaunchKernelGGL(aacg_parse_order_fill, dim3(blocks), dim3(256), 0, s, P.frames, P.n_frames, hist, p->d_order, grid, P.wg_threads / 64u);
         P.order = p->d_order;
     }
-    const unsigned grid = (P.n_frames + P.wg_threads - 1) / P.wg_threads;
     hipLaunchKernelGGL(aacg_parse_frames, dim3(grid), dim3(P.wg_threads), p->lds_bytes, s, P);
     HIPCHECK(hipGetLastError());
     return AACG_OK;

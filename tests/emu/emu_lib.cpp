@@ -229,10 +229,16 @@ int emu_parse(int sample_index, const aacg_code_entry* entries, const uint32_t* 
     PP.n_frames = n_frames; PP.max_units = max_units; PP.max_channels = max_channels; PP.options = options;
     /* AACG_EMU_ARENA: a small staging arena sends most frames down the read-in-place path */
     PP.wg_threads = AACG_PARSE_WG_SMALL;
-    /* the launcher's lane order: frames by length, longest first (a host sort here, a counting sort on the device) */
-    std::vector<uint32_t> order(n_frames);
-    for (uint32_t i = 0; i < n_frames; i++) order[i] = i;
-    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return frames[a].byte_length > frames[b].byte_length; });
+    /* the launcher's lane order: frames sorted by length (a host sort here, a counting sort on the device), the sorted
+     * 64-frame pieces dealt out to the workgroups in turn; idle lanes carry 0xffffffff */
+    const uint32_t n_wg = (n_frames + PP.wg_threads - 1) / PP.wg_threads, waves = PP.wg_threads / 64;
+    std::vector<uint32_t> sorted(n_frames), order((size_t)n_wg * PP.wg_threads, 0xffffffffu);
+    for (uint32_t i = 0; i < n_frames; i++) sorted[i] = i;
+    std::stable_sort(sorted.begin(), sorted.end(), [&](uint32_t a, uint32_t b) { return frames[a].byte_length > frames[b].byte_length; });
+    for (uint32_t pos = 0; pos < n_frames; pos++) {
+        const uint32_t piece = pos >> 6;
+        order[((piece % n_wg) * waves + piece / n_wg) * 64u + (pos & 63u)] = sorted[pos];
+    }
     PP.order = n_frames > 64 ? order.data() : nullptr;
     const size_t fixed = AACG_PARSE_LDS_FIXED(tab.lut_words, PP.wg_threads);
     const char* env = std::getenv("AACG_EMU_ARENA");
