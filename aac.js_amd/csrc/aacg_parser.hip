@@ -109,7 +109,7 @@ int launch(aacg_parser* p, aacg_parse_params& P, hipStream_t s)
     if (P.wg_threads != AACG_PARSE_WG_SMALL && P.wg_threads != 512 && P.wg_threads != AACG_PARSE_WG_LARGE) return fail(p, AACG_ERR_INVALID_ARG, "AACG_PARSE_WG must be 256, 512 or 1024");
     while (AACG_PARSE_LDS_FIXED(p->lut_words, P.wg_threads) > p->lds_bytes) P.wg_threads /= 2;      /* very large tables */
     P.arena_bytes = (uint32_t)(p->lds_bytes - AACG_PARSE_LDS_FIXED(p->lut_words, P.wg_threads));
-    HIPCHECK(hipMemsetAsync(P.q, 0, (size_t)P.n_frames * P.max_channels * 1024u * sizeof(int16_t), s));
+    if (!(P.options & AACG_PARSE_SKIP_ZERO_FILL)) HIPCHECK(hipMemsetAsync(P.q, 0, (size_t)P.n_frames * P.max_channels * 1024u * sizeof(int16_t), s));
     HIPCHECK(hipMemsetAsync(P.meta, 0, (size_t)P.n_frames * P.max_channels * sizeof(aacg_band_meta), s));
     if (P.tns) HIPCHECK(hipMemsetAsync(P.tns, 0, (size_t)P.n_frames * P.max_channels * sizeof(aacg_tns_info), s));
     /* Frames of similar length into the same wave, and long and short waves onto every CU alike (AACG_PARSE_SORT=0: table
@@ -234,7 +234,7 @@ int aacg_parse_batch(aacg_parser* p, const uint8_t* bytes, size_t n_bytes, const
     P.bytes = (const uint32_t*)p->d_buf[0]; P.frames = (const aacg_parse_frame*)p->d_buf[1]; P.tab = p->d_tab;
     P.units = (aacg_unit_desc*)p->d_buf[2]; P.q = (int16_t*)p->d_buf[3]; P.meta = (aacg_band_meta*)p->d_buf[4];
     P.tns = tns ? (aacg_tns_info*)p->d_buf[5] : nullptr; P.results = (aacg_parse_result*)p->d_buf[6];
-    P.n_frames = n_frames; P.max_units = max_units; P.max_channels = max_channels; P.options = options;
+    P.n_frames = n_frames; P.max_units = max_units; P.max_channels = max_channels; P.options = options & ~AACG_PARSE_SKIP_ZERO_FILL;
     int rc = launch(p, P, s);
     if (rc) return rc;
     HIPCHECK(hipMemcpyAsync(units, p->d_buf[2], sizes[2], hipMemcpyDeviceToHost, s));

@@ -146,7 +146,7 @@ CODE_ENTRY_DTYPE = np.dtype([("code", "<u4"), ("len", "u1"), ("v", "i1", (4,)), 
 PARSE_FRAME_DTYPE = np.dtype([("byte_offset", "<u4"), ("byte_length", "<u4")])
 PARSE_RESULT_DTYPE = np.dtype([("status", "u1"), ("n_units", "u1"), ("n_channels", "u1"), ("flags", "u1"), ("bits_used", "<u4")])
 META_DTYPE = np.dtype(("<u2", (120,)))
-PARSE_APPLY_PULSES, PARSE_REFERENCE_QUIRKS = 1, 2
+PARSE_APPLY_PULSES, PARSE_REFERENCE_QUIRKS, PARSE_SKIP_ZERO_FILL = 1, 2, 4
 
 
 def alloc_parse_outputs(n_frames, max_units, max_channels, want_tns):

@@ -327,6 +327,9 @@ enum {                         /* aacg_parse_result.status; the reference's mess
 #define AACG_PARSE_REFERENCE_QUIRKS  0x2u   /* coupling channel elements consume the bits cce.js consumes
                                                (AFTER_IMDCT never matches, the band index only steps on coded
                                                bands) rather than the standard's syntax                  */
+#define AACG_PARSE_SKIP_ZERO_FILL    0x4u   /* aacg_parse_device: do not zero d_q first; positions outside the coded bands then
+                                               hold whatever was there — the transform never reads them (bands of type ZERO /
+                                               NOISE / INTENSITY and bands beyond max_sfb are not taken from the spectrum) */
 #define AACG_PARSE_HAS_PNS 0x1
 #define AACG_PARSE_HAS_TNS 0x2
 typedef struct aacg_parse_result {

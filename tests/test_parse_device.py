@@ -269,8 +269,10 @@ def test_gpu_plan_refresh_from_parse(synthetic, oracle, name, layout):
     torch.cuda.synchronize()
     eng = aacgpu.Engine(aacgpu.INPUT_QUANT_I16, max_streams=S, max_channels=C, sample_index=case["sampleIndex"])
     plan = eng.plan(skel)
-    p.parse_device(d_bytes.data_ptr(), d_frames.data_ptr(), n, U, Ch, case["options"], d_units.data_ptr(), d_q.data_ptr(), d_meta.data_ptr(),
-                   None, d_res.data_ptr(), side.cuda_stream)
+    d_q.fill_(12345)                                          # with SKIP_ZERO_FILL the spectrum outside the coded bands is whatever was there
+    torch.cuda.synchronize()
+    p.parse_device(d_bytes.data_ptr(), d_frames.data_ptr(), n, U, Ch, case["options"] | aacgpu.PARSE_SKIP_ZERO_FILL, d_units.data_ptr(),
+                   d_q.data_ptr(), d_meta.data_ptr(), None, d_res.data_ptr(), side.cuda_stream)
     eng.plan_refresh_from_parse(plan, d_units.data_ptr(), d_res.data_ptr(), U, d_refused.data_ptr(), side.cuda_stream)
     eng.decode_device(plan, d_q.data_ptr(), d_meta.data_ptr(), d_pcm.data_ptr(), side.cuda_stream)
     side.synchronize()

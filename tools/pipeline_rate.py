@@ -112,7 +112,7 @@ def main():
         d_refused = torch.zeros(1, dtype=torch.int32, device=dev)
 
         def batch():
-            p.parse_device(d_bytes.data_ptr(), d_frames.data_ptr(), n, 1, 2, aacgpu.PARSE_REFERENCE_QUIRKS,
+            p.parse_device(d_bytes.data_ptr(), d_frames.data_ptr(), n, 1, 2, aacgpu.PARSE_REFERENCE_QUIRKS | aacgpu.PARSE_SKIP_ZERO_FILL,
                            d_units.data_ptr(), d_q.data_ptr(), d_meta.data_ptr(), None, d_res.data_ptr(), side.cuda_stream)
             eng3.plan_refresh_from_parse(plan, d_units.data_ptr(), d_res.data_ptr(), 1, d_refused.data_ptr(), side.cuda_stream)
             eng3.decode_device(plan, d_q.data_ptr(), d_meta.data_ptr(), d_pcm.data_ptr(), side.cuda_stream)
