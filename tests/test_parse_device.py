@@ -110,6 +110,44 @@ def test_emulated_kernel_real_codebooks(tmp_path):
     assert run_emulated(make_cases(tmp_path, "provider")) >= 10
 
 
+def adts_frame_table(data):
+    """(offset, length) of every ADTS frame: 13-bit frame_length at bit 30 of the header."""
+    out, off = [], 0
+    while off + 7 <= len(data):
+        assert data[off] == 0xFF and (data[off + 1] & 0xF0) == 0xF0
+        length = ((int(data[off + 3]) & 3) << 11) | (int(data[off + 4]) << 3) | (int(data[off + 5]) >> 5)
+        out.append((off, length))
+        off += length
+    return np.array(out, aacgpu.PARSE_FRAME_DTYPE)
+
+
+def test_emulated_kernel_on_the_reference_streams(tmp_path):
+    """Build container only.  tests/golden/streams/*.aac were decoded by the reference itself (their .refpcm), and their
+    .units / .q / .meta were checked field by field against the reference's own parse when they were generated
+    (tests/js/test_frontend.js).  The device parser's source, given the real code words, reproduces them from the bytes."""
+    d = make_cases(tmp_path, "provider")                        # only for the real codebooks as aacg_code_entry records
+    entries, counts = codebooks(d)
+    streams = os.path.join(ROOT, "tests", "golden", "streams")
+    emu = emu_lib.Emu()
+    for case in json.load(open(os.path.join(streams, "manifest.json"))):
+        f = lambda ext, dt: np.fromfile(os.path.join(streams, case["name"] + ext), dt)
+        data, want_units = f(".aac", np.uint8), f(".units", aacgpu.UNIT_DTYPE)
+        want_q, want_meta = f(".q", np.int16).reshape(-1, 1024), f(".meta", np.uint16).reshape(-1, 120)
+        table = adts_frame_table(data)
+        assert len(table) == case["frames"]
+        C = case["channels"]
+        U = len(want_units) // case["frames"]
+        got = emu_lib.emu_parse(emu, case["sampleIndex"], entries, counts, data, table, U, C, aacgpu.PARSE_REFERENCE_QUIRKS, False)
+        assert not got["results"]["status"].any(), case["name"]
+        assert (got["results"]["n_units"] == U).all() and (got["results"]["n_channels"] == C).all()
+        assert np.array_equal(got["q"], want_q), case["name"]
+        assert np.array_equal(got["meta"], want_meta), case["name"]
+        for field in ("n_ch", "flags", "channel"):
+            assert np.array_equal(got["units"][field], want_units[field]), (case["name"], field)
+        for field in ("window_sequence", "window_shape", "max_sfb", "group_count", "group_len"):
+            assert np.array_equal(got["units"]["ch"][field], want_units["ch"][field]), (case["name"], field)
+
+
 def test_table_builder_refuses_bad_codebooks(synthetic):
     entries, counts = codebooks(synthetic)
     emu = emu_lib.Emu()
