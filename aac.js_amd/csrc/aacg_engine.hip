@@ -76,9 +76,10 @@ struct aacg_engine {
         float* user_pcm = nullptr; size_t user_pcm_bytes = 0;   /* copy-back target at aacg_wait, or null */
         aacg_plan_host h;
     } slot[2];
-    /* plans: device buffers come from a free list and are filled by asynchronous copies on `upload`, so that creating
-     * or destroying a plan does not wait for kernels that are running (hipMalloc / hipMemcpy / hipFree would) */
-    hipStream_t upload = nullptr;
+    /* plans: device buffers come from a free list and are filled by asynchronous copies on the engine's own stream, so that
+     * creating or destroying a plan does not wait for kernels that are running (hipMalloc / hipMemcpy / hipFree would).
+     * No stream of its own for that: one more stream shifted HIP's stream -> hardware-queue assignment, and a caller's two
+     * streams ended up on one queue (two batches in flight: 12.0 -> 13.5 us per step) */
     std::vector<std::pair<void*, size_t>> pool;
     uint64_t submitted = 0;
     hipEvent_t last_kernel = nullptr;       /* completion of the most recently submitted batch's kernel */
@@ -247,7 +248,6 @@ int aacg_create(const aacg_config* cfg, aacg_engine** out)
     const size_t ov_bytes = (size_t)cfg->max_streams * (size_t)cfg->max_channels * 2u * 1024u * sizeof(float);
     if (!hip_ok(e, hipSetDevice(cfg->device_ordinal), "hipSetDevice") ||
         !hip_ok(e, hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking), "hipStreamCreate") ||
-        !hip_ok(e, hipStreamCreateWithFlags(&e->upload, hipStreamNonBlocking), "hipStreamCreate") ||
         !hip_ok(e, hipMalloc((void**)&e->d_tab, sizeof(aacg_tables)), "hipMalloc tables") ||
         !hip_ok(e, hipMalloc((void**)&e->d_overlap, ov_bytes), "hipMalloc overlap") ||
         !hip_ok(e, hipMemcpy(e->d_tab, &e->h_tab, sizeof(aacg_tables), hipMemcpyHostToDevice), "upload tables") ||
@@ -294,7 +294,6 @@ void aacg_destroy(aacg_engine* e)
     }
     if (e->d_trace) (void)hipFree(e->d_trace);
     for (auto& b : e->pool) (void)hipFree(b.first);
-    if (e->upload) (void)hipStreamDestroy(e->upload);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }
@@ -407,9 +406,9 @@ int aacg_plan_create_tns(aacg_engine* e, const aacg_unit_desc* units, uint32_t n
         if (!want[i]) continue;
         *slot[i] = pool_take(e, want[i], &p->bytes[i]);
         ok = *slot[i] != nullptr &&
-             (!src[i] || hip_ok(e, hipMemcpyAsync(*slot[i], src[i], want[i], hipMemcpyHostToDevice, e->upload), "upload plan tables"));
+             (!src[i] || hip_ok(e, hipMemcpyAsync(*slot[i], src[i], want[i], hipMemcpyHostToDevice, e->stream), "upload plan tables"));
     }
-    ok = ok && hip_ok(e, hipEventRecord(p->uploaded, e->upload), "hipEventRecord");
+    ok = ok && hip_ok(e, hipEventRecord(p->uploaded, e->stream), "hipEventRecord");
     if (!ok) {
         aacg_plan_destroy(p);
         return AACG_ERR_OUT_OF_MEMORY;
