@@ -1,72 +1,47 @@
 /*
  * aac.js_amd/js/codebooks.js — the 12 AAC Huffman codebooks as two-level lookup tables.
  *
- * The code words themselves (ISO/IEC 14496-3 tables 4.A.1-4.A.12; the reference keeps them as the private
- * arrays HCB1..HCB11 / HCB_SF of src/huffman.js:22-1418) are NOT part of this repository.  They come from a
- * *provider* at start-up:
+ * The code words (ISO/IEC 14496-3 tables 4.A.1-4.A.12; the reference keeps the same facts as the private arrays
+ * HCB1..HCB11 / HCB_SF of src/huffman.js:22-1418) ship with this package in its own format:
+ * aac.js_amd/data/aac_codebooks.json — per book, (length, code word) in the standard's index order, the values
+ * following from the index (tools/gen/gen_codebooks.js documents the layout and wrote the file).
  *
- *   fromProvider(h)   h is any object with the two entry points of the reference's Huffman module
- *                     (decodeScaleFactor(stream), decodeSpectralData(stream, cb, data, off); huffman.js:1456-1490)
- *                     — in a drop-in installation that is require('aac/src/huffman').  The provider is used as
- *                     a black box: every codebook's prefix tree is walked once by feeding it chosen bit strings
- *                     and watching how many bits it consumes, which yields (length, code word, values) for
- *                     every entry.  After that the provider is not called again.
- *   fromTables(t)     t = { sf: [[len, code, value]...], spectral: [ [[len, code, v0, v1(, v2, v3)]...] x 11 ] },
- *                     e.g. a file the user generated from the standard's tables (toTables() writes this shape)
- *   load(opts)        opts.huffman / opts.tables / $AACG_HUFFMAN_MODULE / an installed `aac` package, in that
- *                     order; throws if none is there — the parser cannot run without code words
+ *   standard()        the shipped books (built once, cached)
+ *   fromTables(t)     t = { sf: [[len, code, value]...], spectral: [ [[len, code, v0, v1(, v2, v3)]...] x 11 ] }:
+ *                     any complete prefix codes over the same alphabets (the tests use stand-ins to exercise the
+ *                     table builder; toTables() writes this shape)
+ *   load(opts)        opts.codebooks / opts.tables, else standard()
  *
  * What is built from the entries is this repository's own decoder: a 9-bit first-level table and second-level
  * tables for the longer codes (one peek + one table read per code word; the reference compares code words one
  * by one down a list sorted by length, huffman.js:1426-1439).
  *
- * Facts of the standard used here (not taken from the provider): books 1,2,5,6 carry signed values, the others
- * magnitudes followed by one sign bit per non-zero value; books 1-4 code 4 values, 5-11 code 2; book 11 has the
- * escape (|v| = 16 -> N ones, a zero, N+4 bits; value 2^(N+4) + bits).
+ * Facts of the standard used here: books 1,2,5,6 carry signed values, the others magnitudes followed by one sign
+ * bit per non-zero value; books 1-4 code 4 values, 5-11 code 2; book 11 has the escape (|v| = 16 -> N ones, a
+ * zero, N+4 bits; value 2^(N+4) + bits).
  */
 'use strict';
+const fs = require('fs'), path = require('path');
 
-const L1_BITS = 9, MAX_CODE_LEN = 24;
+const L1_BITS = 9;
 const UNSIGNED_BOOK = [false, false, false, true, true, false, false, true, true, true, true, true];   // by codebook number
 const ENTRY_COUNT = [121, 81, 81, 81, 81, 81, 81, 64, 64, 169, 169, 289];                              // sf, 1..11
+const DATA_FILE = path.join(__dirname, '..', 'data', 'aac_codebooks.json');
 
-/* ---- walking a provider's prefix trees ------------------------------------------------------------------ */
-function ProbeStream(prefix) { this.prefix = prefix; this.used = 0; }
-ProbeStream.prototype.read = function (n) {
-    let v = 0;
-    for (let i = 0; i < n; i++, this.used++)
-        v = v * 2 + (this.used < this.prefix.length ? this.prefix[this.used] : 0);      // zeros after the prefix
-    return v;
-};
-
-/* book 0 = scalefactor book.  Returns [[len, code, v...]] sorted by (len, code). */
-function probeBook(provider, book) {
-    const dim = book === 0 ? 1 : (book < 5 ? 4 : 2), out = [], buf = new Int32Array(4);
-    const stack = [[]];
-    while (stack.length) {
-        const prefix = stack.pop(), s = new ProbeStream(prefix);
-        let vals, dead = false;
-        try {
-            if (book === 0) vals = [provider.decodeScaleFactor(s)];
-            else { provider.decodeSpectralData(s, book, buf, 0); vals = Array.prototype.slice.call(buf, 0, dim); }
-        } catch (e) { dead = true; }                         // ran off the provider's table: not a code word on this path
-        if (dead) { if (prefix.length >= MAX_CODE_LEN) continue; }
-        let extra = 0;
-        if (!dead && book && UNSIGNED_BOOK[book])
-            for (const v of vals) { if (v) extra++; if (book === 11 && Math.abs(v) === 16) extra += 5; }   // sign bit; escape '0' + 4 bits
-        const len = dead ? Infinity : s.used - extra;
-        if (len <= prefix.length) {
-            if (len !== prefix.length) throw new Error('codebook ' + book + ': provider is not a prefix code');
-            let code = 0;
-            for (const b of prefix) code = code * 2 + b;
-            out.push([len, code].concat(vals));
-        } else {
-            if (prefix.length >= MAX_CODE_LEN) throw new Error('codebook ' + book + ': code longer than ' + MAX_CODE_LEN + ' bits');
-            stack.push(prefix.concat(1), prefix.concat(0));
+/* aac_codebooks.json -> the { sf, spectral } shape, each book sorted by (length, code word) */
+function tablesFromData(data) {
+    if (!data || !Array.isArray(data.books) || data.books.length !== 12) throw new Error('codebooks: malformed data file');
+    const out = data.books.map(function (b, book) {
+        const n = Math.pow(b.mod, b.dim), off = b.signed ? (b.mod - 1) / 2 : 0, entries = [];
+        if (b.book !== book || n !== ENTRY_COUNT[book] || b.codes.length !== 6 * n) throw new Error('codebooks: malformed book ' + book);
+        for (let idx = 0; idx < n; idx++) {
+            const w = parseInt(b.codes.substr(6 * idx, 6), 16), e = [w >>> 19, w & 0x7ffff];
+            for (let j = b.dim - 1, r = idx; j >= 0; j--, r = Math.floor(r / b.mod)) e[2 + j] = r % b.mod - off;      // first value most significant
+            entries.push(e);
         }
-    }
-    out.sort(function (a, b) { return a[0] - b[0] || a[1] - b[1]; });
-    return out;
+        return entries.sort(function (a, c) { return a[0] - c[0] || a[1] - c[1]; });
+    });
+    return { sf: out[0], spectral: out.slice(1) };
 }
 
 /* ---- two-level tables --------------------------------------------------------------------------------------
@@ -183,28 +158,17 @@ function fromTables(t) {
     return new Codebooks(t);
 }
 
-function fromProvider(h) {
-    if (!h || typeof h.decodeScaleFactor !== 'function' || typeof h.decodeSpectralData !== 'function')
-        throw new Error('codebooks: provider lacks decodeScaleFactor / decodeSpectralData');
-    const t = { sf: probeBook(h, 0), spectral: [] };
-    for (let b = 1; b <= 11; b++) t.spectral.push(probeBook(h, b));
-    return new Codebooks(t);
+let cached = null;
+function standard() {
+    if (!cached) cached = new Codebooks(tablesFromData(JSON.parse(fs.readFileSync(DATA_FILE, 'utf8'))));
+    return cached;
 }
 
 function load(opts) {
     opts = opts || {};
     if (opts.codebooks) return opts.codebooks;
     if (opts.tables) return fromTables(opts.tables);
-    if (opts.huffman) return fromProvider(opts.huffman);
-    const tried = [];
-    for (const name of [process.env.AACG_HUFFMAN_MODULE, 'aac/src/huffman', 'aac/src/huffman.js']) {
-        if (!name) continue;
-        let mod = null;
-        try { mod = require(name); } catch (e) { tried.push(name); continue; }
-        return fromProvider(mod);
-    }
-    throw new Error('AAC Huffman codebooks unavailable (tried ' + tried.join(', ') + '): pass { huffman: require("aac/src/huffman") }, ' +
-                    '{ tables: ... } or set AACG_HUFFMAN_MODULE; the frame parser cannot run without them');
+    return standard();
 }
 
-module.exports = { Codebooks, fromProvider, fromTables, load, probeBook, UNSIGNED_BOOK, ENTRY_COUNT };
+module.exports = { Codebooks, standard, fromTables, tablesFromData, load, UNSIGNED_BOOK, ENTRY_COUNT };

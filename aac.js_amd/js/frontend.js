@@ -20,7 +20,7 @@
  * parsed once it is complete, so parseFrame() returns null instead of failing half-way — or whole
  * raw_data_blocks (MP4 samples) through pushPacket().
  *
- * The Huffman code words come from ./codebooks.js (see there: they are not part of this repository).
+ * The Huffman code words come from ./codebooks.js (the standard's books ship in aac.js_amd/data/).
  * Own code; nothing is imported from the reference.
  */
 'use strict';

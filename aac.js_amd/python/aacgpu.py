@@ -24,7 +24,7 @@ ABI_SYMBOLS = ["aacg_create", "aacg_destroy", "aacg_last_error", "aacg_abi_versi
                "aacg_host_alloc", "aacg_host_free", "aacg_plan_create", "aacg_plan_destroy",
                "aacg_decode_device", "aacg_spectral_device", "aacg_synchronize", "aacg_get_table", "aacg_kernel_name",
                "aacg_parser_create", "aacg_parser_destroy", "aacg_parser_last_error", "aacg_parse_status_string",
-               "aacg_parse_batch", "aacg_parse_device", "aacg_parse_kernel_name", "aacg_plan_refresh_from_parse"]
+               "aacg_parse_batch", "aacg_parse_device", "aacg_parse_kernel_name", "aacg_plan_refresh_from_parse", "aacg_standard_codebooks"]
 
 UNIT_DTYPE = np.dtype([
     ("stream", "<u4"), ("pcm_offset", "<u4"), ("channel", "<u2"), ("n_out_ch", "<u2"),
@@ -137,6 +137,8 @@ def load_library(path=LIB_PATH):
     L.aacg_plan_refresh_from_parse.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
     L.aacg_parse_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.aacg_standard_codebooks.argtypes = [C.c_void_p, C.c_void_p]
+    L.aacg_standard_codebooks.restype = C.c_uint32
     _lib = L
     return L
 
@@ -149,6 +151,14 @@ META_DTYPE = np.dtype(("<u2", (120,)))
 PARSE_APPLY_PULSES, PARSE_REFERENCE_QUIRKS, PARSE_SKIP_ZERO_FILL = 1, 2, 4
 
 
+def standard_codebooks():
+    """The 12 codebooks of ISO/IEC 14496-3 as (entries, counts), from the library (aacg_standard_codebooks)."""
+    L = load_library()
+    entries, counts = np.zeros(L.aacg_standard_codebooks(None, None), CODE_ENTRY_DTYPE), np.zeros(12, np.uint32)
+    L.aacg_standard_codebooks(entries.ctypes.data, counts.ctypes.data)
+    return entries, counts
+
+
 def alloc_parse_outputs(n_frames, max_units, max_channels, want_tns):
     blocks = n_frames * max_channels
     return {"units": np.zeros(n_frames * max_units, UNIT_DTYPE), "q": np.zeros((blocks, 1024), np.int16),
@@ -159,8 +169,10 @@ def alloc_parse_outputs(n_frames, max_units, max_channels, want_tns):
 class Parser:
     """aacg_parser: one GPU lane parses one frame.  entries / counts: the 12 codebooks as CODE_ENTRY_DTYPE records."""
 
-    def __init__(self, entries, counts, sample_index=3, device=0):
+    def __init__(self, entries=None, counts=None, sample_index=3, device=0):
         self.lib = load_library()
+        if entries is None:
+            entries, counts = standard_codebooks()
         entries = np.ascontiguousarray(entries)
         counts = np.ascontiguousarray(counts, np.uint32)
         assert entries.dtype == CODE_ENTRY_DTYPE and counts.size == 12

@@ -283,16 +283,22 @@ const char* aacg_kernel_name(void);
  * once, writing the records aacg_decode_* / aacg_plan_create* take.  The host keeps what is trivial and
  * serial: finding frame boundaries (ADTS frame_length, MP4 sample sizes) and numbering streams.
  *
- * The Huffman code words are not part of this library.  The caller supplies the 12 codebooks as
- * (length, code word, values) lists — book 0 = scalefactors (v[0] = 0..120, huffman.js HCB_SF), books
- * 1..11 = spectral (huffman.js HCB1..HCB11; v[0..3] for books 1-4, v[0..1] for 5-11; magnitudes for the
- * unsigned books 3,4,7..11) — e.g. as aac.js_amd/js/codebooks.js obtains them from a provider.        */
+ * The parser takes the 12 codebooks as (length, code word, values) lists — book 0 = scalefactors
+ * (v[0] = 0..120, huffman.js HCB_SF), books 1..11 = spectral (huffman.js HCB1..HCB11; v[0..3] for books 1-4,
+ * v[0..1] for 5-11; magnitudes for the unsigned books 3,4,7..11).  aacg_standard_codebooks() supplies the
+ * ones of ISO/IEC 14496-3 (tables 4.A.1-4.A.12), which is what every AAC stream uses; a caller may pass any
+ * other complete prefix codes over the same alphabets (the tests do).                                   */
 typedef struct aacg_code_entry {
     uint32_t code;             /* the code word, right-aligned                                     */
     uint8_t  len;              /* its length in bits, 1..24                                        */
     int8_t   v[4];
     uint8_t  reserved[3];
 } aacg_code_entry;
+
+#define AACG_STANDARD_CODEBOOK_ENTRIES 1362   /* 121 + 4*81 + 2*81 + 2*64 + 2*169 + 289 */
+/* Fills entries[AACG_STANDARD_CODEBOOK_ENTRIES] (book after book) and counts[12]; either may be NULL.
+ * Returns the number of entries.  Replaces the private tables of src/huffman.js:22-1418.               */
+uint32_t aacg_standard_codebooks(aacg_code_entry* entries, uint32_t counts[12]);
 
 typedef struct aacg_parse_frame {
     uint32_t byte_offset;      /* of the frame in `bytes`: an ADTS frame (header included, decoder.js:129-130)

@@ -2,15 +2,16 @@
 /*
  * tests/js/parse_cases.js — TEST KIT: inputs and expected outputs for the device front end (aacg_parse_*).
  *
- *   node tests/js/parse_cases.js <outdir> [synthetic|provider]
+ *   node tests/js/parse_cases.js <outdir> [standard|synthetic]
  *
  * Writes streams with the synthetic writer (aac_writer.js), parses them with the JavaScript front end (frontend.js,
  * itself checked against the reference's parser in test_frontend.js) and stores, per case, the bytes, the frame
  * table and what aacg_parse_batch must return for them: unit records, spectra, band words, TNS records, per-frame
  * results — in exactly the layout of include/aacgpu.h.  tests/test_parse_device.py compares the emulated kernel and
  * the GPU against these files bit for bit.
- *   synthetic (default)  stand-in codebooks (synth_codebooks.js): runs anywhere
- *   provider             the real code words from $AACG_HUFFMAN_MODULE / the reference checkout; prints SKIP without
+ *   standard (default)   the standard's codebooks as shipped (aac.js_amd/data/aac_codebooks.json)
+ *   synthetic            stand-in codebooks (synth_codebooks.js: same alphabets, other prefix codes) — the table
+ *                        builders and the parser must not depend on which prefix code they are given
  */
 'use strict';
 const fs = require('fs'), path = require('path');
@@ -22,16 +23,10 @@ const { Writer, BitWriter, Rng } = require('./aac_writer.js');
 const { randomFrame, layoutChannels, CASES, PATTERN } = require('./stream_cases.js');
 const { synthTables } = require('./synth_codebooks.js');
 
-const outdir = process.argv[2], mode = process.argv[3] || 'synthetic';
+const outdir = process.argv[2], mode = process.argv[3] || 'standard';
 const SALT = parseInt(process.env.AACG_CASE_SEED || '0', 10) >>> 0;      // other streams of the same kinds (tools/soak_parse.py)
-if (!outdir) { console.error('usage: parse_cases.js <outdir> [synthetic|provider]'); process.exit(2); }
-let cb;
-if (mode === 'provider') {
-    const REF = '/root/reference/src/huffman.js';
-    const name = process.env.AACG_HUFFMAN_MODULE || (fs.existsSync(REF) ? REF : null);
-    if (!name) { console.log('SKIP: no Huffman provider'); process.exit(0); }
-    cb = codebooks.fromProvider(require(name));
-} else cb = codebooks.fromTables(synthTables(0xC0DE));
+if (!outdir) { console.error('usage: parse_cases.js <outdir> [standard|synthetic]'); process.exit(2); }
+const cb = mode === 'synthetic' ? codebooks.fromTables(synthTables(0xC0DE)) : codebooks.standard();
 fs.mkdirSync(outdir, { recursive: true });
 
 /* the codebooks as aacg_code_entry records */

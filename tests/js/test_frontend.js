@@ -4,10 +4,11 @@
  *
  *   node tests/js/test_frontend.js [outdir]
  *
- * Needs a Huffman provider (the code words are not in this repository): $AACG_HUFFMAN_MODULE, or the reference
- * checkout of the build container.  Without one the script prints SKIP and exits 0.
+ * Runs anywhere (the codebooks ship in aac.js_amd/data/); the parts that compare with the reference run where its
+ * checkout is (the build container).
  *
- *  1. codebooks: the provider's prefix trees are walked, the lookup tables decode every code word back
+ *  1. codebooks: the shipped books' lookup tables decode every code word back; with the reference present, the shipped
+ *     books equal what walking the prefix trees of its huffman.js decoder recovers (probe_provider.js)
  *  2. writer -> FrontEnd round trips: every field the synthetic writer (aac_writer.js) put into a stream comes
  *     back bit-exactly — all window sequences, groupings, section escapes, the three scalefactor classes,
  *     M/S masks, pulse and TNS side info, DSE / FIL / CCE elements in between, ADTS with and without CRC, raw
@@ -31,10 +32,6 @@ const { randomFrame, layoutChannels, CASES, PATTERN } = require('./stream_cases.
 
 const REF = '/root/reference/src/';
 const haveRef = fs.existsSync(REF + 'decoder.js');
-let provider = null;
-if (process.env.AACG_HUFFMAN_MODULE) provider = require(process.env.AACG_HUFFMAN_MODULE);
-else if (haveRef) provider = require(REF + 'huffman.js');
-if (!provider) { console.log('SKIP: no Huffman provider'); process.exit(0); }
 const outdir = process.argv[2] || null;
 
 /* ---- 0. bit reader ------------------------------------------------------------------------------------ */
@@ -50,7 +47,7 @@ const outdir = process.argv[2] || null;
 }
 
 /* ---- 1. codebooks --------------------------------------------------------------------------------------- */
-const cb = codebooks.fromProvider(provider);
+const cb = codebooks.standard();
 {
     const again = codebooks.fromTables(JSON.parse(JSON.stringify(cb.toTables())));
     for (let book = 0; book <= 11; book++) {
@@ -65,7 +62,13 @@ const cb = codebooks.fromProvider(provider);
             }
         });
     }
-    assert.throws(() => codebooks.fromProvider({}), /provider lacks/);
+    if (haveRef) {
+        const { probeAll } = require('./probe_provider.js');
+        assert.deepStrictEqual(cb.toTables(), probeAll(require(REF + 'huffman.js')), 'shipped codebooks vs the reference decoder');
+        assert.throws(() => probeAll({}), /provider lacks/);
+        console.log('shipped codebooks == the code words the reference decodes');
+    }
+    assert.throws(() => codebooks.tablesFromData({ books: [] }), /malformed/);
     assert.throws(() => codebooks.fromTables({ sf: cb.tables.sf.slice(1), spectral: cb.tables.spectral }), /entries/);
 }
 if (haveRef) {                                                           // own tables by formula vs the reference's listings
@@ -192,7 +195,6 @@ for (const c of CASES) {
     const fe = new FrontEnd({ codebooks: cb });
     fe.push(new Uint8Array([1, 2, 3, 4, 5, 6, 7, 8]));
     assert.throws(() => fe.parseFrame({ config: config }), /Invalid ADTS header\./);
-    assert.throws(() => new FrontEnd({ huffman: {} }), /provider lacks/);
 }
 
 /* ---- 3. the same bytes through the reference ---------------------------------------------------------- */

@@ -190,11 +190,11 @@ for (const name of ['scn_stereo', 'scn_7ch']) {
     console.log('tns side info ok, rms vs identity', rms(b, ref).toExponential(3));
 }
 {
-    // GpuFrontEnd: the same frames parsed on the device and by the JavaScript front end (stand-in codebooks: the box has no
-    // code words), then decoded through GpuAACDecoder.readChunk with either front end: identical frame objects, identical PCM
+    // GpuFrontEnd: the same frames parsed on the device and by the JavaScript front end (the standard's codebooks), then
+    // decoded through GpuAACDecoder.readChunk with either front end: identical frame objects, identical PCM
     const codebooks = require(path.join(root, 'aac.js_amd', 'js', 'codebooks.js'));
     const { Writer, Rng } = require('./aac_writer.js'), { randomFrame, PATTERN } = require('./stream_cases.js'), { synthTables } = require('./synth_codebooks.js');
-    const cb = codebooks.fromTables(synthTables(0xC0DE)), wr = new Writer(cb, 3), rng = new Rng(0x6F0);
+    const cb = process.env.AACG_TEST_STANDIN_BOOKS ? codebooks.fromTables(synthTables(0xC0DE)) : codebooks.standard(), wr = new Writer(cb, 3), rng = new Rng(0x6F0);
     const frames = [];
     for (let t = 0; t < 40; t++) frames.push(wr.adtsFrame(randomFrame(wr, rng, ['cpe'], function () { return PATTERN[t % PATTERN.length]; }, { tns: t % 3 === 0 }), 2, { crc: t % 2 === 1 }));
     const bad = frames[7].slice(); bad[9] ^= 0x5a; bad[15] ^= 0xff;      // a damaged frame: both front ends must agree on what happens

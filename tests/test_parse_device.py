@@ -4,9 +4,10 @@ Expected outputs come from the JavaScript front end (aac.js_amd/js/frontend.js â
 reference's parser field by field in tests/js/test_frontend.js) run under Node on streams the synthetic writer
 produced (tests/js/parse_cases.js).  Integer / byte work: every comparison is bit-exact.
 
-The Huffman code words are not part of the repository, so the cases are written with stand-in codebooks
-(tests/js/synth_codebooks.js: same alphabets, own prefix codes) â€” a parser does not care which prefix code it is
-given â€” and, in the build container where the reference checkout supplies them, with the real ones as well.
+The cases are written with the standard's codebooks (aac.js_amd/data/aac_codebooks.json; the library's copy,
+aacg_standard_codebooks(), must be the same records) and once more with stand-in codebooks
+(tests/js/synth_codebooks.js: same alphabets, other prefix codes) â€” a parser must not care which complete prefix
+code it is given.
 
   not gpu : the kernel source executed lane by lane on the CPU (tests/emu)
   gpu     : aacg_parse_batch on the device; then parse -> aacg_decode_batch against the oracle
@@ -31,14 +32,18 @@ def make_cases(tmp, mode):
     out = os.path.join(str(tmp), mode)
     r = subprocess.run([NODE, os.path.join(ROOT, "tests", "js", "parse_cases.js"), out, mode], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
-    if "SKIP" in r.stdout:
-        pytest.skip("no Huffman code words on this machine")
     return out
 
 
 @pytest.fixture(scope="module")
+def standard(tmp_path_factory):
+    """Cases written and parsed (JavaScript) with the standard's codebooks."""
+    return make_cases(tmp_path_factory.mktemp("parse"), "standard")
+
+
+@pytest.fixture(scope="module")
 def synthetic(tmp_path_factory):
-    return make_cases(tmp_path_factory.mktemp("parse"), "synthetic")
+    return make_cases(tmp_path_factory.mktemp("parse_standin"), "synthetic")
 
 
 def codebooks(d):
@@ -82,17 +87,34 @@ def run_emulated(d):
     return len(cases)
 
 
+def test_library_codebooks_are_the_shipped_ones(standard):
+    """aacg_standard_codebooks() (C, aacg_codebook_data.inc) == aac_codebooks.json as the JavaScript side expands it."""
+    js_entries, js_counts = codebooks(standard)
+    entries, counts = aacgpu.standard_codebooks()
+    assert np.array_equal(counts, js_counts) and len(entries) == len(js_entries) == 1362
+    o = 0
+    for n in counts:
+        key = lambda a: sorted(x.tobytes() for x in a)
+        assert key(entries[o:o + n]) == key(js_entries[o:o + n])
+        o += int(n)
+
+
+def test_emulated_kernel_standard_codebooks(standard):
+    assert run_emulated(standard) >= 10
+
+
 def test_emulated_kernel_synthetic_codebooks(synthetic):
     assert run_emulated(synthetic) >= 10
 
 
-def test_emulated_kernel_reads_in_place_when_lds_is_full(synthetic, monkeypatch):
+def test_emulated_kernel_reads_in_place_when_lds_is_full(standard, monkeypatch):
     """Frames that do not fit the LDS staging arena are parsed from global memory: same results."""
     monkeypatch.setenv("AACG_EMU_ARENA", "2048")
-    assert run_emulated(synthetic) >= 10
+    assert run_emulated(standard) >= 10
 
 
-def test_kernel_source_under_address_sanitizer(synthetic):
+def test_kernel_source_under_address_sanitizer(standard):
+    synthetic = standard
     """Garbage frames and every other case with exactly-sized buffers under ASan: no access outside what the ABI promises."""
     emu_dir = os.path.join(ROOT, "tests", "emu")
     subprocess.run(["make", "-C", emu_dir, "asan_parse"], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
@@ -103,11 +125,6 @@ def test_kernel_source_under_address_sanitizer(synthetic):
                             str(case["maxChannels"]), str(case["options"]), "1" if case["wantTns"] else "0"],
                            capture_output=True, text=True, timeout=600)
         assert r.returncode == 0 and "asan_parse" in r.stdout, r.stdout + r.stderr[-2000:]
-
-
-def test_emulated_kernel_real_codebooks(tmp_path):
-    """Build container only: the same with the code words the reference checkout supplies."""
-    assert run_emulated(make_cases(tmp_path, "provider")) >= 10
 
 
 def adts_frame_table(data):
@@ -121,31 +138,65 @@ def adts_frame_table(data):
     return np.array(out, aacgpu.PARSE_FRAME_DTYPE)
 
 
-def test_emulated_kernel_on_the_reference_streams(tmp_path):
-    """Build container only.  tests/golden/streams/*.aac were decoded by the reference itself (their .refpcm), and their
-    .units / .q / .meta were checked field by field against the reference's own parse when they were generated
-    (tests/js/test_frontend.js).  The device parser's source, given the real code words, reproduces them from the bytes."""
-    d = make_cases(tmp_path, "provider")                        # only for the real codebooks as aacg_code_entry records
-    entries, counts = codebooks(d)
-    streams = os.path.join(ROOT, "tests", "golden", "streams")
+STREAMS = os.path.join(ROOT, "tests", "golden", "streams")
+
+
+def reference_stream(case):
+    f = lambda ext, dt: np.fromfile(os.path.join(STREAMS, case["name"] + ext), dt)
+    data, want_units = f(".aac", np.uint8), f(".units", aacgpu.UNIT_DTYPE)
+    table = adts_frame_table(data)
+    assert len(table) == case["frames"]
+    return data, table, want_units, f(".q", np.int16).reshape(-1, 1024), f(".meta", np.uint16).reshape(-1, 120), f(".refpcm", np.float32)
+
+
+def check_reference_stream_parse(case, got, want_units, want_q, want_meta, U):
+    C = case["channels"]
+    assert not got["results"]["status"].any(), case["name"]
+    assert (got["results"]["n_units"] == U).all() and (got["results"]["n_channels"] == C).all()
+    assert np.array_equal(got["q"], want_q), case["name"]
+    assert np.array_equal(got["meta"], want_meta), case["name"]
+    for field in ("n_ch", "flags", "channel"):
+        assert np.array_equal(got["units"][field], want_units[field]), (case["name"], field)
+    for field in ("window_sequence", "window_shape", "max_sfb", "group_count", "group_len"):
+        assert np.array_equal(got["units"]["ch"][field], want_units["ch"][field]), (case["name"], field)
+
+
+def test_emulated_kernel_on_the_reference_streams():
+    """tests/golden/streams/*.aac were decoded by the reference itself (their .refpcm), and their .units / .q / .meta were
+    checked field by field against the reference's own parse when they were generated (tests/js/test_frontend.js).
+    The device parser's source, given the library's codebooks, reproduces them from the bytes."""
+    entries, counts = aacgpu.standard_codebooks()
     emu = emu_lib.Emu()
-    for case in json.load(open(os.path.join(streams, "manifest.json"))):
-        f = lambda ext, dt: np.fromfile(os.path.join(streams, case["name"] + ext), dt)
-        data, want_units = f(".aac", np.uint8), f(".units", aacgpu.UNIT_DTYPE)
-        want_q, want_meta = f(".q", np.int16).reshape(-1, 1024), f(".meta", np.uint16).reshape(-1, 120)
-        table = adts_frame_table(data)
-        assert len(table) == case["frames"]
-        C = case["channels"]
-        U = len(want_units) // case["frames"]
+    for case in json.load(open(os.path.join(STREAMS, "manifest.json"))):
+        data, table, want_units, want_q, want_meta, _ = reference_stream(case)
+        C, U = case["channels"], len(want_units) // case["frames"]
         got = emu_lib.emu_parse(emu, case["sampleIndex"], entries, counts, data, table, U, C, aacgpu.PARSE_REFERENCE_QUIRKS, False)
-        assert not got["results"]["status"].any(), case["name"]
-        assert (got["results"]["n_units"] == U).all() and (got["results"]["n_channels"] == C).all()
-        assert np.array_equal(got["q"], want_q), case["name"]
-        assert np.array_equal(got["meta"], want_meta), case["name"]
-        for field in ("n_ch", "flags", "channel"):
-            assert np.array_equal(got["units"][field], want_units[field]), (case["name"], field)
-        for field in ("window_sequence", "window_shape", "max_sfb", "group_count", "group_len"):
-            assert np.array_equal(got["units"]["ch"][field], want_units["ch"][field]), (case["name"], field)
+        check_reference_stream_parse(case, got, want_units, want_q, want_meta, U)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", json.load(open(os.path.join(STREAMS, "manifest.json"))), ids=lambda c: c["name"])
+def test_gpu_reference_streams_from_bytes(case):
+    """Bytes in, PCM out, everything on the device with the library's own codebooks: the committed .aac streams are
+    parsed by aacg_parse_batch (equal to what the reference parsed, bit for bit), decoded by the engine, and the PCM is
+    the one the reference's readChunk() produced from the same bytes (.refpcm) within 1e-5 RMS / 5e-6 of the signal."""
+    data, table, want_units, want_q, want_meta, refpcm = reference_stream(case)
+    C, U, n, si = case["channels"], len(want_units) // case["frames"], case["frames"], case["sampleIndex"]
+    p = aacgpu.Parser(sample_index=si)                          # aacg_standard_codebooks()
+    got = p.parse_batch(data, table, U, C, aacgpu.PARSE_REFERENCE_QUIRKS, False)
+    check_reference_stream_parse(case, got, want_units, want_q, want_meta, U)
+    units = got["units"]
+    units["stream"] = 0
+    units["n_out_ch"] = C
+    units["pcm_offset"] = np.repeat(np.arange(n, dtype=np.uint32) * (1024 * C), U)
+    eng = aacgpu.Engine(aacgpu.INPUT_QUANT_I16, max_streams=1, max_channels=C, sample_index=si)
+    pcm = eng.decode_batch(units, got["q"], got["meta"], n * 1024 * C)
+    assert np.isfinite(pcm).all()
+    d = pcm.astype(np.float64) - refpcm
+    err, sig = float(np.sqrt(np.mean(d * d))), float(np.sqrt(np.mean(refpcm.astype(np.float64) ** 2)))
+    assert sig > 1e-3 and err < 1e-5 and err <= 5e-6 * sig, (err, sig)
+    eng.close()
+    p.close()
 
 
 def test_table_builder_refuses_bad_codebooks(synthetic):
@@ -163,8 +214,9 @@ def test_table_builder_refuses_bad_codebooks(synthetic):
 
 
 @pytest.mark.gpu
-def test_gpu_parse_matches_javascript_front_end(synthetic):
-    entries, counts = codebooks(synthetic)
+def test_gpu_parse_matches_javascript_front_end(standard):
+    synthetic = standard
+    entries, counts = aacgpu.standard_codebooks()
     maps_before = "libaacgpu.so" in open("/proc/self/maps").read()
     for case in json.load(open(os.path.join(synthetic, "manifest.json"))):
         data, frames, exp = load_case(synthetic, case)
@@ -179,12 +231,12 @@ def test_gpu_parse_matches_javascript_front_end(synthetic):
 
 
 @pytest.mark.gpu
-def test_gpu_bytes_to_pcm(synthetic, oracle):
+def test_gpu_bytes_to_pcm(standard, oracle):
     """Frames in, PCM out, both stages on the device: parse -> decode equals the oracle on the JavaScript front end's output."""
-    entries, counts = codebooks(synthetic)
+    synthetic = standard
     case = [c for c in json.load(open(os.path.join(synthetic, "manifest.json"))) if c["name"] == "stereo600"][0]
     data, frames, exp = load_case(synthetic, case)
-    p = aacgpu.Parser(entries, counts, sample_index=3)
+    p = aacgpu.Parser(sample_index=3)
     got = p.parse_batch(data, frames, 1, 2, aacgpu.PARSE_REFERENCE_QUIRKS, False)
     assert not got["results"]["status"].any()
     n = len(frames)
@@ -248,12 +300,13 @@ def _silent(units):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,layout", [("stereo600", [(2, 0)]), ("fuzz", [(1, 0), (2, 1)])])
-def test_gpu_plan_refresh_from_parse(synthetic, oracle, name, layout):
+def test_gpu_plan_refresh_from_parse(standard, oracle, name, layout):
     """Parser -> transform without the host in between: a plan built once from the streams' structure, its device unit
     records rewritten from aacg_parse_device's output (aacg_plan_refresh_from_parse), equals parsing to the host and
     planning there â€” including the frames that become silent (refused by the parser, wrong element, noise bands)."""
     import torch
-    entries, counts = codebooks(synthetic)
+    synthetic = standard
+    entries, counts = aacgpu.standard_codebooks()
     case = [c for c in json.load(open(os.path.join(synthetic, "manifest.json"))) if c["name"] == name][0]
     data, frames, _ = load_case(synthetic, case)
     U, Ch, n = case["maxUnits"], case["maxChannels"], len(frames)

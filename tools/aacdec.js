@@ -1,8 +1,7 @@
 #!/usr/bin/env node
 /* Decode an ADTS .aac file on the GPU:  node tools/aacdec.js in.aac out.f32 [--gpu-parse] [--tns-spec] [--pns-spec] [--pulses]
  * --gpu-parse: the bitstream parser runs on the device too (GpuFrontEnd), else in JavaScript (FrontEnd).
- * Output: interleaved float32 PCM in [-1, 1).  Needs a Huffman provider (aac.js_amd/js/codebooks.js: an installed
- * `aac` package or $AACG_HUFFMAN_MODULE) and the built engine (aac.js_amd/csrc/libaacgpu.so + the N-API addon). */
+ * Output: interleaved float32 PCM in [-1, 1).  Needs the built engine (aac.js_amd/csrc/libaacgpu.so + the N-API addon). */
 'use strict';
 const fs = require('fs'), path = require('path');
 const host = require(path.join(__dirname, '..', 'aac.js_amd', 'js'));

@@ -2,7 +2,7 @@
 /* Parse rate of the JavaScript front end (frames/s on one core), next to the reference's own parser on the same
  * bytes when the reference checkout is present (its readChunk() with process() stubbed out, i.e. element loop +
  * Huffman + its in-loop dequantisation).  Streams: the committed tests/golden/streams/*.aac.
- *   node tools/frontend_rate.js [seconds]        needs a Huffman provider, see aac.js_amd/js/codebooks.js */
+ *   node tools/frontend_rate.js [seconds] */
 'use strict';
 const fs = require('fs'), path = require('path');
 const root = path.join(__dirname, '..');
@@ -12,7 +12,7 @@ const adts = require(path.join(root, 'aac.js_amd', 'js', 'adts.js'));
 const { BitStream } = require(path.join(root, 'aac.js_amd', 'js', 'bits.js'));
 const REF = '/root/reference/src/', haveRef = fs.existsSync(REF + 'decoder.js');
 const seconds = parseFloat(process.argv[2] || '2');
-const cb = codebooks.load(haveRef && !process.env.AACG_HUFFMAN_MODULE ? { huffman: require(REF + 'huffman.js') } : {});
+const cb = codebooks.standard();
 let ref = null;
 if (haveRef) {
     process.env.NODE_PATH = path.join(root, 'tests', 'golden', 'gen', 'stubs');

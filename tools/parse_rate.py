@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
 """Rate of the device front end (aacg_parse_frames) and of bytes -> PCM with both stages on the device.
 
-    python tools/parse_rate.py [--frames 65536] [--steps 50] [--real]
+    python tools/parse_rate.py [--frames 65536] [--steps 50] [--standin]
 
-Streams: the 600 stereo 48 kHz frames of tests/js/parse_cases.js (synthetic writer; stand-in codebooks unless --real
-and a Huffman provider is present), repeated to --frames.  Timed with HIP events on the launch stream, inputs
+Streams: the 600 stereo 48 kHz frames of tests/js/parse_cases.js (synthetic writer; the standard codebooks unless --standin),
+repeated to --frames.  Timed with HIP events on the launch stream, inputs
 resident in HBM.  Prints one JSON line."""
 import argparse
 import json
@@ -25,13 +25,13 @@ def main():
     ap.add_argument("--frames", type=int, default=65536)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--real", action="store_true")
+    ap.add_argument("--standin", action="store_true")
     ap.add_argument("--uniform", action="store_true", help="only the frames within 10 %% of the median length (a constant-bit-rate stream)")
     ap.add_argument("--decode", action="store_true", help="also time parse + plan-reuse decode of the same batch")
     a = ap.parse_args()
     import torch
     d = tempfile.mkdtemp()
-    r = subprocess.run(["node", os.path.join(ROOT, "tests", "js", "parse_cases.js"), d, "provider" if a.real else "synthetic"],
+    r = subprocess.run(["node", os.path.join(ROOT, "tests", "js", "parse_cases.js"), d, "synthetic" if a.standin else "standard"],
                        capture_output=True, text=True)
     assert r.returncode == 0 and "SKIP" not in r.stdout, r.stdout + r.stderr
     entries = np.fromfile(os.path.join(d, "codebooks.entries"), aacgpu.CODE_ENTRY_DTYPE)
@@ -77,7 +77,7 @@ def main():
     in_bytes = int(table["byte_length"].sum())
     out = {"kernel": "aacg_parse_frames", "frames": n, "us_per_batch": ms * 1e3, "frames_per_s": n / (ms * 1e-3),
            "bytes_per_frame": in_bytes / n, "stream_GBps": in_bytes / (ms * 1e-3) / 1e9,
-           "written_GBps": n * (2 * 2048 + 2 * 240 + 64 + 8) / (ms * 1e-3) / 1e9, "codebooks": "real" if a.real else "synthetic"}
+           "written_GBps": n * (2 * 2048 + 2 * 240 + 64 + 8) / (ms * 1e-3) / 1e9, "codebooks": "stand-in" if a.standin else "standard"}
     print(json.dumps(out))
 
 

@@ -3,7 +3,7 @@
 
     python tools/pipeline_rate.py [--streams 4096] [--frames 16] [--steps 10]
 
-Streams: the 600 stereo frames of tests/js/parse_cases.js (stand-in codebooks), dealt out as --streams streams of --frames
+Streams: the 600 stereo frames of tests/js/parse_cases.js (standard codebooks), dealt out as --streams streams of --frames
 consecutive frames.  Bit streams and PCM stay in HBM; what crosses PCIe per batch is the 64-byte unit record and the
 8-byte result per frame (down) and the planner's run table (up).  Wall-clock per stage, one JSON line."""
 import argparse
@@ -32,7 +32,7 @@ def main():
     a = ap.parse_args()
     import torch
     d = tempfile.mkdtemp()
-    r = subprocess.run(["node", os.path.join(ROOT, "tests", "js", "parse_cases.js"), d, "synthetic"], capture_output=True, text=True)
+    r = subprocess.run(["node", os.path.join(ROOT, "tests", "js", "parse_cases.js"), d, "standard"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     entries = np.fromfile(os.path.join(d, "codebooks.entries"), aacgpu.CODE_ENTRY_DTYPE)
     counts = np.fromfile(os.path.join(d, "codebooks.counts"), np.uint32)

@@ -20,7 +20,7 @@ n_seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 frames = refused = 0
 for seed in range(1, n_seeds + 1):
     d = tempfile.mkdtemp()
-    r = subprocess.run(["node", os.path.join(ROOT, "tests", "js", "parse_cases.js"), d, "synthetic"], capture_output=True, text=True,
+    r = subprocess.run(["node", os.path.join(ROOT, "tests", "js", "parse_cases.js"), d, "standard"], capture_output=True, text=True,
                        env=dict(os.environ, AACG_CASE_SEED=str(seed * 2654435761 % (1 << 31))))
     assert r.returncode == 0, r.stdout + r.stderr
     entries, counts = T.codebooks(d)
