@@ -10,14 +10,21 @@ buffer sets so that no step is served from the 256 MiB Infinity Cache.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--input quant|spec] [--workload cfg2|cfg3|cfg4|cfg5] [--tns reference|spec]
 
-Timing: W untimed warm-up steps, then exactly K timed steps between barrier + synchronize on both sides; the
-kernel time comes from HIP events on the launch stream.  A step takes ~13 us, so before the warm-up the GPU is
+Timing: W untimed warm-up steps, then exactly K timed steps between barrier + synchronize on both sides.  The K
+steps are bracketed twice: by HIP events on the launch stream (the time the GPU spent on them) and by the host's
+clock (which adds the launch latency of the first step and the wake-up after the last one — ~70 us, i.e. a quarter
+of a 20-step region of 13 us steps).  `value` = frames of all ranks / MAX over ranks of the event-bracketed time;
+the host-clock figures are reported beside it (`wall_ms_per_step`, `value_wall`).  Before the warm-up the GPU is
 loaded for --precondition-ms (default 300 ms, untimed, reported as config.preconditioning): a few hundred steps
 are over before the clocks have ramped, and the same kernel then measures 12 % slower.
 
-N > 1: launched by torch.distributed.run, one rank per GPU; streams are sharded over ranks (every rank
-decodes its own 256 streams: weak scaling, no data-path collective; RCCL only carries the barrier and
-the max-over-ranks of the elapsed time).
+After the timed region (untimed): every stream is reset, one more step runs, and its PCM is compared with the
+oracle on the whole batch (`parity_rms`, `parity_rel`; gate 1e-5 / 5e-6 — the run fails if it is missed).
+
+N > 1: one rank per GPU under torch.distributed.run (the driver's launch line); started without it, `--gpus N`
+launches the N ranks itself as a child process before touching the GPU.  Streams are sharded over ranks (every
+rank decodes its own 256 streams: weak scaling, no data-path collective; RCCL only carries the barrier and the
+max-over-ranks of the elapsed time).
 """
 import argparse
 import json
@@ -33,11 +40,11 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec peak (
 STREAMS, FRAMES = 256, 16      # config 2: 4096 stereo frames per batch per GPU
 
 
-def algorithmic_bytes_per_stereo_frame(kind):
+def algorithmic_bytes_per_channel_frame(kind, chain_frames, pcm="f32"):
     """per channel-frame 4096 B spectrum (f32) or 2048 B coefficients + 240 B band side
-    info (int16 path), 4096 B PCM out, + 8192/T B of overlap state (read + written once per chain)."""
-    per_cf = (4096 if kind == "spec" else 2048 + 240) + 4096 + 8192.0 / FRAMES
-    return 2 * per_cf
+    info (int16 path), 4096 B PCM out (2048 B as int16), + 8192/T B of overlap state (read + written once per chain
+    of T consecutive frames: 16 for configs 2, 3, 5, 128 for config 4)."""
+    return (4096 if kind == "spec" else 2048 + 240) + (2048 if pcm == "i16" else 4096) + 8192.0 / chain_frames
 
 
 def measured_traffic(kind):
@@ -56,44 +63,68 @@ def measured_traffic(kind):
         return None, None
 
 
-def cpu_baseline(kind, mix, budget_s=12.0):
-    """The oracle (plain C restatement of the reference algorithm, bit-exact with aac.js) on ONE host core,
-    on a bounded sample of the same workload: batches of 4 streams x 16 frames until ~budget_s of CPU time."""
+def cpu_baseline(kind, mix, layout, n_chan, budget_s=10.0):
+    """The oracle (plain C restatement of the reference algorithm, bit-exact with aac.js) on the host cores, on a
+    bounded sample of the same workload: batches of 4 streams x 16 frames for ~budget_s on ONE core, then one such
+    stream set per thread on ALL the cores this process may use for ~budget_s / 2 (oracle/orc_bench.c)."""
     import numpy as np
     import aacgpu_workload
     import orc
     o = orc.load()
-    wl = aacgpu_workload.make_batch(n_streams=4, n_frames=FRAMES, mix=mix, seed=0xAAC00002)
-    ov = np.zeros((4, 2, 1024), np.float32)
+    wl = aacgpu_workload.make_batch(n_streams=4, n_frames=FRAMES, mix=mix, layout=layout, seed=0xAAC00002)
+    ov = np.zeros((4, n_chan, 1024), np.float32)
     coeffs = wl["q"]
     if kind == "spec":
         _, coeffs = o.decode_batch(wl["units"], wl["q"], wl["meta"], wl["n_pcm"], ov, want_spec=True)
     meta = wl["meta"] if kind == "quant" else None
     o.decode_batch(wl["units"], coeffs, meta, wl["n_pcm"], ov)          # warm
-    frames, t0 = 0, time.perf_counter()
-    while time.perf_counter() - t0 < budget_s:
-        o.decode_batch(wl["units"], coeffs, meta, wl["n_pcm"], ov)
-        frames += wl["n_frames_total"]
-    dt = time.perf_counter() - t0
-    out = {"value": frames / dt, "unit": "stereo frames/s", "cores": 1, "kind": "port",
-           "sample": "%d stereo frames (4 streams x 16-frame batches, same generator as the GPU workload) in %.1f s "
-                     "on 1 of %d host cores; oracle/aac_oracle.c, gcc -O2 -ffp-contract=off" % (frames, dt, os.cpu_count())}
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    per_batch = wl["n_frames_total"]
+    n1, dt1 = o.bench_threads(1, budget_s, wl["units"], coeffs, meta, wl["n_pcm"], 4, n_chan)
+    nall, dtall = o.bench_threads(cores, budget_s / 2, wl["units"], coeffs, meta, wl["n_pcm"], 4, n_chan)
+    what = "4 streams x 16-frame batches, same generator as the GPU workload; oracle/aac_oracle.c, gcc -O2 -ffp-contract=off"
+    out = {"value": nall * per_batch / dtall, "unit": "frames/s", "cores": cores, "kind": "port",
+           "sample": "%d frames in %.1f s on %d threads (one stream set each) of %d host cores; %s" % (nall * per_batch, dtall, cores, os.cpu_count(), what),
+           "single_core": {"value": n1 * per_batch / dt1, "unit": "frames/s", "cores": 1,
+                           "sample": "%d frames in %.1f s on 1 thread; %s" % (n1 * per_batch, dt1, what)}}
     # the same path as plain JavaScript under Node, the stand-in for "aac.js's own Node path" (the reference cannot
     # travel to the GPU box); in the build container the real aac.js ran process()+interleave at 0.55x this port's rate
     # (BASELINE.md §4)
     import shutil
     import subprocess
     node = shutil.which("node")
-    if node and not mix and kind == "quant":
+    if node and not mix and kind == "quant" and n_chan == 2:
         try:
-            r = subprocess.run([node, os.path.join(ROOT, "oracle", "js", "aac_port.js"), "bench", "5"],
+            r = subprocess.run([node, os.path.join(ROOT, "oracle", "js", "aac_port.js"), "bench", "4"],
                                capture_output=True, text=True, timeout=60)
             js = json.loads(r.stdout.strip().splitlines()[-1])
-            out["js_port"] = {"value": js["frames_per_s"], "unit": "stereo frames/s", "cores": 1, "node": js["node"],
+            out["js_port"] = {"value": js["frames_per_s"], "unit": "frames/s", "cores": 1, "node": js["node"],
                               "sample": "%d frames in %.1f s, oracle/js/aac_port.js" % (js["frames"], js["seconds"])}
         except Exception as exc:                        # baseline extra only; never fails the bench
             out["js_port"] = {"error": str(exc)[:200]}
     return out
+
+
+def parity_check(eng, plan, step0, bufs, host_in0, base, units, tns, n_streams, n_chan, stream):
+    """Untimed, after the timed region: reset every stream (= new FilterBank), run the bench's own step once more on
+    buffer set 0 and compare the whole batch with the oracle.  Returns (rms error, rms error / signal rms)."""
+    import numpy as np
+    import torch
+    import orc
+    torch.cuda.synchronize()
+    for s in range(n_streams):
+        eng.reset_stream(s)
+    d_in, d_out = bufs[0]
+    d_out.zero_()
+    torch.cuda.synchronize()
+    step0()
+    torch.cuda.synchronize()
+    got = d_out.float().cpu().numpy() if d_out.dtype != torch.float32 else d_out.cpu().numpy()
+    ov = np.zeros((n_streams, n_chan, 1024), np.float32)
+    ref = orc.load().decode_batch(units, host_in0, base["meta"] if host_in0.dtype == np.int16 else None, base["n_pcm"], ov, tns=tns)
+    d = got.astype(np.float64) - ref
+    err, sig = float(np.sqrt(np.mean(d * d))), float(np.sqrt(np.mean(ref.astype(np.float64) ** 2)))
+    return err, err / sig if sig > 0 else float("inf"), bool(np.isfinite(got).all())
 
 
 def main():
@@ -110,9 +141,22 @@ def main():
                          "the reference's TNS is the identity, which is what the headline figure measures)")
     ap.add_argument("--nbuf", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the untimed oracle comparison after the timed region")
     ap.add_argument("--pipelines", type=int, default=1, choices=[1, 2],
                     help="2: alternate batches of two disjoint stream sets on two HIP streams (supplementary figure)")
+    ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
+                    help="collective backend of the harness (barrier + MAX only); gloo for ranks that share a GPU")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="testing on a box with fewer GPUs than ranks: rank r uses device r mod device_count (use with --dist-backend gloo)")
     args = ap.parse_args()
+
+    import aacgpu_shard
+    if args.gpus > 1 and not aacgpu_shard.launched_by_torchrun():
+        # started without a launcher: run the N ranks as a child process group (nothing here has touched the GPU yet)
+        sys.exit(aacgpu_shard.self_launch(args.gpus, os.path.abspath(__file__), sys.argv[1:]))
+    # profiling switches of a -DAACG_PROFILE build must never reach a timed run
+    if os.environ.pop("AACG_ABLATE", None) is not None:
+        print("bench.py: AACG_ABLATE ignored (work-skipping switches are for tools/ only)", file=sys.stderr)
 
     import numpy as np
     import torch
@@ -123,29 +167,31 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node N" % (args.gpus, world))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local)
+    n_dev = torch.cuda.device_count()
+    if local >= n_dev and not args.share_gpu:
+        raise SystemExit("rank %d has no GPU of its own (%d visible); --share-gpu is for tests only" % (local, n_dev))
+    device = local % n_dev
+    torch.cuda.set_device(device)
     dist = None
-    if world > 1 or "RANK" in os.environ:              # launched by torch.distributed.run: RCCL for barrier / max only
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    if aacgpu_shard.launched_by_torchrun():            # RCCL (or gloo) for barrier / max only
+        dist = aacgpu_shard.init_process_group(args.dist_backend, device=torch.device("cuda", device))
 
     # cfg2 (the metric's configuration) / cfg3: 256 streams x 16 frames; cfg4: 32 streams x 128 frames per GPU
-    # (chains of 9 runs: later runs recompute their predecessor's tail); cfg5: 3 CPE + LFE = 7 channels per frame
+    # (chains of 8 runs: later runs recompute their predecessor's tail); cfg5: 3 CPE + LFE = 7 channels per frame
     mix = args.workload in ("cfg3", "cfg4", "cfg5")
     n_streams, n_frames = (32, 128) if args.workload == "cfg4" else (STREAMS, FRAMES)
     layout = ("cpe", "cpe", "cpe", "sce") if args.workload == "cfg5" else ("cpe",)
     n_chan = 7 if args.workload == "cfg5" else 2
     kind = aacgpu.INPUT_QUANT_I16 if args.input == "quant" else aacgpu.INPUT_SPEC_F32
-    eng = aacgpu.Engine(kind, max_streams=n_streams * args.pipelines, max_channels=n_chan, device=local,
+    eng = aacgpu.Engine(kind, max_streams=n_streams * args.pipelines, max_channels=n_chan, device=device,
                         tns_mode=aacgpu.TNS_SPEC if args.tns == "spec" else aacgpu.TNS_REFERENCE)
 
     # rank r owns its own streams: independent data per rank, same shape
     base = aacgpu_workload.make_batch(n_streams=n_streams, n_frames=n_frames, mix=mix, layout=layout,
-                                      seed=0xAAC00002 + 1000 * rank)
+                                      seed=aacgpu_shard.rank_seed(0xAAC00002, rank))
     units, tns = base["units"], None
     if args.tns == "spec":                               # a filter on every channel-frame
         units, tns = aacgpu_workload.add_tns_config3(base, seed=0xAAC00003 + rank)
@@ -154,25 +200,24 @@ def main():
         up = units.copy()
         up["stream"] += pl * n_streams
         plans.append(eng.plan(up, tns=tns))
-    plan = plans[0]
     d_meta = torch.from_numpy(base["meta"].view(np.int16)).cuda() if args.input == "quant" else None
-    bufs = []
+    bufs, host_in0 = [], None
     rng = np.random.default_rng(rank)
     for b in range(args.nbuf):
         q = base["q"] if b == 0 else np.roll(base["q"], 131 * b, axis=0) * rng.choice([-1, 1]).astype(np.int16)
         if args.input == "quant":
-            d_in = torch.from_numpy(np.ascontiguousarray(q)).cuda()
+            h_in = np.ascontiguousarray(q)
         else:
             # filterbank seam: f32 spectra of matching magnitude (IQ * scalefactor of the same data)
-            x = np.sign(q) * np.abs(q.astype(np.float32)) ** (4.0 / 3.0) * 2.0 ** 12
-            d_in = torch.from_numpy(x.astype(np.float32)).cuda()
+            h_in = (np.sign(q) * np.abs(q.astype(np.float32)) ** (4.0 / 3.0) * 2.0 ** 12).astype(np.float32)
+        if b == 0:
+            host_in0 = h_in
         d_out = torch.empty(base["n_pcm"], dtype=torch.float32, device="cuda")
-        bufs.append((d_in, d_out))
+        bufs.append((torch.from_numpy(h_in).cuda(), d_out))
     # a dedicated (non-null) stream: kernels, warm-up and the timing events all live on it
     tstream = torch.cuda.Stream()
     torch.cuda.set_stream(tstream)
-    stream = tstream.cuda_stream
-    assert stream != 0
+    assert tstream.cuda_stream != 0
     tstreams = [tstream] + [torch.cuda.Stream() for _ in range(args.pipelines - 1)]
     meta_ptr = d_meta.data_ptr() if d_meta is not None else None
 
@@ -181,7 +226,7 @@ def main():
         pl = i % args.pipelines
         eng.decode_device(plans[pl], d_in.data_ptr(), meta_ptr, d_out.data_ptr(), tstreams[pl].cuda_stream)
 
-    # The GPU reaches its steady clocks only after tens of milliseconds of load: a 4096-frame step takes ~15 us,
+    # The GPU reaches its steady clocks only after tens of milliseconds of load: a 4096-frame step takes ~13 us,
     # so a few hundred warm-up steps are over before the clocks have ramped (measured: 15.9 us per step after 40
     # warm-up steps, 14.2 us after 4000).  Untimed preconditioning, reported in the JSON line; then the W warm-up
     # steps of the contract; the timed region is exactly K steps.
@@ -194,45 +239,49 @@ def main():
         torch.cuda.synchronize()
     for i in range(args.warmup):
         step(n_pre + i)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()
-    for i in range(args.steps):
-        step(n_pre + args.warmup + i)
-    t_issued = time.perf_counter() - t0                   # host time to enqueue the K launches
-    for extra in tstreams[1:]:
-        tstream.wait_stream(extra)                        # the closing event sees every pipeline
-    ev1.record()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    kernel_ms = ev0.elapsed_time(ev1) / args.steps          # HIP events on the launch stream
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    issued = [0.0]
 
-    # sanity: the last output is finite and non-trivial (never part of the timed region)
+    def timed_steps():
+        t0 = time.perf_counter()
+        ev0.record()
+        for i in range(args.steps):
+            step(n_pre + args.warmup + i)
+        issued[0] = time.perf_counter() - t0             # host time to enqueue the K launches
+        for extra in tstreams[1:]:
+            tstream.wait_stream(extra)                    # the closing event sees every pipeline
+        ev1.record()
+
+    dev = torch.device("cuda", device)
+    _, wall = aacgpu_shard.timed(dist, torch.cuda.synchronize, timed_steps, dev)      # barrier + synchronize on both sides, MAX over ranks
+    event_s = aacgpu_shard.reduce_max(dist, ev0.elapsed_time(ev1) * 1e-3, dev)        # the K steps on the launch stream, MAX over ranks
+    kernel_ms = ev0.elapsed_time(ev1) / args.steps
+
+    # untimed: the last output is finite and non-trivial; then the oracle comparison on the bench's own batch
     out = bufs[(n_pre + args.warmup + args.steps - 1) % args.nbuf][1]
     ok = bool(torch.isfinite(out).all().item()) and float(out.abs().max().item()) > 0
+    parity = None
+    if not args.no_parity:
+        err, rel, finite = parity_check(eng, plans[0], lambda: step(0), bufs, host_in0, base, units, tns, n_streams, n_chan, tstream)
+        gate_rel = 5e-6 if tns is None else 1e-5         # AACG_TNS_SPEC: DESIGN.md §3a
+        parity = {"rms": err, "rel": rel, "gate_rms": 1e-5, "gate_rel": gate_rel, "frames": n_streams * n_frames,
+                  "against": "oracle/aac_oracle.c on the whole batch after aacg_reset_stream on every stream"}
+        ok = ok and finite and err <= 1e-5 and rel <= gate_rel
 
     frames_per_step = n_streams * n_frames
-    value = world * frames_per_step * args.steps / elapsed
-    # cfg5: 7 channel-frames per frame instead of 2; cfg4: overlap state once per 128 frames
-    abytes = algorithmic_bytes_per_stereo_frame(args.input) * frames_per_step * (n_chan / 2.0)
+    value = world * frames_per_step * args.steps / event_s
+    abytes = algorithmic_bytes_per_channel_frame(args.input, n_frames) * frames_per_step * n_chan
     achieved = abytes / (kernel_ms * 1e-3) / 1e9
     traffic, traffic_src = measured_traffic(args.input) if args.workload == "cfg2" else (None, None)
+    unit = "stereo frames/s" if n_chan == 2 else "7-channel frames/s"
     line = {
         "metric": "AAC-LC 48 kHz stereo frames/sec per node + achieved HBM GB/s vs roofline",
-        "value": value, "unit": "stereo frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "value": value, "unit": unit, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": event_s / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "timing": "value and ms_per_step: HIP events around the K timed steps on the launch stream, MAX over ranks; "
+                  "wall_*: host clock between the barriers (adds first-launch latency and the wake-up after the last step)",
+        "wall_ms_per_step": wall / args.steps * 1e3, "value_wall": world * frames_per_step * args.steps / wall,
         "config": {"workload": {"cfg2": "BASELINE config 2: batch of 4096 stereo LC frames (256 streams x 16 frames, ONLY_LONG_SEQUENCE, KBD)",
                                 "cfg3": "BASELINE config 3: 4096 stereo frames, window-sequence mix [0,0,1,2,2,3,0,0], TNS identity",
                                 "cfg4": "BASELINE config 4 shape per GPU: 32 streams x 128 frames, config-3 mix",
@@ -243,17 +292,21 @@ def main():
                    "realtime_multiple": value / 46.875, "sharding": "streams over ranks, no data-path collective", "pipelines": args.pipelines,
                    "preconditioning": "%d untimed steps (%.0f ms of load) before the warm-up steps: steady GPU clocks" % (n_pre, args.precondition_ms),
                    "tns": "identity, as the reference executes it" if tns is None
-                          else "AACG_TNS_SPEC, every channel-frame: long one filter of order 12 over 20 bands, short one of order 7 per window"},
+                          else "AACG_TNS_SPEC, every channel-frame: long one filter of order 12 over 20 bands, short one of order 7 per window",
+                   "collectives": "none on the data path; %s barrier + 8-byte MAX around the timed region" % (dist.get_backend() if dist is not None else "no")},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                      "kernel": ("aacg_spectral_ex_%s + aacg_imdct_run_f32" % ("quant" if args.input == "quant" else "f32")) if tns is not None
                                else (eng.kernel_name() if args.input == "quant" else "aacg_imdct_run_f32"),
                      "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": abytes,
-                     "host_enqueue_us_per_step": t_issued / args.steps * 1e6},
-        "output_ok": ok,
+                     "host_enqueue_us_per_step": issued[0] / args.steps * 1e6},
+        "output_ok": ok, "parity_rms": parity["rms"] if parity else None, "parity": parity,
     }
     if rank == 0 and not args.no_cpu_baseline and world == 1:
-        line["cpu_baseline"] = cpu_baseline(args.input, mix)
+        line["cpu_baseline"] = cpu_baseline(args.input, mix, layout, n_chan)
+        line["cpu_baseline"]["unit"] = line["cpu_baseline"]["single_core"]["unit"] = unit
+        if "js_port" in line["cpu_baseline"] and "unit" in line["cpu_baseline"]["js_port"]:
+            line["cpu_baseline"]["js_port"]["unit"] = unit
     elif rank == 0:
         line["cpu_baseline"] = None
     if rank == 0:
@@ -262,7 +315,10 @@ def main():
         pl.destroy()
     eng.close()
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
+    if not ok:
+        raise SystemExit("bench.py: output check failed (finite=%s, parity=%s)" % (ok, parity))
 
 
 if __name__ == "__main__":

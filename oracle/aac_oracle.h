@@ -95,6 +95,12 @@ int orc_decode_batch_tns(int sample_index, int input_kind, int max_streams, int 
                          const aacg_tns_info* tns, int tns_mode,
                          float* pcm_out, float* overlaps, float* spec_out);
 
+/* orc_bench.c: the CPU baseline's timing loop — n_threads workers, each decoding its own copy of the batch (its own
+ * stream set) for ~seconds; returns whole batches decoded (< 0: error), *elapsed = the longest worker's time. */
+long long orc_bench_threads(int n_threads, double seconds, int sample_index, int input_kind, int max_streams, int max_channels,
+                            const aacg_unit_desc* units, uint32_t n_units, const void* coeffs, size_t coeff_bytes,
+                            const aacg_band_meta* meta, size_t n_meta, size_t n_pcm_floats, double* elapsed);
+
 #ifdef __cplusplus
 }
 #endif

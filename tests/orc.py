@@ -53,6 +53,9 @@ class Oracle:
         L.orc_decode_batch_ex.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_uint32,
                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_tns_spec.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_bench_threads.restype = C.c_longlong
+        L.orc_bench_threads.argtypes = [C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t,
+                                        C.c_void_p, C.c_size_t, C.c_size_t, C.POINTER(C.c_double)]
         L.orc_init()
 
     def table_f32(self, which):
@@ -104,6 +107,20 @@ class Oracle:
         if rc != 0:
             raise RuntimeError("orc_tns_spec failed: %d" % rc)
         return out
+
+    def bench_threads(self, n_threads, seconds, units, coeffs, meta, n_pcm_floats, max_streams, max_channels, sample_index=3):
+        """CPU-baseline timing loop (oracle/orc_bench.c): returns (whole batches decoded by all threads, longest thread's seconds)."""
+        units, coeffs = np.ascontiguousarray(units), np.ascontiguousarray(coeffs)
+        kind = 1 if coeffs.dtype == np.int16 else 0
+        if meta is not None:
+            meta = np.ascontiguousarray(meta, np.uint16)
+        dt = C.c_double()
+        n = self.lib.orc_bench_threads(n_threads, seconds, sample_index, kind, max_streams, max_channels, units.ctypes.data, len(units),
+                                       coeffs.ctypes.data, coeffs.nbytes, meta.ctypes.data if meta is not None else None,
+                                       meta.size // 120 if meta is not None else 0, n_pcm_floats, C.byref(dt))
+        if n < 0:
+            raise RuntimeError("orc_bench_threads failed: %d" % n)
+        return int(n), float(dt.value)
 
     def decode_batch(self, units, coeffs, meta, n_pcm_floats, overlaps, sample_index=3, want_spec=False, tns=None, pns=False):
         """overlaps: float32 [max_streams, max_channels, 1024], updated in place.  tns: TNS_DTYPE array -> AACG_TNS_SPEC."""

@@ -1,64 +1,71 @@
-"""Multi-GPU sharding logic on CPU: world_size-2 gloo.  The path has no data-path collective (streams are
-sharded over ranks); the only collectives are the harness's barrier and MAX of elapsed time, exercised here
-together with the property that makes sharding valid: a rank's streams decode identically alone or together."""
+"""Multi-GPU sharding harness on CPU (aac.js_amd/python/aacgpu_shard.py): world_size-2 gloo.
+
+The path has no data-path collective (streams are sharded over ranks); the only collectives are the harness's
+barrier, the MAX of the elapsed time and a SUM of counters.  Checked here, without a GPU: the shard arithmetic, the
+launch line, that `self_launch` really starts N ranks as a child process and relays their exit code, and — with the
+oracle standing in for a device (tests/shard_rank.py --decoder oracle) — the property that makes sharding valid: a
+rank's streams decode identically alone or next to the others.  The same program runs the HIP engine per rank in the
+-m gpu test (tests/test_gpu_parity.py::test_two_ranks_share_a_gpu)."""
+import json
 import os
-import socket
 import sys
 
 import numpy as np
-import torch
-import torch.distributed as dist
-import torch.multiprocessing as mp
+import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "aac.js_amd", "python"))
+import aacgpu_shard  # noqa: E402
 
 
-def _worker(rank, world, port, out):
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    sys.path.insert(0, os.path.join(ROOT, "aac.js_amd", "python"))
+def test_stream_shard_covers_every_stream_once():
+    for total in (0, 1, 7, 32, 256, 257):
+        for world in (1, 2, 3, 8):
+            blocks = [aacgpu_shard.stream_shard(total, r, world) for r in range(world)]
+            assert blocks[0][0] == 0 and blocks[-1][1] == total
+            assert all(a[1] == b[0] for a, b in zip(blocks, blocks[1:]))
+            sizes = [hi - lo for lo, hi in blocks]
+            assert max(sizes) - min(sizes) <= 1
+    assert aacgpu_shard.stream_shard(256, 3, 8) == (96, 128)          # BASELINE config 4: streams [32r, 32r + 32)
+    with pytest.raises(ValueError):
+        aacgpu_shard.stream_shard(8, 2, 2)
+    assert len({aacgpu_shard.rank_seed(0xAAC00002, r) for r in range(8)}) == 8
+
+
+def test_launch_command_is_the_drivers_line():
+    cmd = aacgpu_shard.launch_command(4, "bench.py", ["--gpus", "4", "--steps", "20"], port=29533, python="python")
+    assert cmd == ["python", "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1",
+                   "--master-port", "29533", "bench.py", "--gpus", "4", "--steps", "20"]
+    assert not aacgpu_shard.launched_by_torchrun({})
+    assert aacgpu_shard.launched_by_torchrun({"RANK": "0", "WORLD_SIZE": "2"})
+
+
+def test_bench_refuses_to_run_without_a_gpu():
+    """bench.py --gpus 2 here (no GPU): it must start two ranks by itself and each must fail loudly — no CPU fallback."""
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--dist-backend", "gloo"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0
+    assert "bench.py needs a GPU" in r.stdout + r.stderr
+
+
+def test_two_ranks_self_launched(tmp_path, oracle):
+    out = str(tmp_path)
+    S, T = 5, 6
+    rc = aacgpu_shard.self_launch(2, os.path.join(ROOT, "tests", "shard_rank.py"),
+                                  ["--out", out, "--streams", str(S), "--frames", str(T), "--decoder", "oracle"], timeout=600)
+    assert rc == 0
+    summary = json.load(open(os.path.join(out, "summary.json")))
+    assert summary["world"] == 2 and summary["frames"] == S * T and summary["t_max"] >= summary["t_rank0"] > 0
     import aacgpu_workload
-    import orc
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    S, T = 2, 5
-    # rank r owns streams [S r, S r + S): same seeding rule as bench.py
-    wl = aacgpu_workload.make_batch(n_streams=S, n_frames=T, mix=True, seed=0xAAC00002 + 1000 * rank)
+    wl = aacgpu_workload.make_batch(n_streams=S, n_frames=T, mix=True, intensity=True, seed=0xAAC00004)
     ov = np.zeros((S, 2, 1024), np.float32)
-    pcm = orc.load().decode_batch(wl["units"], wl["q"], wl["meta"], wl["n_pcm"], ov)
-    dist.barrier()
-    t = torch.tensor([0.001 * (rank + 1)], dtype=torch.float64)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)                       # bench.py's max-over-ranks
-    frames = torch.tensor([wl["n_frames_total"]], dtype=torch.int64)
-    dist.all_reduce(frames)                                          # whole-job count
-    csum = torch.tensor([float(np.abs(pcm).sum())], dtype=torch.float64)
-    gathered = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
-    dist.all_gather(gathered, csum)
-    if rank == 0:
-        out.put((float(t.item()), int(frames.item()), [float(g.item()) for g in gathered]))
-    dist.destroy_process_group()
+    whole = oracle.decode_batch(wl["units"], wl["q"], wl["meta"], wl["n_pcm"], ov)
+    parts = np.concatenate([np.fromfile(os.path.join(out, "pcm_rank%d.f32" % r), np.float32) for r in range(2)])
+    assert parts.size == whole.size and np.array_equal(parts.view(np.uint32), whole.view(np.uint32))
 
 
-def test_two_rank_sharding():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    ctx = mp.get_context("spawn")
-    out = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, out)) for r in range(2)]
-    for p in procs:
-        p.start()
-    tmax, frames, sums = out.get(timeout=120)
-    for p in procs:
-        p.join(60)
-        assert p.exitcode == 0
-    assert abs(tmax - 0.002) < 1e-12 and frames == 2 * 2 * 5
-    # each rank's checksum equals decoding that rank's streams alone in this process (no cross-stream coupling)
-    sys.path.insert(0, os.path.join(ROOT, "aac.js_amd", "python"))
-    import aacgpu_workload
-    import orc
-    for r in range(2):
-        wl = aacgpu_workload.make_batch(n_streams=2, n_frames=5, mix=True, seed=0xAAC00002 + 1000 * r)
-        ov = np.zeros((2, 2, 1024), np.float32)
-        pcm = orc.load().decode_batch(wl["units"], wl["q"], wl["meta"], wl["n_pcm"], ov)
-        assert abs(float(np.abs(pcm).sum()) - sums[r]) < 1e-6 * max(1.0, sums[r])
+def test_self_launch_relays_the_exit_code(tmp_path):
+    script = tmp_path / "fail.py"
+    script.write_text("import os, sys\nsys.exit(3 if os.environ['RANK'] == '1' else 0)\n")
+    assert aacgpu_shard.self_launch(2, str(script), [], timeout=300) != 0

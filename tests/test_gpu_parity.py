@@ -500,3 +500,78 @@ def test_other_sample_rates(oracle, sample_index, max_long):
     rms(pcm, ref)
     assert np.abs(overlaps(eng, S, C) - ov).max() < 1e-5 * max(1.0, float(np.abs(ov).max()))
     eng.close()
+
+
+# ---- the exact bench workload, and the multi-process path ------------------------------------------------
+def test_bench_workload_vs_oracle(oracle):
+    """bench.py's own step — BASELINE config 2: 256 streams x 16 ONLY_LONG stereo frames, KBD, int16 seam, one launch of a
+    plan on device-resident buffers — against the oracle: 16 sampled streams at full precision (the oracle decodes
+    exactly those streams' units alone), and the remaining 240 through split invariance: they are bit-identical whether
+    decoded in the 4096-frame launch or in a launch of their own."""
+    torch = _torch()
+    S, T = 256, 16
+    wl = aacgpu_workload.make_batch(n_streams=S, n_frames=T, mix=False, seed=0xAAC00002)
+    eng = aacgpu.Engine(aacgpu.INPUT_QUANT_I16, max_streams=S, max_channels=2)
+    plan = eng.plan(wl["units"])
+    d_q, d_meta = torch.from_numpy(wl["q"]).cuda(), torch.from_numpy(wl["meta"].view(np.int16)).cuda()
+    d_pcm = torch.full((wl["n_pcm"],), float("nan"), dtype=torch.float32, device="cuda")
+    stream = torch.cuda.Stream()
+    eng.decode_device(plan, d_q.data_ptr(), d_meta.data_ptr(), d_pcm.data_ptr(), stream.cuda_stream)
+    stream.synchronize()
+    pcm = d_pcm.cpu().numpy().reshape(S, T * 2048)
+    assert np.isfinite(pcm).all()
+    sampled = list(range(0, S, 16))
+    units = wl["units"]
+    for s in sampled:
+        ov = np.zeros((S, 2, 1024), np.float32)
+        ref = oracle.decode_batch(units[units["stream"] == s], wl["q"], wl["meta"], wl["n_pcm"], ov).reshape(S, T * 2048)[s]
+        assert rms(pcm[s], ref) < RMS_TOL
+        assert np.abs(eng.get_overlap(s, 0) - ov[s, 0]).max() <= 1e-5 * max(1.0, float(np.abs(ov[s, 0]).max()))
+    plan.destroy()
+    rest = units[~np.isin(units["stream"], sampled)]
+    eng2 = aacgpu.Engine(aacgpu.INPUT_QUANT_I16, max_streams=S, max_channels=2)
+    alone = eng2.decode_batch(rest, wl["q"], wl["meta"], wl["n_pcm"]).reshape(S, T * 2048)
+    others = [s for s in range(S) if s not in sampled]
+    assert np.array_equal(alone[others].view(np.uint32), pcm[others].view(np.uint32))
+    eng.close()
+    eng2.close()
+
+
+def test_two_ranks_share_a_gpu(tmp_path):
+    """The sharded path with the product in it: two rank processes (torch.distributed.run, gloo for the barrier), each with
+    its own aacgpu.Engine on cuda:0 for its stream shard; their PCM, concatenated, is bit-identical to one process decoding
+    every stream (SURVEY.md §4 'multi-GPU' row; on an 8-GPU node the same ranks sit on 8 devices)."""
+    import json
+    import os
+    import aacgpu_shard
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path)
+    S, T = 6, 20
+    rc = aacgpu_shard.self_launch(2, os.path.join(root, "tests", "shard_rank.py"),
+                                  ["--out", out, "--streams", str(S), "--frames", str(T), "--decoder", "engine"], timeout=900)
+    assert rc == 0
+    summary = json.load(open(os.path.join(out, "summary.json")))
+    assert summary["world"] == 2 and summary["frames"] == S * T
+    wl = aacgpu_workload.make_batch(n_streams=S, n_frames=T, mix=True, intensity=True, seed=0xAAC00004)
+    eng = aacgpu.Engine(aacgpu.INPUT_QUANT_I16, max_streams=S, max_channels=2)
+    whole = eng.decode_batch(wl["units"], wl["q"], wl["meta"], wl["n_pcm"])
+    eng.close()
+    parts = np.concatenate([np.fromfile(os.path.join(out, "pcm_rank%d.f32" % r), np.float32) for r in range(2)])
+    assert parts.size == whole.size and np.array_equal(parts.view(np.uint32), whole.view(np.uint32))
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` without a launcher starts two ranks itself (before touching the GPU) and rank 0 prints the
+    JSON line with n_gpus 2.  The box has one GPU, so the ranks share it (--share-gpu, gloo barrier): this checks the launch
+    path and the whole-job arithmetic, not scaling."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--precondition-ms", "20",
+                        "--dist-backend", "gloo", "--share-gpu"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["steps"] == 20 and line["output_ok"] and line["parity_rms"] < 1e-5
+    assert abs(line["value"] - 2 * 4096 / (line["ms_per_step"] * 1e-3)) < 1e-6 * line["value"]
