@@ -79,6 +79,8 @@ struct aacg_parser {
     /* device staging of aacg_parse_batch, grown on demand */
     uint32_t* d_order = nullptr;      /* lane order + the bucket counters behind it */
     size_t order_cap = 0;
+    hipEvent_t order_free = nullptr;  /* recorded behind every launch: the scratch above may be rewritten after it */
+    hipStream_t last_stream = nullptr;
     void* d_buf[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     size_t cap[7] = {0, 0, 0, 0, 0, 0, 0};
     std::string err;
@@ -112,6 +114,11 @@ int launch(aacg_parser* p, aacg_parse_params& P, hipStream_t s)
     if (!(P.options & AACG_PARSE_SKIP_ZERO_FILL)) HIPCHECK(hipMemsetAsync(P.q, 0, (size_t)P.n_frames * P.max_channels * 1024u * sizeof(int16_t), s));
     HIPCHECK(hipMemsetAsync(P.meta, 0, (size_t)P.n_frames * P.max_channels * sizeof(aacg_band_meta), s));
     if (P.tns) HIPCHECK(hipMemsetAsync(P.tns, 0, (size_t)P.n_frames * P.max_channels * sizeof(aacg_tns_info), s));
+    /* unit records of refused frames and of element slots beyond a frame's count stay zero (never stale memory) */
+    HIPCHECK(hipMemsetAsync(P.units, 0, (size_t)P.n_frames * P.max_units * sizeof(aacg_unit_desc), s));
+    /* The lane-order scratch belongs to the parser, not to the launch: a launch on another stream first waits for the
+     * previous launch's kernels (same stream: ordered anyway).  Two streams may therefore alternate on one parser. */
+    if (p->last_stream && p->last_stream != s) HIPCHECK(hipStreamWaitEvent(s, p->order_free, 0));
     /* Frames of similar length into the same wave, and long and short waves onto every CU alike (AACG_PARSE_SORT=0: table
      * order).  Measured with frame lengths spread 44..1186 bytes: 16 k frames 1.40 -> 0.89 ms, 64 k 1.36 -> 0.94. */
     static const bool sort_enabled = [] { const char* v = std::getenv("AACG_PARSE_SORT"); return !(v && v[0] == '0'); }();
@@ -136,6 +143,8 @@ int launch(aacg_parser* p, aacg_parse_params& P, hipStream_t s)
     }
     hipLaunchKernelGGL(aacg_parse_frames, dim3(grid), dim3(P.wg_threads), p->lds_bytes, s, P);
     HIPCHECK(hipGetLastError());
+    HIPCHECK(hipEventRecord(p->order_free, s));
+    p->last_stream = s;
     return AACG_OK;
 }
 
@@ -172,6 +181,7 @@ int aacg_parser_create(int device_ordinal, int sample_index, const aacg_code_ent
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device_ordinal) == hipSuccess && prop.multiProcessorCount > 0) p->n_cus = prop.multiProcessorCount;
         if (hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&p->order_free, hipEventDisableTiming) != hipSuccess ||
             hipMalloc((void**)&p->d_tab, sizeof(aacg_parse_tables)) != hipSuccess ||
             hipMemcpy(p->d_tab, tab.data(), sizeof(aacg_parse_tables), hipMemcpyHostToDevice) != hipSuccess ||
             hipFuncSetAttribute((const void*)aacg_parse_frames, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_bytes) != hipSuccess)
@@ -185,6 +195,9 @@ int aacg_parser_create(int device_ordinal, int sample_index, const aacg_code_ent
 void aacg_parser_destroy(aacg_parser* p)
 {
     if (!p) return;
+    (void)hipSetDevice(p->device);
+    (void)hipDeviceSynchronize();
+    if (p->order_free) (void)hipEventDestroy(p->order_free);
     if (p->d_order) (void)hipFree(p->d_order);
     for (int i = 0; i < 7; i++) if (p->d_buf[i]) (void)hipFree(p->d_buf[i]);
     if (p->d_tab) (void)hipFree(p->d_tab);
@@ -229,7 +242,6 @@ int aacg_parse_batch(aacg_parser* p, const uint8_t* bytes, size_t n_bytes, const
     HIPCHECK(hipMemsetAsync((char*)p->d_buf[0] + padded - tail, 0, tail, s));
     HIPCHECK(hipMemcpyAsync(p->d_buf[0], bytes, n_bytes, hipMemcpyHostToDevice, s));
     HIPCHECK(hipMemcpyAsync(p->d_buf[1], frames, sizes[1], hipMemcpyHostToDevice, s));
-    HIPCHECK(hipMemsetAsync(p->d_buf[2], 0, sizes[2], s));
     aacg_parse_params P;
     P.bytes = (const uint32_t*)p->d_buf[0]; P.frames = (const aacg_parse_frame*)p->d_buf[1]; P.tab = p->d_tab;
     P.units = (aacg_unit_desc*)p->d_buf[2]; P.q = (int16_t*)p->d_buf[3]; P.meta = (aacg_band_meta*)p->d_buf[4];

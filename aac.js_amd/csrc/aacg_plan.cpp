@@ -200,9 +200,13 @@ int aacg_plan_build(const aacg_unit_desc* units, uint32_t n_units, int sample_in
         }
         out->units.push_back(du);
 
+        /* extents in 64 bits: an offset near UINT32_MAX (the records come straight from a caller's byte array) must not
+         * wrap to a small extent and pass the bounds checks */
+        if (u.coef_offset > UINT32_MAX - 2u || u.meta_offset > UINT32_MAX - 2u || (uint64_t)u.pcm_offset + 1024u * (uint64_t)u.n_out_ch > UINT32_MAX)
+            return fail(err, AACG_ERR_INVALID_ARG, "unit %ld: coefficient / meta / pcm offset out of range", i, 0);
         out->coef_blocks = std::max(out->coef_blocks, u.coef_offset + u.n_ch);
         out->meta_blocks = std::max(out->meta_blocks, u.meta_offset + u.n_ch);
-        out->pcm_floats = std::max(out->pcm_floats, (size_t)u.pcm_offset + 1024u * u.n_out_ch);
+        out->pcm_floats = std::max(out->pcm_floats, (size_t)((uint64_t)u.pcm_offset + 1024u * (uint64_t)u.n_out_ch));
     }
     for (auto& s : st) close_frame(s);
     /* every chain must reach its stream's last frame, or a later batch would chain onto a stale tail */

@@ -243,15 +243,22 @@ GpuAACDecoder.prototype.setCookie = function (buffer) {
 GpuAACDecoder.prototype.unitsOfFrame = function (frame, frameSlot, blockBase, tnsList) {
     const C = this.config.chanConfig, units = [];
     let channel = 0, block = blockBase;
+    /* everything that can refuse the frame comes first: a frame that throws leaves no trace in the decoder's state */
+    for (const e of frame.elements) {
+        if (channel >= C) break;
+        if (e.gainPresent) throw new Error('Gain control not implemented');
+        if (e.hasPns && this.pnsMode !== PNS_SPEC) throw new Error('aacgpu: NOISE_BT (PNS) band: not decodable by the reference either (pnsMode: PNS_SPEC fills them)');
+        for (const ch of e.ch) if (ch.pulse && !this.applyPulses) throw new Error('TODO: add pulse data');
+        channel += e.type === 'cpe' ? 2 : 1;
+    }
+    channel = 0;
     for (const e of frame.elements) {
         const n = e.type === 'cpe' ? 2 : 1;
         if (channel >= C) break;
-        if (e.gainPresent) throw new Error('Gain control not implemented');
         for (let c = 0; c < n; c++) {
             e.ch[c].windowShapePrev = this.carryWindowShape ? (this.prevShape[channel + c] | 0) : 0;
             this.prevShape[channel + c] = e.ch[c].windowShape;
             if (e.ch[c].pulse) {
-                if (!this.applyPulses) throw new Error('TODO: add pulse data');
                 applyPulses(frame.q.subarray(FRAME * (block - blockBase + c), FRAME * (block - blockBase + c + 1)), e.ch[c].pulse.offset, e.ch[c].pulse.amp);
             }
         }
@@ -270,32 +277,42 @@ GpuAACDecoder.prototype.unitsOfFrame = function (frame, frameSlot, blockBase, tn
     return units;
 };
 
+/* The queue holds, in stream order, the PCM of frames decoded ahead and — as an Error — a frame the look-ahead found
+ * malformed: it is thrown by the readChunk call that reaches it, after the good frames before it have been returned,
+ * which is what a caller of the reference sees frame by frame (decoder.js:125-201 throws at exactly that frame). */
 GpuAACDecoder.prototype.readChunk = function () {
-    if (this.queue.length) return this.queue.shift();
+    if (!this.queue.length) this.decodeAhead();
+    if (!this.queue.length) return null;
+    const next = this.queue.shift();
+    if (next instanceof Error) throw next;
+    return next;
+};
+
+GpuAACDecoder.prototype.decodeAhead = function () {
     if (this.config.profile === 1) throw new Error('Main prediction unimplemented');
     if (this.config.profile === 4) throw new Error('LTP prediction unimplemented');
-    const C = this.config.chanConfig, frames = [];
+    const C = this.config.chanConfig, frames = [], tnsList = this.tnsMode === TNS_SPEC ? [] : null;
+    let units = [], block = 0, failed = null;
     while (frames.length < this.lookahead) {
-        let f = null;
-        try { f = this.frontend.parseFrame(this); } catch (err) { if (!frames.length) throw err; break; }   // underflow ends look-ahead
-        if (!f) break;
-        frames.push(f);
+        /* both front ends have consumed a frame by the time they throw for it, and return null on underflow: an
+         * exception here is a malformed (or unsupported) frame, kept in order behind the frames parsed so far */
+        try {
+            const f = this.frontend.parseFrame(this);
+            if (!f) break;
+            units = units.concat(this.unitsOfFrame(f, frames.length, block, tnsList));
+            block += f.q.length / FRAME;
+            frames.push(f);
+        } catch (err) { failed = err instanceof Error ? err : new Error(String(err)); break; }
     }
-    if (!frames.length) return null;
-    let nBlocks = 0;
-    for (const f of frames) nBlocks += f.q.length / FRAME;
-    const q = new Int16Array(nBlocks * FRAME), meta = new Uint16Array(nBlocks * META_WORDS);
-    let units = [], block = 0;
-    const tnsList = this.tnsMode === TNS_SPEC ? [] : null;
-    frames.forEach((f, slot) => {
-        units = units.concat(this.unitsOfFrame(f, slot, block, tnsList));
-        q.set(f.q, block * FRAME); meta.set(f.meta, block * META_WORDS);
-        block += f.q.length / FRAME;
-    });
-    const pcm = new Float32Array(frames.length * FRAME * C);
-    this.engine.decodeBatch(packUnits(units), q, meta, pcm, tnsList && tnsList.length ? packTns(tnsList) : null);
-    for (let i = 0; i < frames.length; i++) this.queue.push(pcm.slice(i * FRAME * C, (i + 1) * FRAME * C));   // caller owns each array
-    return this.queue.shift();
+    if (frames.length) {
+        const q = new Int16Array(block * FRAME), meta = new Uint16Array(block * META_WORDS);
+        let b = 0;
+        for (const f of frames) { q.set(f.q, b * FRAME); meta.set(f.meta, b * META_WORDS); b += f.q.length / FRAME; }
+        const pcm = new Float32Array(frames.length * FRAME * C);
+        this.engine.decodeBatch(packUnits(units), q, meta, pcm, tnsList && tnsList.length ? packTns(tnsList) : null);
+        for (let i = 0; i < frames.length; i++) this.queue.push(pcm.slice(i * FRAME * C, (i + 1) * FRAME * C));   // caller owns each array
+    }
+    if (failed) this.queue.push(failed);
 };
 
 /* bytes from the demuxer ('data' events of AdtsDemuxer / an MP4 demuxer's samples) to the front end */

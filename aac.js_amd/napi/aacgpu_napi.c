@@ -10,6 +10,7 @@
 #include <node_api.h>
 
 #include <dlfcn.h>
+#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -82,10 +83,39 @@ static int get_i32(napi_env env, napi_value obj, const char* key, int32_t dflt)
     return out;
 }
 
+/* What an external points to: the native object behind a tag that says which kind it is (a parser handle passed where an
+ * engine is expected is refused instead of being cast), and a lock: an aacg_engine is not re-entrant (include/aacgpu.h:
+ * externally serialised), so synchronous calls and the async jobs of one engine — which run on libuv threads — take
+ * turns.  Jobs keep a reference on the external, so a collected Engine object cannot be finalised under a running job. */
+#define BOX_ENGINE 0x41454e47u   /* 'AENG' */
+#define BOX_PARSER 0x41505253u   /* 'APRS' */
+typedef struct { uint32_t kind; void* ptr; pthread_mutex_t lock; } handle_box;
+
+static handle_box* box_new(uint32_t kind, void* ptr)
+{
+    handle_box* b = (handle_box*)calloc(1, sizeof *b);
+    if (!b) return NULL;
+    b->kind = kind; b->ptr = ptr;
+    pthread_mutex_init(&b->lock, NULL);
+    return b;
+}
+
+static handle_box* box_of(napi_env env, napi_value v, uint32_t kind, const char* what)
+{
+    void* p = NULL;
+    if (napi_get_value_external(env, v, &p) != napi_ok || !p || ((handle_box*)p)->kind != kind) { napi_throw_error(env, NULL, what); return NULL; }
+    return (handle_box*)p;
+}
+
 static void engine_finalize(napi_env env, void* data, void* hint)
 {
     (void)env; (void)hint;
-    if (data && L.destroy) L.destroy((aacg_engine*)data);
+    handle_box* b = (handle_box*)data;
+    if (!b) return;
+    if (b->ptr && L.destroy) L.destroy((aacg_engine*)b->ptr);
+    b->kind = 0;
+    pthread_mutex_destroy(&b->lock);
+    free(b);
 }
 
 /* load(path) -> abi version */
@@ -119,15 +149,22 @@ static napi_value js_create(napi_env env, napi_callback_info info)
     aacg_engine* e = NULL;
     int rc = L.create(&cfg, &e);
     if (rc) return fail(env, NULL, rc, "aacg_create (is a GPU visible?)");
-    CHECK(env, napi_create_external(env, e, engine_finalize, NULL, &out));
+    handle_box* b = box_new(BOX_ENGINE, e);
+    if (!b) { L.destroy(e); napi_throw_error(env, NULL, "aacgpu: out of memory"); return NULL; }
+    CHECK(env, napi_create_external(env, b, engine_finalize, NULL, &out));
     return out;
 }
 
+static handle_box* engine_box(napi_env env, napi_value v) { return box_of(env, v, BOX_ENGINE, "aacgpu: bad engine handle"); }
+/* for the synchronous entry points: waits for a running async job of the same engine (the JS wrapper awaits its
+ * jobs anyway; this is the backstop) */
 static aacg_engine* engine_of(napi_env env, napi_value v)
 {
-    void* p = NULL;
-    if (napi_get_value_external(env, v, &p) != napi_ok || !p) { napi_throw_error(env, NULL, "aacgpu: bad engine handle"); return NULL; }
-    return (aacg_engine*)p;
+    handle_box* b = engine_box(env, v);
+    if (!b) return NULL;
+    pthread_mutex_lock(&b->lock);
+    pthread_mutex_unlock(&b->lock);
+    return (aacg_engine*)b->ptr;
 }
 
 static int typed(napi_env env, napi_value v, napi_typedarray_type* type, size_t* len, void** data)
@@ -219,7 +256,8 @@ static napi_value js_set_overlap(napi_env env, napi_callback_info info) { return
 typedef struct {
     napi_async_work work;
     napi_deferred deferred;
-    napi_ref refs[5];            /* units, coeffs, meta, pcm, tns stay alive until completion */
+    napi_ref refs[6];            /* units, coeffs, meta, pcm, tns and the engine handle stay alive until completion */
+    handle_box* box;
     const aacg_tns_info* tns; uint32_t n_tns;
     aacg_engine* e;
     const aacg_unit_desc* units; uint32_t n_units;
@@ -235,10 +273,12 @@ static void job_execute(napi_env env, void* data)
     (void)env;
     async_job* j = (async_job*)data;
     uint64_t t = 0;
+    pthread_mutex_lock(&j->box->lock);             /* jobs of one engine run one at a time, whatever thread they land on */
     j->rc = L.submit_tns(j->e, j->units, j->n_units, j->coeffs, j->n_blocks, j->meta, j->n_meta, j->tns, j->n_tns,
                          j->pcm, j->n_pcm, &t);
     if (!j->rc) j->rc = L.wait(j->e, t);
     if (j->rc) snprintf(j->err, sizeof j->err, "aacgpu: decodeBatchAsync failed (%d): %.400s", j->rc, L.last_error(j->e));
+    pthread_mutex_unlock(&j->box->lock);
 }
 
 static void job_complete(napi_env env, napi_status status, void* data)
@@ -254,7 +294,7 @@ static void job_complete(napi_env env, napi_status status, void* data)
         napi_create_error(env, NULL, msg, &v);
         napi_reject_deferred(env, j->deferred, v);
     }
-    for (int i = 0; i < 5; i++) if (j->refs[i]) napi_delete_reference(env, j->refs[i]);
+    for (int i = 0; i < 6; i++) if (j->refs[i]) napi_delete_reference(env, j->refs[i]);
     napi_delete_async_work(env, j->work);
     free(j);
 }
@@ -265,8 +305,9 @@ static napi_value js_decode_batch_async(napi_env env, napi_callback_info info)
     CHECK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
     void* dt; size_t nt;
     if (!optional_tns(env, argc, argv, 5, &dt, &nt)) return NULL;
-    aacg_engine* e = engine_of(env, argv[0]);
-    if (!e) return NULL;
+    handle_box* box = engine_box(env, argv[0]);
+    if (!box) return NULL;
+    aacg_engine* e = (aacg_engine*)box->ptr;
     napi_typedarray_type tu, tc, tm, tp; size_t nu, nc, nm = 0, np; void *du, *dc, *dm = NULL, *dp;
     napi_valuetype vt;
     if (!typed(env, argv[1], &tu, &nu, &du) || tu != napi_uint8_array || nu % sizeof(aacg_unit_desc) ||
@@ -283,7 +324,8 @@ static napi_value js_decode_batch_async(napi_env env, napi_callback_info info)
     }
     async_job* j = (async_job*)calloc(1, sizeof *j);
     if (!j) { napi_throw_error(env, NULL, "aacgpu: out of memory"); return NULL; }
-    j->e = e; j->units = (const aacg_unit_desc*)du; j->n_units = (uint32_t)(nu / sizeof(aacg_unit_desc));
+    j->e = e; j->box = box; j->units = (const aacg_unit_desc*)du;
+    napi_create_reference(env, argv[0], 1, &j->refs[5]); j->n_units = (uint32_t)(nu / sizeof(aacg_unit_desc));
     j->coeffs = dc; j->n_blocks = (uint32_t)(nc / 1024); j->meta = (const aacg_band_meta*)dm; j->n_meta = (uint32_t)(nm / AACG_MAX_SECTIONS);
     j->pcm = (float*)dp; j->n_pcm = np;
     j->tns = (const aacg_tns_info*)dt; j->n_tns = (uint32_t)nt;
@@ -302,7 +344,12 @@ static napi_value js_decode_batch_async(napi_env env, napi_callback_info info)
 static void parser_finalize(napi_env env, void* data, void* hint)
 {
     (void)env; (void)hint;
-    if (data && L.parser_destroy) L.parser_destroy((aacg_parser*)data);
+    handle_box* b = (handle_box*)data;
+    if (!b) return;
+    if (b->ptr && L.parser_destroy) L.parser_destroy((aacg_parser*)b->ptr);
+    b->kind = 0;
+    pthread_mutex_destroy(&b->lock);
+    free(b);
 }
 
 /* parserCreate({deviceOrdinal, sampleIndex}, entries:Uint8Array(12*n) of aacg_code_entry, counts:Uint32Array(12)) -> external */
@@ -328,7 +375,9 @@ static napi_value js_parser_create(napi_env env, napi_callback_info info)
         napi_throw_error(env, NULL, msg);
         return NULL;
     }
-    CHECK(env, napi_create_external(env, p, parser_finalize, NULL, &out));
+    handle_box* b = box_new(BOX_PARSER, p);
+    if (!b) { L.parser_destroy(p); napi_throw_error(env, NULL, "aacgpu: out of memory"); return NULL; }
+    CHECK(env, napi_create_external(env, b, parser_finalize, NULL, &out));
     return out;
 }
 
@@ -339,9 +388,10 @@ static napi_value js_parse_batch(napi_env env, napi_callback_info info)
 {
     size_t argc = 11; napi_value argv[11];
     CHECK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
-    void* pv = NULL;
-    if (argc < 11 || napi_get_value_external(env, argv[0], &pv) != napi_ok || !pv) { napi_throw_error(env, NULL, "aacgpu: bad parser handle"); return NULL; }
-    aacg_parser* p = (aacg_parser*)pv;
+    handle_box* pb = argc < 11 ? NULL : box_of(env, argv[0], BOX_PARSER, "aacgpu: bad parser handle");
+    if (argc < 11) napi_throw_error(env, NULL, "aacgpu: parseBatch takes 11 arguments");
+    if (!pb) return NULL;
+    aacg_parser* p = (aacg_parser*)pb->ptr;
     napi_typedarray_type t; size_t nb, nf, nu, nq, nm, nr; void *db, *df, *du, *dq, *dm, *dr, *dt; size_t nt;
     uint32_t max_units = 0, max_ch = 0, options = 0;
     napi_get_value_uint32(env, argv[3], &max_units); napi_get_value_uint32(env, argv[4], &max_ch); napi_get_value_uint32(env, argv[5], &options);

@@ -339,7 +339,8 @@ enum {                         /* aacg_parse_result.status; the reference's mess
 #define AACG_PARSE_HAS_PNS 0x1
 #define AACG_PARSE_HAS_TNS 0x2
 typedef struct aacg_parse_result {
-    uint8_t  status;           /* AACG_PARSE_*; a failed frame's output records are unspecified    */
+    uint8_t  status;           /* AACG_PARSE_*; a failed frame's output records are unspecified
+                                  (partially written; never uninitialised memory)                  */
     uint8_t  n_units;          /* SCE/LFE/CPE elements found = records written for this frame      */
     uint8_t  n_channels;
     uint8_t  flags;            /* AACG_PARSE_HAS_*                                                 */
@@ -362,7 +363,9 @@ const char* aacg_parse_status_string(int status);
  *
  * aacg_parse_batch: host pointers, returns when the results are there.
  * aacg_parse_device: DEVICE pointers, asynchronous on hip_stream; d_bytes 16-byte aligned with >= 32 readable
- * bytes after the last frame; zero-fills d_q, d_meta (and d_tns) itself.                                        */
+ * bytes after the last frame; zero-fills d_units, d_q, d_meta (and d_tns) itself, so a refused frame's records and
+ * the element slots beyond a frame's count read as zero.  A parser may be used from several streams in turn: a launch
+ * on another stream waits (on the device) for the parser's previous launch, whose lane-order scratch it reuses.   */
 int aacg_parse_batch(aacg_parser* p, const uint8_t* bytes, size_t n_bytes,
                      const aacg_parse_frame* frames, uint32_t n_frames,
                      uint32_t max_units, uint32_t max_channels, uint32_t options,

@@ -85,6 +85,26 @@ const tnsLong = { short: false, nFilt: [2], length: [[20, 9]], order: [[3, 1]], 
     assert.strictEqual(mk(true), 7);
     assert.throws(() => mk(false), /TODO: add pulse data/);
 }
+// readChunk look-ahead: a malformed frame in the middle of a batch is thrown by the call that reaches it — after the good
+// frames before it have been returned, and the frames behind it still follow (decoder.js:125-201 throws at exactly that
+// frame); a frame the host itself refuses (noise bands without PNS_SPEC, pulse data) behaves the same way
+{
+    const frame = function (extra) {
+        const ch = Object.assign({ windowSequence: 0, windowShape: 0, maxSFB: 0, groupLength: [1] }, (extra && extra.ch) || {});
+        return { elements: [Object.assign({ type: 'sce', id: 0, ch: [ch] }, (extra && extra.el) || {})], q: new Int16Array(1024), meta: new Uint16Array(120) };
+    };
+    const script = [frame(), frame(), frame(), new Error('Invalid band type: 12'), frame(), frame({ el: { hasPns: true } }), frame(),
+                    frame({ ch: { pulse: { offset: [1], amp: [1] } } }), frame(), null, null];
+    let at = 0, batches = [];
+    const frontend = { parseFrame: function () { const s = script[at++]; if (s instanceof Error) throw s; return s; } };
+    const engine = { resetStream: function () {}, decodeBatch: function (units, q, meta, pcm) { batches.push(units.length / host.UNIT_BYTES); pcm.fill(batches.length); } };
+    const dec = new host.GpuAACDecoder({ engine: engine, frontend: frontend, lookahead: 16 });
+    dec.config = { profile: 2, sampleIndex: 3, chanConfig: 1 };
+    const seen = [];
+    for (let i = 0; i < 11; i++) { try { const r = dec.readChunk(); seen.push(r ? r[0] : null); } catch (e) { seen.push(e.message.replace(/^aacgpu: (NOISE_BT).*/, '$1')); } }
+    assert.deepStrictEqual(seen, [1, 1, 1, 'Invalid band type: 12', 2, 'NOISE_BT', 3, 'TODO: add pulse data', 4, null, null]);
+    assert.deepStrictEqual(batches, [3, 1, 1, 1]);
+}
 // ADTS framing (aac.js_amd/js/adts.js): headers built here bit by bit from the field layout
 {
     const adts = require(path.join(__dirname, '..', '..', 'aac.js_amd', 'js', 'adts.js'));
