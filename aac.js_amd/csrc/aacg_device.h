@@ -135,7 +135,7 @@ struct aacg_kparams {
     const aacg_tables*    tab;
     int32_t               flip;       /* 0/1: swap ov_a and ov_b (plan reuse, see aacg_engine.hip) */
     int32_t               n_runs;
-    int32_t               ablate;     /* profiling only (env AACG_ABLATE): 1 skip IMDCT, 2 skip PCM stores, 4 skip spectrum loads */
+    int32_t               ablate;     /* -DAACG_PROFILE builds only (AACG_ABL in aacg_kernels.h); 0 otherwise */
     int32_t               reserved;
     float*                scratch;    /* [n_runs][2048]: parked predecessor tails of double-duty runs (last: the plain kernels never load it) */
     const aacg_pns_tables* pns;       /* AACG_PNS_SPEC: the spectral stage's noise tables */

@@ -84,7 +84,7 @@ struct aacg_engine {
     uint64_t submitted = 0;
     hipEvent_t last_kernel = nullptr;       /* completion of the most recently submitted batch's kernel */
     void* d_trace = nullptr;                /* profiling: per-wave phase timestamps when (ablate & 16) */
-    int ablate = 0;                         /* profiling knob, env AACG_ABLATE (see aacg_device.h); 0 in normal use */
+    int ablate = 0;                         /* -DAACG_PROFILE builds: env AACG_ABLATE (aacg_kernels.h); always 0 in the shipped library */
     std::string err;
 };
 
@@ -270,8 +270,10 @@ int aacg_create(const aacg_config* cfg, aacg_engine** out)
         delete pt;
         if (!ok) { aacg_destroy(e); return AACG_ERR_OUT_OF_MEMORY; }
     }
+#ifdef AACG_PROFILE                              /* profiling builds only (make profile); the shipped library has no such switch */
     if (const char* a = std::getenv("AACG_ABLATE")) e->ablate = std::atoi(a);
     if ((e->ablate & 16) && hipMalloc(&e->d_trace, 1u << 22) == hipSuccess) (void)hipMemset(e->d_trace, 0, 1u << 22);
+#endif
     *out = e;
     return AACG_OK;
 }

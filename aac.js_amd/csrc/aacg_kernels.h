@@ -32,6 +32,16 @@
 #include "devport.h"
 #include "aacg_device.h"
 
+/* Work-skipping / tracing switches for tools/ (timeline, ablations).  They exist only in a build made with
+ * -DAACG_PROFILE (`make profile` -> variants/profile.so): the library that ships has no such branches and ignores
+ * AACG_ABLATE.  Bits: 1 skip IMDCT (f32 seam), 2 skip PCM stores, 8 skip dequant arithmetic, 16 per-wave phase
+ * timestamps, 32 / 64 priority schemes, 128 no load stagger. */
+#ifdef AACG_PROFILE
+#define AACG_ABL(P, bits) ((P).ablate & (bits))
+#else
+#define AACG_ABL(P, bits) 0
+#endif
+
 struct cpx { float re, im; };
 
 DP_DEVICE cpx c_add(cpx a, cpx b) { cpx r; r.re = a.re + b.re; r.im = a.im + b.im; return r; }
@@ -1481,9 +1491,9 @@ DP_DEVICE void imdct_run_body(const aacg_kparams& P)
     /* Earlier frames get the higher issue priority: they finish first and their PCM stores overlap
      * the later waves' arithmetic.  A wave only ever waits for the wave before it, whose priority is
      * never lower, so a spinning consumer cannot starve its producer. */
-    if (P.ablate & 64) dp_setprio(0); else if (P.ablate & 32) dp_setprio(1 - (wave >> 3)); else dp_setprio(3 - (wave >> 2));
-    const unsigned long long t_start = (P.ablate & 16) ? dp_clock() : 0;
-    unsigned long long* trace = (P.ablate & 16) ? (unsigned long long*)P.spec_out + ((size_t)dp_block() * AACG_WG_WAVES + wave) * 8 : nullptr;
+    if (AACG_ABL(P, 64)) dp_setprio(0); else if (AACG_ABL(P, 32)) dp_setprio(1 - (wave >> 3)); else dp_setprio(3 - (wave >> 2));
+    const unsigned long long t_start = AACG_ABL(P, 16) ? dp_clock() : 0;
+    unsigned long long* trace = AACG_ABL(P, 16) ? (unsigned long long*)P.spec_out + ((size_t)dp_block() * AACG_WG_WAVES + wave) * 8 : nullptr;
     if (trace && lane == 0) trace[0] = t_start;
     const int n_ch = ui >= 0 ? u.n_ch : 0;
     const int cls0 = u.seq[0] == AACG_EIGHT_SHORT_SEQUENCE;
@@ -1505,7 +1515,7 @@ DP_DEVICE void imdct_run_body(const aacg_kparams& P)
      * join), and only then do the other twelve waves issue their requests.  The first group therefore sees
      * its data after ~1.7 us instead of queueing behind the whole chip's 33 MB, and the later groups' data
      * arrives while the SIMD is still busy with the earlier ones. */
-    const bool early = wave < (KIND == AACG_INPUT_QUANT_I16 ? 2 : 4) || (P.ablate & 128);
+    const bool early = wave < (KIND == AACG_INPUT_QUANT_I16 ? 2 : 4) || AACG_ABL(P, 128);
     if (early) {
         if (KIND == AACG_INPUT_QUANT_I16) quant_load(P, u, u.n_ch, qreg);
         else {
@@ -1525,13 +1535,13 @@ DP_DEVICE void imdct_run_body(const aacg_kparams& P)
     }
     if (trace && lane == 0) trace[1] = dp_clock();
 
-    if (ui >= 0 && (P.ablate & 1) && KIND != AACG_INPUT_QUANT_I16) {
+    if (ui >= 0 && AACG_ABL(P, 1) && KIND != AACG_INPUT_QUANT_I16) {
 #pragma unroll
         for (int m = 0; m < 8; m++) { hx0[m] = xa[m & 3].x; hy0[m] = xa[m & 3].y; hx1[m] = xb[m & 3].z; hy1[m] = xb[m & 3].w; }
     } else if (ui >= 0) {
         if (KIND == AACG_INPUT_QUANT_I16) {
             float xl[16], xr[16];
-            if (P.ablate & 8) {                        /* profiling: no dequant / MS / IS arithmetic */
+            if (AACG_ABL(P, 8)) {                        /* profiling: no dequant / MS / IS arithmetic */
 #pragma unroll
                 for (int i = 0; i < 2; i++) {
                     xl[8 * i] = (float)qreg.ql[i].x; xl[8 * i + 1] = (float)qreg.ql[i].y; xl[8 * i + 2] = (float)qreg.ql[i].z; xl[8 * i + 3] = (float)qreg.ql[i].w;
@@ -1566,7 +1576,7 @@ DP_DEVICE void imdct_run_body(const aacg_kparams& P)
     if (lane == 0) dp_flag_set(&flags[wave], 1);
     if (trace && lane == 0) trace[3] = dp_clock();         /* IMDCT done, tail released */
 
-    if (ui >= 0 && !is_pred_wave && (P.ablate & 2)) {
+    if (ui >= 0 && !is_pred_wave && AACG_ABL(P, 2)) {
         /* profiling: keep the values live without storing 8 KiB of PCM */
         float acc = 0.0f;
 #pragma unroll
@@ -1656,9 +1666,9 @@ DP_DEVICE void imdct_run_body_dd(const aacg_kparams& P)
     /* Earlier frames get the higher issue priority: they finish first and their PCM stores overlap
      * the later waves' arithmetic.  A wave only ever waits for the wave before it, whose priority is
      * never lower, so a spinning consumer cannot starve its producer. */
-    if (P.ablate & 64) dp_setprio(0); else if (P.ablate & 32) dp_setprio(1 - (wave >> 3)); else dp_setprio(3 - (wave >> 2));
-    const unsigned long long t_start = (P.ablate & 16) ? dp_clock() : 0;
-    unsigned long long* trace = (P.ablate & 16) ? (unsigned long long*)P.spec_out + ((size_t)dp_block() * AACG_WG_WAVES + wave) * 8 : nullptr;
+    if (AACG_ABL(P, 64)) dp_setprio(0); else if (AACG_ABL(P, 32)) dp_setprio(1 - (wave >> 3)); else dp_setprio(3 - (wave >> 2));
+    const unsigned long long t_start = AACG_ABL(P, 16) ? dp_clock() : 0;
+    unsigned long long* trace = AACG_ABL(P, 16) ? (unsigned long long*)P.spec_out + ((size_t)dp_block() * AACG_WG_WAVES + wave) * 8 : nullptr;
     if (trace && lane == 0) trace[0] = t_start;
     int n_ch = ui >= 0 ? u.n_ch : 0;
     int cls0 = u.seq[0] == AACG_EIGHT_SHORT_SEQUENCE;
@@ -1704,7 +1714,7 @@ DP_DEVICE void imdct_run_body_dd(const aacg_kparams& P)
      * join), and only then do the other twelve waves issue their requests.  The first group therefore sees
      * its data after ~1.7 us instead of queueing behind the whole chip's 33 MB, and the later groups' data
      * arrives while the SIMD is still busy with the earlier ones. */
-    const bool early = wave < (KIND == AACG_INPUT_QUANT_I16 ? 2 : 4) || (P.ablate & 128);
+    const bool early = wave < (KIND == AACG_INPUT_QUANT_I16 ? 2 : 4) || AACG_ABL(P, 128);
     if (early) issue_loads();
     stage_tables_store(lds, TAB_FLOATS, tr0, tr1);
     if (lane == 0) flags[wave] = 0;
@@ -1715,14 +1725,14 @@ DP_DEVICE void imdct_run_body_dd(const aacg_kparams& P)
     /* dequantise / stage this wave's loaded spectrum and run the filterbank on it: tails into the slot, the
      * windowed first half into hx / hy */
     auto front = [&](bool want_head) {
-        if ((P.ablate & 1) && KIND != AACG_INPUT_QUANT_I16) {
+        if (AACG_ABL(P, 1) && KIND != AACG_INPUT_QUANT_I16) {
 #pragma unroll
             for (int m = 0; m < 8; m++) { hx0[m] = xa[m & 3].x; hy0[m] = xa[m & 3].y; hx1[m] = xb[m & 3].z; hy1[m] = xb[m & 3].w; }
             return;
         }
         if (KIND == AACG_INPUT_QUANT_I16) {
             float xl[16], xr[16];
-            if (P.ablate & 8) {                        /* profiling: no dequant / MS / IS arithmetic */
+            if (AACG_ABL(P, 8)) {                        /* profiling: no dequant / MS / IS arithmetic */
 #pragma unroll
                 for (int i = 0; i < 2; i++) {
                     xl[8 * i] = (float)qreg.ql[i].x; xl[8 * i + 1] = (float)qreg.ql[i].y; xl[8 * i + 2] = (float)qreg.ql[i].z; xl[8 * i + 3] = (float)qreg.ql[i].w;
@@ -1774,7 +1784,7 @@ DP_DEVICE void imdct_run_body_dd(const aacg_kparams& P)
     if (lane == 0) dp_flag_set(&flags[wave], 1);
     if (trace && lane == 0) trace[3] = dp_clock();         /* IMDCT done, tail released */
 
-    if (ui >= 0 && !is_pred_wave && (P.ablate & 2)) {
+    if (ui >= 0 && !is_pred_wave && AACG_ABL(P, 2)) {
         /* profiling: keep the values live without storing 8 KiB of PCM */
         float acc = 0.0f;
 #pragma unroll
@@ -1991,7 +2001,7 @@ DP_DEVICE void imdct_run_body_fm(const aacg_kparams& P)
             }
         }
     };
-    const bool early = wave < E || (P.ablate & 128);    /* the first frame's waves */
+    const bool early = wave < E || AACG_ABL(P, 128);    /* the first frame's waves */
     if (early) issue_loads();
     stage_tables_store(lds, TAB_FLOATS, tr0, tr1);
     if (lane == 0) flags[wave] = 0;

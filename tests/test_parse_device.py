@@ -341,7 +341,7 @@ def test_gpu_plan_refresh_from_parse(standard, oracle, name, layout):
     ref_units["coef_offset"] = got["coef_offset"]
     ref_units["meta_offset"] = got["meta_offset"]
     bad = ~ok
-    ref_units["coef_offset"][bad] = skel["coef_offset"][bad]     # a refused frame's offsets are whatever the parser left: unused, max_sfb is 0
+    ref_units["coef_offset"][bad] = skel["coef_offset"][bad]     # a refused frame keeps the planner's offsets: the silent unit still loads its blocks
     ref_units["meta_offset"][bad] = skel["meta_offset"][bad]
     ov = np.zeros((S, C, 1024), np.float32)
     ref = oracle.decode_batch(ref_units, host["q"], host["meta"], n * 1024 * C, ov, sample_index=case["sampleIndex"])
@@ -350,7 +350,7 @@ def test_gpu_plan_refresh_from_parse(standard, oracle, name, layout):
     t = lambda arr: torch.from_numpy(np.ascontiguousarray(arr).view(np.uint8).reshape(-1)).to(dev)
     pad = np.concatenate([data, np.zeros((-len(data)) % 16 + 32, np.uint8)])
     d_bytes, d_frames = t(pad), t(frames)
-    d_units = torch.zeros(n * U * 64, dtype=torch.uint8, device=dev)
+    d_units = torch.full((n * U * 64,), 0xFF, dtype=torch.uint8, device=dev)      # stale memory: a refused frame's record must not be trusted
     d_q = torch.zeros(n * Ch * 1024, dtype=torch.int16, device=dev)
     d_meta = torch.zeros(n * Ch * 120, dtype=torch.int16, device=dev)
     d_res = torch.zeros(n * 8, dtype=torch.uint8, device=dev)
