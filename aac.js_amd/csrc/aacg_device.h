@@ -104,23 +104,29 @@ struct aacg_run {
     int32_t reserved;
 };
 
-/* Frame-major run (multichannel streams: n_out_ch > 2 with several elements per frame): one workgroup holds
- * F consecutive frames x the E elements of a frame, wave w = f * E + e.  A wave takes its predecessor's tail from
- * wave w - E; the E waves of a frame put their PCM into an LDS staging area in the stream's interleaved layout
- * and the whole workgroup stores it as full lines (a wave on its own can only write its 1-2 channels of every
- * sample: 8-byte pieces at a stride of n_out_ch floats).  A later run's frame-0 waves do double duty. */
-#define AACG_FM_MAX_ELEMENTS 8
-#define AACG_FM_HALF         512      /* samples staged per round */
-struct aacg_fm_run {
-    int32_t n_elem, n_frames;         /* E, F: E * F <= 16 */
+/* Stream-resident run (multichannel streams: n_out_ch > 2 with several elements per frame): ONE workgroup walks the
+ * frames of one stream.  Its E elements x F frames in flight (E * F <= 16 waves) form a ring: wave r * E + e takes
+ * element e of frames r, r + F, r + 2F, ... and receives the tails of frame t - 1 from wave ((r - 1) mod F) * E + e
+ * through LDS — no frame is ever recomputed inside a run, the tables are staged once, and while the waves of some
+ * frames compute, those of others load and store.  The E waves of a frame put their PCM, half a frame at a time, into
+ * an LDS staging area in the stream's interleaved layout and store it together as full lines (a wave on its own can
+ * only write its 1-2 channels of every sample: 8-byte pieces at a stride of n_out_ch floats, which is bound by the L2's
+ * write-request rate, not by bytes).  A run may be a piece of a longer chain (has_pred): its frame-0 waves then first
+ * redo the frame before it, as the element-major runs do. */
+#define AACG_SR_MAX_ELEMENTS 8
+#define AACG_SR_HALF         512      /* samples staged per round */
+#define AACG_SR_SYNC_WORDS   48       /* [0..15] tails released, [16..31] tails consumed (counts per wave), [32] staging turn,
+                                         [33] waves arrived, [34] waves done storing */
+struct aacg_sr_run {
+    int32_t n_elem, ring;             /* E, F */
+    int32_t n_frames;                 /* frames of this run, any number */
     int32_t has_pred, is_last;
     int32_t n_out_ch, stage_off;      /* stage_off: float offset of the staging area behind the slots */
-    int32_t reserved[2];
-    int32_t unit[AACG_RUN_W];         /* wave w = f * E + e; -1 = idle */
+    int32_t unit_base;                /* unit of (frame t, element e) = sr_units[unit_base + t * E + e] */
     int32_t slot_off[AACG_RUN_W];     /* float offset of wave w's slot in the slot area (CPE 2048, single channel 1536) */
-    int32_t pred[AACG_FM_MAX_ELEMENTS];
-    int32_t ov_a[AACG_FM_MAX_ELEMENTS][2];
-    int32_t ov_b[AACG_FM_MAX_ELEMENTS][2];
+    int32_t pred[AACG_SR_MAX_ELEMENTS];
+    int32_t ov_a[AACG_SR_MAX_ELEMENTS][2];
+    int32_t ov_b[AACG_SR_MAX_ELEMENTS][2];
 };
 
 struct aacg_kparams {
@@ -139,7 +145,8 @@ struct aacg_kparams {
     int32_t               reserved;
     float*                scratch;    /* [n_runs][2048]: parked predecessor tails of double-duty runs (last: the plain kernels never load it) */
     const aacg_pns_tables* pns;       /* AACG_PNS_SPEC: the spectral stage's noise tables */
-    const aacg_fm_run*    fm_runs;    /* frame-major runs (their own kernel) */
+    const aacg_sr_run*    sr_runs;    /* stream-resident runs of multichannel streams (their own kernel) */
+    const int32_t*        sr_units;   /* their unit index table */
 };
 
 /* ---- device front end (aacg_parse.h) ------------------------------------------------------------ */

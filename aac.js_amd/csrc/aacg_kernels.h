@@ -1872,10 +1872,10 @@ DP_DEVICE void spectral_ex_body(const aacg_kparams& P, int n_units)
 }
 
 /* ------------------------------------------------------------------------------------ */
-/* frame-major runs: multichannel streams                                                   */
+/* stream-resident runs: multichannel streams                                               */
 /* ------------------------------------------------------------------------------------ */
 /* One sample pair of one channel into the staging area, if it lies in the half being staged. */
-DP_DEVICE void fm_emit(float* stage, int half, int C, int ch, int n, float v0, float v1)
+DP_DEVICE void sr_emit(float* stage, int half, int C, int ch, int n, float v0, float v1)
 {
     if ((n >> 9) == half) {
         stage[(n & 511) * C + ch] = v0;
@@ -1886,7 +1886,7 @@ DP_DEVICE void fm_emit(float* stage, int half, int C, int ch, int n, float v0, f
 /* out = (overlap + head) / 32768 of one unit for the samples of one half, into the staging area in the stream's
  * interleaved layout (filter_bank.js + decoder.js:203-215); the counterpart of epilogue<>. */
 template <bool FROM_LDS>
-DP_DEVICE void fm_stage_unit(const float* p0, const float* p1, const unit_view& u, int n_ch, int cls0, int cls1,
+DP_DEVICE void sr_stage_unit(const float* p0, const float* p1, const unit_view& u, int n_ch, int cls0, int cls1,
                              float* stage, int half, const float (&hx0)[8], const float (&hy0)[8],
                              const float (&hx1)[8], const float (&hy1)[8])
 {
@@ -1906,7 +1906,7 @@ DP_DEVICE void fm_stage_unit(const float* p0, const float* p1, const unit_view& 
                     if ((m >> 2) == half) {            /* n = 2 lane + 128 m: m picks the half */
                         const int n = 2 * lane + 128 * m;
                         const dpf4 v = incoming<FROM_LDS>(p0, p1, n_ch, n);
-                        fm_emit(stage, half, C, ch, n, ((c ? v.y : v.x) + hx[m]) * S, ((c ? v.w : v.z) + hy[m]) * S);
+                        sr_emit(stage, half, C, ch, n, ((c ? v.y : v.x) + hx[m]) * S, ((c ? v.w : v.z) + hy[m]) * S);
                     }
                 }
             } else {
@@ -1916,7 +1916,7 @@ DP_DEVICE void fm_stage_unit(const float* p0, const float* p1, const unit_view& 
                         const int n = 448 + 128 * w + 2 * g + 16 * m;
                         if ((n >> 9) == half) {
                             const dpf4 v = incoming<FROM_LDS>(p0, p1, n_ch, n);
-                            fm_emit(stage, half, C, ch, n, ((c ? v.y : v.x) + hx[m]) * S, ((c ? v.w : v.z) + hy[m]) * S);
+                            sr_emit(stage, half, C, ch, n, ((c ? v.y : v.x) + hx[m]) * S, ((c ? v.w : v.z) + hy[m]) * S);
                         }
                     }
                 }
@@ -1926,7 +1926,7 @@ DP_DEVICE void fm_stage_unit(const float* p0, const float* p1, const unit_view& 
                         const int n = 2 * lane + 128 * t4;
                         if (n < 448) {
                             const dpf4 v = incoming<FROM_LDS>(p0, p1, n_ch, n);
-                            fm_emit(stage, half, C, ch, n, (c ? v.y : v.x) * S, (c ? v.w : v.z) * S);
+                            sr_emit(stage, half, C, ch, n, (c ? v.y : v.x) * S, (c ? v.w : v.z) * S);
                         }
                     }
                 }
@@ -1935,48 +1935,63 @@ DP_DEVICE void fm_stage_unit(const float* p0, const float* p1, const unit_view& 
     }
 }
 
-/* The run body for frame-major runs (aacg_fm_run, aacg_device.h).  Same stages as imdct_run_body_dd; what differs:
- * the predecessor is wave - E, slots have per-wave offsets, frame-0 waves of a later run do the double duty, and the
- * epilogue goes through the staging area: per frame and half, the frame's waves stage their PCM, a workgroup
- * barrier, every thread stores 16 contiguous bytes, a second barrier. */
-template <int KIND>
-DP_DEVICE void imdct_run_body_fm(const aacg_kparams& P)
+/* The run body for stream-resident runs (aacg_sr_run, aacg_device.h): the stages of imdct_run_body_dd, in a loop.
+ * Wave r * E + e walks element e of frames r, r + F, ...; per frame: spectrum -> IMDCT -> tails released; tails of the
+ * frame before it taken from the ring predecessor's slot; PCM through the staging area in frame order, half by half
+ * (the frame's E waves stage, meet, and store the half together as contiguous 16-byte pieces).  Waves meet through
+ * LDS counters only — after the table barrier there is no workgroup barrier, so waves of other frames keep
+ * computing, loading and storing meanwhile.
+ *
+ * One frame is one call of sr_frame (a real call, DP_NOINLINE): inlined into the loop, the compiler hoisted the
+ * frame's loop-invariant address arithmetic out of it and spilled 1 KB per lane.  The function re-derives what it needs
+ * from the kernel's parameter block (scalar loads) and the wave's position; nothing but t and k crosses the call. */
+struct sr_pos { int E, F, C, N, my_r, my_e, pr, pw; };
+DP_DEVICE sr_pos sr_position(const aacg_sr_run* run)
 {
+    sr_pos p;
+    const int wave = dp_wave();
+    p.E = run->n_elem; p.F = run->ring; p.C = run->n_out_ch; p.N = run->n_frames;
+    p.my_r = 0;                                         /* wave / E without a divide */
+    for (int k = 1; k < AACG_WG_WAVES; k++) p.my_r += (k * p.E <= wave) ? 1 : 0;
+    p.my_e = wave - p.my_r * p.E;
+    p.pr = p.my_r == 0 ? p.F - 1 : p.my_r - 1;          /* ring predecessor: the wave that holds frame t - 1 of this element */
+    p.pw = p.pr * p.E + p.my_e;
+    return p;
+}
+
+template <int KIND>
+DP_NOINLINE void sr_frame(int t_in, int k_in)
+{
+    const aacg_kparams& P = dp_kernarg<aacg_kparams>();
     const int TAB_FLOATS = (KIND == AACG_INPUT_QUANT_I16) ? AACG_TAB_QUANT_FLOATS : AACG_TAB_F32_FLOATS;
     const int lane = dp_lane(), wave = dp_wave();
-    const aacg_fm_run* run = P.fm_runs + dp_block();
+    const int t = dp_uniform(t_in), k = dp_uniform(k_in);
+    const aacg_sr_run* run = P.sr_runs + dp_block();
     float* lds = (float*)dp_lds();
     const float* tab = lds;
     float* slots = lds + TAB_FLOATS;
-    const int E = run->n_elem, F = run->n_frames, C = run->n_out_ch;
-    int* flags = (int*)(slots + run->stage_off + AACG_FM_HALF * C);
+    const sr_pos pos = sr_position(run);
+    const int E = pos.E, F = pos.F, C = pos.C, N = pos.N, my_e = pos.my_e, pr = pos.pr, pw = pos.pw;
     float* stage = slots + run->stage_off;
+    int* sync = (int*)(stage + AACG_SR_HALF * C);
+    int* ready = sync, * consumed = sync + 16, * turn = sync + 32, * arrived = sync + 33, * done = sync + 34;
     float* slot = slots + run->slot_off[wave];
+    const float* prev = slots + run->slot_off[pw];
+    const int32_t* uidx = P.sr_units + run->unit_base;
+    float* scratch = P.scratch + ((size_t)dp_block() * AACG_SR_MAX_ELEMENTS + (size_t)my_e) * AACG_SLOT_FLOATS;
 
-    dpf4 tr0, tr1;
-    stage_tables_load(P.tab, TAB_FLOATS, tr0, tr1);
-
-    int my_f = 0;                                       /* wave / E without a divide */
-    for (int k = 1; k < AACG_WG_WAVES; k++) my_f += (k * E <= wave) ? 1 : 0;
-    const int my_e = wave - my_f * E;
-    const bool active = my_f < F;
-    const bool has_pred = run->has_pred != 0;
-    int ui = active ? run->unit[wave] : -1;
-    ui = dp_uniform(ui);
-    const int n_pass = (active && has_pred && my_f == 0) ? 2 : 1;
-    float* scratch = P.scratch + ((size_t)dp_block() * AACG_FM_MAX_ELEMENTS + (size_t)my_e) * AACG_SLOT_FLOATS;
-
-    float hx0[8], hy0[8], hx1[8], hy1[8];
-    unit_view u = load_unit(P.units + (n_pass == 2 ? run->pred[my_e] : (ui >= 0 ? ui : 0)));
-    dp_setprio(my_f < 3 ? 3 - my_f : 0);
-    int n_ch = ui >= 0 ? u.n_ch : 0;
-    int cls0 = u.seq[0] == AACG_EIGHT_SHORT_SEQUENCE;
-    int cls1 = u.seq[1] == AACG_EIGHT_SHORT_SEQUENCE;
-    bool pair_path = n_ch == 2 && u.seq[0] == u.seq[1] && u.shape[0] == u.shape[1] && u.shape_prev[0] == u.shape_prev[1];
-
+    unit_view u;
+    int n_ch = 0, cls0 = 0, cls1 = 0;
+    bool pair_path = false;
     quant_regs qreg;
     dpf4 xa[4], xb[4];
-    auto issue_loads = [&]() {
+    float hx0[8], hy0[8], hx1[8], hy1[8];
+    auto take_unit = [&](int index) {
+        u = load_unit(P.units + index);
+        n_ch = u.n_ch;
+        cls0 = u.seq[0] == AACG_EIGHT_SHORT_SEQUENCE;
+        cls1 = u.seq[1] == AACG_EIGHT_SHORT_SEQUENCE;
+        pair_path = n_ch == 2 && u.seq[0] == u.seq[1] && u.shape[0] == u.shape[1] && u.shape_prev[0] == u.shape_prev[1];
         if (KIND == AACG_INPUT_QUANT_I16) quant_load(P, u, u.n_ch, qreg);
         else {
             const float* xsrc = (const float*)P.coeffs + (size_t)u.coef_offset * 1024u;
@@ -2001,13 +2016,6 @@ DP_DEVICE void imdct_run_body_fm(const aacg_kparams& P)
             }
         }
     };
-    const bool early = wave < E || AACG_ABL(P, 128);    /* the first frame's waves */
-    if (early) issue_loads();
-    stage_tables_store(lds, TAB_FLOATS, tr0, tr1);
-    if (lane == 0) flags[wave] = 0;
-    dp_block_sync_lds();
-    if (!early) issue_loads();
-
     auto front = [&](bool want_head) {
         if (KIND == AACG_INPUT_QUANT_I16) {
             float xl[16], xr[16];
@@ -2028,54 +2036,73 @@ DP_DEVICE void imdct_run_body_fm(const aacg_kparams& P)
         filter_unit(tab, u, n_ch, pair_path, want_head, slot, hx0, hy0, hx1, hy1);
     };
 
-    if (ui >= 0) front(n_pass == 1);
-    if (n_pass == 2) {
+    const int ui = dp_uniform(uidx[t * E + my_e]);
+    const bool dd = run->has_pred != 0 && t == 0;       /* piece of a longer chain: redo the frame before it first */
+    take_unit(dd ? run->pred[my_e] : ui);
+    /* the slot is free once the ring successor has taken the tails of this wave's previous frame */
+    if (k > 0) dp_flag_wait_ge(&consumed[wave], k);
+    front(!dd);
+    if (dd) {
         dp_keep_branch();
         dp_wave_sync();
         save_tails(scratch, scratch + 1024);
-        u = load_unit(P.units + ui);
-        n_ch = u.n_ch;
-        cls0 = u.seq[0] == AACG_EIGHT_SHORT_SEQUENCE;
-        cls1 = u.seq[1] == AACG_EIGHT_SHORT_SEQUENCE;
-        pair_path = n_ch == 2 && u.seq[0] == u.seq[1] && u.shape[0] == u.shape[1] && u.shape_prev[0] == u.shape_prev[1];
-        issue_loads();
+        take_unit(ui);
         dp_wave_sync();
         front(true);
     }
-
     dp_wave_sync();
-    if (lane == 0) dp_flag_set(&flags[wave], 1);
+    if (lane == 0) dp_flag_set(&ready[wave], k + 1);               /* tails of frame t are in the slot (release) */
 
-    /* epilogue through the staging area, frame by frame, half by half */
+    /* incoming tails: the overlap state (first frame of the chain in this launch; the parked tails of a piece's
+     * predecessor), else the ring predecessor's slot once it has released frame t - 1 */
+    const float* ov0 = dd ? scratch : P.overlap + (P.flip ? run->ov_b[my_e][0] : run->ov_a[my_e][0]);
+    const float* ov1 = dd ? scratch + 1024 : P.overlap + (P.flip ? run->ov_b[my_e][1] : run->ov_a[my_e][1]);
+    const int kp = t > 0 ? (t - 1 - pr) / F + 1 : 0;                /* frames the predecessor has released by then */
+    if (t > 0) dp_flag_wait_ge(&ready[pw], kp);
+    const uint32_t frame_pcm = u.pcm_offset;
 #pragma unroll 1
-    for (int f = 0; f < F; f++) {
-        const uint32_t frame_pcm = P.units[run->unit[f * E]].d.pcm_offset;
-#pragma unroll 1
-        for (int half = 0; half < 2; half++) {
-            if (active && my_f == f && ui >= 0) {
-                if (my_f == 0) {
-                    const float* ov0 = n_pass == 2 ? scratch : P.overlap + (P.flip ? run->ov_b[my_e][0] : run->ov_a[my_e][0]);
-                    const float* ov1 = n_pass == 2 ? scratch + 1024 : P.overlap + (P.flip ? run->ov_b[my_e][1] : run->ov_a[my_e][1]);
-                    fm_stage_unit<false>(ov0, ov1, u, n_ch, cls0, cls1, stage, half, hx0, hy0, hx1, hy1);
-                } else {
-                    if (half == 0) dp_flag_wait(&flags[wave - E], 1);
-                    const float* prev = slots + run->slot_off[wave - E];
-                    fm_stage_unit<true>(prev, prev, u, n_ch, cls0, cls1, stage, half, hx0, hy0, hx1, hy1);
-                }
-            }
-            dp_block_sync_lds();
-            {
-                const int n4 = (AACG_FM_HALF * C) >> 2;    /* 16-byte pieces of this half: C * 128 */
-                float* dst = P.pcm + frame_pcm + (size_t)half * AACG_FM_HALF * C;
-                for (int i = dp_tid(); i < n4; i += AACG_WG_THREADS) dp_store_nt((dpf4*)(dst + 4 * i), *(const dpf4*)(stage + 4 * i));
-            }
-            dp_block_sync_lds();
+    for (int half = 0; half < 2; half++) {
+        const int tn = 2 * t + half;
+        dp_flag_wait_ge(turn, tn);                                 /* the staging area is this frame's, this half's */
+        if (t == 0) sr_stage_unit<false>(ov0, ov1, u, n_ch, cls0, cls1, stage, half, hx0, hy0, hx1, hy1);
+        else        sr_stage_unit<true>(prev, prev, u, n_ch, cls0, cls1, stage, half, hx0, hy0, hx1, hy1);
+        dp_wave_sync();
+        if (lane == 0) dp_flag_add(arrived, 1);
+        dp_flag_wait_ge(arrived, (tn + 1) * E);                    /* all E waves of the frame have staged this half */
+        {
+            const int n4 = (AACG_SR_HALF * C) >> 2;                /* 16-byte pieces of this half: C * 128 */
+            float* dst = P.pcm + frame_pcm + (size_t)half * AACG_SR_HALF * C;
+            for (int i = my_e * 64 + lane; i < n4; i += 64 * E) dp_store_nt((dpf4*)(dst + 4 * i), *(const dpf4*)(stage + 4 * i));
         }
+        dp_wave_sync();
+        if (lane == 0 && dp_flag_add(done, 1) == (tn + 1) * E - 1) dp_flag_set(turn, tn + 1);
     }
+    if (t > 0 && lane == 0) dp_flag_set(&consumed[pw], kp);        /* the predecessor may overwrite its slot */
 
     /* the last frame of a chain's last run: its tails are the new overlap state (planar in HBM) */
-    if (active && ui >= 0 && my_f == F - 1 && run->is_last)
+    if (t == N - 1 && run->is_last)
         save_tails(P.overlap + (P.flip ? run->ov_a[my_e][0] : run->ov_b[my_e][0]), P.overlap + (P.flip ? run->ov_a[my_e][1] : run->ov_b[my_e][1]));
+}
+
+template <int KIND>
+DP_DEVICE void imdct_stream_body(const aacg_kparams& P)
+{
+    const int TAB_FLOATS = (KIND == AACG_INPUT_QUANT_I16) ? AACG_TAB_QUANT_FLOATS : AACG_TAB_F32_FLOATS;
+    const aacg_sr_run* run = P.sr_runs + dp_block();
+    float* lds = (float*)dp_lds();
+    int* sync = (int*)(lds + TAB_FLOATS + run->stage_off + AACG_SR_HALF * run->n_out_ch);
+
+    dpf4 tr0, tr1;
+    stage_tables_load(P.tab, TAB_FLOATS, tr0, tr1);
+    stage_tables_store(lds, TAB_FLOATS, tr0, tr1);
+    if (dp_tid() < AACG_SR_SYNC_WORDS) sync[dp_tid()] = 0;
+    dp_block_sync_lds();
+
+    const sr_pos pos = sr_position(run);
+    if (pos.my_r >= pos.F) return;                      /* waves beyond the ring: nothing after the table barrier needs them */
+    int k = 0;                                          /* frames this wave has finished */
+#pragma unroll 1
+    for (int t = pos.my_r; t < pos.N; t += pos.F, k++) sr_frame<KIND>(t, k);
 }
 
 /* Spectral stage alone (16 units per workgroup, one wave each): spec_out in ICStream.data order. */

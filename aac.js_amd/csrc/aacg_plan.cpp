@@ -215,61 +215,74 @@ int aacg_plan_build(const aacg_unit_desc* units, uint32_t n_units, int sample_in
             return fail(err, AACG_ERR_LAYOUT_CHANGE, "stream %ld: element at channel %ld ends before the batch does",
                         (long)(kv.first >> 16), (long)(kv.first & 0xffff));
 
-    /* Multichannel streams go frame-major (aacg_fm_run): all elements of a frame in one workgroup, so that the PCM
-     * can be interleaved in LDS and stored as full lines.  Needs every channel of every frame written (the staging
-     * area is stored as it is), 16-byte aligned frames, 2..8 elements.  Opt-in for now (AACG_FM=1 in the environment):
-     * correct, but with workgroup barriers around every staging round it is slower than element-major runs. */
-    static const bool fm_enabled = [] { const char* v = std::getenv("AACG_FM"); return v && v[0] == '1'; }();
-    auto is_fm = [&](uint32_t stream) {
-        const stream_state& s = st[stream];
-        return fm_enabled && s.n_out > 2 && s.n_chains >= 2 && s.n_chains <= AACG_FM_MAX_ELEMENTS && !s.holes && s.aligned;
+    /* Multichannel streams go stream-resident (aacg_sr_run): one workgroup walks the stream's frames with all elements
+     * of a frame side by side, so that the PCM can be interleaved in LDS and stored as full lines, and no frame inside a
+     * run is ever recomputed.  Needs every channel of every frame written (the staging area is stored as it is),
+     * 16-byte aligned frames, 2..8 elements, room for two frames in flight.  AACG_SR=0 in the environment keeps such
+     * streams on element-major runs (A/B measurements). */
+    static const bool sr_enabled = [] { const char* v = std::getenv("AACG_SR"); return !(v && v[0] == '0'); }();
+    auto sr_frame_floats = [&](uint32_t stream) {
+        int ff = 0;
+        for (auto it = open.lower_bound((uint64_t)stream << 16); it != open.end() && (it->first >> 16) == stream; ++it) ff += it->second.n_ch == 2 ? AACG_SLOT_FLOATS : 1536;
+        return ff;
     };
-    {
-        std::map<uint32_t, std::vector<uint64_t>> by_stream;       /* chains of a stream, by channel */
-        for (auto& kv : open) if (is_fm((uint32_t)(kv.first >> 16))) by_stream[(uint32_t)(kv.first >> 16)].push_back(kv.first);
-        for (auto& sv : by_stream) {
-            const uint32_t stream = sv.first;
-            const int E = (int)sv.second.size(), C = st[stream].n_out;
-            /* frames per run: as many as the waves and the LDS allow (slots of a frame + staging + flags; the larger,
-             * quantised-input table set is assumed) */
-            int frame_floats = 0;
-            for (int e = 0; e < E; e++) frame_floats += open[sv.second[(size_t)e]].n_ch == 2 ? AACG_SLOT_FLOATS : 1536;
-            const int budget = 160 * 1024 / 4 - AACG_TAB_QUANT_FLOATS - AACG_FM_HALF * C - AACG_RUN_W;
-            const int F = std::min(AACG_RUN_W / E, budget / frame_floats);      /* >= 1: E <= 8 frames of <= 2048 floats */
-            const size_t n = open[sv.second[0]].units.size();
-            for (size_t t0 = 0; t0 < n; t0 += (size_t)F) {
-                aacg_fm_run r;
-                std::memset(&r, 0, sizeof r);
-                r.n_elem = E; r.n_frames = (int32_t)std::min<size_t>((size_t)F, n - t0);
-                r.has_pred = t0 ? 1 : 0; r.is_last = t0 + (size_t)F >= n ? 1 : 0; r.n_out_ch = C;
-                for (int w = 0; w < AACG_RUN_W; w++) r.unit[w] = -1;
-                int off = 0;
-                for (int f = 0; f < F; f++)
-                    for (int e = 0; e < E; e++) {
-                        const open_chain& oc = open[sv.second[(size_t)e]];
-                        const int w = f * E + e;
-                        r.slot_off[w] = off;
-                        off += oc.n_ch == 2 ? AACG_SLOT_FLOATS : 1536;
-                        if (f < r.n_frames) r.unit[w] = oc.units[t0 + (size_t)f];
-                    }
-                for (int w = F * E; w < AACG_RUN_W; w++) r.slot_off[w] = 0;    /* idle waves never touch their slot */
-                r.stage_off = off;
+    auto sr_ring = [&](uint32_t stream) {
+        const stream_state& s = st[stream];
+        /* frames in flight: as many as the waves and the LDS allow (slots of a frame + staging + counters; the larger,
+         * quantised-input table set is assumed) */
+        const int budget = 160 * 1024 / 4 - AACG_TAB_QUANT_FLOATS - AACG_SR_HALF * (int)s.n_out - AACG_SR_SYNC_WORDS;
+        return std::min<int>(AACG_RUN_W / (int)s.n_chains, budget / sr_frame_floats(stream));
+    };
+    std::vector<uint8_t> sr_flag((size_t)max_streams, 0);
+    uint32_t sr_streams = 0;
+    for (uint32_t sidx = 0; sidx < (uint32_t)max_streams; sidx++) {
+        const stream_state& s = st[sidx];
+        if (sr_enabled && s.seen && s.n_out > 2 && s.n_chains >= 2 && s.n_chains <= AACG_SR_MAX_ELEMENTS && !s.holes && s.aligned && sr_ring(sidx) >= 2) {
+            sr_flag[sidx] = 1;
+            sr_streams++;
+        }
+    }
+    auto is_sr = [&](uint32_t stream) { return sr_flag[stream] != 0; };
+    for (uint32_t stream = 0; stream < (uint32_t)max_streams; stream++) {
+        if (!is_sr(stream)) continue;
+        std::vector<uint64_t> keys;                                /* the stream's chains, by channel */
+        for (auto it = open.lower_bound((uint64_t)stream << 16); it != open.end() && (it->first >> 16) == stream; ++it) keys.push_back(it->first);
+        const int E = (int)keys.size(), C = st[stream].n_out, F = sr_ring(stream);
+        const size_t n = open[keys[0]].units.size();
+        /* One run per stream, unless the streams are too few to fill the CUs: then a stream is cut into pieces of at
+         * least 16 frames (a later piece redoes the frame before it, 1 / length extra work). */
+        size_t len = std::max<size_t>(16, (n * sr_streams + 255) / 256);
+        len = std::min(n, (len + (size_t)F - 1) / (size_t)F * (size_t)F);
+        for (size_t t0 = 0; t0 < n; t0 += len) {
+            aacg_sr_run r;
+            std::memset(&r, 0, sizeof r);
+            r.n_elem = E; r.ring = F; r.n_frames = (int32_t)std::min(len, n - t0);
+            r.has_pred = t0 ? 1 : 0; r.is_last = t0 + len >= n ? 1 : 0; r.n_out_ch = C;
+            r.unit_base = (int32_t)out->sr_units.size();
+            for (int t = 0; t < r.n_frames; t++)
+                for (int e = 0; e < E; e++) out->sr_units.push_back(open[keys[(size_t)e]].units[t0 + (size_t)t]);
+            int off = 0;
+            for (int f = 0; f < F; f++)
                 for (int e = 0; e < E; e++) {
-                    const uint64_t key = sv.second[(size_t)e];
-                    const open_chain& oc = open[key];
-                    const uint32_t channel = (uint32_t)(key & 0xffff);
-                    r.pred[e] = t0 ? oc.units[t0 - 1] : -1;
-                    for (int c = 0; c < 2; c++) {
-                        const uint32_t chn = channel + (c < oc.n_ch ? c : 0);
-                        const int par = parity ? parity[(size_t)stream * (size_t)max_channels + chn] : 0;
-                        r.ov_a[e][c] = aacg_ov_offset(max_channels, stream, chn, par);
-                        r.ov_b[e][c] = aacg_ov_offset(max_channels, stream, chn, par ^ 1);
-                    }
+                    r.slot_off[f * E + e] = off;
+                    off += open[keys[(size_t)e]].n_ch == 2 ? AACG_SLOT_FLOATS : 1536;
                 }
-                out->fm_lds_floats = std::max(out->fm_lds_floats, (uint32_t)(off + AACG_FM_HALF * C + AACG_RUN_W));
-                if (r.has_pred) out->fm_needs_scratch = true;
-                out->fm_runs.push_back(r);
+            for (int w = F * E; w < AACG_RUN_W; w++) r.slot_off[w] = 0;        /* waves beyond the ring never touch a slot */
+            r.stage_off = off;
+            for (int e = 0; e < E; e++) {
+                const open_chain& oc = open[keys[(size_t)e]];
+                const uint32_t channel = (uint32_t)(keys[(size_t)e] & 0xffff);
+                r.pred[e] = t0 ? oc.units[t0 - 1] : -1;
+                for (int c = 0; c < 2; c++) {
+                    const uint32_t chn = channel + (c < oc.n_ch ? c : 0);
+                    const int par = parity ? parity[(size_t)stream * (size_t)max_channels + chn] : 0;
+                    r.ov_a[e][c] = aacg_ov_offset(max_channels, stream, chn, par);
+                    r.ov_b[e][c] = aacg_ov_offset(max_channels, stream, chn, par ^ 1);
+                }
             }
+            out->sr_lds_floats = std::max(out->sr_lds_floats, (uint32_t)(off + AACG_SR_HALF * C + AACG_SR_SYNC_WORDS));
+            if (r.has_pred) out->sr_needs_scratch = true;
+            out->sr_runs.push_back(r);
         }
     }
 
@@ -284,7 +297,7 @@ int aacg_plan_build(const aacg_unit_desc* units, uint32_t n_units, int sample_in
         ch.first_run = (uint32_t)gen.size();
         for (int c = 0; c < 2; c++)
             ch.parity[c] = (parity && c < oc.n_ch) ? parity[(size_t)ch.stream * (size_t)max_channels + ch.channel + c] : 0;
-        if (is_fm(ch.stream)) {                            /* its runs are in fm_runs; the chain record keeps the parity bookkeeping */
+        if (is_sr(ch.stream)) {                            /* its runs are in sr_runs; the chain record keeps the parity bookkeeping */
             ch.n_runs = 0;
             out->chains.push_back(ch);
             continue;

@@ -21,6 +21,13 @@
 
 #define DP_DEVICE __device__ __forceinline__
 #define DP_KERNEL(bounds_threads, bounds_waves) __global__ __launch_bounds__(bounds_threads, bounds_waves)
+/* a real function call: the body of a loop whose iterations must not share hoisted address arithmetic (the frame
+ * loop of the stream-resident kernel spilled 1 KB per lane when it was inlined) */
+#define DP_NOINLINE __device__ __attribute__((noinline))
+/* the kernel's (single, by-value) parameter block as it lies in the kernarg segment: a called function reads it with
+ * scalar loads instead of receiving a per-lane copy */
+template <class T>
+DP_DEVICE const T& dp_kernarg() { return *(const T*)__builtin_amdgcn_kernarg_segment_ptr(); }
 
 typedef float2 dpf2;
 typedef float4 dpf4;
@@ -59,6 +66,12 @@ DP_DEVICE void dp_flag_wait(int* flag, int v)
 {
     while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != v) __builtin_amdgcn_s_sleep(2);
 }
+/* counting forms for rings of waves: wait until the counter has reached v; add 1 with release / acquire ordering */
+DP_DEVICE void dp_flag_wait_ge(int* flag, int v)
+{
+    while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < v) __builtin_amdgcn_s_sleep(2);
+}
+DP_DEVICE int dp_flag_add(int* flag, int v) { return __hip_atomic_fetch_add(flag, v, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP); }
 /* issue priority of this wave on its SIMD (0..3); s_setprio takes an immediate */
 DP_DEVICE void dp_setprio(int p)
 {

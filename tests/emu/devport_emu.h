@@ -21,6 +21,7 @@
 
 #define DP_DEVICE static inline
 #define DP_KERNEL(a, b)
+#define DP_NOINLINE static __attribute__((noinline))
 
 struct alignas(8)  dpf2 { float x, y; };
 struct alignas(16) dpf4 { float x, y, z, w; };
@@ -43,9 +44,12 @@ struct emu_lane_ctx {
     int lane, wave;
     emu_wave* w;
     emu_block* b;
+    const void* kernarg;        /* the kernel's parameter block */
 };
 extern thread_local emu_lane_ctx g_emu;
 
+template <class T>
+DP_DEVICE const T& dp_kernarg() { return *(const T*)g_emu.kernarg; }
 DP_DEVICE int dp_tid()   { return g_emu.wave * 64 + g_emu.lane; }
 DP_DEVICE int dp_lane()  { return g_emu.lane; }
 DP_DEVICE int dp_wave()  { return g_emu.wave; }
@@ -56,6 +60,8 @@ DP_DEVICE void dp_block_sync() { pthread_barrier_wait(&g_emu.b->bar); }
 DP_DEVICE void dp_block_sync_lds() { pthread_barrier_wait(&g_emu.b->bar); }
 DP_DEVICE void dp_flag_set(int* flag, int v) { __atomic_store_n(flag, v, __ATOMIC_RELEASE); }
 DP_DEVICE void dp_flag_wait(int* flag, int v) { while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != v) sched_yield(); }
+DP_DEVICE void dp_flag_wait_ge(int* flag, int v) { while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) < v) sched_yield(); }
+DP_DEVICE int dp_flag_add(int* flag, int v) { return __atomic_fetch_add(flag, v, __ATOMIC_ACQ_REL); }
 DP_DEVICE void dp_setprio(int) {}
 
 template <int N>

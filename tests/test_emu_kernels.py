@@ -215,6 +215,28 @@ def test_ragged_streams_and_eight_channels(emu, oracle):
     assert rms(pcm, ref) < RMS_TOL
 
 
+@pytest.mark.parametrize("layout,T", [(("cpe", "cpe", "cpe", "sce"), 40), (("sce", "cpe", "cpe", "sce"), 21), (("sce", "cpe", "cpe", "cpe", "sce"), 7),
+                                      (("sce",) * 8, 5)])
+def test_stream_resident_runs(emu, oracle, layout, T):
+    """Multichannel streams take the stream-resident kernel: the ring of waves walks more frames than it holds (5.1 and 7
+    channels: 4 frames in flight, 7.1: 3, eight mono elements: 2), a stream of 40 frames is cut into pieces of 16 whose
+    first waves redo the frame before them, and two consecutive batches chain through the overlap state."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "aac.js_amd", "python"))
+    import aacgpu_workload
+    S = 2
+    C = sum(2 if e == "cpe" else 1 for e in layout)
+    ov = np.zeros((S, C, 1024), np.float32)
+    pool = np.zeros((S, C, 2, 1024), np.float32)
+    par = np.zeros(S * C, np.uint8)
+    for batch in range(2):
+        wl = aacgpu_workload.make_batch(n_streams=S, n_frames=T, layout=layout, mix=True, intensity=True, seed=900 + batch, frame_base=batch * T)
+        ref = oracle.decode_batch(wl["units"], wl["q"], wl["meta"], wl["n_pcm"], ov)
+        pcm = emu.decode(wl["units"], wl["q"], wl["meta"], wl["n_pcm"], pool, par)
+        assert rms(pcm, ref) < RMS_TOL
+        assert np.abs(emu_lib.pool_current(pool, par) - ov).max() < 1e-5 * max(1.0, np.abs(ov).max())
+
+
 @pytest.mark.parametrize("seed", [1, 2, 3, 4])
 def test_fuzz_vs_oracle(emu, oracle, seed):
     """Random layouts, sequences, shapes (also previous shapes), groupings, band types, masks: emulated kernels vs oracle."""

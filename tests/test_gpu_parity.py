@@ -575,3 +575,23 @@ def test_bench_launches_its_own_ranks():
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["steps"] == 20 and line["output_ok"] and line["parity_rms"] < 1e-5
     assert abs(line["value"] - 2 * 4096 / (line["ms_per_step"] * 1e-3)) < 1e-6 * line["value"]
+
+
+@pytest.mark.parametrize("layout,T", [(("cpe", "cpe", "cpe", "sce"), 40), (("sce", "cpe", "cpe", "sce"), 21), (("sce", "cpe", "cpe", "cpe", "sce"), 7),
+                                      (("sce",) * 8, 5), (("cpe", "cpe", "cpe", "sce"), 16)])
+def test_stream_resident_runs(oracle, layout, T):
+    """Multichannel streams take the stream-resident kernel (aacg_imdct_stream_*): rings of 4 / 3 / 2 frames in flight, a
+    stream cut into pieces whose first waves redo the frame before them, two consecutive batches chained through the
+    overlap state; 24 streams so that several workgroups run side by side."""
+    S = 24
+    C = sum(2 if e == "cpe" else 1 for e in layout)
+    eng = aacgpu.Engine(aacgpu.INPUT_QUANT_I16, max_streams=S, max_channels=C)
+    ov = np.zeros((S, C, 1024), np.float32)
+    for batch in range(2):
+        wl = aacgpu_workload.make_batch(n_streams=S, n_frames=T, layout=layout, mix=True, intensity=True, seed=900 + batch, frame_base=batch * T)
+        ref = oracle.decode_batch(wl["units"], wl["q"], wl["meta"], wl["n_pcm"], ov)
+        pcm = eng.decode_batch(wl["units"], wl["q"], wl["meta"], wl["n_pcm"])
+        assert rms(pcm, ref) < RMS_TOL
+        got = overlaps(eng, S, C)
+        assert np.abs(got - ov).max() <= 1e-5 * max(1.0, float(np.abs(ov).max()))
+    eng.close()
