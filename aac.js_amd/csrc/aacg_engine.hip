@@ -336,6 +336,9 @@ int aacg_get_overlap(aacg_engine* e, uint32_t stream, uint32_t channel, float* d
     if (rc) return rc;
     if (!dst) return AACG_ERR_INVALID_ARG;
     HIP_TRY(e, hipMemcpy(dst, ov_ptr(e, stream, channel), 4096, hipMemcpyDeviceToHost), AACG_ERR_NO_DEVICE);
+    /* the pool holds the state PCM-scaled (AACG_PCM_SCALE in the windows); the ABI speaks the reference's scale
+     * (FilterBank.overlaps, filter_bank.js:38-41): a power of two, exact both ways */
+    for (int i = 0; i < 1024; i++) dst[i] *= 32768.0f;
     return AACG_OK;
 }
 
@@ -344,7 +347,9 @@ int aacg_set_overlap(aacg_engine* e, uint32_t stream, uint32_t channel, const fl
     int rc = ov_check(e, stream, channel);
     if (rc) return rc;
     if (!src) return AACG_ERR_INVALID_ARG;
-    HIP_TRY(e, hipMemcpy(ov_ptr(e, stream, channel), src, 4096, hipMemcpyHostToDevice), AACG_ERR_NO_DEVICE);
+    float scaled[1024];
+    for (int i = 0; i < 1024; i++) scaled[i] = src[i] * AACG_PCM_SCALE;
+    HIP_TRY(e, hipMemcpy(ov_ptr(e, stream, channel), scaled, 4096, hipMemcpyHostToDevice), AACG_ERR_NO_DEVICE);
     return AACG_OK;
 }
 

@@ -6,6 +6,7 @@
  */
 #include <hip/hip_runtime.h>
 
+#define DP_LANE_OPAQUE      /* devport.h: the frame loop must not hoist lane-derived addresses (1.2 KB of spills per lane) */
 #include "aacg_kernels.h"
 
 extern "C" __global__ __launch_bounds__(AACG_WG_THREADS)

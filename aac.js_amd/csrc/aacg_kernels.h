@@ -160,7 +160,7 @@ DP_DEVICE dpf2 head_window(const float* tab, int seq, int shape_prev, int n)
     int i = n - 448; i = i < 0 ? 0 : (i > 126 ? 126 : i);
     dpf2 v = *(const dpf2*)(ws + i);
     if (n < 448) { v.x = 0.0f; v.y = 0.0f; }
-    if (n >= 576) { v.x = 1.0f; v.y = 1.0f; }
+    if (n >= 576) { v.x = AACG_PCM_SCALE; v.y = AACG_PCM_SCALE; }     /* "1": the tables carry the PCM scale */
     return v;
 }
 /* (w[n], w[n+1]) multiplying IMDCT output 1024 + n, 1024 + n + 1 (n even). */
@@ -176,7 +176,7 @@ DP_DEVICE dpf2 tail_window(const float* tab, int seq, int shape, int n)
     int i = 574 - n; i = i < 0 ? 0 : (i > 126 ? 126 : i);
     v = *(const dpf2*)(tab + AACG_TAB_OFF_WIN_SHORT + 128 * shape + i);
     r.x = v.y; r.y = v.x;
-    if (n < 448) { r.x = 1.0f; r.y = 1.0f; }
+    if (n < 448) { r.x = AACG_PCM_SCALE; r.y = AACG_PCM_SCALE; }
     if (n >= 576) { r.x = 0.0f; r.y = 0.0f; }
     return r;
 }
@@ -1339,7 +1339,7 @@ DP_DEVICE void epilogue(const float* p0, const float* p1, const unit_view& u, in
                         const float (&hx1)[8], const float (&hy1)[8])
 {
     const int lane = dp_lane(), w = lane >> 3, g = lane & 7;
-    const float S = 1.0f / 32768.0f;                   /* decoder.js:211 */
+    /* decoder.js:211's 1 / 32768 is already in the windows (AACG_PCM_SCALE): heads and tails arrive PCM-scaled */
     const int C = u.n_out_ch;
     float* pcm = pcm_base + u.pcm_offset + u.channel;
 
@@ -1354,8 +1354,8 @@ DP_DEVICE void epilogue(const float* p0, const float* p1, const unit_view& u, in
             for (int m = 0; m < 8; m++) {
                 const int n = 2 * lane + 128 * m;
                 dpf4 o;
-                o.x = (v[m].x + hx0[m]) * S; o.y = (v[m].y + hx1[m]) * S;
-                o.z = (v[m].z + hy0[m]) * S; o.w = (v[m].w + hy1[m]) * S;
+                o.x = v[m].x + hx0[m]; o.y = v[m].y + hx1[m];
+                o.z = v[m].z + hy0[m]; o.w = v[m].w + hy1[m];
                 dp_store_nt((dpf4*)(pcm + 2 * n), o);
             }
         } else {
@@ -1365,8 +1365,8 @@ DP_DEVICE void epilogue(const float* p0, const float* p1, const unit_view& u, in
                     const int n = 448 + 128 * w + 2 * g + 16 * m;
                     const dpf4 v = incoming<FROM_LDS>(p0, p1, 2, n);
                     dpf4 o;
-                    o.x = (v.x + hx0[m]) * S; o.y = (v.y + hx1[m]) * S;
-                    o.z = (v.z + hy0[m]) * S; o.w = (v.w + hy1[m]) * S;
+                    o.x = v.x + hx0[m]; o.y = v.y + hx1[m];
+                    o.z = v.z + hy0[m]; o.w = v.w + hy1[m];
                     dp_store_nt((dpf4*)(pcm + 2 * n), o);
                 }
             }
@@ -1375,8 +1375,7 @@ DP_DEVICE void epilogue(const float* p0, const float* p1, const unit_view& u, in
                 const int n = 2 * lane + 128 * t4;
                 if (n < 448) {
                     const dpf4 v = incoming<FROM_LDS>(p0, p1, 2, n);
-                    dpf4 o; o.x = v.x * S; o.y = v.y * S; o.z = v.z * S; o.w = v.w * S;
-                    dp_store_nt((dpf4*)(pcm + 2 * n), o);
+                    dp_store_nt((dpf4*)(pcm + 2 * n), v);
                 }
             }
         }
@@ -1391,8 +1390,8 @@ DP_DEVICE void epilogue(const float* p0, const float* p1, const unit_view& u, in
             for (int m = 0; m < 8; m++) {
                 const int n = 2 * lane + 128 * m;
                 const dpf4 v = incoming<FROM_LDS>(p0, p1, 2, n);
-                dp_store2_u(pcm + (size_t)n * C, (v.x + hx0[m]) * S, (v.y + hx1[m]) * S);
-                dp_store2_u(pcm + (size_t)(n + 1) * C, (v.z + hy0[m]) * S, (v.w + hy1[m]) * S);
+                dp_store2_u(pcm + (size_t)n * C, v.x + hx0[m], v.y + hx1[m]);
+                dp_store2_u(pcm + (size_t)(n + 1) * C, v.z + hy0[m], v.w + hy1[m]);
             }
         } else {
 #pragma unroll
@@ -1400,8 +1399,8 @@ DP_DEVICE void epilogue(const float* p0, const float* p1, const unit_view& u, in
                 if (w < 4 || (w == 4 && m < 4)) {
                     const int n = 448 + 128 * w + 2 * g + 16 * m;
                     const dpf4 v = incoming<FROM_LDS>(p0, p1, 2, n);
-                    dp_store2_u(pcm + (size_t)n * C, (v.x + hx0[m]) * S, (v.y + hx1[m]) * S);
-                    dp_store2_u(pcm + (size_t)(n + 1) * C, (v.z + hy0[m]) * S, (v.w + hy1[m]) * S);
+                    dp_store2_u(pcm + (size_t)n * C, v.x + hx0[m], v.y + hx1[m]);
+                    dp_store2_u(pcm + (size_t)(n + 1) * C, v.z + hy0[m], v.w + hy1[m]);
                 }
             }
 #pragma unroll
@@ -1409,8 +1408,8 @@ DP_DEVICE void epilogue(const float* p0, const float* p1, const unit_view& u, in
                 const int n = 2 * lane + 128 * t4;
                 if (n < 448) {
                     const dpf4 v = incoming<FROM_LDS>(p0, p1, 2, n);
-                    dp_store2_u(pcm + (size_t)n * C, v.x * S, v.y * S);
-                    dp_store2_u(pcm + (size_t)(n + 1) * C, v.z * S, v.w * S);
+                    dp_store2_u(pcm + (size_t)n * C, v.x, v.y);
+                    dp_store2_u(pcm + (size_t)(n + 1) * C, v.z, v.w);
                 }
             }
         }
@@ -1430,8 +1429,8 @@ DP_DEVICE void epilogue(const float* p0, const float* p1, const unit_view& u, in
                 for (int m = 0; m < 8; m++) {
                     const int n = 2 * lane + 128 * m;
                     const dpf4 v = incoming<FROM_LDS>(p0, p1, n_ch, n);
-                    dst[(size_t)n * C]       = ((c ? v.y : v.x) + hx[m]) * S;
-                    dst[(size_t)(n + 1) * C] = ((c ? v.w : v.z) + hy[m]) * S;
+                    dst[(size_t)n * C]       = (c ? v.y : v.x) + hx[m];
+                    dst[(size_t)(n + 1) * C] = (c ? v.w : v.z) + hy[m];
                 }
             } else {
 #pragma unroll
@@ -1439,8 +1438,8 @@ DP_DEVICE void epilogue(const float* p0, const float* p1, const unit_view& u, in
                     if (w < 4 || (w == 4 && m < 4)) {
                         const int n = 448 + 128 * w + 2 * g + 16 * m;
                         const dpf4 v = incoming<FROM_LDS>(p0, p1, n_ch, n);
-                        dst[(size_t)n * C]       = ((c ? v.y : v.x) + hx[m]) * S;
-                        dst[(size_t)(n + 1) * C] = ((c ? v.w : v.z) + hy[m]) * S;
+                        dst[(size_t)n * C]       = (c ? v.y : v.x) + hx[m];
+                        dst[(size_t)(n + 1) * C] = (c ? v.w : v.z) + hy[m];
                     }
                 }
 #pragma unroll
@@ -1448,8 +1447,8 @@ DP_DEVICE void epilogue(const float* p0, const float* p1, const unit_view& u, in
                     const int n = 2 * lane + 128 * t4;
                     if (n < 448) {
                         const dpf4 v = incoming<FROM_LDS>(p0, p1, n_ch, n);
-                        dst[(size_t)n * C]       = (c ? v.y : v.x) * S;
-                        dst[(size_t)(n + 1) * C] = (c ? v.w : v.z) * S;
+                        dst[(size_t)n * C]       = c ? v.y : v.x;
+                        dst[(size_t)(n + 1) * C] = c ? v.w : v.z;
                     }
                 }
             }
@@ -1874,77 +1873,82 @@ DP_DEVICE void spectral_ex_body(const aacg_kparams& P, int n_units)
 /* ------------------------------------------------------------------------------------ */
 /* stream-resident runs: multichannel streams                                               */
 /* ------------------------------------------------------------------------------------ */
-/* One sample pair of one channel into the staging area, if it lies in the half being staged. */
-DP_DEVICE void sr_emit(float* stage, int half, int C, int ch, int n, float v0, float v1)
-{
-    if ((n >> 9) == half) {
-        stage[(n & 511) * C + ch] = v0;
-        stage[((n + 1) & 511) * C + ch] = v1;
-    }
-}
-
-/* out = (overlap + head) / 32768 of one unit for the samples of one half, into the staging area in the stream's
- * interleaved layout (filter_bank.js + decoder.js:203-215); the counterpart of epilogue<>. */
-template <bool FROM_LDS>
-DP_DEVICE void sr_stage_unit(const float* p0, const float* p1, const unit_view& u, int n_ch, int cls0, int cls1,
-                             float* stage, int half, const float (&hx0)[8], const float (&hy0)[8],
-                             const float (&hx1)[8], const float (&hy1)[8])
+/* Overlap-add in place: this unit's windowed first half onto the previous frame's tails in the ring predecessor's slot
+ * (filter_bank.js:109-111, 153-160, 185-195 — both operands are PCM-scaled already), which then holds the element's
+ * finished samples: (L[n], R[n]) pairs for a CPE, planar for a single channel.  Samples a window sequence takes from the
+ * overlap alone (EIGHT_SHORT: 0..447) are simply left as they are. */
+DP_DEVICE void sr_overlap_add(float* prev, int n_ch, int cls0, int cls1,
+                              const float (&hx0)[8], const float (&hy0)[8], const float (&hx1)[8], const float (&hy1)[8])
 {
     const int lane = dp_lane(), w = lane >> 3, g = lane & 7;
-    const float S = 1.0f / 32768.0f;                   /* decoder.js:211 */
-    const int C = u.n_out_ch;
+    if (n_ch == 2 && cls0 == cls1) {
+#pragma unroll
+        for (int m = 0; m < 8; m++) {
+            const int n = cls0 ? 448 + 128 * w + 2 * g + 16 * m : 2 * lane + 128 * m;
+            if (!cls0 || w < 4 || (w == 4 && m < 4)) {
+                dpf4 v = *(const dpf4*)(prev + 2 * n);
+                v.x += hx0[m]; v.y += hx1[m]; v.z += hy0[m]; v.w += hy1[m];
+                *(dpf4*)(prev + 2 * n) = v;
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int c = 0; c < 2; c++) {
         if (c < n_ch) {
             const int cls = c ? cls1 : cls0;
             const float (&hx)[8] = c ? hx1 : hx0;
             const float (&hy)[8] = c ? hy1 : hy0;
-            const int ch = u.channel + c;
-            if (!cls) {
+            float* p = prev + c;                       /* single channel: planar; CPE with mixed lane maps: stride 2 */
+            const int st = n_ch;
 #pragma unroll
-                for (int m = 0; m < 8; m++) {
-                    if ((m >> 2) == half) {            /* n = 2 lane + 128 m: m picks the half */
-                        const int n = 2 * lane + 128 * m;
-                        const dpf4 v = incoming<FROM_LDS>(p0, p1, n_ch, n);
-                        sr_emit(stage, half, C, ch, n, ((c ? v.y : v.x) + hx[m]) * S, ((c ? v.w : v.z) + hy[m]) * S);
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int m = 0; m < 8; m++) {
-                    if (w < 4 || (w == 4 && m < 4)) {
-                        const int n = 448 + 128 * w + 2 * g + 16 * m;
-                        if ((n >> 9) == half) {
-                            const dpf4 v = incoming<FROM_LDS>(p0, p1, n_ch, n);
-                            sr_emit(stage, half, C, ch, n, ((c ? v.y : v.x) + hx[m]) * S, ((c ? v.w : v.z) + hy[m]) * S);
-                        }
-                    }
-                }
-                if (half == 0) {
-#pragma unroll
-                    for (int t4 = 0; t4 < 4; t4++) {   /* out[0..447] = overlap (filter_bank.js:149-151) */
-                        const int n = 2 * lane + 128 * t4;
-                        if (n < 448) {
-                            const dpf4 v = incoming<FROM_LDS>(p0, p1, n_ch, n);
-                            sr_emit(stage, half, C, ch, n, (c ? v.y : v.x) * S, (c ? v.w : v.z) * S);
-                        }
-                    }
+            for (int m = 0; m < 8; m++) {
+                const int n = cls ? 448 + 128 * w + 2 * g + 16 * m : 2 * lane + 128 * m;
+                if (!cls || w < 4 || (w == 4 && m < 4)) {
+                    p[n * st] += hx[m];
+                    p[(n + 1) * st] += hy[m];
                 }
             }
         }
     }
 }
 
+/* One wave's share of a finished frame: the interleaved [1024][C] block (decoder.js:203-215) as contiguous 16-byte
+ * pieces, every float gathered from the slot that holds its channel (cmap[c] = float offset | stride << 24). */
+DP_DEVICE void sr_store_frame(const float* slots, const int* cmap, int C, int E, int my_e, int step_q, int step_r, float* dst)
+{
+    const int lane = dp_lane();
+    const int n4 = 256 * C;                             /* 16-byte pieces of the frame */
+    int i = my_e * 64 + lane;
+    int n = (4 * i) / C, c = 4 * i - n * C;             /* sample and channel of the piece's first float */
+#pragma unroll 1
+    for (; i < n4; i += 64 * E) {
+        float v[4];
+        int nn = n, cc = c;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int m = cmap[cc];
+            v[j] = slots[(m & 0xffffff) + nn * (int)((unsigned)m >> 24)];
+            cc++;
+            if (cc == C) { cc = 0; nn++; }
+        }
+        dpf4 o; o.x = v[0]; o.y = v[1]; o.z = v[2]; o.w = v[3];
+        dp_store_nt((dpf4*)(dst + 4 * i), o);
+        n += step_q; c += step_r;
+        if (c >= C) { c -= C; n++; }
+    }
+}
+
 /* The run body for stream-resident runs (aacg_sr_run, aacg_device.h): the stages of imdct_run_body_dd, in a loop.
- * Wave r * E + e walks element e of frames r, r + F, ...; per frame: spectrum -> IMDCT -> tails released; tails of the
- * frame before it taken from the ring predecessor's slot; PCM through the staging area in frame order, half by half
- * (the frame's E waves stage, meet, and store the half together as contiguous 16-byte pieces).  Waves meet through
+ * Wave r * E + e walks element e of frames r, r + F, ...; per frame: spectrum -> IMDCT -> tails released; overlap-add in
+ * place onto the ring predecessor's tails; the frame's E waves meet and store the frame together.  Waves meet through
  * LDS counters only — after the table barrier there is no workgroup barrier, so waves of other frames keep
- * computing, loading and storing meanwhile.
+ * computing, loading and storing meanwhile.  The loop is software-pipelined: the next frame's unit record and spectrum
+ * are requested while the current frame's PCM is still being added and stored.
  *
- * One frame is one call of sr_frame (a real call, DP_NOINLINE): inlined into the loop, the compiler hoisted the
- * frame's loop-invariant address arithmetic out of it and spilled 1 KB per lane.  The function re-derives what it needs
- * from the kernel's parameter block (scalar loads) and the wave's position; nothing but t and k crosses the call. */
+ * The translation unit of this kernel defines DP_LANE_OPAQUE (devport.h): with a plain lane number the compiler hoisted
+ * the frame's dozens of lane-derived address patterns out of the loop and spilled 1.2 KB per lane.
+ * Job -1 of a piece of a longer chain (has_pred) redoes the frame before the piece and parks its tails. */
 struct sr_pos { int E, F, C, N, my_r, my_e, pr, pw; };
 DP_DEVICE sr_pos sr_position(const aacg_sr_run* run)
 {
@@ -1960,63 +1964,89 @@ DP_DEVICE sr_pos sr_position(const aacg_sr_run* run)
 }
 
 template <int KIND>
-DP_NOINLINE void sr_frame(int t_in, int k_in)
+DP_DEVICE void imdct_stream_body(const aacg_kparams& P)
 {
-    const aacg_kparams& P = dp_kernarg<aacg_kparams>();
     const int TAB_FLOATS = (KIND == AACG_INPUT_QUANT_I16) ? AACG_TAB_QUANT_FLOATS : AACG_TAB_F32_FLOATS;
-    const int lane = dp_lane(), wave = dp_wave();
-    const int t = dp_uniform(t_in), k = dp_uniform(k_in);
+    const int wave = dp_wave();
     const aacg_sr_run* run = P.sr_runs + dp_block();
     float* lds = (float*)dp_lds();
     const float* tab = lds;
     float* slots = lds + TAB_FLOATS;
-    const sr_pos pos = sr_position(run);
-    const int E = pos.E, F = pos.F, C = pos.C, N = pos.N, my_e = pos.my_e, pr = pos.pr, pw = pos.pw;
-    float* stage = slots + run->stage_off;
-    int* sync = (int*)(stage + AACG_SR_HALF * C);
-    int* ready = sync, * consumed = sync + 16, * turn = sync + 32, * arrived = sync + 33, * done = sync + 34;
-    float* slot = slots + run->slot_off[wave];
-    const float* prev = slots + run->slot_off[pw];
-    const int32_t* uidx = P.sr_units + run->unit_base;
-    float* scratch = P.scratch + ((size_t)dp_block() * AACG_SR_MAX_ELEMENTS + (size_t)my_e) * AACG_SLOT_FLOATS;
+    int* cmap_all = (int*)(slots + run->map_off);
 
-    unit_view u;
-    int n_ch = 0, cls0 = 0, cls1 = 0;
-    bool pair_path = false;
+    dpf4 tr0, tr1;
+    stage_tables_load(P.tab, TAB_FLOATS, tr0, tr1);
+    stage_tables_store(lds, TAB_FLOATS, tr0, tr1);
+    const sr_pos pos = sr_position(run);
+    const int E = pos.E, F = pos.F, C = pos.C, N = pos.N, my_r = pos.my_r, my_e = pos.my_e, pr = pos.pr, pw = pos.pw;
+    {   /* counters, and the channel map: ring position r, channel c -> where the predecessor position's slots hold c */
+        const int tid = dp_tid();
+        if (tid < AACG_SR_SYNC_WORDS) cmap_all[AACG_SR_MAP_WORDS + tid] = 0;
+        if (tid < F * C) {
+            int r = 0;
+            for (int q = 1; q < AACG_WG_WAVES; q++) r += (q * C <= tid) ? 1 : 0;
+            const int c = tid - r * C, rp = r == 0 ? F - 1 : r - 1;
+            int m = 0;
+            for (int e = 0; e < E; e++) {
+                const int c0 = run->elem_ch0[e], nc = run->elem_nch[e];
+                if (c >= c0 && c < c0 + nc) m = (run->slot_off[rp * E + e] + (c - c0)) | (nc << 24);
+            }
+            cmap_all[tid] = m;
+        }
+    }
+    dp_block_sync_lds();
+    if (my_r >= F) return;                              /* waves beyond the ring: nothing after the table barrier needs them */
+
+    const int* cmap = cmap_all + my_r * C;
+    int* sync = cmap_all + AACG_SR_MAP_WORDS;
+    int* ready = sync, * added = sync + 16, * stored = sync + 24;
+    float* slot = slots + run->slot_off[wave];
+    float* prev = slots + run->slot_off[pw];
+    float* scratch = P.scratch + ((size_t)dp_block() * AACG_SR_MAX_ELEMENTS + (size_t)my_e) * AACG_SLOT_FLOATS;
+    const int32_t* uidx = P.sr_units + run->unit_base + my_e;
+    const int succ = my_r + 1 == F ? 0 : my_r + 1;      /* ring position of the frames behind this wave's frames */
+
     quant_regs qreg;
     dpf4 xa[4], xb[4];
-    float hx0[8], hy0[8], hx1[8], hy1[8];
-    auto take_unit = [&](int index) {
-        u = load_unit(P.units + index);
-        n_ch = u.n_ch;
-        cls0 = u.seq[0] == AACG_EIGHT_SHORT_SEQUENCE;
-        cls1 = u.seq[1] == AACG_EIGHT_SHORT_SEQUENCE;
-        pair_path = n_ch == 2 && u.seq[0] == u.seq[1] && u.shape[0] == u.shape[1] && u.shape_prev[0] == u.shape_prev[1];
-        if (KIND == AACG_INPUT_QUANT_I16) quant_load(P, u, u.n_ch, qreg);
+    auto request = [&](const unit_view& v) {            /* the unit's spectrum: in flight until the front end takes it */
+        if (KIND == AACG_INPUT_QUANT_I16) quant_load(P, v, v.n_ch, qreg);
         else {
-            const float* xsrc = (const float*)P.coeffs + (size_t)u.coef_offset * 1024u;
-            const float* xsrc1 = xsrc + (u.n_ch == 2 ? 1024 : 0);
+            const int lane = dp_lane();
+            const float* xsrc = (const float*)P.coeffs + (size_t)v.coef_offset * 1024u;
+            const float* xsrc1 = xsrc + (v.n_ch == 2 ? 1024 : 0);
 #pragma unroll
             for (int i = 0; i < 4; i++) { xa[i] = *(const dpf4*)(xsrc + 4 * lane + 256 * i); xb[i] = *(const dpf4*)(xsrc1 + 4 * lane + 256 * i); }
         }
     };
-    auto save_tails = [&](float* d0, float* d1) {
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int n = 4 * lane + 256 * i;
-            if (n_ch == 2) {
-                const dpf4 a = *(const dpf4*)(slot + 2 * n), b = *(const dpf4*)(slot + 2 * n + 4);
-                dpf4 l4, r4;
-                l4.x = a.x; l4.y = a.z; l4.z = b.x; l4.w = b.z;
-                r4.x = a.y; r4.y = a.w; r4.z = b.y; r4.w = b.w;
-                *(dpf4*)(d0 + n) = l4;
-                *(dpf4*)(d1 + n) = r4;
-            } else {
-                *(dpf4*)(d0 + n) = *(const dpf4*)(slot + n);
-            }
-        }
-    };
-    auto front = [&](bool want_head) {
+
+    /* jobs of this wave: [-1 (piece of a longer chain, ring position 0: the frame before the piece)], my_r, my_r + F, ... */
+    int t = (run->has_pred && my_r == 0) ? -1 : my_r;
+    int k = 0;                                          /* frames this wave has finished */
+    if (t >= N) return;
+    unit_view u = load_unit(P.units + dp_uniform(t < 0 ? run->pred[my_e] : uidx[t * E]));
+    request(u);
+#pragma unroll 1
+    for (;;) {
+        const int lane = dp_lane();
+        /* -DAACG_PROFILE builds: phase timestamps per (workgroup, wave, own frame), tools/timeline_sr.py */
+        unsigned long long* trace = (AACG_ABL(P, 16) && t >= 0) ? (unsigned long long*)P.spec_out + (((size_t)dp_block() * AACG_WG_WAVES + wave) * 8 + (size_t)(k & 7)) * 8 : nullptr;
+        if (trace && lane == 0) trace[0] = dp_clock();
+        const bool pred_pass = t < 0;
+        const int t_next = pred_pass ? my_r : t + F;
+        const bool more = t_next < N;
+        /* the next job's unit index: requested now, used after this frame's IMDCT */
+        const int ui_next = dp_uniform(uidx[(more ? t_next : t < 0 ? 0 : t) * E]);
+        const int n_ch = u.n_ch;
+        const int cls0 = u.seq[0] == AACG_EIGHT_SHORT_SEQUENCE, cls1 = u.seq[1] == AACG_EIGHT_SHORT_SEQUENCE;
+        const bool pair_path = n_ch == 2 && u.seq[0] == u.seq[1] && u.shape[0] == u.shape[1] && u.shape_prev[0] == u.shape_prev[1];
+
+        /* The slot is free once every wave of the frame behind this wave's previous frame has stored (they gather from
+         * all E slots of the ring position).  That frame belongs to the next ring position; after the last position
+         * comes position 0, one round further on. */
+        if (k > 0) dp_flag_wait_ge(&stored[succ], (my_r + 1 == F ? k + 1 : k) * E);
+        if (trace && lane == 0) trace[1] = dp_clock();             /* slot free */
+
+        float hx0[8], hy0[8], hx1[8], hy1[8];
         if (KIND == AACG_INPUT_QUANT_I16) {
             float xl[16], xr[16];
             spectral_quant(P, tab, u, n_ch, qreg, slot + 1024, xl, xr);
@@ -2033,76 +2063,67 @@ DP_NOINLINE void sr_frame(int t_in, int k_in)
             }
         }
         dp_wave_sync();
-        filter_unit(tab, u, n_ch, pair_path, want_head, slot, hx0, hy0, hx1, hy1);
-    };
+        filter_unit(tab, u, n_ch, pair_path, !pred_pass, slot, hx0, hy0, hx1, hy1);
+        dp_wave_sync();
 
-    const int ui = dp_uniform(uidx[t * E + my_e]);
-    const bool dd = run->has_pred != 0 && t == 0;       /* piece of a longer chain: redo the frame before it first */
-    take_unit(dd ? run->pred[my_e] : ui);
-    /* the slot is free once the ring successor has taken the tails of this wave's previous frame */
-    if (k > 0) dp_flag_wait_ge(&consumed[wave], k);
-    front(!dd);
-    if (dd) {
-        dp_keep_branch();
-        dp_wave_sync();
-        save_tails(scratch, scratch + 1024);
-        take_unit(ui);
-        dp_wave_sync();
-        front(true);
-    }
-    dp_wave_sync();
-    if (lane == 0) dp_flag_set(&ready[wave], k + 1);               /* tails of frame t are in the slot (release) */
-
-    /* incoming tails: the overlap state (first frame of the chain in this launch; the parked tails of a piece's
-     * predecessor), else the ring predecessor's slot once it has released frame t - 1 */
-    const float* ov0 = dd ? scratch : P.overlap + (P.flip ? run->ov_b[my_e][0] : run->ov_a[my_e][0]);
-    const float* ov1 = dd ? scratch + 1024 : P.overlap + (P.flip ? run->ov_b[my_e][1] : run->ov_a[my_e][1]);
-    const int kp = t > 0 ? (t - 1 - pr) / F + 1 : 0;                /* frames the predecessor has released by then */
-    if (t > 0) dp_flag_wait_ge(&ready[pw], kp);
-    const uint32_t frame_pcm = u.pcm_offset;
-#pragma unroll 1
-    for (int half = 0; half < 2; half++) {
-        const int tn = 2 * t + half;
-        dp_flag_wait_ge(turn, tn);                                 /* the staging area is this frame's, this half's */
-        if (t == 0) sr_stage_unit<false>(ov0, ov1, u, n_ch, cls0, cls1, stage, half, hx0, hy0, hx1, hy1);
-        else        sr_stage_unit<true>(prev, prev, u, n_ch, cls0, cls1, stage, half, hx0, hy0, hx1, hy1);
-        dp_wave_sync();
-        if (lane == 0) dp_flag_add(arrived, 1);
-        dp_flag_wait_ge(arrived, (tn + 1) * E);                    /* all E waves of the frame have staged this half */
-        {
-            const int n4 = (AACG_SR_HALF * C) >> 2;                /* 16-byte pieces of this half: C * 128 */
-            float* dst = P.pcm + frame_pcm + (size_t)half * AACG_SR_HALF * C;
-            for (int i = my_e * 64 + lane; i < n4; i += 64 * E) dp_store_nt((dpf4*)(dst + 4 * i), *(const dpf4*)(stage + 4 * i));
+        auto save_tails = [&](float* d0, float* d1) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int n = 4 * lane + 256 * i;
+                if (n_ch == 2) {
+                    const dpf4 a = *(const dpf4*)(slot + 2 * n), b = *(const dpf4*)(slot + 2 * n + 4);
+                    dpf4 l4, r4;
+                    l4.x = a.x; l4.y = a.z; l4.z = b.x; l4.w = b.z;
+                    r4.x = a.y; r4.y = a.w; r4.z = b.y; r4.w = b.w;
+                    *(dpf4*)(d0 + n) = l4;
+                    *(dpf4*)(d1 + n) = r4;
+                } else {
+                    *(dpf4*)(d0 + n) = *(const dpf4*)(slot + n);
+                }
+            }
+        };
+        /* the next job's unit record (scalar loads; the index has arrived by now) */
+        const unit_view u_next = load_unit(P.units + ui_next);
+        if (pred_pass) {                                           /* park the tails: frame 0 of the piece starts from them */
+            save_tails(scratch, scratch + 1024);
+            dp_wave_sync();
+            request(u_next);
+        } else {
+            if (lane == 0) dp_flag_set(&ready[wave], k + 1);       /* tails of frame t are in the slot (release) */
+            if (trace && lane == 0) trace[2] = dp_clock();         /* IMDCT done */
+            const uint32_t frame_pcm = u.pcm_offset;
+            if (t == 0) {
+                /* the run's first frame has no predecessor slot: overlap state from HBM (filter_bank.js:38-41; the tails
+                 * the pred pass parked, for a piece of a longer chain), strided stores like an element-major run */
+                const bool parked = run->has_pred != 0;
+                const float* ov0 = parked ? scratch : P.overlap + (P.flip ? run->ov_b[my_e][0] : run->ov_a[my_e][0]);
+                const float* ov1 = parked ? scratch + 1024 : P.overlap + (P.flip ? run->ov_b[my_e][1] : run->ov_a[my_e][1]);
+                epilogue<false>(ov0, ov1, u, n_ch, cls0, cls1, P.pcm, hx0, hy0, hx1, hy1);
+                request(u_next);
+                if (lane == 0) { dp_flag_add(&added[my_r], 1); dp_flag_add(&stored[my_r], 1); }   /* the counts stay per frame */
+            } else {
+                dp_flag_wait_ge(&ready[pw], (t - 1 - pr) / F + 1);     /* the ring predecessor has released frame t - 1 */
+                if (trace && lane == 0) trace[3] = dp_clock();
+                sr_overlap_add(prev, n_ch, cls0, cls1, hx0, hy0, hx1, hy1);
+                dp_wave_sync();
+                if (lane == 0) dp_flag_add(&added[my_r], 1);
+                request(u_next);                                       /* in flight while the frame is stored */
+                dp_flag_wait_ge(&added[my_r], (k + 1) * E);            /* all E elements of the frame are finished PCM */
+                if (trace && lane == 0) trace[4] = dp_clock();
+                sr_store_frame(slots, cmap, C, E, my_e, run->step_q, run->step_r, P.pcm + frame_pcm);
+                dp_wave_sync();
+                if (lane == 0) dp_flag_add(&stored[my_r], 1);          /* the predecessors may overwrite their slots */
+            }
+            if (trace && lane == 0) trace[6] = dp_clock();
+            /* the last frame of a chain's last run: its tails are the new overlap state (planar in HBM) */
+            if (t == N - 1 && run->is_last)
+                save_tails(P.overlap + (P.flip ? run->ov_a[my_e][0] : run->ov_b[my_e][0]), P.overlap + (P.flip ? run->ov_a[my_e][1] : run->ov_b[my_e][1]));
+            k++;
         }
-        dp_wave_sync();
-        if (lane == 0 && dp_flag_add(done, 1) == (tn + 1) * E - 1) dp_flag_set(turn, tn + 1);
+        if (!more) break;
+        t = t_next;
+        u = u_next;
     }
-    if (t > 0 && lane == 0) dp_flag_set(&consumed[pw], kp);        /* the predecessor may overwrite its slot */
-
-    /* the last frame of a chain's last run: its tails are the new overlap state (planar in HBM) */
-    if (t == N - 1 && run->is_last)
-        save_tails(P.overlap + (P.flip ? run->ov_a[my_e][0] : run->ov_b[my_e][0]), P.overlap + (P.flip ? run->ov_a[my_e][1] : run->ov_b[my_e][1]));
-}
-
-template <int KIND>
-DP_DEVICE void imdct_stream_body(const aacg_kparams& P)
-{
-    const int TAB_FLOATS = (KIND == AACG_INPUT_QUANT_I16) ? AACG_TAB_QUANT_FLOATS : AACG_TAB_F32_FLOATS;
-    const aacg_sr_run* run = P.sr_runs + dp_block();
-    float* lds = (float*)dp_lds();
-    int* sync = (int*)(lds + TAB_FLOATS + run->stage_off + AACG_SR_HALF * run->n_out_ch);
-
-    dpf4 tr0, tr1;
-    stage_tables_load(P.tab, TAB_FLOATS, tr0, tr1);
-    stage_tables_store(lds, TAB_FLOATS, tr0, tr1);
-    if (dp_tid() < AACG_SR_SYNC_WORDS) sync[dp_tid()] = 0;
-    dp_block_sync_lds();
-
-    const sr_pos pos = sr_position(run);
-    if (pos.my_r >= pos.F) return;                      /* waves beyond the ring: nothing after the table barrier needs them */
-    int k = 0;                                          /* frames this wave has finished */
-#pragma unroll 1
-    for (int t = pos.my_r; t < pos.N; t += pos.F, k++) sr_frame<KIND>(t, k);
 }
 
 /* Spectral stage alone (16 units per workgroup, one wave each): spec_out in ICStream.data order. */

@@ -217,7 +217,7 @@ int aacg_plan_build(const aacg_unit_desc* units, uint32_t n_units, int sample_in
 
     /* Multichannel streams go stream-resident (aacg_sr_run): one workgroup walks the stream's frames with all elements
      * of a frame side by side, so that the PCM can be interleaved in LDS and stored as full lines, and no frame inside a
-     * run is ever recomputed.  Needs every channel of every frame written (the staging area is stored as it is),
+     * run is ever recomputed.  Needs every channel of every frame written (a frame is stored as one block),
      * 16-byte aligned frames, 2..8 elements, room for two frames in flight.  AACG_SR=0 in the environment keeps such
      * streams on element-major runs (A/B measurements). */
     static const bool sr_enabled = [] { const char* v = std::getenv("AACG_SR"); return !(v && v[0] == '0'); }();
@@ -228,9 +228,9 @@ int aacg_plan_build(const aacg_unit_desc* units, uint32_t n_units, int sample_in
     };
     auto sr_ring = [&](uint32_t stream) {
         const stream_state& s = st[stream];
-        /* frames in flight: as many as the waves and the LDS allow (slots of a frame + staging + counters; the larger,
-         * quantised-input table set is assumed) */
-        const int budget = 160 * 1024 / 4 - AACG_TAB_QUANT_FLOATS - AACG_SR_HALF * (int)s.n_out - AACG_SR_SYNC_WORDS;
+        /* frames in flight: as many as the waves and the LDS allow (slots of a frame + channel map + counters; the
+         * larger, quantised-input table set is assumed) */
+        const int budget = 160 * 1024 / 4 - AACG_TAB_QUANT_FLOATS - AACG_SR_MAP_WORDS - AACG_SR_SYNC_WORDS;
         return std::min<int>(AACG_RUN_W / (int)s.n_chains, budget / sr_frame_floats(stream));
     };
     std::vector<uint8_t> sr_flag((size_t)max_streams, 0);
@@ -268,11 +268,13 @@ int aacg_plan_build(const aacg_unit_desc* units, uint32_t n_units, int sample_in
                     off += open[keys[(size_t)e]].n_ch == 2 ? AACG_SLOT_FLOATS : 1536;
                 }
             for (int w = F * E; w < AACG_RUN_W; w++) r.slot_off[w] = 0;        /* waves beyond the ring never touch a slot */
-            r.stage_off = off;
+            r.map_off = off;
+            r.step_q = 256 * E / C; r.step_r = 256 * E % C;
             for (int e = 0; e < E; e++) {
                 const open_chain& oc = open[keys[(size_t)e]];
                 const uint32_t channel = (uint32_t)(keys[(size_t)e] & 0xffff);
                 r.pred[e] = t0 ? oc.units[t0 - 1] : -1;
+                r.elem_ch0[e] = (uint8_t)channel; r.elem_nch[e] = oc.n_ch;
                 for (int c = 0; c < 2; c++) {
                     const uint32_t chn = channel + (c < oc.n_ch ? c : 0);
                     const int par = parity ? parity[(size_t)stream * (size_t)max_channels + chn] : 0;
@@ -280,7 +282,7 @@ int aacg_plan_build(const aacg_unit_desc* units, uint32_t n_units, int sample_in
                     r.ov_b[e][c] = aacg_ov_offset(max_channels, stream, chn, par ^ 1);
                 }
             }
-            out->sr_lds_floats = std::max(out->sr_lds_floats, (uint32_t)(off + AACG_SR_HALF * C + AACG_SR_SYNC_WORDS));
+            out->sr_lds_floats = std::max(out->sr_lds_floats, (uint32_t)(off + AACG_SR_MAP_WORDS + AACG_SR_SYNC_WORDS));
             if (r.has_pred) out->sr_needs_scratch = true;
             out->sr_runs.push_back(r);
         }

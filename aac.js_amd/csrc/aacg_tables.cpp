@@ -127,10 +127,12 @@ int aacg_build_tables(int sample_index, aacg_tables* t, aacg_host_windows* hw)
     kbd_window(w.kbd_long, 4.0, 1024);       /* filter_bank.js:83 */
     kbd_window(w.kbd_short, 6.0, 128);       /* filter_bank.js:84 */
     if (hw) *hw = w;
-    std::memcpy(t->win_long[0], w.sine_long, sizeof w.sine_long);
-    std::memcpy(t->win_long[1], w.kbd_long, sizeof w.kbd_long);
-    std::memcpy(t->win_short[0], w.sine_short, sizeof w.sine_short);
-    std::memcpy(t->win_short[1], w.kbd_short, sizeof w.kbd_short);
+    /* The device copies carry the output scale 1/32768 of decoder.js:211 (AACG_PCM_SCALE, a power of two: exact), so that
+     * windowed heads and tails are PCM-scaled where they are made and the overlap-add is a bare addition:
+     * (ov + x w) / 32768 == ov / 32768 + x (w / 32768) bit for bit.  The overlap state in HBM is at that scale too
+     * (aacg_get / set_overlap convert). */
+    for (int i = 0; i < 1024; i++) { t->win_long[0][i] = w.sine_long[i] * AACG_PCM_SCALE; t->win_long[1][i] = w.kbd_long[i] * AACG_PCM_SCALE; }
+    for (int i = 0; i < 128; i++) { t->win_short[0][i] = w.sine_short[i] * AACG_PCM_SCALE; t->win_short[1][i] = w.kbd_short[i] * AACG_PCM_SCALE; }
 
     for (int i = 0; i < 8191; i++) t->iq[i] = (float)std::pow((double)i, 4.0 / 3.0);
     t->iq[8191] = std::numeric_limits<float>::quiet_NaN();

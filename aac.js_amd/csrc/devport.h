@@ -24,10 +24,17 @@
 /* a real function call: the body of a loop whose iterations must not share hoisted address arithmetic (the frame
  * loop of the stream-resident kernel spilled 1 KB per lane when it was inlined) */
 #define DP_NOINLINE __device__ __attribute__((noinline))
-/* the kernel's (single, by-value) parameter block as it lies in the kernarg segment: a called function reads it with
- * scalar loads instead of receiving a per-lane copy */
+/* The kernel's (single, by-value) parameter block as it lies in the kernarg segment.  dp_kernarg_addr(): its address,
+ * valid in the kernel function itself only (a called function does not inherit the segment pointer); dp_kernarg_at():
+ * the block behind that address in a called function — the address arrives in a VGPR pair, is made wave-uniform again and
+ * points into the constant address space, so the fields are read with scalar loads, not copied per lane. */
+DP_DEVICE unsigned long long dp_kernarg_addr() { return (unsigned long long)(uintptr_t)__builtin_amdgcn_kernarg_segment_ptr(); }
 template <class T>
-DP_DEVICE const T& dp_kernarg() { return *(const T*)__builtin_amdgcn_kernarg_segment_ptr(); }
+DP_DEVICE const T& dp_kernarg_at(unsigned long long a)
+{
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32));
+    return *(const T*)(const __attribute__((address_space(4))) T*)(uintptr_t)(((unsigned long long)hi << 32) | lo);
+}
 
 typedef float2 dpf2;
 typedef float4 dpf4;
@@ -37,7 +44,14 @@ typedef uint2  dpu2;
 typedef float dpv2 __attribute__((ext_vector_type(2)));
 
 DP_DEVICE int dp_tid()   { return (int)threadIdx.x; }
+#ifdef DP_LANE_OPAQUE
+/* The lane number recomputed wherever it is asked for (two VALU instructions the optimiser may neither hoist nor share):
+ * inside a loop over frames this keeps the dozens of lane-derived address patterns of a frame from being hoisted out of
+ * the loop and spilled — the stream-resident kernel's translation unit defines DP_LANE_OPAQUE. */
+DP_DEVICE int dp_lane()  { int l; asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l)); return l; }
+#else
 DP_DEVICE int dp_lane()  { return (int)(threadIdx.x & 63u); }
+#endif
 DP_DEVICE int dp_wave()  { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 DP_DEVICE int dp_block() { return (int)blockIdx.x; }
 /* make a wave-uniform value provably uniform (lets hipcc use scalar loads behind it) */

@@ -48,8 +48,9 @@ struct emu_lane_ctx {
 };
 extern thread_local emu_lane_ctx g_emu;
 
+DP_DEVICE unsigned long long dp_kernarg_addr() { return (unsigned long long)(uintptr_t)g_emu.kernarg; }
 template <class T>
-DP_DEVICE const T& dp_kernarg() { return *(const T*)g_emu.kernarg; }
+DP_DEVICE const T& dp_kernarg_at(unsigned long long a) { return *(const T*)(uintptr_t)a; }
 DP_DEVICE int dp_tid()   { return g_emu.wave * 64 + g_emu.lane; }
 DP_DEVICE int dp_lane()  { return g_emu.lane; }
 DP_DEVICE int dp_wave()  { return g_emu.wave; }

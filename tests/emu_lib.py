@@ -77,12 +77,13 @@ class Emu:
 
 
 def pool_current(pool, parity):
-    """[S][C][1024] view of the live overlap buffers."""
+    """[S][C][1024] copy of the live overlap buffers at the reference's scale (the pool is PCM-scaled, like the engine's:
+    aacg_get_overlap multiplies by 32768 too)."""
     S, Cn = pool.shape[:2]
     out = np.empty((S, Cn, 1024), np.float32)
     for s in range(S):
         for c in range(Cn):
-            out[s, c] = pool[s, c, parity[s * Cn + c]]
+            out[s, c] = pool[s, c, parity[s * Cn + c]] * np.float32(32768.0)
     return out
 
 
