@@ -152,6 +152,8 @@ DP_DEVICE void dp_store_nt(dpf4* p, dpf4 v)
  * global_store_dwordx2 — gfx950 runs in unaligned-access mode, and the type says align 4 */
 typedef float dp_f2u __attribute__((ext_vector_type(2), aligned(4)));
 DP_DEVICE void dp_store2_u(float* p, float a, float b) { dp_f2u v; v[0] = a; v[1] = b; *(dp_f2u*)p = v; }
+DP_DEVICE void dp_store2_u_nt(float* p, float a, float b) { dp_f2u v; v[0] = a; v[1] = b; __builtin_nontemporal_store(v, (dp_f2u*)p); }
+DP_DEVICE void dp_store1_nt(float* p, float a) { __builtin_nontemporal_store(a, p); }
 /* constant-rate (100 MHz) wall clock, same time base on every CU: phase timelines for profiling */
 DP_DEVICE unsigned long long dp_clock() { return wall_clock64(); }
 /* keep the instruction scheduler from hoisting the next block's loads above this point
