@@ -107,37 +107,6 @@ struct aacg_run {
     int32_t reserved;
 };
 
-/* Stream-resident run (multichannel streams: n_out_ch > 2 with several elements per frame): ONE workgroup walks the
- * frames of one stream.  Its E elements x F frames in flight (E * F <= 16 waves) form a ring: wave r * E + e takes
- * element e of frames r, r + F, r + 2F, ... and receives the tails of frame t - 1 from wave ((r - 1) mod F) * E + e
- * through LDS — no frame is ever recomputed inside a run, the tables are staged once, and while the waves of some
- * frames compute, those of others load and store.  The overlap-add happens in place: a wave adds its windowed first
- * half onto the tails in its ring predecessor's slot, which then holds the frame's finished PCM for that element; the
- * E waves of the frame meet, and each stores a quarter of the frame's interleaved [1024][C] block as contiguous
- * 16-byte pieces gathered from the E slots — full lines (a wave on its own can only write its 1-2 channels of every
- * sample: 8-byte pieces at a stride of n_out_ch floats, which is bound by the L2's write-request rate, not by bytes).
- * Only the first frame of a run has no predecessor slot and stores the old way.  A run may be a piece of a longer
- * chain (has_pred): its ring-0 waves then first redo the frame before it, as the element-major runs do. */
-#define AACG_SR_MAX_ELEMENTS 8
-#define AACG_SR_MAP_WORDS    64       /* channel map: [ring][channel] -> float offset of that channel's samples in the ring
-                                         predecessor's slots | samples' stride << 24 */
-#define AACG_SR_SYNC_WORDS   32       /* [0..15] tails released (count per wave), [16..23] waves of the ring position's
-                                         frames that have done their overlap-add, [24..31] ... that have stored */
-struct aacg_sr_run {
-    int32_t n_elem, ring;             /* E, F */
-    int32_t n_frames;                 /* frames of this run, any number */
-    int32_t has_pred, is_last;
-    int32_t n_out_ch;
-    int32_t map_off;                  /* float offset of the channel map (then the counters) behind the slots */
-    int32_t unit_base;                /* unit of (frame t, element e) = sr_units[unit_base + t * E + e] */
-    int32_t step_q, step_r;           /* (256 * E) / C and % C: a lane's advance from one 16-byte piece to its next */
-    int32_t slot_off[AACG_RUN_W];     /* float offset of wave w's slot in the slot area (CPE 2048, single channel 1536) */
-    int32_t pred[AACG_SR_MAX_ELEMENTS];
-    uint8_t elem_ch0[AACG_SR_MAX_ELEMENTS], elem_nch[AACG_SR_MAX_ELEMENTS];   /* first output channel and width of element e */
-    int32_t ov_a[AACG_SR_MAX_ELEMENTS][2];
-    int32_t ov_b[AACG_SR_MAX_ELEMENTS][2];
-};
-
 struct aacg_kparams {
     const aacg_dev_unit*  units;
     const aacg_run*       runs;
@@ -154,8 +123,6 @@ struct aacg_kparams {
     int32_t               reserved;
     float*                scratch;    /* [n_runs][2048]: parked predecessor tails of double-duty runs (last: the plain kernels never load it) */
     const aacg_pns_tables* pns;       /* AACG_PNS_SPEC: the spectral stage's noise tables */
-    const aacg_sr_run*    sr_runs;    /* stream-resident runs of multichannel streams (their own kernel) */
-    const int32_t*        sr_units;   /* their unit index table */
 };
 
 /* ---- device front end (aacg_parse.h) ------------------------------------------------------------ */

@@ -32,9 +32,6 @@ void aacg_imdct_run_f32(const aacg_kparams P) { imdct_run_body<AACG_INPUT_SPEC_F
 int aacg_ext_set_lds_limits(void);
 void aacg_ext_launch(bool quant, dim3 grid, dim3 block, hipStream_t s, const aacg_kparams& P);
 /* aacg_engine_spectral.hip: the optional stages (AACG_PNS_SPEC noise bands, AACG_TNS_SPEC filters) -> f32 spectra */
-/* aacg_engine_stream.hip: stream-resident runs of multichannel streams */
-int aacg_sr_set_lds_limits(void);
-int aacg_sr_launch(bool quant, unsigned n_runs, unsigned lds_floats, hipStream_t s, const aacg_kparams& P);
 void aacg_refresh_launch(aacg_dev_unit* units, const aacg_unit_desc* parsed, const aacg_parse_result* results, uint32_t n_units,
                          uint32_t max_units, int refuse_pns, uint32_t* refused, hipStream_t s);
 int aacg_spectral_ex_set_lds_limits(void);
@@ -63,8 +60,6 @@ struct aacg_engine {
         bool busy = false;
         void* d_units = nullptr;  size_t units_cap = 0;
         void* d_runs = nullptr;   size_t runs_cap = 0;
-        void* d_sr_runs = nullptr; size_t sr_runs_cap = 0;
-        void* d_sr_units = nullptr; size_t sr_units_cap = 0;
         void* d_coeffs = nullptr; size_t coeffs_cap = 0;
         void* d_meta = nullptr;   size_t meta_cap = 0;
         void* d_tns = nullptr;    size_t tns_cap = 0;
@@ -95,12 +90,10 @@ struct aacg_plan {
     uint32_t n_units = 0;
     aacg_dev_unit* d_units = nullptr;
     aacg_run* d_runs = nullptr;
-    aacg_sr_run* d_sr_runs = nullptr;
-    int32_t* d_sr_units = nullptr;
     aacg_dev_tns* d_tns = nullptr;
     float* d_scratch = nullptr;             /* parked predecessor tails of double-duty runs */
     float* d_spec = nullptr;                /* PNS route: f32 spectra between the two kernels */
-    size_t bytes[7] = {0, 0, 0, 0, 0, 0, 0};   /* sizes of the seven buffers above, for the engine's free list */
+    size_t bytes[5] = {0, 0, 0, 0, 0};      /* sizes of the five buffers above, for the engine's free list */
     hipEvent_t uploaded = nullptr;          /* the tables are on the device */
     hipEvent_t last_use = nullptr;          /* recorded at destruction on last_stream: everything launched with this plan */
     hipStream_t last_stream = nullptr;      /* stream of the most recent launch (no per-launch event: it costs 3 us per step) */
@@ -174,7 +167,7 @@ bool is_pinned(const void* p)
 }
 
 /* enqueue the run kernel for a planned batch (device pointers) */
-int launch_run(aacg_engine* e, const aacg_dev_unit* d_units, const aacg_run* d_runs, const aacg_sr_run* d_sr_runs, const int32_t* d_sr_units, const aacg_dev_tns* d_tns,
+int launch_run(aacg_engine* e, const aacg_dev_unit* d_units, const aacg_run* d_runs, const aacg_dev_tns* d_tns,
                float* d_scratch, float* d_spec, const aacg_plan_host& h, const void* d_coeffs, const aacg_band_meta* d_meta,
                float* d_pcm, int flip, hipStream_t s)
 {
@@ -184,8 +177,7 @@ int launch_run(aacg_engine* e, const aacg_dev_unit* d_units, const aacg_run* d_r
     aacg_kparams P;
     P.units = d_units; P.runs = d_runs; P.coeffs = d_coeffs; P.meta = d_meta; P.pcm = d_pcm;
     P.tns = h.any_tns ? d_tns : nullptr;
-    P.scratch = (h.needs_scratch || h.sr_needs_scratch) ? d_scratch : nullptr;
-    P.sr_runs = d_sr_runs; P.sr_units = d_sr_units;
+    P.scratch = h.needs_scratch ? d_scratch : nullptr;
     P.pns = nullptr;
     P.overlap = e->d_overlap; P.spec_out = nullptr; P.tab = e->d_tab;
     P.flip = flip; P.n_runs = (int32_t)h.runs.size();
@@ -207,10 +199,6 @@ int launch_run(aacg_engine* e, const aacg_dev_unit* d_units, const aacg_run* d_r
             if (quant) hipLaunchKernelGGL(aacg_imdct_run_quant, grid, block, AACG_LDS_BYTES_QUANT, s, P);
             else       hipLaunchKernelGGL(aacg_imdct_run_f32, grid, block, AACG_LDS_BYTES_F32, s, P);
         }
-    }
-    if (!h.sr_runs.empty() && aacg_sr_launch(quant, (unsigned)h.sr_runs.size(), h.sr_lds_floats, s, P) != 0) {
-        e->err = "a stream-resident run does not fit the LDS";
-        return AACG_ERR_CAPACITY;
     }
     HIP_TRY(e, hipGetLastError(), AACG_ERR_NO_DEVICE);
     return AACG_OK;
@@ -257,7 +245,7 @@ int aacg_create(const aacg_config* cfg, aacg_engine** out)
         /* ~158 KiB of dynamic LDS per workgroup is above the 64 KiB default limit */
         !hip_ok(e, hipFuncSetAttribute((const void*)aacg_imdct_run_quant, hipFuncAttributeMaxDynamicSharedMemorySize, AACG_LDS_BYTES_QUANT), "LDS attr") ||
         !hip_ok(e, hipFuncSetAttribute((const void*)aacg_imdct_run_f32, hipFuncAttributeMaxDynamicSharedMemorySize, AACG_LDS_BYTES_F32), "LDS attr") ||
-        aacg_ext_set_lds_limits() != 0 || aacg_spectral_ex_set_lds_limits() != 0 || aacg_sr_set_lds_limits() != 0 ||
+        aacg_ext_set_lds_limits() != 0 || aacg_spectral_ex_set_lds_limits() != 0 ||
         !hip_ok(e, hipFuncSetAttribute((const void*)aacg_spectral, hipFuncAttributeMaxDynamicSharedMemorySize, AACG_LDS_BYTES_SPECTRAL), "LDS attr")) {
         std::fprintf(stderr, "aacgpu: %s\n", e->err.c_str());
         aacg_destroy(e);
@@ -289,7 +277,7 @@ void aacg_destroy(aacg_engine* e)
     if (e->d_pns) (void)hipFree(e->d_pns);
     if (e->d_overlap) (void)hipFree(e->d_overlap);
     for (auto& sl : e->slot) {
-        for (void* p : {sl.d_units, sl.d_runs, sl.d_sr_runs, sl.d_sr_units, sl.d_coeffs, sl.d_meta, sl.d_tns, sl.d_scratch, sl.d_spec, sl.d_pcm}) if (p) (void)hipFree(p);
+        for (void* p : {sl.d_units, sl.d_runs, sl.d_coeffs, sl.d_meta, sl.d_tns, sl.d_scratch, sl.d_spec, sl.d_pcm}) if (p) (void)hipFree(p);
         if (sl.h_in) (void)hipHostFree(sl.h_in);
         if (sl.h_pcm) (void)hipHostFree(sl.h_pcm);
         if (sl.done) (void)hipEventDestroy(sl.done);
@@ -400,18 +388,16 @@ int aacg_plan_create_tns(aacg_engine* e, const aacg_unit_desc* units, uint32_t n
         return AACG_ERR_UNSUPPORTED;
     }
     const size_t ub = sizeof(aacg_dev_unit) * n_units, rb = sizeof(aacg_run) * p->h.runs.size();
-    const size_t fb = sizeof(aacg_sr_run) * p->h.sr_runs.size(), ib = sizeof(int32_t) * p->h.sr_units.size();
     const size_t xb = (p->h.any_pns || p->h.any_tns) ? (size_t)p->h.coef_blocks * 1024u * sizeof(float) : 0;
     const size_t tb = sizeof(aacg_dev_tns) * p->h.tns.size();
-    const size_t sb = std::max(p->h.needs_scratch ? p->h.runs.size() * AACG_SLOT_FLOATS * sizeof(float) : 0,
-                               p->h.sr_needs_scratch ? p->h.sr_runs.size() * AACG_SR_MAX_ELEMENTS * AACG_SLOT_FLOATS * sizeof(float) : 0);
+    const size_t sb = p->h.needs_scratch ? p->h.runs.size() * AACG_SLOT_FLOATS * sizeof(float) : 0;
     bool ok = hip_ok(e, hipSetDevice(e->cfg.device_ordinal), "hipSetDevice") &&
               hip_ok(e, hipEventCreateWithFlags(&p->uploaded, hipEventDisableTiming), "hipEventCreate") &&
               hip_ok(e, hipEventCreateWithFlags(&p->last_use, hipEventDisableTiming), "hipEventCreate");
-    const size_t want[7] = {ub, rb, fb, tb, sb, xb, ib};
-    void** const slot[7] = {(void**)&p->d_units, (void**)&p->d_runs, (void**)&p->d_sr_runs, (void**)&p->d_tns, (void**)&p->d_scratch, (void**)&p->d_spec, (void**)&p->d_sr_units};
-    const void* const src[7] = {p->h.units.data(), p->h.runs.data(), p->h.sr_runs.data(), p->h.tns.data(), nullptr, nullptr, p->h.sr_units.data()};
-    for (int i = 0; i < 7 && ok; i++) {
+    const size_t want[5] = {ub, rb, tb, sb, xb};
+    void** const slot[5] = {(void**)&p->d_units, (void**)&p->d_runs, (void**)&p->d_tns, (void**)&p->d_scratch, (void**)&p->d_spec};
+    const void* const src[5] = {p->h.units.data(), p->h.runs.data(), p->h.tns.data(), nullptr, nullptr};
+    for (int i = 0; i < 5 && ok; i++) {
         if (!want[i]) continue;
         *slot[i] = pool_take(e, want[i], &p->bytes[i]);
         ok = *slot[i] != nullptr &&
@@ -441,8 +427,8 @@ void aacg_plan_destroy(aacg_plan* p)
         }
         (void)hipEventDestroy(p->last_use);
     }
-    void* const ptr[7] = {p->d_units, p->d_runs, p->d_sr_runs, p->d_tns, p->d_scratch, p->d_spec, p->d_sr_units};
-    for (int i = 0; i < 7; i++) pool_give(e, ptr[i], p->bytes[i]);
+    void* const ptr[5] = {p->d_units, p->d_runs, p->d_tns, p->d_scratch, p->d_spec};
+    for (int i = 0; i < 5; i++) pool_give(e, ptr[i], p->bytes[i]);
     delete p;
 }
 
@@ -469,7 +455,7 @@ int aacg_decode_device(aacg_engine* e, aacg_plan* p, const void* d_coeffs, const
     if (rc) return rc;
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : e->stream;
     if (!p->used) HIP_TRY(e, hipStreamWaitEvent(s, p->uploaded, 0), AACG_ERR_NO_DEVICE);
-    rc = launch_run(e, p->d_units, p->d_runs, p->d_sr_runs, p->d_sr_units, p->d_tns, p->d_scratch, p->d_spec, p->h, d_coeffs, d_meta, d_pcm, (int)(p->launches & 1u), s);
+    rc = launch_run(e, p->d_units, p->d_runs, p->d_tns, p->d_scratch, p->d_spec, p->h, d_coeffs, d_meta, d_pcm, (int)(p->launches & 1u), s);
     if (rc) return rc;
     p->last_stream = s;
     p->used = true;
@@ -614,16 +600,13 @@ int aacg_submit_tns(aacg_engine* e, const aacg_unit_desc* units, uint32_t n_unit
     }
 
     const size_t ub = sizeof(aacg_dev_unit) * h.units.size(), rb = sizeof(aacg_run) * h.runs.size();
-    const size_t fb = sizeof(aacg_sr_run) * h.sr_runs.size(), ib = sizeof(int32_t) * h.sr_units.size();
     const size_t tb = sizeof(aacg_dev_tns) * h.tns.size();
-    const size_t sb = std::max(h.needs_scratch ? h.runs.size() * AACG_SLOT_FLOATS * sizeof(float) : 0,
-                               h.sr_needs_scratch ? h.sr_runs.size() * AACG_SR_MAX_ELEMENTS * AACG_SLOT_FLOATS * sizeof(float) : 0);
+    const size_t sb = h.needs_scratch ? h.runs.size() * AACG_SLOT_FLOATS * sizeof(float) : 0;
     const size_t xb = (h.any_pns || h.any_tns) ? (size_t)n_coef_blocks * 1024u * sizeof(float) : 0;
     const size_t cb = (size_t)n_coef_blocks * 1024u * coef_elem_size(e);
     const size_t mb = quant ? (size_t)n_meta * sizeof(aacg_band_meta) : 0;
     const size_t pb = h.pcm_floats * sizeof(float);
     if ((rc = grow(e, &sl.d_units, &sl.units_cap, ub)) || (rb && (rc = grow(e, &sl.d_runs, &sl.runs_cap, rb))) ||
-        (fb && (rc = grow(e, &sl.d_sr_runs, &sl.sr_runs_cap, fb))) || (ib && (rc = grow(e, &sl.d_sr_units, &sl.sr_units_cap, ib))) ||
         (rc = grow(e, &sl.d_coeffs, &sl.coeffs_cap, cb)) || (quant && (rc = grow(e, &sl.d_meta, &sl.meta_cap, mb))) ||
         (tb && (rc = grow(e, &sl.d_tns, &sl.tns_cap, tb))) || (sb && (rc = grow(e, &sl.d_scratch, &sl.scratch_cap, sb))) || (xb && (rc = grow(e, &sl.d_spec, &sl.spec_cap, xb))) || (rc = grow(e, &sl.d_pcm, &sl.pcm_cap, pb)))
         return rc;
@@ -651,15 +634,13 @@ int aacg_submit_tns(aacg_engine* e, const aacg_unit_desc* units, uint32_t n_unit
     }
     HIP_TRY(e, hipMemcpyAsync(sl.d_units, h.units.data(), ub, hipMemcpyHostToDevice, s), AACG_ERR_NO_DEVICE);
     if (rb) HIP_TRY(e, hipMemcpyAsync(sl.d_runs, h.runs.data(), rb, hipMemcpyHostToDevice, s), AACG_ERR_NO_DEVICE);
-    if (fb) HIP_TRY(e, hipMemcpyAsync(sl.d_sr_runs, h.sr_runs.data(), fb, hipMemcpyHostToDevice, s), AACG_ERR_NO_DEVICE);
-    if (ib) HIP_TRY(e, hipMemcpyAsync(sl.d_sr_units, h.sr_units.data(), ib, hipMemcpyHostToDevice, s), AACG_ERR_NO_DEVICE);
     if (tb) HIP_TRY(e, hipMemcpyAsync(sl.d_tns, h.tns.data(), tb, hipMemcpyHostToDevice, s), AACG_ERR_NO_DEVICE);
     HIP_TRY(e, hipMemcpyAsync(sl.d_coeffs, src_coeffs, cb, hipMemcpyHostToDevice, s), AACG_ERR_NO_DEVICE);
     if (quant) HIP_TRY(e, hipMemcpyAsync(sl.d_meta, src_meta, mb, hipMemcpyHostToDevice, s), AACG_ERR_NO_DEVICE);
     /* kernels chain through the overlap state: this one starts after the previous batch's kernel,
      * while its uploads above overlapped it */
     if (e->last_kernel) HIP_TRY(e, hipStreamWaitEvent(s, e->last_kernel, 0), AACG_ERR_NO_DEVICE);
-    rc = launch_run(e, (const aacg_dev_unit*)sl.d_units, (const aacg_run*)sl.d_runs, (const aacg_sr_run*)sl.d_sr_runs, (const int32_t*)sl.d_sr_units, (const aacg_dev_tns*)sl.d_tns,
+    rc = launch_run(e, (const aacg_dev_unit*)sl.d_units, (const aacg_run*)sl.d_runs, (const aacg_dev_tns*)sl.d_tns,
                     (float*)sl.d_scratch, (float*)sl.d_spec, h, sl.d_coeffs,
                     (const aacg_band_meta*)sl.d_meta, (float*)sl.d_pcm, 0, s);
     if (rc) return rc;

@@ -37,10 +37,6 @@ struct aacg_plan_host {
     bool     any_pns = false;         /* some unit carries AACG_UNIT_HAS_PNS */
     bool     needs_scratch = false;   /* some later run holds 16 frames: its first wave parks the predecessor's tails */
     std::vector<aacg_run>   runs;     /* in launch (block) order, XCD-aware */
-    std::vector<aacg_sr_run> sr_runs; /* stream-resident runs of multichannel streams (their own launch) */
-    std::vector<int32_t> sr_units;    /* their unit index table: (frame, element) -> unit */
-    uint32_t sr_lds_floats = 0;       /* slots + staging + counters of the largest stream-resident run */
-    bool     sr_needs_scratch = false;
     std::vector<aacg_chain> chains;
     bool     zero_fill = false;       /* some frame has a channel no unit writes (decoder.js:229-231) */
     uint32_t coef_blocks = 0;         /* 1 + highest (coef_offset + c) referenced */

@@ -42,11 +42,6 @@
 #define AACG_ABL(P, bits) 0
 #endif
 
-#ifndef AACG_MC_STORE2
-#define AACG_MC_STORE2(p, a, b) dp_store2_u(p, a, b)
-#define AACG_MC_STORE1(p, a) (*(p) = (a))
-#endif
-
 struct cpx { float re, im; };
 
 DP_DEVICE cpx c_add(cpx a, cpx b) { cpx r; r.re = a.re + b.re; r.im = a.im + b.im; return r; }
@@ -1433,7 +1428,8 @@ DP_DEVICE void epilogue(const float* p0, const float* p1, const unit_view& u, in
          * CONSECUTIVE samples in consecutive lanes.  A store instruction then covers 64 x 4 C contiguous bytes (14 lines
          * for C = 7) instead of the IMDCT lane map's two samples per lane at 8 C bytes from lane to lane (28 lines): the
          * multichannel layouts are bound by the L2's write requests, not by bytes (14.8 M requests per config-5 launch,
-         * 7.9 M this way: 93 -> 66.5 us).  Non-temporal stores here: 93 us again (measured). */
+         * 7.9 M this way: 93 -> 66.5 us).  Non-temporal stores here: 150 us (they bypass the L2's merging of the
+         * elements' partial lines). */
         float* prev = const_cast<float*>(p0);
         overlap_add_in_place(prev, n_ch, cls0, cls1, hx0, hy0, hx1, hy1);
         dp_wave_sync();
@@ -1442,13 +1438,13 @@ DP_DEVICE void epilogue(const float* p0, const float* p1, const unit_view& u, in
             for (int j = 0; j < 16; j++) {
                 const int n = lane + 64 * j;
                 const dpf2 lr = *(const dpf2*)(prev + 2 * n);
-                AACG_MC_STORE2(pcm + (size_t)n * C, lr.x, lr.y);
+                dp_store2_u(pcm + (size_t)n * C, lr.x, lr.y);
             }
         } else {
 #pragma unroll
             for (int j = 0; j < 16; j++) {
                 const int n = lane + 64 * j;
-                AACG_MC_STORE1(pcm + (size_t)n * C, prev[n]);
+                pcm[(size_t)n * C] = prev[n];
             }
         }
         return;
@@ -1939,222 +1935,6 @@ DP_DEVICE void spectral_ex_body(const aacg_kparams& P, int n_units)
             *(dpf4*)(out + 1024 + 8 * lane + 512 * i) = a;
             *(dpf4*)(out + 1024 + 8 * lane + 512 * i + 4) = b;
         }
-    }
-}
-
-/* ------------------------------------------------------------------------------------ */
-/* stream-resident runs: multichannel streams                                               */
-/* ------------------------------------------------------------------------------------ */
-/* One wave's share of a finished frame: the interleaved [1024][C] block (decoder.js:203-215) as contiguous 16-byte
- * pieces, every float gathered from the slot that holds its channel (cmap[c] = float offset | stride << 24). */
-DP_DEVICE void sr_store_frame(const float* slots, const int* cmap, int C, int E, int my_e, int step_q, int step_r, float* dst)
-{
-    const int lane = dp_lane();
-    const int n4 = 256 * C;                             /* 16-byte pieces of the frame */
-    int i = my_e * 64 + lane;
-    int n = (4 * i) / C, c = 4 * i - n * C;             /* sample and channel of the piece's first float */
-#pragma unroll 1
-    for (; i < n4; i += 64 * E) {
-        float v[4];
-        int nn = n, cc = c;
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int m = cmap[cc];
-            v[j] = slots[(m & 0xffffff) + nn * (int)((unsigned)m >> 24)];
-            cc++;
-            if (cc == C) { cc = 0; nn++; }
-        }
-        dpf4 o; o.x = v[0]; o.y = v[1]; o.z = v[2]; o.w = v[3];
-        dp_store_nt((dpf4*)(dst + 4 * i), o);
-        n += step_q; c += step_r;
-        if (c >= C) { c -= C; n++; }
-    }
-}
-
-/* The run body for stream-resident runs (aacg_sr_run, aacg_device.h): the stages of imdct_run_body_dd, in a loop.
- * Wave r * E + e walks element e of frames r, r + F, ...; per frame: spectrum -> IMDCT -> tails released; overlap-add in
- * place onto the ring predecessor's tails; the frame's E waves meet and store the frame together.  Waves meet through
- * LDS counters only — after the table barrier there is no workgroup barrier, so waves of other frames keep
- * computing, loading and storing meanwhile.  The loop is software-pipelined: the next frame's unit record and spectrum
- * are requested while the current frame's PCM is still being added and stored.
- *
- * The translation unit of this kernel defines DP_LANE_OPAQUE (devport.h): with a plain lane number the compiler hoisted
- * the frame's dozens of lane-derived address patterns out of the loop and spilled 1.2 KB per lane.
- * Job -1 of a piece of a longer chain (has_pred) redoes the frame before the piece and parks its tails. */
-struct sr_pos { int E, F, C, N, my_r, my_e, pr, pw; };
-DP_DEVICE sr_pos sr_position(const aacg_sr_run* run)
-{
-    sr_pos p;
-    const int wave = dp_wave();
-    p.E = run->n_elem; p.F = run->ring; p.C = run->n_out_ch; p.N = run->n_frames;
-    p.my_r = 0;                                         /* wave / E without a divide */
-    for (int k = 1; k < AACG_WG_WAVES; k++) p.my_r += (k * p.E <= wave) ? 1 : 0;
-    p.my_e = wave - p.my_r * p.E;
-    p.pr = p.my_r == 0 ? p.F - 1 : p.my_r - 1;          /* ring predecessor: the wave that holds frame t - 1 of this element */
-    p.pw = p.pr * p.E + p.my_e;
-    return p;
-}
-
-template <int KIND>
-DP_DEVICE void imdct_stream_body(const aacg_kparams& P)
-{
-    const int TAB_FLOATS = (KIND == AACG_INPUT_QUANT_I16) ? AACG_TAB_QUANT_FLOATS : AACG_TAB_F32_FLOATS;
-    const int wave = dp_wave();
-    const aacg_sr_run* run = P.sr_runs + dp_block();
-    float* lds = (float*)dp_lds();
-    const float* tab = lds;
-    float* slots = lds + TAB_FLOATS;
-    int* cmap_all = (int*)(slots + run->map_off);
-
-    dpf4 tr0, tr1;
-    stage_tables_load(P.tab, TAB_FLOATS, tr0, tr1);
-    stage_tables_store(lds, TAB_FLOATS, tr0, tr1);
-    const sr_pos pos = sr_position(run);
-    const int E = pos.E, F = pos.F, C = pos.C, N = pos.N, my_r = pos.my_r, my_e = pos.my_e, pr = pos.pr, pw = pos.pw;
-    {   /* counters, and the channel map: ring position r, channel c -> where the predecessor position's slots hold c */
-        const int tid = dp_tid();
-        if (tid < AACG_SR_SYNC_WORDS) cmap_all[AACG_SR_MAP_WORDS + tid] = 0;
-        if (tid < F * C) {
-            int r = 0;
-            for (int q = 1; q < AACG_WG_WAVES; q++) r += (q * C <= tid) ? 1 : 0;
-            const int c = tid - r * C, rp = r == 0 ? F - 1 : r - 1;
-            int m = 0;
-            for (int e = 0; e < E; e++) {
-                const int c0 = run->elem_ch0[e], nc = run->elem_nch[e];
-                if (c >= c0 && c < c0 + nc) m = (run->slot_off[rp * E + e] + (c - c0)) | (nc << 24);
-            }
-            cmap_all[tid] = m;
-        }
-    }
-    dp_block_sync_lds();
-    if (my_r >= F) return;                              /* waves beyond the ring: nothing after the table barrier needs them */
-
-    const int* cmap = cmap_all + my_r * C;
-    int* sync = cmap_all + AACG_SR_MAP_WORDS;
-    int* ready = sync, * added = sync + 16, * stored = sync + 24;
-    float* slot = slots + run->slot_off[wave];
-    float* prev = slots + run->slot_off[pw];
-    float* scratch = P.scratch + ((size_t)dp_block() * AACG_SR_MAX_ELEMENTS + (size_t)my_e) * AACG_SLOT_FLOATS;
-    const int32_t* uidx = P.sr_units + run->unit_base + my_e;
-    const int succ = my_r + 1 == F ? 0 : my_r + 1;      /* ring position of the frames behind this wave's frames */
-
-    quant_regs qreg;
-    dpf4 xa[4], xb[4];
-    auto request = [&](const unit_view& v) {            /* the unit's spectrum: in flight until the front end takes it */
-        if (KIND == AACG_INPUT_QUANT_I16) quant_load(P, v, v.n_ch, qreg);
-        else {
-            const int lane = dp_lane();
-            const float* xsrc = (const float*)P.coeffs + (size_t)v.coef_offset * 1024u;
-            const float* xsrc1 = xsrc + (v.n_ch == 2 ? 1024 : 0);
-#pragma unroll
-            for (int i = 0; i < 4; i++) { xa[i] = *(const dpf4*)(xsrc + 4 * lane + 256 * i); xb[i] = *(const dpf4*)(xsrc1 + 4 * lane + 256 * i); }
-        }
-    };
-
-    /* jobs of this wave: [-1 (piece of a longer chain, ring position 0: the frame before the piece)], my_r, my_r + F, ... */
-    int t = (run->has_pred && my_r == 0) ? -1 : my_r;
-    int k = 0;                                          /* frames this wave has finished */
-    if (t >= N) return;
-    unit_view u = load_unit(P.units + dp_uniform(t < 0 ? run->pred[my_e] : uidx[t * E]));
-    request(u);
-#pragma unroll 1
-    for (;;) {
-        const int lane = dp_lane();
-        /* -DAACG_PROFILE builds: phase timestamps per (workgroup, wave, own frame), tools/timeline_sr.py */
-        unsigned long long* trace = (AACG_ABL(P, 16) && t >= 0) ? (unsigned long long*)P.spec_out + (((size_t)dp_block() * AACG_WG_WAVES + wave) * 8 + (size_t)(k & 7)) * 8 : nullptr;
-        if (trace && lane == 0) trace[0] = dp_clock();
-        const bool pred_pass = t < 0;
-        const int t_next = pred_pass ? my_r : t + F;
-        const bool more = t_next < N;
-        /* the next job's unit index: requested now, used after this frame's IMDCT */
-        const int ui_next = dp_uniform(uidx[(more ? t_next : t < 0 ? 0 : t) * E]);
-        const int n_ch = u.n_ch;
-        const int cls0 = u.seq[0] == AACG_EIGHT_SHORT_SEQUENCE, cls1 = u.seq[1] == AACG_EIGHT_SHORT_SEQUENCE;
-        const bool pair_path = n_ch == 2 && u.seq[0] == u.seq[1] && u.shape[0] == u.shape[1] && u.shape_prev[0] == u.shape_prev[1];
-
-        /* The slot is free once every wave of the frame behind this wave's previous frame has stored (they gather from
-         * all E slots of the ring position).  That frame belongs to the next ring position; after the last position
-         * comes position 0, one round further on. */
-        if (k > 0) dp_flag_wait_ge(&stored[succ], (my_r + 1 == F ? k + 1 : k) * E);
-        if (trace && lane == 0) trace[1] = dp_clock();             /* slot free */
-
-        float hx0[8], hy0[8], hx1[8], hy1[8];
-        if (KIND == AACG_INPUT_QUANT_I16) {
-            float xl[16], xr[16];
-            spectral_quant(P, tab, u, n_ch, qreg, slot + 1024, xl, xr);
-            if (pair_path) stage_pair_nat8(xl, xr, slot);
-            else { stage_nat8(xl, slot); if (n_ch == 2) stage_nat8(xr, slot + 1024); }
-        } else {
-            if (pair_path) stage_pair_f32(xa, xb, slot);
-            else {
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    *(dpf4*)(slot + 4 * lane + 256 * i) = xa[i];
-                    if (n_ch == 2) *(dpf4*)(slot + 1024 + 4 * lane + 256 * i) = xb[i];
-                }
-            }
-        }
-        dp_wave_sync();
-        filter_unit(tab, u, n_ch, pair_path, !pred_pass, slot, hx0, hy0, hx1, hy1);
-        dp_wave_sync();
-
-        auto save_tails = [&](float* d0, float* d1) {
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const int n = 4 * lane + 256 * i;
-                if (n_ch == 2) {
-                    const dpf4 a = *(const dpf4*)(slot + 2 * n), b = *(const dpf4*)(slot + 2 * n + 4);
-                    dpf4 l4, r4;
-                    l4.x = a.x; l4.y = a.z; l4.z = b.x; l4.w = b.z;
-                    r4.x = a.y; r4.y = a.w; r4.z = b.y; r4.w = b.w;
-                    *(dpf4*)(d0 + n) = l4;
-                    *(dpf4*)(d1 + n) = r4;
-                } else {
-                    *(dpf4*)(d0 + n) = *(const dpf4*)(slot + n);
-                }
-            }
-        };
-        /* the next job's unit record (scalar loads; the index has arrived by now) */
-        const unit_view u_next = load_unit(P.units + ui_next);
-        if (pred_pass) {                                           /* park the tails: frame 0 of the piece starts from them */
-            save_tails(scratch, scratch + 1024);
-            dp_wave_sync();
-            request(u_next);
-        } else {
-            if (lane == 0) dp_flag_set(&ready[wave], k + 1);       /* tails of frame t are in the slot (release) */
-            if (trace && lane == 0) trace[2] = dp_clock();         /* IMDCT done */
-            const uint32_t frame_pcm = u.pcm_offset;
-            if (t == 0) {
-                /* the run's first frame has no predecessor slot: overlap state from HBM (filter_bank.js:38-41; the tails
-                 * the pred pass parked, for a piece of a longer chain), strided stores like an element-major run */
-                const bool parked = run->has_pred != 0;
-                const float* ov0 = parked ? scratch : P.overlap + (P.flip ? run->ov_b[my_e][0] : run->ov_a[my_e][0]);
-                const float* ov1 = parked ? scratch + 1024 : P.overlap + (P.flip ? run->ov_b[my_e][1] : run->ov_a[my_e][1]);
-                epilogue<false>(ov0, ov1, u, n_ch, cls0, cls1, P.pcm, hx0, hy0, hx1, hy1);
-                request(u_next);
-                if (lane == 0) { dp_flag_add(&added[my_r], 1); dp_flag_add(&stored[my_r], 1); }   /* the counts stay per frame */
-            } else {
-                dp_flag_wait_ge(&ready[pw], (t - 1 - pr) / F + 1);     /* the ring predecessor has released frame t - 1 */
-                if (trace && lane == 0) trace[3] = dp_clock();
-                overlap_add_in_place(prev, n_ch, cls0, cls1, hx0, hy0, hx1, hy1);
-                dp_wave_sync();
-                if (lane == 0) dp_flag_add(&added[my_r], 1);
-                request(u_next);                                       /* in flight while the frame is stored */
-                dp_flag_wait_ge(&added[my_r], (k + 1) * E);            /* all E elements of the frame are finished PCM */
-                if (trace && lane == 0) trace[4] = dp_clock();
-                sr_store_frame(slots, cmap, C, E, my_e, run->step_q, run->step_r, P.pcm + frame_pcm);
-                dp_wave_sync();
-                if (lane == 0) dp_flag_add(&stored[my_r], 1);          /* the predecessors may overwrite their slots */
-            }
-            if (trace && lane == 0) trace[6] = dp_clock();
-            /* the last frame of a chain's last run: its tails are the new overlap state (planar in HBM) */
-            if (t == N - 1 && run->is_last)
-                save_tails(P.overlap + (P.flip ? run->ov_a[my_e][0] : run->ov_b[my_e][0]), P.overlap + (P.flip ? run->ov_a[my_e][1] : run->ov_b[my_e][1]));
-            k++;
-        }
-        if (!more) break;
-        t = t_next;
-        u = u_next;
     }
 }
 

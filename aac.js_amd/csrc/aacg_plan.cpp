@@ -215,79 +215,6 @@ int aacg_plan_build(const aacg_unit_desc* units, uint32_t n_units, int sample_in
             return fail(err, AACG_ERR_LAYOUT_CHANGE, "stream %ld: element at channel %ld ends before the batch does",
                         (long)(kv.first >> 16), (long)(kv.first & 0xffff));
 
-    /* Multichannel streams go stream-resident (aacg_sr_run): one workgroup walks the stream's frames with all elements
-     * of a frame side by side, so that the PCM can be interleaved in LDS and stored as full lines, and no frame inside a
-     * run is ever recomputed.  Needs every channel of every frame written (a frame is stored as one block),
-     * 16-byte aligned frames, 2..8 elements, room for two frames in flight.  AACG_SR=0 in the environment keeps such
-     * streams on element-major runs (A/B measurements). */
-    static const bool sr_enabled = [] { const char* v = std::getenv("AACG_SR"); return !(v && v[0] == '0'); }();
-    auto sr_frame_floats = [&](uint32_t stream) {
-        int ff = 0;
-        for (auto it = open.lower_bound((uint64_t)stream << 16); it != open.end() && (it->first >> 16) == stream; ++it) ff += it->second.n_ch == 2 ? AACG_SLOT_FLOATS : 1536;
-        return ff;
-    };
-    auto sr_ring = [&](uint32_t stream) {
-        const stream_state& s = st[stream];
-        /* frames in flight: as many as the waves and the LDS allow (slots of a frame + channel map + counters; the
-         * larger, quantised-input table set is assumed) */
-        const int budget = 160 * 1024 / 4 - AACG_TAB_QUANT_FLOATS - AACG_SR_MAP_WORDS - AACG_SR_SYNC_WORDS;
-        return std::min<int>(AACG_RUN_W / (int)s.n_chains, budget / sr_frame_floats(stream));
-    };
-    std::vector<uint8_t> sr_flag((size_t)max_streams, 0);
-    uint32_t sr_streams = 0;
-    for (uint32_t sidx = 0; sidx < (uint32_t)max_streams; sidx++) {
-        const stream_state& s = st[sidx];
-        if (sr_enabled && s.seen && s.n_out > 2 && s.n_chains >= 2 && s.n_chains <= AACG_SR_MAX_ELEMENTS && !s.holes && s.aligned && sr_ring(sidx) >= 2) {
-            sr_flag[sidx] = 1;
-            sr_streams++;
-        }
-    }
-    auto is_sr = [&](uint32_t stream) { return sr_flag[stream] != 0; };
-    for (uint32_t stream = 0; stream < (uint32_t)max_streams; stream++) {
-        if (!is_sr(stream)) continue;
-        std::vector<uint64_t> keys;                                /* the stream's chains, by channel */
-        for (auto it = open.lower_bound((uint64_t)stream << 16); it != open.end() && (it->first >> 16) == stream; ++it) keys.push_back(it->first);
-        const int E = (int)keys.size(), C = st[stream].n_out, F = sr_ring(stream);
-        const size_t n = open[keys[0]].units.size();
-        /* One run per stream, unless the streams are too few to fill the CUs: then a stream is cut into pieces of at
-         * least 16 frames (a later piece redoes the frame before it, 1 / length extra work). */
-        size_t len = std::max<size_t>(16, (n * sr_streams + 255) / 256);
-        len = std::min(n, (len + (size_t)F - 1) / (size_t)F * (size_t)F);
-        for (size_t t0 = 0; t0 < n; t0 += len) {
-            aacg_sr_run r;
-            std::memset(&r, 0, sizeof r);
-            r.n_elem = E; r.ring = F; r.n_frames = (int32_t)std::min(len, n - t0);
-            r.has_pred = t0 ? 1 : 0; r.is_last = t0 + len >= n ? 1 : 0; r.n_out_ch = C;
-            r.unit_base = (int32_t)out->sr_units.size();
-            for (int t = 0; t < r.n_frames; t++)
-                for (int e = 0; e < E; e++) out->sr_units.push_back(open[keys[(size_t)e]].units[t0 + (size_t)t]);
-            int off = 0;
-            for (int f = 0; f < F; f++)
-                for (int e = 0; e < E; e++) {
-                    r.slot_off[f * E + e] = off;
-                    off += open[keys[(size_t)e]].n_ch == 2 ? AACG_SLOT_FLOATS : 1536;
-                }
-            for (int w = F * E; w < AACG_RUN_W; w++) r.slot_off[w] = 0;        /* waves beyond the ring never touch a slot */
-            r.map_off = off;
-            r.step_q = 256 * E / C; r.step_r = 256 * E % C;
-            for (int e = 0; e < E; e++) {
-                const open_chain& oc = open[keys[(size_t)e]];
-                const uint32_t channel = (uint32_t)(keys[(size_t)e] & 0xffff);
-                r.pred[e] = t0 ? oc.units[t0 - 1] : -1;
-                r.elem_ch0[e] = (uint8_t)channel; r.elem_nch[e] = oc.n_ch;
-                for (int c = 0; c < 2; c++) {
-                    const uint32_t chn = channel + (c < oc.n_ch ? c : 0);
-                    const int par = parity ? parity[(size_t)stream * (size_t)max_channels + chn] : 0;
-                    r.ov_a[e][c] = aacg_ov_offset(max_channels, stream, chn, par);
-                    r.ov_b[e][c] = aacg_ov_offset(max_channels, stream, chn, par ^ 1);
-                }
-            }
-            out->sr_lds_floats = std::max(out->sr_lds_floats, (uint32_t)(off + AACG_SR_MAP_WORDS + AACG_SR_SYNC_WORDS));
-            if (r.has_pred) out->sr_needs_scratch = true;
-            out->sr_runs.push_back(r);
-        }
-    }
-
     /* chains -> runs, generated chain by chain */
     std::vector<aacg_run> gen;
     for (auto& kv : open) {
@@ -299,11 +226,6 @@ int aacg_plan_build(const aacg_unit_desc* units, uint32_t n_units, int sample_in
         ch.first_run = (uint32_t)gen.size();
         for (int c = 0; c < 2; c++)
             ch.parity[c] = (parity && c < oc.n_ch) ? parity[(size_t)ch.stream * (size_t)max_channels + ch.channel + c] : 0;
-        if (is_sr(ch.stream)) {                            /* its runs are in sr_runs; the chain record keeps the parity bookkeeping */
-            ch.n_runs = 0;
-            out->chains.push_back(ch);
-            continue;
-        }
         const size_t n = oc.units.size();
         /* The first run takes 16 frames.  A later run recomputes the tail of the frame before it: with up to 15
          * frames a wave of its own does that, a full run of 16 gives its first wave double duty (one IMDCT more in

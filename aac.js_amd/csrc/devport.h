@@ -21,20 +21,6 @@
 
 #define DP_DEVICE __device__ __forceinline__
 #define DP_KERNEL(bounds_threads, bounds_waves) __global__ __launch_bounds__(bounds_threads, bounds_waves)
-/* a real function call: the body of a loop whose iterations must not share hoisted address arithmetic (the frame
- * loop of the stream-resident kernel spilled 1 KB per lane when it was inlined) */
-#define DP_NOINLINE __device__ __attribute__((noinline))
-/* The kernel's (single, by-value) parameter block as it lies in the kernarg segment.  dp_kernarg_addr(): its address,
- * valid in the kernel function itself only (a called function does not inherit the segment pointer); dp_kernarg_at():
- * the block behind that address in a called function — the address arrives in a VGPR pair, is made wave-uniform again and
- * points into the constant address space, so the fields are read with scalar loads, not copied per lane. */
-DP_DEVICE unsigned long long dp_kernarg_addr() { return (unsigned long long)(uintptr_t)__builtin_amdgcn_kernarg_segment_ptr(); }
-template <class T>
-DP_DEVICE const T& dp_kernarg_at(unsigned long long a)
-{
-    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32));
-    return *(const T*)(const __attribute__((address_space(4))) T*)(uintptr_t)(((unsigned long long)hi << 32) | lo);
-}
 
 typedef float2 dpf2;
 typedef float4 dpf4;
@@ -44,14 +30,7 @@ typedef uint2  dpu2;
 typedef float dpv2 __attribute__((ext_vector_type(2)));
 
 DP_DEVICE int dp_tid()   { return (int)threadIdx.x; }
-#ifdef DP_LANE_OPAQUE
-/* The lane number recomputed wherever it is asked for (two VALU instructions the optimiser may neither hoist nor share):
- * inside a loop over frames this keeps the dozens of lane-derived address patterns of a frame from being hoisted out of
- * the loop and spilled — the stream-resident kernel's translation unit defines DP_LANE_OPAQUE. */
-DP_DEVICE int dp_lane()  { int l; asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l)); return l; }
-#else
 DP_DEVICE int dp_lane()  { return (int)(threadIdx.x & 63u); }
-#endif
 DP_DEVICE int dp_wave()  { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 DP_DEVICE int dp_block() { return (int)blockIdx.x; }
 /* make a wave-uniform value provably uniform (lets hipcc use scalar loads behind it) */
@@ -80,12 +59,6 @@ DP_DEVICE void dp_flag_wait(int* flag, int v)
 {
     while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != v) __builtin_amdgcn_s_sleep(2);
 }
-/* counting forms for rings of waves: wait until the counter has reached v; add 1 with release / acquire ordering */
-DP_DEVICE void dp_flag_wait_ge(int* flag, int v)
-{
-    while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < v) __builtin_amdgcn_s_sleep(2);
-}
-DP_DEVICE int dp_flag_add(int* flag, int v) { return __hip_atomic_fetch_add(flag, v, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP); }
 /* issue priority of this wave on its SIMD (0..3); s_setprio takes an immediate */
 DP_DEVICE void dp_setprio(int p)
 {
@@ -152,8 +125,6 @@ DP_DEVICE void dp_store_nt(dpf4* p, dpf4 v)
  * global_store_dwordx2 — gfx950 runs in unaligned-access mode, and the type says align 4 */
 typedef float dp_f2u __attribute__((ext_vector_type(2), aligned(4)));
 DP_DEVICE void dp_store2_u(float* p, float a, float b) { dp_f2u v; v[0] = a; v[1] = b; *(dp_f2u*)p = v; }
-DP_DEVICE void dp_store2_u_nt(float* p, float a, float b) { dp_f2u v; v[0] = a; v[1] = b; __builtin_nontemporal_store(v, (dp_f2u*)p); }
-DP_DEVICE void dp_store1_nt(float* p, float a) { __builtin_nontemporal_store(a, p); }
 /* constant-rate (100 MHz) wall clock, same time base on every CU: phase timelines for profiling */
 DP_DEVICE unsigned long long dp_clock() { return wall_clock64(); }
 /* keep the instruction scheduler from hoisting the next block's loads above this point

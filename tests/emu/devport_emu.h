@@ -21,7 +21,6 @@
 
 #define DP_DEVICE static inline
 #define DP_KERNEL(a, b)
-#define DP_NOINLINE static __attribute__((noinline))
 
 struct alignas(8)  dpf2 { float x, y; };
 struct alignas(16) dpf4 { float x, y, z, w; };
@@ -44,13 +43,9 @@ struct emu_lane_ctx {
     int lane, wave;
     emu_wave* w;
     emu_block* b;
-    const void* kernarg;        /* the kernel's parameter block */
 };
 extern thread_local emu_lane_ctx g_emu;
 
-DP_DEVICE unsigned long long dp_kernarg_addr() { return (unsigned long long)(uintptr_t)g_emu.kernarg; }
-template <class T>
-DP_DEVICE const T& dp_kernarg_at(unsigned long long a) { return *(const T*)(uintptr_t)a; }
 DP_DEVICE int dp_tid()   { return g_emu.wave * 64 + g_emu.lane; }
 DP_DEVICE int dp_lane()  { return g_emu.lane; }
 DP_DEVICE int dp_wave()  { return g_emu.wave; }
@@ -61,8 +56,6 @@ DP_DEVICE void dp_block_sync() { pthread_barrier_wait(&g_emu.b->bar); }
 DP_DEVICE void dp_block_sync_lds() { pthread_barrier_wait(&g_emu.b->bar); }
 DP_DEVICE void dp_flag_set(int* flag, int v) { __atomic_store_n(flag, v, __ATOMIC_RELEASE); }
 DP_DEVICE void dp_flag_wait(int* flag, int v) { while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != v) sched_yield(); }
-DP_DEVICE void dp_flag_wait_ge(int* flag, int v) { while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) < v) sched_yield(); }
-DP_DEVICE int dp_flag_add(int* flag, int v) { return __atomic_fetch_add(flag, v, __ATOMIC_ACQ_REL); }
 DP_DEVICE void dp_setprio(int) {}
 
 template <int N>
@@ -122,8 +115,6 @@ DP_DEVICE double dp_fma(double a, double b, double c) { return fma(a, b, c); }
 DP_DEVICE dpv2 dp_fma2(dpv2 a, dpv2 b, dpv2 c) { dpv2 r; r[0] = fmaf(a[0], b[0], c[0]); r[1] = fmaf(a[1], b[1], c[1]); return r; }
 DP_DEVICE void dp_store_nt(dpf4* p, dpf4 v) { *p = v; }
 DP_DEVICE void dp_store2_u(float* p, float a, float b) { p[0] = a; p[1] = b; }
-DP_DEVICE void dp_store2_u_nt(float* p, float a, float b) { p[0] = a; p[1] = b; }
-DP_DEVICE void dp_store1_nt(float* p, float a) { *p = a; }
 DP_DEVICE unsigned long long dp_clock() { return 0; }
 DP_DEVICE void dp_keep_branch() {}
 DP_DEVICE void dp_sched_fence() {}

@@ -19,7 +19,7 @@ namespace {
 struct launch_arg {
     emu_lane_ctx ctx;
     const aacg_kparams* P;
-    int kind;     /* 0 f32 run, 1 quant run, 2 spectral, 3/4 optional stages, 5/6 stream-resident, 7 front end */
+    int kind;     /* 0 f32 run, 1 quant run, 2 spectral, 3/4 optional stages, 7 front end */
     int n_units;
     const aacg_parse_params* PP;
 };
@@ -33,8 +33,6 @@ void* lane_main(void* p)
     const bool dd = a->P->scratch != nullptr;
     if (a->kind == 0)      { if (dd) imdct_run_body_dd<AACG_INPUT_SPEC_F32>(*a->P); else imdct_run_body<AACG_INPUT_SPEC_F32>(*a->P); }
     else if (a->kind == 1) { if (dd) imdct_run_body_dd<AACG_INPUT_QUANT_I16>(*a->P); else imdct_run_body<AACG_INPUT_QUANT_I16>(*a->P); }
-    else if (a->kind == 5) imdct_stream_body<AACG_INPUT_SPEC_F32>(*a->P);
-    else if (a->kind == 6) imdct_stream_body<AACG_INPUT_QUANT_I16>(*a->P);
     else if (a->kind == 3) spectral_ex_body<AACG_INPUT_QUANT_I16>(*a->P, a->n_units);
     else if (a->kind == 4) spectral_ex_body<AACG_INPUT_SPEC_F32>(*a->P, a->n_units);
     else                   spectral_body(*a->P, a->n_units);
@@ -60,7 +58,7 @@ void launch(const aacg_kparams& P, int kind, int grid, int waves, size_t lds_byt
         pthread_barrier_init(&blk.bar, nullptr, (unsigned)threads);
         for (int w = 0; w < waves; w++) pthread_barrier_init(&wv[(size_t)w].bar, nullptr, 64);
         for (int t = 0; t < threads; t++) {
-            args[(size_t)t].ctx = emu_lane_ctx{t & 63, t >> 6, &wv[(size_t)(t >> 6)], &blk, &P};
+            args[(size_t)t].ctx = emu_lane_ctx{t & 63, t >> 6, &wv[(size_t)(t >> 6)], &blk};
             args[(size_t)t].P = &P;
             args[(size_t)t].kind = kind;
             args[(size_t)t].n_units = n_units;
@@ -161,9 +159,8 @@ int emu_decode_ex(int input_kind, int sample_index, int max_streams, int max_cha
     P.units = ph.units.data(); P.runs = ph.runs.data(); P.coeffs = coeffs; P.meta = meta; P.pcm = pcm;
     P.overlap = overlap_pool; P.tab = &g_tab; P.flip = 0; P.n_runs = (int32_t)ph.runs.size();
     P.tns = ph.any_tns ? ph.tns.data() : nullptr;
-    std::vector<float> scratch(std::max<size_t>(ph.needs_scratch ? ph.runs.size() * AACG_SLOT_FLOATS : 1,
-                                                 ph.sr_needs_scratch ? ph.sr_runs.size() * AACG_SR_MAX_ELEMENTS * AACG_SLOT_FLOATS : 1), 0.0f);
-    P.scratch = (ph.needs_scratch || ph.sr_needs_scratch) ? scratch.data() : nullptr;
+    std::vector<float> scratch(ph.needs_scratch ? ph.runs.size() * AACG_SLOT_FLOATS : 1, 0.0f);
+    P.scratch = ph.needs_scratch ? scratch.data() : nullptr;
     std::vector<float> spec;
     static aacg_pns_tables pns_tab;
     if (ph.any_pns && (pns_mode != AACG_PNS_SPEC || input_kind != AACG_INPUT_QUANT_I16)) { g_err = "PNS unit in a batch without AACG_PNS_SPEC"; return AACG_ERR_UNSUPPORTED; }
@@ -181,13 +178,6 @@ int emu_decode_ex(int input_kind, int sample_index, int max_streams, int max_cha
     if (!ph.runs.empty())
         launch(P, input_kind == AACG_INPUT_QUANT_I16 ? 1 : 0, (int)ph.runs.size(), AACG_WG_WAVES,
                input_kind == AACG_INPUT_QUANT_I16 ? AACG_LDS_BYTES_QUANT : AACG_LDS_BYTES_F32);
-    if (!ph.sr_runs.empty()) {                          /* stream-resident runs of multichannel streams: their own launch */
-        const bool quant = input_kind == AACG_INPUT_QUANT_I16;
-        P.sr_runs = ph.sr_runs.data(); P.sr_units = ph.sr_units.data();
-        const size_t bytes = ((size_t)(quant ? AACG_TAB_QUANT_FLOATS : AACG_TAB_F32_FLOATS) + ph.sr_lds_floats) * 4;
-        if (bytes > 160 * 1024) { g_err = "a stream-resident run does not fit the LDS"; return AACG_ERR_CAPACITY; }
-        launch(P, quant ? 6 : 5, (int)ph.sr_runs.size(), AACG_WG_WAVES, bytes);
-    }
     for (auto& c : ph.chains)
         for (int k = 0; k < c.n_ch; k++) parity[(size_t)c.stream * (size_t)max_channels + c.channel + k] ^= 1;
     return AACG_OK;

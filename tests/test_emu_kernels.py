@@ -217,10 +217,10 @@ def test_ragged_streams_and_eight_channels(emu, oracle):
 
 @pytest.mark.parametrize("layout,T", [(("cpe", "cpe", "cpe", "sce"), 40), (("sce", "cpe", "cpe", "sce"), 21), (("sce", "cpe", "cpe", "cpe", "sce"), 7),
                                       (("sce",) * 8, 5)])
-def test_stream_resident_runs(emu, oracle, layout, T):
-    """Multichannel streams take the stream-resident kernel: the ring of waves walks more frames than it holds (5.1 and 7
-    channels: 4 frames in flight, 7.1: 3, eight mono elements: 2), a stream of 40 frames is cut into pieces of 16 whose
-    first waves redo the frame before them, and two consecutive batches chain through the overlap state."""
+def test_multichannel_long_chains(emu, oracle, layout, T):
+    """Multichannel layouts (7 channels, 5.1, 7.1, eight mono elements) with chains longer than a run: their PCM is
+    overlap-added in place in the previous wave's slot and stored with consecutive samples in consecutive lanes; later runs
+    redo the frame before them; two consecutive batches chain through the overlap state."""
     import sys, os
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "aac.js_amd", "python"))
     import aacgpu_workload

@@ -579,10 +579,10 @@ def test_bench_launches_its_own_ranks():
 
 @pytest.mark.parametrize("layout,T", [(("cpe", "cpe", "cpe", "sce"), 40), (("sce", "cpe", "cpe", "sce"), 21), (("sce", "cpe", "cpe", "cpe", "sce"), 7),
                                       (("sce",) * 8, 5), (("cpe", "cpe", "cpe", "sce"), 16)])
-def test_stream_resident_runs(oracle, layout, T):
-    """Multichannel streams take the stream-resident kernel (aacg_imdct_stream_*): rings of 4 / 3 / 2 frames in flight, a
-    stream cut into pieces whose first waves redo the frame before them, two consecutive batches chained through the
-    overlap state; 24 streams so that several workgroups run side by side."""
+def test_multichannel_long_chains(oracle, layout, T):
+    """Multichannel layouts (7 channels, 5.1, 7.1, eight mono elements) with chains longer than a run: the in-place
+    overlap-add + consecutive-sample stores of the multichannel epilogue, later runs that redo the frame before them, two
+    consecutive batches chained through the overlap state; 24 streams so that many workgroups run side by side."""
     S = 24
     C = sum(2 if e == "cpe" else 1 for e in layout)
     eng = aacgpu.Engine(aacgpu.INPUT_QUANT_I16, max_streams=S, max_channels=C)
