@@ -1,0 +1,93 @@
+#!/usr/bin/env node
+/* The plugin under an Aurora stand-in (tests/js/av_stub.js):  node tests/js/test_aurora.js [cpu|gpu]
+ *  cpu: registration ('mp4a', 'aac ', the ADTS demuxer's probe), the demuxer's events, and the whole chain
+ *       source -> demuxer -> decoder with a recording engine: every frame of a committed stream reaches the engine once,
+ *       in order, however the source cuts the bytes (Aurora rewinds the stream after a readChunk() that returned nothing)
+ *  gpu: the same chain with the real engine: the PCM Aurora's 'data' events carry equals what the reference's own
+ *       readChunk() produced from the same bytes (tests/golden/streams/*.refpcm) */
+'use strict';
+const fs = require('fs'), path = require('path'), assert = require('assert');
+const root = path.join(__dirname, '..', '..');
+const AV = require('./av_stub.js');
+const host = require(path.join(root, 'aac.js_amd', 'js'));
+const mode = process.argv[2] || 'cpu';
+const streams = path.join(root, 'tests', 'golden', 'streams');
+const manifest = JSON.parse(fs.readFileSync(path.join(streams, 'manifest.json')));
+
+function play(name, pieces, options) {
+    AV.Demuxer.registry.length = 0;                              // one registration per process in real use; the test registers per run
+    const plugin = require(path.join(root, 'aac.js_amd', 'js', 'aurora.js')).register(AV, options);
+    const bytes = new Uint8Array(fs.readFileSync(path.join(streams, name + '.aac')));
+    const source = new AV.EventEmitter(), out = { pcm: [], events: [], errors: [] };
+    const first = new AV.Buffer(bytes.subarray(0, pieces[0]));
+    const DemuxerClass = AV.Demuxer.find(first);
+    assert.strictEqual(DemuxerClass, plugin.Demuxer, 'the ADTS demuxer answers the probe');
+    let decoder = null;
+    const demuxer = Object.create(DemuxerClass.prototype);
+    /* Aurora's Asset: on 'format' it looks the decoder up by formatID and constructs it */
+    AV.EventEmitter.call(demuxer);
+    demuxer.on('format', function (format) {
+        out.events.push('format');
+        out.format = format;
+        const DecoderClass = AV.Decoder.find(format.formatID);
+        assert.strictEqual(DecoderClass, plugin.Decoder);
+        decoder = new DecoderClass(demuxer, format);
+        decoder.on('data', function (pcm) { out.pcm.push(pcm); });
+        decoder.on('error', function (e) { out.errors.push(e); });
+        decoder.on('end', function () { out.ended = true; });
+    });
+    demuxer.on('cookie', function () { out.events.push('cookie'); });
+    DemuxerClass.call(demuxer, source, null);
+    let at = 0, i = 0;
+    while (at < bytes.length) {
+        const n = Math.min(pieces[i % pieces.length], bytes.length - at);
+        source.emit('data', new AV.Buffer(bytes.subarray(at, at + n)));
+        at += n; i++;
+        while (decoder && decoder.decode()) {}                    // Aurora's queue keeps calling decode() while it yields
+    }
+    source.emit('end');
+    while (decoder && decoder.decode()) {}
+    out.decoder = decoder;
+    return out;
+}
+
+{
+    AV.Demuxer.registry.length = 0;
+    const plugin = require(path.join(root, 'aac.js_amd', 'js', 'aurora.js')).register(AV, { engine: function () { return { resetStream: function () {}, decodeBatch: function () {} }; } });
+    assert.strictEqual(AV.Decoder.find('mp4a'), plugin.Decoder);
+    assert.strictEqual(AV.Decoder.find('aac '), plugin.Decoder);
+    assert.strictEqual(AV.Demuxer.find(new AV.Buffer(new Uint8Array([0, 1, 2, 3, 4, 5, 6, 7]))), null);
+    assert.strictEqual(typeof plugin.Demuxer.readHeader, 'function');
+}
+
+for (const c of manifest) {
+    if (mode === 'cpu') {
+        /* a recording engine: what reaches aacg_decode_batch, frame by frame */
+        for (const pieces of [[1 << 20], [997], [7, 300, 1], [64]]) {
+            let units = 0;
+            const engine = { resetStream: function () {}, decodeBatch: function (u, q, meta, pcm) { units += u.length / host.UNIT_BYTES; pcm.fill(1); } };
+            const out = play(c.name, pieces, { engine: function () { return engine; }, lookahead: 8 });
+            assert.deepStrictEqual(out.events.slice(0, 2), ['format', 'cookie']);
+            assert.strictEqual(out.format.channelsPerFrame, c.channels);
+            assert.strictEqual(out.errors.length, 0, String(out.errors[0]));
+            assert.strictEqual(out.pcm.length, c.frames, c.name + ' pieces ' + pieces + ': frames delivered');
+            assert.ok(out.pcm.every(function (p) { return p.length === 1024 * c.channels; }));
+            const perFrame = fs.statSync(path.join(streams, c.name + '.units')).size / host.UNIT_BYTES / c.frames;
+            assert.strictEqual(units, c.frames * perFrame, c.name + ': every element reached the engine exactly once');
+            assert.ok(out.ended);
+        }
+    } else {
+        const ref = new Float32Array(new Uint8Array(fs.readFileSync(path.join(streams, c.name + '.refpcm'))).buffer);
+        for (const pieces of [[1 << 20], [1500, 13]]) {
+            const out = play(c.name, pieces, { lookahead: 16 });
+            assert.strictEqual(out.errors.length, 0, String(out.errors[0]));
+            assert.strictEqual(out.pcm.length, c.frames);
+            let err = 0, sig = 0, n = 0;
+            out.pcm.forEach(function (p, t) { for (let i = 0; i < p.length; i++, n++) { const d = p[i] - ref[t * p.length + i]; err += d * d; sig += ref[t * p.length + i] * ref[t * p.length + i]; } });
+            err = Math.sqrt(err / n); sig = Math.sqrt(sig / n);
+            assert.ok(err < 1e-5 && err <= 5e-6 * sig, c.name + ': rms ' + err + ' of ' + sig);
+            console.log(c.name + ' through av stub: ' + c.frames + ' frames, rms error ' + err.toExponential(2));
+        }
+    }
+}
+console.log('aurora ' + mode + ' tests ok');

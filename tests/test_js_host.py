@@ -50,3 +50,20 @@ def test_js_port_matches_golden():
                        capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr
     assert json.loads(r.stdout)["rms"] < 1e-6
+
+
+@needs_node
+def test_aurora_registration_cpu():
+    """aac.js_amd/js/aurora.js under an Aurora stand-in (tests/js/av_stub.js): 'mp4a' / 'aac ' registration, the ADTS demuxer's
+    probe and events, and source -> demuxer -> decoder with a recording engine, however the source cuts the bytes."""
+    r = subprocess.run([NODE, os.path.join(ROOT, "tests", "js", "test_aurora.js"), "cpu"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "aurora cpu tests ok" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+@needs_node
+def test_aurora_registration_gpu():
+    """The same chain with the real engine: the PCM of Aurora's 'data' events == the reference's readChunk() output (.refpcm)."""
+    build_addon()
+    r = subprocess.run([NODE, os.path.join(ROOT, "tests", "js", "test_aurora.js"), "gpu"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "aurora gpu tests ok" in r.stdout, r.stdout + r.stderr
