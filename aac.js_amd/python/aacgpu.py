@@ -24,7 +24,7 @@ ABI_SYMBOLS = ["aacg_create", "aacg_destroy", "aacg_last_error", "aacg_abi_versi
                "aacg_host_alloc", "aacg_host_free", "aacg_plan_create", "aacg_plan_destroy",
                "aacg_decode_device", "aacg_spectral_device", "aacg_synchronize", "aacg_get_table", "aacg_kernel_name",
                "aacg_parser_create", "aacg_parser_destroy", "aacg_parser_last_error", "aacg_parse_status_string",
-               "aacg_parse_batch", "aacg_parse_device", "aacg_parse_kernel_name", "aacg_plan_refresh_from_parse", "aacg_standard_codebooks"]
+               "aacg_parse_batch", "aacg_parse_device", "aacg_parse_kernel_name", "aacg_plan_refresh_from_parse", "aacg_standard_codebooks", "aacg_debug_transform"]
 
 UNIT_DTYPE = np.dtype([
     ("stream", "<u4"), ("pcm_offset", "<u4"), ("channel", "<u2"), ("n_out_ch", "<u2"),
@@ -138,6 +138,7 @@ def load_library(path=LIB_PATH):
     L.aacg_parse_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.aacg_standard_codebooks.argtypes = [C.c_void_p, C.c_void_p]
+    L.aacg_debug_transform.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     L.aacg_standard_codebooks.restype = C.c_uint32
     _lib = L
     return L
@@ -149,6 +150,18 @@ PARSE_FRAME_DTYPE = np.dtype([("byte_offset", "<u4"), ("byte_length", "<u4")])
 PARSE_RESULT_DTYPE = np.dtype([("status", "u1"), ("n_units", "u1"), ("n_channels", "u1"), ("flags", "u1"), ("bits_used", "<u4")])
 META_DTYPE = np.dtype(("<u2", (120,)))
 PARSE_APPLY_PULSES, PARSE_REFERENCE_QUIRKS, PARSE_SKIP_ZERO_FILL = 1, 2, 4
+
+
+def debug_transform(x, is_short=False, identity_rotation=False, sample_index=3, device=0):
+    """aacg_debug_transform: the kernels' IMDCT stage on one spectrum (1024 floats), windows forced to 1; returns 2048 floats."""
+    L = load_library()
+    x = np.ascontiguousarray(x, np.float32)
+    assert x.size == 1024
+    out = np.zeros(2048, np.float32)
+    rc = L.aacg_debug_transform(device, sample_index, int(is_short), int(identity_rotation), x.ctypes.data, out.ctypes.data)
+    if rc:
+        raise AacgError(rc, "aacg_debug_transform failed")
+    return out
 
 
 def standard_codebooks():

@@ -390,6 +390,14 @@ int aacg_plan_refresh_from_parse(aacg_engine* e, aacg_plan* p, const aacg_unit_d
                                  const aacg_parse_result* d_results, uint32_t max_units, uint32_t* d_refused,
                                  void* hip_stream);
 
+/* Diagnostic: the IMDCT stage of the kernels on its own, for known-answer tests against the reference's MDCT.process
+ * (mdct.js:62-115) and FFT.process (fft.js:105-192) vectors.  One spectrum in (1024 floats: one long window, or eight
+ * short ones), windows forced to 1.  Long: out[0..2047] = the 2048 IMDCT outputs.  Short: out[128 w + i] =
+ * y_(w-1)[128 + i] + y_w[i] (i < 128), so a window whose neighbours are zero shows its 256 outputs.  identity_rotation:
+ * the pre / post rotations (mdct.js:73-76, 82-87) are replaced by the identity, which leaves the N/4-point complex inverse
+ * FFT of z[k] = X[N/2-1-2k] + i X[2k] in the output order of mdct.js:90-114.  Nothing on the decode path calls this. */
+int aacg_debug_transform(int device_ordinal, int sample_index, int is_short, int identity_rotation, const float* in, float* out);
+
 #ifdef __cplusplus
 }
 #endif

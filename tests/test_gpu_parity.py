@@ -595,3 +595,71 @@ def test_multichannel_long_chains(oracle, layout, T):
         got = overlaps(eng, S, C)
         assert np.abs(got - ov).max() <= 1e-5 * max(1.0, float(np.abs(ov).max()))
     eng.close()
+
+
+# ---- stand-alone known-answer tests of the transform stage (aacg_debug_transform) ---------------------------
+def _unreorder(y, N):
+    """Invert mdct.js:90-114: from the N IMDCT-order outputs back to the N/4 complex values (re, im) behind them (every value
+    appears twice in the output; both copies must agree)."""
+    n8, n4, n2 = N // 8, N // 4, N // 2
+    re, im, re2, im2 = np.zeros(n4), np.zeros(n4), np.zeros(n4), np.zeros(n4)
+    k = np.arange(n8)
+    im[n8 + k] = y[2 * k];                 re[n8 - 1 - k] = -y[2 * k + 1]
+    re2[k] = y[n4 + 2 * k];                im2[n4 - 1 - k] = -y[n4 + 2 * k + 1]
+    re[n8 + k] = y[n2 + 2 * k];            im[n8 - 1 - k] = -y[n2 + 2 * k + 1]
+    im2[k] = -y[3 * n4 + 2 * k];           re2[n4 - 1 - k] = y[3 * n4 + 2 * k + 1]
+    tol = 1e-5 * max(1.0, float(np.abs(y).max()))
+    assert np.allclose(re, re2, rtol=0, atol=tol) and np.allclose(im, im2, rtol=0, atol=tol)
+    return re, im
+
+
+def _rel(a, b):
+    a, b = np.asarray(a, np.float64).ravel(), np.asarray(b, np.float64).ravel()
+    return float(np.sqrt(np.mean((a - b) ** 2)) / np.sqrt(np.mean(b ** 2)))
+
+
+def test_imdct_2048_kat(golden):
+    """mdct.js:62-115, N = 2048: the kernels' long-window IMDCT alone against the reference's MDCT.process vectors.
+    Tolerance 5e-6 of the output RMS (the reference's own float32 twiddle recurrence is 1.3e-6 from exact)."""
+    for v in range(4):
+        got = aacgpu.debug_transform(golden["imdct2048.in"][v])
+        assert _rel(got, golden["imdct2048.out"][v]) < 5e-6
+
+
+def test_imdct_256_kat(golden):
+    """N = 256: four reference vectors as windows 0, 2, 4, 6 of one EIGHT_SHORT spectrum (odd windows zero: the window
+    overlap then leaves every IMDCT's 256 outputs in the clear)."""
+    x = np.zeros((8, 128), np.float32)
+    x[0::2] = golden["imdct256.in"]
+    s = aacgpu.debug_transform(x.ravel(), is_short=True)[:1024].reshape(8, 128)
+    for v in range(4):
+        y = np.concatenate([s[2 * v], s[2 * v + 1]])
+        assert _rel(y, golden["imdct256.out"][v]) < 5e-6
+
+
+def test_fft_512_kat(golden):
+    """fft.js:105-192, 512 points, inverse, unscaled: with the MDCT rotations replaced by the identity the long-window stage is
+    the FFT of z[k] = X[1023 - 2k] + i X[2k]; the reference's FFT.process vectors are fed through that map."""
+    for v in range(3):
+        z = golden["fft512.in"][v].astype(np.float32)                   # [512][re, im]
+        X = np.zeros(1024, np.float32)
+        k = np.arange(512)
+        X[1023 - 2 * k] = z[:, 0]
+        X[2 * k] = z[:, 1]
+        re, im = _unreorder(aacgpu.debug_transform(X, identity_rotation=True).astype(np.float64), 2048)
+        want = golden["fft512.out"][v].astype(np.float64)
+        assert _rel(np.stack([re, im], 1), want) < 5e-6
+
+
+def test_fft_64_kat(golden):
+    """64 points: three reference vectors as windows 0, 2, 4 of an EIGHT_SHORT spectrum, identity rotations."""
+    x = np.zeros((8, 128), np.float32)
+    k = np.arange(64)
+    for v in range(3):
+        z = golden["fft64.in"][v].astype(np.float32)
+        x[2 * v, 127 - 2 * k] = z[:, 0]
+        x[2 * v, 2 * k] = z[:, 1]
+    s = aacgpu.debug_transform(x.ravel(), is_short=True, identity_rotation=True)[:1024].reshape(8, 128).astype(np.float64)
+    for v in range(3):
+        re, im = _unreorder(np.concatenate([s[2 * v], s[2 * v + 1]]), 256)
+        assert _rel(np.stack([re, im], 1), golden["fft64.out"][v].astype(np.float64)) < 5e-6
