@@ -2,7 +2,7 @@
  * aacg_engine_spectral.hip — the optional stages as a kernel of their own: noise bands (AACG_PNS_SPEC) and the TNS
  * filters (AACG_TNS_SPEC), for quantised or f32 input, writing f32 spectra that the f32 run kernel then consumes.
  * Batches without noise bands and without TNS side info never come here.  Its own translation unit, compiled with
- * LLVM's default machine scheduler (it suits the long dependent chains of tns_pass).  MI355X (gfx950) only.
+ * LLVM's default machine scheduler (it suits the long dependent chains of the TNS passes).  MI355X (gfx950) only.
  */
 #include <hip/hip_runtime.h>
 
@@ -14,8 +14,8 @@ void aacg_spectral_ex_quant(const aacg_kparams P, int n_units) { spectral_ex_bod
 extern "C" __global__ __launch_bounds__(AACG_WG_THREADS)
 void aacg_spectral_ex_f32(const aacg_kparams P, int n_units) { spectral_ex_body<AACG_INPUT_SPEC_F32>(P, n_units); }
 
-#define AACG_LDS_BYTES_EX_QUANT ((AACG_TAB_QUANT_FLOATS + AACG_WG_WAVES * AACG_SLOT_FLOATS) * 4)
-#define AACG_LDS_BYTES_EX_F32   ((AACG_WG_WAVES * AACG_SLOT_FLOATS) * 4)
+#define AACG_LDS_BYTES_EX_QUANT ((AACG_SPX_TAB_FLOATS + AACG_WG_WAVES * AACG_SPX_WAVE_FLOATS) * 4)
+#define AACG_LDS_BYTES_EX_F32   ((AACG_WG_WAVES * AACG_SPX_WAVE_FLOATS) * 4)
 
 int aacg_spectral_ex_set_lds_limits(void)
 {

@@ -1086,183 +1086,182 @@ DP_DEVICE void stage_pair_f32(const dpf4 (&xa)[4], const dpf4 (&xb)[4], float* s
 }
 
 /* ------------------------------------------------------------------------------------ */
-/* AACG_TNS_SPEC: the all-pole filter tns.js:155-163 was meant to run, as a block scan       */
+/* AACG_TNS_SPEC: the all-pole filter tns.js:155-163 was meant to run                        */
 /* ------------------------------------------------------------------------------------ */
-/* y[m] = x[m] - sum_{k=1..min(m,order)} lpc[k-1] y[m-k] over `size` samples in processing order
- * (position = start + inc * m).  A serial recurrence per (window, filter); here every lane takes a
- * block of 16 consecutive samples and the blocks of one filter are chained by a scan:
- *   1. zero-state response of the block, whose last P outputs form c_b;
- *   2. the block's state transition is the same P x P matrix M = A^16 for every block (A = companion
- *      matrix of the filter); lane i builds column i by running the homogeneous recurrence 16 steps from
- *      e_i; M^2, M^4, ... by distributed squaring through LDS;
- *   3. Hillis-Steele scan over the blocks of the filter: v_b <- M^(2^k) v_(b-2^k) + v_b;
- *   4. the block is recomputed from its true incoming state v_(b-1) and written back.
- * SB = lanes (blocks) per filter: 64 for a long window (one filter at a time), 8 for EIGHT_SHORT (lane group w
- * runs the filter of window w, all eight in parallel).  P = largest order handled (coefficients beyond `order`
- * are zero).  area: the channel's spectrum in ICStream.data order; scratch: P * P doubles per filter. */
-template <int SB, int P>
-DP_DEVICE void tns_pass(float* area, float* scratch, int start, int size, int inc, int order, const float* lpc_src)
+/* y[m] = x[m] - sum_{k=1..min(m,order)} lpc[k-1] y[m-k] over `size` samples in processing order (position =
+ * start + inc * m): a serial recurrence per (window, filter).  Both channels of a unit are filtered side by side, one
+ * per half of the wave (lanes 0..31 and 32..63), on their spectra in ICStream.data order in the wave's slot.
+ *
+ * Long windows (up to three filters per channel, one pass each): lane b of a half takes block b = 32 consecutive
+ * samples.
+ *   1. zero-state response of the block (float32, tap by tap like tns.js:160); its last P outputs are c_b;
+ *   2. the block transition is the same matrix M = A^32 for every block (A = companion matrix of the filter): lane
+ *      r < P computes ROW r of it in double precision by 32 steps of the row recurrence w <- w A (in float32 the
+ *      transitions of a near-unstable filter lose the state: 2e-3 of the signal against 2e-6);
+ *   3. the true block-end states by a serial carry v_b = M v_(b-1) + c_b: per step the P row lanes read v_(b-1)
+ *      (P doubles, a broadcast read from a 96-byte exchange buffer) and c_b and write v_b; lane b + 1 picks v_b up
+ *      as its incoming state.  P^2 multiply-adds per block — the block scan this replaces (Hillis-Steele over 64
+ *      blocks of 16 with the matrix squared between levels) spent log2(64) P^2 per block on every lane and read the
+ *      matrices from LDS for each: 97 us per config-3 batch, bound by the LDS broadcast reads;
+ *   4. the block again from its true incoming state, same arithmetic as step 1, written back in place.
+ * EIGHT_SHORT (one filter per window, 128 samples, order <= 7): lane w of a half runs window w serially in place,
+ * four samples per trip — no transition matrices at all.
+ * xch: the wave's exchange area, AACG_SPX_XCH_FLOATS floats (per half: c_b as P floats, two P-double state buffers). */
+#define AACG_TNS_BLOCK 32
+
+/* chunk c (four samples in processing order) of the run that starts at blk */
+DP_DEVICE void tns_chunk_load(const float* blk, int inc, int c, float (&x)[4])
 {
-    const int lane = dp_lane(), b = lane & (SB - 1), seg = lane / SB;
-    /* scan levels: log2 of the number of blocks the (longest) filter spans */
-    const int n_blocks = (size + 15) >> 4;
-    const int LEVELS = (SB == 64) ? (n_blocks > 1 ? 32 - __builtin_clz((unsigned)(n_blocks - 1)) : 0) : 3;
-    double* mbuf = (double*)scratch + seg * P * P;     /* [row][col]; <= 4 KiB over the wave */
+    const dpf4 t = *(const dpf4*)(blk + 4 * c * inc);
+    if (inc > 0) { x[0] = t.x; x[1] = t.y; x[2] = t.z; x[3] = t.w; }
+    else         { x[0] = t.w; x[1] = t.z; x[2] = t.y; x[3] = t.x; }
+}
+DP_DEVICE void tns_chunk_store(float* blk, int inc, int c, const float (&y)[4])
+{
+    dpf4 t;
+    if (inc > 0) { t.x = y[0]; t.y = y[1]; t.z = y[2]; t.w = y[3]; }
+    else         { t.w = y[0]; t.z = y[1]; t.y = y[2]; t.x = y[3]; }
+    *(dpf4*)(blk + 4 * c * inc) = t;
+}
 
-    float lpc[P];
+/* `chunks` chunks of four samples of the recurrence, starting from the state h (h[k] = y[-1-k]) and leaving the state
+ * behind the last chunk in h; STORE: outputs written back in place.  Chunks at or beyond n_valid samples take zeros in
+ * and store nothing.  float32, tap by tap like tns.js:160 (a zero state contributes exact zeros). */
+template <int P, bool STORE>
+DP_DEVICE void tns_run(float* blk, int inc, int chunks, int n_valid, const float (&lpc)[P], float (&h)[P])
+{
+#pragma unroll 1
+    for (int c = 0; c < chunks; c++) {
+        float x[4] = {0.0f, 0.0f, 0.0f, 0.0f}, y[4];
+        if (4 * c < n_valid) tns_chunk_load(blk, inc, c, x);
 #pragma unroll
-    for (int k = 0; k < P; k++) lpc[k] = (k < order) ? lpc_src[k] : 0.0f;
-
-    /* this lane's block, in processing order */
-    const int m0 = 16 * b;
-    const int n_valid = order > 0 ? (size - m0 < 0 ? 0 : (size - m0 > 16 ? 16 : size - m0)) : 0;
-    const float* blk = area + (inc > 0 ? start + m0 : start - m0 - 3);   /* chunk c at blk + 4 c inc */
-    auto load_block = [&](float (&x)[16]) {
-#pragma unroll
-        for (int c = 0; c < 4; c++) {
-            dpf4 t; t.x = t.y = t.z = t.w = 0.0f;
-            if (4 * c < n_valid) t = *(const dpf4*)(blk + 4 * c * inc);
-            if (inc > 0) { x[4 * c] = t.x; x[4 * c + 1] = t.y; x[4 * c + 2] = t.z; x[4 * c + 3] = t.w; }
-            else         { x[4 * c] = t.w; x[4 * c + 1] = t.z; x[4 * c + 2] = t.y; x[4 * c + 3] = t.x; }
-        }
-    };
-
-    /* 1. zero-state response (float32, tap by tap like tns.js:160); only its last P outputs are kept */
-    double v[P];
-    {
-        float x[16], y[16];
-        load_block(x);
-#pragma unroll
-        for (int j = 0; j < 16; j++) {
+        for (int j = 0; j < 4; j++) {
             float acc = x[j];
 #pragma unroll
-            for (int k = 1; k <= P; k++) if (k <= j) acc = dp_fma(-lpc[k - 1], y[j - k], acc);
+            for (int k = 1; k <= P; k++) acc = dp_fma(-lpc[k - 1], (k <= j) ? y[j - k] : h[k - j - 1], acc);
             y[j] = acc;
         }
+        if (STORE && 4 * c < n_valid) tns_chunk_store(blk, inc, c, y);
 #pragma unroll
-        for (int k = 0; k < P; k++) v[k] = (double)y[15 - k];
+        for (int k = P - 1; k >= 4; k--) h[k] = h[k - 4];
+        h[0] = y[3]; h[1] = y[2]; h[2] = y[1]; h[3] = y[0];
     }
+}
 
-    /* 2. M = A^16 in double precision: lane i < P of the filter runs the homogeneous recurrence from e_i.
-     * The block transitions are where a near-unstable filter (reflection coefficients close to 1) would lose
-     * accuracy in float32; in double the state that enters a block is as good as the serial evaluation's. */
+/* one long-window filter of each channel (slot f of the records; order 0 / null record = nothing to do in that half) */
+DP_DEVICE void tns_long_pass(float* slot, float* xch, const aacg_dev_tns* recA, const aacg_dev_tns* recB, int f)
+{
+    constexpr int P = AACG_TNS_MAX_ORDER, BL = AACG_TNS_BLOCK;
+    const int lane = dp_lane(), half = lane >> 5, b = lane & 31;
+    /* per-half parameters: wave-uniform loads, selected by half */
+    const int orderA = recA ? recA->order[f] : 0, orderB = recB ? recB->order[f] : 0;
+    if (orderA <= 0 && orderB <= 0) return;
+    const int sizeA = orderA > 0 ? recA->size[f] : 0, sizeB = orderB > 0 ? recB->size[f] : 0;
+    const int n_steps = (((sizeA > sizeB ? sizeA : sizeB) + BL - 1) / BL) - 1;       /* carry steps: blocks of the longer filter - 1 */
+    const aacg_dev_tns* rec = half ? recB : recA;
+    const int order = half ? orderB : orderA, size = half ? sizeB : sizeA;
+    const int start = order > 0 ? rec->start[f] : 0, inc = order > 0 ? rec->inc[f] : 1;
+    float lpc[P];
+#pragma unroll
+    for (int k = 0; k < P; k++) lpc[k] = (k < order) ? rec->lpc[f][k] : 0.0f;
+    float* area = slot + 1024 * half;
+    float* cbuf = xch + 64 * half;                       /* c_b of the block being carried: P floats */
+    double* vbuf = (double*)(xch + 64 * half + 16);      /* two state buffers of P doubles (steps alternate) */
+
+    /* this lane's block, in processing order; blocks before the last are full */
+    const int m0 = BL * b;
+    const int n_valid = order > 0 ? (size - m0 < 0 ? 0 : (size - m0 > BL ? BL : size - m0)) : 0;
+    float* blk = area + (inc > 0 ? start + m0 : start - m0 - 3);
+
+    /* 1. zero-state response; the state it leaves is the block's own contribution c_b to the state behind it */
+    float c_own[P];
+#pragma unroll
+    for (int k = 0; k < P; k++) c_own[k] = 0.0f;
+    tns_run<P, false>(blk, inc, BL / 4, n_valid, lpc, c_own);
+
+    /* 2. row b of M = A^BL: w <- w A, BL times, from e_b (A: first row -lpc, ones below the diagonal) */
+    double row[P];
     if (b < P) {
-        double s[P];
 #pragma unroll
-        for (int k = 0; k < P; k++) s[k] = (k == b) ? 1.0 : 0.0;
+        for (int k = 0; k < P; k++) row[k] = (k == b) ? 1.0 : 0.0;
+#pragma unroll 2
+        for (int step = 0; step < BL; step++) {
+            const double w0 = row[0];
 #pragma unroll
-        for (int step = 0; step < 16; step++) {
-            double acc = 0.0;
-#pragma unroll
-            for (int k = 0; k < P; k++) acc = dp_fma(-(double)lpc[k], s[k], acc);
-#pragma unroll
-            for (int k = P - 1; k > 0; k--) s[k] = s[k - 1];
-            s[0] = acc;
+            for (int k = 0; k < P - 1; k++) row[k] = dp_fma(-w0, (double)lpc[k], row[k + 1]);
+            row[P - 1] = -w0 * (double)lpc[P - 1];
         }
-#pragma unroll
-        for (int r = 0; r < P; r++) mbuf[r * P + b] = s[r];
     }
-    dp_wave_sync();
 
-    /* 3. scan: after level k, v holds the state behind a zero-initial-state run of up to 2^(k+1) blocks ending
-     * here; the matrix is squared in place between levels (M, M^2, M^4, ...) */
-    constexpr int EPL = (P * P + SB - 1) / SB;         /* matrix entries per lane when squaring */
-#pragma unroll 1
-    for (int lev = 0; lev < LEVELS; lev++) {
-        double pv[P];
-#pragma unroll
-        for (int k = 0; k < P; k++) pv[k] = v[k];
-        dp_shfl(pv, (lane - (1 << lev)) & 63);
-        if (b >= (1 << lev)) {
-#pragma unroll
-            for (int r = 0; r < P; r++) {
-                double acc = v[r];
-#pragma unroll
-                for (int t = 0; t < P; t++) acc = dp_fma(mbuf[r * P + t], pv[t], acc);
-                v[r] = acc;
-                dp_sched_fence();                      /* keep the next row's LDS reads from being hoisted */
-            }
-        }
-        if (lev + 1 < LEVELS) {
-            double sq[EPL];
-#pragma unroll
-            for (int q = 0; q < EPL; q++) {
-                const int e = b + q * SB, r = e / P, c = e % P;
-                double acc = 0.0;
-                if (e < P * P) {
-#pragma unroll
-                    for (int t = 0; t < P; t++) acc = dp_fma(mbuf[r * P + t], mbuf[t * P + c], acc);
-                }
-                sq[q] = acc;
-                dp_sched_fence();
-            }
-            dp_wave_sync();                            /* every lane has read the old matrix */
-#pragma unroll
-            for (int q = 0; q < EPL; q++) if (b + q * SB < P * P) mbuf[b + q * SB] = sq[q];
-            dp_wave_sync();
-        }
-    }
-    dp_shfl(v, (lane - 1) & 63);
+    /* 3. serial carry: v_0 = c_0; v_s = M v_(s-1) + c_s.  s_in = this block's incoming state (y[-1-k]). */
     float s_in[P];
 #pragma unroll
-    for (int k = 0; k < P; k++) s_in[k] = (b == 0) ? 0.0f : (float)v[k];
-
-    /* 4. the block from its true incoming state (s_in[k] = y[-1-k]), same arithmetic as step 1; the block is
-     * read again rather than held in registers across the scan */
-    float x[16], y[16];
-    load_block(x);
+    for (int k = 0; k < P; k++) s_in[k] = 0.0f;
+    if (b == 0) {
 #pragma unroll
-    for (int j = 0; j < 16; j++) {
-        float acc = x[j];
-#pragma unroll
-        for (int k = 1; k <= P; k++) acc = dp_fma(-lpc[k - 1], (k <= j) ? y[j - k] : s_in[k - j - 1], acc);
-        y[j] = acc;
+        for (int k = 0; k < P; k++) vbuf[k] = (double)c_own[k];
     }
-    dp_wave_sync();                                    /* every lane has read the matrix / its block */
+    dp_wave_sync();
+#pragma unroll 1
+    for (int s = 1; s <= n_steps; s++) {
+        const double* vprev = vbuf + P * ((s - 1) & 1);
+        double* vnext = vbuf + P * (s & 1);
+        if (b == s) {
 #pragma unroll
-    for (int c = 0; c < 4; c++) {
-        if (4 * c < n_valid) {
-            dpf4 t;
-            if (inc > 0) { t.x = y[4 * c]; t.y = y[4 * c + 1]; t.z = y[4 * c + 2]; t.w = y[4 * c + 3]; }
-            else         { t.w = y[4 * c]; t.z = y[4 * c + 1]; t.y = y[4 * c + 2]; t.x = y[4 * c + 3]; }
-            *(dpf4*)(const_cast<float*>(blk) + 4 * c * inc) = t;
+            for (int k = 0; k < P; k += 4) { dpf4 t; t.x = c_own[k]; t.y = c_own[k + 1]; t.z = c_own[k + 2]; t.w = c_own[k + 3]; *(dpf4*)(cbuf + k) = t; }
+#pragma unroll
+            for (int k = 0; k < P; k++) s_in[k] = (float)vprev[k];       /* the state behind block s - 1 */
         }
+        dp_wave_sync();
+        if (b < P) {
+            double acc0 = (double)cbuf[b], acc1 = 0.0, acc2 = 0.0;     /* three short chains instead of one of P */
+#pragma unroll
+            for (int t = 0; t < P; t += 3) {
+                acc0 = dp_fma(row[t], vprev[t], acc0);
+                acc1 = dp_fma(row[t + 1], vprev[t + 1], acc1);
+                acc2 = dp_fma(row[t + 2], vprev[t + 2], acc2);
+            }
+            vnext[b] = acc0 + (acc1 + acc2);
+        }
+        dp_wave_sync();
     }
+
+    /* 4. the block from its true incoming state, same arithmetic as step 1 (read again rather than held in registers
+     * across the carry), written back in place */
+    tns_run<P, true>(blk, inc, BL / 4, n_valid, lpc, s_in);
     dp_wave_sync();
 }
 
-/* All TNS filters of one channel, in place on `area` (ICStream.data order); `scratch` holds the block-transition
- * matrices.  Callers stage the spectrum, sync the wave, call this, and read it back. */
-DP_DEVICE void tns_area(const aacg_dev_tns* rec, bool is_short, float* area, float* scratch)
+/* EIGHT_SHORT channels (shortA / shortB): lane w of the half filters window w (record slot w) serially, in place */
+DP_DEVICE void tns_short_pass(float* slot, const aacg_dev_tns* recA, const aacg_dev_tns* recB, bool shortA, bool shortB)
 {
-    if (is_short) {
-        const int w = dp_lane() >> 3;                  /* lane group w filters window w */
-        tns_pass<8, 8>(area, scratch, rec->start[w], rec->size[w], rec->inc[w], rec->order[w], rec->lpc[w]);
-    } else {
-        for (int f = 0; f < 3; f++) {                  /* up to three filters, disjoint band ranges (tns.js:119-124) */
-            const int order = rec->order[f];           /* wave-uniform: the matrix work goes with the square of P */
-            if (order <= 0) continue;
-            if (order <= 4)      tns_pass<64, 4>(area, scratch, rec->start[f], rec->size[f], rec->inc[f], order, rec->lpc[f]);
-            else if (order <= 8) tns_pass<64, 8>(area, scratch, rec->start[f], rec->size[f], rec->inc[f], order, rec->lpc[f]);
-            else                 tns_pass<64, AACG_TNS_MAX_ORDER>(area, scratch, rec->start[f], rec->size[f], rec->inc[f], order, rec->lpc[f]);
-        }
-    }
+    constexpr int P = 8;                               /* AAC-LC's short-window limit is 7 */
+    const int lane = dp_lane(), half = lane >> 5, w = lane & 31;
+    const aacg_dev_tns* rec = half ? recB : recA;
+    const bool mine = (half ? shortB : shortA) && rec != nullptr && w < 8;
+    const int order = mine ? rec->order[w] : 0;
+    const int size = order > 0 ? rec->size[w] : 0;
+    const int start = order > 0 ? rec->start[w] : 0, inc = order > 0 ? rec->inc[w] : 1;
+    float lpc[P];
+#pragma unroll
+    for (int k = 0; k < P; k++) lpc[k] = (k < order) ? rec->lpc[w][k] : 0.0f;
+    float* blk = slot + 1024 * half + (inc > 0 ? start : start - 3);
+    float h[P];                                        /* h[k] = y[m - 1 - k] */
+#pragma unroll
+    for (int k = 0; k < P; k++) h[k] = 0.0f;
+    if (dp_any(size > 0)) tns_run<P, true>(blk, inc, 32, size, lpc, h);      /* a window is 128 samples: at most 32 chunks */
+    dp_wave_sync();
 }
 
-/* ... on the natural-order registers of the QUANT path (8 lane + 512 i + e) */
-DP_DEVICE void tns_channel(const aacg_dev_tns* rec, bool is_short, float* area, float* scratch, float (&x)[16])
+/* All TNS filters of a unit, in place on its spectra in the slot (channel c at slot + 1024 c, ICStream.data order).
+ * rec0 / rec1: the channels' records, null where a channel has none. */
+DP_DEVICE void tns_unit(float* slot, float* xch, const aacg_dev_tns* rec0, const aacg_dev_tns* rec1, bool short0, bool short1)
 {
-    const int lane = dp_lane();
-    stage_nat8(x, area);
-    dp_wave_sync();
-    tns_area(rec, is_short, area, scratch);
-#pragma unroll
-    for (int i = 0; i < 2; i++) {
-        const dpf4 a = *(const dpf4*)(area + 8 * lane + 512 * i), b = *(const dpf4*)(area + 8 * lane + 512 * i + 4);
-        x[8 * i] = a.x; x[8 * i + 1] = a.y; x[8 * i + 2] = a.z; x[8 * i + 3] = a.w;
-        x[8 * i + 4] = b.x; x[8 * i + 5] = b.y; x[8 * i + 6] = b.z; x[8 * i + 7] = b.w;
-    }
-    dp_wave_sync();
+    const aacg_dev_tns* l0 = short0 ? nullptr : rec0;
+    const aacg_dev_tns* l1 = short1 ? nullptr : rec1;
+    if (l0 || l1)
+        for (int f = 0; f < 3; f++) tns_long_pass(slot, xch, l0, l1, f);   /* up to three filters, disjoint band ranges (tns.js:119-124) */
+    if ((short0 && rec0) || (short1 && rec1)) tns_short_pass(slot, rec0, rec1, short0, short1);
 }
 
 /* IMDCT + window of a unit whose spectra are staged in its slot.  CPE tails always end up
@@ -1880,18 +1879,23 @@ DP_DEVICE void imdct_run_body_dd(const aacg_kparams& P)
 /* The optional stages as a kernel of their own (16 units per workgroup, one wave each), so that the run kernels
  * never carry them: quantised input -> dequantisation, noise bands (AACG_PNS_SPEC), MS / IS, then the TNS filters
  * (AACG_TNS_SPEC); f32 input -> the TNS filters only.  f32 spectra in ICStream.data order to spec_out, which the
- * f32 run kernel then consumes.  Per wave 2048 floats of LDS: band records and PNS scratch first, then the TNS
- * work area of one channel and the block matrices in the other half. */
+ * f32 run kernel then consumes.  LDS: the dequantisation part of the tables only (scalefactors, IQ, band maps: `tab` is
+ * biased so that the usual offsets work), then per wave a 2048-float slot (band records and PNS scratch first; for TNS
+ * both channels' spectra) and the TNS exchange area. */
+#define AACG_SPX_TAB_FLOATS  (AACG_TAB_QUANT_FLOATS - AACG_TAB_F32_FLOATS)
+#define AACG_SPX_XCH_FLOATS  128
+#define AACG_SPX_WAVE_FLOATS (AACG_SLOT_FLOATS + AACG_SPX_XCH_FLOATS)
 template <int KIND>
 DP_DEVICE void spectral_ex_body(const aacg_kparams& P, int n_units)
 {
-    const int TAB_FLOATS = (KIND == AACG_INPUT_QUANT_I16) ? AACG_TAB_QUANT_FLOATS : 0;
+    const int TAB_FLOATS = (KIND == AACG_INPUT_QUANT_I16) ? AACG_SPX_TAB_FLOATS : 0;
     const int lane = dp_lane(), wave = dp_wave();
     float* lds = (float*)dp_lds();
-    const float* tab = lds;
-    float* slot = lds + TAB_FLOATS + wave * AACG_SLOT_FLOATS;
+    const float* tab = lds - AACG_TAB_F32_FLOATS;      /* only offsets >= AACG_TAB_OFF_SF are ever read through it */
+    float* slot = lds + TAB_FLOATS + wave * AACG_SPX_WAVE_FLOATS;
+    float* xch = slot + AACG_SLOT_FLOATS;
     if (KIND == AACG_INPUT_QUANT_I16) {
-        stage_tables(P.tab, lds, AACG_TAB_QUANT_FLOATS);
+        stage_tables((const aacg_tables*)((const float*)P.tab + AACG_TAB_F32_FLOATS), lds, AACG_SPX_TAB_FLOATS);
         dp_block_sync();
     }
     const int ui = dp_block() * AACG_WG_WAVES + wave;
@@ -1916,10 +1920,25 @@ DP_DEVICE void spectral_ex_body(const aacg_kparams& P, int n_units)
             xr[8 * i + 4] = d.x; xr[8 * i + 5] = d.y; xr[8 * i + 6] = d.z; xr[8 * i + 7] = d.w;
         }
     }
-    /* tns.process (decoder.js:309-313) as it was meant to run, after MS / IS */
-    if (P.tns) {
-        if (u.tns[0]) tns_channel(P.tns + u.tns_offset, u.seq[0] == AACG_EIGHT_SHORT_SEQUENCE, slot, slot + 1024, xl);
-        if (n_ch == 2 && u.tns[1]) tns_channel(P.tns + u.tns_offset + 1, u.seq[1] == AACG_EIGHT_SHORT_SEQUENCE, slot + 1024, slot, xr);
+    /* tns.process (decoder.js:309-313) as it was meant to run, after MS / IS: both channels side by side */
+    const bool tns0 = P.tns && u.tns[0], tns1 = P.tns && n_ch == 2 && u.tns[1];
+    if (tns0 || tns1) {
+        stage_nat8(xl, slot);
+        if (n_ch == 2) stage_nat8(xr, slot + 1024);
+        dp_wave_sync();
+        tns_unit(slot, xch, tns0 ? P.tns + u.tns_offset : nullptr, tns1 ? P.tns + u.tns_offset + 1 : nullptr,
+                 u.seq[0] == AACG_EIGHT_SHORT_SEQUENCE, u.seq[1] == AACG_EIGHT_SHORT_SEQUENCE);
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const dpf4 a = *(const dpf4*)(slot + 8 * lane + 512 * i), b = *(const dpf4*)(slot + 8 * lane + 512 * i + 4);
+            xl[8 * i] = a.x; xl[8 * i + 1] = a.y; xl[8 * i + 2] = a.z; xl[8 * i + 3] = a.w;
+            xl[8 * i + 4] = b.x; xl[8 * i + 5] = b.y; xl[8 * i + 6] = b.z; xl[8 * i + 7] = b.w;
+            if (n_ch == 2) {
+                const dpf4 c = *(const dpf4*)(slot + 1024 + 8 * lane + 512 * i), d = *(const dpf4*)(slot + 1024 + 8 * lane + 512 * i + 4);
+                xr[8 * i] = c.x; xr[8 * i + 1] = c.y; xr[8 * i + 2] = c.z; xr[8 * i + 3] = c.w;
+                xr[8 * i + 4] = d.x; xr[8 * i + 5] = d.y; xr[8 * i + 6] = d.z; xr[8 * i + 7] = d.w;
+            }
+        }
     }
     float* out = P.spec_out + (size_t)u.coef_offset * 1024u;
 #pragma unroll

@@ -171,7 +171,7 @@ int emu_decode_ex(int input_kind, int sample_index, int max_streams, int max_cha
         aacg_kparams Q = P;
         Q.spec_out = spec.data(); Q.pns = &pns_tab;
         launch(Q, quant ? 3 : 4, (int)((n_units + AACG_WG_WAVES - 1) / AACG_WG_WAVES), AACG_WG_WAVES,
-               ((quant ? AACG_TAB_QUANT_FLOATS : 0) + AACG_WG_WAVES * AACG_SLOT_FLOATS) * 4, (int)n_units);
+               ((quant ? AACG_SPX_TAB_FLOATS : 0) + AACG_WG_WAVES * AACG_SPX_WAVE_FLOATS) * 4, (int)n_units);
         P.coeffs = spec.data(); P.meta = nullptr; P.tns = nullptr;
         input_kind = AACG_INPUT_SPEC_F32;
     }
