@@ -34,6 +34,9 @@ void aacg_ext_launch(bool quant, dim3 grid, dim3 block, hipStream_t s, const aac
 /* aacg_engine_spectral.hip: the optional stages (AACG_PNS_SPEC noise bands, AACG_TNS_SPEC filters) -> f32 spectra */
 void aacg_refresh_launch(aacg_dev_unit* units, const aacg_unit_desc* parsed, const aacg_parse_result* results, uint32_t n_units,
                          uint32_t max_units, int refuse_pns, uint32_t* refused, hipStream_t s);
+/* aacg_engine_i16.hip: the run kernels with int16 PCM stores (AACG_OUTPUT_I16 engines) */
+int aacg_i16_set_lds_limits(void);
+void aacg_i16_launch(bool quant, bool dd, dim3 grid, dim3 block, hipStream_t s, const aacg_kparams& P);
 int aacg_spectral_ex_set_lds_limits(void);
 void aacg_spectral_ex_launch(bool quant, int n_units, hipStream_t s, const aacg_kparams& P);
 
@@ -69,7 +72,7 @@ struct aacg_engine {
         /* page-locked staging for callers that pass ordinary (pageable) memory */
         void* h_in = nullptr;     size_t h_in_cap = 0;
         void* h_pcm = nullptr;    size_t h_pcm_cap = 0;
-        float* user_pcm = nullptr; size_t user_pcm_bytes = 0;   /* copy-back target at aacg_wait, or null */
+        void* user_pcm = nullptr; size_t user_pcm_bytes = 0;   /* copy-back target at aacg_wait, or null */
         aacg_plan_host h;
     } slot[2];
     /* plans: device buffers come from a free list and are filled by asynchronous copies on the engine's own stream, so that
@@ -114,6 +117,7 @@ bool hip_ok(aacg_engine* e, hipError_t rc, const char* what)
 #define HIP_TRY(e, call, code) do { if (!hip_ok((e), (call), #call)) return (code); } while (0)
 
 size_t coef_elem_size(const aacg_engine* e) { return e->cfg.input_kind == AACG_INPUT_QUANT_I16 ? 2 : 4; }
+size_t pcm_elem_size(const aacg_engine* e) { return e->cfg.output_kind == AACG_OUTPUT_I16 ? 2 : 4; }
 
 /* smallest free block that fits without wasting more than half of it, else a new allocation */
 void* pool_take(aacg_engine* e, size_t bytes, size_t* got)
@@ -169,13 +173,14 @@ bool is_pinned(const void* p)
 /* enqueue the run kernel for a planned batch (device pointers) */
 int launch_run(aacg_engine* e, const aacg_dev_unit* d_units, const aacg_run* d_runs, const aacg_dev_tns* d_tns,
                float* d_scratch, float* d_spec, const aacg_plan_host& h, const void* d_coeffs, const aacg_band_meta* d_meta,
-               float* d_pcm, int flip, hipStream_t s)
+               void* d_pcm, int flip, hipStream_t s)
 {
+    const bool i16 = e->cfg.output_kind == AACG_OUTPUT_I16;
     bool quant = e->cfg.input_kind == AACG_INPUT_QUANT_I16;
     if (h.zero_fill)
-        HIP_TRY(e, hipMemsetAsync(d_pcm, 0, h.pcm_floats * sizeof(float), s), AACG_ERR_NO_DEVICE);
+        HIP_TRY(e, hipMemsetAsync(d_pcm, 0, h.pcm_floats * pcm_elem_size(e), s), AACG_ERR_NO_DEVICE);
     aacg_kparams P;
-    P.units = d_units; P.runs = d_runs; P.coeffs = d_coeffs; P.meta = d_meta; P.pcm = d_pcm;
+    P.units = d_units; P.runs = d_runs; P.coeffs = d_coeffs; P.meta = d_meta; P.pcm = (float*)d_pcm;
     P.tns = h.any_tns ? d_tns : nullptr;
     P.scratch = h.needs_scratch ? d_scratch : nullptr;
     P.pns = nullptr;
@@ -193,7 +198,9 @@ int launch_run(aacg_engine* e, const aacg_dev_unit* d_units, const aacg_run* d_r
         quant = false;
     }
     if (!h.runs.empty()) {
-        if (h.needs_scratch) {
+        if (i16) {
+            aacg_i16_launch(quant, h.needs_scratch, grid, block, s, P);
+        } else if (h.needs_scratch) {
             aacg_ext_launch(quant, grid, block, s, P);
         } else {
             if (quant) hipLaunchKernelGGL(aacg_imdct_run_quant, grid, block, AACG_LDS_BYTES_QUANT, s, P);
@@ -222,6 +229,7 @@ int aacg_create(const aacg_config* cfg, aacg_engine** out)
         cfg->max_channels > AACG_MAX_CHANNELS || (cfg->tns_mode != AACG_TNS_REFERENCE && cfg->tns_mode != AACG_TNS_SPEC) ||
         (cfg->pns_mode != AACG_PNS_REFERENCE && cfg->pns_mode != AACG_PNS_SPEC) ||
         (cfg->pns_mode == AACG_PNS_SPEC && cfg->input_kind != AACG_INPUT_QUANT_I16) ||
+        (cfg->output_kind != AACG_OUTPUT_F32 && cfg->output_kind != AACG_OUTPUT_I16) ||
         (cfg->input_kind != AACG_INPUT_SPEC_F32 && cfg->input_kind != AACG_INPUT_QUANT_I16))
         return AACG_ERR_INVALID_ARG;
 
@@ -245,7 +253,7 @@ int aacg_create(const aacg_config* cfg, aacg_engine** out)
         /* ~158 KiB of dynamic LDS per workgroup is above the 64 KiB default limit */
         !hip_ok(e, hipFuncSetAttribute((const void*)aacg_imdct_run_quant, hipFuncAttributeMaxDynamicSharedMemorySize, AACG_LDS_BYTES_QUANT), "LDS attr") ||
         !hip_ok(e, hipFuncSetAttribute((const void*)aacg_imdct_run_f32, hipFuncAttributeMaxDynamicSharedMemorySize, AACG_LDS_BYTES_F32), "LDS attr") ||
-        aacg_ext_set_lds_limits() != 0 || aacg_spectral_ex_set_lds_limits() != 0 ||
+        aacg_ext_set_lds_limits() != 0 || aacg_i16_set_lds_limits() != 0 || aacg_spectral_ex_set_lds_limits() != 0 ||
         !hip_ok(e, hipFuncSetAttribute((const void*)aacg_spectral, hipFuncAttributeMaxDynamicSharedMemorySize, AACG_LDS_BYTES_SPECTRAL), "LDS attr")) {
         std::fprintf(stderr, "aacgpu: %s\n", e->err.c_str());
         aacg_destroy(e);
@@ -445,7 +453,7 @@ static int plan_check_parity(aacg_engine* e, const aacg_plan* p)
 }
 
 int aacg_decode_device(aacg_engine* e, aacg_plan* p, const void* d_coeffs, const aacg_band_meta* d_meta,
-                       float* d_pcm, void* hip_stream)
+                       void* d_pcm, void* hip_stream)
 {
     if (!e || !p || p->e != e || !d_coeffs || !d_pcm) return AACG_ERR_INVALID_ARG;
     const bool quant = e->cfg.input_kind == AACG_INPUT_QUANT_I16;
@@ -535,7 +543,7 @@ int aacg_wait(aacg_engine* e, uint64_t ticket)
 int aacg_submit(aacg_engine* e, const aacg_unit_desc* units, uint32_t n_units,
                 const void* coeffs, uint32_t n_coef_blocks,
                 const aacg_band_meta* meta, uint32_t n_meta,
-                float* pcm_out, size_t n_pcm_floats, uint64_t* ticket)
+                void* pcm_out, size_t n_pcm_floats, uint64_t* ticket)
 {
     return aacg_submit_tns(e, units, n_units, coeffs, n_coef_blocks, meta, n_meta, nullptr, 0, pcm_out, n_pcm_floats, ticket);
 }
@@ -544,7 +552,7 @@ int aacg_submit_tns(aacg_engine* e, const aacg_unit_desc* units, uint32_t n_unit
                     const void* coeffs, uint32_t n_coef_blocks,
                     const aacg_band_meta* meta, uint32_t n_meta,
                     const aacg_tns_info* tns, uint32_t n_tns,
-                    float* pcm_out, size_t n_pcm_floats, uint64_t* ticket)
+                    void* pcm_out, size_t n_pcm_floats, uint64_t* ticket)
 {
     if (!e || !units || !n_units || !coeffs || !pcm_out || !ticket) return AACG_ERR_INVALID_ARG;
     if (e->cfg.tns_mode != AACG_TNS_SPEC) { tns = nullptr; n_tns = 0; }   /* REFERENCE mode: TNS is the identity */
@@ -605,7 +613,7 @@ int aacg_submit_tns(aacg_engine* e, const aacg_unit_desc* units, uint32_t n_unit
     const size_t xb = (h.any_pns || h.any_tns) ? (size_t)n_coef_blocks * 1024u * sizeof(float) : 0;
     const size_t cb = (size_t)n_coef_blocks * 1024u * coef_elem_size(e);
     const size_t mb = quant ? (size_t)n_meta * sizeof(aacg_band_meta) : 0;
-    const size_t pb = h.pcm_floats * sizeof(float);
+    const size_t pb = h.pcm_floats * pcm_elem_size(e);
     if ((rc = grow(e, &sl.d_units, &sl.units_cap, ub)) || (rb && (rc = grow(e, &sl.d_runs, &sl.runs_cap, rb))) ||
         (rc = grow(e, &sl.d_coeffs, &sl.coeffs_cap, cb)) || (quant && (rc = grow(e, &sl.d_meta, &sl.meta_cap, mb))) ||
         (tb && (rc = grow(e, &sl.d_tns, &sl.tns_cap, tb))) || (sb && (rc = grow(e, &sl.d_scratch, &sl.scratch_cap, sb))) || (xb && (rc = grow(e, &sl.d_spec, &sl.spec_cap, xb))) || (rc = grow(e, &sl.d_pcm, &sl.pcm_cap, pb)))
@@ -624,11 +632,11 @@ int aacg_submit_tns(aacg_engine* e, const aacg_unit_desc* units, uint32_t n_unit
         src_coeffs = sl.h_in;
         src_meta = (char*)sl.h_in + mb_al;
     }
-    float* dst_pcm = pcm_out;
+    void* dst_pcm = pcm_out;
     sl.user_pcm = nullptr;
     if (!is_pinned(pcm_out)) {
         if ((rc = grow_host(e, &sl.h_pcm, &sl.h_pcm_cap, pb))) return rc;
-        dst_pcm = (float*)sl.h_pcm;
+        dst_pcm = sl.h_pcm;
         sl.user_pcm = pcm_out;
         sl.user_pcm_bytes = pb;
     }
@@ -642,7 +650,7 @@ int aacg_submit_tns(aacg_engine* e, const aacg_unit_desc* units, uint32_t n_unit
     if (e->last_kernel) HIP_TRY(e, hipStreamWaitEvent(s, e->last_kernel, 0), AACG_ERR_NO_DEVICE);
     rc = launch_run(e, (const aacg_dev_unit*)sl.d_units, (const aacg_run*)sl.d_runs, (const aacg_dev_tns*)sl.d_tns,
                     (float*)sl.d_scratch, (float*)sl.d_spec, h, sl.d_coeffs,
-                    (const aacg_band_meta*)sl.d_meta, (float*)sl.d_pcm, 0, s);
+                    (const aacg_band_meta*)sl.d_meta, sl.d_pcm, 0, s);
     if (rc) return rc;
     HIP_TRY(e, hipEventRecord(sl.kernel_done, s), AACG_ERR_NO_DEVICE);
     e->last_kernel = sl.kernel_done;
@@ -662,7 +670,7 @@ int aacg_submit_tns(aacg_engine* e, const aacg_unit_desc* units, uint32_t n_unit
 int aacg_decode_batch(aacg_engine* e, const aacg_unit_desc* units, uint32_t n_units,
                       const void* coeffs, uint32_t n_coef_blocks,
                       const aacg_band_meta* meta, uint32_t n_meta,
-                      float* pcm_out, size_t n_pcm_floats)
+                      void* pcm_out, size_t n_pcm_floats)
 {
     return aacg_decode_batch_tns(e, units, n_units, coeffs, n_coef_blocks, meta, n_meta, nullptr, 0, pcm_out, n_pcm_floats);
 }
@@ -671,7 +679,7 @@ int aacg_decode_batch_tns(aacg_engine* e, const aacg_unit_desc* units, uint32_t 
                           const void* coeffs, uint32_t n_coef_blocks,
                           const aacg_band_meta* meta, uint32_t n_meta,
                           const aacg_tns_info* tns, uint32_t n_tns,
-                          float* pcm_out, size_t n_pcm_floats)
+                          void* pcm_out, size_t n_pcm_floats)
 {
     uint64_t t = 0;
     int rc = aacg_submit_tns(e, units, n_units, coeffs, n_coef_blocks, meta, n_meta, tns, n_tns, pcm_out, n_pcm_floats, &t);

@@ -1,0 +1,37 @@
+/*
+ * aacg_engine_i16.hip — the run kernels for AACG_OUTPUT_I16 engines: the same bodies with the epilogue's stores
+ * narrowed to int16 (round to nearest, saturating).  Their own translation unit, like the other variants, so that
+ * the float32 kernels' code objects do not move.  MI355X (gfx950) only.
+ */
+#include <hip/hip_runtime.h>
+
+#include "aacg_kernels.h"
+
+extern "C" __global__ __launch_bounds__(AACG_WG_THREADS)
+void aacg_imdct_run_quant_i16(const aacg_kparams P) { imdct_run_body<AACG_INPUT_QUANT_I16, AACG_OUTPUT_I16>(P); }
+extern "C" __global__ __launch_bounds__(AACG_WG_THREADS)
+void aacg_imdct_run_f32_i16(const aacg_kparams P) { imdct_run_body<AACG_INPUT_SPEC_F32, AACG_OUTPUT_I16>(P); }
+extern "C" __global__ __launch_bounds__(AACG_WG_THREADS)
+void aacg_imdct_run_quant_dd_i16(const aacg_kparams P) { imdct_run_body_dd<AACG_INPUT_QUANT_I16, AACG_OUTPUT_I16>(P); }
+extern "C" __global__ __launch_bounds__(AACG_WG_THREADS)
+void aacg_imdct_run_f32_dd_i16(const aacg_kparams P) { imdct_run_body_dd<AACG_INPUT_SPEC_F32, AACG_OUTPUT_I16>(P); }
+
+int aacg_i16_set_lds_limits(void)
+{
+    hipError_t rc = hipFuncSetAttribute((const void*)aacg_imdct_run_quant_i16, hipFuncAttributeMaxDynamicSharedMemorySize, AACG_LDS_BYTES_QUANT);
+    if (rc == hipSuccess) rc = hipFuncSetAttribute((const void*)aacg_imdct_run_f32_i16, hipFuncAttributeMaxDynamicSharedMemorySize, AACG_LDS_BYTES_F32);
+    if (rc == hipSuccess) rc = hipFuncSetAttribute((const void*)aacg_imdct_run_quant_dd_i16, hipFuncAttributeMaxDynamicSharedMemorySize, AACG_LDS_BYTES_QUANT);
+    if (rc == hipSuccess) rc = hipFuncSetAttribute((const void*)aacg_imdct_run_f32_dd_i16, hipFuncAttributeMaxDynamicSharedMemorySize, AACG_LDS_BYTES_F32);
+    return rc == hipSuccess ? 0 : -1;
+}
+
+void aacg_i16_launch(bool quant, bool dd, dim3 grid, dim3 block, hipStream_t s, const aacg_kparams& P)
+{
+    if (dd) {
+        if (quant) hipLaunchKernelGGL(aacg_imdct_run_quant_dd_i16, grid, block, AACG_LDS_BYTES_QUANT, s, P);
+        else       hipLaunchKernelGGL(aacg_imdct_run_f32_dd_i16, grid, block, AACG_LDS_BYTES_F32, s, P);
+    } else {
+        if (quant) hipLaunchKernelGGL(aacg_imdct_run_quant_i16, grid, block, AACG_LDS_BYTES_QUANT, s, P);
+        else       hipLaunchKernelGGL(aacg_imdct_run_f32_i16, grid, block, AACG_LDS_BYTES_F32, s, P);
+    }
+}

@@ -1372,15 +1372,28 @@ DP_DEVICE dpf4 incoming(const float* p0, const float* p1, int n_ch, int n)
     return r;
 }
 
-template <bool FROM_LDS>
+/* PCM goes out as float32 (the reference's Float32Array, decoder.js:204) or, for engines created with
+ * AACG_OUTPUT_I16, as int16 (round to nearest, saturating): the same sample positions, narrower elements. */
+template <int OUT> struct pcm_elem { typedef float type; };
+template <> struct pcm_elem<AACG_OUTPUT_I16> { typedef int16_t type; };
+DP_DEVICE void pcm_put4(float* p, float a, float b, float c, float d) { dpf4 o; o.x = a; o.y = b; o.z = c; o.w = d; dp_store_nt((dpf4*)p, o); }   /* four adjacent samples, 16-byte aligned position (8 for int16) */
+DP_DEVICE void pcm_put4(int16_t* p, float a, float b, float c, float d) { dp_store_i2_nt(p, dp_pcm16_pair(a, b), dp_pcm16_pair(c, d)); }
+DP_DEVICE void pcm_put2(float* p, float a, float b) { dp_store2_u(p, a, b); }                      /* two adjacent samples */
+DP_DEVICE void pcm_put2(int16_t* p, float a, float b) { dp_store_i1_u(p, dp_pcm16_pair(a, b)); }
+DP_DEVICE void pcm_put1(float* p, float a) { *p = a; }
+DP_DEVICE void pcm_put1(int16_t* p, float a) { *p = (int16_t)(dp_pcm16_pair(a, a) & 0xffff); }
+
+template <bool FROM_LDS, int OUT>
 DP_DEVICE void epilogue(const float* p0, const float* p1, const unit_view& u, int n_ch, int cls0, int cls1,
-                        float* pcm_base, const float (&hx0)[8], const float (&hy0)[8],
+                        float* pcm_base_f32, const float (&hx0)[8], const float (&hy0)[8],
                         const float (&hx1)[8], const float (&hy1)[8])
 {
+    typedef typename pcm_elem<OUT>::type elem;
+    elem* pcm_base = (elem*)pcm_base_f32;
     const int lane = dp_lane(), w = lane >> 3, g = lane & 7;
     /* decoder.js:211's 1 / 32768 is already in the windows (AACG_PCM_SCALE): heads and tails arrive PCM-scaled */
     const int C = u.n_out_ch;
-    float* pcm = pcm_base + u.pcm_offset + u.channel;
+    elem* pcm = pcm_base + u.pcm_offset + u.channel;
 
     if (n_ch == 2 && C == 2 && cls0 == cls1 && ((u.pcm_offset | (uint32_t)u.channel) & 3u) == 0) {
         /* stereo fast path: (L[n], R[n], L[n+1], R[n+1]) = 16 bytes per lane */
@@ -1392,10 +1405,7 @@ DP_DEVICE void epilogue(const float* p0, const float* p1, const unit_view& u, in
 #pragma unroll
             for (int m = 0; m < 8; m++) {
                 const int n = 2 * lane + 128 * m;
-                dpf4 o;
-                o.x = v[m].x + hx0[m]; o.y = v[m].y + hx1[m];
-                o.z = v[m].z + hy0[m]; o.w = v[m].w + hy1[m];
-                dp_store_nt((dpf4*)(pcm + 2 * n), o);
+                pcm_put4(pcm + 2 * n, v[m].x + hx0[m], v[m].y + hx1[m], v[m].z + hy0[m], v[m].w + hy1[m]);
             }
         } else {
 #pragma unroll
@@ -1403,10 +1413,7 @@ DP_DEVICE void epilogue(const float* p0, const float* p1, const unit_view& u, in
                 if (w < 4 || (w == 4 && m < 4)) {
                     const int n = 448 + 128 * w + 2 * g + 16 * m;
                     const dpf4 v = incoming<FROM_LDS>(p0, p1, 2, n);
-                    dpf4 o;
-                    o.x = v.x + hx0[m]; o.y = v.y + hx1[m];
-                    o.z = v.z + hy0[m]; o.w = v.w + hy1[m];
-                    dp_store_nt((dpf4*)(pcm + 2 * n), o);
+                    pcm_put4(pcm + 2 * n, v.x + hx0[m], v.y + hx1[m], v.z + hy0[m], v.w + hy1[m]);
                 }
             }
 #pragma unroll
@@ -1414,7 +1421,7 @@ DP_DEVICE void epilogue(const float* p0, const float* p1, const unit_view& u, in
                 const int n = 2 * lane + 128 * t4;
                 if (n < 448) {
                     const dpf4 v = incoming<FROM_LDS>(p0, p1, 2, n);
-                    dp_store_nt((dpf4*)(pcm + 2 * n), v);
+                    pcm_put4(pcm + 2 * n, v.x, v.y, v.z, v.w);
                 }
             }
         }
@@ -1437,13 +1444,13 @@ DP_DEVICE void epilogue(const float* p0, const float* p1, const unit_view& u, in
             for (int j = 0; j < 16; j++) {
                 const int n = lane + 64 * j;
                 const dpf2 lr = *(const dpf2*)(prev + 2 * n);
-                dp_store2_u(pcm + (size_t)n * C, lr.x, lr.y);
+                pcm_put2(pcm + (size_t)n * C, lr.x, lr.y);
             }
         } else {
 #pragma unroll
             for (int j = 0; j < 16; j++) {
                 const int n = lane + 64 * j;
-                pcm[(size_t)n * C] = prev[n];
+                pcm_put1(pcm + (size_t)n * C, prev[n]);
             }
         }
         return;
@@ -1457,8 +1464,8 @@ DP_DEVICE void epilogue(const float* p0, const float* p1, const unit_view& u, in
             for (int m = 0; m < 8; m++) {
                 const int n = 2 * lane + 128 * m;
                 const dpf4 v = incoming<FROM_LDS>(p0, p1, 2, n);
-                dp_store2_u(pcm + (size_t)n * C, v.x + hx0[m], v.y + hx1[m]);
-                dp_store2_u(pcm + (size_t)(n + 1) * C, v.z + hy0[m], v.w + hy1[m]);
+                pcm_put2(pcm + (size_t)n * C, v.x + hx0[m], v.y + hx1[m]);
+                pcm_put2(pcm + (size_t)(n + 1) * C, v.z + hy0[m], v.w + hy1[m]);
             }
         } else {
 #pragma unroll
@@ -1466,8 +1473,8 @@ DP_DEVICE void epilogue(const float* p0, const float* p1, const unit_view& u, in
                 if (w < 4 || (w == 4 && m < 4)) {
                     const int n = 448 + 128 * w + 2 * g + 16 * m;
                     const dpf4 v = incoming<FROM_LDS>(p0, p1, 2, n);
-                    dp_store2_u(pcm + (size_t)n * C, v.x + hx0[m], v.y + hx1[m]);
-                    dp_store2_u(pcm + (size_t)(n + 1) * C, v.z + hy0[m], v.w + hy1[m]);
+                    pcm_put2(pcm + (size_t)n * C, v.x + hx0[m], v.y + hx1[m]);
+                    pcm_put2(pcm + (size_t)(n + 1) * C, v.z + hy0[m], v.w + hy1[m]);
                 }
             }
 #pragma unroll
@@ -1475,8 +1482,8 @@ DP_DEVICE void epilogue(const float* p0, const float* p1, const unit_view& u, in
                 const int n = 2 * lane + 128 * t4;
                 if (n < 448) {
                     const dpf4 v = incoming<FROM_LDS>(p0, p1, 2, n);
-                    dp_store2_u(pcm + (size_t)n * C, v.x, v.y);
-                    dp_store2_u(pcm + (size_t)(n + 1) * C, v.z, v.w);
+                    pcm_put2(pcm + (size_t)n * C, v.x, v.y);
+                    pcm_put2(pcm + (size_t)(n + 1) * C, v.z, v.w);
                 }
             }
         }
@@ -1487,7 +1494,7 @@ DP_DEVICE void epilogue(const float* p0, const float* p1, const unit_view& u, in
 #pragma unroll
     for (int c = 0; c < 2; c++) {
         if (c < n_ch) {
-            float* dst = pcm + c;
+            elem* dst = pcm + c;
             const int cls = c ? cls1 : cls0;
             const float (&hx)[8] = c ? hx1 : hx0;
             const float (&hy)[8] = c ? hy1 : hy0;
@@ -1496,8 +1503,8 @@ DP_DEVICE void epilogue(const float* p0, const float* p1, const unit_view& u, in
                 for (int m = 0; m < 8; m++) {
                     const int n = 2 * lane + 128 * m;
                     const dpf4 v = incoming<FROM_LDS>(p0, p1, n_ch, n);
-                    dst[(size_t)n * C]       = (c ? v.y : v.x) + hx[m];
-                    dst[(size_t)(n + 1) * C] = (c ? v.w : v.z) + hy[m];
+                    pcm_put1(dst + (size_t)n * C, (c ? v.y : v.x) + hx[m]);
+                    pcm_put1(dst + (size_t)(n + 1) * C, (c ? v.w : v.z) + hy[m]);
                 }
             } else {
 #pragma unroll
@@ -1505,8 +1512,8 @@ DP_DEVICE void epilogue(const float* p0, const float* p1, const unit_view& u, in
                     if (w < 4 || (w == 4 && m < 4)) {
                         const int n = 448 + 128 * w + 2 * g + 16 * m;
                         const dpf4 v = incoming<FROM_LDS>(p0, p1, n_ch, n);
-                        dst[(size_t)n * C]       = (c ? v.y : v.x) + hx[m];
-                        dst[(size_t)(n + 1) * C] = (c ? v.w : v.z) + hy[m];
+                        pcm_put1(dst + (size_t)n * C, (c ? v.y : v.x) + hx[m]);
+                        pcm_put1(dst + (size_t)(n + 1) * C, (c ? v.w : v.z) + hy[m]);
                     }
                 }
 #pragma unroll
@@ -1514,8 +1521,8 @@ DP_DEVICE void epilogue(const float* p0, const float* p1, const unit_view& u, in
                     const int n = 2 * lane + 128 * t4;
                     if (n < 448) {
                         const dpf4 v = incoming<FROM_LDS>(p0, p1, n_ch, n);
-                        dst[(size_t)n * C]       = c ? v.y : v.x;
-                        dst[(size_t)(n + 1) * C] = c ? v.w : v.z;
+                        pcm_put1(dst + (size_t)n * C, c ? v.y : v.x);
+                        pcm_put1(dst + (size_t)(n + 1) * C, c ? v.w : v.z);
                     }
                 }
             }
@@ -1526,7 +1533,7 @@ DP_DEVICE void epilogue(const float* p0, const float* p1, const unit_view& u, in
 /* ------------------------------------------------------------------------------------ */
 /* one run per workgroup                                                                   */
 /* ------------------------------------------------------------------------------------ */
-template <int KIND>
+template <int KIND, int OUT = AACG_OUTPUT_F32>
 DP_DEVICE void imdct_run_body(const aacg_kparams& P)
 {
     const int TAB_FLOATS = (KIND == AACG_INPUT_QUANT_I16) ? AACG_TAB_QUANT_FLOATS : AACG_TAB_F32_FLOATS;
@@ -1654,11 +1661,11 @@ DP_DEVICE void imdct_run_body(const aacg_kparams& P)
              * (filter_bank.js:38-41, `overlap = this.overlaps[channel]`) */
             const float* ov0 = P.overlap + (P.flip ? run->ov_b[0] : run->ov_a[0]);
             const float* ov1 = P.overlap + (P.flip ? run->ov_b[1] : run->ov_a[1]);
-            epilogue<false>(ov0, ov1, u, n_ch, cls0, cls1, P.pcm, hx0, hy0, hx1, hy1);
+            epilogue<false, OUT>(ov0, ov1, u, n_ch, cls0, cls1, P.pcm, hx0, hy0, hx1, hy1);
         } else {
             dp_flag_wait(&flags[wave - 1], 1);         /* the previous frame's tails (acquire) */
             if (trace && lane == 0) trace[4] = dp_clock();
-            epilogue<true>(slot - AACG_SLOT_FLOATS, slot - AACG_SLOT_FLOATS, u, n_ch, cls0, cls1, P.pcm, hx0, hy0, hx1, hy1);
+            epilogue<true, OUT>(slot - AACG_SLOT_FLOATS, slot - AACG_SLOT_FLOATS, u, n_ch, cls0, cls1, P.pcm, hx0, hy0, hx1, hy1);
         }
         if (trace && lane == 0) trace[5] = dp_clock();     /* PCM stores issued */
         /* the chain's last frame in this launch: its tail is the new overlap state (planar in HBM) */
@@ -1694,7 +1701,7 @@ DP_DEVICE void imdct_run_body(const aacg_kparams& P)
  * Kept as a second function on purpose: the same source instantiated without the second pass compiles to a run
  * body that is 0.8 us slower on config 2 than the one above (interleaved A/B, 16.8 vs 16.0 us), and a non-inlined
  * predecessor pass costs config 4 more than it saves (29 vs 23 us).  The stages themselves are shared. */
-template <int KIND>
+template <int KIND, int OUT = AACG_OUTPUT_F32>
 DP_DEVICE void imdct_run_body_dd(const aacg_kparams& P)
 {
     const int TAB_FLOATS = (KIND == AACG_INPUT_QUANT_I16) ? AACG_TAB_QUANT_FLOATS : AACG_TAB_F32_FLOATS;
@@ -1862,11 +1869,11 @@ DP_DEVICE void imdct_run_body_dd(const aacg_kparams& P)
              * `overlap = this.overlaps[channel]`); a double-duty wave: the tails it parked itself */
             const float* ov0 = n_pass == 2 ? scratch : P.overlap + (P.flip ? run->ov_b[0] : run->ov_a[0]);
             const float* ov1 = n_pass == 2 ? scratch + 1024 : P.overlap + (P.flip ? run->ov_b[1] : run->ov_a[1]);
-            epilogue<false>(ov0, ov1, u, n_ch, cls0, cls1, P.pcm, hx0, hy0, hx1, hy1);
+            epilogue<false, OUT>(ov0, ov1, u, n_ch, cls0, cls1, P.pcm, hx0, hy0, hx1, hy1);
         } else {
             dp_flag_wait(&flags[wave - 1], 1);         /* the previous frame's tails (acquire) */
             if (trace && lane == 0) trace[4] = dp_clock();
-            epilogue<true>(slot - AACG_SLOT_FLOATS, slot - AACG_SLOT_FLOATS, u, n_ch, cls0, cls1, P.pcm, hx0, hy0, hx1, hy1);
+            epilogue<true, OUT>(slot - AACG_SLOT_FLOATS, slot - AACG_SLOT_FLOATS, u, n_ch, cls0, cls1, P.pcm, hx0, hy0, hx1, hy1);
         }
         if (trace && lane == 0) trace[5] = dp_clock();     /* PCM stores issued */
         /* the chain's last frame in this launch: its tail is the new overlap state (planar in HBM) */

@@ -125,6 +125,17 @@ DP_DEVICE void dp_store_nt(dpf4* p, dpf4 v)
  * global_store_dwordx2 — gfx950 runs in unaligned-access mode, and the type says align 4 */
 typedef float dp_f2u __attribute__((ext_vector_type(2), aligned(4)));
 DP_DEVICE void dp_store2_u(float* p, float a, float b) { dp_f2u v; v[0] = a; v[1] = b; *(dp_f2u*)p = v; }
+/* two PCM-scale samples (|x| < 1 nominally) as int16, round to nearest even, saturating: low half = a */
+typedef short dp_i16x2 __attribute__((ext_vector_type(2)));
+DP_DEVICE int dp_pcm16_pair(float a, float b)
+{
+    const dp_i16x2 p = __builtin_amdgcn_cvt_pk_i16(__builtin_rintf(a * 32768.0f), __builtin_rintf(b * 32768.0f));   /* v_cvt_pk_i16_i32 saturates */
+    return __builtin_bit_cast(int, p);
+}
+typedef int dp_i2u __attribute__((ext_vector_type(2), aligned(4)));
+DP_DEVICE void dp_store_i2_nt(void* p, int a, int b) { dp_i2u v; v[0] = a; v[1] = b; __builtin_nontemporal_store(v, (dp_i2u*)p); }
+typedef int dp_i1u __attribute__((aligned(2)));
+DP_DEVICE void dp_store_i1_u(void* p, int a) { *(dp_i1u*)p = a; }
 /* constant-rate (100 MHz) wall clock, same time base on every CU: phase timelines for profiling */
 DP_DEVICE unsigned long long dp_clock() { return wall_clock64(); }
 /* keep the instruction scheduler from hoisting the next block's loads above this point

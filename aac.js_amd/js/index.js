@@ -12,6 +12,7 @@
 const path = require('path');
 
 const INPUT_SPEC_F32 = 0, INPUT_QUANT_I16 = 1;
+const OUTPUT_F32 = 0, OUTPUT_I16 = 1;       // Engine({ outputKind }): OUTPUT_I16 engines take an Int16Array for pcm
 const UNIT_BYTES = 64, META_WORDS = 120, FRAME = 1024, TNS_BYTES = 424, TNS_MAX_ORDER = 12;
 const TNS_REFERENCE = 0, TNS_SPEC = 1, PNS_REFERENCE = 0, PNS_SPEC = 1;
 const SAMPLE_RATES = [96000, 88200, 64000, 48000, 44100, 32000, 24000, 22050, 16000, 12000, 11025, 8000, 7350];
@@ -142,7 +143,7 @@ function Engine(opts) {
     this.handle = this.addon.create({ deviceOrdinal: opts.deviceOrdinal | 0, sampleIndex: opts.sampleIndex === undefined ? 3 : opts.sampleIndex,
                                       maxStreams: opts.maxStreams || 1, maxChannels: opts.maxChannels || 2,
                                       maxBatchUnits: opts.maxBatchUnits | 0, inputKind: this.inputKind,
-                                      tnsMode: opts.tnsMode | 0, pnsMode: opts.pnsMode | 0 });
+                                      tnsMode: opts.tnsMode | 0, pnsMode: opts.pnsMode | 0, outputKind: opts.outputKind | 0 });
 }
 /* tns: packTns(...) records for TNS_SPEC engines, else omitted */
 Engine.prototype.decodeBatch = function (units, coeffs, meta, pcm, tns) {
@@ -320,7 +321,7 @@ GpuAACDecoder.prototype.feed = function (bytes) { this.frontend.push(bytes.data 
 GpuAACDecoder.prototype.feedPacket = function (bytes) { this.frontend.pushPacket(bytes.data || bytes); };
 
 module.exports = { Engine, GpuAACDecoder, BitReader, packUnits, unpackUnits, packBandWord, packTns, unpackTns, applyPulses, loadAddon,
-                   INPUT_SPEC_F32, INPUT_QUANT_I16, TNS_REFERENCE, TNS_SPEC, PNS_REFERENCE, PNS_SPEC, UNIT_BYTES, META_WORDS, TNS_BYTES, SAMPLE_RATES };
+                   INPUT_SPEC_F32, INPUT_QUANT_I16, OUTPUT_F32, OUTPUT_I16, TNS_REFERENCE, TNS_SPEC, PNS_REFERENCE, PNS_SPEC, UNIT_BYTES, META_WORDS, TNS_BYTES, SAMPLE_RATES };
 /* the bitstream front end and its pieces (loaded on first use: they require this module themselves) */
 for (const [name, file] of [['FrontEnd', './frontend.js'], ['GpuFrontEnd', './gpu_frontend.js'], ['codebooks', './codebooks.js'], ['adts', './adts.js'], ['BitStream', './bits.js']])
     Object.defineProperty(module.exports, name, { enumerable: true, get: function () { const m = require(file); return m[name] || m; } });

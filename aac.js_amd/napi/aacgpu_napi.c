@@ -27,14 +27,14 @@ static struct {
     int  (*get_overlap)(aacg_engine*, uint32_t, uint32_t, float*);
     int  (*set_overlap)(aacg_engine*, uint32_t, uint32_t, const float*);
     int  (*decode_batch)(aacg_engine*, const aacg_unit_desc*, uint32_t, const void*, uint32_t,
-                         const aacg_band_meta*, uint32_t, float*, size_t);
+                         const aacg_band_meta*, uint32_t, void*, size_t);
     int  (*submit)(aacg_engine*, const aacg_unit_desc*, uint32_t, const void*, uint32_t,
-                   const aacg_band_meta*, uint32_t, float*, size_t, uint64_t*);
+                   const aacg_band_meta*, uint32_t, void*, size_t, uint64_t*);
     int  (*wait)(aacg_engine*, uint64_t);
     int  (*decode_batch_tns)(aacg_engine*, const aacg_unit_desc*, uint32_t, const void*, uint32_t,
-                             const aacg_band_meta*, uint32_t, const aacg_tns_info*, uint32_t, float*, size_t);
+                             const aacg_band_meta*, uint32_t, const aacg_tns_info*, uint32_t, void*, size_t);
     int  (*submit_tns)(aacg_engine*, const aacg_unit_desc*, uint32_t, const void*, uint32_t,
-                       const aacg_band_meta*, uint32_t, const aacg_tns_info*, uint32_t, float*, size_t, uint64_t*);
+                       const aacg_band_meta*, uint32_t, const aacg_tns_info*, uint32_t, void*, size_t, uint64_t*);
     int  (*parser_create)(int, int, const aacg_code_entry*, const uint32_t*, aacg_parser**);
     void (*parser_destroy)(aacg_parser*);
     const char* (*parser_last_error)(const aacg_parser*);
@@ -89,7 +89,7 @@ static int get_i32(napi_env env, napi_value obj, const char* key, int32_t dflt)
  * turns.  Jobs keep a reference on the external, so a collected Engine object cannot be finalised under a running job. */
 #define BOX_ENGINE 0x41454e47u   /* 'AENG' */
 #define BOX_PARSER 0x41505253u   /* 'APRS' */
-typedef struct { uint32_t kind; void* ptr; pthread_mutex_t lock; } handle_box;
+typedef struct { uint32_t kind; void* ptr; pthread_mutex_t lock; int out_i16; /* engine: AACG_OUTPUT_I16 */ } handle_box;
 
 static handle_box* box_new(uint32_t kind, void* ptr)
 {
@@ -146,11 +146,13 @@ static napi_value js_create(napi_env env, napi_callback_info info)
     cfg.input_kind = get_i32(env, argv[0], "inputKind", AACG_INPUT_QUANT_I16);
     cfg.tns_mode = get_i32(env, argv[0], "tnsMode", AACG_TNS_REFERENCE);
     cfg.pns_mode = get_i32(env, argv[0], "pnsMode", AACG_PNS_REFERENCE);
+    cfg.output_kind = get_i32(env, argv[0], "outputKind", AACG_OUTPUT_F32);
     aacg_engine* e = NULL;
     int rc = L.create(&cfg, &e);
     if (rc) return fail(env, NULL, rc, "aacg_create (is a GPU visible?)");
     handle_box* b = box_new(BOX_ENGINE, e);
     if (!b) { L.destroy(e); napi_throw_error(env, NULL, "aacgpu: out of memory"); return NULL; }
+    b->out_i16 = cfg.output_kind == AACG_OUTPUT_I16;
     CHECK(env, napi_create_external(env, b, engine_finalize, NULL, &out));
     return out;
 }
@@ -211,11 +213,11 @@ static napi_value js_decode_batch(napi_env env, napi_callback_info info)
         if (!typed(env, argv[3], &tm, &nm, &dm) || tm != napi_uint16_array || nm % AACG_MAX_SECTIONS) {
             napi_throw_type_error(env, NULL, "meta must be a Uint16Array of 120-word aacg_band_meta records"); return NULL; }
     }
-    if (!typed(env, argv[4], &tp, &np, &dp) || tp != napi_float32_array) {
-        napi_throw_type_error(env, NULL, "pcm must be a Float32Array"); return NULL; }
+    if (!typed(env, argv[4], &tp, &np, &dp) || tp != (engine_box(env, argv[0])->out_i16 ? napi_int16_array : napi_float32_array)) {
+        napi_throw_type_error(env, NULL, "pcm must be a Float32Array (an Int16Array for an engine created with outputKind: OUTPUT_I16)"); return NULL; }
     int rc = L.decode_batch_tns(e, (const aacg_unit_desc*)du, (uint32_t)(nu / sizeof(aacg_unit_desc)), dc, (uint32_t)(nc / 1024),
                                 (const aacg_band_meta*)dm, (uint32_t)(nm / AACG_MAX_SECTIONS),
-                                (const aacg_tns_info*)dt, (uint32_t)nt, (float*)dp, np);
+                                (const aacg_tns_info*)dt, (uint32_t)nt, dp, np);
     if (rc) return fail(env, e, rc, "aacg_decode_batch");
     return argv[4];
 }
@@ -263,7 +265,7 @@ typedef struct {
     const aacg_unit_desc* units; uint32_t n_units;
     const void* coeffs; uint32_t n_blocks;
     const aacg_band_meta* meta; uint32_t n_meta;
-    float* pcm; size_t n_pcm;
+    void* pcm; size_t n_pcm;
     int rc;
     char err[512];
 } async_job;
@@ -312,7 +314,7 @@ static napi_value js_decode_batch_async(napi_env env, napi_callback_info info)
     napi_valuetype vt;
     if (!typed(env, argv[1], &tu, &nu, &du) || tu != napi_uint8_array || nu % sizeof(aacg_unit_desc) ||
         !typed(env, argv[2], &tc, &nc, &dc) || (tc != napi_int16_array && tc != napi_float32_array) || nc % 1024 ||
-        !typed(env, argv[4], &tp, &np, &dp) || tp != napi_float32_array) {
+        !typed(env, argv[4], &tp, &np, &dp) || tp != (box->out_i16 ? napi_int16_array : napi_float32_array)) {
         napi_throw_type_error(env, NULL, "decodeBatchAsync(engine, Uint8Array units, Int16Array|Float32Array coeffs, Uint16Array|null meta, Float32Array pcm)");
         return NULL;
     }
@@ -327,7 +329,7 @@ static napi_value js_decode_batch_async(napi_env env, napi_callback_info info)
     j->e = e; j->box = box; j->units = (const aacg_unit_desc*)du;
     napi_create_reference(env, argv[0], 1, &j->refs[5]); j->n_units = (uint32_t)(nu / sizeof(aacg_unit_desc));
     j->coeffs = dc; j->n_blocks = (uint32_t)(nc / 1024); j->meta = (const aacg_band_meta*)dm; j->n_meta = (uint32_t)(nm / AACG_MAX_SECTIONS);
-    j->pcm = (float*)dp; j->n_pcm = np;
+    j->pcm = dp; j->n_pcm = np;
     j->tns = (const aacg_tns_info*)dt; j->n_tns = (uint32_t)nt;
     if (dt) napi_create_reference(env, argv[5], 1, &j->refs[4]);
     const int idx[4] = {1, 2, 3, 4};

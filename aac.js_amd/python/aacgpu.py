@@ -14,6 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 LIB_PATH = os.environ.get("AACGPU_LIB") or os.path.join(ROOT, "aac.js_amd", "csrc", "libaacgpu.so")
 
 INPUT_SPEC_F32, INPUT_QUANT_I16 = 0, 1
+OUTPUT_F32, OUTPUT_I16 = 0, 1
 ERR_NAMES = {0: "OK", -1: "INVALID_ARG", -2: "NO_DEVICE", -3: "OUT_OF_MEMORY", -4: "CAPACITY",
              -5: "UNSUPPORTED", -6: "LAYOUT_CHANGE", -7: "STALE_PLAN"}
 
@@ -50,7 +51,7 @@ CHAN_TNS_PRESENT = 0x01
 class Config(C.Structure):
     _fields_ = [("abi_version", C.c_int32), ("device_ordinal", C.c_int32), ("sample_index", C.c_int32),
                 ("max_streams", C.c_int32), ("max_channels", C.c_int32), ("max_batch_units", C.c_int32),
-                ("input_kind", C.c_int32), ("tns_mode", C.c_int32), ("pns_mode", C.c_int32)]
+                ("input_kind", C.c_int32), ("tns_mode", C.c_int32), ("pns_mode", C.c_int32), ("output_kind", C.c_int32)]
 
 
 class AacgError(RuntimeError):
@@ -251,10 +252,11 @@ class Engine:
     """One engine per device (mirrors one FilterBank per decoder, for many streams at once)."""
 
     def __init__(self, input_kind=INPUT_QUANT_I16, max_streams=1, max_channels=2, device=0, sample_index=3,
-                 max_batch_units=0, tns_mode=TNS_REFERENCE, pns_mode=PNS_REFERENCE):
+                 max_batch_units=0, tns_mode=TNS_REFERENCE, pns_mode=PNS_REFERENCE, output_kind=OUTPUT_F32):
         self.lib = load_library()
         cfg = Config(self.lib.aacg_abi_version(), device, sample_index, max_streams, max_channels, max_batch_units,
-                     input_kind, tns_mode, pns_mode)
+                     input_kind, tns_mode, pns_mode, output_kind)
+        self.pcm_dtype = np.int16 if output_kind == OUTPUT_I16 else np.float32
         h = C.c_void_p()
         rc = self.lib.aacg_create(C.byref(cfg), C.byref(h))
         if rc:
@@ -288,7 +290,7 @@ class Engine:
         n_blocks = coeffs.size // 1024
         if meta is not None:
             meta = np.ascontiguousarray(meta, np.uint16)
-        pcm = np.full(n_pcm_floats, np.nan, np.float32)
+        pcm = np.full(n_pcm_floats, np.nan, np.float32) if self.pcm_dtype == np.float32 else np.full(n_pcm_floats, -32768, np.int16)
         if tns is not None:
             tns = np.ascontiguousarray(tns)
             assert tns.dtype == TNS_DTYPE

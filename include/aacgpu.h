@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define AACG_ABI_VERSION 3
+#define AACG_ABI_VERSION 4
 
 #define AACG_FRAME_LEN      1024   /* decoder.js:86 frameLength                       */
 #define AACG_MAX_SECTIONS   120    /* ics.js:49 MAX_SECTIONS (bandTypes/scaleFactors) */
@@ -177,6 +177,14 @@ typedef struct aacg_band_meta {
 #define AACG_META_MS_USED   0x0400u
 #define AACG_META_BT_SHIFT  12
 
+enum {                          /* aacg_config.output_kind (ABI version 4)                          */
+    AACG_OUTPUT_F32 = 0,        /* the reference's output: interleaved float in [-1, 1) (decoder.js:203-215)   */
+    AACG_OUTPUT_I16 = 1         /* the same samples as int16: round-to-nearest(x * 32768), saturated — half the
+                                   bytes of the path's dominant stream, for hosts that feed 16-bit sinks.  Every
+                                   `pcm` pointer of such an engine is an int16_t*, every PCM count is in samples.
+                                   Not aac.js behaviour: an explicit output format              */
+};
+
 typedef struct aacg_config {
     int32_t abi_version;       /* AACG_ABI_VERSION                                             */
     int32_t device_ordinal;    /* HIP device                                                   */
@@ -187,6 +195,7 @@ typedef struct aacg_config {
     int32_t input_kind;        /* AACG_INPUT_*                                                 */
     int32_t tns_mode;          /* AACG_TNS_*                                                   */
     int32_t pns_mode;          /* AACG_PNS_* (ABI version 2)                                   */
+    int32_t output_kind;       /* AACG_OUTPUT_* (ABI version 4)                                */
 } aacg_config;
 
 typedef struct aacg_engine aacg_engine;
@@ -210,13 +219,13 @@ int aacg_set_overlap(aacg_engine* e, uint32_t stream, uint32_t channel, const fl
  * uploads units/coefficients, runs the kernels, downloads PCM.
  *   coeffs  float[...] (SPEC_F32) or int16_t[...] (QUANT_I16), n_coef_blocks * 1024 elements
  *   meta    aacg_band_meta[n_meta] or NULL (SPEC_F32)
- *   pcm_out float[n_pcm_floats]; every frame block [1024][n_out_ch] is fully written
+ *   pcm_out float[n_pcm_floats] (int16_t[n_pcm_floats] for AACG_OUTPUT_I16 engines); every frame block [1024][n_out_ch] is fully written
  *           (channels no unit covers are zero, decoder.js:229-231), scale 1/32768.   */
 int aacg_decode_batch(aacg_engine* e,
                       const aacg_unit_desc* units, uint32_t n_units,
                       const void* coeffs, uint32_t n_coef_blocks,
                       const aacg_band_meta* meta, uint32_t n_meta,
-                      float* pcm_out, size_t n_pcm_floats);
+                      void* pcm_out, size_t n_pcm_floats);
 
 /* Asynchronous pair of the same call, for pipelining: aacg_submit enqueues upload, kernels and
  * download of one batch on one of two internal HIP streams and returns a ticket; aacg_wait blocks
@@ -228,7 +237,7 @@ int aacg_submit(aacg_engine* e,
                 const aacg_unit_desc* units, uint32_t n_units,
                 const void* coeffs, uint32_t n_coef_blocks,
                 const aacg_band_meta* meta, uint32_t n_meta,
-                float* pcm_out, size_t n_pcm_floats, uint64_t* ticket);
+                void* pcm_out, size_t n_pcm_floats, uint64_t* ticket);
 int aacg_wait(aacg_engine* e, uint64_t ticket);
 /* The same three calls with TNS side info (AACG_TNS_SPEC engines; tns may be NULL otherwise). */
 int aacg_decode_batch_tns(aacg_engine* e,
@@ -236,13 +245,13 @@ int aacg_decode_batch_tns(aacg_engine* e,
                           const void* coeffs, uint32_t n_coef_blocks,
                           const aacg_band_meta* meta, uint32_t n_meta,
                           const aacg_tns_info* tns, uint32_t n_tns,
-                          float* pcm_out, size_t n_pcm_floats);
+                          void* pcm_out, size_t n_pcm_floats);
 int aacg_submit_tns(aacg_engine* e,
                     const aacg_unit_desc* units, uint32_t n_units,
                     const void* coeffs, uint32_t n_coef_blocks,
                     const aacg_band_meta* meta, uint32_t n_meta,
                     const aacg_tns_info* tns, uint32_t n_tns,
-                    float* pcm_out, size_t n_pcm_floats, uint64_t* ticket);
+                    void* pcm_out, size_t n_pcm_floats, uint64_t* ticket);
 /* Pinned (page-locked) host memory for the calls above: hipHostMalloc / hipHostFree. */
 void* aacg_host_alloc(size_t bytes);
 void  aacg_host_free(void* p);
@@ -260,7 +269,7 @@ void aacg_plan_destroy(aacg_plan* p);
  * returns after enqueueing.  d_coeffs / d_meta / d_pcm are DEVICE pointers.            */
 int aacg_decode_device(aacg_engine* e, aacg_plan* p,
                        const void* d_coeffs, const aacg_band_meta* d_meta,
-                       float* d_pcm, void* hip_stream);
+                       void* d_pcm, void* hip_stream);
 /* Spectral stage only (dequant + MS + IS): writes float[(coef_offset + c) * 1024 ...] so
  * that tests can gate this stage bit-exact.  QUANT_I16 engines only.                   */
 int aacg_spectral_device(aacg_engine* e, aacg_plan* p,

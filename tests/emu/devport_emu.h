@@ -115,6 +115,13 @@ DP_DEVICE double dp_fma(double a, double b, double c) { return fma(a, b, c); }
 DP_DEVICE dpv2 dp_fma2(dpv2 a, dpv2 b, dpv2 c) { dpv2 r; r[0] = fmaf(a[0], b[0], c[0]); r[1] = fmaf(a[1], b[1], c[1]); return r; }
 DP_DEVICE void dp_store_nt(dpf4* p, dpf4 v) { *p = v; }
 DP_DEVICE void dp_store2_u(float* p, float a, float b) { p[0] = a; p[1] = b; }
+DP_DEVICE int dp_pcm16_pair(float a, float b)
+{
+    auto one = [](float x) { float r = rintf(x * 32768.0f); r = r < -32768.0f ? -32768.0f : (r > 32767.0f ? 32767.0f : r); return (int)r & 0xffff; };
+    return one(a) | (one(b) << 16);
+}
+DP_DEVICE void dp_store_i2_nt(void* p, int a, int b) { memcpy(p, &a, 4); memcpy((char*)p + 4, &b, 4); }
+DP_DEVICE void dp_store_i1_u(void* p, int a) { memcpy(p, &a, 4); }
 DP_DEVICE unsigned long long dp_clock() { return 0; }
 DP_DEVICE void dp_keep_branch() {}
 DP_DEVICE void dp_sched_fence() {}

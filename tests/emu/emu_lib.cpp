@@ -22,6 +22,7 @@ struct launch_arg {
     int kind;     /* 0 f32 run, 1 quant run, 2 spectral, 3/4 optional stages, 7 front end */
     int n_units;
     const aacg_parse_params* PP;
+    int out_kind;
 };
 
 void* lane_main(void* p)
@@ -31,13 +32,17 @@ void* lane_main(void* p)
     /* the same dispatch as the engine's launch_run: double-duty variant / plain; kinds 3, 4: the optional-stage kernel */
     if (a->kind == 7) { aacg_parse::parse_body(*a->PP); return nullptr; }
     const bool dd = a->P->scratch != nullptr;
-    if (a->kind == 0)      { if (dd) imdct_run_body_dd<AACG_INPUT_SPEC_F32>(*a->P); else imdct_run_body<AACG_INPUT_SPEC_F32>(*a->P); }
+    if (a->out_kind == AACG_OUTPUT_I16 && a->kind == 0) { if (dd) imdct_run_body_dd<AACG_INPUT_SPEC_F32, AACG_OUTPUT_I16>(*a->P); else imdct_run_body<AACG_INPUT_SPEC_F32, AACG_OUTPUT_I16>(*a->P); }
+    else if (a->out_kind == AACG_OUTPUT_I16 && a->kind == 1) { if (dd) imdct_run_body_dd<AACG_INPUT_QUANT_I16, AACG_OUTPUT_I16>(*a->P); else imdct_run_body<AACG_INPUT_QUANT_I16, AACG_OUTPUT_I16>(*a->P); }
+    else if (a->kind == 0) { if (dd) imdct_run_body_dd<AACG_INPUT_SPEC_F32>(*a->P); else imdct_run_body<AACG_INPUT_SPEC_F32>(*a->P); }
     else if (a->kind == 1) { if (dd) imdct_run_body_dd<AACG_INPUT_QUANT_I16>(*a->P); else imdct_run_body<AACG_INPUT_QUANT_I16>(*a->P); }
     else if (a->kind == 3) spectral_ex_body<AACG_INPUT_QUANT_I16>(*a->P, a->n_units);
     else if (a->kind == 4) spectral_ex_body<AACG_INPUT_SPEC_F32>(*a->P, a->n_units);
     else                   spectral_body(*a->P, a->n_units);
     return nullptr;
 }
+
+int g_out_kind = AACG_OUTPUT_F32;          /* emu_set_output_kind: the next decodes store int16 PCM */
 
 void launch(const aacg_kparams& P, int kind, int grid, int waves, size_t lds_bytes, int n_units = 0, const aacg_parse_params* PP = nullptr)
 {
@@ -63,6 +68,7 @@ void launch(const aacg_kparams& P, int kind, int grid, int waves, size_t lds_byt
             args[(size_t)t].kind = kind;
             args[(size_t)t].n_units = n_units;
             args[(size_t)t].PP = PP;
+            args[(size_t)t].out_kind = g_out_kind;
             pthread_create(&tid[(size_t)t], &attr, lane_main, &args[(size_t)t]);
         }
         for (int t = 0; t < threads; t++) pthread_join(tid[(size_t)t], nullptr);
@@ -82,6 +88,7 @@ std::string g_err;
 extern "C" {
 
 const char* emu_last_error() { return g_err.c_str(); }
+void emu_set_output_kind(int kind) { g_out_kind = kind; }       /* AACG_OUTPUT_*: the pcm buffer of later decodes is int16 */
 
 int emu_get_windows(int sample_index, float* dst /* 1024+1024+128+128 */)
 {
@@ -153,7 +160,7 @@ int emu_decode_ex(int input_kind, int sample_index, int max_streams, int max_cha
     int rc = aacg_plan_build(units, n_units, sample_index, max_streams, max_channels, parity, &ph, &g_err, tns, n_tns);
     if (rc) return rc;
     if (ph.pcm_floats > n_pcm_floats) { g_err = "pcm buffer too small"; return AACG_ERR_CAPACITY; }
-    if (ph.zero_fill) std::memset(pcm, 0, n_pcm_floats * sizeof(float));
+    if (ph.zero_fill) std::memset(pcm, 0, n_pcm_floats * (g_out_kind == AACG_OUTPUT_I16 ? 2 : 4));
     aacg_kparams P;
     std::memset(&P, 0, sizeof P);
     P.units = ph.units.data(); P.runs = ph.runs.data(); P.coeffs = coeffs; P.meta = meta; P.pcm = pcm;

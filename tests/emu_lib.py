@@ -32,18 +32,20 @@ class Emu:
     def error(self):
         return self.lib.emu_last_error().decode()
 
-    def decode(self, units, coeffs, meta, n_pcm, pool, parity, sample_index=3, tns=None, pns=False):
+    def decode(self, units, coeffs, meta, n_pcm, pool, parity, sample_index=3, tns=None, pns=False, int16_out=False):
         units = np.ascontiguousarray(units)
         coeffs = np.ascontiguousarray(coeffs)
         kind = 1 if coeffs.dtype == np.int16 else 0
         meta = np.ascontiguousarray(meta, np.uint16) if meta is not None else None
-        pcm = np.full(n_pcm, np.nan, np.float32)
+        pcm = np.full(n_pcm, -32768, np.int16) if int16_out else np.full(n_pcm, np.nan, np.float32)
         tns = np.ascontiguousarray(tns) if tns is not None else None
+        self.lib.emu_set_output_kind(1 if int16_out else 0)
         rc = self.lib.emu_decode_ex(kind, sample_index, pool.shape[0], pool.shape[1], units.ctypes.data, len(units),
                                     coeffs.ctypes.data, meta.ctypes.data if meta is not None else None,
                                     tns.ctypes.data if tns is not None else None, len(tns) if tns is not None else 0,
                                     1 if pns else 0,
                                     pcm.ctypes.data, n_pcm, pool.ctypes.data, parity.ctypes.data)
+        self.lib.emu_set_output_kind(0)
         if rc:
             raise RuntimeError("emu_decode rc=%d: %s" % (rc, self.error()))
         return pcm

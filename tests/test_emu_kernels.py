@@ -237,6 +237,31 @@ def test_multichannel_long_chains(emu, oracle, layout, T):
         assert np.abs(emu_lib.pool_current(pool, par) - ov).max() < 1e-5 * max(1.0, np.abs(ov).max())
 
 
+def pcm16(ref):
+    """What AACG_OUTPUT_I16 means: round-to-nearest-even of x * 32768, saturated."""
+    return np.clip(np.rint(ref.astype(np.float64) * 32768.0), -32768, 32767).astype(np.int16)
+
+
+@pytest.mark.parametrize("layout,T", [(("cpe",), 20), (("cpe", "cpe", "cpe", "sce"), 5), (("sce",), 18)])
+def test_int16_output(emu, oracle, layout, T):
+    """AACG_OUTPUT_I16: the same samples as int16.  Against the oracle's float PCM rounded the same way: the float results
+    differ by ~1e-6 of their magnitude (a few hundredths of a step near full scale), so a sample next to a rounding boundary may
+    land one step off — never more, and for under 1 % of the samples."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "aac.js_amd", "python"))
+    import aacgpu_workload
+    S = 2
+    C = sum(2 if e == "cpe" else 1 for e in layout)
+    wl = aacgpu_workload.make_batch(n_streams=S, n_frames=T, layout=layout, mix=True, intensity=True, seed=31)
+    ov = np.zeros((S, C, 1024), np.float32)
+    want = pcm16(oracle.decode_batch(wl["units"], wl["q"], wl["meta"], wl["n_pcm"], ov))
+    pool = np.zeros((S, C, 2, 1024), np.float32)
+    got = emu.decode(wl["units"], wl["q"], wl["meta"], wl["n_pcm"], pool, np.zeros(S * C, np.uint8), int16_out=True)
+    d = got.astype(np.int32) - want
+    assert np.abs(d).max() <= 1 and np.count_nonzero(d) <= 1e-2 * d.size, (np.abs(d).max(), np.count_nonzero(d))
+    assert np.abs(want).max() > 1000
+
+
 @pytest.mark.parametrize("seed", [1, 2, 3, 4])
 def test_fuzz_vs_oracle(emu, oracle, seed):
     """Random layouts, sequences, shapes (also previous shapes), groupings, band types, masks: emulated kernels vs oracle."""

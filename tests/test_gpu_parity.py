@@ -663,3 +663,37 @@ def test_fft_64_kat(golden):
     for v in range(3):
         re, im = _unreorder(np.concatenate([s[2 * v], s[2 * v + 1]]), 256)
         assert _rel(np.stack([re, im], 1), golden["fft64.out"][v].astype(np.float64)) < 5e-6
+
+
+def _pcm16(ref):
+    return np.clip(np.rint(ref.astype(np.float64) * 32768.0), -32768, 32767).astype(np.int16)
+
+
+@pytest.mark.parametrize("layout,T,inp", [(("cpe",), 40, "q"), (("cpe",), 16, "spec"), (("cpe", "cpe", "cpe", "sce"), 20, "q"), (("sce",), 18, "q")])
+def test_int16_output(oracle, layout, T, inp):
+    """AACG_OUTPUT_I16 engines (aacg_imdct_run_*_i16): the same samples as int16, round to nearest, saturating; every path of
+    the epilogue (stereo fast path, multichannel in-place path, single channels, later runs of long chains).  Against the
+    oracle's float PCM rounded the same way: at most one step off, and only for samples within the float error of a rounding
+    boundary."""
+    S = 12
+    C = sum(2 if e == "cpe" else 1 for e in layout)
+    wl = aacgpu_workload.make_batch(n_streams=S, n_frames=T, layout=layout, mix=True, intensity=True, seed=31)
+    ov = np.zeros((S, C, 1024), np.float32)
+    ref, spec = oracle.decode_batch(wl["units"], wl["q"], wl["meta"], wl["n_pcm"], ov, want_spec=True)
+    want = _pcm16(ref)
+    kind = aacgpu.INPUT_QUANT_I16 if inp == "q" else aacgpu.INPUT_SPEC_F32
+    eng = aacgpu.Engine(kind, max_streams=S, max_channels=C, output_kind=aacgpu.OUTPUT_I16)
+    got = eng.decode_batch(wl["units"], wl["q"] if inp == "q" else spec, wl["meta"] if inp == "q" else None, wl["n_pcm"])
+    assert got.dtype == np.int16
+    d = got.astype(np.int32) - want
+    assert np.abs(d).max() <= 1 and np.count_nonzero(d) <= 1e-2 * d.size, (np.abs(d).max(), np.count_nonzero(d))
+    assert np.abs(want).max() > 1000
+    sat = np.full((1, 1024), 8190, np.int16)                     # far beyond full scale: saturates instead of wrapping
+    u1 = wl["units"][:1].copy()
+    u1["stream"] = 0; u1["pcm_offset"] = 0; u1["coef_offset"] = 0; u1["meta_offset"] = 0
+    if inp == "q" and layout == ("cpe",):
+        m = wl["meta"][:2].copy()
+        m[:] = (1 << 12) | 300                                    # sf index 300: 2^25
+        big = eng.decode_batch(u1, np.repeat(sat, 2, 0), m, 2048)
+        assert big.max() == 32767 and big.min() == -32768
+    eng.close()
