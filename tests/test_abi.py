@@ -24,7 +24,7 @@ def test_header_and_binding_agree():
 def test_library_exports_every_declared_symbol(engine_lib):
     for name in declared_symbols():
         assert hasattr(engine_lib, name), "libaacgpu.so does not export " + name
-    assert engine_lib.aacg_abi_version() == 3
+    assert engine_lib.aacg_abi_version() == 4
     assert engine_lib.aacg_kernel_name().decode().startswith("aacg_imdct_run")
 
 
@@ -42,7 +42,7 @@ def test_unit_desc_layout_matches_header():
         so = os.path.join(d, "s.so")
         subprocess.run(["gcc", "-shared", "-fPIC", "-I", ROOT, "-o", so, os.path.join(d, "s.c")], check=True)
         arr = (ctypes.c_int * 7).in_dll(ctypes.CDLL(so), "sizes")
-        assert list(arr) == [64, 16, 240, 36, 16, 24, 8]
+        assert list(arr) == [64, 16, 240, 40, 16, 24, 8]
     assert aacgpu.UNIT_DTYPE.itemsize == 64
     assert aacgpu.UNIT_DTYPE.fields["coef_offset"][1] == 16 and aacgpu.UNIT_DTYPE.fields["ch"][1] == 24
 
