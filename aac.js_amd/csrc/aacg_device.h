@@ -107,6 +107,30 @@ struct aacg_run {
     int32_t reserved;
 };
 
+/* AACG_CCE_SPEC: one (coupling element, target channel) pair of one frame.  Dependent coupling (spectral domain,
+ * cce.js:130-158): dst / src are coefficient blocks of the f32 spectrum buffer; independent (cce.js:121-128 with the
+ * CCE's own filterbank output): src is the CCE's block in the side PCM buffer, dst the float offset of the target
+ * channel's first sample in the PCM buffer, stride its n_out_ch. */
+struct aacg_couple_job {
+    uint32_t cce_unit;                /* the CCE's unit (window info, band types) */
+    uint32_t src, dst, stride;
+    uint32_t gain_off;                /* float index of the gain list in the plan's gain array */
+    uint32_t reserved[3];
+};
+
+struct aacg_couple_params {
+    const aacg_couple_job* jobs;
+    const aacg_dev_unit*   units;
+    const aacg_band_meta*  meta;      /* band types of the coupling elements (quantised input), or null */
+    const aacg_tables*     tab;       /* the coefficient -> band maps (global memory) */
+    const float*           gains;
+    float*                 spec;      /* dependent coupling: the f32 spectra, in place */
+    const float*           side;      /* independent coupling: the coupling elements' filterbank output, [block][1024] */
+    float*                 pcm;       /* ... added into the interleaved PCM */
+    int32_t                n_jobs;
+    int32_t                reserved;
+};
+
 struct aacg_kparams {
     const aacg_dev_unit*  units;
     const aacg_run*       runs;

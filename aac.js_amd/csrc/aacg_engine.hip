@@ -39,6 +39,9 @@ int aacg_i16_set_lds_limits(void);
 void aacg_i16_launch(bool quant, bool dd, dim3 grid, dim3 block, hipStream_t s, const aacg_kparams& P);
 int aacg_spectral_ex_set_lds_limits(void);
 void aacg_spectral_ex_launch(bool quant, int n_units, hipStream_t s, const aacg_kparams& P);
+/* aacg_engine_couple.hip: AACG_CCE_SPEC */
+void aacg_couple_launch(bool pcm, hipStream_t s, const aacg_couple_params& Q);
+struct cce_bufs { const aacg_run* runs; const aacg_couple_job* jobs; const float* gains; float* side; };
 
 extern "C" __global__ __launch_bounds__(AACG_WG_THREADS)
 void aacg_spectral(const aacg_kparams P, int n_units) { spectral_body(P, n_units); }
@@ -68,6 +71,7 @@ struct aacg_engine {
         void* d_tns = nullptr;    size_t tns_cap = 0;
         void* d_scratch = nullptr; size_t scratch_cap = 0;
         void* d_spec = nullptr;   size_t spec_cap = 0;       /* PNS route: f32 spectra between the two kernels */
+        void* d_cce[4] = {nullptr, nullptr, nullptr, nullptr}; size_t cce_cap[4] = {0, 0, 0, 0};   /* AACG_CCE_SPEC: runs, jobs, gains, side PCM */
         void* d_pcm = nullptr;    size_t pcm_cap = 0;
         /* page-locked staging for callers that pass ordinary (pageable) memory */
         void* h_in = nullptr;     size_t h_in_cap = 0;
@@ -96,7 +100,8 @@ struct aacg_plan {
     aacg_dev_tns* d_tns = nullptr;
     float* d_scratch = nullptr;             /* parked predecessor tails of double-duty runs */
     float* d_spec = nullptr;                /* PNS route: f32 spectra between the two kernels */
-    size_t bytes[5] = {0, 0, 0, 0, 0};      /* sizes of the five buffers above, for the engine's free list */
+    void*  d_cce[4] = {nullptr, nullptr, nullptr, nullptr};   /* AACG_CCE_SPEC: coupling elements' runs, jobs, gains, side PCM */
+    size_t bytes[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};            /* sizes of the nine buffers above, for the engine's free list */
     hipEvent_t uploaded = nullptr;          /* the tables are on the device */
     hipEvent_t last_use = nullptr;          /* recorded at destruction on last_stream: everything launched with this plan */
     hipStream_t last_stream = nullptr;      /* stream of the most recent launch (no per-launch event: it costs 3 us per step) */
@@ -172,7 +177,7 @@ bool is_pinned(const void* p)
 
 /* enqueue the run kernel for a planned batch (device pointers) */
 int launch_run(aacg_engine* e, const aacg_dev_unit* d_units, const aacg_run* d_runs, const aacg_dev_tns* d_tns,
-               float* d_scratch, float* d_spec, const aacg_plan_host& h, const void* d_coeffs, const aacg_band_meta* d_meta,
+               float* d_scratch, float* d_spec, const cce_bufs& cb, const aacg_plan_host& h, const void* d_coeffs, const aacg_band_meta* d_meta,
                void* d_pcm, int flip, hipStream_t s)
 {
     const bool i16 = e->cfg.output_kind == AACG_OUTPUT_I16;
@@ -189,7 +194,32 @@ int launch_run(aacg_engine* e, const aacg_dev_unit* d_units, const aacg_run* d_r
     P.ablate = e->d_trace ? e->ablate : (e->ablate & ~16);
     if (e->d_trace) P.spec_out = (float*)e->d_trace;
     const dim3 grid((unsigned)h.runs.size()), block(AACG_WG_THREADS);
-    if (h.any_tns || (quant && h.any_pns)) {
+    auto couple = [&](int point) {                      /* the coupling launches of one coupling point, round by round */
+        for (uint32_t r = 0; r < h.couple_rounds; r++) {
+            const uint32_t first = h.couple_first[(size_t)point * h.couple_rounds + r], last = h.couple_first[(size_t)point * h.couple_rounds + r + 1];
+            if (last <= first) continue;
+            aacg_couple_params Q;
+            Q.jobs = cb.jobs + first; Q.n_jobs = (int32_t)(last - first); Q.units = d_units; Q.meta = d_meta; Q.tab = e->d_tab;
+            Q.gains = cb.gains; Q.spec = d_spec; Q.side = cb.side; Q.pcm = (float*)d_pcm; Q.reserved = 0;
+            aacg_couple_launch(point == AACG_CCE_AFTER_IMDCT, s, Q);
+        }
+    };
+    if (h.any_cce) {
+        /* AACG_CCE_SPEC: every unit's spectrum (the coupling elements' too) as f32, then decoder.js:258-266 / 304-316 in
+         * stages: coupling before TNS, the TNS filters, coupling after TNS — each its own small launch, in place */
+        float* trace_or_null = P.spec_out;
+        P.spec_out = d_spec; P.pns = e->d_pns; P.tns = nullptr;
+        if (quant) aacg_spectral_ex_launch(true, (int)h.units.size(), s, P);
+        else HIP_TRY(e, hipMemcpyAsync(d_spec, d_coeffs, (size_t)h.coef_blocks * 4096u, hipMemcpyDeviceToDevice, s), AACG_ERR_NO_DEVICE);
+        couple(AACG_CCE_BEFORE_TNS);
+        if (h.any_tns) {
+            P.coeffs = d_spec; P.meta = nullptr; P.tns = d_tns;
+            aacg_spectral_ex_launch(false, (int)h.units.size(), s, P);
+        }
+        couple(AACG_CCE_AFTER_TNS);
+        P.spec_out = trace_or_null; P.coeffs = d_spec; P.meta = nullptr; P.tns = nullptr;
+        quant = false;
+    } else if (h.any_tns || (quant && h.any_pns)) {
         /* optional stages first (noise bands, TNS filters): f32 spectra, which the f32 run kernel takes from there */
         float* trace_or_null = P.spec_out;
         P.spec_out = d_spec; P.pns = e->d_pns;
@@ -206,6 +236,14 @@ int launch_run(aacg_engine* e, const aacg_dev_unit* d_units, const aacg_run* d_r
             if (quant) hipLaunchKernelGGL(aacg_imdct_run_quant, grid, block, AACG_LDS_BYTES_QUANT, s, P);
             else       hipLaunchKernelGGL(aacg_imdct_run_f32, grid, block, AACG_LDS_BYTES_F32, s, P);
         }
+    }
+    if (h.any_cce) {
+        if (!h.cce_runs.empty()) {                      /* the independently switched coupling elements' own filterbank pass */
+            aacg_kparams C = P;
+            C.runs = cb.runs; C.n_runs = (int32_t)h.cce_runs.size(); C.pcm = cb.side; C.scratch = nullptr;
+            hipLaunchKernelGGL(aacg_imdct_run_f32, dim3((unsigned)h.cce_runs.size()), block, AACG_LDS_BYTES_F32, s, C);
+        }
+        couple(AACG_CCE_AFTER_IMDCT);
     }
     HIP_TRY(e, hipGetLastError(), AACG_ERR_NO_DEVICE);
     return AACG_OK;
@@ -230,6 +268,8 @@ int aacg_create(const aacg_config* cfg, aacg_engine** out)
         (cfg->pns_mode != AACG_PNS_REFERENCE && cfg->pns_mode != AACG_PNS_SPEC) ||
         (cfg->pns_mode == AACG_PNS_SPEC && cfg->input_kind != AACG_INPUT_QUANT_I16) ||
         (cfg->output_kind != AACG_OUTPUT_F32 && cfg->output_kind != AACG_OUTPUT_I16) ||
+        (cfg->cce_mode != AACG_CCE_REFERENCE && cfg->cce_mode != AACG_CCE_SPEC) ||
+        (cfg->cce_mode == AACG_CCE_SPEC && cfg->output_kind != AACG_OUTPUT_F32) ||
         (cfg->input_kind != AACG_INPUT_SPEC_F32 && cfg->input_kind != AACG_INPUT_QUANT_I16))
         return AACG_ERR_INVALID_ARG;
 
@@ -286,6 +326,7 @@ void aacg_destroy(aacg_engine* e)
     if (e->d_overlap) (void)hipFree(e->d_overlap);
     for (auto& sl : e->slot) {
         for (void* p : {sl.d_units, sl.d_runs, sl.d_coeffs, sl.d_meta, sl.d_tns, sl.d_scratch, sl.d_spec, sl.d_pcm}) if (p) (void)hipFree(p);
+        for (void* p : sl.d_cce) if (p) (void)hipFree(p);
         if (sl.h_in) (void)hipHostFree(sl.h_in);
         if (sl.h_pcm) (void)hipHostFree(sl.h_pcm);
         if (sl.done) (void)hipEventDestroy(sl.done);
@@ -380,15 +421,22 @@ int aacg_plan_create(aacg_engine* e, const aacg_unit_desc* units, uint32_t n_uni
 int aacg_plan_create_tns(aacg_engine* e, const aacg_unit_desc* units, uint32_t n_units,
                          const aacg_tns_info* tns, uint32_t n_tns, aacg_plan** out)
 {
+    return aacg_plan_create_ex(e, units, n_units, tns, n_tns, nullptr, 0, out);
+}
+
+int aacg_plan_create_ex(aacg_engine* e, const aacg_unit_desc* units, uint32_t n_units,
+                        const aacg_tns_info* tns, uint32_t n_tns, const aacg_cce_info* cce, uint32_t n_cce, aacg_plan** out)
+{
     if (!e || !units || !n_units || !out) return AACG_ERR_INVALID_ARG;
     if (e->cfg.tns_mode != AACG_TNS_SPEC) { tns = nullptr; n_tns = 0; }   /* REFERENCE mode: TNS is the identity */
+    if (e->cfg.cce_mode != AACG_CCE_SPEC) { cce = nullptr; n_cce = 0; }   /* REFERENCE mode: a coupling element in the batch is refused */
     *out = nullptr;
     aacg_plan* p = new (std::nothrow) aacg_plan();
     if (!p) return AACG_ERR_OUT_OF_MEMORY;
     p->e = e;
     p->n_units = n_units;
     int rc = aacg_plan_build(units, n_units, e->cfg.sample_index, e->cfg.max_streams, e->cfg.max_channels,
-                             e->parity.data(), &p->h, &e->err, tns, n_tns);
+                             e->parity.data(), &p->h, &e->err, tns, n_tns, cce, n_cce);
     if (rc) { delete p; return rc; }
     if (p->h.any_pns && e->cfg.pns_mode != AACG_PNS_SPEC) {
         e->err = "a unit carries AACG_UNIT_HAS_PNS: NOISE_BT bands are not decodable by the reference either (AACG_PNS_SPEC engines fill them)";
@@ -396,16 +444,20 @@ int aacg_plan_create_tns(aacg_engine* e, const aacg_unit_desc* units, uint32_t n
         return AACG_ERR_UNSUPPORTED;
     }
     const size_t ub = sizeof(aacg_dev_unit) * n_units, rb = sizeof(aacg_run) * p->h.runs.size();
-    const size_t xb = (p->h.any_pns || p->h.any_tns) ? (size_t)p->h.coef_blocks * 1024u * sizeof(float) : 0;
+    const size_t xb = (p->h.any_pns || p->h.any_tns || p->h.any_cce) ? (size_t)p->h.coef_blocks * 1024u * sizeof(float) : 0;
     const size_t tb = sizeof(aacg_dev_tns) * p->h.tns.size();
     const size_t sb = p->h.needs_scratch ? p->h.runs.size() * AACG_SLOT_FLOATS * sizeof(float) : 0;
+    const size_t cb[4] = {sizeof(aacg_run) * p->h.cce_runs.size(), sizeof(aacg_couple_job) * p->h.couple_jobs.size(),
+                          sizeof(float) * p->h.gains.size(), (size_t)p->h.side_blocks * 4096u};
     bool ok = hip_ok(e, hipSetDevice(e->cfg.device_ordinal), "hipSetDevice") &&
               hip_ok(e, hipEventCreateWithFlags(&p->uploaded, hipEventDisableTiming), "hipEventCreate") &&
               hip_ok(e, hipEventCreateWithFlags(&p->last_use, hipEventDisableTiming), "hipEventCreate");
-    const size_t want[5] = {ub, rb, tb, sb, xb};
-    void** const slot[5] = {(void**)&p->d_units, (void**)&p->d_runs, (void**)&p->d_tns, (void**)&p->d_scratch, (void**)&p->d_spec};
-    const void* const src[5] = {p->h.units.data(), p->h.runs.data(), p->h.tns.data(), nullptr, nullptr};
-    for (int i = 0; i < 5 && ok; i++) {
+    const size_t want[9] = {ub, rb, tb, sb, xb, cb[0], cb[1], cb[2], cb[3]};
+    void** const slot[9] = {(void**)&p->d_units, (void**)&p->d_runs, (void**)&p->d_tns, (void**)&p->d_scratch, (void**)&p->d_spec,
+                            &p->d_cce[0], &p->d_cce[1], &p->d_cce[2], &p->d_cce[3]};
+    const void* const src[9] = {p->h.units.data(), p->h.runs.data(), p->h.tns.data(), nullptr, nullptr,
+                                p->h.cce_runs.data(), p->h.couple_jobs.data(), p->h.gains.data(), nullptr};
+    for (int i = 0; i < 9 && ok; i++) {
         if (!want[i]) continue;
         *slot[i] = pool_take(e, want[i], &p->bytes[i]);
         ok = *slot[i] != nullptr &&
@@ -435,8 +487,8 @@ void aacg_plan_destroy(aacg_plan* p)
         }
         (void)hipEventDestroy(p->last_use);
     }
-    void* const ptr[5] = {p->d_units, p->d_runs, p->d_tns, p->d_scratch, p->d_spec};
-    for (int i = 0; i < 5; i++) pool_give(e, ptr[i], p->bytes[i]);
+    void* const ptr[9] = {p->d_units, p->d_runs, p->d_tns, p->d_scratch, p->d_spec, p->d_cce[0], p->d_cce[1], p->d_cce[2], p->d_cce[3]};
+    for (int i = 0; i < 9; i++) pool_give(e, ptr[i], p->bytes[i]);
     delete p;
 }
 
@@ -463,7 +515,8 @@ int aacg_decode_device(aacg_engine* e, aacg_plan* p, const void* d_coeffs, const
     if (rc) return rc;
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : e->stream;
     if (!p->used) HIP_TRY(e, hipStreamWaitEvent(s, p->uploaded, 0), AACG_ERR_NO_DEVICE);
-    rc = launch_run(e, p->d_units, p->d_runs, p->d_tns, p->d_scratch, p->d_spec, p->h, d_coeffs, d_meta, d_pcm, (int)(p->launches & 1u), s);
+    const cce_bufs cb = {(const aacg_run*)p->d_cce[0], (const aacg_couple_job*)p->d_cce[1], (const float*)p->d_cce[2], (float*)p->d_cce[3]};
+    rc = launch_run(e, p->d_units, p->d_runs, p->d_tns, p->d_scratch, p->d_spec, cb, p->h, d_coeffs, d_meta, d_pcm, (int)(p->launches & 1u), s);
     if (rc) return rc;
     p->last_stream = s;
     p->used = true;
@@ -554,8 +607,22 @@ int aacg_submit_tns(aacg_engine* e, const aacg_unit_desc* units, uint32_t n_unit
                     const aacg_tns_info* tns, uint32_t n_tns,
                     void* pcm_out, size_t n_pcm_floats, uint64_t* ticket)
 {
-    if (!e || !units || !n_units || !coeffs || !pcm_out || !ticket) return AACG_ERR_INVALID_ARG;
+    const aacg_batch b = {units, n_units, coeffs, n_coef_blocks, meta, n_meta, tns, n_tns, nullptr, 0, pcm_out, n_pcm_floats};
+    return aacg_submit_ex(e, &b, ticket);
+}
+
+int aacg_submit_ex(aacg_engine* e, const aacg_batch* batch, uint64_t* ticket)
+{
+    if (!e || !batch) return AACG_ERR_INVALID_ARG;
+    const aacg_unit_desc* units = batch->units; const uint32_t n_units = batch->n_units;
+    const void* coeffs = batch->coeffs; const uint32_t n_coef_blocks = batch->n_coef_blocks;
+    const aacg_band_meta* meta = batch->meta; const uint32_t n_meta = batch->n_meta;
+    const aacg_tns_info* tns = batch->tns; uint32_t n_tns = batch->n_tns;
+    const aacg_cce_info* cce = batch->cce; uint32_t n_cce = batch->n_cce;
+    void* pcm_out = batch->pcm_out; const size_t n_pcm_floats = batch->n_pcm_floats;
+    if (!units || !n_units || !coeffs || !pcm_out || !ticket) return AACG_ERR_INVALID_ARG;
     if (e->cfg.tns_mode != AACG_TNS_SPEC) { tns = nullptr; n_tns = 0; }   /* REFERENCE mode: TNS is the identity */
+    if (e->cfg.cce_mode != AACG_CCE_SPEC) { cce = nullptr; n_cce = 0; }   /* REFERENCE mode: a coupling element in the batch is refused */
     const bool quant = e->cfg.input_kind == AACG_INPUT_QUANT_I16;
     if (quant && !meta) { e->err = "QUANT_I16 engine needs band meta"; return AACG_ERR_INVALID_ARG; }
     if (e->cfg.max_batch_units > 0 && (int)n_units > e->cfg.max_batch_units) {
@@ -575,7 +642,7 @@ int aacg_submit_tns(aacg_engine* e, const aacg_unit_desc* units, uint32_t n_unit
     }
 
     int rc = aacg_plan_build(units, n_units, e->cfg.sample_index, e->cfg.max_streams, e->cfg.max_channels,
-                             e->parity.data(), &sl.h, &e->err, tns, n_tns);
+                             e->parity.data(), &sl.h, &e->err, tns, n_tns, cce, n_cce);
     if (rc) return rc;
     const aacg_plan_host& h = sl.h;
     if (h.coef_blocks > n_coef_blocks || (quant && h.meta_blocks > n_meta) || h.pcm_floats > n_pcm_floats) {
@@ -610,7 +677,11 @@ int aacg_submit_tns(aacg_engine* e, const aacg_unit_desc* units, uint32_t n_unit
     const size_t ub = sizeof(aacg_dev_unit) * h.units.size(), rb = sizeof(aacg_run) * h.runs.size();
     const size_t tb = sizeof(aacg_dev_tns) * h.tns.size();
     const size_t sb = h.needs_scratch ? h.runs.size() * AACG_SLOT_FLOATS * sizeof(float) : 0;
-    const size_t xb = (h.any_pns || h.any_tns) ? (size_t)n_coef_blocks * 1024u * sizeof(float) : 0;
+    const size_t xb = (h.any_pns || h.any_tns || h.any_cce) ? (size_t)n_coef_blocks * 1024u * sizeof(float) : 0;
+    const size_t ccb[4] = {sizeof(aacg_run) * h.cce_runs.size(), sizeof(aacg_couple_job) * h.couple_jobs.size(),
+                           sizeof(float) * h.gains.size(), (size_t)h.side_blocks * 4096u};
+    const void* const cce_src[4] = {h.cce_runs.data(), h.couple_jobs.data(), h.gains.data(), nullptr};
+    for (int i = 0; i < 4; i++) if (ccb[i] && (rc = grow(e, &sl.d_cce[i], &sl.cce_cap[i], ccb[i]))) return rc;
     const size_t cb = (size_t)n_coef_blocks * 1024u * coef_elem_size(e);
     const size_t mb = quant ? (size_t)n_meta * sizeof(aacg_band_meta) : 0;
     const size_t pb = h.pcm_floats * pcm_elem_size(e);
@@ -643,13 +714,14 @@ int aacg_submit_tns(aacg_engine* e, const aacg_unit_desc* units, uint32_t n_unit
     HIP_TRY(e, hipMemcpyAsync(sl.d_units, h.units.data(), ub, hipMemcpyHostToDevice, s), AACG_ERR_NO_DEVICE);
     if (rb) HIP_TRY(e, hipMemcpyAsync(sl.d_runs, h.runs.data(), rb, hipMemcpyHostToDevice, s), AACG_ERR_NO_DEVICE);
     if (tb) HIP_TRY(e, hipMemcpyAsync(sl.d_tns, h.tns.data(), tb, hipMemcpyHostToDevice, s), AACG_ERR_NO_DEVICE);
+    for (int i = 0; i < 3; i++) if (ccb[i]) HIP_TRY(e, hipMemcpyAsync(sl.d_cce[i], cce_src[i], ccb[i], hipMemcpyHostToDevice, s), AACG_ERR_NO_DEVICE);
     HIP_TRY(e, hipMemcpyAsync(sl.d_coeffs, src_coeffs, cb, hipMemcpyHostToDevice, s), AACG_ERR_NO_DEVICE);
     if (quant) HIP_TRY(e, hipMemcpyAsync(sl.d_meta, src_meta, mb, hipMemcpyHostToDevice, s), AACG_ERR_NO_DEVICE);
     /* kernels chain through the overlap state: this one starts after the previous batch's kernel,
      * while its uploads above overlapped it */
     if (e->last_kernel) HIP_TRY(e, hipStreamWaitEvent(s, e->last_kernel, 0), AACG_ERR_NO_DEVICE);
     rc = launch_run(e, (const aacg_dev_unit*)sl.d_units, (const aacg_run*)sl.d_runs, (const aacg_dev_tns*)sl.d_tns,
-                    (float*)sl.d_scratch, (float*)sl.d_spec, h, sl.d_coeffs,
+                    (float*)sl.d_scratch, (float*)sl.d_spec, cce_bufs{(const aacg_run*)sl.d_cce[0], (const aacg_couple_job*)sl.d_cce[1], (const float*)sl.d_cce[2], (float*)sl.d_cce[3]}, h, sl.d_coeffs,
                     (const aacg_band_meta*)sl.d_meta, sl.d_pcm, 0, s);
     if (rc) return rc;
     HIP_TRY(e, hipEventRecord(sl.kernel_done, s), AACG_ERR_NO_DEVICE);
@@ -673,6 +745,14 @@ int aacg_decode_batch(aacg_engine* e, const aacg_unit_desc* units, uint32_t n_un
                       void* pcm_out, size_t n_pcm_floats)
 {
     return aacg_decode_batch_tns(e, units, n_units, coeffs, n_coef_blocks, meta, n_meta, nullptr, 0, pcm_out, n_pcm_floats);
+}
+
+int aacg_decode_batch_ex(aacg_engine* e, const aacg_batch* b)
+{
+    uint64_t t = 0;
+    int rc = aacg_submit_ex(e, b, &t);
+    if (rc) return rc;
+    return aacg_wait(e, t);
 }
 
 int aacg_decode_batch_tns(aacg_engine* e, const aacg_unit_desc* units, uint32_t n_units,

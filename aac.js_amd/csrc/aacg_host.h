@@ -37,6 +37,16 @@ struct aacg_plan_host {
     bool     any_pns = false;         /* some unit carries AACG_UNIT_HAS_PNS */
     bool     needs_scratch = false;   /* some later run holds 16 frames: its first wave parks the predecessor's tails */
     std::vector<aacg_run>   runs;     /* in launch (block) order, XCD-aware */
+    /* AACG_CCE_SPEC: independently switched coupling elements run through the filterbank like any channel, but into a
+     * side buffer (cce_runs: their own launch); coupling jobs by coupling point and by round (round r: the r-th coupling
+     * element of its frame, so that no two jobs of a round add to the same channel) */
+    bool     any_cce = false;
+    std::vector<aacg_run> cce_runs;
+    uint32_t side_blocks = 0;         /* 1024-float blocks of the side PCM buffer */
+    std::vector<aacg_couple_job> couple_jobs;                   /* sorted by (point, round) */
+    std::vector<uint32_t> couple_first;                         /* couple_first[point][round] ... start indices, see aacg_plan.cpp */
+    uint32_t couple_rounds = 0;
+    std::vector<float> gains;                                   /* [n_cce][16][120] */
     std::vector<aacg_chain> chains;
     bool     zero_fill = false;       /* some frame has a channel no unit writes (decoder.js:229-231) */
     uint32_t coef_blocks = 0;         /* 1 + highest (coef_offset + c) referenced */
@@ -56,7 +66,8 @@ static inline int32_t aacg_ov_offset(int max_channels, uint32_t stream, uint32_t
 int aacg_plan_build(const aacg_unit_desc* units, uint32_t n_units, int sample_index,
                     int max_streams, int max_channels, const uint8_t* parity,
                     aacg_plan_host* out, std::string* err,
-                    const aacg_tns_info* tns = nullptr, uint32_t n_tns = 0);
+                    const aacg_tns_info* tns = nullptr, uint32_t n_tns = 0,
+                    const aacg_cce_info* cce = nullptr, uint32_t n_cce = 0);
 
 /* tns.js:111-152: per-filter sample range and LPC coefficients of one channel (float32 stores as in the
  * reference's Float32Array lpc).  Returns AACG_OK or AACG_ERR_UNSUPPORTED (order > 12). */

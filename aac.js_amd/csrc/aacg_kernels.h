@@ -1964,6 +1964,54 @@ DP_DEVICE void spectral_ex_body(const aacg_kparams& P, int n_units)
     }
 }
 
+/* ------------------------------------------------------------------------------------ */
+/* AACG_CCE_SPEC: coupling channel elements (cce.js:121-158, decoder.js:406-433 as meant)    */
+/* ------------------------------------------------------------------------------------ */
+/* Dependent coupling, one wave per (coupling element, target channel) job: target[k] += gain[band of k] * cce[k] over
+ * the coupling element's coded bands (cce.js:130-158; the band of a coefficient comes from the same maps the
+ * dequantisation uses, the group of a short window from the element's group map).  One rounding per sample, like the
+ * reference's `data[i] += gain * iqData[i]` on a Float32Array: a fused multiply-add. */
+DP_DEVICE void couple_spec_body(const aacg_couple_params& Q, int waves_per_block)
+{
+    const int lane = dp_lane(), j = dp_block() * waves_per_block + dp_wave();
+    if (j >= Q.n_jobs) return;
+    const aacg_couple_job& job = Q.jobs[j];
+    const unit_view u = load_unit(Q.units + dp_uniform((int)job.cce_unit));
+    const int is_short = u.seq[0] == AACG_EIGHT_SHORT_SEQUENCE, max_sfb = u.max_sfb[0];
+    const float* src = Q.spec + (size_t)job.src * 1024u;
+    float* dst = Q.spec + (size_t)job.dst * 1024u;
+    const float* gains = Q.gains + job.gain_off;
+    const aacg_band_meta* m = Q.meta ? Q.meta + u.meta_offset : nullptr;
+#pragma unroll 4
+    for (int i = 0; i < 16; i++) {
+        const int k = lane + 64 * i;
+        const int sfb = is_short ? Q.tab->band_of_short[k & 127] : Q.tab->band_of_long[k];
+        const int g = is_short ? (int)((u.gmap[0] >> (4 * (k >> 7))) & 15u) : 0;
+        if (sfb < max_sfb) {
+            const int idx = g * max_sfb + sfb;
+            if (!m || (m->band[idx] >> AACG_META_BT_SHIFT) != AACG_ZERO_BT) dst[k] = dp_fma(gains[idx], src[k], dst[k]);
+        }
+    }
+}
+
+/* Independent coupling: the coupling element's own filterbank output (side buffer, PCM-scaled like everything the
+ * windows touched) times the list's gain, added to the target channel's samples in the interleaved PCM. */
+DP_DEVICE void couple_pcm_body(const aacg_couple_params& Q, int waves_per_block)
+{
+    const int lane = dp_lane(), j = dp_block() * waves_per_block + dp_wave();
+    if (j >= Q.n_jobs) return;
+    const aacg_couple_job& job = Q.jobs[j];
+    const float gain = Q.gains[job.gain_off];
+    const float* src = Q.side + (size_t)job.src * 1024u;
+    float* dst = Q.pcm + job.dst;
+    const size_t stride = job.stride;
+#pragma unroll 4
+    for (int i = 0; i < 16; i++) {
+        const int n = lane + 64 * i;
+        dst[n * stride] = dp_fma(gain, src[n], dst[n * stride]);
+    }
+}
+
 /* Spectral stage alone (16 units per workgroup, one wave each): spec_out in ICStream.data order. */
 DP_DEVICE void spectral_body(const aacg_kparams& P, int n_units)
 {

@@ -37,6 +37,7 @@ struct open_chain {
     std::vector<int32_t> units;
     uint32_t last_frame;
     uint8_t  n_ch;
+    bool     is_cce = false;   /* an independently switched coupling element: filterbank output to the side buffer */
 };
 
 int fail(std::string* err, int code, const char* fmt, long a = 0, long b = 0, long c = 0)
@@ -107,7 +108,8 @@ int aacg_tns_prepare(int sample_index, const aacg_chan_info* info, const aacg_tn
 int aacg_plan_build(const aacg_unit_desc* units, uint32_t n_units, int sample_index,
                     int max_streams, int max_channels, const uint8_t* parity,
                     aacg_plan_host* out, std::string* err,
-                    const aacg_tns_info* tns, uint32_t n_tns)
+                    const aacg_tns_info* tns, uint32_t n_tns,
+                    const aacg_cce_info* cce, uint32_t n_cce)
 {
     int swb[64];
     const int n_long = aacg_swb_offsets(sample_index, 1, swb);
@@ -123,13 +125,28 @@ int aacg_plan_build(const aacg_unit_desc* units, uint32_t n_units, int sample_in
         if (s.seen && s.mask != ((1u << s.n_out) - 1u)) { out->zero_fill = true; s.holes = true; }
     };
 
+    std::vector<uint32_t> frame_of(n_units, 0);             /* frame ordinal of every unit inside its stream's batch */
     for (uint32_t i = 0; i < n_units; i++) {
         const aacg_unit_desc& u = units[i];
         if (u.flags & AACG_UNIT_HAS_PNS) out->any_pns = true;
         if (u.n_ch < 1 || u.n_ch > 2) return fail(err, AACG_ERR_INVALID_ARG, "unit %ld: n_ch %ld", i, u.n_ch);
         if ((int)u.stream >= max_streams) return fail(err, AACG_ERR_CAPACITY, "unit %ld: stream %ld >= max_streams", i, u.stream);
-        if (u.n_out_ch < 1 || u.n_out_ch > max_channels || u.channel + u.n_ch > u.n_out_ch)
+        const bool is_cce = (u.flags & AACG_UNIT_CCE) != 0;
+        if (u.n_out_ch < 1 || u.n_out_ch > max_channels || (!is_cce && u.channel + u.n_ch > u.n_out_ch))
             return fail(err, AACG_ERR_INVALID_ARG, "unit %ld: channel %ld does not fit %ld output channels", i, u.channel, u.n_out_ch);
+        if (is_cce) {
+            /* cce.js:25-31: one channel of its own, beyond the output channels; the reference parses and ignores it */
+            if (!cce) return fail(err, AACG_ERR_UNSUPPORTED, "unit %ld is a coupling channel element: aac.js never applies them (AACG_CCE_SPEC engines do)", i);
+            if (u.n_ch != 1 || u.reserved1 >= n_cce || u.channel < u.n_out_ch || (int)u.channel >= max_channels)
+                return fail(err, AACG_ERR_INVALID_ARG, "unit %ld: a coupling element is one channel at a stream channel beyond the output channels", i);
+            const aacg_cce_info& ci = cce[u.reserved1];
+            if (ci.coupling_point > AACG_CCE_AFTER_IMDCT || ci.n_targets > AACG_CCE_MAX_TARGETS)
+                return fail(err, AACG_ERR_INVALID_ARG, "unit %ld: malformed aacg_cce_info", i);
+            for (int t = 0; t < ci.n_targets; t++)
+                if (ci.target[t].channel >= u.n_out_ch || ci.target[t].gain_list >= AACG_CCE_MAX_TARGETS)
+                    return fail(err, AACG_ERR_INVALID_ARG, "unit %ld: coupling target %ld out of range", i, t);
+            out->any_cce = true;
+        }
         for (int c = 0; c < u.n_ch; c++) {
             const aacg_chan_info& ci = u.ch[c];
             if (ci.window_sequence > 3 || ci.window_shape > 1 || ci.window_shape_prev > 1)
@@ -153,18 +170,24 @@ int aacg_plan_build(const aacg_unit_desc* units, uint32_t n_units, int sample_in
         else if (u.pcm_offset != s.cur_off) { close_frame(s); s.cur_off = u.pcm_offset; s.frame++; s.mask = 0; }
         if (u.n_out_ch != s.n_out) return fail(err, AACG_ERR_LAYOUT_CHANGE, "unit %ld: stream %ld changes channel count inside a batch", i, u.stream);
         if (u.pcm_offset & 3u) s.aligned = false;
-        const uint32_t bits = ((1u << u.n_ch) - 1u) << u.channel;
-        if (s.mask & bits) return fail(err, AACG_ERR_INVALID_ARG, "unit %ld: channel %ld written twice in one frame", i, u.channel);
-        s.mask |= bits;
+        frame_of[i] = s.frame;
+        const bool independent = is_cce && cce[u.reserved1].coupling_point == AACG_CCE_AFTER_IMDCT;
+        if (!is_cce) {
+            const uint32_t bits = ((1u << u.n_ch) - 1u) << u.channel;
+            if (s.mask & bits) return fail(err, AACG_ERR_INVALID_ARG, "unit %ld: channel %ld written twice in one frame", i, u.channel);
+            s.mask |= bits;
+        }
 
         const uint64_t key = ((uint64_t)u.stream << 16) | u.channel;
         open_chain* found = nullptr;
-        const uint32_t cached = std::min<uint32_t>(s.n_chains, 4u);
+        const bool chained = !is_cce || independent;           /* dependent coupling: spectrum only, no filterbank, no state */
+        const uint32_t cached = chained ? std::min<uint32_t>(s.n_chains, 4u) : 0u;
         for (uint32_t k = 0; k < cached; k++) if (s.chain_channel[k] == u.channel) { found = s.chain[k]; break; }
-        if (!found && s.n_chains > 4u) { auto it = open.find(key); if (it != open.end()) found = &it->second; }
-        if (!found) {
+        if (chained && !found && s.n_chains > 4u) { auto it = open.find(key); if (it != open.end()) found = &it->second; }
+        if (!chained) {
+        } else if (!found) {
             if (s.frame != 0) return fail(err, AACG_ERR_LAYOUT_CHANGE, "unit %ld: element at channel %ld appears mid-batch", i, u.channel);
-            open_chain oc; oc.last_frame = 0; oc.n_ch = u.n_ch; oc.units.reserve(16); oc.units.push_back((int32_t)i);
+            open_chain oc; oc.last_frame = 0; oc.n_ch = u.n_ch; oc.is_cce = is_cce; oc.units.reserve(16); oc.units.push_back((int32_t)i);
             auto at = open.emplace(key, std::move(oc)).first;
             if (s.n_chains < 4u) { s.chain[s.n_chains] = &at->second; s.chain_channel[s.n_chains] = u.channel; }
             s.n_chains++;
@@ -180,6 +203,11 @@ int aacg_plan_build(const aacg_unit_desc* units, uint32_t n_units, int sample_in
         aacg_dev_unit du;
         std::memset(&du, 0, sizeof du);
         du.d = u;
+        if (independent) {                                     /* its filterbank output goes to the side buffer, planar */
+            du.d.pcm_offset = out->side_blocks++ * 1024u;
+            du.d.n_out_ch = 1;
+            du.d.channel = 0;
+        }
         for (int c = 0; c < 2; c++) {
             uint32_t gmap = 0;
             if (c < u.n_ch && u.ch[c].window_sequence == AACG_EIGHT_SHORT_SEQUENCE) {
@@ -208,6 +236,57 @@ int aacg_plan_build(const aacg_unit_desc* units, uint32_t n_units, int sample_in
         out->meta_blocks = std::max(out->meta_blocks, u.meta_offset + u.n_ch);
         out->pcm_floats = std::max(out->pcm_floats, (size_t)((uint64_t)u.pcm_offset + 1024u * (uint64_t)u.n_out_ch));
     }
+
+    if (out->any_cce) {
+        /* coupling jobs: every (coupling element, target) pair, by coupling point and by round — the r-th coupling element
+         * of a frame is in round r, so that the jobs of one launch never add to the same channel (decoder.js:411-431 walks
+         * the elements in order; additions commute up to rounding only within the tolerance, so the order is kept) */
+        out->gains.resize((size_t)n_cce * AACG_CCE_MAX_TARGETS * AACG_MAX_SECTIONS);
+        for (uint32_t c = 0; c < n_cce; c++) std::memcpy(&out->gains[(size_t)c * AACG_CCE_MAX_TARGETS * AACG_MAX_SECTIONS], cce[c].gain, sizeof cce[c].gain);
+        std::map<uint64_t, std::vector<uint32_t>> frames;      /* (stream, frame) -> its units */
+        for (uint32_t i = 0; i < n_units; i++) frames[((uint64_t)units[i].stream << 32) | frame_of[i]].push_back(i);
+        struct keyed { uint32_t key; aacg_couple_job job; };
+        std::vector<keyed> jobs;
+        for (auto& fr : frames) {
+            uint32_t round = 0;
+            for (uint32_t i : fr.second) {
+                const aacg_unit_desc& u = units[i];
+                if (!(u.flags & AACG_UNIT_CCE)) continue;
+                const aacg_cce_info& ci = cce[u.reserved1];
+                for (int t = 0; t < ci.n_targets; t++) {
+                    const uint32_t tch = ci.target[t].channel;
+                    int32_t target = -1;
+                    for (uint32_t j : fr.second)
+                        if (!(units[j].flags & AACG_UNIT_CCE) && tch >= units[j].channel && tch < (uint32_t)units[j].channel + units[j].n_ch) target = (int32_t)j;
+                    if (target < 0) return fail(err, AACG_ERR_INVALID_ARG, "unit %ld: coupling target channel %ld is not in the frame", i, tch);
+                    const aacg_unit_desc& tu = units[target];
+                    keyed k;
+                    std::memset(&k, 0, sizeof k);
+                    k.key = ci.coupling_point * 4096u + round;
+                    k.job.cce_unit = i;
+                    k.job.gain_off = (uint32_t)(((size_t)u.reserved1 * AACG_CCE_MAX_TARGETS + ci.target[t].gain_list) * AACG_MAX_SECTIONS);
+                    if (ci.coupling_point == AACG_CCE_AFTER_IMDCT) {
+                        k.job.src = out->units[i].d.pcm_offset / 1024u;
+                        k.job.dst = tu.pcm_offset + tch;
+                        k.job.stride = tu.n_out_ch;
+                    } else {
+                        k.job.src = u.coef_offset;
+                        k.job.dst = tu.coef_offset + (tch - tu.channel);
+                    }
+                    jobs.push_back(k);
+                }
+                round++;
+                if (round >= 4096u) return fail(err, AACG_ERR_CAPACITY, "too many coupling elements in one frame");
+            }
+            out->couple_rounds = std::max(out->couple_rounds, round);
+        }
+        std::stable_sort(jobs.begin(), jobs.end(), [](const keyed& a, const keyed& b) { return a.key < b.key; });
+        /* couple_first[point * rounds + round] = first job of that launch; one entry more closes the last */
+        out->couple_first.assign((size_t)3 * out->couple_rounds + 1, (uint32_t)jobs.size());
+        for (size_t j = jobs.size(); j-- > 0;) out->couple_first[(size_t)(jobs[j].key / 4096u) * out->couple_rounds + jobs[j].key % 4096u] = (uint32_t)j;
+        for (size_t k = out->couple_first.size() - 1; k-- > 0;) out->couple_first[k] = std::min(out->couple_first[k], out->couple_first[k + 1]);
+        for (auto& k : jobs) out->couple_jobs.push_back(k.job);
+    }
     for (auto& s : st) close_frame(s);
     /* every chain must reach its stream's last frame, or a later batch would chain onto a stale tail */
     for (auto& kv : open)
@@ -216,7 +295,7 @@ int aacg_plan_build(const aacg_unit_desc* units, uint32_t n_units, int sample_in
                         (long)(kv.first >> 16), (long)(kv.first & 0xffff));
 
     /* chains -> runs, generated chain by chain */
-    std::vector<aacg_run> gen;
+    std::vector<aacg_run> gen, cce_gen;
     for (auto& kv : open) {
         const open_chain& oc = kv.second;
         aacg_chain ch;
@@ -231,7 +310,7 @@ int aacg_plan_build(const aacg_unit_desc* units, uint32_t n_units, int sample_in
          * frames a wave of its own does that, a full run of 16 gives its first wave double duty (one IMDCT more in
          * series).  Use as few double-duty runs as it takes to reach the minimum number of runs. */
         size_t n_full = 0;
-        if (n > AACG_RUN_W) {
+        if (n > AACG_RUN_W && !oc.is_cce) {                /* coupling elements' runs: their own launch of the plain kernel */
             const size_t rem = n - AACG_RUN_W, later = (rem + AACG_RUN_W - 1) / AACG_RUN_W;
             n_full = rem > later * (AACG_RUN_W - 1) ? rem - later * (AACG_RUN_W - 1) : 0;
         }
@@ -251,9 +330,9 @@ int aacg_plan_build(const aacg_unit_desc* units, uint32_t n_units, int sample_in
             pos += (size_t)r.n_units;
             r.is_last = pos >= n ? 1 : 0;
             r.reserved = 0;
-            gen.push_back(r);
+            (oc.is_cce ? cce_gen : gen).push_back(r);
         }
-        ch.n_runs = (uint32_t)gen.size() - ch.first_run;
+        ch.n_runs = oc.is_cce ? 0 : (uint32_t)gen.size() - ch.first_run;
         out->chains.push_back(ch);
     }
 
@@ -266,6 +345,7 @@ int aacg_plan_build(const aacg_unit_desc* units, uint32_t n_units, int sample_in
         const size_t cnt = (R - 1 - x) / 8 + 1;
         for (size_t s = 0; s < cnt; s++) out->runs[s * 8 + x] = gen[i++];
     }
+    out->cce_runs = cce_gen;
     /* chain.first_run refers to generation order; the engine only needs counts, keep as is */
     return AACG_OK;
 }

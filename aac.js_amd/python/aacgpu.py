@@ -25,7 +25,8 @@ ABI_SYMBOLS = ["aacg_create", "aacg_destroy", "aacg_last_error", "aacg_abi_versi
                "aacg_host_alloc", "aacg_host_free", "aacg_plan_create", "aacg_plan_destroy",
                "aacg_decode_device", "aacg_spectral_device", "aacg_synchronize", "aacg_get_table", "aacg_kernel_name",
                "aacg_parser_create", "aacg_parser_destroy", "aacg_parser_last_error", "aacg_parse_status_string",
-               "aacg_parse_batch", "aacg_parse_device", "aacg_parse_kernel_name", "aacg_plan_refresh_from_parse", "aacg_standard_codebooks", "aacg_debug_transform"]
+               "aacg_parse_batch", "aacg_parse_device", "aacg_parse_kernel_name", "aacg_plan_refresh_from_parse", "aacg_standard_codebooks", "aacg_debug_transform",
+               "aacg_decode_batch_ex", "aacg_submit_ex", "aacg_plan_create_ex"]
 
 UNIT_DTYPE = np.dtype([
     ("stream", "<u4"), ("pcm_offset", "<u4"), ("channel", "<u2"), ("n_out_ch", "<u2"),
@@ -42,16 +43,28 @@ TNS_DTYPE = np.dtype([
     ("filt", [("length", "u1"), ("order", "u1"), ("direction", "u1"), ("reserved", "u1"), ("coef", "<f4", (12,))], (8,)),
 ])
 assert TNS_DTYPE.itemsize == 424
+# aacg_cce_info: one per coupling channel element (CCE_SPEC engines; units flagged UNIT_CCE, reserved1 = its index)
+CCE_DTYPE = np.dtype([("coupling_point", "u1"), ("n_targets", "u1"), ("reserved", "u1", (2,)),
+                      ("target", [("channel", "u1"), ("gain_list", "u1")], (16,)), ("gain", "<f4", (16, 120))])
+assert CCE_DTYPE.itemsize == 7716
+CCE_REFERENCE, CCE_SPEC = 0, 1
+CCE_BEFORE_TNS, CCE_AFTER_TNS, CCE_AFTER_IMDCT = 0, 1, 2
 TNS_REFERENCE, TNS_SPEC = 0, 1
 PNS_REFERENCE, PNS_SPEC = 0, 1
-UNIT_COMMON_WINDOW, UNIT_MASK_PRESENT, UNIT_HAS_PNS = 1, 2, 4
+UNIT_COMMON_WINDOW, UNIT_MASK_PRESENT, UNIT_HAS_PNS, UNIT_CCE = 1, 2, 4, 8
 CHAN_TNS_PRESENT = 0x01
 
 
 class Config(C.Structure):
     _fields_ = [("abi_version", C.c_int32), ("device_ordinal", C.c_int32), ("sample_index", C.c_int32),
                 ("max_streams", C.c_int32), ("max_channels", C.c_int32), ("max_batch_units", C.c_int32),
-                ("input_kind", C.c_int32), ("tns_mode", C.c_int32), ("pns_mode", C.c_int32), ("output_kind", C.c_int32)]
+                ("input_kind", C.c_int32), ("tns_mode", C.c_int32), ("pns_mode", C.c_int32), ("output_kind", C.c_int32), ("cce_mode", C.c_int32)]
+
+
+class Batch(C.Structure):
+    _fields_ = [("units", C.c_void_p), ("n_units", C.c_uint32), ("coeffs", C.c_void_p), ("n_coef_blocks", C.c_uint32),
+                ("meta", C.c_void_p), ("n_meta", C.c_uint32), ("tns", C.c_void_p), ("n_tns", C.c_uint32),
+                ("cce", C.c_void_p), ("n_cce", C.c_uint32), ("pcm_out", C.c_void_p), ("n_pcm_floats", C.c_size_t)]
 
 
 class AacgError(RuntimeError):
@@ -139,6 +152,9 @@ def load_library(path=LIB_PATH):
     L.aacg_parse_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.aacg_standard_codebooks.argtypes = [C.c_void_p, C.c_void_p]
+    L.aacg_decode_batch_ex.argtypes = [C.c_void_p, C.POINTER(Batch)]
+    L.aacg_submit_ex.argtypes = [C.c_void_p, C.POINTER(Batch), C.POINTER(C.c_uint64)]
+    L.aacg_plan_create_ex.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]
     L.aacg_debug_transform.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     L.aacg_standard_codebooks.restype = C.c_uint32
     _lib = L
@@ -252,10 +268,10 @@ class Engine:
     """One engine per device (mirrors one FilterBank per decoder, for many streams at once)."""
 
     def __init__(self, input_kind=INPUT_QUANT_I16, max_streams=1, max_channels=2, device=0, sample_index=3,
-                 max_batch_units=0, tns_mode=TNS_REFERENCE, pns_mode=PNS_REFERENCE, output_kind=OUTPUT_F32):
+                 max_batch_units=0, tns_mode=TNS_REFERENCE, pns_mode=PNS_REFERENCE, output_kind=OUTPUT_F32, cce_mode=CCE_REFERENCE):
         self.lib = load_library()
         cfg = Config(self.lib.aacg_abi_version(), device, sample_index, max_streams, max_channels, max_batch_units,
-                     input_kind, tns_mode, pns_mode, output_kind)
+                     input_kind, tns_mode, pns_mode, output_kind, cce_mode)
         self.pcm_dtype = np.int16 if output_kind == OUTPUT_I16 else np.float32
         h = C.c_void_p()
         rc = self.lib.aacg_create(C.byref(cfg), C.byref(h))
@@ -282,7 +298,9 @@ class Engine:
         return rc
 
     # -- host-buffer path -----------------------------------------------------------------
-    def decode_batch(self, units, coeffs, meta, n_pcm_floats, tns=None):
+    def decode_batch(self, units, coeffs, meta, n_pcm_floats, tns=None, cce=None):
+        if cce is not None:
+            return self._decode_batch_ex(units, coeffs, meta, n_pcm_floats, tns, cce)
         units = np.ascontiguousarray(units)
         assert units.dtype == UNIT_DTYPE
         coeffs = np.ascontiguousarray(coeffs)
@@ -302,6 +320,20 @@ class Engine:
         self._check(self.lib.aacg_decode_batch(self.handle, units.ctypes.data, len(units), coeffs.ctypes.data, n_blocks,
                                                meta.ctypes.data if meta is not None else None,
                                                meta.size // 120 if meta is not None else 0, pcm.ctypes.data, pcm.size))
+        return pcm
+
+    def _decode_batch_ex(self, units, coeffs, meta, n_pcm_floats, tns, cce):
+        """aacg_decode_batch_ex: every array of the batch in one record (coupling side info included)."""
+        units, coeffs, cce = np.ascontiguousarray(units), np.ascontiguousarray(coeffs), np.ascontiguousarray(cce)
+        assert units.dtype == UNIT_DTYPE and cce.dtype == CCE_DTYPE
+        meta = np.ascontiguousarray(meta, np.uint16) if meta is not None else None
+        tns = np.ascontiguousarray(tns) if tns is not None else None
+        pcm = np.full(n_pcm_floats, np.nan, np.float32)
+        b = Batch(units.ctypes.data, len(units), coeffs.ctypes.data, coeffs.size // 1024,
+                  meta.ctypes.data if meta is not None else None, meta.size // 120 if meta is not None else 0,
+                  tns.ctypes.data if tns is not None else None, len(tns) if tns is not None else 0,
+                  cce.ctypes.data, len(cce), pcm.ctypes.data, pcm.size)
+        self._check(self.lib.aacg_decode_batch_ex(self.handle, C.byref(b)))
         return pcm
 
     def submit(self, units, coeffs, meta, pcm, tns=None):
@@ -336,10 +368,17 @@ class Engine:
         return a
 
     # -- device-resident path -----------------------------------------------------------------
-    def plan(self, units, tns=None):
+    def plan(self, units, tns=None, cce=None):
         units = np.ascontiguousarray(units)
         assert units.dtype == UNIT_DTYPE
         h = C.c_void_p()
+        if cce is not None:
+            cce = np.ascontiguousarray(cce)
+            assert cce.dtype == CCE_DTYPE
+            tns = np.ascontiguousarray(tns) if tns is not None else None
+            self._check(self.lib.aacg_plan_create_ex(self.handle, units.ctypes.data, len(units), tns.ctypes.data if tns is not None else None,
+                                                     len(tns) if tns is not None else 0, cce.ctypes.data, len(cce), C.byref(h)))
+            return Plan(self, h, len(units))
         if tns is not None:
             tns = np.ascontiguousarray(tns)
             assert tns.dtype == TNS_DTYPE

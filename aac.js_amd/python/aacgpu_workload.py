@@ -294,6 +294,54 @@ def add_tns_config3(batch, seed=0xAAC00003):
     return units, np.array(recs, TNS_DTYPE)
 
 
+def add_cce(batch, points=(2,), seed=0xAAC00005, max_targets=4):
+    """Coupling channel elements (AACG_CCE_SPEC) for a make_batch() workload: per frame one CCE per entry of `points`
+    (0 before TNS, 1 after TNS: dependent, per-band gains; 2 after the IMDCT: independent, one gain per target), with the
+    frame's window info, a quantised spectrum of its own (blocks appended behind the batch's), 1..max_targets target
+    channels and gains +-2^(-t/4).  CCE number k of a frame lives at stream channel C + k; its unit sits at a varying
+    position among the frame's elements (the order of elements in a raw_data_block is free).
+    Returns (units, q, meta, cce records); the engine needs max_channels = C + len(points)."""
+    from aacgpu import CCE_DTYPE, UNIT_CCE
+    rng = np.random.default_rng(seed)
+    units, C = batch["units"], batch["C"]
+    F = batch["n_frames_total"]
+    L = len(units) // F
+    K = len(points)
+    blocks0 = batch["q"].shape[0]
+    q = np.concatenate([batch["q"], np.zeros((F * K, 1024), np.int16)])
+    meta = np.concatenate([batch["meta"], np.zeros((F * K, 120), np.uint16)])
+    cce = np.zeros(F * K, CCE_DTYPE)
+    out = np.zeros(F * (L + K), UNIT_DTYPE)
+    k1024 = np.arange(1024)
+    for f in range(F):
+        frame = units[f * L:(f + 1) * L]
+        extra = np.zeros(K, UNIT_DTYPE)
+        for k, point in enumerate(points):
+            idx, blk = f * K + k, blocks0 + f * K + k
+            u = extra[k]
+            u["stream"], u["pcm_offset"], u["n_out_ch"] = frame[0]["stream"], frame[0]["pcm_offset"], C
+            u["channel"], u["n_ch"], u["flags"], u["reserved1"] = C + k, 1, UNIT_CCE, idx
+            u["coef_offset"] = u["meta_offset"] = blk
+            u["ch"][0] = frame[0]["ch"][0]
+            u["ch"][0]["flags"] = 0
+            short = int(u["ch"][0]["window_sequence"]) == 2
+            lam = np.tile(16.0 * np.exp(-(np.arange(128) * 8) / 200.0), 8) if short else 16.0 * np.exp(-k1024 / 200.0)
+            q[blk] = (np.floor(rng.exponential(1.0, 1024) * lam * 0.5) * (rng.integers(0, 2, 1024) * 2 - 1)).astype(np.int16)
+            nb = int(u["ch"][0]["group_count"]) * int(u["ch"][0]["max_sfb"])
+            bt = rng.integers(0, 12, 120).astype(np.uint16)                   # type 0 = ZERO_BT: skipped by the coupling
+            meta[blk, :nb] = ((244 + rng.integers(-6, 7, 120)).astype(np.uint16) | (bt << 12))[:nb]
+            rec = cce[idx]
+            rec["coupling_point"] = point
+            targets = rng.choice(C, size=int(rng.integers(1, min(max_targets, C) + 1)), replace=False)
+            rec["n_targets"] = len(targets)
+            for t, ch in enumerate(targets):
+                rec["target"][t]["channel"], rec["target"][t]["gain_list"] = ch, t
+                rec["gain"][t] = (rng.integers(0, 2, 120) * 2 - 1) * 2.0 ** (-rng.integers(0, 12, 120) / 4.0)
+        at = f % (L + 1)
+        out[f * (L + K):(f + 1) * (L + K)] = np.concatenate([frame[:at], extra, frame[at:]])
+    return out, q, meta, cce
+
+
 # ---- device front end: stand-in codebooks and a hand-assembled frame (smoke test, no Node needed) -------------------
 def standin_codebooks():
     """The 12 codebooks' alphabets (ISO/IEC 14496-3 4.A.1) with the simplest complete prefix code over each: the first

@@ -105,7 +105,7 @@ def cpu_baseline(kind, mix, layout, n_chan, budget_s=10.0):
     return out
 
 
-def parity_check(eng, plan, step0, bufs, host_in0, base, units, tns, n_streams, n_chan, stream):
+def parity_check(eng, plan, step0, bufs, host_in0, base, units, tns, n_streams, n_chan, stream, cce=None):
     """Untimed, after the timed region: reset every stream (= new FilterBank), run the bench's own step once more on
     buffer set 0 and compare the whole batch with the oracle.  Returns (rms error, rms error / signal rms)."""
     import numpy as np
@@ -122,8 +122,8 @@ def parity_check(eng, plan, step0, bufs, host_in0, base, units, tns, n_streams, 
     got = d_out.cpu().numpy()
     if got.dtype == np.int16:                              # AACG_OUTPUT_I16: compared on the float scale (half a step of rounding on top)
         got = got.astype(np.float32) / np.float32(32768.0)
-    ov = np.zeros((n_streams, n_chan, 1024), np.float32)
-    ref = orc.load().decode_batch(units, host_in0, base["meta"] if host_in0.dtype == np.int16 else None, base["n_pcm"], ov, tns=tns)
+    ov = np.zeros((n_streams, n_chan + (1 if cce is not None else 0), 1024), np.float32)
+    ref = orc.load().decode_batch(units, host_in0, base["meta"] if host_in0.dtype == np.int16 else None, base["n_pcm"], ov, tns=tns, cce=cce)
     d = got.astype(np.float64) - ref
     err, sig = float(np.sqrt(np.mean(d * d))), float(np.sqrt(np.mean(ref.astype(np.float64) ** 2)))
     return err, err / sig if sig > 0 else float("inf"), bool(np.isfinite(got).all())
@@ -141,6 +141,9 @@ def main():
     ap.add_argument("--tns", choices=["reference", "spec"], default="reference",
                     help="spec: AACG_TNS_SPEC engine with TNS side info on every channel-frame as SURVEY config 3 has it (supplementary; "
                          "the reference's TNS is the identity, which is what the headline figure measures)")
+    ap.add_argument("--cce", choices=["reference", "spec"], default="reference",
+                    help="spec: AACG_CCE_SPEC engine, one independently switched coupling element per frame coupled into 1-4 channels "
+                         "(supplementary; the reference parses coupling elements and never applies them)")
     ap.add_argument("--output", choices=["f32", "i16"], default="f32",
                     help="i16: AACG_OUTPUT_I16 engine (supplementary; the reference returns float PCM, which is what the headline measures)")
     ap.add_argument("--nbuf", type=int, default=8)
@@ -190,21 +193,27 @@ def main():
     layout = ("cpe", "cpe", "cpe", "sce") if args.workload == "cfg5" else ("cpe",)
     n_chan = 7 if args.workload == "cfg5" else 2
     kind = aacgpu.INPUT_QUANT_I16 if args.input == "quant" else aacgpu.INPUT_SPEC_F32
-    eng = aacgpu.Engine(kind, max_streams=n_streams * args.pipelines, max_channels=n_chan, device=device,
+    eng = aacgpu.Engine(kind, max_streams=n_streams * args.pipelines, max_channels=n_chan + (1 if args.cce == "spec" else 0), device=device,
+                        cce_mode=aacgpu.CCE_SPEC if args.cce == "spec" else aacgpu.CCE_REFERENCE,
                         tns_mode=aacgpu.TNS_SPEC if args.tns == "spec" else aacgpu.TNS_REFERENCE,
                         output_kind=aacgpu.OUTPUT_I16 if args.output == "i16" else aacgpu.OUTPUT_F32)
 
     # rank r owns its own streams: independent data per rank, same shape
     base = aacgpu_workload.make_batch(n_streams=n_streams, n_frames=n_frames, mix=mix, layout=layout,
                                       seed=aacgpu_shard.rank_seed(0xAAC00002, rank))
-    units, tns = base["units"], None
+    units, tns, cce = base["units"], None, None
     if args.tns == "spec":                               # a filter on every channel-frame
         units, tns = aacgpu_workload.add_tns_config3(base, seed=0xAAC00003 + rank)
+    if args.cce == "spec":                              # BASELINE config 5 names cce.js coupling: one independent CCE per frame
+        if args.input != "quant" or tns is not None:
+            raise SystemExit("--cce spec: int16 seam, without --tns spec")
+        units, cq, cmeta, cce = aacgpu_workload.add_cce(base, points=(2,), seed=0xAAC00005 + rank)
+        base = dict(base, q=cq, meta=cmeta)
     plans = []
     for pl in range(args.pipelines):               # pipeline p owns stream slots [p * n_streams, (p + 1) * n_streams)
         up = units.copy()
         up["stream"] += pl * n_streams
-        plans.append(eng.plan(up, tns=tns))
+        plans.append(eng.plan(up, tns=tns, cce=cce))
     d_meta = torch.from_numpy(base["meta"].view(np.int16)).cuda() if args.input == "quant" else None
     bufs, host_in0 = [], None
     rng = np.random.default_rng(rank)
@@ -267,7 +276,7 @@ def main():
     ok = bool(torch.isfinite(out.float()).all().item()) and float(out.float().abs().max().item()) > 0
     parity = None
     if not args.no_parity:
-        err, rel, finite = parity_check(eng, plans[0], lambda: step(0), bufs, host_in0, base, units, tns, n_streams, n_chan, tstream)
+        err, rel, finite = parity_check(eng, plans[0], lambda: step(0), bufs, host_in0, base, units, tns, n_streams, n_chan, tstream, cce)
         gate_rel = 5e-6 if tns is None else 1e-5         # AACG_TNS_SPEC: DESIGN.md §3a
         gate_rms = 1e-5
         if args.output == "i16":                          # rounding to 1 / 32768: 8.8e-6 rms of quantisation noise by itself
@@ -279,6 +288,8 @@ def main():
     frames_per_step = n_streams * n_frames
     value = world * frames_per_step * args.steps / event_s
     abytes = algorithmic_bytes_per_channel_frame(args.input, n_frames, args.output) * frames_per_step * n_chan
+    if cce is not None:
+        abytes += (2048 + 240) * frames_per_step             # the coupling element's own spectrum and band words in, nothing extra out
     achieved = abytes / (kernel_ms * 1e-3) / 1e9
     traffic, traffic_src = measured_traffic(args.input) if args.workload == "cfg2" else (None, None)
     unit = "stereo frames/s" if n_chan == 2 else "7-channel frames/s"
@@ -302,10 +313,13 @@ def main():
                    "preconditioning": "%d untimed steps (%.0f ms of load) before the warm-up steps: steady GPU clocks" % (n_pre, args.precondition_ms),
                    "tns": "identity, as the reference executes it" if tns is None
                           else "AACG_TNS_SPEC, every channel-frame: long one filter of order 12 over 20 bands, short one of order 7 per window",
+                   "coupling": "none applied, as the reference executes it" if cce is None
+                               else "AACG_CCE_SPEC: one independently switched coupling element per frame into 1-4 channels",
                    "collectives": "none on the data path; %s barrier + 8-byte MAX around the timed region" % (dist.get_backend() if dist is not None else "no")},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                     "kernel": ("aacg_spectral_ex_%s + aacg_imdct_run_f32" % ("quant" if args.input == "quant" else "f32")) if tns is not None
+                     "kernel": "aacg_spectral_ex_quant + aacg_imdct_run_f32 (x2) + aacg_couple_pcm" if cce is not None else
+                               ("aacg_spectral_ex_%s + aacg_imdct_run_f32" % ("quant" if args.input == "quant" else "f32")) if tns is not None
                                else (eng.kernel_name() if args.input == "quant" else "aacg_imdct_run_f32"),
                      "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": abytes,
                      "host_enqueue_us_per_step": issued[0] / args.steps * 1e6},

@@ -107,6 +107,38 @@ enum {
                                   separately tested mode (QUANT_I16 engines; units flag AACG_UNIT_HAS_PNS) */
 };
 
+enum {                          /* aacg_config.cce_mode (ABI version 4)                              */
+    AACG_CCE_REFERENCE = 0,     /* coupling channel elements are not part of a batch: aac.js parses them and
+                                   never applies them (`1 === true` at decoder.js:418, coupling point 3 at
+                                   cce.js:69-70, undefined `swb` at cce.js:149 — SURVEY.md §8a row 9), so the
+                                   host drops them; a unit with AACG_UNIT_CCE is refused                   */
+    AACG_CCE_SPEC      = 1      /* what cce.js:121-158 + decoder.js:406-433 were written to do: a CCE's own
+                                   spectrum, scaled by per-band gains, added to the channels it names —
+                                   before or after their TNS (dependent coupling, spectral domain) or, after
+                                   its own IMDCT with its own overlap state, to their PCM (independent
+                                   coupling).  Not aac.js behaviour: an explicit, separately tested mode
+                                   (float32 output engines)                                                */
+};
+
+/* ---- coupling side info (AACG_CCE_SPEC), the fields of the reference's CCEElement (cce.js:25-31) after
+ * the host has resolved which output channels an element pair / id / select triple means ---- */
+#define AACG_CCE_BEFORE_TNS   0      /* CCEElement.BEFORE_TNS  (cce.js:33) */
+#define AACG_CCE_AFTER_TNS    1      /* CCEElement.AFTER_TNS   (cce.js:34) */
+#define AACG_CCE_AFTER_IMDCT  2      /* CCEElement.AFTER_IMDCT (cce.js:35) */
+#define AACG_CCE_MAX_TARGETS  16
+typedef struct aacg_cce_target {
+    uint8_t channel;           /* output channel of the stream that receives the coupled signal   */
+    uint8_t gain_list;         /* which of gain[] applies to it (cce.gain[index], cce.js:77-107)   */
+} aacg_cce_target;
+typedef struct aacg_cce_info {
+    uint8_t coupling_point;    /* AACG_CCE_*                                                       */
+    uint8_t n_targets;         /* <= AACG_CCE_MAX_TARGETS                                          */
+    uint8_t reserved[2];
+    aacg_cce_target target[AACG_CCE_MAX_TARGETS];
+    float   gain[AACG_CCE_MAX_TARGETS][AACG_MAX_SECTIONS];   /* dependent: per band, index g * max_sfb + sfb
+                                  of the CCE's own ICS; independent: [list][0] for the whole frame      */
+} aacg_cce_info;
+
 /* ---- TNS side info (AACG_TNS_SPEC), the fields of the reference's TNS object (tns.js:22-44) ---- */
 #define AACG_TNS_MAX_ORDER 12  /* AAC-LC limit; tns.js:84 accepts up to 20, orders 13..20 are refused */
 typedef struct aacg_tns_filter {
@@ -139,6 +171,10 @@ typedef struct aacg_chan_info {
 #define AACG_CHAN_TNS_PRESENT    0x01   /* ics.tnsPresent (ics.js:71); only read in AACG_TNS_SPEC mode */
 #define AACG_UNIT_COMMON_WINDOW 0x01   /* cpe.commonWindow (cpe.js:43)  */
 #define AACG_UNIT_MASK_PRESENT  0x02   /* cpe.maskPresent  (cpe.js:47)  */
+#define AACG_UNIT_CCE           0x08   /* a coupling channel element (AACG_CCE_SPEC engines): one channel; `channel` is a
+                                          stream channel beyond the n_out_ch output channels (it owns overlap state when the
+                                          coupling is independent, it is never interleaved); reserved1 = index of its
+                                          aacg_cce_info                                                                  */
 #define AACG_UNIT_HAS_PNS       0x04   /* some band of the unit is NOISE_BT (the parser knows, ics.js:84-121):
                                           AACG_PNS_SPEC engines route such batches through the PNS stage,
                                           AACG_PNS_REFERENCE engines refuse them                          */
@@ -196,6 +232,7 @@ typedef struct aacg_config {
     int32_t tns_mode;          /* AACG_TNS_*                                                   */
     int32_t pns_mode;          /* AACG_PNS_* (ABI version 2)                                   */
     int32_t output_kind;       /* AACG_OUTPUT_* (ABI version 4)                                */
+    int32_t cce_mode;          /* AACG_CCE_* (ABI version 4)                                   */
 } aacg_config;
 
 typedef struct aacg_engine aacg_engine;
@@ -252,6 +289,17 @@ int aacg_submit_tns(aacg_engine* e,
                     const aacg_band_meta* meta, uint32_t n_meta,
                     const aacg_tns_info* tns, uint32_t n_tns,
                     void* pcm_out, size_t n_pcm_floats, uint64_t* ticket);
+/* ... and with coupling side info as well (AACG_CCE_SPEC engines): every array of a batch in one record. */
+typedef struct aacg_batch {
+    const aacg_unit_desc* units;  uint32_t n_units;
+    const void* coeffs;           uint32_t n_coef_blocks;
+    const aacg_band_meta* meta;   uint32_t n_meta;
+    const aacg_tns_info* tns;     uint32_t n_tns;      /* NULL / 0: none */
+    const aacg_cce_info* cce;     uint32_t n_cce;      /* NULL / 0: none */
+    void* pcm_out;                size_t n_pcm_floats;
+} aacg_batch;
+int aacg_decode_batch_ex(aacg_engine* e, const aacg_batch* b);
+int aacg_submit_ex(aacg_engine* e, const aacg_batch* b, uint64_t* ticket);
 /* Pinned (page-locked) host memory for the calls above: hipHostMalloc / hipHostFree. */
 void* aacg_host_alloc(size_t bytes);
 void  aacg_host_free(void* p);
@@ -264,6 +312,8 @@ int  aacg_plan_create(aacg_engine* e, const aacg_unit_desc* units, uint32_t n_un
 /* with TNS side info (host pointer; becomes part of the plan like the unit table) */
 int  aacg_plan_create_tns(aacg_engine* e, const aacg_unit_desc* units, uint32_t n_units,
                           const aacg_tns_info* tns, uint32_t n_tns, aacg_plan** out);
+int  aacg_plan_create_ex(aacg_engine* e, const aacg_unit_desc* units, uint32_t n_units,
+                         const aacg_tns_info* tns, uint32_t n_tns, const aacg_cce_info* cce, uint32_t n_cce, aacg_plan** out);
 void aacg_plan_destroy(aacg_plan* p);
 /* Launch on `hip_stream` (a hipStream_t passed as void*, NULL = the engine's own stream);
  * returns after enqueueing.  d_coeffs / d_meta / d_pcm are DEVICE pointers.            */

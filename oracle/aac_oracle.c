@@ -634,65 +634,149 @@ int orc_decode_batch_ex(int sample_index, int input_kind, int max_streams, int m
                         const aacg_tns_info* tns, int tns_mode, int pns_mode,
                         float* pcm_out, float* overlaps, float* spec_out)
 {
+    return orc_decode_batch_cce(sample_index, input_kind, max_streams, max_channels, units, n_units, coeffs, meta,
+                                tns, tns_mode, pns_mode, NULL, 0, pcm_out, overlaps, spec_out);
+}
+
+/* AACG_CCE_SPEC: cce.js:130-158 (applyDependentCoupling) for one target channel: data += gain[idx] * cce spectrum over
+ * the CCE's non-zero bands, with the repairs the code needs to run at all: `swbOffsets[sfb + 1]` for the undefined
+ * `swb` (cce.js:149), and the gain list indexed by the band like bandTypes (cce.decode packs it densely, cce.js:85-103,
+ * while this loop steps idx with every band).  f32 input has no band types: every band below maxSFB counts. */
+static void couple_dependent(int sample_index, const aacg_chan_info* info, const aacg_band_meta* cce_meta,
+                             const float* gains, const float* iq, float* data)
+{
+    const uint16_t* swb = swb_of(sample_index, info);
+    int idx = 0, offset = 0;
+    for (int g = 0; g < info->group_count; g++) {
+        const int len = info->group_len[g];
+        for (int sfb = 0; sfb < info->max_sfb; sfb++, idx++) {
+            if (cce_meta && meta_bt(cce_meta->band[idx]) == AACG_ZERO_BT) continue;
+            const float gain = gains[idx];
+            for (int group = 0; group < len; group++)
+                for (int k = swb[sfb]; k < swb[sfb + 1]; k++) {
+                    const int p = offset + group * 128 + k;
+                    data[p] = (float)((double)data[p] + (double)gain * (double)iq[p]);
+                }
+        }
+        offset += len * 128;
+    }
+}
+
+/* process(elements) + interleave with every optional mode.  cce != NULL (AACG_CCE_SPEC): units flagged AACG_UNIT_CCE
+ * are coupling channel elements; decoder.js:406-433 + cce.js:121-158 as they were meant to run —
+ *   the `=== isChannelPair` comparison of a number with a boolean (decoder.js:418), the coupling point that becomes 3
+ *   instead of 2 (cce.js:69-70) and the loop that stops one coupled element short (decoder.js:416 against cce.js:53) are
+ *   the host's business here: it hands over resolved (output channel, gain list) targets;
+ *   dependent coupling (points 0, 1) adds the CCE's spectrum band by band before / after the target's TNS;
+ *   independent coupling (point 2) adds the CCE's own filterbank output (its own overlap state, at its `channel` beyond
+ *   the output channels) times gain[list][0] to the target's — cce.js:121-128 adds the CCE's SPECTRUM to the target's
+ *   time signal, which cannot have been the intent.
+ * NOT pinned by the reference (it never couples); tests cross-check it against an independent numpy form. */
+int orc_decode_batch_cce(int sample_index, int input_kind, int max_streams, int max_channels,
+                         const aacg_unit_desc* units, uint32_t n_units,
+                         const void* coeffs, const aacg_band_meta* meta,
+                         const aacg_tns_info* tns, int tns_mode, int pns_mode,
+                         const aacg_cce_info* cce, uint32_t n_cce,
+                         float* pcm_out, float* overlaps, float* spec_out)
+{
     orc_init();
     if (sample_index < 0 || sample_index > 11) return AACG_ERR_INVALID_ARG;
-    float data[2][1024], out[1024];
-    uint32_t prev_stream = 0xffffffffu, prev_off = 0xffffffffu;
+    enum { MAXU = 32 };
+    static __thread float spec[MAXU][2][1024];
+    static __thread float cce_time[MAXU][1024];
+    float out[1024];
 
-    for (uint32_t n = 0; n < n_units; n++) {
-        const aacg_unit_desc* u = &units[n];
-        if (u->n_ch < 1 || u->n_ch > 2 || (int)u->stream >= max_streams ||
-            u->channel + u->n_ch > max_channels || u->channel + u->n_ch > u->n_out_ch)
-            return AACG_ERR_INVALID_ARG;
+    for (uint32_t n0 = 0; n0 < n_units;) {
+        /* one frame: the units that share stream and pcm_offset (include/aacgpu.h) */
+        uint32_t n1 = n0 + 1;
+        while (n1 < n_units && units[n1].stream == units[n0].stream && units[n1].pcm_offset == units[n0].pcm_offset) n1++;
+        if (n1 - n0 > MAXU) return AACG_ERR_CAPACITY;
+        const aacg_unit_desc* f = units + n0;
+        const int nu = (int)(n1 - n0);
+        memset(pcm_out + f->pcm_offset, 0, sizeof(float) * 1024u * f->n_out_ch);   /* decoder.js:229-231 */
 
-        /* decoder.js:229-231: every channel of a frame starts as zeros */
-        if (u->stream != prev_stream || u->pcm_offset != prev_off) {
-            memset(pcm_out + u->pcm_offset, 0, sizeof(float) * 1024u * u->n_out_ch);
-            prev_stream = u->stream; prev_off = u->pcm_offset;
-        }
-
-        const aacg_band_meta* ml = NULL; const aacg_band_meta* mr = NULL;
-        for (int c = 0; c < u->n_ch; c++) {
-            size_t base = ((size_t)u->coef_offset + (size_t)c) * 1024u;
-            if (input_kind == AACG_INPUT_SPEC_F32) {
-                memcpy(data[c], (const float*)coeffs + base, sizeof(float) * 1024);
-            } else {
-                const aacg_band_meta* m = &meta[u->meta_offset + (uint32_t)c];
-                int rc = orc_dequant_pns(sample_index, &u->ch[c], m, (const int16_t*)coeffs + base, pns_mode, data[c]);
-                if (rc) return rc;
-                if (c == 0) ml = m; else mr = m;
+        /* spectra of every element, MS / IS inside pairs */
+        for (int i = 0; i < nu; i++) {
+            const aacg_unit_desc* u = f + i;
+            const int is_cce = (u->flags & AACG_UNIT_CCE) != 0;
+            if (u->n_ch < 1 || u->n_ch > 2 || (int)u->stream >= max_streams || u->channel + u->n_ch > max_channels ||
+                (!is_cce && u->channel + u->n_ch > u->n_out_ch) || (is_cce && (!cce || u->n_ch != 1 || u->reserved1 >= n_cce)))
+                return AACG_ERR_INVALID_ARG;
+            const aacg_band_meta* ml = NULL; const aacg_band_meta* mr = NULL;
+            for (int c = 0; c < u->n_ch; c++) {
+                size_t base = ((size_t)u->coef_offset + (size_t)c) * 1024u;
+                if (input_kind == AACG_INPUT_SPEC_F32) {
+                    memcpy(spec[i][c], (const float*)coeffs + base, sizeof(float) * 1024);
+                } else {
+                    const aacg_band_meta* m = &meta[u->meta_offset + (uint32_t)c];
+                    int rc = orc_dequant_pns(sample_index, &u->ch[c], m, (const int16_t*)coeffs + base, pns_mode, spec[i][c]);
+                    if (rc) return rc;
+                    if (c == 0) ml = m; else mr = m;
+                }
+            }
+            if (u->n_ch == 2 && input_kind == AACG_INPUT_QUANT_I16) {
+                /* processPair, decoder.js:294-302 */
+                if ((u->flags & AACG_UNIT_COMMON_WINDOW) && (u->flags & AACG_UNIT_MASK_PRESENT))
+                    orc_process_ms(sample_index, u, ml, mr, spec[i][0], spec[i][1]);
+                orc_process_is(sample_index, u, ml, mr, spec[i][0], spec[i][1]);
             }
         }
-
-        if (u->n_ch == 2 && input_kind == AACG_INPUT_QUANT_I16) {
-            /* processPair, decoder.js:294-302 */
-            if ((u->flags & AACG_UNIT_COMMON_WINDOW) && (u->flags & AACG_UNIT_MASK_PRESENT))
-                orc_process_ms(sample_index, u, ml, mr, data[0], data[1]);
-            orc_process_is(sample_index, u, ml, mr, data[0], data[1]);
+        /* independently switched coupling elements: their own filterbank output */
+        for (int i = 0; i < nu; i++) {
+            const aacg_unit_desc* u = f + i;
+            if (!(u->flags & AACG_UNIT_CCE) || cce[u->reserved1].coupling_point != AACG_CCE_AFTER_IMDCT) continue;
+            float* ov = overlaps + ((size_t)u->stream * (size_t)max_channels + (size_t)u->channel) * 1024u;
+            orc_filterbank(u->ch[0].window_sequence, u->ch[0].window_shape, u->ch[0].window_shape_prev, spec[i][0], cce_time[i], ov);
         }
-        /* tns.process: no-op as the reference runs (tns.js:106,122); coupling: never applied
-         * (decoder.js:408,418).  SURVEY.md §8a rows 8, 9.  AACG_TNS_SPEC: the intended filter, after MS/IS
-         * (decoder.js:309-313). */
-        if (tns && tns_mode == AACG_TNS_SPEC)
-            for (int c = 0; c < u->n_ch; c++)
-                if (u->ch[c].flags & AACG_CHAN_TNS_PRESENT) {
-                    int rc = orc_tns_spec(sample_index, &u->ch[c], &tns[u->tns_offset + (uint32_t)c], data[c]);
-                    if (rc) return rc;
+
+        for (int i = 0; i < nu; i++) {
+            const aacg_unit_desc* u = f + i;
+            if (u->flags & AACG_UNIT_CCE) continue;
+            for (int c = 0; c < u->n_ch; c++) {
+                const int ch = u->channel + c;
+                float* data = spec[i][c];
+                /* processSingle / processPair: coupling before TNS, TNS, coupling after TNS (decoder.js:258-266, 304-316).
+                 * tns.process is a no-op as the reference runs (tns.js:106,122); AACG_TNS_SPEC: the intended filter */
+                for (int point = AACG_CCE_BEFORE_TNS; point <= AACG_CCE_AFTER_TNS; point++) {
+                    if (point == AACG_CCE_AFTER_TNS && tns && tns_mode == AACG_TNS_SPEC && (u->ch[c].flags & AACG_CHAN_TNS_PRESENT)) {
+                        int rc = orc_tns_spec(sample_index, &u->ch[c], &tns[u->tns_offset + (uint32_t)c], data);
+                        if (rc) return rc;
+                    }
+                    for (int j = 0; j < nu; j++) {
+                        const aacg_unit_desc* q = f + j;
+                        if (!(q->flags & AACG_UNIT_CCE)) continue;
+                        const aacg_cce_info* ci = &cce[q->reserved1];
+                        if (ci->coupling_point != point) continue;
+                        for (int t = 0; t < ci->n_targets; t++)
+                            if (ci->target[t].channel == ch)
+                                couple_dependent(sample_index, &q->ch[0], input_kind == AACG_INPUT_QUANT_I16 ? &meta[q->meta_offset] : NULL,
+                                                 ci->gain[ci->target[t].gain_list], spec[j][0], data);
+                    }
                 }
-
-        for (int c = 0; c < u->n_ch; c++) {
-            int ch = u->channel + c;
-            float* ov = overlaps + ((size_t)u->stream * (size_t)max_channels + (size_t)ch) * 1024u;
-            if (spec_out)
-                memcpy(spec_out + ((size_t)u->coef_offset + (size_t)c) * 1024u, data[c], sizeof(float) * 1024);
-            /* filter_bank.process(info, data, this.data[channel], channel), decoder.js:269,318-319 */
-            orc_filterbank(u->ch[c].window_sequence, u->ch[c].window_shape, u->ch[c].window_shape_prev,
-                           data[c], out, ov);
-            /* interleave, decoder.js:209-213: output[j++] = data[i][k] / 32768 */
-            float* dst = pcm_out + u->pcm_offset + ch;
-            for (int k = 0; k < 1024; k++)
-                dst[(size_t)k * u->n_out_ch] = (float)((double)out[k] / 32768.0);
+                float* ov = overlaps + ((size_t)u->stream * (size_t)max_channels + (size_t)ch) * 1024u;
+                if (spec_out)
+                    memcpy(spec_out + ((size_t)u->coef_offset + (size_t)c) * 1024u, data, sizeof(float) * 1024);
+                /* filter_bank.process(info, data, this.data[channel], channel), decoder.js:269,318-319 */
+                orc_filterbank(u->ch[c].window_sequence, u->ch[c].window_shape, u->ch[c].window_shape_prev, data, out, ov);
+                /* coupling after the IMDCT (decoder.js:271-272, 321-322) */
+                for (int j = 0; j < nu; j++) {
+                    const aacg_unit_desc* q = f + j;
+                    if (!(q->flags & AACG_UNIT_CCE)) continue;
+                    const aacg_cce_info* ci = &cce[q->reserved1];
+                    if (ci->coupling_point != AACG_CCE_AFTER_IMDCT) continue;
+                    for (int t = 0; t < ci->n_targets; t++)
+                        if (ci->target[t].channel == ch) {
+                            const float gain = ci->gain[ci->target[t].gain_list][0];
+                            for (int k = 0; k < 1024; k++) out[k] = (float)((double)out[k] + (double)gain * (double)cce_time[j][k]);
+                        }
+                }
+                /* interleave, decoder.js:209-213: output[j++] = data[i][k] / 32768 */
+                float* dst = pcm_out + u->pcm_offset + ch;
+                for (int k = 0; k < 1024; k++)
+                    dst[(size_t)k * u->n_out_ch] = (float)((double)out[k] / 32768.0);
+            }
         }
+        n0 = n1;
     }
     return AACG_OK;
 }

@@ -88,6 +88,14 @@ int orc_decode_batch_ex(int sample_index, int input_kind, int max_streams, int m
                         const aacg_tns_info* tns, int tns_mode, int pns_mode,
                         float* pcm_out, float* overlaps, float* spec_out);
 
+/* ... and coupling channel elements (AACG_CCE_SPEC; cce == NULL: none; unpinned, see aac_oracle.c) */
+int orc_decode_batch_cce(int sample_index, int input_kind, int max_streams, int max_channels,
+                         const aacg_unit_desc* units, uint32_t n_units,
+                         const void* coeffs, const aacg_band_meta* meta,
+                         const aacg_tns_info* tns, int tns_mode, int pns_mode,
+                         const aacg_cce_info* cce, uint32_t n_cce,
+                         float* pcm_out, float* overlaps, float* spec_out);
+
 /* the same with TNS side info: tns == NULL or tns_mode == AACG_TNS_REFERENCE leaves the spectrum untouched */
 int orc_decode_batch_tns(int sample_index, int input_kind, int max_streams, int max_channels,
                          const aacg_unit_desc* units, uint32_t n_units,

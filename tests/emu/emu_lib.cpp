@@ -23,6 +23,7 @@ struct launch_arg {
     int n_units;
     const aacg_parse_params* PP;
     int out_kind;
+    const aacg_couple_params* Q;
 };
 
 void* lane_main(void* p)
@@ -31,6 +32,8 @@ void* lane_main(void* p)
     g_emu = a->ctx;
     /* the same dispatch as the engine's launch_run: double-duty variant / plain; kinds 3, 4: the optional-stage kernel */
     if (a->kind == 7) { aacg_parse::parse_body(*a->PP); return nullptr; }
+    if (a->kind == 8) { couple_spec_body(*a->Q, 4); return nullptr; }
+    if (a->kind == 9) { couple_pcm_body(*a->Q, 4); return nullptr; }
     const bool dd = a->P->scratch != nullptr;
     if (a->out_kind == AACG_OUTPUT_I16 && a->kind == 0) { if (dd) imdct_run_body_dd<AACG_INPUT_SPEC_F32, AACG_OUTPUT_I16>(*a->P); else imdct_run_body<AACG_INPUT_SPEC_F32, AACG_OUTPUT_I16>(*a->P); }
     else if (a->out_kind == AACG_OUTPUT_I16 && a->kind == 1) { if (dd) imdct_run_body_dd<AACG_INPUT_QUANT_I16, AACG_OUTPUT_I16>(*a->P); else imdct_run_body<AACG_INPUT_QUANT_I16, AACG_OUTPUT_I16>(*a->P); }
@@ -44,7 +47,8 @@ void* lane_main(void* p)
 
 int g_out_kind = AACG_OUTPUT_F32;          /* emu_set_output_kind: the next decodes store int16 PCM */
 
-void launch(const aacg_kparams& P, int kind, int grid, int waves, size_t lds_bytes, int n_units = 0, const aacg_parse_params* PP = nullptr)
+void launch(const aacg_kparams& P, int kind, int grid, int waves, size_t lds_bytes, int n_units = 0, const aacg_parse_params* PP = nullptr,
+            const aacg_couple_params* Q = nullptr)
 {
     const int threads = waves * 64;
     std::vector<emu_wave> wv((size_t)waves);
@@ -69,6 +73,7 @@ void launch(const aacg_kparams& P, int kind, int grid, int waves, size_t lds_byt
             args[(size_t)t].n_units = n_units;
             args[(size_t)t].PP = PP;
             args[(size_t)t].out_kind = g_out_kind;
+            args[(size_t)t].Q = Q;
             pthread_create(&tid[(size_t)t], &attr, lane_main, &args[(size_t)t]);
         }
         for (int t = 0; t < threads; t++) pthread_join(tid[(size_t)t], nullptr);
@@ -130,6 +135,10 @@ int emu_decode_ex(int input_kind, int sample_index, int max_streams, int max_cha
                   const aacg_unit_desc* units, uint32_t n_units, const void* coeffs, const aacg_band_meta* meta,
                   const aacg_tns_info* tns, uint32_t n_tns, int pns_mode,
                   float* pcm, size_t n_pcm_floats, float* overlap_pool, uint8_t* parity);
+int emu_decode_cce(int input_kind, int sample_index, int max_streams, int max_channels,
+                   const aacg_unit_desc* units, uint32_t n_units, const void* coeffs, const aacg_band_meta* meta,
+                   const aacg_tns_info* tns, uint32_t n_tns, int pns_mode, const aacg_cce_info* cce, uint32_t n_cce,
+                   float* pcm, size_t n_pcm_floats, float* overlap_pool, uint8_t* parity);
 
 int emu_decode(int input_kind, int sample_index, int max_streams, int max_channels,
                const aacg_unit_desc* units, uint32_t n_units, const void* coeffs, const aacg_band_meta* meta,
@@ -149,15 +158,25 @@ int emu_decode_tns(int input_kind, int sample_index, int max_streams, int max_ch
                          AACG_PNS_REFERENCE, pcm, n_pcm_floats, overlap_pool, parity);
 }
 
-/* pns_mode == AACG_PNS_SPEC: batches with AACG_UNIT_HAS_PNS units take the engine's two-kernel route */
 int emu_decode_ex(int input_kind, int sample_index, int max_streams, int max_channels,
                   const aacg_unit_desc* units, uint32_t n_units, const void* coeffs, const aacg_band_meta* meta,
                   const aacg_tns_info* tns, uint32_t n_tns, int pns_mode,
                   float* pcm, size_t n_pcm_floats, float* overlap_pool, uint8_t* parity)
 {
+    return emu_decode_cce(input_kind, sample_index, max_streams, max_channels, units, n_units, coeffs, meta, tns, n_tns, pns_mode,
+                          nullptr, 0, pcm, n_pcm_floats, overlap_pool, parity);
+}
+
+/* pns_mode == AACG_PNS_SPEC: batches with AACG_UNIT_HAS_PNS units take the engine's two-kernel route;
+ * cce != NULL: AACG_CCE_SPEC, the engine's staged route (launch_run in aacg_engine.hip) */
+int emu_decode_cce(int input_kind, int sample_index, int max_streams, int max_channels,
+                   const aacg_unit_desc* units, uint32_t n_units, const void* coeffs, const aacg_band_meta* meta,
+                   const aacg_tns_info* tns, uint32_t n_tns, int pns_mode, const aacg_cce_info* cce, uint32_t n_cce,
+                   float* pcm, size_t n_pcm_floats, float* overlap_pool, uint8_t* parity)
+{
     if (g_tab_index != sample_index) { int rc = aacg_build_tables(sample_index, &g_tab, nullptr); if (rc) return rc; g_tab_index = sample_index; }
     aacg_plan_host ph;
-    int rc = aacg_plan_build(units, n_units, sample_index, max_streams, max_channels, parity, &ph, &g_err, tns, n_tns);
+    int rc = aacg_plan_build(units, n_units, sample_index, max_streams, max_channels, parity, &ph, &g_err, tns, n_tns, cce, n_cce);
     if (rc) return rc;
     if (ph.pcm_floats > n_pcm_floats) { g_err = "pcm buffer too small"; return AACG_ERR_CAPACITY; }
     if (ph.zero_fill) std::memset(pcm, 0, n_pcm_floats * (g_out_kind == AACG_OUTPUT_I16 ? 2 : 4));
@@ -171,7 +190,34 @@ int emu_decode_ex(int input_kind, int sample_index, int max_streams, int max_cha
     std::vector<float> spec;
     static aacg_pns_tables pns_tab;
     if (ph.any_pns && (pns_mode != AACG_PNS_SPEC || input_kind != AACG_INPUT_QUANT_I16)) { g_err = "PNS unit in a batch without AACG_PNS_SPEC"; return AACG_ERR_UNSUPPORTED; }
-    if (ph.any_pns || ph.any_tns) {                     /* the engine's two-kernel route */
+    std::vector<float> side((size_t)ph.side_blocks * 1024u + 1, 0.0f);
+    auto couple = [&](int point) {
+        for (uint32_t r = 0; r < ph.couple_rounds; r++) {
+            const uint32_t first = ph.couple_first[(size_t)point * ph.couple_rounds + r], last = ph.couple_first[(size_t)point * ph.couple_rounds + r + 1];
+            if (last <= first) continue;
+            aacg_couple_params Q;
+            Q.jobs = ph.couple_jobs.data() + first; Q.n_jobs = (int32_t)(last - first); Q.units = ph.units.data(); Q.meta = meta; Q.tab = &g_tab;
+            Q.gains = ph.gains.data(); Q.spec = spec.data(); Q.side = side.data(); Q.pcm = pcm; Q.reserved = 0;
+            launch(P, point == AACG_CCE_AFTER_IMDCT ? 9 : 8, (Q.n_jobs + 3) / 4, 4, 64, 0, nullptr, &Q);
+        }
+    };
+    if (ph.any_cce) {
+        const bool quant = input_kind == AACG_INPUT_QUANT_I16;
+        aacg_build_pns_tables(sample_index, &pns_tab);
+        spec.assign((size_t)ph.coef_blocks * 1024u, 0.0f);
+        aacg_kparams Q = P;
+        Q.spec_out = spec.data(); Q.pns = &pns_tab; Q.tns = nullptr;
+        if (quant) launch(Q, 3, (int)((n_units + AACG_WG_WAVES - 1) / AACG_WG_WAVES), AACG_WG_WAVES, (AACG_SPX_TAB_FLOATS + AACG_WG_WAVES * AACG_SPX_WAVE_FLOATS) * 4, (int)n_units);
+        else std::memcpy(spec.data(), coeffs, spec.size() * sizeof(float));
+        couple(AACG_CCE_BEFORE_TNS);
+        if (ph.any_tns) {
+            Q.coeffs = spec.data(); Q.meta = nullptr; Q.tns = ph.tns.data();
+            launch(Q, 4, (int)((n_units + AACG_WG_WAVES - 1) / AACG_WG_WAVES), AACG_WG_WAVES, AACG_WG_WAVES * AACG_SPX_WAVE_FLOATS * 4, (int)n_units);
+        }
+        couple(AACG_CCE_AFTER_TNS);
+        P.coeffs = spec.data(); P.meta = nullptr; P.tns = nullptr;
+        input_kind = AACG_INPUT_SPEC_F32;
+    } else if (ph.any_pns || ph.any_tns) {              /* the engine's two-kernel route */
         const bool quant = input_kind == AACG_INPUT_QUANT_I16;
         aacg_build_pns_tables(sample_index, &pns_tab);
         spec.assign((size_t)ph.coef_blocks * 1024u, 0.0f);
@@ -185,6 +231,14 @@ int emu_decode_ex(int input_kind, int sample_index, int max_streams, int max_cha
     if (!ph.runs.empty())
         launch(P, input_kind == AACG_INPUT_QUANT_I16 ? 1 : 0, (int)ph.runs.size(), AACG_WG_WAVES,
                input_kind == AACG_INPUT_QUANT_I16 ? AACG_LDS_BYTES_QUANT : AACG_LDS_BYTES_F32);
+    if (ph.any_cce) {
+        if (!ph.cce_runs.empty()) {
+            aacg_kparams C = P;
+            C.runs = ph.cce_runs.data(); C.n_runs = (int32_t)ph.cce_runs.size(); C.pcm = side.data(); C.scratch = nullptr;
+            launch(C, 0, (int)ph.cce_runs.size(), AACG_WG_WAVES, AACG_LDS_BYTES_F32);
+        }
+        couple(AACG_CCE_AFTER_IMDCT);
+    }
     for (auto& c : ph.chains)
         for (int k = 0; k < c.n_ch; k++) parity[(size_t)c.stream * (size_t)max_channels + c.channel + k] ^= 1;
     return AACG_OK;

@@ -24,6 +24,8 @@ class Emu:
                                      C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
         L.emu_decode_ex.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+        L.emu_decode_cce.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
         L.emu_spectral.argtypes = [C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         L.emu_plan.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
         L.emu_get_windows.argtypes = [C.c_int, C.c_void_p]
@@ -32,7 +34,7 @@ class Emu:
     def error(self):
         return self.lib.emu_last_error().decode()
 
-    def decode(self, units, coeffs, meta, n_pcm, pool, parity, sample_index=3, tns=None, pns=False, int16_out=False):
+    def decode(self, units, coeffs, meta, n_pcm, pool, parity, sample_index=3, tns=None, pns=False, int16_out=False, cce=None):
         units = np.ascontiguousarray(units)
         coeffs = np.ascontiguousarray(coeffs)
         kind = 1 if coeffs.dtype == np.int16 else 0
@@ -40,11 +42,12 @@ class Emu:
         pcm = np.full(n_pcm, -32768, np.int16) if int16_out else np.full(n_pcm, np.nan, np.float32)
         tns = np.ascontiguousarray(tns) if tns is not None else None
         self.lib.emu_set_output_kind(1 if int16_out else 0)
-        rc = self.lib.emu_decode_ex(kind, sample_index, pool.shape[0], pool.shape[1], units.ctypes.data, len(units),
-                                    coeffs.ctypes.data, meta.ctypes.data if meta is not None else None,
-                                    tns.ctypes.data if tns is not None else None, len(tns) if tns is not None else 0,
-                                    1 if pns else 0,
-                                    pcm.ctypes.data, n_pcm, pool.ctypes.data, parity.ctypes.data)
+        cce = np.ascontiguousarray(cce) if cce is not None else None
+        rc = self.lib.emu_decode_cce(kind, sample_index, pool.shape[0], pool.shape[1], units.ctypes.data, len(units),
+                                     coeffs.ctypes.data, meta.ctypes.data if meta is not None else None,
+                                     tns.ctypes.data if tns is not None else None, len(tns) if tns is not None else 0,
+                                     1 if pns else 0, cce.ctypes.data if cce is not None else None, len(cce) if cce is not None else 0,
+                                     pcm.ctypes.data, n_pcm, pool.ctypes.data, parity.ctypes.data)
         self.lib.emu_set_output_kind(0)
         if rc:
             raise RuntimeError("emu_decode rc=%d: %s" % (rc, self.error()))

@@ -22,6 +22,9 @@ TNS_DTYPE = np.dtype([
 ])
 assert TNS_DTYPE.itemsize == 424
 CHAN_INFO_DTYPE = UNIT_DTYPE["ch"].base
+CCE_DTYPE = np.dtype([("coupling_point", "u1"), ("n_targets", "u1"), ("reserved", "u1", (2,)),
+                      ("target", [("channel", "u1"), ("gain_list", "u1")], (16,)), ("gain", "<f4", (16, 120))])
+assert CCE_DTYPE.itemsize == 7716
 
 
 def build(target="liboracle.so"):
@@ -53,6 +56,8 @@ class Oracle:
         L.orc_decode_batch_ex.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_uint32,
                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_tns_spec.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_decode_batch_cce.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,
+                                           C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_bench_threads.restype = C.c_longlong
         L.orc_bench_threads.argtypes = [C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t,
                                         C.c_void_p, C.c_size_t, C.c_size_t, C.POINTER(C.c_double)]
@@ -122,7 +127,7 @@ class Oracle:
             raise RuntimeError("orc_bench_threads failed: %d" % n)
         return int(n), float(dt.value)
 
-    def decode_batch(self, units, coeffs, meta, n_pcm_floats, overlaps, sample_index=3, want_spec=False, tns=None, pns=False):
+    def decode_batch(self, units, coeffs, meta, n_pcm_floats, overlaps, sample_index=3, want_spec=False, tns=None, pns=False, cce=None):
         """overlaps: float32 [max_streams, max_channels, 1024], updated in place.  tns: TNS_DTYPE array -> AACG_TNS_SPEC."""
         units = np.ascontiguousarray(units)
         assert units.dtype == UNIT_DTYPE
@@ -137,13 +142,17 @@ class Oracle:
         if tns is not None:
             tns = np.ascontiguousarray(tns)
             assert tns.dtype == TNS_DTYPE
-        rc = self.lib.orc_decode_batch_ex(sample_index, kind, overlaps.shape[0], overlaps.shape[1],
-                                          units.ctypes.data, len(units), coeffs.ctypes.data,
-                                          meta.ctypes.data if meta is not None else None,
-                                          tns.ctypes.data if tns is not None else None, 1 if tns is not None else 0,
-                                          1 if pns else 0,
-                                          pcm.ctypes.data, overlaps.ctypes.data,
-                                          spec.ctypes.data if want_spec else None)
+        if cce is not None:
+            cce = np.ascontiguousarray(cce)
+            assert cce.dtype == CCE_DTYPE
+        rc = self.lib.orc_decode_batch_cce(sample_index, kind, overlaps.shape[0], overlaps.shape[1],
+                                           units.ctypes.data, len(units), coeffs.ctypes.data,
+                                           meta.ctypes.data if meta is not None else None,
+                                           tns.ctypes.data if tns is not None else None, 1 if tns is not None else 0,
+                                           1 if pns else 0,
+                                           cce.ctypes.data if cce is not None else None, len(cce) if cce is not None else 0,
+                                           pcm.ctypes.data, overlaps.ctypes.data,
+                                           spec.ctypes.data if want_spec else None)
         if rc != 0:
             raise RuntimeError("orc_decode_batch failed: %d" % rc)
         return (pcm, spec.reshape(-1, 1024)) if want_spec else pcm

@@ -42,7 +42,7 @@ def test_unit_desc_layout_matches_header():
         so = os.path.join(d, "s.so")
         subprocess.run(["gcc", "-shared", "-fPIC", "-I", ROOT, "-o", so, os.path.join(d, "s.c")], check=True)
         arr = (ctypes.c_int * 7).in_dll(ctypes.CDLL(so), "sizes")
-        assert list(arr) == [64, 16, 240, 40, 16, 24, 8]
+        assert list(arr) == [64, 16, 240, 44, 16, 24, 8]
     assert aacgpu.UNIT_DTYPE.itemsize == 64
     assert aacgpu.UNIT_DTYPE.fields["coef_offset"][1] == 16 and aacgpu.UNIT_DTYPE.fields["ch"][1] == 24
 
