@@ -204,9 +204,10 @@ int launch_run(aacg_engine* e, const aacg_dev_unit* d_units, const aacg_run* d_r
             aacg_couple_launch(point == AACG_CCE_AFTER_IMDCT, s, Q);
         }
     };
-    if (h.any_cce) {
-        /* AACG_CCE_SPEC: every unit's spectrum (the coupling elements' too) as f32, then decoder.js:258-266 / 304-316 in
-         * stages: coupling before TNS, the TNS filters, coupling after TNS — each its own small launch, in place */
+    if (h.any_cce_dependent) {
+        /* AACG_CCE_SPEC with coupling in the spectral domain: every unit's spectrum (the coupling elements' too) as f32,
+         * then decoder.js:258-266 / 304-316 in stages: coupling before TNS, the TNS filters, coupling after TNS — each its
+         * own small launch, in place.  (Independent coupling alone leaves the spectral route as it is.) */
         float* trace_or_null = P.spec_out;
         P.spec_out = d_spec; P.pns = e->d_pns; P.tns = nullptr;
         if (quant) aacg_spectral_ex_launch(true, (int)h.units.size(), s, P);
@@ -241,7 +242,8 @@ int launch_run(aacg_engine* e, const aacg_dev_unit* d_units, const aacg_run* d_r
         if (!h.cce_runs.empty()) {                      /* the independently switched coupling elements' own filterbank pass */
             aacg_kparams C = P;
             C.runs = cb.runs; C.n_runs = (int32_t)h.cce_runs.size(); C.pcm = cb.side; C.scratch = nullptr;
-            hipLaunchKernelGGL(aacg_imdct_run_f32, dim3((unsigned)h.cce_runs.size()), block, AACG_LDS_BYTES_F32, s, C);
+            if (quant) hipLaunchKernelGGL(aacg_imdct_run_quant, dim3((unsigned)h.cce_runs.size()), block, AACG_LDS_BYTES_QUANT, s, C);
+            else       hipLaunchKernelGGL(aacg_imdct_run_f32, dim3((unsigned)h.cce_runs.size()), block, AACG_LDS_BYTES_F32, s, C);
         }
         couple(AACG_CCE_AFTER_IMDCT);
     }
@@ -444,7 +446,7 @@ int aacg_plan_create_ex(aacg_engine* e, const aacg_unit_desc* units, uint32_t n_
         return AACG_ERR_UNSUPPORTED;
     }
     const size_t ub = sizeof(aacg_dev_unit) * n_units, rb = sizeof(aacg_run) * p->h.runs.size();
-    const size_t xb = (p->h.any_pns || p->h.any_tns || p->h.any_cce) ? (size_t)p->h.coef_blocks * 1024u * sizeof(float) : 0;
+    const size_t xb = (p->h.any_pns || p->h.any_tns || p->h.any_cce_dependent) ? (size_t)p->h.coef_blocks * 1024u * sizeof(float) : 0;
     const size_t tb = sizeof(aacg_dev_tns) * p->h.tns.size();
     const size_t sb = p->h.needs_scratch ? p->h.runs.size() * AACG_SLOT_FLOATS * sizeof(float) : 0;
     const size_t cb[4] = {sizeof(aacg_run) * p->h.cce_runs.size(), sizeof(aacg_couple_job) * p->h.couple_jobs.size(),
@@ -677,7 +679,7 @@ int aacg_submit_ex(aacg_engine* e, const aacg_batch* batch, uint64_t* ticket)
     const size_t ub = sizeof(aacg_dev_unit) * h.units.size(), rb = sizeof(aacg_run) * h.runs.size();
     const size_t tb = sizeof(aacg_dev_tns) * h.tns.size();
     const size_t sb = h.needs_scratch ? h.runs.size() * AACG_SLOT_FLOATS * sizeof(float) : 0;
-    const size_t xb = (h.any_pns || h.any_tns || h.any_cce) ? (size_t)n_coef_blocks * 1024u * sizeof(float) : 0;
+    const size_t xb = (h.any_pns || h.any_tns || h.any_cce_dependent) ? (size_t)n_coef_blocks * 1024u * sizeof(float) : 0;
     const size_t ccb[4] = {sizeof(aacg_run) * h.cce_runs.size(), sizeof(aacg_couple_job) * h.couple_jobs.size(),
                            sizeof(float) * h.gains.size(), (size_t)h.side_blocks * 4096u};
     const void* const cce_src[4] = {h.cce_runs.data(), h.couple_jobs.data(), h.gains.data(), nullptr};

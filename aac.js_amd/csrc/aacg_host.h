@@ -41,6 +41,7 @@ struct aacg_plan_host {
      * side buffer (cce_runs: their own launch); coupling jobs by coupling point and by round (round r: the r-th coupling
      * element of its frame, so that no two jobs of a round add to the same channel) */
     bool     any_cce = false;
+    bool     any_cce_dependent = false;   /* some element couples in the spectral domain: the batch takes the staged f32 route */
     std::vector<aacg_run> cce_runs;
     uint32_t side_blocks = 0;         /* 1024-float blocks of the side PCM buffer */
     std::vector<aacg_couple_job> couple_jobs;                   /* sorted by (point, round) */

@@ -146,6 +146,7 @@ int aacg_plan_build(const aacg_unit_desc* units, uint32_t n_units, int sample_in
                 if (ci.target[t].channel >= u.n_out_ch || ci.target[t].gain_list >= AACG_CCE_MAX_TARGETS)
                     return fail(err, AACG_ERR_INVALID_ARG, "unit %ld: coupling target %ld out of range", i, t);
             out->any_cce = true;
+            if (ci.coupling_point != AACG_CCE_AFTER_IMDCT) out->any_cce_dependent = true;
         }
         for (int c = 0; c < u.n_ch; c++) {
             const aacg_chan_info& ci = u.ch[c];

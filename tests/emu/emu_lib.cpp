@@ -201,7 +201,7 @@ int emu_decode_cce(int input_kind, int sample_index, int max_streams, int max_ch
             launch(P, point == AACG_CCE_AFTER_IMDCT ? 9 : 8, (Q.n_jobs + 3) / 4, 4, 64, 0, nullptr, &Q);
         }
     };
-    if (ph.any_cce) {
+    if (ph.any_cce_dependent) {
         const bool quant = input_kind == AACG_INPUT_QUANT_I16;
         aacg_build_pns_tables(sample_index, &pns_tab);
         spec.assign((size_t)ph.coef_blocks * 1024u, 0.0f);
@@ -235,7 +235,8 @@ int emu_decode_cce(int input_kind, int sample_index, int max_streams, int max_ch
         if (!ph.cce_runs.empty()) {
             aacg_kparams C = P;
             C.runs = ph.cce_runs.data(); C.n_runs = (int32_t)ph.cce_runs.size(); C.pcm = side.data(); C.scratch = nullptr;
-            launch(C, 0, (int)ph.cce_runs.size(), AACG_WG_WAVES, AACG_LDS_BYTES_F32);
+            launch(C, input_kind == AACG_INPUT_QUANT_I16 ? 1 : 0, (int)ph.cce_runs.size(), AACG_WG_WAVES,
+                   input_kind == AACG_INPUT_QUANT_I16 ? AACG_LDS_BYTES_QUANT : AACG_LDS_BYTES_F32);
         }
         couple(AACG_CCE_AFTER_IMDCT);
     }

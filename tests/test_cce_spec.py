@@ -154,7 +154,7 @@ def test_planner_refuses_coupling_elements_without_the_mode(oracle):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("layout,points,T,inp", [(("cpe", "sce"), (0, 1, 2), 5, "q"), (("cpe", "cpe", "cpe", "sce"), (2,), 20, "q"),
-                                                (("cpe",), (0,), 40, "q"), (("sce", "cpe", "cpe", "sce"), (1, 2, 2), 7, "q"),
+                                                (("cpe",), (0,), 40, "q"), (("sce", "cpe", "cpe", "sce"), (1, 2), 7, "q"), (("cpe", "cpe"), (2, 2, 0), 19, "q"),
                                                 (("cpe", "sce"), (0, 2), 6, "spec")])
 def test_gpu_coupling_vs_oracle(oracle, layout, points, T, inp):
     S = 6
