@@ -77,6 +77,9 @@ function FrontEnd(opts) {
     this.packets = [];                    // raw_data_blocks not yet consumed
     this.swb = {};
     this.referenceQuirks = opts.referenceQuirks !== false;   // coupling channel elements: see cce()
+    /* coupling: true (with referenceQuirks: false, the standard's syntax): coupling channel elements are kept — their
+     * spectrum, targets and gain lists — for decoders in CCE_SPEC mode; the default drops them like the reference */
+    this.keepCoupling = !!opts.coupling && !this.referenceQuirks;
     this.scratchQ = new Int16Array(FRAME);
     this.scratchMeta = new Uint16Array(META_WORDS);
 }
@@ -246,20 +249,54 @@ FrontEnd.prototype.cpe = function (bits, config, q, meta) {
 };
 
 /* ---- coupling_channel_element: consume exactly the bits the reference consumes (cce.js:45-119) ------------ */
-FrontEnd.prototype.cce = function (bits, config) {
+const CCE_SCALE = [Math.pow(2, 1 / 8), Math.pow(2, 1 / 4), Math.SQRT2, 2];     // cce.js:37-42
+FrontEnd.prototype.cce = function (bits, config, keep) {
     let point = 2 * bits.read1(), gains = 0;
-    const coupled = bits.read(3);
+    const coupled = bits.read(3), targets = [];
     for (let i = 0; i <= coupled; i++) {
         gains++;
-        const pair = bits.read1();
-        bits.advance(4);                                 // id select
-        if (pair && bits.read(2) === 3) gains++;
+        const pair = bits.read1(), id = bits.read(4), sel = pair ? bits.read(2) : 2;   // cce.js:56-65
+        if (pair && sel === 3) gains++;
+        targets.push({ pair: pair === 1, id: id, sel: sel });
     }
     point += bits.read1();
     point |= point >>> 1;
-    bits.advance(3);                                     // sign, scale
+    const sign = bits.read1(), scale = CCE_SCALE[bits.read(2)];
+    const q = keep ? new Int16Array(FRAME) : this.scratchQ, meta = keep ? new Uint16Array(META_WORDS) : this.scratchMeta;
     this.scratchQ.fill(0); this.scratchMeta.fill(0);
-    const chan = this.ics(bits, config, null, this.scratchQ, this.scratchMeta), nb = chan.groupLength.length * chan.maxSFB;
+    const chan = this.ics(bits, config, null, q, meta), nb = chan.groupLength.length * chan.maxSFB;
+    if (keep) {
+        /* the standard's syntax (4.4.2.1 coupling_channel_element), gains as cce.js:77-107 forms them: list 0 is all
+         * ones; a list is one common gain (cge) or one per coded band, coded differentially with the sign in the low
+         * bit unless gain_element_sign says otherwise.  Here a list is indexed by the band like bandTypes (the
+         * reference packs it densely, cce.js:103, and then reads it by band, cce.js:146: see oracle/aac_oracle.c). */
+        const independent = point === 3, lists = [];
+        for (let i = 0; i < gains; i++) {
+            let cge = 1, gain = 0, cache = 1;
+            if (i > 0) {
+                cge = independent ? 1 : bits.read1();
+                gain = cge ? this.cb.scaleFactor(bits) - 60 : 0;
+                cache = Math.pow(scale, -gain);
+            }
+            const list = new Float32Array(META_WORDS);
+            if (independent) list[0] = cache;
+            else for (let b = 0; b < nb; b++) {
+                if ((meta[b] >>> 12) === ZERO_BT) continue;
+                if (cge === 0) {
+                    let t = this.cb.scaleFactor(bits) - 60;
+                    if (t !== 0) {
+                        let s = 1;
+                        t = gain += t;
+                        if (!sign) { s -= 2 * (t & 1); t >>>= 1; }
+                        cache = Math.pow(scale, -t) * s;
+                    }
+                }
+                list[b] = cache;
+            }
+            lists.push(list);
+        }
+        return { type: 'cce', couplingPoint: independent ? 2 : point, targets: targets, gains: lists, ch: [chan], q: q, meta: meta };
+    }
     /* The reference compares the coupling point with AFTER_IMDCT = 2 (cce.js:35,88,95), a value the `|=` above
      * never leaves, so it reads a per-band gain list for every coupling point; and it only steps its band index
      * on a coded band (cce.js:99-114), so it keeps testing the first ZERO band's type once it meets one.
@@ -300,9 +337,11 @@ FrontEnd.prototype.parseRawDataBlock = function (bits, config) {
             elements.push(e); parts.push([q, meta]);
             break;
         }
-        case CCE:
-            this.cce(bits, config);
+        case CCE: {
+            const e = this.cce(bits, config, this.keepCoupling);
+            if (e) { e.id = id; elements.push(e); parts.push([e.q, e.meta]); }
             break;
+        }
         case DSE: {
             const align = bits.read1();
             let count = bits.read(8);

@@ -12,7 +12,8 @@
 const path = require('path');
 
 const INPUT_SPEC_F32 = 0, INPUT_QUANT_I16 = 1;
-const OUTPUT_F32 = 0, OUTPUT_I16 = 1;       // Engine({ outputKind }): OUTPUT_I16 engines take an Int16Array for pcm
+const OUTPUT_F32 = 0, OUTPUT_I16 = 1;
+const CCE_REFERENCE = 0, CCE_SPEC = 1;          // GpuAACDecoder({ cceMode }), Engine({ cceMode })       // Engine({ outputKind }): OUTPUT_I16 engines take an Int16Array for pcm
 const UNIT_BYTES = 64, META_WORDS = 120, FRAME = 1024, TNS_BYTES = 424, TNS_MAX_ORDER = 12;
 const TNS_REFERENCE = 0, TNS_SPEC = 1, PNS_REFERENCE = 0, PNS_SPEC = 1;
 const SAMPLE_RATES = [96000, 88200, 64000, 48000, 44100, 32000, 24000, 22050, 16000, 12000, 11025, 8000, 7350];
@@ -47,12 +48,28 @@ function packUnits(units) {
         view.setUint16(o + 8, u.channel, true);
         view.setUint16(o + 10, u.nOutCh, true);
         view.setUint8(o + 12, u.ch.length);
-        view.setUint8(o + 13, (u.commonWindow ? 1 : 0) | (u.maskPresent ? 2 : 0) | (u.hasPns ? 4 : 0));   // AACG_UNIT_*
+        view.setUint8(o + 13, (u.commonWindow ? 1 : 0) | (u.maskPresent ? 2 : 0) | (u.hasPns ? 4 : 0) | (u.cce ? 8 : 0));   // AACG_UNIT_*
         view.setUint32(o + 16, u.coefOffset, true);
         view.setUint32(o + 20, u.metaOffset, true);
         packChanInfo(view, o + 24, u.ch[0]);
         if (u.ch.length > 1) packChanInfo(view, o + 40, u.ch[1]);
         view.setUint32(o + 56, u.tnsOffset >>> 0, true);
+        view.setUint32(o + 60, u.cceOffset >>> 0, true);     // reserved1: index of the coupling element's aacg_cce_info
+    });
+    return new Uint8Array(buf);
+}
+
+/* coupling side info -> aacg_cce_info records (include/aacgpu.h): [{ couplingPoint, targets: [{channel, gainList}],
+ * gains: [Float32Array(120)...] }] */
+const CCE_BYTES = 7716, CCE_MAX_TARGETS = 16;
+function packCce(list) {
+    const buf = new ArrayBuffer(CCE_BYTES * Math.max(1, list.length)), view = new DataView(buf);
+    list.forEach(function (c, i) {
+        const o = CCE_BYTES * i;
+        if (c.targets.length > CCE_MAX_TARGETS || c.gains.length > CCE_MAX_TARGETS) throw new Error('coupling element with more than 16 targets');
+        view.setUint8(o, c.couplingPoint); view.setUint8(o + 1, c.targets.length);
+        c.targets.forEach(function (t, k) { view.setUint8(o + 4 + 2 * k, t.channel); view.setUint8(o + 5 + 2 * k, t.gainList); });
+        c.gains.forEach(function (g, l) { for (let b = 0; b < META_WORDS; b++) view.setFloat32(o + 36 + 4 * (META_WORDS * l + b), g[b], true); });
     });
     return new Uint8Array(buf);
 }
@@ -143,11 +160,12 @@ function Engine(opts) {
     this.handle = this.addon.create({ deviceOrdinal: opts.deviceOrdinal | 0, sampleIndex: opts.sampleIndex === undefined ? 3 : opts.sampleIndex,
                                       maxStreams: opts.maxStreams || 1, maxChannels: opts.maxChannels || 2,
                                       maxBatchUnits: opts.maxBatchUnits | 0, inputKind: this.inputKind,
-                                      tnsMode: opts.tnsMode | 0, pnsMode: opts.pnsMode | 0, outputKind: opts.outputKind | 0 });
+                                      tnsMode: opts.tnsMode | 0, pnsMode: opts.pnsMode | 0, outputKind: opts.outputKind | 0, cceMode: opts.cceMode | 0 });
 }
 /* tns: packTns(...) records for TNS_SPEC engines, else omitted */
-Engine.prototype.decodeBatch = function (units, coeffs, meta, pcm, tns) {
-    return this.addon.decodeBatch(this.handle, units, coeffs, meta || null, pcm, tns || null);   // throws on error
+/* cce: packCce(...) records for CCE_SPEC engines, else omitted */
+Engine.prototype.decodeBatch = function (units, coeffs, meta, pcm, tns, cce) {
+    return this.addon.decodeBatch(this.handle, units, coeffs, meta || null, pcm, tns || null, cce || null);   // throws on error
 };
 /* the same off the JavaScript thread: resolves with `pcm`; one call in flight per engine (the kernels chain
  * through the overlap state, so batches of one engine are decoded in order) */
@@ -204,6 +222,11 @@ function GpuAACDecoder(opts) {
     /* PNS_REFERENCE (default): a frame with NOISE_BT bands (element.hasPns) is refused, aac.js produces NaN there
      * (ics.js:234,239); PNS_SPEC fills the bands as ics.js:228-243 was meant to */
     this.pnsMode = opts.pnsMode | 0;
+    /* CCE_REFERENCE (default): coupling channel elements are parsed and dropped, as aac.js effectively does (decoder.js:418
+     * never matches).  CCE_SPEC: a front end that keeps them ({ coupling: true, referenceQuirks: false }) hands them on, and
+     * the engine applies them; maxCoupling = coupling elements a frame may carry (each needs a stream channel of its own). */
+    this.cceMode = opts.cceMode | 0;
+    this.maxCoupling = this.cceMode === CCE_SPEC ? (opts.maxCoupling || 1) : 0;
     /* chanInfo.pulse = { offset: [...], amp: [...] } (ics.pulseOffset / pulseAmp): aac.js throws 'TODO: add pulse
      * data' on such a frame (ics.js:263-265); applyPulses: true adds them to the quantised spectrum instead. */
     this.applyPulses = !!opts.applyPulses;
@@ -234,18 +257,22 @@ GpuAACDecoder.prototype.setCookie = function (buffer) {
     if (s.read(1)) { if (cfg.profile > 16) s.advance(3); s.advance(1); }
     if (cfg.chanConfig === 0) throw new Error('PCE unimplemented');
     if (!this.engine)
-        this.engine = new Engine({ sampleIndex: cfg.sampleIndex, maxStreams: this.stream + 1, maxChannels: cfg.chanConfig, inputKind: INPUT_QUANT_I16,
-                                   tnsMode: this.tnsMode, pnsMode: this.pnsMode });
+        this.engine = new Engine({ sampleIndex: cfg.sampleIndex, maxStreams: this.stream + 1, maxChannels: cfg.chanConfig + this.maxCoupling, inputKind: INPUT_QUANT_I16,
+                                   tnsMode: this.tnsMode, pnsMode: this.pnsMode, cceMode: this.cceMode });
     this.engine.resetStream(this.stream);    // new FilterBank(false, chanConfig): zeroed overlaps (filter_bank.js:38-41)
 };
 
 /* elements of one parsed frame -> unit records; channel indices assigned in element order, elements beyond
  * chanConfig channels dropped (decoder.js:233-247) */
-GpuAACDecoder.prototype.unitsOfFrame = function (frame, frameSlot, blockBase, tnsList) {
+GpuAACDecoder.prototype.unitsOfFrame = function (frame, frameSlot, blockBase, tnsList, cceList) {
     const C = this.config.chanConfig, units = [];
     let channel = 0, block = blockBase;
+    const audio = frame.elements.filter(function (e) { return e.type !== 'cce'; });
+    const coupling = frame.elements.filter(function (e) { return e.type === 'cce'; });
+    if (coupling.length && !cceList) throw new Error('coupling channel element in the frame: the decoder was not created with cceMode: CCE_SPEC');
+    if (coupling.length > this.maxCoupling) throw new Error('more coupling channel elements in a frame than maxCoupling allows for');
     /* everything that can refuse the frame comes first: a frame that throws leaves no trace in the decoder's state */
-    for (const e of frame.elements) {
+    for (const e of audio) {
         if (channel >= C) break;
         if (e.gainPresent) throw new Error('Gain control not implemented');
         if (e.hasPns && this.pnsMode !== PNS_SPEC) throw new Error('aacgpu: NOISE_BT (PNS) band: not decodable by the reference either (pnsMode: PNS_SPEC fills them)');
@@ -253,9 +280,15 @@ GpuAACDecoder.prototype.unitsOfFrame = function (frame, frameSlot, blockBase, tn
         channel += e.type === 'cpe' ? 2 : 1;
     }
     channel = 0;
-    for (const e of frame.elements) {
+    /* blocks follow the order of frame.elements (that is how the front end lays q / meta out) */
+    const blockOf = new Map();
+    { let b = blockBase; for (const e of frame.elements) { blockOf.set(e, b); b += e.type === 'cpe' ? 2 : 1; } }
+    const placed = [];                                   // audio elements with their first output channel (decoder.js:233-247)
+    for (const e of audio) {
         const n = e.type === 'cpe' ? 2 : 1;
         if (channel >= C) break;
+        block = blockOf.get(e);
+        placed.push({ e: e, channel: channel });
         for (let c = 0; c < n; c++) {
             e.ch[c].windowShapePrev = this.carryWindowShape ? (this.prevShape[channel + c] | 0) : 0;
             this.prevShape[channel + c] = e.ch[c].windowShape;
@@ -273,8 +306,29 @@ GpuAACDecoder.prototype.unitsOfFrame = function (frame, frameSlot, blockBase, tn
         }
         units.push({ stream: this.stream, pcmOffset: frameSlot * FRAME * C, channel: channel, nOutCh: C, coefOffset: block, metaOffset: block,
                      commonWindow: !!e.commonWindow, maskPresent: !!e.maskPresent, hasPns: !!e.hasPns, ch: e.ch, tnsOffset: tnsOffset });
-        channel += n; block += n;
+        channel += n;
     }
+    /* coupling channel elements (CCE_SPEC): stream channel C + k for the k-th of the frame; which output channels an
+     * (is-a-pair, id, select) triple means is decided as decoder.js:411-431 walks them — with the comparison of
+     * channelPair that can be true (decoder.js:418 compares a number with a boolean) and every coupled element visited
+     * (decoder.js:416 stops one short of cce.js:53) */
+    coupling.forEach((e, k) => {
+        const targets = [];
+        let index = 0;
+        for (const t of e.targets) {
+            const hit = placed.find(function (p) { return (p.e.type === 'cpe') === t.pair && p.e.id === t.id; });
+            if (hit) {
+                if (t.sel !== 1) { targets.push({ channel: hit.channel, gainList: index }); if (t.sel) index++; }
+                if (t.sel !== 2) targets.push({ channel: hit.channel + 1, gainList: index++ });
+            } else index += 1 + (t.sel === 3 ? 1 : 0);
+        }
+        e.ch[0].windowShapePrev = this.carryWindowShape ? (this.prevShape[C + k] | 0) : 0;
+        this.prevShape[C + k] = e.ch[0].windowShape;
+        const info = Object.assign({}, e.ch[0], { tns: null });       // the reference never runs a coupling element's own TNS either
+        units.push({ stream: this.stream, pcmOffset: frameSlot * FRAME * C, channel: C + k, nOutCh: C, coefOffset: blockOf.get(e), metaOffset: blockOf.get(e),
+                     commonWindow: false, maskPresent: false, hasPns: false, cce: true, cceOffset: cceList.length, ch: [info], tnsOffset: 0 });
+        cceList.push({ couplingPoint: e.couplingPoint, targets: targets, gains: e.gains });
+    });
     return units;
 };
 
@@ -292,7 +346,7 @@ GpuAACDecoder.prototype.readChunk = function () {
 GpuAACDecoder.prototype.decodeAhead = function () {
     if (this.config.profile === 1) throw new Error('Main prediction unimplemented');
     if (this.config.profile === 4) throw new Error('LTP prediction unimplemented');
-    const C = this.config.chanConfig, frames = [], tnsList = this.tnsMode === TNS_SPEC ? [] : null;
+    const C = this.config.chanConfig, frames = [], tnsList = this.tnsMode === TNS_SPEC ? [] : null, cceList = this.cceMode === CCE_SPEC ? [] : null;
     let units = [], block = 0, failed = null;
     while (frames.length < this.lookahead) {
         /* both front ends have consumed a frame by the time they throw for it, and return null on underflow: an
@@ -300,7 +354,7 @@ GpuAACDecoder.prototype.decodeAhead = function () {
         try {
             const f = this.frontend.parseFrame(this);
             if (!f) break;
-            units = units.concat(this.unitsOfFrame(f, frames.length, block, tnsList));
+            units = units.concat(this.unitsOfFrame(f, frames.length, block, tnsList, cceList));
             block += f.q.length / FRAME;
             frames.push(f);
         } catch (err) { failed = err instanceof Error ? err : new Error(String(err)); break; }
@@ -310,7 +364,8 @@ GpuAACDecoder.prototype.decodeAhead = function () {
         let b = 0;
         for (const f of frames) { q.set(f.q, b * FRAME); meta.set(f.meta, b * META_WORDS); b += f.q.length / FRAME; }
         const pcm = new Float32Array(frames.length * FRAME * C);
-        this.engine.decodeBatch(packUnits(units), q, meta, pcm, tnsList && tnsList.length ? packTns(tnsList) : null);
+        this.engine.decodeBatch(packUnits(units), q, meta, pcm, tnsList && tnsList.length ? packTns(tnsList) : null,
+                                cceList && cceList.length ? packCce(cceList) : null);
         for (let i = 0; i < frames.length; i++) this.queue.push(pcm.slice(i * FRAME * C, (i + 1) * FRAME * C));   // caller owns each array
     }
     if (failed) this.queue.push(failed);
@@ -320,7 +375,7 @@ GpuAACDecoder.prototype.decodeAhead = function () {
 GpuAACDecoder.prototype.feed = function (bytes) { this.frontend.push(bytes.data || bytes); };
 GpuAACDecoder.prototype.feedPacket = function (bytes) { this.frontend.pushPacket(bytes.data || bytes); };
 
-module.exports = { Engine, GpuAACDecoder, BitReader, packUnits, unpackUnits, packBandWord, packTns, unpackTns, applyPulses, loadAddon,
+module.exports = { Engine, GpuAACDecoder, BitReader, packUnits, unpackUnits, packBandWord, packTns, unpackTns, packCce, CCE_REFERENCE, CCE_SPEC, CCE_BYTES, applyPulses, loadAddon,
                    INPUT_SPEC_F32, INPUT_QUANT_I16, OUTPUT_F32, OUTPUT_I16, TNS_REFERENCE, TNS_SPEC, PNS_REFERENCE, PNS_SPEC, UNIT_BYTES, META_WORDS, TNS_BYTES, SAMPLE_RATES };
 /* the bitstream front end and its pieces (loaded on first use: they require this module themselves) */
 for (const [name, file] of [['FrontEnd', './frontend.js'], ['GpuFrontEnd', './gpu_frontend.js'], ['codebooks', './codebooks.js'], ['adts', './adts.js'], ['BitStream', './bits.js']])

@@ -31,6 +31,7 @@ static struct {
     int  (*submit)(aacg_engine*, const aacg_unit_desc*, uint32_t, const void*, uint32_t,
                    const aacg_band_meta*, uint32_t, void*, size_t, uint64_t*);
     int  (*wait)(aacg_engine*, uint64_t);
+    int  (*decode_batch_ex)(aacg_engine*, const aacg_batch*);
     int  (*decode_batch_tns)(aacg_engine*, const aacg_unit_desc*, uint32_t, const void*, uint32_t,
                              const aacg_band_meta*, uint32_t, const aacg_tns_info*, uint32_t, void*, size_t);
     int  (*submit_tns)(aacg_engine*, const aacg_unit_desc*, uint32_t, const void*, uint32_t,
@@ -68,7 +69,7 @@ static int load_lib(napi_env env, const char* path)
     SYM(abi_version, "aacg_abi_version"); SYM(reset_stream, "aacg_reset_stream");
     SYM(get_overlap, "aacg_get_overlap"); SYM(set_overlap, "aacg_set_overlap"); SYM(decode_batch, "aacg_decode_batch");
     SYM(submit, "aacg_submit"); SYM(wait, "aacg_wait");
-    SYM(decode_batch_tns, "aacg_decode_batch_tns"); SYM(submit_tns, "aacg_submit_tns");
+    SYM(decode_batch_ex, "aacg_decode_batch_ex"); SYM(decode_batch_tns, "aacg_decode_batch_tns"); SYM(submit_tns, "aacg_submit_tns");
     SYM(parser_create, "aacg_parser_create"); SYM(parser_destroy, "aacg_parser_destroy"); SYM(parser_last_error, "aacg_parser_last_error");
     SYM(parse_status_string, "aacg_parse_status_string"); SYM(parse_batch, "aacg_parse_batch");
 #undef SYM
@@ -147,6 +148,7 @@ static napi_value js_create(napi_env env, napi_callback_info info)
     cfg.tns_mode = get_i32(env, argv[0], "tnsMode", AACG_TNS_REFERENCE);
     cfg.pns_mode = get_i32(env, argv[0], "pnsMode", AACG_PNS_REFERENCE);
     cfg.output_kind = get_i32(env, argv[0], "outputKind", AACG_OUTPUT_F32);
+    cfg.cce_mode = get_i32(env, argv[0], "cceMode", AACG_CCE_REFERENCE);
     aacg_engine* e = NULL;
     int rc = L.create(&cfg, &e);
     if (rc) return fail(env, NULL, rc, "aacg_create (is a GPU visible?)");
@@ -192,14 +194,31 @@ static int optional_tns(napi_env env, size_t argc, napi_value* argv, size_t at, 
     return 1;
 }
 
+/* optional trailing argument: cce:Uint8Array of aacg_cce_info records (AACG_CCE_SPEC engines); 1 ok, 0 thrown */
+static int optional_cce(napi_env env, size_t argc, napi_value* argv, size_t at, void** data, size_t* count)
+{
+    *data = NULL; *count = 0;
+    if (argc <= at) return 1;
+    napi_valuetype vt;
+    if (napi_typeof(env, argv[at], &vt) != napi_ok) return 0;
+    if (vt == napi_null || vt == napi_undefined) return 1;
+    napi_typedarray_type tt; size_t nt;
+    if (!typed(env, argv[at], &tt, &nt, data) || tt != napi_uint8_array || nt % sizeof(aacg_cce_info)) {
+        napi_throw_type_error(env, NULL, "cce must be a Uint8Array of 7716-byte aacg_cce_info records");
+        return 0;
+    }
+    *count = nt / sizeof(aacg_cce_info);
+    return 1;
+}
+
 /* decodeBatch(engine, units:Uint8Array(64*n), coeffs:Int16Array|Float32Array, meta:Uint16Array|null, pcm:Float32Array
- *             [, tns:Uint8Array(424*m)]) */
+ *             [, tns:Uint8Array(424*m) [, cce:Uint8Array(7716*k)]]) */
 static napi_value js_decode_batch(napi_env env, napi_callback_info info)
 {
-    size_t argc = 6; napi_value argv[6];
+    size_t argc = 7; napi_value argv[7];
     CHECK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
-    void* dt; size_t nt;
-    if (!optional_tns(env, argc, argv, 5, &dt, &nt)) return NULL;
+    void* dt; size_t nt; void* dcce; size_t ncce;
+    if (!optional_tns(env, argc, argv, 5, &dt, &nt) || !optional_cce(env, argc, argv, 6, &dcce, &ncce)) return NULL;
     aacg_engine* e = engine_of(env, argv[0]);
     if (!e) return NULL;
     napi_typedarray_type tu, tc, tm, tp; size_t nu, nc, nm = 0, np; void *du, *dc, *dm = NULL, *dp;
@@ -215,9 +234,15 @@ static napi_value js_decode_batch(napi_env env, napi_callback_info info)
     }
     if (!typed(env, argv[4], &tp, &np, &dp) || tp != (engine_box(env, argv[0])->out_i16 ? napi_int16_array : napi_float32_array)) {
         napi_throw_type_error(env, NULL, "pcm must be a Float32Array (an Int16Array for an engine created with outputKind: OUTPUT_I16)"); return NULL; }
-    int rc = L.decode_batch_tns(e, (const aacg_unit_desc*)du, (uint32_t)(nu / sizeof(aacg_unit_desc)), dc, (uint32_t)(nc / 1024),
-                                (const aacg_band_meta*)dm, (uint32_t)(nm / AACG_MAX_SECTIONS),
-                                (const aacg_tns_info*)dt, (uint32_t)nt, dp, np);
+    aacg_batch b;
+    memset(&b, 0, sizeof b);
+    b.units = (const aacg_unit_desc*)du; b.n_units = (uint32_t)(nu / sizeof(aacg_unit_desc));
+    b.coeffs = dc; b.n_coef_blocks = (uint32_t)(nc / 1024);
+    b.meta = (const aacg_band_meta*)dm; b.n_meta = (uint32_t)(nm / AACG_MAX_SECTIONS);
+    b.tns = (const aacg_tns_info*)dt; b.n_tns = (uint32_t)nt;
+    b.cce = (const aacg_cce_info*)dcce; b.n_cce = (uint32_t)ncce;
+    b.pcm_out = dp; b.n_pcm_floats = np;
+    int rc = L.decode_batch_ex(e, &b);
     if (rc) return fail(env, e, rc, "aacg_decode_batch");
     return argv[4];
 }

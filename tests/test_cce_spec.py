@@ -230,3 +230,52 @@ def test_gpu_coupling_plan_and_errors(oracle):
     plain.close()
     with pytest.raises(aacgpu.AacgError):
         aacgpu.Engine(aacgpu.INPUT_QUANT_I16, max_streams=1, max_channels=3, cce_mode=aacgpu.CCE_SPEC, output_kind=aacgpu.OUTPUT_I16)
+
+
+# ---- through the JavaScript host: front end keeps the coupling elements, GpuAACDecoder hands them to the engine ----
+import json
+import os
+import shutil
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NODE = shutil.which("node")
+needs_node = pytest.mark.skipif(NODE is None or not os.path.exists("/usr/include/node/node_api.h"), reason="node / node_api.h not present")
+
+
+def js_records(tmp, mode):
+    out = str(tmp)
+    subprocess.run(["make", "-C", os.path.join(ROOT, "aac.js_amd", "napi")], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    r = subprocess.run([NODE, os.path.join(ROOT, "tests", "js", "test_coupling.js"), out, mode], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "coupling %s tests ok" % mode in r.stdout, r.stdout + r.stderr
+    f = lambda ext, dt: np.fromfile(os.path.join(out, "coupling" + ext), dt)
+    info = json.load(open(os.path.join(out, "coupling.json")))
+    return info, f(".units", np.uint8).view(orc.UNIT_DTYPE).ravel(), f(".q", np.int16), f(".meta", np.uint16), f(".cce", np.uint8).view(orc.CCE_DTYPE).ravel(), out
+
+
+@needs_node
+def test_js_host_coupling_records(oracle, tmp_path):
+    """tests/js/test_coupling.js checks what the front end parsed (targets, every gain) and how the decoder resolved it; the
+    records it hands to the engine then decode the same in the oracle and in the emulated kernels, and differently from the
+    same stream with the coupling elements dropped."""
+    info, units, q, meta, cce, _ = js_records(tmp_path, "cpu")
+    C, H, n = info["channels"], info["channels"] + info["hidden"], info["frames"]
+    ov = np.zeros((1, H, 1024), np.float32)
+    ref = oracle.decode_batch(units, q, meta, n * 1024 * C, ov, cce=cce)
+    pool = np.zeros((1, H, 2, 1024), np.float32)
+    got = emu_lib.Emu().decode(units, q, meta, n * 1024 * C, pool, np.zeros(H, np.uint8), cce=cce)
+    assert rel(got, ref) < RMS_REL
+    dropped = oracle.decode_batch(units[(units["flags"] & aacgpu.UNIT_CCE) == 0], q, meta, n * 1024 * C, np.zeros((1, H, 1024), np.float32))
+    assert rel(ref, dropped) > 1e-3
+
+
+@pytest.mark.gpu
+@needs_node
+def test_js_host_coupling_gpu(oracle, tmp_path):
+    """bytes -> FrontEnd (coupling kept) -> GpuAACDecoder({ cceMode: CCE_SPEC }).readChunk() on the real engine == the oracle on
+    the records the same decoder produced."""
+    info, units, q, meta, cce, out = js_records(tmp_path, "gpu")
+    C, H, n = info["channels"], info["channels"] + info["hidden"], info["frames"]
+    ref = oracle.decode_batch(units, q, meta, n * 1024 * C, np.zeros((1, H, 1024), np.float32), cce=cce)
+    pcm = np.fromfile(os.path.join(out, "coupling.pcm"), np.float32)
+    assert pcm.size == ref.size and rel(pcm, ref) < RMS_REL
