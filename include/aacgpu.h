@@ -173,8 +173,9 @@ typedef struct aacg_chan_info {
 #define AACG_UNIT_MASK_PRESENT  0x02   /* cpe.maskPresent  (cpe.js:47)  */
 #define AACG_UNIT_CCE           0x08   /* a coupling channel element (AACG_CCE_SPEC engines): one channel; `channel` is a
                                           stream channel beyond the n_out_ch output channels (it owns overlap state when the
-                                          coupling is independent, it is never interleaved); reserved1 = index of its
-                                          aacg_cce_info                                                                  */
+                                          coupling is independent — such an element must then be present in every frame of the
+                                          stream's batch, like any element with state — it is never interleaved); reserved1 =
+                                          index of its aacg_cce_info                                                     */
 #define AACG_UNIT_HAS_PNS       0x04   /* some band of the unit is NOISE_BT (the parser knows, ics.js:84-121):
                                           AACG_PNS_SPEC engines route such batches through the PNS stage,
                                           AACG_PNS_REFERENCE engines refuse them                          */

@@ -29,7 +29,9 @@ for (let t = 0; t < FRAMES; t++) {
     cpe.id = 1; sce.id = 4;
     elements.forEach(function (e, i) {
         if (e.type !== 'cce') return;
-        e.point = [0, 1, 2, 3][(t + i) % 4];                 // as coded: ind_sw_cce_flag << 1 | cc_domain
+        /* as coded: ind_sw_cce_flag << 1 | cc_domain.  The first coupling element of every frame is independently switched
+         * (it owns overlap state, so it has to be there in every frame of a batch: include/aacgpu.h), the second is dependent */
+        e.point = i === 0 ? 2 + (t & 1) : (t >> 1) & 1;
         /* targets that exist: the pair (one channel, the other, both with one list, both with two), the single channel,
          * and one that matches nothing (skipped, but its gain lists are still in the stream) */
         const sel = (t + i) % 4;
