@@ -11,10 +11,10 @@
  *   _dd : plans with full later runs (chains longer than 16 frames), whose first wave does double duty;
  * (the optional TNS / PNS stages are a kernel of their own, aacg_engine_spectral.hip) */
 extern "C" __global__ __launch_bounds__(AACG_WG_THREADS)
-void aacg_imdct_run_quant_dd(const aacg_kparams P) { imdct_run_body_dd<AACG_INPUT_QUANT_I16>(P); }
+void aacg_imdct_run_quant_dd(const aacg_kparams P) { imdct_run_body<AACG_INPUT_QUANT_I16, AACG_OUTPUT_F32, true>(P); }
 
 extern "C" __global__ __launch_bounds__(AACG_WG_THREADS)
-void aacg_imdct_run_f32_dd(const aacg_kparams P) { imdct_run_body_dd<AACG_INPUT_SPEC_F32>(P); }
+void aacg_imdct_run_f32_dd(const aacg_kparams P) { imdct_run_body<AACG_INPUT_SPEC_F32, AACG_OUTPUT_F32, true>(P); }
 
 
 

@@ -12,9 +12,9 @@ void aacg_imdct_run_quant_i16(const aacg_kparams P) { imdct_run_body<AACG_INPUT_
 extern "C" __global__ __launch_bounds__(AACG_WG_THREADS)
 void aacg_imdct_run_f32_i16(const aacg_kparams P) { imdct_run_body<AACG_INPUT_SPEC_F32, AACG_OUTPUT_I16>(P); }
 extern "C" __global__ __launch_bounds__(AACG_WG_THREADS)
-void aacg_imdct_run_quant_dd_i16(const aacg_kparams P) { imdct_run_body_dd<AACG_INPUT_QUANT_I16, AACG_OUTPUT_I16>(P); }
+void aacg_imdct_run_quant_dd_i16(const aacg_kparams P) { imdct_run_body<AACG_INPUT_QUANT_I16, AACG_OUTPUT_I16, true>(P); }
 extern "C" __global__ __launch_bounds__(AACG_WG_THREADS)
-void aacg_imdct_run_f32_dd_i16(const aacg_kparams P) { imdct_run_body_dd<AACG_INPUT_SPEC_F32, AACG_OUTPUT_I16>(P); }
+void aacg_imdct_run_f32_dd_i16(const aacg_kparams P) { imdct_run_body<AACG_INPUT_SPEC_F32, AACG_OUTPUT_I16, true>(P); }
 
 int aacg_i16_set_lds_limits(void)
 {

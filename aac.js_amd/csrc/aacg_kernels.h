@@ -1533,176 +1533,15 @@ DP_DEVICE void epilogue(const float* p0, const float* p1, const unit_view& u, in
 /* ------------------------------------------------------------------------------------ */
 /* one run per workgroup                                                                   */
 /* ------------------------------------------------------------------------------------ */
-template <int KIND, int OUT = AACG_OUTPUT_F32>
+/* The run body.  A later run of a chain starts from the tail of the frame before it, which another workgroup owns, so it
+ * recomputes that frame's IMDCT.  With up to 15 frames a wave of its own does that; a full run of 16 gives its first
+ * wave double duty (DD = true builds only): first the predecessor, whose tails it parks in a scratch area in global
+ * memory, then its own frame, which takes its overlap from there.  DD is a template constant, not a run-time flag: the
+ * kernels for plans without full later runs (DD = false, aacg_engine.hip) contain no second pass at all — with the pass
+ * behind a run-time condition the same source compiled to a run body 0.8 us slower on config 2 (interleaved A/B, 16.8 vs
+ * 16.0 us), and a non-inlined predecessor pass cost config 4 more than it saved (29 vs 23 us).  ONE source for both. */
+template <int KIND, int OUT = AACG_OUTPUT_F32, bool DD = false>
 DP_DEVICE void imdct_run_body(const aacg_kparams& P)
-{
-    const int TAB_FLOATS = (KIND == AACG_INPUT_QUANT_I16) ? AACG_TAB_QUANT_FLOATS : AACG_TAB_F32_FLOATS;
-    const int lane = dp_lane(), wave = dp_wave();
-    const aacg_run* run = P.runs + dp_block();
-    float* lds = (float*)dp_lds();
-    const float* tab = lds;
-    float* slots = lds + TAB_FLOATS;
-    float* slot = slots + wave * AACG_SLOT_FLOATS;
-    int* flags = (int*)(slots + AACG_WG_WAVES * AACG_SLOT_FLOATS);
-
-    /* the table loads go first: everything behind them in the vector-memory queue may stay in flight
-     * while the tables are copied to LDS */
-    dpf4 tr0, tr1;
-    stage_tables_load(P.tab, TAB_FLOATS, tr0, tr1);
-
-    const int n_units = run->n_units;
-    const bool has_pred = run->pred_unit >= 0;
-    int ui = -1;
-    if (has_pred) { if (wave == 0) ui = run->pred_unit; else if (wave - 1 < n_units) ui = run->unit[wave - 1]; }
-    else          { if (wave < n_units) ui = run->unit[wave]; }
-    ui = dp_uniform(ui);
-    const bool is_pred_wave = has_pred && wave == 0;
-
-    float hx0[8], hy0[8], hx1[8], hy1[8];
-    /* scalar loads: nothing that may clobber memory (stores, clock reads) precedes them */
-    const unit_view u = load_unit(P.units + (ui >= 0 ? ui : 0));
-    /* Earlier frames get the higher issue priority: they finish first and their PCM stores overlap
-     * the later waves' arithmetic.  A wave only ever waits for the wave before it, whose priority is
-     * never lower, so a spinning consumer cannot starve its producer. */
-    if (AACG_ABL(P, 64)) dp_setprio(0); else if (AACG_ABL(P, 32)) dp_setprio(1 - (wave >> 3)); else dp_setprio(3 - (wave >> 2));
-    const unsigned long long t_start = AACG_ABL(P, 16) ? dp_clock() : 0;
-    unsigned long long* trace = AACG_ABL(P, 16) ? (unsigned long long*)P.spec_out + ((size_t)dp_block() * AACG_WG_WAVES + wave) * 8 : nullptr;
-    if (trace && lane == 0) trace[0] = t_start;
-    const int n_ch = ui >= 0 ? u.n_ch : 0;
-    const int cls0 = u.seq[0] == AACG_EIGHT_SHORT_SEQUENCE;
-    const int cls1 = u.seq[1] == AACG_EIGHT_SHORT_SEQUENCE;
-    const bool pair_path = n_ch == 2 && u.seq[0] == u.seq[1] && u.shape[0] == u.shape[1] && u.shape_prev[0] == u.shape_prev[1];
-
-    /* This wave's spectrum: only the tables are waited for before the barrier.  All loads are
-     * unconditional (an idle wave of a short run re-reads unit 0 and ignores it; a single channel reads
-     * its block twice): a load under a condition makes hipcc wait vmcnt(0) at the join, which would
-     * serialise the HBM round trips. */
-    quant_regs qreg;
-    dpf4 xa[4], xb[4];
-    const float* xsrc = (const float*)P.coeffs + (size_t)u.coef_offset * 1024u;
-    const float* xsrc1 = xsrc + (u.n_ch == 2 ? 1024 : 0);
-    /* Load staggering (measured: -1 us on the f32 path).  The first four frames of the run (the highest-
-     * priority waves, one per SIMD; two on the int16 path, where a sweep of 0..8 early waves at steady clocks
-     * gave 14.5 / 14.2 / 13.5 / 13.9 / 14.1 / - / - / - / 14.8 us) request their spectra first and alone: the table barrier below is only
-     * released once their data has landed (the loads sit under a condition, so hipcc waits for them at the
-     * join), and only then do the other twelve waves issue their requests.  The first group therefore sees
-     * its data after ~1.7 us instead of queueing behind the whole chip's 33 MB, and the later groups' data
-     * arrives while the SIMD is still busy with the earlier ones. */
-    const bool early = wave < (KIND == AACG_INPUT_QUANT_I16 ? 2 : 4) || AACG_ABL(P, 128);
-    if (early) {
-        if (KIND == AACG_INPUT_QUANT_I16) quant_load(P, u, u.n_ch, qreg);
-        else {
-#pragma unroll
-            for (int i = 0; i < 4; i++) { xa[i] = *(const dpf4*)(xsrc + 4 * lane + 256 * i); xb[i] = *(const dpf4*)(xsrc1 + 4 * lane + 256 * i); }
-        }
-    }
-    stage_tables_store(lds, TAB_FLOATS, tr0, tr1);
-    if (lane == 0) flags[wave] = 0;
-    dp_block_sync_lds();                               /* tables and flags are in LDS */
-    if (!early) {
-        if (KIND == AACG_INPUT_QUANT_I16) quant_load(P, u, u.n_ch, qreg);
-        else {
-#pragma unroll
-            for (int i = 0; i < 4; i++) { xa[i] = *(const dpf4*)(xsrc + 4 * lane + 256 * i); xb[i] = *(const dpf4*)(xsrc1 + 4 * lane + 256 * i); }
-        }
-    }
-    if (trace && lane == 0) trace[1] = dp_clock();
-
-    if (ui >= 0 && AACG_ABL(P, 1) && KIND != AACG_INPUT_QUANT_I16) {
-#pragma unroll
-        for (int m = 0; m < 8; m++) { hx0[m] = xa[m & 3].x; hy0[m] = xa[m & 3].y; hx1[m] = xb[m & 3].z; hy1[m] = xb[m & 3].w; }
-    } else if (ui >= 0) {
-        if (KIND == AACG_INPUT_QUANT_I16) {
-            float xl[16], xr[16];
-            if (AACG_ABL(P, 8)) {                        /* profiling: no dequant / MS / IS arithmetic */
-#pragma unroll
-                for (int i = 0; i < 2; i++) {
-                    xl[8 * i] = (float)qreg.ql[i].x; xl[8 * i + 1] = (float)qreg.ql[i].y; xl[8 * i + 2] = (float)qreg.ql[i].z; xl[8 * i + 3] = (float)qreg.ql[i].w;
-                    xl[8 * i + 4] = xl[8 * i]; xl[8 * i + 5] = xl[8 * i + 1]; xl[8 * i + 6] = xl[8 * i + 2]; xl[8 * i + 7] = xl[8 * i + 3];
-                    xr[8 * i] = (float)qreg.qr[i].x; xr[8 * i + 1] = (float)qreg.qr[i].y; xr[8 * i + 2] = (float)qreg.qr[i].z; xr[8 * i + 3] = (float)qreg.qr[i].w;
-                    xr[8 * i + 4] = xr[8 * i]; xr[8 * i + 5] = xr[8 * i + 1]; xr[8 * i + 6] = xr[8 * i + 2]; xr[8 * i + 7] = xr[8 * i + 3];
-                }
-            } else
-            spectral_quant(P, tab, u, n_ch, qreg, slot + 1024, xl, xr);
-            /* TNS would run here (decoder.js:309-313): identity as the reference executes it (tns.js:106,122).
-             * AACG_TNS_SPEC batches never reach this kernel with quantised input: spectral_ex_body applies the filter
-             * and hands f32 spectra to the f32 run kernel. */
-            if (pair_path) stage_pair_nat8(xl, xr, slot);
-            else { stage_nat8(xl, slot); if (n_ch == 2) stage_nat8(xr, slot + 1024); }
-        } else {
-            if (pair_path) stage_pair_f32(xa, xb, slot);
-            else {
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    *(dpf4*)(slot + 4 * lane + 256 * i) = xa[i];
-                    if (n_ch == 2) *(dpf4*)(slot + 1024 + 4 * lane + 256 * i) = xb[i];
-                }
-            }
-        }
-        dp_wave_sync();
-        if (trace && lane == 0) trace[2] = dp_clock();     /* spectrum arrived and staged */
-        filter_unit(tab, u, n_ch, pair_path, !is_pred_wave, slot, hx0, hy0, hx1, hy1);
-    }
-
-    /* this wave's tails are complete in its slot: release them to the next wave */
-    dp_wave_sync();
-    if (lane == 0) dp_flag_set(&flags[wave], 1);
-    if (trace && lane == 0) trace[3] = dp_clock();         /* IMDCT done, tail released */
-
-    if (ui >= 0 && !is_pred_wave && AACG_ABL(P, 2)) {
-        /* profiling: keep the values live without storing 8 KiB of PCM */
-        float acc = 0.0f;
-#pragma unroll
-        for (int m = 0; m < 8; m++) acc += hx0[m] + hy0[m] + hx1[m] + hy1[m];
-        if (acc == 123456.789f) P.pcm[0] = acc;
-    } else if (ui >= 0 && !is_pred_wave) {
-        if (wave == 0) {
-            /* first frame of its chain in this launch: overlap state from HBM
-             * (filter_bank.js:38-41, `overlap = this.overlaps[channel]`) */
-            const float* ov0 = P.overlap + (P.flip ? run->ov_b[0] : run->ov_a[0]);
-            const float* ov1 = P.overlap + (P.flip ? run->ov_b[1] : run->ov_a[1]);
-            epilogue<false, OUT>(ov0, ov1, u, n_ch, cls0, cls1, P.pcm, hx0, hy0, hx1, hy1);
-        } else {
-            dp_flag_wait(&flags[wave - 1], 1);         /* the previous frame's tails (acquire) */
-            if (trace && lane == 0) trace[4] = dp_clock();
-            epilogue<true, OUT>(slot - AACG_SLOT_FLOATS, slot - AACG_SLOT_FLOATS, u, n_ch, cls0, cls1, P.pcm, hx0, hy0, hx1, hy1);
-        }
-        if (trace && lane == 0) trace[5] = dp_clock();     /* PCM stores issued */
-        /* the chain's last frame in this launch: its tail is the new overlap state (planar in HBM) */
-        const int last_wave = has_pred ? n_units : n_units - 1;
-        if (wave == last_wave && run->is_last) {
-            float* d0 = P.overlap + (P.flip ? run->ov_a[0] : run->ov_b[0]);
-            float* d1 = P.overlap + (P.flip ? run->ov_a[1] : run->ov_b[1]);
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const int n = 4 * lane + 256 * i;
-                if (n_ch == 2) {
-                    const dpf4 a = *(const dpf4*)(slot + 2 * n), b = *(const dpf4*)(slot + 2 * n + 4);
-                    dpf4 l4, r4;
-                    l4.x = a.x; l4.y = a.z; l4.z = b.x; l4.w = b.z;
-                    r4.x = a.y; r4.y = a.w; r4.z = b.y; r4.w = b.w;
-                    *(dpf4*)(d0 + n) = l4;
-                    *(dpf4*)(d1 + n) = r4;
-                } else {
-                    *(dpf4*)(d0 + n) = *(const dpf4*)(slot + n);
-                }
-            }
-        }
-    }
-}
-
-/* ------------------------------------------------------------------------------------ */
-/* one run per workgroup, with double duty                                                 */
-/* ------------------------------------------------------------------------------------ */
-/* The run body again, for plans that contain full later runs (chains longer than 16 frames).  A later run of a chain starts from the tail of the frame before it, which another workgroup owns,
- * so it recomputes that frame's IMDCT.  With up to 15 frames a wave of its own does that (imdct_run_body above
- * handles it as well); a full run of 16 gives its first wave double duty: first the predecessor, whose tails it
- * parks in a scratch area in global memory, then its own frame, which takes its overlap from there.
- * Kept as a second function on purpose: the same source instantiated without the second pass compiles to a run
- * body that is 0.8 us slower on config 2 than the one above (interleaved A/B, 16.8 vs 16.0 us), and a non-inlined
- * predecessor pass costs config 4 more than it saves (29 vs 23 us).  The stages themselves are shared. */
-template <int KIND, int OUT = AACG_OUTPUT_F32>
-DP_DEVICE void imdct_run_body_dd(const aacg_kparams& P)
 {
     const int TAB_FLOATS = (KIND == AACG_INPUT_QUANT_I16) ? AACG_TAB_QUANT_FLOATS : AACG_TAB_F32_FLOATS;
     const int lane = dp_lane(), wave = dp_wave();
@@ -1724,14 +1563,14 @@ DP_DEVICE void imdct_run_body_dd(const aacg_kparams& P)
      * recomputes that frame's IMDCT.  With up to 15 frames wave 0 does only that (waves 1.. own the frames);
      * a full run of 16 frames gives wave 0 double duty: first the predecessor (its tail goes to a scratch
      * area in global memory), then its own frame, which takes its overlap from that scratch area. */
-    const bool dd = has_pred && n_units == AACG_WG_WAVES;
+    const bool dd = DD && has_pred && n_units == AACG_WG_WAVES;
     int ui = -1;
     if (has_pred && !dd) { if (wave == 0) ui = run->pred_unit; else if (wave - 1 < n_units) ui = run->unit[wave - 1]; }
     else                 { if (wave < n_units) ui = run->unit[wave]; }
     ui = dp_uniform(ui);
     const bool is_pred_wave = has_pred && !dd && wave == 0;
-    const int n_pass = (dd && wave == 0) ? 2 : 1;
-    float* scratch = P.scratch + (size_t)dp_block() * AACG_SLOT_FLOATS;
+    const int n_pass = (DD && dd && wave == 0) ? 2 : 1;
+    float* scratch = DD ? P.scratch + (size_t)dp_block() * AACG_SLOT_FLOATS : nullptr;
 
     float hx0[8], hy0[8], hx1[8], hy1[8];
     /* scalar loads: nothing that may clobber memory (stores, clock reads) precedes them */
@@ -1836,7 +1675,7 @@ DP_DEVICE void imdct_run_body_dd(const aacg_kparams& P)
     };
 
     if (ui >= 0) front(!is_pred_wave && n_pass == 1);
-    if (n_pass == 2) {
+    if (DD && n_pass == 2) {
         /* double duty (cold: only the first wave of a full later run): park the predecessor's tails, then fetch
          * and process this wave's own frame with a second copy of the code above */
         dp_keep_branch();

@@ -35,10 +35,10 @@ void* lane_main(void* p)
     if (a->kind == 8) { couple_spec_body(*a->Q, 4); return nullptr; }
     if (a->kind == 9) { couple_pcm_body(*a->Q, 4); return nullptr; }
     const bool dd = a->P->scratch != nullptr;
-    if (a->out_kind == AACG_OUTPUT_I16 && a->kind == 0) { if (dd) imdct_run_body_dd<AACG_INPUT_SPEC_F32, AACG_OUTPUT_I16>(*a->P); else imdct_run_body<AACG_INPUT_SPEC_F32, AACG_OUTPUT_I16>(*a->P); }
-    else if (a->out_kind == AACG_OUTPUT_I16 && a->kind == 1) { if (dd) imdct_run_body_dd<AACG_INPUT_QUANT_I16, AACG_OUTPUT_I16>(*a->P); else imdct_run_body<AACG_INPUT_QUANT_I16, AACG_OUTPUT_I16>(*a->P); }
-    else if (a->kind == 0) { if (dd) imdct_run_body_dd<AACG_INPUT_SPEC_F32>(*a->P); else imdct_run_body<AACG_INPUT_SPEC_F32>(*a->P); }
-    else if (a->kind == 1) { if (dd) imdct_run_body_dd<AACG_INPUT_QUANT_I16>(*a->P); else imdct_run_body<AACG_INPUT_QUANT_I16>(*a->P); }
+    if (a->out_kind == AACG_OUTPUT_I16 && a->kind == 0) { if (dd) imdct_run_body<AACG_INPUT_SPEC_F32, AACG_OUTPUT_I16, true>(*a->P); else imdct_run_body<AACG_INPUT_SPEC_F32, AACG_OUTPUT_I16>(*a->P); }
+    else if (a->out_kind == AACG_OUTPUT_I16 && a->kind == 1) { if (dd) imdct_run_body<AACG_INPUT_QUANT_I16, AACG_OUTPUT_I16, true>(*a->P); else imdct_run_body<AACG_INPUT_QUANT_I16, AACG_OUTPUT_I16>(*a->P); }
+    else if (a->kind == 0) { if (dd) imdct_run_body<AACG_INPUT_SPEC_F32, AACG_OUTPUT_F32, true>(*a->P); else imdct_run_body<AACG_INPUT_SPEC_F32>(*a->P); }
+    else if (a->kind == 1) { if (dd) imdct_run_body<AACG_INPUT_QUANT_I16, AACG_OUTPUT_F32, true>(*a->P); else imdct_run_body<AACG_INPUT_QUANT_I16>(*a->P); }
     else if (a->kind == 3) spectral_ex_body<AACG_INPUT_QUANT_I16>(*a->P, a->n_units);
     else if (a->kind == 4) spectral_ex_body<AACG_INPUT_SPEC_F32>(*a->P, a->n_units);
     else                   spectral_body(*a->P, a->n_units);
