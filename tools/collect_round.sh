@@ -1,0 +1,35 @@
+#!/bin/bash
+# Runs on the GPU box (via gpurun): the round's bench lines and rocprofv3 summaries into gpurun_out/<tag>/.
+# usage: tools/collect_round.sh r02
+set -u
+TAG=${1:-round}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out/$TAG
+mkdir -p $OUT
+cd $R
+python3 -c "import torch" >/dev/null 2>&1
+b() { name=$1; shift; python3 bench.py "$@" > $OUT/bench_$name.json 2> $OUT/bench_$name.err || echo "bench $name failed" >> $OUT/failures.txt; tail -c 400 $OUT/bench_$name.json | head -c 0; }
+b quant
+b quant_20steps --steps 20 --warmup 5
+b spec --input spec --no-cpu-baseline
+b cfg3 --workload cfg3 --no-cpu-baseline
+b cfg4 --workload cfg4 --no-cpu-baseline
+b cfg5 --workload cfg5 --steps 4000 --warmup 400
+b cfg5_spec --workload cfg5 --input spec --steps 4000 --warmup 400 --no-cpu-baseline
+b cfg3_tns_spec_quant --workload cfg3 --tns spec --steps 2000 --warmup 200 --no-cpu-baseline
+b cfg3_tns_spec_f32 --workload cfg3 --tns spec --input spec --steps 2000 --warmup 200 --no-cpu-baseline
+b cfg5_cce_spec --workload cfg5 --cce spec --steps 1000 --warmup 100 --no-cpu-baseline
+b quant_i16out --output i16 --no-cpu-baseline
+b quant_pipelines2 --pipelines 2 --no-cpu-baseline
+b quant_2ranks_shared_gpu --gpus 2 --dist-backend gloo --share-gpu --steps 2000 --warmup 200
+bash tools/prof.sh $TAG/prof_quant > $OUT/prof_quant.log 2>&1
+bash tools/prof.sh $TAG/prof_spec --input spec > $OUT/prof_spec.log 2>&1
+bash tools/prof.sh $TAG/prof_cfg5 --workload cfg5 > $OUT/prof_cfg5.log 2>&1
+bash tools/prof.sh $TAG/prof_cfg3_tns --workload cfg3 --tns spec > $OUT/prof_cfg3_tns.log 2>&1
+# keep what is judged: summaries and kernel stats (the raw rocprofv3 trees stay behind)
+for p in prof_quant prof_spec prof_cfg5 prof_cfg3_tns; do
+  cp $OUT/$p/summary.txt $OUT/${p}_summary.txt 2>/dev/null
+  find $OUT/$p/trace -name "*kernel_stats.csv" -exec cp {} $OUT/${p}_kernel_stats.csv \; 2>/dev/null
+  rm -rf $OUT/$p
+done
+ls -la $OUT
