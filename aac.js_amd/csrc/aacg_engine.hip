@@ -37,6 +37,9 @@ void aacg_refresh_launch(aacg_dev_unit* units, const aacg_unit_desc* parsed, con
 /* aacg_engine_i16.hip: the run kernels with int16 PCM stores (AACG_OUTPUT_I16 engines) */
 int aacg_i16_set_lds_limits(void);
 void aacg_i16_launch(bool quant, bool dd, dim3 grid, dim3 block, hipStream_t s, const aacg_kparams& P);
+/* aacg_engine_exrun.hip: the run kernels with the optional stages inside (one launch for TNS / PNS batches) */
+int aacg_exrun_set_lds_limits(void);
+void aacg_exrun_launch(bool quant, bool dd, dim3 grid, dim3 block, hipStream_t s, const aacg_kparams& P);
 int aacg_spectral_ex_set_lds_limits(void);
 void aacg_spectral_ex_launch(bool quant, int n_units, hipStream_t s, const aacg_kparams& P);
 /* aacg_engine_couple.hip: AACG_CCE_SPEC */
@@ -181,7 +184,7 @@ int launch_run(aacg_engine* e, const aacg_dev_unit* d_units, const aacg_run* d_r
                void* d_pcm, int flip, hipStream_t s)
 {
     const bool i16 = e->cfg.output_kind == AACG_OUTPUT_I16;
-    bool quant = e->cfg.input_kind == AACG_INPUT_QUANT_I16;
+    bool quant = e->cfg.input_kind == AACG_INPUT_QUANT_I16, ex = false;
     if (h.zero_fill)
         HIP_TRY(e, hipMemsetAsync(d_pcm, 0, h.pcm_floats * pcm_elem_size(e), s), AACG_ERR_NO_DEVICE);
     aacg_kparams P;
@@ -220,8 +223,13 @@ int launch_run(aacg_engine* e, const aacg_dev_unit* d_units, const aacg_run* d_r
         couple(AACG_CCE_AFTER_TNS);
         P.spec_out = trace_or_null; P.coeffs = d_spec; P.meta = nullptr; P.tns = nullptr;
         quant = false;
+    } else if ((h.any_tns || (quant && h.any_pns)) && !i16 && !h.any_cce) {
+        /* optional stages (noise bands, TNS filters) inside the run kernel: one launch */
+        P.pns = e->d_pns;
+        ex = true;
     } else if (h.any_tns || (quant && h.any_pns)) {
-        /* optional stages first (noise bands, TNS filters): f32 spectra, which the f32 run kernel takes from there */
+        /* int16 PCM or coupling elements: the optional stages first, as a launch of their own that leaves f32 spectra,
+         * which the f32 run kernel takes from there */
         float* trace_or_null = P.spec_out;
         P.spec_out = d_spec; P.pns = e->d_pns;
         aacg_spectral_ex_launch(quant, (int)h.units.size(), s, P);
@@ -229,7 +237,9 @@ int launch_run(aacg_engine* e, const aacg_dev_unit* d_units, const aacg_run* d_r
         quant = false;
     }
     if (!h.runs.empty()) {
-        if (i16) {
+        if (ex) {
+            aacg_exrun_launch(quant, h.needs_scratch, grid, block, s, P);
+        } else if (i16) {
             aacg_i16_launch(quant, h.needs_scratch, grid, block, s, P);
         } else if (h.needs_scratch) {
             aacg_ext_launch(quant, grid, block, s, P);
@@ -295,7 +305,7 @@ int aacg_create(const aacg_config* cfg, aacg_engine** out)
         /* ~158 KiB of dynamic LDS per workgroup is above the 64 KiB default limit */
         !hip_ok(e, hipFuncSetAttribute((const void*)aacg_imdct_run_quant, hipFuncAttributeMaxDynamicSharedMemorySize, AACG_LDS_BYTES_QUANT), "LDS attr") ||
         !hip_ok(e, hipFuncSetAttribute((const void*)aacg_imdct_run_f32, hipFuncAttributeMaxDynamicSharedMemorySize, AACG_LDS_BYTES_F32), "LDS attr") ||
-        aacg_ext_set_lds_limits() != 0 || aacg_i16_set_lds_limits() != 0 || aacg_spectral_ex_set_lds_limits() != 0 ||
+        aacg_ext_set_lds_limits() != 0 || aacg_i16_set_lds_limits() != 0 || aacg_exrun_set_lds_limits() != 0 || aacg_spectral_ex_set_lds_limits() != 0 ||
         !hip_ok(e, hipFuncSetAttribute((const void*)aacg_spectral, hipFuncAttributeMaxDynamicSharedMemorySize, AACG_LDS_BYTES_SPECTRAL), "LDS attr")) {
         std::fprintf(stderr, "aacgpu: %s\n", e->err.c_str());
         aacg_destroy(e);

@@ -1099,15 +1099,16 @@ DP_DEVICE void stage_pair_f32(const dpf4 (&xa)[4], const dpf4 (&xb)[4], float* s
  *      r < P computes ROW r of it in double precision by 32 steps of the row recurrence w <- w A (in float32 the
  *      transitions of a near-unstable filter lose the state: 2e-3 of the signal against 2e-6);
  *   3. the true block-end states by a serial carry v_b = M v_(b-1) + c_b: per step the P row lanes read v_(b-1)
- *      (P doubles, a broadcast read from a 96-byte exchange buffer) and c_b and write v_b; lane b + 1 picks v_b up
- *      as its incoming state.  P^2 multiply-adds per block — the block scan this replaces (Hillis-Steele over 64
+ *      (P floats, a broadcast read from a small exchange buffer), add their element of c_b and write v_b; lane b + 1
+ *      picks v_b up as its incoming state.  P^2 multiply-adds per block — the block scan this replaces (Hillis-Steele over 64
  *      blocks of 16 with the matrix squared between levels) spent log2(64) P^2 per block on every lane and read the
  *      matrices from LDS for each: 97 us per config-3 batch, bound by the LDS broadcast reads;
  *   4. the block again from its true incoming state, same arithmetic as step 1, written back in place.
  * EIGHT_SHORT (one filter per window, 128 samples, order <= 7): lane w of a half runs window w serially in place,
  * four samples per trip — no transition matrices at all.
- * xch: the wave's exchange area, AACG_SPX_XCH_FLOATS floats (per half: c_b as P floats, two P-double state buffers). */
+ * xch: the wave's exchange area, AACG_SPX_XCH_FLOATS floats (per half: the c_b of a round of blocks, two P-float state buffers). */
 #define AACG_TNS_BLOCK 32
+#define AACG_TNS_XCH_FLOATS(R) (2 * ((R) + 2) * AACG_TNS_MAX_ORDER)   /* per wave: two halves of [R][P] + 2 [P] floats */
 
 /* chunk c (four samples in processing order) of the run that starts at blk */
 DP_DEVICE void tns_chunk_load(const float* blk, int inc, int c, float (&x)[4])
@@ -1149,6 +1150,7 @@ DP_DEVICE void tns_run(float* blk, int inc, int chunks, int n_valid, const float
 }
 
 /* one long-window filter of each channel (slot f of the records; order 0 / null record = nothing to do in that half) */
+template <int R>
 DP_DEVICE void tns_long_pass(float* slot, float* xch, const aacg_dev_tns* recA, const aacg_dev_tns* recB, int f)
 {
     constexpr int P = AACG_TNS_MAX_ORDER, BL = AACG_TNS_BLOCK;
@@ -1165,8 +1167,8 @@ DP_DEVICE void tns_long_pass(float* slot, float* xch, const aacg_dev_tns* recA, 
 #pragma unroll
     for (int k = 0; k < P; k++) lpc[k] = (k < order) ? rec->lpc[f][k] : 0.0f;
     float* area = slot + 1024 * half;
-    float* cbuf = xch + 64 * half;                       /* c_b of the block being carried: P floats */
-    double* vbuf = (double*)(xch + 64 * half + 16);      /* two state buffers of P doubles (steps alternate) */
+    float* cbuf = xch + AACG_TNS_XCH_FLOATS(R) / 2 * half;   /* c_b of a round's blocks, [R][P] floats */
+    float* vbuf = cbuf + R * P;                          /* two state buffers of P floats (steps alternate) */
 
     /* this lane's block, in processing order; blocks before the last are full */
     const int m0 = BL * b;
@@ -1180,50 +1182,66 @@ DP_DEVICE void tns_long_pass(float* slot, float* xch, const aacg_dev_tns* recA, 
     tns_run<P, false>(blk, inc, BL / 4, n_valid, lpc, c_own);
 
     /* 2. row b of M = A^BL: w <- w A, BL times, from e_b (A: first row -lpc, ones below the diagonal) */
-    double row[P];
-    if (b < P) {
+    double row[P];                                       /* lanes b >= P: zeros, they ride along */
 #pragma unroll
-        for (int k = 0; k < P; k++) row[k] = (k == b) ? 1.0 : 0.0;
+    for (int k = 0; k < P; k++) row[k] = (k == b) ? 1.0 : 0.0;
 #pragma unroll 2
-        for (int step = 0; step < BL; step++) {
-            const double w0 = row[0];
+    for (int step = 0; step < BL; step++) {
+        const double w0 = row[0];
 #pragma unroll
-            for (int k = 0; k < P - 1; k++) row[k] = dp_fma(-w0, (double)lpc[k], row[k + 1]);
-            row[P - 1] = -w0 * (double)lpc[P - 1];
-        }
+        for (int k = 0; k < P - 1; k++) row[k] = dp_fma(-w0, (double)lpc[k], row[k + 1]);
+        row[P - 1] = -w0 * (double)lpc[P - 1];
     }
 
-    /* 3. serial carry: v_0 = c_0; v_s = M v_(s-1) + c_s.  s_in = this block's incoming state (y[-1-k]). */
+    /* 3. serial carry: v_0 = c_0; v_s = M v_(s-1) + c_s.  s_in = this block's incoming state (y[-1-k]).
+     * What this loop costs is LDS time, one pipe for the CU's 16 waves (a wave-wide 16-byte store takes 13 cycles to
+     * issue whatever its exec mask, a 16-byte read 4): so c_s goes to the row lanes transposed once per ROUND of
+     * R blocks (lane b of the round stores its c_own, row lane r picks element r of each), the state
+     * travels as 12 floats (one 4-byte store per step by the row lanes, three 16-byte reads by everybody: the row
+     * lanes take it as M's operand, lane s keeps it as its incoming state), and M stays in double in the row lanes'
+     * registers.  23 LDS cycles per step against 95 when lane s published c_s and the state went round as doubles
+     * (config-3 batch with a filter everywhere: 40.0 -> 36.1 us).  M and its products in float32 were measured too:
+     * nothing on encoder-like filters, but a filter drawn from the full coefficient table left the state 1e-2 off
+     * (1e-4 in double), and the serial recurrence of steps 1 and 4 in the other tap order: no faster. */
     float s_in[P];
 #pragma unroll
     for (int k = 0; k < P; k++) s_in[k] = 0.0f;
-    if (b == 0) {
-#pragma unroll
-        for (int k = 0; k < P; k++) vbuf[k] = (double)c_own[k];
-    }
-    dp_wave_sync();
+    float vmine = 0.0f;                                  /* row lane r: v_(s-1)[r] */
 #pragma unroll 1
-    for (int s = 1; s <= n_steps; s++) {
-        const double* vprev = vbuf + P * ((s - 1) & 1);
-        double* vnext = vbuf + P * (s & 1);
-        if (b == s) {
+    for (int g = 0; R * g <= n_steps; g++) {
+        if (b / R == g) {
 #pragma unroll
-            for (int k = 0; k < P; k += 4) { dpf4 t; t.x = c_own[k]; t.y = c_own[k + 1]; t.z = c_own[k + 2]; t.w = c_own[k + 3]; *(dpf4*)(cbuf + k) = t; }
-#pragma unroll
-            for (int k = 0; k < P; k++) s_in[k] = (float)vprev[k];       /* the state behind block s - 1 */
+            for (int k = 0; k < P; k += 4) { dpf4 t; t.x = c_own[k]; t.y = c_own[k + 1]; t.z = c_own[k + 2]; t.w = c_own[k + 3]; *(dpf4*)(cbuf + P * (b % R) + k) = t; }
         }
         dp_wave_sync();
-        if (b < P) {
-            double acc0 = (double)cbuf[b], acc1 = 0.0, acc2 = 0.0;     /* three short chains instead of one of P */
+        float cs[R];
 #pragma unroll
-            for (int t = 0; t < P; t += 3) {
-                acc0 = dp_fma(row[t], vprev[t], acc0);
-                acc1 = dp_fma(row[t + 1], vprev[t + 1], acc1);
-                acc2 = dp_fma(row[t + 2], vprev[t + 2], acc2);
+        for (int j = 0; j < R; j++) cs[j] = cbuf[P * j + (b < P ? b : 0)];
+        dp_wave_sync();
+#pragma unroll
+        for (int j = 0; j < R; j++) {
+            const int st = R * g + j;
+            if (st <= n_steps) {                         /* wave-uniform */
+                double acc0 = (double)cs[j], acc1 = 0.0, acc2 = 0.0;
+                if (st > 0) {
+                    const float* vprev = vbuf + P * ((st - 1) & 1);
+                    float f[P];
+#pragma unroll
+                    for (int k = 0; k < P; k += 4) { const dpf4 t = *(const dpf4*)(vprev + k); f[k] = t.x; f[k + 1] = t.y; f[k + 2] = t.z; f[k + 3] = t.w; }
+#pragma unroll
+                    for (int k = 0; k < P; k++) s_in[k] = (b == st) ? f[k] : s_in[k];
+#pragma unroll
+                    for (int t = 0; t < P; t += 3) {     /* three short chains instead of one of P */
+                        acc0 = dp_fma(row[t], (double)f[t], acc0);
+                        acc1 = dp_fma(row[t + 1], (double)f[t + 1], acc1);
+                        acc2 = dp_fma(row[t + 2], (double)f[t + 2], acc2);
+                    }
+                }
+                vmine = (float)(acc0 + (acc1 + acc2));
+                if (b < P) vbuf[P * (st & 1) + b] = vmine;
+                dp_wave_sync();
             }
-            vnext[b] = acc0 + (acc1 + acc2);
         }
-        dp_wave_sync();
     }
 
     /* 4. the block from its true incoming state, same arithmetic as step 1 (read again rather than held in registers
@@ -1255,14 +1273,17 @@ DP_DEVICE void tns_short_pass(float* slot, const aacg_dev_tns* recA, const aacg_
 
 /* All TNS filters of a unit, in place on its spectra in the slot (channel c at slot + 1024 c, ICStream.data order).
  * rec0 / rec1: the channels' records, null where a channel has none. */
+template <int R>
 DP_DEVICE void tns_unit(float* slot, float* xch, const aacg_dev_tns* rec0, const aacg_dev_tns* rec1, bool short0, bool short1)
 {
     const aacg_dev_tns* l0 = short0 ? nullptr : rec0;
     const aacg_dev_tns* l1 = short1 ? nullptr : rec1;
     if (l0 || l1)
-        for (int f = 0; f < 3; f++) tns_long_pass(slot, xch, l0, l1, f);   /* up to three filters, disjoint band ranges (tns.js:119-124) */
+        for (int f = 0; f < 3; f++) tns_long_pass<R>(slot, xch, l0, l1, f);   /* up to three filters, disjoint band ranges (tns.js:119-124) */
     if ((short0 && rec0) || (short1 && rec1)) tns_short_pass(slot, rec0, rec1, short0, short1);
 }
+
+#define AACG_RUN_TNS_ROUND  3
 
 /* IMDCT + window of a unit whose spectra are staged in its slot.  CPE tails always end up
  * interleaved (pair index n = (tailL[n], tailR[n])); a single channel's tail is planar. */
@@ -1540,7 +1561,14 @@ DP_DEVICE void epilogue(const float* p0, const float* p1, const unit_view& u, in
  * kernels for plans without full later runs (DD = false, aacg_engine.hip) contain no second pass at all — with the pass
  * behind a run-time condition the same source compiled to a run body 0.8 us slower on config 2 (interleaved A/B, 16.8 vs
  * 16.0 us), and a non-inlined predecessor pass cost config 4 more than it saved (29 vs 23 us).  ONE source for both. */
-template <int KIND, int OUT = AACG_OUTPUT_F32, bool DD = false>
+/* EX = true builds (aacg_engine_exrun.hip) carry the optional stages inside the run: noise bands (AACG_PNS_SPEC) in the
+ * dequantisation, then the TNS filters (AACG_TNS_SPEC) on the wave's spectra in its own slot before they are staged for
+ * the IMDCT — no second kernel and no f32 spectra through HBM (a two-kernel batch costs 26 us before any filter has
+ * run, the plain run kernel 14).  They need AACG_RUN_XCH_FLOATS of LDS per wave behind the flags for the TNS carry. */
+#define AACG_RUN_XCH_FLOATS AACG_TNS_XCH_FLOATS(AACG_RUN_TNS_ROUND)
+#define AACG_LDS_BYTES_F32_EX   (AACG_LDS_BYTES_F32 + 4 * AACG_WG_WAVES * AACG_RUN_XCH_FLOATS)
+#define AACG_LDS_BYTES_QUANT_EX (AACG_LDS_BYTES_QUANT + 4 * AACG_WG_WAVES * AACG_RUN_XCH_FLOATS)
+template <int KIND, int OUT = AACG_OUTPUT_F32, bool DD = false, bool EX = false>
 DP_DEVICE void imdct_run_body(const aacg_kparams& P)
 {
     const int TAB_FLOATS = (KIND == AACG_INPUT_QUANT_I16) ? AACG_TAB_QUANT_FLOATS : AACG_TAB_F32_FLOATS;
@@ -1551,6 +1579,7 @@ DP_DEVICE void imdct_run_body(const aacg_kparams& P)
     float* slots = lds + TAB_FLOATS;
     float* slot = slots + wave * AACG_SLOT_FLOATS;
     int* flags = (int*)(slots + AACG_WG_WAVES * AACG_SLOT_FLOATS);
+    float* xch = EX ? (float*)(flags + AACG_WG_WAVES) + wave * AACG_RUN_XCH_FLOATS : nullptr;
 
     /* the table loads go first: everything behind them in the vector-memory queue may stay in flight
      * while the tables are copied to LDS */
@@ -1653,13 +1682,48 @@ DP_DEVICE void imdct_run_body(const aacg_kparams& P)
                     xr[8 * i + 4] = xr[8 * i]; xr[8 * i + 5] = xr[8 * i + 1]; xr[8 * i + 6] = xr[8 * i + 2]; xr[8 * i + 7] = xr[8 * i + 3];
                 }
             } else
-            spectral_quant(P, tab, u, n_ch, qreg, slot + 1024, xl, xr);
-            /* TNS would run here (decoder.js:309-313): identity as the reference executes it (tns.js:106,122).
-             * AACG_TNS_SPEC batches never reach this kernel with quantised input: spectral_ex_body applies the filter
-             * and hands f32 spectra to the f32 run kernel. */
+            spectral_quant<EX>(P, tab, u, n_ch, qreg, slot + 1024, xl, xr);
+            /* TNS runs here (decoder.js:309-313): identity as the reference executes it (tns.js:106,122), so the plain
+             * kernels have nothing to do; the EX builds apply the filters AACG_TNS_SPEC asks for */
+            if (EX && P.tns && (u.tns[0] || (n_ch == 2 && u.tns[1]))) {
+                stage_nat8(xl, slot);
+                if (n_ch == 2) stage_nat8(xr, slot + 1024);
+                dp_wave_sync();
+                tns_unit<AACG_RUN_TNS_ROUND>(slot, xch, u.tns[0] ? P.tns + u.tns_offset : nullptr, (n_ch == 2 && u.tns[1]) ? P.tns + u.tns_offset + 1 : nullptr,
+                                             u.seq[0] == AACG_EIGHT_SHORT_SEQUENCE, u.seq[1] == AACG_EIGHT_SHORT_SEQUENCE);
+#pragma unroll
+                for (int i = 0; i < 2; i++) {
+                    const dpf4 a = *(const dpf4*)(slot + 8 * lane + 512 * i), b = *(const dpf4*)(slot + 8 * lane + 512 * i + 4);
+                    xl[8 * i] = a.x; xl[8 * i + 1] = a.y; xl[8 * i + 2] = a.z; xl[8 * i + 3] = a.w;
+                    xl[8 * i + 4] = b.x; xl[8 * i + 5] = b.y; xl[8 * i + 6] = b.z; xl[8 * i + 7] = b.w;
+                    if (n_ch == 2) {
+                        const dpf4 c = *(const dpf4*)(slot + 1024 + 8 * lane + 512 * i), d = *(const dpf4*)(slot + 1024 + 8 * lane + 512 * i + 4);
+                        xr[8 * i] = c.x; xr[8 * i + 1] = c.y; xr[8 * i + 2] = c.z; xr[8 * i + 3] = c.w;
+                        xr[8 * i + 4] = d.x; xr[8 * i + 5] = d.y; xr[8 * i + 6] = d.z; xr[8 * i + 7] = d.w;
+                    }
+                }
+                dp_wave_sync();
+            }
             if (pair_path) stage_pair_nat8(xl, xr, slot);
             else { stage_nat8(xl, slot); if (n_ch == 2) stage_nat8(xr, slot + 1024); }
         } else {
+            if (EX && P.tns && (u.tns[0] || (n_ch == 2 && u.tns[1]))) {
+                /* the spectra as loaded are in ICStream.data order already: through the slot and back */
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    *(dpf4*)(slot + 4 * lane + 256 * i) = xa[i];
+                    if (n_ch == 2) *(dpf4*)(slot + 1024 + 4 * lane + 256 * i) = xb[i];
+                }
+                dp_wave_sync();
+                tns_unit<AACG_RUN_TNS_ROUND>(slot, xch, u.tns[0] ? P.tns + u.tns_offset : nullptr, (n_ch == 2 && u.tns[1]) ? P.tns + u.tns_offset + 1 : nullptr,
+                                             u.seq[0] == AACG_EIGHT_SHORT_SEQUENCE, u.seq[1] == AACG_EIGHT_SHORT_SEQUENCE);
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    xa[i] = *(const dpf4*)(slot + 4 * lane + 256 * i);
+                    xb[i] = *(const dpf4*)(slot + (n_ch == 2 ? 1024 : 0) + 4 * lane + 256 * i);
+                }
+                dp_wave_sync();
+            }
             if (pair_path) stage_pair_f32(xa, xb, slot);
             else {
 #pragma unroll
@@ -1729,7 +1793,8 @@ DP_DEVICE void imdct_run_body(const aacg_kparams& P)
  * biased so that the usual offsets work), then per wave a 2048-float slot (band records and PNS scratch first; for TNS
  * both channels' spectra) and the TNS exchange area. */
 #define AACG_SPX_TAB_FLOATS  (AACG_TAB_QUANT_FLOATS - AACG_TAB_F32_FLOATS)
-#define AACG_SPX_XCH_FLOATS  128
+#define AACG_SPX_TNS_ROUND   8
+#define AACG_SPX_XCH_FLOATS  AACG_TNS_XCH_FLOATS(AACG_SPX_TNS_ROUND)
 #define AACG_SPX_WAVE_FLOATS (AACG_SLOT_FLOATS + AACG_SPX_XCH_FLOATS)
 template <int KIND>
 DP_DEVICE void spectral_ex_body(const aacg_kparams& P, int n_units)
@@ -1772,7 +1837,7 @@ DP_DEVICE void spectral_ex_body(const aacg_kparams& P, int n_units)
         stage_nat8(xl, slot);
         if (n_ch == 2) stage_nat8(xr, slot + 1024);
         dp_wave_sync();
-        tns_unit(slot, xch, tns0 ? P.tns + u.tns_offset : nullptr, tns1 ? P.tns + u.tns_offset + 1 : nullptr,
+        tns_unit<AACG_SPX_TNS_ROUND>(slot, xch, tns0 ? P.tns + u.tns_offset : nullptr, tns1 ? P.tns + u.tns_offset + 1 : nullptr,
                  u.seq[0] == AACG_EIGHT_SHORT_SEQUENCE, u.seq[1] == AACG_EIGHT_SHORT_SEQUENCE);
 #pragma unroll
         for (int i = 0; i < 2; i++) {

@@ -19,7 +19,7 @@ namespace {
 struct launch_arg {
     emu_lane_ctx ctx;
     const aacg_kparams* P;
-    int kind;     /* 0 f32 run, 1 quant run, 2 spectral, 3/4 optional stages, 7 front end */
+    int kind;     /* 0 f32 run, 1 quant run, 2 spectral, 3/4 optional stages, 5/6 f32 / quant run with the optional stages inside, 7 front end */
     int n_units;
     const aacg_parse_params* PP;
     int out_kind;
@@ -39,6 +39,8 @@ void* lane_main(void* p)
     else if (a->out_kind == AACG_OUTPUT_I16 && a->kind == 1) { if (dd) imdct_run_body<AACG_INPUT_QUANT_I16, AACG_OUTPUT_I16, true>(*a->P); else imdct_run_body<AACG_INPUT_QUANT_I16, AACG_OUTPUT_I16>(*a->P); }
     else if (a->kind == 0) { if (dd) imdct_run_body<AACG_INPUT_SPEC_F32, AACG_OUTPUT_F32, true>(*a->P); else imdct_run_body<AACG_INPUT_SPEC_F32>(*a->P); }
     else if (a->kind == 1) { if (dd) imdct_run_body<AACG_INPUT_QUANT_I16, AACG_OUTPUT_F32, true>(*a->P); else imdct_run_body<AACG_INPUT_QUANT_I16>(*a->P); }
+    else if (a->kind == 5) { if (dd) imdct_run_body<AACG_INPUT_SPEC_F32, AACG_OUTPUT_F32, true, true>(*a->P); else imdct_run_body<AACG_INPUT_SPEC_F32, AACG_OUTPUT_F32, false, true>(*a->P); }
+    else if (a->kind == 6) { if (dd) imdct_run_body<AACG_INPUT_QUANT_I16, AACG_OUTPUT_F32, true, true>(*a->P); else imdct_run_body<AACG_INPUT_QUANT_I16, AACG_OUTPUT_F32, false, true>(*a->P); }
     else if (a->kind == 3) spectral_ex_body<AACG_INPUT_QUANT_I16>(*a->P, a->n_units);
     else if (a->kind == 4) spectral_ex_body<AACG_INPUT_SPEC_F32>(*a->P, a->n_units);
     else                   spectral_body(*a->P, a->n_units);
@@ -46,6 +48,7 @@ void* lane_main(void* p)
 }
 
 int g_out_kind = AACG_OUTPUT_F32;          /* emu_set_output_kind: the next decodes store int16 PCM */
+int g_staged = 0;                          /* emu_set_staged: optional stages as a launch of their own even where the engine would not */
 
 void launch(const aacg_kparams& P, int kind, int grid, int waves, size_t lds_bytes, int n_units = 0, const aacg_parse_params* PP = nullptr,
             const aacg_couple_params* Q = nullptr)
@@ -93,6 +96,7 @@ std::string g_err;
 extern "C" {
 
 const char* emu_last_error() { return g_err.c_str(); }
+void emu_set_staged(int on) { g_staged = on; }
 void emu_set_output_kind(int kind) { g_out_kind = kind; }       /* AACG_OUTPUT_*: the pcm buffer of later decodes is int16 */
 
 int emu_get_windows(int sample_index, float* dst /* 1024+1024+128+128 */)
@@ -188,6 +192,7 @@ int emu_decode_cce(int input_kind, int sample_index, int max_streams, int max_ch
     std::vector<float> scratch(ph.needs_scratch ? ph.runs.size() * AACG_SLOT_FLOATS : 1, 0.0f);
     P.scratch = ph.needs_scratch ? scratch.data() : nullptr;
     std::vector<float> spec;
+    bool ex = false;
     static aacg_pns_tables pns_tab;
     if (ph.any_pns && (pns_mode != AACG_PNS_SPEC || input_kind != AACG_INPUT_QUANT_I16)) { g_err = "PNS unit in a batch without AACG_PNS_SPEC"; return AACG_ERR_UNSUPPORTED; }
     std::vector<float> side((size_t)ph.side_blocks * 1024u + 1, 0.0f);
@@ -217,6 +222,10 @@ int emu_decode_cce(int input_kind, int sample_index, int max_streams, int max_ch
         couple(AACG_CCE_AFTER_TNS);
         P.coeffs = spec.data(); P.meta = nullptr; P.tns = nullptr;
         input_kind = AACG_INPUT_SPEC_F32;
+    } else if ((ph.any_pns || ph.any_tns) && g_out_kind == AACG_OUTPUT_F32 && !ph.any_cce && !g_staged) {
+        aacg_build_pns_tables(sample_index, &pns_tab);  /* the engine's one-launch route: optional stages inside the run kernel */
+        P.pns = &pns_tab;
+        ex = true;
     } else if (ph.any_pns || ph.any_tns) {              /* the engine's two-kernel route */
         const bool quant = input_kind == AACG_INPUT_QUANT_I16;
         aacg_build_pns_tables(sample_index, &pns_tab);
@@ -228,7 +237,10 @@ int emu_decode_cce(int input_kind, int sample_index, int max_streams, int max_ch
         P.coeffs = spec.data(); P.meta = nullptr; P.tns = nullptr;
         input_kind = AACG_INPUT_SPEC_F32;
     }
-    if (!ph.runs.empty())
+    if (!ph.runs.empty() && ex)
+        launch(P, input_kind == AACG_INPUT_QUANT_I16 ? 6 : 5, (int)ph.runs.size(), AACG_WG_WAVES,
+               input_kind == AACG_INPUT_QUANT_I16 ? AACG_LDS_BYTES_QUANT_EX : AACG_LDS_BYTES_F32_EX);
+    else if (!ph.runs.empty())
         launch(P, input_kind == AACG_INPUT_QUANT_I16 ? 1 : 0, (int)ph.runs.size(), AACG_WG_WAVES,
                input_kind == AACG_INPUT_QUANT_I16 ? AACG_LDS_BYTES_QUANT : AACG_LDS_BYTES_F32);
     if (ph.any_cce) {

@@ -222,6 +222,28 @@ def test_emulated_kernels_tns_f32_seam(emu, oracle):
     assert _rel(pcm, ref) < KERNEL_REL_TOL
 
 
+@pytest.mark.parametrize("seed", [11, 14])
+def test_emulated_one_launch_and_staged_routes_agree(emu, oracle, seed):
+    """The engine runs the filters inside the run kernel (f32 PCM, no coupling elements) or as a launch of their own
+    (int16 PCM, coupling): the same arithmetic either way, so the same bits; and the int16 route rounds that PCM."""
+    wl = W.random_batch(seed, n_streams=2, max_frames=5)
+    units, tns = W.add_tns(wl, seed=seed)
+    S, C = int(units["stream"].max()) + 1, 8
+    out = []
+    for staged in (False, True):
+        pool = np.zeros((S, C, 2, 1024), np.float32)
+        par = np.zeros(S * C, np.uint8)
+        out.append((emu.decode(units, wl["q"], wl["meta"], wl["n_pcm"], pool, par, tns=tns, staged=staged), pool.copy()))
+    assert np.array_equal(out[0][0].view(np.uint32), out[1][0].view(np.uint32))
+    assert np.array_equal(out[0][1].view(np.uint32), out[1][1].view(np.uint32))
+    pool = np.zeros((S, C, 2, 1024), np.float32)
+    par = np.zeros(S * C, np.uint8)
+    p16 = emu.decode(units, wl["q"], wl["meta"], wl["n_pcm"], pool, par, tns=tns, int16_out=True)
+    want = np.clip(np.rint(out[0][0].astype(np.float64) * 32768.0), -32768, 32767).astype(np.int32)
+    ok = ~np.isnan(out[0][0])
+    assert np.abs(p16.astype(np.int32)[ok] - want[ok]).max() <= 1
+
+
 def test_planner_rejects_bad_tns(emu):
     wl = W.make_batch(n_streams=1, n_frames=2, seed=1)
     units, tns = W.add_tns(wl, seed=1, p_channel=1.0)
@@ -264,6 +286,34 @@ def test_gpu_tns_fuzz_vs_oracle(oracle, seed, wild):
     b = eng.decode_batch(wl["units"], wl["q"], wl["meta"], wl["n_pcm"])
     eng.close()
     assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("inp", ["q", "f"])
+def test_gpu_tns_int16_engine_takes_the_staged_route(oracle, inp):
+    """AACG_OUTPUT_I16 + AACG_TNS_SPEC: the filters as a launch of their own in front of the int16 run kernel; the samples are
+    the one-launch engine's f32 PCM, rounded (at most one step apart at a rounding boundary)."""
+    import aacgpu
+    wl = W.random_batch(207, n_streams=4, max_frames=20)
+    units, tns = W.add_tns(wl, seed=207)
+    ref, ov, S, C = _decode_pair(oracle, wl, tns, units=units)
+    kind = aacgpu.INPUT_QUANT_I16 if inp == "q" else aacgpu.INPUT_SPEC_F32
+    coeffs, meta = wl["q"], wl["meta"]
+    if inp == "f":
+        ov0 = np.zeros((S, C, 1024), np.float32)
+        _, coeffs = oracle.decode_batch(wl["units"], wl["q"], wl["meta"], wl["n_pcm"], ov0, want_spec=True)   # spectra before TNS
+        meta = None
+    eng = aacgpu.Engine(kind, S, C, tns_mode=aacgpu.TNS_SPEC)
+    f32 = eng.decode_batch(units, coeffs, meta, wl["n_pcm"], tns=tns)
+    eng.close()
+    assert _rel(f32, ref) < KERNEL_REL_TOL
+    eng = aacgpu.Engine(kind, S, C, tns_mode=aacgpu.TNS_SPEC, output_kind=aacgpu.OUTPUT_I16)
+    i16 = eng.decode_batch(units, coeffs, meta, wl["n_pcm"], tns=tns)
+    eng.close()
+    assert i16.dtype == np.int16
+    want = np.clip(np.rint(f32.astype(np.float64) * 32768.0), -32768, 32767).astype(np.int32)
+    d = np.abs(i16.astype(np.int32) - want)
+    assert d.max() <= 1 and np.count_nonzero(d) <= 1e-2 * d.size
 
 
 @pytest.mark.gpu
