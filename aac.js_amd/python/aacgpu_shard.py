@@ -6,6 +6,7 @@ independent engines.  What this module holds is the part around them that bench.
 share:
 
   stream_shard(total, rank, world)   contiguous block of streams of a rank (BASELINE config 4: streams [32r, 32r+32))
+  time_shard(frames, rank, world)    a single long stream cut in time: each rank recomputes one frame for its tail
   rank_seed(base, rank)              the synthetic generator's seed of a rank (independent data per rank, same shape)
   launch_command / self_launch       `--gpus N` without a launcher: start N ranks under torch.distributed.run as a CHILD
                                      process — before anything in this process has touched the GPU — and relay its output
@@ -29,6 +30,16 @@ def stream_shard(total_streams, rank, world):
     base, extra = divmod(total_streams, world)
     lo = rank * base + min(rank, extra)
     return lo, lo + base + (1 if rank < extra else 0)
+
+
+def time_shard(n_frames, rank, world):
+    """One long stream cut in time: rank r produces frames [lo, hi) of the stream and, when lo > 0, decodes
+    frame lo - 1 in front of them for nothing but its windowed tail — the overlap state frame lo starts from depends on
+    frame lo - 1's spectrum alone (src/filter_bank.js:109-118: `overlap[i] = buf[length + i] * window[...]`), so nothing
+    has to come from the rank that owns the earlier frames.  Returns (lo, hi, warm): decode frames [lo - warm, hi) on a
+    freshly reset stream and drop the PCM of the first `warm` (0 or 1) frames; cost 1 / (hi - lo) extra work."""
+    lo, hi = stream_shard(n_frames, rank, world)
+    return lo, hi, (1 if lo > 0 and hi > lo else 0)
 
 
 def rank_seed(base_seed, rank):

@@ -47,6 +47,22 @@ def algorithmic_bytes_per_channel_frame(kind, chain_frames, pcm="f32"):
     return (4096 if kind == "spec" else 2048 + 240) + (2048 if pcm == "i16" else 4096) + 8192.0 / chain_frames
 
 
+def kernels_of_route(kind, tns, cce, i16):
+    """The launches of one step (launch_run in aac.js_amd/csrc/aacg_engine.hip): the plain run kernel; with TNS records the
+    run kernel that carries the optional stages; with int16 PCM or coupling elements beside TNS, the stages as a launch of
+    their own in front of the f32 run kernel; coupling elements add their own filterbank pass and the coupling kernel."""
+    run = "aacg_imdct_run_%s" % ("quant" if kind == "quant" else "f32")
+    if tns and (i16 or cce):
+        k = "aacg_spectral_ex_%s + aacg_imdct_run_f32%s" % ("quant" if kind == "quant" else "f32", "_i16" if i16 else "")
+    elif tns:
+        k = run + "_ex"
+    else:
+        k = run + ("_i16" if i16 else "")
+    if cce:
+        k += " + %s (coupling elements) + aacg_couple_pcm" % (run if not tns else "aacg_imdct_run_f32")
+    return k
+
+
 def measured_traffic(kind):
     """HBM bytes per launch from the PMC counters (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, separate rocprofv3
     --pmc passes of this same command, tools/prof.sh); bench.py cannot run the profiler on itself, so the
@@ -318,9 +334,7 @@ def main():
                    "collectives": "none on the data path; %s barrier + 8-byte MAX around the timed region" % (dist.get_backend() if dist is not None else "no")},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                     "kernel": "aacg_spectral_ex_quant + aacg_imdct_run_f32 (x2) + aacg_couple_pcm" if cce is not None else
-                               ("aacg_spectral_ex_%s + aacg_imdct_run_f32" % ("quant" if args.input == "quant" else "f32")) if tns is not None
-                               else (eng.kernel_name() if args.input == "quant" else "aacg_imdct_run_f32"),
+                     "kernel": kernels_of_route(args.input, tns is not None, cce is not None, args.output == "i16"),
                      "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": abytes,
                      "host_enqueue_us_per_step": issued[0] / args.steps * 1e6},
         "output_ok": ok, "parity_rms": parity["rms"] if parity else None, "parity": parity,

@@ -27,15 +27,23 @@ def main():
     ap.add_argument("--frames", type=int, default=20)
     ap.add_argument("--decoder", choices=["engine", "oracle"], required=True)
     ap.add_argument("--backend", choices=["gloo", "nccl"], default="gloo")
+    ap.add_argument("--shard", choices=["stream", "time"], default="stream",
+                    help="time: every rank takes a span of frames of EVERY stream (aacgpu_shard.time_shard) instead of whole streams")
     args = ap.parse_args()
     import aacgpu_shard
     import aacgpu_workload
     rank, world, local = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ.get("LOCAL_RANK", "0"))
     dist = aacgpu_shard.init_process_group(args.backend)
     wl = aacgpu_workload.make_batch(n_streams=args.streams, n_frames=args.frames, mix=True, intensity=True, seed=0xAAC00004)
-    lo, hi = aacgpu_shard.stream_shard(args.streams, rank, world)
-    mine = wl["units"][(wl["units"]["stream"] >= lo) & (wl["units"]["stream"] < hi)]
-    per_stream = args.frames * 1024 * wl["C"]
+    per_frame = 1024 * wl["C"]
+    per_stream = args.frames * per_frame
+    t_of = (wl["units"]["pcm_offset"] // per_frame) % args.frames          # frame number inside its stream
+    if args.shard == "time":
+        lo, hi, warm = aacgpu_shard.time_shard(args.frames, rank, world)
+        mine = wl["units"][(t_of >= lo - warm) & (t_of < hi)]
+    else:
+        lo, hi = aacgpu_shard.stream_shard(args.streams, rank, world)
+        mine = wl["units"][(wl["units"]["stream"] >= lo) & (wl["units"]["stream"] < hi)]
     if args.decoder == "engine":
         import torch
         import aacgpu
@@ -56,8 +64,11 @@ def main():
         def body():
             box["pcm"] = orc.load().decode_batch(mine, wl["q"], wl["meta"], wl["n_pcm"], ov)
     t_mine, t_max = aacgpu_shard.timed(dist, sync, body)
-    frames = aacgpu_shard.reduce_sum(dist, len(mine))
-    box["pcm"][lo * per_stream:hi * per_stream].tofile(os.path.join(args.out, "pcm_rank%d.f32" % rank))
+    frames = aacgpu_shard.reduce_sum(dist, len(mine))              # decoded, warm-up frames included
+    if args.shard == "time":                           # frames [lo, hi) of every stream; the warm-up frame's PCM is dropped
+        box["pcm"].reshape(args.streams, args.frames, per_frame)[:, lo:hi].tofile(os.path.join(args.out, "pcm_rank%d.f32" % rank))
+    else:
+        box["pcm"][lo * per_stream:hi * per_stream].tofile(os.path.join(args.out, "pcm_rank%d.f32" % rank))
     if rank == 0:
         with open(os.path.join(args.out, "summary.json"), "w") as f:
             json.dump({"world": world, "frames": frames, "t_max": t_max, "t_rank0": t_mine}, f)

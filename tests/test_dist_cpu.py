@@ -65,6 +65,33 @@ def test_two_ranks_self_launched(tmp_path, oracle):
     assert parts.size == whole.size and np.array_equal(parts.view(np.uint32), whole.view(np.uint32))
 
 
+def test_time_shard_partitions_the_frames():
+    for n, world in ((128, 8), (17, 4), (3, 5), (1, 2)):
+        spans = [aacgpu_shard.time_shard(n, r, world) for r in range(world)]
+        assert [f for lo, hi, _ in spans for f in range(lo, hi)] == list(range(n))
+        assert all(warm == (1 if lo > 0 and hi > lo else 0) for lo, hi, warm in spans)
+
+
+def test_two_ranks_cut_the_streams_in_time(tmp_path, oracle):
+    """SURVEY.md §8e, second partitioning: each rank takes a span of frames of every stream and recomputes the frame in
+    front of its span for the tail; the spans, put together, are bit-identical to one decoder running straight through."""
+    out = str(tmp_path)
+    S, T = 3, 11
+    rc = aacgpu_shard.self_launch(2, os.path.join(ROOT, "tests", "shard_rank.py"),
+                                  ["--out", out, "--streams", str(S), "--frames", str(T), "--decoder", "oracle", "--shard", "time"], timeout=600)
+    assert rc == 0
+    summary = json.load(open(os.path.join(out, "summary.json")))
+    assert summary["world"] == 2 and summary["frames"] == S * (T + 1)           # one warm-up frame per stream on rank 1
+    import aacgpu_workload
+    wl = aacgpu_workload.make_batch(n_streams=S, n_frames=T, mix=True, intensity=True, seed=0xAAC00004)
+    ov = np.zeros((S, 2, 1024), np.float32)
+    whole = oracle.decode_batch(wl["units"], wl["q"], wl["meta"], wl["n_pcm"], ov).reshape(S, T, -1)
+    spans = [aacgpu_shard.time_shard(T, r, 2) for r in range(2)]
+    parts = [np.fromfile(os.path.join(out, "pcm_rank%d.f32" % r), np.float32).reshape(S, hi - lo, -1) for r, (lo, hi, _) in enumerate(spans)]
+    got = np.concatenate(parts, axis=1)
+    assert got.shape == whole.shape and np.array_equal(got.view(np.uint32), whole.view(np.uint32))
+
+
 def test_self_launch_relays_the_exit_code(tmp_path):
     script = tmp_path / "fail.py"
     script.write_text("import os, sys\nsys.exit(3 if os.environ['RANK'] == '1' else 0)\n")

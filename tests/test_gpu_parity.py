@@ -560,6 +560,27 @@ def test_two_ranks_share_a_gpu(tmp_path):
     assert parts.size == whole.size and np.array_equal(parts.view(np.uint32), whole.view(np.uint32))
 
 
+def test_two_ranks_cut_the_streams_in_time(tmp_path):
+    """The other partitioning of SURVEY.md §8e with the product in it: each rank's engine decodes a span of frames of every
+    stream plus the one frame in front of it (for its tail only); the spans together == one engine running straight through."""
+    import os
+    import aacgpu_shard
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path)
+    S, T = 4, 37
+    rc = aacgpu_shard.self_launch(2, os.path.join(root, "tests", "shard_rank.py"),
+                                  ["--out", out, "--streams", str(S), "--frames", str(T), "--decoder", "engine", "--shard", "time"], timeout=900)
+    assert rc == 0
+    wl = aacgpu_workload.make_batch(n_streams=S, n_frames=T, mix=True, intensity=True, seed=0xAAC00004)
+    eng = aacgpu.Engine(aacgpu.INPUT_QUANT_I16, max_streams=S, max_channels=2)
+    whole = eng.decode_batch(wl["units"], wl["q"], wl["meta"], wl["n_pcm"]).reshape(S, T, -1)
+    eng.close()
+    spans = [aacgpu_shard.time_shard(T, r, 2) for r in range(2)]
+    parts = [np.fromfile(os.path.join(out, "pcm_rank%d.f32" % r), np.float32).reshape(S, hi - lo, -1) for r, (lo, hi, _) in enumerate(spans)]
+    got = np.concatenate(parts, axis=1)
+    assert got.shape == whole.shape and np.array_equal(got.view(np.uint32), whole.view(np.uint32))
+
+
 def test_bench_launches_its_own_ranks():
     """`python bench.py --gpus 2` without a launcher starts two ranks itself (before touching the GPU) and rank 0 prints the
     JSON line with n_gpus 2.  The box has one GPU, so the ranks share it (--share-gpu, gloo barrier): this checks the launch
