@@ -92,7 +92,20 @@ def init_process_group(backend, rank=None, world=None, device=None):
         kw.update(rank=rank, world_size=world)
     if backend == "nccl" and device is not None:
         kw["device_id"] = device
-    dist.init_process_group(backend, **kw)
+    try:
+        dist.init_process_group(backend, **kw)
+        if backend == "nccl":
+            dist.barrier()                            # the communicator works, or we learn it here and not in the timed region
+    except Exception as exc:                          # noqa: BLE001 - whatever RCCL raises
+        if backend != "nccl":
+            raise
+        # RCCL unavailable between these ranks (IPC / topology): the harness needs a barrier and 8-byte reductions, which
+        # gloo carries just as well; the data path has no collective either way.  Every rank sees the same failure.
+        print("aacgpu_shard: RCCL unavailable (%s); the barrier falls back to gloo" % str(exc).splitlines()[0][:200], file=sys.stderr)
+        if dist.is_initialized():
+            dist.destroy_process_group()
+        kw.pop("device_id", None)
+        dist.init_process_group("gloo", **kw)
     return dist
 
 
