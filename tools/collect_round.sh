@@ -22,6 +22,9 @@ b cfg5_cce_spec --workload cfg5 --cce spec --steps 1000 --warmup 100 --no-cpu-ba
 b quant_i16out --output i16 --no-cpu-baseline
 b quant_pipelines2 --pipelines 2 --no-cpu-baseline
 b quant_2ranks_shared_gpu --gpus 2 --dist-backend gloo --share-gpu --steps 2000 --warmup 200
+# the driver's launch line with one rank: RCCL carries the barrier and the 8-byte reductions
+python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29541 bench.py --gpus 1 --steps 2000 --warmup 200 --no-cpu-baseline \
+  > $OUT/bench_quant_torchrun_rccl_1rank.json 2> $OUT/bench_quant_torchrun_rccl_1rank.err || echo "bench torchrun failed" >> $OUT/failures.txt
 bash tools/prof.sh $TAG/prof_quant > $OUT/prof_quant.log 2>&1
 bash tools/prof.sh $TAG/prof_spec --input spec > $OUT/prof_spec.log 2>&1
 bash tools/prof.sh $TAG/prof_cfg5 --workload cfg5 > $OUT/prof_cfg5.log 2>&1
