@@ -39,7 +39,7 @@ int aacg_i16_set_lds_limits(void);
 void aacg_i16_launch(bool quant, bool dd, dim3 grid, dim3 block, hipStream_t s, const aacg_kparams& P);
 /* aacg_engine_exrun.hip: the run kernels with the optional stages inside (one launch for TNS / PNS batches) */
 int aacg_exrun_set_lds_limits(void);
-void aacg_exrun_launch(bool quant, bool dd, dim3 grid, dim3 block, hipStream_t s, const aacg_kparams& P);
+void aacg_exrun_launch(bool quant, dim3 grid, dim3 block, hipStream_t s, const aacg_kparams& P);
 int aacg_spectral_ex_set_lds_limits(void);
 void aacg_spectral_ex_launch(bool quant, int n_units, hipStream_t s, const aacg_kparams& P);
 /* aacg_engine_couple.hip: AACG_CCE_SPEC */
@@ -223,12 +223,12 @@ int launch_run(aacg_engine* e, const aacg_dev_unit* d_units, const aacg_run* d_r
         couple(AACG_CCE_AFTER_TNS);
         P.spec_out = trace_or_null; P.coeffs = d_spec; P.meta = nullptr; P.tns = nullptr;
         quant = false;
-    } else if ((h.any_tns || (quant && h.any_pns)) && !i16 && !h.any_cce) {
+    } else if ((h.any_tns || (quant && h.any_pns)) && !i16 && !h.any_cce && !h.needs_scratch) {
         /* optional stages (noise bands, TNS filters) inside the run kernel: one launch */
         P.pns = e->d_pns;
         ex = true;
     } else if (h.any_tns || (quant && h.any_pns)) {
-        /* int16 PCM or coupling elements: the optional stages first, as a launch of their own that leaves f32 spectra,
+        /* int16 PCM, coupling elements or double-duty runs: the optional stages first, as a launch of their own that leaves f32 spectra,
          * which the f32 run kernel takes from there */
         float* trace_or_null = P.spec_out;
         P.spec_out = d_spec; P.pns = e->d_pns;
@@ -238,7 +238,7 @@ int launch_run(aacg_engine* e, const aacg_dev_unit* d_units, const aacg_run* d_r
     }
     if (!h.runs.empty()) {
         if (ex) {
-            aacg_exrun_launch(quant, h.needs_scratch, grid, block, s, P);
+            aacg_exrun_launch(quant, grid, block, s, P);
         } else if (i16) {
             aacg_i16_launch(quant, h.needs_scratch, grid, block, s, P);
         } else if (h.needs_scratch) {

@@ -1,8 +1,10 @@
 /*
  * aacg_engine_exrun.hip — the run kernels with the optional stages inside (imdct_run_body<..., EX = true>): noise bands
  * (AACG_PNS_SPEC) and TNS filters (AACG_TNS_SPEC) applied between dequantisation and IMDCT, in the wave's own slot.
- * Batches that carry TNS records or noise bands, produce f32 PCM and have no coupling elements run here in ONE launch;
- * everything else with optional stages takes the staged route (aacg_engine_spectral.hip).  A code object of its own,
+ * Batches that carry TNS records or noise bands, produce f32 PCM, have no coupling elements and no chain longer than a
+ * run's double-duty variant is needed for (with the filters in both copies of its front end that variant spilled 800
+ * bytes per lane) run here in ONE launch; everything else with optional stages takes the staged route
+ * (aacg_engine_spectral.hip).  A code object of its own,
  * so that the plain kernels of aacg_engine.hip never move.  MI355X (gfx950) only.
  */
 #include <hip/hip_runtime.h>
@@ -15,27 +17,17 @@ void aacg_imdct_run_quant_ex(const aacg_kparams P) { imdct_run_body<AACG_INPUT_Q
 extern "C" __global__ __launch_bounds__(AACG_WG_THREADS)
 void aacg_imdct_run_f32_ex(const aacg_kparams P) { imdct_run_body<AACG_INPUT_SPEC_F32, AACG_OUTPUT_F32, false, true>(P); }
 
-extern "C" __global__ __launch_bounds__(AACG_WG_THREADS)
-void aacg_imdct_run_quant_ex_dd(const aacg_kparams P) { imdct_run_body<AACG_INPUT_QUANT_I16, AACG_OUTPUT_F32, true, true>(P); }
-
-extern "C" __global__ __launch_bounds__(AACG_WG_THREADS)
-void aacg_imdct_run_f32_ex_dd(const aacg_kparams P) { imdct_run_body<AACG_INPUT_SPEC_F32, AACG_OUTPUT_F32, true, true>(P); }
-
 static_assert(AACG_LDS_BYTES_QUANT_EX <= 160 * 1024, "the TNS exchange areas must fit beside the slots");
 
 int aacg_exrun_set_lds_limits(void)
 {
     hipError_t rc = hipFuncSetAttribute((const void*)aacg_imdct_run_quant_ex, hipFuncAttributeMaxDynamicSharedMemorySize, AACG_LDS_BYTES_QUANT_EX);
     if (rc == hipSuccess) rc = hipFuncSetAttribute((const void*)aacg_imdct_run_f32_ex, hipFuncAttributeMaxDynamicSharedMemorySize, AACG_LDS_BYTES_F32_EX);
-    if (rc == hipSuccess) rc = hipFuncSetAttribute((const void*)aacg_imdct_run_quant_ex_dd, hipFuncAttributeMaxDynamicSharedMemorySize, AACG_LDS_BYTES_QUANT_EX);
-    if (rc == hipSuccess) rc = hipFuncSetAttribute((const void*)aacg_imdct_run_f32_ex_dd, hipFuncAttributeMaxDynamicSharedMemorySize, AACG_LDS_BYTES_F32_EX);
     return rc == hipSuccess ? 0 : -1;
 }
 
-void aacg_exrun_launch(bool quant, bool dd, dim3 grid, dim3 block, hipStream_t s, const aacg_kparams& P)
+void aacg_exrun_launch(bool quant, dim3 grid, dim3 block, hipStream_t s, const aacg_kparams& P)
 {
-    if (quant) { if (dd) hipLaunchKernelGGL(aacg_imdct_run_quant_ex_dd, grid, block, AACG_LDS_BYTES_QUANT_EX, s, P);
-                 else    hipLaunchKernelGGL(aacg_imdct_run_quant_ex, grid, block, AACG_LDS_BYTES_QUANT_EX, s, P); }
-    else       { if (dd) hipLaunchKernelGGL(aacg_imdct_run_f32_ex_dd, grid, block, AACG_LDS_BYTES_F32_EX, s, P);
-                 else    hipLaunchKernelGGL(aacg_imdct_run_f32_ex, grid, block, AACG_LDS_BYTES_F32_EX, s, P); }
+    if (quant) hipLaunchKernelGGL(aacg_imdct_run_quant_ex, grid, block, AACG_LDS_BYTES_QUANT_EX, s, P);
+    else       hipLaunchKernelGGL(aacg_imdct_run_f32_ex, grid, block, AACG_LDS_BYTES_F32_EX, s, P);
 }

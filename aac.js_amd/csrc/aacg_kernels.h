@@ -1696,11 +1696,11 @@ DP_DEVICE void imdct_run_body(const aacg_kparams& P)
                     const dpf4 a = *(const dpf4*)(slot + 8 * lane + 512 * i), b = *(const dpf4*)(slot + 8 * lane + 512 * i + 4);
                     xl[8 * i] = a.x; xl[8 * i + 1] = a.y; xl[8 * i + 2] = a.z; xl[8 * i + 3] = a.w;
                     xl[8 * i + 4] = b.x; xl[8 * i + 5] = b.y; xl[8 * i + 6] = b.z; xl[8 * i + 7] = b.w;
-                    if (n_ch == 2) {
-                        const dpf4 c = *(const dpf4*)(slot + 1024 + 8 * lane + 512 * i), d = *(const dpf4*)(slot + 1024 + 8 * lane + 512 * i + 4);
-                        xr[8 * i] = c.x; xr[8 * i + 1] = c.y; xr[8 * i + 2] = c.z; xr[8 * i + 3] = c.w;
-                        xr[8 * i + 4] = d.x; xr[8 * i + 5] = d.y; xr[8 * i + 6] = d.z; xr[8 * i + 7] = d.w;
-                    }
+                    /* unconditionally (a single channel reads what nobody uses): with the read under n_ch == 2 the old xr
+                     * stays live across the filters and goes to scratch (18 MB per 4096-frame batch, written and read) */
+                    const dpf4 c = *(const dpf4*)(slot + 1024 + 8 * lane + 512 * i), d = *(const dpf4*)(slot + 1024 + 8 * lane + 512 * i + 4);
+                    xr[8 * i] = c.x; xr[8 * i + 1] = c.y; xr[8 * i + 2] = c.z; xr[8 * i + 3] = c.w;
+                    xr[8 * i + 4] = d.x; xr[8 * i + 5] = d.y; xr[8 * i + 6] = d.z; xr[8 * i + 7] = d.w;
                 }
                 dp_wave_sync();
             }
@@ -1793,7 +1793,7 @@ DP_DEVICE void imdct_run_body(const aacg_kparams& P)
  * biased so that the usual offsets work), then per wave a 2048-float slot (band records and PNS scratch first; for TNS
  * both channels' spectra) and the TNS exchange area. */
 #define AACG_SPX_TAB_FLOATS  (AACG_TAB_QUANT_FLOATS - AACG_TAB_F32_FLOATS)
-#define AACG_SPX_TNS_ROUND   8
+#define AACG_SPX_TNS_ROUND   4      /* rounds of 8 cost 12 bytes per lane of scratch */
 #define AACG_SPX_XCH_FLOATS  AACG_TNS_XCH_FLOATS(AACG_SPX_TNS_ROUND)
 #define AACG_SPX_WAVE_FLOATS (AACG_SLOT_FLOATS + AACG_SPX_XCH_FLOATS)
 template <int KIND>
@@ -1844,11 +1844,10 @@ DP_DEVICE void spectral_ex_body(const aacg_kparams& P, int n_units)
             const dpf4 a = *(const dpf4*)(slot + 8 * lane + 512 * i), b = *(const dpf4*)(slot + 8 * lane + 512 * i + 4);
             xl[8 * i] = a.x; xl[8 * i + 1] = a.y; xl[8 * i + 2] = a.z; xl[8 * i + 3] = a.w;
             xl[8 * i + 4] = b.x; xl[8 * i + 5] = b.y; xl[8 * i + 6] = b.z; xl[8 * i + 7] = b.w;
-            if (n_ch == 2) {
-                const dpf4 c = *(const dpf4*)(slot + 1024 + 8 * lane + 512 * i), d = *(const dpf4*)(slot + 1024 + 8 * lane + 512 * i + 4);
-                xr[8 * i] = c.x; xr[8 * i + 1] = c.y; xr[8 * i + 2] = c.z; xr[8 * i + 3] = c.w;
-                xr[8 * i + 4] = d.x; xr[8 * i + 5] = d.y; xr[8 * i + 6] = d.z; xr[8 * i + 7] = d.w;
-            }
+            /* unconditionally: see the same read in imdct_run_body */
+            const dpf4 c = *(const dpf4*)(slot + 1024 + 8 * lane + 512 * i), d = *(const dpf4*)(slot + 1024 + 8 * lane + 512 * i + 4);
+            xr[8 * i] = c.x; xr[8 * i + 1] = c.y; xr[8 * i + 2] = c.z; xr[8 * i + 3] = c.w;
+            xr[8 * i + 4] = d.x; xr[8 * i + 5] = d.y; xr[8 * i + 6] = d.z; xr[8 * i + 7] = d.w;
         }
     }
     float* out = P.spec_out + (size_t)u.coef_offset * 1024u;

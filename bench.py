@@ -140,6 +140,8 @@ def parity_check(eng, plan, step0, bufs, host_in0, base, units, tns, n_streams, 
         got = got.astype(np.float32) / np.float32(32768.0)
     ov = np.zeros((n_streams, n_chan + (1 if cce is not None else 0), 1024), np.float32)
     ref = orc.load().decode_batch(units, host_in0, base["meta"] if host_in0.dtype == np.int16 else None, base["n_pcm"], ov, tns=tns, cce=cce)
+    if d_out.dtype == torch.int16:                         # int16 PCM saturates (TNS SPEC filters have gain): so does the yardstick
+        ref = np.clip(ref, -1.0, 32767.0 / 32768.0)
     d = got.astype(np.float64) - ref
     err, sig = float(np.sqrt(np.mean(d * d))), float(np.sqrt(np.mean(ref.astype(np.float64) ** 2)))
     return err, err / sig if sig > 0 else float("inf"), bool(np.isfinite(got).all())

@@ -39,8 +39,8 @@ void* lane_main(void* p)
     else if (a->out_kind == AACG_OUTPUT_I16 && a->kind == 1) { if (dd) imdct_run_body<AACG_INPUT_QUANT_I16, AACG_OUTPUT_I16, true>(*a->P); else imdct_run_body<AACG_INPUT_QUANT_I16, AACG_OUTPUT_I16>(*a->P); }
     else if (a->kind == 0) { if (dd) imdct_run_body<AACG_INPUT_SPEC_F32, AACG_OUTPUT_F32, true>(*a->P); else imdct_run_body<AACG_INPUT_SPEC_F32>(*a->P); }
     else if (a->kind == 1) { if (dd) imdct_run_body<AACG_INPUT_QUANT_I16, AACG_OUTPUT_F32, true>(*a->P); else imdct_run_body<AACG_INPUT_QUANT_I16>(*a->P); }
-    else if (a->kind == 5) { if (dd) imdct_run_body<AACG_INPUT_SPEC_F32, AACG_OUTPUT_F32, true, true>(*a->P); else imdct_run_body<AACG_INPUT_SPEC_F32, AACG_OUTPUT_F32, false, true>(*a->P); }
-    else if (a->kind == 6) { if (dd) imdct_run_body<AACG_INPUT_QUANT_I16, AACG_OUTPUT_F32, true, true>(*a->P); else imdct_run_body<AACG_INPUT_QUANT_I16, AACG_OUTPUT_F32, false, true>(*a->P); }
+    else if (a->kind == 5) imdct_run_body<AACG_INPUT_SPEC_F32, AACG_OUTPUT_F32, false, true>(*a->P);
+    else if (a->kind == 6) imdct_run_body<AACG_INPUT_QUANT_I16, AACG_OUTPUT_F32, false, true>(*a->P);
     else if (a->kind == 3) spectral_ex_body<AACG_INPUT_QUANT_I16>(*a->P, a->n_units);
     else if (a->kind == 4) spectral_ex_body<AACG_INPUT_SPEC_F32>(*a->P, a->n_units);
     else                   spectral_body(*a->P, a->n_units);
@@ -222,7 +222,7 @@ int emu_decode_cce(int input_kind, int sample_index, int max_streams, int max_ch
         couple(AACG_CCE_AFTER_TNS);
         P.coeffs = spec.data(); P.meta = nullptr; P.tns = nullptr;
         input_kind = AACG_INPUT_SPEC_F32;
-    } else if ((ph.any_pns || ph.any_tns) && g_out_kind == AACG_OUTPUT_F32 && !ph.any_cce && !g_staged) {
+    } else if ((ph.any_pns || ph.any_tns) && g_out_kind == AACG_OUTPUT_F32 && !ph.any_cce && !ph.needs_scratch && !g_staged) {
         aacg_build_pns_tables(sample_index, &pns_tab);  /* the engine's one-launch route: optional stages inside the run kernel */
         P.pns = &pns_tab;
         ex = true;
