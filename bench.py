@@ -47,17 +47,19 @@ def algorithmic_bytes_per_channel_frame(kind, chain_frames, pcm="f32"):
     return (4096 if kind == "spec" else 2048 + 240) + (2048 if pcm == "i16" else 4096) + 8192.0 / chain_frames
 
 
-def kernels_of_route(kind, tns, cce, i16):
-    """The launches of one step (launch_run in aac.js_amd/csrc/aacg_engine.hip): the plain run kernel; with TNS records the
-    run kernel that carries the optional stages; with int16 PCM or coupling elements beside TNS, the stages as a launch of
-    their own in front of the f32 run kernel; coupling elements add their own filterbank pass and the coupling kernel."""
+def kernels_of_route(kind, tns, cce, i16, long_chains=False):
+    """The launches of one step (launch_run in aac.js_amd/csrc/aacg_engine.hip): the plain run kernel (its double-duty
+    build for chains longer than a run); with TNS records the run kernel that carries the optional stages; with int16 PCM,
+    coupling elements or long chains beside TNS, the stages as a launch of their own in front of the f32 run kernel;
+    coupling elements add their own filterbank pass and the coupling kernel."""
+    dd = "_dd" if long_chains else ""
     run = "aacg_imdct_run_%s" % ("quant" if kind == "quant" else "f32")
-    if tns and (i16 or cce):
-        k = "aacg_spectral_ex_%s + aacg_imdct_run_f32%s" % ("quant" if kind == "quant" else "f32", "_i16" if i16 else "")
+    if tns and (i16 or cce or long_chains):
+        k = "aacg_spectral_ex_%s + aacg_imdct_run_f32%s%s" % ("quant" if kind == "quant" else "f32", dd, "_i16" if i16 else "")
     elif tns:
         k = run + "_ex"
     else:
-        k = run + ("_i16" if i16 else "")
+        k = run + dd + ("_i16" if i16 else "")
     if cce:
         k += " + %s (coupling elements) + aacg_couple_pcm" % (run if not tns else "aacg_imdct_run_f32")
     return k
@@ -336,7 +338,7 @@ def main():
                    "collectives": "none on the data path; %s barrier + 8-byte MAX around the timed region" % (dist.get_backend() if dist is not None else "no")},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                     "kernel": kernels_of_route(args.input, tns is not None, cce is not None, args.output == "i16"),
+                     "kernel": kernels_of_route(args.input, tns is not None, cce is not None, args.output == "i16", n_frames > 16),
                      "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": abytes,
                      "host_enqueue_us_per_step": issued[0] / args.steps * 1e6},
         "output_ok": ok, "parity_rms": parity["rms"] if parity else None, "parity": parity,
