@@ -60,6 +60,21 @@ function play(name, pieces, options) {
     assert.strictEqual(typeof plugin.Demuxer.readHeader, 'function');
 }
 
+if (mode === 'cpu') {
+    /* the package's main: require('av'); require('aac.js_amd') registers as a side effect and exports the decoder class, like
+     * the reference's package.json main (src/decoder.js) — `av` resolved to the stand-in through NODE_PATH */
+    const os = require('os'), cp = require('child_process');
+    const dir = fs.mkdtempSync(path.join(os.tmpdir(), 'av-stub-'));
+    fs.writeFileSync(path.join(dir, 'av.js'), 'module.exports = require(' + JSON.stringify(path.join(__dirname, 'av_stub.js')) + ');\n');
+    const code = "const AV = require('av'); const D = require(" + JSON.stringify(path.join(root, 'aac.js_amd')) + ");" +
+                 "if (AV.Decoder.find('mp4a') !== D || AV.Decoder.find('aac ') !== D || typeof D.Demuxer.readHeader !== 'function') process.exit(3);" +
+                 "console.log('main ok ' + JSON.stringify(Object.keys(D.prototype).sort()));";
+    const r = cp.spawnSync(process.execPath, ['-e', code], { env: Object.assign({}, process.env, { NODE_PATH: dir, AACG_OPTIONS: '{"lookahead":4}' }), encoding: 'utf8' });
+    assert.strictEqual(r.status, 0, r.stdout + r.stderr);
+    assert.ok(/main ok .*init.*readChunk.*setCookie/.test(r.stdout), r.stdout);
+    fs.unlinkSync(path.join(dir, 'av.js')); fs.rmdirSync(dir);
+}
+
 for (const c of manifest) {
     if (mode === 'cpu') {
         /* a recording engine: what reaches aacg_decode_batch, frame by frame */
