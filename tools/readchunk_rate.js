@@ -1,0 +1,58 @@
+#!/usr/bin/env node
+/* Plugin-level rate: frames per second out of readChunk(), bytes in -> PCM out, on one JavaScript thread.
+ *   node tools/readchunk_rate.js [repeats]
+ * A long ADTS stream (the committed tests/golden/streams/stereo48.aac repeated) through
+ *   - GpuAACDecoder with the JavaScript front end (parse on the CPU, transform on the GPU),
+ *   - GpuAACDecoder with the device front end (parse and transform on the GPU),
+ *   - the reference's own AACDecoder.readChunk() when the reference checkout is present (build container only; CPU).
+ * The GPU lines need the built engine and a GPU; without one they are reported as null. */
+'use strict';
+const fs = require('fs'), path = require('path');
+const root = path.join(__dirname, '..');
+const host = require(path.join(root, 'aac.js_amd', 'js'));
+const repeats = parseInt(process.argv[2] || '400', 10);
+const one = new Uint8Array(fs.readFileSync(path.join(root, 'tests', 'golden', 'streams', 'stereo48.aac')));
+const perFile = host.adts.frames(one).length;
+const bytes = new Uint8Array(one.length * repeats);
+for (let i = 0; i < repeats; i++) bytes.set(one, i * one.length);
+const out = { stream: 'stereo48.aac x ' + repeats, frames: perFile * repeats, bytes: bytes.length };
+
+function ours(gpuParse) {
+    try {
+        const fe = gpuParse ? new host.GpuFrontEnd({ batch: 4096 }) : new host.FrontEnd();
+        const dec = new host.GpuAACDecoder({ frontend: fe, lookahead: 4096 });
+        dec.init();
+        const demux = new host.adts.AdtsDemuxer(function (event, payload) {
+            if (event === 'format') Object.assign(dec.format, payload);
+            else if (event === 'cookie') dec.setCookie(payload);
+            else if (event === 'data') dec.feed(payload);
+        });
+        const t0 = process.hrtime.bigint();
+        demux.push(bytes);
+        let n = 0, sum = 0;
+        for (let pcm; (pcm = dec.readChunk()); n++) sum += pcm[17];
+        const s = Number(process.hrtime.bigint() - t0) / 1e9;
+        return { frames_per_s: Math.round(n / s), frames: n, seconds: +s.toFixed(3), checksum: sum };
+    } catch (e) { return { error: String(e.message || e).slice(0, 160) }; }
+}
+out.gpu_transform_js_parse = ours(false);
+out.gpu_transform_gpu_parse = ours(true);
+
+const REF = '/root/reference/src/';
+if (fs.existsSync(REF + 'decoder.js')) {
+    process.env.NODE_PATH = path.join(root, 'tests', 'golden', 'gen', 'stubs');
+    require('module').Module._initPaths();
+    const { BitStream } = require(path.join(root, 'aac.js_amd', 'js', 'bits.js'));
+    const AACDecoder = require(REF + 'decoder.js');
+    const FilterBank = require(REF + 'filter_bank.js');
+    const ref = new AACDecoder(); ref.format = {};
+    ref.config = { profile: 2, sampleIndex: 3, sampleRate: 48000, chanConfig: 2, frameLength: 1024 };   // what setCookie leaves (decoder.js:53-113)
+    ref.filter_bank = new FilterBank(false, 2);                                                         // decoder.js:112
+    const frames = host.adts.frames(one).map(function (f) { return one.subarray(f.offset + (f.headerLength || 7), f.offset + f.length); });
+    const t0 = process.hrtime.bigint();
+    let n = 0;
+    const budget = 5e9;
+    while (Number(process.hrtime.bigint() - t0) < budget) { for (const f of frames) { ref.bitstream = new BitStream(f); ref.readChunk(); } n += frames.length; }
+    out.reference_readChunk = { frames_per_s: Math.round(n / (Number(process.hrtime.bigint() - t0) / 1e9)), frames: n };
+}
+console.log(JSON.stringify(out, null, 1));
