@@ -178,6 +178,15 @@ bool is_pinned(const void* p)
     return a.type == hipMemoryTypeHost;
 }
 
+/* does launch_run stage f32 spectra in HBM for this batch (the optional stages as a launch of their own, or coupling
+ * in the spectral domain)?  Batches whose optional stages run inside the run kernel need no such buffer. */
+bool needs_spec_buffer(const aacg_engine* e, const aacg_plan_host& h)
+{
+    const bool quant = e->cfg.input_kind == AACG_INPUT_QUANT_I16, i16 = e->cfg.output_kind == AACG_OUTPUT_I16;
+    const bool stages = h.any_tns || (quant && h.any_pns);
+    return h.any_cce_dependent || (stages && (i16 || h.any_cce || h.needs_scratch));
+}
+
 /* enqueue the run kernel for a planned batch (device pointers) */
 int launch_run(aacg_engine* e, const aacg_dev_unit* d_units, const aacg_run* d_runs, const aacg_dev_tns* d_tns,
                float* d_scratch, float* d_spec, const cce_bufs& cb, const aacg_plan_host& h, const void* d_coeffs, const aacg_band_meta* d_meta,
@@ -456,7 +465,7 @@ int aacg_plan_create_ex(aacg_engine* e, const aacg_unit_desc* units, uint32_t n_
         return AACG_ERR_UNSUPPORTED;
     }
     const size_t ub = sizeof(aacg_dev_unit) * n_units, rb = sizeof(aacg_run) * p->h.runs.size();
-    const size_t xb = (p->h.any_pns || p->h.any_tns || p->h.any_cce_dependent) ? (size_t)p->h.coef_blocks * 1024u * sizeof(float) : 0;
+    const size_t xb = needs_spec_buffer(e, p->h) ? (size_t)p->h.coef_blocks * 1024u * sizeof(float) : 0;
     const size_t tb = sizeof(aacg_dev_tns) * p->h.tns.size();
     const size_t sb = p->h.needs_scratch ? p->h.runs.size() * AACG_SLOT_FLOATS * sizeof(float) : 0;
     const size_t cb[4] = {sizeof(aacg_run) * p->h.cce_runs.size(), sizeof(aacg_couple_job) * p->h.couple_jobs.size(),
@@ -689,7 +698,7 @@ int aacg_submit_ex(aacg_engine* e, const aacg_batch* batch, uint64_t* ticket)
     const size_t ub = sizeof(aacg_dev_unit) * h.units.size(), rb = sizeof(aacg_run) * h.runs.size();
     const size_t tb = sizeof(aacg_dev_tns) * h.tns.size();
     const size_t sb = h.needs_scratch ? h.runs.size() * AACG_SLOT_FLOATS * sizeof(float) : 0;
-    const size_t xb = (h.any_pns || h.any_tns || h.any_cce_dependent) ? (size_t)n_coef_blocks * 1024u * sizeof(float) : 0;
+    const size_t xb = needs_spec_buffer(e, h) ? (size_t)n_coef_blocks * 1024u * sizeof(float) : 0;
     const size_t ccb[4] = {sizeof(aacg_run) * h.cce_runs.size(), sizeof(aacg_couple_job) * h.couple_jobs.size(),
                            sizeof(float) * h.gains.size(), (size_t)h.side_blocks * 4096u};
     const void* const cce_src[4] = {h.cce_runs.data(), h.couple_jobs.data(), h.gains.data(), nullptr};
