@@ -326,7 +326,7 @@ DP_DEVICE void long_channels(const float* tab, const chan_par (&cp)[NC], bool wa
         else                                            long_planar_window<AACG_LONG_STOP_SEQUENCE>(tab, cp[c], want_head, area[c], R[c], I[c], m, hx[c], hy[c]);
     }
 }
-template <int NC>
+template <int NC, bool VM = false>                     /* VM: the l ^ 7 exchange on the VALU (dp_mirror8_valu) */
 DP_DEVICE void short_channels(const float* tab, const chan_par (&cp)[NC],
                               float* const (&area)[NC], float (&hx)[NC][8], float (&hy)[NC][8])
 {
@@ -385,7 +385,7 @@ DP_DEVICE void short_channels(const float* tab, const chan_par (&cp)[NC],
         float m[16];
 #pragma unroll
         for (int r = 0; r < 8; r++) { m[r] = R[c][r]; m[8 + r] = I[c][r]; }
-        dp_shfl(m, l ^ 7);
+        if (VM) dp_mirror8_valu(m); else dp_shfl(m, l ^ 7);
 
         /* window each block: head with W[i] (block 0: previous shape), tail with W[127-i] */
         const float* ws = tab + AACG_TAB_OFF_WIN_SHORT + 128 * cp[c].shape;
@@ -505,13 +505,14 @@ DP_DEVICE dpv2 lds_pair(const float* base, int pair_index)
 }
 
 /* mirror-lane exchange of 8 (L,R) complex values: m*[r] <- lane `src`'s value */
+template <bool GROUP8_VALU = false>                     /* GROUP8_VALU: src is l ^ 7, taken without the LDS pipe (dp_mirror8_valu) */
 DP_DEVICE void shfl_pairs(const dpv2 (&R)[8], const dpv2 (&I)[8], int src, dpv2 (&mR)[8], dpv2 (&mI)[8])
 {
     float a[16], b[16];
 #pragma unroll
     for (int r = 0; r < 8; r++) { a[r] = R[r][0]; a[8 + r] = R[r][1]; b[r] = I[r][0]; b[8 + r] = I[r][1]; }
-    dp_shfl(a, src);
-    dp_shfl(b, src);
+    if (GROUP8_VALU) { dp_mirror8_valu(a); dp_mirror8_valu(b); }
+    else             { dp_shfl(a, src); dp_shfl(b, src); }
 #pragma unroll
     for (int r = 0; r < 8; r++) { mR[r] = v2(a[r], a[8 + r]); mI[r] = v2(b[r], b[8 + r]); }
 }
@@ -628,6 +629,7 @@ DP_DEVICE void long_pair(const float* tab, const chan_par& cp, bool want_head, f
 }
 
 /* EIGHT_SHORT, both channels. */
+template <bool VM>
 DP_DEVICE void short_pair(const float* tab, const chan_par& cp, float* slot, dpv2 (&hx)[8], dpv2 (&hy)[8])
 {
     const int l = dp_lane(), w = l >> 3, g = l & 7;
@@ -662,7 +664,7 @@ DP_DEVICE void short_pair(const float* tab, const chan_par& cp, float* slot, dpv
         R[r] = z[r].re * v2s(sc.re) - z[r].im * v2s(sc.im);
         I[r] = z[r].im * v2s(sc.re) + z[r].re * v2s(sc.im);
     }
-    shfl_pairs(R, I, l ^ 7, mR, mI);
+    shfl_pairs<VM>(R, I, l ^ 7, mR, mI);
 
     const float* ws = tab + AACG_TAB_OFF_WIN_SHORT + 128 * cp.shape;
     const float* wh = (w == 0) ? tab + AACG_TAB_OFF_WIN_SHORT + 128 * cp.shape_prev : ws;
@@ -1287,6 +1289,9 @@ DP_DEVICE void tns_unit(float* slot, float* xch, const aacg_dev_tns* rec0, const
 
 /* IMDCT + window of a unit whose spectra are staged in its slot.  CPE tails always end up
  * interleaved (pair index n = (tailL[n], tailR[n])); a single channel's tail is planar. */
+/* VM: the mirror exchanges of the short windows on the VALU: worth it where the LDS pipe is the busier one — the int16 seam
+ * (all-short batch 14.67 -> 13.70 us, config 3 13.94 -> 13.56); the f32 seam lost 0.07 us with it and keeps ds_bpermute */
+template <bool VM>
 DP_DEVICE void filter_unit(const float* tab, const unit_view& u, int n_ch, bool pair_path, bool want_head, float* slot,
                            float (&hx0)[8], float (&hy0)[8], float (&hx1)[8], float (&hy1)[8])
 {
@@ -1296,7 +1301,7 @@ DP_DEVICE void filter_unit(const float* tab, const unit_view& u, int n_ch, bool 
     const bool s0 = p0.seq == AACG_EIGHT_SHORT_SEQUENCE, s1 = p1.seq == AACG_EIGHT_SHORT_SEQUENCE;
     if (pair_path) {
         dpv2 hx[8], hy[8];
-        if (s0) short_pair(tab, p0, slot, hx, hy);
+        if (s0) short_pair<VM>(tab, p0, slot, hx, hy);
         else    long_pair(tab, p0, want_head, slot, hx, hy);
 #pragma unroll
         for (int m = 0; m < 8; m++) { hx0[m] = hx[m][0]; hx1[m] = hx[m][1]; hy0[m] = hy[m][0]; hy1[m] = hy[m][1]; }
@@ -1306,7 +1311,7 @@ DP_DEVICE void filter_unit(const float* tab, const unit_view& u, int n_ch, bool 
         const chan_par cp[1] = {p0};
         float* const area[1] = {slot};
         float hx[1][8], hy[1][8];
-        if (s0) short_channels<1>(tab, cp, area, hx, hy);
+        if (s0) short_channels<1, VM>(tab, cp, area, hx, hy);
         else    long_channels<1>(tab, cp, want_head, area, hx, hy);
 #pragma unroll
         for (int m = 0; m < 8; m++) { hx0[m] = hx[0][m]; hy0[m] = hy[0][m]; }
@@ -1315,7 +1320,7 @@ DP_DEVICE void filter_unit(const float* tab, const unit_view& u, int n_ch, bool 
         const chan_par cp[1] = {p1};
         float* const area[1] = {slot + 1024};
         float hx[1][8], hy[1][8];
-        if (s1) short_channels<1>(tab, cp, area, hx, hy);
+        if (s1) short_channels<1, VM>(tab, cp, area, hx, hy);
         else    long_channels<1>(tab, cp, want_head, area, hx, hy);
 #pragma unroll
         for (int m = 0; m < 8; m++) { hx1[m] = hx[0][m]; hy1[m] = hy[0][m]; }
@@ -1735,7 +1740,7 @@ DP_DEVICE void imdct_run_body(const aacg_kparams& P)
         }
         dp_wave_sync();
         if (trace && lane == 0) trace[2] = dp_clock();     /* spectrum arrived and staged */
-        filter_unit(tab, u, n_ch, pair_path, want_head, slot, hx0, hy0, hx1, hy1);
+        filter_unit<KIND == AACG_INPUT_QUANT_I16>(tab, u, n_ch, pair_path, want_head, slot, hx0, hy0, hx1, hy1);
     };
 
     if (ui >= 0) front(!is_pred_wave && n_pass == 1);

@@ -76,6 +76,24 @@ DP_DEVICE void dp_shfl(float (&v)[N], int src)
     for (int i = 0; i < N; i++) v[i] = __shfl(v[i], src, 64);
 }
 
+/* v[i] <- lane (lane ^ 7)'s v[i] without the LDS pipe: DPP row_half_mirror reverses every group of eight lanes.  Inline
+ * assembly, eight values a block: with __builtin_amdgcn_update_dpp in the run kernels hipcc 7.2's register allocator
+ * crashed under -amdgpu-sched-strategy=iterative-ilp; the s_nop covers the wait states a DPP read needs after a VALU
+ * write of its source (2) or of EXEC (5), which the compiler cannot see from outside the block. */
+template <int N>
+DP_DEVICE void dp_mirror8_valu(float (&v)[N])
+{
+    static_assert(N % 8 == 0, "eight values at a time");
+#pragma unroll
+    for (int i = 0; i < N; i += 8)
+        __asm__("s_nop 4\n\t"
+                "v_mov_b32_dpp %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+                "v_mov_b32_dpp %2, %2 row_half_mirror row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %3, %3 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+                "v_mov_b32_dpp %4, %4 row_half_mirror row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %5, %5 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+                "v_mov_b32_dpp %6, %6 row_half_mirror row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %7, %7 row_half_mirror row_mask:0xf bank_mask:0xf"
+                : "+v"(v[i]), "+v"(v[i + 1]), "+v"(v[i + 2]), "+v"(v[i + 3]), "+v"(v[i + 4]), "+v"(v[i + 5]), "+v"(v[i + 6]), "+v"(v[i + 7]));
+}
+
 template <int N>
 DP_DEVICE void dp_shfl(double (&v)[N], int src)
 {

@@ -68,6 +68,8 @@ DP_DEVICE void dp_shfl(float (&v)[N], int src)
     pthread_barrier_wait(&g_emu.w->bar);
 }
 
+template <int N> DP_DEVICE void dp_mirror8_valu(float (&v)[N]) { dp_shfl(v, g_emu.lane ^ 7); }
+
 template <int N>
 DP_DEVICE void dp_shfl(double (&v)[N], int src)
 {
