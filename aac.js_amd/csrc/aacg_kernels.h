@@ -504,15 +504,31 @@ DP_DEVICE dpv2 lds_pair(const float* base, int pair_index)
     return v2(t.x, t.y);
 }
 
+/* The last FFT stage of the long path leaves lane l with column k = l + 64 i of the spectrum, and the reorder needs the
+ * column 63 - l beside it: a whole-wave mirror, 32 ds_bpermute_b32 per channel pair on the CU's one LDS pipe.  Nothing
+ * forces column = lane there: with the columns dealt out so that c and 63 - c sit in one row of sixteen lanes at
+ * mirrored positions, the exchange is DPP row_mirror on the VALU.  long_col(l): row r = l / 16, position p:
+ *   p < 8:  c = 8 r + (p ^ 4 (r & 1));    p >= 8:  c = 63 - long_col(l ^ 15)
+ * (the ^ 4 in odd rows keeps every 16-lane read group of ds_read_b128 on 16 distinct 16-byte bank groups: its eight
+ * mirror pairs then cover all residues mod 16).  Everything after that stage indexes by column: rotation factors,
+ * window positions, tail positions, and the epilogue's sample positions (its `lcol` argument). */
+DP_DEVICE int long_col(int l)
+{
+    const int r = l >> 4, p = l & 15, q = p < 8 ? p : 15 - p;
+    const int base = 8 * r + (q ^ ((r & 1) << 2));
+    return p < 8 ? base : 63 - base;
+}
+
 /* mirror-lane exchange of 8 (L,R) complex values: m*[r] <- lane `src`'s value */
-template <bool GROUP8_VALU = false>                     /* GROUP8_VALU: src is l ^ 7, taken without the LDS pipe (dp_mirror8_valu) */
+template <int VALU = 0>                                 /* 8 / 16: src is l ^ 7 / l ^ 15, taken without the LDS pipe (DPP) */
 DP_DEVICE void shfl_pairs(const dpv2 (&R)[8], const dpv2 (&I)[8], int src, dpv2 (&mR)[8], dpv2 (&mI)[8])
 {
     float a[16], b[16];
 #pragma unroll
     for (int r = 0; r < 8; r++) { a[r] = R[r][0]; a[8 + r] = R[r][1]; b[r] = I[r][0]; b[8 + r] = I[r][1]; }
-    if (GROUP8_VALU) { dp_mirror8_valu(a); dp_mirror8_valu(b); }
-    else             { dp_shfl(a, src); dp_shfl(b, src); }
+    if (VALU == 8)       { dp_mirror8_valu(a); dp_mirror8_valu(b); }
+    else if (VALU == 16) { dp_mirror16_valu(a); dp_mirror16_valu(b); }
+    else                 { dp_shfl(a, src); dp_shfl(b, src); }
 #pragma unroll
     for (int r = 0; r < 8; r++) { mR[r] = v2(a[r], a[8 + r]); mI[r] = v2(b[r], b[8 + r]); }
 }
@@ -520,11 +536,10 @@ DP_DEVICE void shfl_pairs(const dpv2 (&R)[8], const dpv2 (&I)[8], int src, dpv2 
 /* window + reorder of the long pair path for one window sequence (mdct.js:90-114 fused with
  * filter_bank.js:109-141,180-202); tails interleaved into the slot */
 template <int SEQ>
-DP_DEVICE void long_pair_window(const float* tab, const chan_par& cp, bool want_head, float* slot,
+DP_DEVICE void long_pair_window(const float* tab, const chan_par& cp, bool want_head, float* slot, int l /* column */,
                                 const dpv2 (&R)[8], const dpv2 (&I)[8], const dpv2 (&mR)[8], const dpv2 (&mI)[8],
                                 dpv2 (&hx)[8], dpv2 (&hy)[8])
 {
-    const int l = dp_lane();
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const int n = 2 * l + 128 * j;
@@ -549,6 +564,7 @@ DP_DEVICE void long_pair_window(const float* tab, const chan_par& cp, bool want_
 }
 
 /* Long windows, both channels (they share sequence and shapes: one ICSInfo, cpe.js:44, or equal by value). */
+template <bool VM>                                      /* VM: columns dealt out by long_col, mirror exchange as DPP row_mirror */
 DP_DEVICE void long_pair(const float* tab, const chan_par& cp, bool want_head, float* slot,
                          dpv2 (&hx)[8], dpv2 (&hy)[8])
 {
@@ -582,19 +598,20 @@ DP_DEVICE void long_pair(const float* tab, const chan_par& cp, bool want_head, f
 #pragma unroll
     for (int r = 0; r < 8; r++) lds_put2(slot, pch2(qq + 8 * r, l0), z[r]);
     dp_wave_sync();
+    const int c = VM ? long_col(l) : l;                /* this lane's column from here on */
 #pragma unroll
-    for (int i = 0; i < 8; i++) z[i] = lds_get2(slot, pch2(l, i));
+    for (int i = 0; i < 8; i++) z[i] = lds_get2(slot, pch2(c, i));
     dp_wave_sync();
     radix8_inv2(z);
 
     dpv2 R[8], I[8], mR[8], mI[8];
 #pragma unroll
     for (int r = 0; r < 8; r++) {
-        const cpx sc = lds_get(sincos, 64 * r + l);
+        const cpx sc = lds_get(sincos, 64 * r + c);
         R[r] = z[r].re * v2s(sc.re) - z[r].im * v2s(sc.im);          /* mdct.js:82-87 */
         I[r] = z[r].im * v2s(sc.re) + z[r].re * v2s(sc.im);
     }
-    shfl_pairs(R, I, 63 - l, mR, mI);
+    shfl_pairs<VM ? 16 : 0>(R, I, 63 - l, mR, mI);
 
     if (cp.seq == AACG_ONLY_LONG_SEQUENCE) {
         /* the common case as straight-line code: with no branch between them the window reads of an iteration
@@ -605,7 +622,7 @@ DP_DEVICE void long_pair(const float* tab, const chan_par& cp, bool want_head, f
         const float* wt = tab + AACG_TAB_OFF_WIN_LONG + 1024 * cp.shape;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            const int n = 2 * l + 128 * j;
+            const int n = 2 * c + 128 * j;
             const dpf2 w0 = *(const dpf2*)(wh + n), w1 = *(const dpf2*)(wh + n + 512);
             const dpf2 r0 = *(const dpf2*)(wt + 1022 - n), r1 = *(const dpf2*)(wt + 510 - n);   /* reversed: (w[1022-n], w[1023-n]) */
             hx[j]     = I[j + 4] * v2s(w0.x);
@@ -624,8 +641,8 @@ DP_DEVICE void long_pair(const float* tab, const chan_par& cp, bool want_head, f
     }
     /* LONG_START / LONG_STOP: the same loop with the sequence as a compile-time constant, so that the branches
      * inside head_window / tail_window fold and each iteration's window reads are issued together */
-    if (cp.seq == AACG_LONG_START_SEQUENCE) long_pair_window<AACG_LONG_START_SEQUENCE>(tab, cp, want_head, slot, R, I, mR, mI, hx, hy);
-    else                                    long_pair_window<AACG_LONG_STOP_SEQUENCE>(tab, cp, want_head, slot, R, I, mR, mI, hx, hy);
+    if (cp.seq == AACG_LONG_START_SEQUENCE) long_pair_window<AACG_LONG_START_SEQUENCE>(tab, cp, want_head, slot, c, R, I, mR, mI, hx, hy);
+    else                                    long_pair_window<AACG_LONG_STOP_SEQUENCE>(tab, cp, want_head, slot, c, R, I, mR, mI, hx, hy);
 }
 
 /* EIGHT_SHORT, both channels. */
@@ -664,7 +681,7 @@ DP_DEVICE void short_pair(const float* tab, const chan_par& cp, float* slot, dpv
         R[r] = z[r].re * v2s(sc.re) - z[r].im * v2s(sc.im);
         I[r] = z[r].im * v2s(sc.re) + z[r].re * v2s(sc.im);
     }
-    shfl_pairs<VM>(R, I, l ^ 7, mR, mI);
+    shfl_pairs<VM ? 8 : 0>(R, I, l ^ 7, mR, mI);
 
     const float* ws = tab + AACG_TAB_OFF_WIN_SHORT + 128 * cp.shape;
     const float* wh = (w == 0) ? tab + AACG_TAB_OFF_WIN_SHORT + 128 * cp.shape_prev : ws;
@@ -1302,7 +1319,7 @@ DP_DEVICE void filter_unit(const float* tab, const unit_view& u, int n_ch, bool 
     if (pair_path) {
         dpv2 hx[8], hy[8];
         if (s0) short_pair<VM>(tab, p0, slot, hx, hy);
-        else    long_pair(tab, p0, want_head, slot, hx, hy);
+        else    long_pair<VM>(tab, p0, want_head, slot, hx, hy);
 #pragma unroll
         for (int m = 0; m < 8; m++) { hx0[m] = hx[m][0]; hx1[m] = hx[m][1]; hy0[m] = hy[m][0]; hy1[m] = hy[m][1]; }
         return;
@@ -1346,14 +1363,15 @@ DP_DEVICE void filter_unit(const float* tab, const unit_view& u, int n_ch, bool 
  * (filter_bank.js:109-111, 153-160, 185-195 — both operands are PCM-scaled already), which then holds the element's
  * finished samples: (L[n], R[n]) pairs for a CPE, planar for a single channel.  Samples a window sequence takes from the
  * overlap alone (EIGHT_SHORT: 0..447) are simply left as they are. */
-DP_DEVICE void overlap_add_in_place(float* prev, int n_ch, int cls0, int cls1,
+DP_DEVICE void overlap_add_in_place(float* prev, int n_ch, int cls0, int cls1, int lcol,
                               const float (&hx0)[8], const float (&hy0)[8], const float (&hx1)[8], const float (&hy1)[8])
 {
     const int lane = dp_lane(), w = lane >> 3, g = lane & 7;
+    (void)lane;
     if (n_ch == 2 && cls0 == cls1) {
 #pragma unroll
         for (int m = 0; m < 8; m++) {
-            const int n = cls0 ? 448 + 128 * w + 2 * g + 16 * m : 2 * lane + 128 * m;
+            const int n = cls0 ? 448 + 128 * w + 2 * g + 16 * m : 2 * lcol + 128 * m;
             if (!cls0 || w < 4 || (w == 4 && m < 4)) {
                 dpf4 v = *(const dpf4*)(prev + 2 * n);
                 v.x += hx0[m]; v.y += hx1[m]; v.z += hy0[m]; v.w += hy1[m];
@@ -1372,7 +1390,7 @@ DP_DEVICE void overlap_add_in_place(float* prev, int n_ch, int cls0, int cls1,
             const int st = n_ch;
 #pragma unroll
             for (int m = 0; m < 8; m++) {
-                const int n = cls ? 448 + 128 * w + 2 * g + 16 * m : 2 * lane + 128 * m;
+                const int n = cls ? 448 + 128 * w + 2 * g + 16 * m : 2 * lcol + 128 * m;
                 if (!cls || w < 4 || (w == 4 && m < 4)) {
                     p[n * st] += hx[m];
                     p[(n + 1) * st] += hy[m];
@@ -1412,7 +1430,7 @@ DP_DEVICE void pcm_put1(int16_t* p, float a) { *p = (int16_t)(dp_pcm16_pair(a, a
 template <bool FROM_LDS, int OUT>
 DP_DEVICE void epilogue(const float* p0, const float* p1, const unit_view& u, int n_ch, int cls0, int cls1,
                         float* pcm_base_f32, const float (&hx0)[8], const float (&hy0)[8],
-                        const float (&hx1)[8], const float (&hy1)[8])
+                        const float (&hx1)[8], const float (&hy1)[8], int lcol /* the lane's column in the long lane map: long_col(lane) or lane */)
 {
     typedef typename pcm_elem<OUT>::type elem;
     elem* pcm_base = (elem*)pcm_base_f32;
@@ -1427,10 +1445,10 @@ DP_DEVICE void epilogue(const float* p0, const float* p1, const unit_view& u, in
             /* all eight reads of the incoming tails first: one LDS (or HBM) round trip, not one per store */
             dpf4 v[8];
 #pragma unroll
-            for (int m = 0; m < 8; m++) v[m] = incoming<FROM_LDS>(p0, p1, 2, 2 * lane + 128 * m);
+            for (int m = 0; m < 8; m++) v[m] = incoming<FROM_LDS>(p0, p1, 2, 2 * lcol + 128 * m);
 #pragma unroll
             for (int m = 0; m < 8; m++) {
-                const int n = 2 * lane + 128 * m;
+                const int n = 2 * lcol + 128 * m;
                 pcm_put4(pcm + 2 * n, v[m].x + hx0[m], v[m].y + hx1[m], v[m].z + hy0[m], v[m].w + hy1[m]);
             }
         } else {
@@ -1463,7 +1481,7 @@ DP_DEVICE void epilogue(const float* p0, const float* p1, const unit_view& u, in
          * 7.9 M this way: 93 -> 66.5 us).  Non-temporal stores here: 150 us (they bypass the L2's merging of the
          * elements' partial lines). */
         float* prev = const_cast<float*>(p0);
-        overlap_add_in_place(prev, n_ch, cls0, cls1, hx0, hy0, hx1, hy1);
+        overlap_add_in_place(prev, n_ch, cls0, cls1, lcol, hx0, hy0, hx1, hy1);
         dp_wave_sync();
         if (n_ch == 2) {
 #pragma unroll
@@ -1488,7 +1506,7 @@ DP_DEVICE void epilogue(const float* p0, const float* p1, const unit_view& u, in
         if (!cls0) {
 #pragma unroll
             for (int m = 0; m < 8; m++) {
-                const int n = 2 * lane + 128 * m;
+                const int n = 2 * lcol + 128 * m;
                 const dpf4 v = incoming<FROM_LDS>(p0, p1, 2, n);
                 pcm_put2(pcm + (size_t)n * C, v.x + hx0[m], v.y + hx1[m]);
                 pcm_put2(pcm + (size_t)(n + 1) * C, v.z + hy0[m], v.w + hy1[m]);
@@ -1527,7 +1545,7 @@ DP_DEVICE void epilogue(const float* p0, const float* p1, const unit_view& u, in
             if (!cls) {
 #pragma unroll
                 for (int m = 0; m < 8; m++) {
-                    const int n = 2 * lane + 128 * m;
+                    const int n = 2 * lcol + 128 * m;
                     const dpf4 v = incoming<FROM_LDS>(p0, p1, n_ch, n);
                     pcm_put1(dst + (size_t)n * C, (c ? v.y : v.x) + hx[m]);
                     pcm_put1(dst + (size_t)(n + 1) * C, (c ? v.w : v.z) + hy[m]);
@@ -1772,16 +1790,18 @@ DP_DEVICE void imdct_run_body(const aacg_kparams& P)
         for (int m = 0; m < 8; m++) acc += hx0[m] + hy0[m] + hx1[m] + hy1[m];
         if (acc == 123456.789f) P.pcm[0] = acc;
     } else if (ui >= 0 && !is_pred_wave) {
+        /* the long pair path of the int16 seam deals its columns out by long_col (filter_unit<VM>) */
+        const int lcol = (KIND == AACG_INPUT_QUANT_I16 && pair_path) ? long_col(lane) : lane;
         if (wave == 0) {
             /* first frame of its chain in this launch: overlap state from HBM (filter_bank.js:38-41,
              * `overlap = this.overlaps[channel]`); a double-duty wave: the tails it parked itself */
             const float* ov0 = n_pass == 2 ? scratch : P.overlap + (P.flip ? run->ov_b[0] : run->ov_a[0]);
             const float* ov1 = n_pass == 2 ? scratch + 1024 : P.overlap + (P.flip ? run->ov_b[1] : run->ov_a[1]);
-            epilogue<false, OUT>(ov0, ov1, u, n_ch, cls0, cls1, P.pcm, hx0, hy0, hx1, hy1);
+            epilogue<false, OUT>(ov0, ov1, u, n_ch, cls0, cls1, P.pcm, hx0, hy0, hx1, hy1, lcol);
         } else {
             dp_flag_wait(&flags[wave - 1], 1);         /* the previous frame's tails (acquire) */
             if (trace && lane == 0) trace[4] = dp_clock();
-            epilogue<true, OUT>(slot - AACG_SLOT_FLOATS, slot - AACG_SLOT_FLOATS, u, n_ch, cls0, cls1, P.pcm, hx0, hy0, hx1, hy1);
+            epilogue<true, OUT>(slot - AACG_SLOT_FLOATS, slot - AACG_SLOT_FLOATS, u, n_ch, cls0, cls1, P.pcm, hx0, hy0, hx1, hy1, lcol);
         }
         if (trace && lane == 0) trace[5] = dp_clock();     /* PCM stores issued */
         /* the chain's last frame in this launch: its tail is the new overlap state (planar in HBM) */

@@ -94,6 +94,21 @@ DP_DEVICE void dp_mirror8_valu(float (&v)[N])
                 : "+v"(v[i]), "+v"(v[i + 1]), "+v"(v[i + 2]), "+v"(v[i + 3]), "+v"(v[i + 4]), "+v"(v[i + 5]), "+v"(v[i + 6]), "+v"(v[i + 7]));
 }
 
+/* v[i] <- lane (lane ^ 15)'s v[i]: DPP row_mirror reverses every row of sixteen lanes (see dp_mirror8_valu) */
+template <int N>
+DP_DEVICE void dp_mirror16_valu(float (&v)[N])
+{
+    static_assert(N % 8 == 0, "eight values at a time");
+#pragma unroll
+    for (int i = 0; i < N; i += 8)
+        __asm__("s_nop 4\n\t"
+                "v_mov_b32_dpp %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %1, %1 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+                "v_mov_b32_dpp %2, %2 row_mirror row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %3, %3 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+                "v_mov_b32_dpp %4, %4 row_mirror row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %5, %5 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+                "v_mov_b32_dpp %6, %6 row_mirror row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %7, %7 row_mirror row_mask:0xf bank_mask:0xf"
+                : "+v"(v[i]), "+v"(v[i + 1]), "+v"(v[i + 2]), "+v"(v[i + 3]), "+v"(v[i + 4]), "+v"(v[i + 5]), "+v"(v[i + 6]), "+v"(v[i + 7]));
+}
+
 template <int N>
 DP_DEVICE void dp_shfl(double (&v)[N], int src)
 {

@@ -69,6 +69,7 @@ DP_DEVICE void dp_shfl(float (&v)[N], int src)
 }
 
 template <int N> DP_DEVICE void dp_mirror8_valu(float (&v)[N]) { dp_shfl(v, g_emu.lane ^ 7); }
+template <int N> DP_DEVICE void dp_mirror16_valu(float (&v)[N]) { dp_shfl(v, g_emu.lane ^ 15); }
 
 template <int N>
 DP_DEVICE void dp_shfl(double (&v)[N], int src)
