@@ -202,6 +202,8 @@ struct chan_par { int seq, shape, shape_prev; };
 /* ------------------------------------------------------------------------------------ */
 /* long windows: IMDCT-2048 + window, mdct.js:62-115 + filter_bank.js                      */
 /* ------------------------------------------------------------------------------------ */
+DP_DEVICE int long_col(int l);
+
 /* NC channels advance together as independent instruction streams (ILP across the LDS and
  * FMA latencies); they share the rotation and twiddle reads.  area[c][0..1023] holds channel
  * c's spectrum in natural order on entry, is reused for its FFT transposes and receives its
@@ -209,11 +211,10 @@ struct chan_par { int seq, shape, shape_prev; };
  * (hx[c][m]) and n + 1 (hy[c][m]). */
 /* window + reorder of one planar long channel for one window sequence; m[r] = re, m[8+r] = im of lane 63 - l */
 template <int SEQ>
-DP_DEVICE void long_planar_window(const float* tab, const chan_par& cp, bool want_head, float* area,
+DP_DEVICE void long_planar_window(const float* tab, const chan_par& cp, bool want_head, float* area, int l /* column */,
                                   const float (&R)[8], const float (&I)[8], const float (&m)[16],
                                   float (&hx)[8], float (&hy)[8])
 {
-    const int l = dp_lane();
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const int n = 2 * l + 128 * j;
@@ -237,7 +238,7 @@ DP_DEVICE void long_planar_window(const float* tab, const chan_par& cp, bool wan
     }
 }
 
-template <int NC>
+template <int NC, bool VM = false>                     /* VM: columns dealt out by long_col (below), mirror exchange as DPP row_mirror */
 DP_DEVICE void long_channels(const float* tab, const chan_par (&cp)[NC], bool want_head,
                              float* const (&area)[NC], float (&hx)[NC][8], float (&hy)[NC][8])
 {
@@ -292,19 +293,20 @@ DP_DEVICE void long_channels(const float* tab, const chan_par (&cp)[NC], bool wa
 #pragma unroll
         for (int c = 0; c < NC; c++) lds_put(area[c], xch2(qq + 8 * r, l0), z[c][r]);
     dp_wave_sync();
+    const int col = VM ? long_col(l) : l;              /* this lane's column from here on */
 #pragma unroll
     for (int i = 0; i < 8; i++)
 #pragma unroll
-        for (int c = 0; c < NC; c++) z[c][i] = lds_get(area[c], xch2(l, i));
+        for (int c = 0; c < NC; c++) z[c][i] = lds_get(area[c], xch2(col, i));
     dp_wave_sync();
 #pragma unroll
-    for (int c = 0; c < NC; c++) radix8_inv(z[c]);     /* over l0; lane l now holds Z[l + 64 r] */
+    for (int c = 0; c < NC; c++) radix8_inv(z[c]);     /* over l0; the lane now holds Z[col + 64 r] */
 
     /* post-IFFT rotation (mdct.js:82-87) */
     float R[NC][8], I[NC][8];
 #pragma unroll
     for (int r = 0; r < 8; r++) {
-        const cpx sc = lds_get(sincos, 64 * r + l);
+        const cpx sc = lds_get(sincos, 64 * r + col);
 #pragma unroll
         for (int c = 0; c < NC; c++) {
             R[c][r] = dp_fma(z[c][r].re, sc.re, -(z[c][r].im * sc.im));
@@ -318,12 +320,12 @@ DP_DEVICE void long_channels(const float* tab, const chan_par (&cp)[NC], bool wa
         float m[16];
 #pragma unroll
         for (int r = 0; r < 8; r++) { m[r] = R[c][r]; m[8 + r] = I[c][r]; }
-        dp_shfl(m, 63 - l);
+        if (VM) dp_mirror16_valu(m); else dp_shfl(m, 63 - l);
         /* reorder (mdct.js:90-114) fused with the window (filter_bank.js:109-116 etc.), with the sequence as a
          * compile-time constant: the branches inside head_window / tail_window fold, the reads go out together */
-        if (cp[c].seq == AACG_ONLY_LONG_SEQUENCE)       long_planar_window<AACG_ONLY_LONG_SEQUENCE>(tab, cp[c], want_head, area[c], R[c], I[c], m, hx[c], hy[c]);
-        else if (cp[c].seq == AACG_LONG_START_SEQUENCE) long_planar_window<AACG_LONG_START_SEQUENCE>(tab, cp[c], want_head, area[c], R[c], I[c], m, hx[c], hy[c]);
-        else                                            long_planar_window<AACG_LONG_STOP_SEQUENCE>(tab, cp[c], want_head, area[c], R[c], I[c], m, hx[c], hy[c]);
+        if (cp[c].seq == AACG_ONLY_LONG_SEQUENCE)       long_planar_window<AACG_ONLY_LONG_SEQUENCE>(tab, cp[c], want_head, area[c], col, R[c], I[c], m, hx[c], hy[c]);
+        else if (cp[c].seq == AACG_LONG_START_SEQUENCE) long_planar_window<AACG_LONG_START_SEQUENCE>(tab, cp[c], want_head, area[c], col, R[c], I[c], m, hx[c], hy[c]);
+        else                                            long_planar_window<AACG_LONG_STOP_SEQUENCE>(tab, cp[c], want_head, area[c], col, R[c], I[c], m, hx[c], hy[c]);
     }
 }
 template <int NC, bool VM = false>                     /* VM: the l ^ 7 exchange on the VALU (dp_mirror8_valu) */
@@ -1306,6 +1308,11 @@ DP_DEVICE void tns_unit(float* slot, float* xch, const aacg_dev_tns* rec0, const
 
 /* IMDCT + window of a unit whose spectra are staged in its slot.  CPE tails always end up
  * interleaved (pair index n = (tailL[n], tailR[n])); a single channel's tail is planar. */
+#ifdef AACG_VM_F32
+#define AACG_VM_KIND(kind) true
+#else
+#define AACG_VM_KIND(kind) ((kind) == AACG_INPUT_QUANT_I16)
+#endif
 /* VM: the mirror exchanges of the short windows on the VALU: worth it where the LDS pipe is the busier one — the int16 seam
  * (all-short batch 14.67 -> 13.70 us, config 3 13.94 -> 13.56); the f32 seam lost 0.07 us with it and keeps ds_bpermute */
 template <bool VM>
@@ -1329,7 +1336,7 @@ DP_DEVICE void filter_unit(const float* tab, const unit_view& u, int n_ch, bool 
         float* const area[1] = {slot};
         float hx[1][8], hy[1][8];
         if (s0) short_channels<1, VM>(tab, cp, area, hx, hy);
-        else    long_channels<1>(tab, cp, want_head, area, hx, hy);
+        else    long_channels<1, VM>(tab, cp, want_head, area, hx, hy);
 #pragma unroll
         for (int m = 0; m < 8; m++) { hx0[m] = hx[0][m]; hy0[m] = hy[0][m]; }
     }
@@ -1338,7 +1345,7 @@ DP_DEVICE void filter_unit(const float* tab, const unit_view& u, int n_ch, bool 
         float* const area[1] = {slot + 1024};
         float hx[1][8], hy[1][8];
         if (s1) short_channels<1, VM>(tab, cp, area, hx, hy);
-        else    long_channels<1>(tab, cp, want_head, area, hx, hy);
+        else    long_channels<1, VM>(tab, cp, want_head, area, hx, hy);
 #pragma unroll
         for (int m = 0; m < 8; m++) { hx1[m] = hx[0][m]; hy1[m] = hy[0][m]; }
         /* two planar tails -> the interleaved form the next wave expects */
@@ -1758,7 +1765,7 @@ DP_DEVICE void imdct_run_body(const aacg_kparams& P)
         }
         dp_wave_sync();
         if (trace && lane == 0) trace[2] = dp_clock();     /* spectrum arrived and staged */
-        filter_unit<KIND == AACG_INPUT_QUANT_I16>(tab, u, n_ch, pair_path, want_head, slot, hx0, hy0, hx1, hy1);
+        filter_unit<AACG_VM_KIND(KIND)>(tab, u, n_ch, pair_path, want_head, slot, hx0, hy0, hx1, hy1);
     };
 
     if (ui >= 0) front(!is_pred_wave && n_pass == 1);
@@ -1790,8 +1797,8 @@ DP_DEVICE void imdct_run_body(const aacg_kparams& P)
         for (int m = 0; m < 8; m++) acc += hx0[m] + hy0[m] + hx1[m] + hy1[m];
         if (acc == 123456.789f) P.pcm[0] = acc;
     } else if (ui >= 0 && !is_pred_wave) {
-        /* the long pair path of the int16 seam deals its columns out by long_col (filter_unit<VM>) */
-        const int lcol = (KIND == AACG_INPUT_QUANT_I16 && pair_path) ? long_col(lane) : lane;
+        /* the long paths of the int16 seam deal their columns out by long_col (filter_unit<VM>) */
+        const int lcol = AACG_VM_KIND(KIND) ? long_col(lane) : lane;
         if (wave == 0) {
             /* first frame of its chain in this launch: overlap state from HBM (filter_bank.js:38-41,
              * `overlap = this.overlaps[channel]`); a double-duty wave: the tails it parked itself */
