@@ -162,8 +162,14 @@ DP_DEVICE void dp_store2_u(float* p, float a, float b) { dp_f2u v; v[0] = a; v[1
 typedef short dp_i16x2 __attribute__((ext_vector_type(2)));
 DP_DEVICE int dp_pcm16_pair(float a, float b)
 {
-    const dp_i16x2 p = __builtin_amdgcn_cvt_pk_i16(__builtin_rintf(a * 32768.0f), __builtin_rintf(b * 32768.0f));   /* v_cvt_pk_i16_i32 saturates */
-    return __builtin_bit_cast(int, p);
+    /* clamp to the int16 range, then x * 32768 + 1.5 * 2^23 in ONE fused multiply-add: the sum has an ulp of 1, so the
+     * rounding to nearest even is the addition's, and the low 16 mantissa bits are the integer in two's complement;
+     * v_perm_b32 packs the two low halves.  Five instructions per pair (multiply, round, convert twice, pack: seven). */
+    a = __builtin_amdgcn_fmed3f(a, -1.0f, 0.999969482421875f);
+    b = __builtin_amdgcn_fmed3f(b, -1.0f, 0.999969482421875f);
+    const unsigned ua = __builtin_bit_cast(unsigned, __builtin_fmaf(a, 32768.0f, 12582912.0f));
+    const unsigned ub = __builtin_bit_cast(unsigned, __builtin_fmaf(b, 32768.0f, 12582912.0f));
+    return (int)__builtin_amdgcn_perm(ub, ua, 0x05040100u);
 }
 typedef int dp_i2u __attribute__((ext_vector_type(2), aligned(4)));
 DP_DEVICE void dp_store_i2_nt(void* p, int a, int b) { dp_i2u v; v[0] = a; v[1] = b; __builtin_nontemporal_store(v, (dp_i2u*)p); }
