@@ -24,19 +24,21 @@ void aacg_debug_transform_kernel(const aacg_tables* tab_global, const float* in,
     for (int i = lane; i < 1024; i += 64) area[i] = in[i];
     dp_wave_sync();
     chan_par cp[1];
-    cp[0].seq = is_short ? AACG_EIGHT_SHORT_SEQUENCE : AACG_ONLY_LONG_SEQUENCE; cp[0].shape = 0; cp[0].shape_prev = 0;
+    cp[0].seq = (is_short & 1) ? AACG_EIGHT_SHORT_SEQUENCE : AACG_ONLY_LONG_SEQUENCE; cp[0].shape = 0; cp[0].shape_prev = 0;
     float* const areas[1] = {area};
     float hx[1][8], hy[1][8];
-    if (is_short) {
-        short_channels<1>(lds, cp, areas, hx, hy);
+    const bool vm = (is_short & 2) != 0;               /* the int16 seam's variants: mirror-lane exchanges as DPP, columns dealt out by long_col */
+    if (is_short & 1) {
+        if (vm) short_channels<1, true>(lds, cp, areas, hx, hy); else short_channels<1>(lds, cp, areas, hx, hy);
         const int w = lane >> 3, g = lane & 7;
 #pragma unroll
         for (int m = 0; m < 8; m++) { out[128 * w + 2 * g + 16 * m] = hx[0][m]; out[128 * w + 2 * g + 16 * m + 1] = hy[0][m]; }
     } else {
-        long_channels<1>(lds, cp, true, areas, hx, hy);
+        if (vm) long_channels<1, true>(lds, cp, true, areas, hx, hy); else long_channels<1>(lds, cp, true, areas, hx, hy);
         dp_wave_sync();
+        const int col = vm ? long_col(lane) : lane;
 #pragma unroll
-        for (int m = 0; m < 8; m++) { out[2 * lane + 128 * m] = hx[0][m]; out[2 * lane + 128 * m + 1] = hy[0][m]; }
+        for (int m = 0; m < 8; m++) { out[2 * col + 128 * m] = hx[0][m]; out[2 * col + 128 * m + 1] = hy[0][m]; }
         for (int i = lane; i < 1024; i += 64) out[1024 + i] = area[i];
     }
 }

@@ -317,10 +317,10 @@ DP_DEVICE void long_channels(const float* tab, const chan_par (&cp)[NC], bool wa
 #pragma unroll
     for (int c = 0; c < NC; c++) {
         /* the mirror lane's values for the reorder: m[r] = re, m[8+r] = im of lane 63 - l */
-        float m[16];
+        float m[16], own[16];
 #pragma unroll
-        for (int r = 0; r < 8; r++) { m[r] = R[c][r]; m[8 + r] = I[c][r]; }
-        if (VM) dp_mirror16_valu(m); else dp_shfl(m, 63 - l);
+        for (int r = 0; r < 8; r++) { own[r] = m[r] = R[c][r]; own[8 + r] = m[8 + r] = I[c][r]; }
+        if (VM) dp_mirror16_valu(own, m); else dp_shfl(m, 63 - l);
         /* reorder (mdct.js:90-114) fused with the window (filter_bank.js:109-116 etc.), with the sequence as a
          * compile-time constant: the branches inside head_window / tail_window fold, the reads go out together */
         if (cp[c].seq == AACG_ONLY_LONG_SEQUENCE)       long_planar_window<AACG_ONLY_LONG_SEQUENCE>(tab, cp[c], want_head, area[c], col, R[c], I[c], m, hx[c], hy[c]);
@@ -384,10 +384,10 @@ DP_DEVICE void short_channels(const float* tab, const chan_par (&cp)[NC],
 
 #pragma unroll
     for (int c = 0; c < NC; c++) {
-        float m[16];
+        float m[16], own[16];
 #pragma unroll
-        for (int r = 0; r < 8; r++) { m[r] = R[c][r]; m[8 + r] = I[c][r]; }
-        if (VM) dp_mirror8_valu(m); else dp_shfl(m, l ^ 7);
+        for (int r = 0; r < 8; r++) { own[r] = m[r] = R[c][r]; own[8 + r] = m[8 + r] = I[c][r]; }
+        if (VM) dp_mirror8_valu(own, m); else dp_shfl(m, l ^ 7);
 
         /* window each block: head with W[i] (block 0: previous shape), tail with W[127-i] */
         const float* ws = tab + AACG_TAB_OFF_WIN_SHORT + 128 * cp[c].shape;
@@ -525,14 +525,15 @@ DP_DEVICE int long_col(int l)
 template <int VALU = 0>                                 /* 8 / 16: src is l ^ 7 / l ^ 15, taken without the LDS pipe (DPP) */
 DP_DEVICE void shfl_pairs(const dpv2 (&R)[8], const dpv2 (&I)[8], int src, dpv2 (&mR)[8], dpv2 (&mI)[8])
 {
-    float a[16], b[16];
+    /* the two halves of a pair next to each other: a block of eight moves then fills four register pairs */
+    float a[16], b[16], ma[16], mb[16];
 #pragma unroll
-    for (int r = 0; r < 8; r++) { a[r] = R[r][0]; a[8 + r] = R[r][1]; b[r] = I[r][0]; b[8 + r] = I[r][1]; }
-    if (VALU == 8)       { dp_mirror8_valu(a); dp_mirror8_valu(b); }
-    else if (VALU == 16) { dp_mirror16_valu(a); dp_mirror16_valu(b); }
-    else                 { dp_shfl(a, src); dp_shfl(b, src); }
+    for (int r = 0; r < 8; r++) { ma[2 * r] = a[2 * r] = R[r][0]; ma[2 * r + 1] = a[2 * r + 1] = R[r][1]; mb[2 * r] = b[2 * r] = I[r][0]; mb[2 * r + 1] = b[2 * r + 1] = I[r][1]; }
+    if (VALU == 8)       { dp_mirror8_valu(a, ma); dp_mirror8_valu(b, mb); }
+    else if (VALU == 16) { dp_mirror16_valu(a, ma); dp_mirror16_valu(b, mb); }
+    else                 { dp_shfl(ma, src); dp_shfl(mb, src); }
 #pragma unroll
-    for (int r = 0; r < 8; r++) { mR[r] = v2(a[r], a[8 + r]); mI[r] = v2(b[r], b[8 + r]); }
+    for (int r = 0; r < 8; r++) { mR[r] = v2(ma[2 * r], ma[2 * r + 1]); mI[r] = v2(mb[2 * r], mb[2 * r + 1]); }
 }
 
 /* window + reorder of the long pair path for one window sequence (mdct.js:90-114 fused with
@@ -799,35 +800,43 @@ DP_DEVICE void band_indices(const band_raw& r, const chan_ctx& cc, int (&idx)[4]
     }
 }
 
-/* Band records of both channels, two bands per lane; sl / sr: the bands' SF-table entries, loaded by the
- * caller together with the band maps.  Bit operations instead of && / ||: no short-circuit branches. */
+/* Band records of both channels, two bands per lane; sl / sr: the bands' SF-table entries (positive), loaded by the
+ * caller together with the band maps.  Everything is a bit field of the two band words (include/aacgpu.h: scalefactor
+ * index, negate, ms_used, band type), so the decisions are shifts of small constants by the band type instead of
+ * compare chains — `K >> type & 1` with K the set of types for which the property holds; the wave-uniform conditions
+ * (two channels, MS possible, mask present) are folded into those constants on the scalar unit. */
 DP_DEVICE void prepare_bands(const quant_regs& r, const float (&sl_in)[2], const float (&sr_in)[2],
                              bool two, bool ms_on, bool mask, float* bt)
 {
     const int lane = dp_lane();
     unsigned* bw = (unsigned*)bt;
+    const unsigned kCoded = 0x1FFEu;                   /* band types 1..12 carry coefficients (ics.js:222-227) */
+    const unsigned kBelowNoise = 0x1FFFu;              /* 0..12 */
+    const unsigned kLiveR = two ? kCoded : 0u, kMsL = ms_on ? kBelowNoise : 0u;
+    const unsigned kIs = two ? 0xC000u : 0u;           /* INTENSITY_BT2, INTENSITY_BT on the right channel */
+    const unsigned mask_u = mask ? 1u : 0u;
 #pragma unroll
     for (int h = 0; h < 2; h++) {
         const int b = lane + 64 * h;
-        const bool coded = b < AACG_MAX_SECTIONS;      /* the rest (incl. AACG_BR_NONE) are empty records */
-        const unsigned wl = r.mw[0][h], wr = r.mw[1][h];
-        const int tl = (int)(wl >> AACG_META_BT_SHIFT), tr = (int)(wr >> AACG_META_BT_SHIFT);
-        const float sl = (wl & AACG_META_NEGATE) ? -sl_in[h] : sl_in[h];
-        const float sr = (wr & AACG_META_NEGATE) ? -sr_in[h] : sr_in[h];
-        const bool ms_used = (wl & AACG_META_MS_USED) != 0;
-        const bool live_l = coded & (tl != AACG_ZERO_BT) & (tl < AACG_NOISE_BT);
-        const bool live_r = coded & two & (tr != AACG_ZERO_BT) & (tr < AACG_NOISE_BT);
+        const bool coded = b < AACG_MAX_SECTIONS;      /* the rest (incl. AACG_BR_NONE) are empty records: band type 0 */
+        const unsigned wl = coded ? r.mw[0][h] : 0u, wr = coded ? r.mw[1][h] : 0u;
+        const unsigned tl = wl >> AACG_META_BT_SHIFT, tr = wr >> AACG_META_BT_SHIFT;
+        const unsigned live_l = 0u - ((kCoded >> tl) & 1u), live_r = 0u - ((kLiveR >> tr) & 1u);       /* all ones / zero */
+        const unsigned ms_used = (wl / AACG_META_MS_USED) & 1u;
         /* decoder.js:295-296,393: MS needs commonWindow && maskPresent && ms_used[idx] && both band types < NOISE */
-        const bool ms = coded & ms_on & ms_used & (tl < AACG_NOISE_BT) & (tr < AACG_NOISE_BT);
+        const unsigned ms = ms_used & (kMsL >> tl) & (kBelowNoise >> tr) & 1u;
         /* decoder.js:353-368: right = left * (c * sf) on the right channel's intensity bands; c = -1 for
          * INTENSITY_BT2, flipped again where the mask is present and ms_used is set */
-        const bool is = coded & two & (tr >= AACG_INTENSITY_BT2);
-        const bool neg = (tr == AACG_INTENSITY_BT2) ^ (mask & ms_used);
+        const unsigned is = (kIs >> tr) & 1u;
+        const unsigned neg = ((0x4000u >> tr) ^ (mask_u & ms_used)) & 1u;
+        /* the scalefactor with the word's negate bit as its sign (the table holds positive values) */
+        const unsigned sl = __builtin_bit_cast(unsigned, sl_in[h]) ^ ((wl * (0x80000000u / AACG_META_NEGATE)) & 0x80000000u);
+        const unsigned sr = __builtin_bit_cast(unsigned, sr_in[h]) ^ ((wr * (0x80000000u / AACG_META_NEGATE)) & 0x80000000u);
         dpf2 rl, rr;
-        rl.x = live_l ? sl : 0.0f;
-        rl.y = __builtin_bit_cast(float, (live_l ? AACG_BR_LIVE : 0u) | (ms ? AACG_BR_FLAG : 0u));
-        rr.x = live_r ? sr : (is ? (neg ? -sr : sr) : 0.0f);
-        rr.y = __builtin_bit_cast(float, (live_r ? AACG_BR_LIVE : 0u) | (is ? AACG_BR_FLAG : 0u));
+        rl.x = __builtin_bit_cast(float, sl & live_l);
+        rl.y = __builtin_bit_cast(float, (live_l & AACG_BR_LIVE) | ms);
+        rr.x = __builtin_bit_cast(float, (sr & live_r) | ((sr ^ (neg << 31)) & (0u - is)));
+        rr.y = __builtin_bit_cast(float, (live_r & AACG_BR_LIVE) | is);
         *(dpf2*)(bw + 2 * b) = rl;
         *(dpf2*)(bw + 256 + 2 * b) = rr;
     }
@@ -975,7 +984,12 @@ DP_DEVICE void spectral_quant(const aacg_kparams& P, const float* tab, const uni
     prepare_bands(qreg, sl, sr, two, ms_on, mask, bt);
     int idxL[4], idxR[4];
     band_indices(braw, ccL, idxL);
-    band_indices(braw, ccR, idxR);
+#pragma unroll
+    for (int k = 0; k < 4; k++) idxR[k] = idxL[k];
+    if (ccR.cls != ccL.cls || ccR.max_sfb != ccL.max_sfb || ccR.gmap != ccL.gmap) {   /* wave-uniform; a common window never gets here */
+        dp_keep_branch();
+        band_indices(braw, ccR, idxR);
+    }
     dp_wave_sync();
 
     /* per 4-coefficient group (bands are multiples of 4 wide): the band records of both channels, all loads

@@ -76,38 +76,37 @@ DP_DEVICE void dp_shfl(float (&v)[N], int src)
     for (int i = 0; i < N; i++) v[i] = __shfl(v[i], src, 64);
 }
 
-/* v[i] <- lane (lane ^ 7)'s v[i] without the LDS pipe: DPP row_half_mirror reverses every group of eight lanes.  Inline
- * assembly, eight values a block: with __builtin_amdgcn_update_dpp in the run kernels hipcc 7.2's register allocator
- * crashed under -amdgpu-sched-strategy=iterative-ilp; the s_nop covers the wait states a DPP read needs after a VALU
- * write of its source (2) or of EXEC (5), which the compiler cannot see from outside the block. */
+/* out[i] <- lane (lane ^ 7)'s in[i] without the LDS pipe: DPP row_half_mirror reverses every group of eight lanes
+ * (row_mirror, lane ^ 15: every row of sixteen).  Inline assembly, eight values a block: with __builtin_amdgcn_update_dpp
+ * in the run kernels hipcc 7.2's register allocator crashed under -amdgpu-sched-strategy=iterative-ilp.  Out of place (every
+ * lane of the destination is written, so it needs no previous value): the in-place form of round 2 made the compiler
+ * copy all the sources first where both the value and its mirror are used — 32 v_mov per channel pair.  The s_nop covers
+ * the wait states a DPP read needs after a VALU write of its source (2) or — first block — of EXEC (5), which the compiler
+ * cannot see from outside the block; the blocks are volatile so that they keep their order. */
+#define DP_DPP_BLOCK8(NOP, CTL) \
+    __asm__ volatile(NOP "\n\t" \
+            "v_mov_b32_dpp %0, %8 " CTL " row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %1, %9 " CTL " row_mask:0xf bank_mask:0xf\n\t" \
+            "v_mov_b32_dpp %2, %10 " CTL " row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %3, %11 " CTL " row_mask:0xf bank_mask:0xf\n\t" \
+            "v_mov_b32_dpp %4, %12 " CTL " row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %5, %13 " CTL " row_mask:0xf bank_mask:0xf\n\t" \
+            "v_mov_b32_dpp %6, %14 " CTL " row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %7, %15 " CTL " row_mask:0xf bank_mask:0xf" \
+            : "=&v"(out[i]), "=&v"(out[i + 1]), "=&v"(out[i + 2]), "=&v"(out[i + 3]), "=&v"(out[i + 4]), "=&v"(out[i + 5]), "=&v"(out[i + 6]), "=&v"(out[i + 7]) \
+            : "v"(in[i]), "v"(in[i + 1]), "v"(in[i + 2]), "v"(in[i + 3]), "v"(in[i + 4]), "v"(in[i + 5]), "v"(in[i + 6]), "v"(in[i + 7]))
 template <int N>
-DP_DEVICE void dp_mirror8_valu(float (&v)[N])
+DP_DEVICE void dp_mirror8_valu(const float (&in)[N], float (&out)[N])
 {
     static_assert(N % 8 == 0, "eight values at a time");
 #pragma unroll
-    for (int i = 0; i < N; i += 8)
-        __asm__("s_nop 4\n\t"
-                "v_mov_b32_dpp %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
-                "v_mov_b32_dpp %2, %2 row_half_mirror row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %3, %3 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
-                "v_mov_b32_dpp %4, %4 row_half_mirror row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %5, %5 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
-                "v_mov_b32_dpp %6, %6 row_half_mirror row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %7, %7 row_half_mirror row_mask:0xf bank_mask:0xf"
-                : "+v"(v[i]), "+v"(v[i + 1]), "+v"(v[i + 2]), "+v"(v[i + 3]), "+v"(v[i + 4]), "+v"(v[i + 5]), "+v"(v[i + 6]), "+v"(v[i + 7]));
+    for (int i = 0; i < N; i += 8) { if (i == 0) DP_DPP_BLOCK8("s_nop 4", "row_half_mirror"); else DP_DPP_BLOCK8("s_nop 1", "row_half_mirror"); }
 }
-
-/* v[i] <- lane (lane ^ 15)'s v[i]: DPP row_mirror reverses every row of sixteen lanes (see dp_mirror8_valu) */
+/* out[i] <- lane (lane ^ 15)'s in[i]: DPP row_mirror reverses every row of sixteen lanes */
 template <int N>
-DP_DEVICE void dp_mirror16_valu(float (&v)[N])
+DP_DEVICE void dp_mirror16_valu(const float (&in)[N], float (&out)[N])
 {
     static_assert(N % 8 == 0, "eight values at a time");
 #pragma unroll
-    for (int i = 0; i < N; i += 8)
-        __asm__("s_nop 4\n\t"
-                "v_mov_b32_dpp %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %1, %1 row_mirror row_mask:0xf bank_mask:0xf\n\t"
-                "v_mov_b32_dpp %2, %2 row_mirror row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %3, %3 row_mirror row_mask:0xf bank_mask:0xf\n\t"
-                "v_mov_b32_dpp %4, %4 row_mirror row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %5, %5 row_mirror row_mask:0xf bank_mask:0xf\n\t"
-                "v_mov_b32_dpp %6, %6 row_mirror row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %7, %7 row_mirror row_mask:0xf bank_mask:0xf"
-                : "+v"(v[i]), "+v"(v[i + 1]), "+v"(v[i + 2]), "+v"(v[i + 3]), "+v"(v[i + 4]), "+v"(v[i + 5]), "+v"(v[i + 6]), "+v"(v[i + 7]));
+    for (int i = 0; i < N; i += 8) { if (i == 0) DP_DPP_BLOCK8("s_nop 4", "row_mirror"); else DP_DPP_BLOCK8("s_nop 1", "row_mirror"); }
 }
+#undef DP_DPP_BLOCK8
 
 template <int N>
 DP_DEVICE void dp_shfl(double (&v)[N], int src)

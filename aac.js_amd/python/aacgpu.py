@@ -169,13 +169,14 @@ META_DTYPE = np.dtype(("<u2", (120,)))
 PARSE_APPLY_PULSES, PARSE_REFERENCE_QUIRKS, PARSE_SKIP_ZERO_FILL = 1, 2, 4
 
 
-def debug_transform(x, is_short=False, identity_rotation=False, sample_index=3, device=0):
-    """aacg_debug_transform: the kernels' IMDCT stage on one spectrum (1024 floats), windows forced to 1; returns 2048 floats."""
+def debug_transform(x, is_short=False, identity_rotation=False, sample_index=3, device=0, vm=False):
+    """aacg_debug_transform: the kernels' IMDCT stage on one spectrum (1024 floats), windows forced to 1; returns 2048 floats.
+    vm: the int16 seam's variant of the stage (mirror-lane exchanges as DPP, long columns dealt out by long_col)."""
     L = load_library()
     x = np.ascontiguousarray(x, np.float32)
     assert x.size == 1024
     out = np.zeros(2048, np.float32)
-    rc = L.aacg_debug_transform(device, sample_index, int(is_short), int(identity_rotation), x.ctypes.data, out.ctypes.data)
+    rc = L.aacg_debug_transform(device, sample_index, int(bool(is_short)) | (2 if vm else 0), int(identity_rotation), x.ctypes.data, out.ctypes.data)
     if rc:
         raise AacgError(rc, "aacg_debug_transform failed")
     return out

@@ -455,7 +455,8 @@ int aacg_plan_refresh_from_parse(aacg_engine* e, aacg_plan* p, const aacg_unit_d
  * short ones), windows forced to 1.  Long: out[0..2047] = the 2048 IMDCT outputs.  Short: out[128 w + i] =
  * y_(w-1)[128 + i] + y_w[i] (i < 128), so a window whose neighbours are zero shows its 256 outputs.  identity_rotation:
  * the pre / post rotations (mdct.js:73-76, 82-87) are replaced by the identity, which leaves the N/4-point complex inverse
- * FFT of z[k] = X[N/2-1-2k] + i X[2k] in the output order of mdct.js:90-114.  Nothing on the decode path calls this. */
+ * FFT of z[k] = X[N/2-1-2k] + i X[2k] in the output order of mdct.js:90-114.  is_short: bit 0 = eight short windows; bit 1 =
+ * the int16 seam's variant of the stage (mirror-lane exchanges as DPP moves, long columns dealt out by long_col).  Nothing on the decode path calls this. */
 int aacg_debug_transform(int device_ordinal, int sample_index, int is_short, int identity_rotation, const float* in, float* out);
 
 #ifdef __cplusplus

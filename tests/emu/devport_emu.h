@@ -68,8 +68,8 @@ DP_DEVICE void dp_shfl(float (&v)[N], int src)
     pthread_barrier_wait(&g_emu.w->bar);
 }
 
-template <int N> DP_DEVICE void dp_mirror8_valu(float (&v)[N]) { dp_shfl(v, g_emu.lane ^ 7); }
-template <int N> DP_DEVICE void dp_mirror16_valu(float (&v)[N]) { dp_shfl(v, g_emu.lane ^ 15); }
+template <int N> DP_DEVICE void dp_mirror8_valu(const float (&in)[N], float (&out)[N]) { for (int i = 0; i < N; i++) out[i] = in[i]; dp_shfl(out, g_emu.lane ^ 7); }
+template <int N> DP_DEVICE void dp_mirror16_valu(const float (&in)[N], float (&out)[N]) { for (int i = 0; i < N; i++) out[i] = in[i]; dp_shfl(out, g_emu.lane ^ 15); }
 
 template <int N>
 DP_DEVICE void dp_shfl(double (&v)[N], int src)

@@ -639,26 +639,33 @@ def _rel(a, b):
     return float(np.sqrt(np.mean((a - b) ** 2)) / np.sqrt(np.mean(b ** 2)))
 
 
-def test_imdct_2048_kat(golden):
+VM = pytest.mark.parametrize("vm", [False, True], ids=["f32-seam", "int16-seam"])
+
+
+@VM
+def test_imdct_2048_kat(golden, vm):
     """mdct.js:62-115, N = 2048: the kernels' long-window IMDCT alone against the reference's MDCT.process vectors.
-    Tolerance 5e-6 of the output RMS (the reference's own float32 twiddle recurrence is 1.3e-6 from exact)."""
+    Tolerance 5e-6 of the output RMS (the reference's own float32 twiddle recurrence is 1.3e-6 from exact).  Both variants of
+    the stage: the f32 seam's (mirror-lane exchange as ds_bpermute) and the int16 seam's (columns dealt out by long_col, DPP)."""
     for v in range(4):
-        got = aacgpu.debug_transform(golden["imdct2048.in"][v])
+        got = aacgpu.debug_transform(golden["imdct2048.in"][v], vm=vm)
         assert _rel(got, golden["imdct2048.out"][v]) < 5e-6
 
 
-def test_imdct_256_kat(golden):
+@VM
+def test_imdct_256_kat(golden, vm):
     """N = 256: four reference vectors as windows 0, 2, 4, 6 of one EIGHT_SHORT spectrum (odd windows zero: the window
     overlap then leaves every IMDCT's 256 outputs in the clear)."""
     x = np.zeros((8, 128), np.float32)
     x[0::2] = golden["imdct256.in"]
-    s = aacgpu.debug_transform(x.ravel(), is_short=True)[:1024].reshape(8, 128)
+    s = aacgpu.debug_transform(x.ravel(), is_short=True, vm=vm)[:1024].reshape(8, 128)
     for v in range(4):
         y = np.concatenate([s[2 * v], s[2 * v + 1]])
         assert _rel(y, golden["imdct256.out"][v]) < 5e-6
 
 
-def test_fft_512_kat(golden):
+@VM
+def test_fft_512_kat(golden, vm):
     """fft.js:105-192, 512 points, inverse, unscaled: with the MDCT rotations replaced by the identity the long-window stage is
     the FFT of z[k] = X[1023 - 2k] + i X[2k]; the reference's FFT.process vectors are fed through that map."""
     for v in range(3):
@@ -667,12 +674,13 @@ def test_fft_512_kat(golden):
         k = np.arange(512)
         X[1023 - 2 * k] = z[:, 0]
         X[2 * k] = z[:, 1]
-        re, im = _unreorder(aacgpu.debug_transform(X, identity_rotation=True).astype(np.float64), 2048)
+        re, im = _unreorder(aacgpu.debug_transform(X, identity_rotation=True, vm=vm).astype(np.float64), 2048)
         want = golden["fft512.out"][v].astype(np.float64)
         assert _rel(np.stack([re, im], 1), want) < 5e-6
 
 
-def test_fft_64_kat(golden):
+@VM
+def test_fft_64_kat(golden, vm):
     """64 points: three reference vectors as windows 0, 2, 4 of an EIGHT_SHORT spectrum, identity rotations."""
     x = np.zeros((8, 128), np.float32)
     k = np.arange(64)
@@ -680,7 +688,7 @@ def test_fft_64_kat(golden):
         z = golden["fft64.in"][v].astype(np.float32)
         x[2 * v, 127 - 2 * k] = z[:, 0]
         x[2 * v, 2 * k] = z[:, 1]
-    s = aacgpu.debug_transform(x.ravel(), is_short=True, identity_rotation=True)[:1024].reshape(8, 128).astype(np.float64)
+    s = aacgpu.debug_transform(x.ravel(), is_short=True, identity_rotation=True, vm=vm)[:1024].reshape(8, 128).astype(np.float64)
     for v in range(3):
         re, im = _unreorder(np.concatenate([s[2 * v], s[2 * v + 1]]), 256)
         assert _rel(np.stack([re, im], 1), golden["fft64.out"][v].astype(np.float64)) < 5e-6
