@@ -574,36 +574,63 @@ DP_DEVICE void long_pair(const float* tab, const chan_par& cp, bool want_head, f
     const int l = dp_lane();
     const float* sincos = tab + AACG_TAB_OFF_SINCOS_LONG;
 
+    /* Slot indices spelled out as a few lane-dependent bases plus compile-time offsets (which become the instructions'
+     * immediate offsets): left to itself the compiler rebuilt every swizzled index from the lane number, some 100 vector
+     * instructions per frame for index arithmetic alone. */
     cpx2 z[8];
+    {
+        /* stg(l + 64 j) = 64 j + (l ^ 8 (j & 3));  stg(511 - l - 64 j) = 64 (7 - j) + ((63 - l) ^ 8 (3 - (j & 3))) */
+        int eb[4], ob[4];
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
-        const cpx sc = lds_get(sincos, 64 * j + l);
-        const dpv2 xe = lds_pair(slot, stg(l + 64 * j));                  /* X[2k],        k = l + 64 j */
-        const dpv2 xo = lds_pair(slot, 512 + stg(511 - l - 64 * j));      /* X[1023 - 2k]               */
-        z[j].im = xe * v2s(sc.re) + xo * v2s(sc.im);                 /* mdct.js:74 */
-        z[j].re = xo * v2s(sc.re) - xe * v2s(sc.im);                 /* mdct.js:75 */
+        for (int m = 0; m < 4; m++) { eb[m] = l ^ (m << 3); ob[m] = (63 - l) ^ ((3 - m) << 3); }
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const cpx sc = lds_get(sincos, 64 * j + l);
+            const dpv2 xe = lds_pair(slot, 64 * j + eb[j & 3]);                       /* X[2k],        k = l + 64 j */
+            const dpv2 xo = lds_pair(slot, 512 + 64 * (7 - j) + ob[j & 3]);           /* X[1023 - 2k]               */
+            z[j].im = xe * v2s(sc.re) + xo * v2s(sc.im);             /* mdct.js:74 */
+            z[j].re = xo * v2s(sc.re) - xe * v2s(sc.im);             /* mdct.js:75 */
+        }
     }
     dp_wave_sync();
 
     radix8_inv2(z);
 #pragma unroll
     for (int q = 1; q < 8; q++) z[q] = c2_mul(z[q], lds_get(tab + AACG_TAB_OFF_TW512, 64 * (q - 1) + l));
+    {
+        const int w0 = l, w1 = l ^ 8;                  /* pch1(q, l) = 64 q + (l ^ 8 (q >> 1 & 1)) */
 #pragma unroll
-    for (int q = 0; q < 8; q++) lds_put2(slot, pch1(q, l), z[q]);
+        for (int q = 0; q < 8; q++) lds_put2(slot, 64 * q + ((q & 2) ? w1 : w0), z[q]);
+    }
     dp_wave_sync();
     const int l0 = l & 7, qq = l >> 3;
+    {
+        /* pch1(qq, l0 + 8 j) = 64 qq + l0 + 8 (j ^ (qq >> 1 & 1)): j even + 8, j odd - 8 where that bit is set */
+        const int q1 = (qq >> 1) & 1, r0 = 64 * qq + l0 + 8 * q1, r1 = 64 * qq + l0 - 8 * q1;
 #pragma unroll
-    for (int j = 0; j < 8; j++) z[j] = lds_get2(slot, pch1(qq, l0 + 8 * j));
+        for (int j = 0; j < 8; j++) z[j] = lds_get2(slot, ((j & 1) ? r1 : r0) + 8 * j);
+    }
     dp_wave_sync();
     radix8_inv2(z);
 #pragma unroll
     for (int r = 1; r < 8; r++) z[r] = c2_mul(z[r], lds_get(tab + AACG_TAB_OFF_TW64, 8 * (r - 1) + l0));
+    {
+        /* pch2(qq + 8 r, l0) = 64 r + 8 qq + (l0 ^ (qq >> 1) ^ 4 (r & 1)) */
+        const int e0 = 8 * qq + (l0 ^ (qq >> 1)), e1 = e0 ^ 4;
 #pragma unroll
-    for (int r = 0; r < 8; r++) lds_put2(slot, pch2(qq + 8 * r, l0), z[r]);
+        for (int r = 0; r < 8; r++) lds_put2(slot, 64 * r + ((r & 1) ? e1 : e0), z[r]);
+    }
     dp_wave_sync();
     const int c = VM ? long_col(l) : l;                /* this lane's column from here on */
+    {
+        /* pch2(c, i) = (8 c + (c >> 1 & 7)) ^ i, and with the slot 128-byte aligned the byte address is base ^ 16 i */
+        const int ab = dp_lds_addr(slot) + 16 * (8 * c + ((c >> 1) & 7));
 #pragma unroll
-    for (int i = 0; i < 8; i++) z[i] = lds_get2(slot, pch2(c, i));
+        for (int i = 0; i < 8; i++) {
+            const dpf4 t = dp_lds_read_f4(ab ^ (16 * i));
+            z[i].re = v2(t.x, t.y); z[i].im = v2(t.z, t.w);
+        }
+    }
     dp_wave_sync();
     radix8_inv2(z);
 
@@ -1620,7 +1647,7 @@ DP_DEVICE void imdct_run_body(const aacg_kparams& P)
     const aacg_run* run = P.runs + dp_block();
     float* lds = (float*)dp_lds();
     const float* tab = lds;
-    float* slots = lds + TAB_FLOATS;
+    float* slots = lds + AACG_TAB_SLOT_BASE(TAB_FLOATS);
     float* slot = slots + wave * AACG_SLOT_FLOATS;
     int* flags = (int*)(slots + AACG_WG_WAVES * AACG_SLOT_FLOATS);
     float* xch = EX ? (float*)(flags + AACG_WG_WAVES) + wave * AACG_RUN_XCH_FLOATS : nullptr;

@@ -122,6 +122,12 @@ DP_DEVICE unsigned char* dp_lds() { return dp_lds_raw; }
  * workgroup's allocation returns 0 (the LDS has no fault path). */
 DP_DEVICE int dp_lds_addr(const void* p) { return (int)(uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)p; }
 DP_DEVICE float dp_lds_read_f32(int a) { return *(__attribute__((address_space(3))) const float*)(uintptr_t)(uint32_t)a; }
+typedef float dp_lv4 __attribute__((ext_vector_type(4)));
+DP_DEVICE dpf4 dp_lds_read_f4(int a)                   /* ds_read_b128 on a computed address */
+{
+    const dp_lv4 v = *(__attribute__((address_space(3))) const dp_lv4*)(uintptr_t)(uint32_t)a;
+    dpf4 r; r.x = v[0]; r.y = v[1]; r.z = v[2]; r.w = v[3]; return r;
+}
 DP_DEVICE uint32_t dp_lds_read_u32(int a) { return *(__attribute__((address_space(3))) const uint32_t*)(uintptr_t)(uint32_t)a; }
 DP_DEVICE uint32_t dp_lds_read_u16(int a) { return *(__attribute__((address_space(3))) const uint16_t*)(uintptr_t)(uint32_t)a; }
 DP_DEVICE uint32_t dp_lds_read_u8(int a) { return *(__attribute__((address_space(3))) const uint8_t*)(uintptr_t)(uint32_t)a; }

@@ -101,6 +101,7 @@ DP_DEVICE float dp_lds_read_f32(int a)
     if (a < 0 || (size_t)a + 4 > g_emu.b->lds_bytes) return 0.0f;
     float v; memcpy(&v, g_emu.b->lds + a, 4); return v;
 }
+DP_DEVICE dpf4 dp_lds_read_f4(int a) { dpf4 v; memcpy(&v, g_emu.b->lds + a, 16); return v; }
 DP_DEVICE uint32_t dp_lds_read_u32(int a) { uint32_t v; memcpy(&v, g_emu.b->lds + a, 4); return v; }
 DP_DEVICE uint32_t dp_lds_read_u16(int a) { uint16_t v; memcpy(&v, g_emu.b->lds + a, 2); return v; }
 DP_DEVICE uint32_t dp_lds_read_u8(int a) { return g_emu.b->lds[a]; }
