@@ -1,5 +1,5 @@
-mkdir -p gpurun_out/r3d
-python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "kat or tables or spectral_stage or scenarios or fuzz" 2>&1 | tail -5 | tee gpurun_out/r3d/kat.log
-bash tools/ab.sh "" mirror.so addr.so 2>&1 | tee gpurun_out/r3d/ab_cfg2.log
-bash tools/ab.sh "--input spec" r2.so addr.so 2>&1 | tee gpurun_out/r3d/ab_spec.log
-bash tools/pmc_insts.sh "" addr.so 2>&1 | tee gpurun_out/r3d/pmc.log
+mkdir -p gpurun_out/r3e
+timeout 300 bash tools/ab.sh "" addr.so xpose2.so 2>&1 | tee gpurun_out/r3e/ab_cfg2.log
+timeout 300 bash tools/ab.sh "--workload cfg3" addr.so xpose2.so 2>&1 | tee gpurun_out/r3e/ab_cfg3.log
+timeout 300 bash tools/ab.sh "--workload cfg5" addr.so xpose2.so 2>&1 | tee gpurun_out/r3e/ab_cfg5.log
+timeout 200 bash tools/pmc_insts.sh "" xpose2.so 2>&1 | tee gpurun_out/r3e/pmc.log
