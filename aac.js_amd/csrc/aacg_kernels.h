@@ -641,8 +641,6 @@ DP_DEVICE void long_pair(const float* tab, const chan_par& cp, bool want_head, f
         R[r] = z[r].re * v2s(sc.re) - z[r].im * v2s(sc.im);          /* mdct.js:82-87 */
         I[r] = z[r].im * v2s(sc.re) + z[r].re * v2s(sc.im);
     }
-    shfl_pairs<VM ? 16 : 0>(R, I, 63 - l, mR, mI);
-
     if (cp.seq == AACG_ONLY_LONG_SEQUENCE) {
         /* the common case as straight-line code: with no branch between them the window reads of an iteration
          * are issued together instead of one LDS round trip each (filter_bank.js:109-116).  Reading all sixteen
@@ -656,11 +654,22 @@ DP_DEVICE void long_pair(const float* tab, const chan_par& cp, bool want_head, f
             const dpf2 w0 = *(const dpf2*)(wh + n), w1 = *(const dpf2*)(wh + n + 512);
             const dpf2 r0 = *(const dpf2*)(wt + 1022 - n), r1 = *(const dpf2*)(wt + 510 - n);   /* reversed: (w[1022-n], w[1023-n]) */
             hx[j]     = I[j + 4] * v2s(w0.x);
-            hy[j]     = -mR[3 - j] * v2s(w0.y);
             hx[j + 4] = R[j] * v2s(w1.x);
-            hy[j + 4] = -mI[7 - j] * v2s(w1.y);
-            const dpv2 t0 = R[j + 4] * v2s(r0.y), t1 = -mI[3 - j] * v2s(r0.x);
-            const dpv2 t2 = -I[j] * v2s(r1.y),    t3 = mR[7 - j] * v2s(r1.x);
+            const dpv2 t0 = R[j + 4] * v2s(r0.y), t2 = -I[j] * v2s(r1.y);
+            dpv2 t1, t3;
+            if (VM) {
+                /* the four values of the column 63 - c: fetched from the mirror lane and windowed in one instruction each */
+                const float src[8] = {R[3 - j][0], R[3 - j][1], I[7 - j][0], I[7 - j][1], I[3 - j][0], I[3 - j][1], R[7 - j][0], R[7 - j][1]};
+                const float wv[4] = {w0.y, w1.y, r0.x, r1.x};
+                float o[8];
+                dp_window_mirror<16>(src, wv, o, j == 0);
+                hy[j] = v2(o[0], o[1]); hy[j + 4] = v2(o[2], o[3]); t1 = v2(o[4], o[5]); t3 = v2(o[6], o[7]);
+            } else {
+                if (j == 0) shfl_pairs<0>(R, I, 63 - l, mR, mI);
+                hy[j]     = -mR[3 - j] * v2s(w0.y);
+                hy[j + 4] = -mI[7 - j] * v2s(w1.y);
+                t1 = -mI[3 - j] * v2s(r0.x); t3 = mR[7 - j] * v2s(r1.x);
+            }
             dpf4 o;
             o.x = t0[0]; o.y = t0[1]; o.z = t1[0]; o.w = t1[1];
             *(dpf4*)(slot + 2 * n) = o;
@@ -669,6 +678,7 @@ DP_DEVICE void long_pair(const float* tab, const chan_par& cp, bool want_head, f
         }
         return;
     }
+    shfl_pairs<VM ? 16 : 0>(R, I, 63 - l, mR, mI);
     /* LONG_START / LONG_STOP: the same loop with the sequence as a compile-time constant, so that the branches
      * inside head_window / tail_window fold and each iteration's window reads are issued together */
     if (cp.seq == AACG_LONG_START_SEQUENCE) long_pair_window<AACG_LONG_START_SEQUENCE>(tab, cp, want_head, slot, c, R, I, mR, mI, hx, hy);
@@ -711,7 +721,7 @@ DP_DEVICE void short_pair(const float* tab, const chan_par& cp, float* slot, dpv
         R[r] = z[r].re * v2s(sc.re) - z[r].im * v2s(sc.im);
         I[r] = z[r].im * v2s(sc.re) + z[r].re * v2s(sc.im);
     }
-    shfl_pairs<VM ? 8 : 0>(R, I, l ^ 7, mR, mI);
+    if (!VM) shfl_pairs<0>(R, I, l ^ 7, mR, mI);
 
     const float* ws = tab + AACG_TAB_OFF_WIN_SHORT + 128 * cp.shape;
     const float* wh = (w == 0) ? tab + AACG_TAB_OFF_WIN_SHORT + 128 * cp.shape_prev : ws;
@@ -722,13 +732,22 @@ DP_DEVICE void short_pair(const float* tab, const chan_par& cp, float* slot, dpv
         const dpf2 h0 = *(const dpf2*)(wh + i), h1 = *(const dpf2*)(wh + i + 64);
         const dpf2 t0 = *(const dpf2*)(ws + 126 - i), t1 = *(const dpf2*)(ws + 62 - i);
         hd[j]         = I[j + 4] * v2s(h0.x);
-        hd[8 + j]     = -mR[3 - j] * v2s(h0.y);
         hd[j + 4]     = R[j] * v2s(h1.x);
-        hd[8 + j + 4] = -mI[7 - j] * v2s(h1.y);
         tl[j]         = R[j + 4] * v2s(t0.y);
-        tl[8 + j]     = -mI[3 - j] * v2s(t0.x);
         tl[j + 4]     = -I[j] * v2s(t1.y);
-        tl[8 + j + 4] = mR[7 - j] * v2s(t1.x);
+        if (VM) {
+            /* the values of lane ^ 7 (the window's column 63 - k), fetched and windowed in one instruction each */
+            const float src[8] = {R[3 - j][0], R[3 - j][1], I[7 - j][0], I[7 - j][1], I[3 - j][0], I[3 - j][1], R[7 - j][0], R[7 - j][1]};
+            const float wv[4] = {h0.y, h1.y, t0.x, t1.x};
+            float o[8];
+            dp_window_mirror<8>(src, wv, o, j == 0);
+            hd[8 + j] = v2(o[0], o[1]); hd[8 + j + 4] = v2(o[2], o[3]); tl[8 + j] = v2(o[4], o[5]); tl[8 + j + 4] = v2(o[6], o[7]);
+        } else {
+            hd[8 + j]     = -mR[3 - j] * v2s(h0.y);
+            hd[8 + j + 4] = -mI[7 - j] * v2s(h1.y);
+            tl[8 + j]     = -mI[3 - j] * v2s(t0.x);
+            tl[8 + j + 4] = mR[7 - j] * v2s(t1.x);
+        }
     }
     /* s[128 w + i] = tail of block w-1 + head of block w (filter_bank.js:155-160) */
     float pa[16], pb[16];

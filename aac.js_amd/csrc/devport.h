@@ -108,6 +108,28 @@ DP_DEVICE void dp_mirror16_valu(const float (&in)[N], float (&out)[N])
 }
 #undef DP_DPP_BLOCK8
 
+/* The reorder + window step of the IMDCT for the values that come from the mirror lane (mdct.js:90-114 with
+ * filter_bank.js:109-116): out[2k + c] = s_k * (mirror lane's src[2k + c]) * w[k], signs s = (-, -, -, +), as ONE
+ * v_mul_f32 per value with the DPP control on its first operand — instead of a DPP move per value plus a packed
+ * multiply per pair.  One rounding, like the separate multiply.  MIRROR: 16 = lane ^ 15 (row_mirror), 8 = lane ^ 7. */
+template <int MIRROR>
+DP_DEVICE void dp_window_mirror(const float (&src)[8], const float (&w)[4], float (&out)[8], bool first)
+{
+    static_assert(MIRROR == 16 || MIRROR == 8, "row_mirror or row_half_mirror");
+#define DP_WM_BLOCK(NOP, CTL) \
+    __asm__ volatile(NOP "\n\t" \
+            "v_mul_f32_dpp %0, -%8, %16 " CTL " row_mask:0xf bank_mask:0xf\n\tv_mul_f32_dpp %1, -%9, %16 " CTL " row_mask:0xf bank_mask:0xf\n\t" \
+            "v_mul_f32_dpp %2, -%10, %17 " CTL " row_mask:0xf bank_mask:0xf\n\tv_mul_f32_dpp %3, -%11, %17 " CTL " row_mask:0xf bank_mask:0xf\n\t" \
+            "v_mul_f32_dpp %4, -%12, %18 " CTL " row_mask:0xf bank_mask:0xf\n\tv_mul_f32_dpp %5, -%13, %18 " CTL " row_mask:0xf bank_mask:0xf\n\t" \
+            "v_mul_f32_dpp %6, %14, %19 " CTL " row_mask:0xf bank_mask:0xf\n\tv_mul_f32_dpp %7, %15, %19 " CTL " row_mask:0xf bank_mask:0xf" \
+            : "=&v"(out[0]), "=&v"(out[1]), "=&v"(out[2]), "=&v"(out[3]), "=&v"(out[4]), "=&v"(out[5]), "=&v"(out[6]), "=&v"(out[7]) \
+            : "v"(src[0]), "v"(src[1]), "v"(src[2]), "v"(src[3]), "v"(src[4]), "v"(src[5]), "v"(src[6]), "v"(src[7]), \
+              "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]))
+    if (MIRROR == 16) { if (first) DP_WM_BLOCK("s_nop 4", "row_mirror"); else DP_WM_BLOCK("s_nop 1", "row_mirror"); }
+    else              { if (first) DP_WM_BLOCK("s_nop 4", "row_half_mirror"); else DP_WM_BLOCK("s_nop 1", "row_half_mirror"); }
+#undef DP_WM_BLOCK
+}
+
 template <int N>
 DP_DEVICE void dp_shfl(double (&v)[N], int src)
 {

@@ -71,6 +71,16 @@ DP_DEVICE void dp_shfl(float (&v)[N], int src)
 template <int N> DP_DEVICE void dp_mirror8_valu(const float (&in)[N], float (&out)[N]) { for (int i = 0; i < N; i++) out[i] = in[i]; dp_shfl(out, g_emu.lane ^ 7); }
 template <int N> DP_DEVICE void dp_mirror16_valu(const float (&in)[N], float (&out)[N]) { for (int i = 0; i < N; i++) out[i] = in[i]; dp_shfl(out, g_emu.lane ^ 15); }
 
+/* out[2k + c] = s_k * (mirror lane's src[2k + c]) * w[k], s = (-, -, -, +)  (devport.h) */
+template <int MIRROR>
+DP_DEVICE void dp_window_mirror(const float (&src)[8], const float (&w)[4], float (&out)[8], bool)
+{
+    float m[8];
+    for (int i = 0; i < 8; i++) m[i] = src[i];
+    dp_shfl(m, g_emu.lane ^ (MIRROR - 1));
+    for (int i = 0; i < 8; i++) out[i] = (i < 6 ? -m[i] : m[i]) * w[i >> 1];
+}
+
 template <int N>
 DP_DEVICE void dp_shfl(double (&v)[N], int src)
 {
