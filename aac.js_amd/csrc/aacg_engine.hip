@@ -187,6 +187,34 @@ bool needs_spec_buffer(const aacg_engine* e, const aacg_plan_host& h)
     return h.any_cce_dependent || (stages && (i16 || h.any_cce || h.needs_scratch));
 }
 
+/* The launches launch_run makes for a plan, by kernel name: what a rocprofv3 kernel trace of the batch shows. */
+std::string route_names(const aacg_engine* e, const aacg_plan_host& h)
+{
+    const bool i16 = e->cfg.output_kind == AACG_OUTPUT_I16;
+    bool quant = e->cfg.input_kind == AACG_INPUT_QUANT_I16, ex = false;
+    const bool stages = h.any_tns || (quant && h.any_pns);
+    std::string r;
+    auto add = [&](const std::string& k) { if (!r.empty()) r += " + "; r += k; };
+    if (h.any_cce_dependent) {
+        add(quant ? "aacg_spectral_ex_quant" : "copy");
+        add("aacg_couple_spec");
+        if (h.any_tns) add("aacg_spectral_ex_f32");
+        quant = false;
+    } else if (stages && !i16 && !h.any_cce && !h.needs_scratch) {
+        ex = true;
+    } else if (stages) {
+        add(quant ? "aacg_spectral_ex_quant" : "aacg_spectral_ex_f32");
+        quant = false;
+    }
+    const std::string run = std::string("aacg_imdct_run_") + (quant ? "quant" : "f32");
+    if (!h.runs.empty()) add(run + (ex ? "_ex" : "") + (!ex && h.needs_scratch ? "_dd" : "") + (!ex && i16 ? "_i16" : ""));
+    if (h.any_cce) {
+        if (!h.cce_runs.empty()) add(run + " (coupling elements)");
+        add("aacg_couple_pcm");
+    }
+    return r;
+}
+
 /* enqueue the run kernel for a planned batch (device pointers) */
 int launch_run(aacg_engine* e, const aacg_dev_unit* d_units, const aacg_run* d_runs, const aacg_dev_tns* d_tns,
                float* d_scratch, float* d_spec, const cce_bufs& cb, const aacg_plan_host& h, const void* d_coeffs, const aacg_band_meta* d_meta,
@@ -277,6 +305,15 @@ extern "C" {
 int aacg_abi_version(void) { return AACG_ABI_VERSION; }
 
 const char* aacg_kernel_name(void) { return "aacg_imdct_run_quant"; }
+
+int aacg_plan_kernels(aacg_engine* e, const aacg_plan* p, char* dst, size_t n)
+{
+    if (!e || !p || p->e != e || !dst || n == 0) return AACG_ERR_INVALID_ARG;
+    const std::string r = route_names(e, p->h);
+    if (r.size() + 1 > n) return AACG_ERR_INVALID_ARG;
+    std::memcpy(dst, r.c_str(), r.size() + 1);
+    return AACG_OK;
+}
 
 const char* aacg_last_error(const aacg_engine* e) { return e ? e->err.c_str() : "null engine"; }
 

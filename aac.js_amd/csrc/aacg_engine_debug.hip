@@ -73,3 +73,22 @@ extern "C" int aacg_debug_transform(int device_ordinal, int sample_index, int is
     if (d_out) (void)hipFree(d_out);
     return rc;
 }
+
+/* Calibration for bench.py: a float4 copy with the run kernels' launch shape (one 1024-thread workgroup per CU, 16-byte
+ * loads, 16-byte non-temporal stores) — what this box's memory system delivers for a launch of a given byte volume, timed
+ * beside the run kernel in the same process.  Nothing on the decode path calls this. */
+extern "C" __global__ __launch_bounds__(1024)
+void aacg_calib_copy_kernel(dpf4* dst, const dpf4* src, size_t n4)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) dp_store_nt(dst + i, src[i]);
+}
+
+extern "C" int aacg_calib_copy(void* d_dst, const void* d_src, size_t bytes, void* hip_stream)
+{
+    if (!d_dst || !d_src || (bytes & 15u)) return AACG_ERR_INVALID_ARG;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    hipLaunchKernelGGL(aacg_calib_copy_kernel, dim3((unsigned)cus), dim3(1024), 0, (hipStream_t)hip_stream, (dpf4*)d_dst, (const dpf4*)d_src, bytes / 16);
+    return hipGetLastError() == hipSuccess ? AACG_OK : AACG_ERR_NO_DEVICE;
+}

@@ -26,7 +26,7 @@ ABI_SYMBOLS = ["aacg_create", "aacg_destroy", "aacg_last_error", "aacg_abi_versi
                "aacg_decode_device", "aacg_spectral_device", "aacg_synchronize", "aacg_get_table", "aacg_kernel_name",
                "aacg_parser_create", "aacg_parser_destroy", "aacg_parser_last_error", "aacg_parse_status_string",
                "aacg_parse_batch", "aacg_parse_device", "aacg_parse_kernel_name", "aacg_plan_refresh_from_parse", "aacg_standard_codebooks", "aacg_debug_transform",
-               "aacg_decode_batch_ex", "aacg_submit_ex", "aacg_plan_create_ex"]
+               "aacg_decode_batch_ex", "aacg_submit_ex", "aacg_plan_create_ex", "aacg_plan_kernels", "aacg_calib_copy"]
 
 UNIT_DTYPE = np.dtype([
     ("stream", "<u4"), ("pcm_offset", "<u4"), ("channel", "<u2"), ("n_out_ch", "<u2"),
@@ -108,6 +108,8 @@ def load_library(path=LIB_PATH):
     L = C.CDLL(path)
     L.aacg_abi_version.restype = C.c_int
     L.aacg_kernel_name.restype = C.c_char_p
+    L.aacg_plan_kernels.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.c_size_t]
+    L.aacg_calib_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     L.aacg_last_error.restype = C.c_char_p
     L.aacg_last_error.argtypes = [C.c_void_p]
     L.aacg_create.argtypes = [C.POINTER(Config), C.POINTER(C.c_void_p)]
@@ -180,6 +182,13 @@ def debug_transform(x, is_short=False, identity_rotation=False, sample_index=3, 
     if rc:
         raise AacgError(rc, "aacg_debug_transform failed")
     return out
+
+
+def calib_copy(d_dst, d_src, n_bytes, stream=0):
+    """aacg_calib_copy: float4 device-to-device copy with the run kernels' launch shape, enqueued on `stream`."""
+    rc = load_library().aacg_calib_copy(d_dst, d_src, n_bytes, stream)
+    if rc:
+        raise AacgError(rc, "aacg_calib_copy failed")
 
 
 def standard_codebooks():
@@ -424,3 +433,9 @@ class Engine:
 
     def kernel_name(self):
         return self.lib.aacg_kernel_name().decode()
+
+    def plan_kernels(self, plan):
+        """The launches aacg_decode_device makes for this plan, by kernel name (what a rocprofv3 kernel trace shows)."""
+        buf = C.create_string_buffer(512)
+        self._check(self.lib.aacg_plan_kernels(self.handle, plan.handle, buf, 512))
+        return buf.value.decode()

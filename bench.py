@@ -47,24 +47,6 @@ def algorithmic_bytes_per_channel_frame(kind, chain_frames, pcm="f32"):
     return (4096 if kind == "spec" else 2048 + 240) + (2048 if pcm == "i16" else 4096) + 8192.0 / chain_frames
 
 
-def kernels_of_route(kind, tns, cce, i16, long_chains=False):
-    """The launches of one step (launch_run in aac.js_amd/csrc/aacg_engine.hip): the plain run kernel (its double-duty
-    build for chains longer than a run); with TNS records the run kernel that carries the optional stages; with int16 PCM,
-    coupling elements or long chains beside TNS, the stages as a launch of their own in front of the f32 run kernel;
-    coupling elements add their own filterbank pass and the coupling kernel."""
-    dd = "_dd" if long_chains else ""
-    run = "aacg_imdct_run_%s" % ("quant" if kind == "quant" else "f32")
-    if tns and (i16 or cce or long_chains):
-        k = "aacg_spectral_ex_%s + aacg_imdct_run_f32%s%s" % ("quant" if kind == "quant" else "f32", dd, "_i16" if i16 else "")
-    elif tns:
-        k = run + "_ex"
-    else:
-        k = run + dd + ("_i16" if i16 else "")
-    if cce:
-        k += " + %s (coupling elements) + aacg_couple_pcm" % (run if not tns else "aacg_imdct_run_f32")
-    return k
-
-
 def measured_traffic(kind):
     """HBM bytes per launch from the PMC counters (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, separate rocprofv3
     --pmc passes of this same command, tools/prof.sh); bench.py cannot run the profiler on itself, so the
@@ -184,6 +166,9 @@ def main():
     # profiling switches of a -DAACG_PROFILE build must never reach a timed run
     if os.environ.pop("AACG_ABLATE", None) is not None:
         print("bench.py: AACG_ABLATE ignored (work-skipping switches are for tools/ only)", file=sys.stderr)
+    # the workload generator's diagnostic override of the config-3 window-sequence pattern: allowed (tools/ use it), but never
+    # silently — it is recorded in config.workload_override and the line then no longer claims a BASELINE configuration
+    seq_override = os.environ.get("AACG_SEQ_PATTERN") or None
 
     import numpy as np
     import torch
@@ -291,6 +276,28 @@ def main():
     event_s = aacgpu_shard.reduce_max(dist, ev0.elapsed_time(ev1) * 1e-3, dev)        # the K steps on the launch stream, MAX over ranks
     kernel_ms = ev0.elapsed_time(ev1) / args.steps
 
+    # Same process, same box, same clocks, right behind the timed region (untimed itself): what this box's memory system
+    # gives a float4 copy launch of the step's byte volume (half read, half written; buffers rotated past the Infinity
+    # Cache like the step's), and a 1 GiB copy for the streaming rate.  Boxes of the pool differ by several per cent
+    # (DESIGN.md 5); `frac_of_copy` = achieved / copy_ceiling is the figure that does not move with them.
+    def copy_rate(n_bytes, n_sets, reps):
+        n_bytes = int(n_bytes) // 16 * 16
+        src = [torch.empty(n_bytes, dtype=torch.uint8, device="cuda").random_(0, 255) for _ in range(n_sets)]
+        dst = [torch.empty(n_bytes, dtype=torch.uint8, device="cuda") for _ in range(n_sets)]
+        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for i in range(max(2, reps // 10)):
+            aacgpu.calib_copy(dst[i % n_sets].data_ptr(), src[i % n_sets].data_ptr(), n_bytes, tstream.cuda_stream)
+        c0.record()
+        for i in range(reps):
+            aacgpu.calib_copy(dst[i % n_sets].data_ptr(), src[i % n_sets].data_ptr(), n_bytes, tstream.cuda_stream)
+        c1.record()
+        torch.cuda.synchronize()
+        return 2.0 * n_bytes / (c0.elapsed_time(c1) * 1e-3 / reps) / 1e9, c0.elapsed_time(c1) / reps
+
+    abytes_step = algorithmic_bytes_per_channel_frame(args.input, n_frames, args.output) * n_streams * n_frames * n_chan
+    copy_gbs, copy_ms = copy_rate(abytes_step / 2, max(2, args.nbuf), max(200, min(args.steps, 4000)))
+    copy_large_gbs, _ = copy_rate(1 << 29, 2, 20)
+
     # untimed: the last output is finite and non-trivial; then the oracle comparison on the bench's own batch
     out = bufs[(n_pre + args.warmup + args.steps - 1) % args.nbuf][1]
     ok = bool(torch.isfinite(out.float()).all().item()) and float(out.float().abs().max().item()) > 0
@@ -325,6 +332,7 @@ def main():
                                 "cfg3": "BASELINE config 3: 4096 stereo frames, window-sequence mix [0,0,1,2,2,3,0,0], TNS identity",
                                 "cfg4": "BASELINE config 4 shape per GPU: 32 streams x 128 frames, config-3 mix",
                                 "cfg5": "BASELINE config 5 shape per GPU: 4096 frames of 3 CPE + LFE (7 channels), config-3 mix"}[args.workload],
+                   "workload_override": ("AACG_SEQ_PATTERN=%s: NOT the BASELINE window-sequence mix" % seq_override) if (seq_override and mix) else None,
                    "input": "int16 quantised spectra + band side info (process(elements) seam)" if args.input == "quant"
                    else "f32 spectra (FilterBank.process seam)",
                    "output": "float32 PCM as the reference returns it" if args.output == "f32" else "int16 PCM (AACG_OUTPUT_I16)",
@@ -335,10 +343,15 @@ def main():
                           else "AACG_TNS_SPEC, every channel-frame: long one filter of order 12 over 20 bands, short one of order 7 per window",
                    "coupling": "none applied, as the reference executes it" if cce is None
                                else "AACG_CCE_SPEC: one independently switched coupling element per frame into 1-4 channels",
-                   "collectives": "none on the data path; %s barrier + 8-byte MAX around the timed region" % (dist.get_backend() if dist is not None else "no")},
+                   "collectives": "none on the data path; %s" % (("%s barrier + 8-byte MAX around the timed region, world size %d as the backend reports it"
+                                                                   % (dist.get_backend(), dist.get_world_size())) if dist is not None else "single process, no process group")},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                     "kernel": kernels_of_route(args.input, tns is not None, cce is not None, args.output == "i16", n_frames > 16),
+                     "copy_ceiling_GBs": copy_gbs, "frac_of_copy": achieved / copy_gbs, "copy_ms": copy_ms,
+                     "copy_ceiling_note": "aacg_calib_copy: float4 copy of the step's algorithmic byte volume (half read, half written) with the run "
+                                          "kernel's launch shape, %d launches right behind the timed region on the same stream; 1 GiB copy: %.0f GB/s" % (max(200, min(args.steps, 4000)), copy_large_gbs),
+                     "copy_ceiling_large_GBs": copy_large_gbs,
+                     "kernel": eng.plan_kernels(plans[0]),
                      "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": abytes,
                      "host_enqueue_us_per_step": issued[0] / args.steps * 1e6},
         "output_ok": ok, "parity_rms": parity["rms"] if parity else None, "parity": parity,

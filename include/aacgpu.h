@@ -332,8 +332,13 @@ int aacg_synchronize(aacg_engine* e, void* hip_stream);
 /* Copies the engine's host-built tables (what the device kernels read) for table KATs.
  * which: 0 IQ[8191], 1 SF[428], 2 sine1024, 3 kbd1024, 4 sine128, 5 kbd128               */
 int aacg_get_table(aacg_engine* e, int which, float* dst, size_t n);
-/* Name of the dominant kernel (for matching rocprofv3 rows).                            */
+/* Name of the dominant kernel of the headline route (for matching rocprofv3 rows).      */
 const char* aacg_kernel_name(void);
+/* The launches aacg_decode_device makes for this plan, by kernel name, " + " between them (dst: n bytes). */
+int aacg_plan_kernels(aacg_engine* e, const aacg_plan* p, char* dst, size_t n);
+/* Calibration for the bench: a float4 copy of `bytes` (multiple of 16) device to device with the run kernels' launch
+ * shape, enqueued on hip_stream.  Gives the copy rate of THIS box for a launch of that size, next to the run kernel. */
+int aacg_calib_copy(void* d_dst, const void* d_src, size_t bytes, void* hip_stream);
 
 
 /* ---- the bitstream front end on the device (optional; independent of aacg_engine) ---------------
