@@ -256,6 +256,11 @@ int aacg_plan_build(const aacg_unit_desc* units, uint32_t n_units, int sample_in
                 const aacg_cce_info& ci = cce[u.reserved1];
                 for (int t = 0; t < ci.n_targets; t++) {
                     const uint32_t tch = ci.target[t].channel;
+                    /* one coupling element's jobs share a launch, and a launch must not add to one channel twice (a
+                     * read-modify-write race, and the reference's order of additions would be lost): a coupling element
+                     * that names a channel twice is refused (cce.js:56-66 lists distinct targets) */
+                    for (int t2 = 0; t2 < t; t2++)
+                        if (ci.target[t2].channel == tch) return fail(err, AACG_ERR_INVALID_ARG, "unit %ld: coupling element lists target channel %ld twice", i, tch);
                     int32_t target = -1;
                     for (uint32_t j : fr.second)
                         if (!(units[j].flags & AACG_UNIT_CCE) && tch >= units[j].channel && tch < (uint32_t)units[j].channel + units[j].n_ch) target = (int32_t)j;

@@ -12,7 +12,7 @@
  *
  * Decoder: Aurora constructs it with (demuxer, format), appends the demuxer's 'data' buffers to this.stream, and calls
  * init(), setCookie(buffer), readChunk().  The wrapper moves whatever bytes have arrived from this.stream to the
- * bitstream front end (ADTS bytes for formatID 'aac ', one raw_data_block per buffer for 'mp4a') and serves frames from
+ * bitstream front end (ADTS bytes for formatID 'aac ', the demuxer's buffers of one or more raw_data_blocks for 'mp4a') and serves frames from
  * GpuAACDecoder.readChunk(): a Float32Array of 1024 * channels samples, null when no complete frame is buffered (Aurora
  * then waits for more data and calls again), or the reference's Error for a malformed frame.  Aurora rewinds the
  * stream after a null — bytes already handed to the front end are skipped, not fed twice.
@@ -35,7 +35,7 @@ function register(AV, options) {
             this.impl = new host.GpuAACDecoder(Object.assign({}, options, { format: this.format, frontend: frontend, engine: options.engine ? options.engine() : null }));
             this.impl.init();                                   // format.floatingPoint = true (decoder.js:49-51)
             this.fed = 0;                                       // absolute stream offset up to which bytes went to the front end
-            this.packets = this.format.formatID === 'mp4a';     // MP4 samples arrive one per buffer; ADTS is a byte stream
+            this.packets = this.format.formatID === 'mp4a';     // MP4 samples arrive as buffers of whole samples; ADTS is a byte stream
         };
 
         this.prototype.setCookie = function (buffer) {
@@ -48,7 +48,7 @@ function register(AV, options) {
             if (s.offset < this.fed) s.advance(this.fed - s.offset);            // Aurora rewound after a null: those bytes are in already
             while (s.available(1)) {
                 const buf = this.packets ? s.readSingleBuffer(s.remainingBytes()) : s.readBuffer(s.remainingBytes());
-                if (this.packets) this.impl.feedPacket(buf); else this.impl.feed(buf);
+                if (this.packets) this.impl.feedPacket(buf, true); else this.impl.feed(buf);   // an M4A demuxer's buffer: one sample or a chunk of them
             }
             this.fed = s.offset;
             return this.impl.readChunk();

@@ -90,7 +90,10 @@ FrontEnd.prototype.push = function (bytes) {
     joined.set(this.buf); joined.set(bytes, this.buf.length);
     this.buf = joined;
 };
-FrontEnd.prototype.pushPacket = function (bytes) { this.packets.push(bytes); };
+/* pushPacket(bytes): one raw_data_block (an MP4 sample).  pushPacket(bytes, true): whatever an MP4 demuxer emitted — a
+ * buffer that may hold several byte-aligned raw_data_blocks back to back (Aurora's M4A demuxer emits a chunk's contiguous
+ * samples as one buffer); parseFrame() then goes on behind a block where the reference's bitstream would. */
+FrontEnd.prototype.pushPacket = function (bytes, multi) { this.packets.push({ bytes: bytes, multi: !!multi }); };
 
 FrontEnd.prototype.offsets = function (sampleIndex, short) {
     const key = sampleIndex * 2 + (short ? 1 : 0);
@@ -371,9 +374,14 @@ FrontEnd.prototype.parseRawDataBlock = function (bits, config) {
 FrontEnd.prototype.parseFrame = function (decoder) {
     const config = decoder.config;
     if (this.packets.length) {
-        const bytes = this.packets.shift(), bits = new BitStream(bytes);
+        /* A multi-block packet: the reference keeps reading from the same bitstream after END_ELEMENT + align()
+         * (decoder.js:129-199); here the rest of the packet goes back to the head of the queue.  A block that fails to
+         * parse takes the rest of its packet with it. */
+        const p = this.packets.shift(), bytes = p.bytes, bits = new BitStream(bytes);
         if (bits.peek(12) === 0xfff) adts.readHeader(bits);                              // decoder.js:129-130
-        return this.parseRawDataBlock(bits, config);
+        const frame = this.parseRawDataBlock(bits, config), used = frame.bitsUsed >>> 3;
+        if (p.multi && used < bytes.length) this.packets.unshift({ bytes: bytes.subarray(used), multi: true });
+        return frame;
     }
     const buf = this.buf;
     if (buf.length < 7) return null;

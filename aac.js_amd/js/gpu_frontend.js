@@ -38,7 +38,7 @@ GpuFrontEnd.prototype.push = function (bytes) {
     joined.set(this.buf); joined.set(bytes, this.buf.length);
     this.buf = joined;
 };
-GpuFrontEnd.prototype.pushPacket = function (bytes) { this.packets.push(bytes); };
+GpuFrontEnd.prototype.pushPacket = function (bytes, multi) { this.packets.push({ bytes: bytes, multi: !!multi }); };   // multi: see FrontEnd.pushPacket
 
 /* parse everything that is complete: fills this.queue with frame objects or Error objects */
 GpuFrontEnd.prototype.fill = function (config) {
@@ -47,14 +47,14 @@ GpuFrontEnd.prototype.fill = function (config) {
         this.parser = this.addon.parserCreate({ deviceOrdinal: this.deviceOrdinal, sampleIndex: config.sampleIndex }, rec.entries, rec.counts);
         this.sampleIndex = config.sampleIndex;
     }
-    let bytes, table;
+    let bytes, table, take = null;
     if (this.packets.length) {
-        const take = this.packets.splice(0, this.batch);
+        take = this.packets.splice(0, this.batch);
         let total = 0;
-        for (const p of take) total += p.length;
+        for (const p of take) total += p.bytes.length;
         bytes = new Uint8Array(total); table = new Uint32Array(2 * take.length);
         let at = 0;
-        take.forEach(function (p, i) { bytes.set(p, at); table[2 * i] = at; table[2 * i + 1] = p.length; at += p.length; });
+        take.forEach(function (p, i) { bytes.set(p.bytes, at); table[2 * i] = at; table[2 * i + 1] = p.bytes.length; at += p.bytes.length; });
     } else {
         const list = adts.frames(this.buf).slice(0, this.batch);
         if (!list.length) {
@@ -70,7 +70,22 @@ GpuFrontEnd.prototype.fill = function (config) {
     const units = new Uint8Array(n * U * UNIT_BYTES), q = new Int16Array(n * C * FRAME), meta = new Uint16Array(n * C * META_WORDS);
     const tns = this.wantTns ? new Uint8Array(n * C * TNS_BYTES) : null, results = new Uint8Array(8 * n);
     this.addon.parseBatch(this.parser, bytes, table, U, C, this.options, units, q, meta, tns, results);
-    for (let f = 0; f < n; f++) {
+    /* A multi-block packet may hold several byte-aligned raw_data_blocks back to back (Aurora's M4A demuxer emits a chunk's contiguous
+     * samples in one buffer; the reference reads on from the same bitstream, decoder.js:129-199).  The device parses the
+     * first block of every packet; where bits are left over, the frames behind that packet wait and the rest of the batch
+     * is re-queued in order with the packet's remainder in front, to be parsed by the next fill(). */
+    let limit = n;
+    if (take) {
+        const view = new DataView(results.buffer, results.byteOffset, results.byteLength);
+        for (let f = 0; f < n && limit === n; f++) {
+            const used = (view.getUint32(8 * f + 4, true) + 7) >>> 3;
+            if (take[f].multi && !results[8 * f] && used < take[f].bytes.length) {
+                this.packets = [{ bytes: take[f].bytes.subarray(used), multi: true }].concat(take.slice(f + 1), this.packets);
+                limit = f + 1;
+            }
+        }
+    }
+    for (let f = 0; f < limit; f++) {
         const status = results[8 * f], nUnits = results[8 * f + 1], nCh = results[8 * f + 2];
         if (status) { this.queue.push(new Error(this.addon.parseStatusString(status))); continue; }
         const frame = { elements: [], q: q.slice(f * C * FRAME, (f * C + nCh) * FRAME), meta: meta.slice(f * C * META_WORDS, (f * C + nCh) * META_WORDS) };

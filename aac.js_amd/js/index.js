@@ -347,13 +347,27 @@ GpuAACDecoder.prototype.decodeAhead = function () {
     if (this.config.profile === 1) throw new Error('Main prediction unimplemented');
     if (this.config.profile === 4) throw new Error('LTP prediction unimplemented');
     const C = this.config.chanConfig, frames = [], tnsList = this.tnsMode === TNS_SPEC ? [] : null, cceList = this.cceMode === CCE_SPEC ? [] : null;
-    let units = [], block = 0, failed = null;
+    let units = [], block = 0, failed = null, layout = null;
+    /* the elements that carry state from frame to frame (overlap-add): which ones a frame has, in order.  A batch is one
+     * chain per element for the planner — an element (a coupling element with its own filterbank included) that appears
+     * or disappears ends the batch; the frame that differs starts the next one (it waits in this.pendingFrame). */
+    const layoutOf = function (f) {
+        let k = 0;                                      // coupling elements count from stream channel C on, in frame order
+        return f.elements.map(function (e) {
+            if (e.couplingPoint === undefined) return e.type + e.id;
+            return e.couplingPoint === 2 ? 'cce@' + k++ : (k++, '');     // dependent coupling (spectral domain) carries no state
+        }).join(',');
+    };
     while (frames.length < this.lookahead) {
         /* both front ends have consumed a frame by the time they throw for it, and return null on underflow: an
          * exception here is a malformed (or unsupported) frame, kept in order behind the frames parsed so far */
         try {
-            const f = this.frontend.parseFrame(this);
+            const f = this.pendingFrame || this.frontend.parseFrame(this);
+            this.pendingFrame = null;
             if (!f) break;
+            const sig = layoutOf(f);
+            if (layout !== null && sig !== layout) { this.pendingFrame = f; break; }
+            layout = sig;
             units = units.concat(this.unitsOfFrame(f, frames.length, block, tnsList, cceList));
             block += f.q.length / FRAME;
             frames.push(f);
@@ -364,16 +378,22 @@ GpuAACDecoder.prototype.decodeAhead = function () {
         let b = 0;
         for (const f of frames) { q.set(f.q, b * FRAME); meta.set(f.meta, b * META_WORDS); b += f.q.length / FRAME; }
         const pcm = new Float32Array(frames.length * FRAME * C);
-        this.engine.decodeBatch(packUnits(units), q, meta, pcm, tnsList && tnsList.length ? packTns(tnsList) : null,
-                                cceList && cceList.length ? packCce(cceList) : null);
-        for (let i = 0; i < frames.length; i++) this.queue.push(pcm.slice(i * FRAME * C, (i + 1) * FRAME * C));   // caller owns each array
+        /* an engine error costs this batch's frames, not the order: it is queued where their PCM would have been,
+         * in front of a parse error found behind them, and the next call goes on with the frames that follow */
+        let refused = null;
+        try {
+            this.engine.decodeBatch(packUnits(units), q, meta, pcm, tnsList && tnsList.length ? packTns(tnsList) : null,
+                                    cceList && cceList.length ? packCce(cceList) : null);
+        } catch (err) { refused = err instanceof Error ? err : new Error(String(err)); }
+        if (refused) this.queue.push(refused);
+        else for (let i = 0; i < frames.length; i++) this.queue.push(pcm.slice(i * FRAME * C, (i + 1) * FRAME * C));   // caller owns each array
     }
     if (failed) this.queue.push(failed);
 };
 
 /* bytes from the demuxer ('data' events of AdtsDemuxer / an MP4 demuxer's samples) to the front end */
 GpuAACDecoder.prototype.feed = function (bytes) { this.frontend.push(bytes.data || bytes); };
-GpuAACDecoder.prototype.feedPacket = function (bytes) { this.frontend.pushPacket(bytes.data || bytes); };
+GpuAACDecoder.prototype.feedPacket = function (bytes, multi) { this.frontend.pushPacket(bytes.data || bytes, multi); };   // multi: the buffer may hold several samples
 
 module.exports = { Engine, GpuAACDecoder, BitReader, packUnits, unpackUnits, packBandWord, packTns, unpackTns, packCce, CCE_REFERENCE, CCE_SPEC, CCE_BYTES, applyPulses, loadAddon,
                    INPUT_SPEC_F32, INPUT_QUANT_I16, OUTPUT_F32, OUTPUT_I16, TNS_REFERENCE, TNS_SPEC, PNS_REFERENCE, PNS_SPEC, UNIT_BYTES, META_WORDS, TNS_BYTES, SAMPLE_RATES };

@@ -160,16 +160,18 @@ static napi_value js_create(napi_env env, napi_callback_info info)
 }
 
 static handle_box* engine_box(napi_env env, napi_value v) { return box_of(env, v, BOX_ENGINE, "aacgpu: bad engine handle"); }
-/* for the synchronous entry points: waits for a running async job of the same engine (the JS wrapper awaits its
- * jobs anyway; this is the backstop) */
-static aacg_engine* engine_of(napi_env env, napi_value v)
+/* The synchronous entry points hold the engine's lock for the whole library call: an async job of the same engine —
+ * queued or running on a libuv thread — takes the same lock around aacg_submit / aacg_wait, so the two can never be
+ * inside the (non-re-entrant) engine at once.  (The JS wrapper awaits its jobs anyway; this is the backstop.) */
+static aacg_engine* engine_lock(napi_env env, napi_value v, handle_box** box)
 {
     handle_box* b = engine_box(env, v);
+    *box = b;
     if (!b) return NULL;
     pthread_mutex_lock(&b->lock);
-    pthread_mutex_unlock(&b->lock);
     return (aacg_engine*)b->ptr;
 }
+static void engine_unlock(handle_box* b) { pthread_mutex_unlock(&b->lock); }
 
 static int typed(napi_env env, napi_value v, napi_typedarray_type* type, size_t* len, void** data)
 {
@@ -219,8 +221,8 @@ static napi_value js_decode_batch(napi_env env, napi_callback_info info)
     CHECK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
     void* dt; size_t nt; void* dcce; size_t ncce;
     if (!optional_tns(env, argc, argv, 5, &dt, &nt) || !optional_cce(env, argc, argv, 6, &dcce, &ncce)) return NULL;
-    aacg_engine* e = engine_of(env, argv[0]);
-    if (!e) return NULL;
+    handle_box* box = engine_box(env, argv[0]);
+    if (!box) return NULL;
     napi_typedarray_type tu, tc, tm, tp; size_t nu, nc, nm = 0, np; void *du, *dc, *dm = NULL, *dp;
     if (!typed(env, argv[1], &tu, &nu, &du) || tu != napi_uint8_array || nu % sizeof(aacg_unit_desc)) {
         napi_throw_type_error(env, NULL, "units must be a Uint8Array of 64-byte aacg_unit_desc records"); return NULL; }
@@ -232,7 +234,7 @@ static napi_value js_decode_batch(napi_env env, napi_callback_info info)
         if (!typed(env, argv[3], &tm, &nm, &dm) || tm != napi_uint16_array || nm % AACG_MAX_SECTIONS) {
             napi_throw_type_error(env, NULL, "meta must be a Uint16Array of 120-word aacg_band_meta records"); return NULL; }
     }
-    if (!typed(env, argv[4], &tp, &np, &dp) || tp != (engine_box(env, argv[0])->out_i16 ? napi_int16_array : napi_float32_array)) {
+    if (!typed(env, argv[4], &tp, &np, &dp) || tp != (box->out_i16 ? napi_int16_array : napi_float32_array)) {
         napi_throw_type_error(env, NULL, "pcm must be a Float32Array (an Int16Array for an engine created with outputKind: OUTPUT_I16)"); return NULL; }
     aacg_batch b;
     memset(&b, 0, sizeof b);
@@ -242,8 +244,12 @@ static napi_value js_decode_batch(napi_env env, napi_callback_info info)
     b.tns = (const aacg_tns_info*)dt; b.n_tns = (uint32_t)nt;
     b.cce = (const aacg_cce_info*)dcce; b.n_cce = (uint32_t)ncce;
     b.pcm_out = dp; b.n_pcm_floats = np;
+    aacg_engine* e = engine_lock(env, argv[0], &box);
+    if (!e) return NULL;
     int rc = L.decode_batch_ex(e, &b);
-    if (rc) return fail(env, e, rc, "aacg_decode_batch");
+    napi_value failed = rc ? fail(env, e, rc, "aacg_decode_batch") : NULL;     /* reads aacg_last_error: still under the lock */
+    engine_unlock(box);
+    if (rc) return failed;
     return argv[4];
 }
 
@@ -251,11 +257,13 @@ static napi_value js_reset_stream(napi_env env, napi_callback_info info)
 {
     size_t argc = 2; napi_value argv[2]; uint32_t s = 0;
     CHECK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
-    aacg_engine* e = engine_of(env, argv[0]);
-    if (!e) return NULL;
+    handle_box* box;
     napi_get_value_uint32(env, argv[1], &s);
+    aacg_engine* e = engine_lock(env, argv[0], &box);
+    if (!e) return NULL;
     int rc = L.reset_stream(e, s);
-    if (rc) return fail(env, e, rc, "aacg_reset_stream");
+    if (rc) (void)fail(env, e, rc, "aacg_reset_stream");
+    engine_unlock(box);
     return NULL;
 }
 
@@ -264,16 +272,18 @@ static napi_value overlap_io(napi_env env, napi_callback_info info, int set)
 {
     size_t argc = 4; napi_value argv[4]; uint32_t s = 0, c = 0;
     CHECK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
-    aacg_engine* e = engine_of(env, argv[0]);
-    if (!e) return NULL;
+    handle_box* box;
     napi_get_value_uint32(env, argv[1], &s);
     napi_get_value_uint32(env, argv[2], &c);
     napi_typedarray_type t; size_t n; void* d;
     if (!typed(env, argv[3], &t, &n, &d) || t != napi_float32_array || n != 1024) {
         napi_throw_type_error(env, NULL, "overlap buffer must be a Float32Array(1024)"); return NULL; }
+    aacg_engine* e = engine_lock(env, argv[0], &box);
+    if (!e) return NULL;
     int rc = set ? L.set_overlap(e, s, c, (const float*)d) : L.get_overlap(e, s, c, (float*)d);
-    if (rc) return fail(env, e, rc, set ? "aacg_set_overlap" : "aacg_get_overlap");
-    return argv[3];
+    if (rc) (void)fail(env, e, rc, set ? "aacg_set_overlap" : "aacg_get_overlap");
+    engine_unlock(box);
+    return rc ? NULL : argv[3];
 }
 static napi_value js_get_overlap(napi_env env, napi_callback_info info) { return overlap_io(env, info, 0); }
 static napi_value js_set_overlap(napi_env env, napi_callback_info info) { return overlap_io(env, info, 1); }

@@ -51,6 +51,42 @@ function play(name, pieces, options) {
     return out;
 }
 
+/* The 'mp4a' route: Aurora's M4A demuxer hands the decoder a track's samples without ADTS headers, and one buffer may hold
+ * several contiguous samples (a chunk); the reference reads block after block from the same bitstream (decoder.js:129-199).
+ * The ADTS test streams with their headers cut off are such samples; `groups` = samples per emitted buffer, cycled. */
+function playMp4(name, groups, options) {
+    AV.Demuxer.registry.length = 0;
+    const plugin = require(path.join(root, 'aac.js_amd', 'js', 'aurora.js')).register(AV, options);
+    const adts = require(path.join(root, 'aac.js_amd', 'js', 'adts.js'));
+    const bytes = new Uint8Array(fs.readFileSync(path.join(streams, name + '.aac')));
+    const list = adts.frames(bytes), h = list[0].header;
+    const format = { formatID: 'mp4a', sampleRate: host.SAMPLE_RATES[h.samplingIndex], channelsPerFrame: h.chanConfig, bitsPerChannel: 16 };
+    const demuxer = new AV.EventEmitter(), out = { pcm: [], errors: [] };
+    const DecoderClass = AV.Decoder.find('mp4a');
+    assert.strictEqual(DecoderClass, plugin.Decoder);
+    const decoder = new DecoderClass(demuxer, format);
+    decoder.on('data', function (pcm) { out.pcm.push(pcm); });
+    decoder.on('error', function (e) { out.errors.push(e); });
+    decoder.on('end', function () { out.ended = true; });
+    demuxer.emit('cookie', new AV.Buffer(adts.cookie(h)));
+    for (let i = 0, g = 0; i < list.length; g++) {
+        const n = Math.min(groups[g % groups.length], list.length - i);
+        let total = 0;
+        for (let k = i; k < i + n; k++) total += list[k].length - list[k].header.headerBytes;
+        const chunk = new Uint8Array(total);
+        for (let k = i, at = 0; k < i + n; k++) {
+            const block = bytes.subarray(list[k].offset + list[k].header.headerBytes, list[k].offset + list[k].length);
+            chunk.set(block, at); at += block.length;
+        }
+        demuxer.emit('data', new AV.Buffer(chunk));
+        i += n;
+        while (decoder.decode()) {}
+    }
+    demuxer.emit('end');
+    while (decoder.decode()) {}
+    return out;
+}
+
 {
     AV.Demuxer.registry.length = 0;
     const plugin = require(path.join(root, 'aac.js_amd', 'js', 'aurora.js')).register(AV, { engine: function () { return { resetStream: function () {}, decodeBatch: function () {} }; } });
@@ -91,7 +127,29 @@ for (const c of manifest) {
             assert.strictEqual(units, c.frames * perFrame, c.name + ': every element reached the engine exactly once');
             assert.ok(out.ended);
         }
+        for (const groups of [[1], [3], [1, 5, 2], [1000]]) {       // samples per buffer, as an M4A demuxer may emit them
+            let units = 0;
+            const engine = { resetStream: function () {}, decodeBatch: function (u, q, meta, pcm) { units += u.length / host.UNIT_BYTES; pcm.fill(1); } };
+            const out = playMp4(c.name, groups, { engine: function () { return engine; }, lookahead: 8 });
+            assert.strictEqual(out.errors.length, 0, String(out.errors[0]));
+            assert.strictEqual(out.pcm.length, c.frames, c.name + " 'mp4a' samples per buffer " + groups + ': frames delivered');
+            const perFrame = fs.statSync(path.join(streams, c.name + '.units')).size / host.UNIT_BYTES / c.frames;
+            assert.strictEqual(units, c.frames * perFrame, c.name + " 'mp4a': every element reached the engine exactly once");
+            assert.ok(out.ended);
+        }
     } else {
+        {
+            /* 'mp4a' with several samples per buffer through the real engine, JavaScript and device front ends */
+            const refm = new Float32Array(new Uint8Array(fs.readFileSync(path.join(streams, c.name + '.refpcm'))).buffer);
+            for (const opt of [{ lookahead: 16 }, { lookahead: 16, gpuParse: true }]) {
+                const out = playMp4(c.name, [2, 7, 1], opt);
+                assert.strictEqual(out.errors.length, 0, String(out.errors[0]));
+                assert.strictEqual(out.pcm.length, c.frames, c.name + " 'mp4a' " + JSON.stringify(opt));
+                let err = 0, n = 0;
+                out.pcm.forEach(function (p, t) { for (let i = 0; i < p.length; i++, n++) { const d = p[i] - refm[t * p.length + i]; err += d * d; } });
+                assert.ok(Math.sqrt(err / n) < 1e-5, c.name + " 'mp4a': rms " + Math.sqrt(err / n));
+            }
+        }
         const ref = new Float32Array(new Uint8Array(fs.readFileSync(path.join(streams, c.name + '.refpcm'))).buffer);
         for (const pieces of [[1 << 20], [1500, 13]]) {
             const out = play(c.name, pieces, { lookahead: 16 });

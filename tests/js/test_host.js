@@ -105,6 +105,29 @@ const tnsLong = { short: false, nFilt: [2], length: [[20, 9]], order: [[3, 1]], 
     assert.deepStrictEqual(seen, [1, 1, 1, 'Invalid band type: 12', 2, 'NOISE_BT', 3, 'TODO: add pulse data', 4, null, null]);
     assert.deepStrictEqual(batches, [3, 1, 1, 1]);
 }
+// look-ahead batches end where the set of elements changes (an element that appears or disappears mid-stream — a coupling
+// element with its own filterbank included — is a new chain for the planner), and an engine error takes the place of its
+// batch's frames in the queue: later frames still follow, in order
+{
+    const frame = function (types) {
+        return { elements: types.map(function (t, i) { return { type: t, id: i, ch: [{ windowSequence: 0, windowShape: 0, maxSFB: 0, groupLength: [1] }] }; }),
+                 q: new Int16Array(1024 * types.length), meta: new Uint16Array(120 * types.length) };
+    };
+    const script = [frame(['sce']), frame(['sce']), frame(['sce', 'lfe']), frame(['sce', 'lfe']), frame(['sce']), frame(['sce']), frame(['sce']), null, null];
+    let at = 0, batches = [];
+    const frontend = { parseFrame: function () { return script[at++]; } };
+    const engine = { resetStream: function () {}, decodeBatch: function (units, q, meta, pcm) {
+        batches.push(units.length / host.UNIT_BYTES);
+        if (batches.length === 2) throw new Error('aacgpu: aacg_decode_batch failed (-7)');
+        pcm.fill(batches.length);
+    } };
+    const dec = new host.GpuAACDecoder({ engine: engine, frontend: frontend, lookahead: 16 });
+    dec.config = { profile: 2, sampleIndex: 3, chanConfig: 2 };
+    const seen = [];
+    for (let i = 0; i < 7; i++) { try { const r = dec.readChunk(); seen.push(r ? r[0] : null); } catch (e) { seen.push('error'); } }
+    assert.deepStrictEqual(batches, [2, 4, 3]);               // units per batch: 2 frames x 1, 2 frames x 2, 3 frames x 1
+    assert.deepStrictEqual(seen, [1, 1, 'error', 3, 3, 3, null]);
+}
 // ADTS framing (aac.js_amd/js/adts.js): headers built here bit by bit from the field layout
 {
     const adts = require(path.join(__dirname, '..', '..', 'aac.js_amd', 'js', 'adts.js'));

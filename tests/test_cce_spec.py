@@ -150,6 +150,11 @@ def test_planner_refuses_coupling_elements_without_the_mode(oracle):
     bad["target"][0][0]["channel"] = 7
     with pytest.raises(RuntimeError, match="out of range"):
         emu_lib.Emu().decode(units, q, meta, wl["n_pcm"], pool, np.zeros(6, np.uint8), cce=bad)
+    twice = cce.copy()                                            # the same target channel listed twice: two jobs of one launch would add to it
+    twice["n_targets"][0] = 2
+    twice["target"][0][1] = twice["target"][0][0]
+    with pytest.raises(RuntimeError, match="twice"):
+        emu_lib.Emu().decode(units, q, meta, wl["n_pcm"], pool, np.zeros(6, np.uint8), cce=twice)
 
 
 @pytest.mark.gpu

@@ -503,34 +503,49 @@ def test_other_sample_rates(oracle, sample_index, max_long):
 
 
 # ---- the exact bench workload, and the multi-process path ------------------------------------------------
-def test_bench_workload_vs_oracle(oracle):
-    """bench.py's own step — BASELINE config 2: 256 streams x 16 ONLY_LONG stereo frames, KBD, int16 seam, one launch of a
-    plan on device-resident buffers — against the oracle: 16 sampled streams at full precision (the oracle decodes
-    exactly those streams' units alone), and the remaining 240 through split invariance: they are bit-identical whether
-    decoded in the 4096-frame launch or in a launch of their own."""
+BENCH_WORKLOADS = {
+    # name: (streams, frames per stream, window-sequence mix, element layout, sampled streams)
+    "cfg2": (256, 16, False, ("cpe",), 16),
+    "cfg3": (256, 16, True, ("cpe",), 16),
+    "cfg4": (32, 128, True, ("cpe",), 4),                     # one GPU's shard of config 4: chains of 8 runs, double-duty first waves
+    "cfg5": (256, 16, True, ("cpe", "cpe", "cpe", "sce"), 16),  # 4096 frames x 7 channels
+}
+
+
+@pytest.mark.parametrize("name", sorted(BENCH_WORKLOADS))
+def test_bench_workload_vs_oracle(oracle, name):
+    """bench.py's own step at BASELINE's full sizes — config 2 (256 streams x 16 ONLY_LONG stereo frames, KBD), config 3 (the
+    window-sequence mix: filter_bank.js:105-202, all four sequences and both shapes), one GPU's shard of config 4 (32 streams x
+    128 frames: the overlap state chained through eight runs, filter_bank.js:38-41) and config 5 (4096 frames of 3 CPE + LFE,
+    the 7-way interleave of decoder.js:203-215) — int16 seam, one launch of a plan on device-resident buffers, same generator and
+    seed as bench.py.  Against the oracle: the sampled streams at full precision (the oracle decodes exactly those streams'
+    units alone), and the rest through split invariance: they are bit-identical whether decoded in the full launch or in a
+    launch of their own."""
     torch = _torch()
-    S, T = 256, 16
-    wl = aacgpu_workload.make_batch(n_streams=S, n_frames=T, mix=False, seed=0xAAC00002)
-    eng = aacgpu.Engine(aacgpu.INPUT_QUANT_I16, max_streams=S, max_channels=2)
+    S, T, mix, layout, n_sampled = BENCH_WORKLOADS[name]
+    C = sum(2 if e == "cpe" else 1 for e in layout)
+    wl = aacgpu_workload.make_batch(n_streams=S, n_frames=T, mix=mix, layout=layout, seed=0xAAC00002)
+    eng = aacgpu.Engine(aacgpu.INPUT_QUANT_I16, max_streams=S, max_channels=C)
     plan = eng.plan(wl["units"])
     d_q, d_meta = torch.from_numpy(wl["q"]).cuda(), torch.from_numpy(wl["meta"].view(np.int16)).cuda()
     d_pcm = torch.full((wl["n_pcm"],), float("nan"), dtype=torch.float32, device="cuda")
     stream = torch.cuda.Stream()
     eng.decode_device(plan, d_q.data_ptr(), d_meta.data_ptr(), d_pcm.data_ptr(), stream.cuda_stream)
     stream.synchronize()
-    pcm = d_pcm.cpu().numpy().reshape(S, T * 2048)
+    pcm = d_pcm.cpu().numpy().reshape(S, T * 1024 * C)
     assert np.isfinite(pcm).all()
-    sampled = list(range(0, S, 16))
+    sampled = list(range(0, S, S // n_sampled))
     units = wl["units"]
     for s in sampled:
-        ov = np.zeros((S, 2, 1024), np.float32)
-        ref = oracle.decode_batch(units[units["stream"] == s], wl["q"], wl["meta"], wl["n_pcm"], ov).reshape(S, T * 2048)[s]
-        assert rms(pcm[s], ref) < RMS_TOL
-        assert np.abs(eng.get_overlap(s, 0) - ov[s, 0]).max() <= 1e-5 * max(1.0, float(np.abs(ov[s, 0]).max()))
+        ov = np.zeros((S, C, 1024), np.float32)
+        ref = oracle.decode_batch(units[units["stream"] == s], wl["q"], wl["meta"], wl["n_pcm"], ov).reshape(S, T * 1024 * C)[s]
+        assert rms(pcm[s], ref) < RMS_TOL                        # rms() also gates the error relative to the signal level
+        for c in range(C):
+            assert np.abs(eng.get_overlap(s, c) - ov[s, c]).max() <= 1e-5 * max(1.0, float(np.abs(ov[s, c]).max()))
     plan.destroy()
     rest = units[~np.isin(units["stream"], sampled)]
-    eng2 = aacgpu.Engine(aacgpu.INPUT_QUANT_I16, max_streams=S, max_channels=2)
-    alone = eng2.decode_batch(rest, wl["q"], wl["meta"], wl["n_pcm"]).reshape(S, T * 2048)
+    eng2 = aacgpu.Engine(aacgpu.INPUT_QUANT_I16, max_streams=S, max_channels=C)
+    alone = eng2.decode_batch(rest, wl["q"], wl["meta"], wl["n_pcm"]).reshape(S, T * 1024 * C)
     others = [s for s in range(S) if s not in sampled]
     assert np.array_equal(alone[others].view(np.uint32), pcm[others].view(np.uint32))
     eng.close()
@@ -595,6 +610,28 @@ def test_bench_launches_its_own_ranks():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["steps"] == 20 and line["output_ok"] and line["parity_rms"] < 1e-5
+    assert abs(line["value"] - 2 * 4096 / (line["ms_per_step"] * 1e-3)) < 1e-6 * line["value"]
+
+
+def test_two_gpus_rccl_config4():
+    """On a box with at least two GPUs (skipped on the one-GPU boxes of this pool): `bench.py --gpus 2 --workload cfg4` with one
+    rank per GPU and RCCL (= the nccl backend over xGMI) carrying the harness's barrier and 8-byte MAX — BASELINE config 4's
+    launch line at N = 2, so that the driver's scaling run needs nothing this suite has not run.  Each rank checks its own batch
+    against the oracle (parity_rms); the line must name nccl and the world size the backend reports."""
+    import json
+    import os
+    import subprocess
+    import sys
+    torch = _torch()
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (one rank per GPU over RCCL)")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "cfg4", "--steps", "50", "--warmup", "10",
+                        "--precondition-ms", "50"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["output_ok"] and line["parity_rms"] < 1e-5 and line["scaling"] == "weak"
+    assert "nccl" in line["config"]["collectives"] and "world size 2" in line["config"]["collectives"]
     assert abs(line["value"] - 2 * 4096 / (line["ms_per_step"] * 1e-3)) < 1e-6 * line["value"]
 
 
