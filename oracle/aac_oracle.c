@@ -148,6 +148,24 @@ static void gen_mdct(double (*t)[2], int N)
     }
 }
 
+/* the reference's FFT roots come from a float32 recurrence (fft.js:59-103) that drifts from the exact roots
+ * of unity (<= 8.8e-7 for 512 points).  The oracle follows the recurrence — that is what pins it bit for bit to aac.js;
+ * orc_set_fft_roots(1) swaps in correctly rounded roots (what the GPU engine uses) so that tests can measure how much of
+ * the engine's distance from the reference is that drift and how much is its own arithmetic.  0 restores the recurrence. */
+void orc_set_fft_roots(int exact)
+{
+    orc_init();
+    if (!exact) { gen_roots_long(g_roots_long, 512); gen_roots_short(g_roots_short, 64); return; }
+    for (int i = 0; i < 512; i++) {
+        const double a = 2.0 * M_PI * i / 512.0;
+        g_roots_long[i][0] = (float)cos(a); g_roots_long[i][1] = (float)sin(a); g_roots_long[i][2] = -g_roots_long[i][1];
+    }
+    for (int i = 0; i < 64; i++) {
+        const double a = 2.0 * M_PI * i / 64.0;
+        g_roots_short[i][0] = (float)cos(a); g_roots_short[i][1] = (float)sin(a);
+    }
+}
+
 void orc_init(void)
 {
     if (g_ready) return;

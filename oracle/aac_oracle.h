@@ -27,6 +27,9 @@ extern "C" {
 /* Build all tables (idempotent).  tables.js:168-191, filter_bank.js:46-86,
  * fft.js:59-103, mdct_tables.js (by formula). */
 void orc_init(void);
+/* exact = 1: correctly rounded FFT roots instead of the reference's float32 recurrence (fft.js:59-103); 0 restores it.
+ * Test aid for attributing the GPU engine's distance from the reference; never changes golden parity. */
+void orc_set_fft_roots(int exact);
 
 /* Table access for known-answer tests.
  * which: 0 IQ_TABLE[8191] f32        1 SCALEFACTOR_TABLE[428] f32

@@ -80,6 +80,20 @@ class Oracle:
         n = self.lib.orc_get_swb_offsets(sample_index, int(is_long), a.ctypes.data)
         return a[:n + 1].copy()
 
+    def exact_fft_roots(self):
+        """Context manager: inside it the oracle's FFT uses correctly rounded roots instead of the reference's float32
+        recurrence (orc_set_fft_roots) — for attributing the GPU engine's distance from the reference."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def cm():
+            self.lib.orc_set_fft_roots(1)
+            try:
+                yield self
+            finally:
+                self.lib.orc_set_fft_roots(0)
+        return cm()
+
     def fft_inverse(self, x):
         buf = np.ascontiguousarray(x, np.float32).copy()
         self.lib.orc_fft_inverse(buf.shape[0], buf.ctypes.data)

@@ -731,6 +731,21 @@ def test_fft_64_kat(golden, vm):
         assert _rel(np.stack([re, im], 1), golden["fft64.out"][v].astype(np.float64)) < 5e-6
 
 
+def test_distance_from_the_reference_is_the_roots_recurrence(oracle, golden):
+    """SURVEY.md 9.2 / DESIGN.md 2: the engine uses correctly rounded FFT twiddles, the reference a float32 recurrence that
+    drifts (fft.js:59-103).  Against the oracle as it follows the reference the kernels' IMDCT is ~1e-6 off; against the same
+    oracle with exact roots (orc_set_fft_roots) it is several times closer: the distance is the reference's table, not the
+    engine's arithmetic."""
+    for vm in (False, True):
+        for v in range(2):
+            x = golden["imdct2048.in"][v]
+            got = aacgpu.debug_transform(x, vm=vm)
+            to_reference = _rel(got, oracle.imdct(x))
+            with oracle.exact_fft_roots():
+                to_exact = _rel(got, oracle.imdct(x))
+            assert to_reference < 5e-6 and to_exact < 4e-7 and to_exact < 0.5 * to_reference, (vm, v, to_reference, to_exact)
+
+
 def _pcm16(ref):
     return np.clip(np.rint(ref.astype(np.float64) * 32768.0), -32768, 32767).astype(np.int16)
 

@@ -165,3 +165,21 @@ def test_oracle_sanitized(golden):
     env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
+
+
+def test_exact_roots_variant_measures_the_recurrence_drift(oracle, golden):
+    """the reference's FFT roots come from a float32 recurrence (fft.js:59-103).  With correctly rounded roots
+    instead (orc_set_fft_roots) the IMDCT moves by about 1e-6 of its output — the figure BASELINE.md quotes for the
+    reference's own distance from an exact transform — and back to bit-exact when the recurrence is restored."""
+    x = golden["imdct2048.in"][0]
+    want = golden["imdct2048.out"][0]
+    y_rec = oracle.imdct(x)
+    assert np.array_equal(y_rec.view(np.uint32), want.view(np.uint32))
+    with oracle.exact_fft_roots():
+        y_exact = oracle.imdct(x)
+        k = np.arange(512)
+        roots = oracle.table_f32(6).reshape(512, 3)
+        assert np.array_equal(roots[:, 0], np.cos(2 * np.pi * k / 512).astype(np.float32))
+    rel = float(np.sqrt(np.mean((y_exact.astype(np.float64) - y_rec) ** 2)) / np.sqrt(np.mean(y_rec.astype(np.float64) ** 2)))
+    assert 2e-7 < rel < 3e-6, rel
+    assert np.array_equal(oracle.imdct(x).view(np.uint32), want.view(np.uint32))          # restored
