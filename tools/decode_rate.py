@@ -21,10 +21,12 @@ def main():
     ap.add_argument("--frames", type=int, default=16)
     ap.add_argument("--mix", action="store_true")
     ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--layout", default="cpe", help="comma-separated elements of a frame, e.g. cpe,cpe,cpe,sce")
     a = ap.parse_args()
     import torch
-    wl = aacgpu_workload.make_batch(n_streams=a.streams, n_frames=a.frames, mix=a.mix)
-    eng = aacgpu.Engine(aacgpu.INPUT_QUANT_I16, max_streams=a.streams, max_channels=2)
+    layout = tuple(a.layout.split(","))
+    wl = aacgpu_workload.make_batch(n_streams=a.streams, n_frames=a.frames, mix=a.mix, layout=layout)
+    eng = aacgpu.Engine(aacgpu.INPUT_QUANT_I16, max_streams=a.streams, max_channels=max(2, wl["C"]))
     plan = eng.plan(wl["units"])
     dev = torch.device("cuda:0")
     bufs = [(torch.from_numpy(wl["q"]).to(dev), torch.from_numpy(wl["meta"].view(np.int16)).to(dev),
@@ -43,7 +45,7 @@ def main():
     side.synchronize()
     ms = e0.elapsed_time(e1) / a.steps
     n = a.streams * a.frames
-    print(json.dumps({"frames": n, "us_per_launch": ms * 1e3, "frames_per_s": n / (ms * 1e-3), "ns_per_frame": ms * 1e6 / n,
+    print(json.dumps({"layout": a.layout, "frames": n, "us_per_launch": ms * 1e3, "frames_per_s": n / (ms * 1e-3), "ns_per_frame": ms * 1e6 / n,
                       "GBps": (wl["q"].nbytes + wl["meta"].nbytes + wl["n_pcm"] * 4) / (ms * 1e-3) / 1e9}))
 
 
