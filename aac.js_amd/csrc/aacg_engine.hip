@@ -606,6 +606,22 @@ int aacg_plan_refresh_from_parse(aacg_engine* e, aacg_plan* p, const aacg_unit_d
     return AACG_OK;
 }
 
+/* The plan's unit records rewritten from the host's next batch of the same structure; the run tables stay. */
+int aacg_plan_refresh_units(aacg_engine* e, aacg_plan* p, const aacg_unit_desc* units, uint32_t n_units, void* hip_stream)
+{
+    if (!e || !p || p->e != e || !units) return AACG_ERR_INVALID_ARG;
+    int rc = aacg_plan_refresh_host(&p->h, units, n_units, e->cfg.sample_index, &e->err);
+    if (rc) return rc;
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : e->stream;
+    HIP_TRY(e, hipStreamWaitEvent(s, p->uploaded, 0), AACG_ERR_NO_DEVICE);
+    /* pageable source: the runtime stages it before returning, so the host copy may change again right away; in stream
+     * order behind the launches that read the previous records */
+    HIP_TRY(e, hipMemcpyAsync(p->d_units, p->h.units.data(), sizeof(aacg_dev_unit) * p->h.units.size(), hipMemcpyHostToDevice, s), AACG_ERR_NO_DEVICE);
+    p->last_stream = s;
+    p->used = true;
+    return AACG_OK;
+}
+
 int aacg_spectral_device(aacg_engine* e, aacg_plan* p, const void* d_coeffs, const aacg_band_meta* d_meta,
                          float* d_spec_out, void* hip_stream)
 {

@@ -105,6 +105,73 @@ int aacg_tns_prepare(int sample_index, const aacg_chan_info* info, const aacg_tn
     return AACG_OK;
 }
 
+/* the window fields of one channel as the kernels rely on them (ics.js:279-314); 0 or an error text */
+static const char* check_chan(const aacg_chan_info& ci, int n_long, int n_short)
+{
+    if (ci.window_sequence > 3 || ci.window_shape > 1 || ci.window_shape_prev > 1) return "bad window fields";
+    if (ci.window_sequence == AACG_EIGHT_SHORT_SEQUENCE) {
+        int sum = 0;
+        if (ci.group_count < 1 || ci.group_count > 8) return "group_count";
+        for (int g = 0; g < ci.group_count; g++) sum += ci.group_len[g];
+        if (sum != 8) return "group lengths do not sum to 8";
+        if (ci.max_sfb > n_short) return "max_sfb (short)";
+    } else {
+        if (ci.group_count != 1 || ci.group_len[0] != 1) return "long window needs one group of one";
+        if (ci.max_sfb > n_long) return "max_sfb (long)";
+    }
+    if ((int)ci.group_count * (int)ci.max_sfb > AACG_MAX_SECTIONS) return "more than 120 bands";
+    return nullptr;
+}
+
+/* group-of-window map: 4 bits per window (ics.js:288-296 grouping) */
+static uint32_t group_map(const aacg_chan_info& ci)
+{
+    uint32_t gmap = 0;
+    if (ci.window_sequence == AACG_EIGHT_SHORT_SEQUENCE) {
+        int w = 0;
+        for (int g = 0; g < ci.group_count; g++)
+            for (int k = 0; k < ci.group_len[g] && w < 8; k++, w++) gmap |= (uint32_t)g << (4 * w);
+    }
+    return gmap;
+}
+
+/* A kept plan takes the next batch's unit records: same streams, frames, elements and PCM positions (that is what the run
+ * tables were built from), new window info, flags and block offsets.  What the host pays per batch is this loop and a
+ * copy of the records instead of aacg_plan_build (27 ns per unit) — for callers that keep spectra on the device and
+ * parse on the host.  Plans with TNS records, noise bands or coupling elements are built per batch. */
+int aacg_plan_refresh_host(aacg_plan_host* h, const aacg_unit_desc* units, uint32_t n_units, int sample_index, std::string* err)
+{
+    int swb[64];
+    const int n_long = aacg_swb_offsets(sample_index, 1, swb), n_short = aacg_swb_offsets(sample_index, 0, swb);
+    if (n_units != h->units.size()) return fail(err, AACG_ERR_LAYOUT_CHANGE, "the plan was built for %ld units, the batch has %ld", (long)h->units.size(), (long)n_units);
+    if (h->any_tns || h->any_pns || h->any_cce) return fail(err, AACG_ERR_UNSUPPORTED, "plans with TNS records, noise bands or coupling elements are built per batch");
+    uint32_t coef_blocks = 0, meta_blocks = 0;
+    for (uint32_t i = 0; i < n_units; i++) {
+        const aacg_unit_desc& u = units[i];
+        const aacg_unit_desc& was = h->units[i].d;
+        if (u.stream != was.stream || u.pcm_offset != was.pcm_offset || u.channel != was.channel || u.n_out_ch != was.n_out_ch || u.n_ch != was.n_ch)
+            return fail(err, AACG_ERR_LAYOUT_CHANGE, "unit %ld: stream / PCM position / channels differ from the plan's", i);
+        if (u.flags & (AACG_UNIT_CCE | AACG_UNIT_HAS_PNS))
+            return fail(err, AACG_ERR_LAYOUT_CHANGE, "unit %ld: a coupling element or noise bands: the route changes, plan anew", i);
+        for (int c = 0; c < u.n_ch; c++)
+            if (const char* why = check_chan(u.ch[c], n_long, n_short)) { if (err) *err = why; return AACG_ERR_INVALID_ARG; }
+        if (u.coef_offset > UINT32_MAX - 2u || u.meta_offset > UINT32_MAX - 2u)
+            return fail(err, AACG_ERR_INVALID_ARG, "unit %ld: coefficient / meta offset out of range", i);
+        coef_blocks = std::max(coef_blocks, u.coef_offset + u.n_ch);
+        meta_blocks = std::max(meta_blocks, u.meta_offset + u.n_ch);
+    }
+    for (uint32_t i = 0; i < n_units; i++) {               /* nothing is touched before the whole batch has passed */
+        aacg_dev_unit& du = h->units[i];
+        du.d = units[i];
+        for (int c = 0; c < 2; c++) {
+            du.gmap[c] = c < du.d.n_ch ? group_map(du.d.ch[c]) : 0;
+            du.d.ch[c].flags &= (uint8_t)~AACG_CHAN_TNS_PRESENT;                  /* no TNS records in such a plan */
+        }
+    }
+    h->coef_blocks = coef_blocks; h->meta_blocks = meta_blocks;
+    return AACG_OK;
+}
+
 int aacg_plan_build(const aacg_unit_desc* units, uint32_t n_units, int sample_index,
                     int max_streams, int max_channels, const uint8_t* parity,
                     aacg_plan_host* out, std::string* err,
@@ -148,23 +215,11 @@ int aacg_plan_build(const aacg_unit_desc* units, uint32_t n_units, int sample_in
             out->any_cce = true;
             if (ci.coupling_point != AACG_CCE_AFTER_IMDCT) out->any_cce_dependent = true;
         }
-        for (int c = 0; c < u.n_ch; c++) {
-            const aacg_chan_info& ci = u.ch[c];
-            if (ci.window_sequence > 3 || ci.window_shape > 1 || ci.window_shape_prev > 1)
-                return fail(err, AACG_ERR_INVALID_ARG, "unit %ld ch %ld: bad window fields", i, c);
-            if (ci.window_sequence == AACG_EIGHT_SHORT_SEQUENCE) {
-                int sum = 0;
-                if (ci.group_count < 1 || ci.group_count > 8) return fail(err, AACG_ERR_INVALID_ARG, "unit %ld ch %ld: group_count", i, c);
-                for (int g = 0; g < ci.group_count; g++) sum += ci.group_len[g];
-                if (sum != 8) return fail(err, AACG_ERR_INVALID_ARG, "unit %ld ch %ld: group lengths sum to %ld, not 8", i, c, sum);
-                if (ci.max_sfb > n_short) return fail(err, AACG_ERR_INVALID_ARG, "unit %ld ch %ld: max_sfb %ld (short)", i, c, ci.max_sfb);
-            } else {
-                if (ci.group_count != 1 || ci.group_len[0] != 1) return fail(err, AACG_ERR_INVALID_ARG, "unit %ld ch %ld: long window needs one group of one", i, c);
-                if (ci.max_sfb > n_long) return fail(err, AACG_ERR_INVALID_ARG, "unit %ld ch %ld: max_sfb %ld (long)", i, c, ci.max_sfb);
+        for (int c = 0; c < u.n_ch; c++)
+            if (const char* why = check_chan(u.ch[c], n_long, n_short)) {
+                if (err) { char buf[160]; std::snprintf(buf, sizeof buf, "unit %ld ch %d: %s", (long)i, c, why); *err = buf; }
+                return AACG_ERR_INVALID_ARG;
             }
-            if ((int)ci.group_count * (int)ci.max_sfb > AACG_MAX_SECTIONS)
-                return fail(err, AACG_ERR_INVALID_ARG, "unit %ld ch %ld: more than 120 bands", i, c);
-        }
 
         stream_state& s = st[u.stream];
         if (!s.seen) { s.seen = true; s.cur_off = u.pcm_offset; s.frame = 0; s.mask = 0; s.n_out = u.n_out_ch; }
@@ -210,13 +265,7 @@ int aacg_plan_build(const aacg_unit_desc* units, uint32_t n_units, int sample_in
             du.d.channel = 0;
         }
         for (int c = 0; c < 2; c++) {
-            uint32_t gmap = 0;
-            if (c < u.n_ch && u.ch[c].window_sequence == AACG_EIGHT_SHORT_SEQUENCE) {
-                int w = 0;
-                for (int g = 0; g < u.ch[c].group_count; g++)
-                    for (int k = 0; k < u.ch[c].group_len[g] && w < 8; k++, w++) gmap |= (uint32_t)g << (4 * w);
-            }
-            du.gmap[c] = gmap;
+            du.gmap[c] = c < u.n_ch ? group_map(u.ch[c]) : 0;
             if (!tns) du.d.ch[c].flags &= (uint8_t)~AACG_CHAN_TNS_PRESENT;       /* no records: nothing to apply */
             if (tns && c < u.n_ch && (u.ch[c].flags & AACG_CHAN_TNS_PRESENT)) {
                 const uint32_t ti = u.tns_offset + (uint32_t)c;

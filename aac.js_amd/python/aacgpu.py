@@ -26,7 +26,7 @@ ABI_SYMBOLS = ["aacg_create", "aacg_destroy", "aacg_last_error", "aacg_abi_versi
                "aacg_decode_device", "aacg_spectral_device", "aacg_synchronize", "aacg_get_table", "aacg_kernel_name",
                "aacg_parser_create", "aacg_parser_destroy", "aacg_parser_last_error", "aacg_parse_status_string",
                "aacg_parse_batch", "aacg_parse_device", "aacg_parse_kernel_name", "aacg_plan_refresh_from_parse", "aacg_standard_codebooks", "aacg_debug_transform",
-               "aacg_decode_batch_ex", "aacg_submit_ex", "aacg_plan_create_ex", "aacg_plan_kernels", "aacg_calib_copy"]
+               "aacg_decode_batch_ex", "aacg_submit_ex", "aacg_plan_create_ex", "aacg_plan_kernels", "aacg_calib_copy", "aacg_plan_refresh_units"]
 
 UNIT_DTYPE = np.dtype([
     ("stream", "<u4"), ("pcm_offset", "<u4"), ("channel", "<u2"), ("n_out_ch", "<u2"),
@@ -109,6 +109,7 @@ def load_library(path=LIB_PATH):
     L.aacg_abi_version.restype = C.c_int
     L.aacg_kernel_name.restype = C.c_char_p
     L.aacg_plan_kernels.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.c_size_t]
+    L.aacg_plan_refresh_units.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
     L.aacg_calib_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     L.aacg_last_error.restype = C.c_char_p
     L.aacg_last_error.argtypes = [C.c_void_p]
@@ -308,7 +309,9 @@ class Engine:
         return rc
 
     # -- host-buffer path -----------------------------------------------------------------
-    def decode_batch(self, units, coeffs, meta, n_pcm_floats, tns=None, cce=None):
+    def decode_batch(self, units, coeffs, meta, n_pcm_floats, tns=None, cce=None, out=None):
+        """out: an array to decode into (a caller that reuses its output buffer, as a real host does; default: a fresh one
+        filled with NaN so that tests see every sample that was not written)."""
         if cce is not None:
             return self._decode_batch_ex(units, coeffs, meta, n_pcm_floats, tns, cce)
         units = np.ascontiguousarray(units)
@@ -318,7 +321,11 @@ class Engine:
         n_blocks = coeffs.size // 1024
         if meta is not None:
             meta = np.ascontiguousarray(meta, np.uint16)
-        pcm = np.full(n_pcm_floats, np.nan, np.float32) if self.pcm_dtype == np.float32 else np.full(n_pcm_floats, -32768, np.int16)
+        if out is not None:
+            assert out.dtype == self.pcm_dtype and out.size >= n_pcm_floats and out.flags["C_CONTIGUOUS"]
+            pcm = out
+        else:
+            pcm = np.full(n_pcm_floats, np.nan, np.float32) if self.pcm_dtype == np.float32 else np.full(n_pcm_floats, -32768, np.int16)
         if tns is not None:
             tns = np.ascontiguousarray(tns)
             assert tns.dtype == TNS_DTYPE
@@ -404,6 +411,12 @@ class Engine:
     def plan_refresh_from_parse(self, plan, d_parsed_units, d_results, max_units, d_refused, stream=0):
         """Device pointers: the plan's unit records take what aacg_parse_device wrote (run tables unchanged)."""
         self._check(self.lib.aacg_plan_refresh_from_parse(self.handle, plan.handle, d_parsed_units, d_results, max_units, d_refused, stream))
+
+    def plan_refresh_units(self, plan, units, stream=0):
+        """The kept plan takes the next batch's unit records (same structure); raises AacgError(LAYOUT_CHANGE) otherwise."""
+        units = np.ascontiguousarray(units)
+        assert units.dtype == UNIT_DTYPE
+        self._check(self.lib.aacg_plan_refresh_units(self.handle, plan.handle, units.ctypes.data, len(units), stream))
 
     def spectral_device(self, plan, d_coeffs, d_meta, d_spec, stream=0):
         self._check(self.lib.aacg_spectral_device(self.handle, plan.handle, d_coeffs, d_meta, d_spec, stream))

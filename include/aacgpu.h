@@ -455,6 +455,15 @@ int aacg_plan_refresh_from_parse(aacg_engine* e, aacg_plan* p, const aacg_unit_d
                                  const aacg_parse_result* d_results, uint32_t max_units, uint32_t* d_refused,
                                  void* hip_stream);
 
+/* The host's counterpart of aacg_plan_refresh_from_parse, for callers that parse on the CPU (the JavaScript front end) but
+ * keep spectra and PCM on the device: batch after batch of the same streams keeps ONE plan, and the next batch's unit
+ * records — same streams, frames, elements and PCM positions; new window sequences, shapes, grouping, flags and block
+ * offsets — replace the plan's (validated like aacg_plan_create validates them, then one asynchronous copy on hip_stream;
+ * follow with aacg_decode_device on the same stream).  AACG_ERR_LAYOUT_CHANGE if the structure differs (nothing is
+ * changed then: build a new plan); plans with TNS records, noise bands or coupling elements are built per batch
+ * (AACG_ERR_UNSUPPORTED).  Replaces decoder.js:138-198's per-frame `new ICStream` bookkeeping for a whole batch. */
+int aacg_plan_refresh_units(aacg_engine* e, aacg_plan* p, const aacg_unit_desc* units, uint32_t n_units, void* hip_stream);
+
 /* Diagnostic: the IMDCT stage of the kernels on its own, for known-answer tests against the reference's MDCT.process
  * (mdct.js:62-115) and FFT.process (fft.js:105-192) vectors.  One spectrum in (1024 floats: one long window, or eight
  * short ones), windows forced to 1.  Long: out[0..2047] = the 2048 IMDCT outputs.  Short: out[128 w + i] =

@@ -613,6 +613,45 @@ def test_bench_launches_its_own_ranks():
     assert abs(line["value"] - 2 * 4096 / (line["ms_per_step"] * 1e-3)) < 1e-6 * line["value"]
 
 
+def test_plan_refresh_units_keeps_one_plan(oracle):
+    """aacg_plan_refresh_units: batch after batch of the same streams — new window sequences, shapes, grouping, M/S and block
+    offsets every time (the config-3 mix at different phases) — runs on ONE plan whose unit records are replaced from the
+    host's, against the oracle chained through the overlap state; a batch of another structure is refused with
+    LAYOUT_CHANGE and leaves the plan usable."""
+    torch = _torch()
+    S, T = 12, 16
+    eng = aacgpu.Engine(aacgpu.INPUT_QUANT_I16, max_streams=S, max_channels=2)
+    ov = np.zeros((S, 2, 1024), np.float32)
+    stream = torch.cuda.Stream()
+    plan = None
+    for b in range(4):
+        wl = aacgpu_workload.make_batch(n_streams=S, n_frames=T, mix=True, intensity=True, seed=7300 + b, frame_base=b * T + b)
+        if plan is None:
+            plan = eng.plan(wl["units"])
+        else:
+            eng.plan_refresh_units(plan, wl["units"], stream.cuda_stream)
+        d_q, d_meta = torch.from_numpy(wl["q"]).cuda(), torch.from_numpy(wl["meta"].view(np.int16)).cuda()
+        d_pcm = torch.full((wl["n_pcm"],), float("nan"), dtype=torch.float32, device="cuda")
+        eng.decode_device(plan, d_q.data_ptr(), d_meta.data_ptr(), d_pcm.data_ptr(), stream.cuda_stream)
+        stream.synchronize()
+        ref = oracle.decode_batch(wl["units"], wl["q"], wl["meta"], wl["n_pcm"], ov)
+        assert rms(d_pcm.cpu().numpy(), ref) < RMS_TOL
+    assert np.abs(overlaps(eng, S, 2) - ov).max() <= 1e-5 * max(1.0, float(np.abs(ov).max()))
+    other = aacgpu_workload.make_batch(n_streams=S, n_frames=T - 1, mix=True, seed=1)
+    with pytest.raises(aacgpu.AacgError) as ei:
+        eng.plan_refresh_units(plan, other["units"], stream.cuda_stream)
+    assert ei.value.code == -6                                   # AACG_ERR_LAYOUT_CHANGE
+    moved = wl["units"].copy()
+    moved["pcm_offset"][3] += 2048
+    with pytest.raises(aacgpu.AacgError):
+        eng.plan_refresh_units(plan, moved, stream.cuda_stream)
+    eng.decode_device(plan, d_q.data_ptr(), d_meta.data_ptr(), d_pcm.data_ptr(), stream.cuda_stream)   # still the last good records
+    stream.synchronize()
+    assert np.isfinite(d_pcm.cpu().numpy()).all()
+    plan.destroy()
+    eng.close()
+
+
 def test_two_gpus_rccl_config4():
     """On a box with at least two GPUs (skipped on the one-GPU boxes of this pool): `bench.py --gpus 2 --workload cfg4` with one
     rank per GPU and RCCL (= the nccl backend over xGMI) carrying the harness's barrier and 8-byte MAX — BASELINE config 4's

@@ -30,9 +30,28 @@ fps = S * T * ROUNDS / dt
 print("host-buffer path (%s PCM), pinned, 2 in flight: %.3f ms per 4096-frame batch, %.2f M stereo frames/s (%.0fx real time), "
       "%.1f GB/s H2D + %.1f GB/s D2H" % ("int16" if I16 else "f32", dt / ROUNDS * 1e3, fps / 1e6, fps / 46.875,
       (wl["q"].nbytes + wl["meta"].nbytes) * ROUNDS / dt / 1e9, wl["n_pcm"] * (2 if I16 else 4) * ROUNDS / dt / 1e9))
-# synchronous, pageable (what a naive caller gets)
+# synchronous, pageable: a caller that reuses its arrays (staged through the engine's pinned buffers), and one that takes a
+# fresh output array per call (the page faults of 33 MB of new memory are then part of the call)
 qn, mn = wl["q"].copy(), wl["meta"].copy()
+out = np.empty(wl["n_pcm"], np.int16 if I16 else np.float32)
+for i in range(3): eng.decode_batch(units, qn, mn, wl["n_pcm"], out=out)
+t0 = time.perf_counter()
+for i in range(10): eng.decode_batch(units, qn, mn, wl["n_pcm"], out=out)
+dt = time.perf_counter() - t0
+print("synchronous aacg_decode_batch, pageable memory, arrays reused: %.3f ms per batch, %.2f M stereo frames/s" % (dt / 10 * 1e3, S * T * 10 / dt / 1e6))
 t0 = time.perf_counter()
 for i in range(10): eng.decode_batch(units, qn, mn, wl["n_pcm"])
 dt = time.perf_counter() - t0
-print("synchronous aacg_decode_batch, pageable memory: %.3f ms per batch, %.2f M stereo frames/s" % (dt / 10 * 1e3, S * T * 10 / dt / 1e6))
+print("synchronous aacg_decode_batch, pageable memory, fresh output array per call: %.3f ms per batch, %.2f M stereo frames/s" % (dt / 10 * 1e3, S * T * 10 / dt / 1e6))
+# the host's share of a device-resident batch: a plan per batch against one plan refreshed from the host's unit records
+t0 = time.perf_counter()
+for i in range(20):
+    p = eng.plan(units); p.destroy()
+t_plan = (time.perf_counter() - t0) / 20
+p = eng.plan(units)
+t0 = time.perf_counter()
+for i in range(20): eng.plan_refresh_units(p, units)
+eng.synchronize()
+t_refresh = (time.perf_counter() - t0) / 20
+p.destroy()
+print("host work per device-resident batch of %d units: aacg_plan_create + destroy %.0f us, aacg_plan_refresh_units %.0f us" % (len(units), t_plan * 1e6, t_refresh * 1e6))
