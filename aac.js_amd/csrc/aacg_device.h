@@ -69,7 +69,10 @@ struct aacg_tables {
 struct aacg_dev_unit {
     aacg_unit_desc d;
     uint32_t gmap[2];                 /* per channel: group of window w in bits 4w..4w+3 (ics.js:288-296 grouping) */
-    uint32_t pad[2];
+    /* AACG_CCE_SPEC, independent coupling applied where the target's PCM is formed: this unit's jobs in the plan's
+     * fused-job list (aacg_couple_job: src = block of the side buffer, dst = channel 0 / 1 of this unit), in the order
+     * of the frame's coupling elements; 0 jobs otherwise */
+    uint32_t cpl_first, cpl_n;
 };
 
 /* Device form of one channel's TNS side info (AACG_TNS_SPEC): per filter slot the sample range and the
@@ -150,6 +153,17 @@ struct aacg_kparams {
     float*                scratch;    /* [n_runs][2048]: parked predecessor tails of double-duty runs (last: the plain kernels never load it) */
     const aacg_pns_tables* pns;       /* AACG_PNS_SPEC: the spectral stage's noise tables */
 };
+/* AACG_CCE_SPEC kernels with the independent coupling in their epilogue (aacg_imdct_run_*_cpl) take three more pointers.  They
+ * ride in fields those kernels have no other use for — no double duty (scratch), no optional stages (pns), no spectral
+ * output (spec_out) — so that the kernel arguments of every other launch stay as they are (a longer argument block costs the
+ * headline kernel its measured 0.05 us, and the layout of that block has cost it 0.35 us before: DESIGN.md 6). */
+static inline void aacg_set_cpl(aacg_kparams* P, const aacg_couple_job* jobs, const float* gains, const float* side)
+{
+    P->scratch = (float*)(void*)jobs; P->pns = (const aacg_pns_tables*)(const void*)gains; P->spec_out = (float*)side;
+}
+#define AACG_CPL_JOBS(P)  ((const aacg_couple_job*)(const void*)(P).scratch)
+#define AACG_CPL_GAINS(P) ((const float*)(const void*)(P).pns)
+#define AACG_CPL_SIDE(P)  ((const float*)(P).spec_out)   /* the coupling elements' filterbank output, [block][1024], PCM-scaled */
 
 /* ---- device front end (aacg_parse.h) ------------------------------------------------------------ */
 #define AACG_PARSE_WG_SMALL   256      /* frames staged in LDS: shortest time per frame */

@@ -44,6 +44,8 @@ int aacg_spectral_ex_set_lds_limits(void);
 void aacg_spectral_ex_launch(bool quant, int n_units, hipStream_t s, const aacg_kparams& P);
 /* aacg_engine_couple.hip: AACG_CCE_SPEC */
 void aacg_couple_launch(bool pcm, hipStream_t s, const aacg_couple_params& Q);
+int aacg_couple_set_lds_limits(void);
+void aacg_couple_run_launch(bool quant, dim3 grid, dim3 block, hipStream_t s, const aacg_kparams& P);
 struct cce_bufs { const aacg_run* runs; const aacg_couple_job* jobs; const float* gains; float* side; };
 
 extern "C" __global__ __launch_bounds__(AACG_WG_THREADS)
@@ -207,6 +209,12 @@ std::string route_names(const aacg_engine* e, const aacg_plan_host& h)
         quant = false;
     }
     const std::string run = std::string("aacg_imdct_run_") + (quant ? "quant" : "f32");
+    const bool fused = h.fused_independent && !ex && !i16;
+    if (fused) {
+        if (!h.cce_runs.empty()) add(run + " (coupling elements)");
+        if (!h.runs.empty()) add(run + "_cpl");
+        return r;
+    }
     if (!h.runs.empty()) add(run + (ex ? "_ex" : "") + (!ex && h.needs_scratch ? "_dd" : "") + (!ex && i16 ? "_i16" : ""));
     if (h.any_cce) {
         if (!h.cce_runs.empty()) add(run + " (coupling elements)");
@@ -273,7 +281,20 @@ int launch_run(aacg_engine* e, const aacg_dev_unit* d_units, const aacg_run* d_r
         P.spec_out = trace_or_null; P.coeffs = d_spec; P.meta = nullptr; P.tns = nullptr;
         quant = false;
     }
-    if (!h.runs.empty()) {
+    auto cce_filterbank = [&]() {                       /* the independently switched coupling elements' own filterbank pass */
+        aacg_kparams C = P;
+        C.runs = cb.runs; C.n_runs = (int32_t)h.cce_runs.size(); C.pcm = cb.side; C.scratch = nullptr;
+        if (quant) hipLaunchKernelGGL(aacg_imdct_run_quant, dim3((unsigned)h.cce_runs.size()), block, AACG_LDS_BYTES_QUANT, s, C);
+        else       hipLaunchKernelGGL(aacg_imdct_run_f32, dim3((unsigned)h.cce_runs.size()), block, AACG_LDS_BYTES_F32, s, C);
+    };
+    const bool fused = h.fused_independent && !ex && !i16;
+    if (fused) {
+        /* independent coupling in the targets' epilogues: the coupling elements go first (into the side buffer), then the
+         * run kernel that adds gain * side where it forms the PCM — no read-modify-write pass over the interleaved PCM */
+        if (!h.cce_runs.empty()) cce_filterbank();
+        aacg_set_cpl(&P, cb.jobs + h.fused_first, cb.gains, cb.side);
+        if (!h.runs.empty()) aacg_couple_run_launch(quant, grid, block, s, P);
+    } else if (!h.runs.empty()) {
         if (ex) {
             aacg_exrun_launch(quant, grid, block, s, P);
         } else if (i16) {
@@ -285,13 +306,8 @@ int launch_run(aacg_engine* e, const aacg_dev_unit* d_units, const aacg_run* d_r
             else       hipLaunchKernelGGL(aacg_imdct_run_f32, grid, block, AACG_LDS_BYTES_F32, s, P);
         }
     }
-    if (h.any_cce) {
-        if (!h.cce_runs.empty()) {                      /* the independently switched coupling elements' own filterbank pass */
-            aacg_kparams C = P;
-            C.runs = cb.runs; C.n_runs = (int32_t)h.cce_runs.size(); C.pcm = cb.side; C.scratch = nullptr;
-            if (quant) hipLaunchKernelGGL(aacg_imdct_run_quant, dim3((unsigned)h.cce_runs.size()), block, AACG_LDS_BYTES_QUANT, s, C);
-            else       hipLaunchKernelGGL(aacg_imdct_run_f32, dim3((unsigned)h.cce_runs.size()), block, AACG_LDS_BYTES_F32, s, C);
-        }
+    if (h.any_cce && !fused) {
+        if (!h.cce_runs.empty()) cce_filterbank();
         couple(AACG_CCE_AFTER_IMDCT);
     }
     HIP_TRY(e, hipGetLastError(), AACG_ERR_NO_DEVICE);
@@ -351,7 +367,7 @@ int aacg_create(const aacg_config* cfg, aacg_engine** out)
         /* ~158 KiB of dynamic LDS per workgroup is above the 64 KiB default limit */
         !hip_ok(e, hipFuncSetAttribute((const void*)aacg_imdct_run_quant, hipFuncAttributeMaxDynamicSharedMemorySize, AACG_LDS_BYTES_QUANT), "LDS attr") ||
         !hip_ok(e, hipFuncSetAttribute((const void*)aacg_imdct_run_f32, hipFuncAttributeMaxDynamicSharedMemorySize, AACG_LDS_BYTES_F32), "LDS attr") ||
-        aacg_ext_set_lds_limits() != 0 || aacg_i16_set_lds_limits() != 0 || aacg_exrun_set_lds_limits() != 0 || aacg_spectral_ex_set_lds_limits() != 0 ||
+        aacg_ext_set_lds_limits() != 0 || aacg_i16_set_lds_limits() != 0 || aacg_exrun_set_lds_limits() != 0 || aacg_spectral_ex_set_lds_limits() != 0 || aacg_couple_set_lds_limits() != 0 ||
         !hip_ok(e, hipFuncSetAttribute((const void*)aacg_spectral, hipFuncAttributeMaxDynamicSharedMemorySize, AACG_LDS_BYTES_SPECTRAL), "LDS attr")) {
         std::fprintf(stderr, "aacgpu: %s\n", e->err.c_str());
         aacg_destroy(e);

@@ -15,6 +15,26 @@ void aacg_couple_spec(const aacg_couple_params Q) { couple_spec_body(Q, AACG_COU
 extern "C" __global__ __launch_bounds__(AACG_COUPLE_WAVES * 64)
 void aacg_couple_pcm(const aacg_couple_params Q) { couple_pcm_body(Q, AACG_COUPLE_WAVES); }
 
+/* the run kernels with the independent coupling in their epilogue (plans whose every run is a first run or a run with a
+ * wave of its own for the predecessor: no double duty) */
+extern "C" __global__ __launch_bounds__(AACG_WG_THREADS)
+void aacg_imdct_run_quant_cpl(const aacg_kparams P) { imdct_run_body<AACG_INPUT_QUANT_I16, AACG_OUTPUT_F32, false, false, true>(P); }
+extern "C" __global__ __launch_bounds__(AACG_WG_THREADS)
+void aacg_imdct_run_f32_cpl(const aacg_kparams P) { imdct_run_body<AACG_INPUT_SPEC_F32, AACG_OUTPUT_F32, false, false, true>(P); }
+
+int aacg_couple_set_lds_limits(void)
+{
+    hipError_t rc = hipFuncSetAttribute((const void*)aacg_imdct_run_quant_cpl, hipFuncAttributeMaxDynamicSharedMemorySize, AACG_LDS_BYTES_QUANT);
+    if (rc == hipSuccess) rc = hipFuncSetAttribute((const void*)aacg_imdct_run_f32_cpl, hipFuncAttributeMaxDynamicSharedMemorySize, AACG_LDS_BYTES_F32);
+    return rc == hipSuccess ? 0 : -1;
+}
+
+void aacg_couple_run_launch(bool quant, dim3 grid, dim3 block, hipStream_t s, const aacg_kparams& P)
+{
+    if (quant) hipLaunchKernelGGL(aacg_imdct_run_quant_cpl, grid, block, AACG_LDS_BYTES_QUANT, s, P);
+    else       hipLaunchKernelGGL(aacg_imdct_run_f32_cpl, grid, block, AACG_LDS_BYTES_F32, s, P);
+}
+
 void aacg_couple_launch(bool pcm, hipStream_t s, const aacg_couple_params& Q)
 {
     if (Q.n_jobs <= 0) return;

@@ -48,6 +48,11 @@ struct aacg_plan_host {
     std::vector<uint32_t> couple_first;                         /* couple_first[point][round] ... start indices, see aacg_plan.cpp */
     uint32_t couple_rounds = 0;
     std::vector<float> gains;                                   /* [n_cce][16][120] */
+    /* independent coupling fused into the targets' epilogues (plans without double-duty runs): per-unit job lists
+     * (aacg_dev_unit.cpl_first / cpl_n index fused_jobs); the AFTER_IMDCT entries of couple_first are then empty */
+    bool     fused_independent = false;
+    std::vector<aacg_couple_job> fused_jobs;
+    uint32_t fused_first = 0;         /* where they start in couple_jobs (they are appended to it for the upload) */
     std::vector<aacg_chain> chains;
     bool     zero_fill = false;       /* some frame has a channel no unit writes (decoder.js:229-231) */
     uint32_t coef_blocks = 0;         /* 1 + highest (coef_offset + c) referenced */

@@ -98,6 +98,7 @@ struct unit_view {
     int channel, n_out_ch, n_ch, flags;
     int seq[2], shape[2], shape_prev[2], max_sfb[2], tns[2];
     uint32_t gmap[2];           /* 4 bits per window: its group (planner-filled) */
+    uint32_t cpl_first, cpl_n;  /* AACG_CCE_SPEC: this unit's independent-coupling jobs (aacg_dev_unit) */
 };
 DP_DEVICE unit_view load_unit(const aacg_dev_unit* u)
 {
@@ -116,6 +117,7 @@ DP_DEVICE unit_view load_unit(const aacg_dev_unit* u)
         v.gmap[c] = w[16 + c];
     }
     v.tns_offset = w[14];
+    v.cpl_first = w[18]; v.cpl_n = w[19];
     return v;
 }
 
@@ -1494,11 +1496,42 @@ DP_DEVICE void pcm_put2(int16_t* p, float a, float b) { dp_store_i1_u(p, dp_pcm1
 DP_DEVICE void pcm_put1(float* p, float a) { *p = a; }
 DP_DEVICE void pcm_put1(int16_t* p, float a) { *p = (int16_t)(dp_pcm16_pair(a, a) & 0xffff); }
 
-template <bool FROM_LDS, int OUT>
-DP_DEVICE void epilogue(const float* p0, const float* p1, const unit_view& u, int n_ch, int cls0, int cls1,
+/* AACG_CCE_SPEC, independent coupling where the target's PCM is formed (CPL builds of the run kernels): a sample of a target
+ * channel takes data[n] += gain * cce.data[n] (cce.js:121-128; on a Float32Array: one fused multiply-add) for each of its
+ * unit's jobs, in the order of the frame's coupling elements, on the finished sample (overlap + windowed first half),
+ * PCM-scaled like the side buffer.  The job list is wave-uniform: scalar loads. */
+
+/* the first two coupling jobs of a unit, their coupling element's samples lane + 64 j requested before the wave waits for its
+ * predecessor's tails (a job's loads are a memory round trip: inside the epilogue they were 37 us of a 7-channel batch) */
+struct cpl_prefetch { float sv[2][16]; float gain[2]; int second[2]; int n; };
+template <bool CPL>
+DP_DEVICE void couple_prefetch(const aacg_kparams& P, const unit_view& u, cpl_prefetch& pre)
+{
+    pre.n = 0;
+    if (!CPL) return;
+    const int lane = dp_lane();
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        if ((uint32_t)k < u.cpl_n) {
+            const aacg_couple_job* job = AACG_CPL_JOBS(P) + (u.cpl_first + k);
+            const float* src = AACG_CPL_SIDE(P) + (size_t)job->src * 1024u;
+            pre.gain[k] = AACG_CPL_GAINS(P)[job->gain_off];
+            pre.second[k] = job->dst != 0;
+#pragma unroll
+            for (int j = 0; j < 16; j++) pre.sv[k][j] = src[lane + 64 * j];
+            pre.n = k + 1;
+        }
+    }
+}
+
+template <bool FROM_LDS, int OUT, bool CPL = false>
+DP_DEVICE void epilogue(const aacg_kparams& P, const cpl_prefetch& pre, const float* p0, const float* p1, const unit_view& u, int n_ch, int cls0, int cls1,
                         float* pcm_base_f32, const float (&hx0)[8], const float (&hy0)[8],
                         const float (&hx1)[8], const float (&hy1)[8], int lcol /* the lane's column in the long lane map: long_col(lane) or lane */)
 {
+    /* a unit with coupling jobs: the paths that finish a sample in one place — in place in the previous wave's slot, or the
+     * per-channel scalar path of a chain's first frame — so that the jobs are applied to finished samples, in order */
+    const bool coupled = CPL && u.cpl_n > 0;
     typedef typename pcm_elem<OUT>::type elem;
     elem* pcm_base = (elem*)pcm_base_f32;
     const int lane = dp_lane(), w = lane >> 3, g = lane & 7;
@@ -1506,7 +1539,7 @@ DP_DEVICE void epilogue(const float* p0, const float* p1, const unit_view& u, in
     const int C = u.n_out_ch;
     elem* pcm = pcm_base + u.pcm_offset + u.channel;
 
-    if (n_ch == 2 && C == 2 && cls0 == cls1 && ((u.pcm_offset | (uint32_t)u.channel) & 3u) == 0) {
+    if (n_ch == 2 && C == 2 && !coupled && cls0 == cls1 && ((u.pcm_offset | (uint32_t)u.channel) & 3u) == 0) {
         /* stereo fast path: (L[n], R[n], L[n+1], R[n+1]) = 16 bytes per lane */
         if (!cls0) {
             /* all eight reads of the incoming tails first: one LDS (or HBM) round trip, not one per store */
@@ -1550,6 +1583,41 @@ DP_DEVICE void epilogue(const float* p0, const float* p1, const unit_view& u, in
         float* prev = const_cast<float*>(p0);
         overlap_add_in_place(prev, n_ch, cls0, cls1, lcol, hx0, hy0, hx1, hy1);
         dp_wave_sync();
+        if (coupled) {
+            /* the unit's finished samples in registers (sample lane + 64 j of channel 0 / 1), then job after job: its gain
+             * and side block as scalars, sixteen coalesced loads of the coupling element's samples, sixteen multiply-adds */
+            float a[16], b[16];
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                const int n = lane + 64 * j;
+                if (n_ch == 2) { const dpf2 lr = *(const dpf2*)(prev + 2 * n); a[j] = lr.x; b[j] = lr.y; }
+                else           { a[j] = prev[n]; b[j] = 0.0f; }
+            }
+#pragma unroll
+            for (int k = 0; k < 2; k++) {                  /* the prefetched jobs (couple_prefetch) */
+                if (k < pre.n) {
+#pragma unroll
+                    for (int j = 0; j < 16; j++) { if (pre.second[k]) b[j] = dp_fma(pre.gain[k], pre.sv[k][j], b[j]); else a[j] = dp_fma(pre.gain[k], pre.sv[k][j], a[j]); }
+                }
+            }
+            for (uint32_t k = (uint32_t)pre.n; k < u.cpl_n; k++) {
+                const aacg_couple_job* job = AACG_CPL_JOBS(P) + (u.cpl_first + k);
+                const float gain = AACG_CPL_GAINS(P)[job->gain_off];
+                const float* src = AACG_CPL_SIDE(P) + (size_t)job->src * 1024u;
+                const bool second = job->dst != 0;
+                float sv[16];
+#pragma unroll
+                for (int j = 0; j < 16; j++) sv[j] = src[lane + 64 * j];
+#pragma unroll
+                for (int j = 0; j < 16; j++) { if (second) b[j] = dp_fma(gain, sv[j], b[j]); else a[j] = dp_fma(gain, sv[j], a[j]); }
+            }
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                const int n = lane + 64 * j;
+                if (n_ch == 2) pcm_put2(pcm + (size_t)n * C, a[j], b[j]); else pcm_put1(pcm + (size_t)n * C, a[j]);
+            }
+            return;
+        }
         if (n_ch == 2) {
 #pragma unroll
             for (int j = 0; j < 16; j++) {
@@ -1567,7 +1635,7 @@ DP_DEVICE void epilogue(const float* p0, const float* p1, const unit_view& u, in
         return;
     }
 
-    if (n_ch == 2 && cls0 == cls1) {
+    if (n_ch == 2 && cls0 == cls1 && !coupled) {
         /* a CPE inside a wider frame (5.1 etc.): (L[n], R[n]) are adjacent, one 8-byte store per sample
          * (4-byte aligned when the channel count is odd) */
         if (!cls0) {
@@ -1595,6 +1663,49 @@ DP_DEVICE void epilogue(const float* p0, const float* p1, const unit_view& u, in
                     const dpf4 v = incoming<FROM_LDS>(p0, p1, 2, n);
                     pcm_put2(pcm + (size_t)n * C, v.x, v.y);
                     pcm_put2(pcm + (size_t)(n + 1) * C, v.z, v.w);
+                }
+            }
+        }
+        return;
+    }
+
+    if (coupled) {
+        /* the first frame of a chain with coupling jobs (overlap from the state buffer; FROM_LDS units took the in-place
+         * path above): per channel the lane's finished samples (n, n + 1) at up to twelve positions — eight of the
+         * windowed first half, and for EIGHT_SHORT four more of the stretch the overlap alone fills (filter_bank.js:149-151)
+         * — then job after job (gain and side block as scalars, the loads issued together), then the stores */
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            if (c < n_ch) {
+                elem* dst = pcm + c;
+                const int cls = c ? cls1 : cls0;
+                const float (&hx)[8] = c ? hx1 : hx0;
+                const float (&hy)[8] = c ? hy1 : hy0;
+                int pos[12]; bool ok[12]; float x[12], y[12];
+#pragma unroll
+                for (int i = 0; i < 12; i++) {
+                    const int m = i & 7, t4 = i - 8;
+                    if (i < 8) { pos[i] = cls ? 448 + 128 * w + 2 * g + 16 * m : 2 * lcol + 128 * m; ok[i] = !cls || w < 4 || (w == 4 && m < 4); }
+                    else       { pos[i] = 2 * lane + 128 * t4; ok[i] = cls && pos[i] < 448; }
+                    if (!ok[i]) pos[i] = 0;
+                    const dpf4 v = incoming<FROM_LDS>(p0, p1, n_ch, pos[i]);
+                    x[i] = (c ? v.y : v.x) + (i < 8 ? hx[m] : 0.0f);
+                    y[i] = (c ? v.w : v.z) + (i < 8 ? hy[m] : 0.0f);
+                }
+                for (uint32_t k = 0; k < u.cpl_n; k++) {
+                    const aacg_couple_job* job = AACG_CPL_JOBS(P) + (u.cpl_first + k);
+                    if ((int)job->dst != c) continue;
+                    const float gain = AACG_CPL_GAINS(P)[job->gain_off];
+                    const float* src = AACG_CPL_SIDE(P) + (size_t)job->src * 1024u;
+                    dpf2 sv[12];
+#pragma unroll
+                    for (int i = 0; i < 12; i++) sv[i] = *(const dpf2*)(src + pos[i]);
+#pragma unroll
+                    for (int i = 0; i < 12; i++) { x[i] = dp_fma(gain, sv[i].x, x[i]); y[i] = dp_fma(gain, sv[i].y, y[i]); }
+                }
+#pragma unroll
+                for (int i = 0; i < 12; i++) {
+                    if (ok[i]) { pcm_put1(dst + (size_t)pos[i] * C, x[i]); pcm_put1(dst + (size_t)(pos[i] + 1) * C, y[i]); }
                 }
             }
         }
@@ -1658,7 +1769,7 @@ DP_DEVICE void epilogue(const float* p0, const float* p1, const unit_view& u, in
 #define AACG_RUN_XCH_FLOATS AACG_TNS_XCH_FLOATS(AACG_RUN_TNS_ROUND)
 #define AACG_LDS_BYTES_F32_EX   (AACG_LDS_BYTES_F32 + 4 * AACG_WG_WAVES * AACG_RUN_XCH_FLOATS)
 #define AACG_LDS_BYTES_QUANT_EX (AACG_LDS_BYTES_QUANT + 4 * AACG_WG_WAVES * AACG_RUN_XCH_FLOATS)
-template <int KIND, int OUT = AACG_OUTPUT_F32, bool DD = false, bool EX = false>
+template <int KIND, int OUT = AACG_OUTPUT_F32, bool DD = false, bool EX = false, bool CPL = false>
 DP_DEVICE void imdct_run_body(const aacg_kparams& P)
 {
     const int TAB_FLOATS = (KIND == AACG_INPUT_QUANT_I16) ? AACG_TAB_QUANT_FLOATS : AACG_TAB_F32_FLOATS;
@@ -1864,11 +1975,14 @@ DP_DEVICE void imdct_run_body(const aacg_kparams& P)
              * `overlap = this.overlaps[channel]`); a double-duty wave: the tails it parked itself */
             const float* ov0 = n_pass == 2 ? scratch : P.overlap + (P.flip ? run->ov_b[0] : run->ov_a[0]);
             const float* ov1 = n_pass == 2 ? scratch + 1024 : P.overlap + (P.flip ? run->ov_b[1] : run->ov_a[1]);
-            epilogue<false, OUT>(ov0, ov1, u, n_ch, cls0, cls1, P.pcm, hx0, hy0, hx1, hy1, lcol);
+            cpl_prefetch none; none.n = 0;
+            epilogue<false, OUT, CPL>(P, none, ov0, ov1, u, n_ch, cls0, cls1, P.pcm, hx0, hy0, hx1, hy1, lcol);
         } else {
+            cpl_prefetch pre;
+            couple_prefetch<CPL>(P, u, pre);
             dp_flag_wait(&flags[wave - 1], 1);         /* the previous frame's tails (acquire) */
             if (trace && lane == 0) trace[4] = dp_clock();
-            epilogue<true, OUT>(slot - AACG_SLOT_FLOATS, slot - AACG_SLOT_FLOATS, u, n_ch, cls0, cls1, P.pcm, hx0, hy0, hx1, hy1, lcol);
+            epilogue<true, OUT, CPL>(P, pre, slot - AACG_SLOT_FLOATS, slot - AACG_SLOT_FLOATS, u, n_ch, cls0, cls1, P.pcm, hx0, hy0, hx1, hy1, lcol);
         }
         if (trace && lane == 0) trace[5] = dp_clock();     /* PCM stores issued */
         /* the chain's last frame in this launch: its tail is the new overlap state (planar in HBM) */

@@ -287,6 +287,7 @@ int aacg_plan_build(const aacg_unit_desc* units, uint32_t n_units, int sample_in
         out->pcm_floats = std::max(out->pcm_floats, (size_t)((uint64_t)u.pcm_offset + 1024u * (uint64_t)u.n_out_ch));
     }
 
+    std::vector<uint32_t> couple_target;                     /* target unit of couple_jobs[j] */
     if (out->any_cce) {
         /* coupling jobs: every (coupling element, target) pair, by coupling point and by round — the r-th coupling element
          * of a frame is in round r, so that the jobs of one launch never add to the same channel (decoder.js:411-431 walks
@@ -295,7 +296,7 @@ int aacg_plan_build(const aacg_unit_desc* units, uint32_t n_units, int sample_in
         for (uint32_t c = 0; c < n_cce; c++) std::memcpy(&out->gains[(size_t)c * AACG_CCE_MAX_TARGETS * AACG_MAX_SECTIONS], cce[c].gain, sizeof cce[c].gain);
         std::map<uint64_t, std::vector<uint32_t>> frames;      /* (stream, frame) -> its units */
         for (uint32_t i = 0; i < n_units; i++) frames[((uint64_t)units[i].stream << 32) | frame_of[i]].push_back(i);
-        struct keyed { uint32_t key; aacg_couple_job job; };
+        struct keyed { uint32_t key; uint32_t target; aacg_couple_job job; };
         std::vector<keyed> jobs;
         for (auto& fr : frames) {
             uint32_t round = 0;
@@ -318,6 +319,7 @@ int aacg_plan_build(const aacg_unit_desc* units, uint32_t n_units, int sample_in
                     keyed k;
                     std::memset(&k, 0, sizeof k);
                     k.key = ci.coupling_point * 4096u + round;
+                    k.target = (uint32_t)target;
                     k.job.cce_unit = i;
                     k.job.gain_off = (uint32_t)(((size_t)u.reserved1 * AACG_CCE_MAX_TARGETS + ci.target[t].gain_list) * AACG_MAX_SECTIONS);
                     if (ci.coupling_point == AACG_CCE_AFTER_IMDCT) {
@@ -340,7 +342,7 @@ int aacg_plan_build(const aacg_unit_desc* units, uint32_t n_units, int sample_in
         out->couple_first.assign((size_t)3 * out->couple_rounds + 1, (uint32_t)jobs.size());
         for (size_t j = jobs.size(); j-- > 0;) out->couple_first[(size_t)(jobs[j].key / 4096u) * out->couple_rounds + jobs[j].key % 4096u] = (uint32_t)j;
         for (size_t k = out->couple_first.size() - 1; k-- > 0;) out->couple_first[k] = std::min(out->couple_first[k], out->couple_first[k + 1]);
-        for (auto& k : jobs) out->couple_jobs.push_back(k.job);
+        for (auto& k : jobs) { out->couple_jobs.push_back(k.job); couple_target.push_back(k.target); }
     }
     for (auto& s : st) close_frame(s);
     /* every chain must reach its stream's last frame, or a later batch would chain onto a stale tail */
@@ -389,6 +391,38 @@ int aacg_plan_build(const aacg_unit_desc* units, uint32_t n_units, int sample_in
         }
         ch.n_runs = oc.is_cce ? 0 : (uint32_t)gen.size() - ch.first_run;
         out->chains.push_back(ch);
+    }
+
+    /* Independent coupling (cce.js:121-128) where the target's PCM is formed instead of a read-modify-write pass over the
+     * interleaved PCM: the jobs regrouped by target unit, in the order of the frame's coupling elements (the reference adds
+     * them in that order, decoder.js:411-431).  Plans with double-duty runs keep the separate pass (their kernels have no
+     * coupling epilogue). */
+    if (out->any_cce && !out->needs_scratch && out->couple_rounds) {
+        const uint32_t rounds = out->couple_rounds;
+        const uint32_t first = out->couple_first[(size_t)AACG_CCE_AFTER_IMDCT * rounds], last = out->couple_first[(size_t)AACG_CCE_AFTER_IMDCT * rounds + rounds];
+        if (last > first) {
+            struct by_unit { uint32_t unit, order; aacg_couple_job job; };
+            std::vector<by_unit> list;
+            for (uint32_t j = first; j < last; j++) {
+                const aacg_unit_desc& tu = units[couple_target[j]];
+                by_unit b; b.unit = couple_target[j]; b.order = j; b.job = out->couple_jobs[j];
+                b.job.dst = out->couple_jobs[j].dst - (tu.pcm_offset + tu.channel); b.job.stride = 0;     /* channel 0 / 1 of the target unit */
+                list.push_back(b);
+            }
+            if (list.size() == (size_t)(last - first)) {
+                std::stable_sort(list.begin(), list.end(), [](const by_unit& a, const by_unit& b) { return a.unit != b.unit ? a.unit < b.unit : a.order < b.order; });
+                for (size_t j = 0; j < list.size(); j++) {
+                    aacg_dev_unit& du = out->units[list[j].unit];
+                    if (du.cpl_n == 0) du.cpl_first = (uint32_t)j;
+                    du.cpl_n++;
+                    out->fused_jobs.push_back(list[j].job);
+                }
+                /* they travel behind the launch-ordered jobs in the same array (couple_first only indexes the part in front) */
+                out->fused_first = (uint32_t)out->couple_jobs.size();
+                out->couple_jobs.insert(out->couple_jobs.end(), out->fused_jobs.begin(), out->fused_jobs.end());
+                out->fused_independent = true;
+            }
+        }
     }
 
     /* XCD-aware block order: the dispatcher puts block b on XCD b % 8 (observed, speed only), and a

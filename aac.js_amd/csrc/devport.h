@@ -57,7 +57,14 @@ DP_DEVICE void dp_block_sync_lds()
 DP_DEVICE void dp_flag_set(int* flag, int v) { __hip_atomic_store(flag, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
 DP_DEVICE void dp_flag_wait(int* flag, int v)
 {
-    while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != v) __builtin_amdgcn_s_sleep(2);
+    /* every spin is bounded (MI355X_MICROARCH.md, correctness boundaries): a producer that never arrives — which cannot
+     * happen unless a wave of this workgroup died — ends the kernel with a trap after about a second instead of hanging
+     * the queue */
+    unsigned spins = 0;
+    while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != v) {
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins == (1u << 25)) __builtin_trap();
+    }
 }
 /* issue priority of this wave on its SIMD (0..3); s_setprio takes an immediate */
 DP_DEVICE void dp_setprio(int p)

@@ -34,6 +34,8 @@ void* lane_main(void* p)
     if (a->kind == 7) { aacg_parse::parse_body(*a->PP); return nullptr; }
     if (a->kind == 8) { couple_spec_body(*a->Q, 4); return nullptr; }
     if (a->kind == 9) { couple_pcm_body(*a->Q, 4); return nullptr; }
+    if (a->kind == 10) { imdct_run_body<AACG_INPUT_SPEC_F32, AACG_OUTPUT_F32, false, false, true>(*a->P); return nullptr; }   /* aacg_imdct_run_f32_cpl */
+    if (a->kind == 11) { imdct_run_body<AACG_INPUT_QUANT_I16, AACG_OUTPUT_F32, false, false, true>(*a->P); return nullptr; }  /* aacg_imdct_run_quant_cpl */
     const bool dd = a->P->scratch != nullptr;
     if (a->out_kind == AACG_OUTPUT_I16 && a->kind == 0) { if (dd) imdct_run_body<AACG_INPUT_SPEC_F32, AACG_OUTPUT_I16, true>(*a->P); else imdct_run_body<AACG_INPUT_SPEC_F32, AACG_OUTPUT_I16>(*a->P); }
     else if (a->out_kind == AACG_OUTPUT_I16 && a->kind == 1) { if (dd) imdct_run_body<AACG_INPUT_QUANT_I16, AACG_OUTPUT_I16, true>(*a->P); else imdct_run_body<AACG_INPUT_QUANT_I16, AACG_OUTPUT_I16>(*a->P); }
@@ -48,6 +50,7 @@ void* lane_main(void* p)
 }
 
 int g_out_kind = AACG_OUTPUT_F32;          /* emu_set_output_kind: the next decodes store int16 PCM */
+int g_unfused = 0;                         /* emu_set_unfused: independent coupling as the separate pass over the PCM even where the engine fuses it */
 int g_staged = 0;                          /* emu_set_staged: optional stages as a launch of their own even where the engine would not */
 
 void launch(const aacg_kparams& P, int kind, int grid, int waves, size_t lds_bytes, int n_units = 0, const aacg_parse_params* PP = nullptr,
@@ -97,6 +100,7 @@ extern "C" {
 
 const char* emu_last_error() { return g_err.c_str(); }
 void emu_set_staged(int on) { g_staged = on; }
+void emu_set_unfused(int on) { g_unfused = on; }
 void emu_set_output_kind(int kind) { g_out_kind = kind; }       /* AACG_OUTPUT_*: the pcm buffer of later decodes is int16 */
 
 int emu_get_windows(int sample_index, float* dst /* 1024+1024+128+128 */)
@@ -237,19 +241,27 @@ int emu_decode_cce(int input_kind, int sample_index, int max_streams, int max_ch
         P.coeffs = spec.data(); P.meta = nullptr; P.tns = nullptr;
         input_kind = AACG_INPUT_SPEC_F32;
     }
-    if (!ph.runs.empty() && ex)
+    auto cce_filterbank = [&]() {
+        aacg_kparams C = P;
+        C.runs = ph.cce_runs.data(); C.n_runs = (int32_t)ph.cce_runs.size(); C.pcm = side.data(); C.scratch = nullptr;
+        launch(C, input_kind == AACG_INPUT_QUANT_I16 ? 1 : 0, (int)ph.cce_runs.size(), AACG_WG_WAVES,
+               input_kind == AACG_INPUT_QUANT_I16 ? AACG_LDS_BYTES_QUANT : AACG_LDS_BYTES_F32);
+    };
+    const bool fused = ph.fused_independent && !ex && g_out_kind == AACG_OUTPUT_F32 && !g_unfused;     /* the engine's launch_run */
+    if (fused) {
+        if (!ph.cce_runs.empty()) cce_filterbank();
+        aacg_set_cpl(&P, ph.couple_jobs.data() + ph.fused_first, ph.gains.data(), side.data());
+        if (!ph.runs.empty())
+            launch(P, input_kind == AACG_INPUT_QUANT_I16 ? 11 : 10, (int)ph.runs.size(), AACG_WG_WAVES,
+                   input_kind == AACG_INPUT_QUANT_I16 ? AACG_LDS_BYTES_QUANT : AACG_LDS_BYTES_F32);
+    } else if (!ph.runs.empty() && ex)
         launch(P, input_kind == AACG_INPUT_QUANT_I16 ? 6 : 5, (int)ph.runs.size(), AACG_WG_WAVES,
                input_kind == AACG_INPUT_QUANT_I16 ? AACG_LDS_BYTES_QUANT_EX : AACG_LDS_BYTES_F32_EX);
     else if (!ph.runs.empty())
         launch(P, input_kind == AACG_INPUT_QUANT_I16 ? 1 : 0, (int)ph.runs.size(), AACG_WG_WAVES,
                input_kind == AACG_INPUT_QUANT_I16 ? AACG_LDS_BYTES_QUANT : AACG_LDS_BYTES_F32);
-    if (ph.any_cce) {
-        if (!ph.cce_runs.empty()) {
-            aacg_kparams C = P;
-            C.runs = ph.cce_runs.data(); C.n_runs = (int32_t)ph.cce_runs.size(); C.pcm = side.data(); C.scratch = nullptr;
-            launch(C, input_kind == AACG_INPUT_QUANT_I16 ? 1 : 0, (int)ph.cce_runs.size(), AACG_WG_WAVES,
-                   input_kind == AACG_INPUT_QUANT_I16 ? AACG_LDS_BYTES_QUANT : AACG_LDS_BYTES_F32);
-        }
+    if (ph.any_cce && !fused) {
+        if (!ph.cce_runs.empty()) cce_filterbank();
         couple(AACG_CCE_AFTER_IMDCT);
     }
     for (auto& c : ph.chains)

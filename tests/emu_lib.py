@@ -34,8 +34,10 @@ class Emu:
     def error(self):
         return self.lib.emu_last_error().decode()
 
-    def decode(self, units, coeffs, meta, n_pcm, pool, parity, sample_index=3, tns=None, pns=False, int16_out=False, cce=None, staged=False):
-        """staged: the optional stages (TNS, PNS) as a launch of their own even where the engine would run them inside the run kernel."""
+    def decode(self, units, coeffs, meta, n_pcm, pool, parity, sample_index=3, tns=None, pns=False, int16_out=False, cce=None, staged=False, unfused=False):
+        """staged: the optional stages (TNS, PNS) as a launch of their own even where the engine would run them inside the run kernel.
+        unfused: independent coupling as the separate pass over the PCM (what plans with double-duty runs take) even where the
+        engine applies it in the targets' epilogues."""
         units = np.ascontiguousarray(units)
         coeffs = np.ascontiguousarray(coeffs)
         kind = 1 if coeffs.dtype == np.int16 else 0
@@ -44,6 +46,7 @@ class Emu:
         tns = np.ascontiguousarray(tns) if tns is not None else None
         self.lib.emu_set_output_kind(1 if int16_out else 0)
         self.lib.emu_set_staged(1 if staged else 0)
+        self.lib.emu_set_unfused(1 if unfused else 0)
         cce = np.ascontiguousarray(cce) if cce is not None else None
         rc = self.lib.emu_decode_cce(kind, sample_index, pool.shape[0], pool.shape[1], units.ctypes.data, len(units),
                                      coeffs.ctypes.data, meta.ctypes.data if meta is not None else None,
@@ -52,6 +55,7 @@ class Emu:
                                      pcm.ctypes.data, n_pcm, pool.ctypes.data, parity.ctypes.data)
         self.lib.emu_set_output_kind(0)
         self.lib.emu_set_staged(0)
+        self.lib.emu_set_unfused(0)
         if rc:
             raise RuntimeError("emu_decode rc=%d: %s" % (rc, self.error()))
         return pcm

@@ -141,6 +141,25 @@ def test_emulated_kernels_vs_oracle(oracle, layout, points):
     assert np.abs(emu_lib.pool_current(pool, par) - ov).max() <= 1e-5 * max(1.0, float(np.abs(ov).max()))
 
 
+def test_fused_and_separate_independent_coupling_agree(oracle):
+    """Independent coupling is applied where the target's PCM is formed (aacg_imdct_run_*_cpl: per-unit job lists, coupling
+    elements' filterbank first) — except in plans with double-duty runs, which keep the separate pass over the interleaved
+    PCM (aacg_couple_pcm).  Both routes on the same batches: the same samples bit for bit (one fused multiply-add per
+    coupling on the finished sample either way, in the order of the frame's coupling elements), for first frames of chains
+    (overlap from the state buffer), later frames (in place in the previous wave's slot), long and short windows."""
+    for layout, points, T in [(("cpe", "cpe", "cpe", "sce"), (2, 2), 9), (("cpe",), (2,), 6), (("sce", "cpe"), (2, 0, 2), 5)]:
+        S = 2
+        wl, units, q, meta, cce = workload(layout, points, S, T)
+        H = wl["C"] + len(points)
+        outs = []
+        for unfused in (False, True):
+            pool = np.zeros((S, H, 2, 1024), np.float32)
+            outs.append(emu_lib.Emu().decode(units, q, meta, wl["n_pcm"], pool, np.zeros(S * H, np.uint8), cce=cce, unfused=unfused))
+        assert np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32))
+        ov = np.zeros((S, H, 1024), np.float32)
+        assert rel(outs[0], oracle.decode_batch(units, q, meta, wl["n_pcm"], ov, cce=cce)) < RMS_REL
+
+
 def test_planner_refuses_coupling_elements_without_the_mode(oracle):
     wl, units, q, meta, cce = workload(("cpe",), (0,))
     pool = np.zeros((2, 3, 2, 1024), np.float32)
