@@ -1189,9 +1189,9 @@ DP_DEVICE void stage_pair_f32(const dpf4 (&xa)[4], const dpf4 (&xb)[4], float* s
  *   4. the block again from its true incoming state, same arithmetic as step 1, written back in place.
  * EIGHT_SHORT (one filter per window, 128 samples, order <= 7): lane w of a half runs window w serially in place,
  * four samples per trip — no transition matrices at all.
- * xch: the wave's exchange area, AACG_SPX_XCH_FLOATS floats (per half: the c_b of a round of blocks, two P-float state buffers). */
+ * xch: the wave's exchange area, AACG_SPX_XCH_FLOATS floats (per half: the c_b of a round of blocks). */
 #define AACG_TNS_BLOCK 32
-#define AACG_TNS_XCH_FLOATS(R) (2 * ((R) + 2) * AACG_TNS_MAX_ORDER)   /* per wave: two halves of [R][P] + 2 [P] floats */
+#define AACG_TNS_XCH_FLOATS(R) (2 * (R) * AACG_TNS_MAX_ORDER)   /* per wave: two halves of [R][P] floats (the c_b of a round of blocks) */
 
 /* chunk c (four samples in processing order) of the run that starts at blk */
 DP_DEVICE void tns_chunk_load(const float* blk, int inc, int c, float (&x)[4])
@@ -1251,7 +1251,6 @@ DP_DEVICE void tns_long_pass(float* slot, float* xch, const aacg_dev_tns* recA, 
     for (int k = 0; k < P; k++) lpc[k] = (k < order) ? rec->lpc[f][k] : 0.0f;
     float* area = slot + 1024 * half;
     float* cbuf = xch + AACG_TNS_XCH_FLOATS(R) / 2 * half;   /* c_b of a round's blocks, [R][P] floats */
-    float* vbuf = cbuf + R * P;                          /* two state buffers of P floats (steps alternate) */
 
     /* this lane's block, in processing order; blocks before the last are full */
     const int m0 = BL * b;
@@ -1264,10 +1263,12 @@ DP_DEVICE void tns_long_pass(float* slot, float* xch, const aacg_dev_tns* recA, 
     for (int k = 0; k < P; k++) c_own[k] = 0.0f;
     tns_run<P, false>(blk, inc, BL / 4, n_valid, lpc, c_own);
 
-    /* 2. row b of M = A^BL: w <- w A, BL times, from e_b (A: first row -lpc, ones below the diagonal) */
-    double row[P];                                       /* lanes b >= P: zeros, they ride along */
+    /* 2. row r of M = A^BL: w <- w A, BL times, from e_r (A: first row -lpc, ones below the diagonal).  Every row of
+     * sixteen lanes holds the twelve rows (lane r of the row: row r): the carry below then never leaves a lane row */
+    const int r16 = lane & 15;
+    double row[P];                                       /* lanes r16 >= P: zeros, they ride along */
 #pragma unroll
-    for (int k = 0; k < P; k++) row[k] = (k == b) ? 1.0 : 0.0;
+    for (int k = 0; k < P; k++) row[k] = (k == r16) ? 1.0 : 0.0;
 #pragma unroll 2
     for (int step = 0; step < BL; step++) {
         const double w0 = row[0];
@@ -1289,7 +1290,7 @@ DP_DEVICE void tns_long_pass(float* slot, float* xch, const aacg_dev_tns* recA, 
     float s_in[P];
 #pragma unroll
     for (int k = 0; k < P; k++) s_in[k] = 0.0f;
-    float vmine = 0.0f;                                  /* row lane r: v_(s-1)[r] */
+    float vmine = 0.0f;                                  /* lane r of a lane row: v_(s-1)[r] */
 #pragma unroll 1
     for (int g = 0; R * g <= n_steps; g++) {
         if (b / R == g) {
@@ -1299,7 +1300,7 @@ DP_DEVICE void tns_long_pass(float* slot, float* xch, const aacg_dev_tns* recA, 
         dp_wave_sync();
         float cs[R];
 #pragma unroll
-        for (int j = 0; j < R; j++) cs[j] = cbuf[P * j + (b < P ? b : 0)];
+        for (int j = 0; j < R; j++) cs[j] = cbuf[P * j + (r16 < P ? r16 : 0)];
         dp_wave_sync();
 #pragma unroll
         for (int j = 0; j < R; j++) {
@@ -1307,10 +1308,11 @@ DP_DEVICE void tns_long_pass(float* slot, float* xch, const aacg_dev_tns* recA, 
             if (st <= n_steps) {                         /* wave-uniform */
                 double acc0 = (double)cs[j], acc1 = 0.0, acc2 = 0.0;
                 if (st > 0) {
-                    const float* vprev = vbuf + P * ((st - 1) & 1);
+                    /* v_(s-1) from the twelve row lanes of this lane's own row of sixteen: DPP broadcasts on the VALU
+                     * (round 2 kept the state in LDS: a store, a wave-wide sync and three loads on every step's critical
+                     * path — the carry is one long dependency chain, its latency is what the filter costs) */
                     float f[P];
-#pragma unroll
-                    for (int k = 0; k < P; k += 4) { const dpf4 t = *(const dpf4*)(vprev + k); f[k] = t.x; f[k + 1] = t.y; f[k + 2] = t.z; f[k + 3] = t.w; }
+                    dp_row_gather12(vmine, f);
 #pragma unroll
                     for (int k = 0; k < P; k++) s_in[k] = (b == st) ? f[k] : s_in[k];
 #pragma unroll
@@ -1321,8 +1323,6 @@ DP_DEVICE void tns_long_pass(float* slot, float* xch, const aacg_dev_tns* recA, 
                     }
                 }
                 vmine = (float)(acc0 + (acc1 + acc2));
-                if (b < P) vbuf[P * (st & 1) + b] = vmine;
-                dp_wave_sync();
             }
         }
     }

@@ -137,6 +137,23 @@ DP_DEVICE void dp_window_mirror(const float (&src)[8], const float (&w)[4], floa
 #undef DP_WM_BLOCK
 }
 
+/* out[k] <- the value v of lane k of this lane's row of sixteen, k = 0..11: DPP row_newbcast on the VALU (the TNS carry's
+ * state vector: twelve values held by twelve lanes of a row, wanted by every lane of the row — through LDS that was a
+ * store, a wave-wide sync and three 16-byte loads on the critical path of every step) */
+DP_DEVICE void dp_row_gather12(float v, float (&out)[12])
+{
+    __asm__ volatile("s_nop 1\n\t"
+            "v_mov_b32_dpp %0, %12 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %1, %12 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+            "v_mov_b32_dpp %2, %12 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %3, %12 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+            "v_mov_b32_dpp %4, %12 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %5, %12 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
+            "v_mov_b32_dpp %6, %12 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %7, %12 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
+            "v_mov_b32_dpp %8, %12 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %9, %12 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
+            "v_mov_b32_dpp %10, %12 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %11, %12 row_newbcast:11 row_mask:0xf bank_mask:0xf"
+            : "=&v"(out[0]), "=&v"(out[1]), "=&v"(out[2]), "=&v"(out[3]), "=&v"(out[4]), "=&v"(out[5]),
+              "=&v"(out[6]), "=&v"(out[7]), "=&v"(out[8]), "=&v"(out[9]), "=&v"(out[10]), "=&v"(out[11])
+            : "v"(v));
+}
+
 template <int N>
 DP_DEVICE void dp_shfl(double (&v)[N], int src)
 {

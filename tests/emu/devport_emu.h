@@ -81,6 +81,15 @@ DP_DEVICE void dp_window_mirror(const float (&src)[8], const float (&w)[4], floa
     for (int i = 0; i < 8; i++) out[i] = (i < 6 ? -m[i] : m[i]) * w[i >> 1];
 }
 
+/* out[k] <- the value v of lane k of this lane's row of sixteen (devport.h) */
+DP_DEVICE void dp_row_gather12(float v, float (&out)[12])
+{
+    g_emu.w->shfl[g_emu.lane][0] = v;
+    pthread_barrier_wait(&g_emu.w->bar);
+    for (int k = 0; k < 12; k++) out[k] = g_emu.w->shfl[(g_emu.lane & ~15) | k][0];
+    pthread_barrier_wait(&g_emu.w->bar);
+}
+
 template <int N>
 DP_DEVICE void dp_shfl(double (&v)[N], int src)
 {
