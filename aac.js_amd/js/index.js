@@ -354,7 +354,7 @@ GpuAACDecoder.prototype.decodeAhead = function () {
     const layoutOf = function (f) {
         let k = 0;                                      // coupling elements count from stream channel C on, in frame order
         return f.elements.map(function (e) {
-            if (e.couplingPoint === undefined) return e.type + e.id;
+            if (e.couplingPoint === undefined) return e.type;          // channels are dealt out in element order (decoder.js:233-247): the tags do not matter
             return e.couplingPoint === 2 ? 'cce@' + k++ : (k++, '');     // dependent coupling (spectral domain) carries no state
         }).join(',');
     };

@@ -110,7 +110,7 @@ const tnsLong = { short: false, nFilt: [2], length: [[20, 9]], order: [[3, 1]], 
 // batch's frames in the queue: later frames still follow, in order
 {
     const frame = function (types) {
-        return { elements: types.map(function (t, i) { return { type: t, id: i, ch: [{ windowSequence: 0, windowShape: 0, maxSFB: 0, groupLength: [1] }] }; }),
+        return { elements: types.map(function (t, i) { return { type: t, id: (i * 7 + types.length) & 15, ch: [{ windowSequence: 0, windowShape: 0, maxSFB: 0, groupLength: [1] }] }; }),
                  q: new Int16Array(1024 * types.length), meta: new Uint16Array(120 * types.length) };
     };
     const script = [frame(['sce']), frame(['sce']), frame(['sce', 'lfe']), frame(['sce', 'lfe']), frame(['sce']), frame(['sce']), frame(['sce']), null, null];

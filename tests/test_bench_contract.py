@@ -7,7 +7,7 @@ import os
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LINES = sorted(glob.glob(os.path.join(ROOT, "profiles", "r02_bench_*.json")))
+LINES = sorted(glob.glob(os.path.join(ROOT, "profiles", "r02_bench_*.json")) + glob.glob(os.path.join(ROOT, "profiles", "r03_bench_*.json")))
 
 
 def _load(path):
@@ -34,10 +34,22 @@ def test_bench_line_contract(path):
     assert d["parity"]["rms"] <= d["parity"]["gate_rms"] and d["parity"]["rel"] <= d["parity"]["gate_rel"]
 
 
-def test_headline_line_has_the_cpu_baseline_and_traffic():
-    d = _load(os.path.join(ROOT, "profiles", "r02_bench_quant.json"))
+@pytest.mark.parametrize("rnd", ["r02", "r03"])
+def test_headline_line_has_the_cpu_baseline_and_traffic(rnd):
+    d = _load(os.path.join(ROOT, "profiles", rnd + "_bench_quant.json"))
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] > 1 and cb["value"] > cb["single_core"]["value"] > 0 and cb["sample"]
     assert d["n_gpus"] == 1 and d["roofline"]["kernel"] == "aacg_imdct_run_quant"
     assert d["roofline"]["traffic"] and 0.9 < d["roofline"]["traffic"] / d["roofline"]["algorithmic_bytes_per_launch"] < 1.2
     assert "config 2" in d["config"]["workload"]
+
+
+def test_round3_lines_carry_the_same_run_copy_ceiling():
+    """Round 3: every line measures, in the same process right behind the timed region, what a float4 copy launch of the step's
+    byte volume gets on that box (aacg_calib_copy) — boxes of the pool differ by several per cent, `frac_of_copy` does not."""
+    for path in LINES:
+        if "r03_" not in os.path.basename(path):
+            continue
+        r = _load(path)["roofline"]
+        assert r["copy_ceiling_GBs"] > 0 and abs(r["frac_of_copy"] - r["achieved"] / r["copy_ceiling_GBs"]) < 1e-9
+        assert r["copy_ceiling_large_GBs"] > 1000 and r["kernel"].startswith("aacg_")

@@ -7,7 +7,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd $R
-python3 -c "import torch" >/dev/null 2>&1
+timeout 200 python3 -c "import torch; torch.zeros(1).cuda()" >/dev/null 2>&1 || { echo "gpu init failed or slow"; exit 1; }
 b() { name=$1; shift; python3 bench.py "$@" > $OUT/bench_$name.json 2> $OUT/bench_$name.err || echo "bench $name failed" >> $OUT/failures.txt; tail -c 400 $OUT/bench_$name.json | head -c 0; }
 b quant
 b quant_20steps --steps 20 --warmup 5
