@@ -853,8 +853,8 @@ DP_DEVICE void band_indices(const band_raw& r, const chan_ctx& cc, int (&idx)[4]
  * index, negate, ms_used, band type), so the decisions are shifts of small constants by the band type instead of
  * compare chains — `K >> type & 1` with K the set of types for which the property holds; the wave-uniform conditions
  * (two channels, MS possible, mask present) are folded into those constants on the scalar unit. */
-DP_DEVICE void prepare_bands(const quant_regs& r, const float (&sl_in)[2], const float (&sr_in)[2],
-                             bool two, bool ms_on, bool mask, float* bt)
+template <int H0, int H1>
+DP_DEVICE void prepare_bands(const quant_regs& r, const float* tab, bool two, bool ms_on, bool mask, float* bt)
 {
     const int lane = dp_lane();
     unsigned* bw = (unsigned*)bt;
@@ -863,8 +863,15 @@ DP_DEVICE void prepare_bands(const quant_regs& r, const float (&sl_in)[2], const
     const unsigned kLiveR = two ? kCoded : 0u, kMsL = ms_on ? kBelowNoise : 0u;
     const unsigned kIs = two ? 0xC000u : 0u;           /* INTENSITY_BT2, INTENSITY_BT on the right channel */
     const unsigned mask_u = mask ? 1u : 0u;
+    /* one batch of independent LDS reads: the SF-table entries of this lane's bands */
+    float sl_in[2], sr_in[2];
 #pragma unroll
-    for (int h = 0; h < 2; h++) {
+    for (int h = H0; h < H1; h++) {
+        sl_in[h] = tab[AACG_TAB_OFF_SF + (r.mw[0][h] & AACG_META_SF_MASK)];
+        sr_in[h] = tab[AACG_TAB_OFF_SF + (r.mw[1][h] & AACG_META_SF_MASK)];
+    }
+#pragma unroll
+    for (int h = H0; h < H1; h++) {
         const int b = lane + 64 * h;
         const bool coded = b < AACG_MAX_SECTIONS;      /* the rest (incl. AACG_BR_NONE) are empty records: band type 0 */
         const unsigned wl = coded ? r.mw[0][h] : 0u, wr = coded ? r.mw[1][h] : 0u;
@@ -1020,16 +1027,19 @@ DP_DEVICE void spectral_quant(const aacg_kparams& P, const float* tab, const uni
     const bool two = n_ch == 2;
     const bool ms_on = two && (u.flags & AACG_UNIT_COMMON_WINDOW) && (u.flags & AACG_UNIT_MASK_PRESENT);
     const bool mask  = (u.flags & AACG_UNIT_MASK_PRESENT) != 0;
-    /* one batch of independent LDS reads: the four SF-table entries of this lane's two bands and the band maps */
-    float sl[2], sr[2];
-#pragma unroll
-    for (int h = 0; h < 2; h++) {
-        sl[h] = tab[AACG_TAB_OFF_SF + (qreg.mw[0][h] & AACG_META_SF_MASK)];
-        sr[h] = tab[AACG_TAB_OFF_SF + (qreg.mw[1][h] & AACG_META_SF_MASK)];
-    }
     band_raw braw;
     band_raw_load(tab, braw);
-    prepare_bands(qreg, sl, sr, two, ms_on, mask, bt);
+    /* band indices g * maxSFB + sfb reach 64 and beyond only with window groups (8 x 15 sections); a long window has
+     * at most 51 bands, so its frames prepare one band per lane and the "no band" record (wave-uniform) */
+    if (ccL.cls | ccR.cls) {
+        dp_keep_branch();
+        prepare_bands<0, 2>(qreg, tab, two, ms_on, mask, bt);
+    } else {
+        prepare_bands<0, 1>(qreg, tab, two, ms_on, mask, bt);
+        dpf2 none; none.x = none.y = 0.0f;
+        *(dpf2*)(bt + 2 * (64 + dp_lane())) = none;
+        *(dpf2*)(bt + 256 + 2 * (64 + dp_lane())) = none;
+    }
     int idxL[4], idxR[4];
     band_indices(braw, ccL, idxL);
 #pragma unroll
@@ -1048,7 +1058,8 @@ DP_DEVICE void spectral_quant(const aacg_kparams& P, const float* tab, const uni
         recL[k] = *(const dpf2*)(bt + 2 * idxL[k]);
         recR[k] = *(const dpf2*)(bt + 256 + 2 * idxR[k]);
     }
-    bool  g_ms[4], g_is[4], liveL[4], liveR[4];
+    dp_lanes g_ms[4], g_is[4];
+    bool  liveL[4], liveR[4], isR[4];
     float g_isc[4], sfL[4], sfR[4];
     int big = 0;
     const int iq0 = dp_lds_addr(tab + AACG_TAB_OFF_IQ_SMALL + 512);
@@ -1056,13 +1067,14 @@ DP_DEVICE void spectral_quant(const aacg_kparams& P, const float* tab, const uni
     for (int k = 0; k < 4; k++) {
         const int i = k >> 1, h = k & 1;
         const unsigned fl = __builtin_bit_cast(unsigned, recL[k].y), fr = __builtin_bit_cast(unsigned, recR[k].y);
-        g_ms[k] = (fl & AACG_BR_FLAG) != 0;
-        g_is[k] = (fr & AACG_BR_FLAG) != 0;
+        g_ms[k] = dp_lanes_where((fl & AACG_BR_FLAG) != 0);
+        g_is[k] = dp_lanes_where((fr & AACG_BR_FLAG) != 0);
+        isR[k] = (fr & AACG_BR_FLAG) != 0;
         liveL[k] = (fl & AACG_BR_LIVE) != 0;
         liveR[k] = (fr & AACG_BR_LIVE) != 0;
         sfL[k] = recL[k].x;
         g_isc[k] = recR[k].x;
-        sfR[k] = g_is[k] ? 0.0f : recR[k].x;
+        sfR[k] = isR[k] ? 0.0f : recR[k].x;
         /* the addend is -0 on a band that carries coefficients, +0 elsewhere: the flag's sign bit */
         dequant4(iq0, sfL[k], __builtin_bit_cast(float, fl & AACG_BR_LIVE), h ? ql[i].z : ql[i].x, h ? ql[i].w : ql[i].y, *(float (*)[4])&xl[4 * k], big);
         dequant4(iq0, sfR[k], __builtin_bit_cast(float, fr & AACG_BR_LIVE), h ? qr[i].z : qr[i].x, h ? qr[i].w : qr[i].y, *(float (*)[4])&xr[4 * k], big);
@@ -1086,30 +1098,23 @@ DP_DEVICE void spectral_quant(const aacg_kparams& P, const float* tab, const uni
     }
     if (two) {
         /* wave-uniform skips: most frames carry no intensity bands, many no MS */
-        if (dp_any(g_ms[0] || g_ms[1] || g_ms[2] || g_ms[3])) {
+        if (dp_lanes_any(g_ms[0] | g_ms[1] | g_ms[2] | g_ms[3])) {
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-#pragma unroll
-                for (int e = 0; e < 4; e += 2) {       /* sums and differences two at a time (v_pk_add_f32) */
-                    dpv2 a, b;
-                    a[0] = xl[4 * k + e]; a[1] = xl[4 * k + e + 1];
-                    b[0] = xr[4 * k + e]; b[1] = xr[4 * k + e + 1];
-                    const dpv2 sum = a + b, dif = a - b;
-                    xl[4 * k + e]     = g_ms[k] ? sum[0] : a[0];
-                    xl[4 * k + e + 1] = g_ms[k] ? sum[1] : a[1];
-                    xr[4 * k + e]     = g_ms[k] ? dif[0] : b[0];
-                    xr[4 * k + e + 1] = g_ms[k] ? dif[1] : b[1];
-                }
+            for (int k = 0; k < 4; k++) {              /* sums and differences two at a time, under the group's lane mask */
+                dpv2 a0 = v2(xl[4 * k], xl[4 * k + 1]), a1 = v2(xl[4 * k + 2], xl[4 * k + 3]);
+                dpv2 b0 = v2(xr[4 * k], xr[4 * k + 1]), b1 = v2(xr[4 * k + 2], xr[4 * k + 3]);
+                dp_sumdiff_where(g_ms[k], a0, a1, b0, b1);
+                xl[4 * k] = a0[0]; xl[4 * k + 1] = a0[1]; xl[4 * k + 2] = a1[0]; xl[4 * k + 3] = a1[1];
+                xr[4 * k] = b0[0]; xr[4 * k + 1] = b0[1]; xr[4 * k + 2] = b1[0]; xr[4 * k + 3] = b1[1];
             }
         }
-        if (dp_any(g_is[0] || g_is[1] || g_is[2] || g_is[3])) {
+        if (dp_lanes_any(g_is[0] | g_is[1] | g_is[2] | g_is[3])) {
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    const float is = xl[4 * k + e] * g_isc[k];
-                    xr[4 * k + e] = g_is[k] ? is : xr[4 * k + e];
-                }
+                const dpv2 l0 = v2(xl[4 * k], xl[4 * k + 1]), l1 = v2(xl[4 * k + 2], xl[4 * k + 3]);
+                dpv2 r0 = v2(xr[4 * k], xr[4 * k + 1]), r1 = v2(xr[4 * k + 2], xr[4 * k + 3]);
+                dp_scale_where(g_is[k], l0, l1, g_isc[k], r0, r1);
+                xr[4 * k] = r0[0]; xr[4 * k + 1] = r0[1]; xr[4 * k + 2] = r1[0]; xr[4 * k + 3] = r1[1];
             }
         }
     }

@@ -194,6 +194,44 @@ DP_DEVICE dpv2 dp_fma2(dpv2 a, dpv2 b, dpv2 c) { return __builtin_elementwise_fm
 DP_DEVICE int dp_lds_atomic_add(int* p, int v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
 DP_DEVICE bool dp_any(bool p) { return __any(p) != 0; }
+
+/* A set of lanes as a value: the wave's lane mask in a scalar register pair (what a compare produces anyway). */
+typedef unsigned long long dp_lanes;
+#define dp_lanes_where(p) __builtin_amdgcn_ballot_w64(p)
+DP_DEVICE bool dp_lanes_any(dp_lanes m) { return m != 0; }
+
+/* Lanes of m: (a, b) <- (a + b, a - b) on two register pairs, the other lanes untouched — the additions run under
+ * an EXEC mask instead of being computed everywhere and selected per element (2 v_pk_add + 4 v_cndmask per pair become
+ * 2 v_pk_add + 1 v_pk_mov). */
+DP_DEVICE void dp_sumdiff_where(dp_lanes m, dpv2& a0, dpv2& a1, dpv2& b0, dpv2& b1)
+{
+    unsigned long long sv;
+    dpv2 t0, t1;
+    asm volatile("s_and_saveexec_b64 %[sv], %[m]\n\t"
+                 "v_pk_add_f32 %[t0], %[a0], %[b0]\n\t"
+                 "v_pk_add_f32 %[t1], %[a1], %[b1]\n\t"
+                 "v_pk_add_f32 %[b0], %[a0], %[b0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+                 "v_pk_add_f32 %[b1], %[a1], %[b1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+                 "v_pk_mov_b32 %[a0], %[t0], %[t0] op_sel:[0,1]\n\t"
+                 "v_pk_mov_b32 %[a1], %[t1], %[t1] op_sel:[0,1]\n\t"
+                 "s_mov_b64 exec, %[sv]"
+                 : [sv] "=&s"(sv), [t0] "=&v"(t0), [t1] "=&v"(t1), [a0] "+v"(a0), [a1] "+v"(a1), [b0] "+v"(b0), [b1] "+v"(b1)
+                 : [m] "s"(m)
+                 : "scc");
+}
+/* Lanes of m: r <- l * s on two register pairs (v_pk_mul_f32 under an EXEC mask), the other lanes untouched. */
+DP_DEVICE void dp_scale_where(dp_lanes m, const dpv2& l0, const dpv2& l1, float s, dpv2& r0, dpv2& r1)
+{
+    unsigned long long sv;
+    dpv2 sc; sc[0] = sc[1] = s;
+    asm volatile("s_and_saveexec_b64 %[sv], %[m]\n\t"
+                 "v_pk_mul_f32 %[r0], %[l0], %[sc]\n\t"
+                 "v_pk_mul_f32 %[r1], %[l1], %[sc]\n\t"
+                 "s_mov_b64 exec, %[sv]"
+                 : [sv] "=&s"(sv), [r0] "+v"(r0), [r1] "+v"(r1)
+                 : [m] "s"(m), [l0] "v"(l0), [l1] "v"(l1), [sc] "v"(sc)
+                 : "scc");
+}
 /* streaming (non-temporal) 16-byte accesses: PCM is written once and never re-read by the kernel,
  * spectra are read once */
 typedef float dp_nv4 __attribute__((ext_vector_type(4)));

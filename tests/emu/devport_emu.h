@@ -135,6 +135,20 @@ DP_DEVICE int dp_pk_add_u16(int a, int b)
 }
 DP_DEVICE float dp_fma(float a, float b, float c) { return fmaf(a, b, c); }
 DP_DEVICE double dp_fma(double a, double b, double c) { return fma(a, b, c); }
+typedef bool dp_lanes;                                 /* lane-by-lane: a lane's own membership */
+#define dp_lanes_where(p) ((bool)(p))
+DP_DEVICE bool dp_lanes_any(dp_lanes m) { return dp_any(m); }
+DP_DEVICE void dp_sumdiff_where(dp_lanes on, dpv2& a0, dpv2& a1, dpv2& b0, dpv2& b1)
+{
+    if (on) {
+        const dpv2 s0 = a0 + b0, s1 = a1 + b1, d0 = a0 - b0, d1 = a1 - b1;
+        a0 = s0; a1 = s1; b0 = d0; b1 = d1;
+    }
+}
+DP_DEVICE void dp_scale_where(dp_lanes on, const dpv2& l0, const dpv2& l1, float s, dpv2& r0, dpv2& r1)
+{
+    if (on) { r0[0] = l0[0] * s; r0[1] = l0[1] * s; r1[0] = l1[0] * s; r1[1] = l1[1] * s; }
+}
 DP_DEVICE dpv2 dp_fma2(dpv2 a, dpv2 b, dpv2 c) { dpv2 r; r[0] = fmaf(a[0], b[0], c[0]); r[1] = fmaf(a[1], b[1], c[1]); return r; }
 DP_DEVICE void dp_store_nt(dpf4* p, dpf4 v) { *p = v; }
 DP_DEVICE void dp_store2_u(float* p, float a, float b) { p[0] = a; p[1] = b; }
