@@ -59,8 +59,9 @@ struct aacg_tables {
  * (512 complex, XOR-swizzled instead of padded) and finally its windowed tail, which the
  * next wave reads after the workgroup barrier. */
 #define AACG_SLOT_FLOATS  2048
-/* the slots start on a 128-byte boundary: the kernels XOR small offsets into slot addresses (long_pair) */
-#define AACG_TAB_SLOT_BASE(tab_floats) (((tab_floats) + 31) & ~31)
+/* the slots start on a 512-byte boundary: the kernels XOR small offsets into slot addresses (long_pair), and the
+ * strided two-address LDS reads (ds_read2st64_b64) count their offsets in units of 512 bytes */
+#define AACG_TAB_SLOT_BASE(tab_floats) (((tab_floats) + 127) & ~127)
 #define AACG_LDS_FLOATS(tab_floats) (AACG_TAB_SLOT_BASE(tab_floats) + AACG_WG_WAVES * AACG_SLOT_FLOATS + AACG_WG_WAVES)   /* + one hand-off flag per wave */
 #define AACG_LDS_BYTES_F32    (4 * AACG_LDS_FLOATS(AACG_TAB_F32_FLOATS))
 #define AACG_LDS_BYTES_QUANT  (4 * AACG_LDS_FLOATS(AACG_TAB_QUANT_FLOATS))

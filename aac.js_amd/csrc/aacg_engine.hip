@@ -29,22 +29,18 @@ void aacg_imdct_run_f32(const aacg_kparams P) { imdct_run_body<AACG_INPUT_SPEC_F
 /* The variant for plans with full later runs (_dd: their first wave does double duty) lives in aacg_engine_ext.hip,
  * the optional TNS / PNS stages in aacg_engine_spectral.hip: their own code objects, so that adding to them never
  * moves the two kernels above. */
-int aacg_ext_set_lds_limits(void);
 void aacg_ext_launch(bool quant, dim3 grid, dim3 block, hipStream_t s, const aacg_kparams& P);
 /* aacg_engine_spectral.hip: the optional stages (AACG_PNS_SPEC noise bands, AACG_TNS_SPEC filters) -> f32 spectra */
 void aacg_refresh_launch(aacg_dev_unit* units, const aacg_unit_desc* parsed, const aacg_parse_result* results, uint32_t n_units,
                          uint32_t max_units, int refuse_pns, uint32_t* refused, hipStream_t s);
 /* aacg_engine_i16.hip: the run kernels with int16 PCM stores (AACG_OUTPUT_I16 engines) */
-int aacg_i16_set_lds_limits(void);
 void aacg_i16_launch(bool quant, bool dd, dim3 grid, dim3 block, hipStream_t s, const aacg_kparams& P);
 /* aacg_engine_exrun.hip: the run kernels with the optional stages inside (one launch for TNS / PNS batches) */
-int aacg_exrun_set_lds_limits(void);
 void aacg_exrun_launch(bool quant, dim3 grid, dim3 block, hipStream_t s, const aacg_kparams& P);
 int aacg_spectral_ex_set_lds_limits(void);
 void aacg_spectral_ex_launch(bool quant, int n_units, hipStream_t s, const aacg_kparams& P);
 /* aacg_engine_couple.hip: AACG_CCE_SPEC */
 void aacg_couple_launch(bool pcm, hipStream_t s, const aacg_couple_params& Q);
-int aacg_couple_set_lds_limits(void);
 void aacg_couple_run_launch(bool quant, dim3 grid, dim3 block, hipStream_t s, const aacg_kparams& P);
 struct cce_bufs { const aacg_run* runs; const aacg_couple_job* jobs; const float* gains; float* side; };
 
@@ -284,8 +280,8 @@ int launch_run(aacg_engine* e, const aacg_dev_unit* d_units, const aacg_run* d_r
     auto cce_filterbank = [&]() {                       /* the independently switched coupling elements' own filterbank pass */
         aacg_kparams C = P;
         C.runs = cb.runs; C.n_runs = (int32_t)h.cce_runs.size(); C.pcm = cb.side; C.scratch = nullptr;
-        if (quant) hipLaunchKernelGGL(aacg_imdct_run_quant, dim3((unsigned)h.cce_runs.size()), block, AACG_LDS_BYTES_QUANT, s, C);
-        else       hipLaunchKernelGGL(aacg_imdct_run_f32, dim3((unsigned)h.cce_runs.size()), block, AACG_LDS_BYTES_F32, s, C);
+        if (quant) hipLaunchKernelGGL(aacg_imdct_run_quant, dim3((unsigned)h.cce_runs.size()), block, 0, s, C);
+        else       hipLaunchKernelGGL(aacg_imdct_run_f32, dim3((unsigned)h.cce_runs.size()), block, 0, s, C);
     };
     const bool fused = h.fused_independent && !ex && !i16;
     if (fused) {
@@ -302,8 +298,8 @@ int launch_run(aacg_engine* e, const aacg_dev_unit* d_units, const aacg_run* d_r
         } else if (h.needs_scratch) {
             aacg_ext_launch(quant, grid, block, s, P);
         } else {
-            if (quant) hipLaunchKernelGGL(aacg_imdct_run_quant, grid, block, AACG_LDS_BYTES_QUANT, s, P);
-            else       hipLaunchKernelGGL(aacg_imdct_run_f32, grid, block, AACG_LDS_BYTES_F32, s, P);
+            if (quant) hipLaunchKernelGGL(aacg_imdct_run_quant, grid, block, 0, s, P);
+            else       hipLaunchKernelGGL(aacg_imdct_run_f32, grid, block, 0, s, P);
         }
     }
     if (h.any_cce && !fused) {
@@ -364,10 +360,8 @@ int aacg_create(const aacg_config* cfg, aacg_engine** out)
         !hip_ok(e, hipMalloc((void**)&e->d_overlap, ov_bytes), "hipMalloc overlap") ||
         !hip_ok(e, hipMemcpy(e->d_tab, &e->h_tab, sizeof(aacg_tables), hipMemcpyHostToDevice), "upload tables") ||
         !hip_ok(e, hipMemset(e->d_overlap, 0, ov_bytes), "zero overlap") ||
-        /* ~158 KiB of dynamic LDS per workgroup is above the 64 KiB default limit */
-        !hip_ok(e, hipFuncSetAttribute((const void*)aacg_imdct_run_quant, hipFuncAttributeMaxDynamicSharedMemorySize, AACG_LDS_BYTES_QUANT), "LDS attr") ||
-        !hip_ok(e, hipFuncSetAttribute((const void*)aacg_imdct_run_f32, hipFuncAttributeMaxDynamicSharedMemorySize, AACG_LDS_BYTES_F32), "LDS attr") ||
-        aacg_ext_set_lds_limits() != 0 || aacg_i16_set_lds_limits() != 0 || aacg_exrun_set_lds_limits() != 0 || aacg_spectral_ex_set_lds_limits() != 0 || aacg_couple_set_lds_limits() != 0 ||
+        /* (the run kernels' ~152 KiB of LDS per workgroup are static allocations: dp_lds_fixed) */
+        aacg_spectral_ex_set_lds_limits() != 0 ||
         !hip_ok(e, hipFuncSetAttribute((const void*)aacg_spectral, hipFuncAttributeMaxDynamicSharedMemorySize, AACG_LDS_BYTES_SPECTRAL), "LDS attr")) {
         std::fprintf(stderr, "aacgpu: %s\n", e->err.c_str());
         aacg_destroy(e);

@@ -22,17 +22,10 @@ void aacg_imdct_run_quant_cpl(const aacg_kparams P) { imdct_run_body<AACG_INPUT_
 extern "C" __global__ __launch_bounds__(AACG_WG_THREADS)
 void aacg_imdct_run_f32_cpl(const aacg_kparams P) { imdct_run_body<AACG_INPUT_SPEC_F32, AACG_OUTPUT_F32, false, false, true>(P); }
 
-int aacg_couple_set_lds_limits(void)
-{
-    hipError_t rc = hipFuncSetAttribute((const void*)aacg_imdct_run_quant_cpl, hipFuncAttributeMaxDynamicSharedMemorySize, AACG_LDS_BYTES_QUANT);
-    if (rc == hipSuccess) rc = hipFuncSetAttribute((const void*)aacg_imdct_run_f32_cpl, hipFuncAttributeMaxDynamicSharedMemorySize, AACG_LDS_BYTES_F32);
-    return rc == hipSuccess ? 0 : -1;
-}
-
 void aacg_couple_run_launch(bool quant, dim3 grid, dim3 block, hipStream_t s, const aacg_kparams& P)
 {
-    if (quant) hipLaunchKernelGGL(aacg_imdct_run_quant_cpl, grid, block, AACG_LDS_BYTES_QUANT, s, P);
-    else       hipLaunchKernelGGL(aacg_imdct_run_f32_cpl, grid, block, AACG_LDS_BYTES_F32, s, P);
+    if (quant) hipLaunchKernelGGL(aacg_imdct_run_quant_cpl, grid, block, 0, s, P);
+    else       hipLaunchKernelGGL(aacg_imdct_run_f32_cpl, grid, block, 0, s, P);
 }
 
 void aacg_couple_launch(bool pcm, hipStream_t s, const aacg_couple_params& Q)

@@ -19,15 +19,8 @@ void aacg_imdct_run_f32_ex(const aacg_kparams P) { imdct_run_body<AACG_INPUT_SPE
 
 static_assert(AACG_LDS_BYTES_QUANT_EX <= 160 * 1024, "the TNS exchange areas must fit beside the slots");
 
-int aacg_exrun_set_lds_limits(void)
-{
-    hipError_t rc = hipFuncSetAttribute((const void*)aacg_imdct_run_quant_ex, hipFuncAttributeMaxDynamicSharedMemorySize, AACG_LDS_BYTES_QUANT_EX);
-    if (rc == hipSuccess) rc = hipFuncSetAttribute((const void*)aacg_imdct_run_f32_ex, hipFuncAttributeMaxDynamicSharedMemorySize, AACG_LDS_BYTES_F32_EX);
-    return rc == hipSuccess ? 0 : -1;
-}
-
 void aacg_exrun_launch(bool quant, dim3 grid, dim3 block, hipStream_t s, const aacg_kparams& P)
 {
-    if (quant) hipLaunchKernelGGL(aacg_imdct_run_quant_ex, grid, block, AACG_LDS_BYTES_QUANT_EX, s, P);
-    else       hipLaunchKernelGGL(aacg_imdct_run_f32_ex, grid, block, AACG_LDS_BYTES_F32_EX, s, P);
+    if (quant) hipLaunchKernelGGL(aacg_imdct_run_quant_ex, grid, block, 0, s, P);
+    else       hipLaunchKernelGGL(aacg_imdct_run_f32_ex, grid, block, 0, s, P);
 }

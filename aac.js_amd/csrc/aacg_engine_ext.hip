@@ -18,17 +18,8 @@ void aacg_imdct_run_f32_dd(const aacg_kparams P) { imdct_run_body<AACG_INPUT_SPE
 
 
 
-int aacg_ext_set_lds_limits(void)
-{
-    /* ~158 KiB of dynamic LDS per workgroup is above the 64 KiB default limit */
-    hipError_t rc = hipSuccess;
-    if (rc == hipSuccess) rc = hipFuncSetAttribute((const void*)aacg_imdct_run_quant_dd, hipFuncAttributeMaxDynamicSharedMemorySize, AACG_LDS_BYTES_QUANT);
-    if (rc == hipSuccess) rc = hipFuncSetAttribute((const void*)aacg_imdct_run_f32_dd, hipFuncAttributeMaxDynamicSharedMemorySize, AACG_LDS_BYTES_F32);
-    return rc == hipSuccess ? 0 : -1;
-}
-
 void aacg_ext_launch(bool quant, dim3 grid, dim3 block, hipStream_t s, const aacg_kparams& P)
 {
-    if (quant) hipLaunchKernelGGL(aacg_imdct_run_quant_dd, grid, block, AACG_LDS_BYTES_QUANT, s, P);
-    else       hipLaunchKernelGGL(aacg_imdct_run_f32_dd, grid, block, AACG_LDS_BYTES_F32, s, P);
+    if (quant) hipLaunchKernelGGL(aacg_imdct_run_quant_dd, grid, block, 0, s, P);
+    else       hipLaunchKernelGGL(aacg_imdct_run_f32_dd, grid, block, 0, s, P);
 }

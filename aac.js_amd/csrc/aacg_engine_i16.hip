@@ -16,22 +16,13 @@ void aacg_imdct_run_quant_dd_i16(const aacg_kparams P) { imdct_run_body<AACG_INP
 extern "C" __global__ __launch_bounds__(AACG_WG_THREADS)
 void aacg_imdct_run_f32_dd_i16(const aacg_kparams P) { imdct_run_body<AACG_INPUT_SPEC_F32, AACG_OUTPUT_I16, true>(P); }
 
-int aacg_i16_set_lds_limits(void)
-{
-    hipError_t rc = hipFuncSetAttribute((const void*)aacg_imdct_run_quant_i16, hipFuncAttributeMaxDynamicSharedMemorySize, AACG_LDS_BYTES_QUANT);
-    if (rc == hipSuccess) rc = hipFuncSetAttribute((const void*)aacg_imdct_run_f32_i16, hipFuncAttributeMaxDynamicSharedMemorySize, AACG_LDS_BYTES_F32);
-    if (rc == hipSuccess) rc = hipFuncSetAttribute((const void*)aacg_imdct_run_quant_dd_i16, hipFuncAttributeMaxDynamicSharedMemorySize, AACG_LDS_BYTES_QUANT);
-    if (rc == hipSuccess) rc = hipFuncSetAttribute((const void*)aacg_imdct_run_f32_dd_i16, hipFuncAttributeMaxDynamicSharedMemorySize, AACG_LDS_BYTES_F32);
-    return rc == hipSuccess ? 0 : -1;
-}
-
 void aacg_i16_launch(bool quant, bool dd, dim3 grid, dim3 block, hipStream_t s, const aacg_kparams& P)
 {
     if (dd) {
-        if (quant) hipLaunchKernelGGL(aacg_imdct_run_quant_dd_i16, grid, block, AACG_LDS_BYTES_QUANT, s, P);
-        else       hipLaunchKernelGGL(aacg_imdct_run_f32_dd_i16, grid, block, AACG_LDS_BYTES_F32, s, P);
+        if (quant) hipLaunchKernelGGL(aacg_imdct_run_quant_dd_i16, grid, block, 0, s, P);
+        else       hipLaunchKernelGGL(aacg_imdct_run_f32_dd_i16, grid, block, 0, s, P);
     } else {
-        if (quant) hipLaunchKernelGGL(aacg_imdct_run_quant_i16, grid, block, AACG_LDS_BYTES_QUANT, s, P);
-        else       hipLaunchKernelGGL(aacg_imdct_run_f32_i16, grid, block, AACG_LDS_BYTES_F32, s, P);
+        if (quant) hipLaunchKernelGGL(aacg_imdct_run_quant_i16, grid, block, 0, s, P);
+        else       hipLaunchKernelGGL(aacg_imdct_run_f32_i16, grid, block, 0, s, P);
     }
 }

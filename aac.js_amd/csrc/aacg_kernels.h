@@ -1780,7 +1780,7 @@ DP_DEVICE void imdct_run_body(const aacg_kparams& P)
     const int TAB_FLOATS = (KIND == AACG_INPUT_QUANT_I16) ? AACG_TAB_QUANT_FLOATS : AACG_TAB_F32_FLOATS;
     const int lane = dp_lane(), wave = dp_wave();
     const aacg_run* run = P.runs + dp_block();
-    float* lds = (float*)dp_lds();
+    float* lds = (float*)dp_lds_fixed<4 * AACG_LDS_FLOATS(TAB_FLOATS) + (EX ? 4 * AACG_WG_WAVES * AACG_RUN_XCH_FLOATS : 0)>();
     const float* tab = lds;
     float* slots = lds + AACG_TAB_SLOT_BASE(TAB_FLOATS);
     float* slot = slots + wave * AACG_SLOT_FLOATS;

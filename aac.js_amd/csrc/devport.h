@@ -163,6 +163,15 @@ DP_DEVICE void dp_shfl(double (&v)[N], int src)
 
 extern __shared__ __attribute__((aligned(16))) unsigned char dp_lds_raw[];
 DP_DEVICE unsigned char* dp_lds() { return dp_lds_raw; }
+/* A workgroup's LDS as a static allocation of BYTES (one per kernel: a kernel must not mix this with dp_lds()): the
+ * allocation then starts at a compile-time address, so table and slot offsets fold into the instructions' immediate
+ * offsets instead of being added to a link-time symbol.  Such kernels are launched with no dynamic LDS. */
+template <int BYTES>
+DP_DEVICE unsigned char* dp_lds_fixed()
+{
+    __shared__ __attribute__((aligned(16))) unsigned char raw[BYTES];
+    return raw;
+}
 
 /* LDS byte addresses as integers (table gathers): ds_read_b32 on a computed address.  A read outside the
  * workgroup's allocation returns 0 (the LDS has no fault path). */

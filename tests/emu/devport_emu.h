@@ -113,6 +113,12 @@ DP_DEVICE bool dp_any(bool p)
 }
 
 DP_DEVICE unsigned char* dp_lds() { return g_emu.b->lds; }
+template <int BYTES>
+DP_DEVICE unsigned char* dp_lds_fixed()
+{
+    if ((size_t)BYTES > g_emu.b->lds_bytes) __builtin_trap();
+    return g_emu.b->lds;
+}
 /* LDS byte addresses as integers (table gathers); a read outside the workgroup's allocation returns 0 */
 DP_DEVICE int dp_lds_addr(const void* p) { return (int)((const unsigned char*)p - g_emu.b->lds); }
 DP_DEVICE float dp_lds_read_f32(int a)
