@@ -1644,12 +1644,16 @@ DP_DEVICE void epilogue(const aacg_kparams& P, const cpl_prefetch& pre, const fl
         /* a CPE inside a wider frame (5.1 etc.): (L[n], R[n]) are adjacent, one 8-byte store per sample
          * (4-byte aligned when the channel count is odd) */
         if (!cls0) {
+            /* all reads of the incoming tails first: the stores may alias them as far as the compiler knows, and a read
+             * behind every store is a memory round trip each (a chain's first frame takes its state from HBM) */
+            dpf4 v[8];
+#pragma unroll
+            for (int m = 0; m < 8; m++) v[m] = incoming<FROM_LDS>(p0, p1, 2, 2 * lcol + 128 * m);
 #pragma unroll
             for (int m = 0; m < 8; m++) {
                 const int n = 2 * lcol + 128 * m;
-                const dpf4 v = incoming<FROM_LDS>(p0, p1, 2, n);
-                pcm_put2(pcm + (size_t)n * C, v.x + hx0[m], v.y + hx1[m]);
-                pcm_put2(pcm + (size_t)(n + 1) * C, v.z + hy0[m], v.w + hy1[m]);
+                pcm_put2(pcm + (size_t)n * C, v[m].x + hx0[m], v[m].y + hx1[m]);
+                pcm_put2(pcm + (size_t)(n + 1) * C, v[m].z + hy0[m], v[m].w + hy1[m]);
             }
         } else {
 #pragma unroll
@@ -1726,12 +1730,14 @@ DP_DEVICE void epilogue(const aacg_kparams& P, const cpl_prefetch& pre, const fl
             const float (&hx)[8] = c ? hx1 : hx0;
             const float (&hy)[8] = c ? hy1 : hy0;
             if (!cls) {
+                dpf4 v[8];                              /* reads first, as above */
+#pragma unroll
+                for (int m = 0; m < 8; m++) v[m] = incoming<FROM_LDS>(p0, p1, n_ch, 2 * lcol + 128 * m);
 #pragma unroll
                 for (int m = 0; m < 8; m++) {
                     const int n = 2 * lcol + 128 * m;
-                    const dpf4 v = incoming<FROM_LDS>(p0, p1, n_ch, n);
-                    pcm_put1(dst + (size_t)n * C, (c ? v.y : v.x) + hx[m]);
-                    pcm_put1(dst + (size_t)(n + 1) * C, (c ? v.w : v.z) + hy[m]);
+                    pcm_put1(dst + (size_t)n * C, (c ? v[m].y : v[m].x) + hx[m]);
+                    pcm_put1(dst + (size_t)(n + 1) * C, (c ? v[m].w : v[m].z) + hy[m]);
                 }
             } else {
 #pragma unroll

@@ -8,13 +8,14 @@ import numpy as np, torch, aacgpu, aacgpu_workload
 
 kind = sys.argv[1] if len(sys.argv) > 1 else "quant"
 S, T = 256, int(os.environ.get("TL_FRAMES", "16"))
-eng = aacgpu.Engine(aacgpu.INPUT_QUANT_I16 if kind == "quant" else aacgpu.INPUT_SPEC_F32, S, 2)
-wl = aacgpu_workload.make_batch(S, T)
+layout = tuple(os.environ.get("TL_LAYOUT", "cpe").split(","))          # e.g. TL_LAYOUT=sce: a folded mono chain per workgroup
+wl = aacgpu_workload.make_batch(S, T, layout=layout, mix=bool(os.environ.get("TL_MIX")))
+eng = aacgpu.Engine(aacgpu.INPUT_QUANT_I16 if kind == "quant" else aacgpu.INPUT_SPEC_F32, S, max(2, wl["C"]))
 plan = eng.plan(wl["units"])
 if kind == "quant":
     d_in = torch.from_numpy(wl["q"]).cuda(); d_meta = torch.from_numpy(wl["meta"].view(np.int16)).cuda(); mp = d_meta.data_ptr()
 else:
-    d_in = torch.randn(S * T * 2, 1024, device="cuda") * 1000; mp = None
+    d_in = torch.randn(S * T * wl["C"], 1024, device="cuda") * 1000; mp = None
 d_out = torch.empty(wl["n_pcm"], dtype=torch.float32, device="cuda")
 torch.cuda.synchronize()
 for _ in range(5):
@@ -22,11 +23,13 @@ for _ in range(5):
 eng.synchronize()
 raw = np.zeros(1 << 20, np.float32)
 eng._check(eng.lib.aacg_get_table(eng.handle, 100, raw.ctypes.data, raw.size))
-t = raw.view(np.uint64)[: 256 * 16 * 8].reshape(256, 16, 8)[:, :T].astype(np.float64) * 0.01     # 100 MHz ticks -> us
+NW = int(os.environ.get("TL_WAVES", str(min(16, T))))                  # waves of a workgroup that carry a frame (T / 2 for a folded chain)
+NB = int(os.environ.get("TL_BLOCKS", "256"))
+t = raw.view(np.uint64)[: NB * 16 * 8].reshape(NB, 16, 8)[:, :NW].astype(np.float64) * 0.01     # 100 MHz ticks -> us
 t0 = t[:, :, 0].min()
 names = ["start", "tables+barrier", "spectrum staged", "imdct done", "prev tail seen", "stores issued"]
 print("phase (us since first wave start): median over workgroups, by wave")
-for w in range(min(16, T)):
+for w in range(NW):
     row = [np.median(t[:, w, k] - t0) for k in range(6)]
     print("wave %2d: " % w + "  ".join("%s %6.2f" % (names[k][:14], row[k]) for k in range(6)))
 print("kernel span (last stores issued - first start): %.2f us; start skew across WGs: %.2f us" % ((t[:, :, 5].max() - t0), t[:, :, 0].max() - t0))
@@ -37,7 +40,7 @@ start = t[:, :, 0].min(axis=1) - t0
 print("per-workgroup end (last stores issued): " + "  ".join("p%d %.2f" % (q, np.percentile(end, q)) for q in (0, 10, 50, 90, 99, 100)))
 print("per-workgroup duration: " + "  ".join("p%d %.2f" % (q, np.percentile(end - start, q)) for q in (0, 10, 50, 90, 99, 100)))
 for x in range(8):
-    sel = np.arange(256) % 8 == x                     # blockIdx -> XCD round-robin
+    sel = np.arange(NB) % 8 == x                     # blockIdx -> XCD round-robin
     print("XCD %d: start %.2f..%.2f  end median %.2f max %.2f" % (x, start[sel].min(), start[sel].max(), np.median(end[sel]), end[sel].max()))
 late = np.argsort(end)[-8:]
 print("latest workgroups:", [(int(i), round(float(start[i]), 2), round(float(end[i]), 2)) for i in late])
