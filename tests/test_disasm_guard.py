@@ -64,3 +64,27 @@ def test_dpp_blocks_keep_their_wait_states(tmp_path):
             if states >= 5:
                 break
     assert n_dpp >= 64, "the DPP blocks are gone from the library? (%d DPP instructions found)" % n_dpp
+
+
+@pytest.mark.skipif(not (os.path.exists(OBJDUMP) and os.path.exists(LIB)), reason="needs llvm-objdump and the built library")
+def test_exec_masked_blocks_restore_exec(tmp_path):
+    """M/S and intensity stereo run under an EXEC mask per coefficient group (devport.h: dp_sumdiff_where, dp_scale_where):
+    inline assembly that narrows EXEC behind the compiler's back.  In the shipped code every such block — an
+    s_and_saveexec_b64 followed at once by packed arithmetic — must hold nothing but v_pk_* instructions and end by putting
+    back the very register pair it saved EXEC in."""
+    lines = [l.split("//")[0].strip() for l in disassemble(str(tmp_path)).splitlines()]
+    n_blocks = 0
+    for i, ins in enumerate(lines):
+        if not ins.startswith("s_and_saveexec_b64") or i + 1 >= len(lines) or not lines[i + 1].startswith(("v_pk_add_f32", "v_pk_mul_f32")):
+            continue
+        saved = ins.split(None, 1)[1].split(",")[0].strip()
+        n_blocks += 1
+        for j in range(i + 1, i + 10):
+            nxt = lines[j]
+            if nxt.startswith("s_mov_b64 exec"):
+                assert nxt.split(",")[1].strip() == saved, "line %d: %s saved EXEC in %s, line %d restores %s" % (i, ins, saved, j, nxt)
+                break
+            assert nxt.startswith("v_pk_"), "line %d: %s inside an EXEC-masked block that began at line %d" % (j, nxt, i)
+        else:
+            raise AssertionError("line %d: %s is never undone" % (i, ins))
+    assert n_blocks >= 8, "the EXEC-masked M/S and intensity blocks are gone from the library? (%d found)" % n_blocks
