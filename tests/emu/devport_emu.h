@@ -160,7 +160,16 @@ DP_DEVICE void dp_store_nt(dpf4* p, dpf4 v) { *p = v; }
 DP_DEVICE void dp_store2_u(float* p, float a, float b) { p[0] = a; p[1] = b; }
 DP_DEVICE int dp_pcm16_pair(float a, float b)
 {
-    auto one = [](float x) { float r = rintf(x * 32768.0f); r = r < -32768.0f ? -32768.0f : (r > 32767.0f ? 32767.0f : r); return (int)r & 0xffff; };
+    /* the device's arithmetic (devport.h), not an independent formula: clamp to [-1, 32767/32768], then ONE fused
+     * multiply-add against 1.5 * 2^23, whose sum has an ulp of 1 — the rounding to nearest even is the addition's — and whose
+     * low 16 mantissa bits are the integer in two's complement (tests/test_emu_kernels.py::test_int16_output checks the
+     * result against rint + saturate) */
+    auto one = [](float x) {
+        x = fminf(fmaxf(x, -1.0f), 0.999969482421875f);
+        const float f = fmaf(x, 32768.0f, 12582912.0f);
+        unsigned u; memcpy(&u, &f, 4);
+        return (int)(u & 0xffffu);
+    };
     return one(a) | (one(b) << 16);
 }
 DP_DEVICE void dp_store_i2_nt(void* p, int a, int b) { memcpy(p, &a, 4); memcpy((char*)p + 4, &b, 4); }
