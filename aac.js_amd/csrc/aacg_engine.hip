@@ -88,6 +88,7 @@ struct aacg_engine {
     uint64_t submitted = 0;
     hipEvent_t last_kernel = nullptr;       /* completion of the most recently submitted batch's kernel */
     void* d_trace = nullptr;                /* profiling: per-wave phase timestamps when (ablate & 16) */
+    int debug_route = 0;                    /* aacg_debug_set_route: diagnostic route choices for parity tests (0 in production) */
     int ablate = 0;                         /* -DAACG_PROFILE builds: env AACG_ABLATE (aacg_kernels.h); always 0 in the shipped library */
     std::string err;
 };
@@ -205,7 +206,7 @@ std::string route_names(const aacg_engine* e, const aacg_plan_host& h)
         quant = false;
     }
     const std::string run = std::string("aacg_imdct_run_") + (quant ? "quant" : "f32");
-    const bool fused = h.fused_independent && !ex && !i16;
+    const bool fused = h.fused_independent && !ex && !i16 && !(e->debug_route & AACG_DEBUG_ROUTE_UNFUSED_COUPLING);
     if (fused) {
         if (!h.cce_runs.empty()) add(run + " (coupling elements)");
         if (!h.runs.empty()) add(run + "_cpl");
@@ -283,7 +284,7 @@ int launch_run(aacg_engine* e, const aacg_dev_unit* d_units, const aacg_run* d_r
         if (quant) hipLaunchKernelGGL(aacg_imdct_run_quant, dim3((unsigned)h.cce_runs.size()), block, 0, s, C);
         else       hipLaunchKernelGGL(aacg_imdct_run_f32, dim3((unsigned)h.cce_runs.size()), block, 0, s, C);
     };
-    const bool fused = h.fused_independent && !ex && !i16;
+    const bool fused = h.fused_independent && !ex && !i16 && !(e->debug_route & AACG_DEBUG_ROUTE_UNFUSED_COUPLING);
     if (fused) {
         /* independent coupling in the targets' epilogues: the coupling elements go first (into the side buffer), then the
          * run kernel that adds gain * side where it forms the PCM — no read-modify-write pass over the interleaved PCM */
@@ -317,6 +318,13 @@ extern "C" {
 int aacg_abi_version(void) { return AACG_ABI_VERSION; }
 
 const char* aacg_kernel_name(void) { return "aacg_imdct_run_quant"; }
+
+int aacg_debug_set_route(aacg_engine* e, int flags)
+{
+    if (!e || (flags & ~AACG_DEBUG_ROUTE_UNFUSED_COUPLING)) return AACG_ERR_INVALID_ARG;
+    e->debug_route = flags;
+    return AACG_OK;
+}
 
 int aacg_plan_kernels(aacg_engine* e, const aacg_plan* p, char* dst, size_t n)
 {
@@ -620,10 +628,15 @@ int aacg_plan_refresh_from_parse(aacg_engine* e, aacg_plan* p, const aacg_unit_d
 int aacg_plan_refresh_units(aacg_engine* e, aacg_plan* p, const aacg_unit_desc* units, uint32_t n_units, void* hip_stream)
 {
     if (!e || !p || p->e != e || !units) return AACG_ERR_INVALID_ARG;
-    int rc = aacg_plan_refresh_host(&p->h, units, n_units, e->cfg.sample_index, &e->err);
+    int rc = aacg_plan_refresh_host(&p->h, units, n_units, e->cfg.sample_index, e->cfg.tns_mode == AACG_TNS_SPEC, &e->err);
     if (rc) return rc;
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : e->stream;
     HIP_TRY(e, hipStreamWaitEvent(s, p->uploaded, 0), AACG_ERR_NO_DEVICE);
+    /* the plan's previous launch on ANOTHER stream may still be reading the records this copy overwrites: order behind it */
+    if (p->used && p->last_stream != s) {
+        HIP_TRY(e, hipEventRecord(p->last_use, p->last_stream), AACG_ERR_NO_DEVICE);
+        HIP_TRY(e, hipStreamWaitEvent(s, p->last_use, 0), AACG_ERR_NO_DEVICE);
+    }
     /* pageable source: the runtime stages it before returning, so the host copy may change again right away; in stream
      * order behind the launches that read the previous records */
     HIP_TRY(e, hipMemcpyAsync(p->d_units, p->h.units.data(), sizeof(aacg_dev_unit) * p->h.units.size(), hipMemcpyHostToDevice, s), AACG_ERR_NO_DEVICE);

@@ -77,7 +77,7 @@ int aacg_plan_build(const aacg_unit_desc* units, uint32_t n_units, int sample_in
 
 /* A kept plan's unit records rewritten from the next batch's (same structure: streams, frames, elements, PCM positions);
  * AACG_ERR_LAYOUT_CHANGE if the structure differs, in which case nothing has been touched. */
-int aacg_plan_refresh_host(aacg_plan_host* h, const aacg_unit_desc* units, uint32_t n_units, int sample_index, std::string* err);
+int aacg_plan_refresh_host(aacg_plan_host* h, const aacg_unit_desc* units, uint32_t n_units, int sample_index, bool tns_spec, std::string* err);
 
 /* tns.js:111-152: per-filter sample range and LPC coefficients of one channel (float32 stores as in the
  * reference's Float32Array lpc).  Returns AACG_OK or AACG_ERR_UNSUPPORTED (order > 12). */

@@ -1821,7 +1821,8 @@ DP_DEVICE void imdct_run_body(const aacg_kparams& P)
      * never lower, so a spinning consumer cannot starve its producer. */
     if (AACG_ABL(P, 64)) dp_setprio(0); else if (AACG_ABL(P, 32)) dp_setprio(1 - (wave >> 3)); else dp_setprio(3 - (wave >> 2));
     const unsigned long long t_start = AACG_ABL(P, 16) ? dp_clock() : 0;
-    unsigned long long* trace = AACG_ABL(P, 16) ? (unsigned long long*)P.spec_out + ((size_t)dp_block() * AACG_WG_WAVES + wave) * 8 : nullptr;
+    /* (the coupling builds carry their side buffer in spec_out, aacg_set_cpl: never a trace there) */
+    unsigned long long* trace = (!CPL && AACG_ABL(P, 16)) ? (unsigned long long*)P.spec_out + ((size_t)dp_block() * AACG_WG_WAVES + wave) * 8 : nullptr;
     if (trace && lane == 0) trace[0] = t_start;
     int n_ch = ui >= 0 ? u.n_ch : 0;
     int cls0 = u.seq[0] == AACG_EIGHT_SHORT_SEQUENCE;

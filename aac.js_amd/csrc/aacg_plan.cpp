@@ -139,7 +139,7 @@ static uint32_t group_map(const aacg_chan_info& ci)
  * tables were built from), new window info, flags and block offsets.  What the host pays per batch is this loop and a
  * copy of the records instead of aacg_plan_build (27 ns per unit) — for callers that keep spectra on the device and
  * parse on the host.  Plans with TNS records, noise bands or coupling elements are built per batch. */
-int aacg_plan_refresh_host(aacg_plan_host* h, const aacg_unit_desc* units, uint32_t n_units, int sample_index, std::string* err)
+int aacg_plan_refresh_host(aacg_plan_host* h, const aacg_unit_desc* units, uint32_t n_units, int sample_index, bool tns_spec, std::string* err)
 {
     int swb[64];
     const int n_long = aacg_swb_offsets(sample_index, 1, swb), n_short = aacg_swb_offsets(sample_index, 0, swb);
@@ -153,6 +153,11 @@ int aacg_plan_refresh_host(aacg_plan_host* h, const aacg_unit_desc* units, uint3
             return fail(err, AACG_ERR_LAYOUT_CHANGE, "unit %ld: stream / PCM position / channels differ from the plan's", i);
         if (u.flags & (AACG_UNIT_CCE | AACG_UNIT_HAS_PNS))
             return fail(err, AACG_ERR_LAYOUT_CHANGE, "unit %ld: a coupling element or noise bands: the route changes, plan anew", i);
+        /* an AACG_TNS_SPEC engine runs the filters of a frame that carries TNS side info: such a batch needs a plan with TNS
+         * records (aacg_plan_create_tns) — clearing the flag below would decode it without them, wrong PCM and no error */
+        for (int c = 0; tns_spec && c < u.n_ch; c++)
+            if (u.ch[c].flags & AACG_CHAN_TNS_PRESENT)
+                return fail(err, AACG_ERR_LAYOUT_CHANGE, "unit %ld: TNS side info on an AACG_TNS_SPEC engine: the route changes, plan anew with the TNS records", i);
         for (int c = 0; c < u.n_ch; c++)
             if (const char* why = check_chan(u.ch[c], n_long, n_short)) { if (err) *err = why; return AACG_ERR_INVALID_ARG; }
         if (u.coef_offset > UINT32_MAX - 2u || u.meta_offset > UINT32_MAX - 2u)

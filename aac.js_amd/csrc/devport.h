@@ -169,7 +169,9 @@ DP_DEVICE unsigned char* dp_lds() { return dp_lds_raw; }
 template <int BYTES>
 DP_DEVICE unsigned char* dp_lds_fixed()
 {
-    __shared__ __attribute__((aligned(16))) unsigned char raw[BYTES];
+    /* 512-byte alignment: the run kernels XOR small offsets into absolute slot addresses and count ds_read2st64 offsets in
+     * units of 512 bytes, so the block's start must not move if another LDS object ever joins it */
+    __shared__ __attribute__((aligned(512))) unsigned char raw[BYTES];
     return raw;
 }
 

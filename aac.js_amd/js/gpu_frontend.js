@@ -40,54 +40,19 @@ GpuFrontEnd.prototype.push = function (bytes) {
 };
 GpuFrontEnd.prototype.pushPacket = function (bytes, multi) { this.packets.push({ bytes: bytes, multi: !!multi }); };   // multi: see FrontEnd.pushPacket
 
-/* parse everything that is complete: fills this.queue with frame objects or Error objects */
-GpuFrontEnd.prototype.fill = function (config) {
-    if (!this.parser || this.sampleIndex !== config.sampleIndex) {
-        const rec = this.cb.toEntryRecords();
-        this.parser = this.addon.parserCreate({ deviceOrdinal: this.deviceOrdinal, sampleIndex: config.sampleIndex }, rec.entries, rec.counts);
-        this.sampleIndex = config.sampleIndex;
-    }
-    let bytes, table, take = null;
-    if (this.packets.length) {
-        take = this.packets.splice(0, this.batch);
-        let total = 0;
-        for (const p of take) total += p.bytes.length;
-        bytes = new Uint8Array(total); table = new Uint32Array(2 * take.length);
-        let at = 0;
-        take.forEach(function (p, i) { bytes.set(p.bytes, at); table[2 * i] = at; table[2 * i + 1] = p.bytes.length; at += p.bytes.length; });
-    } else {
-        const list = adts.frames(this.buf).slice(0, this.batch);
-        if (!list.length) {
-            if (this.buf.length >= 7) adts.readHeader(new host.BitReader(this.buf));      // throws 'Invalid ADTS header.' on garbage
-            return;
-        }
-        const end = list[list.length - 1].offset + list[list.length - 1].length;
-        bytes = this.buf.subarray(0, end); this.buf = this.buf.subarray(end);
-        table = new Uint32Array(2 * list.length);
-        list.forEach(function (f, i) { table[2 * i] = f.offset; table[2 * i + 1] = f.length; });
-    }
+/* one aacg_parse_batch call over `table` (offset, length pairs into `bytes`): per frame a frame object or an Error, and
+ * the bytes the parser consumed */
+GpuFrontEnd.prototype.parseTable = function (bytes, table) {
     const n = table.length / 2, U = this.maxUnits, C = this.maxChannels;
     const units = new Uint8Array(n * U * UNIT_BYTES), q = new Int16Array(n * C * FRAME), meta = new Uint16Array(n * C * META_WORDS);
     const tns = this.wantTns ? new Uint8Array(n * C * TNS_BYTES) : null, results = new Uint8Array(8 * n);
     this.addon.parseBatch(this.parser, bytes, table, U, C, this.options, units, q, meta, tns, results);
-    /* A multi-block packet may hold several byte-aligned raw_data_blocks back to back (Aurora's M4A demuxer emits a chunk's contiguous
-     * samples in one buffer; the reference reads on from the same bitstream, decoder.js:129-199).  The device parses the
-     * first block of every packet; where bits are left over, the frames behind that packet wait and the rest of the batch
-     * is re-queued in order with the packet's remainder in front, to be parsed by the next fill(). */
-    let limit = n;
-    if (take) {
-        const view = new DataView(results.buffer, results.byteOffset, results.byteLength);
-        for (let f = 0; f < n && limit === n; f++) {
-            const used = (view.getUint32(8 * f + 4, true) + 7) >>> 3;
-            if (take[f].multi && !results[8 * f] && used < take[f].bytes.length) {
-                this.packets = [{ bytes: take[f].bytes.subarray(used), multi: true }].concat(take.slice(f + 1), this.packets);
-                limit = f + 1;
-            }
-        }
-    }
-    for (let f = 0; f < limit; f++) {
+    const view = new DataView(results.buffer, results.byteOffset, results.byteLength);
+    const out = new Array(n);
+    for (let f = 0; f < n; f++) {
         const status = results[8 * f], nUnits = results[8 * f + 1], nCh = results[8 * f + 2];
-        if (status) { this.queue.push(new Error(this.addon.parseStatusString(status))); continue; }
+        const used = (view.getUint32(8 * f + 4, true) + 7) >>> 3;
+        if (status) { out[f] = { frame: new Error(this.addon.parseStatusString(status)), used: used, failed: true }; continue; }
         const frame = { elements: [], q: q.slice(f * C * FRAME, (f * C + nCh) * FRAME), meta: meta.slice(f * C * META_WORDS, (f * C + nCh) * META_WORDS) };
         for (const u of host.unpackUnits(units.subarray(f * U * UNIT_BYTES, (f * U + nUnits) * UNIT_BYTES))) {
             const e = { type: TYPE_NAME[u.tag >> 4], id: u.tag & 15, commonWindow: u.commonWindow, maskPresent: u.maskPresent, hasPns: u.hasPns, ch: [] };
@@ -99,8 +64,57 @@ GpuFrontEnd.prototype.fill = function (config) {
             });
             frame.elements.push(e);
         }
-        this.queue.push(frame);
+        out[f] = { frame: frame, used: used, failed: false };
     }
+    return out;
+};
+
+/* parse everything that is complete: fills this.queue with frame objects or Error objects */
+GpuFrontEnd.prototype.fill = function (config) {
+    if (!this.parser || this.sampleIndex !== config.sampleIndex) {
+        const rec = this.cb.toEntryRecords();
+        this.parser = this.addon.parserCreate({ deviceOrdinal: this.deviceOrdinal, sampleIndex: config.sampleIndex }, rec.entries, rec.counts);
+        this.sampleIndex = config.sampleIndex;
+    }
+    if (!this.packets.length) {
+        const list = adts.frames(this.buf).slice(0, this.batch);
+        if (!list.length) {
+            if (this.buf.length >= 7) adts.readHeader(new host.BitReader(this.buf));      // throws 'Invalid ADTS header.' on garbage
+            return;
+        }
+        const end = list[list.length - 1].offset + list[list.length - 1].length;
+        const bytes = this.buf.subarray(0, end); this.buf = this.buf.subarray(end);
+        const table = new Uint32Array(2 * list.length);
+        list.forEach(function (f, i) { table[2 * i] = f.offset; table[2 * i + 1] = f.length; });
+        for (const r of this.parseTable(bytes, table)) this.queue.push(r.frame);
+        return;
+    }
+    /* A multi-block packet may hold several byte-aligned raw_data_blocks back to back (Aurora's M4A demuxer emits a chunk's contiguous
+     * samples in one buffer; the reference reads on from the same bitstream, decoder.js:129-199).  Pass k hands the device
+     * block k of every packet that still has bytes — every block is parsed exactly once, whatever the packets hold (re-queueing
+     * the batch behind the first packet with bytes left over parsed the later packets again and again) — and the frames
+     * are queued packet by packet, in stream order. */
+    const take = this.packets.splice(0, this.batch);
+    const perPacket = take.map(function () { return []; });
+    let pending = take.map(function (p, i) { return { i: i, at: 0 }; });
+    while (pending.length) {
+        let total = 0;
+        for (const e of pending) total += take[e.i].bytes.length - e.at;
+        const bytes = new Uint8Array(total), table = new Uint32Array(2 * pending.length);
+        let at = 0;
+        pending.forEach(function (e, k) {
+            const rest = take[e.i].bytes.subarray(e.at);
+            bytes.set(rest, at); table[2 * k] = at; table[2 * k + 1] = rest.length; at += rest.length;
+        });
+        const res = this.parseTable(bytes, table), next = [];
+        pending.forEach(function (e, k) {
+            perPacket[e.i].push(res[k].frame);
+            const left = take[e.i].bytes.length - e.at - res[k].used;
+            if (take[e.i].multi && !res[k].failed && res[k].used > 0 && left > 0) next.push({ i: e.i, at: e.at + res[k].used });
+        });
+        pending = next;
+    }
+    for (const list of perPacket) for (const f of list) this.queue.push(f);
 };
 
 GpuFrontEnd.prototype.parseFrame = function (decoder) {

@@ -26,7 +26,7 @@ ABI_SYMBOLS = ["aacg_create", "aacg_destroy", "aacg_last_error", "aacg_abi_versi
                "aacg_decode_device", "aacg_spectral_device", "aacg_synchronize", "aacg_get_table", "aacg_kernel_name",
                "aacg_parser_create", "aacg_parser_destroy", "aacg_parser_last_error", "aacg_parse_status_string",
                "aacg_parse_batch", "aacg_parse_device", "aacg_parse_kernel_name", "aacg_plan_refresh_from_parse", "aacg_standard_codebooks", "aacg_debug_transform",
-               "aacg_decode_batch_ex", "aacg_submit_ex", "aacg_plan_create_ex", "aacg_plan_kernels", "aacg_calib_copy", "aacg_plan_refresh_units"]
+               "aacg_decode_batch_ex", "aacg_submit_ex", "aacg_plan_create_ex", "aacg_plan_kernels", "aacg_calib_copy", "aacg_plan_refresh_units", "aacg_debug_set_route"]
 
 UNIT_DTYPE = np.dtype([
     ("stream", "<u4"), ("pcm_offset", "<u4"), ("channel", "<u2"), ("n_out_ch", "<u2"),
@@ -111,6 +111,7 @@ def load_library(path=LIB_PATH):
     L.aacg_plan_kernels.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.c_size_t]
     L.aacg_plan_refresh_units.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
     L.aacg_calib_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    L.aacg_debug_set_route.argtypes = [C.c_void_p, C.c_int]
     L.aacg_last_error.restype = C.c_char_p
     L.aacg_last_error.argtypes = [C.c_void_p]
     L.aacg_create.argtypes = [C.POINTER(Config), C.POINTER(C.c_void_p)]
@@ -446,6 +447,10 @@ class Engine:
 
     def kernel_name(self):
         return self.lib.aacg_kernel_name().decode()
+
+    def debug_set_route(self, flags):
+        """Diagnostic route choices for parity tests (aacg_debug_set_route): 1 = independent coupling as the separate pass."""
+        self._check(self.lib.aacg_debug_set_route(self.handle, flags))
 
     def plan_kernels(self, plan):
         """The launches aacg_decode_device makes for this plan, by kernel name (what a rocprofv3 kernel trace shows)."""

@@ -119,6 +119,16 @@ def reduce_max(dist, value, device=None):
     return float(t.item())
 
 
+def reduce_max_list(dist, values, device=None):
+    """Element-wise MAX over ranks of a list of floats (the R repeats of a timed region)."""
+    if dist is None:
+        return [float(v) for v in values]
+    import torch
+    t = torch.tensor(list(values), dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return [float(v) for v in t.tolist()]
+
+
 def reduce_sum(dist, value, device=None):
     if dist is None:
         return float(value)

@@ -10,13 +10,15 @@ buffer sets so that no step is served from the 256 MiB Infinity Cache.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--input quant|spec] [--workload cfg2|cfg3|cfg4|cfg5] [--tns reference|spec]
 
-Timing: W untimed warm-up steps, then exactly K timed steps between barrier + synchronize on both sides.  The K
-steps are bracketed twice: by HIP events on the launch stream (the time the GPU spent on them) and by the host's
-clock (which adds the launch latency of the first step and the wake-up after the last one — ~70 us, i.e. a quarter
-of a 20-step region of 13 us steps).  `value` = frames of all ranks / MAX over ranks of the event-bracketed time;
-the host-clock figures are reported beside it (`wall_ms_per_step`, `value_wall`).  Before the warm-up the GPU is
-loaded for --precondition-ms (default 300 ms, untimed, reported as config.preconditioning): a few hundred steps
-are over before the clocks have ramped, and the same kernel then measures 12 % slower.
+Timing: W untimed warm-up steps, then the timed region of exactly K steps — R times back to back (--repeats, default 25),
+every repeat bracketed by its own HIP events on the launch stream, the whole set between barrier + synchronize on both
+sides.  `ms_per_step` = MEDIAN over the R repeats of (MAX over ranks of the repeat's event time) / K (SURVEY.md 8d asks
+for a median; one 0.25 ms window says nothing about its own spread), `timing` carries min / max / first / R, and
+`value` = frames of all ranks per step / that median.  The host's clock between the barriers is reported beside it
+(`wall_ms_per_step`, `value_wall`: adds the launch latency of the first step and the wake-up after the last one).
+Before the warm-up the GPU is loaded for --precondition-ms (default 300 ms, untimed, reported as
+config.preconditioning): a few hundred steps are over before the clocks have ramped, and the same kernel then measures
+12 % slower.
 
 After the timed region (untimed): every stream is reset, one more step runs, and its PCM is compared with the
 oracle on the whole batch (`parity_rms`, `parity_rel`; gate 1e-5 / 5e-6 — the run fails if it is missed).
@@ -38,6 +40,41 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec peak (6.29 TB/s measured copy)
 STREAMS, FRAMES = 256, 16      # config 2: 4096 stereo frames per batch per GPU
+
+
+def workload_shape(workload):
+    """(mix, streams per GPU, frames per stream per step, element layout, channels) of a --workload.
+    cfg2 (the metric's configuration) / cfg3: 256 streams x 16 frames; cfg4: 32 streams x 128 frames per GPU (BASELINE config 4:
+    256 streams over 8 GPUs); cfg5: 3 CPE + LFE = 7 channels per frame."""
+    mix = workload in ("cfg3", "cfg4", "cfg5")
+    n_streams, n_frames = (32, 128) if workload == "cfg4" else (STREAMS, FRAMES)
+    layout = ("cpe", "cpe", "cpe", "sce") if workload == "cfg5" else ("cpe",)
+    return mix, n_streams, n_frames, layout, (7 if workload == "cfg5" else 2)
+
+
+def region_stats(region_ms, steps):
+    """Per-step time of the R timed repeats (each K steps): median (the figure quoted), min, max, first."""
+    per = sorted(float(t) / steps for t in region_ms)
+    n = len(per)
+    med = per[n // 2] if n % 2 else 0.5 * (per[n // 2 - 1] + per[n // 2])
+    return {"repeats": n, "ms_per_step_median": med, "ms_per_step_min": per[0], "ms_per_step_max": per[-1],
+            "ms_per_step_first": float(region_ms[0]) / steps}
+
+
+def whole_job_value(world, frames_per_step, ms_per_step):
+    """BASELINE metric: frames of ALL ranks per step / the step time (MAX over ranks already taken)."""
+    return world * frames_per_step / (ms_per_step * 1e-3)
+
+
+def backend_fields(requested, dist):
+    """Top-level facts about the harness's process group: which backend actually carries the barrier / MAX, the world size IT
+    reports, and whether RCCL was asked for and something else answered (a line with `collectives_backend_fallback` true must be
+    read as "RCCL did not see these ranks", whatever its numbers say)."""
+    if dist is None:
+        return {"dist_backend": None, "dist_backend_requested": requested, "dist_world_size": 1, "collectives_backend_fallback": False}
+    used = dist.get_backend()
+    return {"dist_backend": used, "dist_backend_requested": requested, "dist_world_size": dist.get_world_size(),
+            "collectives_backend_fallback": bool(requested == "nccl" and used != "nccl")}
 
 
 def algorithmic_bytes_per_channel_frame(kind, chain_frames, pcm="f32"):
@@ -134,8 +171,8 @@ def parity_check(eng, plan, step0, bufs, host_in0, base, units, tns, n_streams, 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20000)
-    ap.add_argument("--warmup", type=int, default=2000)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--precondition-ms", type=float, default=300.0,
                     help="untimed load before the warm-up steps so that the GPU is at its steady clocks (0 = none)")
     ap.add_argument("--input", choices=["quant", "spec"], default="quant")
@@ -148,6 +185,11 @@ def main():
                          "(supplementary; the reference parses coupling elements and never applies them)")
     ap.add_argument("--output", choices=["f32", "i16"], default="f32",
                     help="i16: AACG_OUTPUT_I16 engine (supplementary; the reference returns float PCM, which is what the headline measures)")
+    ap.add_argument("--repeats", type=int, default=25,
+                    help="R: the K-step timed region is run R times back to back, each bracketed by its own HIP events; ms_per_step is the median")
+    ap.add_argument("--strict-backend", action="store_true",
+                    help="exit non-zero if --dist-backend nccl was asked for and RCCL could not be initialised (default: fall back to gloo and say so "
+                         "in the line's top-level collectives_backend_fallback)")
     ap.add_argument("--nbuf", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the untimed oracle comparison after the timed region")
@@ -190,13 +232,12 @@ def main():
     dist = None
     if aacgpu_shard.launched_by_torchrun():            # RCCL (or gloo) for barrier / max only
         dist = aacgpu_shard.init_process_group(args.dist_backend, device=torch.device("cuda", device))
+        if args.strict_backend and dist.get_backend() != args.dist_backend:
+            raise SystemExit("bench.py: --dist-backend %s asked for, %s answered (--strict-backend)" % (args.dist_backend, dist.get_backend()))
 
     # cfg2 (the metric's configuration) / cfg3: 256 streams x 16 frames; cfg4: 32 streams x 128 frames per GPU
     # (chains of 8 runs: later runs recompute their predecessor's tail); cfg5: 3 CPE + LFE = 7 channels per frame
-    mix = args.workload in ("cfg3", "cfg4", "cfg5")
-    n_streams, n_frames = (32, 128) if args.workload == "cfg4" else (STREAMS, FRAMES)
-    layout = ("cpe", "cpe", "cpe", "sce") if args.workload == "cfg5" else ("cpe",)
-    n_chan = 7 if args.workload == "cfg5" else 2
+    mix, n_streams, n_frames, layout, n_chan = workload_shape(args.workload)
     kind = aacgpu.INPUT_QUANT_I16 if args.input == "quant" else aacgpu.INPUT_SPEC_F32
     eng = aacgpu.Engine(kind, max_streams=n_streams * args.pipelines, max_channels=n_chan + (1 if args.cce == "spec" else 0), device=device,
                         cce_mode=aacgpu.CCE_SPEC if args.cce == "spec" else aacgpu.CCE_REFERENCE,
@@ -258,48 +299,56 @@ def main():
         torch.cuda.synchronize()
     for i in range(args.warmup):
         step(n_pre + i)
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    R = max(1, args.repeats)
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(R + 1)]
     issued = [0.0]
 
     def timed_steps():
         t0 = time.perf_counter()
-        ev0.record()
-        for i in range(args.steps):
-            step(n_pre + args.warmup + i)
-        issued[0] = time.perf_counter() - t0             # host time to enqueue the K launches
-        for extra in tstreams[1:]:
-            tstream.wait_stream(extra)                    # the closing event sees every pipeline
-        ev1.record()
+        evs[0].record()
+        for r in range(R):
+            for i in range(args.steps):
+                step(n_pre + args.warmup + r * args.steps + i)
+            for extra in tstreams[1:]:
+                tstream.wait_stream(extra)                # the closing event sees every pipeline
+            evs[r + 1].record()
+        issued[0] = time.perf_counter() - t0             # host time to enqueue the R x K launches
 
     dev = torch.device("cuda", device)
     _, wall = aacgpu_shard.timed(dist, torch.cuda.synchronize, timed_steps, dev)      # barrier + synchronize on both sides, MAX over ranks
-    event_s = aacgpu_shard.reduce_max(dist, ev0.elapsed_time(ev1) * 1e-3, dev)        # the K steps on the launch stream, MAX over ranks
-    kernel_ms = ev0.elapsed_time(ev1) / args.steps
+    mine_ms = [evs[r].elapsed_time(evs[r + 1]) for r in range(R)]                     # this rank's R repeats of K steps, on the launch stream
+    region_ms = aacgpu_shard.reduce_max_list(dist, mine_ms, dev)                      # MAX over ranks, repeat by repeat
+    stats = region_stats(region_ms, args.steps)
+    kernel_ms = region_stats(mine_ms, args.steps)["ms_per_step_median"]               # rank 0's own launches, for its roofline
 
     # Same process, same box, same clocks, right behind the timed region (untimed itself): what this box's memory system
     # gives a float4 copy launch of the step's byte volume (half read, half written; buffers rotated past the Infinity
     # Cache like the step's), and a 1 GiB copy for the streaming rate.  Boxes of the pool differ by several per cent
     # (DESIGN.md 5); `frac_of_copy` = achieved / copy_ceiling is the figure that does not move with them.
-    def copy_rate(n_bytes, n_sets, reps):
+    def copy_rate(n_bytes, n_sets, reps, repeats):
         n_bytes = int(n_bytes) // 16 * 16
         src = [torch.empty(n_bytes, dtype=torch.uint8, device="cuda").random_(0, 255) for _ in range(n_sets)]
         dst = [torch.empty(n_bytes, dtype=torch.uint8, device="cuda") for _ in range(n_sets)]
-        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ce = [torch.cuda.Event(enable_timing=True) for _ in range(repeats + 1)]
         for i in range(max(2, reps // 10)):
             aacgpu.calib_copy(dst[i % n_sets].data_ptr(), src[i % n_sets].data_ptr(), n_bytes, tstream.cuda_stream)
-        c0.record()
-        for i in range(reps):
-            aacgpu.calib_copy(dst[i % n_sets].data_ptr(), src[i % n_sets].data_ptr(), n_bytes, tstream.cuda_stream)
-        c1.record()
+        ce[0].record()
+        for r in range(repeats):
+            for i in range(reps):
+                aacgpu.calib_copy(dst[i % n_sets].data_ptr(), src[i % n_sets].data_ptr(), n_bytes, tstream.cuda_stream)
+            ce[r + 1].record()
         torch.cuda.synchronize()
-        return 2.0 * n_bytes / (c0.elapsed_time(c1) * 1e-3 / reps) / 1e9, c0.elapsed_time(c1) / reps
+        st = region_stats([ce[r].elapsed_time(ce[r + 1]) for r in range(repeats)], reps)
+        return 2.0 * n_bytes / (st["ms_per_step_median"] * 1e-3) / 1e9, st
 
     abytes_step = algorithmic_bytes_per_channel_frame(args.input, n_frames, args.output) * n_streams * n_frames * n_chan
-    copy_gbs, copy_ms = copy_rate(abytes_step / 2, max(2, args.nbuf), max(200, min(args.steps, 4000)))
-    copy_large_gbs, _ = copy_rate(1 << 29, 2, 20)
+    copy_reps = max(20, min(args.steps, 400))
+    copy_gbs, copy_stats = copy_rate(abytes_step / 2, max(2, args.nbuf), copy_reps, R)
+    copy_ms = copy_stats["ms_per_step_median"]
+    copy_large_gbs, _ = copy_rate(1 << 29, 2, 20, 1)
 
     # untimed: the last output is finite and non-trivial; then the oracle comparison on the bench's own batch
-    out = bufs[(n_pre + args.warmup + args.steps - 1) % args.nbuf][1]
+    out = bufs[(n_pre + args.warmup + R * args.steps - 1) % args.nbuf][1]
     ok = bool(torch.isfinite(out.float()).all().item()) and float(out.float().abs().max().item()) > 0
     parity = None
     if not args.no_parity:
@@ -313,7 +362,7 @@ def main():
         ok = ok and finite and err <= gate_rms and rel <= gate_rel
 
     frames_per_step = n_streams * n_frames
-    value = world * frames_per_step * args.steps / event_s
+    value = whole_job_value(world, frames_per_step, stats["ms_per_step_median"])
     abytes = algorithmic_bytes_per_channel_frame(args.input, n_frames, args.output) * frames_per_step * n_chan
     if cce is not None:
         abytes += (2048 + 240) * frames_per_step             # the coupling element's own spectrum and band words in, nothing extra out
@@ -323,11 +372,12 @@ def main():
     line = {
         "metric": "AAC-LC 48 kHz stereo frames/sec per node + achieved HBM GB/s vs roofline",
         "value": value, "unit": unit, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": event_s / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": stats["ms_per_step_median"], "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "timing": "value and ms_per_step: HIP events around the K timed steps on the launch stream, MAX over ranks; "
-                  "wall_*: host clock between the barriers (adds first-launch latency and the wake-up after the last step)",
-        "wall_ms_per_step": wall / args.steps * 1e3, "value_wall": world * frames_per_step * args.steps / wall,
+        "timing": dict(stats, method="the K timed steps are run R times back to back, each repeat between its own HIP events on the launch "
+                                     "stream (MAX over ranks per repeat); value and ms_per_step: the MEDIAN repeat; wall_*: host clock between "
+                                     "the barriers over all R x K steps (adds first-launch latency and the wake-up after the last step)"),
+        "wall_ms_per_step": wall / (R * args.steps) * 1e3, "value_wall": world * frames_per_step * R * args.steps / wall,
         "config": {"workload": {"cfg2": "BASELINE config 2: batch of 4096 stereo LC frames (256 streams x 16 frames, ONLY_LONG_SEQUENCE, KBD)",
                                 "cfg3": "BASELINE config 3: 4096 stereo frames, window-sequence mix [0,0,1,2,2,3,0,0], TNS identity",
                                 "cfg4": "BASELINE config 4 shape per GPU: 32 streams x 128 frames, config-3 mix",
@@ -348,14 +398,16 @@ def main():
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                      "copy_ceiling_GBs": copy_gbs, "frac_of_copy": achieved / copy_gbs, "copy_ms": copy_ms,
+                     "copy_timing": copy_stats,
                      "copy_ceiling_note": "aacg_calib_copy: float4 copy of the step's algorithmic byte volume (half read, half written) with the run "
-                                          "kernel's launch shape, %d launches right behind the timed region on the same stream; 1 GiB copy: %.0f GB/s" % (max(200, min(args.steps, 4000)), copy_large_gbs),
+                                          "kernel's launch shape, %d x %d launches right behind the timed region on the same stream (median repeat); 1 GiB copy: %.0f GB/s" % (R, copy_reps, copy_large_gbs),
                      "copy_ceiling_large_GBs": copy_large_gbs,
                      "kernel": eng.plan_kernels(plans[0]),
                      "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": abytes,
-                     "host_enqueue_us_per_step": issued[0] / args.steps * 1e6},
+                     "host_enqueue_us_per_step": issued[0] / (R * args.steps) * 1e6},
         "output_ok": ok, "parity_rms": parity["rms"] if parity else None, "parity": parity,
     }
+    line.update(backend_fields(args.dist_backend, dist))
     if rank == 0 and not args.no_cpu_baseline and world == 1:
         line["cpu_baseline"] = cpu_baseline(args.input, mix, layout, n_chan)
         line["cpu_baseline"]["unit"] = line["cpu_baseline"]["single_core"]["unit"] = unit

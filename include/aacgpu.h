@@ -473,6 +473,13 @@ int aacg_plan_refresh_units(aacg_engine* e, aacg_plan* p, const aacg_unit_desc* 
  * the int16 seam's variant of the stage (mirror-lane exchanges as DPP moves, long columns dealt out by long_col).  Nothing on the decode path calls this. */
 int aacg_debug_transform(int device_ordinal, int sample_index, int is_short, int identity_rotation, const float* in, float* out);
 
+/* Diagnostic: route choices a parity test wants to make by hand; 0 (the default) = the engine's own choice.  Nothing on the
+ * decode path calls this.  AACG_DEBUG_ROUTE_UNFUSED_COUPLING: independent coupling (cce.js:121-128) as the separate pass over
+ * the interleaved PCM (aacg_couple_pcm, what plans with double-duty runs take) even where the engine would apply it in the
+ * targets' epilogues (aacg_imdct_run_*_cpl): the two routes must produce the same bits. */
+#define AACG_DEBUG_ROUTE_UNFUSED_COUPLING 1
+int aacg_debug_set_route(aacg_engine* e, int flags);
+
 #ifdef __cplusplus
 }
 #endif

@@ -134,6 +134,17 @@ int emu_plan(const aacg_unit_desc* units, uint32_t n_units, int sample_index, in
     return (int)ph.runs.size();
 }
 
+/* host planner only: a plan for `first`, then aacg_plan_refresh_host with `next` (tns_spec: the engine's TNS mode) */
+int emu_plan_refresh(const aacg_unit_desc* first, const aacg_unit_desc* next, uint32_t n_units, int sample_index, int max_streams,
+                     int max_channels, int tns_spec)
+{
+    aacg_plan_host ph;
+    std::vector<uint8_t> parity((size_t)max_streams * (size_t)max_channels, 0);
+    int rc = aacg_plan_build(first, n_units, sample_index, max_streams, max_channels, parity.data(), &ph, &g_err);
+    if (rc) return rc;
+    return aacg_plan_refresh_host(&ph, next, n_units, sample_index, tns_spec != 0, &g_err);
+}
+
 /* full path: plan + "launch".  overlap_pool: [max_streams][max_channels][2][1024]; parity: [max_streams*max_channels], updated. */
 int emu_decode_tns(int input_kind, int sample_index, int max_streams, int max_channels,
                    const aacg_unit_desc* units, uint32_t n_units, const void* coeffs, const aacg_band_meta* meta,

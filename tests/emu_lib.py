@@ -28,6 +28,7 @@ class Emu:
                                      C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
         L.emu_spectral.argtypes = [C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         L.emu_plan.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+        L.emu_plan_refresh.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int]
         L.emu_get_windows.argtypes = [C.c_int, C.c_void_p]
         L.emu_get_iq_sf.argtypes = [C.c_void_p, C.c_void_p]
 
@@ -68,6 +69,12 @@ class Emu:
         rc = self.lib.emu_spectral(sample_index, units.ctypes.data, len(units), q.ctypes.data, meta.ctypes.data, spec.ctypes.data)
         assert rc == 0
         return spec
+
+    def plan_refresh(self, first, nxt, max_streams, max_channels, tns_spec=False, sample_index=3):
+        """The host planner's refresh of a kept plan (aacg_plan_refresh_host): 0 or the AACG_ERR_* code."""
+        first, nxt = np.ascontiguousarray(first), np.ascontiguousarray(nxt)
+        assert len(first) == len(nxt)
+        return self.lib.emu_plan_refresh(first.ctypes.data, nxt.ctypes.data, len(first), sample_index, max_streams, max_channels, 1 if tns_spec else 0)
 
     def plan(self, units, max_streams, max_channels, parity=None, sample_index=3):
         units = np.ascontiguousarray(units)

@@ -177,6 +177,42 @@ def test_planner_refuses_coupling_elements_without_the_mode(oracle):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("layout,points,T", [(("cpe", "cpe", "cpe", "sce"), (2, 2), 15), (("cpe", "cpe", "cpe", "sce"), (2,), 20), (("cpe",), (2,), 31),
+                                             (("sce", "cpe"), (2, 0, 2), 9)])
+def test_gpu_fused_and_separate_independent_coupling_agree(oracle, layout, points, T):
+    """on the GPU, the fused route (coupling applied in the targets' epilogues, aacg_imdct_run_quant_cpl)
+    and the staged route (aacg_couple_pcm over the finished PCM; forced with aacg_debug_set_route) give the SAME BITS — 7 channels
+    + coupling elements, two batches chained through the overlap state — and both stay at the oracle."""
+    S = 12
+    wl0 = aacgpu_workload.make_batch(n_streams=S, n_frames=T, layout=layout, mix=True, seed=21)
+    H = wl0["C"] + len(points)
+    outs, routes = [], []
+    for unfused in (0, 1):
+        eng = aacgpu.Engine(aacgpu.INPUT_QUANT_I16, max_streams=S, max_channels=H, cce_mode=aacgpu.CCE_SPEC)
+        eng.debug_set_route(unfused)
+        got = []
+        for batch in range(2):
+            wl = aacgpu_workload.make_batch(n_streams=S, n_frames=T, layout=layout, mix=True, seed=21 + batch, frame_base=batch * T)
+            units, q, meta, cce = aacgpu_workload.add_cce(wl, points=points, seed=400 + batch)
+            if batch == 0:
+                plan = eng.plan(units, cce=cce)
+                routes.append(eng.plan_kernels(plan))
+                plan.destroy()
+            got.append(eng.decode_batch(units, q, meta, wl["n_pcm"], cce=cce))
+        outs.append(np.concatenate(got))
+        eng.close()
+    assert "_cpl" in routes[0] and "aacg_couple_pcm" in routes[1] and "_cpl" not in routes[1]
+    assert np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32))
+    ov = np.zeros((S, H, 1024), np.float32)
+    ref = []
+    for batch in range(2):
+        wl = aacgpu_workload.make_batch(n_streams=S, n_frames=T, layout=layout, mix=True, seed=21 + batch, frame_base=batch * T)
+        units, q, meta, cce = aacgpu_workload.add_cce(wl, points=points, seed=400 + batch)
+        ref.append(oracle.decode_batch(units, q, meta, wl["n_pcm"], ov, cce=cce))
+    assert rel(outs[0], np.concatenate(ref)) < RMS_REL
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("layout,points,T,inp", [(("cpe", "sce"), (0, 1, 2), 5, "q"), (("cpe", "cpe", "cpe", "sce"), (2,), 20, "q"),
                                                 (("cpe",), (0,), 40, "q"), (("sce", "cpe", "cpe", "sce"), (1, 2), 7, "q"), (("cpe", "cpe"), (2, 2, 0), 19, "q"),
                                                 (("cpe", "sce"), (0, 2), 6, "spec")])

@@ -260,6 +260,17 @@ def test_planner_rejects_bad_tns(emu):
         emu.decode(units, wl["q"], wl["meta"], wl["n_pcm"], pool, par, tns=t2)
 
 
+def test_refresh_of_a_kept_plan_refuses_tns_frames_on_a_spec_engine(emu):
+    """a plan made from a batch without TNS must not take a later batch WITH TNS side info on an AACG_TNS_SPEC
+    engine (the refresh would clear the flags and decode without the filters); a REFERENCE engine ignores the side info."""
+    wl = W.make_batch(n_streams=2, n_frames=4, seed=5)
+    with_tns, _ = W.add_tns(wl, seed=5, p_channel=1.0)
+    assert emu.plan_refresh(wl["units"], wl["units"], 2, 2, tns_spec=True) == 0
+    assert emu.plan_refresh(wl["units"], with_tns, 2, 2, tns_spec=False) == 0
+    assert emu.plan_refresh(wl["units"], with_tns, 2, 2, tns_spec=True) == -6          # AACG_ERR_LAYOUT_CHANGE
+    assert "TNS" in emu.error()
+
+
 # ---- the HIP path (needs a real MI355X) -----------------------------------------------------------------
 def _gpu_overlaps(eng, S, C):
     return np.stack([[eng.get_overlap(s, c) for c in range(C)] for s in range(S)])
@@ -377,6 +388,15 @@ def test_gpu_tns_errors():
     eng.close()
     with pytest.raises(aacgpu.AacgError):
         aacgpu.Engine(aacgpu.INPUT_QUANT_I16, 1, 2, tns_mode=2)
+    # a kept plan without TNS records refuses a refresh with TNS frames on this engine
+    eng = aacgpu.Engine(aacgpu.INPUT_QUANT_I16, 1, 2, tns_mode=aacgpu.TNS_SPEC)
+    plan = eng.plan(wl["units"])
+    with pytest.raises(aacgpu.AacgError) as ei:
+        eng.plan_refresh_units(plan, units)
+    assert ei.value.code == -6
+    eng.plan_refresh_units(plan, wl["units"])
+    plan.destroy()
+    eng.close()
 
 
 def test_emulated_tns_long_chain(emu, oracle):
