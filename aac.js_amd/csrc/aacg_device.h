@@ -166,6 +166,68 @@ static inline void aacg_set_cpl(aacg_kparams* P, const aacg_couple_job* jobs, co
 #define AACG_CPL_GAINS(P) ((const float*)(const void*)(P).pns)
 #define AACG_CPL_SIDE(P)  ((const float*)(P).spec_out)   /* the coupling elements' filterbank output, [block][1024], PCM-scaled */
 
+/* ---- the 8-waves-per-SIMD run kernels (aacg_kernels8.h): one CHANNEL per wave ---------------------------------- */
+/* A workgroup is still 16 waves, but a wave carries one channel of one frame (4 KB of LDS, <= 64 VGPRs), so that two
+ * workgroups share a CU: 32 waves, 8 per SIMD.  What that changes in the data the kernel reads:
+ *  - the windows are no longer staged in LDS (two copies of the 25 KB table block would not fit beside 2 x 64 KB of
+ *    slots): they come from global memory / L2 in the order the epilogue reads them, with the START / STOP shapes
+ *    composed on the host (aacg_win8);
+ *  - a run holds 8 frames of a channel pair (wave 2 f + c) or 16 frames of a single channel (wave f), and a chain's
+ *    consecutive runs hand the windowed tail over through global memory (a rendezvous per link: whichever side arrives
+ *    second finishes the frame; no dispatch-order assumption, no recomputed IMDCT). */
+struct aacg_win8 {
+    /* head[v][n] multiplies IMDCT output n (n < 1024) of a long-type frame: v = 2 * (sequence == LONG_STOP) + previous shape
+     * (filter_bank.js:109-111,124-126,185-195: long window | 0, short window, 1); PCM-scaled like aacg_tables.win_* */
+    float head[4][1024];
+    /* tail[v][n] multiplies IMDCT output 1024 + n: v = 2 * (sequence == LONG_START) + shape
+     * (filter_bank.js:114-116,129-139: reversed long window | 1, reversed short window, 0) */
+    float tail[4][1024];
+    float shrt[2][128];               /* SINE_128, KBD_128, PCM-scaled */
+};
+
+/* table block of the 8-wave kernels in LDS (floats): rotations and twiddles, then (quantised input) SF, signed IQ, band maps */
+#define AACG8_TAB_F32_FLOATS   AACG_TAB_OFF_WIN_LONG                                  /* 2160: everything in front of the windows */
+#define AACG8_TAB_QUANT_FLOATS (AACG8_TAB_F32_FLOATS + (AACG_TAB_QUANT_FLOATS - AACG_TAB_F32_FLOATS))   /* 3904 */
+#define AACG8_WIN_GAP_FLOATS   (AACG_TAB_F32_FLOATS - AACG_TAB_OFF_WIN_LONG)          /* the windows' place in aacg_tables: skipped */
+#define AACG8_SLOT_FLOATS      1024
+/* LDS map: [16 slots of 4 KB][tables][one flag per wave]; two workgroups per CU: at most 80 KB each */
+#define AACG8_LDS_BYTES(tab_floats) (4 * (AACG_WG_WAVES * AACG8_SLOT_FLOATS + (tab_floats) + AACG_WG_WAVES))
+
+struct aacg_run8 {
+    int32_t n_units;                  /* frames in this run: <= 8 for a channel pair, <= 16 for a single channel */
+    int32_t n_ch;                     /* 1 / 2: channels of the element */
+    int32_t unit[AACG_RUN_W];
+    int32_t ov_a[2], ov_b[2];         /* the chain's overlap state, as in aacg_run */
+    int32_t link_in;                  /* rendezvous cell through which the run before it hands over its tail; -1: first run of its chain */
+    int32_t link_out;                 /* cell towards the next run; -1: last run of its chain (its tail is the new overlap state) */
+    int32_t succ_unit;                /* first unit of the next run (whose PCM this run finishes if it arrives second), or -1 */
+    int32_t reserved[5];
+};
+
+/* one rendezvous cell (global memory): two state words (one per sample half of a channel pair; a single channel uses the
+ * first) and two payload buffers of [2 channels][1024] floats: the windowed tail, or the windowed first half */
+#define AACG8_RV_STATE_WORDS 2
+#define AACG8_RV_DATA_FLOATS 4096     /* [tail | head][channel][1024] */
+#define AACG8_RV_TAIL 1ull
+#define AACG8_RV_HEAD 2ull
+
+struct aacg_kparams8 {
+    const aacg_dev_unit*  units;
+    const aacg_run8*      runs;
+    const void*           coeffs;
+    const aacg_band_meta* meta;
+    float*                pcm;
+    float*                overlap;
+    const aacg_tables*    tab;
+    const aacg_win8*      win;
+    unsigned long long*   rv_state;   /* [n_links][AACG8_RV_STATE_WORDS], never reset: a word counts only when it carries this launch's epoch */
+    float*                rv_data;    /* [n_links][AACG8_RV_DATA_FLOATS] */
+    unsigned long long    epoch;      /* unique per launch that uses these cells, never 0 */
+    int32_t               flip;
+    int32_t               n_runs;
+    unsigned long long*   trace;      /* -DAACG_PROFILE builds: per-wave phase time stamps (tools/timeline.py); null otherwise */
+};
+
 /* ---- device front end (aacg_parse.h) ------------------------------------------------------------ */
 #define AACG_PARSE_WG_SMALL   256      /* frames staged in LDS: shortest time per frame */
 #define AACG_PARSE_WG_LARGE   1024     /* frames read in place, 16 waves per CU: highest rate on large batches */

@@ -43,6 +43,9 @@ void aacg_spectral_ex_launch(bool quant, int n_units, hipStream_t s, const aacg_
 void aacg_couple_launch(bool pcm, hipStream_t s, const aacg_couple_params& Q);
 void aacg_couple_run_launch(bool quant, dim3 grid, dim3 block, hipStream_t s, const aacg_kparams& P);
 struct cce_bufs { const aacg_run* runs; const aacg_couple_job* jobs; const float* gains; float* side; };
+/* aacg_engine8.hip: the one-channel-per-wave run kernels (two workgroups per CU) */
+void aacg_run8_launch(bool quant, dim3 grid, dim3 block, hipStream_t s, const aacg_kparams8& P);
+struct run8_bufs { const aacg_run8* runs; unsigned long long* rv_state; float* rv_data; };
 
 extern "C" __global__ __launch_bounds__(AACG_WG_THREADS)
 void aacg_spectral(const aacg_kparams P, int n_units) { spectral_body(P, n_units); }
@@ -55,6 +58,9 @@ struct aacg_engine {
     hipStream_t stream = nullptr;
     aacg_tables* d_tab = nullptr;
     aacg_pns_tables* d_pns = nullptr;       /* AACG_PNS_SPEC */
+    aacg_win8* d_win8 = nullptr;            /* the windows as the 8-wave kernels read them */
+    bool run8 = true;                       /* plain batches (f32 PCM, no optional stage) on the one-channel-per-wave kernels */
+    unsigned long long rv_epoch = 0;        /* rendezvous epoch: one per launch of those kernels, never 0 */
     float* d_overlap = nullptr;             /* [max_streams][max_channels][2][1024] */
     std::vector<uint8_t> parity;            /* live buffer per (stream, channel) */
     uint64_t epoch = 0;                     /* bumped whenever `parity` changes: lets a relaunched plan skip its check */
@@ -73,6 +79,7 @@ struct aacg_engine {
         void* d_scratch = nullptr; size_t scratch_cap = 0;
         void* d_spec = nullptr;   size_t spec_cap = 0;       /* PNS route: f32 spectra between the two kernels */
         void* d_cce[4] = {nullptr, nullptr, nullptr, nullptr}; size_t cce_cap[4] = {0, 0, 0, 0};   /* AACG_CCE_SPEC: runs, jobs, gains, side PCM */
+        void* d_run8[3] = {nullptr, nullptr, nullptr}; size_t run8_cap[3] = {0, 0, 0};             /* 8-wave kernels: runs, rendezvous state, payload */
         void* d_pcm = nullptr;    size_t pcm_cap = 0;
         /* page-locked staging for callers that pass ordinary (pageable) memory */
         void* h_in = nullptr;     size_t h_in_cap = 0;
@@ -103,7 +110,8 @@ struct aacg_plan {
     float* d_scratch = nullptr;             /* parked predecessor tails of double-duty runs */
     float* d_spec = nullptr;                /* PNS route: f32 spectra between the two kernels */
     void*  d_cce[4] = {nullptr, nullptr, nullptr, nullptr};   /* AACG_CCE_SPEC: coupling elements' runs, jobs, gains, side PCM */
-    size_t bytes[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};            /* sizes of the nine buffers above, for the engine's free list */
+    void*  d_run8[3] = {nullptr, nullptr, nullptr};           /* 8-wave kernels: their run table, rendezvous state words and payload */
+    size_t bytes[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  /* sizes of the twelve buffers above, for the engine's free list */
     hipEvent_t uploaded = nullptr;          /* the tables are on the device */
     hipEvent_t last_use = nullptr;          /* recorded at destruction on last_stream: everything launched with this plan */
     hipStream_t last_stream = nullptr;      /* stream of the most recent launch (no per-launch event: it costs 3 us per step) */
@@ -186,6 +194,14 @@ bool needs_spec_buffer(const aacg_engine* e, const aacg_plan_host& h)
     return h.any_cce_dependent || (stages && (i16 || h.any_cce || h.needs_scratch));
 }
 
+/* Plain batches — f32 PCM, no optional stage, no coupling element — run on the one-channel-per-wave kernels (aacg_kernels8.h). */
+bool takes_run8(const aacg_engine* e, const aacg_plan_host& h)
+{
+    const bool quant = e->cfg.input_kind == AACG_INPUT_QUANT_I16;
+    return e->run8 && !(e->debug_route & AACG_DEBUG_ROUTE_WIDE_KERNELS) && e->cfg.output_kind == AACG_OUTPUT_F32 &&
+           !h.any_cce && !h.any_tns && !(quant && h.any_pns) && !h.runs8.empty();
+}
+
 /* The launches launch_run makes for a plan, by kernel name: what a rocprofv3 kernel trace of the batch shows. */
 std::string route_names(const aacg_engine* e, const aacg_plan_host& h)
 {
@@ -205,6 +221,7 @@ std::string route_names(const aacg_engine* e, const aacg_plan_host& h)
         add(quant ? "aacg_spectral_ex_quant" : "aacg_spectral_ex_f32");
         quant = false;
     }
+    if (takes_run8(e, h)) return std::string("aacg_imdct_run8_") + (quant ? "quant" : "f32");
     const std::string run = std::string("aacg_imdct_run_") + (quant ? "quant" : "f32");
     const bool fused = h.fused_independent && !ex && !i16 && !(e->debug_route & AACG_DEBUG_ROUTE_UNFUSED_COUPLING);
     if (fused) {
@@ -222,13 +239,23 @@ std::string route_names(const aacg_engine* e, const aacg_plan_host& h)
 
 /* enqueue the run kernel for a planned batch (device pointers) */
 int launch_run(aacg_engine* e, const aacg_dev_unit* d_units, const aacg_run* d_runs, const aacg_dev_tns* d_tns,
-               float* d_scratch, float* d_spec, const cce_bufs& cb, const aacg_plan_host& h, const void* d_coeffs, const aacg_band_meta* d_meta,
+               float* d_scratch, float* d_spec, const cce_bufs& cb, const run8_bufs& r8, const aacg_plan_host& h, const void* d_coeffs, const aacg_band_meta* d_meta,
                void* d_pcm, int flip, hipStream_t s)
 {
     const bool i16 = e->cfg.output_kind == AACG_OUTPUT_I16;
     bool quant = e->cfg.input_kind == AACG_INPUT_QUANT_I16, ex = false;
     if (h.zero_fill)
         HIP_TRY(e, hipMemsetAsync(d_pcm, 0, h.pcm_floats * pcm_elem_size(e), s), AACG_ERR_NO_DEVICE);
+    if (takes_run8(e, h)) {
+        aacg_kparams8 P8;
+        P8.units = d_units; P8.runs = r8.runs; P8.coeffs = d_coeffs; P8.meta = d_meta; P8.pcm = (float*)d_pcm; P8.overlap = e->d_overlap;
+        P8.tab = e->d_tab; P8.win = e->d_win8; P8.rv_state = r8.rv_state; P8.rv_data = r8.rv_data; P8.epoch = ++e->rv_epoch;
+        P8.flip = flip; P8.n_runs = (int32_t)h.runs8.size();
+        P8.trace = (e->d_trace && (e->ablate & 16)) ? (unsigned long long*)e->d_trace : nullptr;
+        aacg_run8_launch(quant, dim3((unsigned)h.runs8.size()), dim3(AACG_WG_THREADS), s, P8);
+        HIP_TRY(e, hipGetLastError(), AACG_ERR_NO_DEVICE);
+        return AACG_OK;
+    }
     aacg_kparams P;
     P.units = d_units; P.runs = d_runs; P.coeffs = d_coeffs; P.meta = d_meta; P.pcm = (float*)d_pcm;
     P.tns = h.any_tns ? d_tns : nullptr;
@@ -321,7 +348,7 @@ const char* aacg_kernel_name(void) { return "aacg_imdct_run_quant"; }
 
 int aacg_debug_set_route(aacg_engine* e, int flags)
 {
-    if (!e || (flags & ~AACG_DEBUG_ROUTE_UNFUSED_COUPLING)) return AACG_ERR_INVALID_ARG;
+    if (!e || (flags & ~(AACG_DEBUG_ROUTE_UNFUSED_COUPLING | AACG_DEBUG_ROUTE_WIDE_KERNELS))) return AACG_ERR_INVALID_ARG;
     e->debug_route = flags;
     return AACG_OK;
 }
@@ -376,6 +403,15 @@ int aacg_create(const aacg_config* cfg, aacg_engine** out)
         return AACG_ERR_NO_DEVICE;
     }
     e->parity.assign((size_t)cfg->max_streams * (size_t)cfg->max_channels, 0);
+    {
+        aacg_win8* w8 = new (std::nothrow) aacg_win8;
+        if (w8) aacg_build_win8(&e->h_tab, w8);
+        const bool ok = w8 && hip_ok(e, hipMalloc((void**)&e->d_win8, sizeof *w8), "hipMalloc window tables") &&
+                        hip_ok(e, hipMemcpy(e->d_win8, w8, sizeof *w8, hipMemcpyHostToDevice), "upload window tables");
+        delete w8;
+        if (!ok) { aacg_destroy(e); return AACG_ERR_OUT_OF_MEMORY; }
+        if (const char* r = std::getenv("AACG_RUN8")) e->run8 = std::atoi(r) != 0;    /* A/B switch for tools/: 0 = the 16-wave kernels for everything */
+    }
     if (cfg->pns_mode == AACG_PNS_SPEC) {
         aacg_pns_tables* pt = new (std::nothrow) aacg_pns_tables;
         const bool ok = pt && aacg_build_pns_tables(cfg->sample_index, pt) == AACG_OK &&
@@ -399,10 +435,12 @@ void aacg_destroy(aacg_engine* e)
     (void)hipDeviceSynchronize();
     if (e->d_tab) (void)hipFree(e->d_tab);
     if (e->d_pns) (void)hipFree(e->d_pns);
+    if (e->d_win8) (void)hipFree(e->d_win8);
     if (e->d_overlap) (void)hipFree(e->d_overlap);
     for (auto& sl : e->slot) {
         for (void* p : {sl.d_units, sl.d_runs, sl.d_coeffs, sl.d_meta, sl.d_tns, sl.d_scratch, sl.d_spec, sl.d_pcm}) if (p) (void)hipFree(p);
         for (void* p : sl.d_cce) if (p) (void)hipFree(p);
+        for (void* p : sl.d_run8) if (p) (void)hipFree(p);
         if (sl.h_in) (void)hipHostFree(sl.h_in);
         if (sl.h_pcm) (void)hipHostFree(sl.h_pcm);
         if (sl.done) (void)hipEventDestroy(sl.done);
@@ -528,16 +566,21 @@ int aacg_plan_create_ex(aacg_engine* e, const aacg_unit_desc* units, uint32_t n_
     bool ok = hip_ok(e, hipSetDevice(e->cfg.device_ordinal), "hipSetDevice") &&
               hip_ok(e, hipEventCreateWithFlags(&p->uploaded, hipEventDisableTiming), "hipEventCreate") &&
               hip_ok(e, hipEventCreateWithFlags(&p->last_use, hipEventDisableTiming), "hipEventCreate");
-    const size_t want[9] = {ub, rb, tb, sb, xb, cb[0], cb[1], cb[2], cb[3]};
-    void** const slot[9] = {(void**)&p->d_units, (void**)&p->d_runs, (void**)&p->d_tns, (void**)&p->d_scratch, (void**)&p->d_spec,
-                            &p->d_cce[0], &p->d_cce[1], &p->d_cce[2], &p->d_cce[3]};
-    const void* const src[9] = {p->h.units.data(), p->h.runs.data(), p->h.tns.data(), nullptr, nullptr,
-                                p->h.cce_runs.data(), p->h.couple_jobs.data(), p->h.gains.data(), nullptr};
-    for (int i = 0; i < 9 && ok; i++) {
+    const bool r8 = takes_run8(e, p->h);
+    const size_t r8b[3] = {r8 ? sizeof(aacg_run8) * p->h.runs8.size() : 0, r8 ? sizeof(unsigned long long) * AACG8_RV_STATE_WORDS * (size_t)p->h.n_links : 0,
+                           r8 ? sizeof(float) * AACG8_RV_DATA_FLOATS * (size_t)p->h.n_links : 0};
+    const size_t want[12] = {ub, r8 ? 0 : rb, tb, r8 ? 0 : sb, xb, cb[0], cb[1], cb[2], cb[3], r8b[0], r8b[1], r8b[2]};
+    void** const slot[12] = {(void**)&p->d_units, (void**)&p->d_runs, (void**)&p->d_tns, (void**)&p->d_scratch, (void**)&p->d_spec,
+                             &p->d_cce[0], &p->d_cce[1], &p->d_cce[2], &p->d_cce[3], &p->d_run8[0], &p->d_run8[1], &p->d_run8[2]};
+    const void* const src[12] = {p->h.units.data(), p->h.runs.data(), p->h.tns.data(), nullptr, nullptr,
+                                 p->h.cce_runs.data(), p->h.couple_jobs.data(), p->h.gains.data(), nullptr, p->h.runs8.data(), nullptr, nullptr};
+    for (int i = 0; i < 12 && ok; i++) {
         if (!want[i]) continue;
         *slot[i] = pool_take(e, want[i], &p->bytes[i]);
         ok = *slot[i] != nullptr &&
              (!src[i] || hip_ok(e, hipMemcpyAsync(*slot[i], src[i], want[i], hipMemcpyHostToDevice, e->stream), "upload plan tables"));
+        /* rendezvous state words count only with a launch's epoch in them; a recycled or fresh buffer starts from zero all the same */
+        if (ok && i == 10) ok = hip_ok(e, hipMemsetAsync(*slot[i], 0, want[i], e->stream), "zero rendezvous state");
     }
     ok = ok && hip_ok(e, hipEventRecord(p->uploaded, e->stream), "hipEventRecord");
     if (!ok) {
@@ -563,8 +606,9 @@ void aacg_plan_destroy(aacg_plan* p)
         }
         (void)hipEventDestroy(p->last_use);
     }
-    void* const ptr[9] = {p->d_units, p->d_runs, p->d_tns, p->d_scratch, p->d_spec, p->d_cce[0], p->d_cce[1], p->d_cce[2], p->d_cce[3]};
-    for (int i = 0; i < 9; i++) pool_give(e, ptr[i], p->bytes[i]);
+    void* const ptr[12] = {p->d_units, p->d_runs, p->d_tns, p->d_scratch, p->d_spec, p->d_cce[0], p->d_cce[1], p->d_cce[2], p->d_cce[3],
+                           p->d_run8[0], p->d_run8[1], p->d_run8[2]};
+    for (int i = 0; i < 12; i++) pool_give(e, ptr[i], p->bytes[i]);
     delete p;
 }
 
@@ -592,7 +636,10 @@ int aacg_decode_device(aacg_engine* e, aacg_plan* p, const void* d_coeffs, const
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : e->stream;
     if (!p->used) HIP_TRY(e, hipStreamWaitEvent(s, p->uploaded, 0), AACG_ERR_NO_DEVICE);
     const cce_bufs cb = {(const aacg_run*)p->d_cce[0], (const aacg_couple_job*)p->d_cce[1], (const float*)p->d_cce[2], (float*)p->d_cce[3]};
-    rc = launch_run(e, p->d_units, p->d_runs, p->d_tns, p->d_scratch, p->d_spec, cb, p->h, d_coeffs, d_meta, d_pcm, (int)(p->launches & 1u), s);
+    const run8_bufs r8 = {(const aacg_run8*)p->d_run8[0], (unsigned long long*)p->d_run8[1], (float*)p->d_run8[2]};
+    if (takes_run8(e, p->h) && !p->d_run8[0]) { e->err = "the plan was made for the 16-wave kernels (aacg_debug_set_route changed since)"; return AACG_ERR_STALE_PLAN; }
+    if (!takes_run8(e, p->h) && !p->d_runs && !p->h.runs.empty()) { e->err = "the plan was made for the 8-wave kernels (aacg_debug_set_route changed since)"; return AACG_ERR_STALE_PLAN; }
+    rc = launch_run(e, p->d_units, p->d_runs, p->d_tns, p->d_scratch, p->d_spec, cb, r8, p->h, d_coeffs, d_meta, d_pcm, (int)(p->launches & 1u), s);
     if (rc) return rc;
     p->last_stream = s;
     p->used = true;
@@ -779,6 +826,14 @@ int aacg_submit_ex(aacg_engine* e, const aacg_batch* batch, uint64_t* ticket)
                            sizeof(float) * h.gains.size(), (size_t)h.side_blocks * 4096u};
     const void* const cce_src[4] = {h.cce_runs.data(), h.couple_jobs.data(), h.gains.data(), nullptr};
     for (int i = 0; i < 4; i++) if (ccb[i] && (rc = grow(e, &sl.d_cce[i], &sl.cce_cap[i], ccb[i]))) return rc;
+    const bool r8 = takes_run8(e, h);
+    const size_t r8b[3] = {r8 ? sizeof(aacg_run8) * h.runs8.size() : 0, r8 ? sizeof(unsigned long long) * AACG8_RV_STATE_WORDS * (size_t)h.n_links : 0,
+                           r8 ? sizeof(float) * AACG8_RV_DATA_FLOATS * (size_t)h.n_links : 0};
+    for (int i = 0; i < 3; i++) {
+        const size_t had = sl.run8_cap[i];
+        if (r8b[i] && (rc = grow(e, &sl.d_run8[i], &sl.run8_cap[i], r8b[i]))) return rc;
+        if (i == 1 && sl.run8_cap[i] != had) HIP_TRY(e, hipMemset(sl.d_run8[i], 0, sl.run8_cap[i]), AACG_ERR_NO_DEVICE);   /* a new state buffer starts from zero */
+    }
     const size_t cb = (size_t)n_coef_blocks * 1024u * coef_elem_size(e);
     const size_t mb = quant ? (size_t)n_meta * sizeof(aacg_band_meta) : 0;
     const size_t pb = h.pcm_floats * pcm_elem_size(e);
@@ -810,6 +865,7 @@ int aacg_submit_ex(aacg_engine* e, const aacg_batch* batch, uint64_t* ticket)
     }
     HIP_TRY(e, hipMemcpyAsync(sl.d_units, h.units.data(), ub, hipMemcpyHostToDevice, s), AACG_ERR_NO_DEVICE);
     if (rb) HIP_TRY(e, hipMemcpyAsync(sl.d_runs, h.runs.data(), rb, hipMemcpyHostToDevice, s), AACG_ERR_NO_DEVICE);
+    if (r8b[0]) HIP_TRY(e, hipMemcpyAsync(sl.d_run8[0], h.runs8.data(), r8b[0], hipMemcpyHostToDevice, s), AACG_ERR_NO_DEVICE);
     if (tb) HIP_TRY(e, hipMemcpyAsync(sl.d_tns, h.tns.data(), tb, hipMemcpyHostToDevice, s), AACG_ERR_NO_DEVICE);
     for (int i = 0; i < 3; i++) if (ccb[i]) HIP_TRY(e, hipMemcpyAsync(sl.d_cce[i], cce_src[i], ccb[i], hipMemcpyHostToDevice, s), AACG_ERR_NO_DEVICE);
     HIP_TRY(e, hipMemcpyAsync(sl.d_coeffs, src_coeffs, cb, hipMemcpyHostToDevice, s), AACG_ERR_NO_DEVICE);
@@ -818,7 +874,8 @@ int aacg_submit_ex(aacg_engine* e, const aacg_batch* batch, uint64_t* ticket)
      * while its uploads above overlapped it */
     if (e->last_kernel) HIP_TRY(e, hipStreamWaitEvent(s, e->last_kernel, 0), AACG_ERR_NO_DEVICE);
     rc = launch_run(e, (const aacg_dev_unit*)sl.d_units, (const aacg_run*)sl.d_runs, (const aacg_dev_tns*)sl.d_tns,
-                    (float*)sl.d_scratch, (float*)sl.d_spec, cce_bufs{(const aacg_run*)sl.d_cce[0], (const aacg_couple_job*)sl.d_cce[1], (const float*)sl.d_cce[2], (float*)sl.d_cce[3]}, h, sl.d_coeffs,
+                    (float*)sl.d_scratch, (float*)sl.d_spec, cce_bufs{(const aacg_run*)sl.d_cce[0], (const aacg_couple_job*)sl.d_cce[1], (const float*)sl.d_cce[2], (float*)sl.d_cce[3]},
+                    run8_bufs{(const aacg_run8*)sl.d_run8[0], (unsigned long long*)sl.d_run8[1], (float*)sl.d_run8[2]}, h, sl.d_coeffs,
                     (const aacg_band_meta*)sl.d_meta, sl.d_pcm, 0, s);
     if (rc) return rc;
     HIP_TRY(e, hipEventRecord(sl.kernel_done, s), AACG_ERR_NO_DEVICE);

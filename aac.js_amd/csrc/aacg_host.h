@@ -18,6 +18,7 @@ struct aacg_host_windows {
 /* Fills *t for config.sampleIndex (decoder.js:63); hw (optional) receives the plain windows. */
 int aacg_build_tables(int sample_index, aacg_tables* t, aacg_host_windows* hw);
 int aacg_build_pns_tables(int sample_index, aacg_pns_tables* t);
+void aacg_build_win8(const aacg_tables* t, aacg_win8* w);
 /* SWB_OFFSET_1024/128[sample_index] (tables.js:34-155): writes count+1 offsets, returns count. */
 int aacg_swb_offsets(int sample_index, int is_long, int* dst);
 
@@ -37,6 +38,10 @@ struct aacg_plan_host {
     bool     any_pns = false;         /* some unit carries AACG_UNIT_HAS_PNS */
     bool     needs_scratch = false;   /* some later run holds 16 frames: its first wave parks the predecessor's tails */
     std::vector<aacg_run>   runs;     /* in launch (block) order, XCD-aware */
+    /* the same chains cut for the 8-waves-per-SIMD kernels (aacg_kernels8.h): 8 frames of a channel pair or 16 of a single
+     * channel per run, consecutive runs of a chain joined by a rendezvous cell instead of a recomputed frame */
+    std::vector<aacg_run8>  runs8;
+    uint32_t n_links = 0;
     /* AACG_CCE_SPEC: independently switched coupling elements run through the filterbank like any channel, but into a
      * side buffer (cce_runs: their own launch); coupling jobs by coupling point and by round (round r: the r-th coupling
      * element of its frame, so that no two jobs of a round add to the same channel) */

@@ -1440,6 +1440,10 @@ DP_DEVICE void filter_unit(const float* tab, const unit_view& u, int n_ch, bool 
 DP_DEVICE void overlap_add_in_place(float* prev, int n_ch, int cls0, int cls1, int lcol,
                               const float (&hx0)[8], const float (&hy0)[8], const float (&hx1)[8], const float (&hy1)[8])
 {
+    /* the overlap-add is an addition of two rounded floats (filter_bank.js:109-111 adds a stored product): never a
+     * multiply-add fused with the window product, whatever the compiler finds next to it — the fused and the staged
+     * coupling routes, the first and the later frames of a chain must produce the same bits */
+#pragma clang fp contract(off)
     const int lane = dp_lane(), w = lane >> 3, g = lane & 7;
     (void)lane;
     if (n_ch == 2 && cls0 == cls1) {
@@ -1534,6 +1538,9 @@ DP_DEVICE void epilogue(const aacg_kparams& P, const cpl_prefetch& pre, const fl
                         float* pcm_base_f32, const float (&hx0)[8], const float (&hy0)[8],
                         const float (&hx1)[8], const float (&hy1)[8], int lcol /* the lane's column in the long lane map: long_col(lane) or lane */)
 {
+    /* overlap + windowed first half: an addition of two rounded floats, never fused with the window product (see
+     * overlap_add_in_place); the coupling terms are explicit fused multiply-adds (dp_fma), which the pragma leaves alone */
+#pragma clang fp contract(off)
     /* a unit with coupling jobs: the paths that finish a sample in one place — in place in the previous wave's slot, or the
      * per-channel scalar path of a chain's first frame — so that the jobs are applied to finished samples, in order */
     const bool coupled = CPL && u.cpl_n > 0;

@@ -185,6 +185,11 @@ DP_DEVICE dpf4 dp_lds_read_f4(int a)                   /* ds_read_b128 on a comp
     const dp_lv4 v = *(__attribute__((address_space(3))) const dp_lv4*)(uintptr_t)(uint32_t)a;
     dpf4 r; r.x = v[0]; r.y = v[1]; r.z = v[2]; r.w = v[3]; return r;
 }
+/* 8-byte and 4-byte LDS accesses on computed byte addresses (the one-channel-per-wave kernels spell their addresses out as a
+ * lane-dependent base, an XOR with a constant and an immediate offset) */
+DP_DEVICE dpv2 dp_lds_read_v2(int a) { return *(__attribute__((address_space(3))) const dpv2*)(uintptr_t)(uint32_t)a; }
+DP_DEVICE void dp_lds_write_v2(int a, dpv2 v) { *(__attribute__((address_space(3))) dpv2*)(uintptr_t)(uint32_t)a = v; }
+DP_DEVICE void dp_lds_write_f32(int a, float v) { *(__attribute__((address_space(3))) float*)(uintptr_t)(uint32_t)a = v; }
 DP_DEVICE uint32_t dp_lds_read_u32(int a) { return *(__attribute__((address_space(3))) const uint32_t*)(uintptr_t)(uint32_t)a; }
 DP_DEVICE uint32_t dp_lds_read_u16(int a) { return *(__attribute__((address_space(3))) const uint16_t*)(uintptr_t)(uint32_t)a; }
 DP_DEVICE uint32_t dp_lds_read_u8(int a) { return *(__attribute__((address_space(3))) const uint8_t*)(uintptr_t)(uint32_t)a; }
@@ -200,6 +205,64 @@ DP_DEVICE int dp_pk_add_u16(int a, int b)
 DP_DEVICE float dp_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 DP_DEVICE double dp_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
 DP_DEVICE dpv2 dp_fma2(dpv2 a, dpv2 b, dpv2 c) { return __builtin_elementwise_fma(a, b, c); }
+/* ---- one complex value per register pair: (re, im) as a dpv2, every operation one v_pk_*_f32 (aacg_kernels8.h) ---- */
+DP_DEVICE dpv2 dp_cswap(dpv2 a) { return __builtin_shufflevector(a, a, 1, 0); }
+/* a + i b and a - i b: the swap is the instruction's op_sel, the signs a constant pair — one v_pk_fma_f32, exact in the
+ * product (x 1 / x -1), rounded once like the addition it stands for */
+DP_DEVICE dpv2 dp_cadd_i(dpv2 a, dpv2 b) { const dpv2 k = {-1.0f, 1.0f}; return __builtin_elementwise_fma(dp_cswap(b), k, a); }
+DP_DEVICE dpv2 dp_csub_i(dpv2 a, dpv2 b) { const dpv2 k = {1.0f, -1.0f}; return __builtin_elementwise_fma(dp_cswap(b), k, a); }
+/* a * w (complex): (a.re w.re, a.im w.re), then (-a.im w.im, a.re w.im) on top — two instructions; left to the compiler the
+ * (-w.im, w.im) pair was built with a v_xor + v_mov per multiply */
+DP_DEVICE dpv2 dp_cmul(dpv2 a, dpv2 w)
+{
+    dpv2 t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "v"(w));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]" : "=v"(r) : "v"(a), "v"(w), "v"(t));
+    return r;
+}
+
+/* wave -> wave hand-off by phase: wait until the flag has reached at least v (flags only ever grow within a launch) */
+DP_DEVICE void dp_flag_wait_ge(int* flag, int v)
+{
+    unsigned spins = 0;
+    while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < v) {
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins == (1u << 25)) __builtin_trap();
+    }
+}
+
+/* ---- workgroup -> workgroup through global memory (the run-to-run rendezvous of aacg_kernels8.h) ---------------------
+ * MI355X_MICROARCH.md, inter-workgroup visibility: payload as agent-scope (sc1, write-through) 8-byte stores, drained with
+ * s_waitcnt vmcnt(0) BEFORE the state word changes; the reader takes the state word with an agent-scope load and the
+ * payload with agent-scope (sc1) loads, which bypass its CU's L1.  No fences (an agent-scope release is a write-back of the
+ * whole L2), no assumption on dispatch order or on which XCD either side runs. */
+typedef unsigned long long dp_u64;
+DP_DEVICE dp_u64 dp_g_load_u64(const dp_u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+DP_DEVICE bool dp_g_cas_u64(dp_u64* p, dp_u64 expected, dp_u64 desired)
+{
+    return __hip_atomic_compare_exchange_strong(p, &expected, desired, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+DP_DEVICE void dp_g_store_f2(float* p, float a, float b)
+{
+    dpf2 v; v.x = a; v.y = b;
+    __hip_atomic_store((dp_u64*)p, __builtin_bit_cast(dp_u64, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+DP_DEVICE dpf2 dp_g_load_f2(const float* p)
+{
+    return __builtin_bit_cast(dpf2, __hip_atomic_load((const dp_u64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+DP_DEVICE float dp_g_load_f1(const float* p)
+{
+    return __builtin_bit_cast(float, __hip_atomic_load((const unsigned*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+DP_DEVICE void dp_vm_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+/* lane 0's value in every lane (a 64-bit scalar) */
+DP_DEVICE dp_u64 dp_first_u64(dp_u64 v)
+{
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+    return ((dp_u64)hi << 32) | lo;
+}
+
 /* true in every lane if the predicate holds in any lane of the wave */
 /* LDS bump allocation: returns the old value */
 DP_DEVICE int dp_lds_atomic_add(int* p, int v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }

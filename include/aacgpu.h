@@ -476,8 +476,11 @@ int aacg_debug_transform(int device_ordinal, int sample_index, int is_short, int
 /* Diagnostic: route choices a parity test wants to make by hand; 0 (the default) = the engine's own choice.  Nothing on the
  * decode path calls this.  AACG_DEBUG_ROUTE_UNFUSED_COUPLING: independent coupling (cce.js:121-128) as the separate pass over
  * the interleaved PCM (aacg_couple_pcm, what plans with double-duty runs take) even where the engine would apply it in the
- * targets' epilogues (aacg_imdct_run_*_cpl): the two routes must produce the same bits. */
+ * targets' epilogues (aacg_imdct_run_*_cpl): the two routes must produce the same bits.
+ * AACG_DEBUG_ROUTE_WIDE_KERNELS: plain batches on the 16-wave kernels (a channel pair per wave, aacg_kernels.h) instead of the
+ * one-channel-per-wave kernels (aacg_kernels8.h) the engine takes for them; set it before the plan is made. */
 #define AACG_DEBUG_ROUTE_UNFUSED_COUPLING 1
+#define AACG_DEBUG_ROUTE_WIDE_KERNELS     2
 int aacg_debug_set_route(aacg_engine* e, int flags);
 
 #ifdef __cplusplus

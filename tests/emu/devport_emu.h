@@ -100,6 +100,39 @@ DP_DEVICE void dp_shfl(double (&v)[N], int src)
     pthread_barrier_wait(&g_emu.w->bar);
 }
 
+/* one complex value per dpv2 (devport.h) */
+DP_DEVICE dpv2 dp_cswap(dpv2 a) { dpv2 r; r[0] = a[1]; r[1] = a[0]; return r; }
+DP_DEVICE dpv2 dp_cadd_i(dpv2 a, dpv2 b) { dpv2 r; r[0] = a[0] - b[1]; r[1] = a[1] + b[0]; return r; }
+DP_DEVICE dpv2 dp_csub_i(dpv2 a, dpv2 b) { dpv2 r; r[0] = a[0] + b[1]; r[1] = a[1] - b[0]; return r; }
+DP_DEVICE dpv2 dp_cmul(dpv2 a, dpv2 w)
+{
+    dpv2 r;
+    r[0] = fmaf(-a[1], w[1], a[0] * w[0]);
+    r[1] = fmaf(a[0], w[1], a[1] * w[0]);
+    return r;
+}
+DP_DEVICE void dp_flag_wait_ge(int* flag, int v) { while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) < v) sched_yield(); }
+/* the run-to-run rendezvous through global memory (devport.h): plain host memory here */
+typedef unsigned long long dp_u64;
+DP_DEVICE dp_u64 dp_g_load_u64(const dp_u64* p) { return __atomic_load_n(p, __ATOMIC_ACQUIRE); }
+DP_DEVICE bool dp_g_cas_u64(dp_u64* p, dp_u64 expected, dp_u64 desired)
+{
+    return __atomic_compare_exchange_n(p, &expected, desired, false, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE);
+}
+DP_DEVICE void dp_g_store_f2(float* p, float a, float b) { p[0] = a; p[1] = b; }
+DP_DEVICE dpf2 dp_g_load_f2(const float* p) { dpf2 v; v.x = p[0]; v.y = p[1]; return v; }
+DP_DEVICE float dp_g_load_f1(const float* p) { return *p; }
+DP_DEVICE void dp_vm_drain() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
+/* lane 0's value in every lane */
+DP_DEVICE dp_u64 dp_first_u64(dp_u64 v)
+{
+    if (g_emu.lane == 0) memcpy(&g_emu.w->shfl_d[0][0], &v, 8);
+    pthread_barrier_wait(&g_emu.w->bar);
+    dp_u64 r; memcpy(&r, &g_emu.w->shfl_d[0][0], 8);
+    pthread_barrier_wait(&g_emu.w->bar);
+    return r;
+}
+
 DP_DEVICE int dp_lds_atomic_add(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 
 DP_DEVICE bool dp_any(bool p)
@@ -126,6 +159,9 @@ DP_DEVICE float dp_lds_read_f32(int a)
     if (a < 0 || (size_t)a + 4 > g_emu.b->lds_bytes) return 0.0f;
     float v; memcpy(&v, g_emu.b->lds + a, 4); return v;
 }
+DP_DEVICE dpv2 dp_lds_read_v2(int a) { dpv2 v; memcpy(&v, g_emu.b->lds + a, 8); return v; }
+DP_DEVICE void dp_lds_write_v2(int a, dpv2 v) { memcpy(g_emu.b->lds + a, &v, 8); }
+DP_DEVICE void dp_lds_write_f32(int a, float v) { memcpy(g_emu.b->lds + a, &v, 4); }
 DP_DEVICE dpf4 dp_lds_read_f4(int a) { dpf4 v; memcpy(&v, g_emu.b->lds + a, 16); return v; }
 DP_DEVICE uint32_t dp_lds_read_u32(int a) { uint32_t v; memcpy(&v, g_emu.b->lds + a, 4); return v; }
 DP_DEVICE uint32_t dp_lds_read_u16(int a) { uint16_t v; memcpy(&v, g_emu.b->lds + a, 2); return v; }

@@ -4,11 +4,13 @@
  */
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <string>
 #include <algorithm>
 #include <vector>
 
 #include "../../aac.js_amd/csrc/aacg_kernels.h"
+#include "../../aac.js_amd/csrc/aacg_kernels8.h"
 #include "../../aac.js_amd/csrc/aacg_parse.h"
 #include "../../aac.js_amd/csrc/aacg_host.h"
 
@@ -24,6 +26,7 @@ struct launch_arg {
     const aacg_parse_params* PP;
     int out_kind;
     const aacg_couple_params* Q;
+    const aacg_kparams8* P8;
 };
 
 void* lane_main(void* p)
@@ -32,6 +35,8 @@ void* lane_main(void* p)
     g_emu = a->ctx;
     /* the same dispatch as the engine's launch_run: double-duty variant / plain; kinds 3, 4: the optional-stage kernel */
     if (a->kind == 7) { aacg_parse::parse_body(*a->PP); return nullptr; }
+    if (a->kind == 12) { imdct_run8_body<AACG_INPUT_SPEC_F32>(*a->P8); return nullptr; }      /* aacg_imdct_run8_f32 */
+    if (a->kind == 13) { imdct_run8_body<AACG_INPUT_QUANT_I16>(*a->P8); return nullptr; }     /* aacg_imdct_run8_quant */
     if (a->kind == 8) { couple_spec_body(*a->Q, 4); return nullptr; }
     if (a->kind == 9) { couple_pcm_body(*a->Q, 4); return nullptr; }
     if (a->kind == 10) { imdct_run_body<AACG_INPUT_SPEC_F32, AACG_OUTPUT_F32, false, false, true>(*a->P); return nullptr; }   /* aacg_imdct_run_f32_cpl */
@@ -51,10 +56,11 @@ void* lane_main(void* p)
 
 int g_out_kind = AACG_OUTPUT_F32;          /* emu_set_output_kind: the next decodes store int16 PCM */
 int g_unfused = 0;                         /* emu_set_unfused: independent coupling as the separate pass over the PCM even where the engine fuses it */
+int g_run8 = 1;                            /* emu_set_run8: plain batches on the one-channel-per-wave kernels, as the engine routes them */
 int g_staged = 0;                          /* emu_set_staged: optional stages as a launch of their own even where the engine would not */
 
 void launch(const aacg_kparams& P, int kind, int grid, int waves, size_t lds_bytes, int n_units = 0, const aacg_parse_params* PP = nullptr,
-            const aacg_couple_params* Q = nullptr)
+            const aacg_couple_params* Q = nullptr, const aacg_kparams8* P8 = nullptr)
 {
     const int threads = waves * 64;
     std::vector<emu_wave> wv((size_t)waves);
@@ -80,6 +86,7 @@ void launch(const aacg_kparams& P, int kind, int grid, int waves, size_t lds_byt
             args[(size_t)t].PP = PP;
             args[(size_t)t].out_kind = g_out_kind;
             args[(size_t)t].Q = Q;
+            args[(size_t)t].P8 = P8;
             pthread_create(&tid[(size_t)t], &attr, lane_main, &args[(size_t)t]);
         }
         for (int t = 0; t < threads; t++) pthread_join(tid[(size_t)t], nullptr);
@@ -100,6 +107,7 @@ extern "C" {
 
 const char* emu_last_error() { return g_err.c_str(); }
 void emu_set_staged(int on) { g_staged = on; }
+void emu_set_run8(int on) { g_run8 = on; }
 void emu_set_unfused(int on) { g_unfused = on; }
 void emu_set_output_kind(int kind) { g_out_kind = kind; }       /* AACG_OUTPUT_*: the pcm buffer of later decodes is int16 */
 
@@ -132,6 +140,18 @@ int emu_plan(const aacg_unit_desc* units, uint32_t n_units, int sample_index, in
     if (runs_out) for (size_t i = 0; i < ph.runs.size() && i < runs_cap; i++) runs_out[i] = ph.runs[i];
     if (info) { info[0] = ph.zero_fill; info[1] = (int32_t)ph.chains.size(); info[2] = (int32_t)ph.coef_blocks; info[3] = (int32_t)ph.meta_blocks; }
     return (int)ph.runs.size();
+}
+
+/* the planner's run table for the one-channel-per-wave kernels: returns the number of runs (or < 0), *n_links = rendezvous cells */
+int emu_plan8(const aacg_unit_desc* units, uint32_t n_units, int sample_index, int max_streams, int max_channels,
+              aacg_run8* runs_out, uint32_t runs_cap, int32_t* n_links)
+{
+    aacg_plan_host ph;
+    int rc = aacg_plan_build(units, n_units, sample_index, max_streams, max_channels, nullptr, &ph, &g_err);
+    if (rc) return rc;
+    for (size_t i = 0; i < ph.runs8.size() && i < runs_cap; i++) runs_out[i] = ph.runs8[i];
+    if (n_links) *n_links = (int32_t)ph.n_links;
+    return (int)ph.runs8.size();
 }
 
 /* host planner only: a plan for `first`, then aacg_plan_refresh_host with `next` (tns_spec: the engine's TNS mode) */
@@ -268,7 +288,24 @@ int emu_decode_cce(int input_kind, int sample_index, int max_streams, int max_ch
     } else if (!ph.runs.empty() && ex)
         launch(P, input_kind == AACG_INPUT_QUANT_I16 ? 6 : 5, (int)ph.runs.size(), AACG_WG_WAVES,
                input_kind == AACG_INPUT_QUANT_I16 ? AACG_LDS_BYTES_QUANT_EX : AACG_LDS_BYTES_F32_EX);
-    else if (!ph.runs.empty())
+    else if (!ph.runs.empty() && g_run8 && g_out_kind == AACG_OUTPUT_F32 && !ph.any_cce && !ph.any_tns && !ph.any_pns) {
+        /* the engine's route for plain batches: the one-channel-per-wave kernels (aacg_kernels8.h); the workgroups run one after
+         * the other here, in block order or — g_run8 == 2 — in reverse, so that both sides of every rendezvous arrive first once */
+        static aacg_win8 win8;
+        static unsigned long long epoch = 0;
+        aacg_build_win8(&g_tab, &win8);
+        std::vector<unsigned long long> rv_state((size_t)ph.n_links * AACG8_RV_STATE_WORDS + 1, 0x5a5a5a5a5a5a5a5aull);
+        std::vector<float> rv_data((size_t)ph.n_links * AACG8_RV_DATA_FLOATS + 1, std::numeric_limits<float>::quiet_NaN());
+        std::vector<aacg_run8> runs8 = ph.runs8;
+        if (g_run8 == 2) std::reverse(runs8.begin(), runs8.end());
+        aacg_kparams8 P8;
+        std::memset(&P8, 0, sizeof P8);
+        P8.units = ph.units.data(); P8.runs = runs8.data(); P8.coeffs = P.coeffs; P8.meta = P.meta; P8.pcm = pcm; P8.overlap = overlap_pool;
+        P8.tab = &g_tab; P8.win = &win8; P8.rv_state = rv_state.data(); P8.rv_data = rv_data.data(); P8.epoch = ++epoch; P8.flip = 0;
+        P8.n_runs = (int32_t)runs8.size();
+        launch(P, input_kind == AACG_INPUT_QUANT_I16 ? 13 : 12, (int)runs8.size(), AACG_WG_WAVES,
+               input_kind == AACG_INPUT_QUANT_I16 ? AACG8_LDS_BYTES(AACG8_TAB_QUANT_FLOATS) : AACG8_LDS_BYTES(AACG8_TAB_F32_FLOATS), 0, nullptr, nullptr, &P8);
+    } else if (!ph.runs.empty())
         launch(P, input_kind == AACG_INPUT_QUANT_I16 ? 1 : 0, (int)ph.runs.size(), AACG_WG_WAVES,
                input_kind == AACG_INPUT_QUANT_I16 ? AACG_LDS_BYTES_QUANT : AACG_LDS_BYTES_F32);
     if (ph.any_cce && !fused) {

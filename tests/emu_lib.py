@@ -13,6 +13,10 @@ RUN_DTYPE = np.dtype([("pred_unit", "<i4"), ("n_units", "<i4"), ("unit", "<i4", 
                       ("ov_a", "<i4", (2,)), ("ov_b", "<i4", (2,)), ("is_last", "<i4"), ("reserved", "<i4")])
 
 
+RUN8_DTYPE = np.dtype([("n_units", "<i4"), ("n_ch", "<i4"), ("unit", "<i4", (16,)), ("ov_a", "<i4", (2,)), ("ov_b", "<i4", (2,)),
+                       ("link_in", "<i4"), ("link_out", "<i4"), ("succ_unit", "<i4"), ("reserved", "<i4", (5,))])
+
+
 class Emu:
     def __init__(self, target="libaacg_emu.so"):
         subprocess.run(["make", "-C", os.path.join(HERE, "emu"), target], check=True, stdout=subprocess.DEVNULL)
@@ -29,13 +33,14 @@ class Emu:
         L.emu_spectral.argtypes = [C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         L.emu_plan.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
         L.emu_plan_refresh.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.emu_plan8.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_uint32, C.c_void_p]
         L.emu_get_windows.argtypes = [C.c_int, C.c_void_p]
         L.emu_get_iq_sf.argtypes = [C.c_void_p, C.c_void_p]
 
     def error(self):
         return self.lib.emu_last_error().decode()
 
-    def decode(self, units, coeffs, meta, n_pcm, pool, parity, sample_index=3, tns=None, pns=False, int16_out=False, cce=None, staged=False, unfused=False):
+    def decode(self, units, coeffs, meta, n_pcm, pool, parity, sample_index=3, tns=None, pns=False, int16_out=False, cce=None, staged=False, unfused=False, run8=1):
         """staged: the optional stages (TNS, PNS) as a launch of their own even where the engine would run them inside the run kernel.
         unfused: independent coupling as the separate pass over the PCM (what plans with double-duty runs take) even where the
         engine applies it in the targets' epilogues."""
@@ -48,6 +53,7 @@ class Emu:
         self.lib.emu_set_output_kind(1 if int16_out else 0)
         self.lib.emu_set_staged(1 if staged else 0)
         self.lib.emu_set_unfused(1 if unfused else 0)
+        self.lib.emu_set_run8(run8)       # 1: plain batches on the one-channel-per-wave kernels (the engine's route); 2: their workgroups in reverse order; 0: the 16-wave kernels
         cce = np.ascontiguousarray(cce) if cce is not None else None
         rc = self.lib.emu_decode_cce(kind, sample_index, pool.shape[0], pool.shape[1], units.ctypes.data, len(units),
                                      coeffs.ctypes.data, meta.ctypes.data if meta is not None else None,
@@ -57,6 +63,7 @@ class Emu:
         self.lib.emu_set_output_kind(0)
         self.lib.emu_set_staged(0)
         self.lib.emu_set_unfused(0)
+        self.lib.emu_set_run8(1)
         if rc:
             raise RuntimeError("emu_decode rc=%d: %s" % (rc, self.error()))
         return pcm
@@ -75,6 +82,16 @@ class Emu:
         first, nxt = np.ascontiguousarray(first), np.ascontiguousarray(nxt)
         assert len(first) == len(nxt)
         return self.lib.emu_plan_refresh(first.ctypes.data, nxt.ctypes.data, len(first), sample_index, max_streams, max_channels, 1 if tns_spec else 0)
+
+    def plan8(self, units, max_streams, max_channels, sample_index=3):
+        """The planner's run table for the one-channel-per-wave kernels: (runs as RUN8_DTYPE, number of rendezvous cells)."""
+        units = np.ascontiguousarray(units)
+        runs = np.zeros(2 * len(units) + 8, RUN8_DTYPE)
+        links = C.c_int32(0)
+        n = self.lib.emu_plan8(units.ctypes.data, len(units), sample_index, max_streams, max_channels, runs.ctypes.data, len(runs), C.byref(links))
+        if n < 0:
+            raise RuntimeError("emu_plan8 rc=%d: %s" % (n, self.error()))
+        return runs[:n], links.value
 
     def plan(self, units, max_streams, max_channels, parity=None, sample_index=3):
         units = np.ascontiguousarray(units)

@@ -177,7 +177,7 @@ def test_planner_refuses_coupling_elements_without_the_mode(oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("layout,points,T", [(("cpe", "cpe", "cpe", "sce"), (2, 2), 15), (("cpe", "cpe", "cpe", "sce"), (2,), 20), (("cpe",), (2,), 31),
+@pytest.mark.parametrize("layout,points,T", [(("sce", "cpe", "cpe", "sce"), (2, 2), 15), (("cpe", "cpe", "cpe", "sce"), (2,), 20), (("cpe",), (2,), 31),
                                              (("sce", "cpe"), (2, 0, 2), 9)])
 def test_gpu_fused_and_separate_independent_coupling_agree(oracle, layout, points, T):
     """on the GPU, the fused route (coupling applied in the targets' epilogues, aacg_imdct_run_quant_cpl)
