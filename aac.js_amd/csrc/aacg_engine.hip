@@ -59,7 +59,9 @@ struct aacg_engine {
     aacg_tables* d_tab = nullptr;
     aacg_pns_tables* d_pns = nullptr;       /* AACG_PNS_SPEC */
     aacg_win8* d_win8 = nullptr;            /* the windows as the 8-wave kernels read them */
-    bool run8 = true;                       /* plain batches (f32 PCM, no optional stage) on the one-channel-per-wave kernels */
+    bool run8 = false;                      /* plain batches (f32 PCM, no optional stage) on the one-channel-per-wave kernels: opt-in
+                                               (AACG_RUN8=1 / AACG_DEBUG_ROUTE_NARROW_KERNELS) — built to parity and measured slower than the
+                                               16-wave kernels on every BASELINE configuration */
     unsigned long long rv_epoch = 0;        /* rendezvous epoch: one per launch of those kernels, never 0 */
     float* d_overlap = nullptr;             /* [max_streams][max_channels][2][1024] */
     std::vector<uint8_t> parity;            /* live buffer per (stream, channel) */
@@ -198,7 +200,8 @@ bool needs_spec_buffer(const aacg_engine* e, const aacg_plan_host& h)
 bool takes_run8(const aacg_engine* e, const aacg_plan_host& h)
 {
     const bool quant = e->cfg.input_kind == AACG_INPUT_QUANT_I16;
-    return e->run8 && !(e->debug_route & AACG_DEBUG_ROUTE_WIDE_KERNELS) && e->cfg.output_kind == AACG_OUTPUT_F32 &&
+    const bool on = (e->run8 || (e->debug_route & AACG_DEBUG_ROUTE_NARROW_KERNELS)) && !(e->debug_route & AACG_DEBUG_ROUTE_WIDE_KERNELS);
+    return on && e->cfg.output_kind == AACG_OUTPUT_F32 &&
            !h.any_cce && !h.any_tns && !(quant && h.any_pns) && !h.runs8.empty();
 }
 
@@ -348,7 +351,7 @@ const char* aacg_kernel_name(void) { return "aacg_imdct_run_quant"; }
 
 int aacg_debug_set_route(aacg_engine* e, int flags)
 {
-    if (!e || (flags & ~(AACG_DEBUG_ROUTE_UNFUSED_COUPLING | AACG_DEBUG_ROUTE_WIDE_KERNELS))) return AACG_ERR_INVALID_ARG;
+    if (!e || (flags & ~(AACG_DEBUG_ROUTE_UNFUSED_COUPLING | AACG_DEBUG_ROUTE_WIDE_KERNELS | AACG_DEBUG_ROUTE_NARROW_KERNELS))) return AACG_ERR_INVALID_ARG;
     e->debug_route = flags;
     return AACG_OK;
 }
@@ -410,7 +413,7 @@ int aacg_create(const aacg_config* cfg, aacg_engine** out)
                         hip_ok(e, hipMemcpy(e->d_win8, w8, sizeof *w8, hipMemcpyHostToDevice), "upload window tables");
         delete w8;
         if (!ok) { aacg_destroy(e); return AACG_ERR_OUT_OF_MEMORY; }
-        if (const char* r = std::getenv("AACG_RUN8")) e->run8 = std::atoi(r) != 0;    /* A/B switch for tools/: 0 = the 16-wave kernels for everything */
+        if (const char* r = std::getenv("AACG_RUN8")) e->run8 = std::atoi(r) != 0;    /* A/B switch for tools/: 1 = plain batches on the one-channel-per-wave kernels */
     }
     if (cfg->pns_mode == AACG_PNS_SPEC) {
         aacg_pns_tables* pt = new (std::nothrow) aacg_pns_tables;

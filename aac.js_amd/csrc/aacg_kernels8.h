@@ -42,7 +42,7 @@
 #endif
 
 #ifndef AACG8_EARLY_WAVES
-#define AACG8_EARLY_WAVES 4
+#define AACG8_EARLY_WAVES 2
 #endif
 #define K8_PHASE_STAGED 1
 #define K8_PHASE_DUMPED 2
@@ -343,17 +343,28 @@ DP_DEVICE k8_pair_addr k8_tail_addr(int base, int h, int lane)
  * (ONLY_LONG / LONG_START / LONG_STOP: the shapes are tables), a frame of two interleaved channels.  Wave h finishes samples
  * 512 h + 2 k, + 1 for k = lane + 64 j: per j four (L, R) pairs from LDS (the two slots of a channel pair are 4 KB apart: one
  * two-address read each), two 8-byte window reads, six packed operations, one 16-byte (L[n], R[n], L[n+1], R[n+1]) store. */
-DP_DEVICE void k8_finish_stereo_long(const aacg_win8* W, const k8_src& T, const k8_src& H, float* pcm, int h)
+struct k8_wins { dpf2 wh[4], wt[4]; };
+/* the fast path's window values, requested BEFORE the wave waits for the previous frame (they depend on window fields only:
+ * inside the pass the loads were a memory round trip on every wave's critical path) */
+DP_DEVICE void k8_stereo_windows(const aacg_win8* W, const k8_src& T, const k8_src& H, int h, k8_wins& w)
+{
+    const int lane = dp_lane();
+    const int hv = 2 * (H.ch[0].seq == AACG_LONG_STOP_SEQUENCE ? 1 : 0) + H.ch[0].shape_prev;
+    const int tv = 2 * (T.ch[0].seq == AACG_LONG_START_SEQUENCE ? 1 : 0) + T.ch[0].shape;
+    const float* whp = W->head[hv] + 512 * h + 2 * lane;
+    const float* wtp = W->tail[tv] + 512 * h + 2 * lane;
+#pragma unroll
+    for (int j = 0; j < 4; j++) { w.wh[j] = *(const dpf2*)(whp + 128 * j); w.wt[j] = *(const dpf2*)(wtp + 128 * j); }
+}
+DP_DEVICE void k8_finish_stereo_long(const k8_wins& w, const k8_src& T, const k8_src& H, float* pcm, int h)
 {
 #pragma clang fp contract(off)
     const int lane = dp_lane();
     const int hv = 2 * (H.ch[0].seq == AACG_LONG_STOP_SEQUENCE ? 1 : 0) + H.ch[0].shape_prev;
     const int tv = 2 * (T.ch[0].seq == AACG_LONG_START_SEQUENCE ? 1 : 0) + T.ch[0].shape;
-    const bool from_lds = T.glob[0] == nullptr;
-    const bool guard = hv >= 2 || (from_lds && tv >= 2);       /* START / STOP shapes: regions the window takes nothing from */
-    const float* whp = W->head[hv] + 512 * h + 2 * lane;
-    const float* wtp = W->tail[tv] + 512 * h + 2 * lane;
-    const k8_pair_addr ca = k8_head_addr(dp_lds_addr(H.lds[0]), h, lane);
+    const bool from_lds = T.glob[0] == nullptr, head_lds = H.glob[0] == nullptr;
+    const bool guard = (head_lds && hv >= 2) || (from_lds && tv >= 2);       /* START / STOP shapes: regions the window takes nothing from */
+    const k8_pair_addr ca = k8_head_addr(head_lds ? dp_lds_addr(H.lds[0]) : 0, h, lane);
     const k8_pair_addr pa = k8_tail_addr(from_lds ? dp_lds_addr(T.lds[0]) : 0, h, lane);
     /* the signs of the second half's two elements: (+, -) for h = 0, (-, +) for h = 1 */
     const unsigned s_first = h ? 0x80000000u : 0u, s_second = h ? 0u : 0x80000000u;
@@ -361,15 +372,23 @@ DP_DEVICE void k8_finish_stereo_long(const aacg_win8* W, const k8_src& T, const 
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         dpv2 h0, h1, t0, t1;                           /* (left, right) */
-        h0[0] = dp_lds_read_f32(ca.first + 256 * j);  h0[1] = dp_lds_read_f32(ca.first + 256 * j + 4096);
-        h1[0] = dp_lds_read_f32(ca.second - 256 * j); h1[1] = dp_lds_read_f32(ca.second - 256 * j + 4096);
-        const dpf2 wh = *(const dpf2*)(whp + 128 * j);
-        h0 = h0 * k8_v2(wh.x, wh.x);
-        h1 = h1 * k8_v2(-wh.y, -wh.y);
+        dpf2 wh = w.wh[j];
+        if (head_lds) {
+            h0[0] = dp_lds_read_f32(ca.first + 256 * j);  h0[1] = dp_lds_read_f32(ca.first + 256 * j + 4096);
+            h1[0] = dp_lds_read_f32(ca.second - 256 * j); h1[1] = dp_lds_read_f32(ca.second - 256 * j + 4096);
+            h0 = h0 * k8_v2(wh.x, wh.x);
+            h1 = h1 * k8_v2(-wh.y, -wh.y);
+        } else {
+            /* the next run's first frame, whose windowed first half that run left behind (rendezvous payload) */
+            const int n = 512 * h + 2 * lane + 128 * j;
+            const dpf2 hl = dp_g_load_f2(H.glob[0] + n), hr = dp_g_load_f2(H.glob[1] + n);
+            h0 = k8_v2(hl.x, hr.x); h1 = k8_v2(hl.y, hr.y);
+            wh.x = wh.y = 1.0f;
+        }
         if (from_lds) {
             t0[0] = dp_lds_read_f32(pa.first + 256 * j);  t0[1] = dp_lds_read_f32(pa.first + 256 * j + 4096);
             t1[0] = dp_lds_read_f32(pa.second - 256 * j); t1[1] = dp_lds_read_f32(pa.second - 256 * j + 4096);
-            const dpf2 wt = *(const dpf2*)(wtp + 128 * j);
+            const dpf2 wt = w.wt[j];
             const float wx = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, wt.x) ^ s_first);
             const float wy = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, wt.y) ^ s_second);
             t0 = t0 * k8_v2(wx, wx);
@@ -407,20 +426,27 @@ DP_DEVICE void k8_export_long(const aacg_win8* W, const float* slot, const k8_ch
     const float* wp = (TAIL ? W->tail[v] : W->head[v]) + 512 * h + 2 * lane;
     const k8_pair_addr a = TAIL ? k8_tail_addr(dp_lds_addr(slot), h, lane) : k8_head_addr(dp_lds_addr(slot), h, lane);
     const unsigned s_first = (TAIL && h) ? 0x80000000u : 0u, s_second = (TAIL && h) ? 0u : 0x80000000u;
+    /* all window reads first: one memory round trip, not one per store */
+    dpf2 w[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) w[j] = *(const dpf2*)(wp + 128 * j);
+    float x0[4], x1[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const float y0 = dp_lds_read_f32(a.first + 256 * j), y1 = dp_lds_read_f32(a.second - 256 * j);
-        const dpf2 w = *(const dpf2*)(wp + 128 * j);
-        float x0 = y0 * __builtin_bit_cast(float, __builtin_bit_cast(unsigned, w.x) ^ s_first);
-        float x1 = y1 * __builtin_bit_cast(float, __builtin_bit_cast(unsigned, w.y) ^ s_second);
-        if (v >= 2) {
-            dp_keep_branch();
-            if (w.x == 0.0f) x0 = 0.0f;
-            if (w.y == 0.0f) x1 = 0.0f;
-        }
+        x0[j] = y0 * __builtin_bit_cast(float, __builtin_bit_cast(unsigned, w[j].x) ^ s_first);
+        x1[j] = y1 * __builtin_bit_cast(float, __builtin_bit_cast(unsigned, w[j].y) ^ s_second);
+    }
+    if (v >= 2) {
+        dp_keep_branch();
+#pragma unroll
+        for (int j = 0; j < 4; j++) { if (w[j].x == 0.0f) x0[j] = 0.0f; if (w[j].y == 0.0f) x1[j] = 0.0f; }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
         float* d = dst + 512 * h + 2 * lane + 128 * j;
-        if (PUBLISH) dp_g_store_f2(d, x0, x1);
-        else { dpf2 o; o.x = x0; o.y = x1; *(dpf2*)d = o; }
+        if (PUBLISH) dp_g_store_f2(d, x0[j], x1[j]);
+        else { dpf2 o; o.x = x0[j]; o.y = x1[j]; *(dpf2*)d = o; }
     }
 }
 
@@ -616,6 +642,10 @@ DP_DEVICE void imdct_run8_body(const aacg_kparams8& P)
     const int ui = dp_uniform(active ? run->unit[f] : run->unit[0]);
     const unit_view u = load_unit(P.units + ui);
     const int last = n_units - 1;
+    /* window fields of the frame before this one (two scalar dwords of its unit record), requested now: behind the transform
+     * they were a memory round trip in front of the window loads */
+    const uint32_t* pw = (const uint32_t*)(P.units + dp_uniform(active && f > 0 ? run->unit[f - 1] : run->unit[0]));
+    const uint32_t pw0 = pw[6], pw1 = pw[10];
     /* earlier frames first; the frame another workgroup waits for (a run's last, when the chain goes on) ahead of them */
     const bool hands_over = active && f == last && run->link_out >= 0;
     dp_setprio(hands_over ? 3 : 3 - (two ? f >> 1 : f >> 2));
@@ -647,7 +677,7 @@ DP_DEVICE void imdct_run8_body(const aacg_kparams8& P)
     /* load staggering as in the 16-wave kernels: the run's first frames request their spectra ahead of the table barrier (which
      * is then only released once that data has landed), the others behind it — the first frames see their data after one
      * round trip instead of queueing behind the whole chip's requests */
-    const bool early = wave < AACG8_EARLY_WAVES;
+    const bool early = wave < AACG8_EARLY_WAVES || hands_over;     /* (the frame another workgroup may be waiting for: no later than the first) */
     if (early) issue_loads();
     if (tid < n4) ((dpf4*)tabw)[tid] = tr;
     if (lane == 0) flags[wave] = 0;
@@ -753,8 +783,14 @@ DP_DEVICE void imdct_run8_body(const aacg_kparams8& P)
             hs.lds[0] = hs.lds[1] = nullptr; hs.glob[0] = data + 2048; hs.glob[1] = data + 2048 + 1024;
             hs.ch[0] = cur.ch[0]; hs.ch[1] = cur.ch[1];
             float* spcm = P.pcm + su.pcm_offset + su.channel;
-            if (two) k8_finish_general<2, 8>(W, cur, hs, spcm, su.n_out_ch, n0);
-            else     k8_finish_general<1, 16>(W, cur, hs, spcm, su.n_out_ch, n0);
+            const bool sfast = two && su.n_out_ch == 2 && ((su.pcm_offset | (uint32_t)su.channel) & 3u) == 0 &&
+                               cur.ch[0].seq != AACG_EIGHT_SHORT_SEQUENCE && cur.ch[0].seq == cur.ch[1].seq && cur.ch[0].shape == cur.ch[1].shape;
+            if (sfast) {
+                k8_wins wins;
+                k8_stereo_windows(W, cur, hs, c, wins);          /* (only the tail windows are used) */
+                k8_finish_stereo_long(wins, cur, hs, spcm, c);
+            } else if (two) { dp_keep_branch(); k8_finish_general<2, 8>(W, cur, hs, spcm, su.n_out_ch, n0); }
+            else            { dp_keep_branch(); k8_finish_general<1, 16>(W, cur, hs, spcm, su.n_out_ch, n0); }
         }
     }
     /* the chain's last frame in this launch: its windowed tail is the new overlap state (planar in HBM) */
@@ -771,19 +807,38 @@ DP_DEVICE void imdct_run8_body(const aacg_kparams8& P)
     prev.glob[0] = prev.glob[1] = nullptr;
     prev.lds[0] = slot_l - (two ? 2 : 1) * AACG8_SLOT_FLOATS; prev.lds[1] = slot_r - 2 * AACG8_SLOT_FLOATS;
     prev.ch[0] = cur.ch[0]; prev.ch[1] = cur.ch[1];
+    const bool from_state = f == 0 && run->link_in < 0, from_link = f == 0 && run->link_in >= 0;
     if (f > 0) {
-        /* window fields of the previous frame (two scalar dwords of its unit record) */
-        const uint32_t* pw = (const uint32_t*)(P.units + dp_uniform(run->unit[f - 1]));
 #pragma unroll
-        for (int k = 0; k < 2; k++) { const uint32_t ci = pw[6 + 4 * k]; prev.ch[k].seq = (int)(ci & 0xffu); prev.ch[k].shape = (int)((ci >> 8) & 0xffu); prev.ch[k].shape_prev = (int)((ci >> 16) & 0xffu); }
+        for (int k = 0; k < 2; k++) { const uint32_t ci = k ? pw1 : pw0; prev.ch[k].seq = (int)(ci & 0xffu); prev.ch[k].shape = (int)((ci >> 8) & 0xffu); prev.ch[k].shape_prev = (int)((ci >> 16) & 0xffu); }
+    }
+    /* which pass finishes the frame is known from window fields alone: decide, and request the fast pass's windows, before waiting */
+    const bool long_l = cur.ch[0].seq != AACG_EIGHT_SHORT_SEQUENCE && (f == 0 || prev.ch[0].seq != AACG_EIGHT_SHORT_SEQUENCE);
+    const bool long_r = cur.ch[1].seq != AACG_EIGHT_SHORT_SEQUENCE && (f == 0 || prev.ch[1].seq != AACG_EIGHT_SHORT_SEQUENCE);
+    /* the same window tables for both channels (a common window, or equal by value) */
+    const bool same_tables = cur.ch[0].seq == cur.ch[1].seq && cur.ch[0].shape_prev == cur.ch[1].shape_prev &&
+                             (f == 0 || (prev.ch[0].seq == prev.ch[1].seq && prev.ch[0].shape == prev.ch[1].shape));
+    const bool fast = two && C == 2 && long_l && long_r && same_tables && ((u.pcm_offset | (uint32_t)u.channel) & 3u) == 0;
+    if (fast && f > 0) {
+        /* the common case, kept apart from the rest so that its window registers live nowhere else */
+        k8_wins wins;
+        k8_stereo_windows(W, prev, cur, c, wins);
+        dp_flag_wait_ge(&flags[wave - 2], K8_PHASE_DUMPED);
+        dp_flag_wait_ge(&flags[(wave ^ 1) - 2], K8_PHASE_DUMPED);
+        K8_TRACE(4);
+        k8_finish_stereo_long(wins, prev, cur, pcm, c);
+        K8_TRACE(5);
+        return;
+    }
+    if (f > 0) {
         dp_flag_wait_ge(&flags[wave - (two ? 2 : 1)], K8_PHASE_DUMPED);
         if (two) dp_flag_wait_ge(&flags[(wave ^ 1) - 2], K8_PHASE_DUMPED);
-    } else if (run->link_in < 0) {
+    } else if (from_state) {
         /* first frame of its chain in this launch: the overlap state (filter_bank.js:38-41) */
         prev.lds[0] = prev.lds[1] = nullptr;
         prev.glob[0] = P.overlap + (P.flip ? run->ov_b[0] : run->ov_a[0]);
         prev.glob[1] = P.overlap + (P.flip ? run->ov_b[1] : run->ov_a[1]);
-    } else {
+    } else if (from_link) {
         /* first frame of a later run: the tail the run before it published — or, if that is not there yet, leave the windowed
          * first half for it and go */
         dp_keep_branch();
@@ -804,13 +859,11 @@ DP_DEVICE void imdct_run8_body(const aacg_kparams8& P)
         prev.glob[0] = data; prev.glob[1] = data + 1024;
     }
     K8_TRACE(4);
-    const bool long_l = cur.ch[0].seq != AACG_EIGHT_SHORT_SEQUENCE && (prev.glob[0] || prev.ch[0].seq != AACG_EIGHT_SHORT_SEQUENCE);
-    const bool long_r = cur.ch[1].seq != AACG_EIGHT_SHORT_SEQUENCE && (prev.glob[1] || prev.ch[1].seq != AACG_EIGHT_SHORT_SEQUENCE);
-    /* the same window tables for both channels (a common window, or equal by value) */
-    const bool same_tables = cur.ch[0].seq == cur.ch[1].seq && cur.ch[0].shape_prev == cur.ch[1].shape_prev &&
-                             (prev.glob[0] || (prev.ch[0].seq == prev.ch[1].seq && prev.ch[0].shape == prev.ch[1].shape));
-    if (two && C == 2 && long_l && long_r && same_tables && ((u.pcm_offset | (uint32_t)u.channel) & 3u) == 0) {
-        k8_finish_stereo_long(W, prev, cur, pcm, c);
+    if (fast) {
+        dp_keep_branch();
+        k8_wins wins;
+        k8_stereo_windows(W, prev, cur, c, wins);
+        k8_finish_stereo_long(wins, prev, cur, pcm, c);
     } else if (two) {
         dp_keep_branch();
         k8_finish_general<2, 8>(W, prev, cur, pcm, C, n0);

@@ -477,10 +477,13 @@ int aacg_debug_transform(int device_ordinal, int sample_index, int is_short, int
  * decode path calls this.  AACG_DEBUG_ROUTE_UNFUSED_COUPLING: independent coupling (cce.js:121-128) as the separate pass over
  * the interleaved PCM (aacg_couple_pcm, what plans with double-duty runs take) even where the engine would apply it in the
  * targets' epilogues (aacg_imdct_run_*_cpl): the two routes must produce the same bits.
- * AACG_DEBUG_ROUTE_WIDE_KERNELS: plain batches on the 16-wave kernels (a channel pair per wave, aacg_kernels.h) instead of the
- * one-channel-per-wave kernels (aacg_kernels8.h) the engine takes for them; set it before the plan is made. */
+ * AACG_DEBUG_ROUTE_NARROW_KERNELS: plain batches (float PCM, no optional stage, no coupling element) on the one-channel-per-wave
+ * kernels (aacg_kernels8.h: 8 waves per SIMD, run-to-run rendezvous) instead of the 16-wave kernels (a channel pair per wave,
+ * aacg_kernels.h) the engine takes by default; AACG_DEBUG_ROUTE_WIDE_KERNELS: the 16-wave kernels even where the environment
+ * (AACG_RUN8=1) asks for the others.  Set before the plan is made. */
 #define AACG_DEBUG_ROUTE_UNFUSED_COUPLING 1
 #define AACG_DEBUG_ROUTE_WIDE_KERNELS     2
+#define AACG_DEBUG_ROUTE_NARROW_KERNELS   4
 int aacg_debug_set_route(aacg_engine* e, int flags);
 
 #ifdef __cplusplus

@@ -56,7 +56,7 @@ void* lane_main(void* p)
 
 int g_out_kind = AACG_OUTPUT_F32;          /* emu_set_output_kind: the next decodes store int16 PCM */
 int g_unfused = 0;                         /* emu_set_unfused: independent coupling as the separate pass over the PCM even where the engine fuses it */
-int g_run8 = 1;                            /* emu_set_run8: plain batches on the one-channel-per-wave kernels, as the engine routes them */
+int g_run8 = 0;                            /* emu_set_run8: plain batches on the one-channel-per-wave kernels (the engine's opt-in route) */
 int g_staged = 0;                          /* emu_set_staged: optional stages as a launch of their own even where the engine would not */
 
 void launch(const aacg_kparams& P, int kind, int grid, int waves, size_t lds_bytes, int n_units = 0, const aacg_parse_params* PP = nullptr,

@@ -817,3 +817,66 @@ def test_int16_output(oracle, layout, T, inp):
         big = eng.decode_batch(u1, np.repeat(sat, 2, 0), m, 2048)
         assert big.max() == 32767 and big.min() == -32768
     eng.close()
+
+
+# ---- the one-channel-per-wave kernels (aacg_kernels8.h; opt-in route: AACG_DEBUG_ROUTE_NARROW_KERNELS) -----------------------
+NARROW = 4
+
+
+@pytest.mark.parametrize("layout,S,T,seam", [(("cpe",), 40, 16, "q"), (("cpe",), 24, 37, "q"), (("cpe",), 24, 19, "f"), (("sce",), 24, 35, "q"),
+                                             (("cpe", "cpe", "cpe", "sce"), 12, 21, "q"), (("sce", "cpe"), 12, 9, "f")])
+def test_narrow_kernels_vs_oracle(oracle, layout, S, T, seam):
+    """8 waves per SIMD, one channel per wave, runs of 8 pair-frames / 16 single-channel frames handing their tail over through a
+    rendezvous in global memory: two batches chained through the overlap state, all window sequences, M/S and intensity, against
+    the oracle — PCM and the overlap state — through the C ABI (host-buffer path and plans)."""
+    wl0 = aacgpu_workload.make_batch(n_streams=S, n_frames=T, layout=layout, mix=True, intensity=True, seed=4100)
+    C = wl0["C"]
+    kind = aacgpu.INPUT_QUANT_I16 if seam == "q" else aacgpu.INPUT_SPEC_F32
+    eng = aacgpu.Engine(kind, max_streams=S, max_channels=C)
+    eng.debug_set_route(NARROW)
+    ov = np.zeros((S, C, 1024), np.float32)
+    for batch in range(2):
+        wl = aacgpu_workload.make_batch(n_streams=S, n_frames=T, layout=layout, mix=True, intensity=True, seed=4100 + batch, frame_base=batch * T)
+        ref, spec = oracle.decode_batch(wl["units"], wl["q"], wl["meta"], wl["n_pcm"], ov, want_spec=True)
+        coeffs, meta = (wl["q"], wl["meta"]) if seam == "q" else (spec.astype(np.float32), None)
+        if batch == 0:
+            plan = eng.plan(wl["units"])
+            assert eng.plan_kernels(plan).startswith("aacg_imdct_run8_")
+            plan.destroy()
+        pcm = eng.decode_batch(wl["units"], coeffs, meta, wl["n_pcm"])
+        assert not np.isnan(pcm).any() and rms(pcm, ref) < RMS_TOL
+        assert np.abs(overlaps(eng, S, C) - ov).max() <= 1e-5 * max(1.0, float(np.abs(ov).max()))
+    eng.close()
+
+
+def test_narrow_kernels_same_bits_however_the_batch_is_cut_and_whoever_arrives_first(oracle):
+    """Whichever side of a run-to-run rendezvous arrives first finishes the frame with the same arithmetic (tail + head, both rounded
+    products, never fused), and a chain cut into batches goes through the overlap state the same way: 300 streams x 24 frames —
+    more workgroups than the chip holds, so both arrival orders occur — decoded whole, twice, and as 8 + 16: the same bits."""
+    S, T = 300, 24
+    whole = aacgpu_workload.make_batch(n_streams=S, n_frames=T, mix=True, intensity=True, seed=4242)
+    outs = []
+    for _ in range(2):
+        eng = aacgpu.Engine(aacgpu.INPUT_QUANT_I16, max_streams=S, max_channels=2)
+        eng.debug_set_route(NARROW)
+        outs.append(eng.decode_batch(whole["units"], whole["q"], whole["meta"], whole["n_pcm"]).reshape(S, T, 2048))
+        eng.close()
+    assert np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32))
+    eng = aacgpu.Engine(aacgpu.INPUT_QUANT_I16, max_streams=S, max_channels=2)
+    eng.debug_set_route(NARROW)
+    per_frame = len(whole["units"]) // (S * T)
+    parts = []
+    for lo, hi in ((0, 8), (8, T)):
+        keep = np.zeros(len(whole["units"]), bool)
+        for s in range(S):
+            keep[(s * T + lo) * per_frame:(s * T + hi) * per_frame] = True
+        units = whole["units"][keep].copy()
+        for s in range(S):
+            sel = units["stream"] == s
+            units["pcm_offset"][sel] = units["pcm_offset"][sel] - units["pcm_offset"][sel].min() + s * (hi - lo) * 2048
+        parts.append(eng.decode_batch(units, whole["q"], whole["meta"], S * (hi - lo) * 2048).reshape(S, hi - lo, 2048))
+    eng.close()
+    got = np.concatenate(parts, axis=1)
+    assert np.array_equal(got.view(np.uint32), outs[0].view(np.uint32))
+    ov = np.zeros((S, 2, 1024), np.float32)
+    assert rms(outs[0].reshape(-1), oracle.decode_batch(whole["units"], whole["q"], whole["meta"], whole["n_pcm"], ov)) < RMS_TOL
