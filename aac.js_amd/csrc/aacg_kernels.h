@@ -49,6 +49,7 @@ DP_DEVICE cpx c_sub(cpx a, cpx b) { cpx r; r.re = a.re - b.re; r.im = a.im - b.i
 DP_DEVICE cpx c_muli(cpx a)       { cpx r; r.re = -a.im; r.im = a.re; return r; }            /* i * a */
 DP_DEVICE cpx c_mul(cpx a, cpx w)
 {
+#pragma clang fp contract(off)
     cpx r;
     r.re = dp_fma(a.re, w.re, -(a.im * w.im));
     r.im = dp_fma(a.re, w.im, a.im * w.re);
@@ -58,6 +59,11 @@ DP_DEVICE cpx c_mul(cpx a, cpx w)
 /* 8-point inverse DFT  y[q] = sum_j x[j] e^{+2 pi i j q / 8}, in place. */
 DP_DEVICE void radix8_inv(cpx (&x)[8])
 {
+    /* the single-channel (planar) transform is instantiated in several kernels of different translation units (plain, coupling,
+     * optional stages): with multiply-adds formed wherever the compiler finds a product next to a sum, those kernels disagreed
+     * in the last bit on the GPU (the fused and the staged coupling routes on single-channel elements).  Every multiply-add of
+     * this path is spelled out (dp_fma); nothing else is fused. */
+#pragma clang fp contract(off)
     const float h = 0.70710678118654752440f;
     cpx a0 = c_add(x[0], x[4]), a1 = c_sub(x[0], x[4]);
     cpx a2 = c_add(x[2], x[6]), a3 = c_sub(x[2], x[6]);
@@ -217,6 +223,7 @@ DP_DEVICE void long_planar_window(const float* tab, const chan_par& cp, bool wan
                                   const float (&R)[8], const float (&I)[8], const float (&m)[16],
                                   float (&hx)[8], float (&hy)[8])
 {
+#pragma clang fp contract(off)
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const int n = 2 * l + 128 * j;
@@ -244,6 +251,7 @@ template <int NC, bool VM = false>                     /* VM: columns dealt out 
 DP_DEVICE void long_channels(const float* tab, const chan_par (&cp)[NC], bool want_head,
                              float* const (&area)[NC], float (&hx)[NC][8], float (&hy)[NC][8])
 {
+#pragma clang fp contract(off)
     const int l = dp_lane();
     const float* sincos = tab + AACG_TAB_OFF_SINCOS_LONG;
 
@@ -334,6 +342,7 @@ template <int NC, bool VM = false>                     /* VM: the l ^ 7 exchange
 DP_DEVICE void short_channels(const float* tab, const chan_par (&cp)[NC],
                               float* const (&area)[NC], float (&hx)[NC][8], float (&hy)[NC][8])
 {
+#pragma clang fp contract(off)
     const int l = dp_lane(), w = l >> 3, g = l & 7;
     const float* sincos = tab + AACG_TAB_OFF_SINCOS_SHORT;
 

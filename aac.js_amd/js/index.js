@@ -210,6 +210,10 @@ function GpuAACDecoder(opts) {
     this.frontend = opts.frontend || null;
     this.engine = opts.engine || null;
     this.stream = opts.stream | 0;           // engine stream slot of this decoder instance
+    /* a SharedEngine (shared_engine.js): this decoder takes a stream slot of an engine it shares with the other decoders
+     * registered there, and a look-ahead batch holds the buffered frames of ALL of them — one launch instead of one per
+     * stream (decoder.js:125-216 is one instance per stream; the GPU wants their frames together) */
+    this.shared = opts.shared || null;
     this.lookahead = opts.lookahead || 16;
     /* aac.js always windows the first half of a frame with the SINE shape, because it builds a fresh ICSInfo
      * per frame and so loses windowShape[0] (decoder.js:145,153; SURVEY.md 9.1).  false (default) reproduces
@@ -256,6 +260,7 @@ GpuAACDecoder.prototype.setCookie = function (buffer) {
     if (s.read(1)) s.advance(14);
     if (s.read(1)) { if (cfg.profile > 16) s.advance(3); s.advance(1); }
     if (cfg.chanConfig === 0) throw new Error('PCE unimplemented');
+    if (this.shared) this.shared.attach(this);          // engine + stream slot for this sample rate
     if (!this.engine)
         this.engine = new Engine({ sampleIndex: cfg.sampleIndex, maxStreams: this.stream + 1, maxChannels: cfg.chanConfig + this.maxCoupling, inputKind: INPUT_QUANT_I16,
                                    tnsMode: this.tnsMode, pnsMode: this.pnsMode, cceMode: this.cceMode });
@@ -264,8 +269,9 @@ GpuAACDecoder.prototype.setCookie = function (buffer) {
 
 /* elements of one parsed frame -> unit records; channel indices assigned in element order, elements beyond
  * chanConfig channels dropped (decoder.js:233-247) */
-GpuAACDecoder.prototype.unitsOfFrame = function (frame, frameSlot, blockBase, tnsList, cceList) {
+GpuAACDecoder.prototype.unitsOfFrame = function (frame, frameSlot, blockBase, tnsList, cceList, pcmBase) {
     const C = this.config.chanConfig, units = [];
+    pcmBase = pcmBase | 0;                               // float offset of this decoder's frames in the batch's PCM buffer
     let channel = 0, block = blockBase;
     const audio = frame.elements.filter(function (e) { return e.type !== 'cce'; });
     const coupling = frame.elements.filter(function (e) { return e.type === 'cce'; });
@@ -304,7 +310,7 @@ GpuAACDecoder.prototype.unitsOfFrame = function (frame, frameSlot, blockBase, tn
                 tnsList.push(e.ch[c].tns || null);
             }
         }
-        units.push({ stream: this.stream, pcmOffset: frameSlot * FRAME * C, channel: channel, nOutCh: C, coefOffset: block, metaOffset: block,
+        units.push({ stream: this.stream, pcmOffset: pcmBase + frameSlot * FRAME * C, channel: channel, nOutCh: C, coefOffset: block, metaOffset: block,
                      commonWindow: !!e.commonWindow, maskPresent: !!e.maskPresent, hasPns: !!e.hasPns, ch: e.ch, tnsOffset: tnsOffset });
         channel += n;
     }
@@ -325,7 +331,7 @@ GpuAACDecoder.prototype.unitsOfFrame = function (frame, frameSlot, blockBase, tn
         e.ch[0].windowShapePrev = this.carryWindowShape ? (this.prevShape[C + k] | 0) : 0;
         this.prevShape[C + k] = e.ch[0].windowShape;
         const info = Object.assign({}, e.ch[0], { tns: null });       // the reference never runs a coupling element's own TNS either
-        units.push({ stream: this.stream, pcmOffset: frameSlot * FRAME * C, channel: C + k, nOutCh: C, coefOffset: blockOf.get(e), metaOffset: blockOf.get(e),
+        units.push({ stream: this.stream, pcmOffset: pcmBase + frameSlot * FRAME * C, channel: C + k, nOutCh: C, coefOffset: blockOf.get(e), metaOffset: blockOf.get(e),
                      commonWindow: false, maskPresent: false, hasPns: false, cce: true, cceOffset: cceList.length, ch: [info], tnsOffset: 0 });
         cceList.push({ couplingPoint: e.couplingPoint, targets: targets, gains: e.gains });
     });
@@ -336,18 +342,21 @@ GpuAACDecoder.prototype.unitsOfFrame = function (frame, frameSlot, blockBase, tn
  * malformed: it is thrown by the readChunk call that reaches it, after the good frames before it have been returned,
  * which is what a caller of the reference sees frame by frame (decoder.js:125-201 throws at exactly that frame). */
 GpuAACDecoder.prototype.readChunk = function () {
-    if (!this.queue.length) this.decodeAhead();
+    if (!this.queue.length) { if (this.shared) this.shared.flush(); else this.decodeAhead(); }
     if (!this.queue.length) return null;
     const next = this.queue.shift();
     if (next instanceof Error) throw next;
     return next;
 };
 
-GpuAACDecoder.prototype.decodeAhead = function () {
+/* Parse ahead every complete frame already buffered (up to `lookahead`): { frames, units, nBlocks, failed }.  The units'
+ * block and PCM offsets count from (blockBase, pcmBase) — a batch of its own starts at (0, 0), a SharedEngine batch wherever the
+ * decoders before this one ended.  Nothing is decoded here. */
+GpuAACDecoder.prototype.collectAhead = function (blockBase, pcmBase, tnsList, cceList) {
     if (this.config.profile === 1) throw new Error('Main prediction unimplemented');
     if (this.config.profile === 4) throw new Error('LTP prediction unimplemented');
-    const C = this.config.chanConfig, frames = [], tnsList = this.tnsMode === TNS_SPEC ? [] : null, cceList = this.cceMode === CCE_SPEC ? [] : null;
-    let units = [], block = 0, failed = null, layout = null;
+    const frames = [];
+    let units = [], block = blockBase, failed = null, layout = null;
     /* the elements that carry state from frame to frame (overlap-add): which ones a frame has, in order.  A batch is one
      * chain per element for the planner — an element (a coupling element with its own filterbank included) that appears
      * or disappears ends the batch; the frame that differs starts the next one (it waits in this.pendingFrame). */
@@ -368,28 +377,51 @@ GpuAACDecoder.prototype.decodeAhead = function () {
             const sig = layoutOf(f);
             if (layout !== null && sig !== layout) { this.pendingFrame = f; break; }
             layout = sig;
-            units = units.concat(this.unitsOfFrame(f, frames.length, block, tnsList, cceList));
+            units = units.concat(this.unitsOfFrame(f, frames.length, block, tnsList, cceList, pcmBase));
             block += f.q.length / FRAME;
             frames.push(f);
         } catch (err) { failed = err instanceof Error ? err : new Error(String(err)); break; }
     }
-    if (frames.length) {
-        const q = new Int16Array(block * FRAME), meta = new Uint16Array(block * META_WORDS);
-        let b = 0;
-        for (const f of frames) { q.set(f.q, b * FRAME); meta.set(f.meta, b * META_WORDS); b += f.q.length / FRAME; }
-        const pcm = new Float32Array(frames.length * FRAME * C);
+    return { frames: frames, units: units, nBlocks: block - blockBase, failed: failed };
+};
+
+/* the frames' spectra and band words into the batch's arrays, from block `blockBase` on */
+GpuAACDecoder.prototype.fillBatch = function (part, blockBase, q, meta) {
+    let b = blockBase;
+    for (const f of part.frames) { q.set(f.q, b * FRAME); meta.set(f.meta, b * META_WORDS); b += f.q.length / FRAME; }
+};
+
+/* what a batch produced, into the queue in stream order: the frames' PCM (each its own array: the caller owns it), or the
+ * engine's refusal in their place; then the parse error found behind them, if any */
+GpuAACDecoder.prototype.deliver = function (part, pcm, pcmBase, refused) {
+    const C = this.config.chanConfig;
+    if (part.frames.length) {
+        if (refused) this.queue.push(refused);
+        else for (let i = 0; i < part.frames.length; i++) this.queue.push(pcm.slice(pcmBase + i * FRAME * C, pcmBase + (i + 1) * FRAME * C));
+    }
+    if (part.failed) this.queue.push(part.failed);
+};
+
+GpuAACDecoder.prototype.decodeAhead = function () {
+    const C = this.config.chanConfig, tnsList = this.tnsMode === TNS_SPEC ? [] : null, cceList = this.cceMode === CCE_SPEC ? [] : null;
+    const part = this.collectAhead(0, 0, tnsList, cceList);
+    let pcm = null, refused = null;
+    if (part.frames.length) {
+        const q = new Int16Array(part.nBlocks * FRAME), meta = new Uint16Array(part.nBlocks * META_WORDS);
+        this.fillBatch(part, 0, q, meta);
+        pcm = new Float32Array(part.frames.length * FRAME * C);
         /* an engine error costs this batch's frames, not the order: it is queued where their PCM would have been,
          * in front of a parse error found behind them, and the next call goes on with the frames that follow */
-        let refused = null;
         try {
-            this.engine.decodeBatch(packUnits(units), q, meta, pcm, tnsList && tnsList.length ? packTns(tnsList) : null,
+            this.engine.decodeBatch(packUnits(part.units), q, meta, pcm, tnsList && tnsList.length ? packTns(tnsList) : null,
                                     cceList && cceList.length ? packCce(cceList) : null);
         } catch (err) { refused = err instanceof Error ? err : new Error(String(err)); }
-        if (refused) this.queue.push(refused);
-        else for (let i = 0; i < frames.length; i++) this.queue.push(pcm.slice(i * FRAME * C, (i + 1) * FRAME * C));   // caller owns each array
     }
-    if (failed) this.queue.push(failed);
+    this.deliver(part, pcm, 0, refused);
 };
+
+/* a decoder that is done with its stream gives its slot of a SharedEngine back */
+GpuAACDecoder.prototype.close = function () { if (this.shared) this.shared.detach(this); };
 
 /* bytes from the demuxer ('data' events of AdtsDemuxer / an MP4 demuxer's samples) to the front end */
 GpuAACDecoder.prototype.feed = function (bytes) { this.frontend.push(bytes.data || bytes); };
@@ -398,5 +430,5 @@ GpuAACDecoder.prototype.feedPacket = function (bytes, multi) { this.frontend.pus
 module.exports = { Engine, GpuAACDecoder, BitReader, packUnits, unpackUnits, packBandWord, packTns, unpackTns, packCce, CCE_REFERENCE, CCE_SPEC, CCE_BYTES, applyPulses, loadAddon,
                    INPUT_SPEC_F32, INPUT_QUANT_I16, OUTPUT_F32, OUTPUT_I16, TNS_REFERENCE, TNS_SPEC, PNS_REFERENCE, PNS_SPEC, UNIT_BYTES, META_WORDS, TNS_BYTES, SAMPLE_RATES };
 /* the bitstream front end and its pieces (loaded on first use: they require this module themselves) */
-for (const [name, file] of [['FrontEnd', './frontend.js'], ['GpuFrontEnd', './gpu_frontend.js'], ['codebooks', './codebooks.js'], ['adts', './adts.js'], ['BitStream', './bits.js']])
+for (const [name, file] of [['SharedEngine', './shared_engine.js'], ['FrontEnd', './frontend.js'], ['GpuFrontEnd', './gpu_frontend.js'], ['codebooks', './codebooks.js'], ['adts', './adts.js'], ['BitStream', './bits.js']])
     Object.defineProperty(module.exports, name, { enumerable: true, get: function () { const m = require(file); return m[name] || m; } });
