@@ -1,0 +1,113 @@
+#!/usr/bin/env node
+/* SharedEngine (aac.js_amd/js/shared_engine.js): N decoders, one engine per sample rate, ONE batch per flush.
+ *   node tests/js/test_shared.js cpu   a recording engine: batch shapes, stream slots, order, error isolation (no GPU)
+ *   node tests/js/test_shared.js gpu   8 interleaved streams through the real engine against the PCM the reference decoded from
+ *                                      the same bytes (tests/golden/streams/*.refpcm), and against 8 independent decoders */
+'use strict';
+const fs = require('fs'), path = require('path'), assert = require('assert');
+const root = path.join(__dirname, '..', '..');
+const host = require(path.join(root, 'aac.js_amd', 'js'));
+const streams = path.join(root, 'tests', 'golden', 'streams');
+const manifest = JSON.parse(fs.readFileSync(path.join(streams, 'manifest.json')));
+const mode = process.argv[2] || 'cpu';
+
+function open(name, opts) {
+    const dec = new host.GpuAACDecoder(Object.assign({ frontend: new host.FrontEnd(), lookahead: 4 }, opts));
+    dec.init();
+    const demux = new host.adts.AdtsDemuxer(function (event, payload) {
+        if (event === 'format') Object.assign(dec.format, payload);
+        else if (event === 'cookie') dec.setCookie(payload);
+        else if (event === 'data') dec.feed(payload);
+    });
+    demux.push(new Uint8Array(fs.readFileSync(path.join(streams, name + '.aac'))));
+    return dec;
+}
+function drainRoundRobin(decs) {
+    const out = decs.map(function () { return []; });
+    for (let live = decs.length; live;) {
+        live = 0;
+        decs.forEach(function (d, i) { const pcm = d.readChunk(); if (pcm) { out[i].push(pcm); live++; } });
+    }
+    return out;
+}
+const names = ['stereo48', 'surround48', 'mono22', 'stereo48', 'extras8k', 'cce96', 'surround48', 'stereo48'];
+
+if (mode === 'cpu') {
+    /* recording engines, one per sample rate: what reaches decodeBatch */
+    const calls = [];
+    let poison = -1;                                   // a stream slot (of the 48 kHz engine) whose units the engine refuses
+    const mk = function (maxStreams) {
+        return new host.SharedEngine({ maxStreams: maxStreams, engine: function (sampleIndex) {
+            return { resetStream: function () {}, decodeBatch: function (u, q, meta, pcm) {
+                const units = host.unpackUnits(u);
+                if (sampleIndex === 3 && units.some(function (x) { return x.stream === poison; })) throw new Error('engine refuses stream ' + poison);
+                calls.push({ sampleIndex: sampleIndex, units: units });
+                for (const x of units) for (let c = 0; c < x.ch.length; c++) pcm[x.pcmOffset + x.channel + c] = 1000 * x.stream + 1;   // sample 0 of every channel: its stream
+            } };
+        } });
+    };
+    const shared = mk(8);
+    const decs = names.map(function (n) { return open(n, { shared: shared }); });
+    /* slots: dense from 0 per sample rate (one engine each: 48 kHz, 22.05 kHz, 8 kHz, 96 kHz) */
+    assert.deepStrictEqual(decs.map(function (d) { return d.stream; }), [0, 1, 0, 2, 0, 0, 3, 4]);
+    assert.strictEqual(shared.groups.size, 4);
+    const got = drainRoundRobin(decs);
+    names.forEach(function (n, i) {
+        const c = manifest.find(function (m) { return m.name === n; });
+        assert.strictEqual(got[i].length, c.frames, n + ': frames delivered');
+        for (const p of got[i]) {
+            assert.strictEqual(p.length, 1024 * c.channels);
+            for (let ch = 0; ch < c.channels; ch++) assert.strictEqual(p[ch], 1000 * decs[i].stream + 1, n + ': a frame of another stream');
+        }
+    });
+    /* the first 48 kHz batch holds the look-ahead (4 frames) of all five 48 kHz decoders */
+    const first = calls.find(function (c) { return c.sampleIndex === 3; });
+    assert.deepStrictEqual(Array.from(new Set(first.units.map(function (u) { return u.stream; }))).sort(), [0, 1, 2, 3, 4]);
+    const blocks = first.units.map(function (u) { return u.coefOffset; });
+    assert.strictEqual(new Set(blocks).size, blocks.length, 'two units share a coefficient block');
+    assert.ok(shared.stats.batches < 30 && shared.stats.frames === names.reduce(function (a, n) { return a + manifest.find(function (m) { return m.name === n; }).frames; }, 0));
+
+    /* an engine error on a shared batch costs the stream that caused it, nobody else */
+    calls.length = 0; poison = 1;
+    const sh2 = mk(8);
+    const d2 = ['stereo48', 'stereo48', 'stereo48'].map(function (n) { return open(n, { shared: sh2 }); });
+    assert.ok(d2[0].readChunk() instanceof Float32Array);
+    assert.throws(function () { d2[1].readChunk(); }, /engine refuses stream 1/);
+    assert.ok(d2[2].readChunk() instanceof Float32Array);
+    assert.ok(sh2.stats.retries >= 1);
+    poison = -1;
+
+    /* capacity and slot reuse */
+    const sh3 = mk(1);
+    const a = open('stereo48', { shared: sh3 });
+    assert.throws(function () { open('stereo48', { shared: sh3 }); }, /more than 1 streams/);
+    a.close();
+    assert.strictEqual(open('stereo48', { shared: sh3 }).stream, 0);
+    assert.throws(function () { open('stereo48', { shared: mk(4), tnsMode: host.TNS_SPEC }); }, /differ from the shared engine/);
+} else if (mode === 'gpu') {
+    const shared = new host.SharedEngine({ maxStreams: 16, maxChannels: 8 });
+    const decs = names.map(function (n) { return open(n, { shared: shared }); });
+    const got = drainRoundRobin(decs);
+    const alone = drainRoundRobin(names.map(function (n) { return open(n, {}); }));
+    names.forEach(function (n, i) {
+        const c = manifest.find(function (m) { return m.name === n; });
+        const ref = new Float32Array(new Uint8Array(fs.readFileSync(path.join(streams, n + '.refpcm'))).buffer);
+        assert.strictEqual(got[i].length, c.frames, n + ': frames delivered');
+        let err = 0, sig = 0, k = 0;
+        got[i].forEach(function (p, t) {
+            assert.strictEqual(p.length, 1024 * c.channels);
+            for (let j = 0; j < p.length; j++, k++) { const d = p[j] - ref[t * p.length + j]; err += d * d; sig += ref[t * p.length + j] * ref[t * p.length + j]; }
+            /* the same bits as a decoder with an engine of its own: streams only meet in the launch */
+            assert.deepStrictEqual(Buffer.from(p.buffer, p.byteOffset, p.byteLength), Buffer.from(alone[i][t].buffer, alone[i][t].byteOffset, alone[i][t].byteLength), n + ' frame ' + t);
+        });
+        err = Math.sqrt(err / k); sig = Math.sqrt(sig / k);
+        assert.ok(err < 1e-5 && err <= 5e-6 * sig, n + ': rms ' + err + ' of ' + sig);
+    });
+    /* 8 streams, look-ahead 4: a flush carries the buffered frames of every decoder of a sample rate, so the three stereo48 (18
+     * frames each) and two surround48 (5 frames) decoders at 48 kHz share their batches */
+    assert.ok(shared.stats.batches < 8 * 5, 'batches ' + shared.stats.batches);
+    assert.strictEqual(shared.stats.frames, names.reduce(function (a, n) { return a + manifest.find(function (m) { return m.name === n; }).frames; }, 0));
+    assert.strictEqual(shared.stats.retries, 0);
+    console.log('shared engine: ' + shared.stats.frames + ' frames of 8 streams in ' + shared.stats.batches + ' batches (' + shared.groups.size + ' engines)');
+}
+console.log('shared ' + mode + ' tests ok');

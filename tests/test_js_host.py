@@ -67,3 +67,21 @@ def test_aurora_registration_gpu():
     build_addon()
     r = subprocess.run([NODE, os.path.join(ROOT, "tests", "js", "test_aurora.js"), "gpu"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "aurora gpu tests ok" in r.stdout, r.stdout + r.stderr
+
+
+@needs_node
+def test_shared_engine_cpu():
+    """aac.js_amd/js/shared_engine.js with recording engines: stream slots per sample rate, one batch for all decoders of a rate,
+    every frame back to its own decoder in order, an engine error isolated to the stream that caused it, capacity, slot reuse."""
+    r = subprocess.run([NODE, os.path.join(ROOT, "tests", "js", "test_shared.js"), "cpu"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "shared cpu tests ok" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+@needs_node
+def test_shared_engine_gpu():
+    """8 interleaved streams (5 sample rates / layouts) on one SharedEngine through the real engine: every stream equals the PCM
+    the reference decoded from the same bytes (.refpcm) and, bit for bit, a decoder with an engine of its own."""
+    build_addon()
+    r = subprocess.run([NODE, os.path.join(ROOT, "tests", "js", "test_shared.js"), "gpu"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "shared gpu tests ok" in r.stdout, r.stdout + r.stderr

@@ -1,6 +1,8 @@
 #!/usr/bin/env node
 /* Plugin-level rate: frames per second out of readChunk(), bytes in -> PCM out, on one JavaScript thread.
  *   node tools/readchunk_rate.js [repeats]
+ *   node tools/readchunk_rate.js --streams 256 [repeats]     N decoders on one SharedEngine (cross-stream batches), read round robin,
+ *                                                            next to N decoders with an engine each: engine time per frame, checksum
  * A long ADTS stream (the committed tests/golden/streams/stereo48.aac repeated) through
  *   - GpuAACDecoder with the JavaScript front end (parse on the CPU, transform on the GPU),
  *   - GpuAACDecoder with the device front end (parse and transform on the GPU),
@@ -10,7 +12,9 @@
 const fs = require('fs'), path = require('path');
 const root = path.join(__dirname, '..');
 const host = require(path.join(root, 'aac.js_amd', 'js'));
-const repeats = parseInt(process.argv[2] || '400', 10);
+const argv = process.argv.slice(2);
+const nStreams = argv[0] === '--streams' ? parseInt(argv[1], 10) : 0;
+const repeats = parseInt((nStreams ? argv[2] : argv[0]) || (nStreams ? '4' : '400'), 10);
 const one = new Uint8Array(fs.readFileSync(path.join(root, 'tests', 'golden', 'streams', 'stereo48.aac')));
 const perFile = host.adts.frames(one).length;
 const bytes = new Uint8Array(one.length * repeats);
@@ -34,6 +38,54 @@ function ours(gpuParse) {
         const s = Number(process.hrtime.bigint() - t0) / 1e9;
         return { frames_per_s: Math.round(n / s), frames: n, seconds: +s.toFixed(3), checksum: sum };
     } catch (e) { return { error: String(e.message || e).slice(0, 160) }; }
+}
+/* N concurrent streams: the same bytes into N decoders, read round robin as N players would; `shared`: one SharedEngine
+ * (one batch per flush for all of them) or an engine per decoder (one batch per decoder: what N independent plugin instances
+ * do).  Engine time = wall time inside engine.decodeBatch (upload, kernels, download), on this one JavaScript thread. */
+function many(shared, lookahead) {
+    try {
+        let engineNs = 0n, batches = 0;
+        const timed = function (eng) {
+            const inner = eng.decodeBatch.bind(eng);
+            eng.decodeBatch = function () { const t = process.hrtime.bigint(); try { return inner.apply(null, arguments); } finally { engineNs += process.hrtime.bigint() - t; batches++; } };
+            return eng;
+        };
+        const sh = shared ? new host.SharedEngine({ maxStreams: nStreams, maxChannels: 2 }) : null;
+        const decs = [];
+        for (let i = 0; i < nStreams; i++) {
+            const dec = new host.GpuAACDecoder({ frontend: new host.FrontEnd(), lookahead: lookahead, shared: sh });
+            dec.init();
+            const demux = new host.adts.AdtsDemuxer(function (event, payload) {
+                if (event === 'format') Object.assign(dec.format, payload);
+                else if (event === 'cookie') dec.setCookie(payload);
+                else if (event === 'data') dec.feed(payload);
+            });
+            demux.push(bytes);
+            if (!shared) timed(dec.engine);
+            decs.push(dec);
+        }
+        if (shared) for (const g of sh.groups.values()) timed(g.engine);
+        const t0 = process.hrtime.bigint();
+        let n = 0, sum = 0;
+        for (let live = nStreams; live;) {
+            live = 0;
+            for (const d of decs) { const pcm = d.readChunk(); if (pcm) { n++; sum += pcm[17]; live++; } }
+        }
+        const s = Number(process.hrtime.bigint() - t0) / 1e9, es = Number(engineNs) / 1e9;
+        return { streams: nStreams, lookahead: lookahead, frames: n, seconds: +s.toFixed(3), frames_per_s: Math.round(n / s), batches: batches,
+                 frames_per_batch: +(n / batches).toFixed(1), engine_seconds: +es.toFixed(3), frames_per_engine_second: Math.round(n / es), checksum: sum };
+    } catch (e) { return { error: String(e.message || e).slice(0, 200) }; }
+}
+if (nStreams) {
+    out.stream = 'stereo48.aac x ' + repeats + ' x ' + nStreams + ' streams';
+    out.independent_decoders = many(false, 16);
+    out.shared_engine = many(true, 16);
+    if (out.independent_decoders.frames_per_engine_second && out.shared_engine.frames_per_engine_second) {
+        out.engine_time_ratio = +(out.shared_engine.frames_per_engine_second / out.independent_decoders.frames_per_engine_second).toFixed(2);
+        out.same_checksum = out.shared_engine.checksum === out.independent_decoders.checksum;
+    }
+    console.log(JSON.stringify(out, null, 1));
+    process.exit(0);
 }
 out.gpu_transform_js_parse = ours(false);
 out.gpu_transform_gpu_parse = ours(true);
