@@ -760,16 +760,27 @@ DP_DEVICE void short_pair(const float* tab, const chan_par& cp, float* slot, dpv
             tl[8 + j + 4] = mR[7 - j] * v2s(t1.x);
         }
     }
-    /* s[128 w + i] = tail of block w-1 + head of block w (filter_bank.js:155-160) */
-    float pa[16], pb[16];
+    /* s[128 w + i] = tail of block w-1 + head of block w (filter_bank.js:155-160): the previous window's tails sit eight lanes
+     * down.  The rotation goes through the wave's own slot, which is free between the last transpose read and the tails:
+     * eight 16-byte stores ([m][lane]: conflict-free) + eight loads instead of 32 ds_bpermute (a rotation by eight lanes
+     * crosses the 16-lane rows, so it has no DPP form) */
+    dpv2 pt[16];
 #pragma unroll
-    for (int i = 0; i < 16; i++) { pa[i] = tl[i][0]; pb[i] = tl[i][1]; }
-    dp_shfl(pa, (l - 8) & 63);
-    dp_shfl(pb, (l - 8) & 63);
+    for (int m = 0; m < 8; m++) {
+        dpf4 o; o.x = tl[2 * m][0]; o.y = tl[2 * m][1]; o.z = tl[2 * m + 1][0]; o.w = tl[2 * m + 1][1];
+        *(dpf4*)(slot + 256 * m + 4 * l) = o;
+    }
+    dp_wave_sync();
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+        const dpf4 t = *(const dpf4*)(slot + 256 * m + 4 * ((l - 8) & 63));
+        pt[2 * m] = v2(t.x, t.y); pt[2 * m + 1] = v2(t.z, t.w);
+    }
+    dp_wave_sync();                                    /* the slot takes the tails next */
 #pragma unroll
     for (int i = 0; i < 8; i++) {
-        hx[i] = (w == 0 ? v2s(0.0f) : v2(pa[i], pb[i])) + hd[i];
-        hy[i] = (w == 0 ? v2s(0.0f) : v2(pa[8 + i], pb[8 + i])) + hd[8 + i];
+        hx[i] = (w == 0 ? v2s(0.0f) : pt[i]) + hd[i];
+        hy[i] = (w == 0 ? v2s(0.0f) : pt[8 + i]) + hd[8 + i];
     }
 
     /* second half of s -> new overlap, interleaved (filter_bank.js:164-176) */
