@@ -14,23 +14,29 @@ b quant_20steps --steps 20 --warmup 5
 b spec --input spec --no-cpu-baseline
 b cfg3 --workload cfg3 --no-cpu-baseline
 b cfg4 --workload cfg4 --no-cpu-baseline
-b cfg5 --workload cfg5 --steps 4000 --warmup 400
-b cfg5_spec --workload cfg5 --input spec --steps 4000 --warmup 400 --no-cpu-baseline
-b cfg3_tns_spec_quant --workload cfg3 --tns spec --steps 2000 --warmup 200 --no-cpu-baseline
-b cfg3_tns_spec_f32 --workload cfg3 --tns spec --input spec --steps 2000 --warmup 200 --no-cpu-baseline
-b cfg5_cce_spec --workload cfg5 --cce spec --steps 1000 --warmup 100 --no-cpu-baseline
+b cfg5 --workload cfg5 --steps 1000 --warmup 200
+b cfg5_spec --workload cfg5 --input spec --steps 1000 --warmup 200 --no-cpu-baseline
+b cfg3_tns_spec_quant --workload cfg3 --tns spec --steps 1000 --warmup 200 --no-cpu-baseline
+b cfg3_tns_spec_f32 --workload cfg3 --tns spec --input spec --steps 1000 --warmup 200 --no-cpu-baseline
+b cfg5_cce_spec --workload cfg5 --cce spec --steps 500 --warmup 100 --no-cpu-baseline
 b quant_i16out --output i16 --no-cpu-baseline
 b quant_pipelines2 --pipelines 2 --no-cpu-baseline
-b quant_2ranks_shared_gpu --gpus 2 --dist-backend gloo --share-gpu --steps 2000 --warmup 200
+# the one-channel-per-wave kernels (opt-in route): the same workloads, for the record of what they measure
+AACG_RUN8=1 python3 bench.py --no-cpu-baseline > $OUT/bench_quant_run8.json 2> $OUT/bench_quant_run8.err || echo "bench quant_run8 failed" >> $OUT/failures.txt
+AACG_RUN8=1 python3 bench.py --no-cpu-baseline --input spec > $OUT/bench_spec_run8.json 2> $OUT/bench_spec_run8.err || echo "bench spec_run8 failed" >> $OUT/failures.txt
+AACG_RUN8=1 python3 bench.py --no-cpu-baseline --workload cfg4 > $OUT/bench_cfg4_run8.json 2> $OUT/bench_cfg4_run8.err || echo "bench cfg4_run8 failed" >> $OUT/failures.txt
+AACG_RUN8=1 python3 bench.py --no-cpu-baseline --workload cfg5 --steps 500 --warmup 100 > $OUT/bench_cfg5_run8.json 2> $OUT/bench_cfg5_run8.err || echo "bench cfg5_run8 failed" >> $OUT/failures.txt
+b quant_2ranks_shared_gpu --gpus 2 --dist-backend gloo --share-gpu --steps 1000 --warmup 200
 # the driver's launch line with one rank: RCCL carries the barrier and the 8-byte reductions
-python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29541 bench.py --gpus 1 --steps 2000 --warmup 200 --no-cpu-baseline \
+python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29541 bench.py --gpus 1 --steps 1000 --warmup 200 --no-cpu-baseline \
   > $OUT/bench_quant_torchrun_rccl_1rank.json 2> $OUT/bench_quant_torchrun_rccl_1rank.err || echo "bench torchrun failed" >> $OUT/failures.txt
 bash tools/prof.sh $TAG/prof_quant > $OUT/prof_quant.log 2>&1
 bash tools/prof.sh $TAG/prof_spec --input spec > $OUT/prof_spec.log 2>&1
 bash tools/prof.sh $TAG/prof_cfg5 --workload cfg5 > $OUT/prof_cfg5.log 2>&1
 bash tools/prof.sh $TAG/prof_cfg3_tns --workload cfg3 --tns spec > $OUT/prof_cfg3_tns.log 2>&1
+AACG_RUN8=1 bash tools/prof.sh $TAG/prof_quant_run8 > $OUT/prof_quant_run8.log 2>&1
 # keep what is judged: summaries and kernel stats (the raw rocprofv3 trees stay behind)
-for p in prof_quant prof_spec prof_cfg5 prof_cfg3_tns; do
+for p in prof_quant prof_spec prof_cfg5 prof_cfg3_tns prof_quant_run8; do
   cp $OUT/$p/summary.txt $OUT/${p}_summary.txt 2>/dev/null
   find $OUT/$p/trace -name "*kernel_stats.csv" -exec cp {} $OUT/${p}_kernel_stats.csv \; 2>/dev/null
   rm -rf $OUT/$p
