@@ -42,7 +42,7 @@
 #endif
 
 #ifndef AACG8_EARLY_WAVES
-#define AACG8_EARLY_WAVES 2
+#define AACG8_EARLY_WAVES 8
 #endif
 #define K8_PHASE_STAGED 1
 #define K8_PHASE_DUMPED 2

@@ -32,7 +32,9 @@ function register(AV, options) {
 
         this.prototype.init = function () {
             const frontend = options.frontend ? options.frontend() : (options.gpuParse ? new host.GpuFrontEnd(options) : new host.FrontEnd(options));
-            this.impl = new host.GpuAACDecoder(Object.assign({}, options, { format: this.format, frontend: frontend, engine: options.engine ? options.engine() : null }));
+            /* options.shared: a SharedEngine — every decoder Aurora constructs takes a stream slot of it (cross-stream batches) */
+            this.impl = new host.GpuAACDecoder(Object.assign({}, options, { format: this.format, frontend: frontend, engine: options.engine ? options.engine() : null,
+                                                                             shared: options.shared || null }));
             this.impl.init();                                   // format.floatingPoint = true (decoder.js:49-51)
             this.fed = 0;                                       // absolute stream offset up to which bytes went to the front end
             this.packets = this.format.formatID === 'mp4a';     // MP4 samples arrive as buffers of whole samples; ADTS is a byte stream
