@@ -166,6 +166,23 @@ static inline void aacg_set_cpl(aacg_kparams* P, const aacg_couple_job* jobs, co
 #define AACG_CPL_GAINS(P) ((const float*)(const void*)(P).pns)
 #define AACG_CPL_SIDE(P)  ((const float*)(P).spec_out)   /* the coupling elements' filterbank output, [block][1024], PCM-scaled */
 
+/* ---- chains longer than a run without a recomputed frame: the run-to-run rendezvous for the 16-wave kernels (_rv builds) ---- */
+/* Every run of such a plan holds up to 16 frames and nobody recomputes anything: a later run's first frame and the run
+ * before it meet in a rendezvous cell in global memory (as in aacg_kernels8.h) — whichever side arrives first publishes what
+ * it has (the windowed tail, or the windowed first half) and leaves, the second finishes the frame.  One record per block. */
+struct aacg_rv_link {
+    int32_t link_in;                  /* cell through which the run before this one hands over; -1: first run of its chain */
+    int32_t link_out;                 /* cell towards the next run; -1: last run of its chain */
+    int32_t succ_unit;                /* first unit of the next run, or -1 */
+    int32_t reserved;
+};
+struct aacg_rv_args {
+    const aacg_rv_link*  links;       /* [n_runs], block order */
+    unsigned long long*  state;       /* [n_links][AACG8_RV_STATE_WORDS] (the first word is used), epoch-tagged, never reset */
+    float*               data;        /* [n_links][AACG8_RV_DATA_FLOATS]: tail | head, [channel][1024] each */
+    unsigned long long   epoch;
+};
+
 /* ---- the 8-waves-per-SIMD run kernels (aacg_kernels8.h): one CHANNEL per wave ---------------------------------- */
 /* A workgroup is still 16 waves, but a wave carries one channel of one frame (4 KB of LDS, <= 64 VGPRs), so that two
  * workgroups share a CU: 32 waves, 8 per SIMD.  What that changes in the data the kernel reads:

@@ -46,6 +46,9 @@ struct cce_bufs { const aacg_run* runs; const aacg_couple_job* jobs; const float
 /* aacg_engine8.hip: the one-channel-per-wave run kernels (two workgroups per CU) */
 void aacg_run8_launch(bool quant, dim3 grid, dim3 block, hipStream_t s, const aacg_kparams8& P);
 struct run8_bufs { const aacg_run8* runs; unsigned long long* rv_state; float* rv_data; };
+/* aacg_engine_rv.hip: the 16-wave kernels for chains longer than a run, with a run-to-run rendezvous instead of a recomputed frame */
+void aacg_rv_launch(bool quant, dim3 grid, dim3 block, hipStream_t s, const aacg_kparams& P, const aacg_rv_args& V);
+struct rv_bufs { const aacg_run* runs; const aacg_rv_link* links; unsigned long long* state; float* data; };
 
 extern "C" __global__ __launch_bounds__(AACG_WG_THREADS)
 void aacg_spectral(const aacg_kparams P, int n_units) { spectral_body(P, n_units); }
@@ -63,6 +66,7 @@ struct aacg_engine {
                                                (AACG_RUN8=1 / AACG_DEBUG_ROUTE_NARROW_KERNELS) — built to parity and measured slower than the
                                                16-wave kernels on every BASELINE configuration */
     unsigned long long rv_epoch = 0;        /* rendezvous epoch: one per launch of those kernels, never 0 */
+    bool rv = true;                         /* chains longer than a run: rendezvous between their runs (the _rv kernels) instead of a recomputed frame (_dd) */
     float* d_overlap = nullptr;             /* [max_streams][max_channels][2][1024] */
     std::vector<uint8_t> parity;            /* live buffer per (stream, channel) */
     uint64_t epoch = 0;                     /* bumped whenever `parity` changes: lets a relaunched plan skip its check */
@@ -82,6 +86,7 @@ struct aacg_engine {
         void* d_spec = nullptr;   size_t spec_cap = 0;       /* PNS route: f32 spectra between the two kernels */
         void* d_cce[4] = {nullptr, nullptr, nullptr, nullptr}; size_t cce_cap[4] = {0, 0, 0, 0};   /* AACG_CCE_SPEC: runs, jobs, gains, side PCM */
         void* d_run8[3] = {nullptr, nullptr, nullptr}; size_t run8_cap[3] = {0, 0, 0};             /* 8-wave kernels: runs, rendezvous state, payload */
+        void* d_rv[4] = {nullptr, nullptr, nullptr, nullptr}; size_t rv_cap[4] = {0, 0, 0, 0};     /* _rv kernels: runs, links, rendezvous state, payload */
         void* d_pcm = nullptr;    size_t pcm_cap = 0;
         /* page-locked staging for callers that pass ordinary (pageable) memory */
         void* h_in = nullptr;     size_t h_in_cap = 0;
@@ -113,7 +118,8 @@ struct aacg_plan {
     float* d_spec = nullptr;                /* PNS route: f32 spectra between the two kernels */
     void*  d_cce[4] = {nullptr, nullptr, nullptr, nullptr};   /* AACG_CCE_SPEC: coupling elements' runs, jobs, gains, side PCM */
     void*  d_run8[3] = {nullptr, nullptr, nullptr};           /* 8-wave kernels: their run table, rendezvous state words and payload */
-    size_t bytes[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  /* sizes of the twelve buffers above, for the engine's free list */
+    void*  d_rv[4] = {nullptr, nullptr, nullptr, nullptr};    /* _rv kernels: run table, link records, rendezvous state words and payload */
+    size_t bytes[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  /* sizes of the sixteen buffers above, for the engine's free list */
     hipEvent_t uploaded = nullptr;          /* the tables are on the device */
     hipEvent_t last_use = nullptr;          /* recorded at destruction on last_stream: everything launched with this plan */
     hipStream_t last_stream = nullptr;      /* stream of the most recent launch (no per-launch event: it costs 3 us per step) */
@@ -205,6 +211,13 @@ bool takes_run8(const aacg_engine* e, const aacg_plan_host& h)
            !h.any_cce && !h.any_tns && !(quant && h.any_pns) && !h.runs8.empty();
 }
 
+/* Plain batches with a chain longer than a run: the 16-wave kernels with a run-to-run rendezvous (no recomputed frame). */
+bool takes_rv(const aacg_engine* e, const aacg_plan_host& h)
+{
+    const bool quant = e->cfg.input_kind == AACG_INPUT_QUANT_I16;
+    return e->rv && !takes_run8(e, h) && e->cfg.output_kind == AACG_OUTPUT_F32 && !h.any_cce && !h.any_tns && !(quant && h.any_pns) && !h.runs_rv.empty();
+}
+
 /* The launches launch_run makes for a plan, by kernel name: what a rocprofv3 kernel trace of the batch shows. */
 std::string route_names(const aacg_engine* e, const aacg_plan_host& h)
 {
@@ -225,6 +238,7 @@ std::string route_names(const aacg_engine* e, const aacg_plan_host& h)
         quant = false;
     }
     if (takes_run8(e, h)) return std::string("aacg_imdct_run8_") + (quant ? "quant" : "f32");
+    if (takes_rv(e, h)) return std::string("aacg_imdct_run_") + (quant ? "quant" : "f32") + "_rv";
     const std::string run = std::string("aacg_imdct_run_") + (quant ? "quant" : "f32");
     const bool fused = h.fused_independent && !ex && !i16 && !(e->debug_route & AACG_DEBUG_ROUTE_UNFUSED_COUPLING);
     if (fused) {
@@ -242,7 +256,7 @@ std::string route_names(const aacg_engine* e, const aacg_plan_host& h)
 
 /* enqueue the run kernel for a planned batch (device pointers) */
 int launch_run(aacg_engine* e, const aacg_dev_unit* d_units, const aacg_run* d_runs, const aacg_dev_tns* d_tns,
-               float* d_scratch, float* d_spec, const cce_bufs& cb, const run8_bufs& r8, const aacg_plan_host& h, const void* d_coeffs, const aacg_band_meta* d_meta,
+               float* d_scratch, float* d_spec, const cce_bufs& cb, const run8_bufs& r8, const rv_bufs& rvb, const aacg_plan_host& h, const void* d_coeffs, const aacg_band_meta* d_meta,
                void* d_pcm, int flip, hipStream_t s)
 {
     const bool i16 = e->cfg.output_kind == AACG_OUTPUT_I16;
@@ -256,6 +270,17 @@ int launch_run(aacg_engine* e, const aacg_dev_unit* d_units, const aacg_run* d_r
         P8.flip = flip; P8.n_runs = (int32_t)h.runs8.size();
         P8.trace = (e->d_trace && (e->ablate & 16)) ? (unsigned long long*)e->d_trace : nullptr;
         aacg_run8_launch(quant, dim3((unsigned)h.runs8.size()), dim3(AACG_WG_THREADS), s, P8);
+        HIP_TRY(e, hipGetLastError(), AACG_ERR_NO_DEVICE);
+        return AACG_OK;
+    }
+    if (takes_rv(e, h)) {
+        aacg_kparams P;
+        std::memset(&P, 0, sizeof P);
+        P.units = d_units; P.runs = rvb.runs; P.coeffs = d_coeffs; P.meta = d_meta; P.pcm = (float*)d_pcm;
+        P.overlap = e->d_overlap; P.tab = e->d_tab; P.flip = flip; P.n_runs = (int32_t)h.runs_rv.size();
+        aacg_rv_args V;
+        V.links = rvb.links; V.state = rvb.state; V.data = rvb.data; V.epoch = ++e->rv_epoch;
+        aacg_rv_launch(quant, dim3((unsigned)h.runs_rv.size()), dim3(AACG_WG_THREADS), s, P, V);
         HIP_TRY(e, hipGetLastError(), AACG_ERR_NO_DEVICE);
         return AACG_OK;
     }
@@ -351,8 +376,9 @@ const char* aacg_kernel_name(void) { return "aacg_imdct_run_quant"; }
 
 int aacg_debug_set_route(aacg_engine* e, int flags)
 {
-    if (!e || (flags & ~(AACG_DEBUG_ROUTE_UNFUSED_COUPLING | AACG_DEBUG_ROUTE_WIDE_KERNELS | AACG_DEBUG_ROUTE_NARROW_KERNELS))) return AACG_ERR_INVALID_ARG;
+    if (!e || (flags & ~(AACG_DEBUG_ROUTE_UNFUSED_COUPLING | AACG_DEBUG_ROUTE_WIDE_KERNELS | AACG_DEBUG_ROUTE_NARROW_KERNELS | AACG_DEBUG_ROUTE_RECOMPUTE))) return AACG_ERR_INVALID_ARG;
     e->debug_route = flags;
+    if (flags & AACG_DEBUG_ROUTE_RECOMPUTE) e->rv = false;
     return AACG_OK;
 }
 
@@ -413,7 +439,8 @@ int aacg_create(const aacg_config* cfg, aacg_engine** out)
                         hip_ok(e, hipMemcpy(e->d_win8, w8, sizeof *w8, hipMemcpyHostToDevice), "upload window tables");
         delete w8;
         if (!ok) { aacg_destroy(e); return AACG_ERR_OUT_OF_MEMORY; }
-        if (const char* r = std::getenv("AACG_RUN8")) e->run8 = std::atoi(r) != 0;    /* A/B switch for tools/: 1 = plain batches on the one-channel-per-wave kernels */
+        if (const char* r = std::getenv("AACG_RUN8")) e->run8 = std::atoi(r) != 0;
+        if (const char* r = std::getenv("AACG_RV")) e->rv = std::atoi(r) != 0;         /* A/B switch for tools/: 0 = long chains recompute a frame per later run (_dd kernels) */    /* A/B switch for tools/: 1 = plain batches on the one-channel-per-wave kernels */
     }
     if (cfg->pns_mode == AACG_PNS_SPEC) {
         aacg_pns_tables* pt = new (std::nothrow) aacg_pns_tables;
@@ -444,6 +471,7 @@ void aacg_destroy(aacg_engine* e)
         for (void* p : {sl.d_units, sl.d_runs, sl.d_coeffs, sl.d_meta, sl.d_tns, sl.d_scratch, sl.d_spec, sl.d_pcm}) if (p) (void)hipFree(p);
         for (void* p : sl.d_cce) if (p) (void)hipFree(p);
         for (void* p : sl.d_run8) if (p) (void)hipFree(p);
+        for (void* p : sl.d_rv) if (p) (void)hipFree(p);
         if (sl.h_in) (void)hipHostFree(sl.h_in);
         if (sl.h_pcm) (void)hipHostFree(sl.h_pcm);
         if (sl.done) (void)hipEventDestroy(sl.done);
@@ -569,21 +597,27 @@ int aacg_plan_create_ex(aacg_engine* e, const aacg_unit_desc* units, uint32_t n_
     bool ok = hip_ok(e, hipSetDevice(e->cfg.device_ordinal), "hipSetDevice") &&
               hip_ok(e, hipEventCreateWithFlags(&p->uploaded, hipEventDisableTiming), "hipEventCreate") &&
               hip_ok(e, hipEventCreateWithFlags(&p->last_use, hipEventDisableTiming), "hipEventCreate");
-    const bool r8 = takes_run8(e, p->h);
+    const bool r8 = takes_run8(e, p->h), rvp = takes_rv(e, p->h);
     const size_t r8b[3] = {r8 ? sizeof(aacg_run8) * p->h.runs8.size() : 0, r8 ? sizeof(unsigned long long) * AACG8_RV_STATE_WORDS * (size_t)p->h.n_links : 0,
                            r8 ? sizeof(float) * AACG8_RV_DATA_FLOATS * (size_t)p->h.n_links : 0};
-    const size_t want[12] = {ub, r8 ? 0 : rb, tb, r8 ? 0 : sb, xb, cb[0], cb[1], cb[2], cb[3], r8b[0], r8b[1], r8b[2]};
-    void** const slot[12] = {(void**)&p->d_units, (void**)&p->d_runs, (void**)&p->d_tns, (void**)&p->d_scratch, (void**)&p->d_spec,
-                             &p->d_cce[0], &p->d_cce[1], &p->d_cce[2], &p->d_cce[3], &p->d_run8[0], &p->d_run8[1], &p->d_run8[2]};
-    const void* const src[12] = {p->h.units.data(), p->h.runs.data(), p->h.tns.data(), nullptr, nullptr,
-                                 p->h.cce_runs.data(), p->h.couple_jobs.data(), p->h.gains.data(), nullptr, p->h.runs8.data(), nullptr, nullptr};
-    for (int i = 0; i < 12 && ok; i++) {
+    const size_t rvs[4] = {rvp ? sizeof(aacg_run) * p->h.runs_rv.size() : 0, rvp ? sizeof(aacg_rv_link) * p->h.links_rv.size() : 0,
+                           rvp ? sizeof(unsigned long long) * AACG8_RV_STATE_WORDS * (size_t)p->h.n_links_rv : 0,
+                           rvp ? sizeof(float) * AACG8_RV_DATA_FLOATS * (size_t)p->h.n_links_rv : 0};
+    const bool other = r8 || rvp;                        /* the plan's launches never read the 16-wave run table / scratch */
+    const size_t want[16] = {ub, other ? 0 : rb, tb, other ? 0 : sb, xb, cb[0], cb[1], cb[2], cb[3], r8b[0], r8b[1], r8b[2], rvs[0], rvs[1], rvs[2], rvs[3]};
+    void** const slot[16] = {(void**)&p->d_units, (void**)&p->d_runs, (void**)&p->d_tns, (void**)&p->d_scratch, (void**)&p->d_spec,
+                             &p->d_cce[0], &p->d_cce[1], &p->d_cce[2], &p->d_cce[3], &p->d_run8[0], &p->d_run8[1], &p->d_run8[2],
+                             &p->d_rv[0], &p->d_rv[1], &p->d_rv[2], &p->d_rv[3]};
+    const void* const src[16] = {p->h.units.data(), p->h.runs.data(), p->h.tns.data(), nullptr, nullptr,
+                                 p->h.cce_runs.data(), p->h.couple_jobs.data(), p->h.gains.data(), nullptr, p->h.runs8.data(), nullptr, nullptr,
+                                 p->h.runs_rv.data(), p->h.links_rv.data(), nullptr, nullptr};
+    for (int i = 0; i < 16 && ok; i++) {
         if (!want[i]) continue;
         *slot[i] = pool_take(e, want[i], &p->bytes[i]);
         ok = *slot[i] != nullptr &&
              (!src[i] || hip_ok(e, hipMemcpyAsync(*slot[i], src[i], want[i], hipMemcpyHostToDevice, e->stream), "upload plan tables"));
         /* rendezvous state words count only with a launch's epoch in them; a recycled or fresh buffer starts from zero all the same */
-        if (ok && i == 10) ok = hip_ok(e, hipMemsetAsync(*slot[i], 0, want[i], e->stream), "zero rendezvous state");
+        if (ok && (i == 10 || i == 14)) ok = hip_ok(e, hipMemsetAsync(*slot[i], 0, want[i], e->stream), "zero rendezvous state");
     }
     ok = ok && hip_ok(e, hipEventRecord(p->uploaded, e->stream), "hipEventRecord");
     if (!ok) {
@@ -609,9 +643,9 @@ void aacg_plan_destroy(aacg_plan* p)
         }
         (void)hipEventDestroy(p->last_use);
     }
-    void* const ptr[12] = {p->d_units, p->d_runs, p->d_tns, p->d_scratch, p->d_spec, p->d_cce[0], p->d_cce[1], p->d_cce[2], p->d_cce[3],
-                           p->d_run8[0], p->d_run8[1], p->d_run8[2]};
-    for (int i = 0; i < 12; i++) pool_give(e, ptr[i], p->bytes[i]);
+    void* const ptr[16] = {p->d_units, p->d_runs, p->d_tns, p->d_scratch, p->d_spec, p->d_cce[0], p->d_cce[1], p->d_cce[2], p->d_cce[3],
+                           p->d_run8[0], p->d_run8[1], p->d_run8[2], p->d_rv[0], p->d_rv[1], p->d_rv[2], p->d_rv[3]};
+    for (int i = 0; i < 16; i++) pool_give(e, ptr[i], p->bytes[i]);
     delete p;
 }
 
@@ -641,8 +675,10 @@ int aacg_decode_device(aacg_engine* e, aacg_plan* p, const void* d_coeffs, const
     const cce_bufs cb = {(const aacg_run*)p->d_cce[0], (const aacg_couple_job*)p->d_cce[1], (const float*)p->d_cce[2], (float*)p->d_cce[3]};
     const run8_bufs r8 = {(const aacg_run8*)p->d_run8[0], (unsigned long long*)p->d_run8[1], (float*)p->d_run8[2]};
     if (takes_run8(e, p->h) && !p->d_run8[0]) { e->err = "the plan was made for the 16-wave kernels (aacg_debug_set_route changed since)"; return AACG_ERR_STALE_PLAN; }
-    if (!takes_run8(e, p->h) && !p->d_runs && !p->h.runs.empty()) { e->err = "the plan was made for the 8-wave kernels (aacg_debug_set_route changed since)"; return AACG_ERR_STALE_PLAN; }
-    rc = launch_run(e, p->d_units, p->d_runs, p->d_tns, p->d_scratch, p->d_spec, cb, r8, p->h, d_coeffs, d_meta, d_pcm, (int)(p->launches & 1u), s);
+    const rv_bufs rvb = {(const aacg_run*)p->d_rv[0], (const aacg_rv_link*)p->d_rv[1], (unsigned long long*)p->d_rv[2], (float*)p->d_rv[3]};
+    if (takes_rv(e, p->h) && !p->d_rv[0]) { e->err = "the plan was made for another route (aacg_debug_set_route changed since)"; return AACG_ERR_STALE_PLAN; }
+    if (!takes_run8(e, p->h) && !takes_rv(e, p->h) && !p->d_runs && !p->h.runs.empty()) { e->err = "the plan was made for another route (aacg_debug_set_route changed since)"; return AACG_ERR_STALE_PLAN; }
+    rc = launch_run(e, p->d_units, p->d_runs, p->d_tns, p->d_scratch, p->d_spec, cb, r8, rvb, p->h, d_coeffs, d_meta, d_pcm, (int)(p->launches & 1u), s);
     if (rc) return rc;
     p->last_stream = s;
     p->used = true;
@@ -829,6 +865,15 @@ int aacg_submit_ex(aacg_engine* e, const aacg_batch* batch, uint64_t* ticket)
                            sizeof(float) * h.gains.size(), (size_t)h.side_blocks * 4096u};
     const void* const cce_src[4] = {h.cce_runs.data(), h.couple_jobs.data(), h.gains.data(), nullptr};
     for (int i = 0; i < 4; i++) if (ccb[i] && (rc = grow(e, &sl.d_cce[i], &sl.cce_cap[i], ccb[i]))) return rc;
+    const bool rvp = takes_rv(e, h);
+    const size_t rvs[4] = {rvp ? sizeof(aacg_run) * h.runs_rv.size() : 0, rvp ? sizeof(aacg_rv_link) * h.links_rv.size() : 0,
+                           rvp ? sizeof(unsigned long long) * AACG8_RV_STATE_WORDS * (size_t)h.n_links_rv : 0,
+                           rvp ? sizeof(float) * AACG8_RV_DATA_FLOATS * (size_t)h.n_links_rv : 0};
+    for (int i = 0; i < 4; i++) {
+        const size_t had = sl.rv_cap[i];
+        if (rvs[i] && (rc = grow(e, &sl.d_rv[i], &sl.rv_cap[i], rvs[i]))) return rc;
+        if (i == 2 && sl.rv_cap[i] != had) HIP_TRY(e, hipMemset(sl.d_rv[i], 0, sl.rv_cap[i]), AACG_ERR_NO_DEVICE);     /* a new state buffer starts from zero */
+    }
     const bool r8 = takes_run8(e, h);
     const size_t r8b[3] = {r8 ? sizeof(aacg_run8) * h.runs8.size() : 0, r8 ? sizeof(unsigned long long) * AACG8_RV_STATE_WORDS * (size_t)h.n_links : 0,
                            r8 ? sizeof(float) * AACG8_RV_DATA_FLOATS * (size_t)h.n_links : 0};
@@ -869,6 +914,8 @@ int aacg_submit_ex(aacg_engine* e, const aacg_batch* batch, uint64_t* ticket)
     HIP_TRY(e, hipMemcpyAsync(sl.d_units, h.units.data(), ub, hipMemcpyHostToDevice, s), AACG_ERR_NO_DEVICE);
     if (rb) HIP_TRY(e, hipMemcpyAsync(sl.d_runs, h.runs.data(), rb, hipMemcpyHostToDevice, s), AACG_ERR_NO_DEVICE);
     if (r8b[0]) HIP_TRY(e, hipMemcpyAsync(sl.d_run8[0], h.runs8.data(), r8b[0], hipMemcpyHostToDevice, s), AACG_ERR_NO_DEVICE);
+    if (rvs[0]) HIP_TRY(e, hipMemcpyAsync(sl.d_rv[0], h.runs_rv.data(), rvs[0], hipMemcpyHostToDevice, s), AACG_ERR_NO_DEVICE);
+    if (rvs[1]) HIP_TRY(e, hipMemcpyAsync(sl.d_rv[1], h.links_rv.data(), rvs[1], hipMemcpyHostToDevice, s), AACG_ERR_NO_DEVICE);
     if (tb) HIP_TRY(e, hipMemcpyAsync(sl.d_tns, h.tns.data(), tb, hipMemcpyHostToDevice, s), AACG_ERR_NO_DEVICE);
     for (int i = 0; i < 3; i++) if (ccb[i]) HIP_TRY(e, hipMemcpyAsync(sl.d_cce[i], cce_src[i], ccb[i], hipMemcpyHostToDevice, s), AACG_ERR_NO_DEVICE);
     HIP_TRY(e, hipMemcpyAsync(sl.d_coeffs, src_coeffs, cb, hipMemcpyHostToDevice, s), AACG_ERR_NO_DEVICE);
@@ -878,7 +925,8 @@ int aacg_submit_ex(aacg_engine* e, const aacg_batch* batch, uint64_t* ticket)
     if (e->last_kernel) HIP_TRY(e, hipStreamWaitEvent(s, e->last_kernel, 0), AACG_ERR_NO_DEVICE);
     rc = launch_run(e, (const aacg_dev_unit*)sl.d_units, (const aacg_run*)sl.d_runs, (const aacg_dev_tns*)sl.d_tns,
                     (float*)sl.d_scratch, (float*)sl.d_spec, cce_bufs{(const aacg_run*)sl.d_cce[0], (const aacg_couple_job*)sl.d_cce[1], (const float*)sl.d_cce[2], (float*)sl.d_cce[3]},
-                    run8_bufs{(const aacg_run8*)sl.d_run8[0], (unsigned long long*)sl.d_run8[1], (float*)sl.d_run8[2]}, h, sl.d_coeffs,
+                    run8_bufs{(const aacg_run8*)sl.d_run8[0], (unsigned long long*)sl.d_run8[1], (float*)sl.d_run8[2]},
+                    rv_bufs{(const aacg_run*)sl.d_rv[0], (const aacg_rv_link*)sl.d_rv[1], (unsigned long long*)sl.d_rv[2], (float*)sl.d_rv[3]}, h, sl.d_coeffs,
                     (const aacg_band_meta*)sl.d_meta, sl.d_pcm, 0, s);
     if (rc) return rc;
     HIP_TRY(e, hipEventRecord(sl.kernel_done, s), AACG_ERR_NO_DEVICE);

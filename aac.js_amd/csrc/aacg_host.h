@@ -42,6 +42,11 @@ struct aacg_plan_host {
      * channel per run, consecutive runs of a chain joined by a rendezvous cell instead of a recomputed frame */
     std::vector<aacg_run8>  runs8;
     uint32_t n_links = 0;
+    /* chains longer than a run for the 16-wave kernels WITHOUT a recomputed frame (_rv builds): every run up to 16 frames,
+     * consecutive runs of a chain joined by a rendezvous cell; empty when no chain is longer than a run */
+    std::vector<aacg_run>     runs_rv;
+    std::vector<aacg_rv_link> links_rv;     /* one per run, same order */
+    uint32_t n_links_rv = 0;
     /* AACG_CCE_SPEC: independently switched coupling elements run through the filterbank like any channel, but into a
      * side buffer (cce_runs: their own launch); coupling jobs by coupling point and by round (round r: the r-th coupling
      * element of its frame, so that no two jobs of a round add to the same channel) */

@@ -1503,14 +1503,14 @@ DP_DEVICE void overlap_add_in_place(float* prev, int n_ch, int cls0, int cls1, i
 /* ------------------------------------------------------------------------------------ */
 /* (ov0[n], ov1[n], ov0[n+1], ov1[n+1]) of the incoming tails: FROM_LDS: the previous wave's slot
  * (interleaved for a CPE, planar for one channel); else the overlap state in HBM (planar). */
-template <bool FROM_LDS>
+template <bool FROM_LDS, bool SC1 = false>            /* SC1: a rendezvous payload another workgroup wrote in this launch: agent-scope loads */
 DP_DEVICE dpf4 incoming(const float* p0, const float* p1, int n_ch, int n)
 {
     dpf4 r;
     if (FROM_LDS && n_ch == 2) return *(const dpf4*)(p0 + 2 * n);
-    const dpf2 a = *(const dpf2*)(p0 + n);
+    const dpf2 a = (!FROM_LDS && SC1) ? dp_g_load_f2(p0 + n) : *(const dpf2*)(p0 + n);
     r.x = a.x; r.z = a.y; r.y = 0.0f; r.w = 0.0f;
-    if (n_ch == 2) { const dpf2 b = *(const dpf2*)(p1 + n); r.y = b.x; r.w = b.y; }
+    if (n_ch == 2) { const dpf2 b = (!FROM_LDS && SC1) ? dp_g_load_f2(p1 + n) : *(const dpf2*)(p1 + n); r.y = b.x; r.w = b.y; }
     return r;
 }
 
@@ -1553,7 +1553,7 @@ DP_DEVICE void couple_prefetch(const aacg_kparams& P, const unit_view& u, cpl_pr
     }
 }
 
-template <bool FROM_LDS, int OUT, bool CPL = false>
+template <bool FROM_LDS, int OUT, bool CPL = false, bool SC1 = false>
 DP_DEVICE void epilogue(const aacg_kparams& P, const cpl_prefetch& pre, const float* p0, const float* p1, const unit_view& u, int n_ch, int cls0, int cls1,
                         float* pcm_base_f32, const float (&hx0)[8], const float (&hy0)[8],
                         const float (&hx1)[8], const float (&hy1)[8], int lcol /* the lane's column in the long lane map: long_col(lane) or lane */)
@@ -1577,7 +1577,7 @@ DP_DEVICE void epilogue(const aacg_kparams& P, const cpl_prefetch& pre, const fl
             /* all eight reads of the incoming tails first: one LDS (or HBM) round trip, not one per store */
             dpf4 v[8];
 #pragma unroll
-            for (int m = 0; m < 8; m++) v[m] = incoming<FROM_LDS>(p0, p1, 2, 2 * lcol + 128 * m);
+            for (int m = 0; m < 8; m++) v[m] = incoming<FROM_LDS, SC1>(p0, p1, 2, 2 * lcol + 128 * m);
 #pragma unroll
             for (int m = 0; m < 8; m++) {
                 const int n = 2 * lcol + 128 * m;
@@ -1588,7 +1588,7 @@ DP_DEVICE void epilogue(const aacg_kparams& P, const cpl_prefetch& pre, const fl
             for (int m = 0; m < 8; m++) {
                 if (w < 4 || (w == 4 && m < 4)) {
                     const int n = 448 + 128 * w + 2 * g + 16 * m;
-                    const dpf4 v = incoming<FROM_LDS>(p0, p1, 2, n);
+                    const dpf4 v = incoming<FROM_LDS, SC1>(p0, p1, 2, n);
                     pcm_put4(pcm + 2 * n, v.x + hx0[m], v.y + hx1[m], v.z + hy0[m], v.w + hy1[m]);
                 }
             }
@@ -1596,7 +1596,7 @@ DP_DEVICE void epilogue(const aacg_kparams& P, const cpl_prefetch& pre, const fl
             for (int t4 = 0; t4 < 4; t4++) {           /* out[0..447] = overlap (filter_bank.js:149-151) */
                 const int n = 2 * lane + 128 * t4;
                 if (n < 448) {
-                    const dpf4 v = incoming<FROM_LDS>(p0, p1, 2, n);
+                    const dpf4 v = incoming<FROM_LDS, SC1>(p0, p1, 2, n);
                     pcm_put4(pcm + 2 * n, v.x, v.y, v.z, v.w);
                 }
             }
@@ -1675,7 +1675,7 @@ DP_DEVICE void epilogue(const aacg_kparams& P, const cpl_prefetch& pre, const fl
              * behind every store is a memory round trip each (a chain's first frame takes its state from HBM) */
             dpf4 v[8];
 #pragma unroll
-            for (int m = 0; m < 8; m++) v[m] = incoming<FROM_LDS>(p0, p1, 2, 2 * lcol + 128 * m);
+            for (int m = 0; m < 8; m++) v[m] = incoming<FROM_LDS, SC1>(p0, p1, 2, 2 * lcol + 128 * m);
 #pragma unroll
             for (int m = 0; m < 8; m++) {
                 const int n = 2 * lcol + 128 * m;
@@ -1687,7 +1687,7 @@ DP_DEVICE void epilogue(const aacg_kparams& P, const cpl_prefetch& pre, const fl
             for (int m = 0; m < 8; m++) {
                 if (w < 4 || (w == 4 && m < 4)) {
                     const int n = 448 + 128 * w + 2 * g + 16 * m;
-                    const dpf4 v = incoming<FROM_LDS>(p0, p1, 2, n);
+                    const dpf4 v = incoming<FROM_LDS, SC1>(p0, p1, 2, n);
                     pcm_put2(pcm + (size_t)n * C, v.x + hx0[m], v.y + hx1[m]);
                     pcm_put2(pcm + (size_t)(n + 1) * C, v.z + hy0[m], v.w + hy1[m]);
                 }
@@ -1696,7 +1696,7 @@ DP_DEVICE void epilogue(const aacg_kparams& P, const cpl_prefetch& pre, const fl
             for (int t4 = 0; t4 < 4; t4++) {
                 const int n = 2 * lane + 128 * t4;
                 if (n < 448) {
-                    const dpf4 v = incoming<FROM_LDS>(p0, p1, 2, n);
+                    const dpf4 v = incoming<FROM_LDS, SC1>(p0, p1, 2, n);
                     pcm_put2(pcm + (size_t)n * C, v.x, v.y);
                     pcm_put2(pcm + (size_t)(n + 1) * C, v.z, v.w);
                 }
@@ -1724,7 +1724,7 @@ DP_DEVICE void epilogue(const aacg_kparams& P, const cpl_prefetch& pre, const fl
                     if (i < 8) { pos[i] = cls ? 448 + 128 * w + 2 * g + 16 * m : 2 * lcol + 128 * m; ok[i] = !cls || w < 4 || (w == 4 && m < 4); }
                     else       { pos[i] = 2 * lane + 128 * t4; ok[i] = cls && pos[i] < 448; }
                     if (!ok[i]) pos[i] = 0;
-                    const dpf4 v = incoming<FROM_LDS>(p0, p1, n_ch, pos[i]);
+                    const dpf4 v = incoming<FROM_LDS, SC1>(p0, p1, n_ch, pos[i]);
                     x[i] = (c ? v.y : v.x) + (i < 8 ? hx[m] : 0.0f);
                     y[i] = (c ? v.w : v.z) + (i < 8 ? hy[m] : 0.0f);
                 }
@@ -1759,7 +1759,7 @@ DP_DEVICE void epilogue(const aacg_kparams& P, const cpl_prefetch& pre, const fl
             if (!cls) {
                 dpf4 v[8];                              /* reads first, as above */
 #pragma unroll
-                for (int m = 0; m < 8; m++) v[m] = incoming<FROM_LDS>(p0, p1, n_ch, 2 * lcol + 128 * m);
+                for (int m = 0; m < 8; m++) v[m] = incoming<FROM_LDS, SC1>(p0, p1, n_ch, 2 * lcol + 128 * m);
 #pragma unroll
                 for (int m = 0; m < 8; m++) {
                     const int n = 2 * lcol + 128 * m;
@@ -1771,7 +1771,7 @@ DP_DEVICE void epilogue(const aacg_kparams& P, const cpl_prefetch& pre, const fl
                 for (int m = 0; m < 8; m++) {
                     if (w < 4 || (w == 4 && m < 4)) {
                         const int n = 448 + 128 * w + 2 * g + 16 * m;
-                        const dpf4 v = incoming<FROM_LDS>(p0, p1, n_ch, n);
+                        const dpf4 v = incoming<FROM_LDS, SC1>(p0, p1, n_ch, n);
                         pcm_put1(dst + (size_t)n * C, (c ? v.y : v.x) + hx[m]);
                         pcm_put1(dst + (size_t)(n + 1) * C, (c ? v.w : v.z) + hy[m]);
                     }
@@ -1780,12 +1780,96 @@ DP_DEVICE void epilogue(const aacg_kparams& P, const cpl_prefetch& pre, const fl
                 for (int t4 = 0; t4 < 4; t4++) {
                     const int n = 2 * lane + 128 * t4;
                     if (n < 448) {
-                        const dpf4 v = incoming<FROM_LDS>(p0, p1, n_ch, n);
+                        const dpf4 v = incoming<FROM_LDS, SC1>(p0, p1, n_ch, n);
                         pcm_put1(dst + (size_t)n * C, c ? v.y : v.x);
                         pcm_put1(dst + (size_t)(n + 1) * C, c ? v.w : v.z);
                     }
                 }
             }
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* run-to-run rendezvous of the _rv builds (aacg_rv_args, aacg_device.h)                      */
+/* ------------------------------------------------------------------------------------ */
+#define AACG_RV_TAIL 1ull
+#define AACG_RV_HEAD 2ull
+/* a wave's windowed first half (hx / hy in the IMDCT lane map) as planar [channel][1024] floats in a rendezvous payload:
+ * -0.0 where the sequence takes the sample from the overlap alone (EIGHT_SHORT: 0..447), so that tail + head = tail there */
+DP_DEVICE void rv_publish_head(float* d0, float* d1, int n_ch, int cls0, int cls1, int lcol,
+                               const float (&hx0)[8], const float (&hy0)[8], const float (&hx1)[8], const float (&hy1)[8])
+{
+    const int lane = dp_lane(), w = lane >> 3, g = lane & 7;
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        if (c < n_ch) {
+            float* d = c ? d1 : d0;
+            const int cls = c ? cls1 : cls0;
+            const float (&hx)[8] = c ? hx1 : hx0;
+            const float (&hy)[8] = c ? hy1 : hy0;
+            if (!cls) {
+#pragma unroll
+                for (int m = 0; m < 8; m++) dp_g_store_f2(d + 2 * lcol + 128 * m, hx[m], hy[m]);
+            } else {
+#pragma unroll
+                for (int m = 0; m < 8; m++)
+                    if (w < 4 || (w == 4 && m < 4)) dp_g_store_f2(d + 448 + 128 * w + 2 * g + 16 * m, hx[m], hy[m]);
+#pragma unroll
+                for (int t4 = 0; t4 < 4; t4++) {
+                    const int n = 2 * lane + 128 * t4;
+                    if (n < 448) dp_g_store_f2(d + n, -0.0f, -0.0f);
+                }
+            }
+        }
+    }
+}
+/* the tails in a wave's slot (interleaved for two channels) as planar arrays in a rendezvous payload */
+DP_DEVICE void rv_publish_tails(const float* slot, int n_ch, float* d0, float* d1)
+{
+    const int lane = dp_lane();
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const int n = 2 * lane + 128 * i;
+        if (n_ch == 2) {
+            const dpf4 a = *(const dpf4*)(slot + 2 * n);           /* (L[n], R[n], L[n+1], R[n+1]) */
+            dp_g_store_f2(d0 + n, a.x, a.z);
+            dp_g_store_f2(d1 + n, a.y, a.w);
+        } else {
+            const dpf2 a = *(const dpf2*)(slot + n);
+            dp_g_store_f2(d0 + n, a.x, a.y);
+        }
+    }
+}
+/* the run that arrives second at a rendezvous whose other side left its windowed first half: the next run's first frame =
+ * this wave's tails (its slot) + that first half, to that frame's place in the PCM (su: its unit) */
+template <int OUT>
+DP_DEVICE void rv_finish_successor(const aacg_kparams& P, const unit_view& su, int n_ch, const float* slot, const float* h0, const float* h1)
+{
+#pragma clang fp contract(off)
+    typedef typename pcm_elem<OUT>::type elem;
+    const int lane = dp_lane(), C = su.n_out_ch;
+    elem* pcm = (elem*)P.pcm + su.pcm_offset + su.channel;
+    if (n_ch == 2 && C == 2 && ((su.pcm_offset | (uint32_t)su.channel) & 3u) == 0) {
+        dpf2 hl[8], hr[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) { const int n = 2 * lane + 128 * i; hl[i] = dp_g_load_f2(h0 + n); hr[i] = dp_g_load_f2(h1 + n); }
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int n = 2 * lane + 128 * i;
+            const dpf4 t = *(const dpf4*)(slot + 2 * n);
+            pcm_put4(pcm + 2 * n, t.x + hl[i].x, t.y + hr[i].x, t.z + hl[i].y, t.w + hr[i].y);
+        }
+        return;
+    }
+#pragma unroll 4
+    for (int j = 0; j < 16; j++) {
+        const int n = lane + 64 * j;
+        if (n_ch == 2) {
+            const dpf2 t = *(const dpf2*)(slot + 2 * n);
+            pcm_put2(pcm + (size_t)n * C, t.x + dp_g_load_f1(h0 + n), t.y + dp_g_load_f1(h1 + n));
+        } else {
+            pcm_put1(pcm + (size_t)n * C, slot[n] + dp_g_load_f1(h0 + n));
         }
     }
 }
@@ -1807,8 +1891,10 @@ DP_DEVICE void epilogue(const aacg_kparams& P, const cpl_prefetch& pre, const fl
 #define AACG_RUN_XCH_FLOATS AACG_TNS_XCH_FLOATS(AACG_RUN_TNS_ROUND)
 #define AACG_LDS_BYTES_F32_EX   (AACG_LDS_BYTES_F32 + 4 * AACG_WG_WAVES * AACG_RUN_XCH_FLOATS)
 #define AACG_LDS_BYTES_QUANT_EX (AACG_LDS_BYTES_QUANT + 4 * AACG_WG_WAVES * AACG_RUN_XCH_FLOATS)
-template <int KIND, int OUT = AACG_OUTPUT_F32, bool DD = false, bool EX = false, bool CPL = false>
-DP_DEVICE void imdct_run_body(const aacg_kparams& P)
+/* RV = true builds (aacg_engine_rv.hip): chains longer than a run without a recomputed frame — the plan's runs all start from
+ * what the run before them hands over through a rendezvous cell (aacg_rv_args), never from a recomputed predecessor. */
+template <int KIND, int OUT = AACG_OUTPUT_F32, bool DD = false, bool EX = false, bool CPL = false, bool RV = false>
+DP_DEVICE void imdct_run_body(const aacg_kparams& P, const aacg_rv_args* V = nullptr)
 {
     const int TAB_FLOATS = (KIND == AACG_INPUT_QUANT_I16) ? AACG_TAB_QUANT_FLOATS : AACG_TAB_F32_FLOATS;
     const int lane = dp_lane(), wave = dp_wave();
@@ -1826,7 +1912,11 @@ DP_DEVICE void imdct_run_body(const aacg_kparams& P)
     stage_tables_load(P.tab, TAB_FLOATS, tr0, tr1);
 
     const int n_units = run->n_units;
-    const bool has_pred = run->pred_unit >= 0;
+    const bool has_pred = !RV && run->pred_unit >= 0;
+    aacg_rv_link lk; lk.link_in = lk.link_out = lk.succ_unit = -1; lk.reserved = 0;
+    if (RV) lk = V->links[dp_block()];
+    /* the frame another workgroup may be waiting for: a run's last, when its chain goes on */
+    const bool hands_over = RV && lk.link_out >= 0 && wave == n_units - 1;
     /* A later run of a chain starts from the tail of the frame before it, which another workgroup owns, so it
      * recomputes that frame's IMDCT.  With up to 15 frames wave 0 does only that (waves 1.. own the frames);
      * a full run of 16 frames gives wave 0 double duty: first the predecessor (its tail goes to a scratch
@@ -1846,7 +1936,7 @@ DP_DEVICE void imdct_run_body(const aacg_kparams& P)
     /* Earlier frames get the higher issue priority: they finish first and their PCM stores overlap
      * the later waves' arithmetic.  A wave only ever waits for the wave before it, whose priority is
      * never lower, so a spinning consumer cannot starve its producer. */
-    if (AACG_ABL(P, 64)) dp_setprio(0); else if (AACG_ABL(P, 32)) dp_setprio(1 - (wave >> 3)); else dp_setprio(3 - (wave >> 2));
+    if (AACG_ABL(P, 64)) dp_setprio(0); else if (AACG_ABL(P, 32)) dp_setprio(1 - (wave >> 3)); else dp_setprio(hands_over ? 3 : 3 - (wave >> 2));
     const unsigned long long t_start = AACG_ABL(P, 16) ? dp_clock() : 0;
     /* (the coupling builds carry their side buffer in spec_out, aacg_set_cpl: never a trace there) */
     unsigned long long* trace = (!CPL && AACG_ABL(P, 16)) ? (unsigned long long*)P.spec_out + ((size_t)dp_block() * AACG_WG_WAVES + wave) * 8 : nullptr;
@@ -1895,7 +1985,7 @@ DP_DEVICE void imdct_run_body(const aacg_kparams& P)
      * join), and only then do the other twelve waves issue their requests.  The first group therefore sees
      * its data after ~1.7 us instead of queueing behind the whole chip's 33 MB, and the later groups' data
      * arrives while the SIMD is still busy with the earlier ones. */
-    const bool early = wave < (KIND == AACG_INPUT_QUANT_I16 ? 2 : 4) || AACG_ABL(P, 128);
+    const bool early = wave < (KIND == AACG_INPUT_QUANT_I16 ? 2 : 4) || hands_over || AACG_ABL(P, 128);
     if (early) issue_loads();
     stage_tables_store(lds, TAB_FLOATS, tr0, tr1);
     if (lane == 0) flags[wave] = 0;
@@ -2000,6 +2090,29 @@ DP_DEVICE void imdct_run_body(const aacg_kparams& P)
     if (lane == 0) dp_flag_set(&flags[wave], 1);
     if (trace && lane == 0) trace[3] = dp_clock();         /* IMDCT done, tail released */
 
+    const unsigned long long rv_tag = RV ? V->epoch << 2 : 0ull;
+    if (RV && hands_over && ui >= 0) {
+        /* the chain goes on in another workgroup: publish this frame's tails — or, if that workgroup was here first and left
+         * its windowed first half, finish its frame (nobody waits for anybody: no dispatch order is assumed) */
+        dp_keep_branch();
+        unsigned long long* st = V->state + (size_t)lk.link_out * AACG8_RV_STATE_WORDS;
+        float* data = V->data + (size_t)lk.link_out * AACG8_RV_DATA_FLOATS;
+        const unsigned long long seen = dp_first_u64(dp_g_load_u64(st));
+        bool theirs = seen == (rv_tag | AACG_RV_HEAD);
+        if (!theirs) {
+            rv_publish_tails(slot, n_ch, data, data + 1024);
+            dp_vm_drain();
+            dp_wave_sync();
+            bool won = true;
+            if (lane == 0) won = dp_g_cas_u64(st, seen, rv_tag | AACG_RV_TAIL);
+            theirs = dp_first_u64(won ? 0ull : 1ull) != 0ull;
+        }
+        if (theirs) {
+            const unit_view su = load_unit(P.units + dp_uniform(lk.succ_unit));
+            rv_finish_successor<OUT>(P, su, n_ch, slot, data + 2048, data + 2048 + 1024);
+        }
+    }
+
     if (ui >= 0 && !is_pred_wave && AACG_ABL(P, 2)) {
         /* profiling: keep the values live without storing 8 KiB of PCM */
         float acc = 0.0f;
@@ -2015,6 +2128,24 @@ DP_DEVICE void imdct_run_body(const aacg_kparams& P)
             const float* ov0 = n_pass == 2 ? scratch : P.overlap + (P.flip ? run->ov_b[0] : run->ov_a[0]);
             const float* ov1 = n_pass == 2 ? scratch + 1024 : P.overlap + (P.flip ? run->ov_b[1] : run->ov_a[1]);
             cpl_prefetch none; none.n = 0;
+            if (RV && lk.link_in >= 0) {
+                /* first frame of a later run: the tails the run before it published — or, if they are not there yet, leave the
+                 * windowed first half for that run and go */
+                dp_keep_branch();
+                unsigned long long* st = V->state + (size_t)lk.link_in * AACG8_RV_STATE_WORDS;
+                float* data = V->data + (size_t)lk.link_in * AACG8_RV_DATA_FLOATS;
+                const unsigned long long seen = dp_first_u64(dp_g_load_u64(st));
+                bool theirs = seen == (rv_tag | AACG_RV_TAIL);
+                if (!theirs) {
+                    rv_publish_head(data + 2048, data + 2048 + 1024, n_ch, cls0, cls1, lcol, hx0, hy0, hx1, hy1);
+                    dp_vm_drain();
+                    dp_wave_sync();
+                    bool won = true;
+                    if (lane == 0) won = dp_g_cas_u64(st, seen, rv_tag | AACG_RV_HEAD);
+                    theirs = dp_first_u64(won ? 0ull : 1ull) != 0ull;
+                }
+                if (theirs) epilogue<false, OUT, CPL, true>(P, none, data, data + 1024, u, n_ch, cls0, cls1, P.pcm, hx0, hy0, hx1, hy1, lcol);
+            } else
             epilogue<false, OUT, CPL>(P, none, ov0, ov1, u, n_ch, cls0, cls1, P.pcm, hx0, hy0, hx1, hy1, lcol);
         } else {
             cpl_prefetch pre;

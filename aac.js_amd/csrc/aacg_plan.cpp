@@ -359,6 +359,9 @@ int aacg_plan_build(const aacg_unit_desc* units, uint32_t n_units, int sample_in
     /* chains -> runs, generated chain by chain */
     std::vector<aacg_run> gen, cce_gen;
     std::vector<aacg_run8> gen8;
+    std::vector<aacg_run> gen_rv;
+    std::vector<aacg_rv_link> gen_rv_links;
+    bool long_chain = false;
     for (auto& kv : open) {
         const open_chain& oc = kv.second;
         aacg_chain ch;
@@ -397,6 +400,33 @@ int aacg_plan_build(const aacg_unit_desc* units, uint32_t n_units, int sample_in
         }
         ch.n_runs = oc.is_cce ? 0 : (uint32_t)gen.size() - ch.first_run;
         out->chains.push_back(ch);
+        /* the same chain for the 16-wave kernels with a rendezvous between its runs instead of a recomputed frame */
+        if (!oc.is_cce) {
+            if (n > AACG_RUN_W) long_chain = true;
+            int32_t link = -1;
+            for (size_t pos = 0; pos < n; pos += AACG_RUN_W) {
+                aacg_run r;
+                r.pred_unit = -1;
+                r.n_units = (int32_t)std::min<size_t>(AACG_RUN_W, n - pos);
+                for (int k = 0; k < AACG_RUN_W; k++) r.unit[k] = k < r.n_units ? oc.units[pos + k] : -1;
+                for (int c = 0; c < 2; c++) {
+                    const uint32_t chn = ch.channel + (c < oc.n_ch ? c : 0);
+                    r.ov_a[c] = aacg_ov_offset(max_channels, ch.stream, chn, ch.parity[c]);
+                    r.ov_b[c] = aacg_ov_offset(max_channels, ch.stream, chn, ch.parity[c] ^ 1);
+                }
+                const bool more = pos + AACG_RUN_W < n;
+                r.is_last = more ? 0 : 1;
+                r.reserved = 0;
+                aacg_rv_link lk;
+                lk.link_in = link;
+                link = more ? (int32_t)out->n_links_rv++ : -1;
+                lk.link_out = link;
+                lk.succ_unit = more ? oc.units[pos + AACG_RUN_W] : -1;
+                lk.reserved = 0;
+                gen_rv.push_back(r);
+                gen_rv_links.push_back(lk);
+            }
+        }
         /* the same chain for the one-channel-per-wave kernels: a workgroup's 16 waves hold 8 frames of a pair or 16 of a single
          * channel; a later run takes its predecessor's tail through rendezvous cell link_in (no recomputed frame) */
         if (!oc.is_cce) {
@@ -473,6 +503,16 @@ int aacg_plan_build(const aacg_unit_desc* units, uint32_t n_units, int sample_in
         const size_t cnt = (R8 - 1 - x) / 8 + 1;
         for (size_t s = 0; s < cnt; s++) out->runs8[s * 8 + x] = gen8[i++];
     }
+    if (long_chain) {
+        const size_t RR = gen_rv.size();
+        out->runs_rv.resize(RR);
+        out->links_rv.resize(RR);
+        i = 0;
+        for (size_t x = 0; x < 8 && x < RR; x++) {
+            const size_t cnt = (RR - 1 - x) / 8 + 1;
+            for (size_t s = 0; s < cnt; s++) { out->runs_rv[s * 8 + x] = gen_rv[i]; out->links_rv[s * 8 + x] = gen_rv_links[i]; i++; }
+        }
+    } else out->n_links_rv = 0;
     out->cce_runs = cce_gen;
     /* chain.first_run refers to generation order; the engine only needs counts, keep as is */
     return AACG_OK;

@@ -480,10 +480,13 @@ int aacg_debug_transform(int device_ordinal, int sample_index, int is_short, int
  * AACG_DEBUG_ROUTE_NARROW_KERNELS: plain batches (float PCM, no optional stage, no coupling element) on the one-channel-per-wave
  * kernels (aacg_kernels8.h: 8 waves per SIMD, run-to-run rendezvous) instead of the 16-wave kernels (a channel pair per wave,
  * aacg_kernels.h) the engine takes by default; AACG_DEBUG_ROUTE_WIDE_KERNELS: the 16-wave kernels even where the environment
- * (AACG_RUN8=1) asks for the others.  Set before the plan is made. */
+ * (AACG_RUN8=1) asks for the others.  AACG_DEBUG_ROUTE_RECOMPUTE: chains longer than a run the old way — every later run recomputes
+ * the frame before it (aacg_imdct_run_*_dd) — instead of the run-to-run rendezvous (aacg_imdct_run_*_rv) the engine takes for plain
+ * batches; both must produce the same bits.  Set before the plan is made. */
 #define AACG_DEBUG_ROUTE_UNFUSED_COUPLING 1
 #define AACG_DEBUG_ROUTE_WIDE_KERNELS     2
 #define AACG_DEBUG_ROUTE_NARROW_KERNELS   4
+#define AACG_DEBUG_ROUTE_RECOMPUTE        8
 int aacg_debug_set_route(aacg_engine* e, int flags);
 
 #ifdef __cplusplus

@@ -27,6 +27,7 @@ struct launch_arg {
     int out_kind;
     const aacg_couple_params* Q;
     const aacg_kparams8* P8;
+    const aacg_rv_args* V;
 };
 
 void* lane_main(void* p)
@@ -35,6 +36,8 @@ void* lane_main(void* p)
     g_emu = a->ctx;
     /* the same dispatch as the engine's launch_run: double-duty variant / plain; kinds 3, 4: the optional-stage kernel */
     if (a->kind == 7) { aacg_parse::parse_body(*a->PP); return nullptr; }
+    if (a->kind == 14) { imdct_run_body<AACG_INPUT_SPEC_F32, AACG_OUTPUT_F32, false, false, false, true>(*a->P, a->V); return nullptr; }     /* aacg_imdct_run_f32_rv */
+    if (a->kind == 15) { imdct_run_body<AACG_INPUT_QUANT_I16, AACG_OUTPUT_F32, false, false, false, true>(*a->P, a->V); return nullptr; }    /* aacg_imdct_run_quant_rv */
     if (a->kind == 12) { imdct_run8_body<AACG_INPUT_SPEC_F32>(*a->P8); return nullptr; }      /* aacg_imdct_run8_f32 */
     if (a->kind == 13) { imdct_run8_body<AACG_INPUT_QUANT_I16>(*a->P8); return nullptr; }     /* aacg_imdct_run8_quant */
     if (a->kind == 8) { couple_spec_body(*a->Q, 4); return nullptr; }
@@ -57,10 +60,11 @@ void* lane_main(void* p)
 int g_out_kind = AACG_OUTPUT_F32;          /* emu_set_output_kind: the next decodes store int16 PCM */
 int g_unfused = 0;                         /* emu_set_unfused: independent coupling as the separate pass over the PCM even where the engine fuses it */
 int g_run8 = 0;                            /* emu_set_run8: plain batches on the one-channel-per-wave kernels (the engine's opt-in route) */
+int g_rv = 1;                              /* emu_set_rv: chains longer than a run through the run-to-run rendezvous (the engine's route; 2: blocks in reverse); 0: recomputed frames */
 int g_staged = 0;                          /* emu_set_staged: optional stages as a launch of their own even where the engine would not */
 
 void launch(const aacg_kparams& P, int kind, int grid, int waves, size_t lds_bytes, int n_units = 0, const aacg_parse_params* PP = nullptr,
-            const aacg_couple_params* Q = nullptr, const aacg_kparams8* P8 = nullptr)
+            const aacg_couple_params* Q = nullptr, const aacg_kparams8* P8 = nullptr, const aacg_rv_args* V = nullptr)
 {
     const int threads = waves * 64;
     std::vector<emu_wave> wv((size_t)waves);
@@ -87,6 +91,7 @@ void launch(const aacg_kparams& P, int kind, int grid, int waves, size_t lds_byt
             args[(size_t)t].out_kind = g_out_kind;
             args[(size_t)t].Q = Q;
             args[(size_t)t].P8 = P8;
+            args[(size_t)t].V = V;
             pthread_create(&tid[(size_t)t], &attr, lane_main, &args[(size_t)t]);
         }
         for (int t = 0; t < threads; t++) pthread_join(tid[(size_t)t], nullptr);
@@ -108,6 +113,7 @@ extern "C" {
 const char* emu_last_error() { return g_err.c_str(); }
 void emu_set_staged(int on) { g_staged = on; }
 void emu_set_run8(int on) { g_run8 = on; }
+void emu_set_rv(int on) { g_rv = on; }
 void emu_set_unfused(int on) { g_unfused = on; }
 void emu_set_output_kind(int kind) { g_out_kind = kind; }       /* AACG_OUTPUT_*: the pcm buffer of later decodes is int16 */
 
@@ -305,6 +311,21 @@ int emu_decode_cce(int input_kind, int sample_index, int max_streams, int max_ch
         P8.n_runs = (int32_t)runs8.size();
         launch(P, input_kind == AACG_INPUT_QUANT_I16 ? 13 : 12, (int)runs8.size(), AACG_WG_WAVES,
                input_kind == AACG_INPUT_QUANT_I16 ? AACG8_LDS_BYTES(AACG8_TAB_QUANT_FLOATS) : AACG8_LDS_BYTES(AACG8_TAB_F32_FLOATS), 0, nullptr, nullptr, &P8);
+    } else if (!ph.runs_rv.empty() && g_rv && g_out_kind == AACG_OUTPUT_F32 && !ph.any_cce && !ph.any_tns && !ph.any_pns) {
+        /* the engine's route for plain batches with a chain longer than a run: every run 16 frames, a rendezvous between
+         * consecutive runs (imdct_run_body<..., RV>); block order forward or — g_rv == 2 — reversed */
+        static unsigned long long epoch = 1000;
+        std::vector<unsigned long long> rv_state((size_t)ph.n_links_rv * AACG8_RV_STATE_WORDS + 1, 0x5a5a5a5a5a5a5a5aull);
+        std::vector<float> rv_data((size_t)ph.n_links_rv * AACG8_RV_DATA_FLOATS + 1, std::numeric_limits<float>::quiet_NaN());
+        std::vector<aacg_run> runs = ph.runs_rv;
+        std::vector<aacg_rv_link> links = ph.links_rv;
+        if (g_rv == 2) { std::reverse(runs.begin(), runs.end()); std::reverse(links.begin(), links.end()); }
+        aacg_kparams R = P;
+        R.runs = runs.data(); R.n_runs = (int32_t)runs.size(); R.scratch = nullptr;
+        aacg_rv_args V;
+        V.links = links.data(); V.state = rv_state.data(); V.data = rv_data.data(); V.epoch = ++epoch;
+        launch(R, input_kind == AACG_INPUT_QUANT_I16 ? 15 : 14, (int)runs.size(), AACG_WG_WAVES,
+               input_kind == AACG_INPUT_QUANT_I16 ? AACG_LDS_BYTES_QUANT : AACG_LDS_BYTES_F32, 0, nullptr, nullptr, nullptr, &V);
     } else if (!ph.runs.empty())
         launch(P, input_kind == AACG_INPUT_QUANT_I16 ? 1 : 0, (int)ph.runs.size(), AACG_WG_WAVES,
                input_kind == AACG_INPUT_QUANT_I16 ? AACG_LDS_BYTES_QUANT : AACG_LDS_BYTES_F32);

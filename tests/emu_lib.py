@@ -40,7 +40,7 @@ class Emu:
     def error(self):
         return self.lib.emu_last_error().decode()
 
-    def decode(self, units, coeffs, meta, n_pcm, pool, parity, sample_index=3, tns=None, pns=False, int16_out=False, cce=None, staged=False, unfused=False, run8=0):
+    def decode(self, units, coeffs, meta, n_pcm, pool, parity, sample_index=3, tns=None, pns=False, int16_out=False, cce=None, staged=False, unfused=False, run8=0, rv=1):
         """staged: the optional stages (TNS, PNS) as a launch of their own even where the engine would run them inside the run kernel.
         unfused: independent coupling as the separate pass over the PCM (what plans with double-duty runs take) even where the
         engine applies it in the targets' epilogues."""
@@ -53,6 +53,7 @@ class Emu:
         self.lib.emu_set_output_kind(1 if int16_out else 0)
         self.lib.emu_set_staged(1 if staged else 0)
         self.lib.emu_set_unfused(1 if unfused else 0)
+        self.lib.emu_set_rv(rv)           # 1: chains longer than a run through the run-to-run rendezvous (the engine's route); 2: blocks in reverse; 0: recomputed frames
         self.lib.emu_set_run8(run8)       # 0: the 16-wave kernels (the engine's default); 1: plain batches on the one-channel-per-wave kernels; 2: the same, workgroups in reverse order
         cce = np.ascontiguousarray(cce) if cce is not None else None
         rc = self.lib.emu_decode_cce(kind, sample_index, pool.shape[0], pool.shape[1], units.ctypes.data, len(units),
@@ -64,6 +65,7 @@ class Emu:
         self.lib.emu_set_staged(0)
         self.lib.emu_set_unfused(0)
         self.lib.emu_set_run8(0)
+        self.lib.emu_set_rv(1)
         if rc:
             raise RuntimeError("emu_decode rc=%d: %s" % (rc, self.error()))
         return pcm

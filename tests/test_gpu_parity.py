@@ -880,3 +880,46 @@ def test_narrow_kernels_same_bits_however_the_batch_is_cut_and_whoever_arrives_f
     assert np.array_equal(got.view(np.uint32), outs[0].view(np.uint32))
     ov = np.zeros((S, 2, 1024), np.float32)
     assert rms(outs[0].reshape(-1), oracle.decode_batch(whole["units"], whole["q"], whole["meta"], whole["n_pcm"], ov)) < RMS_TOL
+
+
+# ---- chains longer than a run: the run-to-run rendezvous of the 16-wave kernels (aacg_imdct_run_*_rv) ------------------------
+@pytest.mark.parametrize("layout,S,T,seam", [(("cpe",), 300, 40, "q"), (("cpe",), 64, 128, "q"), (("cpe",), 40, 33, "f"), (("sce",), 40, 50, "q"),
+                                             (("cpe", "cpe", "cpe", "sce"), 24, 20, "q")])
+def test_rendezvous_between_runs_equals_recomputed_frames(oracle, layout, S, T, seam):
+    """Plain batches with chains longer than 16 frames: the engine's route (every run 16 frames, tails handed over through a
+    rendezvous cell; aacg_imdct_run_*_rv) against the old one (later runs recompute the frame before them: _dd / predecessor
+    waves; forced with AACG_DEBUG_ROUTE_RECOMPUTE) — the same bits, PCM and overlap state, over two chained batches, with more
+    workgroups than the chip holds at once (so that both sides of a rendezvous arrive first somewhere) — and the oracle's values."""
+    wl0 = aacgpu_workload.make_batch(n_streams=S, n_frames=T, layout=layout, mix=True, intensity=True, seed=5200)
+    C = wl0["C"]
+    kind = aacgpu.INPUT_QUANT_I16 if seam == "q" else aacgpu.INPUT_SPEC_F32
+    outs, states, routes = [], [], []
+    for route in (0, 8):                                             # 8 = AACG_DEBUG_ROUTE_RECOMPUTE
+        eng = aacgpu.Engine(kind, max_streams=S, max_channels=C)
+        eng.debug_set_route(route)
+        got = []
+        for batch in range(2):
+            wl = aacgpu_workload.make_batch(n_streams=S, n_frames=T, layout=layout, mix=True, intensity=True, seed=5200 + batch, frame_base=batch * T)
+            coeffs, meta = wl["q"], wl["meta"]
+            if seam == "f":
+                _, spec = oracle.decode_batch(wl["units"], wl["q"], wl["meta"], wl["n_pcm"], np.zeros((S, C, 1024), np.float32), want_spec=True)
+                coeffs, meta = spec.astype(np.float32), None
+            if batch == 0:
+                plan = eng.plan(wl["units"])
+                routes.append(eng.plan_kernels(plan))
+                plan.destroy()
+            got.append(eng.decode_batch(wl["units"], coeffs, meta, wl["n_pcm"]))
+        outs.append(np.concatenate(got))
+        states.append(overlaps(eng, S, C))
+        eng.close()
+    assert routes[0].endswith("_rv") and not routes[1].endswith("_rv")
+    assert np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32))
+    assert np.array_equal(states[0].view(np.uint32), states[1].view(np.uint32))
+    if S * T <= 12000:
+        ov = np.zeros((S, C, 1024), np.float32)
+        ref = []
+        for batch in range(2):
+            wl = aacgpu_workload.make_batch(n_streams=S, n_frames=T, layout=layout, mix=True, intensity=True, seed=5200 + batch, frame_base=batch * T)
+            ref.append(oracle.decode_batch(wl["units"], wl["q"], wl["meta"], wl["n_pcm"], ov))
+        assert rms(outs[0], np.concatenate(ref)) < RMS_TOL
+        assert np.abs(states[0] - ov).max() <= 1e-5 * max(1.0, float(np.abs(ov).max()))

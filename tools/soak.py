@@ -11,7 +11,7 @@ import numpy as np, aacgpu, aacgpu_workload as W, orc
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 o = orc.load()
 rng = np.random.default_rng(20261001)
-t0 = time.time(); n_batches = n_frames = 0; worst = 0.0
+t0 = time.time(); n_batches = n_frames = n_narrow = 0; worst = 0.0
 while time.time() - t0 < budget:
     seed = int(rng.integers(1, 1 << 30))
     if rng.random() < 0.5:
@@ -34,6 +34,11 @@ while time.time() - t0 < budget:
     wl = dict(wl, units=units, meta=meta)
     eng = aacgpu.Engine(aacgpu.INPUT_QUANT_I16, S, C, tns_mode=int(use_tns), pns_mode=int(use_pns))
     engf = aacgpu.Engine(aacgpu.INPUT_SPEC_F32, S, C, tns_mode=int(use_tns))
+    # half of the engines take the one-channel-per-wave kernels for their plain batches (aacg_kernels8.h: the opt-in route)
+    narrow = bool(rng.integers(0, 2))
+    if narrow:
+        eng.debug_set_route(4); engf.debug_set_route(4)
+        n_narrow += 1
     for rep in range(int(rng.integers(1, 4))):                 # consecutive batches of the same streams
         ov_in = ov.copy()
         ref, spec = o.decode_batch(units, wl["q"], meta, wl["n_pcm"], ov, want_spec=True, tns=tns, pns=use_pns)
@@ -53,4 +58,4 @@ while time.time() - t0 < budget:
         assert ov_err < (1e-4 if use_tns else 2e-5), (seed, rep, mode, "overlap", ov_err)
         n_batches += 1; n_frames += len(wl["units"])
     eng.close(); engf.close()
-print("soak ok: %d batches, %d units, worst relative rms error %.2e, %.0f s" % (n_batches, n_frames, worst, time.time() - t0))
+print("soak ok: %d batches, %d units, worst relative rms error %.2e, %.0f s; %d engine pairs on the one-channel-per-wave route" % (n_batches, n_frames, worst, time.time() - t0, n_narrow))
