@@ -317,7 +317,9 @@ int  aacg_plan_create_ex(aacg_engine* e, const aacg_unit_desc* units, uint32_t n
                          const aacg_tns_info* tns, uint32_t n_tns, const aacg_cce_info* cce, uint32_t n_cce, aacg_plan** out);
 void aacg_plan_destroy(aacg_plan* p);
 /* Launch on `hip_stream` (a hipStream_t passed as void*, NULL = the engine's own stream);
- * returns after enqueueing.  d_coeffs / d_meta / d_pcm are DEVICE pointers.            */
+ * returns after enqueueing.  d_coeffs / d_meta / d_pcm are DEVICE pointers.
+ * Every call is a NEW launch: the overlap-buffer parity and — for plans whose chains are longer than a run — the epoch of the
+ * run-to-run rendezvous are arguments of that launch.  Do not capture a launch in a hipGraph and replay it: call again.    */
 int aacg_decode_device(aacg_engine* e, aacg_plan* p,
                        const void* d_coeffs, const aacg_band_meta* d_meta,
                        void* d_pcm, void* hip_stream);
