@@ -894,7 +894,7 @@ def test_rendezvous_between_runs_equals_recomputed_frames(oracle, layout, S, T, 
     C = wl0["C"]
     kind = aacgpu.INPUT_QUANT_I16 if seam == "q" else aacgpu.INPUT_SPEC_F32
     outs, states, routes = [], [], []
-    for route in (0, 8):                                             # 8 = AACG_DEBUG_ROUTE_RECOMPUTE
+    for route in (2, 2 | 8):                                         # 2 = AACG_DEBUG_ROUTE_WIDE_KERNELS (whatever AACG_RUN8 says), 8 = AACG_DEBUG_ROUTE_RECOMPUTE
         eng = aacgpu.Engine(kind, max_streams=S, max_channels=C)
         eng.debug_set_route(route)
         got = []
