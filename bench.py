@@ -84,7 +84,7 @@ def algorithmic_bytes_per_channel_frame(kind, chain_frames, pcm="f32"):
     return (4096 if kind == "spec" else 2048 + 240) + (2048 if pcm == "i16" else 4096) + 8192.0 / chain_frames
 
 
-def measured_traffic(kind):
+def measured_traffic(kind, kernel=""):
     """HBM bytes per launch from the PMC counters (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, separate rocprofv3
     --pmc passes of this same command, tools/prof.sh); bench.py cannot run the profiler on itself, so the
     committed summary of the latest round under profiles/ is quoted.  None if there is none."""
@@ -95,7 +95,8 @@ def measured_traffic(kind):
     try:
         with open(files[-1]) as f:
             d = json.load(f)
-        return float(d[kind]["traffic_bytes"]), os.path.relpath(files[-1], ROOT)
+        key = kind + ("_run8" if "run8" in kernel else "")     # the one-channel-per-wave kernels move their rendezvous payloads too
+        return float(d[key]["traffic_bytes"]), os.path.relpath(files[-1], ROOT)
     except (KeyError, ValueError, OSError):
         return None, None
 
@@ -367,7 +368,7 @@ def main():
     if cce is not None:
         abytes += (2048 + 240) * frames_per_step             # the coupling element's own spectrum and band words in, nothing extra out
     achieved = abytes / (kernel_ms * 1e-3) / 1e9
-    traffic, traffic_src = measured_traffic(args.input) if args.workload == "cfg2" else (None, None)
+    traffic, traffic_src = measured_traffic(args.input, eng.plan_kernels(plans[0])) if args.workload == "cfg2" else (None, None)
     unit = "stereo frames/s" if n_chan == 2 else "7-channel frames/s"
     line = {
         "metric": "AAC-LC 48 kHz stereo frames/sec per node + achieved HBM GB/s vs roofline",

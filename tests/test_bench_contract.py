@@ -35,7 +35,7 @@ def test_bench_line_contract(path):
     assert d["parity"]["rms"] <= d["parity"]["gate_rms"] and d["parity"]["rel"] <= d["parity"]["gate_rel"]
 
 
-@pytest.mark.parametrize("rnd", ["r02", "r03"])
+@pytest.mark.parametrize("rnd", ["r02", "r03", "r04"])
 def test_headline_line_has_the_cpu_baseline_and_traffic(rnd):
     d = _load(os.path.join(ROOT, "profiles", rnd + "_bench_quant.json"))
     cb = d["cpu_baseline"]
