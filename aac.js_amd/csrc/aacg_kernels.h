@@ -84,6 +84,29 @@ DP_DEVICE void radix8_inv(cpx (&x)[8])
     x[3] = c_add(e3, t3); x[7] = c_sub(e3, t3);
 }
 
+/* ---- one complex value per register pair, (re, im) packed: the single-channel transforms below and the one-channel-per-wave
+ * kernels (aacg_kernels8.h) — a butterfly is v_pk_add / v_pk_fma with op_sel swaps, a rotation two packed instructions ---- */
+DP_DEVICE dpv2 k8_ld2(const float* p) { const dpf2 t = *(const dpf2*)p; dpv2 r; r[0] = t.x; r[1] = t.y; return r; }
+DP_DEVICE void k8_st2(float* p, dpv2 v) { dpf2 t; t.x = v[0]; t.y = v[1]; *(dpf2*)p = t; }
+DP_DEVICE dpv2 k8_v2(float a, float b) { dpv2 r; r[0] = a; r[1] = b; return r; }
+
+/* 8-point inverse DFT on (re, im) pairs: 26 packed operations */
+DP_DEVICE void k8_radix8(dpv2 (&x)[8])
+{
+    const dpv2 h = {0.70710678118654752440f, 0.70710678118654752440f};
+    const dpv2 mh = {-0.70710678118654752440f, -0.70710678118654752440f};
+    const dpv2 a0 = x[0] + x[4], a1 = x[0] - x[4], a2 = x[2] + x[6], a3 = x[2] - x[6];
+    const dpv2 a4 = x[1] + x[5], a5 = x[1] - x[5], a6 = x[3] + x[7], a7 = x[3] - x[7];
+    const dpv2 e0 = a0 + a2, e2 = a0 - a2, e1 = dp_cadd_i(a1, a3), e3 = dp_csub_i(a1, a3);
+    const dpv2 o0 = a4 + a6, o2 = a4 - a6, o1 = dp_cadd_i(a5, a7), o3 = dp_csub_i(a5, a7);
+    const dpv2 s1 = dp_cadd_i(o1, o1);                 /* o1 (1 + i)  */
+    const dpv2 s3 = dp_cadd_i(-o3, o3);                /* o3 (-1 + i) */
+    x[0] = e0 + o0; x[4] = e0 - o0;
+    x[1] = dp_fma2(s1, h, e1); x[5] = dp_fma2(s1, mh, e1);
+    x[2] = dp_cadd_i(e2, o2); x[6] = dp_csub_i(e2, o2);
+    x[3] = dp_fma2(s3, h, e3); x[7] = dp_fma2(s3, mh, e3);
+}
+
 DP_DEVICE void lds_put(float* base, int idx, cpx v)
 {
     dpf2 t; t.x = v.re; t.y = v.im;
@@ -255,72 +278,72 @@ DP_DEVICE void long_channels(const float* tab, const chan_par (&cp)[NC], bool wa
     const int l = dp_lane();
     const float* sincos = tab + AACG_TAB_OFF_SINCOS_LONG;
 
-    /* k = l + 64 j:  X[2k] and X[N/2-1-2k] (mdct.js:74-75) */
-    cpx z[NC][8];
+    /* k = l + 64 j:  X[2k] and X[N/2-1-2k] (mdct.js:74-75).  One complex value per register pair (round 4): a single channel's
+     * transform in half the vector instructions of the scalar form it replaces */
+    dpv2 z[NC][8];
 #pragma unroll
     for (int j = 0; j < 8; j++) {
-        const cpx sc = lds_get(sincos, 64 * j + l);
+        const dpv2 sc = k8_ld2(sincos + 2 * (64 * j + l));
 #pragma unroll
         for (int c = 0; c < NC; c++) {
             const dpf2 a = *(const dpf2*)(area[c] + 2 * l + 128 * j);
             const dpf2 b = *(const dpf2*)(area[c] + 1022 - 2 * l - 128 * j);
-            z[c][j].im = dp_fma(a.x, sc.re, b.y * sc.im);            /* mdct.js:74 */
-            z[c][j].re = dp_fma(b.y, sc.re, -(a.x * sc.im));         /* mdct.js:75 */
+            z[c][j] = dp_cmul(k8_v2(b.y, a.x), sc);                  /* (re, im) = (b c - a s, a c + b s): mdct.js:74-75 */
         }
     }
     dp_wave_sync();
 
     /* 512-point inverse FFT, unscaled (fft.js with forward = false) */
 #pragma unroll
-    for (int c = 0; c < NC; c++) radix8_inv(z[c]);     /* over j (stride 64)       */
+    for (int c = 0; c < NC; c++) k8_radix8(z[c]);      /* over j (stride 64)       */
 #pragma unroll
     for (int q = 1; q < 8; q++) {
-        const cpx tw = lds_get(tab + AACG_TAB_OFF_TW512, 64 * (q - 1) + l);
+        const dpv2 tw = k8_ld2(tab + AACG_TAB_OFF_TW512 + 2 * (64 * (q - 1) + l));
 #pragma unroll
-        for (int c = 0; c < NC; c++) z[c][q] = c_mul(z[c][q], tw);
+        for (int c = 0; c < NC; c++) z[c][q] = dp_cmul(z[c][q], tw);
     }
 #pragma unroll
     for (int q = 0; q < 8; q++)
 #pragma unroll
-        for (int c = 0; c < NC; c++) lds_put(area[c], xch1(q, l), z[c][q]);
+        for (int c = 0; c < NC; c++) k8_st2(area[c] + 2 * xch1(q, l), z[c][q]);
     dp_wave_sync();
     const int l0 = l & 7, qq = l >> 3;
 #pragma unroll
     for (int j = 0; j < 8; j++)
 #pragma unroll
-        for (int c = 0; c < NC; c++) z[c][j] = lds_get(area[c], xch1(qq, l0 + 8 * j));
+        for (int c = 0; c < NC; c++) z[c][j] = k8_ld2(area[c] + 2 * xch1(qq, l0 + 8 * j));
     dp_wave_sync();
 #pragma unroll
-    for (int c = 0; c < NC; c++) radix8_inv(z[c]);     /* over l1 (stride 8)       */
+    for (int c = 0; c < NC; c++) k8_radix8(z[c]);      /* over l1 (stride 8)       */
 #pragma unroll
     for (int r = 1; r < 8; r++) {
-        const cpx tw = lds_get(tab + AACG_TAB_OFF_TW64, 8 * (r - 1) + l0);
+        const dpv2 tw = k8_ld2(tab + AACG_TAB_OFF_TW64 + 2 * (8 * (r - 1) + l0));
 #pragma unroll
-        for (int c = 0; c < NC; c++) z[c][r] = c_mul(z[c][r], tw);
+        for (int c = 0; c < NC; c++) z[c][r] = dp_cmul(z[c][r], tw);
     }
 #pragma unroll
     for (int r = 0; r < 8; r++)
 #pragma unroll
-        for (int c = 0; c < NC; c++) lds_put(area[c], xch2(qq + 8 * r, l0), z[c][r]);
+        for (int c = 0; c < NC; c++) k8_st2(area[c] + 2 * xch2(qq + 8 * r, l0), z[c][r]);
     dp_wave_sync();
     const int col = VM ? long_col(l) : l;              /* this lane's column from here on */
 #pragma unroll
     for (int i = 0; i < 8; i++)
 #pragma unroll
-        for (int c = 0; c < NC; c++) z[c][i] = lds_get(area[c], xch2(col, i));
+        for (int c = 0; c < NC; c++) z[c][i] = k8_ld2(area[c] + 2 * xch2(col, i));
     dp_wave_sync();
 #pragma unroll
-    for (int c = 0; c < NC; c++) radix8_inv(z[c]);     /* over l0; the lane now holds Z[col + 64 r] */
+    for (int c = 0; c < NC; c++) k8_radix8(z[c]);      /* over l0; the lane now holds Z[col + 64 r] */
 
     /* post-IFFT rotation (mdct.js:82-87) */
     float R[NC][8], I[NC][8];
 #pragma unroll
     for (int r = 0; r < 8; r++) {
-        const cpx sc = lds_get(sincos, 64 * r + col);
+        const dpv2 sc = k8_ld2(sincos + 2 * (64 * r + col));
 #pragma unroll
         for (int c = 0; c < NC; c++) {
-            R[c][r] = dp_fma(z[c][r].re, sc.re, -(z[c][r].im * sc.im));
-            I[c][r] = dp_fma(z[c][r].im, sc.re, z[c][r].re * sc.im);
+            const dpv2 ri = dp_cmul(z[c][r], sc);
+            R[c][r] = ri[0]; I[c][r] = ri[1];
         }
     }
 
@@ -346,50 +369,49 @@ DP_DEVICE void short_channels(const float* tab, const chan_par (&cp)[NC],
     const int l = dp_lane(), w = l >> 3, g = l & 7;
     const float* sincos = tab + AACG_TAB_OFF_SINCOS_SHORT;
 
-    cpx z[NC][8];
+    dpv2 z[NC][8];
 #pragma unroll
     for (int j = 0; j < 8; j++) {
-        const cpx sc = lds_get(sincos, 8 * j + g);
+        const dpv2 sc = k8_ld2(sincos + 2 * (8 * j + g));
 #pragma unroll
         for (int c = 0; c < NC; c++) {
             const dpf2 a = *(const dpf2*)(area[c] + 128 * w + 2 * g + 16 * j);          /* X_w[2k], k = g + 8 j */
             const dpf2 b = *(const dpf2*)(area[c] + 128 * w + 126 - 2 * g - 16 * j);    /* .y = X_w[127 - 2k]   */
-            z[c][j].im = dp_fma(a.x, sc.re, b.y * sc.im);
-            z[c][j].re = dp_fma(b.y, sc.re, -(a.x * sc.im));
+            z[c][j] = dp_cmul(k8_v2(b.y, a.x), sc);
         }
     }
     dp_wave_sync();
 
     /* 64-point inverse FFT per window: 8 lanes x 8 points */
 #pragma unroll
-    for (int c = 0; c < NC; c++) radix8_inv(z[c]);
+    for (int c = 0; c < NC; c++) k8_radix8(z[c]);
 #pragma unroll
     for (int q = 1; q < 8; q++) {
-        const cpx tw = lds_get(tab + AACG_TAB_OFF_TW64, 8 * (q - 1) + g);
+        const dpv2 tw = k8_ld2(tab + AACG_TAB_OFF_TW64 + 2 * (8 * (q - 1) + g));
 #pragma unroll
-        for (int c = 0; c < NC; c++) z[c][q] = c_mul(z[c][q], tw);
+        for (int c = 0; c < NC; c++) z[c][q] = dp_cmul(z[c][q], tw);
     }
 #pragma unroll
     for (int q = 0; q < 8; q++)
 #pragma unroll
-        for (int c = 0; c < NC; c++) lds_put(area[c], xch2(8 * w + q, g), z[c][q]);
+        for (int c = 0; c < NC; c++) k8_st2(area[c] + 2 * xch2(8 * w + q, g), z[c][q]);
     dp_wave_sync();
 #pragma unroll
     for (int i = 0; i < 8; i++)
 #pragma unroll
-        for (int c = 0; c < NC; c++) z[c][i] = lds_get(area[c], xch2(l, i));
+        for (int c = 0; c < NC; c++) z[c][i] = k8_ld2(area[c] + 2 * xch2(l, i));
     dp_wave_sync();
 #pragma unroll
-    for (int c = 0; c < NC; c++) radix8_inv(z[c]);     /* lane (w, q) holds Z_w[q + 8 r] */
+    for (int c = 0; c < NC; c++) k8_radix8(z[c]);      /* lane (w, q) holds Z_w[q + 8 r] */
 
     float R[NC][8], I[NC][8];
 #pragma unroll
     for (int r = 0; r < 8; r++) {
-        const cpx sc = lds_get(sincos, 8 * r + g);
+        const dpv2 sc = k8_ld2(sincos + 2 * (8 * r + g));
 #pragma unroll
         for (int c = 0; c < NC; c++) {
-            R[c][r] = dp_fma(z[c][r].re, sc.re, -(z[c][r].im * sc.im));
-            I[c][r] = dp_fma(z[c][r].im, sc.re, z[c][r].re * sc.im);
+            const dpv2 ri = dp_cmul(z[c][r], sc);
+            R[c][r] = ri[0]; I[c][r] = ri[1];
         }
     }
 

@@ -50,27 +50,6 @@
 /* `tabq + AACG_TAB_OFF_SF` etc. address this kernel's LDS table block, which has no windows in it */
 #define K8_TABQ(tab) ((tab) - AACG8_WIN_GAP_FLOATS)
 
-DP_DEVICE dpv2 k8_ld2(const float* p) { const dpf2 t = *(const dpf2*)p; dpv2 r; r[0] = t.x; r[1] = t.y; return r; }
-DP_DEVICE void k8_st2(float* p, dpv2 v) { dpf2 t; t.x = v[0]; t.y = v[1]; *(dpf2*)p = t; }
-DP_DEVICE dpv2 k8_v2(float a, float b) { dpv2 r; r[0] = a; r[1] = b; return r; }
-
-/* 8-point inverse DFT on (re, im) pairs: 26 packed operations */
-DP_DEVICE void k8_radix8(dpv2 (&x)[8])
-{
-    const dpv2 h = {0.70710678118654752440f, 0.70710678118654752440f};
-    const dpv2 mh = {-0.70710678118654752440f, -0.70710678118654752440f};
-    const dpv2 a0 = x[0] + x[4], a1 = x[0] - x[4], a2 = x[2] + x[6], a3 = x[2] - x[6];
-    const dpv2 a4 = x[1] + x[5], a5 = x[1] - x[5], a6 = x[3] + x[7], a7 = x[3] - x[7];
-    const dpv2 e0 = a0 + a2, e2 = a0 - a2, e1 = dp_cadd_i(a1, a3), e3 = dp_csub_i(a1, a3);
-    const dpv2 o0 = a4 + a6, o2 = a4 - a6, o1 = dp_cadd_i(a5, a7), o3 = dp_csub_i(a5, a7);
-    const dpv2 s1 = dp_cadd_i(o1, o1);                 /* o1 (1 + i)  */
-    const dpv2 s3 = dp_cadd_i(-o3, o3);                /* o3 (-1 + i) */
-    x[0] = e0 + o0; x[4] = e0 - o0;
-    x[1] = dp_fma2(s1, h, e1); x[5] = dp_fma2(s1, mh, e1);
-    x[2] = dp_cadd_i(e2, o2); x[6] = dp_csub_i(e2, o2);
-    x[3] = dp_fma2(s3, h, e3); x[7] = dp_fma2(s3, mh, e3);
-}
-
 /* staging swizzle of the E / O planes (pair index k of X[2k] at k, of X[2k+1] at 512 + k): keeps the long (l + 64 j) and
  * the short (64 w + g + 8 j) read patterns and the 16-byte staging stores conflict-free */
 DP_DEVICE int k8_stg(int k) { return k ^ (((k >> 6) & 7) << 3); }
