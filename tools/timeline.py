@@ -27,11 +27,11 @@ NW = int(os.environ.get("TL_WAVES", str(min(16, T))))                  # waves o
 NB = int(os.environ.get("TL_BLOCKS", "256"))
 t = raw.view(np.uint64)[: NB * 16 * 8].reshape(NB, 16, 8)[:, :NW].astype(np.float64) * 0.01     # 100 MHz ticks -> us
 t0 = t[:, :, 0].min()
-names = ["start", "tables+barrier", "spectrum staged", "imdct done", "prev tail seen", "stores issued"]
+names = ["start", "tables+barrier", "spectrum staged", "imdct done", "prev tail seen", "stores issued", "loads landed"]
 print("phase (us since first wave start): median over workgroups, by wave")
 for w in range(NW):
-    row = [np.median(t[:, w, k] - t0) for k in range(6)]
-    print("wave %2d: " % w + "  ".join("%s %6.2f" % (names[k][:14], row[k]) for k in range(6)))
+    row = [np.median(t[:, w, k] - t0) for k in range(7)]
+    print("wave %2d: " % w + "  ".join("%s %6.2f" % (names[k][:14], row[k]) for k in (0, 1, 6, 2, 3, 4, 5)))
 print("kernel span (last stores issued - first start): %.2f us; start skew across WGs: %.2f us" % ((t[:, :, 5].max() - t0), t[:, :, 0].max() - t0))
 
 # distribution over workgroups: where do the stragglers come from?
