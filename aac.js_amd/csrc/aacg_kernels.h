@@ -599,45 +599,13 @@ DP_DEVICE void long_pair_window(const float* tab, const chan_par& cp, bool want_
     }
 }
 
-#ifndef AACG_GF
-#define AACG_GF 0
-#endif
-/* the exchange between the first two radix-8 stages of the long pair path: 1 = on the VALU (dp_xpose_hi8), 0 = through LDS */
-#ifndef AACG_XPOSE_VALU
-#define AACG_XPOSE_VALU 1
-#endif
-template <int BIT>
-DP_DEVICE cpx fac_get(const float* tab, const float* gt, int off, int idx) { return lds_get(((AACG_GF & BIT) ? gt : tab) + off, idx); }
-
 /* Long windows, both channels (they share sequence and shapes: one ICSInfo, cpe.js:44, or equal by value). */
 template <bool VM>                                      /* VM: columns dealt out by long_col, mirror exchange as DPP row_mirror */
 DP_DEVICE void long_pair(const float* tab, const chan_par& cp, bool want_head, float* slot,
-                         dpv2 (&hx)[8], dpv2 (&hy)[8], int abl = 0, const float* gt = nullptr)
+                         dpv2 (&hx)[8], dpv2 (&hy)[8])
 {
     const int l = dp_lane();
-#ifdef AACG_PROFILE
-    /* timing experiments (results are wrong): 256 no transposes, 512 no rotation / twiddle reads, 1024 no window reads, 2048 one tail store of eight */
-    const bool no_xp = abl & 256, no_xp2 = abl & 16384, no_tw = abl & 512, no_win = abl & 1024, no_tail = abl & 2048;
-    /* stand-ins for register transposes: 4096: 64 cross-lane moves after the first stage, 8192: 96 after the second */
-    auto fake_moves = [&](cpx2 (&z)[8], int rounds) {
-        for (int t = 0; t < rounds; t++) {
-#pragma unroll
-            for (int q = 0; q < 8; q++) {
-#pragma unroll
-                for (int e = 0; e < 2; e++) {
-                    z[q].re[e] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, z[q].re[e]), __builtin_bit_cast(int, z[q ^ 1].re[e]), 0x128, 0xf, 0x3, false));
-                    z[q].im[e] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, z[q].im[e]), __builtin_bit_cast(int, z[q ^ 1].im[e]), 0xB1, 0xf, 0xc, false));
-                }
-            }
-        }
-    };
-    cpx fake; fake.re = 1.0f + 0.001f * (float)l; fake.im = 0.5f;
-    dpf2 fakew; fakew.x = fake.re; fakew.y = 0.25f;
-#else
-    const bool no_xp = false, no_xp2 = false, no_tw = false, no_win = false, no_tail = false;
-    cpx fake; fake.re = fake.im = 0.0f;
-    dpf2 fakew; fakew.x = fakew.y = 0.0f;
-#endif
+    const float* sincos = tab + AACG_TAB_OFF_SINCOS_LONG;
 
     /* Slot indices spelled out as a few lane-dependent bases plus compile-time offsets (which become the instructions'
      * immediate offsets): left to itself the compiler rebuilt every swizzled index from the lane number, some 100 vector
@@ -650,7 +618,7 @@ DP_DEVICE void long_pair(const float* tab, const chan_par& cp, bool want_head, f
         for (int m = 0; m < 4; m++) { eb[m] = l ^ (m << 3); ob[m] = (63 - l) ^ ((3 - m) << 3); }
 #pragma unroll
         for (int j = 0; j < 8; j++) {
-            const cpx sc = no_tw ? fake : fac_get<1>(tab, gt, AACG_TAB_OFF_SINCOS_LONG, 64 * j + l);
+            const cpx sc = lds_get(sincos, 64 * j + l);
             const dpv2 xe = lds_pair(slot, 64 * j + eb[j & 3]);                       /* X[2k],        k = l + 64 j */
             const dpv2 xo = lds_pair(slot, 512 + 64 * (7 - j) + ob[j & 3]);           /* X[1023 - 2k]               */
             z[j].im = xe * v2s(sc.re) + xo * v2s(sc.im);             /* mdct.js:74 */
@@ -661,73 +629,35 @@ DP_DEVICE void long_pair(const float* tab, const chan_par& cp, bool want_head, f
 
     radix8_inv2(z);
 #pragma unroll
-    for (int q = 1; q < 8; q++) z[q] = c2_mul(z[q], no_tw ? fake : fac_get<2>(tab, gt, AACG_TAB_OFF_TW512, 64 * (q - 1) + l));
-    const int l0 = l & 7, qq = l >> 3;
-    if (AACG_XPOSE_VALU) {
-        /* first exchange (register index <-> lane / 8) on the VALU: dp_xpose_hi8 */
-        float v[32];
+    for (int q = 1; q < 8; q++) z[q] = c2_mul(z[q], lds_get(tab + AACG_TAB_OFF_TW512, 64 * (q - 1) + l));
+    {
+        const int w0 = l, w1 = l ^ 8;                  /* pch1(q, l) = 64 q + (l ^ 8 (q >> 1 & 1)) */
 #pragma unroll
-        for (int q = 0; q < 8; q++) { v[4 * q] = z[q].re[0]; v[4 * q + 1] = z[q].re[1]; v[4 * q + 2] = z[q].im[0]; v[4 * q + 3] = z[q].im[1]; }
-        if (!no_xp) dp_xpose_hi8<4>(v);
-#pragma unroll
-        for (int q = 0; q < 8; q++) { z[q].re = v2(v[4 * q], v[4 * q + 1]); z[q].im = v2(v[4 * q + 2], v[4 * q + 3]); }
-    } else {
-        {
-            const int w0 = l, w1 = l ^ 8;              /* pch1(q, l) = 64 q + (l ^ 8 (q >> 1 & 1)) */
-            if (!no_xp)
-#pragma unroll
-            for (int q = 0; q < 8; q++) lds_put2(slot, 64 * q + ((q & 2) ? w1 : w0), z[q]);
-        }
-        dp_wave_sync();
-        {
-            /* pch1(qq, l0 + 8 j) = 64 qq + l0 + 8 (j ^ (qq >> 1 & 1)): j even + 8, j odd - 8 where that bit is set */
-            const int q1 = (qq >> 1) & 1, r0 = 64 * qq + l0 + 8 * q1, r1 = 64 * qq + l0 - 8 * q1;
-            if (!no_xp)
-#pragma unroll
-            for (int j = 0; j < 8; j++) z[j] = lds_get2(slot, ((j & 1) ? r1 : r0) + 8 * j);
-        }
-        dp_wave_sync();
+        for (int q = 0; q < 8; q++) lds_put2(slot, 64 * q + ((q & 2) ? w1 : w0), z[q]);
     }
-#ifdef AACG_PROFILE
-    if (abl & 4096) fake_moves(z, 2);
-#endif
-#if defined(AACG_PAD) && !defined(AACG_EMU_BUILD)
-    /* issue-model experiment (tools only): 256 extra instructions of one kind per frame */
-#if AACG_PAD == 1
-    __asm__ volatile(".rept 256\n\ts_nop 0\n\t.endr");
-#elif AACG_PAD == 2
-    { float pad_t = z[0].re[0]; __asm__ volatile(".rept 256\n\tv_mov_b32 %0, %0\n\t.endr" : "+v"(pad_t)); z[0].re[0] = pad_t; }
-#elif AACG_PAD == 3
-    { float pad_t = z[0].re[0]; __asm__ volatile(".rept 256\n\tv_add_f32 %0, 0, %0\n\t.endr" : "+v"(pad_t)); z[0].re[0] = pad_t; }
-#elif AACG_PAD == 4
-    __asm__ volatile(".rept 256\n\ts_mov_b32 s20, s20\n\t.endr" ::: "s20");
-#elif AACG_PAD == 5
-    { const int pad_a = dp_lds_addr(slot) + 8 * l; dpf2 pad_v; __asm__ volatile(".rept 64\n\tds_read_b64 %0, %1\n\t.endr\n\ts_waitcnt lgkmcnt(0)" : "=&v"(pad_v) : "v"(pad_a) : "memory"); if (pad_v.x == 1.2345f) z[0].re[0] = pad_v.y; }
-#elif AACG_PAD == 6
-    { const int pad_a = dp_lds_addr(slot) + 16 * l; dpf4 pad_v; __asm__ volatile(".rept 64\n\tds_read_b128 %0, %1\n\t.endr\n\ts_waitcnt lgkmcnt(0)" : "=&v"(pad_v) : "v"(pad_a) : "memory"); if (pad_v.x == 1.2345f) z[0].re[0] = pad_v.y; }
-#elif AACG_PAD == 7
-    { const int pad_a = dp_lds_addr(slot) + 4 * l; float pad_v; __asm__ volatile(".rept 64\n\tds_read_b32 %0, %1\n\t.endr\n\ts_waitcnt lgkmcnt(0)" : "=&v"(pad_v) : "v"(pad_a) : "memory"); if (pad_v == 1.2345f) z[0].re[0] = pad_v; }
-#endif
-#endif
+    dp_wave_sync();
+    const int l0 = l & 7, qq = l >> 3;
+    {
+        /* pch1(qq, l0 + 8 j) = 64 qq + l0 + 8 (j ^ (qq >> 1 & 1)): j even + 8, j odd - 8 where that bit is set */
+        const int q1 = (qq >> 1) & 1, r0 = 64 * qq + l0 + 8 * q1, r1 = 64 * qq + l0 - 8 * q1;
+#pragma unroll
+        for (int j = 0; j < 8; j++) z[j] = lds_get2(slot, ((j & 1) ? r1 : r0) + 8 * j);
+    }
+    dp_wave_sync();
     radix8_inv2(z);
 #pragma unroll
-    for (int r = 1; r < 8; r++) z[r] = c2_mul(z[r], no_tw ? fake : fac_get<4>(tab, gt, AACG_TAB_OFF_TW64, 8 * (r - 1) + l0));
+    for (int r = 1; r < 8; r++) z[r] = c2_mul(z[r], lds_get(tab + AACG_TAB_OFF_TW64, 8 * (r - 1) + l0));
     {
         /* pch2(qq + 8 r, l0) = 64 r + 8 qq + (l0 ^ (qq >> 1) ^ 4 (r & 1)) */
         const int e0 = 8 * qq + (l0 ^ (qq >> 1)), e1 = e0 ^ 4;
-        if (!no_xp2)
 #pragma unroll
         for (int r = 0; r < 8; r++) lds_put2(slot, 64 * r + ((r & 1) ? e1 : e0), z[r]);
     }
     dp_wave_sync();
-#ifdef AACG_PROFILE
-    if (abl & 8192) fake_moves(z, 3);
-#endif
     const int c = VM ? long_col(l) : l;                /* this lane's column from here on */
     {
         /* pch2(c, i) = (8 c + (c >> 1 & 7)) ^ i, and with the slot 128-byte aligned the byte address is base ^ 16 i */
         const int ab = dp_lds_addr(slot) + 16 * (8 * c + ((c >> 1) & 7));
-        if (!no_xp2)
 #pragma unroll
         for (int i = 0; i < 8; i++) {
             const dpf4 t = dp_lds_read_f4(ab ^ (16 * i));
@@ -740,7 +670,7 @@ DP_DEVICE void long_pair(const float* tab, const chan_par& cp, bool want_head, f
     dpv2 R[8], I[8], mR[8], mI[8];
 #pragma unroll
     for (int r = 0; r < 8; r++) {
-        const cpx sc = no_tw ? fake : fac_get<8>(tab, gt, AACG_TAB_OFF_SINCOS_LONG, 64 * r + c);
+        const cpx sc = lds_get(sincos, 64 * r + c);
         R[r] = z[r].re * v2s(sc.re) - z[r].im * v2s(sc.im);          /* mdct.js:82-87 */
         I[r] = z[r].im * v2s(sc.re) + z[r].re * v2s(sc.im);
     }
@@ -749,14 +679,13 @@ DP_DEVICE void long_pair(const float* tab, const chan_par& cp, bool want_head, f
          * are issued together instead of one LDS round trip each (filter_bank.js:109-116).  Reading all sixteen
          * ahead of the first tail store was measured too: no faster, and 4 more VGPRs. */
         dp_keep_branch();
-        const float* wh = ((AACG_GF & 16) ? gt : tab) + AACG_TAB_OFF_WIN_LONG + 1024 * cp.shape_prev;
-        const float* wt = ((AACG_GF & 16) ? gt : tab) + AACG_TAB_OFF_WIN_LONG + 1024 * cp.shape;
-        dpf4 keep; keep.x = keep.y = keep.z = keep.w = 0.0f;
+        const float* wh = tab + AACG_TAB_OFF_WIN_LONG + 1024 * cp.shape_prev;
+        const float* wt = tab + AACG_TAB_OFF_WIN_LONG + 1024 * cp.shape;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const int n = 2 * c + 128 * j;
-            const dpf2 w0 = no_win ? fakew : *(const dpf2*)(wh + n), w1 = no_win ? fakew : *(const dpf2*)(wh + n + 512);
-            const dpf2 r0 = no_win ? fakew : *(const dpf2*)(wt + 1022 - n), r1 = no_win ? fakew : *(const dpf2*)(wt + 510 - n);   /* reversed: (w[1022-n], w[1023-n]) */
+            const dpf2 w0 = *(const dpf2*)(wh + n), w1 = *(const dpf2*)(wh + n + 512);
+            const dpf2 r0 = *(const dpf2*)(wt + 1022 - n), r1 = *(const dpf2*)(wt + 510 - n);   /* reversed: (w[1022-n], w[1023-n]) */
             hx[j]     = I[j + 4] * v2s(w0.x);
             hx[j + 4] = R[j] * v2s(w1.x);
             const dpv2 t0 = R[j + 4] * v2s(r0.y), t2 = -I[j] * v2s(r1.y);
@@ -776,11 +705,10 @@ DP_DEVICE void long_pair(const float* tab, const chan_par& cp, bool want_head, f
             }
             dpf4 o;
             o.x = t0[0]; o.y = t0[1]; o.z = t1[0]; o.w = t1[1];
-            if (!no_tail) *(dpf4*)(slot + 2 * n) = o; else { keep.x += o.x; keep.y += o.y; keep.z += o.z; keep.w += o.w; }
+            *(dpf4*)(slot + 2 * n) = o;
             o.x = t2[0]; o.y = t2[1]; o.z = t3[0]; o.w = t3[1];
-            if (!no_tail) *(dpf4*)(slot + 2 * (n + 512)) = o; else { keep.x += o.x; keep.y += o.y; keep.z += o.z; keep.w += o.w; }
+            *(dpf4*)(slot + 2 * (n + 512)) = o;
         }
-        if (no_tail) *(dpf4*)(slot + 4 * c) = keep;
         return;
     }
     shfl_pairs<VM ? 16 : 0>(R, I, 63 - l, mR, mI);
@@ -1498,7 +1426,7 @@ DP_DEVICE void tns_unit(float* slot, float* xch, const aacg_dev_tns* rec0, const
  * (all-short batch 14.67 -> 13.70 us, config 3 13.94 -> 13.56); the f32 seam lost 0.07 us with it and keeps ds_bpermute */
 template <bool VM>
 DP_DEVICE void filter_unit(const float* tab, const unit_view& u, int n_ch, bool pair_path, bool want_head, float* slot,
-                           float (&hx0)[8], float (&hy0)[8], float (&hx1)[8], float (&hy1)[8], int abl = 0, const float* gt = nullptr)
+                           float (&hx0)[8], float (&hy0)[8], float (&hx1)[8], float (&hy1)[8])
 {
     chan_par p0, p1;
     p0.seq = u.seq[0]; p0.shape = u.shape[0]; p0.shape_prev = u.shape_prev[0];
@@ -1507,7 +1435,7 @@ DP_DEVICE void filter_unit(const float* tab, const unit_view& u, int n_ch, bool 
     if (pair_path) {
         dpv2 hx[8], hy[8];
         if (s0) short_pair<VM>(tab, p0, slot, hx, hy);
-        else    long_pair<VM>(tab, p0, want_head, slot, hx, hy, abl, gt);
+        else    long_pair<VM>(tab, p0, want_head, slot, hx, hy);
 #pragma unroll
         for (int m = 0; m < 8; m++) { hx0[m] = hx[m][0]; hx1[m] = hx[m][1]; hy0[m] = hy[m][0]; hy1[m] = hy[m][1]; }
         return;
@@ -2027,11 +1955,6 @@ DP_DEVICE void imdct_run_body(const aacg_kparams& P, const aacg_rv_args* V = nul
     float hx0[8], hy0[8], hx1[8], hy1[8];
     /* scalar loads: nothing that may clobber memory (stores, clock reads) precedes them */
     unit_view u = load_unit(P.units + (n_pass == 2 ? run->pred_unit : (ui >= 0 ? ui : 0)));
-#ifdef AACG_HOT_ONLY
-    /* instruction-count analysis only (never a product build): the config-2 frame, so that the cold paths fold away */
-    u.n_ch = 2; u.seq[0] = u.seq[1] = AACG_ONLY_LONG_SEQUENCE; u.shape[1] = u.shape[0]; u.shape_prev[1] = u.shape_prev[0];
-    u.max_sfb[1] = u.max_sfb[0]; u.gmap[1] = u.gmap[0]; u.tns[0] = u.tns[1] = 0; u.flags = AACG_UNIT_COMMON_WINDOW | AACG_UNIT_MASK_PRESENT;
-#endif
     /* Earlier frames get the higher issue priority: they finish first and their PCM stores overlap
      * the later waves' arithmetic.  A wave only ever waits for the wave before it, whose priority is
      * never lower, so a spinning consumer cannot starve its producer. */
@@ -2165,7 +2088,7 @@ DP_DEVICE void imdct_run_body(const aacg_kparams& P, const aacg_rv_args* V = nul
         }
         dp_wave_sync();
         if (trace && lane == 0) trace[2] = dp_clock();     /* spectrum arrived and staged */
-        filter_unit<AACG_VM_KIND(KIND)>(tab, u, n_ch, pair_path, want_head, slot, hx0, hy0, hx1, hy1, AACG_ABL(P, 256 | 512 | 1024 | 2048 | 4096 | 8192 | 16384), (const float*)P.tab);
+        filter_unit<AACG_VM_KIND(KIND)>(tab, u, n_ch, pair_path, want_head, slot, hx0, hy0, hx1, hy1);
     };
 
     if (ui >= 0) front(!is_pred_wave && n_pass == 1);

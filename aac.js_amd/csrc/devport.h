@@ -115,74 +115,6 @@ DP_DEVICE void dp_mirror16_valu(const float (&in)[N], float (&out)[N])
 }
 #undef DP_DPP_BLOCK8
 
-/* Transpose between the register index and lane bits 5..3: v[D q + d] of lane 8 j + g  ->  v[D j + d] of lane 8 q + g
- * (q, j = 0..7, g = lane & 7, d < D) — the exchange between the first two radix-8 stages of the 512-point transform,
- * on the VALU instead of through LDS (a 16-byte store and a 16-byte load per value and lane, with a wave-wide sync
- * between them, on the CU's one LDS pipe).  Three butterfly steps, register bit t with lane bit 3 + t:
- *   bit 2 / lane 32: v_permlane32_swap_b32 (upper half of the first register <-> lower half of the second), one
- *                    instruction per register PAIR;  bit 1 / lane 16: v_permlane16_swap_b32 (odd rows <-> even rows);
- *   bit 0 / lane 8:  no swap instruction: v_mov_b32 with DPP row_ror:8 and a bank mask (the lanes that take the other
- *                    register's value), a copy and two such moves per register pair, four pairs to a block.
- * The s_nop covers the two wait states a DPP read needs after a VALU write of its source. */
-DP_DEVICE void dp_swap32(float& a, float& b)
-{
-    __asm__ volatile("v_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
-}
-DP_DEVICE void dp_swap16(float& a, float& b)
-{
-    __asm__ volatile("v_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
-}
-DP_DEVICE void dp_xchg8_block(const float (&a)[4], float (&b)[4], float (&a2)[4])
-{
-    /* a2 = a with the upper eight lanes of every row from b's lower eight; b: its lower eight from a's upper eight.  A copy
-     * and two masked DPP moves per register pair: v_cndmask_b32 with a DPP source, one instruction per register, measured
-     * five times slower per instruction (tools/micro/xlane_rate.hip: 9.0 ns against 1.8 per SIMD). */
-    __asm__ volatile("s_nop 1\n\t"
-            "v_mov_b32 %0, %8\n\tv_mov_b32 %1, %9\n\tv_mov_b32 %2, %10\n\tv_mov_b32 %3, %11\n\t"
-            "v_mov_b32_dpp %0, %4 row_ror:8 row_mask:0xf bank_mask:0xc\n\tv_mov_b32_dpp %1, %5 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
-            "v_mov_b32_dpp %2, %6 row_ror:8 row_mask:0xf bank_mask:0xc\n\tv_mov_b32_dpp %3, %7 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
-            "v_mov_b32_dpp %4, %8 row_ror:8 row_mask:0xf bank_mask:0x3\n\tv_mov_b32_dpp %5, %9 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
-            "v_mov_b32_dpp %6, %10 row_ror:8 row_mask:0xf bank_mask:0x3\n\tv_mov_b32_dpp %7, %11 row_ror:8 row_mask:0xf bank_mask:0x3"
-            : "=&v"(a2[0]), "=&v"(a2[1]), "=&v"(a2[2]), "=&v"(a2[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3])
-            : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]));
-}
-template <int D>
-DP_DEVICE void dp_xpose_hi8(float (&v)[8 * D])
-{
-    static_assert(D == 4 || D == 2, "a block of the lane-8 step takes four dwords of a register pair");
-#pragma unroll
-    for (int q = 0; q < 4; q++)
-#pragma unroll
-        for (int d = 0; d < D; d++) dp_swap32(v[D * q + d], v[D * (q + 4) + d]);
-#pragma unroll
-    for (int q = 0; q < 8; q++)
-        if (!(q & 2)) {
-#pragma unroll
-            for (int d = 0; d < D; d++) dp_swap16(v[D * q + d], v[D * (q + 2) + d]);
-        }
-    if (D == 4) {
-#pragma unroll
-        for (int q = 0; q < 8; q += 2) {
-            float a[4], b[4], a2[4];
-#pragma unroll
-            for (int d = 0; d < 4; d++) { a[d] = v[4 * q + d]; b[d] = v[4 * (q + 1) + d]; }
-            dp_xchg8_block(a, b, a2);
-#pragma unroll
-            for (int d = 0; d < 4; d++) { v[4 * q + d] = a2[d]; v[4 * (q + 1) + d] = b[d]; }
-        }
-    } else {
-#pragma unroll
-        for (int q = 0; q < 8; q += 4) {               /* two register pairs to a block */
-            float a[4], b[4], a2[4];
-#pragma unroll
-            for (int d = 0; d < 2; d++) { a[d] = v[2 * q + d]; b[d] = v[2 * (q + 1) + d]; a[2 + d] = v[2 * (q + 2) + d]; b[2 + d] = v[2 * (q + 3) + d]; }
-            dp_xchg8_block(a, b, a2);
-#pragma unroll
-            for (int d = 0; d < 2; d++) { v[2 * q + d] = a2[d]; v[2 * (q + 1) + d] = b[d]; v[2 * (q + 2) + d] = a2[2 + d]; v[2 * (q + 3) + d] = b[2 + d]; }
-        }
-    }
-}
-
 /* The reorder + window step of the IMDCT for the values that come from the mirror lane (mdct.js:90-114 with
  * filter_bank.js:109-116): out[2k + c] = s_k * (mirror lane's src[2k + c]) * w[k], signs s = (-, -, -, +), as ONE
  * v_mul_f32 per value with the DPP control on its first operand — instead of a DPP move per value plus a packed

@@ -32,7 +32,6 @@ struct emu_wave {
     pthread_barrier_t bar;
     float shfl[64][16];
     double shfl_d[64][16];
-    float xpose[64][32];
 };
 struct emu_block {
     pthread_barrier_t bar;
@@ -71,19 +70,6 @@ DP_DEVICE void dp_shfl(float (&v)[N], int src)
 
 template <int N> DP_DEVICE void dp_mirror8_valu(const float (&in)[N], float (&out)[N]) { for (int i = 0; i < N; i++) out[i] = in[i]; dp_shfl(out, g_emu.lane ^ 7); }
 template <int N> DP_DEVICE void dp_mirror16_valu(const float (&in)[N], float (&out)[N]) { for (int i = 0; i < N; i++) out[i] = in[i]; dp_shfl(out, g_emu.lane ^ 15); }
-
-/* v[D q + d] of lane 8 j + g  ->  v[D j + d] of lane 8 q + g  (devport.h): by its definition, not by the three exchange steps */
-template <int D>
-DP_DEVICE void dp_xpose_hi8(float (&v)[8 * D])
-{
-    static_assert(8 * D <= 32, "transpose payload");
-    const int lane = g_emu.lane, g = lane & 7, q = lane >> 3;
-    for (int i = 0; i < 8 * D; i++) g_emu.w->xpose[lane][i] = v[i];
-    pthread_barrier_wait(&g_emu.w->bar);
-    for (int j = 0; j < 8; j++)
-        for (int d = 0; d < D; d++) v[D * j + d] = g_emu.w->xpose[8 * j + g][D * q + d];
-    pthread_barrier_wait(&g_emu.w->bar);
-}
 
 /* out[2k + c] = s_k * (mirror lane's src[2k + c]) * w[k], s = (-, -, -, +)  (devport.h) */
 template <int MIRROR>
