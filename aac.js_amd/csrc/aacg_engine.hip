@@ -672,6 +672,13 @@ int aacg_decode_device(aacg_engine* e, aacg_plan* p, const void* d_coeffs, const
     if (rc) return rc;
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : e->stream;
     if (!p->used) HIP_TRY(e, hipStreamWaitEvent(s, p->uploaded, 0), AACG_ERR_NO_DEVICE);
+    /* the plan's previous launch ran on ANOTHER stream: this one continues its overlap state, reuses its scratch areas and
+     * rendezvous cells, so it is ordered behind it on the device (an event only when the stream changes: per launch it
+     * would cost 3 us) */
+    if (p->used && p->last_stream != s) {
+        HIP_TRY(e, hipEventRecord(p->last_use, p->last_stream), AACG_ERR_NO_DEVICE);
+        HIP_TRY(e, hipStreamWaitEvent(s, p->last_use, 0), AACG_ERR_NO_DEVICE);
+    }
     const cce_bufs cb = {(const aacg_run*)p->d_cce[0], (const aacg_couple_job*)p->d_cce[1], (const float*)p->d_cce[2], (float*)p->d_cce[3]};
     const run8_bufs r8 = {(const aacg_run8*)p->d_run8[0], (unsigned long long*)p->d_run8[1], (float*)p->d_run8[2]};
     if (takes_run8(e, p->h) && !p->d_run8[0]) { e->err = "the plan was made for the 16-wave kernels (aacg_debug_set_route changed since)"; return AACG_ERR_STALE_PLAN; }
@@ -703,6 +710,10 @@ int aacg_plan_refresh_from_parse(aacg_engine* e, aacg_plan* p, const aacg_unit_d
     }
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : e->stream;
     HIP_TRY(e, hipStreamWaitEvent(s, p->uploaded, 0), AACG_ERR_NO_DEVICE);
+    if (p->used && p->last_stream != s) {              /* the records' readers on the plan's previous stream first */
+        HIP_TRY(e, hipEventRecord(p->last_use, p->last_stream), AACG_ERR_NO_DEVICE);
+        HIP_TRY(e, hipStreamWaitEvent(s, p->last_use, 0), AACG_ERR_NO_DEVICE);
+    }
     aacg_refresh_launch(p->d_units, d_parsed_units, d_results, p->n_units, max_units, 1, d_refused, s);
     HIP_TRY(e, hipGetLastError(), AACG_ERR_NO_DEVICE);
     p->last_stream = s;

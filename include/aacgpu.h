@@ -319,7 +319,10 @@ void aacg_plan_destroy(aacg_plan* p);
 /* Launch on `hip_stream` (a hipStream_t passed as void*, NULL = the engine's own stream);
  * returns after enqueueing.  d_coeffs / d_meta / d_pcm are DEVICE pointers.
  * Every call is a NEW launch: the overlap-buffer parity and — for plans whose chains are longer than a run — the epoch of the
- * run-to-run rendezvous are arguments of that launch.  Do not capture a launch in a hipGraph and replay it: call again.    */
+ * run-to-run rendezvous are arguments of that launch.  Do not capture a launch in a hipGraph and replay it: call again.
+ * Launches of ONE plan are ordered on the device also when they go to different HIP streams (the engine inserts an event
+ * wait when the stream changes).  Two PLANS that advance the same audio streams are the caller's to order (same HIP
+ * stream, or an event between them): the engine checks their logical order (AACG_ERR_STALE_PLAN), not the device's.      */
 int aacg_decode_device(aacg_engine* e, aacg_plan* p,
                        const void* d_coeffs, const aacg_band_meta* d_meta,
                        void* d_pcm, void* hip_stream);

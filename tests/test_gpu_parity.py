@@ -552,6 +552,31 @@ def test_bench_workload_vs_oracle(oracle, name):
     eng2.close()
 
 
+@pytest.mark.parametrize("S,T", [(64, 16), (8, 48)])
+def test_one_plan_on_alternating_hip_streams(S, T):
+    """Launches of ONE plan continue each other's overlap state (and, for chains longer than a run, reuse the rendezvous
+    cells): the engine orders them on the device also when they alternate between two HIP streams with no host
+    synchronisation in between (include/aacgpu.h, aacg_decode_device).  Eight batches that way are bit-identical to eight
+    batches on one stream."""
+    torch = _torch()
+    wl = aacgpu_workload.make_batch(n_streams=S, n_frames=T, mix=True, seed=4242)
+    d_q, d_meta = torch.from_numpy(wl["q"]).cuda(), torch.from_numpy(wl["meta"].view(np.int16)).cuda()
+    out = []
+    for streams in ([torch.cuda.Stream()], [torch.cuda.Stream(), torch.cuda.Stream()]):
+        eng = aacgpu.Engine(aacgpu.INPUT_QUANT_I16, max_streams=S, max_channels=2)
+        plan = eng.plan(wl["units"])
+        d_pcm = [torch.full((wl["n_pcm"],), float("nan"), dtype=torch.float32, device="cuda") for _ in range(8)]
+        torch.cuda.synchronize()
+        for i in range(8):
+            eng.decode_device(plan, d_q.data_ptr(), d_meta.data_ptr(), d_pcm[i].data_ptr(), streams[i % len(streams)].cuda_stream)
+        torch.cuda.synchronize()
+        out.append(np.stack([t.cpu().numpy() for t in d_pcm]))
+        plan.destroy()
+        eng.close()
+    assert np.isfinite(out[0]).all()
+    assert np.array_equal(out[0].view(np.uint32), out[1].view(np.uint32))
+
+
 def test_two_ranks_share_a_gpu(tmp_path):
     """The sharded path with the product in it: two rank processes (torch.distributed.run, gloo for the barrier), each with
     its own aacgpu.Engine on cuda:0 for its stream shard; their PCM, concatenated, is bit-identical to one process decoding
