@@ -439,8 +439,8 @@ int aacg_create(const aacg_config* cfg, aacg_engine** out)
                         hip_ok(e, hipMemcpy(e->d_win8, w8, sizeof *w8, hipMemcpyHostToDevice), "upload window tables");
         delete w8;
         if (!ok) { aacg_destroy(e); return AACG_ERR_OUT_OF_MEMORY; }
-        if (const char* r = std::getenv("AACG_RUN8")) e->run8 = std::atoi(r) != 0;
-        if (const char* r = std::getenv("AACG_RV")) e->rv = std::atoi(r) != 0;         /* A/B switch for tools/: 0 = long chains recompute a frame per later run (_dd kernels) */    /* A/B switch for tools/: 1 = plain batches on the one-channel-per-wave kernels */
+        if (const char* r = std::getenv("AACG_RUN8")) e->run8 = std::atoi(r) != 0;     /* A/B switch for tools/: 1 = plain batches on the one-channel-per-wave kernels */
+        if (const char* r = std::getenv("AACG_RV")) e->rv = std::atoi(r) != 0;         /* A/B switch for tools/: 0 = long chains recompute a frame per later run (_dd kernels) */
     }
     if (cfg->pns_mode == AACG_PNS_SPEC) {
         aacg_pns_tables* pt = new (std::nothrow) aacg_pns_tables;
@@ -454,6 +454,8 @@ int aacg_create(const aacg_config* cfg, aacg_engine** out)
     if (const char* a = std::getenv("AACG_ABLATE")) e->ablate = std::atoi(a);
     if ((e->ablate & 16) && hipMalloc(&e->d_trace, 1u << 22) == hipSuccess) (void)hipMemset(e->d_trace, 0, 1u << 22);
 #endif
+    /* the uploads and memsets above went to the null stream; the engine's streams are non-blocking and would not wait for it */
+    if (!hip_ok(e, hipDeviceSynchronize(), "synchronize after setup")) { aacg_destroy(e); return AACG_ERR_NO_DEVICE; }
     *out = e;
     return AACG_OK;
 }
@@ -509,6 +511,7 @@ int aacg_reset_stream(aacg_engine* e, uint32_t stream)
     if (rc) return rc;
     for (int c = 0; c < e->cfg.max_channels; c++)
         HIP_TRY(e, hipMemset(ov_ptr(e, stream, (uint32_t)c), 0, 4096), AACG_ERR_NO_DEVICE);
+    HIP_TRY(e, hipDeviceSynchronize(), AACG_ERR_NO_DEVICE);       /* null-stream memsets: a launch on a non-blocking stream must not overtake them */
     return AACG_OK;
 }
 
@@ -883,7 +886,9 @@ int aacg_submit_ex(aacg_engine* e, const aacg_batch* batch, uint64_t* ticket)
     for (int i = 0; i < 4; i++) {
         const size_t had = sl.rv_cap[i];
         if (rvs[i] && (rc = grow(e, &sl.d_rv[i], &sl.rv_cap[i], rvs[i]))) return rc;
-        if (i == 2 && sl.rv_cap[i] != had) HIP_TRY(e, hipMemset(sl.d_rv[i], 0, sl.rv_cap[i]), AACG_ERR_NO_DEVICE);     /* a new state buffer starts from zero */
+        /* a new state buffer starts from zero — on the slot's own stream, in front of the launch that reads it (a plain
+         * hipMemset is ordered on the null stream, which a non-blocking stream does not wait for) */
+        if (i == 2 && sl.rv_cap[i] != had) HIP_TRY(e, hipMemsetAsync(sl.d_rv[i], 0, sl.rv_cap[i], sl.stream), AACG_ERR_NO_DEVICE);
     }
     const bool r8 = takes_run8(e, h);
     const size_t r8b[3] = {r8 ? sizeof(aacg_run8) * h.runs8.size() : 0, r8 ? sizeof(unsigned long long) * AACG8_RV_STATE_WORDS * (size_t)h.n_links : 0,
@@ -891,7 +896,7 @@ int aacg_submit_ex(aacg_engine* e, const aacg_batch* batch, uint64_t* ticket)
     for (int i = 0; i < 3; i++) {
         const size_t had = sl.run8_cap[i];
         if (r8b[i] && (rc = grow(e, &sl.d_run8[i], &sl.run8_cap[i], r8b[i]))) return rc;
-        if (i == 1 && sl.run8_cap[i] != had) HIP_TRY(e, hipMemset(sl.d_run8[i], 0, sl.run8_cap[i]), AACG_ERR_NO_DEVICE);   /* a new state buffer starts from zero */
+        if (i == 1 && sl.run8_cap[i] != had) HIP_TRY(e, hipMemsetAsync(sl.d_run8[i], 0, sl.run8_cap[i], sl.stream), AACG_ERR_NO_DEVICE);   /* likewise */
     }
     const size_t cb = (size_t)n_coef_blocks * 1024u * coef_elem_size(e);
     const size_t mb = quant ? (size_t)n_meta * sizeof(aacg_band_meta) : 0;
