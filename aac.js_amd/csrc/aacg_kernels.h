@@ -718,7 +718,8 @@ DP_DEVICE void long_pair(const float* tab, const chan_par& cp, bool want_head, f
     else                                    long_pair_window<AACG_LONG_STOP_SEQUENCE>(tab, cp, want_head, slot, c, R, I, mR, mI, hx, hy);
 }
 
-/* EIGHT_SHORT, both channels. */
+/* EIGHT_SHORT, both channels.  Slot indices as a few lane-dependent bases plus compile-time offsets, like long_pair: with
+ * stg / pch2 evaluated per element the path carried some 150 vector instructions of index arithmetic per frame. */
 template <bool VM>
 DP_DEVICE void short_pair(const float* tab, const chan_par& cp, float* slot, dpv2 (&hx)[8], dpv2 (&hy)[8])
 {
@@ -726,24 +727,46 @@ DP_DEVICE void short_pair(const float* tab, const chan_par& cp, float* slot, dpv
     const float* sincos = tab + AACG_TAB_OFF_SINCOS_SHORT;
 
     cpx2 z[8];
+    {
+        /* stg(64 w + g + 8 j)      = 64 w + g + 8 (j ^ (w & 3)):             base eb[j & 3] + 32 (j >> 2)
+         * stg(64 w + 63 - g - 8 j) = 64 w + 7 - g + 8 ((7 - j) ^ (w & 3)):   base ob[3 - (j & 3)] + 32 (1 - (j >> 2)) */
+        const int w3 = (w & 3) << 3, e0 = ((w << 6) | g) | w3, o0 = (512 + ((w << 6) | (7 - g))) | w3;
+        int eb[4], ob[4];
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
-        const cpx sc = lds_get(sincos, 8 * j + g);
-        const dpv2 xe = lds_pair(slot, stg(64 * w + g + 8 * j));                 /* X_w[2k], k = g + 8 j */
-        const dpv2 xo = lds_pair(slot, 512 + stg(64 * w + 63 - g - 8 * j));      /* X_w[127 - 2k]        */
-        z[j].im = xe * v2s(sc.re) + xo * v2s(sc.im);
-        z[j].re = xo * v2s(sc.re) - xe * v2s(sc.im);
+        for (int m = 0; m < 4; m++) { eb[m] = e0 ^ (m << 3); ob[m] = o0 ^ (m << 3); }
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const cpx sc = lds_get(sincos, 8 * j + g);
+            const dpv2 xe = lds_pair(slot, eb[j & 3] + 32 * (j >> 2));                 /* X_w[2k], k = g + 8 j */
+            const dpv2 xo = lds_pair(slot, ob[3 - (j & 3)] + 32 * (1 - (j >> 2)));     /* X_w[127 - 2k]        */
+            z[j].im = xe * v2s(sc.re) + xo * v2s(sc.im);
+            z[j].re = xo * v2s(sc.re) - xe * v2s(sc.im);
+        }
     }
     dp_wave_sync();
 
     radix8_inv2(z);
 #pragma unroll
     for (int q = 1; q < 8; q++) z[q] = c2_mul(z[q], lds_get(tab + AACG_TAB_OFF_TW64, 8 * (q - 1) + g));
+    {
+        /* pch2(8 w + q, g) = 64 w + 8 q + (g ^ 4 (w & 1) ^ (q >> 1)): base pb[q >> 1] + 8 q */
+        const int p0 = (w << 6) | (g ^ ((w & 1) << 2));
+        int pb[4];
 #pragma unroll
-    for (int q = 0; q < 8; q++) lds_put2(slot, pch2(8 * w + q, g), z[q]);
+        for (int m = 0; m < 4; m++) pb[m] = p0 ^ m;
+#pragma unroll
+        for (int q = 0; q < 8; q++) lds_put2(slot, pb[q >> 1] + 8 * q, z[q]);
+    }
     dp_wave_sync();
+    {
+        /* pch2(l, i) = (8 l + (l >> 1 & 7)) ^ i; with the slot 128-byte aligned the byte address is base ^ 16 i */
+        const int ab = dp_lds_addr(slot) + 16 * (8 * l + ((l >> 1) & 7));
 #pragma unroll
-    for (int i = 0; i < 8; i++) z[i] = lds_get2(slot, pch2(l, i));
+        for (int i = 0; i < 8; i++) {
+            const dpf4 t = dp_lds_read_f4(ab ^ (16 * i));
+            z[i].re = v2(t.x, t.y); z[i].im = v2(t.z, t.w);
+        }
+    }
     dp_wave_sync();
     radix8_inv2(z);
 
@@ -785,37 +808,56 @@ DP_DEVICE void short_pair(const float* tab, const chan_par& cp, float* slot, dpv
     /* s[128 w + i] = tail of block w-1 + head of block w (filter_bank.js:155-160): the previous window's tails sit eight lanes
      * down.  The rotation goes through the wave's own slot, which is free between the last transpose read and the tails:
      * eight 16-byte stores ([m][lane]: conflict-free) + eight loads instead of 32 ds_bpermute (a rotation by eight lanes
-     * crosses the 16-lane rows, so it has no DPP form) */
+     * crosses the 16-lane rows, so it has no DPP form).  The first window has no block before it and adds
+     * zeros: its lanes skip the loads (one lane mask around them) instead of selecting 32 registers afterwards. */
     dpv2 pt[16];
 #pragma unroll
     for (int m = 0; m < 8; m++) {
         dpf4 o; o.x = tl[2 * m][0]; o.y = tl[2 * m][1]; o.z = tl[2 * m + 1][0]; o.w = tl[2 * m + 1][1];
         *(dpf4*)(slot + 256 * m + 4 * l) = o;
     }
-    dp_wave_sync();
 #pragma unroll
-    for (int m = 0; m < 8; m++) {
-        const dpf4 t = *(const dpf4*)(slot + 256 * m + 4 * ((l - 8) & 63));
-        pt[2 * m] = v2(t.x, t.y); pt[2 * m + 1] = v2(t.z, t.w);
+    for (int m = 0; m < 16; m++) pt[m] = v2s(0.0f);
+    dp_wave_sync();
+    if (w != 0) {
+#pragma unroll
+        for (int m = 0; m < 8; m++) {
+            const dpf4 t = *(const dpf4*)(slot + 256 * m + 4 * (l - 8));
+            pt[2 * m] = v2(t.x, t.y); pt[2 * m + 1] = v2(t.z, t.w);
+        }
     }
     dp_wave_sync();                                    /* the slot takes the tails next */
 #pragma unroll
     for (int i = 0; i < 8; i++) {
-        hx[i] = (w == 0 ? v2s(0.0f) : pt[i]) + hd[i];
-        hy[i] = (w == 0 ? v2s(0.0f) : pt[8 + i]) + hd[8 + i];
+        hx[i] = pt[i] + hd[i];
+        hy[i] = pt[8 + i] + hd[8 + i];
     }
 
-    /* second half of s -> new overlap, interleaved (filter_bank.js:164-176) */
+    /* second half of s -> new overlap, interleaved (filter_bank.js:164-176): position p = 128 w + 2 g + 16 mm takes part
+     * from 576 on, i.e. windows 5.. with every mm and window 4 with mm >= 4 — two lane masks instead of eight compares */
+    if (w >= 4) {
 #pragma unroll
-    for (int mm = 0; mm < 8; mm++) {
-        const int p = 128 * w + 2 * g + 16 * mm;
-        if (p >= 576) { dpf4 o; o.x = hx[mm][0]; o.y = hx[mm][1]; o.z = hy[mm][0]; o.w = hy[mm][1]; *(dpf4*)(slot + 2 * (p - 576)) = o; }
-        if (w == 7)   { dpf4 o; o.x = tl[mm][0]; o.y = tl[mm][1]; o.z = tl[8 + mm][0]; o.w = tl[8 + mm][1]; *(dpf4*)(slot + 2 * (448 + 2 * g + 16 * mm)) = o; }
+        for (int mm = 4; mm < 8; mm++) {
+            const int p = 128 * w + 2 * g + 16 * mm;
+            dpf4 o; o.x = hx[mm][0]; o.y = hx[mm][1]; o.z = hy[mm][0]; o.w = hy[mm][1]; *(dpf4*)(slot + 2 * (p - 576)) = o;
+        }
     }
+    if (w >= 5) {
 #pragma unroll
-    for (int t4 = 0; t4 < 4; t4++) {
-        const int n = 576 + 2 * l + 128 * t4;
-        if (n < 1024) { dpf4 zz; zz.x = zz.y = zz.z = zz.w = 0.0f; *(dpf4*)(slot + 2 * n) = zz; }
+        for (int mm = 0; mm < 4; mm++) {
+            const int p = 128 * w + 2 * g + 16 * mm;
+            dpf4 o; o.x = hx[mm][0]; o.y = hx[mm][1]; o.z = hy[mm][0]; o.w = hy[mm][1]; *(dpf4*)(slot + 2 * (p - 576)) = o;
+        }
+    }
+    if (w == 7) {
+#pragma unroll
+        for (int mm = 0; mm < 8; mm++) { dpf4 o; o.x = tl[mm][0]; o.y = tl[mm][1]; o.z = tl[8 + mm][0]; o.w = tl[8 + mm][1]; *(dpf4*)(slot + 2 * (448 + 2 * g + 16 * mm)) = o; }
+    }
+    {
+        dpf4 zz; zz.x = zz.y = zz.z = zz.w = 0.0f;
+#pragma unroll
+        for (int t4 = 0; t4 < 3; t4++) *(dpf4*)(slot + 2 * (576 + 2 * l + 128 * t4)) = zz;        /* 576 .. 959 */
+        if (l < 32) *(dpf4*)(slot + 2 * (960 + 2 * l)) = zz;                                      /* 960 .. 1023 */
     }
 }
 
