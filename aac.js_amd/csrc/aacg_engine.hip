@@ -46,6 +46,8 @@ struct cce_bufs { const aacg_run* runs; const aacg_couple_job* jobs; const float
 /* aacg_engine8.hip: the one-channel-per-wave run kernels (two workgroups per CU) */
 void aacg_run8_launch(bool quant, dim3 grid, dim3 block, hipStream_t s, const aacg_kparams8& P);
 struct run8_bufs { const aacg_run8* runs; unsigned long long* rv_state; float* rv_data; };
+/* aacg_engine_nt.hip: the plain run kernels for multichannel batches (non-temporal loads of the spectra) */
+void aacg_nt_launch(bool quant, dim3 grid, dim3 block, hipStream_t s, const aacg_kparams& P);
 /* aacg_engine_rv.hip: the 16-wave kernels for chains longer than a run, with a run-to-run rendezvous instead of a recomputed frame */
 void aacg_rv_launch(bool quant, dim3 grid, dim3 block, hipStream_t s, const aacg_kparams& P, const aacg_rv_args& V);
 struct rv_bufs { const aacg_run* runs; const aacg_rv_link* links; unsigned long long* state; float* data; };
@@ -246,7 +248,8 @@ std::string route_names(const aacg_engine* e, const aacg_plan_host& h)
         if (!h.runs.empty()) add(run + "_cpl");
         return r;
     }
-    if (!h.runs.empty()) add(run + (ex ? "_ex" : "") + (!ex && h.needs_scratch ? "_dd" : "") + (!ex && i16 ? "_i16" : ""));
+    const bool nt = !ex && !i16 && !h.needs_scratch && h.wide_frames && !e->d_trace;
+    if (!h.runs.empty()) add(run + (ex ? "_ex" : "") + (!ex && h.needs_scratch ? "_dd" : "") + (!ex && i16 ? "_i16" : "") + (nt ? "_nt" : ""));
     if (h.any_cce) {
         if (!h.cce_runs.empty()) add(run + " (coupling elements)");
         add("aacg_couple_pcm");
@@ -353,6 +356,8 @@ int launch_run(aacg_engine* e, const aacg_dev_unit* d_units, const aacg_run* d_r
             aacg_i16_launch(quant, h.needs_scratch, grid, block, s, P);
         } else if (h.needs_scratch) {
             aacg_ext_launch(quant, grid, block, s, P);
+        } else if (h.wide_frames && !e->d_trace) {
+            aacg_nt_launch(quant, grid, block, s, P);
         } else {
             if (quant) hipLaunchKernelGGL(aacg_imdct_run_quant, grid, block, 0, s, P);
             else       hipLaunchKernelGGL(aacg_imdct_run_f32, grid, block, 0, s, P);

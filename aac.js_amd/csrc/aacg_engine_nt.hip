@@ -1,0 +1,24 @@
+/*
+ * aacg_engine_nt.hip — the run kernels for multichannel batches (see aacg_engine.hip): separate translation unit, separate
+ * code object.  MI355X (gfx950) only.
+ *
+ * A frame of more than two channels leaves the kernel element by element: a channel pair writes 8 bytes of every 4 C, and the
+ * L2 puts the elements' pieces together for as long as the lines stay resident.  These
+ * variants load their spectra with the non-temporal hint (dp_load_nt), so that 80 MB of input per launch stream past those
+ * lines instead of through them, and skip the per-frame issue priorities.
+ */
+#include <hip/hip_runtime.h>
+
+#include "aacg_kernels.h"
+
+extern "C" __global__ __launch_bounds__(AACG_WG_THREADS)
+void aacg_imdct_run_quant_nt(const aacg_kparams P) { imdct_run_body<AACG_INPUT_QUANT_I16, AACG_OUTPUT_F32, false, false, false, false, true>(P); }
+
+extern "C" __global__ __launch_bounds__(AACG_WG_THREADS)
+void aacg_imdct_run_f32_nt(const aacg_kparams P) { imdct_run_body<AACG_INPUT_SPEC_F32, AACG_OUTPUT_F32, false, false, false, false, true>(P); }
+
+void aacg_nt_launch(bool quant, dim3 grid, dim3 block, hipStream_t s, const aacg_kparams& P)
+{
+    if (quant) hipLaunchKernelGGL(aacg_imdct_run_quant_nt, grid, block, 0, s, P);
+    else       hipLaunchKernelGGL(aacg_imdct_run_f32_nt, grid, block, 0, s, P);
+}

@@ -37,6 +37,7 @@ struct aacg_plan_host {
     bool     any_tns = false;         /* some channel has AACG_CHAN_TNS_PRESENT and TNS records were given */
     bool     any_pns = false;         /* some unit carries AACG_UNIT_HAS_PNS */
     bool     needs_scratch = false;   /* some later run holds 16 frames: its first wave parks the predecessor's tails */
+    bool     wide_frames = false;     /* at least half of the units belong to frames of more than two channels: the multichannel kernel variants (aacg_engine_nt.hip) */
     std::vector<aacg_run>   runs;     /* in launch (block) order, XCD-aware */
     /* the same chains cut for the 8-waves-per-SIMD kernels (aacg_kernels8.h): 8 frames of a channel pair or 16 of a single
      * channel per run, consecutive runs of a chain joined by a rendezvous cell instead of a recomputed frame */

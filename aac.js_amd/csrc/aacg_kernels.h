@@ -809,28 +809,38 @@ DP_DEVICE void short_pair(const float* tab, const chan_par& cp, float* slot, dpv
      * down.  The rotation goes through the wave's own slot, which is free between the last transpose read and the tails:
      * eight 16-byte stores ([m][lane]: conflict-free) + eight loads instead of 32 ds_bpermute (a rotation by eight lanes
      * crosses the 16-lane rows, so it has no DPP form).  The first window has no block before it and adds
-     * zeros: its lanes skip the loads (one lane mask around them) instead of selecting 32 registers afterwards. */
+     * zeros: on the int16 seam (VM) its lanes skip the loads (one lane mask around them) instead of selecting 32 registers
+     * afterwards; the f32 kernels keep the selects — with the mask their register allocation went from 123 to 128 with spills
+     * in the _dd and _rv variants (tests/test_kernel_resources.py). */
     dpv2 pt[16];
 #pragma unroll
     for (int m = 0; m < 8; m++) {
         dpf4 o; o.x = tl[2 * m][0]; o.y = tl[2 * m][1]; o.z = tl[2 * m + 1][0]; o.w = tl[2 * m + 1][1];
         *(dpf4*)(slot + 256 * m + 4 * l) = o;
     }
-#pragma unroll
-    for (int m = 0; m < 16; m++) pt[m] = v2s(0.0f);
     dp_wave_sync();
-    if (w != 0) {
+    if (VM) {
+#pragma unroll
+        for (int m = 0; m < 16; m++) pt[m] = v2s(0.0f);
+        if (w != 0) {
+#pragma unroll
+            for (int m = 0; m < 8; m++) {
+                const dpf4 t = *(const dpf4*)(slot + 256 * m + 4 * (l - 8));
+                pt[2 * m] = v2(t.x, t.y); pt[2 * m + 1] = v2(t.z, t.w);
+            }
+        }
+    } else {
 #pragma unroll
         for (int m = 0; m < 8; m++) {
-            const dpf4 t = *(const dpf4*)(slot + 256 * m + 4 * (l - 8));
+            const dpf4 t = *(const dpf4*)(slot + 256 * m + 4 * ((l - 8) & 63));
             pt[2 * m] = v2(t.x, t.y); pt[2 * m + 1] = v2(t.z, t.w);
         }
     }
     dp_wave_sync();                                    /* the slot takes the tails next */
 #pragma unroll
     for (int i = 0; i < 8; i++) {
-        hx[i] = pt[i] + hd[i];
-        hy[i] = pt[8 + i] + hd[8 + i];
+        hx[i] = ((!VM && w == 0) ? v2s(0.0f) : pt[i]) + hd[i];
+        hy[i] = ((!VM && w == 0) ? v2s(0.0f) : pt[8 + i]) + hd[8 + i];
     }
 
     /* second half of s -> new overlap, interleaved (filter_bank.js:164-176): position p = 128 w + 2 g + 16 mm takes part
@@ -879,6 +889,7 @@ DP_DEVICE void short_pair(const float* tab, const chan_par& cp, float* slot, dpv
 struct quant_regs { dpi4 ql[2], qr[2]; unsigned mw[2][2]; };
 
 /* the unit's quantised spectra (16 bytes per lane per load) and raw band words, issued early */
+template <bool NTL = false>                             /* NTL: non-temporal loads (dp_load_nt) */
 DP_DEVICE void quant_load(const aacg_kparams& P, const unit_view& u, int n_ch, quant_regs& r)
 {
     const int lane = dp_lane();
@@ -891,8 +902,11 @@ DP_DEVICE void quant_load(const aacg_kparams& P, const unit_view& u, int n_ch, q
     const int b1 = lane + 64 < AACG_MAX_SECTIONS ? lane + 64 : AACG_MAX_SECTIONS - 1;
 #pragma unroll
     for (int i = 0; i < 2; i++) {
+        if (NTL) { r.ql[i] = dp_load_nt((const dpi4*)(q0 + 8 * lane + 512 * i)); r.qr[i] = dp_load_nt((const dpi4*)(q1 + 8 * lane + 512 * i)); }
+        else {
         r.ql[i] = *(const dpi4*)(q0 + 8 * lane + 512 * i);
         r.qr[i] = *(const dpi4*)(q1 + 8 * lane + 512 * i);
+        }
     }
     r.mw[0][0] = meta->band[lane]; r.mw[0][1] = meta->band[b1];
     r.mw[1][0] = m1->band[lane];   r.mw[1][1] = m1->band[b1];
@@ -1957,7 +1971,7 @@ DP_DEVICE void rv_finish_successor(const aacg_kparams& P, const unit_view& su, i
 #define AACG_LDS_BYTES_QUANT_EX (AACG_LDS_BYTES_QUANT + 4 * AACG_WG_WAVES * AACG_RUN_XCH_FLOATS)
 /* RV = true builds (aacg_engine_rv.hip): chains longer than a run without a recomputed frame — the plan's runs all start from
  * what the run before them hands over through a rendezvous cell (aacg_rv_args), never from a recomputed predecessor. */
-template <int KIND, int OUT = AACG_OUTPUT_F32, bool DD = false, bool EX = false, bool CPL = false, bool RV = false>
+template <int KIND, int OUT = AACG_OUTPUT_F32, bool DD = false, bool EX = false, bool CPL = false, bool RV = false, bool NTL = false>
 DP_DEVICE void imdct_run_body(const aacg_kparams& P, const aacg_rv_args* V = nullptr)
 {
     const int TAB_FLOATS = (KIND == AACG_INPUT_QUANT_I16) ? AACG_TAB_QUANT_FLOATS : AACG_TAB_F32_FLOATS;
@@ -2000,6 +2014,8 @@ DP_DEVICE void imdct_run_body(const aacg_kparams& P, const aacg_rv_args* V = nul
     /* Earlier frames get the higher issue priority: they finish first and their PCM stores overlap
      * the later waves' arithmetic.  A wave only ever waits for the wave before it, whose priority is
      * never lower, so a spinning consumer cannot starve its producer. */
+    /* (the multichannel variants leave every wave at the default priority: 62.0 -> 61.9 us on config 5, nothing anywhere else) */
+    if (NTL) {} else
     if (AACG_ABL(P, 64)) dp_setprio(0); else if (AACG_ABL(P, 32)) dp_setprio(1 - (wave >> 3)); else dp_setprio(hands_over ? 3 : 3 - (wave >> 2));
     const unsigned long long t_start = AACG_ABL(P, 16) ? dp_clock() : 0;
     /* (the coupling builds carry their side buffer in spec_out, aacg_set_cpl: never a trace there) */
@@ -2017,12 +2033,15 @@ DP_DEVICE void imdct_run_body(const aacg_kparams& P, const aacg_rv_args* V = nul
     quant_regs qreg;
     dpf4 xa[4], xb[4];
     auto issue_loads = [&]() {
-        if (KIND == AACG_INPUT_QUANT_I16) quant_load(P, u, u.n_ch, qreg);
+        if (KIND == AACG_INPUT_QUANT_I16) quant_load<NTL>(P, u, u.n_ch, qreg);
         else {
             const float* xsrc = (const float*)P.coeffs + (size_t)u.coef_offset * 1024u;
             const float* xsrc1 = xsrc + (u.n_ch == 2 ? 1024 : 0);
 #pragma unroll
-            for (int i = 0; i < 4; i++) { xa[i] = *(const dpf4*)(xsrc + 4 * lane + 256 * i); xb[i] = *(const dpf4*)(xsrc1 + 4 * lane + 256 * i); }
+            for (int i = 0; i < 4; i++) {
+                if (NTL) { xa[i] = dp_load_nt((const dpf4*)(xsrc + 4 * lane + 256 * i)); xb[i] = dp_load_nt((const dpf4*)(xsrc1 + 4 * lane + 256 * i)); }
+                else     { xa[i] = *(const dpf4*)(xsrc + 4 * lane + 256 * i); xb[i] = *(const dpf4*)(xsrc1 + 4 * lane + 256 * i); }
+            }
         }
     };
     /* the tails of a unit from its slot (interleaved for two channels) to planar arrays in global memory */

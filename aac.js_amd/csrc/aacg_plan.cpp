@@ -197,10 +197,12 @@ int aacg_plan_build(const aacg_unit_desc* units, uint32_t n_units, int sample_in
         if (s.seen && s.mask != ((1u << s.n_out) - 1u)) { out->zero_fill = true; s.holes = true; }
     };
 
+    uint32_t n_wide = 0;                                    /* units of frames with more than two channels */
     std::vector<uint32_t> frame_of(n_units, 0);             /* frame ordinal of every unit inside its stream's batch */
     for (uint32_t i = 0; i < n_units; i++) {
         const aacg_unit_desc& u = units[i];
         if (u.flags & AACG_UNIT_HAS_PNS) out->any_pns = true;
+        if (u.n_out_ch > 2) n_wide++;
         if (u.n_ch < 1 || u.n_ch > 2) return fail(err, AACG_ERR_INVALID_ARG, "unit %ld: n_ch %ld", i, u.n_ch);
         if ((int)u.stream >= max_streams) return fail(err, AACG_ERR_CAPACITY, "unit %ld: stream %ld >= max_streams", i, u.stream);
         const bool is_cce = (u.flags & AACG_UNIT_CCE) != 0;
@@ -292,6 +294,7 @@ int aacg_plan_build(const aacg_unit_desc* units, uint32_t n_units, int sample_in
         out->pcm_floats = std::max(out->pcm_floats, (size_t)((uint64_t)u.pcm_offset + 1024u * (uint64_t)u.n_out_ch));
     }
 
+    out->wide_frames = 2u * n_wide >= n_units && n_wide > 0;
     std::vector<uint32_t> couple_target;                     /* target unit of couple_jobs[j] */
     if (out->any_cce) {
         /* coupling jobs: every (coupling element, target) pair, by coupling point and by round — the r-th coupling element

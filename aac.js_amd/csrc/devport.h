@@ -317,6 +317,21 @@ DP_DEVICE void dp_store_nt(dpf4* p, dpf4 v)
     dp_nv4 t; t[0] = v.x; t[1] = v.y; t[2] = v.z; t[3] = v.w;
     __builtin_nontemporal_store(t, (dp_nv4*)p);
 }
+/* streaming loads of 16 bytes (global_load_dwordx4 ... nt): the spectra of a multichannel batch.  There the PCM goes out as the
+ * elements' partial lines, which the L2 merges while they stay resident; spectra that stream through it without the hint
+ * push them out early (config 5: 64.5 -> 62.0 us with the hint, f32 seam 69.3 -> 65.6).  Stereo batches store whole lines
+ * and are 4 % slower with it (12.1 -> 12.6 us), so the hint is a kernel variant, not the default. */
+typedef int dp_nv4i __attribute__((ext_vector_type(4)));
+DP_DEVICE dpi4 dp_load_nt(const dpi4* p)
+{
+    const dp_nv4i t = __builtin_nontemporal_load((const dp_nv4i*)p);
+    dpi4 r; r.x = t[0]; r.y = t[1]; r.z = t[2]; r.w = t[3]; return r;
+}
+DP_DEVICE dpf4 dp_load_nt(const dpf4* p)
+{
+    const dp_nv4 t = __builtin_nontemporal_load((const dp_nv4*)p);
+    dpf4 r; r.x = t[0]; r.y = t[1]; r.z = t[2]; r.w = t[3]; return r;
+}
 /* two adjacent floats at an address that is only 4-byte aligned (odd channel counts): one
  * global_store_dwordx2 — gfx950 runs in unaligned-access mode, and the type says align 4 */
 typedef float dp_f2u __attribute__((ext_vector_type(2), aligned(4)));

@@ -193,6 +193,8 @@ DP_DEVICE void dp_scale_where(dp_lanes on, const dpv2& l0, const dpv2& l1, float
 }
 DP_DEVICE dpv2 dp_fma2(dpv2 a, dpv2 b, dpv2 c) { dpv2 r; r[0] = fmaf(a[0], b[0], c[0]); r[1] = fmaf(a[1], b[1], c[1]); return r; }
 DP_DEVICE void dp_store_nt(dpf4* p, dpf4 v) { *p = v; }
+DP_DEVICE dpi4 dp_load_nt(const dpi4* p) { return *p; }
+DP_DEVICE dpf4 dp_load_nt(const dpf4* p) { return *p; }
 DP_DEVICE void dp_store2_u(float* p, float a, float b) { p[0] = a; p[1] = b; }
 DP_DEVICE int dp_pcm16_pair(float a, float b)
 {

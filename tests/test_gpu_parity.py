@@ -527,6 +527,10 @@ def test_bench_workload_vs_oracle(oracle, name):
     wl = aacgpu_workload.make_batch(n_streams=S, n_frames=T, mix=mix, layout=layout, seed=0xAAC00002)
     eng = aacgpu.Engine(aacgpu.INPUT_QUANT_I16, max_streams=S, max_channels=C)
     plan = eng.plan(wl["units"])
+    # the route the planner picks: frames of more than two channels take the multichannel variant (non-temporal loads of the
+    # spectra, aacg_engine_nt.hip), config 4's long chains the run-to-run rendezvous, the rest the plain kernel
+    assert eng.plan_kernels(plan) == {"cfg2": "aacg_imdct_run_quant", "cfg3": "aacg_imdct_run_quant", "cfg4": "aacg_imdct_run_quant_rv",
+                                      "cfg5": "aacg_imdct_run_quant_nt"}[name]
     d_q, d_meta = torch.from_numpy(wl["q"]).cuda(), torch.from_numpy(wl["meta"].view(np.int16)).cuda()
     d_pcm = torch.full((wl["n_pcm"],), float("nan"), dtype=torch.float32, device="cuda")
     stream = torch.cuda.Stream()
