@@ -49,7 +49,7 @@ struct run8_bufs { const aacg_run8* runs; unsigned long long* rv_state; float* r
 /* aacg_engine_nt.hip: the plain run kernels for multichannel batches (non-temporal loads of the spectra) */
 void aacg_nt_launch(bool quant, dim3 grid, dim3 block, hipStream_t s, const aacg_kparams& P);
 /* aacg_engine_rv.hip: the 16-wave kernels for chains longer than a run, with a run-to-run rendezvous instead of a recomputed frame */
-void aacg_rv_launch(bool quant, dim3 grid, dim3 block, hipStream_t s, const aacg_kparams& P, const aacg_rv_args& V);
+void aacg_rv_launch(bool quant, bool wide, dim3 grid, dim3 block, hipStream_t s, const aacg_kparams& P, const aacg_rv_args& V);
 struct rv_bufs { const aacg_run* runs; const aacg_rv_link* links; unsigned long long* state; float* data; };
 
 extern "C" __global__ __launch_bounds__(AACG_WG_THREADS)
@@ -240,7 +240,7 @@ std::string route_names(const aacg_engine* e, const aacg_plan_host& h)
         quant = false;
     }
     if (takes_run8(e, h)) return std::string("aacg_imdct_run8_") + (quant ? "quant" : "f32");
-    if (takes_rv(e, h)) return std::string("aacg_imdct_run_") + (quant ? "quant" : "f32") + "_rv";
+    if (takes_rv(e, h)) return std::string("aacg_imdct_run_") + (quant ? "quant" : "f32") + "_rv" + (h.wide_frames ? "_nt" : "");
     const std::string run = std::string("aacg_imdct_run_") + (quant ? "quant" : "f32");
     const bool fused = h.fused_independent && !ex && !i16 && !(e->debug_route & AACG_DEBUG_ROUTE_UNFUSED_COUPLING);
     if (fused) {
@@ -283,7 +283,7 @@ int launch_run(aacg_engine* e, const aacg_dev_unit* d_units, const aacg_run* d_r
         P.overlap = e->d_overlap; P.tab = e->d_tab; P.flip = flip; P.n_runs = (int32_t)h.runs_rv.size();
         aacg_rv_args V;
         V.links = rvb.links; V.state = rvb.state; V.data = rvb.data; V.epoch = ++e->rv_epoch;
-        aacg_rv_launch(quant, dim3((unsigned)h.runs_rv.size()), dim3(AACG_WG_THREADS), s, P, V);
+        aacg_rv_launch(quant, h.wide_frames, dim3((unsigned)h.runs_rv.size()), dim3(AACG_WG_THREADS), s, P, V);
         HIP_TRY(e, hipGetLastError(), AACG_ERR_NO_DEVICE);
         return AACG_OK;
     }

@@ -2015,7 +2015,7 @@ DP_DEVICE void imdct_run_body(const aacg_kparams& P, const aacg_rv_args* V = nul
      * the later waves' arithmetic.  A wave only ever waits for the wave before it, whose priority is
      * never lower, so a spinning consumer cannot starve its producer. */
     /* (the multichannel variants leave every wave at the default priority: 62.0 -> 61.9 us on config 5, nothing anywhere else) */
-    if (NTL) {} else
+    if (NTL && !RV) {} else
     if (AACG_ABL(P, 64)) dp_setprio(0); else if (AACG_ABL(P, 32)) dp_setprio(1 - (wave >> 3)); else dp_setprio(hands_over ? 3 : 3 - (wave >> 2));
     const unsigned long long t_start = AACG_ABL(P, 16) ? dp_clock() : 0;
     /* (the coupling builds carry their side buffer in spec_out, aacg_set_cpl: never a trace there) */

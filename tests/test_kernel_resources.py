@@ -20,7 +20,7 @@ SCHED = ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"]
 WIDE = (128, 4, 160 * 1024)
 NARROW = (64, 8, 80 * 1024)            # one channel per wave: two 16-wave workgroups per CU
 TUS = {
-    "aacg_engine_rv.hip": (SCHED, {"aacg_imdct_run_quant_rv": WIDE, "aacg_imdct_run_f32_rv": WIDE}),
+    "aacg_engine_rv.hip": (SCHED, {"aacg_imdct_run_quant_rv": WIDE, "aacg_imdct_run_f32_rv": WIDE, "aacg_imdct_run_quant_rv_nt": WIDE, "aacg_imdct_run_f32_rv_nt": WIDE}),
     "aacg_engine_nt.hip": (SCHED, {"aacg_imdct_run_quant_nt": WIDE, "aacg_imdct_run_f32_nt": WIDE}),
     "aacg_engine8.hip": (SCHED, {"aacg_imdct_run8_quant": NARROW, "aacg_imdct_run8_f32": NARROW}),
     "aacg_engine.hip": (SCHED, {"aacg_imdct_run_quant": WIDE, "aacg_imdct_run_f32": WIDE}),
