@@ -92,3 +92,27 @@ extern "C" int aacg_calib_copy(void* d_dst, const void* d_src, size_t bytes, voi
     hipLaunchKernelGGL(aacg_calib_copy_kernel, dim3((unsigned)cus), dim3(1024), 0, (hipStream_t)hip_stream, (dpf4*)d_dst, (const dpf4*)d_src, bytes / 16);
     return hipGetLastError() == hipSuccess ? AACG_OK : AACG_ERR_NO_DEVICE;
 }
+
+/* timing marks (include/aacgpu.h): events that only measure time */
+extern "C" int aacg_timer_create(void** mark)
+{
+    if (!mark) return AACG_ERR_INVALID_ARG;
+    hipEvent_t ev = nullptr;
+    if (hipEventCreateWithFlags(&ev, hipEventDisableSystemFence) != hipSuccess) return AACG_ERR_NO_DEVICE;
+    *mark = (void*)ev;
+    return AACG_OK;
+}
+extern "C" int aacg_timer_record(void* mark, void* hip_stream)
+{
+    if (!mark) return AACG_ERR_INVALID_ARG;
+    return hipEventRecord((hipEvent_t)mark, (hipStream_t)hip_stream) == hipSuccess ? AACG_OK : AACG_ERR_NO_DEVICE;
+}
+extern "C" int aacg_timer_elapsed_ms(void* first, void* second, float* ms)
+{
+    if (!first || !second || !ms) return AACG_ERR_INVALID_ARG;
+    return hipEventElapsedTime(ms, (hipEvent_t)first, (hipEvent_t)second) == hipSuccess ? AACG_OK : AACG_ERR_NO_DEVICE;
+}
+extern "C" void aacg_timer_destroy(void* mark)
+{
+    if (mark) (void)hipEventDestroy((hipEvent_t)mark);
+}

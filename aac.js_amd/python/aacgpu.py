@@ -26,7 +26,8 @@ ABI_SYMBOLS = ["aacg_create", "aacg_destroy", "aacg_last_error", "aacg_abi_versi
                "aacg_decode_device", "aacg_spectral_device", "aacg_synchronize", "aacg_get_table", "aacg_kernel_name",
                "aacg_parser_create", "aacg_parser_destroy", "aacg_parser_last_error", "aacg_parse_status_string",
                "aacg_parse_batch", "aacg_parse_device", "aacg_parse_kernel_name", "aacg_plan_refresh_from_parse", "aacg_standard_codebooks", "aacg_debug_transform",
-               "aacg_decode_batch_ex", "aacg_submit_ex", "aacg_plan_create_ex", "aacg_plan_kernels", "aacg_calib_copy", "aacg_plan_refresh_units", "aacg_debug_set_route"]
+               "aacg_decode_batch_ex", "aacg_submit_ex", "aacg_plan_create_ex", "aacg_plan_kernels", "aacg_calib_copy", "aacg_plan_refresh_units", "aacg_debug_set_route",
+               "aacg_timer_create", "aacg_timer_record", "aacg_timer_elapsed_ms", "aacg_timer_destroy"]
 
 UNIT_DTYPE = np.dtype([
     ("stream", "<u4"), ("pcm_offset", "<u4"), ("channel", "<u2"), ("n_out_ch", "<u2"),
@@ -111,6 +112,11 @@ def load_library(path=LIB_PATH):
     L.aacg_plan_kernels.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.c_size_t]
     L.aacg_plan_refresh_units.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
     L.aacg_calib_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    L.aacg_timer_create.argtypes = [C.POINTER(C.c_void_p)]
+    L.aacg_timer_record.argtypes = [C.c_void_p, C.c_void_p]
+    L.aacg_timer_elapsed_ms.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]
+    L.aacg_timer_destroy.argtypes = [C.c_void_p]
+    L.aacg_timer_destroy.restype = None
     L.aacg_debug_set_route.argtypes = [C.c_void_p, C.c_int]
     L.aacg_last_error.restype = C.c_char_p
     L.aacg_last_error.argtypes = [C.c_void_p]
@@ -185,6 +191,36 @@ def debug_transform(x, is_short=False, identity_rotation=False, sample_index=3, 
         raise AacgError(rc, "aacg_debug_transform failed")
     return out
 
+
+
+class TimerMark:
+    """aacg_timer_*: a HIP event that only measures time (hipEventDisableSystemFence), recorded on a given stream.
+    `a.elapsed_ms(b)` after the stream has been synchronised."""
+    def __init__(self):
+        self.h = C.c_void_p()
+        rc = load_library().aacg_timer_create(C.byref(self.h))
+        if rc:
+            raise AacgError(rc, "aacg_timer_create failed")
+
+    def record(self, stream):
+        rc = load_library().aacg_timer_record(self.h, stream)
+        if rc:
+            raise AacgError(rc, "aacg_timer_record failed")
+
+    def elapsed_ms(self, later):
+        ms = C.c_float()
+        rc = load_library().aacg_timer_elapsed_ms(self.h, later.h, C.byref(ms))
+        if rc:
+            raise AacgError(rc, "aacg_timer_elapsed_ms failed (stream not synchronised?)")
+        return float(ms.value)
+
+    def __del__(self):
+        try:
+            if self.h:
+                load_library().aacg_timer_destroy(self.h)
+                self.h = C.c_void_p()
+        except Exception:
+            pass
 
 def calib_copy(d_dst, d_src, n_bytes, stream=0):
     """aacg_calib_copy: float4 device-to-device copy with the run kernels' launch shape, enqueued on `stream`."""

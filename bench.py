@@ -188,6 +188,8 @@ def main():
                     help="i16: AACG_OUTPUT_I16 engine (supplementary; the reference returns float PCM, which is what the headline measures)")
     ap.add_argument("--repeats", type=int, default=25,
                     help="R: the K-step timed region is run R times back to back, each bracketed by its own HIP events; ms_per_step is the median")
+    ap.add_argument("--default-events", action="store_true",
+                    help="time with torch.cuda.Event (default HIP events: a system-scope fence per record) instead of timing-only events")
     ap.add_argument("--strict-backend", action="store_true",
                     help="exit non-zero if --dist-backend nccl was asked for and RCCL could not be initialised (default: fall back to gloo and say so "
                          "in the line's top-level collectives_backend_fallback)")
@@ -301,7 +303,19 @@ def main():
     for i in range(args.warmup):
         step(n_pre + i)
     R = max(1, args.repeats)
-    evs = [torch.cuda.Event(enable_timing=True) for _ in range(R + 1)]
+    # Timing marks: HIP events that only measure time (hipEventDisableSystemFence, aacg_timer_*).  A default event's record is
+    # a system-scope fence — cache write-back and invalidation — and the launch behind it starts on cold caches: at the
+    # driver's K = 20 that is one fence per 240 us of launches (12.45 against 12.13 us per step at K = 2000 on one box).
+    # --default-events measures with torch.cuda.Event instead.
+    class _Mark:
+        def __init__(self):
+            self.ev = torch.cuda.Event(enable_timing=True) if args.default_events else aacgpu.TimerMark()
+        def record(self):
+            if args.default_events: self.ev.record(tstream)
+            else: self.ev.record(tstream.cuda_stream)
+        def elapsed_time(self, later):
+            return self.ev.elapsed_time(later.ev) if args.default_events else self.ev.elapsed_ms(later.ev)
+    evs = [_Mark() for _ in range(R + 1)]
     issued = [0.0]
 
     def timed_steps():
@@ -330,7 +344,7 @@ def main():
         n_bytes = int(n_bytes) // 16 * 16
         src = [torch.empty(n_bytes, dtype=torch.uint8, device="cuda").random_(0, 255) for _ in range(n_sets)]
         dst = [torch.empty(n_bytes, dtype=torch.uint8, device="cuda") for _ in range(n_sets)]
-        ce = [torch.cuda.Event(enable_timing=True) for _ in range(repeats + 1)]
+        ce = [_Mark() for _ in range(repeats + 1)]
         for i in range(max(2, reps // 10)):
             aacgpu.calib_copy(dst[i % n_sets].data_ptr(), src[i % n_sets].data_ptr(), n_bytes, tstream.cuda_stream)
         ce[0].record()
@@ -375,9 +389,11 @@ def main():
         "value": value, "unit": unit, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": stats["ms_per_step_median"], "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "timing": dict(stats, method="the K timed steps are run R times back to back, each repeat between its own HIP events on the launch "
-                                     "stream (MAX over ranks per repeat); value and ms_per_step: the MEDIAN repeat; wall_*: host clock between "
-                                     "the barriers over all R x K steps (adds first-launch latency and the wake-up after the last step)"),
+        "timing": dict(stats, events=("torch.cuda.Event (default HIP events: a system-scope fence per record)" if args.default_events else
+                                      "hipEventDisableSystemFence (timing-only HIP events, aacg_timer_*)"),
+                       method="the K timed steps are run R times back to back, each repeat between its own HIP events on the launch "
+                              "stream (MAX over ranks per repeat); value and ms_per_step: the MEDIAN repeat; wall_*: host clock between "
+                              "the barriers over all R x K steps (adds first-launch latency and the wake-up after the last step)"),
         "wall_ms_per_step": wall / (R * args.steps) * 1e3, "value_wall": world * frames_per_step * R * args.steps / wall,
         "config": {"workload": {"cfg2": "BASELINE config 2: batch of 4096 stereo LC frames (256 streams x 16 frames, ONLY_LONG_SEQUENCE, KBD)",
                                 "cfg3": "BASELINE config 3: 4096 stereo frames, window-sequence mix [0,0,1,2,2,3,0,0], TNS identity",

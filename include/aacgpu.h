@@ -344,6 +344,14 @@ int aacg_plan_kernels(aacg_engine* e, const aacg_plan* p, char* dst, size_t n);
 /* Calibration for the bench: a float4 copy of `bytes` (multiple of 16) device to device with the run kernels' launch
  * shape, enqueued on hip_stream.  Gives the copy rate of THIS box for a launch of that size, next to the run kernel. */
 int aacg_calib_copy(void* d_dst, const void* d_src, size_t bytes, void* hip_stream);
+/* Timing marks for the bench: HIP events created with hipEventDisableSystemFence — HIP's flag for events that only measure
+ * time.  A default event performs a system-scope fence when it is recorded (cache write-back and invalidation), which a
+ * region of twenty 12-us launches between two events pays for (the launch behind a mark starts on cold caches); these do
+ * not.  They order nothing for the host: the caller synchronises the stream before asking for the elapsed time.          */
+int aacg_timer_create(void** mark);
+int aacg_timer_record(void* mark, void* hip_stream);
+int aacg_timer_elapsed_ms(void* first, void* second, float* ms);
+void aacg_timer_destroy(void* mark);
 
 
 /* ---- the bitstream front end on the device (optional; independent of aacg_engine) ---------------
