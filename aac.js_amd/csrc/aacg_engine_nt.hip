@@ -3,9 +3,10 @@
  * code object.  MI355X (gfx950) only.
  *
  * A frame of more than two channels leaves the kernel element by element: a channel pair writes 8 bytes of every 4 C, and the
- * L2 puts the elements' pieces together for as long as the lines stay resident.  These
- * variants load their spectra with the non-temporal hint (dp_load_nt), so that 80 MB of input per launch stream past those
- * lines instead of through them, and skip the per-frame issue priorities.
+ * L2 puts the elements' pieces together — millions of small write requests per launch, which is what bounds these batches
+ * (DESIGN.md section 8, config 5).  These variants load their spectra with the non-temporal hint (dp_load_nt): the same HBM
+ * traffic, but 80 MB of read-once input per launch no longer allocate lines in that L2; and they skip the per-frame issue
+ * priorities.
  */
 #include <hip/hip_runtime.h>
 

@@ -318,9 +318,10 @@ DP_DEVICE void dp_store_nt(dpf4* p, dpf4 v)
     __builtin_nontemporal_store(t, (dp_nv4*)p);
 }
 /* streaming loads of 16 bytes (global_load_dwordx4 ... nt): the spectra of a multichannel batch.  There the PCM goes out as the
- * elements' partial lines, which the L2 merges while they stay resident; spectra that stream through it without the hint
- * push them out early (config 5: 64.5 -> 62.0 us with the hint, f32 seam 69.3 -> 65.6).  Stereo batches store whole lines
- * and are 4 % slower with it (12.1 -> 12.6 us), so the hint is a kernel variant, not the default. */
+ * elements' partial lines, which the L2 merges — its write requests bound those batches — and read-once spectra that do not
+ * allocate in it leave it more room for that (config 5: 64.5 -> 62.0 us with the hint, f32 seam 69.3 -> 65.6; HBM traffic
+ * unchanged).  Stereo batches store whole lines and are 4 % slower with it (12.1 -> 12.6 us), so the hint is a kernel
+ * variant, not the default. */
 typedef int dp_nv4i __attribute__((ext_vector_type(4)));
 DP_DEVICE dpi4 dp_load_nt(const dpi4* p)
 {
