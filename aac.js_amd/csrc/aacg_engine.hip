@@ -34,7 +34,7 @@ void aacg_ext_launch(bool quant, dim3 grid, dim3 block, hipStream_t s, const aac
 void aacg_refresh_launch(aacg_dev_unit* units, const aacg_unit_desc* parsed, const aacg_parse_result* results, uint32_t n_units,
                          uint32_t max_units, int refuse_pns, uint32_t* refused, hipStream_t s);
 /* aacg_engine_i16.hip: the run kernels with int16 PCM stores (AACG_OUTPUT_I16 engines) */
-void aacg_i16_launch(bool quant, bool dd, dim3 grid, dim3 block, hipStream_t s, const aacg_kparams& P);
+void aacg_i16_launch(bool quant, bool dd, bool wide, dim3 grid, dim3 block, hipStream_t s, const aacg_kparams& P);
 /* aacg_engine_exrun.hip: the run kernels with the optional stages inside (one launch for TNS / PNS batches) */
 void aacg_exrun_launch(bool quant, dim3 grid, dim3 block, hipStream_t s, const aacg_kparams& P);
 int aacg_spectral_ex_set_lds_limits(void);
@@ -248,7 +248,7 @@ std::string route_names(const aacg_engine* e, const aacg_plan_host& h)
         if (!h.runs.empty()) add(run + "_cpl");
         return r;
     }
-    const bool nt = !ex && !i16 && !h.needs_scratch && h.wide_frames && !e->d_trace;
+    const bool nt = !ex && !h.needs_scratch && h.wide_frames && !e->d_trace;
     if (!h.runs.empty()) add(run + (ex ? "_ex" : "") + (!ex && h.needs_scratch ? "_dd" : "") + (!ex && i16 ? "_i16" : "") + (nt ? "_nt" : ""));
     if (h.any_cce) {
         if (!h.cce_runs.empty()) add(run + " (coupling elements)");
@@ -353,7 +353,7 @@ int launch_run(aacg_engine* e, const aacg_dev_unit* d_units, const aacg_run* d_r
         if (ex) {
             aacg_exrun_launch(quant, grid, block, s, P);
         } else if (i16) {
-            aacg_i16_launch(quant, h.needs_scratch, grid, block, s, P);
+            aacg_i16_launch(quant, h.needs_scratch, h.wide_frames && !e->d_trace, grid, block, s, P);
         } else if (h.needs_scratch) {
             aacg_ext_launch(quant, grid, block, s, P);
         } else if (h.wide_frames && !e->d_trace) {

@@ -16,9 +16,18 @@ void aacg_imdct_run_quant_dd_i16(const aacg_kparams P) { imdct_run_body<AACG_INP
 extern "C" __global__ __launch_bounds__(AACG_WG_THREADS)
 void aacg_imdct_run_f32_dd_i16(const aacg_kparams P) { imdct_run_body<AACG_INPUT_SPEC_F32, AACG_OUTPUT_I16, true>(P); }
 
-void aacg_i16_launch(bool quant, bool dd, dim3 grid, dim3 block, hipStream_t s, const aacg_kparams& P)
+/* batches of multichannel frames: non-temporal loads of the spectra (aacg_engine_nt.hip says why) */
+extern "C" __global__ __launch_bounds__(AACG_WG_THREADS)
+void aacg_imdct_run_quant_i16_nt(const aacg_kparams P) { imdct_run_body<AACG_INPUT_QUANT_I16, AACG_OUTPUT_I16, false, false, false, false, true>(P); }
+extern "C" __global__ __launch_bounds__(AACG_WG_THREADS)
+void aacg_imdct_run_f32_i16_nt(const aacg_kparams P) { imdct_run_body<AACG_INPUT_SPEC_F32, AACG_OUTPUT_I16, false, false, false, false, true>(P); }
+
+void aacg_i16_launch(bool quant, bool dd, bool wide, dim3 grid, dim3 block, hipStream_t s, const aacg_kparams& P)
 {
-    if (dd) {
+    if (wide && !dd) {
+        if (quant) hipLaunchKernelGGL(aacg_imdct_run_quant_i16_nt, grid, block, 0, s, P);
+        else       hipLaunchKernelGGL(aacg_imdct_run_f32_i16_nt, grid, block, 0, s, P);
+    } else if (dd) {
         if (quant) hipLaunchKernelGGL(aacg_imdct_run_quant_dd_i16, grid, block, 0, s, P);
         else       hipLaunchKernelGGL(aacg_imdct_run_f32_dd_i16, grid, block, 0, s, P);
     } else {

@@ -25,7 +25,7 @@ TUS = {
     "aacg_engine8.hip": (SCHED, {"aacg_imdct_run8_quant": NARROW, "aacg_imdct_run8_f32": NARROW}),
     "aacg_engine.hip": (SCHED, {"aacg_imdct_run_quant": WIDE, "aacg_imdct_run_f32": WIDE}),
     "aacg_engine_ext.hip": (SCHED, {"aacg_imdct_run_quant_dd": WIDE, "aacg_imdct_run_f32_dd": WIDE}),
-    "aacg_engine_i16.hip": (SCHED, {"aacg_imdct_run_quant_i16": WIDE, "aacg_imdct_run_f32_i16": WIDE}),
+    "aacg_engine_i16.hip": (SCHED, {"aacg_imdct_run_quant_i16": WIDE, "aacg_imdct_run_f32_i16": WIDE, "aacg_imdct_run_quant_i16_nt": WIDE, "aacg_imdct_run_f32_i16_nt": WIDE}),
     "aacg_engine_exrun.hip": (SCHED, {"aacg_imdct_run_quant_ex": WIDE, "aacg_imdct_run_f32_ex": WIDE}),
     "aacg_engine_couple.hip": ([], {"aacg_imdct_run_quant_cpl": WIDE, "aacg_imdct_run_f32_cpl": WIDE}),
 }
