@@ -41,7 +41,7 @@ int aacg_spectral_ex_set_lds_limits(void);
 void aacg_spectral_ex_launch(bool quant, int n_units, hipStream_t s, const aacg_kparams& P);
 /* aacg_engine_couple.hip: AACG_CCE_SPEC */
 void aacg_couple_launch(bool pcm, hipStream_t s, const aacg_couple_params& Q);
-void aacg_couple_run_launch(bool quant, dim3 grid, dim3 block, hipStream_t s, const aacg_kparams& P);
+void aacg_couple_run_launch(bool quant, bool wide, dim3 grid, dim3 block, hipStream_t s, const aacg_kparams& P);
 struct cce_bufs { const aacg_run* runs; const aacg_couple_job* jobs; const float* gains; float* side; };
 /* aacg_engine8.hip: the one-channel-per-wave run kernels (two workgroups per CU) */
 void aacg_run8_launch(bool quant, dim3 grid, dim3 block, hipStream_t s, const aacg_kparams8& P);
@@ -245,7 +245,7 @@ std::string route_names(const aacg_engine* e, const aacg_plan_host& h)
     const bool fused = h.fused_independent && !ex && !i16 && !(e->debug_route & AACG_DEBUG_ROUTE_UNFUSED_COUPLING);
     if (fused) {
         if (!h.cce_runs.empty()) add(run + " (coupling elements)");
-        if (!h.runs.empty()) add(run + "_cpl");
+        if (!h.runs.empty()) add(run + "_cpl" + (h.wide_frames ? "_nt" : ""));
         return r;
     }
     const bool nt = !ex && !h.needs_scratch && h.wide_frames && !e->d_trace;
@@ -348,7 +348,7 @@ int launch_run(aacg_engine* e, const aacg_dev_unit* d_units, const aacg_run* d_r
          * run kernel that adds gain * side where it forms the PCM — no read-modify-write pass over the interleaved PCM */
         if (!h.cce_runs.empty()) cce_filterbank();
         aacg_set_cpl(&P, cb.jobs + h.fused_first, cb.gains, cb.side);
-        if (!h.runs.empty()) aacg_couple_run_launch(quant, grid, block, s, P);
+        if (!h.runs.empty()) aacg_couple_run_launch(quant, h.wide_frames, grid, block, s, P);
     } else if (!h.runs.empty()) {
         if (ex) {
             aacg_exrun_launch(quant, grid, block, s, P);

@@ -22,10 +22,21 @@ void aacg_imdct_run_quant_cpl(const aacg_kparams P) { imdct_run_body<AACG_INPUT_
 extern "C" __global__ __launch_bounds__(AACG_WG_THREADS)
 void aacg_imdct_run_f32_cpl(const aacg_kparams P) { imdct_run_body<AACG_INPUT_SPEC_F32, AACG_OUTPUT_F32, false, false, true>(P); }
 
-void aacg_couple_run_launch(bool quant, dim3 grid, dim3 block, hipStream_t s, const aacg_kparams& P)
+/* batches of multichannel frames (where coupling lives): non-temporal loads of the spectra (aacg_engine_nt.hip says why) */
+extern "C" __global__ __launch_bounds__(AACG_WG_THREADS)
+void aacg_imdct_run_quant_cpl_nt(const aacg_kparams P) { imdct_run_body<AACG_INPUT_QUANT_I16, AACG_OUTPUT_F32, false, false, true, false, true>(P); }
+extern "C" __global__ __launch_bounds__(AACG_WG_THREADS)
+void aacg_imdct_run_f32_cpl_nt(const aacg_kparams P) { imdct_run_body<AACG_INPUT_SPEC_F32, AACG_OUTPUT_F32, false, false, true, false, true>(P); }
+
+void aacg_couple_run_launch(bool quant, bool wide, dim3 grid, dim3 block, hipStream_t s, const aacg_kparams& P)
 {
-    if (quant) hipLaunchKernelGGL(aacg_imdct_run_quant_cpl, grid, block, 0, s, P);
-    else       hipLaunchKernelGGL(aacg_imdct_run_f32_cpl, grid, block, 0, s, P);
+    if (wide) {
+        if (quant) hipLaunchKernelGGL(aacg_imdct_run_quant_cpl_nt, grid, block, 0, s, P);
+        else       hipLaunchKernelGGL(aacg_imdct_run_f32_cpl_nt, grid, block, 0, s, P);
+    } else {
+        if (quant) hipLaunchKernelGGL(aacg_imdct_run_quant_cpl, grid, block, 0, s, P);
+        else       hipLaunchKernelGGL(aacg_imdct_run_f32_cpl, grid, block, 0, s, P);
+    }
 }
 
 void aacg_couple_launch(bool pcm, hipStream_t s, const aacg_couple_params& Q)

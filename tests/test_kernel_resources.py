@@ -27,7 +27,7 @@ TUS = {
     "aacg_engine_ext.hip": (SCHED, {"aacg_imdct_run_quant_dd": WIDE, "aacg_imdct_run_f32_dd": WIDE}),
     "aacg_engine_i16.hip": (SCHED, {"aacg_imdct_run_quant_i16": WIDE, "aacg_imdct_run_f32_i16": WIDE, "aacg_imdct_run_quant_i16_nt": WIDE, "aacg_imdct_run_f32_i16_nt": WIDE}),
     "aacg_engine_exrun.hip": (SCHED, {"aacg_imdct_run_quant_ex": WIDE, "aacg_imdct_run_f32_ex": WIDE}),
-    "aacg_engine_couple.hip": ([], {"aacg_imdct_run_quant_cpl": WIDE, "aacg_imdct_run_f32_cpl": WIDE}),
+    "aacg_engine_couple.hip": ([], {"aacg_imdct_run_quant_cpl": WIDE, "aacg_imdct_run_f32_cpl": WIDE, "aacg_imdct_run_quant_cpl_nt": WIDE, "aacg_imdct_run_f32_cpl_nt": WIDE}),
 }
 
 
