@@ -7,6 +7,7 @@
 
 #include <stdint.h>
 #include "../../include/aacgpu.h"
+#include "../../include/aacgpu_tools.h"
 
 #define AACG_RUN_W        AACG_RUN_FRAMES          /* waves per workgroup = frames per first run of a chain */
 #define AACG_WG_WAVES     AACG_RUN_W
@@ -97,6 +98,13 @@ struct aacg_pns_tables {
     uint16_t swb_short[16];
 };
 
+/* The overlap state (filter_bank.js:38-41) of one channel lives in AACG_OV_BUFFERS rotating buffers of 1024 floats: a launch
+ * that advances the channel reads buffer r and leaves the new state in buffer (r + 1) mod 3.  Two would do for launches that
+ * follow each other on one HIP stream; three are what lets consecutive launches of a plan OVERLAP (aacg_decode_pipelined):
+ * launch n + 1 may be writing buffer r + 2 while launch n still reads r and writes r + 1, and launch n + 2, which writes
+ * buffer r again, is ordered behind launch n by the engine. */
+#define AACG_OV_BUFFERS 3
+
 /* One workgroup's work: consecutive frames of one element of one stream.  The first run of a
  * chain holds up to 16 units (wave w = unit w, wave 0 starts from the overlap state); a later
  * run holds up to 15 units in waves 1..15 and wave 0 recomputes the tail of pred_unit. */
@@ -104,12 +112,10 @@ struct aacg_run {
     int32_t pred_unit;                /* -1: first run of its chain */
     int32_t n_units;
     int32_t unit[AACG_RUN_W];
-    /* The chain's overlap state is double-buffered (the run that reads it and the run that
-     * writes it can be different workgroups of one launch): float offsets of the two buffers
-     * per channel.  Launch parity `flip` selects in = flip ? b : a, out = flip ? a : b.   */
-    int32_t ov_a[2];
-    int32_t ov_b[2];
-    int32_t is_last;                  /* last run of its chain: the final tail goes to `out` */
+    int32_t ov0[2];                   /* per channel: float offset of its buffer 0 in the overlap pool (buffer r at + 1024 r) */
+    int32_t rot[2];                   /* per channel: the buffer that held its state when the plan was made; launch number j of the
+                                         plan (aacg_kparams.flip = j mod 3) reads buffer (rot + flip) mod 3 and writes the next one */
+    int32_t is_last;                  /* last run of its chain: the final tail goes to the out buffer */
     int32_t reserved;
 };
 
@@ -147,7 +153,7 @@ struct aacg_kparams {
     float*                overlap;    /* overlap pool */
     float*                spec_out;   /* spectral-only kernel */
     const aacg_tables*    tab;
-    int32_t               flip;       /* 0/1: swap ov_a and ov_b (plan reuse, see aacg_engine.hip) */
+    int32_t               flip;       /* 0..2: launches of this plan so far, mod 3 (aacg_run.rot) */
     int32_t               n_runs;
     int32_t               ablate;     /* -DAACG_PROFILE builds only (AACG_ABL in aacg_kernels.h); 0 otherwise */
     int32_t               reserved;
@@ -166,83 +172,43 @@ static inline void aacg_set_cpl(aacg_kparams* P, const aacg_couple_job* jobs, co
 #define AACG_CPL_GAINS(P) ((const float*)(const void*)(P).pns)
 #define AACG_CPL_SIDE(P)  ((const float*)(P).spec_out)   /* the coupling elements' filterbank output, [block][1024], PCM-scaled */
 
-/* ---- chains longer than a run without a recomputed frame: the run-to-run rendezvous for the 16-wave kernels (_rv builds) ---- */
+/* ---- rendezvous cells: the runs of a chain in different workgroups (_rv builds) — and, for pipelined launches, in different
+ * LAUNCHES ---- */
 /* Every run of such a plan holds up to 16 frames and nobody recomputes anything: a later run's first frame and the run
- * before it meet in a rendezvous cell in global memory (as in aacg_kernels8.h) — whichever side arrives first publishes what
- * it has (the windowed tail, or the windowed first half) and leaves, the second finishes the frame.  One record per block. */
+ * before it meet in a rendezvous cell in global memory — whichever side arrives first publishes what it has (the windowed
+ * tail, or the windowed first half) and leaves, the second finishes the frame.  Nobody waits for another workgroup, so no
+ * dispatch order is assumed.  One link record per block. */
 struct aacg_rv_link {
     int32_t link_in;                  /* cell through which the run before this one hands over; -1: first run of its chain */
     int32_t link_out;                 /* cell towards the next run; -1: last run of its chain */
     int32_t succ_unit;                /* first unit of the next run, or -1 */
     int32_t reserved;
 };
+#define AACG_RV_STATE_WORDS 2         /* per in-launch cell: the state word and a spare (16-byte records) */
+#define AACG_RV_DATA_FLOATS 4096      /* per in-launch cell: [tail | head][channel][1024] */
+#define AACG_RV_TAIL 1ull             /* state word = (epoch << 2) | one of these; any other value: nobody has been here in this epoch */
+#define AACG_RV_HEAD 2ull
+
+/* The same meeting between the LAST frame of a chain in one launch and its FIRST frame in the plan's next launch, when the
+ * two launches overlap (aacg_decode_pipelined): one cell per (stream, channel, overlap buffer), used through the element's
+ * first channel.  The tail payload of such a cell IS the overlap buffer (the state lands where a launch that comes later
+ * and alone reads it plainly); the head payload has a pool of the same shape (aacg_rv_args.xl_head).  A consumer that leaves
+ * its windowed first half also says where the finished samples go: its launch's PCM buffer is unknown to the launch before. */
+struct aacg_xl_cell {
+    unsigned long long state;         /* (epoch of the launch that WRITES this buffer << 2) | AACG_RV_TAIL / AACG_RV_HEAD */
+    unsigned long long pcm;           /* with HEAD: address of sample 0 of the element's first channel in the consumer's frame */
+    uint32_t n_out_ch;                /* with HEAD: that frame's interleave stride */
+    uint32_t reserved[3];
+};
 struct aacg_rv_args {
     const aacg_rv_link*  links;       /* [n_runs], block order */
-    unsigned long long*  state;       /* [n_links][AACG8_RV_STATE_WORDS] (the first word is used), epoch-tagged, never reset */
-    float*               data;        /* [n_links][AACG8_RV_DATA_FLOATS]: tail | head, [channel][1024] each */
-    unsigned long long   epoch;
-};
-
-/* ---- the 8-waves-per-SIMD run kernels (aacg_kernels8.h): one CHANNEL per wave ---------------------------------- */
-/* A workgroup is still 16 waves, but a wave carries one channel of one frame (4 KB of LDS, <= 64 VGPRs), so that two
- * workgroups share a CU: 32 waves, 8 per SIMD.  What that changes in the data the kernel reads:
- *  - the windows are no longer staged in LDS (two copies of the 25 KB table block would not fit beside 2 x 64 KB of
- *    slots): they come from global memory / L2 in the order the epilogue reads them, with the START / STOP shapes
- *    composed on the host (aacg_win8);
- *  - a run holds 8 frames of a channel pair (wave 2 f + c) or 16 frames of a single channel (wave f), and a chain's
- *    consecutive runs hand the windowed tail over through global memory (a rendezvous per link: whichever side arrives
- *    second finishes the frame; no dispatch-order assumption, no recomputed IMDCT). */
-struct aacg_win8 {
-    /* head[v][n] multiplies IMDCT output n (n < 1024) of a long-type frame: v = 2 * (sequence == LONG_STOP) + previous shape
-     * (filter_bank.js:109-111,124-126,185-195: long window | 0, short window, 1); PCM-scaled like aacg_tables.win_* */
-    float head[4][1024];
-    /* tail[v][n] multiplies IMDCT output 1024 + n: v = 2 * (sequence == LONG_START) + shape
-     * (filter_bank.js:114-116,129-139: reversed long window | 1, reversed short window, 0) */
-    float tail[4][1024];
-    float shrt[2][128];               /* SINE_128, KBD_128, PCM-scaled */
-};
-
-/* table block of the 8-wave kernels in LDS (floats): rotations and twiddles, then (quantised input) SF, signed IQ, band maps */
-#define AACG8_TAB_F32_FLOATS   AACG_TAB_OFF_WIN_LONG                                  /* 2160: everything in front of the windows */
-#define AACG8_TAB_QUANT_FLOATS (AACG8_TAB_F32_FLOATS + (AACG_TAB_QUANT_FLOATS - AACG_TAB_F32_FLOATS))   /* 3904 */
-#define AACG8_WIN_GAP_FLOATS   (AACG_TAB_F32_FLOATS - AACG_TAB_OFF_WIN_LONG)          /* the windows' place in aacg_tables: skipped */
-#define AACG8_SLOT_FLOATS      1024
-/* LDS map: [16 slots of 4 KB][tables][one flag per wave]; two workgroups per CU: at most 80 KB each */
-#define AACG8_LDS_BYTES(tab_floats) (4 * (AACG_WG_WAVES * AACG8_SLOT_FLOATS + (tab_floats) + AACG_WG_WAVES))
-
-struct aacg_run8 {
-    int32_t n_units;                  /* frames in this run: <= 8 for a channel pair, <= 16 for a single channel */
-    int32_t n_ch;                     /* 1 / 2: channels of the element */
-    int32_t unit[AACG_RUN_W];
-    int32_t ov_a[2], ov_b[2];         /* the chain's overlap state, as in aacg_run */
-    int32_t link_in;                  /* rendezvous cell through which the run before it hands over its tail; -1: first run of its chain */
-    int32_t link_out;                 /* cell towards the next run; -1: last run of its chain (its tail is the new overlap state) */
-    int32_t succ_unit;                /* first unit of the next run (whose PCM this run finishes if it arrives second), or -1 */
-    int32_t reserved[5];
-};
-
-/* one rendezvous cell (global memory): two state words (one per sample half of a channel pair; a single channel uses the
- * first) and two payload buffers of [2 channels][1024] floats: the windowed tail, or the windowed first half */
-#define AACG8_RV_STATE_WORDS 2
-#define AACG8_RV_DATA_FLOATS 4096     /* [tail | head][channel][1024] */
-#define AACG8_RV_TAIL 1ull
-#define AACG8_RV_HEAD 2ull
-
-struct aacg_kparams8 {
-    const aacg_dev_unit*  units;
-    const aacg_run8*      runs;
-    const void*           coeffs;
-    const aacg_band_meta* meta;
-    float*                pcm;
-    float*                overlap;
-    const aacg_tables*    tab;
-    const aacg_win8*      win;
-    unsigned long long*   rv_state;   /* [n_links][AACG8_RV_STATE_WORDS], never reset: a word counts only when it carries this launch's epoch */
-    float*                rv_data;    /* [n_links][AACG8_RV_DATA_FLOATS] */
-    unsigned long long    epoch;      /* unique per launch that uses these cells, never 0 */
-    int32_t               flip;
-    int32_t               n_runs;
-    unsigned long long*   trace;      /* -DAACG_PROFILE builds: per-wave phase time stamps (tools/timeline.py); null otherwise */
+    unsigned long long*  state;       /* [n_links][AACG_RV_STATE_WORDS], epoch-tagged, never reset */
+    float*               data;        /* [n_links][AACG_RV_DATA_FLOATS] */
+    unsigned long long   epoch;       /* of this launch, never 0: tags its in-launch cells and the cross-launch cells it writes */
+    aacg_xl_cell*        xl_cells;    /* [stream][channel][AACG_OV_BUFFERS]; null: chain ends read and write the overlap pool plainly */
+    float*               xl_head;     /* [stream][channel][AACG_OV_BUFFERS][1024] */
+    unsigned long long   epoch_in;    /* epoch of the launch that writes this launch's input state and may still be running;
+                                         0: that state is complete (the launch is ordered behind its writer) */
 };
 
 /* ---- device front end (aacg_parse.h) ------------------------------------------------------------ */

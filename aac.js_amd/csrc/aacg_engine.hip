@@ -17,6 +17,7 @@
 
 #include "aacg_kernels.h"
 #include "aacg_host.h"
+#include "aacg_routes.h"
 
 /* ---- kernels ----------------------------------------------------------------------- */
 /* 1024 threads = 16 waves, one workgroup per CU: 4 waves per SIMD -> 128 VGPRs per lane */
@@ -26,30 +27,24 @@ void aacg_imdct_run_quant(const aacg_kparams P) { imdct_run_body<AACG_INPUT_QUAN
 extern "C" __global__ __launch_bounds__(AACG_WG_THREADS)
 void aacg_imdct_run_f32(const aacg_kparams P) { imdct_run_body<AACG_INPUT_SPEC_F32>(P); }
 
-/* The variant for plans with full later runs (_dd: their first wave does double duty) lives in aacg_engine_ext.hip,
- * the optional TNS / PNS stages in aacg_engine_spectral.hip: their own code objects, so that adding to them never
- * moves the two kernels above. */
-void aacg_ext_launch(bool quant, dim3 grid, dim3 block, hipStream_t s, const aacg_kparams& P);
-/* aacg_engine_spectral.hip: the optional stages (AACG_PNS_SPEC noise bands, AACG_TNS_SPEC filters) -> f32 spectra */
+/* Every other variant of the run kernel lives in a translation unit of its own (aacg_engine_{rv,nt,ext,i16,exrun,couple}.hip:
+ * their own code objects, so that adding to them never moves the two kernels above); each exports a table of its kernels
+ * (aacg_routes.h). */
+const aacg_run_kernel aacg_run_kernels_plain[] = {
+    {AACG_RK_QUANT, "aacg_imdct_run_quant", (const void*)aacg_imdct_run_quant},
+    {0, "aacg_imdct_run_f32", (const void*)aacg_imdct_run_f32}
+};
+const int aacg_run_kernels_plain_n = 2;
+
+/* aacg_engine_refresh.hip: a kept plan's unit records from the device parser's output */
 void aacg_refresh_launch(aacg_dev_unit* units, const aacg_unit_desc* parsed, const aacg_parse_result* results, uint32_t n_units,
                          uint32_t max_units, int refuse_pns, uint32_t* refused, hipStream_t s);
-/* aacg_engine_i16.hip: the run kernels with int16 PCM stores (AACG_OUTPUT_I16 engines) */
-void aacg_i16_launch(bool quant, bool dd, bool wide, dim3 grid, dim3 block, hipStream_t s, const aacg_kparams& P);
-/* aacg_engine_exrun.hip: the run kernels with the optional stages inside (one launch for TNS / PNS batches) */
-void aacg_exrun_launch(bool quant, dim3 grid, dim3 block, hipStream_t s, const aacg_kparams& P);
+/* aacg_engine_spectral.hip: the optional stages (AACG_PNS_SPEC noise bands, AACG_TNS_SPEC filters) -> f32 spectra */
 int aacg_spectral_ex_set_lds_limits(void);
 void aacg_spectral_ex_launch(bool quant, int n_units, hipStream_t s, const aacg_kparams& P);
 /* aacg_engine_couple.hip: AACG_CCE_SPEC */
 void aacg_couple_launch(bool pcm, hipStream_t s, const aacg_couple_params& Q);
-void aacg_couple_run_launch(bool quant, bool wide, dim3 grid, dim3 block, hipStream_t s, const aacg_kparams& P);
 struct cce_bufs { const aacg_run* runs; const aacg_couple_job* jobs; const float* gains; float* side; };
-/* aacg_engine8.hip: the one-channel-per-wave run kernels (two workgroups per CU) */
-void aacg_run8_launch(bool quant, dim3 grid, dim3 block, hipStream_t s, const aacg_kparams8& P);
-struct run8_bufs { const aacg_run8* runs; unsigned long long* rv_state; float* rv_data; };
-/* aacg_engine_nt.hip: the plain run kernels for multichannel batches (non-temporal loads of the spectra) */
-void aacg_nt_launch(bool quant, dim3 grid, dim3 block, hipStream_t s, const aacg_kparams& P);
-/* aacg_engine_rv.hip: the 16-wave kernels for chains longer than a run, with a run-to-run rendezvous instead of a recomputed frame */
-void aacg_rv_launch(bool quant, bool wide, dim3 grid, dim3 block, hipStream_t s, const aacg_kparams& P, const aacg_rv_args& V);
 struct rv_bufs { const aacg_run* runs; const aacg_rv_link* links; unsigned long long* state; float* data; };
 
 extern "C" __global__ __launch_bounds__(AACG_WG_THREADS)
@@ -63,17 +58,29 @@ struct aacg_engine {
     hipStream_t stream = nullptr;
     aacg_tables* d_tab = nullptr;
     aacg_pns_tables* d_pns = nullptr;       /* AACG_PNS_SPEC */
-    aacg_win8* d_win8 = nullptr;            /* the windows as the 8-wave kernels read them */
-    bool run8 = false;                      /* plain batches (f32 PCM, no optional stage) on the one-channel-per-wave kernels: opt-in
-                                               (AACG_RUN8=1 / AACG_DEBUG_ROUTE_NARROW_KERNELS) — built to parity and measured slower than the
-                                               16-wave kernels on every BASELINE configuration */
-    unsigned long long rv_epoch = 0;        /* rendezvous epoch: one per launch of those kernels, never 0 */
-    bool rv = true;                         /* chains longer than a run: rendezvous between their runs (the _rv kernels) instead of a recomputed frame (_dd) */
-    float* d_overlap = nullptr;             /* [max_streams][max_channels][2][1024] */
-    std::vector<uint8_t> parity;            /* live buffer per (stream, channel) */
+    unsigned long long rv_epoch = 0;        /* rendezvous epoch: one per launch of the _rv kernels, never 0 */
+    float* d_overlap = nullptr;             /* [max_streams][max_channels][AACG_OV_BUFFERS][1024] */
+    std::vector<uint8_t> parity;            /* live buffer (0..AACG_OV_BUFFERS-1) per (stream, channel) */
     uint64_t epoch = 0;                     /* bumped whenever `parity` changes: lets a relaunched plan skip its check */
     aacg_tables h_tab;
     aacg_host_windows h_win;
+    /* pipelined launches (aacg_decode_pipelined): two internal streams taken in turn, so that a launch starts on the CUs the
+     * launch before it has left while that one is still finishing.  The chains of the two launches meet in cross-launch cells
+     * (aacg_xl_cell); the engine bounds how far a launch may run ahead: launch n is ordered behind launch n - 2 (same stream)
+     * and behind launch n - 3 (event), so only neighbours ever overlap — which is what the three rotating overlap buffers and
+     * cells are safe for. */
+    struct pipe_t {
+        hipStream_t stream[2] = {nullptr, nullptr};
+        hipEvent_t done[4] = {nullptr, nullptr, nullptr, nullptr};   /* done[n % 4]: launch n of the pipeline */
+        hipEvent_t fork = nullptr;
+        uint64_t n = 0;                     /* launches issued so far */
+        bool open = false;                  /* launches issued since the last join that nobody outside is ordered behind yet */
+        aacg_plan* plan = nullptr;          /* the plan of launch n - 1 */
+        unsigned long long epoch = 0;       /* rv epoch of launch n - 1 */
+        uint64_t chained = 0;               /* launches that continued their predecessor through the cross-launch cells (introspection) */
+    } pipe;
+    aacg_xl_cell* d_xl_cells = nullptr;     /* [max_streams][max_channels][AACG_OV_BUFFERS] */
+    float* d_xl_head = nullptr;             /* [max_streams][max_channels][AACG_OV_BUFFERS][1024] */
     /* host-buffer path: two pipeline slots (stream + device buffers grown on demand) */
     struct slot_t {
         hipStream_t stream = nullptr;
@@ -87,7 +94,6 @@ struct aacg_engine {
         void* d_scratch = nullptr; size_t scratch_cap = 0;
         void* d_spec = nullptr;   size_t spec_cap = 0;       /* PNS route: f32 spectra between the two kernels */
         void* d_cce[4] = {nullptr, nullptr, nullptr, nullptr}; size_t cce_cap[4] = {0, 0, 0, 0};   /* AACG_CCE_SPEC: runs, jobs, gains, side PCM */
-        void* d_run8[3] = {nullptr, nullptr, nullptr}; size_t run8_cap[3] = {0, 0, 0};             /* 8-wave kernels: runs, rendezvous state, payload */
         void* d_rv[4] = {nullptr, nullptr, nullptr, nullptr}; size_t rv_cap[4] = {0, 0, 0, 0};     /* _rv kernels: runs, links, rendezvous state, payload */
         void* d_pcm = nullptr;    size_t pcm_cap = 0;
         /* page-locked staging for callers that pass ordinary (pageable) memory */
@@ -109,6 +115,7 @@ struct aacg_engine {
     std::string err;
 };
 
+#define AACG_PLAN_BUFFERS 13
 struct aacg_plan {
     aacg_engine* e;
     aacg_plan_host h;
@@ -119,13 +126,13 @@ struct aacg_plan {
     float* d_scratch = nullptr;             /* parked predecessor tails of double-duty runs */
     float* d_spec = nullptr;                /* PNS route: f32 spectra between the two kernels */
     void*  d_cce[4] = {nullptr, nullptr, nullptr, nullptr};   /* AACG_CCE_SPEC: coupling elements' runs, jobs, gains, side PCM */
-    void*  d_run8[3] = {nullptr, nullptr, nullptr};           /* 8-wave kernels: their run table, rendezvous state words and payload */
-    void*  d_rv[4] = {nullptr, nullptr, nullptr, nullptr};    /* _rv kernels: run table, link records, rendezvous state words and payload */
-    size_t bytes[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  /* sizes of the sixteen buffers above, for the engine's free list */
+    void*  d_rv[4] = {nullptr, nullptr, nullptr, nullptr};    /* _rv kernels: run table, link records, rendezvous state words and payload (two sets: overlapping launches) */
+    size_t bytes[AACG_PLAN_BUFFERS] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  /* sizes of the buffers above, for the engine's free list */
     hipEvent_t uploaded = nullptr;          /* the tables are on the device */
     hipEvent_t last_use = nullptr;          /* recorded at destruction on last_stream: everything launched with this plan */
     hipStream_t last_stream = nullptr;      /* stream of the most recent launch (no per-launch event: it costs 3 us per step) */
     bool used = false;
+    bool last_pipelined = false;            /* its most recent launch went through aacg_decode_pipelined */
     uint64_t seen_epoch = ~0ull;            /* engine epoch right after this plan's last launch */
     uint32_t launches = 0;
 };
@@ -195,108 +202,75 @@ bool is_pinned(const void* p)
     return a.type == hipMemoryTypeHost;
 }
 
-/* does launch_run stage f32 spectra in HBM for this batch (the optional stages as a launch of their own, or coupling
- * in the spectral domain)?  Batches whose optional stages run inside the run kernel need no such buffer. */
-bool needs_spec_buffer(const aacg_engine* e, const aacg_plan_host& h)
+}  // namespace
+
+/* ---- the route: ONE decision (aacg_pick_route, aacg_routes.cpp), executed by launch_run, printed by aacg_plan_kernels ---- */
+/* the registered kernel with these switches; its symbol is what aacg_run_kernel_name composes (checked at aacg_create) */
+const aacg_run_kernel* aacg_find_run_kernel(unsigned key)
 {
-    const bool quant = e->cfg.input_kind == AACG_INPUT_QUANT_I16, i16 = e->cfg.output_kind == AACG_OUTPUT_I16;
-    const bool stages = h.any_tns || (quant && h.any_pns);
-    return h.any_cce_dependent || (stages && (i16 || h.any_cce || h.needs_scratch));
+    const aacg_run_kernel* const tabs[] = {aacg_run_kernels_plain, aacg_run_kernels_rv, aacg_run_kernels_nt, aacg_run_kernels_ext,
+                                           aacg_run_kernels_i16, aacg_run_kernels_exrun, aacg_run_kernels_couple};
+    const int counts[] = {aacg_run_kernels_plain_n, aacg_run_kernels_rv_n, aacg_run_kernels_nt_n, aacg_run_kernels_ext_n,
+                          aacg_run_kernels_i16_n, aacg_run_kernels_exrun_n, aacg_run_kernels_couple_n};
+    for (size_t t = 0; t < sizeof tabs / sizeof tabs[0]; t++)
+        for (int i = 0; i < counts[t]; i++)
+            if (tabs[t][i].key == key) return &tabs[t][i];
+    return nullptr;
 }
 
-/* Plain batches — f32 PCM, no optional stage, no coupling element — run on the one-channel-per-wave kernels (aacg_kernels8.h). */
-bool takes_run8(const aacg_engine* e, const aacg_plan_host& h)
+namespace {
+
+aacg_route route_of(const aacg_engine* e, const aacg_plan_host& h, bool pipelined)
 {
-    const bool quant = e->cfg.input_kind == AACG_INPUT_QUANT_I16;
-    const bool on = (e->run8 || (e->debug_route & AACG_DEBUG_ROUTE_NARROW_KERNELS)) && !(e->debug_route & AACG_DEBUG_ROUTE_WIDE_KERNELS);
-    return on && e->cfg.output_kind == AACG_OUTPUT_F32 &&
-           !h.any_cce && !h.any_tns && !(quant && h.any_pns) && !h.runs8.empty();
+    return aacg_pick_route(e->cfg.input_kind, e->cfg.output_kind, e->debug_route, e->d_trace != nullptr, h, pipelined);
 }
 
-/* Plain batches with a chain longer than a run: the 16-wave kernels with a run-to-run rendezvous (no recomputed frame). */
-bool takes_rv(const aacg_engine* e, const aacg_plan_host& h)
+/* does the route stage f32 spectra in HBM for this batch? */
+bool needs_spec_buffer(const aacg_engine* e, const aacg_plan_host& h) { return route_of(e, h, false).stage != AACG_STAGE_NONE; }
+
+int launch_kernel(aacg_engine* e, const aacg_run_kernel* k, unsigned blocks, hipStream_t s, const aacg_kparams& P, const aacg_rv_args* V)
 {
-    const bool quant = e->cfg.input_kind == AACG_INPUT_QUANT_I16;
-    return e->rv && !takes_run8(e, h) && e->cfg.output_kind == AACG_OUTPUT_F32 && !h.any_cce && !h.any_tns && !(quant && h.any_pns) && !h.runs_rv.empty();
+    if (!k) { e->err = "no run kernel for this route"; return AACG_ERR_UNSUPPORTED; }
+    aacg_kparams p = P;
+    aacg_rv_args v;
+    void* args[2] = {&p, nullptr};
+    if (k->key & AACG_RK_RV) { v = *V; args[1] = &v; }
+    HIP_TRY(e, hipLaunchKernel(k->fn, dim3(blocks), dim3(AACG_WG_THREADS), args, 0, s), AACG_ERR_NO_DEVICE);
+    return AACG_OK;
 }
 
-/* The launches launch_run makes for a plan, by kernel name: what a rocprofv3 kernel trace of the batch shows. */
-std::string route_names(const aacg_engine* e, const aacg_plan_host& h)
-{
-    const bool i16 = e->cfg.output_kind == AACG_OUTPUT_I16;
-    bool quant = e->cfg.input_kind == AACG_INPUT_QUANT_I16, ex = false;
-    const bool stages = h.any_tns || (quant && h.any_pns);
-    std::string r;
-    auto add = [&](const std::string& k) { if (!r.empty()) r += " + "; r += k; };
-    if (h.any_cce_dependent) {
-        add(quant ? "aacg_spectral_ex_quant" : "copy");
-        add("aacg_couple_spec");
-        if (h.any_tns) add("aacg_spectral_ex_f32");
-        quant = false;
-    } else if (stages && !i16 && !h.any_cce && !h.needs_scratch) {
-        ex = true;
-    } else if (stages) {
-        add(quant ? "aacg_spectral_ex_quant" : "aacg_spectral_ex_f32");
-        quant = false;
-    }
-    if (takes_run8(e, h)) return std::string("aacg_imdct_run8_") + (quant ? "quant" : "f32");
-    if (takes_rv(e, h)) return std::string("aacg_imdct_run_") + (quant ? "quant" : "f32") + "_rv" + (h.wide_frames ? "_nt" : "");
-    const std::string run = std::string("aacg_imdct_run_") + (quant ? "quant" : "f32");
-    const bool fused = h.fused_independent && !ex && !i16 && !(e->debug_route & AACG_DEBUG_ROUTE_UNFUSED_COUPLING);
-    if (fused) {
-        if (!h.cce_runs.empty()) add(run + " (coupling elements)");
-        if (!h.runs.empty()) add(run + "_cpl" + (h.wide_frames ? "_nt" : ""));
-        return r;
-    }
-    const bool nt = !ex && !h.needs_scratch && h.wide_frames && !e->d_trace;
-    if (!h.runs.empty()) add(run + (ex ? "_ex" : "") + (!ex && h.needs_scratch ? "_dd" : "") + (!ex && i16 ? "_i16" : "") + (nt ? "_nt" : ""));
-    if (h.any_cce) {
-        if (!h.cce_runs.empty()) add(run + " (coupling elements)");
-        add("aacg_couple_pcm");
-    }
-    return r;
-}
+/* what a pipelined launch adds to the rendezvous arguments: the cross-launch cells, the epoch its input state carries, and
+ * which of the plan's two sets of in-launch cells it uses (overlapping launches must not share one) */
+struct xl_args { bool on; unsigned long long epoch_in; int set; };
 
-/* enqueue the run kernel for a planned batch (device pointers) */
-int launch_run(aacg_engine* e, const aacg_dev_unit* d_units, const aacg_run* d_runs, const aacg_dev_tns* d_tns,
-               float* d_scratch, float* d_spec, const cce_bufs& cb, const run8_bufs& r8, const rv_bufs& rvb, const aacg_plan_host& h, const void* d_coeffs, const aacg_band_meta* d_meta,
-               void* d_pcm, int flip, hipStream_t s)
+/* enqueue the launches of route R for a planned batch (device pointers) */
+int launch_run(aacg_engine* e, const aacg_route& R, const aacg_dev_unit* d_units, const aacg_run* d_runs, const aacg_dev_tns* d_tns,
+               float* d_scratch, float* d_spec, const cce_bufs& cb, const rv_bufs& rvb, const aacg_plan_host& h, const void* d_coeffs, const aacg_band_meta* d_meta,
+               void* d_pcm, int flip, hipStream_t s, const xl_args& xl, unsigned long long* epoch_out)
 {
-    const bool i16 = e->cfg.output_kind == AACG_OUTPUT_I16;
-    bool quant = e->cfg.input_kind == AACG_INPUT_QUANT_I16, ex = false;
     if (h.zero_fill)
         HIP_TRY(e, hipMemsetAsync(d_pcm, 0, h.pcm_floats * pcm_elem_size(e), s), AACG_ERR_NO_DEVICE);
-    if (takes_run8(e, h)) {
-        aacg_kparams8 P8;
-        P8.units = d_units; P8.runs = r8.runs; P8.coeffs = d_coeffs; P8.meta = d_meta; P8.pcm = (float*)d_pcm; P8.overlap = e->d_overlap;
-        P8.tab = e->d_tab; P8.win = e->d_win8; P8.rv_state = r8.rv_state; P8.rv_data = r8.rv_data; P8.epoch = ++e->rv_epoch;
-        P8.flip = flip; P8.n_runs = (int32_t)h.runs8.size();
-        P8.trace = (e->d_trace && (e->ablate & 16)) ? (unsigned long long*)e->d_trace : nullptr;
-        aacg_run8_launch(quant, dim3((unsigned)h.runs8.size()), dim3(AACG_WG_THREADS), s, P8);
-        HIP_TRY(e, hipGetLastError(), AACG_ERR_NO_DEVICE);
-        return AACG_OK;
-    }
-    if (takes_rv(e, h)) {
-        aacg_kparams P;
-        std::memset(&P, 0, sizeof P);
-        P.units = d_units; P.runs = rvb.runs; P.coeffs = d_coeffs; P.meta = d_meta; P.pcm = (float*)d_pcm;
-        P.overlap = e->d_overlap; P.tab = e->d_tab; P.flip = flip; P.n_runs = (int32_t)h.runs_rv.size();
-        aacg_rv_args V;
-        V.links = rvb.links; V.state = rvb.state; V.data = rvb.data; V.epoch = ++e->rv_epoch;
-        aacg_rv_launch(quant, h.wide_frames, dim3((unsigned)h.runs_rv.size()), dim3(AACG_WG_THREADS), s, P, V);
-        HIP_TRY(e, hipGetLastError(), AACG_ERR_NO_DEVICE);
-        return AACG_OK;
-    }
     aacg_kparams P;
-    P.units = d_units; P.runs = d_runs; P.coeffs = d_coeffs; P.meta = d_meta; P.pcm = (float*)d_pcm;
+    std::memset(&P, 0, sizeof P);
+    P.units = d_units; P.coeffs = d_coeffs; P.meta = d_meta; P.pcm = (float*)d_pcm;
+    P.overlap = e->d_overlap; P.tab = e->d_tab; P.flip = flip;
+    if (R.rv) {
+        P.runs = rvb.runs; P.n_runs = (int32_t)h.runs_rv.size();
+        aacg_rv_args V;
+        std::memset(&V, 0, sizeof V);
+        V.links = rvb.links;
+        V.state = rvb.state ? rvb.state + (size_t)xl.set * AACG_RV_STATE_WORDS * (size_t)h.n_links_rv : nullptr;
+        V.data = rvb.data ? rvb.data + (size_t)xl.set * AACG_RV_DATA_FLOATS * (size_t)h.n_links_rv : nullptr;
+        V.epoch = ++e->rv_epoch;
+        if (xl.on) { V.xl_cells = e->d_xl_cells; V.xl_head = e->d_xl_head; V.epoch_in = xl.epoch_in; }
+        if (epoch_out) *epoch_out = V.epoch;
+        return launch_kernel(e, aacg_find_run_kernel(R.run_key), (unsigned)h.runs_rv.size(), s, P, &V);
+    }
+    P.runs = d_runs; P.n_runs = (int32_t)h.runs.size();
     P.tns = h.any_tns ? d_tns : nullptr;
     P.scratch = h.needs_scratch ? d_scratch : nullptr;
-    P.pns = nullptr;
-    P.overlap = e->d_overlap; P.spec_out = nullptr; P.tab = e->d_tab;
-    P.flip = flip; P.n_runs = (int32_t)h.runs.size();
     P.ablate = e->d_trace ? e->ablate : (e->ablate & ~16);
     if (e->d_trace) P.spec_out = (float*)e->d_trace;
-    const dim3 grid((unsigned)h.runs.size()), block(AACG_WG_THREADS);
     auto couple = [&](int point) {                      /* the coupling launches of one coupling point, round by round */
         for (uint32_t r = 0; r < h.couple_rounds; r++) {
             const uint32_t first = h.couple_first[(size_t)point * h.couple_rounds + r], last = h.couple_first[(size_t)point * h.couple_rounds + r + 1];
@@ -307,13 +281,13 @@ int launch_run(aacg_engine* e, const aacg_dev_unit* d_units, const aacg_run* d_r
             aacg_couple_launch(point == AACG_CCE_AFTER_IMDCT, s, Q);
         }
     };
-    if (h.any_cce_dependent) {
+    if (R.stage == AACG_STAGE_DEPENDENT_COUPLING) {
         /* AACG_CCE_SPEC with coupling in the spectral domain: every unit's spectrum (the coupling elements' too) as f32,
          * then decoder.js:258-266 / 304-316 in stages: coupling before TNS, the TNS filters, coupling after TNS — each its
          * own small launch, in place.  (Independent coupling alone leaves the spectral route as it is.) */
         float* trace_or_null = P.spec_out;
         P.spec_out = d_spec; P.pns = e->d_pns; P.tns = nullptr;
-        if (quant) aacg_spectral_ex_launch(true, (int)h.units.size(), s, P);
+        if (R.stage_quant) aacg_spectral_ex_launch(true, (int)h.units.size(), s, P);
         else HIP_TRY(e, hipMemcpyAsync(d_spec, d_coeffs, (size_t)h.coef_blocks * 4096u, hipMemcpyDeviceToDevice, s), AACG_ERR_NO_DEVICE);
         couple(AACG_CCE_BEFORE_TNS);
         if (h.any_tns) {
@@ -322,52 +296,49 @@ int launch_run(aacg_engine* e, const aacg_dev_unit* d_units, const aacg_run* d_r
         }
         couple(AACG_CCE_AFTER_TNS);
         P.spec_out = trace_or_null; P.coeffs = d_spec; P.meta = nullptr; P.tns = nullptr;
-        quant = false;
-    } else if ((h.any_tns || (quant && h.any_pns)) && !i16 && !h.any_cce && !h.needs_scratch) {
-        /* optional stages (noise bands, TNS filters) inside the run kernel: one launch */
-        P.pns = e->d_pns;
-        ex = true;
-    } else if (h.any_tns || (quant && h.any_pns)) {
-        /* int16 PCM, coupling elements or double-duty runs: the optional stages first, as a launch of their own that leaves f32 spectra,
-         * which the f32 run kernel takes from there */
+    } else if (R.stage == AACG_STAGE_SPECTRAL_EX) {
+        /* the optional stages first, as a launch of their own that leaves f32 spectra, which the f32 run kernel takes from there */
         float* trace_or_null = P.spec_out;
         P.spec_out = d_spec; P.pns = e->d_pns;
-        aacg_spectral_ex_launch(quant, (int)h.units.size(), s, P);
+        aacg_spectral_ex_launch(R.stage_quant, (int)h.units.size(), s, P);
         P.spec_out = trace_or_null; P.coeffs = d_spec; P.meta = nullptr; P.tns = nullptr;
-        quant = false;
+    } else if (R.has_run && (R.run_key & AACG_RK_EX)) {
+        P.pns = e->d_pns;                                /* optional stages (noise bands, TNS filters) inside the run kernel: one launch */
     }
-    auto cce_filterbank = [&]() {                       /* the independently switched coupling elements' own filterbank pass */
+    int rc = AACG_OK;
+    auto side_pass = [&]() {                            /* the independently switched coupling elements' own filterbank pass */
         aacg_kparams C = P;
         C.runs = cb.runs; C.n_runs = (int32_t)h.cce_runs.size(); C.pcm = cb.side; C.scratch = nullptr;
-        if (quant) hipLaunchKernelGGL(aacg_imdct_run_quant, dim3((unsigned)h.cce_runs.size()), block, 0, s, C);
-        else       hipLaunchKernelGGL(aacg_imdct_run_f32, dim3((unsigned)h.cce_runs.size()), block, 0, s, C);
+        return launch_kernel(e, aacg_find_run_kernel(R.side_key), (unsigned)h.cce_runs.size(), s, C, nullptr);
     };
-    const bool fused = h.fused_independent && !ex && !i16 && !(e->debug_route & AACG_DEBUG_ROUTE_UNFUSED_COUPLING);
-    if (fused) {
-        /* independent coupling in the targets' epilogues: the coupling elements go first (into the side buffer), then the
-         * run kernel that adds gain * side where it forms the PCM — no read-modify-write pass over the interleaved PCM */
-        if (!h.cce_runs.empty()) cce_filterbank();
-        aacg_set_cpl(&P, cb.jobs + h.fused_first, cb.gains, cb.side);
-        if (!h.runs.empty()) aacg_couple_run_launch(quant, h.wide_frames, grid, block, s, P);
-    } else if (!h.runs.empty()) {
-        if (ex) {
-            aacg_exrun_launch(quant, grid, block, s, P);
-        } else if (i16) {
-            aacg_i16_launch(quant, h.needs_scratch, h.wide_frames && !e->d_trace, grid, block, s, P);
-        } else if (h.needs_scratch) {
-            aacg_ext_launch(quant, grid, block, s, P);
-        } else if (h.wide_frames && !e->d_trace) {
-            aacg_nt_launch(quant, grid, block, s, P);
-        } else {
-            if (quant) hipLaunchKernelGGL(aacg_imdct_run_quant, grid, block, 0, s, P);
-            else       hipLaunchKernelGGL(aacg_imdct_run_f32, grid, block, 0, s, P);
-        }
+    if (R.has_side && R.side_first && (rc = side_pass())) return rc;
+    if (R.has_run) {
+        /* independent coupling in the targets' epilogues: the run kernel adds gain * side where it forms the PCM — no
+         * read-modify-write pass over the interleaved PCM */
+        if (R.run_key & AACG_RK_CPL) aacg_set_cpl(&P, cb.jobs + h.fused_first, cb.gains, cb.side);
+        if ((rc = launch_kernel(e, aacg_find_run_kernel(R.run_key), (unsigned)h.runs.size(), s, P, nullptr))) return rc;
     }
-    if (h.any_cce && !fused) {
-        if (!h.cce_runs.empty()) cce_filterbank();
-        couple(AACG_CCE_AFTER_IMDCT);
-    }
+    if (R.has_side && !R.side_first && (rc = side_pass())) return rc;
+    if (R.couple_pcm) couple(AACG_CCE_AFTER_IMDCT);
     HIP_TRY(e, hipGetLastError(), AACG_ERR_NO_DEVICE);
+    return AACG_OK;
+}
+
+/* Everything the pipeline has in flight in front of work on stream s (device-side wait; s null: the host waits). */
+int pipe_join(aacg_engine* e, hipStream_t s)
+{
+    aacg_engine::pipe_t& pp = e->pipe;
+    if (!pp.open) return AACG_OK;
+    bool all_done = true;
+    for (uint64_t k = 1; k <= 2 && k <= pp.n; k++) {
+        hipEvent_t ev = pp.done[(pp.n - k) & 3u];
+        if (hipEventQuery(ev) == hipSuccess) continue;  /* complete already: nothing to order behind */
+        (void)hipGetLastError();
+        all_done = false;
+        if (s) HIP_TRY(e, hipStreamWaitEvent(s, ev, 0), AACG_ERR_NO_DEVICE);
+        else   HIP_TRY(e, hipEventSynchronize(ev), AACG_ERR_NO_DEVICE);
+    }
+    if (all_done || !s) pp.open = false;               /* the host has seen both complete: nothing in flight any more */
     return AACG_OK;
 }
 
@@ -377,23 +348,72 @@ extern "C" {
 
 int aacg_abi_version(void) { return AACG_ABI_VERSION; }
 
-const char* aacg_kernel_name(void) { return "aacg_imdct_run_quant"; }
+/* the dominant kernel of the headline route: BASELINE config 2 through aacg_decode_pipelined */
+const char* aacg_kernel_name(void) { return "aacg_imdct_run_quant_rv"; }
 
 int aacg_debug_set_route(aacg_engine* e, int flags)
 {
-    if (!e || (flags & ~(AACG_DEBUG_ROUTE_UNFUSED_COUPLING | AACG_DEBUG_ROUTE_WIDE_KERNELS | AACG_DEBUG_ROUTE_NARROW_KERNELS | AACG_DEBUG_ROUTE_RECOMPUTE))) return AACG_ERR_INVALID_ARG;
+    if (!e || (flags & ~(AACG_DEBUG_ROUTE_UNFUSED_COUPLING | AACG_DEBUG_ROUTE_RECOMPUTE))) return AACG_ERR_INVALID_ARG;
     e->debug_route = flags;
-    if (flags & AACG_DEBUG_ROUTE_RECOMPUTE) e->rv = false;
     return AACG_OK;
 }
 
 int aacg_plan_kernels(aacg_engine* e, const aacg_plan* p, char* dst, size_t n)
 {
+    return aacg_plan_kernels_ex(e, p, 0, dst, n);
+}
+
+int aacg_plan_kernels_ex(aacg_engine* e, const aacg_plan* p, int pipelined, char* dst, size_t n)
+{
     if (!e || !p || p->e != e || !dst || n == 0) return AACG_ERR_INVALID_ARG;
-    const std::string r = route_names(e, p->h);
+    const std::string r = aacg_route_names(route_of(e, p->h, pipelined != 0), p->h.any_tns);
     if (r.size() + 1 > n) return AACG_ERR_INVALID_ARG;
     std::memcpy(dst, r.c_str(), r.size() + 1);
     return AACG_OK;
+}
+
+/* The route decision on its own, for tests without a device: flags of a hypothetical engine and planned batch in, the
+ * launches by name out.  plan_flags: AACG_ROUTE_PLAN_* (aacgpu_tools.h). */
+int aacg_debug_route(int input_kind, int output_kind, int debug_route, int plan_flags, int pipelined, char* dst, size_t n)
+{
+    if (!dst || n == 0) return AACG_ERR_INVALID_ARG;
+    aacg_plan_host h;
+    h.any_tns = (plan_flags & AACG_ROUTE_PLAN_TNS) != 0;
+    h.any_pns = (plan_flags & AACG_ROUTE_PLAN_PNS) != 0;
+    h.needs_scratch = (plan_flags & AACG_ROUTE_PLAN_FULL_LATER_RUNS) != 0;
+    h.long_chains = (plan_flags & (AACG_ROUTE_PLAN_LONG_CHAINS | AACG_ROUTE_PLAN_FULL_LATER_RUNS)) != 0;
+    h.wide_frames = (plan_flags & AACG_ROUTE_PLAN_WIDE_FRAMES) != 0;
+    h.any_cce = (plan_flags & (AACG_ROUTE_PLAN_CCE_INDEPENDENT | AACG_ROUTE_PLAN_CCE_DEPENDENT)) != 0;
+    h.any_cce_dependent = (plan_flags & AACG_ROUTE_PLAN_CCE_DEPENDENT) != 0;
+    /* independent coupling is fused into the targets' epilogues unless the plan has double-duty runs (aacg_plan_build) */
+    h.fused_independent = (plan_flags & AACG_ROUTE_PLAN_CCE_INDEPENDENT) && !h.needs_scratch;
+    if (plan_flags & AACG_ROUTE_PLAN_CCE_INDEPENDENT) h.cce_runs.resize(1);
+    if (!(plan_flags & AACG_ROUTE_PLAN_NO_RUNS)) { h.runs.resize(1); h.runs_rv.resize(1); }
+    const aacg_route r = aacg_pick_route(input_kind, output_kind, debug_route, false, h, pipelined != 0);
+    if ((r.has_run && !aacg_find_run_kernel(r.run_key)) || (r.has_side && !aacg_find_run_kernel(r.side_key))) return AACG_ERR_UNSUPPORTED;   /* a route without a kernel */
+    const std::string t = aacg_route_names(r, h.any_tns);
+    if (t.size() + 1 > n) return AACG_ERR_INVALID_ARG;
+    std::memcpy(dst, t.c_str(), t.size() + 1);
+    return AACG_OK;
+}
+
+/* The registered run kernels: `index`-th symbol into dst; returns its switches (AACG_RK_*), or < 0 past the end.  Every
+ * symbol must be what aacg_run_kernel_name composes from its switches (tests/test_routes.py; aacg_create checks it too). */
+int aacg_debug_run_kernel(int index, char* dst, size_t n)
+{
+    const aacg_run_kernel* const tabs[] = {aacg_run_kernels_plain, aacg_run_kernels_rv, aacg_run_kernels_nt, aacg_run_kernels_ext,
+                                           aacg_run_kernels_i16, aacg_run_kernels_exrun, aacg_run_kernels_couple};
+    const int counts[] = {aacg_run_kernels_plain_n, aacg_run_kernels_rv_n, aacg_run_kernels_nt_n, aacg_run_kernels_ext_n,
+                          aacg_run_kernels_i16_n, aacg_run_kernels_exrun_n, aacg_run_kernels_couple_n};
+    for (size_t t = 0; t < sizeof tabs / sizeof tabs[0]; t++) {
+        if (index < counts[t]) {
+            if (!dst || std::strlen(tabs[t][index].name) + 1 > n) return AACG_ERR_INVALID_ARG;
+            std::strcpy(dst, tabs[t][index].name);
+            return (int)tabs[t][index].key;
+        }
+        index -= counts[t];
+    }
+    return AACG_ERR_INVALID_ARG;
 }
 
 const char* aacg_last_error(const aacg_engine* e) { return e ? e->err.c_str() : "null engine"; }
@@ -422,13 +442,18 @@ int aacg_create(const aacg_config* cfg, aacg_engine** out)
     int rc = aacg_build_tables(cfg->sample_index, &e->h_tab, &e->h_win);
     if (rc) { delete e; return rc; }
 
-    const size_t ov_bytes = (size_t)cfg->max_streams * (size_t)cfg->max_channels * 2u * 1024u * sizeof(float);
+    const size_t n_cells = (size_t)cfg->max_streams * (size_t)cfg->max_channels * (size_t)AACG_OV_BUFFERS;
+    const size_t ov_bytes = n_cells * 1024u * sizeof(float);
     if (!hip_ok(e, hipSetDevice(cfg->device_ordinal), "hipSetDevice") ||
         !hip_ok(e, hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking), "hipStreamCreate") ||
         !hip_ok(e, hipMalloc((void**)&e->d_tab, sizeof(aacg_tables)), "hipMalloc tables") ||
         !hip_ok(e, hipMalloc((void**)&e->d_overlap, ov_bytes), "hipMalloc overlap") ||
         !hip_ok(e, hipMemcpy(e->d_tab, &e->h_tab, sizeof(aacg_tables), hipMemcpyHostToDevice), "upload tables") ||
         !hip_ok(e, hipMemset(e->d_overlap, 0, ov_bytes), "zero overlap") ||
+        /* pipelined launches: the cross-launch cells (state words count only with an epoch in them: they start from zero) and the pool of windowed first halves */
+        !hip_ok(e, hipMalloc((void**)&e->d_xl_cells, n_cells * sizeof(aacg_xl_cell)), "hipMalloc cells") ||
+        !hip_ok(e, hipMemset(e->d_xl_cells, 0, n_cells * sizeof(aacg_xl_cell)), "zero cells") ||
+        !hip_ok(e, hipMalloc((void**)&e->d_xl_head, ov_bytes), "hipMalloc heads") ||
         /* (the run kernels' ~152 KiB of LDS per workgroup are static allocations: dp_lds_fixed) */
         aacg_spectral_ex_set_lds_limits() != 0 ||
         !hip_ok(e, hipFuncSetAttribute((const void*)aacg_spectral, hipFuncAttributeMaxDynamicSharedMemorySize, AACG_LDS_BYTES_SPECTRAL), "LDS attr")) {
@@ -437,15 +462,12 @@ int aacg_create(const aacg_config* cfg, aacg_engine** out)
         return AACG_ERR_NO_DEVICE;
     }
     e->parity.assign((size_t)cfg->max_streams * (size_t)cfg->max_channels, 0);
-    {
-        aacg_win8* w8 = new (std::nothrow) aacg_win8;
-        if (w8) aacg_build_win8(&e->h_tab, w8);
-        const bool ok = w8 && hip_ok(e, hipMalloc((void**)&e->d_win8, sizeof *w8), "hipMalloc window tables") &&
-                        hip_ok(e, hipMemcpy(e->d_win8, w8, sizeof *w8, hipMemcpyHostToDevice), "upload window tables");
-        delete w8;
-        if (!ok) { aacg_destroy(e); return AACG_ERR_OUT_OF_MEMORY; }
-        if (const char* r = std::getenv("AACG_RUN8")) e->run8 = std::atoi(r) != 0;     /* A/B switch for tools/: 1 = plain batches on the one-channel-per-wave kernels */
-        if (const char* r = std::getenv("AACG_RV")) e->rv = std::atoi(r) != 0;         /* A/B switch for tools/: 0 = long chains recompute a frame per later run (_dd kernels) */
+    /* every registered run kernel carries the symbol its switches compose: what aacg_plan_kernels prints is what launches */
+    for (int i = 0;; i++) {
+        char name[96];
+        const int key = aacg_debug_run_kernel(i, name, sizeof name);
+        if (key < 0) break;
+        if (aacg_run_kernel_name((unsigned)key) != name) { std::fprintf(stderr, "aacgpu: run kernel table: %s registered with switches %d\n", name, key); aacg_destroy(e); return AACG_ERR_INVALID_ARG; }
     }
     if (cfg->pns_mode == AACG_PNS_SPEC) {
         aacg_pns_tables* pt = new (std::nothrow) aacg_pns_tables;
@@ -472,12 +494,15 @@ void aacg_destroy(aacg_engine* e)
     (void)hipDeviceSynchronize();
     if (e->d_tab) (void)hipFree(e->d_tab);
     if (e->d_pns) (void)hipFree(e->d_pns);
-    if (e->d_win8) (void)hipFree(e->d_win8);
+    if (e->d_xl_cells) (void)hipFree(e->d_xl_cells);
+    if (e->d_xl_head) (void)hipFree(e->d_xl_head);
+    for (hipEvent_t ev : e->pipe.done) if (ev) (void)hipEventDestroy(ev);
+    if (e->pipe.fork) (void)hipEventDestroy(e->pipe.fork);
+    for (hipStream_t st : e->pipe.stream) if (st) (void)hipStreamDestroy(st);
     if (e->d_overlap) (void)hipFree(e->d_overlap);
     for (auto& sl : e->slot) {
         for (void* p : {sl.d_units, sl.d_runs, sl.d_coeffs, sl.d_meta, sl.d_tns, sl.d_scratch, sl.d_spec, sl.d_pcm}) if (p) (void)hipFree(p);
         for (void* p : sl.d_cce) if (p) (void)hipFree(p);
-        for (void* p : sl.d_run8) if (p) (void)hipFree(p);
         for (void* p : sl.d_rv) if (p) (void)hipFree(p);
         if (sl.h_in) (void)hipHostFree(sl.h_in);
         if (sl.h_pcm) (void)hipHostFree(sl.h_pcm);
@@ -501,6 +526,7 @@ static int ov_check(aacg_engine* e, uint32_t stream, uint32_t channel)
     }
     HIP_TRY(e, hipSetDevice(e->cfg.device_ordinal), AACG_ERR_NO_DEVICE);
     HIP_TRY(e, hipDeviceSynchronize(), AACG_ERR_NO_DEVICE);
+    e->pipe.open = false;                               /* nothing in flight any more: the next pipelined launch starts from complete state */
     return AACG_OK;
 }
 
@@ -605,27 +631,25 @@ int aacg_plan_create_ex(aacg_engine* e, const aacg_unit_desc* units, uint32_t n_
     bool ok = hip_ok(e, hipSetDevice(e->cfg.device_ordinal), "hipSetDevice") &&
               hip_ok(e, hipEventCreateWithFlags(&p->uploaded, hipEventDisableTiming), "hipEventCreate") &&
               hip_ok(e, hipEventCreateWithFlags(&p->last_use, hipEventDisableTiming), "hipEventCreate");
-    const bool r8 = takes_run8(e, p->h), rvp = takes_rv(e, p->h);
-    const size_t r8b[3] = {r8 ? sizeof(aacg_run8) * p->h.runs8.size() : 0, r8 ? sizeof(unsigned long long) * AACG8_RV_STATE_WORDS * (size_t)p->h.n_links : 0,
-                           r8 ? sizeof(float) * AACG8_RV_DATA_FLOATS * (size_t)p->h.n_links : 0};
+    /* the rendezvous cut of the chains, for plans that can take it (serially: long chains; through the pipeline: every plain
+     * batch): run table, links, and TWO sets of in-launch cells — overlapping launches of the plan must not share one */
+    const bool rvp = route_of(e, p->h, true).rv;
     const size_t rvs[4] = {rvp ? sizeof(aacg_run) * p->h.runs_rv.size() : 0, rvp ? sizeof(aacg_rv_link) * p->h.links_rv.size() : 0,
-                           rvp ? sizeof(unsigned long long) * AACG8_RV_STATE_WORDS * (size_t)p->h.n_links_rv : 0,
-                           rvp ? sizeof(float) * AACG8_RV_DATA_FLOATS * (size_t)p->h.n_links_rv : 0};
-    const bool other = r8 || rvp;                        /* the plan's launches never read the 16-wave run table / scratch */
-    const size_t want[16] = {ub, other ? 0 : rb, tb, other ? 0 : sb, xb, cb[0], cb[1], cb[2], cb[3], r8b[0], r8b[1], r8b[2], rvs[0], rvs[1], rvs[2], rvs[3]};
-    void** const slot[16] = {(void**)&p->d_units, (void**)&p->d_runs, (void**)&p->d_tns, (void**)&p->d_scratch, (void**)&p->d_spec,
-                             &p->d_cce[0], &p->d_cce[1], &p->d_cce[2], &p->d_cce[3], &p->d_run8[0], &p->d_run8[1], &p->d_run8[2],
-                             &p->d_rv[0], &p->d_rv[1], &p->d_rv[2], &p->d_rv[3]};
-    const void* const src[16] = {p->h.units.data(), p->h.runs.data(), p->h.tns.data(), nullptr, nullptr,
-                                 p->h.cce_runs.data(), p->h.couple_jobs.data(), p->h.gains.data(), nullptr, p->h.runs8.data(), nullptr, nullptr,
+                           rvp ? 2u * sizeof(unsigned long long) * AACG_RV_STATE_WORDS * (size_t)p->h.n_links_rv : 0,
+                           rvp ? 2u * sizeof(float) * AACG_RV_DATA_FLOATS * (size_t)p->h.n_links_rv : 0};
+    const size_t want[AACG_PLAN_BUFFERS] = {ub, rb, tb, sb, xb, cb[0], cb[1], cb[2], cb[3], rvs[0], rvs[1], rvs[2], rvs[3]};
+    void** const slot[AACG_PLAN_BUFFERS] = {(void**)&p->d_units, (void**)&p->d_runs, (void**)&p->d_tns, (void**)&p->d_scratch, (void**)&p->d_spec,
+                             &p->d_cce[0], &p->d_cce[1], &p->d_cce[2], &p->d_cce[3], &p->d_rv[0], &p->d_rv[1], &p->d_rv[2], &p->d_rv[3]};
+    const void* const src[AACG_PLAN_BUFFERS] = {p->h.units.data(), p->h.runs.data(), p->h.tns.data(), nullptr, nullptr,
+                                 p->h.cce_runs.data(), p->h.couple_jobs.data(), p->h.gains.data(), nullptr,
                                  p->h.runs_rv.data(), p->h.links_rv.data(), nullptr, nullptr};
-    for (int i = 0; i < 16 && ok; i++) {
+    for (int i = 0; i < AACG_PLAN_BUFFERS && ok; i++) {
         if (!want[i]) continue;
         *slot[i] = pool_take(e, want[i], &p->bytes[i]);
         ok = *slot[i] != nullptr &&
              (!src[i] || hip_ok(e, hipMemcpyAsync(*slot[i], src[i], want[i], hipMemcpyHostToDevice, e->stream), "upload plan tables"));
         /* rendezvous state words count only with a launch's epoch in them; a recycled or fresh buffer starts from zero all the same */
-        if (ok && (i == 10 || i == 14)) ok = hip_ok(e, hipMemsetAsync(*slot[i], 0, want[i], e->stream), "zero rendezvous state");
+        if (ok && i == 11) ok = hip_ok(e, hipMemsetAsync(*slot[i], 0, want[i], e->stream), "zero rendezvous state");
     }
     ok = ok && hip_ok(e, hipEventRecord(p->uploaded, e->stream), "hipEventRecord");
     if (!ok) {
@@ -644,6 +668,7 @@ void aacg_plan_destroy(aacg_plan* p)
     /* the buffers go back to the free list: wait for the copies into them and for the last kernel that reads them
      * (two events, not the whole device) */
     if (p->uploaded) { (void)hipEventSynchronize(p->uploaded); (void)hipEventDestroy(p->uploaded); }
+    if (p->last_pipelined) (void)pipe_join(e, nullptr);       /* its launches on both internal streams */
     if (p->last_use) {
         if (p->used) {
             if (hipEventRecord(p->last_use, p->last_stream) == hipSuccess) (void)hipEventSynchronize(p->last_use);
@@ -651,21 +676,44 @@ void aacg_plan_destroy(aacg_plan* p)
         }
         (void)hipEventDestroy(p->last_use);
     }
-    void* const ptr[16] = {p->d_units, p->d_runs, p->d_tns, p->d_scratch, p->d_spec, p->d_cce[0], p->d_cce[1], p->d_cce[2], p->d_cce[3],
-                           p->d_run8[0], p->d_run8[1], p->d_run8[2], p->d_rv[0], p->d_rv[1], p->d_rv[2], p->d_rv[3]};
-    for (int i = 0; i < 16; i++) pool_give(e, ptr[i], p->bytes[i]);
+    void* const ptr[AACG_PLAN_BUFFERS] = {p->d_units, p->d_runs, p->d_tns, p->d_scratch, p->d_spec, p->d_cce[0], p->d_cce[1], p->d_cce[2], p->d_cce[3],
+                           p->d_rv[0], p->d_rv[1], p->d_rv[2], p->d_rv[3]};
+    for (int i = 0; i < AACG_PLAN_BUFFERS; i++) pool_give(e, ptr[i], p->bytes[i]);
+    if (e->pipe.plan == p) e->pipe.plan = nullptr;
     delete p;
 }
 
 static int plan_check_parity(aacg_engine* e, const aacg_plan* p)
 {
-    const int flip = (int)(p->launches & 1u);
+    const int flip = (int)(p->launches % AACG_OV_BUFFERS);
     for (const aacg_chain& c : p->h.chains)
         for (int k = 0; k < c.n_ch; k++)
-            if (e->parity[(size_t)c.stream * (size_t)e->cfg.max_channels + c.channel + k] != (c.parity[k] ^ flip)) {
+            if (e->parity[(size_t)c.stream * (size_t)e->cfg.max_channels + c.channel + k] != (c.parity[k] + flip) % AACG_OV_BUFFERS) {
                 e->err = "plan is stale: another plan advanced one of its streams";
                 return AACG_ERR_STALE_PLAN;
             }
+    return AACG_OK;
+}
+
+/* every chain of the plan has moved on by one overlap buffer */
+static void plan_advance(aacg_engine* e, aacg_plan* p)
+{
+    for (const aacg_chain& c : p->h.chains)
+        for (int k = 0; k < c.n_ch; k++) {
+            uint8_t& b = e->parity[(size_t)c.stream * (size_t)e->cfg.max_channels + c.channel + k];
+            b = (uint8_t)((b + 1) % AACG_OV_BUFFERS);
+        }
+    p->launches++;
+    p->seen_epoch = ++e->epoch;
+}
+
+/* the device buffers a route needs are the ones the plan was made with (aacg_debug_set_route may have changed since) */
+static int plan_check_route(aacg_engine* e, const aacg_plan* p, const aacg_route& R)
+{
+    if ((R.rv && !p->d_rv[0]) || (!R.rv && R.has_run && !p->d_runs) || (R.stage != AACG_STAGE_NONE && !p->d_spec)) {
+        e->err = "the plan was made for another route (aacg_debug_set_route changed since)";
+        return AACG_ERR_STALE_PLAN;
+    }
     return AACG_OK;
 }
 
@@ -678,33 +726,108 @@ int aacg_decode_device(aacg_engine* e, aacg_plan* p, const void* d_coeffs, const
     /* relaunched back to back (nothing else advanced any stream since): the per-chain check is known to pass */
     int rc = p->seen_epoch == e->epoch ? AACG_OK : plan_check_parity(e, p);
     if (rc) return rc;
+    const aacg_route R = route_of(e, p->h, false);
+    if ((rc = plan_check_route(e, p, R))) return rc;
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : e->stream;
     if (!p->used) HIP_TRY(e, hipStreamWaitEvent(s, p->uploaded, 0), AACG_ERR_NO_DEVICE);
+    /* pipelined launches in flight (of this plan or of another: the caller orders PLANS, the engine its own streams) first */
+    if ((rc = pipe_join(e, s))) return rc;
     /* the plan's previous launch ran on ANOTHER stream: this one continues its overlap state, reuses its scratch areas and
      * rendezvous cells, so it is ordered behind it on the device (an event only when the stream changes: per launch it
      * would cost 3 us) */
-    if (p->used && p->last_stream != s) {
+    if (p->used && p->last_stream != s && !p->last_pipelined) {
         HIP_TRY(e, hipEventRecord(p->last_use, p->last_stream), AACG_ERR_NO_DEVICE);
         HIP_TRY(e, hipStreamWaitEvent(s, p->last_use, 0), AACG_ERR_NO_DEVICE);
     }
     const cce_bufs cb = {(const aacg_run*)p->d_cce[0], (const aacg_couple_job*)p->d_cce[1], (const float*)p->d_cce[2], (float*)p->d_cce[3]};
-    const run8_bufs r8 = {(const aacg_run8*)p->d_run8[0], (unsigned long long*)p->d_run8[1], (float*)p->d_run8[2]};
-    if (takes_run8(e, p->h) && !p->d_run8[0]) { e->err = "the plan was made for the 16-wave kernels (aacg_debug_set_route changed since)"; return AACG_ERR_STALE_PLAN; }
     const rv_bufs rvb = {(const aacg_run*)p->d_rv[0], (const aacg_rv_link*)p->d_rv[1], (unsigned long long*)p->d_rv[2], (float*)p->d_rv[3]};
-    if (takes_rv(e, p->h) && !p->d_rv[0]) { e->err = "the plan was made for another route (aacg_debug_set_route changed since)"; return AACG_ERR_STALE_PLAN; }
-    if (!takes_run8(e, p->h) && !takes_rv(e, p->h) && !p->d_runs && !p->h.runs.empty()) { e->err = "the plan was made for another route (aacg_debug_set_route changed since)"; return AACG_ERR_STALE_PLAN; }
-    rc = launch_run(e, p->d_units, p->d_runs, p->d_tns, p->d_scratch, p->d_spec, cb, r8, rvb, p->h, d_coeffs, d_meta, d_pcm, (int)(p->launches & 1u), s);
+    const xl_args serial = {false, 0ull, 0};
+    rc = launch_run(e, R, p->d_units, p->d_runs, p->d_tns, p->d_scratch, p->d_spec, cb, rvb, p->h, d_coeffs, d_meta, d_pcm,
+                    (int)(p->launches % AACG_OV_BUFFERS), s, serial, nullptr);
     if (rc) return rc;
     p->last_stream = s;
     p->used = true;
-
-    for (const aacg_chain& c : p->h.chains)
-        for (int k = 0; k < c.n_ch; k++)
-            e->parity[(size_t)c.stream * (size_t)e->cfg.max_channels + c.channel + k] ^= 1;
-    p->launches++;
-    p->seen_epoch = ++e->epoch;
+    p->last_pipelined = false;
+    plan_advance(e, p);
     return AACG_OK;
 }
+
+/* ---- pipelined launches ---------------------------------------------------------------- */
+static int pipe_setup(aacg_engine* e)
+{
+    aacg_engine::pipe_t& pp = e->pipe;
+    if (pp.stream[0]) return AACG_OK;
+    for (hipStream_t& st : pp.stream) HIP_TRY(e, hipStreamCreateWithFlags(&st, hipStreamNonBlocking), AACG_ERR_NO_DEVICE);
+    /* events that order and nothing else: no time stamps, no system-scope fence at the record */
+    for (hipEvent_t& ev : pp.done) HIP_TRY(e, hipEventCreateWithFlags(&ev, hipEventDisableTiming | hipEventDisableSystemFence), AACG_ERR_NO_DEVICE);
+    HIP_TRY(e, hipEventCreateWithFlags(&pp.fork, hipEventDisableTiming | hipEventDisableSystemFence), AACG_ERR_NO_DEVICE);
+    return AACG_OK;
+}
+
+int aacg_decode_pipelined(aacg_engine* e, aacg_plan* p, const void* d_coeffs, const aacg_band_meta* d_meta, void* d_pcm)
+{
+    if (!e || !p || p->e != e || !d_coeffs || !d_pcm) return AACG_ERR_INVALID_ARG;
+    const bool quant = e->cfg.input_kind == AACG_INPUT_QUANT_I16;
+    if (quant && !d_meta) { e->err = "QUANT_I16 engine needs band meta"; return AACG_ERR_INVALID_ARG; }
+    int rc = p->seen_epoch == e->epoch ? AACG_OK : plan_check_parity(e, p);
+    if (rc) return rc;
+    const aacg_route R = route_of(e, p->h, true);
+    if ((rc = plan_check_route(e, p, R)) || (rc = pipe_setup(e))) return rc;
+    aacg_engine::pipe_t& pp = e->pipe;
+    hipStream_t s = pp.stream[pp.n & 1u];
+    /* Does this launch continue the one before it — same plan, nothing in between, a route whose chains meet in cells?  Then
+     * the two may overlap: its input state arrives through the cross-launch cells, tagged with that launch's epoch.  The
+     * launch three back is the one whose cells and buffers this one reuses, and the only one of the earlier launches it is
+     * not ordered behind by its stream: an event.  Otherwise it starts behind everything in flight, from complete state. */
+    const bool continues = R.overlappable && pp.open && pp.plan == p && p->last_pipelined && p->seen_epoch == e->epoch;
+    if (continues) {
+        if (pp.n >= 3) HIP_TRY(e, hipStreamWaitEvent(s, pp.done[(pp.n - 3) & 3u], 0), AACG_ERR_NO_DEVICE);
+    } else {
+        if ((rc = pipe_join(e, s))) return rc;
+        if (p->used && !p->last_pipelined) {
+            HIP_TRY(e, hipEventRecord(p->last_use, p->last_stream), AACG_ERR_NO_DEVICE);
+            HIP_TRY(e, hipStreamWaitEvent(s, p->last_use, 0), AACG_ERR_NO_DEVICE);
+        }
+        if (e->last_kernel) HIP_TRY(e, hipStreamWaitEvent(s, e->last_kernel, 0), AACG_ERR_NO_DEVICE);   /* the host-buffer path's batches */
+    }
+    if (!p->used) HIP_TRY(e, hipStreamWaitEvent(s, p->uploaded, 0), AACG_ERR_NO_DEVICE);
+    const cce_bufs cb = {(const aacg_run*)p->d_cce[0], (const aacg_couple_job*)p->d_cce[1], (const float*)p->d_cce[2], (float*)p->d_cce[3]};
+    const rv_bufs rvb = {(const aacg_run*)p->d_rv[0], (const aacg_rv_link*)p->d_rv[1], (unsigned long long*)p->d_rv[2], (float*)p->d_rv[3]};
+    const xl_args xl = {R.overlappable, continues ? pp.epoch : 0ull, (int)(pp.n & 1u)};
+    unsigned long long epoch = 0;
+    rc = launch_run(e, R, p->d_units, p->d_runs, p->d_tns, p->d_scratch, p->d_spec, cb, rvb, p->h, d_coeffs, d_meta, d_pcm,
+                    (int)(p->launches % AACG_OV_BUFFERS), s, xl, &epoch);
+    if (rc) return rc;
+    HIP_TRY(e, hipEventRecord(pp.done[pp.n & 3u], s), AACG_ERR_NO_DEVICE);
+    if (continues) pp.chained++;
+    pp.n++;
+    pp.open = true;
+    pp.plan = p;
+    pp.epoch = epoch;
+    p->last_stream = s;
+    p->used = true;
+    p->last_pipelined = true;
+    plan_advance(e, p);
+    return AACG_OK;
+}
+
+int aacg_pipeline_fork(aacg_engine* e, void* hip_stream)
+{
+    if (!e || !hip_stream) return AACG_ERR_INVALID_ARG;
+    int rc = pipe_setup(e);
+    if (rc) return rc;
+    HIP_TRY(e, hipEventRecord(e->pipe.fork, (hipStream_t)hip_stream), AACG_ERR_NO_DEVICE);
+    for (hipStream_t st : e->pipe.stream) HIP_TRY(e, hipStreamWaitEvent(st, e->pipe.fork, 0), AACG_ERR_NO_DEVICE);
+    return AACG_OK;
+}
+
+int aacg_pipeline_join(aacg_engine* e, void* hip_stream)
+{
+    if (!e) return AACG_ERR_INVALID_ARG;
+    return pipe_join(e, (hipStream_t)hip_stream);
+}
+
+uint64_t aacg_pipeline_chained(const aacg_engine* e) { return e ? e->pipe.chained : 0; }
 
 /* The plan's device unit records take what the parser found (device to device); the run tables stay. */
 int aacg_plan_refresh_from_parse(aacg_engine* e, aacg_plan* p, const aacg_unit_desc* d_parsed_units,
@@ -718,7 +841,8 @@ int aacg_plan_refresh_from_parse(aacg_engine* e, aacg_plan* p, const aacg_unit_d
     }
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : e->stream;
     HIP_TRY(e, hipStreamWaitEvent(s, p->uploaded, 0), AACG_ERR_NO_DEVICE);
-    if (p->used && p->last_stream != s) {              /* the records' readers on the plan's previous stream first */
+    if (p->last_pipelined) { int jrc = pipe_join(e, s); if (jrc) return jrc; }
+    if (p->used && p->last_stream != s && !p->last_pipelined) {              /* the records' readers on the plan's previous stream first */
         HIP_TRY(e, hipEventRecord(p->last_use, p->last_stream), AACG_ERR_NO_DEVICE);
         HIP_TRY(e, hipStreamWaitEvent(s, p->last_use, 0), AACG_ERR_NO_DEVICE);
     }
@@ -726,6 +850,7 @@ int aacg_plan_refresh_from_parse(aacg_engine* e, aacg_plan* p, const aacg_unit_d
     HIP_TRY(e, hipGetLastError(), AACG_ERR_NO_DEVICE);
     p->last_stream = s;
     p->used = true;
+    p->last_pipelined = false;
     return AACG_OK;
 }
 
@@ -738,7 +863,8 @@ int aacg_plan_refresh_units(aacg_engine* e, aacg_plan* p, const aacg_unit_desc* 
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : e->stream;
     HIP_TRY(e, hipStreamWaitEvent(s, p->uploaded, 0), AACG_ERR_NO_DEVICE);
     /* the plan's previous launch on ANOTHER stream may still be reading the records this copy overwrites: order behind it */
-    if (p->used && p->last_stream != s) {
+    if (p->last_pipelined) { int jrc = pipe_join(e, s); if (jrc) return jrc; }
+    if (p->used && p->last_stream != s && !p->last_pipelined) {
         HIP_TRY(e, hipEventRecord(p->last_use, p->last_stream), AACG_ERR_NO_DEVICE);
         HIP_TRY(e, hipStreamWaitEvent(s, p->last_use, 0), AACG_ERR_NO_DEVICE);
     }
@@ -747,6 +873,7 @@ int aacg_plan_refresh_units(aacg_engine* e, aacg_plan* p, const aacg_unit_desc* 
     HIP_TRY(e, hipMemcpyAsync(p->d_units, p->h.units.data(), sizeof(aacg_dev_unit) * p->h.units.size(), hipMemcpyHostToDevice, s), AACG_ERR_NO_DEVICE);
     p->last_stream = s;
     p->used = true;
+    p->last_pipelined = false;
     return AACG_OK;
 }
 
@@ -772,7 +899,7 @@ int aacg_synchronize(aacg_engine* e, void* hip_stream)
 {
     if (!e) return AACG_ERR_INVALID_ARG;
     HIP_TRY(e, hipStreamSynchronize(hip_stream ? (hipStream_t)hip_stream : e->stream), AACG_ERR_NO_DEVICE);
-    return AACG_OK;
+    return pipe_join(e, nullptr);                       /* and whatever aacg_decode_pipelined has in flight */
 }
 
 /* ---- host-buffer path: process(elements) + interleave for a batch ------------------- */
@@ -884,24 +1011,17 @@ int aacg_submit_ex(aacg_engine* e, const aacg_batch* batch, uint64_t* ticket)
                            sizeof(float) * h.gains.size(), (size_t)h.side_blocks * 4096u};
     const void* const cce_src[4] = {h.cce_runs.data(), h.couple_jobs.data(), h.gains.data(), nullptr};
     for (int i = 0; i < 4; i++) if (ccb[i] && (rc = grow(e, &sl.d_cce[i], &sl.cce_cap[i], ccb[i]))) return rc;
-    const bool rvp = takes_rv(e, h);
+    const aacg_route R = route_of(e, h, false);
+    const bool rvp = R.rv;
     const size_t rvs[4] = {rvp ? sizeof(aacg_run) * h.runs_rv.size() : 0, rvp ? sizeof(aacg_rv_link) * h.links_rv.size() : 0,
-                           rvp ? sizeof(unsigned long long) * AACG8_RV_STATE_WORDS * (size_t)h.n_links_rv : 0,
-                           rvp ? sizeof(float) * AACG8_RV_DATA_FLOATS * (size_t)h.n_links_rv : 0};
+                           rvp ? sizeof(unsigned long long) * AACG_RV_STATE_WORDS * (size_t)h.n_links_rv : 0,
+                           rvp ? sizeof(float) * AACG_RV_DATA_FLOATS * (size_t)h.n_links_rv : 0};
     for (int i = 0; i < 4; i++) {
         const size_t had = sl.rv_cap[i];
         if (rvs[i] && (rc = grow(e, &sl.d_rv[i], &sl.rv_cap[i], rvs[i]))) return rc;
         /* a new state buffer starts from zero — on the slot's own stream, in front of the launch that reads it (a plain
          * hipMemset is ordered on the null stream, which a non-blocking stream does not wait for) */
         if (i == 2 && sl.rv_cap[i] != had) HIP_TRY(e, hipMemsetAsync(sl.d_rv[i], 0, sl.rv_cap[i], sl.stream), AACG_ERR_NO_DEVICE);
-    }
-    const bool r8 = takes_run8(e, h);
-    const size_t r8b[3] = {r8 ? sizeof(aacg_run8) * h.runs8.size() : 0, r8 ? sizeof(unsigned long long) * AACG8_RV_STATE_WORDS * (size_t)h.n_links : 0,
-                           r8 ? sizeof(float) * AACG8_RV_DATA_FLOATS * (size_t)h.n_links : 0};
-    for (int i = 0; i < 3; i++) {
-        const size_t had = sl.run8_cap[i];
-        if (r8b[i] && (rc = grow(e, &sl.d_run8[i], &sl.run8_cap[i], r8b[i]))) return rc;
-        if (i == 1 && sl.run8_cap[i] != had) HIP_TRY(e, hipMemsetAsync(sl.d_run8[i], 0, sl.run8_cap[i], sl.stream), AACG_ERR_NO_DEVICE);   /* likewise */
     }
     const size_t cb = (size_t)n_coef_blocks * 1024u * coef_elem_size(e);
     const size_t mb = quant ? (size_t)n_meta * sizeof(aacg_band_meta) : 0;
@@ -934,7 +1054,6 @@ int aacg_submit_ex(aacg_engine* e, const aacg_batch* batch, uint64_t* ticket)
     }
     HIP_TRY(e, hipMemcpyAsync(sl.d_units, h.units.data(), ub, hipMemcpyHostToDevice, s), AACG_ERR_NO_DEVICE);
     if (rb) HIP_TRY(e, hipMemcpyAsync(sl.d_runs, h.runs.data(), rb, hipMemcpyHostToDevice, s), AACG_ERR_NO_DEVICE);
-    if (r8b[0]) HIP_TRY(e, hipMemcpyAsync(sl.d_run8[0], h.runs8.data(), r8b[0], hipMemcpyHostToDevice, s), AACG_ERR_NO_DEVICE);
     if (rvs[0]) HIP_TRY(e, hipMemcpyAsync(sl.d_rv[0], h.runs_rv.data(), rvs[0], hipMemcpyHostToDevice, s), AACG_ERR_NO_DEVICE);
     if (rvs[1]) HIP_TRY(e, hipMemcpyAsync(sl.d_rv[1], h.links_rv.data(), rvs[1], hipMemcpyHostToDevice, s), AACG_ERR_NO_DEVICE);
     if (tb) HIP_TRY(e, hipMemcpyAsync(sl.d_tns, h.tns.data(), tb, hipMemcpyHostToDevice, s), AACG_ERR_NO_DEVICE);
@@ -944,11 +1063,12 @@ int aacg_submit_ex(aacg_engine* e, const aacg_batch* batch, uint64_t* ticket)
     /* kernels chain through the overlap state: this one starts after the previous batch's kernel,
      * while its uploads above overlapped it */
     if (e->last_kernel) HIP_TRY(e, hipStreamWaitEvent(s, e->last_kernel, 0), AACG_ERR_NO_DEVICE);
-    rc = launch_run(e, (const aacg_dev_unit*)sl.d_units, (const aacg_run*)sl.d_runs, (const aacg_dev_tns*)sl.d_tns,
+    if ((rc = pipe_join(e, s))) return rc;              /* ... and after whatever aacg_decode_pipelined has in flight */
+    const xl_args serial = {false, 0ull, 0};
+    rc = launch_run(e, R, (const aacg_dev_unit*)sl.d_units, (const aacg_run*)sl.d_runs, (const aacg_dev_tns*)sl.d_tns,
                     (float*)sl.d_scratch, (float*)sl.d_spec, cce_bufs{(const aacg_run*)sl.d_cce[0], (const aacg_couple_job*)sl.d_cce[1], (const float*)sl.d_cce[2], (float*)sl.d_cce[3]},
-                    run8_bufs{(const aacg_run8*)sl.d_run8[0], (unsigned long long*)sl.d_run8[1], (float*)sl.d_run8[2]},
                     rv_bufs{(const aacg_run*)sl.d_rv[0], (const aacg_rv_link*)sl.d_rv[1], (unsigned long long*)sl.d_rv[2], (float*)sl.d_rv[3]}, h, sl.d_coeffs,
-                    (const aacg_band_meta*)sl.d_meta, sl.d_pcm, 0, s);
+                    (const aacg_band_meta*)sl.d_meta, sl.d_pcm, 0, s, serial, nullptr);
     if (rc) return rc;
     HIP_TRY(e, hipEventRecord(sl.kernel_done, s), AACG_ERR_NO_DEVICE);
     e->last_kernel = sl.kernel_done;
@@ -958,7 +1078,7 @@ int aacg_submit_ex(aacg_engine* e, const aacg_batch* batch, uint64_t* ticket)
 
     for (const aacg_chain& c : h.chains)
         for (int k = 0; k < c.n_ch; k++)
-            e->parity[(size_t)c.stream * (size_t)e->cfg.max_channels + c.channel + k] ^= 1;
+            { uint8_t& b = e->parity[(size_t)c.stream * (size_t)e->cfg.max_channels + c.channel + k]; b = (uint8_t)((b + 1) % AACG_OV_BUFFERS); }
     e->epoch++;
     *ticket = ++e->submitted;
     return AACG_OK;

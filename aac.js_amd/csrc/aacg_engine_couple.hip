@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include "aacg_kernels.h"
+#include "aacg_routes.h"
 
 #define AACG_COUPLE_WAVES 4
 
@@ -28,16 +29,13 @@ void aacg_imdct_run_quant_cpl_nt(const aacg_kparams P) { imdct_run_body<AACG_INP
 extern "C" __global__ __launch_bounds__(AACG_WG_THREADS)
 void aacg_imdct_run_f32_cpl_nt(const aacg_kparams P) { imdct_run_body<AACG_INPUT_SPEC_F32, AACG_OUTPUT_F32, false, false, true, false, true>(P); }
 
-void aacg_couple_run_launch(bool quant, bool wide, dim3 grid, dim3 block, hipStream_t s, const aacg_kparams& P)
-{
-    if (wide) {
-        if (quant) hipLaunchKernelGGL(aacg_imdct_run_quant_cpl_nt, grid, block, 0, s, P);
-        else       hipLaunchKernelGGL(aacg_imdct_run_f32_cpl_nt, grid, block, 0, s, P);
-    } else {
-        if (quant) hipLaunchKernelGGL(aacg_imdct_run_quant_cpl, grid, block, 0, s, P);
-        else       hipLaunchKernelGGL(aacg_imdct_run_f32_cpl, grid, block, 0, s, P);
-    }
-}
+const aacg_run_kernel aacg_run_kernels_couple[] = {
+    {AACG_RK_CPL | AACG_RK_QUANT, "aacg_imdct_run_quant_cpl", (const void*)aacg_imdct_run_quant_cpl},
+    {AACG_RK_CPL, "aacg_imdct_run_f32_cpl", (const void*)aacg_imdct_run_f32_cpl},
+    {AACG_RK_CPL | AACG_RK_NT | AACG_RK_QUANT, "aacg_imdct_run_quant_cpl_nt", (const void*)aacg_imdct_run_quant_cpl_nt},
+    {AACG_RK_CPL | AACG_RK_NT, "aacg_imdct_run_f32_cpl_nt", (const void*)aacg_imdct_run_f32_cpl_nt}
+};
+const int aacg_run_kernels_couple_n = 4;
 
 void aacg_couple_launch(bool pcm, hipStream_t s, const aacg_couple_params& Q)
 {

@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 
 #include "aacg_kernels.h"
+#include "aacg_routes.h"
 
 extern "C" __global__ __launch_bounds__(AACG_WG_THREADS)
 void aacg_imdct_run_quant_ex(const aacg_kparams P) { imdct_run_body<AACG_INPUT_QUANT_I16, AACG_OUTPUT_F32, false, true>(P); }
@@ -19,8 +20,8 @@ void aacg_imdct_run_f32_ex(const aacg_kparams P) { imdct_run_body<AACG_INPUT_SPE
 
 static_assert(AACG_LDS_BYTES_QUANT_EX <= 160 * 1024, "the TNS exchange areas must fit beside the slots");
 
-void aacg_exrun_launch(bool quant, dim3 grid, dim3 block, hipStream_t s, const aacg_kparams& P)
-{
-    if (quant) hipLaunchKernelGGL(aacg_imdct_run_quant_ex, grid, block, 0, s, P);
-    else       hipLaunchKernelGGL(aacg_imdct_run_f32_ex, grid, block, 0, s, P);
-}
+const aacg_run_kernel aacg_run_kernels_exrun[] = {
+    {AACG_RK_EX | AACG_RK_QUANT, "aacg_imdct_run_quant_ex", (const void*)aacg_imdct_run_quant_ex},
+    {AACG_RK_EX, "aacg_imdct_run_f32_ex", (const void*)aacg_imdct_run_f32_ex}
+};
+const int aacg_run_kernels_exrun_n = 2;

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include "aacg_kernels.h"
+#include "aacg_routes.h"
 
 
 /* Variants of aacg_imdct_run_quant / _f32:
@@ -18,8 +19,8 @@ void aacg_imdct_run_f32_dd(const aacg_kparams P) { imdct_run_body<AACG_INPUT_SPE
 
 
 
-void aacg_ext_launch(bool quant, dim3 grid, dim3 block, hipStream_t s, const aacg_kparams& P)
-{
-    if (quant) hipLaunchKernelGGL(aacg_imdct_run_quant_dd, grid, block, 0, s, P);
-    else       hipLaunchKernelGGL(aacg_imdct_run_f32_dd, grid, block, 0, s, P);
-}
+const aacg_run_kernel aacg_run_kernels_ext[] = {
+    {AACG_RK_DD | AACG_RK_QUANT, "aacg_imdct_run_quant_dd", (const void*)aacg_imdct_run_quant_dd},
+    {AACG_RK_DD, "aacg_imdct_run_f32_dd", (const void*)aacg_imdct_run_f32_dd}
+};
+const int aacg_run_kernels_ext_n = 2;

@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include "aacg_kernels.h"
+#include "aacg_routes.h"
 
 extern "C" __global__ __launch_bounds__(AACG_WG_THREADS)
 void aacg_imdct_run_quant_i16(const aacg_kparams P) { imdct_run_body<AACG_INPUT_QUANT_I16, AACG_OUTPUT_I16>(P); }
@@ -22,16 +23,12 @@ void aacg_imdct_run_quant_i16_nt(const aacg_kparams P) { imdct_run_body<AACG_INP
 extern "C" __global__ __launch_bounds__(AACG_WG_THREADS)
 void aacg_imdct_run_f32_i16_nt(const aacg_kparams P) { imdct_run_body<AACG_INPUT_SPEC_F32, AACG_OUTPUT_I16, false, false, false, false, true>(P); }
 
-void aacg_i16_launch(bool quant, bool dd, bool wide, dim3 grid, dim3 block, hipStream_t s, const aacg_kparams& P)
-{
-    if (wide && !dd) {
-        if (quant) hipLaunchKernelGGL(aacg_imdct_run_quant_i16_nt, grid, block, 0, s, P);
-        else       hipLaunchKernelGGL(aacg_imdct_run_f32_i16_nt, grid, block, 0, s, P);
-    } else if (dd) {
-        if (quant) hipLaunchKernelGGL(aacg_imdct_run_quant_dd_i16, grid, block, 0, s, P);
-        else       hipLaunchKernelGGL(aacg_imdct_run_f32_dd_i16, grid, block, 0, s, P);
-    } else {
-        if (quant) hipLaunchKernelGGL(aacg_imdct_run_quant_i16, grid, block, 0, s, P);
-        else       hipLaunchKernelGGL(aacg_imdct_run_f32_i16, grid, block, 0, s, P);
-    }
-}
+const aacg_run_kernel aacg_run_kernels_i16[] = {
+    {AACG_RK_I16 | AACG_RK_QUANT, "aacg_imdct_run_quant_i16", (const void*)aacg_imdct_run_quant_i16},
+    {AACG_RK_I16, "aacg_imdct_run_f32_i16", (const void*)aacg_imdct_run_f32_i16},
+    {AACG_RK_I16 | AACG_RK_DD | AACG_RK_QUANT, "aacg_imdct_run_quant_dd_i16", (const void*)aacg_imdct_run_quant_dd_i16},
+    {AACG_RK_I16 | AACG_RK_DD, "aacg_imdct_run_f32_dd_i16", (const void*)aacg_imdct_run_f32_dd_i16},
+    {AACG_RK_I16 | AACG_RK_NT | AACG_RK_QUANT, "aacg_imdct_run_quant_i16_nt", (const void*)aacg_imdct_run_quant_i16_nt},
+    {AACG_RK_I16 | AACG_RK_NT, "aacg_imdct_run_f32_i16_nt", (const void*)aacg_imdct_run_f32_i16_nt}
+};
+const int aacg_run_kernels_i16_n = 6;

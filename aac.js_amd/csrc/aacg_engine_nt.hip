@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 
 #include "aacg_kernels.h"
+#include "aacg_routes.h"
 
 extern "C" __global__ __launch_bounds__(AACG_WG_THREADS)
 void aacg_imdct_run_quant_nt(const aacg_kparams P) { imdct_run_body<AACG_INPUT_QUANT_I16, AACG_OUTPUT_F32, false, false, false, false, true>(P); }
@@ -18,8 +19,8 @@ void aacg_imdct_run_quant_nt(const aacg_kparams P) { imdct_run_body<AACG_INPUT_Q
 extern "C" __global__ __launch_bounds__(AACG_WG_THREADS)
 void aacg_imdct_run_f32_nt(const aacg_kparams P) { imdct_run_body<AACG_INPUT_SPEC_F32, AACG_OUTPUT_F32, false, false, false, false, true>(P); }
 
-void aacg_nt_launch(bool quant, dim3 grid, dim3 block, hipStream_t s, const aacg_kparams& P)
-{
-    if (quant) hipLaunchKernelGGL(aacg_imdct_run_quant_nt, grid, block, 0, s, P);
-    else       hipLaunchKernelGGL(aacg_imdct_run_f32_nt, grid, block, 0, s, P);
-}
+const aacg_run_kernel aacg_run_kernels_nt[] = {
+    {AACG_RK_NT | AACG_RK_QUANT, "aacg_imdct_run_quant_nt", (const void*)aacg_imdct_run_quant_nt},
+    {AACG_RK_NT, "aacg_imdct_run_f32_nt", (const void*)aacg_imdct_run_f32_nt}
+};
+const int aacg_run_kernels_nt_n = 2;

@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include "aacg_kernels.h"
+#include "aacg_routes.h"
 
 extern "C" __global__ __launch_bounds__(AACG_WG_THREADS)
 void aacg_imdct_run_quant_rv(const aacg_kparams P, const aacg_rv_args V) { imdct_run_body<AACG_INPUT_QUANT_I16, AACG_OUTPUT_F32, false, false, false, true>(P, &V); }
@@ -20,13 +21,10 @@ void aacg_imdct_run_quant_rv_nt(const aacg_kparams P, const aacg_rv_args V) { im
 extern "C" __global__ __launch_bounds__(AACG_WG_THREADS)
 void aacg_imdct_run_f32_rv_nt(const aacg_kparams P, const aacg_rv_args V) { imdct_run_body<AACG_INPUT_SPEC_F32, AACG_OUTPUT_F32, false, false, false, true, true>(P, &V); }
 
-void aacg_rv_launch(bool quant, bool wide, dim3 grid, dim3 block, hipStream_t s, const aacg_kparams& P, const aacg_rv_args& V)
-{
-    if (wide) {
-        if (quant) hipLaunchKernelGGL(aacg_imdct_run_quant_rv_nt, grid, block, 0, s, P, V);
-        else       hipLaunchKernelGGL(aacg_imdct_run_f32_rv_nt, grid, block, 0, s, P, V);
-    } else {
-        if (quant) hipLaunchKernelGGL(aacg_imdct_run_quant_rv, grid, block, 0, s, P, V);
-        else       hipLaunchKernelGGL(aacg_imdct_run_f32_rv, grid, block, 0, s, P, V);
-    }
-}
+const aacg_run_kernel aacg_run_kernels_rv[] = {
+    {AACG_RK_RV | AACG_RK_QUANT, "aacg_imdct_run_quant_rv", (const void*)aacg_imdct_run_quant_rv},
+    {AACG_RK_RV, "aacg_imdct_run_f32_rv", (const void*)aacg_imdct_run_f32_rv},
+    {AACG_RK_RV | AACG_RK_NT | AACG_RK_QUANT, "aacg_imdct_run_quant_rv_nt", (const void*)aacg_imdct_run_quant_rv_nt},
+    {AACG_RK_RV | AACG_RK_NT, "aacg_imdct_run_f32_rv_nt", (const void*)aacg_imdct_run_f32_rv_nt}
+};
+const int aacg_run_kernels_rv_n = 4;

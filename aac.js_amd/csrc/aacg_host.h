@@ -18,7 +18,6 @@ struct aacg_host_windows {
 /* Fills *t for config.sampleIndex (decoder.js:63); hw (optional) receives the plain windows. */
 int aacg_build_tables(int sample_index, aacg_tables* t, aacg_host_windows* hw);
 int aacg_build_pns_tables(int sample_index, aacg_pns_tables* t);
-void aacg_build_win8(const aacg_tables* t, aacg_win8* w);
 /* SWB_OFFSET_1024/128[sample_index] (tables.js:34-155): writes count+1 offsets, returns count. */
 int aacg_swb_offsets(int sample_index, int is_long, int* dst);
 
@@ -27,7 +26,7 @@ struct aacg_chain {
     uint32_t stream;
     uint16_t channel;
     uint8_t  n_ch;
-    uint8_t  parity[2];     /* overlap buffer holding the chain's input state when the plan was built */
+    uint8_t  parity[2];     /* overlap buffer (0..AACG_OV_BUFFERS-1) holding the chain's input state when the plan was built */
     uint32_t first_run, n_runs;
 };
 
@@ -39,12 +38,10 @@ struct aacg_plan_host {
     bool     needs_scratch = false;   /* some later run holds 16 frames: its first wave parks the predecessor's tails */
     bool     wide_frames = false;     /* at least half of the units belong to frames of more than two channels: the multichannel kernel variants (aacg_engine_nt.hip) */
     std::vector<aacg_run>   runs;     /* in launch (block) order, XCD-aware */
-    /* the same chains cut for the 8-waves-per-SIMD kernels (aacg_kernels8.h): 8 frames of a channel pair or 16 of a single
-     * channel per run, consecutive runs of a chain joined by a rendezvous cell instead of a recomputed frame */
-    std::vector<aacg_run8>  runs8;
-    uint32_t n_links = 0;
-    /* chains longer than a run for the 16-wave kernels WITHOUT a recomputed frame (_rv builds): every run up to 16 frames,
-     * consecutive runs of a chain joined by a rendezvous cell; empty when no chain is longer than a run */
+    /* the same chains cut for the rendezvous kernels (_rv builds): every run up to 16 frames, consecutive runs of a chain joined
+     * by a rendezvous cell instead of a recomputed frame.  The route of plain batches with a chain longer than a run
+     * (long_chains) and of every plain batch launched through aacg_decode_pipelined */
+    bool     long_chains = false;
     std::vector<aacg_run>     runs_rv;
     std::vector<aacg_rv_link> links_rv;     /* one per run, same order */
     uint32_t n_links_rv = 0;
@@ -71,14 +68,14 @@ struct aacg_plan_host {
     size_t   pcm_floats = 0;          /* 1 + highest PCM float written */
 };
 
-/* float offset of overlap buffer `parity` of (stream, channel) in the pool */
+/* float offset of overlap buffer `parity` (0..AACG_OV_BUFFERS-1) of (stream, channel) in the pool */
 static inline int32_t aacg_ov_offset(int max_channels, uint32_t stream, uint32_t channel, int parity)
 {
-    return (int32_t)((((size_t)stream * (size_t)max_channels + channel) * 2u + (unsigned)parity) * 1024u);
+    return (int32_t)((((size_t)stream * (size_t)max_channels + channel) * (size_t)AACG_OV_BUFFERS + (unsigned)parity) * 1024u);
 }
 
 /* Validates the units and cuts them into runs.  parity: [max_streams * max_channels] current
- * input buffer per (stream, channel), or NULL for all zero.  Returns AACG_OK or an error code
+ * input buffer (0..AACG_OV_BUFFERS-1) per (stream, channel), or NULL for all zero.  Returns AACG_OK or an error code
  * with a message in *err. */
 int aacg_plan_build(const aacg_unit_desc* units, uint32_t n_units, int sample_index,
                     int max_streams, int max_channels, const uint8_t* parity,

@@ -84,8 +84,8 @@ DP_DEVICE void radix8_inv(cpx (&x)[8])
     x[3] = c_add(e3, t3); x[7] = c_sub(e3, t3);
 }
 
-/* ---- one complex value per register pair, (re, im) packed: the single-channel transforms below and the one-channel-per-wave
- * kernels (aacg_kernels8.h) — a butterfly is v_pk_add / v_pk_fma with op_sel swaps, a rotation two packed instructions ---- */
+/* ---- one complex value per register pair, (re, im) packed: the single-channel transforms below — a butterfly is v_pk_add /
+ * v_pk_fma with op_sel swaps, a rotation two packed instructions ---- */
 DP_DEVICE dpv2 k8_ld2(const float* p) { const dpf2 t = *(const dpf2*)p; dpv2 r; r[0] = t.x; r[1] = t.y; return r; }
 DP_DEVICE void k8_st2(float* p, dpv2 v) { dpf2 t; t.x = v[0]; t.y = v[1]; *(dpf2*)p = t; }
 DP_DEVICE dpv2 k8_v2(float a, float b) { dpv2 r; r[0] = a; r[1] = b; return r; }
@@ -1869,10 +1869,8 @@ DP_DEVICE void epilogue(const aacg_kparams& P, const cpl_prefetch& pre, const fl
 }
 
 /* ------------------------------------------------------------------------------------ */
-/* run-to-run rendezvous of the _rv builds (aacg_rv_args, aacg_device.h)                      */
+/* run-to-run (and launch-to-launch) rendezvous of the _rv builds (aacg_rv_args, aacg_device.h)  */
 /* ------------------------------------------------------------------------------------ */
-#define AACG_RV_TAIL 1ull
-#define AACG_RV_HEAD 2ull
 /* a wave's windowed first half (hx / hy in the IMDCT lane map) as planar [channel][1024] floats in a rendezvous payload:
  * -0.0 where the sequence takes the sample from the overlap alone (EIGHT_SHORT: 0..447), so that tail + head = tail there */
 DP_DEVICE void rv_publish_head(float* d0, float* d1, int n_ch, int cls0, int cls1, int lcol,
@@ -1920,15 +1918,14 @@ DP_DEVICE void rv_publish_tails(const float* slot, int n_ch, float* d0, float* d
     }
 }
 /* the run that arrives second at a rendezvous whose other side left its windowed first half: the next run's first frame =
- * this wave's tails (its slot) + that first half, to that frame's place in the PCM (su: its unit) */
+ * this wave's tails (its slot) + that first half, to that frame's place in the PCM: `pcm` = sample 0 of the element's first
+ * channel there, C = that frame's interleave stride (a frame of this launch, or — pipelined launches — of the next one) */
 template <int OUT>
-DP_DEVICE void rv_finish_successor(const aacg_kparams& P, const unit_view& su, int n_ch, const float* slot, const float* h0, const float* h1)
+DP_DEVICE void rv_finish_successor(typename pcm_elem<OUT>::type* pcm, int C, int n_ch, const float* slot, const float* h0, const float* h1)
 {
 #pragma clang fp contract(off)
-    typedef typename pcm_elem<OUT>::type elem;
-    const int lane = dp_lane(), C = su.n_out_ch;
-    elem* pcm = (elem*)P.pcm + su.pcm_offset + su.channel;
-    if (n_ch == 2 && C == 2 && ((su.pcm_offset | (uint32_t)su.channel) & 3u) == 0) {
+    const int lane = dp_lane();
+    if (n_ch == 2 && C == 2 && ((uintptr_t)pcm & (4u * sizeof(*pcm) - 1u)) == 0) {
         dpf2 hl[8], hr[8];
 #pragma unroll
         for (int i = 0; i < 8; i++) { const int n = 2 * lane + 128 * i; hl[i] = dp_g_load_f2(h0 + n); hr[i] = dp_g_load_f2(h1 + n); }
@@ -1951,6 +1948,10 @@ DP_DEVICE void rv_finish_successor(const aacg_kparams& P, const unit_view& su, i
         }
     }
 }
+
+/* overlap buffer r of a channel is 1024 r floats behind its buffer 0; this launch reads buffer (rot + flip) mod 3 of a run's
+ * channel and leaves the new state in the next one (aacg_run.rot, aacg_kparams.flip: both 0..2) */
+DP_DEVICE int ov_buffer(int rot, int add) { int r = rot + add; r = r >= AACG_OV_BUFFERS ? r - AACG_OV_BUFFERS : r; return r >= AACG_OV_BUFFERS ? r - AACG_OV_BUFFERS : r; }
 
 /* ------------------------------------------------------------------------------------ */
 /* one run per workgroup                                                                   */
@@ -1993,8 +1994,14 @@ DP_DEVICE void imdct_run_body(const aacg_kparams& P, const aacg_rv_args* V = nul
     const bool has_pred = !RV && run->pred_unit >= 0;
     aacg_rv_link lk; lk.link_in = lk.link_out = lk.succ_unit = -1; lk.reserved = 0;
     if (RV) lk = V->links[dp_block()];
-    /* the frame another workgroup may be waiting for: a run's last, when its chain goes on */
-    const bool hands_over = RV && lk.link_out >= 0 && wave == n_units - 1;
+    /* pipelined launches (aacg_decode_pipelined): the two ends of a chain meet the plan's neighbouring LAUNCHES in cross-launch
+     * cells (aacg_xl_cell) exactly as its runs meet each other in the in-launch ones */
+    const bool xl = RV && V->xl_cells != nullptr;
+    /* the frame another workgroup may be waiting for: a run's last, when its chain goes on — in this launch or in the next */
+    const bool hands_over = RV && wave == n_units - 1 && (lk.link_out >= 0 || xl);
+    /* this launch's overlap buffers of the run's channels (float offsets in the pool), evaluated where a chain's first or last wave needs them */
+#define AACG_OV_IN(c)  (run->ov0[c] + 1024 * ov_buffer(run->rot[c], P.flip))
+#define AACG_OV_OUT(c) (run->ov0[c] + 1024 * ov_buffer(run->rot[c], P.flip + 1))
     /* A later run of a chain starts from the tail of the frame before it, which another workgroup owns, so it
      * recomputes that frame's IMDCT.  With up to 15 frames wave 0 does only that (waves 1.. own the frames);
      * a full run of 16 frames gives wave 0 double duty: first the predecessor (its tail goes to a scratch
@@ -2174,17 +2181,25 @@ DP_DEVICE void imdct_run_body(const aacg_kparams& P, const aacg_rv_args* V = nul
     if (lane == 0) dp_flag_set(&flags[wave], 1);
     if (trace && lane == 0) trace[3] = dp_clock();         /* IMDCT done, tail released */
 
+    typedef typename pcm_elem<OUT>::type pcm_t;
     const unsigned long long rv_tag = RV ? V->epoch << 2 : 0ull;
     if (RV && hands_over && ui >= 0) {
         /* the chain goes on in another workgroup: publish this frame's tails — or, if that workgroup was here first and left
-         * its windowed first half, finish its frame (nobody waits for anybody: no dispatch order is assumed) */
+         * its windowed first half, finish its frame (nobody waits for anybody: no dispatch order is assumed).  `cross`: the
+         * other workgroup belongs to the plan's NEXT launch; the tails then land in the out overlap buffer itself */
         dp_keep_branch();
-        unsigned long long* st = V->state + (size_t)lk.link_out * AACG8_RV_STATE_WORDS;
-        float* data = V->data + (size_t)lk.link_out * AACG8_RV_DATA_FLOATS;
+        const bool cross = lk.link_out < 0;
+        aacg_xl_cell* cell = cross ? V->xl_cells + ((run->ov0[0] >> 10) + ov_buffer(run->rot[0], P.flip + 1)) : nullptr;
+        float* data = cross ? nullptr : V->data + (size_t)lk.link_out * AACG_RV_DATA_FLOATS;
+        unsigned long long* st = cross ? &cell->state : V->state + (size_t)lk.link_out * AACG_RV_STATE_WORDS;
+        float* t0 = cross ? P.overlap + AACG_OV_OUT(0) : data;
+        float* t1 = cross ? P.overlap + AACG_OV_OUT(1) : data + 1024;
+        const float* h0 = cross ? V->xl_head + AACG_OV_OUT(0) : data + 2048;
+        const float* h1 = cross ? V->xl_head + AACG_OV_OUT(1) : data + 2048 + 1024;
         const unsigned long long seen = dp_first_u64(dp_g_load_u64(st));
         bool theirs = seen == (rv_tag | AACG_RV_HEAD);
         if (!theirs) {
-            rv_publish_tails(slot, n_ch, data, data + 1024);
+            rv_publish_tails(slot, n_ch, t0, t1);
             dp_vm_drain();
             dp_wave_sync();
             bool won = true;
@@ -2192,8 +2207,16 @@ DP_DEVICE void imdct_run_body(const aacg_kparams& P, const aacg_rv_args* V = nul
             theirs = dp_first_u64(won ? 0ull : 1ull) != 0ull;
         }
         if (theirs) {
-            const unit_view su = load_unit(P.units + dp_uniform(lk.succ_unit));
-            rv_finish_successor<OUT>(P, su, n_ch, slot, data + 2048, data + 2048 + 1024);
+            pcm_t* dst; int C;
+            if (cross) {
+                dst = (pcm_t*)(uintptr_t)dp_first_u64(dp_g_load_u64(&cell->pcm));
+                C = dp_uniform((int)dp_g_load_u32(&cell->n_out_ch));
+            } else {
+                const unit_view su = load_unit(P.units + dp_uniform(lk.succ_unit));
+                dst = (pcm_t*)P.pcm + su.pcm_offset + su.channel;
+                C = su.n_out_ch;
+            }
+            rv_finish_successor<OUT>(dst, C, n_ch, slot, h0, h1);
         }
     }
 
@@ -2209,26 +2232,39 @@ DP_DEVICE void imdct_run_body(const aacg_kparams& P, const aacg_rv_args* V = nul
         if (wave == 0) {
             /* first frame of its chain in this launch: overlap state from HBM (filter_bank.js:38-41,
              * `overlap = this.overlaps[channel]`); a double-duty wave: the tails it parked itself */
-            const float* ov0 = n_pass == 2 ? scratch : P.overlap + (P.flip ? run->ov_b[0] : run->ov_a[0]);
-            const float* ov1 = n_pass == 2 ? scratch + 1024 : P.overlap + (P.flip ? run->ov_b[1] : run->ov_a[1]);
+            const float* ov0 = n_pass == 2 ? scratch : P.overlap + AACG_OV_IN(0);
+            const float* ov1 = n_pass == 2 ? scratch + 1024 : P.overlap + AACG_OV_IN(1);
             cpl_prefetch none; none.n = 0;
-            if (RV && lk.link_in >= 0) {
-                /* first frame of a later run: the tails the run before it published — or, if they are not there yet, leave the
-                 * windowed first half for that run and go */
+            /* first frame of its chain in a pipelined launch whose predecessor may still be running: its state arrives through
+             * the cross-launch cell of the in buffer (epoch_in = 0: the predecessor is known to be complete, a plain read) */
+            const bool cross = xl && lk.link_in < 0 && V->epoch_in != 0ull;
+            if (RV && (lk.link_in >= 0 || cross)) {
+                /* the tails the run before it published — or, if they are not there yet, leave the windowed first half for that
+                 * run (and, across launches, where the finished samples go) and go */
                 dp_keep_branch();
-                unsigned long long* st = V->state + (size_t)lk.link_in * AACG8_RV_STATE_WORDS;
-                float* data = V->data + (size_t)lk.link_in * AACG8_RV_DATA_FLOATS;
+                aacg_xl_cell* cell = cross ? V->xl_cells + ((run->ov0[0] >> 10) + ov_buffer(run->rot[0], P.flip)) : nullptr;
+                float* data = cross ? nullptr : V->data + (size_t)lk.link_in * AACG_RV_DATA_FLOATS;
+                unsigned long long* st = cross ? &cell->state : V->state + (size_t)lk.link_in * AACG_RV_STATE_WORDS;
+                const float* t0 = cross ? P.overlap + AACG_OV_IN(0) : data;
+                const float* t1 = cross ? P.overlap + AACG_OV_IN(1) : data + 1024;
+                float* h0 = cross ? V->xl_head + AACG_OV_IN(0) : data + 2048;
+                float* h1 = cross ? V->xl_head + AACG_OV_IN(1) : data + 2048 + 1024;
+                const unsigned long long tag = cross ? V->epoch_in << 2 : rv_tag;
                 const unsigned long long seen = dp_first_u64(dp_g_load_u64(st));
-                bool theirs = seen == (rv_tag | AACG_RV_TAIL);
+                bool theirs = seen == (tag | AACG_RV_TAIL);
                 if (!theirs) {
-                    rv_publish_head(data + 2048, data + 2048 + 1024, n_ch, cls0, cls1, lcol, hx0, hy0, hx1, hy1);
+                    rv_publish_head(h0, h1, n_ch, cls0, cls1, lcol, hx0, hy0, hx1, hy1);
+                    if (cross && lane == 0) {
+                        dp_g_store_u64(&cell->pcm, (unsigned long long)(uintptr_t)((pcm_t*)P.pcm + u.pcm_offset + u.channel));
+                        dp_g_store_u32(&cell->n_out_ch, (unsigned)u.n_out_ch);
+                    }
                     dp_vm_drain();
                     dp_wave_sync();
                     bool won = true;
-                    if (lane == 0) won = dp_g_cas_u64(st, seen, rv_tag | AACG_RV_HEAD);
+                    if (lane == 0) won = dp_g_cas_u64(st, seen, tag | AACG_RV_HEAD);
                     theirs = dp_first_u64(won ? 0ull : 1ull) != 0ull;
                 }
-                if (theirs) epilogue<false, OUT, CPL, true>(P, none, data, data + 1024, u, n_ch, cls0, cls1, P.pcm, hx0, hy0, hx1, hy1, lcol);
+                if (theirs) epilogue<false, OUT, CPL, true>(P, none, t0, t1, u, n_ch, cls0, cls1, P.pcm, hx0, hy0, hx1, hy1, lcol);
             } else
             epilogue<false, OUT, CPL>(P, none, ov0, ov1, u, n_ch, cls0, cls1, P.pcm, hx0, hy0, hx1, hy1, lcol);
         } else {
@@ -2241,10 +2277,13 @@ DP_DEVICE void imdct_run_body(const aacg_kparams& P, const aacg_rv_args* V = nul
         if (trace && lane == 0) trace[5] = dp_clock();     /* PCM stores issued */
         /* the chain's last frame in this launch: its tail is the new overlap state (planar in HBM) */
         const int last_wave = (has_pred && !dd) ? n_units : n_units - 1;
-        if (wave == last_wave && run->is_last)
-            save_tails(P.overlap + (P.flip ? run->ov_a[0] : run->ov_b[0]), P.overlap + (P.flip ? run->ov_a[1] : run->ov_b[1]));
+        if (wave == last_wave && run->is_last && !xl)      /* (pipelined: the hand-over above has put it there, or the next launch has taken it) */
+            save_tails(P.overlap + AACG_OV_OUT(0), P.overlap + AACG_OV_OUT(1));
     }
 }
+
+#undef AACG_OV_IN
+#undef AACG_OV_OUT
 
 /* The optional stages as a kernel of their own (16 units per workgroup, one wave each), so that the run kernels
  * never carry them: quantised input -> dequantisation, noise bands (AACG_PNS_SPEC), MS / IS, then the TNS filters

@@ -361,7 +361,6 @@ int aacg_plan_build(const aacg_unit_desc* units, uint32_t n_units, int sample_in
 
     /* chains -> runs, generated chain by chain */
     std::vector<aacg_run> gen, cce_gen;
-    std::vector<aacg_run8> gen8;
     std::vector<aacg_run> gen_rv;
     std::vector<aacg_rv_link> gen_rv_links;
     bool long_chain = false;
@@ -392,8 +391,8 @@ int aacg_plan_build(const aacg_unit_desc* units, uint32_t n_units, int sample_in
             for (int k = 0; k < AACG_RUN_W; k++) r.unit[k] = k < r.n_units ? oc.units[pos + k] : -1;
             for (int c = 0; c < 2; c++) {
                 const uint32_t chn = ch.channel + (c < oc.n_ch ? c : 0);
-                r.ov_a[c] = aacg_ov_offset(max_channels, ch.stream, chn, ch.parity[c]);
-                r.ov_b[c] = aacg_ov_offset(max_channels, ch.stream, chn, ch.parity[c] ^ 1);
+                r.ov0[c] = aacg_ov_offset(max_channels, ch.stream, chn, 0);
+                r.rot[c] = ch.parity[c < oc.n_ch ? c : 0];
             }
             if (pos && r.n_units == AACG_RUN_W) out->needs_scratch = true;
             pos += (size_t)r.n_units;
@@ -414,8 +413,8 @@ int aacg_plan_build(const aacg_unit_desc* units, uint32_t n_units, int sample_in
                 for (int k = 0; k < AACG_RUN_W; k++) r.unit[k] = k < r.n_units ? oc.units[pos + k] : -1;
                 for (int c = 0; c < 2; c++) {
                     const uint32_t chn = ch.channel + (c < oc.n_ch ? c : 0);
-                    r.ov_a[c] = aacg_ov_offset(max_channels, ch.stream, chn, ch.parity[c]);
-                    r.ov_b[c] = aacg_ov_offset(max_channels, ch.stream, chn, ch.parity[c] ^ 1);
+                    r.ov0[c] = aacg_ov_offset(max_channels, ch.stream, chn, 0);
+                    r.rot[c] = ch.parity[c < oc.n_ch ? c : 0];
                 }
                 const bool more = pos + AACG_RUN_W < n;
                 r.is_last = more ? 0 : 1;
@@ -428,30 +427,6 @@ int aacg_plan_build(const aacg_unit_desc* units, uint32_t n_units, int sample_in
                 lk.reserved = 0;
                 gen_rv.push_back(r);
                 gen_rv_links.push_back(lk);
-            }
-        }
-        /* the same chain for the one-channel-per-wave kernels: a workgroup's 16 waves hold 8 frames of a pair or 16 of a single
-         * channel; a later run takes its predecessor's tail through rendezvous cell link_in (no recomputed frame) */
-        if (!oc.is_cce) {
-            const size_t cap8 = oc.n_ch == 2 ? AACG_RUN_W / 2 : AACG_RUN_W;
-            int32_t link = -1;
-            for (size_t pos = 0; pos < n; pos += cap8) {
-                aacg_run8 r;
-                std::memset(&r, 0, sizeof r);
-                r.n_units = (int32_t)std::min<size_t>(cap8, n - pos);
-                r.n_ch = oc.n_ch;
-                for (int k = 0; k < AACG_RUN_W; k++) r.unit[k] = k < r.n_units ? oc.units[pos + k] : -1;
-                for (int c = 0; c < 2; c++) {
-                    const uint32_t chn = ch.channel + (c < oc.n_ch ? c : 0);
-                    r.ov_a[c] = aacg_ov_offset(max_channels, ch.stream, chn, ch.parity[c]);
-                    r.ov_b[c] = aacg_ov_offset(max_channels, ch.stream, chn, ch.parity[c] ^ 1);
-                }
-                r.link_in = link;
-                const bool more = pos + cap8 < n;
-                link = more ? (int32_t)out->n_links++ : -1;
-                r.link_out = link;
-                r.succ_unit = more ? oc.units[pos + cap8] : -1;
-                gen8.push_back(r);
             }
         }
     }
@@ -497,16 +472,10 @@ int aacg_plan_build(const aacg_unit_desc* units, uint32_t n_units, int sample_in
         const size_t cnt = (R - 1 - x) / 8 + 1;
         for (size_t s = 0; s < cnt; s++) out->runs[s * 8 + x] = gen[i++];
     }
-    /* the same dealing for the 8-wave runs: a chain's consecutive runs 8 blocks apart in ascending order — the side that
-     * publishes and the side that reads a rendezvous payload then share an L2 (speed only: the rendezvous assumes no order) */
-    const size_t R8 = gen8.size();
-    out->runs8.resize(R8);
-    i = 0;
-    for (size_t x = 0; x < 8 && x < R8; x++) {
-        const size_t cnt = (R8 - 1 - x) / 8 + 1;
-        for (size_t s = 0; s < cnt; s++) out->runs8[s * 8 + x] = gen8[i++];
-    }
-    if (long_chain) {
+    /* the rendezvous cut of the same chains (every run 16 frames, links between consecutive runs): the route of plain batches
+     * with a chain longer than a run, and of every plain batch launched through aacg_decode_pipelined */
+    out->long_chains = long_chain;
+    {
         const size_t RR = gen_rv.size();
         out->runs_rv.resize(RR);
         out->links_rv.resize(RR);
@@ -515,7 +484,7 @@ int aacg_plan_build(const aacg_unit_desc* units, uint32_t n_units, int sample_in
             const size_t cnt = (RR - 1 - x) / 8 + 1;
             for (size_t s = 0; s < cnt; s++) { out->runs_rv[s * 8 + x] = gen_rv[i]; out->links_rv[s * 8 + x] = gen_rv_links[i]; i++; }
         }
-    } else out->n_links_rv = 0;
+    }
     out->cce_runs = cce_gen;
     /* chain.first_run refers to generation order; the engine only needs counts, keep as is */
     return AACG_OK;

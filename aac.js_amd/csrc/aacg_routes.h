@@ -1,0 +1,67 @@
+/*
+ * aacg_routes.h — the run kernels as a registry, and the ONE decision which of them a plan takes.
+ *
+ * imdct_run_body (aacg_kernels.h) is instantiated per variant in translation units of their own (each its own code object, so
+ * that adding to one never moves another's code); every such unit exports a table of {switches, symbol, host stub}.  The
+ * engine turns a plan into a route — the staging launches in front, the run kernel by its switches, the launches behind —
+ * in one function (aacg_pick_route, aacg_engine.hip): launch_run executes that descriptor, aacg_plan_kernels prints it.
+ * Reference for what every route computes: src/decoder.js:218-248 + src/filter_bank.js:88-204.
+ */
+#ifndef AACG_ROUTES_H
+#define AACG_ROUTES_H
+
+#include "aacg_device.h"
+
+/* template switches of imdct_run_body = key of a run kernel */
+enum {
+    AACG_RK_QUANT = 1,      /* KIND = AACG_INPUT_QUANT_I16 (else f32 spectra) */
+    AACG_RK_I16   = 2,      /* OUT = AACG_OUTPUT_I16 */
+    AACG_RK_DD    = 4,      /* double duty: the first wave of a full later run recomputes the frame before it */
+    AACG_RK_EX    = 8,      /* the optional stages (AACG_TNS_SPEC, AACG_PNS_SPEC) inside the run */
+    AACG_RK_CPL   = 16,     /* independent coupling applied where the target's PCM is formed */
+    AACG_RK_RV    = 32,     /* rendezvous cells between the runs of a chain (and, pipelined, between launches); takes aacg_rv_args */
+    AACG_RK_NT    = 64      /* non-temporal loads of the spectra: batches of multichannel frames */
+};
+
+struct aacg_run_kernel {
+    unsigned    key;        /* AACG_RK_* */
+    const char* name;       /* the symbol a rocprofv3 kernel trace shows */
+    const void* fn;         /* host stub, for hipLaunchKernel */
+};
+
+/* one table per translation unit */
+extern const aacg_run_kernel aacg_run_kernels_plain[];  extern const int aacg_run_kernels_plain_n;    /* aacg_engine.hip */
+extern const aacg_run_kernel aacg_run_kernels_rv[];     extern const int aacg_run_kernels_rv_n;       /* aacg_engine_rv.hip */
+extern const aacg_run_kernel aacg_run_kernels_nt[];     extern const int aacg_run_kernels_nt_n;       /* aacg_engine_nt.hip */
+extern const aacg_run_kernel aacg_run_kernels_ext[];    extern const int aacg_run_kernels_ext_n;      /* aacg_engine_ext.hip */
+extern const aacg_run_kernel aacg_run_kernels_i16[];    extern const int aacg_run_kernels_i16_n;      /* aacg_engine_i16.hip */
+extern const aacg_run_kernel aacg_run_kernels_exrun[];  extern const int aacg_run_kernels_exrun_n;    /* aacg_engine_exrun.hip */
+extern const aacg_run_kernel aacg_run_kernels_couple[]; extern const int aacg_run_kernels_couple_n;   /* aacg_engine_couple.hip */
+
+/* what launch_run does for a plan: the single statement of the route */
+enum { AACG_STAGE_NONE = 0, AACG_STAGE_SPECTRAL_EX = 1, AACG_STAGE_DEPENDENT_COUPLING = 2 };
+struct aacg_route {
+    int      stage;                   /* launches in front of the run kernel that leave f32 spectra in HBM (AACG_STAGE_*) */
+    bool     stage_quant;             /* ... from quantised input */
+    bool     has_run;                 /* the plan has main runs */
+    unsigned run_key;                 /* ... launched with this kernel (AACG_RK_*) */
+    bool     rv;                      /* it walks the rendezvous cut of the chains (runs_rv / links_rv) */
+    bool     has_side;                /* independently switched coupling elements: their own filterbank pass into the side buffer */
+    unsigned side_key;
+    bool     side_first;              /* ... in front of the run kernel (fused coupling) instead of behind it */
+    bool     couple_pcm;              /* aacg_couple_pcm over the finished PCM behind everything (coupling not fused) */
+    bool     overlappable;            /* consecutive launches of the plan may overlap (aacg_decode_pipelined): rendezvous kernels, no staging */
+};
+
+#ifdef AACG_HOST_H
+/* aacg_routes.cpp (plain C++, shared with the lane emulator of tests/emu).
+ * aacg_pick_route: flags of the engine and of the planned batch -> the route.  `pipelined`: the launch comes through
+ * aacg_decode_pipelined; `tracing`: a -DAACG_PROFILE build with per-wave time stamps (keeps the plain kernels). */
+aacg_route aacg_pick_route(int input_kind, int output_kind, int debug_route, bool tracing, const aacg_plan_host& h, bool pipelined);
+/* the symbol of the run kernel with these switches: "aacg_imdct_run_" quant|f32 [_ex][_dd][_cpl][_rv][_i16][_nt] */
+std::string aacg_run_kernel_name(unsigned key);
+/* the launches of a route by kernel name, " + " between them: what a rocprofv3 kernel trace of the batch shows */
+std::string aacg_route_names(const aacg_route& r, bool any_tns);
+#endif
+
+#endif

@@ -160,22 +160,6 @@ int aacg_build_tables(int sample_index, aacg_tables* t, aacg_host_windows* hw)
     return AACG_OK;
 }
 
-/* The windows as the 8-wave kernels' epilogue reads them (aacg_win8): per (sequence class, shape) one 1024-entry table for
- * the first half of a long-type frame and one for its second half, START / STOP composed here (filter_bank.js:129-139,185-195). */
-void aacg_build_win8(const aacg_tables* t, aacg_win8* w)
-{
-    std::memset(w, 0, sizeof *w);
-    for (int sh = 0; sh < 2; sh++) {
-        for (int n = 0; n < 1024; n++) {
-            w->head[sh][n] = t->win_long[sh][n];
-            w->tail[sh][n] = t->win_long[sh][1023 - n];
-            w->head[2 + sh][n] = n < 448 ? 0.0f : (n < 576 ? t->win_short[sh][n - 448] : AACG_PCM_SCALE);
-            w->tail[2 + sh][n] = n < 448 ? AACG_PCM_SCALE : (n < 576 ? t->win_short[sh][575 - n] : 0.0f);
-        }
-        for (int i = 0; i < 128; i++) w->shrt[sh][i] = t->win_short[sh][i];
-    }
-}
-
 /* AACG_PNS_SPEC: the generator's sequence, the running sum of its squares, the band offsets (ics.js:228-243). */
 int aacg_build_pns_tables(int sample_index, aacg_pns_tables* t)
 {

@@ -205,7 +205,7 @@ DP_DEVICE int dp_pk_add_u16(int a, int b)
 DP_DEVICE float dp_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 DP_DEVICE double dp_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
 DP_DEVICE dpv2 dp_fma2(dpv2 a, dpv2 b, dpv2 c) { return __builtin_elementwise_fma(a, b, c); }
-/* ---- one complex value per register pair: (re, im) as a dpv2, every operation one v_pk_*_f32 (aacg_kernels8.h) ---- */
+/* ---- one complex value per register pair: (re, im) as a dpv2, every operation one v_pk_*_f32 ---- */
 DP_DEVICE dpv2 dp_cswap(dpv2 a) { return __builtin_shufflevector(a, a, 1, 0); }
 /* a + i b and a - i b: the swap is the instruction's op_sel, the signs a constant pair — one v_pk_fma_f32, exact in the
  * product (x 1 / x -1), rounded once like the addition it stands for */
@@ -231,7 +231,7 @@ DP_DEVICE void dp_flag_wait_ge(int* flag, int v)
     }
 }
 
-/* ---- workgroup -> workgroup through global memory (the run-to-run rendezvous of aacg_kernels8.h) ---------------------
+/* ---- workgroup -> workgroup through global memory (the rendezvous cells of the _rv run kernels) ---------------------
  * MI355X_MICROARCH.md, inter-workgroup visibility: payload as agent-scope (sc1, write-through) 8-byte stores, drained with
  * s_waitcnt vmcnt(0) BEFORE the state word changes; the reader takes the state word with an agent-scope load and the
  * payload with agent-scope (sc1) loads, which bypass its CU's L1.  No fences (an agent-scope release is a write-back of the
@@ -255,6 +255,9 @@ DP_DEVICE float dp_g_load_f1(const float* p)
 {
     return __builtin_bit_cast(float, __hip_atomic_load((const unsigned*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }
+DP_DEVICE void dp_g_store_u64(dp_u64* p, dp_u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+DP_DEVICE unsigned dp_g_load_u32(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+DP_DEVICE void dp_g_store_u32(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 DP_DEVICE void dp_vm_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 /* lane 0's value in every lane (a 64-bit scalar) */
 DP_DEVICE dp_u64 dp_first_u64(dp_u64 v)

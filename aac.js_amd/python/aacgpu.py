@@ -25,9 +25,18 @@ ABI_SYMBOLS = ["aacg_create", "aacg_destroy", "aacg_last_error", "aacg_abi_versi
                "aacg_host_alloc", "aacg_host_free", "aacg_plan_create", "aacg_plan_destroy",
                "aacg_decode_device", "aacg_spectral_device", "aacg_synchronize", "aacg_get_table", "aacg_kernel_name",
                "aacg_parser_create", "aacg_parser_destroy", "aacg_parser_last_error", "aacg_parse_status_string",
-               "aacg_parse_batch", "aacg_parse_device", "aacg_parse_kernel_name", "aacg_plan_refresh_from_parse", "aacg_standard_codebooks", "aacg_debug_transform",
-               "aacg_decode_batch_ex", "aacg_submit_ex", "aacg_plan_create_ex", "aacg_plan_kernels", "aacg_calib_copy", "aacg_plan_refresh_units", "aacg_debug_set_route",
-               "aacg_timer_create", "aacg_timer_record", "aacg_timer_elapsed_ms", "aacg_timer_destroy"]
+               "aacg_parse_batch", "aacg_parse_device", "aacg_parse_kernel_name", "aacg_plan_refresh_from_parse", "aacg_standard_codebooks",
+               "aacg_decode_batch_ex", "aacg_submit_ex", "aacg_plan_create_ex", "aacg_plan_kernels", "aacg_plan_kernels_ex", "aacg_plan_refresh_units",
+               "aacg_decode_pipelined", "aacg_pipeline_fork", "aacg_pipeline_join"]
+# ... and include/aacgpu_tools.h (measurement and diagnostics: bench.py, tools/, tests)
+TOOLS_SYMBOLS = ["aacg_calib_copy", "aacg_timer_create", "aacg_timer_record", "aacg_timer_elapsed_ms", "aacg_timer_destroy",
+                 "aacg_pipeline_chained", "aacg_debug_transform", "aacg_debug_set_route", "aacg_debug_route", "aacg_debug_run_kernel"]
+# aacg_debug_set_route / aacg_debug_route flags
+DEBUG_ROUTE_UNFUSED_COUPLING, DEBUG_ROUTE_RECOMPUTE = 1, 8
+ROUTE_PLAN_TNS, ROUTE_PLAN_PNS, ROUTE_PLAN_LONG_CHAINS, ROUTE_PLAN_FULL_LATER_RUNS = 1, 2, 4, 8
+ROUTE_PLAN_WIDE_FRAMES, ROUTE_PLAN_CCE_INDEPENDENT, ROUTE_PLAN_CCE_DEPENDENT, ROUTE_PLAN_NO_RUNS = 0x10, 0x20, 0x40, 0x80
+# switches of a run kernel (aacg_routes.h), as aacg_debug_run_kernel returns them
+RK_QUANT, RK_I16, RK_DD, RK_EX, RK_CPL, RK_RV, RK_NT = 1, 2, 4, 8, 16, 32, 64
 
 UNIT_DTYPE = np.dtype([
     ("stream", "<u4"), ("pcm_offset", "<u4"), ("channel", "<u2"), ("n_out_ch", "<u2"),
@@ -110,6 +119,14 @@ def load_library(path=LIB_PATH):
     L.aacg_abi_version.restype = C.c_int
     L.aacg_kernel_name.restype = C.c_char_p
     L.aacg_plan_kernels.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.c_size_t]
+    L.aacg_plan_kernels_ex.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_char_p, C.c_size_t]
+    L.aacg_decode_pipelined.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.aacg_pipeline_fork.argtypes = [C.c_void_p, C.c_void_p]
+    L.aacg_pipeline_join.argtypes = [C.c_void_p, C.c_void_p]
+    L.aacg_pipeline_chained.argtypes = [C.c_void_p]
+    L.aacg_pipeline_chained.restype = C.c_uint64
+    L.aacg_debug_route.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_size_t]
+    L.aacg_debug_run_kernel.argtypes = [C.c_int, C.c_char_p, C.c_size_t]
     L.aacg_plan_refresh_units.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
     L.aacg_calib_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     L.aacg_timer_create.argtypes = [C.POINTER(C.c_void_p)]
@@ -221,6 +238,28 @@ class TimerMark:
                 self.h = C.c_void_p()
         except Exception:
             pass
+
+def debug_route(input_kind, output_kind, plan_flags, pipelined=False, debug_flags=0):
+    """aacg_debug_route: the launches (kernel names, ' + ' between them) the engine's ONE route decision makes for a planned batch
+    with these flags (ROUTE_PLAN_*) on an engine of these kinds.  No device needed."""
+    buf = C.create_string_buffer(512)
+    rc = load_library().aacg_debug_route(input_kind, output_kind, debug_flags, plan_flags, 1 if pipelined else 0, buf, 512)
+    if rc:
+        raise AacgError(rc, "aacg_debug_route: no registered kernel for this route")
+    return buf.value.decode()
+
+
+def run_kernels():
+    """The registered run kernels as {symbol: switches} (aacg_debug_run_kernel)."""
+    out, i = {}, 0
+    buf = C.create_string_buffer(128)
+    while True:
+        key = load_library().aacg_debug_run_kernel(i, buf, 128)
+        if key < 0:
+            return out
+        out[buf.value.decode()] = key
+        i += 1
+
 
 def calib_copy(d_dst, d_src, n_bytes, stream=0):
     """aacg_calib_copy: float4 device-to-device copy with the run kernels' launch shape, enqueued on `stream`."""
@@ -445,6 +484,23 @@ class Engine:
         """d_* are raw device addresses (e.g. torch.Tensor.data_ptr()); stream a hipStream_t handle or 0."""
         self._check(self.lib.aacg_decode_device(self.handle, plan.handle, d_coeffs, d_meta, d_pcm, stream))
 
+    def decode_pipelined(self, plan, d_coeffs, d_meta, d_pcm):
+        """aacg_decode_pipelined: the next launch of `plan` on the engine's two internal streams taken in turn; it may overlap the
+        launch before it (their chains meet in rendezvous cells).  Results: after pipeline_join / synchronize."""
+        self._check(self.lib.aacg_decode_pipelined(self.handle, plan.handle, d_coeffs, d_meta, d_pcm))
+
+    def pipeline_fork(self, stream):
+        """The pipeline's later launches start after everything enqueued on `stream` so far."""
+        self._check(self.lib.aacg_pipeline_fork(self.handle, stream))
+
+    def pipeline_join(self, stream=0):
+        """Work enqueued on `stream` from now on starts after the pipeline's launches so far; 0: the host waits for them."""
+        self._check(self.lib.aacg_pipeline_join(self.handle, stream or None))
+
+    def pipeline_chained(self):
+        """Launches of decode_pipelined that continued (and were allowed to overlap) the launch before them."""
+        return int(self.lib.aacg_pipeline_chained(self.handle))
+
     def plan_refresh_from_parse(self, plan, d_parsed_units, d_results, max_units, d_refused, stream=0):
         """Device pointers: the plan's unit records take what aacg_parse_device wrote (run tables unchanged)."""
         self._check(self.lib.aacg_plan_refresh_from_parse(self.handle, plan.handle, d_parsed_units, d_results, max_units, d_refused, stream))
@@ -488,8 +544,8 @@ class Engine:
         """Diagnostic route choices for parity tests (aacg_debug_set_route): 1 = independent coupling as the separate pass."""
         self._check(self.lib.aacg_debug_set_route(self.handle, flags))
 
-    def plan_kernels(self, plan):
-        """The launches aacg_decode_device makes for this plan, by kernel name (what a rocprofv3 kernel trace shows)."""
+    def plan_kernels(self, plan, pipelined=False):
+        """The launches aacg_decode_device (pipelined: aacg_decode_pipelined) makes for this plan, by kernel name (what a rocprofv3 kernel trace shows)."""
         buf = C.create_string_buffer(512)
-        self._check(self.lib.aacg_plan_kernels(self.handle, plan.handle, buf, 512))
+        self._check(self.lib.aacg_plan_kernels_ex(self.handle, plan.handle, 1 if pipelined else 0, buf, 512))
         return buf.value.decode()

@@ -10,9 +10,15 @@ buffer sets so that no step is served from the 256 MiB Infinity Cache.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--input quant|spec] [--workload cfg2|cfg3|cfg4|cfg5] [--tns reference|spec]
 
+Launches: consecutive steps go through aacg_decode_pipelined — the engine's two internal HIP streams taken in turn, so that
+step k + 1 starts on the compute units step k has already left; the chains of the two launches meet in rendezvous cells
+(include/aacgpu.h; --serial: aacg_decode_device on one stream, every launch behind the one before it, the method of rounds
+1-4).  ONE plan, ONE set of 256 streams continued launch after launch either way (`config.pipelines` 1).
+
 Timing: W untimed warm-up steps, then the timed region of exactly K steps — R times back to back (--repeats, default 25),
-every repeat bracketed by its own HIP events on the launch stream, the whole set between barrier + synchronize on both
-sides.  `ms_per_step` = MEDIAN over the R repeats of (MAX over ranks of the repeat's event time) / K (SURVEY.md 8d asks
+every repeat bracketed by its own HIP events on the timing stream, which the engine joins behind the pipeline's launches in
+front of every mark (aacg_pipeline_join: a mark's time stamp is the completion of the launches before it), the whole set
+between barrier + synchronize on both sides.  `ms_per_step` = MEDIAN over the R repeats of (MAX over ranks of the repeat's event time) / K (SURVEY.md 8d asks
 for a median; one 0.25 ms window says nothing about its own spread), `timing` carries min / max / first / R, and
 `value` = frames of all ranks per step / that median.  The host's clock between the barriers is reported beside it
 (`wall_ms_per_step`, `value_wall`: adds the launch latency of the first step and the wake-up after the last one).
@@ -84,10 +90,11 @@ def algorithmic_bytes_per_channel_frame(kind, chain_frames, pcm="f32"):
     return (4096 if kind == "spec" else 2048 + 240) + (2048 if pcm == "i16" else 4096) + 8192.0 / chain_frames
 
 
-def measured_traffic(kind, kernel=""):
+def measured_traffic(kernel):
     """HBM bytes per launch from the PMC counters (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, separate rocprofv3
     --pmc passes of this same command, tools/prof.sh); bench.py cannot run the profiler on itself, so the
-    committed summary of the latest round under profiles/ is quoted.  None if there is none."""
+    committed summary of the latest round under profiles/ is quoted — for the kernel that was PROFILED there and no
+    other: None unless this run's kernel is that one."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
     if not files:
@@ -95,13 +102,15 @@ def measured_traffic(kind, kernel=""):
     try:
         with open(files[-1]) as f:
             d = json.load(f)
-        key = kind + ("_run8" if "run8" in kernel else "")     # the one-channel-per-wave kernels move their rendezvous payloads too
-        return float(d[key]["traffic_bytes"]), os.path.relpath(files[-1], ROOT)
+        for rec in d.values():
+            if isinstance(rec, dict) and rec.get("kernel") == kernel and rec.get("workload", "cfg2") == "cfg2":
+                return float(rec["traffic_bytes"]), os.path.relpath(files[-1], ROOT)
     except (KeyError, ValueError, OSError):
-        return None, None
+        pass
+    return None, None
 
 
-def cpu_baseline(kind, mix, layout, n_chan, budget_s=10.0):
+def cpu_baseline(kind, mix, layout, n_chan, budget_s=10.0, all_cores=True):
     """The oracle (plain C restatement of the reference algorithm, bit-exact with aac.js) on the host cores, on a
     bounded sample of the same workload: batches of 4 streams x 16 frames for ~budget_s on ONE core, then one such
     stream set per thread on ALL the cores this process may use for ~budget_s / 2 (oracle/orc_bench.c)."""
@@ -119,12 +128,17 @@ def cpu_baseline(kind, mix, layout, n_chan, budget_s=10.0):
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     per_batch = wl["n_frames_total"]
     n1, dt1 = o.bench_threads(1, budget_s, wl["units"], coeffs, meta, wl["n_pcm"], 4, n_chan)
-    nall, dtall = o.bench_threads(cores, budget_s / 2, wl["units"], coeffs, meta, wl["n_pcm"], 4, n_chan)
     what = "4 streams x 16-frame batches, same generator as the GPU workload; oracle/aac_oracle.c, gcc -O2 -ffp-contract=off"
+    single = {"value": n1 * per_batch / dt1, "unit": "frames/s", "cores": 1,
+              "sample": "%d frames in %.1f s on 1 thread; %s" % (n1 * per_batch, dt1, what)}
+    if not all_cores:
+        # N > 1: the other ranks' host threads are parked in the closing barrier on the same cores: one thread only, said so
+        return dict(single, kind="port", single_core=dict(single),
+                    note="rank 0 of a multi-GPU run: one host thread (the all-cores figure is taken at N = 1, where no other rank shares the host)")
+    nall, dtall = o.bench_threads(cores, budget_s / 2, wl["units"], coeffs, meta, wl["n_pcm"], 4, n_chan)
     out = {"value": nall * per_batch / dtall, "unit": "frames/s", "cores": cores, "kind": "port",
            "sample": "%d frames in %.1f s on %d threads (one stream set each) of %d host cores; %s" % (nall * per_batch, dtall, cores, os.cpu_count(), what),
-           "single_core": {"value": n1 * per_batch / dt1, "unit": "frames/s", "cores": 1,
-                           "sample": "%d frames in %.1f s on 1 thread; %s" % (n1 * per_batch, dt1, what)}}
+           "single_core": single}
     # the same path as plain JavaScript under Node, the stand-in for "aac.js's own Node path" (the reference cannot
     # travel to the GPU box); in the build container the real aac.js ran process()+interleave at 0.55x this port's rate
     # 
@@ -191,13 +205,19 @@ def main():
     ap.add_argument("--default-events", action="store_true",
                     help="time with torch.cuda.Event (default HIP events: a system-scope fence per record) instead of timing-only events")
     ap.add_argument("--strict-backend", action="store_true",
-                    help="exit non-zero if --dist-backend nccl was asked for and RCCL could not be initialised (default: fall back to gloo and say so "
-                         "in the line's top-level collectives_backend_fallback)")
+                    help="exit non-zero if the backend asked for (--dist-backend, default nccl = RCCL) could not be initialised.  This IS the default "
+                         "under torch.distributed.run (the driver's launch line): a gloo fallback there is an error, not a field")
+    ap.add_argument("--allow-backend-fallback", action="store_true",
+                    help="under torch.distributed.run: fall back to gloo if RCCL cannot be initialised and say so in the line's top-level "
+                         "collectives_backend_fallback (tests on boxes without enough GPUs)")
     ap.add_argument("--nbuf", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the untimed oracle comparison after the timed region")
     ap.add_argument("--pipelines", type=int, default=1, choices=[1, 2],
-                    help="2: alternate batches of two disjoint stream sets on two HIP streams (supplementary figure)")
+                    help="2: alternate batches of two disjoint stream sets on two HIP streams (supplementary figure; implies --serial)")
+    ap.add_argument("--serial", action="store_true",
+                    help="launch through aacg_decode_device on one HIP stream, every launch behind the one before it (rounds 1-4) instead "
+                         "of aacg_decode_pipelined")
     ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
                     help="collective backend of the harness (barrier + MAX only); gloo for ranks that share a GPU")
     ap.add_argument("--share-gpu", action="store_true",
@@ -235,7 +255,7 @@ def main():
     dist = None
     if aacgpu_shard.launched_by_torchrun():            # RCCL (or gloo) for barrier / max only
         dist = aacgpu_shard.init_process_group(args.dist_backend, device=torch.device("cuda", device))
-        if args.strict_backend and dist.get_backend() != args.dist_backend:
+        if (args.strict_backend or not args.allow_backend_fallback) and dist.get_backend() != args.dist_backend:
             raise SystemExit("bench.py: --dist-backend %s asked for, %s answered (--strict-backend)" % (args.dist_backend, dist.get_backend()))
 
     # cfg2 (the metric's configuration) / cfg3: 256 streams x 16 frames; cfg4: 32 streams x 128 frames per GPU
@@ -284,10 +304,21 @@ def main():
     tstreams = [tstream] + [torch.cuda.Stream() for _ in range(args.pipelines - 1)]
     meta_ptr = d_meta.data_ptr() if d_meta is not None else None
 
+    pipelined = not args.serial and args.pipelines == 1
+
     def step(i):
         d_in, d_out = bufs[i % args.nbuf]
+        if pipelined:                                  # the engine's two internal streams in turn: launch i may overlap launch i - 1
+            eng.decode_pipelined(plans[0], d_in.data_ptr(), meta_ptr, d_out.data_ptr())
+            return
         pl = i % args.pipelines
         eng.decode_device(plans[pl], d_in.data_ptr(), meta_ptr, d_out.data_ptr(), tstreams[pl].cuda_stream)
+
+    def join():                                        # the timing stream behind everything launched so far
+        if pipelined:
+            eng.pipeline_join(tstream.cuda_stream)
+        for extra in tstreams[1:]:
+            tstream.wait_stream(extra)
 
     # The GPU reaches its steady clocks only after tens of milliseconds of load: a 4096-frame step takes ~13 us,
     # so a few hundred warm-up steps are over before the clocks have ramped (measured: 15.9 us per step after 40
@@ -320,12 +351,12 @@ def main():
 
     def timed_steps():
         t0 = time.perf_counter()
+        join()                                           # the opening mark: the warm-up steps are complete
         evs[0].record()
         for r in range(R):
             for i in range(args.steps):
                 step(n_pre + args.warmup + r * args.steps + i)
-            for extra in tstreams[1:]:
-                tstream.wait_stream(extra)                # the closing event sees every pipeline
+            join()                                       # a mark's time stamp is the completion of every launch before it
             evs[r + 1].record()
         issued[0] = time.perf_counter() - t0             # host time to enqueue the R x K launches
 
@@ -382,7 +413,8 @@ def main():
     if cce is not None:
         abytes += (2048 + 240) * frames_per_step             # the coupling element's own spectrum and band words in, nothing extra out
     achieved = abytes / (kernel_ms * 1e-3) / 1e9
-    traffic, traffic_src = measured_traffic(args.input, eng.plan_kernels(plans[0])) if args.workload == "cfg2" else (None, None)
+    kernel_names = eng.plan_kernels(plans[0], pipelined=pipelined)
+    traffic, traffic_src = measured_traffic(kernel_names) if args.workload == "cfg2" else (None, None)
     unit = "stereo frames/s" if n_chan == 2 else "7-channel frames/s"
     line = {
         "metric": "AAC-LC 48 kHz stereo frames/sec per node + achieved HBM GB/s vs roofline",
@@ -405,6 +437,10 @@ def main():
                    "output": "float32 PCM as the reference returns it" if args.output == "f32" else "int16 PCM (AACG_OUTPUT_I16)",
                    "streams_per_gpu": n_streams, "frames_per_stream_per_step": n_frames, "buffers_rotated": args.nbuf,
                    "realtime_multiple": value / 46.875, "sharding": "streams over ranks, no data-path collective", "pipelines": args.pipelines,
+                   "launches": ("aacg_decode_pipelined: ONE plan, the same %d streams continued launch after launch on the engine's two internal HIP "
+                                "streams taken in turn; consecutive launches overlap, their chains meet in rendezvous cells (nobody waits); %d of the %d "
+                                "launches of this process continued the launch before them" % (n_streams, eng.pipeline_chained(), n_pre + args.warmup + R * args.steps + (0 if args.no_parity else 1)))
+                               if pipelined else "aacg_decode_device: every launch behind the one before it on one HIP stream",
                    "preconditioning": "%d untimed steps (%.0f ms of load) before the warm-up steps: steady GPU clocks" % (n_pre, args.precondition_ms),
                    "tns": "identity, as the reference executes it" if tns is None
                           else "AACG_TNS_SPEC, every channel-frame: long one filter of order 12 over 20 bands, short one of order 7 per window",
@@ -413,20 +449,25 @@ def main():
                    "collectives": "none on the data path; %s" % (("%s barrier + 8-byte MAX around the timed region, world size %d as the backend reports it"
                                                                    % (dist.get_backend(), dist.get_world_size())) if dist is not None else "single process, no process group")},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "traffic_measured_in_run": False,
                      "copy_ceiling_GBs": copy_gbs, "frac_of_copy": achieved / copy_gbs, "copy_ms": copy_ms,
                      "copy_timing": copy_stats,
                      "copy_ceiling_note": "aacg_calib_copy: float4 copy of the step's algorithmic byte volume (half read, half written) with the run "
                                           "kernel's launch shape, %d x %d launches right behind the timed region on the same stream (median repeat); 1 GiB copy: %.0f GB/s" % (R, copy_reps, copy_large_gbs),
                      "copy_ceiling_large_GBs": copy_large_gbs,
-                     "kernel": eng.plan_kernels(plans[0]),
+                     "kernel": kernel_names,
                      "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": abytes,
+                     "kernel_ms_note": ("per-launch time of the timed region (K launches between two marks) — with overlapped launches the "
+                                        "START-TO-START interval of consecutive dispatches, which is what a rocprofv3 kernel trace shows as the "
+                                        "spacing of the rows (profiles/rNN_*_intervals.txt); one dispatch's own begin-to-end duration is longer, "
+                                        "two of them are in flight at a time") if pipelined else "per-launch time of the timed region = the dispatch duration a kernel trace shows",
                      "host_enqueue_us_per_step": issued[0] / (R * args.steps) * 1e6},
         "output_ok": ok, "parity_rms": parity["rms"] if parity else None, "parity": parity,
     }
     line.update(backend_fields(args.dist_backend, dist))
-    if rank == 0 and not args.no_cpu_baseline and world == 1:
-        line["cpu_baseline"] = cpu_baseline(args.input, mix, layout, n_chan)
+    if rank == 0 and not args.no_cpu_baseline:
+        # N = 1: all host cores, one core, and the JavaScript port; N > 1: one core (the field is never null on a line the driver records)
+        line["cpu_baseline"] = cpu_baseline(args.input, mix, layout, n_chan) if world == 1 else cpu_baseline(args.input, mix, layout, n_chan, budget_s=5.0, all_cores=False)
         line["cpu_baseline"]["unit"] = line["cpu_baseline"]["single_core"]["unit"] = unit
         if "js_port" in line["cpu_baseline"] and "unit" in line["cpu_baseline"]["js_port"]:
             line["cpu_baseline"]["js_port"]["unit"] = unit

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define AACG_ABI_VERSION 4
+#define AACG_ABI_VERSION 5
 
 #define AACG_FRAME_LEN      1024   /* decoder.js:86 frameLength                       */
 #define AACG_MAX_SECTIONS   120    /* ics.js:49 MAX_SECTIONS (bandTypes/scaleFactors) */
@@ -331,28 +331,45 @@ int aacg_decode_device(aacg_engine* e, aacg_plan* p,
 int aacg_spectral_device(aacg_engine* e, aacg_plan* p,
                          const void* d_coeffs, const aacg_band_meta* d_meta,
                          float* d_spec_out, void* hip_stream);
+/* Waits (on the host) for hip_stream — NULL: the engine's own stream — and for every launch aacg_decode_pipelined has in flight. */
 int aacg_synchronize(aacg_engine* e, void* hip_stream);
 
-/* ---- introspection used by bench/tests ------------------------------------------------ */
+/* ---- the hot path, device-resident, consecutive launches OVERLAPPED ------------------------------------------------
+ * aacg_decode_device puts every launch of a plan behind the one before it: the next batch's first frame needs the last
+ * frame's tail (filter_bank.js:38-41, the only state the path carries; filter_bank.js:105-118 is the hand-over).  But that
+ * dependency is per (stream, element) chain, not per launch: chain c of launch k + 1 needs chain c's tail of launch k and
+ * nothing else.  aacg_decode_pipelined launches on two engine-owned HIP streams taken in turn, so that launch k + 1 starts
+ * on the compute units launch k has already left; the two launches' chains meet in rendezvous cells in global memory —
+ * whichever side of a chain arrives first publishes what it has (launch k: the windowed tail = the new overlap state;
+ * launch k + 1: its windowed first half and where the finished samples go) and leaves, the second finishes the frame.
+ * Nobody waits for another workgroup, no dispatch order is assumed, and both arrival orders add the same two rounded
+ * numbers: the PCM is bit-identical to aacg_decode_device's.
+ *   - Plain batches (float PCM, no AACG_TNS_SPEC / AACG_PNS_SPEC stage, no coupling element) overlap; every other plan
+ *     is accepted and runs behind the launch before it, as aacg_decode_device would run it.
+ *   - Inputs must be complete when the call is made, or be produced on a stream the pipeline has been forked from
+ *     (aacg_pipeline_fork) since; outputs are complete for work on hip_stream after aacg_pipeline_join(e, hip_stream) and
+ *     for the host after aacg_pipeline_join(e, NULL) / aacg_synchronize.
+ *   - Launches through other entry points (aacg_decode_device, aacg_submit*, another plan) are ordered behind the
+ *     pipeline's by the engine; mixing costs the overlap, never the result.
+ * Replaces: one `readChunk()` worth of process() + interleave (decoder.js:201-215) per stream and frame, batch after batch. */
+int aacg_decode_pipelined(aacg_engine* e, aacg_plan* p, const void* d_coeffs, const aacg_band_meta* d_meta, void* d_pcm);
+/* the pipeline's later launches start after everything enqueued on hip_stream so far (inputs produced there) */
+int aacg_pipeline_fork(aacg_engine* e, void* hip_stream);
+/* work enqueued on hip_stream from now on starts after the pipeline's launches so far; NULL: the host waits for them */
+int aacg_pipeline_join(aacg_engine* e, void* hip_stream);
+
+/* ---- introspection ---------------------------------------------------------------------------------------------- */
 /* Copies the engine's host-built tables (what the device kernels read) for table KATs.
  * which: 0 IQ[8191], 1 SF[428], 2 sine1024, 3 kbd1024, 4 sine128, 5 kbd128               */
 int aacg_get_table(aacg_engine* e, int which, float* dst, size_t n);
 /* Name of the dominant kernel of the headline route (for matching rocprofv3 rows).      */
 const char* aacg_kernel_name(void);
-/* The launches aacg_decode_device makes for this plan, by kernel name, " + " between them (dst: n bytes). */
+/* The launches aacg_decode_device makes for this plan, by kernel name, " + " between them (dst: n bytes);
+ * _ex with pipelined != 0: the launches aacg_decode_pipelined makes. */
 int aacg_plan_kernels(aacg_engine* e, const aacg_plan* p, char* dst, size_t n);
-/* Calibration for the bench: a float4 copy of `bytes` (multiple of 16) device to device with the run kernels' launch
- * shape, enqueued on hip_stream.  Gives the copy rate of THIS box for a launch of that size, next to the run kernel. */
-int aacg_calib_copy(void* d_dst, const void* d_src, size_t bytes, void* hip_stream);
-/* Timing marks for the bench: HIP events created with hipEventDisableSystemFence — HIP's flag for events that only measure
- * time.  A default event performs a system-scope fence when it is recorded (cache write-back and invalidation), which a
- * region of twenty 12-us launches between two events pays for (the launch behind a mark starts on cold caches); these do
- * not.  They order nothing for the host: the caller synchronises the stream before asking for the elapsed time.          */
-int aacg_timer_create(void** mark);
-int aacg_timer_record(void* mark, void* hip_stream);
-int aacg_timer_elapsed_ms(void* first, void* second, float* ms);
-void aacg_timer_destroy(void* mark);
-
+int aacg_plan_kernels_ex(aacg_engine* e, const aacg_plan* p, int pipelined, char* dst, size_t n);
+/* (measurement and diagnostic entry points — timing marks, the copy calibration, stage-by-stage transforms, hand-made route
+ * choices — are declared in aacgpu_tools.h: same library, nothing a host needs) */
 
 /* ---- the bitstream front end on the device (optional; independent of aacg_engine) ---------------
  * One GPU lane parses one frame: what aac.js does serially per frame between `stream.peek(12)` and
@@ -476,31 +493,6 @@ int aacg_plan_refresh_from_parse(aacg_engine* e, aacg_plan* p, const aacg_unit_d
  * changed then: build a new plan); plans with TNS records, noise bands or coupling elements are built per batch
  * (AACG_ERR_UNSUPPORTED).  Replaces decoder.js:138-198's per-frame `new ICStream` bookkeeping for a whole batch. */
 int aacg_plan_refresh_units(aacg_engine* e, aacg_plan* p, const aacg_unit_desc* units, uint32_t n_units, void* hip_stream);
-
-/* Diagnostic: the IMDCT stage of the kernels on its own, for known-answer tests against the reference's MDCT.process
- * (mdct.js:62-115) and FFT.process (fft.js:105-192) vectors.  One spectrum in (1024 floats: one long window, or eight
- * short ones), windows forced to 1.  Long: out[0..2047] = the 2048 IMDCT outputs.  Short: out[128 w + i] =
- * y_(w-1)[128 + i] + y_w[i] (i < 128), so a window whose neighbours are zero shows its 256 outputs.  identity_rotation:
- * the pre / post rotations (mdct.js:73-76, 82-87) are replaced by the identity, which leaves the N/4-point complex inverse
- * FFT of z[k] = X[N/2-1-2k] + i X[2k] in the output order of mdct.js:90-114.  is_short: bit 0 = eight short windows; bit 1 =
- * the int16 seam's variant of the stage (mirror-lane exchanges as DPP moves, long columns dealt out by long_col).  Nothing on the decode path calls this. */
-int aacg_debug_transform(int device_ordinal, int sample_index, int is_short, int identity_rotation, const float* in, float* out);
-
-/* Diagnostic: route choices a parity test wants to make by hand; 0 (the default) = the engine's own choice.  Nothing on the
- * decode path calls this.  AACG_DEBUG_ROUTE_UNFUSED_COUPLING: independent coupling (cce.js:121-128) as the separate pass over
- * the interleaved PCM (aacg_couple_pcm, what plans with double-duty runs take) even where the engine would apply it in the
- * targets' epilogues (aacg_imdct_run_*_cpl): the two routes must produce the same bits.
- * AACG_DEBUG_ROUTE_NARROW_KERNELS: plain batches (float PCM, no optional stage, no coupling element) on the one-channel-per-wave
- * kernels (aacg_kernels8.h: 8 waves per SIMD, run-to-run rendezvous) instead of the 16-wave kernels (a channel pair per wave,
- * aacg_kernels.h) the engine takes by default; AACG_DEBUG_ROUTE_WIDE_KERNELS: the 16-wave kernels even where the environment
- * (AACG_RUN8=1) asks for the others.  AACG_DEBUG_ROUTE_RECOMPUTE: chains longer than a run the old way — every later run recomputes
- * the frame before it (aacg_imdct_run_*_dd) — instead of the run-to-run rendezvous (aacg_imdct_run_*_rv) the engine takes for plain
- * batches; both must produce the same bits.  Set before the plan is made. */
-#define AACG_DEBUG_ROUTE_UNFUSED_COUPLING 1
-#define AACG_DEBUG_ROUTE_WIDE_KERNELS     2
-#define AACG_DEBUG_ROUTE_NARROW_KERNELS   4
-#define AACG_DEBUG_ROUTE_RECOMPUTE        8
-int aacg_debug_set_route(aacg_engine* e, int flags);
 
 #ifdef __cplusplus
 }

@@ -122,6 +122,9 @@ DP_DEVICE bool dp_g_cas_u64(dp_u64* p, dp_u64 expected, dp_u64 desired)
 DP_DEVICE void dp_g_store_f2(float* p, float a, float b) { p[0] = a; p[1] = b; }
 DP_DEVICE dpf2 dp_g_load_f2(const float* p) { dpf2 v; v.x = p[0]; v.y = p[1]; return v; }
 DP_DEVICE float dp_g_load_f1(const float* p) { return *p; }
+DP_DEVICE void dp_g_store_u64(dp_u64* p, dp_u64 v) { __atomic_store_n(p, v, __ATOMIC_RELAXED); }
+DP_DEVICE unsigned dp_g_load_u32(const unsigned* p) { return __atomic_load_n(p, __ATOMIC_RELAXED); }
+DP_DEVICE void dp_g_store_u32(unsigned* p, unsigned v) { __atomic_store_n(p, v, __ATOMIC_RELAXED); }
 DP_DEVICE void dp_vm_drain() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 /* lane 0's value in every lane */
 DP_DEVICE dp_u64 dp_first_u64(dp_u64 v)

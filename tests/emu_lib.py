@@ -10,11 +10,15 @@ import orc
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 RUN_DTYPE = np.dtype([("pred_unit", "<i4"), ("n_units", "<i4"), ("unit", "<i4", (16,)),
-                      ("ov_a", "<i4", (2,)), ("ov_b", "<i4", (2,)), ("is_last", "<i4"), ("reserved", "<i4")])
+                      ("ov0", "<i4", (2,)), ("rot", "<i4", (2,)), ("is_last", "<i4"), ("reserved", "<i4")])
 
 
-RUN8_DTYPE = np.dtype([("n_units", "<i4"), ("n_ch", "<i4"), ("unit", "<i4", (16,)), ("ov_a", "<i4", (2,)), ("ov_b", "<i4", (2,)),
-                       ("link_in", "<i4"), ("link_out", "<i4"), ("succ_unit", "<i4"), ("reserved", "<i4", (5,))])
+OV_BUFFERS = 3          # AACG_OV_BUFFERS: rotating overlap buffers per channel (aacg_device.h)
+
+
+def new_pool(streams, channels):
+    """An engine's overlap pool, zeroed: [stream][channel][OV_BUFFERS][1024], and the live-buffer index per (stream, channel)."""
+    return np.zeros((streams, channels, OV_BUFFERS, 1024), np.float32), np.zeros(streams * channels, np.uint8)
 
 
 class Emu:
@@ -33,14 +37,15 @@ class Emu:
         L.emu_spectral.argtypes = [C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         L.emu_plan.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
         L.emu_plan_refresh.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int]
-        L.emu_plan8.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_uint32, C.c_void_p]
+        L.emu_decode_pipelined.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_uint64, C.c_void_p]
         L.emu_get_windows.argtypes = [C.c_int, C.c_void_p]
         L.emu_get_iq_sf.argtypes = [C.c_void_p, C.c_void_p]
 
     def error(self):
         return self.lib.emu_last_error().decode()
 
-    def decode(self, units, coeffs, meta, n_pcm, pool, parity, sample_index=3, tns=None, pns=False, int16_out=False, cce=None, staged=False, unfused=False, run8=0, rv=1):
+    def decode(self, units, coeffs, meta, n_pcm, pool, parity, sample_index=3, tns=None, pns=False, int16_out=False, cce=None, staged=False, unfused=False, rv=1):
         """staged: the optional stages (TNS, PNS) as a launch of their own even where the engine would run them inside the run kernel.
         unfused: independent coupling as the separate pass over the PCM (what plans with double-duty runs take) even where the
         engine applies it in the targets' epilogues."""
@@ -54,7 +59,6 @@ class Emu:
         self.lib.emu_set_staged(1 if staged else 0)
         self.lib.emu_set_unfused(1 if unfused else 0)
         self.lib.emu_set_rv(rv)           # 1: chains longer than a run through the run-to-run rendezvous (the engine's route); 2: blocks in reverse; 0: recomputed frames
-        self.lib.emu_set_run8(run8)       # 0: the 16-wave kernels (the engine's default); 1: plain batches on the one-channel-per-wave kernels; 2: the same, workgroups in reverse order
         cce = np.ascontiguousarray(cce) if cce is not None else None
         rc = self.lib.emu_decode_cce(kind, sample_index, pool.shape[0], pool.shape[1], units.ctypes.data, len(units),
                                      coeffs.ctypes.data, meta.ctypes.data if meta is not None else None,
@@ -64,7 +68,6 @@ class Emu:
         self.lib.emu_set_output_kind(0)
         self.lib.emu_set_staged(0)
         self.lib.emu_set_unfused(0)
-        self.lib.emu_set_run8(0)
         self.lib.emu_set_rv(1)
         if rc:
             raise RuntimeError("emu_decode rc=%d: %s" % (rc, self.error()))
@@ -85,15 +88,26 @@ class Emu:
         assert len(first) == len(nxt)
         return self.lib.emu_plan_refresh(first.ctypes.data, nxt.ctypes.data, len(first), sample_index, max_streams, max_channels, 1 if tns_spec else 0)
 
-    def plan8(self, units, max_streams, max_channels, sample_index=3):
-        """The planner's run table for the one-channel-per-wave kernels: (runs as RUN8_DTYPE, number of rendezvous cells)."""
+    def decode_pipelined(self, units, coeffs_list, meta_list, n_pcm, pool, parity, cells, heads, order=0, epoch_in=0, sample_index=3):
+        """aacg_decode_pipelined for len(coeffs_list) consecutive launches of ONE plan, workgroup by workgroup in an order the
+        engine's rules allow (order: 0 launch after launch, 1 the later launch of every pair first, >= 2 random interleaving with
+        that seed).  cells: uint64 [S][C][OV_BUFFERS][4] (aacg_xl_cell), heads: like pool.  Returns (list of PCM arrays, epoch of the
+        last launch: pass it as epoch_in to continue the sequence with the last launch 'still in flight')."""
         units = np.ascontiguousarray(units)
-        runs = np.zeros(2 * len(units) + 8, RUN8_DTYPE)
-        links = C.c_int32(0)
-        n = self.lib.emu_plan8(units.ctypes.data, len(units), sample_index, max_streams, max_channels, runs.ctypes.data, len(runs), C.byref(links))
-        if n < 0:
-            raise RuntimeError("emu_plan8 rc=%d: %s" % (n, self.error()))
-        return runs[:n], links.value
+        n = len(coeffs_list)
+        coeffs_list = [np.ascontiguousarray(c) for c in coeffs_list]
+        kind = 1 if coeffs_list[0].dtype == np.int16 else 0
+        meta_list = [np.ascontiguousarray(m, np.uint16) for m in meta_list] if meta_list is not None else None
+        pcm = [np.full(n_pcm, np.nan, np.float32) for _ in range(n)]
+        cp = (C.c_void_p * n)(*[c.ctypes.data for c in coeffs_list])
+        mp = (C.c_void_p * n)(*[m.ctypes.data for m in meta_list]) if meta_list is not None else None
+        pp = (C.c_void_p * n)(*[x.ctypes.data for x in pcm])
+        last = C.c_uint64(0)
+        rc = self.lib.emu_decode_pipelined(kind, sample_index, pool.shape[0], pool.shape[1], units.ctypes.data, len(units), n, cp, mp, pp, n_pcm,
+                                           pool.ctypes.data, parity.ctypes.data, cells.ctypes.data, heads.ctypes.data, order, epoch_in, C.byref(last))
+        if rc:
+            raise RuntimeError("emu_decode_pipelined rc=%d: %s" % (rc, self.error()))
+        return pcm, last.value
 
     def plan(self, units, max_streams, max_channels, parity=None, sample_index=3):
         units = np.ascontiguousarray(units)

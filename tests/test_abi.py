@@ -11,20 +11,23 @@ import aacgpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_symbols():
-    text = open(os.path.join(ROOT, "include", "aacgpu.h")).read()
+def declared_symbols(header="aacgpu.h"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(aacg_[a-z_]+)\s*\(", text)))
 
 
 def test_header_and_binding_agree():
     assert declared_symbols() == sorted(aacgpu.ABI_SYMBOLS)
+    assert declared_symbols("aacgpu_tools.h") == sorted(aacgpu.TOOLS_SYMBOLS)
+    # a host needs aacgpu.h only: no measurement / diagnostic entry point is declared there
+    assert not [n for n in declared_symbols() if n.startswith(("aacg_debug_", "aacg_timer_", "aacg_calib_"))]
 
 
 def test_library_exports_every_declared_symbol(engine_lib):
-    for name in declared_symbols():
+    for name in declared_symbols() + declared_symbols("aacgpu_tools.h"):
         assert hasattr(engine_lib, name), "libaacgpu.so does not export " + name
-    assert engine_lib.aacg_abi_version() == 4
+    assert engine_lib.aacg_abi_version() == 5
     assert engine_lib.aacg_kernel_name().decode().startswith("aacg_imdct_run")
 
 

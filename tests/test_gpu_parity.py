@@ -37,7 +37,7 @@ SCENARIOS = ["scn_stereo", "scn_split", "scn_7ch", "scn_mono"]
 
 
 def test_native_library_is_loaded(engine_lib):
-    assert engine_lib.aacg_kernel_name().decode() == "aacg_imdct_run_quant"
+    assert engine_lib.aacg_kernel_name().decode() == "aacg_imdct_run_quant_rv"
     maps = open("/proc/self/maps").read()
     assert "libaacgpu.so" in maps
 
@@ -848,69 +848,6 @@ def test_int16_output(oracle, layout, T, inp):
     eng.close()
 
 
-# ---- the one-channel-per-wave kernels (aacg_kernels8.h; opt-in route: AACG_DEBUG_ROUTE_NARROW_KERNELS) -----------------------
-NARROW = 4
-
-
-@pytest.mark.parametrize("layout,S,T,seam", [(("cpe",), 40, 16, "q"), (("cpe",), 24, 37, "q"), (("cpe",), 24, 19, "f"), (("sce",), 24, 35, "q"),
-                                             (("cpe", "cpe", "cpe", "sce"), 12, 21, "q"), (("sce", "cpe"), 12, 9, "f")])
-def test_narrow_kernels_vs_oracle(oracle, layout, S, T, seam):
-    """8 waves per SIMD, one channel per wave, runs of 8 pair-frames / 16 single-channel frames handing their tail over through a
-    rendezvous in global memory: two batches chained through the overlap state, all window sequences, M/S and intensity, against
-    the oracle — PCM and the overlap state — through the C ABI (host-buffer path and plans)."""
-    wl0 = aacgpu_workload.make_batch(n_streams=S, n_frames=T, layout=layout, mix=True, intensity=True, seed=4100)
-    C = wl0["C"]
-    kind = aacgpu.INPUT_QUANT_I16 if seam == "q" else aacgpu.INPUT_SPEC_F32
-    eng = aacgpu.Engine(kind, max_streams=S, max_channels=C)
-    eng.debug_set_route(NARROW)
-    ov = np.zeros((S, C, 1024), np.float32)
-    for batch in range(2):
-        wl = aacgpu_workload.make_batch(n_streams=S, n_frames=T, layout=layout, mix=True, intensity=True, seed=4100 + batch, frame_base=batch * T)
-        ref, spec = oracle.decode_batch(wl["units"], wl["q"], wl["meta"], wl["n_pcm"], ov, want_spec=True)
-        coeffs, meta = (wl["q"], wl["meta"]) if seam == "q" else (spec.astype(np.float32), None)
-        if batch == 0:
-            plan = eng.plan(wl["units"])
-            assert eng.plan_kernels(plan).startswith("aacg_imdct_run8_")
-            plan.destroy()
-        pcm = eng.decode_batch(wl["units"], coeffs, meta, wl["n_pcm"])
-        assert not np.isnan(pcm).any() and rms(pcm, ref) < RMS_TOL
-        assert np.abs(overlaps(eng, S, C) - ov).max() <= 1e-5 * max(1.0, float(np.abs(ov).max()))
-    eng.close()
-
-
-def test_narrow_kernels_same_bits_however_the_batch_is_cut_and_whoever_arrives_first(oracle):
-    """Whichever side of a run-to-run rendezvous arrives first finishes the frame with the same arithmetic (tail + head, both rounded
-    products, never fused), and a chain cut into batches goes through the overlap state the same way: 300 streams x 24 frames —
-    more workgroups than the chip holds, so both arrival orders occur — decoded whole, twice, and as 8 + 16: the same bits."""
-    S, T = 300, 24
-    whole = aacgpu_workload.make_batch(n_streams=S, n_frames=T, mix=True, intensity=True, seed=4242)
-    outs = []
-    for _ in range(2):
-        eng = aacgpu.Engine(aacgpu.INPUT_QUANT_I16, max_streams=S, max_channels=2)
-        eng.debug_set_route(NARROW)
-        outs.append(eng.decode_batch(whole["units"], whole["q"], whole["meta"], whole["n_pcm"]).reshape(S, T, 2048))
-        eng.close()
-    assert np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32))
-    eng = aacgpu.Engine(aacgpu.INPUT_QUANT_I16, max_streams=S, max_channels=2)
-    eng.debug_set_route(NARROW)
-    per_frame = len(whole["units"]) // (S * T)
-    parts = []
-    for lo, hi in ((0, 8), (8, T)):
-        keep = np.zeros(len(whole["units"]), bool)
-        for s in range(S):
-            keep[(s * T + lo) * per_frame:(s * T + hi) * per_frame] = True
-        units = whole["units"][keep].copy()
-        for s in range(S):
-            sel = units["stream"] == s
-            units["pcm_offset"][sel] = units["pcm_offset"][sel] - units["pcm_offset"][sel].min() + s * (hi - lo) * 2048
-        parts.append(eng.decode_batch(units, whole["q"], whole["meta"], S * (hi - lo) * 2048).reshape(S, hi - lo, 2048))
-    eng.close()
-    got = np.concatenate(parts, axis=1)
-    assert np.array_equal(got.view(np.uint32), outs[0].view(np.uint32))
-    ov = np.zeros((S, 2, 1024), np.float32)
-    assert rms(outs[0].reshape(-1), oracle.decode_batch(whole["units"], whole["q"], whole["meta"], whole["n_pcm"], ov)) < RMS_TOL
-
-
 # ---- chains longer than a run: the run-to-run rendezvous of the 16-wave kernels (aacg_imdct_run_*_rv) ------------------------
 @pytest.mark.parametrize("layout,S,T,seam", [(("cpe",), 300, 40, "q"), (("cpe",), 64, 128, "q"), (("cpe",), 40, 33, "f"), (("sce",), 40, 50, "q"),
                                              (("cpe", "cpe", "cpe", "sce"), 24, 20, "q")])
@@ -923,7 +860,7 @@ def test_rendezvous_between_runs_equals_recomputed_frames(oracle, layout, S, T, 
     C = wl0["C"]
     kind = aacgpu.INPUT_QUANT_I16 if seam == "q" else aacgpu.INPUT_SPEC_F32
     outs, states, routes = [], [], []
-    for route in (2, 2 | 8):                                         # 2 = AACG_DEBUG_ROUTE_WIDE_KERNELS (whatever AACG_RUN8 says), 8 = AACG_DEBUG_ROUTE_RECOMPUTE
+    for route in (0, aacgpu.DEBUG_ROUTE_RECOMPUTE):                  # the engine's route, and the old one
         eng = aacgpu.Engine(kind, max_streams=S, max_channels=C)
         eng.debug_set_route(route)
         got = []
@@ -953,3 +890,129 @@ def test_rendezvous_between_runs_equals_recomputed_frames(oracle, layout, S, T, 
             ref.append(oracle.decode_batch(wl["units"], wl["q"], wl["meta"], wl["n_pcm"], ov))
         assert rms(outs[0], np.concatenate(ref)) < RMS_TOL
         assert np.abs(states[0] - ov).max() <= 1e-5 * max(1.0, float(np.abs(ov).max()))
+
+
+# ---- consecutive launches of one plan overlapped: aacg_decode_pipelined -------------------------------------------------------
+def _device_batches(torch, base, n, seam, oracle, seed):
+    """n consecutive batches of the same streams on the device (the structure of batch 0, new coefficients): inputs, outputs"""
+    rng = np.random.default_rng(seed)
+    ins, host = [], []
+    for j in range(n):
+        q = base["q"] if j == 0 else (np.roll(base["q"], 131 * j, axis=0) * rng.choice([-1, 1])).astype(np.int16)
+        if seam == "f":
+            h = (np.sign(q) * np.abs(q.astype(np.float32)) ** (4.0 / 3.0) * 2.0 ** 4).astype(np.float32)
+        else:
+            h = np.ascontiguousarray(q)
+        host.append(h)
+        ins.append(torch.from_numpy(h).cuda())
+    return ins, host
+
+
+@pytest.mark.parametrize("layout,S,T,n,seam,mix", [(("cpe",), 256, 16, 72, "q", False), (("cpe",), 256, 16, 64, "f", True), (("cpe",), 300, 5, 64, "q", True),
+                                                    (("cpe",), 32, 128, 64, "q", True), (("cpe", "cpe", "cpe", "sce"), 64, 16, 64, "q", True),
+                                                    (("sce",), 700, 3, 64, "q", True)])
+def test_pipelined_launches_equal_the_serialised_route_bit_for_bit(oracle, layout, S, T, n, seam, mix):
+    """>= 64 back-to-back launches of ONE plan through aacg_decode_pipelined (two internal streams taken in turn; the chains of
+    neighbouring launches meet in cross-launch cells, nobody waits) against the same launches through aacg_decode_device on one
+    stream (the plain kernels, every launch behind the one before it): np.array_equal on uint32 views, every launch's PCM and
+    the final overlap state — BASELINE config 2 / 3 / 4 / 5 shapes, a grid larger than the chip (both arrival orders occur),
+    both seams; the first launches against the oracle.  The routes taken are asserted."""
+    torch = _torch()
+    base = aacgpu_workload.make_batch(n_streams=S, n_frames=T, layout=layout, mix=mix, intensity=mix, seed=7300)
+    C = base["C"]
+    kind = aacgpu.INPUT_QUANT_I16 if seam == "q" else aacgpu.INPUT_SPEC_F32
+    ins, host = _device_batches(torch, base, n, seam, oracle, 7)
+    d_meta = torch.from_numpy(base["meta"].view(np.int16)).cuda() if seam == "q" else None
+    mp = d_meta.data_ptr() if d_meta is not None else None
+    results = []
+    for pipelined in (False, True):
+        eng = aacgpu.Engine(kind, max_streams=S, max_channels=C)
+        plan = eng.plan(base["units"])
+        name = eng.plan_kernels(plan, pipelined=pipelined)
+        wide = "_nt" if C > 2 else ""
+        if pipelined:
+            assert name == "aacg_imdct_run_%s_rv%s" % ("quant" if seam == "q" else "f32", wide)
+        else:
+            assert name == "aacg_imdct_run_%s%s%s" % ("quant" if seam == "q" else "f32", "_rv" if T > 16 else "", wide)
+        outs = [torch.full((base["n_pcm"],), float("nan"), dtype=torch.float32, device="cuda") for _ in range(n)]
+        torch.cuda.synchronize()
+        for j in range(n):
+            if pipelined:
+                eng.decode_pipelined(plan, ins[j].data_ptr(), mp, outs[j].data_ptr())
+            else:
+                eng.decode_device(plan, ins[j].data_ptr(), mp, outs[j].data_ptr(), 0)
+        eng.synchronize()
+        torch.cuda.synchronize()
+        if pipelined:
+            assert eng.pipeline_chained() == n - 1                   # every launch but the first continued the one before it
+        results.append(([o.cpu().numpy() for o in outs], overlaps(eng, S, C)))
+        plan.destroy()
+        eng.close()
+    (serial, s_state), (piped, p_state) = results
+    for j in range(n):
+        assert not np.isnan(piped[j]).any(), j
+        assert np.array_equal(piped[j].view(np.uint32), serial[j].view(np.uint32)), "launch %d differs from the serialised route" % j
+    assert np.array_equal(p_state.view(np.uint32), s_state.view(np.uint32))
+    if seam == "q":                                                  # ... and the serialised route is the oracle's, on the first launches
+        ov = np.zeros((S, C, 1024), np.float32)
+        for j in range(2 if S * T > 3000 else 4):
+            assert rms(serial[j], oracle.decode_batch(base["units"], host[j], base["meta"], base["n_pcm"], ov)) < RMS_TOL
+
+
+def test_pipelined_launches_mixed_with_everything_else(oracle):
+    """The pipeline next to the other entry points on the same streams — aacg_decode_device of the same plan, another plan, the
+    host-buffer path, aacg_get_overlap, a fork from and a join onto a caller's stream: mixing costs the overlap, never the
+    result.  One engine does the sequence mixed, one does it serially."""
+    torch = _torch()
+    S, T = 64, 16
+    base = aacgpu_workload.make_batch(n_streams=S, n_frames=T, mix=True, intensity=True, seed=7400)
+    n = 12
+    ins, host = _device_batches(torch, base, n, "q", oracle, 8)
+    d_meta = torch.from_numpy(base["meta"].view(np.int16)).cuda()
+    mp = d_meta.data_ptr()
+    side = torch.cuda.Stream()
+
+    def run(mixed):
+        eng = aacgpu.Engine(aacgpu.INPUT_QUANT_I16, max_streams=S, max_channels=2)
+        plan, plan_b = eng.plan(base["units"]), None
+        outs = [torch.full((base["n_pcm"],), float("nan"), dtype=torch.float32, device="cuda") for _ in range(n)]
+        got = [None] * n
+        torch.cuda.synchronize()
+        for j in range(n):
+            how = ["p", "p", "p", "d", "p", "b", "p", "p", "h", "p", "s", "p"][j] if mixed else "d"
+            if how == "p":
+                eng.decode_pipelined(plan, ins[j].data_ptr(), mp, outs[j].data_ptr())
+            elif how == "d":                                        # the same plan, serial, on the engine's stream
+                eng.decode_device(plan, ins[j].data_ptr(), mp, outs[j].data_ptr(), 0)
+            elif how == "b":                                        # another plan for the same streams (made now: it starts from the current state)
+                plan_b = eng.plan(base["units"])
+                eng.decode_pipelined(plan_b, ins[j].data_ptr(), mp, outs[j].data_ptr())
+                plan.destroy()
+                plan = plan_b
+            elif how == "h":                                        # the host-buffer path
+                got[j] = eng.decode_batch(base["units"], host[j], base["meta"], base["n_pcm"])
+                plan.destroy()
+                plan = eng.plan(base["units"])                      # (a plan is stale once something else has advanced its streams)
+            elif how == "s":                                        # input produced on a caller's stream, output consumed there
+                with torch.cuda.stream(side):
+                    tmp = ins[j].clone()
+                    eng.pipeline_fork(side.cuda_stream)
+                    eng.decode_pipelined(plan, tmp.data_ptr(), mp, outs[j].data_ptr())
+                    eng.pipeline_join(side.cuda_stream)
+                    got[j] = outs[j].clone()
+                side.synchronize()
+                got[j] = got[j].cpu().numpy()
+            if mixed and j == 6:
+                eng.get_overlap(3, 1)                                # host reads the state in the middle: a full stop, nothing more
+        eng.synchronize()
+        torch.cuda.synchronize()
+        state = overlaps(eng, S, 2)
+        res = [got[j] if got[j] is not None else outs[j].cpu().numpy() for j in range(n)]
+        plan.destroy()
+        eng.close()
+        return res, state
+
+    (a, sa), (b, sb) = run(True), run(False)
+    for j in range(n):
+        assert np.array_equal(a[j].view(np.uint32), b[j].view(np.uint32)), j
+    assert np.array_equal(sa.view(np.uint32), sb.view(np.uint32))

@@ -3,8 +3,7 @@ in the build container: a toolchain change (or an edit) that spills, drops occup
 to tests/test_disasm_guard.py, instead of showing up as a slower or failing launch on the GPU box.
 
 The budgets are what the design rests on: the 16-wave run kernels hold one workgroup per CU — 4 waves per SIMD,
-so at most 128 VGPRs, no scratch (a scratch reload waits for the PCM stores in flight), at most 160 KiB of LDS; the 8-wave-per-SIMD
-kernels (one channel per wave, two workgroups per CU) at most 64 VGPRs and half the LDS."""
+so at most 128 VGPRs, no scratch (a scratch reload waits for the PCM stores in flight), at most 160 KiB of LDS."""
 import concurrent.futures
 import os
 import re
@@ -18,11 +17,9 @@ HIPCC = "/opt/rocm/bin/hipcc"
 SCHED = ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"]
 # translation unit -> (extra flags as the Makefile builds it, {kernel: (max VGPRs, min waves/SIMD, max LDS bytes)})
 WIDE = (128, 4, 160 * 1024)
-NARROW = (64, 8, 80 * 1024)            # one channel per wave: two 16-wave workgroups per CU
 TUS = {
     "aacg_engine_rv.hip": (SCHED, {"aacg_imdct_run_quant_rv": WIDE, "aacg_imdct_run_f32_rv": WIDE, "aacg_imdct_run_quant_rv_nt": WIDE, "aacg_imdct_run_f32_rv_nt": WIDE}),
     "aacg_engine_nt.hip": (SCHED, {"aacg_imdct_run_quant_nt": WIDE, "aacg_imdct_run_f32_nt": WIDE}),
-    "aacg_engine8.hip": (SCHED, {"aacg_imdct_run8_quant": NARROW, "aacg_imdct_run8_f32": NARROW}),
     "aacg_engine.hip": (SCHED, {"aacg_imdct_run_quant": WIDE, "aacg_imdct_run_f32": WIDE}),
     "aacg_engine_ext.hip": (SCHED, {"aacg_imdct_run_quant_dd": WIDE, "aacg_imdct_run_f32_dd": WIDE}),
     "aacg_engine_i16.hip": (SCHED, {"aacg_imdct_run_quant_i16": WIDE, "aacg_imdct_run_f32_i16": WIDE, "aacg_imdct_run_quant_i16_nt": WIDE, "aacg_imdct_run_f32_i16_nt": WIDE}),
@@ -63,14 +60,9 @@ def test_hot_kernels_keep_their_register_and_lds_budget(reports, tu):
         rep = reports[tu].get(kernel)
         assert rep, "%s: kernel %s not in the resource report (%s)" % (tu, kernel, sorted(reports[tu]))
         assert int(rep["VGPRs"]) + int(rep["AGPRs"]) <= max_vgpr, (kernel, rep)
-        if "run8" in kernel:
-            # the opt-in one-channel-per-wave kernels sit ON their 64-register limit: a few spilled registers in their general
-            # (cold) passes are what they measure with; pinned so that they do not grow unnoticed
-            assert int(rep["ScratchSize [bytes/lane]"]) <= 64 and int(rep["VGPRs Spill"]) <= 12 and int(rep["SGPRs Spill"]) <= 64, (kernel, rep)
-        else:
-            assert int(rep["ScratchSize [bytes/lane]"]) == 0 and int(rep["VGPRs Spill"]) == 0, (kernel, rep)
-            # scalar spills go to VGPR lanes (no memory traffic); the plain kernels have none, the optional-stage builds a handful
-            assert int(rep["SGPRs Spill"]) <= (32 if kernel.endswith("_ex") else 0), (kernel, rep)
+        assert int(rep["ScratchSize [bytes/lane]"]) == 0 and int(rep["VGPRs Spill"]) == 0, (kernel, rep)
+        # scalar spills go to VGPR lanes (no memory traffic); the plain kernels have none, the optional-stage builds a handful
+        assert int(rep["SGPRs Spill"]) <= (32 if kernel.endswith("_ex") else 0), (kernel, rep)
         assert int(rep["Occupancy [waves/SIMD]"]) >= min_occ, (kernel, rep)
         assert int(rep["LDS Size [bytes/block]"]) <= max_lds, (kernel, rep)
         assert rep["Dynamic Stack"] == "False", (kernel, rep)

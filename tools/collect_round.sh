@@ -21,11 +21,9 @@ b cfg3_tns_spec_f32 --workload cfg3 --tns spec --input spec --steps 1000 --warmu
 b cfg5_cce_spec --workload cfg5 --cce spec --steps 500 --warmup 100 --no-cpu-baseline
 b quant_i16out --output i16 --no-cpu-baseline
 b quant_pipelines2 --pipelines 2 --no-cpu-baseline
-# the one-channel-per-wave kernels (opt-in route): the same workloads, for the record of what they measure
-AACG_RUN8=1 python3 bench.py --no-cpu-baseline > $OUT/bench_quant_run8.json 2> $OUT/bench_quant_run8.err || echo "bench quant_run8 failed" >> $OUT/failures.txt
-AACG_RUN8=1 python3 bench.py --no-cpu-baseline --input spec > $OUT/bench_spec_run8.json 2> $OUT/bench_spec_run8.err || echo "bench spec_run8 failed" >> $OUT/failures.txt
-AACG_RUN8=1 python3 bench.py --no-cpu-baseline --workload cfg4 > $OUT/bench_cfg4_run8.json 2> $OUT/bench_cfg4_run8.err || echo "bench cfg4_run8 failed" >> $OUT/failures.txt
-AACG_RUN8=1 python3 bench.py --no-cpu-baseline --workload cfg5 --steps 500 --warmup 100 > $OUT/bench_cfg5_run8.json 2> $OUT/bench_cfg5_run8.err || echo "bench cfg5_run8 failed" >> $OUT/failures.txt
+b quant_serial --serial --no-cpu-baseline
+b cfg3_serial --workload cfg3 --serial --no-cpu-baseline
+b cfg5_serial --workload cfg5 --serial --steps 1000 --warmup 200 --no-cpu-baseline
 b quant_2ranks_shared_gpu --gpus 2 --dist-backend gloo --share-gpu --steps 1000 --warmup 200
 # the driver's launch line with one rank: RCCL carries the barrier and the 8-byte reductions
 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29541 bench.py --gpus 1 --steps 1000 --warmup 200 --no-cpu-baseline \
@@ -34,9 +32,8 @@ bash tools/prof.sh $TAG/prof_quant > $OUT/prof_quant.log 2>&1
 bash tools/prof.sh $TAG/prof_spec --input spec > $OUT/prof_spec.log 2>&1
 bash tools/prof.sh $TAG/prof_cfg5 --workload cfg5 > $OUT/prof_cfg5.log 2>&1
 bash tools/prof.sh $TAG/prof_cfg3_tns --workload cfg3 --tns spec > $OUT/prof_cfg3_tns.log 2>&1
-AACG_RUN8=1 bash tools/prof.sh $TAG/prof_quant_run8 > $OUT/prof_quant_run8.log 2>&1
 # keep what is judged: summaries and kernel stats (the raw rocprofv3 trees stay behind)
-for p in prof_quant prof_spec prof_cfg5 prof_cfg3_tns prof_quant_run8; do
+for p in prof_quant prof_spec prof_cfg5 prof_cfg3_tns; do
   cp $OUT/$p/summary.txt $OUT/${p}_summary.txt 2>/dev/null
   find $OUT/$p/trace -name "*kernel_stats.csv" -exec cp {} $OUT/${p}_kernel_stats.csv \; 2>/dev/null
   rm -rf $OUT/$p

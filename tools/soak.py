@@ -34,10 +34,10 @@ while time.time() - t0 < budget:
     wl = dict(wl, units=units, meta=meta)
     eng = aacgpu.Engine(aacgpu.INPUT_QUANT_I16, S, C, tns_mode=int(use_tns), pns_mode=int(use_pns))
     engf = aacgpu.Engine(aacgpu.INPUT_SPEC_F32, S, C, tns_mode=int(use_tns))
-    # half of the engines take the one-channel-per-wave kernels for their plain batches (aacg_kernels8.h: the opt-in route)
+    # half of the engines take the old route for chains longer than a run (a recomputed frame per later run instead of the rendezvous)
     narrow = bool(rng.integers(0, 2))
     if narrow:
-        eng.debug_set_route(4); engf.debug_set_route(4)
+        eng.debug_set_route(aacgpu.DEBUG_ROUTE_RECOMPUTE); engf.debug_set_route(aacgpu.DEBUG_ROUTE_RECOMPUTE)
         n_narrow += 1
     for rep in range(int(rng.integers(1, 4))):                 # consecutive batches of the same streams
         ov_in = ov.copy()
