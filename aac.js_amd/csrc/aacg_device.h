@@ -99,11 +99,15 @@ struct aacg_pns_tables {
 };
 
 /* The overlap state (filter_bank.js:38-41) of one channel lives in AACG_OV_BUFFERS rotating buffers of 1024 floats: a launch
- * that advances the channel reads buffer r and leaves the new state in buffer (r + 1) mod 3.  Two would do for launches that
- * follow each other on one HIP stream; three are what lets consecutive launches of a plan OVERLAP (aacg_decode_pipelined):
- * launch n + 1 may be writing buffer r + 2 while launch n still reads r and writes r + 1, and launch n + 2, which writes
- * buffer r again, is ordered behind launch n by the engine. */
-#define AACG_OV_BUFFERS 3
+ * that advances the channel reads buffer r and leaves the new state in buffer r + 1 (mod AACG_OV_BUFFERS).  Two would do for
+ * launches that follow each other on one HIP stream; more are what lets consecutive launches of a plan OVERLAP
+ * (aacg_decode_pipelined): launch n + 1 may be writing buffer r + 2 while launch n still reads r and writes r + 1.  A buffer
+ * (and the rendezvous cell that goes with it) comes round again after AACG_OV_BUFFERS launches, so the engine orders launch n
+ * behind launch n - AACG_OV_BUFFERS: its two streams give "behind n - 2" for free, and every q-th launch of a stream waits for
+ * an event of the launch three before it on the other stream, q = (AACG_OV_BUFFERS - 1) / 2 — with five buffers one event
+ * record and one event wait per FOUR launches (per launch they cost the host more than the launch itself:
+ * tools/micro/launch_cost.hip). */
+#define AACG_OV_BUFFERS 5
 
 /* One workgroup's work: consecutive frames of one element of one stream.  The first run of a
  * chain holds up to 16 units (wave w = unit w, wave 0 starts from the overlap state); a later
@@ -114,7 +118,7 @@ struct aacg_run {
     int32_t unit[AACG_RUN_W];
     int32_t ov0[2];                   /* per channel: float offset of its buffer 0 in the overlap pool (buffer r at + 1024 r) */
     int32_t rot[2];                   /* per channel: the buffer that held its state when the plan was made; launch number j of the
-                                         plan (aacg_kparams.flip = j mod 3) reads buffer (rot + flip) mod 3 and writes the next one */
+                                         plan (aacg_kparams.flip = j mod AACG_OV_BUFFERS) reads buffer (rot + flip) mod AACG_OV_BUFFERS and writes the next one */
     int32_t is_last;                  /* last run of its chain: the final tail goes to the out buffer */
     int32_t reserved;
 };
@@ -153,7 +157,7 @@ struct aacg_kparams {
     float*                overlap;    /* overlap pool */
     float*                spec_out;   /* spectral-only kernel */
     const aacg_tables*    tab;
-    int32_t               flip;       /* 0..2: launches of this plan so far, mod 3 (aacg_run.rot) */
+    int32_t               flip;       /* launches of this plan so far, mod AACG_OV_BUFFERS (aacg_run.rot) */
     int32_t               n_runs;
     int32_t               ablate;     /* -DAACG_PROFILE builds only (AACG_ABL in aacg_kernels.h); 0 otherwise */
     int32_t               reserved;

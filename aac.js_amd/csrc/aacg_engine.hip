@@ -50,6 +50,18 @@ struct rv_bufs { const aacg_run* runs; const aacg_rv_link* links; unsigned long 
 extern "C" __global__ __launch_bounds__(AACG_WG_THREADS)
 void aacg_spectral(const aacg_kparams P, int n_units) { spectral_body(P, n_units); }
 
+/* Do two HIP streams run concurrently?  HIP multiplexes its streams onto a few hardware queues, and two streams that share one
+ * serialise whatever the program meant (tools/micro/queue_map.hip).  One wave waits — bounded — for a word the other stream's
+ * kernel sets: it sees it only if that kernel runs while this one is still running. */
+extern "C" __global__ void aacg_probe_wait(const unsigned* flag, unsigned* seen, long long ticks)
+{
+    const long long t0 = wall_clock64();
+    unsigned ok = 0;
+    while (!ok && wall_clock64() - t0 < ticks) ok = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *seen = ok;
+}
+extern "C" __global__ void aacg_probe_set(unsigned* flag) { __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 #define AACG_LDS_BYTES_SPECTRAL ((AACG_TAB_QUANT_FLOATS + AACG_WG_WAVES * 512) * 4)
 
 /* ---- engine ------------------------------------------------------------------------ */
@@ -66,15 +78,19 @@ struct aacg_engine {
     aacg_host_windows h_win;
     /* pipelined launches (aacg_decode_pipelined): two internal streams taken in turn, so that a launch starts on the CUs the
      * launch before it has left while that one is still finishing.  The chains of the two launches meet in cross-launch cells
-     * (aacg_xl_cell); the engine bounds how far a launch may run ahead: launch n is ordered behind launch n - 2 (same stream)
-     * and behind launch n - 3 (event), so only neighbours ever overlap — which is what the three rotating overlap buffers and
-     * cells are safe for. */
+     * (aacg_xl_cell); the engine bounds how far a launch may run ahead: launch n is ordered behind launch n - 2 (same stream),
+     * and every q-th launch of a stream behind the launch three before it on the other stream (an event), so that every launch is
+     * behind launch n - AACG_OV_BUFFERS — which is when the rotating overlap buffers and cells come round again. */
     struct pipe_t {
         hipStream_t stream[2] = {nullptr, nullptr};
-        hipEvent_t done[4] = {nullptr, nullptr, nullptr, nullptr};   /* done[n % 4]: launch n of the pipeline */
+        hipEvent_t done[4] = {nullptr, nullptr, nullptr, nullptr};   /* done[n % 4]: launch n of the pipeline, where launch n + 3 will wait for it */
+        hipEvent_t tail[2] = {nullptr, nullptr};                      /* joins: everything on stream k so far */
         hipEvent_t fork = nullptr;
+        int q = (AACG_OV_BUFFERS - 1) / 2;  /* every q-th launch of a stream is ordered behind the launch three before it (on the other stream) */
         uint64_t n = 0;                     /* launches issued so far */
+        hipStream_t joined_stream = nullptr; uint64_t joined_n = ~0ull;   /* the stream most recently put behind the pipeline, and at which launch count */
         bool open = false;                  /* launches issued since the last join that nobody outside is ordered behind yet */
+        bool concurrent = false;            /* the two streams were seen to run side by side (pipe_setup's probe) */
         aacg_plan* plan = nullptr;          /* the plan of launch n - 1 */
         unsigned long long epoch = 0;       /* rv epoch of launch n - 1 */
         uint64_t chained = 0;               /* launches that continued their predecessor through the cross-launch cells (introspection) */
@@ -329,16 +345,16 @@ int pipe_join(aacg_engine* e, hipStream_t s)
 {
     aacg_engine::pipe_t& pp = e->pipe;
     if (!pp.open) return AACG_OK;
-    bool all_done = true;
-    for (uint64_t k = 1; k <= 2 && k <= pp.n; k++) {
-        hipEvent_t ev = pp.done[(pp.n - k) & 3u];
-        if (hipEventQuery(ev) == hipSuccess) continue;  /* complete already: nothing to order behind */
-        (void)hipGetLastError();
-        all_done = false;
-        if (s) HIP_TRY(e, hipStreamWaitEvent(s, ev, 0), AACG_ERR_NO_DEVICE);
-        else   HIP_TRY(e, hipEventSynchronize(ev), AACG_ERR_NO_DEVICE);
+    if (s && s == pp.joined_stream && pp.n == pp.joined_n) return AACG_OK;   /* s is behind all of it already */
+    for (int k = 0; k < 2; k++) {
+        if (s == pp.stream[k]) continue;                /* its own launches are in front of it anyway */
+        if (s) {
+            HIP_TRY(e, hipEventRecord(pp.tail[k], pp.stream[k]), AACG_ERR_NO_DEVICE);
+            HIP_TRY(e, hipStreamWaitEvent(s, pp.tail[k], 0), AACG_ERR_NO_DEVICE);
+        } else HIP_TRY(e, hipStreamSynchronize(pp.stream[k]), AACG_ERR_NO_DEVICE);
     }
-    if (all_done || !s) pp.open = false;               /* the host has seen both complete: nothing in flight any more */
+    if (!s) pp.open = false;                           /* the host has seen both streams drained: nothing in flight any more */
+    pp.joined_stream = s; pp.joined_n = pp.n;
     return AACG_OK;
 }
 
@@ -497,6 +513,7 @@ void aacg_destroy(aacg_engine* e)
     if (e->d_xl_cells) (void)hipFree(e->d_xl_cells);
     if (e->d_xl_head) (void)hipFree(e->d_xl_head);
     for (hipEvent_t ev : e->pipe.done) if (ev) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : e->pipe.tail) if (ev) (void)hipEventDestroy(ev);
     if (e->pipe.fork) (void)hipEventDestroy(e->pipe.fork);
     for (hipStream_t st : e->pipe.stream) if (st) (void)hipStreamDestroy(st);
     if (e->d_overlap) (void)hipFree(e->d_overlap);
@@ -753,13 +770,44 @@ int aacg_decode_device(aacg_engine* e, aacg_plan* p, const void* d_coeffs, const
 }
 
 /* ---- pipelined launches ---------------------------------------------------------------- */
+/* true if a kernel on b runs while one on a is running (both idle before) */
+static bool streams_overlap(aacg_engine* e, hipStream_t a, hipStream_t b, unsigned* d_probe)
+{
+    if (hipMemsetAsync(d_probe, 0, 8, a) != hipSuccess || hipStreamSynchronize(a) != hipSuccess) return false;
+    hipLaunchKernelGGL(aacg_probe_wait, dim3(1), dim3(1), 0, a, d_probe, d_probe + 1, 50000LL);      /* at most 0.5 ms (100 MHz clock) */
+    hipLaunchKernelGGL(aacg_probe_set, dim3(1), dim3(1), 0, b, d_probe);
+    unsigned seen = 0;
+    if (hipStreamSynchronize(a) != hipSuccess || hipStreamSynchronize(b) != hipSuccess ||
+        hipMemcpy(&seen, d_probe + 1, 4, hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); return false; }
+    (void)e;
+    return seen != 0;
+}
+
 static int pipe_setup(aacg_engine* e)
 {
     aacg_engine::pipe_t& pp = e->pipe;
     if (pp.stream[0]) return AACG_OK;
-    for (hipStream_t& st : pp.stream) HIP_TRY(e, hipStreamCreateWithFlags(&st, hipStreamNonBlocking), AACG_ERR_NO_DEVICE);
+    /* Two streams that really run side by side.  Streams of the highest priority are dealt their hardware queues apart from the
+     * crowd of ordinary streams a host process may have made (PyTorch: 32 at once); the pair is then PROBED, and further
+     * candidates are tried if it shares a queue after all.  A pair that never overlaps still decodes correctly — serially. */
+    int least = 0, greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+    unsigned* d_probe = nullptr;
+    HIP_TRY(e, hipMalloc((void**)&d_probe, 8), AACG_ERR_OUT_OF_MEMORY);
+    HIP_TRY(e, hipStreamCreateWithPriority(&pp.stream[0], hipStreamNonBlocking, greatest), AACG_ERR_NO_DEVICE);
+    hipStream_t spare[6]; int n_spare = 0;
+    for (int attempt = 0; attempt < 6 && !pp.concurrent; attempt++) {
+        hipStream_t cand = nullptr;
+        HIP_TRY(e, hipStreamCreateWithPriority(&cand, hipStreamNonBlocking, attempt < 4 ? greatest : 0), AACG_ERR_NO_DEVICE);
+        if (streams_overlap(e, pp.stream[0], cand, d_probe)) { pp.stream[1] = cand; pp.concurrent = true; }
+        else spare[n_spare++] = cand;
+    }
+    if (!pp.stream[1]) pp.stream[1] = spare[--n_spare];
+    for (int i = 0; i < n_spare; i++) (void)hipStreamDestroy(spare[i]);
+    (void)hipFree(d_probe);
     /* events that order and nothing else: no time stamps, no system-scope fence at the record */
     for (hipEvent_t& ev : pp.done) HIP_TRY(e, hipEventCreateWithFlags(&ev, hipEventDisableTiming | hipEventDisableSystemFence), AACG_ERR_NO_DEVICE);
+    for (hipEvent_t& ev : pp.tail) HIP_TRY(e, hipEventCreateWithFlags(&ev, hipEventDisableTiming | hipEventDisableSystemFence), AACG_ERR_NO_DEVICE);
     HIP_TRY(e, hipEventCreateWithFlags(&pp.fork, hipEventDisableTiming | hipEventDisableSystemFence), AACG_ERR_NO_DEVICE);
     return AACG_OK;
 }
@@ -776,12 +824,14 @@ int aacg_decode_pipelined(aacg_engine* e, aacg_plan* p, const void* d_coeffs, co
     aacg_engine::pipe_t& pp = e->pipe;
     hipStream_t s = pp.stream[pp.n & 1u];
     /* Does this launch continue the one before it — same plan, nothing in between, a route whose chains meet in cells?  Then
-     * the two may overlap: its input state arrives through the cross-launch cells, tagged with that launch's epoch.  The
-     * launch three back is the one whose cells and buffers this one reuses, and the only one of the earlier launches it is
-     * not ordered behind by its stream: an event.  Otherwise it starts behind everything in flight, from complete state. */
+     * the two may overlap: its input state arrives through the cross-launch cells, tagged with that launch's epoch.  Its
+     * stream puts it behind launch n - 2; every q-th launch of a stream also waits for the launch three before it (the other
+     * stream): together every launch is behind launch n - AACG_OV_BUFFERS, whose buffers and cells it reuses (aacg_device.h).
+     * Otherwise it starts behind everything in flight, from complete state. */
     const bool continues = R.overlappable && pp.open && pp.plan == p && p->last_pipelined && p->seen_epoch == e->epoch;
+    const uint64_t q = (uint64_t)pp.q;
     if (continues) {
-        if (pp.n >= 3) HIP_TRY(e, hipStreamWaitEvent(s, pp.done[(pp.n - 3) & 3u], 0), AACG_ERR_NO_DEVICE);
+        if (pp.n >= 3 && q && ((pp.n >> 1) % q) == 0) HIP_TRY(e, hipStreamWaitEvent(s, pp.done[(pp.n - 3) & 3u], 0), AACG_ERR_NO_DEVICE);
     } else {
         if ((rc = pipe_join(e, s))) return rc;
         if (p->used && !p->last_pipelined) {
@@ -798,7 +848,7 @@ int aacg_decode_pipelined(aacg_engine* e, aacg_plan* p, const void* d_coeffs, co
     rc = launch_run(e, R, p->d_units, p->d_runs, p->d_tns, p->d_scratch, p->d_spec, cb, rvb, p->h, d_coeffs, d_meta, d_pcm,
                     (int)(p->launches % AACG_OV_BUFFERS), s, xl, &epoch);
     if (rc) return rc;
-    HIP_TRY(e, hipEventRecord(pp.done[pp.n & 3u], s), AACG_ERR_NO_DEVICE);
+    if (q && (((pp.n + 3) >> 1) % q) == 0) HIP_TRY(e, hipEventRecord(pp.done[pp.n & 3u], s), AACG_ERR_NO_DEVICE);   /* the launch three on will wait for it */
     if (continues) pp.chained++;
     pp.n++;
     pp.open = true;
@@ -828,6 +878,7 @@ int aacg_pipeline_join(aacg_engine* e, void* hip_stream)
 }
 
 uint64_t aacg_pipeline_chained(const aacg_engine* e) { return e ? e->pipe.chained : 0; }
+int aacg_pipeline_concurrent(const aacg_engine* e) { return e && e->pipe.concurrent ? 1 : 0; }
 
 /* The plan's device unit records take what the parser found (device to device); the run tables stay. */
 int aacg_plan_refresh_from_parse(aacg_engine* e, aacg_plan* p, const aacg_unit_desc* d_parsed_units,

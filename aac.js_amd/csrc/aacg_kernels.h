@@ -1949,8 +1949,8 @@ DP_DEVICE void rv_finish_successor(typename pcm_elem<OUT>::type* pcm, int C, int
     }
 }
 
-/* overlap buffer r of a channel is 1024 r floats behind its buffer 0; this launch reads buffer (rot + flip) mod 3 of a run's
- * channel and leaves the new state in the next one (aacg_run.rot, aacg_kparams.flip: both 0..2) */
+/* overlap buffer r of a channel is 1024 r floats behind its buffer 0; this launch reads buffer (rot + flip) mod AACG_OV_BUFFERS of a
+ * run's channel and leaves the new state in the next one (aacg_run.rot, aacg_kparams.flip: both below AACG_OV_BUFFERS, add at most flip + 1) */
 DP_DEVICE int ov_buffer(int rot, int add) { int r = rot + add; r = r >= AACG_OV_BUFFERS ? r - AACG_OV_BUFFERS : r; return r >= AACG_OV_BUFFERS ? r - AACG_OV_BUFFERS : r; }
 
 /* ------------------------------------------------------------------------------------ */
@@ -1999,6 +1999,11 @@ DP_DEVICE void imdct_run_body(const aacg_kparams& P, const aacg_rv_args* V = nul
     const bool xl = RV && V->xl_cells != nullptr;
     /* the frame another workgroup may be waiting for: a run's last, when its chain goes on — in this launch or in the next */
     const bool hands_over = RV && wave == n_units - 1 && (lk.link_out >= 0 || xl);
+#ifdef AACG_EXP_XL_NOEARLY                               /* experiment: only the in-launch hand-overs run ahead of their group */
+    const bool hurry = RV && wave == n_units - 1 && lk.link_out >= 0;
+#else
+    const bool hurry = hands_over;
+#endif
     /* this launch's overlap buffers of the run's channels (float offsets in the pool), evaluated where a chain's first or last wave needs them */
 #define AACG_OV_IN(c)  (run->ov0[c] + 1024 * ov_buffer(run->rot[c], P.flip))
 #define AACG_OV_OUT(c) (run->ov0[c] + 1024 * ov_buffer(run->rot[c], P.flip + 1))
@@ -2023,7 +2028,7 @@ DP_DEVICE void imdct_run_body(const aacg_kparams& P, const aacg_rv_args* V = nul
      * never lower, so a spinning consumer cannot starve its producer. */
     /* (the multichannel variants leave every wave at the default priority: 62.0 -> 61.9 us on config 5, nothing anywhere else) */
     if (NTL && !RV) {} else
-    if (AACG_ABL(P, 64)) dp_setprio(0); else if (AACG_ABL(P, 32)) dp_setprio(1 - (wave >> 3)); else dp_setprio(hands_over ? 3 : 3 - (wave >> 2));
+    if (AACG_ABL(P, 64)) dp_setprio(0); else if (AACG_ABL(P, 32)) dp_setprio(1 - (wave >> 3)); else dp_setprio(hurry ? 3 : 3 - (wave >> 2));
     const unsigned long long t_start = AACG_ABL(P, 16) ? dp_clock() : 0;
     /* (the coupling builds carry their side buffer in spec_out, aacg_set_cpl: never a trace there) */
     unsigned long long* trace = (!CPL && AACG_ABL(P, 16)) ? (unsigned long long*)P.spec_out + ((size_t)dp_block() * AACG_WG_WAVES + wave) * 8 : nullptr;
@@ -2075,7 +2080,7 @@ DP_DEVICE void imdct_run_body(const aacg_kparams& P, const aacg_rv_args* V = nul
      * join), and only then do the other twelve waves issue their requests.  The first group therefore sees
      * its data after ~1.7 us instead of queueing behind the whole chip's 33 MB, and the later groups' data
      * arrives while the SIMD is still busy with the earlier ones. */
-    const bool early = wave < (KIND == AACG_INPUT_QUANT_I16 ? 2 : 4) || hands_over || AACG_ABL(P, 128);
+    const bool early = wave < (KIND == AACG_INPUT_QUANT_I16 ? 2 : 4) || hurry || AACG_ABL(P, 128);
     if (early) issue_loads();
     stage_tables_store(lds, TAB_FLOATS, tr0, tr1);
     if (lane == 0) flags[wave] = 0;

@@ -30,7 +30,7 @@ ABI_SYMBOLS = ["aacg_create", "aacg_destroy", "aacg_last_error", "aacg_abi_versi
                "aacg_decode_pipelined", "aacg_pipeline_fork", "aacg_pipeline_join"]
 # ... and include/aacgpu_tools.h (measurement and diagnostics: bench.py, tools/, tests)
 TOOLS_SYMBOLS = ["aacg_calib_copy", "aacg_timer_create", "aacg_timer_record", "aacg_timer_elapsed_ms", "aacg_timer_destroy",
-                 "aacg_pipeline_chained", "aacg_debug_transform", "aacg_debug_set_route", "aacg_debug_route", "aacg_debug_run_kernel"]
+                 "aacg_pipeline_chained", "aacg_pipeline_concurrent", "aacg_debug_transform", "aacg_debug_set_route", "aacg_debug_route", "aacg_debug_run_kernel"]
 # aacg_debug_set_route / aacg_debug_route flags
 DEBUG_ROUTE_UNFUSED_COUPLING, DEBUG_ROUTE_RECOMPUTE = 1, 8
 ROUTE_PLAN_TNS, ROUTE_PLAN_PNS, ROUTE_PLAN_LONG_CHAINS, ROUTE_PLAN_FULL_LATER_RUNS = 1, 2, 4, 8
@@ -125,6 +125,7 @@ def load_library(path=LIB_PATH):
     L.aacg_pipeline_join.argtypes = [C.c_void_p, C.c_void_p]
     L.aacg_pipeline_chained.argtypes = [C.c_void_p]
     L.aacg_pipeline_chained.restype = C.c_uint64
+    L.aacg_pipeline_concurrent.argtypes = [C.c_void_p]
     L.aacg_debug_route.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_size_t]
     L.aacg_debug_run_kernel.argtypes = [C.c_int, C.c_char_p, C.c_size_t]
     L.aacg_plan_refresh_units.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
@@ -500,6 +501,10 @@ class Engine:
     def pipeline_chained(self):
         """Launches of decode_pipelined that continued (and were allowed to overlap) the launch before them."""
         return int(self.lib.aacg_pipeline_chained(self.handle))
+
+    def pipeline_concurrent(self):
+        """True if the engine's two internal streams were seen to run side by side (else pipelined launches serialise: correct, not faster)."""
+        return bool(self.lib.aacg_pipeline_concurrent(self.handle))
 
     def plan_refresh_from_parse(self, plan, d_parsed_units, d_results, max_units, d_refused, stream=0):
         """Device pointers: the plan's unit records take what aacg_parse_device wrote (run tables unchanged)."""

@@ -439,7 +439,8 @@ def main():
                    "realtime_multiple": value / 46.875, "sharding": "streams over ranks, no data-path collective", "pipelines": args.pipelines,
                    "launches": ("aacg_decode_pipelined: ONE plan, the same %d streams continued launch after launch on the engine's two internal HIP "
                                 "streams taken in turn; consecutive launches overlap, their chains meet in rendezvous cells (nobody waits); %d of the %d "
-                                "launches of this process continued the launch before them" % (n_streams, eng.pipeline_chained(), n_pre + args.warmup + R * args.steps + (0 if args.no_parity else 1)))
+                                "launches of this process continued the launch before them; the two streams were %s" % (n_streams, eng.pipeline_chained(), n_pre + args.warmup + R * args.steps + (0 if args.no_parity else 1),
+                                   "seen to run side by side when the pipeline was set up" if eng.pipeline_concurrent() else "NOT seen to run side by side (one hardware queue): the launches serialise"))
                                if pipelined else "aacg_decode_device: every launch behind the one before it on one HIP stream",
                    "preconditioning": "%d untimed steps (%.0f ms of load) before the warm-up steps: steady GPU clocks" % (n_pre, args.precondition_ms),
                    "tns": "identity, as the reference executes it" if tns is None

@@ -25,6 +25,9 @@ void aacg_timer_destroy(void* mark);
 /* How many launches of aacg_decode_pipelined continued the launch before them through the cross-launch cells (and so were
  * allowed to overlap it) since the engine was made: tests assert that the route they mean to exercise was taken. */
 uint64_t aacg_pipeline_chained(const aacg_engine* e);
+/* 1 if the engine's two internal streams were seen to run side by side when the pipeline was set up (HIP multiplexes streams onto a
+ * few hardware queues; two streams on one queue serialise): 0 = pipelined launches are correct but do not overlap. */
+int aacg_pipeline_concurrent(const aacg_engine* e);
 
 /* Diagnostic: the IMDCT stage of the kernels on its own, for known-answer tests against the reference's MDCT.process
  * (mdct.js:62-115) and FFT.process (fft.js:105-192) vectors.  One spectrum in (1024 floats: one long window, or eight

@@ -179,7 +179,7 @@ int emu_plan_refresh(const aacg_unit_desc* first, const aacg_unit_desc* next, ui
     return aacg_plan_refresh_host(&ph, next, n_units, sample_index, tns_spec != 0, &g_err);
 }
 
-/* full path: plan + "launch".  overlap_pool: [max_streams][max_channels][AACG_OV_BUFFERS][1024]; parity: [max_streams*max_channels] (0..2), updated. */
+/* full path: plan + "launch".  overlap_pool: [max_streams][max_channels][AACG_OV_BUFFERS][1024]; parity: [max_streams*max_channels] (0..AACG_OV_BUFFERS-1), updated. */
 int emu_decode_tns(int input_kind, int sample_index, int max_streams, int max_channels,
                    const aacg_unit_desc* units, uint32_t n_units, const void* coeffs, const aacg_band_meta* meta,
                    const aacg_tns_info* tns, uint32_t n_tns,
@@ -321,7 +321,7 @@ int emu_decode_cce(int input_kind, int sample_index, int max_streams, int max_ch
  * emulator runs one workgroup at a time, in an order the engine's ordering rules allow: only neighbouring launches overlap
  * (launch j + 2 starts after launch j is complete).  order: 0 = launch after launch; 1 = within every pair (j, j + 1) the LATER
  * launch's workgroups first (every consumer leaves its first half, every producer finishes a frame of the next launch);
- * >= 2: the workgroups of the two launches in flight interleaved at random (seed = order).
+ * >= 2: the workgroups of all launches the engine's ordering rules allow to be in flight, interleaved at random (seed = order).
  * xl_cells: [max_streams][max_channels][3] records of 4 x u64 (aacg_xl_cell), xl_head: like the overlap pool; both kept by the
  * caller so that a sequence can be continued by a later call (first_epoch_in: 0 = its input state is complete; else the epoch
  * the previous call returned in *last_epoch, i.e. that call's last launch is "still in flight"). */
@@ -368,24 +368,30 @@ int emu_decode_pipelined(int input_kind, int sample_index, int max_streams, int 
             for (int b = 0; b < B; b++) sched.emplace_back(j, b);
         }
     } else {
-        /* two launches in flight: draw the next workgroup from either, in each launch's own (shuffled) order; when the older
-         * one is exhausted the next launch enters */
+        /* the engine's ordering rules, exactly (aacg_decode_pipelined): launch j goes to stream j & 1, so it starts after launch
+         * j - 2 is complete; every q-th launch of a stream also waits for launch j - 3, q = (AACG_OV_BUFFERS - 1) / 2.  Among the
+         * launches those rules allow to run, the next workgroup is drawn at random, in each launch's own shuffled block order */
         uint32_t rng = (uint32_t)order * 2654435761u + 12345u;
         auto next = [&]() { rng ^= rng << 13; rng ^= rng >> 17; rng ^= rng << 5; return rng; };
+        const int q = (AACG_OV_BUFFERS - 1) / 2;
         std::vector<std::vector<int>> left((size_t)n_launches);
         for (int j = 0; j < n_launches; j++) {
             for (int b = 0; b < B; b++) left[(size_t)j].push_back(b);
             for (int b = B - 1; b > 0; b--) std::swap(left[(size_t)j][(size_t)b], left[(size_t)j][next() % (uint32_t)(b + 1)]);
         }
-        int lo = 0;
-        while (lo < n_launches) {
-            const int hi = lo + 1 < n_launches ? lo + 1 : lo;
-            int j = (next() & 1u) ? hi : lo;
-            if (left[(size_t)j].empty()) j = j == lo ? hi : lo;
-            if (left[(size_t)lo].empty()) { lo++; continue; }
-            if (left[(size_t)j].empty()) j = lo;
+        auto done = [&](int j) { return j < 0 || left[(size_t)j].empty(); };
+        size_t remaining = (size_t)n_launches * (size_t)B;
+        while (remaining) {
+            std::vector<int> ready;
+            for (int j = 0; j < n_launches; j++) {
+                if (left[(size_t)j].empty() || !done(j - 2)) continue;
+                if (j >= 3 && ((j >> 1) % q) == 0 && !done(j - 3)) continue;
+                ready.push_back(j);
+            }
+            const int j = ready[next() % (uint32_t)ready.size()];
             sched.emplace_back(j, left[(size_t)j].back());
             left[(size_t)j].pop_back();
+            remaining--;
         }
     }
     for (auto& jb : sched)

@@ -13,7 +13,7 @@ RUN_DTYPE = np.dtype([("pred_unit", "<i4"), ("n_units", "<i4"), ("unit", "<i4", 
                       ("ov0", "<i4", (2,)), ("rot", "<i4", (2,)), ("is_last", "<i4"), ("reserved", "<i4")])
 
 
-OV_BUFFERS = 3          # AACG_OV_BUFFERS: rotating overlap buffers per channel (aacg_device.h)
+OV_BUFFERS = 5          # AACG_OV_BUFFERS: rotating overlap buffers per channel (aacg_device.h)
 
 
 def new_pool(streams, channels):

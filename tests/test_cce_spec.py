@@ -134,7 +134,7 @@ def test_emulated_kernels_vs_oracle(oracle, layout, points):
     H = wl["C"] + len(points)
     ov = np.zeros((S, H, 1024), np.float32)
     ref = oracle.decode_batch(units, q, meta, wl["n_pcm"], ov, cce=cce)
-    pool = np.zeros((S, H, 3, 1024), np.float32)
+    pool = np.zeros((S, H, emu_lib.OV_BUFFERS, 1024), np.float32)
     par = np.zeros(S * H, np.uint8)
     got = emu_lib.Emu().decode(units, q, meta, wl["n_pcm"], pool, par, cce=cce)
     assert rel(got, ref) < RMS_REL
@@ -153,7 +153,7 @@ def test_fused_and_separate_independent_coupling_agree(oracle):
         H = wl["C"] + len(points)
         outs = []
         for unfused in (False, True):
-            pool = np.zeros((S, H, 3, 1024), np.float32)
+            pool = np.zeros((S, H, emu_lib.OV_BUFFERS, 1024), np.float32)
             outs.append(emu_lib.Emu().decode(units, q, meta, wl["n_pcm"], pool, np.zeros(S * H, np.uint8), cce=cce, unfused=unfused))
         assert np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32))
         ov = np.zeros((S, H, 1024), np.float32)
@@ -162,7 +162,7 @@ def test_fused_and_separate_independent_coupling_agree(oracle):
 
 def test_planner_refuses_coupling_elements_without_the_mode(oracle):
     wl, units, q, meta, cce = workload(("cpe",), (0,))
-    pool = np.zeros((2, 3, 3, 1024), np.float32)
+    pool = np.zeros((2, 3, emu_lib.OV_BUFFERS, 1024), np.float32)
     with pytest.raises(RuntimeError, match="coupling channel element"):
         emu_lib.Emu().decode(units, q, meta, wl["n_pcm"], pool, np.zeros(6, np.uint8))          # no cce records: AACG_CCE_REFERENCE
     bad = cce.copy()
@@ -322,7 +322,7 @@ def test_js_host_coupling_records(oracle, tmp_path):
     C, H, n = info["channels"], info["channels"] + info["hidden"], info["frames"]
     ov = np.zeros((1, H, 1024), np.float32)
     ref = oracle.decode_batch(units, q, meta, n * 1024 * C, ov, cce=cce)
-    pool = np.zeros((1, H, 3, 1024), np.float32)
+    pool = np.zeros((1, H, emu_lib.OV_BUFFERS, 1024), np.float32)
     got = emu_lib.Emu().decode(units, q, meta, n * 1024 * C, pool, np.zeros(H, np.uint8), cce=cce)
     assert rel(got, ref) < RMS_REL
     dropped = oracle.decode_batch(units[(units["flags"] & aacgpu.UNIT_CCE) == 0], q, meta, n * 1024 * C, np.zeros((1, H, 1024), np.float32))

@@ -51,7 +51,7 @@ def test_scenarios_vs_reference(emu, golden, name, inp):
     units = golden[name + ".units"].view(orc.UNIT_DTYPE).ravel()
     ref = golden[name + ".pcm"]
     C = ref.shape[2]
-    pool = np.zeros((1, C, 3, 1024), np.float32)
+    pool = np.zeros((1, C, emu_lib.OV_BUFFERS, 1024), np.float32)
     par = np.zeros(C, np.uint8)
     pcm = emu.decode(units, golden[name + "." + inp], golden[name + ".meta"] if inp == "q" else None, ref.size, pool, par)
     assert not np.isnan(pcm).any()
@@ -76,7 +76,7 @@ def test_cfg1(emu, golden):
     units["ch"]["max_sfb"][0, 0] = 49
     units["ch"]["group_count"][0, 0] = 1
     units["ch"]["group_len"][0, 0, 0] = 1
-    pool = np.zeros((1, 1, 3, 1024), np.float32)
+    pool = np.zeros((1, 1, emu_lib.OV_BUFFERS, 1024), np.float32)
     par = np.zeros(1, np.uint8)
     pcm = emu.decode(units, golden["cfg1.spec"], None, 1024, pool, par)
     assert rms(pcm, golden["cfg1.pcm"]) < RMS_TOL
@@ -88,7 +88,7 @@ def test_batches_chain_like_one_long_batch(emu, golden, oracle):
     name = "scn_stereo"
     units = golden[name + ".units"].view(orc.UNIT_DTYPE).ravel().copy()
     ref = golden[name + ".pcm"]
-    pool = np.zeros((1, 2, 3, 1024), np.float32)
+    pool = np.zeros((1, 2, emu_lib.OV_BUFFERS, 1024), np.float32)
     par = np.zeros(2, np.uint8)
     got = np.empty(ref.size, np.float32)
     for lo, hi in ((0, 5), (5, 6), (6, 18)):                    # 5 + 1 + 12 frames
@@ -120,7 +120,7 @@ def test_synthetic_multistream_vs_oracle(emu, oracle, mix, layout, intensity):
     C = wl["C"]
     ov = np.zeros((S, C, 1024), np.float32)
     ref, spec_ref = oracle.decode_batch(wl["units"], wl["q"], wl["meta"], wl["n_pcm"], ov, want_spec=True)
-    pool = np.zeros((S, C, 3, 1024), np.float32)
+    pool = np.zeros((S, C, emu_lib.OV_BUFFERS, 1024), np.float32)
     par = np.zeros(S * C, np.uint8)
     pcm = emu.decode(wl["units"], wl["q"], wl["meta"], wl["n_pcm"], pool, par)
     assert rms(pcm, ref) < RMS_TOL
@@ -176,7 +176,7 @@ def test_uncovered_channels_are_zero(emu):
     u = wl["units"].copy()
     u["n_out_ch"] = 2
     u["pcm_offset"] = np.arange(2) * 2048
-    pool = np.zeros((1, 2, 3, 1024), np.float32)
+    pool = np.zeros((1, 2, emu_lib.OV_BUFFERS, 1024), np.float32)
     par = np.zeros(2, np.uint8)
     pcm = emu.decode(u, wl["q"], wl["meta"], 4096, pool, par).reshape(2, 1024, 2)
     assert (pcm[:, :, 1] == 0).all() and np.abs(pcm[:, :, 0]).max() > 0
@@ -200,7 +200,7 @@ def test_ragged_streams_and_eight_channels(emu, oracle):
     n_pcm = sum(counts) * 2048
     ov = np.zeros((4, 2, 1024), np.float32)
     ref = oracle.decode_batch(units, q, meta, n_pcm, ov)
-    pool = np.zeros((4, 2, 3, 1024), np.float32)
+    pool = np.zeros((4, 2, emu_lib.OV_BUFFERS, 1024), np.float32)
     par = np.zeros(8, np.uint8)
     pcm = emu.decode(units, q, meta, n_pcm, pool, par)
     assert rms(pcm, ref) < RMS_TOL
@@ -209,7 +209,7 @@ def test_ragged_streams_and_eight_channels(emu, oracle):
     wl = aacgpu_workload.make_batch(n_streams=1, n_frames=3, layout=("cpe", "sce", "cpe", "cpe", "sce"), mix=True, seed=77)
     ov = np.zeros((1, 8, 1024), np.float32)
     ref = oracle.decode_batch(wl["units"], wl["q"], wl["meta"], wl["n_pcm"], ov)
-    pool = np.zeros((1, 8, 3, 1024), np.float32)
+    pool = np.zeros((1, 8, emu_lib.OV_BUFFERS, 1024), np.float32)
     par = np.zeros(8, np.uint8)
     pcm = emu.decode(wl["units"], wl["q"], wl["meta"], wl["n_pcm"], pool, par)
     assert rms(pcm, ref) < RMS_TOL
@@ -227,7 +227,7 @@ def test_multichannel_long_chains(emu, oracle, layout, T):
     S = 2
     C = sum(2 if e == "cpe" else 1 for e in layout)
     ov = np.zeros((S, C, 1024), np.float32)
-    pool = np.zeros((S, C, 3, 1024), np.float32)
+    pool = np.zeros((S, C, emu_lib.OV_BUFFERS, 1024), np.float32)
     par = np.zeros(S * C, np.uint8)
     for batch in range(2):
         wl = aacgpu_workload.make_batch(n_streams=S, n_frames=T, layout=layout, mix=True, intensity=True, seed=900 + batch, frame_base=batch * T)
@@ -255,7 +255,7 @@ def test_int16_output(emu, oracle, layout, T):
     wl = aacgpu_workload.make_batch(n_streams=S, n_frames=T, layout=layout, mix=True, intensity=True, seed=31)
     ov = np.zeros((S, C, 1024), np.float32)
     want = pcm16(oracle.decode_batch(wl["units"], wl["q"], wl["meta"], wl["n_pcm"], ov))
-    pool = np.zeros((S, C, 3, 1024), np.float32)
+    pool = np.zeros((S, C, emu_lib.OV_BUFFERS, 1024), np.float32)
     got = emu.decode(wl["units"], wl["q"], wl["meta"], wl["n_pcm"], pool, np.zeros(S * C, np.uint8), int16_out=True)
     d = got.astype(np.int32) - want
     assert np.abs(d).max() <= 1 and np.count_nonzero(d) <= 1e-2 * d.size, (np.abs(d).max(), np.count_nonzero(d))
@@ -272,7 +272,7 @@ def test_fuzz_vs_oracle(emu, oracle, seed):
     S, C = wl["n_streams"], wl["max_channels"]
     ov = np.zeros((S, C, 1024), np.float32)
     ref, spec_ref = oracle.decode_batch(wl["units"], wl["q"], wl["meta"], wl["n_pcm"], ov, want_spec=True)
-    pool = np.zeros((S, C, 3, 1024), np.float32)
+    pool = np.zeros((S, C, emu_lib.OV_BUFFERS, 1024), np.float32)
     par = np.zeros(S * C, np.uint8)
     pcm = emu.decode(wl["units"], wl["q"], wl["meta"], wl["n_pcm"], pool, par)
     rms(pcm, ref)
@@ -291,7 +291,7 @@ def test_long_chains_double_duty(emu, oracle, T, want):
     assert sum(int(r["pred_unit"]) >= 0 for r in runs) == len(want) - 1
     ov = np.zeros((1, 2, 1024), np.float32)
     ref = oracle.decode_batch(wl["units"], wl["q"], wl["meta"], wl["n_pcm"], ov)
-    pool = np.zeros((1, 2, 3, 1024), np.float32)
+    pool = np.zeros((1, 2, emu_lib.OV_BUFFERS, 1024), np.float32)
     par = np.zeros(2, np.uint8)
     pcm = emu.decode(wl["units"], wl["q"], wl["meta"], wl["n_pcm"], pool, par)
     assert rms(pcm, ref) < RMS_TOL
@@ -300,7 +300,7 @@ def test_long_chains_double_duty(emu, oracle, T, want):
     wl = _workload(n_streams=1, n_frames=T, layout=("sce",), mix=True, seed=T + 1)
     ov = np.zeros((1, 1, 1024), np.float32)
     ref, spec = oracle.decode_batch(wl["units"], wl["q"], wl["meta"], wl["n_pcm"], ov, want_spec=True)
-    pool = np.zeros((1, 1, 3, 1024), np.float32)
+    pool = np.zeros((1, 1, emu_lib.OV_BUFFERS, 1024), np.float32)
     par = np.zeros(1, np.uint8)
     pcm = emu.decode(wl["units"], spec, None, wl["n_pcm"], pool, par)
     assert rms(pcm, ref) < RMS_TOL
@@ -324,7 +324,7 @@ def test_other_sample_rates_vs_oracle(emu, oracle, sample_index, max_long):
     S, C = wl["n_streams"], wl["max_channels"]
     ov = np.zeros((S, C, 1024), np.float32)
     ref, spec_ref = oracle.decode_batch(units, wl["q"], wl["meta"], wl["n_pcm"], ov, sample_index=sample_index, want_spec=True)
-    pool = np.zeros((S, C, 3, 1024), np.float32)
+    pool = np.zeros((S, C, emu_lib.OV_BUFFERS, 1024), np.float32)
     par = np.zeros(S * C, np.uint8)
     pcm = emu.decode(units, wl["q"], wl["meta"], wl["n_pcm"], pool, par, sample_index=sample_index)
     rms(pcm, ref)

@@ -68,7 +68,7 @@ def test_streams_oracle_and_emulator(oracle, case):
     assert len(ref) == case["frames"] * C * 1024
     ov = np.zeros((1, C, 1024), np.float32)
     check(oracle.decode_batch(units, q, meta, ref.size, ov, sample_index=si), ref)
-    pool = np.zeros((1, C, 3, 1024), np.float32)
+    pool = np.zeros((1, C, emu_lib.OV_BUFFERS, 1024), np.float32)
     par = np.zeros(C, np.uint8)
     check(emu_lib.Emu().decode(units, q, meta, ref.size, pool, par, sample_index=si), ref)
 

@@ -95,7 +95,7 @@ def test_emulated_kernels_pns_vs_oracle(emu, oracle, seed):
     S, C = wl["n_streams"], wl["max_channels"]
     ov = np.zeros((S, C, 1024), np.float32)
     ref = oracle.decode_batch(units, wl["q"], meta, wl["n_pcm"], ov, pns=True)
-    pool = np.zeros((S, C, 3, 1024), np.float32)
+    pool = np.zeros((S, C, emu_lib.OV_BUFFERS, 1024), np.float32)
     par = np.zeros(S * C, np.uint8)
     pcm = emu.decode(units, wl["q"], meta, wl["n_pcm"], pool, par, pns=True)
     assert _rel(pcm, ref) < REL_TOL
@@ -109,7 +109,7 @@ def test_emulated_pns_long_chain_and_grouped_shorts(emu, oracle):
     units, meta = W.add_pns(wl, seed=5, p_unit=1.0, p_band=0.4)
     ov = np.zeros((1, 2, 1024), np.float32)
     ref = oracle.decode_batch(units, wl["q"], meta, wl["n_pcm"], ov, pns=True)
-    pool = np.zeros((1, 2, 3, 1024), np.float32)
+    pool = np.zeros((1, 2, emu_lib.OV_BUFFERS, 1024), np.float32)
     par = np.zeros(2, np.uint8)
     pcm = emu.decode(units, wl["q"], meta, wl["n_pcm"], pool, par, pns=True)
     assert _rel(pcm, ref) < REL_TOL

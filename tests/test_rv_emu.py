@@ -26,7 +26,7 @@ def test_rendezvous_route_equals_the_recompute_route_bit_for_bit(oracle, layout,
     coeffs, meta = (wl["q"], wl["meta"]) if seam == "q" else (spec.astype(np.float32), None)
     got = []
     for rv in (1, 2, 0):
-        pool, par = np.zeros((S, C, 3, 1024), np.float32), np.zeros(S * C, np.uint8)
+        pool, par = np.zeros((S, C, emu_lib.OV_BUFFERS, 1024), np.float32), np.zeros(S * C, np.uint8)
         pcm = emu.decode(wl["units"], coeffs, meta, wl["n_pcm"], pool, par, rv=rv)
         got.append((pcm, emu_lib.pool_current(pool, par)))
     d = got[0][0].astype(np.float64) - ref

@@ -189,7 +189,7 @@ def test_emulated_kernels_tns_vs_oracle(emu, oracle, seed, wild):
     wl = W.random_batch(seed, n_streams=2, max_frames=5)
     units, tns = W.add_tns(wl, seed=seed, wild=wild)
     ref, ov, S, C = _decode_pair(oracle, wl, tns, units=units)
-    pool = np.zeros((S, C, 3, 1024), np.float32)
+    pool = np.zeros((S, C, emu_lib.OV_BUFFERS, 1024), np.float32)
     par = np.zeros(S * C, np.uint8)
     pcm = emu.decode(units, wl["q"], wl["meta"], wl["n_pcm"], pool, par, tns=tns)
     tol = KERNEL_REL_TOL_WILD if wild else KERNEL_REL_TOL
@@ -216,7 +216,7 @@ def test_emulated_kernels_tns_f32_seam(emu, oracle):
     ov2 = np.zeros_like(ov)
     ref_q = oracle.decode_batch(units, wl["q"], wl["meta"], wl["n_pcm"], ov2, tns=tns)
     assert np.array_equal(ref.view(np.uint32), ref_q.view(np.uint32))    # both seams agree in the oracle
-    pool = np.zeros((2, 2, 3, 1024), np.float32)
+    pool = np.zeros((2, 2, emu_lib.OV_BUFFERS, 1024), np.float32)
     par = np.zeros(4, np.uint8)
     pcm = emu.decode(units, spec, None, wl["n_pcm"], pool, par, tns=tns)
     assert _rel(pcm, ref) < KERNEL_REL_TOL
@@ -231,12 +231,12 @@ def test_emulated_one_launch_and_staged_routes_agree(emu, oracle, seed):
     S, C = int(units["stream"].max()) + 1, 8
     out = []
     for staged in (False, True):
-        pool = np.zeros((S, C, 3, 1024), np.float32)
+        pool = np.zeros((S, C, emu_lib.OV_BUFFERS, 1024), np.float32)
         par = np.zeros(S * C, np.uint8)
         out.append((emu.decode(units, wl["q"], wl["meta"], wl["n_pcm"], pool, par, tns=tns, staged=staged), pool.copy()))
     assert np.array_equal(out[0][0].view(np.uint32), out[1][0].view(np.uint32))
     assert np.array_equal(out[0][1].view(np.uint32), out[1][1].view(np.uint32))
-    pool = np.zeros((S, C, 3, 1024), np.float32)
+    pool = np.zeros((S, C, emu_lib.OV_BUFFERS, 1024), np.float32)
     par = np.zeros(S * C, np.uint8)
     p16 = emu.decode(units, wl["q"], wl["meta"], wl["n_pcm"], pool, par, tns=tns, int16_out=True)
     want = np.clip(np.rint(out[0][0].astype(np.float64) * 32768.0), -32768, 32767).astype(np.int32)
@@ -247,7 +247,7 @@ def test_emulated_one_launch_and_staged_routes_agree(emu, oracle, seed):
 def test_planner_rejects_bad_tns(emu):
     wl = W.make_batch(n_streams=1, n_frames=2, seed=1)
     units, tns = W.add_tns(wl, seed=1, p_channel=1.0)
-    pool = np.zeros((1, 2, 3, 1024), np.float32)
+    pool = np.zeros((1, 2, emu_lib.OV_BUFFERS, 1024), np.float32)
     par = np.zeros(2, np.uint8)
     bad = units.copy()
     bad["tns_offset"][1] = len(tns)                   # points outside the array
@@ -406,7 +406,7 @@ def test_emulated_tns_long_chain(emu, oracle):
     units, tns = W.add_tns(wl, seed=9)
     ov = np.zeros((1, 2, 1024), np.float32)
     ref = oracle.decode_batch(units, wl["q"], wl["meta"], wl["n_pcm"], ov, tns=tns)
-    pool = np.zeros((1, 2, 3, 1024), np.float32)
+    pool = np.zeros((1, 2, emu_lib.OV_BUFFERS, 1024), np.float32)
     par = np.zeros(2, np.uint8)
     pcm = emu.decode(units, wl["q"], wl["meta"], wl["n_pcm"], pool, par, tns=tns)
     assert _rel(pcm, ref) < KERNEL_REL_TOL
@@ -435,7 +435,7 @@ def test_config3_tns_workload(emu, oracle):
     assert len(tns) == 2 * len(units) and all(int(u["ch"][c]["flags"]) & 1 for u in units for c in range(2))
     ov = np.zeros((2, 2, 1024), np.float32)
     ref = oracle.decode_batch(units, wl["q"], wl["meta"], wl["n_pcm"], ov, tns=tns)
-    pool = np.zeros((2, 2, 3, 1024), np.float32)
+    pool = np.zeros((2, 2, emu_lib.OV_BUFFERS, 1024), np.float32)
     par = np.zeros(4, np.uint8)
     pcm = emu.decode(units, wl["q"], wl["meta"], wl["n_pcm"], pool, par, tns=tns)
     assert _rel(pcm, ref) < KERNEL_REL_TOL

@@ -3,8 +3,9 @@ frame of a chain in launch k and its first frame in launch k + 1 meet in a rende
 publishes (the windowed tail = the new overlap state, or the windowed first half plus where the finished samples go), the
 second finishes the frame; nobody waits (reference: the hand-over of filter_bank.js:105-118 through `overlaps`, :38-41).
 
-The lane emulator runs one workgroup at a time, in every kind of order the engine's ordering rules allow (only neighbouring
-launches overlap): launch after launch, the LATER launch of every pair first, and random interleavings.  All of them must give
+The lane emulator runs one workgroup at a time, in every kind of order the engine's ordering rules allow (launch n behind
+launch n - 2 by its stream, every other launch of a stream behind launch n - 3 by an event): launch after launch, the LATER
+launch of every pair first, and random interleavings of everything those rules let be in flight.  All of them must give
 the BITS of the serialised route (one aacg_decode_device after the other: the plain kernels) — PCM of every launch and the
 overlap state at the end — and the oracle's values."""
 import os
@@ -48,8 +49,8 @@ def _batches(S, T, layout, n, seam, oracle, seed):
     return base, C, coeffs, (metas if seam == "q" else None), refs, ov
 
 
-@pytest.mark.parametrize("layout,S,T,n,seam", [(("cpe",), 3, 16, 5, "q"), (("cpe",), 2, 7, 4, "f"), (("sce",), 2, 16, 4, "q"),
-                                                (("cpe",), 1, 37, 4, "q"), (("cpe", "cpe", "cpe", "sce"), 1, 5, 4, "q"), (("sce", "cpe"), 1, 18, 3, "f")])
+@pytest.mark.parametrize("layout,S,T,n,seam", [(("cpe",), 3, 16, 7, "q"), (("cpe",), 2, 7, 6, "f"), (("sce",), 2, 16, 4, "q"),
+                                                (("cpe",), 1, 37, 4, "q"), (("cpe", "cpe", "cpe", "sce"), 1, 5, 6, "q"), (("sce", "cpe"), 1, 18, 3, "f")])
 def test_overlapped_launches_equal_the_serialised_route_bit_for_bit(emu, oracle, layout, S, T, n, seam):
     base, C, coeffs, metas, refs, ov = _batches(S, T, layout, n, seam, oracle, 71)
     # the serialised route: one launch after the other, each from the complete state the one before left
