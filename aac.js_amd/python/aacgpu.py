@@ -30,13 +30,13 @@ ABI_SYMBOLS = ["aacg_create", "aacg_destroy", "aacg_last_error", "aacg_abi_versi
                "aacg_decode_pipelined", "aacg_pipeline_fork", "aacg_pipeline_join"]
 # ... and include/aacgpu_tools.h (measurement and diagnostics: bench.py, tools/, tests)
 TOOLS_SYMBOLS = ["aacg_calib_copy", "aacg_timer_create", "aacg_timer_record", "aacg_timer_elapsed_ms", "aacg_timer_destroy",
-                 "aacg_pipeline_chained", "aacg_pipeline_concurrent", "aacg_debug_transform", "aacg_debug_set_route", "aacg_debug_route", "aacg_debug_run_kernel"]
+                 "aacg_pipeline_chained", "aacg_pipeline_concurrent", "aacg_decode_pipelined_timed", "aacg_debug_transform", "aacg_debug_set_route", "aacg_debug_route", "aacg_debug_run_kernel"]
 # aacg_debug_set_route / aacg_debug_route flags
-DEBUG_ROUTE_UNFUSED_COUPLING, DEBUG_ROUTE_RECOMPUTE = 1, 8
+DEBUG_ROUTE_UNFUSED_COUPLING, DEBUG_ROUTE_RECOMPUTE, DEBUG_ROUTE_HALF_RUNS = 1, 8, 16
 ROUTE_PLAN_TNS, ROUTE_PLAN_PNS, ROUTE_PLAN_LONG_CHAINS, ROUTE_PLAN_FULL_LATER_RUNS = 1, 2, 4, 8
 ROUTE_PLAN_WIDE_FRAMES, ROUTE_PLAN_CCE_INDEPENDENT, ROUTE_PLAN_CCE_DEPENDENT, ROUTE_PLAN_NO_RUNS = 0x10, 0x20, 0x40, 0x80
 # switches of a run kernel (aacg_routes.h), as aacg_debug_run_kernel returns them
-RK_QUANT, RK_I16, RK_DD, RK_EX, RK_CPL, RK_RV, RK_NT = 1, 2, 4, 8, 16, 32, 64
+RK_QUANT, RK_I16, RK_DD, RK_EX, RK_CPL, RK_RV, RK_NT, RK_HALF = 1, 2, 4, 8, 16, 32, 64, 128
 
 UNIT_DTYPE = np.dtype([
     ("stream", "<u4"), ("pcm_offset", "<u4"), ("channel", "<u2"), ("n_out_ch", "<u2"),
@@ -121,6 +121,7 @@ def load_library(path=LIB_PATH):
     L.aacg_plan_kernels.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.c_size_t]
     L.aacg_plan_kernels_ex.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_char_p, C.c_size_t]
     L.aacg_decode_pipelined.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.aacg_decode_pipelined_timed.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.aacg_pipeline_fork.argtypes = [C.c_void_p, C.c_void_p]
     L.aacg_pipeline_join.argtypes = [C.c_void_p, C.c_void_p]
     L.aacg_pipeline_chained.argtypes = [C.c_void_p]
@@ -485,10 +486,14 @@ class Engine:
         """d_* are raw device addresses (e.g. torch.Tensor.data_ptr()); stream a hipStream_t handle or 0."""
         self._check(self.lib.aacg_decode_device(self.handle, plan.handle, d_coeffs, d_meta, d_pcm, stream))
 
-    def decode_pipelined(self, plan, d_coeffs, d_meta, d_pcm):
+    def decode_pipelined(self, plan, d_coeffs, d_meta, d_pcm, mark=None):
         """aacg_decode_pipelined: the next launch of `plan` on the engine's two internal streams taken in turn; it may overlap the
-        launch before it (their chains meet in rendezvous cells).  Results: after pipeline_join / synchronize."""
-        self._check(self.lib.aacg_decode_pipelined(self.handle, plan.handle, d_coeffs, d_meta, d_pcm))
+        launch before it (their chains meet in rendezvous cells).  Results: after pipeline_join / synchronize.
+        mark: a TimerMark bound to the launch's completion (aacg_decode_pipelined_timed; measurement only)."""
+        if mark is not None:
+            self._check(self.lib.aacg_decode_pipelined_timed(self.handle, plan.handle, d_coeffs, d_meta, d_pcm, mark.h))
+        else:
+            self._check(self.lib.aacg_decode_pipelined(self.handle, plan.handle, d_coeffs, d_meta, d_pcm))
 
     def pipeline_fork(self, stream):
         """The pipeline's later launches start after everything enqueued on `stream` so far."""

@@ -215,6 +215,8 @@ def main():
     ap.add_argument("--no-parity", action="store_true", help="skip the untimed oracle comparison after the timed region")
     ap.add_argument("--pipelines", type=int, default=1, choices=[1, 2],
                     help="2: alternate batches of two disjoint stream sets on two HIP streams (supplementary figure; implies --serial)")
+    ap.add_argument("--half", action="store_true",
+                    help="EXPERIMENT: plain batches on the 8-wave workgroups (runs of 8 frames, two workgroups per CU; AACG_DEBUG_ROUTE_HALF_RUNS)")
     ap.add_argument("--serial", action="store_true",
                     help="launch through aacg_decode_device on one HIP stream, every launch behind the one before it (rounds 1-4) instead "
                          "of aacg_decode_pipelined")
@@ -267,6 +269,8 @@ def main():
                         tns_mode=aacgpu.TNS_SPEC if args.tns == "spec" else aacgpu.TNS_REFERENCE,
                         output_kind=aacgpu.OUTPUT_I16 if args.output == "i16" else aacgpu.OUTPUT_F32)
 
+    if args.half:
+        eng.debug_set_route(aacgpu.DEBUG_ROUTE_HALF_RUNS)
     # rank r owns its own streams: independent data per rank, same shape
     base = aacgpu_workload.make_batch(n_streams=n_streams, n_frames=n_frames, mix=mix, layout=layout,
                                       seed=aacgpu_shard.rank_seed(0xAAC00002, rank))
@@ -306,10 +310,10 @@ def main():
 
     pipelined = not args.serial and args.pipelines == 1
 
-    def step(i):
+    def step(i, mark=None):
         d_in, d_out = bufs[i % args.nbuf]
         if pipelined:                                  # the engine's two internal streams in turn: launch i may overlap launch i - 1
-            eng.decode_pipelined(plans[0], d_in.data_ptr(), meta_ptr, d_out.data_ptr())
+            eng.decode_pipelined(plans[0], d_in.data_ptr(), meta_ptr, d_out.data_ptr(), mark)
             return
         pl = i % args.pipelines
         eng.decode_device(plans[pl], d_in.data_ptr(), meta_ptr, d_out.data_ptr(), tstreams[pl].cuda_stream)
@@ -348,6 +352,12 @@ def main():
             return self.ev.elapsed_time(later.ev) if args.default_events else self.ev.elapsed_ms(later.ev)
     evs = [_Mark() for _ in range(R + 1)]
     issued = [0.0]
+    # Pipelined launches: a repeat ends when its last launch AND the one before it (which runs beside it on the other stream) are
+    # complete.  Their marks are bound to the dispatches themselves (aacg_decode_pipelined_timed: the time stamp is the
+    # dispatch's end, no marker packet enters a queue, nothing is joined inside the timed region); the opening mark is an
+    # ordinary one on the timing stream, joined behind the warm-up steps.
+    bound = pipelined and not args.default_events
+    tails = [[aacgpu.TimerMark() for _ in range(min(2, args.steps))] for _ in range(R)] if bound else None
 
     def timed_steps():
         t0 = time.perf_counter()
@@ -355,14 +365,20 @@ def main():
         evs[0].record()
         for r in range(R):
             for i in range(args.steps):
-                step(n_pre + args.warmup + r * args.steps + i)
-            join()                                       # a mark's time stamp is the completion of every launch before it
-            evs[r + 1].record()
+                k = args.steps - 1 - i                   # 0 for the repeat's last launch, 1 for the one before it
+                step(n_pre + args.warmup + r * args.steps + i, tails[r][k] if bound and k < len(tails[r]) else None)
+            if not bound:
+                join()                                   # a mark's time stamp is the completion of every launch before it
+                evs[r + 1].record()
         issued[0] = time.perf_counter() - t0             # host time to enqueue the R x K launches
 
     dev = torch.device("cuda", device)
     _, wall = aacgpu_shard.timed(dist, torch.cuda.synchronize, timed_steps, dev)      # barrier + synchronize on both sides, MAX over ranks
-    mine_ms = [evs[r].elapsed_time(evs[r + 1]) for r in range(R)]                     # this rank's R repeats of K steps, on the launch stream
+    if bound:
+        ends = [0.0] + [max(evs[0].ev.elapsed_ms(m) for m in tails[r]) for r in range(R)]      # ms since the opening mark
+        mine_ms = [ends[r + 1] - ends[r] for r in range(R)]
+    else:
+        mine_ms = [evs[r].elapsed_time(evs[r + 1]) for r in range(R)]                 # this rank's R repeats of K steps, on the launch stream
     region_ms = aacgpu_shard.reduce_max_list(dist, mine_ms, dev)                      # MAX over ranks, repeat by repeat
     stats = region_stats(region_ms, args.steps)
     kernel_ms = region_stats(mine_ms, args.steps)["ms_per_step_median"]               # rank 0's own launches, for its roofline
@@ -423,8 +439,11 @@ def main():
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "timing": dict(stats, events=("torch.cuda.Event (default HIP events: a system-scope fence per record)" if args.default_events else
                                       "hipEventDisableSystemFence (timing-only HIP events, aacg_timer_*)"),
-                       method="the K timed steps are run R times back to back, each repeat between its own HIP events on the launch "
-                              "stream (MAX over ranks per repeat); value and ms_per_step: the MEDIAN repeat; wall_*: host clock between "
+                       method=("the K timed steps are run R times back to back; a repeat ends when its last two launches (which run side by "
+                               "side on the engine's two streams) are both complete — HIP events bound to those dispatches' completion "
+                               "(hipExtLaunchKernel stopEvent), the opening event on the timing stream behind the warm-up steps" if bound else
+                               "the K timed steps are run R times back to back, each repeat between its own HIP events on the launch stream") +
+                              " (MAX over ranks per repeat); value and ms_per_step: the MEDIAN repeat; wall_*: host clock between "
                               "the barriers over all R x K steps (adds first-launch latency and the wake-up after the last step)"),
         "wall_ms_per_step": wall / (R * args.steps) * 1e3, "value_wall": world * frames_per_step * R * args.steps / wall,
         "config": {"workload": {"cfg2": "BASELINE config 2: batch of 4096 stereo LC frames (256 streams x 16 frames, ONLY_LONG_SEQUENCE, KBD)",

@@ -22,6 +22,9 @@ int aacg_timer_create(void** mark);
 int aacg_timer_record(void* mark, void* hip_stream);
 int aacg_timer_elapsed_ms(void* first, void* second, float* ms);
 void aacg_timer_destroy(void* mark);
+/* aacg_decode_pipelined with a timing mark bound to the launch's completion (its time stamp is the end of that dispatch; no marker
+ * packet enters the queue): bench.py brackets its timed regions with the marks of the launches at their ends. */
+int aacg_decode_pipelined_timed(aacg_engine* e, aacg_plan* p, const void* d_coeffs, const aacg_band_meta* d_meta, void* d_pcm, void* stop_mark);
 /* How many launches of aacg_decode_pipelined continued the launch before them through the cross-launch cells (and so were
  * allowed to overlap it) since the engine was made: tests assert that the route they mean to exercise was taken. */
 uint64_t aacg_pipeline_chained(const aacg_engine* e);
@@ -47,6 +50,7 @@ int aacg_debug_transform(int device_ordinal, int sample_index, int is_short, int
  * batches; both must produce the same bits.  Set before the plan is made. */
 #define AACG_DEBUG_ROUTE_UNFUSED_COUPLING 1
 #define AACG_DEBUG_ROUTE_RECOMPUTE        8
+#define AACG_DEBUG_ROUTE_HALF_RUNS       16   /* plain stereo / mono batches on the 8-wave workgroups (runs of 8 frames, two workgroups per CU) */
 int aacg_debug_set_route(aacg_engine* e, int flags);
 
 

@@ -18,11 +18,21 @@ else:
     d_in = torch.randn(S * T * wl["C"], 1024, device="cuda") * 1000; mp = None
 d_out = torch.empty(wl["n_pcm"], dtype=torch.float32, device="cuda")
 torch.cuda.synchronize()
-for _ in range(5):
-    eng.decode_device(plan, d_in.data_ptr(), mp, d_out.data_ptr(), 0)
+PIPE = bool(os.environ.get("TL_PIPE"))                                  # TL_PIPE=1: launches through aacg_decode_pipelined (steady state: two in flight)
+N_LAUNCH = int(os.environ.get("TL_LAUNCHES", "41" if PIPE else "5"))
+outs = [torch.empty(wl["n_pcm"], dtype=torch.float32, device="cuda") for _ in range(4)]
+for i in range(N_LAUNCH):
+    if PIPE:
+        eng.decode_pipelined(plan, d_in.data_ptr(), mp, outs[i % 4].data_ptr())
+    else:
+        eng.decode_device(plan, d_in.data_ptr(), mp, d_out.data_ptr(), 0)
 eng.synchronize()
 raw = np.zeros(1 << 20, np.float32)
 eng._check(eng.lib.aacg_get_table(eng.handle, 100, raw.ctypes.data, raw.size))
+if PIPE:                                                                # the last launch stamped half (N - 1) & 1 of the buffer, the one before it the other
+    last, prev = raw[((N_LAUNCH - 1) & 1) << 19:][: 1 << 19], raw[((N_LAUNCH - 2) & 1) << 19:][: 1 << 19]
+    tp = prev.view(np.uint64)[: 256 * 16 * 8].reshape(256, 16, 8).astype(np.float64) * 0.01
+    raw = last
 NW = int(os.environ.get("TL_WAVES", str(min(16, T))))                  # waves of a workgroup that carry a frame (T / 2 for a folded chain)
 NB = int(os.environ.get("TL_BLOCKS", "256"))
 t = raw.view(np.uint64)[: NB * 16 * 8].reshape(NB, 16, 8)[:, :NW].astype(np.float64) * 0.01     # 100 MHz ticks -> us
@@ -33,6 +43,14 @@ for w in range(NW):
     row = [np.median(t[:, w, k] - t0) for k in range(7)]
     print("wave %2d: " % w + "  ".join("%s %6.2f" % (names[k][:14], row[k]) for k in (0, 1, 6, 2, 3, 4, 5)))
 print("kernel span (last stores issued - first start): %.2f us; start skew across WGs: %.2f us" % ((t[:, :, 5].max() - t0), t[:, :, 0].max() - t0))
+if PIPE:
+    NBp = NB
+    sp, ep = tp[:NBp, :NW, 0].min(axis=1), tp[:NBp, :NW, 5].max(axis=1)           # previous launch: per-workgroup start, last stores issued
+    sl, el = t[:, :, 0].min(axis=1), t[:, :, 5].max(axis=1)
+    print("pipelined: previous launch's workgroups start %.2f .. %.2f, issue their last stores %.2f .. %.2f (us, same origin)" % (sp.min() - t0, sp.max() - t0, ep.min() - t0, ep.max() - t0))
+    print("pipelined: this launch's workgroup starts, sorted, against the previous launch's workgroup ends (stores issued), sorted: median lag %.2f us, p10 %.2f, p90 %.2f" % tuple(
+        np.percentile(np.sort(sl) - np.sort(ep), q) for q in (50, 10, 90)))
+    print("pipelined: start-to-start of the two launches (median workgroup): %.2f us; workgroup life (start -> last stores issued) median %.2f us" % (np.median(sl) - np.median(sp), np.median(el - sl)))
 
 # distribution over workgroups: where do the stragglers come from?
 end = t[:, :, 5].max(axis=1) - t0                     # last stores issued per workgroup
