@@ -132,7 +132,7 @@ struct aacg_engine {
     std::string err;
 };
 
-#define AACG_PLAN_BUFFERS 17
+#define AACG_PLAN_BUFFERS 13
 struct aacg_plan {
     aacg_engine* e;
     aacg_plan_host h;
@@ -144,8 +144,7 @@ struct aacg_plan {
     float* d_spec = nullptr;                /* PNS route: f32 spectra between the two kernels */
     void*  d_cce[4] = {nullptr, nullptr, nullptr, nullptr};   /* AACG_CCE_SPEC: coupling elements' runs, jobs, gains, side PCM */
     void*  d_rv[4] = {nullptr, nullptr, nullptr, nullptr};    /* _rv kernels: run table, link records, rendezvous state words and payload (two sets: overlapping launches) */
-    void*  d_rvh[4] = {nullptr, nullptr, nullptr, nullptr};   /* the same for the cut into runs of 8 (8-wave workgroups) */
-    size_t bytes[AACG_PLAN_BUFFERS] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  /* sizes of the buffers above, for the engine's free list */
+    size_t bytes[AACG_PLAN_BUFFERS] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  /* sizes of the buffers above, for the engine's free list */
     hipEvent_t uploaded = nullptr;          /* the tables are on the device */
     hipEvent_t last_use = nullptr;          /* recorded at destruction on last_stream: everything launched with this plan */
     hipStream_t last_stream = nullptr;      /* stream of the most recent launch (no per-launch event: it costs 3 us per step) */
@@ -227,9 +226,9 @@ bool is_pinned(const void* p)
 const aacg_run_kernel* aacg_find_run_kernel(unsigned key)
 {
     const aacg_run_kernel* const tabs[] = {aacg_run_kernels_plain, aacg_run_kernels_rv, aacg_run_kernels_nt, aacg_run_kernels_ext,
-                                           aacg_run_kernels_i16, aacg_run_kernels_exrun, aacg_run_kernels_couple, aacg_run_kernels_half};
+                                           aacg_run_kernels_i16, aacg_run_kernels_exrun, aacg_run_kernels_couple};
     const int counts[] = {aacg_run_kernels_plain_n, aacg_run_kernels_rv_n, aacg_run_kernels_nt_n, aacg_run_kernels_ext_n,
-                          aacg_run_kernels_i16_n, aacg_run_kernels_exrun_n, aacg_run_kernels_couple_n, aacg_run_kernels_half_n};
+                          aacg_run_kernels_i16_n, aacg_run_kernels_exrun_n, aacg_run_kernels_couple_n};
     for (size_t t = 0; t < sizeof tabs / sizeof tabs[0]; t++)
         for (int i = 0; i < counts[t]; i++)
             if (tabs[t][i].key == key) return &tabs[t][i];
@@ -255,7 +254,7 @@ int launch_kernel(aacg_engine* e, const aacg_run_kernel* k, unsigned blocks, hip
     aacg_rv_args v;
     void* args[2] = {&p, nullptr};
     if (k->key & AACG_RK_RV) { v = *V; args[1] = &v; }
-    const dim3 block((k->key & AACG_RK_HALF) ? AACG_WG_THREADS / 2 : AACG_WG_THREADS);
+    const dim3 block(AACG_WG_THREADS);
     if (stop) HIP_TRY(e, hipExtLaunchKernel(k->fn, dim3(blocks), block, args, 0, s, nullptr, stop, 0), AACG_ERR_NO_DEVICE);
     else      HIP_TRY(e, hipLaunchKernel(k->fn, dim3(blocks), block, args, 0, s), AACG_ERR_NO_DEVICE);
     return AACG_OK;
@@ -277,7 +276,7 @@ int launch_run(aacg_engine* e, const aacg_route& R, const aacg_dev_unit* d_units
     P.units = d_units; P.coeffs = d_coeffs; P.meta = d_meta; P.pcm = (float*)d_pcm;
     P.overlap = e->d_overlap; P.tab = e->d_tab; P.flip = flip;
     if (R.rv) {
-        const size_t n_runs = R.half ? h.runs_h.size() : h.runs_rv.size(), n_links = R.half ? h.n_links_h : h.n_links_rv;
+        const size_t n_runs = h.runs_rv.size(), n_links = h.n_links_rv;
         P.runs = rvb.runs; P.n_runs = (int32_t)n_runs;
         aacg_rv_args V;
         std::memset(&V, 0, sizeof V);
@@ -377,7 +376,7 @@ const char* aacg_kernel_name(void) { return "aacg_imdct_run_quant_rv"; }
 
 int aacg_debug_set_route(aacg_engine* e, int flags)
 {
-    if (!e || (flags & ~(AACG_DEBUG_ROUTE_UNFUSED_COUPLING | AACG_DEBUG_ROUTE_RECOMPUTE | AACG_DEBUG_ROUTE_HALF_RUNS))) return AACG_ERR_INVALID_ARG;
+    if (!e || (flags & ~(AACG_DEBUG_ROUTE_UNFUSED_COUPLING | AACG_DEBUG_ROUTE_RECOMPUTE))) return AACG_ERR_INVALID_ARG;
     e->debug_route = flags;
     return AACG_OK;
 }
@@ -426,9 +425,9 @@ int aacg_debug_route(int input_kind, int output_kind, int debug_route, int plan_
 int aacg_debug_run_kernel(int index, char* dst, size_t n)
 {
     const aacg_run_kernel* const tabs[] = {aacg_run_kernels_plain, aacg_run_kernels_rv, aacg_run_kernels_nt, aacg_run_kernels_ext,
-                                           aacg_run_kernels_i16, aacg_run_kernels_exrun, aacg_run_kernels_couple, aacg_run_kernels_half};
+                                           aacg_run_kernels_i16, aacg_run_kernels_exrun, aacg_run_kernels_couple};
     const int counts[] = {aacg_run_kernels_plain_n, aacg_run_kernels_rv_n, aacg_run_kernels_nt_n, aacg_run_kernels_ext_n,
-                          aacg_run_kernels_i16_n, aacg_run_kernels_exrun_n, aacg_run_kernels_couple_n, aacg_run_kernels_half_n};
+                          aacg_run_kernels_i16_n, aacg_run_kernels_exrun_n, aacg_run_kernels_couple_n};
     for (size_t t = 0; t < sizeof tabs / sizeof tabs[0]; t++) {
         if (index < counts[t]) {
             if (!dst || std::strlen(tabs[t][index].name) + 1 > n) return AACG_ERR_INVALID_ARG;
@@ -662,24 +661,19 @@ int aacg_plan_create_ex(aacg_engine* e, const aacg_unit_desc* units, uint32_t n_
     const size_t rvs[4] = {rvp ? sizeof(aacg_run) * p->h.runs_rv.size() : 0, rvp ? sizeof(aacg_rv_link) * p->h.links_rv.size() : 0,
                            rvp ? 2u * sizeof(unsigned long long) * AACG_RV_STATE_WORDS * (size_t)p->h.n_links_rv : 0,
                            rvp ? 2u * sizeof(float) * AACG_RV_DATA_FLOATS * (size_t)p->h.n_links_rv : 0};
-    const bool hp = rvp && !p->h.wide_frames;             /* ... and the cut into runs of 8 for the 8-wave workgroups */
-    const size_t rvh[4] = {hp ? sizeof(aacg_run) * p->h.runs_h.size() : 0, hp ? sizeof(aacg_rv_link) * p->h.links_h.size() : 0,
-                           hp ? 2u * sizeof(unsigned long long) * AACG_RV_STATE_WORDS * (size_t)p->h.n_links_h : 0,
-                           hp ? 2u * sizeof(float) * AACG_RV_DATA_FLOATS * (size_t)p->h.n_links_h : 0};
-    const size_t want[AACG_PLAN_BUFFERS] = {ub, rb, tb, sb, xb, cb[0], cb[1], cb[2], cb[3], rvs[0], rvs[1], rvs[2], rvs[3], rvh[0], rvh[1], rvh[2], rvh[3]};
+    const size_t want[AACG_PLAN_BUFFERS] = {ub, rb, tb, sb, xb, cb[0], cb[1], cb[2], cb[3], rvs[0], rvs[1], rvs[2], rvs[3]};
     void** const slot[AACG_PLAN_BUFFERS] = {(void**)&p->d_units, (void**)&p->d_runs, (void**)&p->d_tns, (void**)&p->d_scratch, (void**)&p->d_spec,
-                             &p->d_cce[0], &p->d_cce[1], &p->d_cce[2], &p->d_cce[3], &p->d_rv[0], &p->d_rv[1], &p->d_rv[2], &p->d_rv[3],
-                             &p->d_rvh[0], &p->d_rvh[1], &p->d_rvh[2], &p->d_rvh[3]};
+                             &p->d_cce[0], &p->d_cce[1], &p->d_cce[2], &p->d_cce[3], &p->d_rv[0], &p->d_rv[1], &p->d_rv[2], &p->d_rv[3]};
     const void* const src[AACG_PLAN_BUFFERS] = {p->h.units.data(), p->h.runs.data(), p->h.tns.data(), nullptr, nullptr,
                                  p->h.cce_runs.data(), p->h.couple_jobs.data(), p->h.gains.data(), nullptr,
-                                 p->h.runs_rv.data(), p->h.links_rv.data(), nullptr, nullptr, p->h.runs_h.data(), p->h.links_h.data(), nullptr, nullptr};
+                                 p->h.runs_rv.data(), p->h.links_rv.data(), nullptr, nullptr};
     for (int i = 0; i < AACG_PLAN_BUFFERS && ok; i++) {
         if (!want[i]) continue;
         *slot[i] = pool_take(e, want[i], &p->bytes[i]);
         ok = *slot[i] != nullptr &&
              (!src[i] || hip_ok(e, hipMemcpyAsync(*slot[i], src[i], want[i], hipMemcpyHostToDevice, e->stream), "upload plan tables"));
         /* rendezvous state words count only with a launch's epoch in them; a recycled or fresh buffer starts from zero all the same */
-        if (ok && (i == 11 || i == 15)) ok = hip_ok(e, hipMemsetAsync(*slot[i], 0, want[i], e->stream), "zero rendezvous state");
+        if (ok && i == 11) ok = hip_ok(e, hipMemsetAsync(*slot[i], 0, want[i], e->stream), "zero rendezvous state");
     }
     ok = ok && hip_ok(e, hipEventRecord(p->uploaded, e->stream), "hipEventRecord");
     if (!ok) {
@@ -707,7 +701,7 @@ void aacg_plan_destroy(aacg_plan* p)
         (void)hipEventDestroy(p->last_use);
     }
     void* const ptr[AACG_PLAN_BUFFERS] = {p->d_units, p->d_runs, p->d_tns, p->d_scratch, p->d_spec, p->d_cce[0], p->d_cce[1], p->d_cce[2], p->d_cce[3],
-                           p->d_rv[0], p->d_rv[1], p->d_rv[2], p->d_rv[3], p->d_rvh[0], p->d_rvh[1], p->d_rvh[2], p->d_rvh[3]};
+                           p->d_rv[0], p->d_rv[1], p->d_rv[2], p->d_rv[3]};
     for (int i = 0; i < AACG_PLAN_BUFFERS; i++) pool_give(e, ptr[i], p->bytes[i]);
     if (e->pipe.plan == p) e->pipe.plan = nullptr;
     delete p;
@@ -740,7 +734,7 @@ static void plan_advance(aacg_engine* e, aacg_plan* p)
 /* the device buffers a route needs are the ones the plan was made with (aacg_debug_set_route may have changed since) */
 static int plan_check_route(aacg_engine* e, const aacg_plan* p, const aacg_route& R)
 {
-    if ((R.rv && !R.half && !p->d_rv[0]) || (R.half && !p->d_rvh[0]) || (!R.rv && R.has_run && !p->d_runs) || (R.stage != AACG_STAGE_NONE && !p->d_spec)) {
+    if ((R.rv && !p->d_rv[0]) || (!R.rv && R.has_run && !p->d_runs) || (R.stage != AACG_STAGE_NONE && !p->d_spec)) {
         e->err = "the plan was made for another route (aacg_debug_set_route changed since)";
         return AACG_ERR_STALE_PLAN;
     }
@@ -770,8 +764,7 @@ int aacg_decode_device(aacg_engine* e, aacg_plan* p, const void* d_coeffs, const
         HIP_TRY(e, hipStreamWaitEvent(s, p->last_use, 0), AACG_ERR_NO_DEVICE);
     }
     const cce_bufs cb = {(const aacg_run*)p->d_cce[0], (const aacg_couple_job*)p->d_cce[1], (const float*)p->d_cce[2], (float*)p->d_cce[3]};
-    void* const* rb4 = R.half ? p->d_rvh : p->d_rv;
-    const rv_bufs rvb = {(const aacg_run*)rb4[0], (const aacg_rv_link*)rb4[1], (unsigned long long*)rb4[2], (float*)rb4[3]};
+    const rv_bufs rvb = {(const aacg_run*)p->d_rv[0], (const aacg_rv_link*)p->d_rv[1], (unsigned long long*)p->d_rv[2], (float*)p->d_rv[3]};
     const xl_args serial = {false, 0ull, 0};
     rc = launch_run(e, R, p->d_units, p->d_runs, p->d_tns, p->d_scratch, p->d_spec, cb, rvb, p->h, d_coeffs, d_meta, d_pcm,
                     (int)(p->launches % AACG_OV_BUFFERS), s, serial, nullptr);
@@ -862,8 +855,7 @@ int aacg_decode_pipelined_timed(aacg_engine* e, aacg_plan* p, const void* d_coef
     }
     if (!p->used) HIP_TRY(e, hipStreamWaitEvent(s, p->uploaded, 0), AACG_ERR_NO_DEVICE);
     const cce_bufs cb = {(const aacg_run*)p->d_cce[0], (const aacg_couple_job*)p->d_cce[1], (const float*)p->d_cce[2], (float*)p->d_cce[3]};
-    void* const* rb4 = R.half ? p->d_rvh : p->d_rv;
-    const rv_bufs rvb = {(const aacg_run*)rb4[0], (const aacg_rv_link*)rb4[1], (unsigned long long*)rb4[2], (float*)rb4[3]};
+    const rv_bufs rvb = {(const aacg_run*)p->d_rv[0], (const aacg_rv_link*)p->d_rv[1], (unsigned long long*)p->d_rv[2], (float*)p->d_rv[3]};
     const xl_args xl = {R.overlappable, continues ? pp.epoch : 0ull, (int)(pp.n & 1u)};
     unsigned long long epoch = 0;
     /* the launch three on may wait for this one: its event rides on the dispatch itself where the route is a single launch

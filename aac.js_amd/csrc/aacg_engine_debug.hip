@@ -29,12 +29,12 @@ void aacg_debug_transform_kernel(const aacg_tables* tab_global, const float* in,
     float hx[1][8], hy[1][8];
     const bool vm = (is_short & 2) != 0;               /* the int16 seam's variants: mirror-lane exchanges as DPP, columns dealt out by long_col */
     if (is_short & 1) {
-        if (vm) short_channels<1, true>(lds, lds + AACG_TAB_OFF_WIN_LONG, cp, areas, hx, hy); else short_channels<1>(lds, lds + AACG_TAB_OFF_WIN_LONG, cp, areas, hx, hy);
+        if (vm) short_channels<1, true>(lds, cp, areas, hx, hy); else short_channels<1>(lds, cp, areas, hx, hy);
         const int w = lane >> 3, g = lane & 7;
 #pragma unroll
         for (int m = 0; m < 8; m++) { out[128 * w + 2 * g + 16 * m] = hx[0][m]; out[128 * w + 2 * g + 16 * m + 1] = hy[0][m]; }
     } else {
-        if (vm) long_channels<1, true>(lds, lds + AACG_TAB_OFF_WIN_LONG, cp, true, areas, hx, hy); else long_channels<1>(lds, lds + AACG_TAB_OFF_WIN_LONG, cp, true, areas, hx, hy);
+        if (vm) long_channels<1, true>(lds, cp, true, areas, hx, hy); else long_channels<1>(lds, cp, true, areas, hx, hy);
         dp_wave_sync();
         const int col = vm ? long_col(lane) : lane;
 #pragma unroll

@@ -45,10 +45,6 @@ struct aacg_plan_host {
     std::vector<aacg_run>     runs_rv;
     std::vector<aacg_rv_link> links_rv;     /* one per run, same order */
     uint32_t n_links_rv = 0;
-    /* ... and cut into runs of up to 8 frames for the 8-wave workgroups (two per CU: aacg_engine_half.hip) */
-    std::vector<aacg_run>     runs_h;
-    std::vector<aacg_rv_link> links_h;
-    uint32_t n_links_h = 0;
     /* AACG_CCE_SPEC: independently switched coupling elements run through the filterbank like any channel, but into a
      * side buffer (cce_runs: their own launch); coupling jobs by coupling point and by round (round r: the r-th coupling
      * element of its frame, so that no two jobs of a round add to the same channel) */

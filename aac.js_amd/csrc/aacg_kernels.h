@@ -156,26 +156,20 @@ DP_DEVICE unit_view load_unit(const aacg_dev_unit* u)
 /* Split in two so that the table loads are issued BEFORE the wave's own spectrum loads: vector
  * loads return in order, so the LDS copy (which waits for the table data only) does not wait for
  * the spectrum, and the spectrum keeps flying across the workgroup barrier. */
-/* THREADS: the workgroup's size; SKIP_AT / SKIP (floats): the source's floats [SKIP_AT, SKIP_AT + SKIP) are left out — the 8-wave
- * kernels' compact table block has no windows in it (AACG_TABC_*).  Two 16-byte loads per thread cover either block. */
-template <int THREADS = AACG_WG_THREADS, int SKIP_AT = 0, int SKIP = 0>
 DP_DEVICE void stage_tables_load(const aacg_tables* T, int n_floats, dpf4& t0, dpf4& t1)
 {
     const dpf4* src = (const dpf4*)T;
     const int n4 = n_floats >> 2, tid = dp_tid();
-    int i0 = tid < n4 ? tid : n4 - 1;                  /* clamped: unconditional loads, conditional stores */
-    int i1 = tid + THREADS < n4 ? tid + THREADS : n4 - 1;
-    if (SKIP) { i0 += i0 >= SKIP_AT / 4 ? SKIP / 4 : 0; i1 += i1 >= SKIP_AT / 4 ? SKIP / 4 : 0; }
-    t0 = src[i0];
-    t1 = src[i1];
+    const int i1 = tid + AACG_WG_THREADS;
+    t0 = src[tid < n4 ? tid : n4 - 1];                 /* clamped: unconditional loads, conditional stores */
+    t1 = src[i1 < n4 ? i1 : n4 - 1];
 }
-template <int THREADS = AACG_WG_THREADS>
 DP_DEVICE void stage_tables_store(float* lds, int n_floats, const dpf4& t0, const dpf4& t1)
 {
     dpf4* dst = (dpf4*)lds;
     const int n4 = n_floats >> 2, tid = dp_tid();
     if (tid < n4) dst[tid] = t0;
-    if (tid + THREADS < n4) dst[tid + THREADS] = t1;
+    if (tid + AACG_WG_THREADS < n4) dst[tid + AACG_WG_THREADS] = t1;
 }
 DP_DEVICE void stage_tables(const aacg_tables* T, float* lds, int n_floats)
 {
@@ -187,16 +181,13 @@ DP_DEVICE void stage_tables(const aacg_tables* T, float* lds, int n_floats)
 /* ------------------------------------------------------------------------------------ */
 /* windows of the long sequences, filter_bank.js:105-141,180-202                           */
 /* ------------------------------------------------------------------------------------ */
-/* `win`: the window tables as aacg_tables lays them out — win_long[2][1024], then win_short[2][128] — in LDS (the 16-wave kernels
- * stage them with the other tables) or in global memory (the 8-wave kernels: two workgroups per CU leave no room for them) */
-#define AACG_WIN_SHORT_OFF 2048
 /* (w[n], w[n+1]) multiplying IMDCT output n, n+1 of the first half (n even). */
-DP_DEVICE dpf2 head_window(const float* win, int seq, int shape_prev, int n)
+DP_DEVICE dpf2 head_window(const float* tab, int seq, int shape_prev, int n)
 {
-    const float* wl = win + 1024 * shape_prev;
+    const float* wl = tab + AACG_TAB_OFF_WIN_LONG + 1024 * shape_prev;
     if (seq != AACG_LONG_STOP_SEQUENCE) return *(const dpf2*)(wl + n);      /* filter_bank.js:109-111,124-126 */
     /* LONG_STOP: 0 | previous-shape short window | 1   (filter_bank.js:185-195) */
-    const float* ws = win + AACG_WIN_SHORT_OFF + 128 * shape_prev;
+    const float* ws = tab + AACG_TAB_OFF_WIN_SHORT + 128 * shape_prev;
     int i = n - 448; i = i < 0 ? 0 : (i > 126 ? 126 : i);
     dpf2 v = *(const dpf2*)(ws + i);
     if (n < 448) { v.x = 0.0f; v.y = 0.0f; }
@@ -204,17 +195,17 @@ DP_DEVICE dpf2 head_window(const float* win, int seq, int shape_prev, int n)
     return v;
 }
 /* (w[n], w[n+1]) multiplying IMDCT output 1024 + n, 1024 + n + 1 (n even). */
-DP_DEVICE dpf2 tail_window(const float* win, int seq, int shape, int n)
+DP_DEVICE dpf2 tail_window(const float* tab, int seq, int shape, int n)
 {
     dpf2 v, r;
     if (seq != AACG_LONG_START_SEQUENCE) {                                   /* reversed long window, filter_bank.js:114-116 */
-        v = *(const dpf2*)(win + 1024 * shape + 1022 - n);
+        v = *(const dpf2*)(tab + AACG_TAB_OFF_WIN_LONG + 1024 * shape + 1022 - n);
         r.x = v.y; r.y = v.x;
         return r;
     }
     /* LONG_START: 1 | reversed short window | 0   (filter_bank.js:129-139) */
     int i = 574 - n; i = i < 0 ? 0 : (i > 126 ? 126 : i);
-    v = *(const dpf2*)(win + AACG_WIN_SHORT_OFF + 128 * shape + i);
+    v = *(const dpf2*)(tab + AACG_TAB_OFF_WIN_SHORT + 128 * shape + i);
     r.x = v.y; r.y = v.x;
     if (n < 448) { r.x = AACG_PCM_SCALE; r.y = AACG_PCM_SCALE; }
     if (n >= 576) { r.x = 0.0f; r.y = 0.0f; }
@@ -251,7 +242,7 @@ DP_DEVICE int long_col(int l);
  * (hx[c][m]) and n + 1 (hy[c][m]). */
 /* window + reorder of one planar long channel for one window sequence; m[r] = re, m[8+r] = im of lane 63 - l */
 template <int SEQ>
-DP_DEVICE void long_planar_window(const float* win, const chan_par& cp, bool want_head, float* area, int l /* column */,
+DP_DEVICE void long_planar_window(const float* tab, const chan_par& cp, bool want_head, float* area, int l /* column */,
                                   const float (&R)[8], const float (&I)[8], const float (&m)[16],
                                   float (&hx)[8], float (&hy)[8])
 {
@@ -259,8 +250,8 @@ DP_DEVICE void long_planar_window(const float* win, const chan_par& cp, bool wan
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const int n = 2 * l + 128 * j;
-        const dpf2 w0 = head_window(win, SEQ, cp.shape_prev, n), w1 = head_window(win, SEQ, cp.shape_prev, n + 512);
-        const dpf2 v0 = tail_window(win, SEQ, cp.shape, n), v1 = tail_window(win, SEQ, cp.shape, n + 512);
+        const dpf2 w0 = head_window(tab, SEQ, cp.shape_prev, n), w1 = head_window(tab, SEQ, cp.shape_prev, n + 512);
+        const dpf2 v0 = tail_window(tab, SEQ, cp.shape, n), v1 = tail_window(tab, SEQ, cp.shape, n + 512);
         if (want_head) {
             hx[j]     = I[j + 4] * w0.x;              /* y[2k]        =  im[N/8 + k]     */
             hy[j]     = -m[3 - j] * w0.y;             /* y[2k+1]      = -re[N/8 - 1 - k] */
@@ -280,7 +271,7 @@ DP_DEVICE void long_planar_window(const float* win, const chan_par& cp, bool wan
 }
 
 template <int NC, bool VM = false>                     /* VM: columns dealt out by long_col (below), mirror exchange as DPP row_mirror */
-DP_DEVICE void long_channels(const float* tab, const float* win, const chan_par (&cp)[NC], bool want_head,
+DP_DEVICE void long_channels(const float* tab, const chan_par (&cp)[NC], bool want_head,
                              float* const (&area)[NC], float (&hx)[NC][8], float (&hy)[NC][8])
 {
 #pragma clang fp contract(off)
@@ -365,13 +356,13 @@ DP_DEVICE void long_channels(const float* tab, const float* win, const chan_par 
         if (VM) dp_mirror16_valu(own, m); else dp_shfl(m, 63 - l);
         /* reorder (mdct.js:90-114) fused with the window (filter_bank.js:109-116 etc.), with the sequence as a
          * compile-time constant: the branches inside head_window / tail_window fold, the reads go out together */
-        if (cp[c].seq == AACG_ONLY_LONG_SEQUENCE)       long_planar_window<AACG_ONLY_LONG_SEQUENCE>(win, cp[c], want_head, area[c], col, R[c], I[c], m, hx[c], hy[c]);
-        else if (cp[c].seq == AACG_LONG_START_SEQUENCE) long_planar_window<AACG_LONG_START_SEQUENCE>(win, cp[c], want_head, area[c], col, R[c], I[c], m, hx[c], hy[c]);
-        else                                            long_planar_window<AACG_LONG_STOP_SEQUENCE>(win, cp[c], want_head, area[c], col, R[c], I[c], m, hx[c], hy[c]);
+        if (cp[c].seq == AACG_ONLY_LONG_SEQUENCE)       long_planar_window<AACG_ONLY_LONG_SEQUENCE>(tab, cp[c], want_head, area[c], col, R[c], I[c], m, hx[c], hy[c]);
+        else if (cp[c].seq == AACG_LONG_START_SEQUENCE) long_planar_window<AACG_LONG_START_SEQUENCE>(tab, cp[c], want_head, area[c], col, R[c], I[c], m, hx[c], hy[c]);
+        else                                            long_planar_window<AACG_LONG_STOP_SEQUENCE>(tab, cp[c], want_head, area[c], col, R[c], I[c], m, hx[c], hy[c]);
     }
 }
 template <int NC, bool VM = false>                     /* VM: the l ^ 7 exchange on the VALU (dp_mirror8_valu) */
-DP_DEVICE void short_channels(const float* tab, const float* win, const chan_par (&cp)[NC],
+DP_DEVICE void short_channels(const float* tab, const chan_par (&cp)[NC],
                               float* const (&area)[NC], float (&hx)[NC][8], float (&hy)[NC][8])
 {
 #pragma clang fp contract(off)
@@ -432,8 +423,8 @@ DP_DEVICE void short_channels(const float* tab, const float* win, const chan_par
         if (VM) dp_mirror8_valu(own, m); else dp_shfl(m, l ^ 7);
 
         /* window each block: head with W[i] (block 0: previous shape), tail with W[127-i] */
-        const float* ws = win + AACG_WIN_SHORT_OFF + 128 * cp[c].shape;
-        const float* wh = (w == 0) ? win + AACG_WIN_SHORT_OFF + 128 * cp[c].shape_prev : ws;
+        const float* ws = tab + AACG_TAB_OFF_WIN_SHORT + 128 * cp[c].shape;
+        const float* wh = (w == 0) ? tab + AACG_TAB_OFF_WIN_SHORT + 128 * cp[c].shape_prev : ws;
         float hd[16], tl[16];                         /* [m] = position i = 2g+16m, [8+m] = i+1 */
 #pragma unroll
         for (int j = 0; j < 4; j++) {
@@ -581,15 +572,15 @@ DP_DEVICE void shfl_pairs(const dpv2 (&R)[8], const dpv2 (&I)[8], int src, dpv2 
 /* window + reorder of the long pair path for one window sequence (mdct.js:90-114 fused with
  * filter_bank.js:109-141,180-202); tails interleaved into the slot */
 template <int SEQ>
-DP_DEVICE void long_pair_window(const float* win, const chan_par& cp, bool want_head, float* slot, int l /* column */,
+DP_DEVICE void long_pair_window(const float* tab, const chan_par& cp, bool want_head, float* slot, int l /* column */,
                                 const dpv2 (&R)[8], const dpv2 (&I)[8], const dpv2 (&mR)[8], const dpv2 (&mI)[8],
                                 dpv2 (&hx)[8], dpv2 (&hy)[8])
 {
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const int n = 2 * l + 128 * j;
-        const dpf2 w0 = head_window(win, SEQ, cp.shape_prev, n), w1 = head_window(win, SEQ, cp.shape_prev, n + 512);
-        const dpf2 v0 = tail_window(win, SEQ, cp.shape, n), v1 = tail_window(win, SEQ, cp.shape, n + 512);
+        const dpf2 w0 = head_window(tab, SEQ, cp.shape_prev, n), w1 = head_window(tab, SEQ, cp.shape_prev, n + 512);
+        const dpf2 v0 = tail_window(tab, SEQ, cp.shape, n), v1 = tail_window(tab, SEQ, cp.shape, n + 512);
         if (want_head) {
             hx[j]     = I[j + 4] * v2s(w0.x);
             hy[j]     = -mR[3 - j] * v2s(w0.y);
@@ -610,7 +601,7 @@ DP_DEVICE void long_pair_window(const float* win, const chan_par& cp, bool want_
 
 /* Long windows, both channels (they share sequence and shapes: one ICSInfo, cpe.js:44, or equal by value). */
 template <bool VM>                                      /* VM: columns dealt out by long_col, mirror exchange as DPP row_mirror */
-DP_DEVICE void long_pair(const float* tab, const float* win, const chan_par& cp, bool want_head, float* slot,
+DP_DEVICE void long_pair(const float* tab, const chan_par& cp, bool want_head, float* slot,
                          dpv2 (&hx)[8], dpv2 (&hy)[8])
 {
     const int l = dp_lane();
@@ -688,8 +679,8 @@ DP_DEVICE void long_pair(const float* tab, const float* win, const chan_par& cp,
          * are issued together instead of one LDS round trip each (filter_bank.js:109-116).  Reading all sixteen
          * ahead of the first tail store was measured too: no faster, and 4 more VGPRs. */
         dp_keep_branch();
-        const float* wh = win + 1024 * cp.shape_prev;
-        const float* wt = win + 1024 * cp.shape;
+        const float* wh = tab + AACG_TAB_OFF_WIN_LONG + 1024 * cp.shape_prev;
+        const float* wt = tab + AACG_TAB_OFF_WIN_LONG + 1024 * cp.shape;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const int n = 2 * c + 128 * j;
@@ -723,14 +714,14 @@ DP_DEVICE void long_pair(const float* tab, const float* win, const chan_par& cp,
     shfl_pairs<VM ? 16 : 0>(R, I, 63 - l, mR, mI);
     /* LONG_START / LONG_STOP: the same loop with the sequence as a compile-time constant, so that the branches
      * inside head_window / tail_window fold and each iteration's window reads are issued together */
-    if (cp.seq == AACG_LONG_START_SEQUENCE) long_pair_window<AACG_LONG_START_SEQUENCE>(win, cp, want_head, slot, c, R, I, mR, mI, hx, hy);
-    else                                    long_pair_window<AACG_LONG_STOP_SEQUENCE>(win, cp, want_head, slot, c, R, I, mR, mI, hx, hy);
+    if (cp.seq == AACG_LONG_START_SEQUENCE) long_pair_window<AACG_LONG_START_SEQUENCE>(tab, cp, want_head, slot, c, R, I, mR, mI, hx, hy);
+    else                                    long_pair_window<AACG_LONG_STOP_SEQUENCE>(tab, cp, want_head, slot, c, R, I, mR, mI, hx, hy);
 }
 
 /* EIGHT_SHORT, both channels.  Slot indices as a few lane-dependent bases plus compile-time offsets, like long_pair: with
  * stg / pch2 evaluated per element the path carried some 150 vector instructions of index arithmetic per frame. */
 template <bool VM>
-DP_DEVICE void short_pair(const float* tab, const float* win, const chan_par& cp, float* slot, dpv2 (&hx)[8], dpv2 (&hy)[8])
+DP_DEVICE void short_pair(const float* tab, const chan_par& cp, float* slot, dpv2 (&hx)[8], dpv2 (&hy)[8])
 {
     const int l = dp_lane(), w = l >> 3, g = l & 7;
     const float* sincos = tab + AACG_TAB_OFF_SINCOS_SHORT;
@@ -788,8 +779,8 @@ DP_DEVICE void short_pair(const float* tab, const float* win, const chan_par& cp
     }
     if (!VM) shfl_pairs<0>(R, I, l ^ 7, mR, mI);
 
-    const float* ws = win + AACG_WIN_SHORT_OFF + 128 * cp.shape;
-    const float* wh = (w == 0) ? win + AACG_WIN_SHORT_OFF + 128 * cp.shape_prev : ws;
+    const float* ws = tab + AACG_TAB_OFF_WIN_SHORT + 128 * cp.shape;
+    const float* wh = (w == 0) ? tab + AACG_TAB_OFF_WIN_SHORT + 128 * cp.shape_prev : ws;
     dpv2 hd[16], tl[16];                               /* [m] = position i = 2g+16m, [8+m] = i+1 */
 #pragma unroll
     for (int j = 0; j < 4; j++) {
@@ -1490,7 +1481,7 @@ DP_DEVICE void tns_unit(float* slot, float* xch, const aacg_dev_tns* rec0, const
 /* VM: the mirror exchanges of the short windows on the VALU: worth it where the LDS pipe is the busier one — the int16 seam
  * (all-short batch 14.67 -> 13.70 us, config 3 13.94 -> 13.56); the f32 seam lost 0.07 us with it and keeps ds_bpermute */
 template <bool VM>
-DP_DEVICE void filter_unit(const float* tab, const float* win, const unit_view& u, int n_ch, bool pair_path, bool want_head, float* slot,
+DP_DEVICE void filter_unit(const float* tab, const unit_view& u, int n_ch, bool pair_path, bool want_head, float* slot,
                            float (&hx0)[8], float (&hy0)[8], float (&hx1)[8], float (&hy1)[8])
 {
     chan_par p0, p1;
@@ -1499,8 +1490,8 @@ DP_DEVICE void filter_unit(const float* tab, const float* win, const unit_view& 
     const bool s0 = p0.seq == AACG_EIGHT_SHORT_SEQUENCE, s1 = p1.seq == AACG_EIGHT_SHORT_SEQUENCE;
     if (pair_path) {
         dpv2 hx[8], hy[8];
-        if (s0) short_pair<VM>(tab, win, p0, slot, hx, hy);
-        else    long_pair<VM>(tab, win, p0, want_head, slot, hx, hy);
+        if (s0) short_pair<VM>(tab, p0, slot, hx, hy);
+        else    long_pair<VM>(tab, p0, want_head, slot, hx, hy);
 #pragma unroll
         for (int m = 0; m < 8; m++) { hx0[m] = hx[m][0]; hx1[m] = hx[m][1]; hy0[m] = hy[m][0]; hy1[m] = hy[m][1]; }
         return;
@@ -1509,8 +1500,8 @@ DP_DEVICE void filter_unit(const float* tab, const float* win, const unit_view& 
         const chan_par cp[1] = {p0};
         float* const area[1] = {slot};
         float hx[1][8], hy[1][8];
-        if (s0) short_channels<1, VM>(tab, win, cp, area, hx, hy);
-        else    long_channels<1, VM>(tab, win, cp, want_head, area, hx, hy);
+        if (s0) short_channels<1, VM>(tab, cp, area, hx, hy);
+        else    long_channels<1, VM>(tab, cp, want_head, area, hx, hy);
 #pragma unroll
         for (int m = 0; m < 8; m++) { hx0[m] = hx[0][m]; hy0[m] = hy[0][m]; }
     }
@@ -1518,8 +1509,8 @@ DP_DEVICE void filter_unit(const float* tab, const float* win, const unit_view& 
         const chan_par cp[1] = {p1};
         float* const area[1] = {slot + 1024};
         float hx[1][8], hy[1][8];
-        if (s1) short_channels<1, VM>(tab, win, cp, area, hx, hy);
-        else    long_channels<1, VM>(tab, win, cp, want_head, area, hx, hy);
+        if (s1) short_channels<1, VM>(tab, cp, area, hx, hy);
+        else    long_channels<1, VM>(tab, cp, want_head, area, hx, hy);
 #pragma unroll
         for (int m = 0; m < 8; m++) { hx1[m] = hx[0][m]; hy1[m] = hy[0][m]; }
         /* two planar tails -> the interleaved form the next wave expects */
@@ -1981,43 +1972,23 @@ DP_DEVICE int ov_buffer(int rot, int add) { int r = rot + add; r = r >= AACG_OV_
 #define AACG_LDS_BYTES_QUANT_EX (AACG_LDS_BYTES_QUANT + 4 * AACG_WG_WAVES * AACG_RUN_XCH_FLOATS)
 /* RV = true builds (aacg_engine_rv.hip): chains longer than a run without a recomputed frame — the plan's runs all start from
  * what the run before them hands over through a rendezvous cell (aacg_rv_args), never from a recomputed predecessor. */
-/* NW = 8 builds (aacg_engine_half.hip): workgroups of EIGHT waves — runs of up to eight frames, half the slots — with a table
- * block that leaves the windows out (they are read from global memory: 9 KB that every wave of the chip shares, L2- and mostly
- * L1-resident), so that a workgroup needs less than 80 KB of LDS and TWO of them share a CU.  Same waves, same registers (128, four
- * waves per SIMD), same arithmetic; what changes is that a CU's two workgroups are at different points of their lives: one
- * computes while the other waits for its first spectra or for its last stores. */
-#define AACG_TABC_F32_FLOATS   AACG_TAB_OFF_WIN_LONG                                                    /* rotations and twiddles */
-#define AACG_TABC_QUANT_FLOATS (AACG_TABC_F32_FLOATS + (AACG_TAB_QUANT_FLOATS - AACG_TAB_F32_FLOATS))   /* + SF, signed IQ, band maps */
-#define AACG_TABC_GAP_FLOATS   (AACG_TAB_F32_FLOATS - AACG_TAB_OFF_WIN_LONG)                            /* the windows' place in aacg_tables */
-#define AACG_LDS_FLOATS_NW(tab_floats, nw) (AACG_TAB_SLOT_BASE(tab_floats) + (nw) * AACG_SLOT_FLOATS + AACG_WG_WAVES)
-#define AACG_HALF_WAVES 8
-#define AACG_LDS_BYTES_HALF_QUANT (4 * AACG_LDS_FLOATS_NW(AACG_TABC_QUANT_FLOATS, AACG_HALF_WAVES))
-#define AACG_LDS_BYTES_HALF_F32   (4 * AACG_LDS_FLOATS_NW(AACG_TABC_F32_FLOATS, AACG_HALF_WAVES))
-template <int KIND, int OUT = AACG_OUTPUT_F32, bool DD = false, bool EX = false, bool CPL = false, bool RV = false, bool NTL = false, int NW = AACG_WG_WAVES>
+template <int KIND, int OUT = AACG_OUTPUT_F32, bool DD = false, bool EX = false, bool CPL = false, bool RV = false, bool NTL = false>
 DP_DEVICE void imdct_run_body(const aacg_kparams& P, const aacg_rv_args* V = nullptr)
 {
-    constexpr bool HALF = NW != AACG_WG_WAVES;
-    static_assert(!HALF || (RV && !EX && !DD && !CPL), "the 8-wave builds are rendezvous kernels without optional stages");
-    const int TAB_FLOATS = HALF ? ((KIND == AACG_INPUT_QUANT_I16) ? AACG_TABC_QUANT_FLOATS : AACG_TABC_F32_FLOATS)
-                                : ((KIND == AACG_INPUT_QUANT_I16) ? AACG_TAB_QUANT_FLOATS : AACG_TAB_F32_FLOATS);
+    const int TAB_FLOATS = (KIND == AACG_INPUT_QUANT_I16) ? AACG_TAB_QUANT_FLOATS : AACG_TAB_F32_FLOATS;
     const int lane = dp_lane(), wave = dp_wave();
     const aacg_run* run = P.runs + dp_block();
-    float* lds = (float*)dp_lds_fixed<4 * AACG_LDS_FLOATS_NW(TAB_FLOATS, NW) + (EX ? 4 * AACG_WG_WAVES * AACG_RUN_XCH_FLOATS : 0)>();
-    const float* tab = lds;                            /* rotations, twiddles (and, 16-wave builds, the windows) */
-    /* the dequantisation tables behind them: in the compact block they sit where the windows would start, so the pointer is
-     * biased and the usual offsets (AACG_TAB_OFF_SF ...) work */
-    const float* tabq = HALF ? lds - AACG_TABC_GAP_FLOATS : lds;
-    const float* win = HALF ? (const float*)P.tab + AACG_TAB_OFF_WIN_LONG : lds + AACG_TAB_OFF_WIN_LONG;
+    float* lds = (float*)dp_lds_fixed<4 * AACG_LDS_FLOATS(TAB_FLOATS) + (EX ? 4 * AACG_WG_WAVES * AACG_RUN_XCH_FLOATS : 0)>();
+    const float* tab = lds;
     float* slots = lds + AACG_TAB_SLOT_BASE(TAB_FLOATS);
     float* slot = slots + wave * AACG_SLOT_FLOATS;
-    int* flags = (int*)(slots + NW * AACG_SLOT_FLOATS);
+    int* flags = (int*)(slots + AACG_WG_WAVES * AACG_SLOT_FLOATS);
     float* xch = EX ? (float*)(flags + AACG_WG_WAVES) + wave * AACG_RUN_XCH_FLOATS : nullptr;
 
     /* the table loads go first: everything behind them in the vector-memory queue may stay in flight
      * while the tables are copied to LDS */
     dpf4 tr0, tr1;
-    static_assert(2 * NW * 64 * 4 >= TAB_FLOATS, "two loads per thread cover the table block");
-    stage_tables_load<NW * 64, HALF ? AACG_TABC_F32_FLOATS : 0, HALF ? AACG_TABC_GAP_FLOATS : 0>(P.tab, TAB_FLOATS, tr0, tr1);
+    stage_tables_load(P.tab, TAB_FLOATS, tr0, tr1);
 
     const int n_units = run->n_units;
     const bool has_pred = !RV && run->pred_unit >= 0;
@@ -2040,7 +2011,7 @@ DP_DEVICE void imdct_run_body(const aacg_kparams& P, const aacg_rv_args* V = nul
      * recomputes that frame's IMDCT.  With up to 15 frames wave 0 does only that (waves 1.. own the frames);
      * a full run of 16 frames gives wave 0 double duty: first the predecessor (its tail goes to a scratch
      * area in global memory), then its own frame, which takes its overlap from that scratch area. */
-    const bool dd = DD && has_pred && n_units == NW;
+    const bool dd = DD && has_pred && n_units == AACG_WG_WAVES;
     int ui = -1;
     if (has_pred && !dd) { if (wave == 0) ui = run->pred_unit; else if (wave - 1 < n_units) ui = run->unit[wave - 1]; }
     else                 { if (wave < n_units) ui = run->unit[wave]; }
@@ -2057,7 +2028,7 @@ DP_DEVICE void imdct_run_body(const aacg_kparams& P, const aacg_rv_args* V = nul
      * never lower, so a spinning consumer cannot starve its producer. */
     /* (the multichannel variants leave every wave at the default priority: 62.0 -> 61.9 us on config 5, nothing anywhere else) */
     if (NTL && !RV) {} else
-    if (AACG_ABL(P, 64)) dp_setprio(0); else if (AACG_ABL(P, 32)) dp_setprio(1 - (wave >> 3)); else dp_setprio(hurry ? 3 : 3 - (wave >> (HALF ? 1 : 2)));
+    if (AACG_ABL(P, 64)) dp_setprio(0); else if (AACG_ABL(P, 32)) dp_setprio(1 - (wave >> 3)); else dp_setprio(hurry ? 3 : 3 - (wave >> 2));
     const unsigned long long t_start = AACG_ABL(P, 16) ? dp_clock() : 0;
     /* (the coupling builds carry their side buffer in spec_out, aacg_set_cpl: never a trace there) */
     unsigned long long* trace = (!CPL && AACG_ABL(P, 16)) ? (unsigned long long*)P.spec_out + ((size_t)dp_block() * AACG_WG_WAVES + wave) * 8 : nullptr;
@@ -2109,9 +2080,9 @@ DP_DEVICE void imdct_run_body(const aacg_kparams& P, const aacg_rv_args* V = nul
      * join), and only then do the other twelve waves issue their requests.  The first group therefore sees
      * its data after ~1.7 us instead of queueing behind the whole chip's 33 MB, and the later groups' data
      * arrives while the SIMD is still busy with the earlier ones. */
-    const bool early = wave < ((KIND == AACG_INPUT_QUANT_I16 || HALF) ? 2 : 4) || hurry || AACG_ABL(P, 128);
+    const bool early = wave < (KIND == AACG_INPUT_QUANT_I16 ? 2 : 4) || hurry || AACG_ABL(P, 128);
     if (early) issue_loads();
-    stage_tables_store<NW * 64>(lds, TAB_FLOATS, tr0, tr1);
+    stage_tables_store(lds, TAB_FLOATS, tr0, tr1);
     if (lane == 0) flags[wave] = 0;
     dp_block_sync_lds();                               /* tables and flags are in LDS */
     if (!early) issue_loads();
@@ -2137,7 +2108,7 @@ DP_DEVICE void imdct_run_body(const aacg_kparams& P, const aacg_rv_args* V = nul
                     xr[8 * i + 4] = xr[8 * i]; xr[8 * i + 5] = xr[8 * i + 1]; xr[8 * i + 6] = xr[8 * i + 2]; xr[8 * i + 7] = xr[8 * i + 3];
                 }
             } else
-            spectral_quant<EX>(P, tabq, u, n_ch, qreg, slot + 1024, xl, xr);
+            spectral_quant<EX>(P, tab, u, n_ch, qreg, slot + 1024, xl, xr);
             /* TNS runs here (decoder.js:309-313): identity as the reference executes it (tns.js:106,122), so the plain
              * kernels have nothing to do; the EX builds apply the filters AACG_TNS_SPEC asks for */
             if (EX && P.tns && (u.tns[0] || (n_ch == 2 && u.tns[1]))) {
@@ -2190,7 +2161,7 @@ DP_DEVICE void imdct_run_body(const aacg_kparams& P, const aacg_rv_args* V = nul
         }
         dp_wave_sync();
         if (trace && lane == 0) trace[2] = dp_clock();     /* spectrum arrived and staged */
-        filter_unit<AACG_VM_KIND(KIND)>(tab, win, u, n_ch, pair_path, want_head, slot, hx0, hy0, hx1, hy1);
+        filter_unit<AACG_VM_KIND(KIND)>(tab, u, n_ch, pair_path, want_head, slot, hx0, hy0, hx1, hy1);
     };
 
     if (ui >= 0) front(!is_pred_wave && n_pass == 1);

@@ -363,8 +363,6 @@ int aacg_plan_build(const aacg_unit_desc* units, uint32_t n_units, int sample_in
     std::vector<aacg_run> gen, cce_gen;
     std::vector<aacg_run> gen_rv;
     std::vector<aacg_rv_link> gen_rv_links;
-    std::vector<aacg_run> gen_h;
-    std::vector<aacg_rv_link> gen_h_links;
     bool long_chain = false;
     for (auto& kv : open) {
         const open_chain& oc = kv.second;
@@ -404,37 +402,32 @@ int aacg_plan_build(const aacg_unit_desc* units, uint32_t n_units, int sample_in
         }
         ch.n_runs = oc.is_cce ? 0 : (uint32_t)gen.size() - ch.first_run;
         out->chains.push_back(ch);
-        /* the same chain for the rendezvous kernels — a cell between consecutive runs instead of a recomputed frame — cut into runs
-         * of 16 frames (16-wave workgroups) and into runs of 8 (8-wave workgroups, two per CU) */
+        /* the same chain for the 16-wave kernels with a rendezvous between its runs instead of a recomputed frame */
         if (!oc.is_cce) {
             if (n > AACG_RUN_W) long_chain = true;
-            auto cut = [&](size_t cap, std::vector<aacg_run>& runs, std::vector<aacg_rv_link>& links, uint32_t& n_links) {
-                int32_t link = -1;
-                for (size_t pos = 0; pos < n; pos += cap) {
-                    aacg_run r;
-                    r.pred_unit = -1;
-                    r.n_units = (int32_t)std::min<size_t>(cap, n - pos);
-                    for (int k = 0; k < AACG_RUN_W; k++) r.unit[k] = k < r.n_units ? oc.units[pos + k] : -1;
-                    for (int c = 0; c < 2; c++) {
-                        const uint32_t chn = ch.channel + (c < oc.n_ch ? c : 0);
-                        r.ov0[c] = aacg_ov_offset(max_channels, ch.stream, chn, 0);
-                        r.rot[c] = ch.parity[c < oc.n_ch ? c : 0];
-                    }
-                    const bool more = pos + cap < n;
-                    r.is_last = more ? 0 : 1;
-                    r.reserved = 0;
-                    aacg_rv_link lk;
-                    lk.link_in = link;
-                    link = more ? (int32_t)n_links++ : -1;
-                    lk.link_out = link;
-                    lk.succ_unit = more ? oc.units[pos + cap] : -1;
-                    lk.reserved = 0;
-                    runs.push_back(r);
-                    links.push_back(lk);
+            int32_t link = -1;
+            for (size_t pos = 0; pos < n; pos += AACG_RUN_W) {
+                aacg_run r;
+                r.pred_unit = -1;
+                r.n_units = (int32_t)std::min<size_t>(AACG_RUN_W, n - pos);
+                for (int k = 0; k < AACG_RUN_W; k++) r.unit[k] = k < r.n_units ? oc.units[pos + k] : -1;
+                for (int c = 0; c < 2; c++) {
+                    const uint32_t chn = ch.channel + (c < oc.n_ch ? c : 0);
+                    r.ov0[c] = aacg_ov_offset(max_channels, ch.stream, chn, 0);
+                    r.rot[c] = ch.parity[c < oc.n_ch ? c : 0];
                 }
-            };
-            cut(AACG_RUN_W, gen_rv, gen_rv_links, out->n_links_rv);
-            cut(AACG_RUN_W / 2, gen_h, gen_h_links, out->n_links_h);
+                const bool more = pos + AACG_RUN_W < n;
+                r.is_last = more ? 0 : 1;
+                r.reserved = 0;
+                aacg_rv_link lk;
+                lk.link_in = link;
+                link = more ? (int32_t)out->n_links_rv++ : -1;
+                lk.link_out = link;
+                lk.succ_unit = more ? oc.units[pos + AACG_RUN_W] : -1;
+                lk.reserved = 0;
+                gen_rv.push_back(r);
+                gen_rv_links.push_back(lk);
+            }
         }
     }
 
@@ -482,18 +475,16 @@ int aacg_plan_build(const aacg_unit_desc* units, uint32_t n_units, int sample_in
     /* the rendezvous cut of the same chains (every run 16 frames, links between consecutive runs): the route of plain batches
      * with a chain longer than a run, and of every plain batch launched through aacg_decode_pipelined */
     out->long_chains = long_chain;
-    auto deal = [](const std::vector<aacg_run>& gen_r, const std::vector<aacg_rv_link>& gen_l, std::vector<aacg_run>& runs, std::vector<aacg_rv_link>& links) {
-        const size_t RR = gen_r.size();
-        runs.resize(RR);
-        links.resize(RR);
-        size_t k = 0;
+    {
+        const size_t RR = gen_rv.size();
+        out->runs_rv.resize(RR);
+        out->links_rv.resize(RR);
+        i = 0;
         for (size_t x = 0; x < 8 && x < RR; x++) {
             const size_t cnt = (RR - 1 - x) / 8 + 1;
-            for (size_t s = 0; s < cnt; s++) { runs[s * 8 + x] = gen_r[k]; links[s * 8 + x] = gen_l[k]; k++; }
+            for (size_t s = 0; s < cnt; s++) { out->runs_rv[s * 8 + x] = gen_rv[i]; out->links_rv[s * 8 + x] = gen_rv_links[i]; i++; }
         }
-    };
-    deal(gen_rv, gen_rv_links, out->runs_rv, out->links_rv);
-    deal(gen_h, gen_h_links, out->runs_h, out->links_h);
+    }
     out->cce_runs = cce_gen;
     /* chain.first_run refers to generation order; the engine only needs counts, keep as is */
     return AACG_OK;

@@ -10,7 +10,7 @@
 aacg_route aacg_pick_route(int input_kind, int output_kind, int debug_route, bool tracing, const aacg_plan_host& h, bool pipelined)
 {
     aacg_route r;
-    r.stage = AACG_STAGE_NONE; r.stage_quant = false; r.has_run = false; r.run_key = 0; r.rv = false; r.half = false;
+    r.stage = AACG_STAGE_NONE; r.stage_quant = false; r.has_run = false; r.run_key = 0; r.rv = false;
     r.has_side = false; r.side_key = 0; r.side_first = false; r.couple_pcm = false; r.overlappable = false;
     const bool i16 = output_kind == AACG_OUTPUT_I16;
     bool quant = input_kind == AACG_INPUT_QUANT_I16;
@@ -24,8 +24,6 @@ aacg_route aacg_pick_route(int input_kind, int output_kind, int debug_route, boo
         r.run_key = AACG_RK_RV | nt | (quant ? AACG_RK_QUANT : 0u);
         r.rv = true;
         r.overlappable = true;
-        /* workgroups of 8 waves, two per CU, where there is such a build: stereo / mono batches (the multichannel variants stay) */
-        if ((debug_route & AACG_DEBUG_ROUTE_HALF_RUNS) && !nt && !h.runs_h.empty()) { r.run_key |= AACG_RK_HALF; r.half = true; }
         return r;
     }
     unsigned key = 0;
@@ -66,7 +64,6 @@ std::string aacg_run_kernel_name(unsigned key)
     if (key & AACG_RK_RV)  s += "_rv";
     if (key & AACG_RK_I16) s += "_i16";
     if (key & AACG_RK_NT)  s += "_nt";
-    if (key & AACG_RK_HALF) s += "_h";
     return s;
 }
 

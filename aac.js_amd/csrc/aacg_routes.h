@@ -20,8 +20,7 @@ enum {
     AACG_RK_EX    = 8,      /* the optional stages (AACG_TNS_SPEC, AACG_PNS_SPEC) inside the run */
     AACG_RK_CPL   = 16,     /* independent coupling applied where the target's PCM is formed */
     AACG_RK_RV    = 32,     /* rendezvous cells between the runs of a chain (and, pipelined, between launches); takes aacg_rv_args */
-    AACG_RK_NT    = 64,     /* non-temporal loads of the spectra: batches of multichannel frames */
-    AACG_RK_HALF  = 128     /* workgroups of 8 waves (runs of up to 8 frames), two per CU */
+    AACG_RK_NT    = 64      /* non-temporal loads of the spectra: batches of multichannel frames */
 };
 
 struct aacg_run_kernel {
@@ -38,7 +37,6 @@ extern const aacg_run_kernel aacg_run_kernels_ext[];    extern const int aacg_ru
 extern const aacg_run_kernel aacg_run_kernels_i16[];    extern const int aacg_run_kernels_i16_n;      /* aacg_engine_i16.hip */
 extern const aacg_run_kernel aacg_run_kernels_exrun[];  extern const int aacg_run_kernels_exrun_n;    /* aacg_engine_exrun.hip */
 extern const aacg_run_kernel aacg_run_kernels_couple[]; extern const int aacg_run_kernels_couple_n;   /* aacg_engine_couple.hip */
-extern const aacg_run_kernel aacg_run_kernels_half[];   extern const int aacg_run_kernels_half_n;     /* aacg_engine_half.hip */
 
 /* what launch_run does for a plan: the single statement of the route */
 enum { AACG_STAGE_NONE = 0, AACG_STAGE_SPECTRAL_EX = 1, AACG_STAGE_DEPENDENT_COUPLING = 2 };
@@ -48,7 +46,6 @@ struct aacg_route {
     bool     has_run;                 /* the plan has main runs */
     unsigned run_key;                 /* ... launched with this kernel (AACG_RK_*) */
     bool     rv;                      /* it walks the rendezvous cut of the chains (runs_rv / links_rv) */
-    bool     half;                    /* ... the cut into runs of 8 frames (runs_h / links_h), workgroups of 8 waves */
     bool     has_side;                /* independently switched coupling elements: their own filterbank pass into the side buffer */
     unsigned side_key;
     bool     side_first;              /* ... in front of the run kernel (fused coupling) instead of behind it */
@@ -61,7 +58,7 @@ struct aacg_route {
  * aacg_pick_route: flags of the engine and of the planned batch -> the route.  `pipelined`: the launch comes through
  * aacg_decode_pipelined; `tracing`: a -DAACG_PROFILE build with per-wave time stamps (keeps the plain kernels). */
 aacg_route aacg_pick_route(int input_kind, int output_kind, int debug_route, bool tracing, const aacg_plan_host& h, bool pipelined);
-/* the symbol of the run kernel with these switches: "aacg_imdct_run_" quant|f32 [_ex][_dd][_cpl][_rv][_i16][_nt][_h] */
+/* the symbol of the run kernel with these switches: "aacg_imdct_run_" quant|f32 [_ex][_dd][_cpl][_rv][_i16][_nt] */
 std::string aacg_run_kernel_name(unsigned key);
 /* the launches of a route by kernel name, " + " between them: what a rocprofv3 kernel trace of the batch shows */
 std::string aacg_route_names(const aacg_route& r, bool any_tns);

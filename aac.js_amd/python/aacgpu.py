@@ -32,11 +32,11 @@ ABI_SYMBOLS = ["aacg_create", "aacg_destroy", "aacg_last_error", "aacg_abi_versi
 TOOLS_SYMBOLS = ["aacg_calib_copy", "aacg_timer_create", "aacg_timer_record", "aacg_timer_elapsed_ms", "aacg_timer_destroy",
                  "aacg_pipeline_chained", "aacg_pipeline_concurrent", "aacg_decode_pipelined_timed", "aacg_debug_transform", "aacg_debug_set_route", "aacg_debug_route", "aacg_debug_run_kernel"]
 # aacg_debug_set_route / aacg_debug_route flags
-DEBUG_ROUTE_UNFUSED_COUPLING, DEBUG_ROUTE_RECOMPUTE, DEBUG_ROUTE_HALF_RUNS = 1, 8, 16
+DEBUG_ROUTE_UNFUSED_COUPLING, DEBUG_ROUTE_RECOMPUTE = 1, 8
 ROUTE_PLAN_TNS, ROUTE_PLAN_PNS, ROUTE_PLAN_LONG_CHAINS, ROUTE_PLAN_FULL_LATER_RUNS = 1, 2, 4, 8
 ROUTE_PLAN_WIDE_FRAMES, ROUTE_PLAN_CCE_INDEPENDENT, ROUTE_PLAN_CCE_DEPENDENT, ROUTE_PLAN_NO_RUNS = 0x10, 0x20, 0x40, 0x80
 # switches of a run kernel (aacg_routes.h), as aacg_debug_run_kernel returns them
-RK_QUANT, RK_I16, RK_DD, RK_EX, RK_CPL, RK_RV, RK_NT, RK_HALF = 1, 2, 4, 8, 16, 32, 64, 128
+RK_QUANT, RK_I16, RK_DD, RK_EX, RK_CPL, RK_RV, RK_NT = 1, 2, 4, 8, 16, 32, 64
 
 UNIT_DTYPE = np.dtype([
     ("stream", "<u4"), ("pcm_offset", "<u4"), ("channel", "<u2"), ("n_out_ch", "<u2"),

@@ -215,8 +215,6 @@ def main():
     ap.add_argument("--no-parity", action="store_true", help="skip the untimed oracle comparison after the timed region")
     ap.add_argument("--pipelines", type=int, default=1, choices=[1, 2],
                     help="2: alternate batches of two disjoint stream sets on two HIP streams (supplementary figure; implies --serial)")
-    ap.add_argument("--half", action="store_true",
-                    help="EXPERIMENT: plain batches on the 8-wave workgroups (runs of 8 frames, two workgroups per CU; AACG_DEBUG_ROUTE_HALF_RUNS)")
     ap.add_argument("--serial", action="store_true",
                     help="launch through aacg_decode_device on one HIP stream, every launch behind the one before it (rounds 1-4) instead "
                          "of aacg_decode_pipelined")
@@ -269,8 +267,6 @@ def main():
                         tns_mode=aacgpu.TNS_SPEC if args.tns == "spec" else aacgpu.TNS_REFERENCE,
                         output_kind=aacgpu.OUTPUT_I16 if args.output == "i16" else aacgpu.OUTPUT_F32)
 
-    if args.half:
-        eng.debug_set_route(aacgpu.DEBUG_ROUTE_HALF_RUNS)
     # rank r owns its own streams: independent data per rank, same shape
     base = aacgpu_workload.make_batch(n_streams=n_streams, n_frames=n_frames, mix=mix, layout=layout,
                                       seed=aacgpu_shard.rank_seed(0xAAC00002, rank))

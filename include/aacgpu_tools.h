@@ -50,7 +50,6 @@ int aacg_debug_transform(int device_ordinal, int sample_index, int is_short, int
  * batches; both must produce the same bits.  Set before the plan is made. */
 #define AACG_DEBUG_ROUTE_UNFUSED_COUPLING 1
 #define AACG_DEBUG_ROUTE_RECOMPUTE        8
-#define AACG_DEBUG_ROUTE_HALF_RUNS       16   /* plain stereo / mono batches on the 8-wave workgroups (runs of 8 frames, two workgroups per CU) */
 int aacg_debug_set_route(aacg_engine* e, int flags);
 
 

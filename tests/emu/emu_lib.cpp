@@ -34,11 +34,6 @@ struct launch_arg {
 void run_kernel(unsigned key, const aacg_kparams& P, const aacg_rv_args* V)
 {
     constexpr int Q = AACG_INPUT_QUANT_I16, F = AACG_INPUT_SPEC_F32, O16 = AACG_OUTPUT_I16, O32 = AACG_OUTPUT_F32;
-    if (key & AACG_RK_HALF) {                      /* workgroups of 8 waves (aacg_engine_half.hip) */
-        if (key & AACG_RK_QUANT) imdct_run_body<Q, O32, false, false, false, true, false, AACG_HALF_WAVES>(P, V);
-        else                     imdct_run_body<F, O32, false, false, false, true, false, AACG_HALF_WAVES>(P, V);
-        return;
-    }
     switch (key & ~(unsigned)AACG_RK_NT) {
     case 0:                                         imdct_run_body<F>(P); break;
     case AACG_RK_QUANT:                             imdct_run_body<Q>(P); break;
@@ -75,7 +70,6 @@ void* lane_main(void* p)
 int g_out_kind = AACG_OUTPUT_F32;          /* emu_set_output_kind: the next decodes store int16 PCM */
 int g_unfused = 0;                         /* emu_set_unfused: independent coupling as the separate pass over the PCM even where the engine fuses it */
 int g_rv = 1;                              /* emu_set_rv: chains longer than a run through the run-to-run rendezvous (the engine's route; 2: blocks in reverse); 0: recomputed frames */
-int g_half = 0;                            /* emu_set_half: plain batches on the 8-wave workgroups (AACG_DEBUG_ROUTE_HALF_RUNS) */
 int g_staged = 0;                          /* emu_set_staged: optional stages as a launch of their own even where the engine would not */
 
 /* one workgroup of a launch, its lanes as threads */
@@ -122,11 +116,9 @@ void launch(const aacg_kparams& P, int kind, unsigned key, int grid, int waves, 
     for (int b = 0; b < grid; b++) run_block(P, kind, key, b, waves, lds_bytes, n_units, PP, Q, V);
 }
 
-int run_waves(unsigned key) { return (key & AACG_RK_HALF) ? AACG_HALF_WAVES : AACG_WG_WAVES; }
 size_t run_lds_bytes(unsigned key)
 {
     const bool quant = (key & AACG_RK_QUANT) != 0;
-    if (key & AACG_RK_HALF) return quant ? AACG_LDS_BYTES_HALF_QUANT : AACG_LDS_BYTES_HALF_F32;
     if (key & AACG_RK_EX) return quant ? AACG_LDS_BYTES_QUANT_EX : AACG_LDS_BYTES_F32_EX;
     return quant ? AACG_LDS_BYTES_QUANT : AACG_LDS_BYTES_F32;
 }
@@ -142,7 +134,6 @@ extern "C" {
 const char* emu_last_error() { return g_err.c_str(); }
 void emu_set_staged(int on) { g_staged = on; }
 void emu_set_rv(int on) { g_rv = on; }
-void emu_set_half(int on) { g_half = on; }
 void emu_set_unfused(int on) { g_unfused = on; }
 void emu_set_output_kind(int kind) { g_out_kind = kind; }       /* AACG_OUTPUT_*: the pcm buffer of later decodes is int16 */
 
@@ -244,7 +235,7 @@ int emu_decode_cce(int input_kind, int sample_index, int max_streams, int max_ch
     if (ph.pcm_floats > n_pcm_floats) { g_err = "pcm buffer too small"; return AACG_ERR_CAPACITY; }
     if (ph.zero_fill) std::memset(pcm, 0, n_pcm_floats * (g_out_kind == AACG_OUTPUT_I16 ? 2 : 4));
     if (ph.any_pns && (pns_mode != AACG_PNS_SPEC || input_kind != AACG_INPUT_QUANT_I16)) { g_err = "PNS unit in a batch without AACG_PNS_SPEC"; return AACG_ERR_UNSUPPORTED; }
-    aacg_route R = aacg_pick_route(input_kind, g_out_kind, (g_unfused ? AACG_DEBUG_ROUTE_UNFUSED_COUPLING : 0) | (g_rv ? 0 : AACG_DEBUG_ROUTE_RECOMPUTE) | (g_half ? AACG_DEBUG_ROUTE_HALF_RUNS : 0), false, ph, false);
+    aacg_route R = aacg_pick_route(input_kind, g_out_kind, (g_unfused ? AACG_DEBUG_ROUTE_UNFUSED_COUPLING : 0) | (g_rv ? 0 : AACG_DEBUG_ROUTE_RECOMPUTE), false, ph, false);
     if (g_staged && R.has_run && (R.run_key & AACG_RK_EX)) {     /* test switch: the optional stages as a launch of their own even where the engine runs them inside */
         R.stage = AACG_STAGE_SPECTRAL_EX; R.stage_quant = input_kind == AACG_INPUT_QUANT_I16;
         R.run_key = 0;
@@ -275,18 +266,17 @@ int emu_decode_cce(int input_kind, int sample_index, int max_streams, int max_ch
         /* plain batches with a chain longer than a run: every run 16 frames, a rendezvous between consecutive runs
          * (imdct_run_body<..., RV>); block order forward or — g_rv == 2 — reversed */
         static unsigned long long epoch = 1000;
-        const uint32_t n_links = R.half ? ph.n_links_h : ph.n_links_rv;
-        std::vector<unsigned long long> rv_state((size_t)n_links * AACG_RV_STATE_WORDS + 1, 0x5a5a5a5a5a5a5a5aull);
-        std::vector<float> rv_data((size_t)n_links * AACG_RV_DATA_FLOATS + 1, std::numeric_limits<float>::quiet_NaN());
-        std::vector<aacg_run> runs = R.half ? ph.runs_h : ph.runs_rv;
-        std::vector<aacg_rv_link> links = R.half ? ph.links_h : ph.links_rv;
+        std::vector<unsigned long long> rv_state((size_t)ph.n_links_rv * AACG_RV_STATE_WORDS + 1, 0x5a5a5a5a5a5a5a5aull);
+        std::vector<float> rv_data((size_t)ph.n_links_rv * AACG_RV_DATA_FLOATS + 1, std::numeric_limits<float>::quiet_NaN());
+        std::vector<aacg_run> runs = ph.runs_rv;
+        std::vector<aacg_rv_link> links = ph.links_rv;
         if (g_rv == 2) { std::reverse(runs.begin(), runs.end()); std::reverse(links.begin(), links.end()); }
         aacg_kparams K = P;
         K.runs = runs.data(); K.n_runs = (int32_t)runs.size(); K.scratch = nullptr;
         aacg_rv_args V;
         std::memset(&V, 0, sizeof V);
         V.links = links.data(); V.state = rv_state.data(); V.data = rv_data.data(); V.epoch = ++epoch;
-        launch(K, 1, R.run_key, (int)runs.size(), run_waves(R.run_key), run_lds_bytes(R.run_key), 0, nullptr, nullptr, &V);
+        launch(K, 1, R.run_key, (int)runs.size(), AACG_WG_WAVES, run_lds_bytes(R.run_key), 0, nullptr, nullptr, &V);
     } else {
         if (R.stage == AACG_STAGE_DEPENDENT_COUPLING) {
             spec.assign((size_t)ph.coef_blocks * 1024u, 0.0f);
@@ -345,12 +335,10 @@ int emu_decode_pipelined(int input_kind, int sample_index, int max_streams, int 
     int rc = aacg_plan_build(units, n_units, sample_index, max_streams, max_channels, parity, &ph, &g_err);
     if (rc) return rc;
     if (ph.pcm_floats > n_pcm_floats) { g_err = "pcm buffer too small"; return AACG_ERR_CAPACITY; }
-    const aacg_route R = aacg_pick_route(input_kind, AACG_OUTPUT_F32, g_half ? AACG_DEBUG_ROUTE_HALF_RUNS : 0, false, ph, true);
+    const aacg_route R = aacg_pick_route(input_kind, AACG_OUTPUT_F32, 0, false, ph, true);
     if (!R.overlappable) { g_err = "not a plain batch"; return AACG_ERR_UNSUPPORTED; }
     static unsigned long long epoch = 5000;
-    const size_t cells = R.half ? (size_t)ph.n_links_h : (size_t)ph.n_links_rv;
-    const std::vector<aacg_run>& p_runs = R.half ? ph.runs_h : ph.runs_rv;
-    const std::vector<aacg_rv_link>& p_links = R.half ? ph.links_h : ph.links_rv;
+    const size_t cells = (size_t)ph.n_links_rv;
     std::vector<unsigned long long> rv_state(2 * cells * AACG_RV_STATE_WORDS + 1, 0x5a5a5a5a5a5a5a5aull);
     std::vector<float> rv_data(2 * cells * AACG_RV_DATA_FLOATS + 1, std::numeric_limits<float>::quiet_NaN());
     std::vector<aacg_kparams> P((size_t)n_launches);
@@ -359,18 +347,18 @@ int emu_decode_pipelined(int input_kind, int sample_index, int max_streams, int 
         if (ph.zero_fill) std::memset(pcm[j], 0, n_pcm_floats * 4);
         std::memset(&P[(size_t)j], 0, sizeof(aacg_kparams));
         aacg_kparams& p = P[(size_t)j];
-        p.units = ph.units.data(); p.runs = p_runs.data(); p.coeffs = coeffs[j]; p.meta = meta ? meta[j] : nullptr; p.pcm = pcm[j];
-        p.overlap = overlap_pool; p.tab = &g_tab; p.flip = j % AACG_OV_BUFFERS; p.n_runs = (int32_t)p_runs.size();
+        p.units = ph.units.data(); p.runs = ph.runs_rv.data(); p.coeffs = coeffs[j]; p.meta = meta ? meta[j] : nullptr; p.pcm = pcm[j];
+        p.overlap = overlap_pool; p.tab = &g_tab; p.flip = j % AACG_OV_BUFFERS; p.n_runs = (int32_t)ph.runs_rv.size();
         aacg_rv_args& v = V[(size_t)j];
         std::memset(&v, 0, sizeof v);
-        v.links = p_links.data();
+        v.links = ph.links_rv.data();
         v.state = rv_state.data() + (size_t)(j & 1) * cells * AACG_RV_STATE_WORDS;
         v.data = rv_data.data() + (size_t)(j & 1) * cells * AACG_RV_DATA_FLOATS;
         v.epoch = ++epoch;
         v.xl_cells = (aacg_xl_cell*)xl_cells; v.xl_head = xl_head;
         v.epoch_in = j ? V[(size_t)j - 1].epoch : first_epoch_in;
     }
-    const int B = (int)p_runs.size();
+    const int B = (int)ph.runs_rv.size();
     std::vector<std::pair<int, int>> sched;               /* (launch, block) */
     if (order == 0) {
         for (int j = 0; j < n_launches; j++) for (int b = 0; b < B; b++) sched.emplace_back(j, b);
@@ -407,7 +395,7 @@ int emu_decode_pipelined(int input_kind, int sample_index, int max_streams, int 
         }
     }
     for (auto& jb : sched)
-        run_block(P[(size_t)jb.first], 1, R.run_key, jb.second, run_waves(R.run_key), run_lds_bytes(R.run_key), 0, nullptr, nullptr, &V[(size_t)jb.first]);
+        run_block(P[(size_t)jb.first], 1, R.run_key, jb.second, AACG_WG_WAVES, run_lds_bytes(R.run_key), 0, nullptr, nullptr, &V[(size_t)jb.first]);
     for (auto& c : ph.chains)
         for (int k = 0; k < c.n_ch; k++) { uint8_t& b = parity[(size_t)c.stream * (size_t)max_channels + c.channel + k]; b = (uint8_t)((b + n_launches) % AACG_OV_BUFFERS); }
     if (last_epoch) *last_epoch = n_launches ? V[(size_t)n_launches - 1].epoch : first_epoch_in;

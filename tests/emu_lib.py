@@ -45,7 +45,7 @@ class Emu:
     def error(self):
         return self.lib.emu_last_error().decode()
 
-    def decode(self, units, coeffs, meta, n_pcm, pool, parity, sample_index=3, tns=None, pns=False, int16_out=False, cce=None, staged=False, unfused=False, rv=1, half=False):
+    def decode(self, units, coeffs, meta, n_pcm, pool, parity, sample_index=3, tns=None, pns=False, int16_out=False, cce=None, staged=False, unfused=False, rv=1):
         """staged: the optional stages (TNS, PNS) as a launch of their own even where the engine would run them inside the run kernel.
         unfused: independent coupling as the separate pass over the PCM (what plans with double-duty runs take) even where the
         engine applies it in the targets' epilogues."""
@@ -58,7 +58,6 @@ class Emu:
         self.lib.emu_set_output_kind(1 if int16_out else 0)
         self.lib.emu_set_staged(1 if staged else 0)
         self.lib.emu_set_unfused(1 if unfused else 0)
-        self.lib.emu_set_half(1 if half else 0)   # plain batches on the 8-wave workgroups (runs of 8 frames)
         self.lib.emu_set_rv(rv)           # 1: chains longer than a run through the run-to-run rendezvous (the engine's route); 2: blocks in reverse; 0: recomputed frames
         cce = np.ascontiguousarray(cce) if cce is not None else None
         rc = self.lib.emu_decode_cce(kind, sample_index, pool.shape[0], pool.shape[1], units.ctypes.data, len(units),
@@ -70,7 +69,6 @@ class Emu:
         self.lib.emu_set_staged(0)
         self.lib.emu_set_unfused(0)
         self.lib.emu_set_rv(1)
-        self.lib.emu_set_half(0)
         if rc:
             raise RuntimeError("emu_decode rc=%d: %s" % (rc, self.error()))
         return pcm
@@ -90,7 +88,7 @@ class Emu:
         assert len(first) == len(nxt)
         return self.lib.emu_plan_refresh(first.ctypes.data, nxt.ctypes.data, len(first), sample_index, max_streams, max_channels, 1 if tns_spec else 0)
 
-    def decode_pipelined(self, units, coeffs_list, meta_list, n_pcm, pool, parity, cells, heads, order=0, epoch_in=0, sample_index=3, half=False):
+    def decode_pipelined(self, units, coeffs_list, meta_list, n_pcm, pool, parity, cells, heads, order=0, epoch_in=0, sample_index=3):
         """aacg_decode_pipelined for len(coeffs_list) consecutive launches of ONE plan, workgroup by workgroup in an order the
         engine's rules allow (order: 0 launch after launch, 1 the later launch of every pair first, >= 2 random interleaving with
         that seed).  cells: uint64 [S][C][OV_BUFFERS][4] (aacg_xl_cell), heads: like pool.  Returns (list of PCM arrays, epoch of the
@@ -105,10 +103,8 @@ class Emu:
         mp = (C.c_void_p * n)(*[m.ctypes.data for m in meta_list]) if meta_list is not None else None
         pp = (C.c_void_p * n)(*[x.ctypes.data for x in pcm])
         last = C.c_uint64(0)
-        self.lib.emu_set_half(1 if half else 0)
         rc = self.lib.emu_decode_pipelined(kind, sample_index, pool.shape[0], pool.shape[1], units.ctypes.data, len(units), n, cp, mp, pp, n_pcm,
                                            pool.ctypes.data, parity.ctypes.data, cells.ctypes.data, heads.ctypes.data, order, epoch_in, C.byref(last))
-        self.lib.emu_set_half(0)
         if rc:
             raise RuntimeError("emu_decode_pipelined rc=%d: %s" % (rc, self.error()))
         return pcm, last.value

@@ -14,7 +14,7 @@ O32, O16 = A.OUTPUT_F32, A.OUTPUT_I16
 def compose(key):
     """aacg_run_kernel_name: the symbol a set of switches stands for"""
     s = "aacg_imdct_run_" + ("quant" if key & A.RK_QUANT else "f32")
-    for bit, suffix in ((A.RK_EX, "_ex"), (A.RK_DD, "_dd"), (A.RK_CPL, "_cpl"), (A.RK_RV, "_rv"), (A.RK_I16, "_i16"), (A.RK_NT, "_nt"), (A.RK_HALF, "_h")):
+    for bit, suffix in ((A.RK_EX, "_ex"), (A.RK_DD, "_dd"), (A.RK_CPL, "_cpl"), (A.RK_RV, "_rv"), (A.RK_I16, "_i16"), (A.RK_NT, "_nt")):
         if key & bit:
             s += suffix
     return s
@@ -22,11 +22,11 @@ def compose(key):
 
 def test_every_registered_kernel_carries_the_symbol_its_switches_compose(engine_lib):
     reg = A.run_kernels()
-    assert len(reg) == 24 and len(set(reg.values())) == 24          # one kernel per set of switches
+    assert len(reg) == 22 and len(set(reg.values())) == 22          # one kernel per set of switches
     for name, key in reg.items():
         assert name == compose(key), (name, key)
     both = {n.replace("_quant", "_X").replace("_f32", "_X") for n in reg}
-    assert len(both) == 12                                          # every variant exists for both seams
+    assert len(both) == 11                                          # every variant exists for both seams
 
 
 def test_named_variants_are_the_routes_of_the_batches_they_were_built_for(engine_lib):

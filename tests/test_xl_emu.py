@@ -108,37 +108,3 @@ def test_window_switching_across_the_launch_boundary(emu, oracle):
         got, _ = emu.decode_pipelined(base["units"], coeffs, [base["meta"]] * n, base["n_pcm"], pool, par, cells, heads, order=order)
         for j in range(n):
             assert np.array_equal(got[j].view(np.uint32), serial[j].view(np.uint32)), (order, j)
-
-
-@pytest.mark.parametrize("layout,S,T,n,seam,mix", [(("cpe",), 2, 16, 5, "q", False), (("cpe",), 1, 21, 4, "f", True), (("sce",), 2, 9, 4, "q", True), (("sce", "cpe"), 1, 16, 3, "q", True)])
-def test_workgroups_of_eight_waves_equal_the_serialised_route_bit_for_bit(emu, oracle, layout, S, T, n, seam, mix):
-    """the same kernels as workgroups of 8 waves (aacg_engine_half.hip: runs of up to 8 frames, the table block without the
-    windows, which come from global memory; two workgroups per CU on the GPU): serial launches and overlapped ones in several
-    orders, bit for bit the plain kernels' PCM and state"""
-    base = W.make_batch(n_streams=S, n_frames=T, layout=layout, mix=mix, intensity=mix, seed=33)
-    C = base["C"]
-    ov = np.zeros((S, C, 1024), np.float32)
-    coeffs, refs = [], []
-    for j in range(n):
-        q = np.roll(base["q"], 7 * j, axis=0)
-        ref, spec = oracle.decode_batch(base["units"], q, base["meta"], base["n_pcm"], ov, want_spec=True)
-        refs.append(ref)
-        coeffs.append(q if seam == "q" else spec.astype(np.float32))
-    metas = [base["meta"]] * n if seam == "q" else None
-    pool, par = emu_lib.new_pool(S, C)
-    serial = [emu.decode(base["units"], coeffs[j], metas[j] if metas else None, base["n_pcm"], pool, par) for j in range(n)]
-    serial_state = emu_lib.pool_current(pool, par)
-    assert float(np.sqrt(np.mean((serial[0].astype(np.float64) - refs[0]) ** 2))) < 1e-5
-    for rv in (1, 2):                                   # serial launches on the 8-wave workgroups, blocks forward and reversed
-        pool, par = emu_lib.new_pool(S, C)
-        got = [emu.decode(base["units"], coeffs[j], metas[j] if metas else None, base["n_pcm"], pool, par, rv=rv, half=True) for j in range(n)]
-        for j in range(n):
-            assert np.array_equal(got[j].view(np.uint32), serial[j].view(np.uint32)), (rv, j)
-        assert np.array_equal(emu_lib.pool_current(pool, par).view(np.uint32), serial_state.view(np.uint32))
-    for order in (0, 1, 5):
-        pool, par = emu_lib.new_pool(S, C)
-        cells, heads = _cells(S, C)
-        got, _ = emu.decode_pipelined(base["units"], coeffs, metas, base["n_pcm"], pool, par, cells, heads, order=order, half=True)
-        for j in range(n):
-            assert np.array_equal(got[j].view(np.uint32), serial[j].view(np.uint32)), (order, j)
-        assert np.array_equal(emu_lib.pool_current(pool, par).view(np.uint32), serial_state.view(np.uint32)), order
