@@ -342,7 +342,7 @@ GpuAACDecoder.prototype.unitsOfFrame = function (frame, frameSlot, blockBase, tn
  * malformed: it is thrown by the readChunk call that reaches it, after the good frames before it have been returned,
  * which is what a caller of the reference sees frame by frame (decoder.js:125-201 throws at exactly that frame). */
 GpuAACDecoder.prototype.readChunk = function () {
-    if (!this.queue.length) { if (this.shared) this.shared.flush(); else this.decodeAhead(); }
+    if (!this.queue.length) { if (this.shared && this.group) this.shared.flush(); else this.decodeAhead(); }
     if (!this.queue.length) return null;
     const next = this.queue.shift();
     if (next instanceof Error) throw next;
@@ -424,7 +424,18 @@ GpuAACDecoder.prototype.decodeAhead = function () {
 GpuAACDecoder.prototype.close = function () { if (this.shared) this.shared.detach(this); };
 
 /* bytes from the demuxer ('data' events of AdtsDemuxer / an MP4 demuxer's samples) to the front end */
-GpuAACDecoder.prototype.feed = function (bytes) { this.frontend.push(bytes.data || bytes); };
+GpuAACDecoder.prototype.feed = function (bytes) {
+    bytes = bytes.data || bytes;
+    if (this.resident) {                                // a resident SharedEngine parses on the device: the decoder only keeps the bytes
+        const rest = this.rbuf.length - this.rpos;
+        if (!rest) { this.rbuf = bytes; this.rpos = 0; return; }
+        const joined = new Uint8Array(rest + bytes.length);
+        joined.set(this.rbuf.subarray(this.rpos)); joined.set(bytes, rest);
+        this.rbuf = joined; this.rpos = 0;
+        return;
+    }
+    this.frontend.push(bytes);
+};
 GpuAACDecoder.prototype.feedPacket = function (bytes, multi) { this.frontend.pushPacket(bytes.data || bytes, multi); };   // multi: the buffer may hold several samples
 
 module.exports = { Engine, GpuAACDecoder, BitReader, packUnits, unpackUnits, packBandWord, packTns, unpackTns, packCce, CCE_REFERENCE, CCE_SPEC, CCE_BYTES, applyPulses, loadAddon,

@@ -13,7 +13,17 @@
  * The surface stays the reference's (init / setCookie / readChunk, synchronous); a stream's frames still come back in order,
  * a malformed frame's error is still thrown by the readChunk call that reaches it, and a stream's PCM does not depend on
  * which other streams shared its batches (streams only meet in the launch: no arithmetic crosses them).  An engine error
- * on a shared batch is retried decoder by decoder, so that it only costs the stream that caused it.
+ * raised BEFORE anything was launched (a refused unit, a capacity or layout error) is retried decoder by decoder, so that it
+ * only costs the stream that caused it; a device error goes to every stream of the batch (their state may have moved).
+ *
+ * { resident: true } — the front end on the device as well: the decoders do not parse at all.  Each keeps the bytes its
+ * demuxer fed it; a flush finds the next frames' boundaries (the 13-bit ADTS frame_length: six byte reads per frame), hands the
+ * bytes of ALL streams to ONE native call (aacg_pipeline_decode: bit streams up, parse kernel, kept plan refreshed on the device,
+ * transform kernel, PCM down) and slices what comes back.  JavaScript touches no coefficient and no unit record; what
+ * readChunk() returns are views of the batch's PCM array.  For streams whose frames are one SCE or one CPE
+ * (channel_configuration 1 / 2), as the reference executes them (TNS identity, no PNS / coupling modes); decoders of other
+ * layouts on a resident SharedEngine take the parsing route above, on an engine of their own sample rate.
+ * Replaces, per batch, what src/decoder.js:125-216 does per frame.
  */
 'use strict';
 const host = require('./index.js');
@@ -24,7 +34,17 @@ function SharedEngine(opts) {
     this.maxStreams = opts.maxStreams || 256;
     this.maxChannels = opts.maxChannels || 8;
     this.groups = new Map();                              // sampleIndex -> { engine, decoders: [], free: [] }
+    this.resident = !!opts.resident;                      // bytes -> PCM in one native call per flush (aacg_pipeline_*)
+    this.lookahead = opts.lookahead || 16;                // resident: frames per stream and flush
     this.stats = { batches: 0, frames: 0, units: 0, engineNs: 0n, retries: 0 };
+}
+
+/* error codes the engine raises before it has launched anything (include/aacgpu.h): a batch refused with one of these has
+ * advanced no stream, and may be retried in parts */
+const BEFORE_LAUNCH = [-1, -4, -5, -6];                   // INVALID_ARG, CAPACITY, UNSUPPORTED, LAYOUT_CHANGE
+function refusedBeforeLaunch(err) {
+    const m = /failed \((-?\d+)\)/.exec(String(err && err.message));
+    return !!m && BEFORE_LAUNCH.indexOf(parseInt(m[1], 10)) >= 0;
 }
 
 /* called by GpuAACDecoder.setCookie: the engine for the decoder's sample rate and a stream slot in it */
@@ -32,6 +52,8 @@ SharedEngine.prototype.attach = function (dec) {
     const cfg = dec.config;
     if (cfg.chanConfig + dec.maxCoupling > this.maxChannels) throw new Error('SharedEngine: ' + cfg.chanConfig + ' channels exceed maxChannels ' + this.maxChannels);
     if (dec.group) this.detach(dec);                       // a new cookie: a new stream
+    if (this.resident && cfg.profile === 2 && (cfg.chanConfig === 1 || cfg.chanConfig === 2) && !dec.tnsMode && !dec.pnsMode && !dec.cceMode && !dec.carryWindowShape)
+        return this.attachResident(dec);
     let g = this.groups.get(cfg.sampleIndex);
     if (!g) {
         const o = this.opts;
@@ -49,6 +71,27 @@ SharedEngine.prototype.attach = function (dec) {
     g.decoders.push(dec);
 };
 
+/* resident route: one pipeline (engine + parser on the device) per (sample rate, channel count) */
+SharedEngine.prototype.attachResident = function (dec) {
+    const cfg = dec.config, key = 'r' + cfg.sampleIndex + '/' + cfg.chanConfig;
+    let g = this.groups.get(key);
+    if (!g) {
+        const addon = host.loadAddon(), rec = require('./codebooks.js').load(this.opts).toEntryRecords();
+        const outI16 = (this.opts.outputKind | 0) === host.OUTPUT_I16;
+        const pipeline = addon.pipelineCreate({ deviceOrdinal: this.opts.deviceOrdinal | 0, sampleIndex: cfg.sampleIndex, maxStreams: this.maxStreams,
+                                                channels: cfg.chanConfig, maxFrames: this.lookahead, outputKind: this.opts.outputKind | 0,
+                                                parseOptions: (this.opts.applyPulses ? 1 : 0) | (this.opts.referenceQuirks !== false ? 2 : 0) }, rec.entries, rec.counts);
+        g = { resident: true, addon: addon, pipeline: pipeline, channels: cfg.chanConfig, outI16: outI16, decoders: [], free: [], next: 0 };
+        this.groups.set(key, g);
+    }
+    const slot = g.free.length ? g.free.pop() : g.next++;
+    if (slot >= this.maxStreams) { g.next--; throw new Error('SharedEngine: more than ' + this.maxStreams + ' streams at one sample rate'); }
+    dec.stream = slot; dec.group = g; dec.resident = true;
+    dec.rbuf = new Uint8Array(0); dec.rpos = 0;
+    dec.engine = { resetStream: function (s) { g.addon.pipelineResetStream(g.pipeline, s); } };
+    g.decoders.push(dec);
+};
+
 SharedEngine.prototype.detach = function (dec) {
     const g = dec.group;
     if (!g) return;
@@ -57,19 +100,81 @@ SharedEngine.prototype.detach = function (dec) {
     dec.group = null;
 };
 
+/* how many complete ADTS frames (at most `max`) start at byte `at` of `b`: their lengths into `lens`; -1 where the bytes at a
+ * frame boundary are not an ADTS header (the reference's 'Invalid ADTS header.', adts_demuxer.js:29) */
+function scanFrames(b, at, max, lens) {
+    let n = 0;
+    while (n < max && at + 7 <= b.length) {
+        if (b[at] !== 0xff || (b[at + 1] & 0xf0) !== 0xf0) return n ? n : -1;
+        const len = ((b[at + 3] & 3) << 11) | (b[at + 4] << 3) | (b[at + 5] >> 5);
+        if (len < 7 || at + len > b.length) break;
+        lens[n++] = len; at += len;
+    }
+    return n;
+}
+
+/* resident flush: the next frames of every stream that has run dry or has room, ONE native call, views of its PCM handed out */
+SharedEngine.prototype.flushResident = function (g) {
+    const L = this.lookahead, C = g.channels;
+    const part = [], lens = new Uint32Array(L);
+    let F = L, total = 0;
+    for (const dec of g.decoders) {
+        if (dec.queue.length >= L) continue;               // a slow reader's queue does not grow with every flush of its peers
+        const n = scanFrames(dec.rbuf, dec.rpos, L, lens);
+        if (n < 0) { if (!dec.badHeader) { dec.badHeader = true; dec.queue.push(new Error('Invalid ADTS header.')); } continue; }
+        if (n === 0) continue;
+        part.push(dec); F = Math.min(F, n);
+    }
+    if (!part.length) return;
+    const S = part.length, frames = new Uint32Array(2 * S * F), slots = new Uint32Array(S), starts = new Uint32Array(S);
+    part.forEach(function (dec, s) {
+        scanFrames(dec.rbuf, dec.rpos, F, lens);
+        let len = 0;
+        for (let f = 0; f < F; f++) { frames[2 * (s * F + f)] = total + len; frames[2 * (s * F + f) + 1] = lens[f]; len += lens[f]; }
+        starts[s] = total; slots[s] = dec.stream; total += len;
+    });
+    const bytes = new Uint8Array(total);
+    part.forEach(function (dec, s) {
+        const len = (s + 1 < S ? starts[s + 1] : total) - starts[s];
+        bytes.set(dec.rbuf.subarray(dec.rpos, dec.rpos + len), starts[s]);
+        dec.rpos += len;
+    });
+    const pcm = g.outI16 ? new Int16Array(S * F * 1024 * C) : new Float32Array(S * F * 1024 * C), results = new Uint8Array(8 * S * F);
+    const t0 = process.hrtime.bigint();
+    let refused = 0, failed = null;
+    try { refused = g.addon.pipelineDecode(g.pipeline, bytes, frames, slots, F, pcm, results); } catch (err) { failed = err instanceof Error ? err : new Error(String(err)); }
+    this.stats.engineNs += process.hrtime.bigint() - t0;
+    this.stats.batches++; this.stats.units += S * F;
+    const per = 1024 * C;
+    part.forEach(function (dec, s) {
+        if (failed) { dec.queue.push(failed); return; }
+        for (let f = 0; f < F; f++) {
+            const i = s * F + f;
+            /* a frame the device refused: the reference's message for its status where the frame is reached (it was decoded as
+             * silence: the stream goes on); a frame whose elements are not the stream's channel configuration likewise */
+            if (refused && results[8 * i]) dec.queue.push(new Error(g.addon.parseStatusString(results[8 * i])));
+            else if (refused && (results[8 * i + 1] !== 1 || results[8 * i + 2] !== C)) dec.queue.push(new Error('aacgpu: the frame\'s elements are not the stream\'s channel configuration'));
+            else dec.queue.push(pcm.subarray(i * per, (i + 1) * per));
+        }
+    });
+    if (!failed) this.stats.frames += S * F;
+};
+
 /* every registered decoder parses ahead what it has buffered; one batch per engine */
 SharedEngine.prototype.flush = function () {
     for (const g of this.groups.values()) this.flushGroup(g);
 };
 
 SharedEngine.prototype.flushGroup = function (g) {
+    if (g.resident) return this.flushResident(g);
     const tnsList = (this.opts.tnsMode | 0) === host.TNS_SPEC ? [] : null, cceList = (this.opts.cceMode | 0) === host.CCE_SPEC ? [] : null;
     const parts = [];
     let block = 0, pcmAt = 0;
     for (const dec of g.decoders) {
         let part;
+        if (dec.failedProfile || dec.queue.length >= dec.lookahead) continue;     // a paused reader's queue does not grow with every flush of its peers
         try { part = dec.collectAhead(block, pcmAt, tnsList, cceList); }
-        catch (err) { dec.queue.push(err instanceof Error ? err : new Error(String(err))); continue; }    // unsupported profile: that decoder's own error
+        catch (err) { dec.failedProfile = true; dec.queue.push(err instanceof Error ? err : new Error(String(err))); continue; }    // unsupported profile: that decoder's own error, once
         if (!part.frames.length) { dec.deliver(part, null, 0, null); continue; }
         part.dec = dec; part.blockBase = block; part.pcmBase = pcmAt;
         /* where this part's TNS / coupling records sit in the shared lists is already in its units */
@@ -91,8 +196,14 @@ SharedEngine.prototype.flushGroup = function (g) {
         for (const p of parts) { p.dec.deliver(p, pcm, p.pcmBase, null); this.stats.frames += p.frames.length; }
         return;
     }
-    /* the engine refused the batch as a whole (nothing was decoded, no state advanced): decoder by decoder, so that only the
-     * stream whose frames it refuses pays for it */
+    /* a device error: the launch may have advanced every stream's state — decoding the same frames again would advance it
+     * twice and deliver wrong PCM without an error: the error goes to every stream of the batch instead */
+    if (!refusedBeforeLaunch(failed)) {
+        for (const p of parts) p.dec.deliver(p, pcm, p.pcmBase, failed);
+        return;
+    }
+    /* the engine refused the batch as a whole before launching anything (nothing was decoded, no state advanced): decoder by
+     * decoder, so that only the stream whose frames it refuses pays for it */
     this.stats.retries++;
     for (const p of parts) {
         let refused = null;

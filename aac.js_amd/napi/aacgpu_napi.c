@@ -42,6 +42,12 @@ static struct {
     const char* (*parse_status_string)(int);
     int  (*parse_batch)(aacg_parser*, const uint8_t*, size_t, const aacg_parse_frame*, uint32_t, uint32_t, uint32_t, uint32_t,
                         aacg_unit_desc*, int16_t*, aacg_band_meta*, aacg_tns_info*, aacg_parse_result*);
+    int  (*pipeline_create)(const aacg_pipeline_config*, const aacg_code_entry*, const uint32_t*, aacg_pipeline**);
+    void (*pipeline_destroy)(aacg_pipeline*);
+    const char* (*pipeline_last_error)(const aacg_pipeline*);
+    int  (*pipeline_reset_stream)(aacg_pipeline*, uint32_t);
+    int  (*pipeline_decode)(aacg_pipeline*, const uint8_t*, size_t, const aacg_parse_frame*, const uint32_t*, uint32_t, uint32_t,
+                            void*, aacg_parse_result*, uint32_t*);
 } L;
 
 #define CHECK(env, call) do { if ((call) != napi_ok) { napi_throw_error((env), NULL, "aacgpu: N-API call failed: " #call); return NULL; } } while (0)
@@ -72,6 +78,8 @@ static int load_lib(napi_env env, const char* path)
     SYM(decode_batch_ex, "aacg_decode_batch_ex"); SYM(decode_batch_tns, "aacg_decode_batch_tns"); SYM(submit_tns, "aacg_submit_tns");
     SYM(parser_create, "aacg_parser_create"); SYM(parser_destroy, "aacg_parser_destroy"); SYM(parser_last_error, "aacg_parser_last_error");
     SYM(parse_status_string, "aacg_parse_status_string"); SYM(parse_batch, "aacg_parse_batch");
+    SYM(pipeline_create, "aacg_pipeline_create"); SYM(pipeline_destroy, "aacg_pipeline_destroy"); SYM(pipeline_last_error, "aacg_pipeline_last_error");
+    SYM(pipeline_reset_stream, "aacg_pipeline_reset_stream"); SYM(pipeline_decode, "aacg_pipeline_decode");
 #undef SYM
     return 1;
 }
@@ -90,6 +98,7 @@ static int get_i32(napi_env env, napi_value obj, const char* key, int32_t dflt)
  * turns.  Jobs keep a reference on the external, so a collected Engine object cannot be finalised under a running job. */
 #define BOX_ENGINE 0x41454e47u   /* 'AENG' */
 #define BOX_PARSER 0x41505253u   /* 'APRS' */
+#define BOX_PIPELINE 0x4150504cu /* 'APPL' */
 typedef struct { uint32_t kind; void* ptr; pthread_mutex_t lock; int out_i16; /* engine: AACG_OUTPUT_I16 */ } handle_box;
 
 static handle_box* box_new(uint32_t kind, void* ptr)
@@ -453,6 +462,101 @@ static napi_value js_parse_batch(napi_env env, napi_callback_info info)
     return argv[10];
 }
 
+/* ---- bytes in, PCM out (aacg_pipeline_*): the resident route behind SharedEngine({ resident: true }) ------------------- */
+static void pipeline_finalize(napi_env env, void* data, void* hint)
+{
+    (void)env; (void)hint;
+    handle_box* b = (handle_box*)data;
+    if (!b) return;
+    if (b->ptr && L.pipeline_destroy) L.pipeline_destroy((aacg_pipeline*)b->ptr);
+    b->kind = 0;
+    pthread_mutex_destroy(&b->lock);
+    free(b);
+}
+
+/* pipelineCreate({deviceOrdinal, sampleIndex, maxStreams, channels, maxFrames, outputKind, parseOptions}, entries, counts) -> external */
+static napi_value js_pipeline_create(napi_env env, napi_callback_info info)
+{
+    size_t argc = 3; napi_value argv[3], out;
+    CHECK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    if (!L.dl) { napi_throw_error(env, NULL, "aacgpu: call load(path) first"); return NULL; }
+    napi_typedarray_type te, tc; size_t ne, nc; void *de, *dc;
+    if (!typed(env, argv[1], &te, &ne, &de) || te != napi_uint8_array || ne % sizeof(aacg_code_entry) ||
+        !typed(env, argv[2], &tc, &nc, &dc) || tc != napi_uint32_array || nc != 12) {
+        napi_throw_type_error(env, NULL, "pipelineCreate(opts, entries:Uint8Array of 12-byte aacg_code_entry, counts:Uint32Array(12))"); return NULL; }
+    size_t total = 0;
+    for (int b = 0; b < 12; b++) total += ((const uint32_t*)dc)[b];
+    if (total * sizeof(aacg_code_entry) != ne) { napi_throw_type_error(env, NULL, "counts do not add up to the number of entries"); return NULL; }
+    aacg_pipeline_config cfg;
+    memset(&cfg, 0, sizeof cfg);
+    cfg.abi_version = AACG_ABI_VERSION;
+    cfg.device_ordinal = get_i32(env, argv[0], "deviceOrdinal", 0);
+    cfg.sample_index = get_i32(env, argv[0], "sampleIndex", 3);
+    cfg.max_streams = get_i32(env, argv[0], "maxStreams", 1);
+    cfg.channels = get_i32(env, argv[0], "channels", 2);
+    cfg.max_frames = get_i32(env, argv[0], "maxFrames", 16);
+    cfg.output_kind = get_i32(env, argv[0], "outputKind", AACG_OUTPUT_F32);
+    cfg.parse_options = get_i32(env, argv[0], "parseOptions", AACG_PARSE_REFERENCE_QUIRKS);
+    aacg_pipeline* p = NULL;
+    int rc = L.pipeline_create(&cfg, (const aacg_code_entry*)de, (const uint32_t*)dc, &p);
+    if (rc) {
+        char msg[256];
+        snprintf(msg, sizeof msg, "aacgpu: aacg_pipeline_create failed (%d) (is a GPU visible?)", rc);
+        napi_throw_error(env, NULL, msg);
+        return NULL;
+    }
+    handle_box* b = box_new(BOX_PIPELINE, p);
+    if (!b) { L.pipeline_destroy(p); napi_throw_error(env, NULL, "aacgpu: out of memory"); return NULL; }
+    b->out_i16 = cfg.output_kind == AACG_OUTPUT_I16;
+    CHECK(env, napi_create_external(env, b, pipeline_finalize, NULL, &out));
+    return out;
+}
+
+/* pipelineDecode(pipeline, bytes:Uint8Array, frames:Uint32Array(2 * S * F) [offset, length]..., slots:Uint32Array(S), framesPerStream,
+ *                pcm:Float32Array|Int16Array(S * F * 1024 * channels), results:Uint8Array(8 * S * F)) -> frames refused */
+static napi_value js_pipeline_decode(napi_env env, napi_callback_info info)
+{
+    size_t argc = 7; napi_value argv[7], out;
+    CHECK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    if (argc < 7) { napi_throw_error(env, NULL, "aacgpu: pipelineDecode takes 7 arguments"); return NULL; }
+    handle_box* pb = box_of(env, argv[0], BOX_PIPELINE, "aacgpu: bad pipeline handle");
+    if (!pb) return NULL;
+    napi_typedarray_type t; size_t nb, nf, ns, np, nr; void *db, *df, *ds, *dp, *dr; uint32_t F = 0;
+    napi_get_value_uint32(env, argv[4], &F);
+    if (!typed(env, argv[1], &t, &nb, &db) || t != napi_uint8_array || !typed(env, argv[2], &t, &nf, &df) || t != napi_uint32_array ||
+        !typed(env, argv[3], &t, &ns, &ds) || t != napi_uint32_array || !F || nf != 2 * ns * F ||
+        !typed(env, argv[5], &t, &np, &dp) || t != (pb->out_i16 ? napi_int16_array : napi_float32_array) ||
+        !typed(env, argv[6], &t, &nr, &dr) || t != napi_uint8_array || nr != ns * F * sizeof(aacg_parse_result)) {
+        napi_throw_type_error(env, NULL, "pipelineDecode(pipeline, Uint8Array bytes, Uint32Array frames (2 per frame), Uint32Array slots, framesPerStream, Float32Array|Int16Array pcm, Uint8Array results (8 per frame))");
+        return NULL;
+    }
+    uint32_t refused = 0;
+    pthread_mutex_lock(&pb->lock);
+    aacg_pipeline* p = (aacg_pipeline*)pb->ptr;
+    int rc = L.pipeline_decode(p, (const uint8_t*)db, nb, (const aacg_parse_frame*)df, (const uint32_t*)ds, (uint32_t)ns, F, dp, (aacg_parse_result*)dr, &refused);
+    char msg[1024];
+    if (rc) snprintf(msg, sizeof msg, "aacgpu: aacg_pipeline_decode failed (%d): %.800s", rc, L.pipeline_last_error(p));
+    pthread_mutex_unlock(&pb->lock);
+    if (rc) { napi_throw_error(env, NULL, msg); return NULL; }
+    (void)np;
+    CHECK(env, napi_create_uint32(env, refused, &out));
+    return out;
+}
+
+static napi_value js_pipeline_reset_stream(napi_env env, napi_callback_info info)
+{
+    size_t argc = 2; napi_value argv[2]; uint32_t slot = 0;
+    CHECK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    handle_box* pb = box_of(env, argv[0], BOX_PIPELINE, "aacgpu: bad pipeline handle");
+    if (!pb) return NULL;
+    napi_get_value_uint32(env, argv[1], &slot);
+    pthread_mutex_lock(&pb->lock);
+    int rc = L.pipeline_reset_stream((aacg_pipeline*)pb->ptr, slot);
+    pthread_mutex_unlock(&pb->lock);
+    if (rc) napi_throw_error(env, NULL, "aacgpu: aacg_pipeline_reset_stream failed");
+    return NULL;
+}
+
 /* parseStatusString(code) -> the reference's message for a per-frame status */
 static napi_value js_parse_status_string(napi_env env, napi_callback_info info)
 {
@@ -477,6 +581,9 @@ static napi_value init(napi_env env, napi_value exports)
         {"parserCreate", NULL, js_parser_create, NULL, NULL, NULL, napi_default, NULL},
         {"parseBatch", NULL, js_parse_batch, NULL, NULL, NULL, napi_default, NULL},
         {"parseStatusString", NULL, js_parse_status_string, NULL, NULL, NULL, napi_default, NULL},
+        {"pipelineCreate", NULL, js_pipeline_create, NULL, NULL, NULL, napi_default, NULL},
+        {"pipelineDecode", NULL, js_pipeline_decode, NULL, NULL, NULL, napi_default, NULL},
+        {"pipelineResetStream", NULL, js_pipeline_reset_stream, NULL, NULL, NULL, napi_default, NULL},
     };
     napi_define_properties(env, exports, sizeof props / sizeof props[0], props);
     return exports;

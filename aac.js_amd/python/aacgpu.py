@@ -27,7 +27,8 @@ ABI_SYMBOLS = ["aacg_create", "aacg_destroy", "aacg_last_error", "aacg_abi_versi
                "aacg_parser_create", "aacg_parser_destroy", "aacg_parser_last_error", "aacg_parse_status_string",
                "aacg_parse_batch", "aacg_parse_device", "aacg_parse_kernel_name", "aacg_plan_refresh_from_parse", "aacg_standard_codebooks",
                "aacg_decode_batch_ex", "aacg_submit_ex", "aacg_plan_create_ex", "aacg_plan_kernels", "aacg_plan_kernels_ex", "aacg_plan_refresh_units",
-               "aacg_decode_pipelined", "aacg_pipeline_fork", "aacg_pipeline_join"]
+               "aacg_decode_pipelined", "aacg_pipeline_fork", "aacg_pipeline_join",
+               "aacg_pipeline_create", "aacg_pipeline_destroy", "aacg_pipeline_last_error", "aacg_pipeline_reset_stream", "aacg_pipeline_decode"]
 # ... and include/aacgpu_tools.h (measurement and diagnostics: bench.py, tools/, tests)
 TOOLS_SYMBOLS = ["aacg_calib_copy", "aacg_timer_create", "aacg_timer_record", "aacg_timer_elapsed_ms", "aacg_timer_destroy",
                  "aacg_pipeline_chained", "aacg_pipeline_concurrent", "aacg_decode_pipelined_timed", "aacg_debug_transform", "aacg_debug_set_route", "aacg_debug_route", "aacg_debug_run_kernel"]

@@ -494,6 +494,40 @@ int aacg_plan_refresh_from_parse(aacg_engine* e, aacg_plan* p, const aacg_unit_d
  * (AACG_ERR_UNSUPPORTED).  Replaces decoder.js:138-198's per-frame `new ICStream` bookkeeping for a whole batch. */
 int aacg_plan_refresh_units(aacg_engine* e, aacg_plan* p, const aacg_unit_desc* units, uint32_t n_units, void* hip_stream);
 
+/* ---- bytes in, PCM out: front end and transform resident, ONE call per batch ---------------------------------------
+ * What a host of the reference does per stream and per frame in readChunk() (decoder.js:125-216: parse the raw_data_block,
+ * process(elements), interleave) for a batch of streams at once: the frames' bytes go up, aacg_parse_device writes the
+ * records in HBM, aacg_plan_refresh_from_parse turns them into a kept plan's unit records, aacg_decode_device runs the
+ * transform, the PCM comes down — three kernels and three copies on one HIP stream behind this call; nothing but the frame
+ * boundaries (ADTS frame_length) and the stream slots is the host's.  For streams whose every frame is one SCE (channels 1)
+ * or one CPE (channels 2) — channel_configuration 1 / 2; other layouts take the aacg_parse_* / aacg_plan_* calls above.
+ * A pipeline owns an engine (AACG_INPUT_QUANT_I16, AACG_TNS_REFERENCE) and a parser; it is not re-entrant. */
+typedef struct aacg_pipeline aacg_pipeline;
+typedef struct aacg_pipeline_config {
+    int32_t abi_version;       /* AACG_ABI_VERSION                                                          */
+    int32_t device_ordinal;
+    int32_t sample_index;      /* config.sampleIndex (decoder.js:63)                                        */
+    int32_t max_streams;       /* stream slots with overlap state                                           */
+    int32_t channels;          /* 1 or 2: every frame one SCE / one CPE                                     */
+    int32_t max_frames;        /* frames per stream in one batch, at most                                   */
+    int32_t output_kind;       /* AACG_OUTPUT_*                                                             */
+    int32_t parse_options;     /* AACG_PARSE_* (AACG_PARSE_REFERENCE_QUIRKS for what aac.js reads)          */
+} aacg_pipeline_config;
+int  aacg_pipeline_create(const aacg_pipeline_config* cfg, const aacg_code_entry* entries, const uint32_t counts[12], aacg_pipeline** out);
+void aacg_pipeline_destroy(aacg_pipeline* p);
+const char* aacg_pipeline_last_error(const aacg_pipeline* p);
+int  aacg_pipeline_reset_stream(aacg_pipeline* p, uint32_t slot);                 /* new FilterBank for that slot */
+/* One batch, synchronous: n_streams streams (slots[s]: the stream slot that owns stream s's overlap state), the next
+ * frames_per_stream frames of each; frames[s * frames_per_stream + f] = frame f of stream s in `bytes` (an ADTS frame,
+ * header included, or a bare raw_data_block).  pcm_out: [stream][frame][1024][channels] (float, or int16 for
+ * AACG_OUTPUT_I16 pipelines), any host memory.  results (optional): one aacg_parse_result per frame; a frame the parser
+ * refused (or whose element is not the one the pipeline was made for) is decoded as silence — its stream's state moves on
+ * through a silent frame — and counted in *n_refused: the caller raises the reference's error for it
+ * (aacg_parse_status_string) where the frame is reached. */
+int  aacg_pipeline_decode(aacg_pipeline* p, const uint8_t* bytes, size_t n_bytes, const aacg_parse_frame* frames,
+                          const uint32_t* slots, uint32_t n_streams, uint32_t frames_per_stream,
+                          void* pcm_out, aacg_parse_result* results, uint32_t* n_refused);
+
 #ifdef __cplusplus
 }
 #endif

@@ -109,5 +109,52 @@ if (mode === 'cpu') {
     assert.strictEqual(shared.stats.frames, names.reduce(function (a, n) { return a + manifest.find(function (m) { return m.name === n; }).frames; }, 0));
     assert.strictEqual(shared.stats.retries, 0);
     console.log('shared engine: ' + shared.stats.frames + ' frames of 8 streams in ' + shared.stats.batches + ' batches (' + shared.groups.size + ' engines)');
+
+    /* RESIDENT: the front end on the device too — one native call per flush, bytes in, PCM out.  The same eight streams: the
+     * stereo and mono ones take the resident route (one pipeline per sample rate and channel count), the 5.1 / coupling ones the
+     * parsing route on the same SharedEngine; every stream against the PCM the reference decoded from the same bytes, and bit for
+     * bit against a decoder of its own */
+    const res = new host.SharedEngine({ maxStreams: 16, maxChannels: 8, resident: true, lookahead: 4 });
+    const rdecs = names.map(function (n) { return open(n, { shared: res }); });
+    assert.deepStrictEqual(rdecs.map(function (d) { return !!d.resident; }), names.map(function (n) { const c = manifest.find(function (m) { return m.name === n; }); return c.channels <= 2 && n !== 'cce96'; }));
+    const rgot = drainRoundRobin(rdecs);
+    names.forEach(function (n, i) {
+        const c = manifest.find(function (m) { return m.name === n; });
+        assert.strictEqual(rgot[i].length, c.frames, n + ' (resident): frames delivered');
+        rgot[i].forEach(function (p, t) {
+            assert.strictEqual(p.length, 1024 * c.channels);
+            assert.deepStrictEqual(Buffer.from(p.buffer, p.byteOffset, p.byteLength), Buffer.from(alone[i][t].buffer, alone[i][t].byteOffset, alone[i][t].byteLength), n + ' (resident) frame ' + t);
+        });
+    });
+    /* a stream fed in pieces (frames split across feeds), and one with a corrupt frame in the middle: the error is thrown where the
+     * frame is reached, the frames before it are delivered, the stream goes on */
+    const whole = new Uint8Array(fs.readFileSync(path.join(streams, 'stereo48.aac')));
+    const r2 = new host.SharedEngine({ maxStreams: 4, maxChannels: 2, resident: true, lookahead: 3 });
+    const piecewise = new host.GpuAACDecoder({ shared: r2 }); piecewise.init();
+    const demux = new host.adts.AdtsDemuxer(function (event, payload) {
+        if (event === 'format') Object.assign(piecewise.format, payload); else if (event === 'cookie') piecewise.setCookie(payload); else if (event === 'data') piecewise.feed(payload);
+    });
+    const got2 = [];
+    for (let at = 0; at < whole.length; at += 777) {
+        demux.push(whole.subarray(at, Math.min(whole.length, at + 777)));
+        for (let p; (p = piecewise.readChunk());) got2.push(p);
+    }
+    const ref0 = alone[0];
+    assert.strictEqual(got2.length, ref0.length, 'piecewise feed: frames delivered');
+    got2.forEach(function (p, t) { assert.deepStrictEqual(Buffer.from(p.buffer, p.byteOffset, p.byteLength), Buffer.from(ref0[t].buffer, ref0[t].byteOffset, ref0[t].byteLength), 'piecewise frame ' + t); });
+    const list = host.adts.frames(whole), bad = new Uint8Array(whole);
+    for (let k = 9; k < list[5].length; k++) bad[list[5].offset + k] = 0;     // frame 5: zeros behind the header (element after element until the frame runs out)
+    const broken = new host.GpuAACDecoder({ shared: r2 }); broken.init();
+    const dm2 = new host.adts.AdtsDemuxer(function (event, payload) {
+        if (event === 'format') Object.assign(broken.format, payload); else if (event === 'cookie') broken.setCookie(payload); else if (event === 'data') broken.feed(payload);
+    });
+    dm2.push(bad);
+    let threw = 0, delivered = 0;
+    for (let t = 0; t < list.length; t++) {
+        try { const p = broken.readChunk(); if (p) { delivered++; if (t < 5) assert.deepStrictEqual(Buffer.from(p.buffer, p.byteOffset, p.byteLength), Buffer.from(ref0[t].buffer, ref0[t].byteOffset, ref0[t].byteLength)); } }
+        catch (e) { threw++; assert.strictEqual(t, 5, 'the error belongs to frame 5: ' + e.message); }
+    }
+    assert.strictEqual(threw, 1); assert.strictEqual(delivered, list.length - 1);
+    console.log('resident shared engine: ' + res.stats.frames + ' frames in ' + res.stats.batches + ' native calls; piecewise feed and a corrupt frame ok');
 }
 console.log('shared ' + mode + ' tests ok');

@@ -2,7 +2,9 @@
 /* Plugin-level rate: frames per second out of readChunk(), bytes in -> PCM out, on one JavaScript thread.
  *   node tools/readchunk_rate.js [repeats]
  *   node tools/readchunk_rate.js --streams 256 [repeats]     N decoders on one SharedEngine (cross-stream batches), read round robin,
- *                                                            next to N decoders with an engine each: engine time per frame, checksum
+ *                                                            next to N decoders with an engine each: engine time per frame, checksum;
+ *                                                            and on a RESIDENT SharedEngine (front end on the device too: one native
+ *                                                            call per flush, bytes in, PCM out)
  * A long ADTS stream (the committed tests/golden/streams/stereo48.aac repeated) through
  *   - GpuAACDecoder with the JavaScript front end (parse on the CPU, transform on the GPU),
  *   - GpuAACDecoder with the device front end (parse and transform on the GPU),
@@ -43,6 +45,7 @@ function ours(gpuParse) {
  * (one batch per flush for all of them) or an engine per decoder (one batch per decoder: what N independent plugin instances
  * do).  Engine time = wall time inside engine.decodeBatch (upload, kernels, download), on this one JavaScript thread. */
 function many(shared, lookahead) {
+    const resident = shared === 'resident';
     try {
         let engineNs = 0n, batches = 0;
         const timed = function (eng) {
@@ -50,10 +53,10 @@ function many(shared, lookahead) {
             eng.decodeBatch = function () { const t = process.hrtime.bigint(); try { return inner.apply(null, arguments); } finally { engineNs += process.hrtime.bigint() - t; batches++; } };
             return eng;
         };
-        const sh = shared ? new host.SharedEngine({ maxStreams: nStreams, maxChannels: 2 }) : null;
+        const sh = shared ? new host.SharedEngine({ maxStreams: nStreams, maxChannels: 2, resident: resident, lookahead: lookahead }) : null;
         const decs = [];
         for (let i = 0; i < nStreams; i++) {
-            const dec = new host.GpuAACDecoder({ frontend: new host.FrontEnd(), lookahead: lookahead, shared: sh });
+            const dec = new host.GpuAACDecoder({ frontend: resident ? null : new host.FrontEnd(), lookahead: lookahead, shared: sh });
             dec.init();
             const demux = new host.adts.AdtsDemuxer(function (event, payload) {
                 if (event === 'format') Object.assign(dec.format, payload);
@@ -64,13 +67,14 @@ function many(shared, lookahead) {
             if (!shared) timed(dec.engine);
             decs.push(dec);
         }
-        if (shared) for (const g of sh.groups.values()) timed(g.engine);
+        if (shared && !resident) for (const g of sh.groups.values()) timed(g.engine);
         const t0 = process.hrtime.bigint();
         let n = 0, sum = 0;
         for (let live = nStreams; live;) {
             live = 0;
             for (const d of decs) { const pcm = d.readChunk(); if (pcm) { n++; sum += pcm[17]; live++; } }
         }
+        if (resident) { engineNs = sh.stats.engineNs; batches = sh.stats.batches; }       // wall time inside the one native call per flush
         const s = Number(process.hrtime.bigint() - t0) / 1e9, es = Number(engineNs) / 1e9;
         return { streams: nStreams, lookahead: lookahead, frames: n, seconds: +s.toFixed(3), frames_per_s: Math.round(n / s), batches: batches,
                  frames_per_batch: +(n / batches).toFixed(1), engine_seconds: +es.toFixed(3), frames_per_engine_second: Math.round(n / es), checksum: sum };
@@ -80,6 +84,8 @@ if (nStreams) {
     out.stream = 'stereo48.aac x ' + repeats + ' x ' + nStreams + ' streams';
     out.independent_decoders = many(false, 16);
     out.shared_engine = many(true, 16);
+    out.shared_engine_resident = many('resident', 16);        // bytes -> PCM in one native call per flush: JavaScript finds frame boundaries and slices PCM
+    if (out.shared_engine_resident.checksum !== undefined) out.resident_same_checksum = out.shared_engine_resident.checksum === out.independent_decoders.checksum;
     if (out.independent_decoders.frames_per_engine_second && out.shared_engine.frames_per_engine_second) {
         out.engine_time_ratio = +(out.shared_engine.frames_per_engine_second / out.independent_decoders.frames_per_engine_second).toFixed(2);
         out.same_checksum = out.shared_engine.checksum === out.independent_decoders.checksum;
