@@ -50,6 +50,14 @@ bool ok(aacg_pipeline* p, hipError_t rc, const char* what)
 
 size_t pcm_elem(const aacg_pipeline* p) { return p->cfg.output_kind == AACG_OUTPUT_I16 ? 2 : 4; }
 
+/* true if the runtime knows this host pointer as page-locked (aacg_host_alloc / hipHostMalloc / hipHostRegister) */
+bool is_pinned(const void* ptr)
+{
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, ptr) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return a.type == hipMemoryTypeHost;
+}
+
 /* the plan for a batch of this shape: every frame one SCE (channels 1) or one CPE (channels 2), frame f of stream s at unit
  * s * F + f, its blocks where aacg_parse_device (max_units 1, max_channels C) puts them */
 int plan_for(aacg_pipeline* p, const uint32_t* slots, uint32_t S, uint32_t F, aacg_plan** out)
@@ -204,11 +212,14 @@ int aacg_pipeline_decode(aacg_pipeline* p, const uint8_t* bytes, size_t n_bytes,
     }
     if (rc) { p->err = std::string("transform: ") + aacg_last_error(p->engine); return rc; }
     const size_t pcm_bytes = (size_t)n * C * 1024u * pcm_elem(p);
-    P_TRY(p, hipMemcpyAsync(p->h_pcm, p->d_pcm, pcm_bytes, hipMemcpyDeviceToHost, st), AACG_ERR_NO_DEVICE);
+    /* page-locked caller memory (aacg_host_alloc) takes the PCM straight from the device; anything else goes through the
+     * pipeline's own page-locked staging and one host copy */
+    const bool direct = is_pinned(pcm_out);
+    P_TRY(p, hipMemcpyAsync(direct ? pcm_out : p->h_pcm, p->d_pcm, pcm_bytes, hipMemcpyDeviceToHost, st), AACG_ERR_NO_DEVICE);
     P_TRY(p, hipMemcpyAsync(p->h_res, p->d_res, (size_t)n * sizeof(aacg_parse_result), hipMemcpyDeviceToHost, st), AACG_ERR_NO_DEVICE);
     P_TRY(p, hipMemcpyAsync((char*)p->h_res + (size_t)n * sizeof(aacg_parse_result), p->d_refused, 4, hipMemcpyDeviceToHost, st), AACG_ERR_NO_DEVICE);
     P_TRY(p, hipStreamSynchronize(st), AACG_ERR_NO_DEVICE);
-    std::memcpy(pcm_out, p->h_pcm, pcm_bytes);
+    if (!direct) std::memcpy(pcm_out, p->h_pcm, pcm_bytes);
     if (results) std::memcpy(results, p->h_res, (size_t)n * sizeof(aacg_parse_result));
     if (n_refused) std::memcpy(n_refused, (char*)p->h_res + (size_t)n * sizeof(aacg_parse_result), 4);
     return AACG_OK;

@@ -15,7 +15,8 @@
  * bitstream front end (ADTS bytes for formatID 'aac ', the demuxer's buffers of one or more raw_data_blocks for 'mp4a') and serves frames from
  * GpuAACDecoder.readChunk(): a Float32Array of 1024 * channels samples, null when no complete frame is buffered (Aurora
  * then waits for more data and calls again), or the reference's Error for a malformed frame.  Aurora rewinds the
- * stream after a null — bytes already handed to the front end are skipped, not fed twice.
+ * stream after a null — bytes already handed to the front end are skipped, not fed twice.  When the demuxer has ended and the
+ * last frame has been delivered the decoder releases its slot of a shared engine (options.shared); destroy() does the same early.
  *
  * Demuxer: probe(stream) and the format / cookie / data events of adts_demuxer.js:7-20, 54-80.
  */
@@ -53,8 +54,15 @@ function register(AV, options) {
                 if (this.packets) this.impl.feedPacket(buf, true); else this.impl.feed(buf);   // an M4A demuxer's buffer: one sample or a chunk of them
             }
             this.fed = s.offset;
-            return this.impl.readChunk();
+            const out = this.impl.readChunk();
+            /* the last buffer is in and nothing is left to deliver: Aurora emits 'end' next and never calls again — the decoder
+             * gives its stream slot of a SharedEngine back (otherwise the N-th player of a process would find no slot left) */
+            if (out === null && this.receivedFinalBuffer) this.impl.close();
+            return out;
         };
+
+        /* hosts that tear a player down early (AV.Asset#stop / destroy) may call this; idempotent */
+        this.prototype.destroy = function () { if (this.impl) this.impl.close(); };
     });
 
     const Demuxer = AV.Demuxer.extend(function () {

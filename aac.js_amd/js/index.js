@@ -421,7 +421,7 @@ GpuAACDecoder.prototype.decodeAhead = function () {
 };
 
 /* a decoder that is done with its stream gives its slot of a SharedEngine back */
-GpuAACDecoder.prototype.close = function () { if (this.shared) this.shared.detach(this); };
+GpuAACDecoder.prototype.close = function () { if (this.shared && this.group) this.shared.detach(this); };
 
 /* bytes from the demuxer ('data' events of AdtsDemuxer / an MP4 demuxer's samples) to the front end */
 GpuAACDecoder.prototype.feed = function (bytes) {

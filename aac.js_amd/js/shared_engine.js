@@ -36,6 +36,11 @@ function SharedEngine(opts) {
     this.groups = new Map();                              // sampleIndex -> { engine, decoders: [], free: [] }
     this.resident = !!opts.resident;                      // bytes -> PCM in one native call per flush (aacg_pipeline_*)
     this.lookahead = opts.lookahead || 16;                // resident: frames per stream and flush
+    /* resident: where a flush's PCM lives.  0 (default): memory of its own, the caller's for as long as it keeps any frame of the
+     * flush (what the reference's readChunk() promises: a fresh array per frame) — a page-locked allocation per flush.  K > 0: K
+     * page-locked buffers made once and used in turn: a frame is valid until its SharedEngine has flushed K more times, i.e. for
+     * at least (K - 1) x lookahead further frames of its stream; a consumer that keeps frames longer copies them (frame.slice()) */
+    this.pcmRing = opts.pcmRing | 0;
     this.stats = { batches: 0, frames: 0, units: 0, engineNs: 0n, retries: 0 };
 }
 
@@ -116,48 +121,52 @@ function scanFrames(b, at, max, lens) {
 /* resident flush: the next frames of every stream that has run dry or has room, ONE native call, views of its PCM handed out */
 SharedEngine.prototype.flushResident = function (g) {
     const L = this.lookahead, C = g.channels;
-    const part = [], lens = new Uint32Array(L);
-    let F = L, total = 0;
+    const part = [];
+    let F = L;
     for (const dec of g.decoders) {
         if (dec.queue.length >= L) continue;               // a slow reader's queue does not grow with every flush of its peers
-        const n = scanFrames(dec.rbuf, dec.rpos, L, lens);
+        if (!dec.rlens) dec.rlens = new Uint32Array(L);
+        const n = scanFrames(dec.rbuf, dec.rpos, L, dec.rlens);
         if (n < 0) { if (!dec.badHeader) { dec.badHeader = true; dec.queue.push(new Error('Invalid ADTS header.')); } continue; }
         if (n === 0) continue;
         part.push(dec); F = Math.min(F, n);
     }
     if (!part.length) return;
-    const S = part.length, frames = new Uint32Array(2 * S * F), slots = new Uint32Array(S), starts = new Uint32Array(S);
-    part.forEach(function (dec, s) {
-        scanFrames(dec.rbuf, dec.rpos, F, lens);
-        let len = 0;
-        for (let f = 0; f < F; f++) { frames[2 * (s * F + f)] = total + len; frames[2 * (s * F + f) + 1] = lens[f]; len += lens[f]; }
-        starts[s] = total; slots[s] = dec.stream; total += len;
-    });
+    const S = part.length, frames = new Uint32Array(2 * S * F), slots = new Uint32Array(S), starts = new Uint32Array(S + 1);
+    let total = 0;
+    for (let s = 0; s < S; s++) {
+        const lens = part[s].rlens;
+        starts[s] = total; slots[s] = part[s].stream;
+        for (let f = 0, i = 2 * s * F; f < F; f++, i += 2) { frames[i] = total; frames[i + 1] = lens[f]; total += lens[f]; }
+    }
+    starts[S] = total;
     const bytes = new Uint8Array(total);
-    part.forEach(function (dec, s) {
-        const len = (s + 1 < S ? starts[s + 1] : total) - starts[s];
+    for (let s = 0; s < S; s++) {
+        const dec = part[s], len = starts[s + 1] - starts[s];
         bytes.set(dec.rbuf.subarray(dec.rpos, dec.rpos + len), starts[s]);
         dec.rpos += len;
-    });
-    const pcm = g.outI16 ? new Int16Array(S * F * 1024 * C) : new Float32Array(S * F * 1024 * C), results = new Uint8Array(8 * S * F);
+    }
+    const results = new Uint8Array(8 * S * F);
     const t0 = process.hrtime.bigint();
-    let refused = 0, failed = null;
-    try { refused = g.addon.pipelineDecode(g.pipeline, bytes, frames, slots, F, pcm, results); } catch (err) { failed = err instanceof Error ? err : new Error(String(err)); }
+    let out = null, failed = null;
+    try { out = g.addon.pipelineDecode(g.pipeline, bytes, frames, slots, F, results, C, this.pcmRing, this.pcmRing ? this.maxStreams * L * 1024 * C : 0); } catch (err) { failed = err instanceof Error ? err : new Error(String(err)); }
     this.stats.engineNs += process.hrtime.bigint() - t0;
     this.stats.batches++; this.stats.units += S * F;
-    const per = 1024 * C;
-    part.forEach(function (dec, s) {
-        if (failed) { dec.queue.push(failed); return; }
-        for (let f = 0; f < F; f++) {
-            const i = s * F + f;
+    if (failed) { for (const dec of part) dec.queue.push(failed); return; }
+    /* the batch's PCM: one array on page-locked memory the device wrote into; a frame is a view of it (the memory returns to the
+     * addon's pool when the last of the batch's frames has been collected) */
+    const pcm = out.pcm, refused = out.refused, per = 1024 * C;
+    for (let s = 0; s < S; s++) {
+        const q = part[s].queue;
+        for (let f = 0, i = s * F; f < F; f++, i++) {
             /* a frame the device refused: the reference's message for its status where the frame is reached (it was decoded as
              * silence: the stream goes on); a frame whose elements are not the stream's channel configuration likewise */
-            if (refused && results[8 * i]) dec.queue.push(new Error(g.addon.parseStatusString(results[8 * i])));
-            else if (refused && (results[8 * i + 1] !== 1 || results[8 * i + 2] !== C)) dec.queue.push(new Error('aacgpu: the frame\'s elements are not the stream\'s channel configuration'));
-            else dec.queue.push(pcm.subarray(i * per, (i + 1) * per));
+            if (refused && results[8 * i]) q.push(new Error(g.addon.parseStatusString(results[8 * i])));
+            else if (refused && (results[8 * i + 1] !== 1 || results[8 * i + 2] !== C)) q.push(new Error('aacgpu: the frame\'s elements are not the stream\'s channel configuration'));
+            else q.push(pcm.subarray(i * per, (i + 1) * per));
         }
-    });
-    if (!failed) this.stats.frames += S * F;
+    }
+    this.stats.frames += S * F;
 };
 
 /* every registered decoder parses ahead what it has buffered; one batch per engine */

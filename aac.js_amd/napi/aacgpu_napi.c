@@ -48,6 +48,8 @@ static struct {
     int  (*pipeline_reset_stream)(aacg_pipeline*, uint32_t);
     int  (*pipeline_decode)(aacg_pipeline*, const uint8_t*, size_t, const aacg_parse_frame*, const uint32_t*, uint32_t, uint32_t,
                             void*, aacg_parse_result*, uint32_t*);
+    void* (*host_alloc)(size_t);
+    void (*host_free)(void*);
 } L;
 
 #define CHECK(env, call) do { if ((call) != napi_ok) { napi_throw_error((env), NULL, "aacgpu: N-API call failed: " #call); return NULL; } } while (0)
@@ -80,6 +82,7 @@ static int load_lib(napi_env env, const char* path)
     SYM(parse_status_string, "aacg_parse_status_string"); SYM(parse_batch, "aacg_parse_batch");
     SYM(pipeline_create, "aacg_pipeline_create"); SYM(pipeline_destroy, "aacg_pipeline_destroy"); SYM(pipeline_last_error, "aacg_pipeline_last_error");
     SYM(pipeline_reset_stream, "aacg_pipeline_reset_stream"); SYM(pipeline_decode, "aacg_pipeline_decode");
+    SYM(host_alloc, "aacg_host_alloc"); SYM(host_free, "aacg_host_free");
 #undef SYM
     return 1;
 }
@@ -99,7 +102,10 @@ static int get_i32(napi_env env, napi_value obj, const char* key, int32_t dflt)
 #define BOX_ENGINE 0x41454e47u   /* 'AENG' */
 #define BOX_PARSER 0x41505253u   /* 'APRS' */
 #define BOX_PIPELINE 0x4150504cu /* 'APPL' */
-typedef struct { uint32_t kind; void* ptr; pthread_mutex_t lock; int out_i16; /* engine: AACG_OUTPUT_I16 */ } handle_box;
+#define PCM_RING_MAX 16
+typedef struct { uint32_t kind; void* ptr; pthread_mutex_t lock; int out_i16; /* engine / pipeline: AACG_OUTPUT_I16 */
+                 /* pipeline, { pcmRing: K }: K page-locked PCM buffers made once and handed out in turn (pipelineDecode) */
+                 napi_ref ring_ab[PCM_RING_MAX]; void* ring_ptr[PCM_RING_MAX]; size_t ring_bytes; int ring_n; unsigned ring_next; } handle_box;
 
 static handle_box* box_new(uint32_t kind, void* ptr)
 {
@@ -463,12 +469,15 @@ static napi_value js_parse_batch(napi_env env, napi_callback_info info)
 }
 
 /* ---- bytes in, PCM out (aacg_pipeline_*): the resident route behind SharedEngine({ resident: true }) ------------------- */
+static void ring_finalize(napi_env env, void* data, void* hint) { (void)env; (void)hint; if (data && L.host_free) L.host_free(data); }
+
 static void pipeline_finalize(napi_env env, void* data, void* hint)
 {
-    (void)env; (void)hint;
+    (void)hint;
     handle_box* b = (handle_box*)data;
     if (!b) return;
     if (b->ptr && L.pipeline_destroy) L.pipeline_destroy((aacg_pipeline*)b->ptr);
+    for (int i = 0; i < b->ring_n; i++) if (b->ring_ab[i]) napi_delete_reference(env, b->ring_ab[i]);   /* (the buffers go with their ArrayBuffers: ring_finalize) */
     b->kind = 0;
     pthread_mutex_destroy(&b->lock);
     free(b);
@@ -512,34 +521,104 @@ static napi_value js_pipeline_create(napi_env env, napi_callback_info info)
     return out;
 }
 
+/* Page-locked PCM buffers handed to JavaScript as external ArrayBuffers: the PCM of a batch comes down from the device
+ * straight into the memory the Float32Array views — no staging copy, no zero-filled allocation of tens of megabytes per batch.
+ * A buffer returns to the pool when the garbage collector has let go of the batch's last frame (the finalizer runs on the
+ * JavaScript thread, like every call into this addon); the pool holds a few, the rest are freed. */
+#define PCM_POOL_MAX 8
+typedef struct { void* ptr; size_t bytes; } pcm_buf;
+static pcm_buf g_pool[PCM_POOL_MAX];
+static int g_pool_n = 0;
+
+static void pcm_finalize(napi_env env, void* data, void* hint)
+{
+    const size_t bytes = (size_t)hint;
+    (void)env;
+    if (g_pool_n < PCM_POOL_MAX) { g_pool[g_pool_n].ptr = data; g_pool[g_pool_n].bytes = bytes; g_pool_n++; }
+    else L.host_free(data);
+}
+
+static void* pcm_take(size_t bytes, size_t* got)
+{
+    for (int i = 0; i < g_pool_n; i++)
+        if (g_pool[i].bytes >= bytes && g_pool[i].bytes <= 2 * bytes + 4096) {
+            void* p = g_pool[i].ptr; *got = g_pool[i].bytes;
+            g_pool[i] = g_pool[--g_pool_n];
+            return p;
+        }
+    *got = bytes;
+    return L.host_alloc(bytes);
+}
+
 /* pipelineDecode(pipeline, bytes:Uint8Array, frames:Uint32Array(2 * S * F) [offset, length]..., slots:Uint32Array(S), framesPerStream,
- *                pcm:Float32Array|Int16Array(S * F * 1024 * channels), results:Uint8Array(8 * S * F)) -> frames refused */
+ *                results:Uint8Array(8 * S * F), channels [, ring, ringElems])
+ *   -> { pcm: Float32Array|Int16Array(S * F * 1024 * channels) on page-locked memory, refused }
+ * ring = 0 / absent: the PCM array's memory is the caller's for as long as any view of it lives (a buffer per call, recycled by
+ * the garbage collector's finalizer).  ring = K: the pipeline's K buffers of ringElems elements, made at the first call, are
+ * handed out in turn — what a call returns is overwritten by the K-th call after it. */
 static napi_value js_pipeline_decode(napi_env env, napi_callback_info info)
 {
-    size_t argc = 7; napi_value argv[7], out;
+    size_t argc = 9; napi_value argv[9], out, v, ab;
     CHECK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
-    if (argc < 7) { napi_throw_error(env, NULL, "aacgpu: pipelineDecode takes 7 arguments"); return NULL; }
+    if (argc < 7) { napi_throw_error(env, NULL, "aacgpu: pipelineDecode takes at least 7 arguments"); return NULL; }
+    uint32_t ring = 0, ring_elems = 0;
+    if (argc >= 9) { napi_get_value_uint32(env, argv[7], &ring); napi_get_value_uint32(env, argv[8], &ring_elems); }
     handle_box* pb = box_of(env, argv[0], BOX_PIPELINE, "aacgpu: bad pipeline handle");
     if (!pb) return NULL;
-    napi_typedarray_type t; size_t nb, nf, ns, np, nr; void *db, *df, *ds, *dp, *dr; uint32_t F = 0;
+    napi_typedarray_type t; size_t nb, nf, ns, nr; void *db, *df, *ds, *dr; uint32_t F = 0, C = 0;
     napi_get_value_uint32(env, argv[4], &F);
+    napi_get_value_uint32(env, argv[6], &C);
     if (!typed(env, argv[1], &t, &nb, &db) || t != napi_uint8_array || !typed(env, argv[2], &t, &nf, &df) || t != napi_uint32_array ||
-        !typed(env, argv[3], &t, &ns, &ds) || t != napi_uint32_array || !F || nf != 2 * ns * F ||
-        !typed(env, argv[5], &t, &np, &dp) || t != (pb->out_i16 ? napi_int16_array : napi_float32_array) ||
-        !typed(env, argv[6], &t, &nr, &dr) || t != napi_uint8_array || nr != ns * F * sizeof(aacg_parse_result)) {
-        napi_throw_type_error(env, NULL, "pipelineDecode(pipeline, Uint8Array bytes, Uint32Array frames (2 per frame), Uint32Array slots, framesPerStream, Float32Array|Int16Array pcm, Uint8Array results (8 per frame))");
+        !typed(env, argv[3], &t, &ns, &ds) || t != napi_uint32_array || !F || nf != 2 * ns * F || (C != 1 && C != 2) ||
+        !typed(env, argv[5], &t, &nr, &dr) || t != napi_uint8_array || nr != ns * F * sizeof(aacg_parse_result)) {
+        napi_throw_type_error(env, NULL, "pipelineDecode(pipeline, Uint8Array bytes, Uint32Array frames (2 per frame), Uint32Array slots, framesPerStream, Uint8Array results (8 per frame), channels)");
         return NULL;
+    }
+    const size_t elems = ns * F * 1024u * C, bytes = elems * (pb->out_i16 ? 2u : 4u);
+    size_t got = 0;
+    void* pcm = NULL;
+    int slot = -1;
+    if (ring) {
+        if (ring > PCM_RING_MAX || ring_elems < elems) { napi_throw_range_error(env, NULL, "aacgpu: pipelineDecode: ring of at most 16 buffers, each at least one batch long"); return NULL; }
+        if (!pb->ring_n) {                                 /* the pipeline's ring: made once, kept alive by references until the pipeline goes */
+            pb->ring_bytes = (size_t)ring_elems * (pb->out_i16 ? 2u : 4u);
+            for (uint32_t i = 0; i < ring; i++) {
+                void* m = L.host_alloc(pb->ring_bytes);
+                napi_value rab;
+                if (!m || napi_create_external_arraybuffer(env, m, pb->ring_bytes, ring_finalize, NULL, &rab) != napi_ok ||
+                    napi_create_reference(env, rab, 1, &pb->ring_ab[i]) != napi_ok) { if (m) L.host_free(m); napi_throw_error(env, NULL, "aacgpu: out of page-locked memory"); return NULL; }
+                pb->ring_ptr[i] = m; pb->ring_n = (int)i + 1;
+            }
+        }
+        if (bytes > pb->ring_bytes) { napi_throw_range_error(env, NULL, "aacgpu: pipelineDecode: batch larger than the ring's buffers"); return NULL; }
+        slot = (int)(pb->ring_next++ % (unsigned)pb->ring_n);
+        pcm = pb->ring_ptr[slot]; got = pb->ring_bytes;
+    } else {
+        pcm = pcm_take(bytes, &got);
+        if (!pcm) { napi_throw_error(env, NULL, "aacgpu: out of page-locked memory"); return NULL; }
     }
     uint32_t refused = 0;
     pthread_mutex_lock(&pb->lock);
     aacg_pipeline* p = (aacg_pipeline*)pb->ptr;
-    int rc = L.pipeline_decode(p, (const uint8_t*)db, nb, (const aacg_parse_frame*)df, (const uint32_t*)ds, (uint32_t)ns, F, dp, (aacg_parse_result*)dr, &refused);
+    int rc = L.pipeline_decode(p, (const uint8_t*)db, nb, (const aacg_parse_frame*)df, (const uint32_t*)ds, (uint32_t)ns, F, pcm, (aacg_parse_result*)dr, &refused);
     char msg[1024];
     if (rc) snprintf(msg, sizeof msg, "aacgpu: aacg_pipeline_decode failed (%d): %.800s", rc, L.pipeline_last_error(p));
     pthread_mutex_unlock(&pb->lock);
-    if (rc) { napi_throw_error(env, NULL, msg); return NULL; }
-    (void)np;
-    CHECK(env, napi_create_uint32(env, refused, &out));
+    if (rc) {
+        if (slot < 0) { if (g_pool_n < PCM_POOL_MAX) { g_pool[g_pool_n].ptr = pcm; g_pool[g_pool_n].bytes = got; g_pool_n++; } else L.host_free(pcm); }
+        napi_throw_error(env, NULL, msg);
+        return NULL;
+    }
+    if (slot >= 0) CHECK(env, napi_get_reference_value(env, pb->ring_ab[slot], &ab));
+    else
+    /* (the engine is not told about the buffer's size with napi_adjust_external_memory: it answers 33 MB of external memory
+     * per batch with a full collection per batch; the views are short-lived objects, ordinary collections find the buffers) */
+    if (napi_create_external_arraybuffer(env, pcm, got, pcm_finalize, (void*)got, &ab) != napi_ok) { L.host_free(pcm); napi_throw_error(env, NULL, "aacgpu: napi_create_external_arraybuffer failed"); return NULL; }
+    CHECK(env, napi_create_typedarray(env, pb->out_i16 ? napi_int16_array : napi_float32_array, elems, ab, 0, &v));
+    CHECK(env, napi_create_object(env, &out));
+    CHECK(env, napi_set_named_property(env, out, "pcm", v));
+    CHECK(env, napi_create_uint32(env, refused, &v));
+    CHECK(env, napi_set_named_property(env, out, "refused", v));
     return out;
 }
 

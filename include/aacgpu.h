@@ -520,7 +520,8 @@ int  aacg_pipeline_reset_stream(aacg_pipeline* p, uint32_t slot);               
 /* One batch, synchronous: n_streams streams (slots[s]: the stream slot that owns stream s's overlap state), the next
  * frames_per_stream frames of each; frames[s * frames_per_stream + f] = frame f of stream s in `bytes` (an ADTS frame,
  * header included, or a bare raw_data_block).  pcm_out: [stream][frame][1024][channels] (float, or int16 for
- * AACG_OUTPUT_I16 pipelines), any host memory.  results (optional): one aacg_parse_result per frame; a frame the parser
+ * AACG_OUTPUT_I16 pipelines), any host memory — page-locked memory (aacg_host_alloc) receives the PCM straight from the
+ * device, other memory through the pipeline's staging and one more host copy.  results (optional): one aacg_parse_result per frame; a frame the parser
  * refused (or whose element is not the one the pipeline was made for) is decoded as silence — its stream's state moves on
  * through a silent frame — and counted in *n_refused: the caller raises the reference's error for it
  * (aacg_parse_status_string) where the frame is reached. */

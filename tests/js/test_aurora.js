@@ -111,6 +111,23 @@ if (mode === 'cpu') {
     fs.unlinkSync(path.join(dir, 'av.js')); fs.rmdirSync(dir);
 }
 
+if (mode === 'cpu') {
+    /* players come and go: with options.shared every decoder Aurora constructs takes a stream slot, and gives it back when its
+     * stream has ended and its last frame is out — five players one after the other on a SharedEngine of TWO slots */
+    const engine = { resetStream: function () {}, decodeBatch: function (u, q, meta, pcm) { pcm.fill(1); } };
+    const shared = new host.SharedEngine({ maxStreams: 2, maxChannels: 8, engine: function () { return engine; } });
+    AV.Demuxer.registry.length = 0;
+    require(path.join(root, 'aac.js_amd', 'js', 'aurora.js')).register(AV, { shared: shared, lookahead: 4 });
+    const slots = [];
+    for (let k = 0; k < 5; k++) {
+        const out = play('stereo48', [4096], { shared: shared, lookahead: 4 });
+        assert.strictEqual(out.errors.length, 0, String(out.errors[0]));
+        assert.ok(out.ended && out.pcm.length === manifest.find(function (m) { return m.name === 'stereo48'; }).frames);
+        slots.push(shared.groups.get(3).decoders.length);
+    }
+    assert.deepStrictEqual(slots, [0, 0, 0, 0, 0], 'a finished player still holds its slot');
+}
+
 for (const c of manifest) {
     if (mode === 'cpu') {
         /* a recording engine: what reaches aacg_decode_batch, frame by frame */

@@ -35,12 +35,12 @@ const names = ['stereo48', 'surround48', 'mono22', 'stereo48', 'extras8k', 'cce9
 if (mode === 'cpu') {
     /* recording engines, one per sample rate: what reaches decodeBatch */
     const calls = [];
-    let poison = -1;                                   // a stream slot (of the 48 kHz engine) whose units the engine refuses
+    let poison = -1, poisonCode = -5;                  // a stream slot (of the 48 kHz engine) whose units the engine refuses, and with which status (include/aacgpu.h)
     const mk = function (maxStreams) {
         return new host.SharedEngine({ maxStreams: maxStreams, engine: function (sampleIndex) {
             return { resetStream: function () {}, decodeBatch: function (u, q, meta, pcm) {
                 const units = host.unpackUnits(u);
-                if (sampleIndex === 3 && units.some(function (x) { return x.stream === poison; })) throw new Error('engine refuses stream ' + poison);
+                if (sampleIndex === 3 && units.some(function (x) { return x.stream === poison; })) throw new Error('aacgpu: aacg_decode_batch failed (' + poisonCode + '): engine refuses stream ' + poison);
                 calls.push({ sampleIndex: sampleIndex, units: units });
                 for (const x of units) for (let c = 0; c < x.ch.length; c++) pcm[x.pcmOffset + x.channel + c] = 1000 * x.stream + 1;   // sample 0 of every channel: its stream
             } };
@@ -75,7 +75,14 @@ if (mode === 'cpu') {
     assert.throws(function () { d2[1].readChunk(); }, /engine refuses stream 1/);
     assert.ok(d2[2].readChunk() instanceof Float32Array);
     assert.ok(sh2.stats.retries >= 1);
-    poison = -1;
+    /* ... but only an error raised BEFORE anything was launched: after a device error (AACG_ERR_NO_DEVICE) the launch may have
+     * advanced every stream's state, decoding the same frames again would advance it twice — the error goes to every stream of the batch */
+    poisonCode = -2;
+    const sh4 = mk(8);
+    const d4 = ['stereo48', 'stereo48', 'stereo48'].map(function (n) { return open(n, { shared: sh4 }); });
+    for (const d of d4) assert.throws(function () { d.readChunk(); }, /failed \(-2\)/);
+    assert.strictEqual(sh4.stats.retries, 0);
+    poison = -1; poisonCode = -5;
 
     /* capacity and slot reuse */
     const sh3 = mk(1);
@@ -155,6 +162,15 @@ if (mode === 'cpu') {
         catch (e) { threw++; assert.strictEqual(t, 5, 'the error belongs to frame 5: ' + e.message); }
     }
     assert.strictEqual(threw, 1); assert.strictEqual(delivered, list.length - 1);
+    /* { pcmRing: K }: the flushes' PCM in K page-locked buffers used in turn — a frame is valid until K more flushes: copied as it
+     * comes (what a consumer that keeps frames does), it is the same PCM; held on to, it is overwritten by the K-th flush after it */
+    const r3 = new host.SharedEngine({ maxStreams: 4, maxChannels: 2, resident: true, lookahead: 2, pcmRing: 3 });
+    const ringDec = open('stereo48', { shared: r3 });
+    const copies = [], views = [];
+    for (let p; (p = ringDec.readChunk());) { copies.push(p.slice()); views.push(p); }
+    assert.strictEqual(copies.length, ref0.length);
+    copies.forEach(function (p, t) { assert.deepStrictEqual(Buffer.from(p.buffer), Buffer.from(ref0[t].buffer, ref0[t].byteOffset, ref0[t].byteLength), 'ring frame ' + t); });
+    assert.notDeepStrictEqual(Buffer.from(views[0].buffer, views[0].byteOffset, views[0].byteLength), Buffer.from(copies[0].buffer), 'frame 0 of flush 0 was not overwritten by flush 3');
     console.log('resident shared engine: ' + res.stats.frames + ' frames in ' + res.stats.batches + ' native calls; piecewise feed and a corrupt frame ok');
 }
 console.log('shared ' + mode + ' tests ok');
