@@ -1,6 +1,6 @@
 #!/bin/bash
 # Runs on the GPU box (via gpurun): the round's bench lines and rocprofv3 summaries into gpurun_out/<tag>/.
-# usage: tools/collect_round.sh r02
+# usage: tools/collect_round.sh r05
 set -u
 TAG=${1:-round}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -8,34 +8,50 @@ OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd $R
 timeout 200 python3 -c "import torch; torch.zeros(1).cuda()" >/dev/null 2>&1 || { echo "gpu init failed or slow"; exit 1; }
-b() { name=$1; shift; python3 bench.py "$@" > $OUT/bench_$name.json 2> $OUT/bench_$name.err || echo "bench $name failed" >> $OUT/failures.txt; tail -c 400 $OUT/bench_$name.json | head -c 0; }
+b() { name=$1; shift; python3 bench.py "$@" > $OUT/bench_$name.json 2> $OUT/bench_$name.err || echo "bench $name failed" >> $OUT/failures.txt; }
+# the headline and its variants: launches through aacg_decode_pipelined (the default), and --serial = rounds 1-4's method
 b quant
 b quant_20steps --steps 20 --warmup 5
+b quant_serial --serial --no-cpu-baseline
+b quant_serial_20steps --serial --steps 20 --warmup 5 --no-cpu-baseline
 b spec --input spec --no-cpu-baseline
+b spec_serial --input spec --serial --no-cpu-baseline
 b cfg3 --workload cfg3 --no-cpu-baseline
+b cfg3_serial --workload cfg3 --serial --no-cpu-baseline
 b cfg4 --workload cfg4 --no-cpu-baseline
+b cfg4_serial --workload cfg4 --serial --no-cpu-baseline
 b cfg5 --workload cfg5 --steps 1000 --warmup 200
+b cfg5_serial --workload cfg5 --serial --steps 1000 --warmup 200 --no-cpu-baseline
 b cfg5_spec --workload cfg5 --input spec --steps 1000 --warmup 200 --no-cpu-baseline
 b cfg3_tns_spec_quant --workload cfg3 --tns spec --steps 1000 --warmup 200 --no-cpu-baseline
 b cfg3_tns_spec_f32 --workload cfg3 --tns spec --input spec --steps 1000 --warmup 200 --no-cpu-baseline
 b cfg5_cce_spec --workload cfg5 --cce spec --steps 500 --warmup 100 --no-cpu-baseline
 b quant_i16out --output i16 --no-cpu-baseline
 b quant_pipelines2 --pipelines 2 --no-cpu-baseline
-b quant_serial --serial --no-cpu-baseline
-b cfg3_serial --workload cfg3 --serial --no-cpu-baseline
-b cfg5_serial --workload cfg5 --serial --steps 1000 --warmup 200 --no-cpu-baseline
 b quant_2ranks_shared_gpu --gpus 2 --dist-backend gloo --share-gpu --steps 1000 --warmup 200
 # the driver's launch line with one rank: RCCL carries the barrier and the 8-byte reductions
 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29541 bench.py --gpus 1 --steps 1000 --warmup 200 --no-cpu-baseline \
   > $OUT/bench_quant_torchrun_rccl_1rank.json 2> $OUT/bench_quant_torchrun_rccl_1rank.err || echo "bench torchrun failed" >> $OUT/failures.txt
+# the plugin surface: 256 streams through readChunk() on one JavaScript thread (independent decoders, SharedEngine, resident SharedEngine)
+node tools/readchunk_rate.js --streams 256 24 > $OUT/readchunk_256streams.json 2> $OUT/readchunk_256streams.err || echo "readchunk failed" >> $OUT/failures.txt
+# microbenchmarks behind the pipeline's design choices
+( for m in launch_cost queue_map stop_event; do echo "== tools/micro/$m"; timeout 120 tools/micro/$m 2>&1; done ) > $OUT/micro.txt
+# rocprofv3: kernel trace + PMC passes (tools/prof.sh); pipelined launches overlap, so the trace's row spacing is printed beside the stats
 bash tools/prof.sh $TAG/prof_quant > $OUT/prof_quant.log 2>&1
+bash tools/prof.sh $TAG/prof_quant_serial --serial > $OUT/prof_quant_serial.log 2>&1
 bash tools/prof.sh $TAG/prof_spec --input spec > $OUT/prof_spec.log 2>&1
 bash tools/prof.sh $TAG/prof_cfg5 --workload cfg5 > $OUT/prof_cfg5.log 2>&1
 bash tools/prof.sh $TAG/prof_cfg3_tns --workload cfg3 --tns spec > $OUT/prof_cfg3_tns.log 2>&1
-# keep what is judged: summaries and kernel stats (the raw rocprofv3 trees stay behind)
-for p in prof_quant prof_spec prof_cfg5 prof_cfg3_tns; do
+# keep what is judged: summaries, kernel stats, dispatch spacing (the raw rocprofv3 trees stay behind)
+for p in prof_quant prof_quant_serial prof_spec prof_cfg5 prof_cfg3_tns; do
   cp $OUT/$p/summary.txt $OUT/${p}_summary.txt 2>/dev/null
+  cp $OUT/$p/intervals.txt $OUT/${p}_intervals.txt 2>/dev/null
   find $OUT/$p/trace -name "*kernel_stats.csv" -exec cp {} $OUT/${p}_kernel_stats.csv \; 2>/dev/null
   rm -rf $OUT/$p
 done
+# per-wave phase timelines (profile build): launch after launch, and pipelined steady state
+if [ -f aac.js_amd/csrc/variants/profile.so ]; then
+  ( echo "== serial launches (aacg_decode_device): one launch, every CU starts together"; AACGPU_LIB=aac.js_amd/csrc/variants/profile.so AACG_ABLATE=16 timeout 120 python3 tools/timeline.py quant 2>/dev/null
+    echo; echo "== pipelined launches (aacg_decode_pipelined): the last of 41 launches, the one before it still running beside it"; AACGPU_LIB=aac.js_amd/csrc/variants/profile.so AACG_ABLATE=16 TL_PIPE=1 timeout 120 python3 tools/timeline.py quant 2>/dev/null ) > $OUT/timeline.txt
+fi
 ls -la $OUT

@@ -8,6 +8,8 @@ OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --steps 2000 --warmup 200 --repeats 5 --no-cpu-baseline "$@" > $OUT/trace.log 2>&1
+# pipelined launches overlap: the spacing of the trace's rows, not a row's own duration, is what a launch costs
+python3 $R/tools/kernel_intervals.py $OUT/trace > $OUT/intervals.txt 2>&1
 # PMC passes: separate runs, counters only (no trace domains)
 i=0
 for PMC in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
