@@ -88,10 +88,12 @@ struct aacg_engine {
         hipEvent_t tail[2] = {nullptr, nullptr};                      /* joins: everything on stream k so far */
         hipEvent_t fork = nullptr;
         int q = (AACG_OV_BUFFERS - 1) / 2;  /* every q-th launch of a stream is ordered behind the launch three before it (on the other stream) */
-        uint64_t n = 0;                     /* launches issued so far */
+        uint64_t n = 0;                     /* overlappable launches issued so far (stream n & 1, events by n) */
+        uint64_t issued = 0;                /* every launch through the pipeline */
         hipStream_t joined_stream = nullptr; uint64_t joined_n = ~0ull;   /* the stream most recently put behind the pipeline, and at which launch count */
         bool open = false;                  /* launches issued since the last join that nobody outside is ordered behind yet */
         bool concurrent = false;            /* the two streams were seen to run side by side (pipe_setup's probe) */
+        bool serial = false;                /* the most recent launch was one that cannot overlap: on stream[0], behind its predecessor */
         aacg_plan* plan = nullptr;          /* the plan of launch n - 1 */
         unsigned long long epoch = 0;       /* rv epoch of launch n - 1 */
         uint64_t chained = 0;               /* launches that continued their predecessor through the cross-launch cells (introspection) */
@@ -352,7 +354,7 @@ int pipe_join(aacg_engine* e, hipStream_t s)
 {
     aacg_engine::pipe_t& pp = e->pipe;
     if (!pp.open) return AACG_OK;
-    if (s && s == pp.joined_stream && pp.n == pp.joined_n) return AACG_OK;   /* s is behind all of it already */
+    if (s && s == pp.joined_stream && pp.issued == pp.joined_n) return AACG_OK;   /* s is behind all of it already */
     for (int k = 0; k < 2; k++) {
         if (s == pp.stream[k]) continue;                /* its own launches are in front of it anyway */
         if (s) {
@@ -361,7 +363,7 @@ int pipe_join(aacg_engine* e, hipStream_t s)
         } else HIP_TRY(e, hipStreamSynchronize(pp.stream[k]), AACG_ERR_NO_DEVICE);
     }
     if (!s) pp.open = false;                           /* the host has seen both streams drained: nothing in flight any more */
-    pp.joined_stream = s; pp.joined_n = pp.n;
+    pp.joined_stream = s; pp.joined_n = pp.issued;
     return AACG_OK;
 }
 
@@ -835,17 +837,20 @@ int aacg_decode_pipelined_timed(aacg_engine* e, aacg_plan* p, const void* d_coef
     const aacg_route R = route_of(e, p->h, true);
     if ((rc = plan_check_route(e, p, R)) || (rc = pipe_setup(e))) return rc;
     aacg_engine::pipe_t& pp = e->pipe;
-    hipStream_t s = pp.stream[pp.n & 1u];
+    /* a route whose launches cannot overlap (optional stages, coupling, int16 PCM: no rendezvous build) runs on the pipeline's
+     * first stream, launch behind launch: the stream orders them, no event is needed between two of them */
+    hipStream_t s = R.overlappable ? pp.stream[pp.n & 1u] : pp.stream[0];
+    const bool follows = !R.overlappable && pp.open && pp.serial && pp.plan == p && p->last_pipelined && p->seen_epoch == e->epoch;
     /* Does this launch continue the one before it — same plan, nothing in between, a route whose chains meet in cells?  Then
      * the two may overlap: its input state arrives through the cross-launch cells, tagged with that launch's epoch.  Its
      * stream puts it behind launch n - 2; every q-th launch of a stream also waits for the launch three before it (the other
      * stream): together every launch is behind launch n - AACG_OV_BUFFERS, whose buffers and cells it reuses (aacg_device.h).
      * Otherwise it starts behind everything in flight, from complete state. */
-    const bool continues = R.overlappable && pp.open && pp.plan == p && p->last_pipelined && p->seen_epoch == e->epoch;
+    const bool continues = R.overlappable && pp.open && !pp.serial && pp.plan == p && p->last_pipelined && p->seen_epoch == e->epoch;
     const uint64_t q = (uint64_t)pp.q;
     if (continues) {
         if (pp.n >= 3 && q && ((pp.n >> 1) % q) == 0) HIP_TRY(e, hipStreamWaitEvent(s, pp.done[(pp.n - 3) & 3u], 0), AACG_ERR_NO_DEVICE);
-    } else {
+    } else if (!follows) {
         if ((rc = pipe_join(e, s))) return rc;
         if (p->used && !p->last_pipelined) {
             HIP_TRY(e, hipEventRecord(p->last_use, p->last_stream), AACG_ERR_NO_DEVICE);
@@ -860,7 +865,7 @@ int aacg_decode_pipelined_timed(aacg_engine* e, aacg_plan* p, const void* d_coef
     unsigned long long epoch = 0;
     /* the launch three on may wait for this one: its event rides on the dispatch itself where the route is a single launch
      * (no marker packet between this launch and the next of its stream), else it is recorded behind the route's last launch */
-    const bool ordered = q && (((pp.n + 3) >> 1) % q) == 0;
+    const bool ordered = R.overlappable && q && (((pp.n + 3) >> 1) % q) == 0;
     hipEvent_t bound = R.rv ? (stop_mark ? (hipEvent_t)stop_mark : (ordered ? pp.done[pp.n & 3u] : nullptr)) : nullptr;
     rc = launch_run(e, R, p->d_units, p->d_runs, p->d_tns, p->d_scratch, p->d_spec, cb, rvb, p->h, d_coeffs, d_meta, d_pcm,
                     (int)(p->launches % AACG_OV_BUFFERS), s, xl, &epoch, bound);
@@ -868,7 +873,9 @@ int aacg_decode_pipelined_timed(aacg_engine* e, aacg_plan* p, const void* d_coef
     if (ordered && bound != pp.done[pp.n & 3u]) HIP_TRY(e, hipEventRecord(pp.done[pp.n & 3u], s), AACG_ERR_NO_DEVICE);
     if (stop_mark && bound != (hipEvent_t)stop_mark) HIP_TRY(e, hipEventRecord((hipEvent_t)stop_mark, s), AACG_ERR_NO_DEVICE);
     if (continues) pp.chained++;
-    pp.n++;
+    if (R.overlappable) pp.n++;
+    pp.issued++;
+    pp.serial = !R.overlappable;
     pp.open = true;
     pp.plan = p;
     pp.epoch = epoch;

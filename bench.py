@@ -64,7 +64,7 @@ def region_stats(region_ms, steps):
     n = len(per)
     med = per[n // 2] if n % 2 else 0.5 * (per[n // 2 - 1] + per[n // 2])
     return {"repeats": n, "ms_per_step_median": med, "ms_per_step_min": per[0], "ms_per_step_max": per[-1],
-            "ms_per_step_first": float(region_ms[0]) / steps}
+            "ms_per_step_first": float(region_ms[0]) / steps, "ms_per_step_each": [float(t) / steps for t in region_ms]}
 
 
 def whole_job_value(world, frames_per_step, ms_per_step):
