@@ -1,10 +1,12 @@
 #!/usr/bin/env python3
 """Install one `tools/collect_round.sh <tag>` collection (gpurun_out/<tag>/) as the round's committed evidence:
-    python tools/install_round.py r04h r04
-copies bench_*.json -> profiles/<round>_bench_*.json and the rocprofv3 summaries -> profiles/<round>_*_{summary.txt,kernel_stats.csv},
-rebuilds profiles/<round>_traffic.json from the PMC passes of the same box (FETCH_SIZE x 2 + WRITE_SIZE, KiB: MI355X_MICROARCH.md,
-HBM section), writes those bytes into the lines that cite the file, and regenerates DESIGN.md section 5's table and README.md's
-headline sentence from the installed lines.  Narrative numbers elsewhere in the docs stay the author's to check."""
+    python tools/install_round.py r05y r05
+copies bench_*.json -> profiles/<round>_bench_*.json, the rocprofv3 summaries / kernel stats / dispatch spacings ->
+profiles/<round>_*_{summary.txt,kernel_stats.csv,intervals.txt}, the plugin-surface rate, the microbenchmarks and the timelines,
+builds profiles/<round>_traffic.json from the PMC passes of the same box (FETCH_SIZE x 2 + WRITE_SIZE, KiB: MI355X_MICROARCH.md,
+HBM section) keyed by the kernel that was PROFILED, writes those bytes into the lines whose kernel it is, and regenerates
+DESIGN.md section 5's table and README.md's headline sentence from the installed lines.  Narrative numbers elsewhere in the docs
+stay the author's to check."""
 import glob
 import json
 import os
@@ -38,21 +40,32 @@ def main():
     tag, rnd = sys.argv[1], sys.argv[2]
     src = os.path.join(ROOT, "gpurun_out", tag)
     prof = os.path.join(ROOT, "profiles")
-    for p_ in ("quant", "spec", "cfg5", "cfg3_tns", "quant_run8"):
-        for suffix in ("summary.txt", "kernel_stats.csv"):
-            shutil.copy(os.path.join(src, "prof_%s_%s" % (p_, suffix)), os.path.join(prof, "%s_%s_%s" % (rnd, p_, suffix)))
-    tpath = os.path.join(prof, rnd + "_traffic.json")
-    T = json.load(open(tpath))
-    for key, p_, kernel in (("quant", "quant", "aacg_imdct_run_quant"), ("spec", "spec", "aacg_imdct_run_f32"), ("cfg5_quant", "cfg5", "aacg_imdct_run_quant_nt"),
-                            ("cfg3_tns_quant_ex", "cfg3_tns", "aacg_imdct_run_quant_ex"), ("quant_run8", "quant_run8", "aacg_imdct_run8_quant")):
-        c = pmc(os.path.join(prof, "%s_%s_summary.txt" % (rnd, p_)), kernel)
+    profiled = {"quant": ("prof_quant", "aacg_imdct_run_quant_rv", "cfg2"), "quant_serial": ("prof_quant_serial", "aacg_imdct_run_quant", "cfg2"),
+                "spec": ("prof_spec", "aacg_imdct_run_f32_rv", "cfg2"), "cfg5_quant": ("prof_cfg5", "aacg_imdct_run_quant_rv_nt", "cfg5"),
+                "cfg3_tns_quant_ex": ("prof_cfg3_tns", "aacg_imdct_run_quant_ex", "cfg3")}
+    for p_ in sorted(set(v[0] for v in profiled.values())):
+        for suffix in ("summary.txt", "kernel_stats.csv", "intervals.txt"):
+            f = os.path.join(src, "%s_%s" % (p_, suffix))
+            if os.path.exists(f):
+                shutil.copy(f, os.path.join(prof, "%s_%s_%s" % (rnd, p_[5:], suffix)))
+    for f, dst in (("readchunk_256streams.json", "readchunk_256streams.json"), ("micro.txt", "micro.txt"), ("timeline.txt", "timeline.txt")):
+        if os.path.exists(os.path.join(src, f)):
+            shutil.copy(os.path.join(src, f), os.path.join(prof, "%s_%s" % (rnd, dst)))
+    T = {"note": "HBM traffic per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (KiB; separate passes, tools/prof.sh, profiles/%s_*_summary.txt). gfx950 correction per "
+                 "MI355X_MICROARCH.md section HBM: FETCH_SIZE reports 1/2 of a wide (16 B/lane) coalesced read -> x2; WRITE_SIZE as is. Both checked in round 1 on a launch with "
+                 "known bytes (profiles/r01_calib_memonly_summary.txt: ratios 0.513 and 1.001). Keyed by the kernel that was profiled: bench.py quotes a record only for that kernel." % rnd}
+    for key, (p_, kernel, workload) in profiled.items():
+        c = pmc(os.path.join(prof, "%s_%s_summary.txt" % (rnd, p_[5:])), kernel)
         if c["FETCH_SIZE"] is None or c["WRITE_SIZE"] is None:
-            print("no PMC values for", key, "- kept", file=sys.stderr)
+            print("no PMC values for", key, kernel, file=sys.stderr)
             continue
-        T[key].update(FETCH_SIZE_KiB=c["FETCH_SIZE"], WRITE_SIZE_KiB=c["WRITE_SIZE"], traffic_bytes=(2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * K)
-        if c["TCP_TCC_WRITE_REQ_sum"] and "TCP_TCC_WRITE_REQ" in T[key]:
+        T[key] = {"kernel": kernel, "workload": workload, "FETCH_SIZE_KiB": c["FETCH_SIZE"], "WRITE_SIZE_KiB": c["WRITE_SIZE"],
+                  "traffic_bytes": (2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * K}
+        if c["TCP_TCC_WRITE_REQ_sum"]:
             T[key]["TCP_TCC_WRITE_REQ"] = int(round(c["TCP_TCC_WRITE_REQ_sum"]))
+    tpath = os.path.join(prof, rnd + "_traffic.json")
     json.dump(T, open(tpath, "w"), indent=1)
+    by_kernel = {(v["kernel"], v["workload"]): v for v in T.values() if isinstance(v, dict)}
     for f in sorted(glob.glob(os.path.join(src, "bench_*.json"))):
         lines = open(f).read().splitlines()
         for i, l in enumerate(lines):
@@ -60,38 +73,42 @@ def main():
                 continue
             d = json.loads(l)
             r = d["roofline"]
-            kind = "quant" if "int16" in d["config"]["input"] else "spec"
-            if "run8" in r["kernel"]:
-                if "config 2" in d["config"]["workload"] and kind == "quant":
-                    r["traffic"], r["traffic_source"] = float(T["quant_run8"]["traffic_bytes"]), "profiles/%s_traffic.json" % rnd
-                else:
-                    r["traffic"], r["traffic_source"] = None, None
-            elif r.get("traffic") and kind in T:
-                r["traffic"], r["traffic_source"] = float(T[kind]["traffic_bytes"]), "profiles/%s_traffic.json" % rnd
+            wl = "cfg2" if "config 2" in d["config"]["workload"] else ("cfg5" if "config 5" in d["config"]["workload"] else ("cfg3" if "config 3" in d["config"]["workload"] else "cfg4"))
+            rec = by_kernel.get((r["kernel"], wl)) if (d["config"].get("tns", "").startswith("identity") or "_ex" in r["kernel"]) else None
+            r["traffic"], r["traffic_source"] = (float(rec["traffic_bytes"]), "profiles/%s_traffic.json" % rnd) if rec else (None, None)
             lines[i] = json.dumps(d)
         open(os.path.join(prof, "%s_%s" % (rnd, os.path.basename(f))), "w").write("\n".join(lines) + "\n")
 
     def L(n):
         return line_of(os.path.join(prof, "%s_bench_%s.json" % (rnd, n)))
     mb = lambda k: T[k]["traffic_bytes"] / 1e6
-    rows = [("int16 in → f32 PCM, config 2 — **headline**", "quant", "%.1f MB (%.2f× algorithmic)" % (mb("quant"), T["quant"]["traffic_bytes"] / L("quant")["roofline"]["algorithmic_bytes_per_launch"])),
+    x_ = lambda k, n: "%.1f MB (%.2f× algorithmic)" % (mb(k), T[k]["traffic_bytes"] / L(n)["roofline"]["algorithmic_bytes_per_launch"]) if k in T else ""
+    rows = [("int16 in → f32 PCM, config 2, launches overlapped (`aacg_decode_pipelined`) — **headline**", "quant", x_("quant", "quant")),
             ("the same at the driver's `--steps 20 --warmup 5`", "quant_20steps", ""),
-            ("f32 in (filterbank seam), config 2", "spec", "%.1f MB (%.2f×)" % (mb("spec"), T["spec"]["traffic_bytes"] / L("spec")["roofline"]["algorithmic_bytes_per_launch"])),
-            ("int16 in, config 3 (all window sequences mixed)", "cfg3", ""),
-            ("config 4 shape (32 streams × 128 frames per GPU), run-to-run rendezvous (`_rv`; round 3: 13.03 with a recomputed frame per later run)", "cfg4", ""),
-            ("config 5 shape (7 channels per frame), int16 in", "cfg5", "%.1f MB (%.2f×); %.1f M L2 write requests" % (mb("cfg5_quant"), T["cfg5_quant"]["traffic_bytes"] / L("cfg5")["roofline"]["algorithmic_bytes_per_launch"], T["cfg5_quant"].get("TCP_TCC_WRITE_REQ", 0) / 1e6)),
-            ("config 5 shape, f32 in", "cfg5_spec", ""),
-            ("int16 in → **int16 PCM**, config 2", "quant_i16out", ""),
-            ("config 3 + `AACG_TNS_SPEC`, a filter on every channel-frame", "cfg3_tns_spec_quant", "%.1f MB, one launch" % mb("cfg3_tns_quant_ex")),
+            ("the same, launch behind launch on one stream (`--serial`: rounds 1-4's method, the plain kernel)", "quant_serial", x_("quant_serial", "quant_serial")),
+            ("`--serial` at `--steps 20 --warmup 5`", "quant_serial_20steps", ""),
+            ("f32 in (filterbank seam), config 2, overlapped", "spec", x_("spec", "spec")),
+            ("f32 in, `--serial`", "spec_serial", ""),
+            ("int16 in, config 3 (all window sequences mixed), overlapped", "cfg3", ""),
+            ("config 3, `--serial`", "cfg3_serial", ""),
+            ("config 4 shape (32 streams × 128 frames per GPU: 8 runs per chain, rendezvous between runs AND between launches), overlapped", "cfg4", ""),
+            ("config 4 shape, `--serial` (rendezvous between runs only)", "cfg4_serial", ""),
+            ("config 5 shape (7 channels per frame), int16 in, overlapped", "cfg5", ("%s; %.1f M L2 write requests" % (x_("cfg5_quant", "cfg5"), T["cfg5_quant"].get("TCP_TCC_WRITE_REQ", 0) / 1e6)) if "cfg5_quant" in T else ""),
+            ("config 5 shape, `--serial`", "cfg5_serial", ""),
+            ("config 5 shape, f32 in, overlapped", "cfg5_spec", ""),
+            ("int16 in → **int16 PCM**, config 2 (no rendezvous build: launch behind launch)", "quant_i16out", ""),
+            ("config 3 + `AACG_TNS_SPEC`, a filter on every channel-frame (one launch, not overlapped)", "cfg3_tns_spec_quant", x_("cfg3_tns_quant_ex", "cfg3_tns_spec_quant")),
             ("the same, f32 seam", "cfg3_tns_spec_f32", ""),
-            ("config 5 + `AACG_CCE_SPEC`, one independent CCE per frame", "cfg5_cce_spec", "two launches"),
-            ("two disjoint stream sets on two HIP streams (`--pipelines 2`, supplementary)", "quant_pipelines2", ""),
-            ("driver's `torch.distributed.run` line, one rank over RCCL", "quant_torchrun_rccl_1rank", ""),
-            ("*one-channel-per-wave kernels (opt-in, §3d)*, config 2, int16 in", "quant_run8", "%.1f MB (%.2f×: rendezvous payloads)" % (mb("quant_run8"), T["quant_run8"]["traffic_bytes"] / L("quant_run8")["roofline"]["algorithmic_bytes_per_launch"])),
-            ("*the same*, f32 in", "spec_run8", ""), ("*the same*, config 4 shape", "cfg4_run8", ""), ("*the same*, config 5 shape (general finishing pass)", "cfg5_run8", "")]
+            ("config 5 + `AACG_CCE_SPEC`, one independent CCE per frame (two launches, not overlapped)", "cfg5_cce_spec", ""),
+            ("two disjoint stream sets on two HIP streams, plain kernel (`--pipelines 2`, supplementary: what overlap is worth without a rendezvous)", "quant_pipelines2", ""),
+            ("driver's `torch.distributed.run` line, one rank over RCCL", "quant_torchrun_rccl_1rank", "")]
     out = ["| path | µs / launch: median (min – max of 25 repeats) | frames/s | achieved | of 8 TB/s | of the same-run copy | PMC traffic / launch | parity vs oracle (rms) |", "|---|---|---|---|---|---|---|---|"]
     for name, key, tr in rows:
-        x = L(key); tm = x["timing"]; r = x["roofline"]
+        try:
+            x = L(key)
+        except (OSError, IndexError):
+            continue
+        tm = x["timing"]; r = x["roofline"]
         out.append("| %s | **%.2f** (%.2f – %.2f) | %.1f M | %.2f TB/s | %.1f %% | %.2f of %.2f TB/s | %s | %.1e |" % (
             name, tm["ms_per_step_median"] * 1e3, tm["ms_per_step_min"] * 1e3, tm["ms_per_step_max"] * 1e3, x["value"] / 1e6, r["achieved"] / 1e3,
             100 * r["frac"], r["frac_of_copy"], r["copy_ceiling_GBs"] / 1e3, tr, x["parity_rms"]))
@@ -109,7 +126,10 @@ def main():
     open(p, "w").write(s)
     print(head)
     for name, key, _ in rows:
-        x = L(key)
+        try:
+            x = L(key)
+        except (OSError, IndexError):
+            continue
         print("%-28s %-34s %.3f us  frac %.3f  of copy %.3f" % (key, x["roofline"]["kernel"][:34], x["roofline"]["kernel_ms"] * 1e3, x["roofline"]["frac"], x["roofline"]["frac_of_copy"]))
 
 
