@@ -101,27 +101,58 @@ struct aacg_pns_tables {
 /* The overlap state (filter_bank.js:38-41) of one channel lives in AACG_OV_BUFFERS rotating buffers of 1024 floats: a launch
  * that advances the channel reads buffer r and leaves the new state in buffer r + 1 (mod AACG_OV_BUFFERS).  Two would do for
  * launches that follow each other on one HIP stream; more are what lets consecutive launches of a plan OVERLAP
- * (aacg_decode_pipelined): launch n + 1 may be writing buffer r + 2 while launch n still reads r and writes r + 1.  A buffer
- * (and the rendezvous cell that goes with it) comes round again after AACG_OV_BUFFERS launches, so the engine orders launch n
- * behind launch n - AACG_OV_BUFFERS: its two streams give "behind n - 2" for free, and every q-th launch of a stream waits for
- * an event of the launch three before it on the other stream, q = (AACG_OV_BUFFERS - 1) / 2 — with five buffers one event
- * record and one event wait per FOUR launches (per launch they cost the host more than the launch itself:
- * tools/micro/launch_cost.hip). */
-#define AACG_OV_BUFFERS 5
+ * (aacg_decode_pipelined): launch n + 1 may be writing buffer r + 2 while launch n still reads r and writes r + 1.
+ * A buffer (and the rendezvous cell that goes with it) comes round again after AACG_OV_BUFFERS launches: launch n shares
+ * buffers with launches n - K + 1, n - K and n - K - 1 (K = AACG_OV_BUFFERS), so it must start behind EVERY launch up to
+ * n - K + 1.  The engine issues launch n on stream n mod AACG_PIPE_STREAMS (behind n - 3, n - 6, ... and nothing else on the
+ * GPU's side) and bounds the rest from the HOST (back-pressure): the launches of every second round of three carry a
+ * completion event, and before the first launch of such a round is enqueued the host waits for the events of the round FOUR
+ * back (aacg_pipeline_order, aacg_routes.cpp).  Everything up to launch 3 (r - 4) + 2 is then complete before launches 3 r ..
+ * 3 r + 5 exist: a distance of at most fifteen, hence sixteen buffers, and the GPU's queues hold three rounds (three launches
+ * running, six waiting) when the host comes back to enqueue two more.  What this replaced, measured on the way
+ * (gpurun_out/ab_*.txt of round 5, profiles/r05_budget.txt): two streams and five buffers with an event WAIT per four
+ * launches kept a CU waiting 1.6-2.5 us between two workgroups, most of it for the launch after next to become eligible —
+ * 11.7 us per launch; three streams without any ordering (not a product) 11.15-11.3; three streams with a cross-stream wait
+ * per two launches 11.9 — a barrier packet in a queue costs more than the third stream gains; the host waiting for the round
+ * two back 11.5-11.8 (the queues run dry while it enqueues), four back 11.3; a fourth stream nothing more. */
+#define AACG_OV_BUFFERS 16
+#define AACG_PIPE_STREAMS 3
 
 /* One workgroup's work: consecutive frames of one element of one stream.  The first run of a
  * chain holds up to 16 units (wave w = unit w, wave 0 starts from the overlap state); a later
- * run holds up to 15 units in waves 1..15 and wave 0 recomputes the tail of pred_unit. */
+ * run holds up to 15 units in waves 1..15 and wave 0 recomputes the tail of pred_unit.
+ * The record is laid out for how a wave reads it — ONE scalar round trip: the header as eight dwords, and three dwords picked by
+ * the wave's number (its unit, and where that unit's spectra and band words lie).  Between a wave's first instruction and its
+ * first spectrum stand dependent memory round trips and nothing else, each 0.15 us on an idle memory system and 0.45 us under
+ * streaming load (profiles/r05_budget.txt): with the addresses here the spectra are requested two round trips after the
+ * start (kernel arguments, this record) instead of five (arguments, n_units, unit index, unit record, spectra), and the
+ * unit record travels beside them. */
 struct aacg_run {
     int32_t pred_unit;                /* -1: first run of its chain */
     int32_t n_units;
-    int32_t unit[AACG_RUN_W];
+    int32_t is_last;                  /* last run of its chain: the final tail goes to the out buffer */
+    uint32_t wave_nch;                /* 2 bits per WAVE: channels of the unit the wave loads first */
     int32_t ov0[2];                   /* per channel: float offset of its buffer 0 in the overlap pool (buffer r at + 1024 r) */
     int32_t rot[2];                   /* per channel: the buffer that held its state when the plan was made; launch number j of the
                                          plan (aacg_kparams.flip = j mod AACG_OV_BUFFERS) reads buffer (rot + flip) mod AACG_OV_BUFFERS and writes the next one */
-    int32_t is_last;                  /* last run of its chain: the final tail goes to the out buffer */
-    int32_t reserved;
+    int32_t unit[AACG_RUN_W];
+    /* per WAVE, not per unit (a predecessor wave shifts them, aacg_run_wave_unit): the unit the wave loads first — its index
+     * (unit 0 for a wave without work: every wave loads, quant_load), its coefficient block and its band-word block
+     * (aacg_unit_desc.coef_offset / meta_offset: copies, kept equal by everything that rewrites unit records) */
+    int32_t  wave_unit[AACG_RUN_W];
+    uint32_t wave_coef[AACG_RUN_W];
+    uint32_t wave_meta[AACG_RUN_W];
 };
+static_assert(sizeof(aacg_run) == 288 && __builtin_offsetof(aacg_run, ov0) == 16 && __builtin_offsetof(aacg_run, wave_unit) == 96,
+              "aacg_run: the header is read as eight dwords, the per-wave words by offset (imdct_run_body)");
+/* the unit wave w of a run loads first: the predecessor in wave 0 of a later run (a full later run's wave 0 then takes its
+ * own frame in a second pass), else its frame; -1: no work */
+static inline int32_t aacg_run_wave_unit(const aacg_run& r, int w)
+{
+    if (r.pred_unit >= 0 && w == 0) return r.pred_unit;
+    const int k = (r.pred_unit >= 0 && r.n_units < AACG_RUN_W) ? w - 1 : w;
+    return k < r.n_units ? r.unit[k] : -1;
+}
 
 /* AACG_CCE_SPEC: one (coupling element, target channel) pair of one frame.  Dependent coupling (spectral domain,
  * cce.js:130-158): dst / src are coefficient blocks of the f32 spectrum buffer; independent (cce.js:121-128 with the

@@ -77,22 +77,22 @@ struct aacg_engine {
     uint64_t epoch = 0;                     /* bumped whenever `parity` changes: lets a relaunched plan skip its check */
     aacg_tables h_tab;
     aacg_host_windows h_win;
-    /* pipelined launches (aacg_decode_pipelined): two internal streams taken in turn, so that a launch starts on the CUs the
-     * launch before it has left while that one is still finishing.  The chains of the two launches meet in cross-launch cells
-     * (aacg_xl_cell); the engine bounds how far a launch may run ahead: launch n is ordered behind launch n - 2 (same stream),
-     * and every q-th launch of a stream behind the launch three before it on the other stream (an event), so that every launch is
-     * behind launch n - AACG_OV_BUFFERS — which is when the rotating overlap buffers and cells come round again. */
+    /* pipelined launches (aacg_decode_pipelined): AACG_PIPE_STREAMS internal streams taken in turn, so that a launch starts on the
+     * CUs the launches before it have left while those are still finishing, and a CU that is done with launch n + 1's workgroup
+     * finds one of launch n + 2 waiting.  The chains of consecutive launches meet in cross-launch cells (aacg_xl_cell); how far
+     * a launch may run ahead of the ones whose overlap buffers and cells it reuses is bounded by the HOST: it does not enqueue
+     * a round of launches before the round AACG_PIPE_DEPTH back is complete (aacg_pipeline_order, aacg_routes.cpp, is the rule in
+     * one place; aacg_device.h has the arithmetic). */
     struct pipe_t {
-        hipStream_t stream[2] = {nullptr, nullptr};
-        hipEvent_t done[4] = {nullptr, nullptr, nullptr, nullptr};   /* done[n % 4]: launch n of the pipeline, where launch n + 3 will wait for it */
-        hipEvent_t tail[2] = {nullptr, nullptr};                      /* joins: everything on stream k so far */
+        hipStream_t stream[AACG_PIPE_STREAMS] = {};
+        hipEvent_t mark[AACG_PIPE_RING][AACG_PIPE_STREAMS] = {};   /* completion events of the marked rounds' launches (aacg_pipeline_order) */
+        hipEvent_t tail[AACG_PIPE_STREAMS] = {};   /* joins: everything on stream k so far */
         hipEvent_t fork = nullptr;
-        int q = (AACG_OV_BUFFERS - 1) / 2;  /* every q-th launch of a stream is ordered behind the launch three before it (on the other stream) */
-        uint64_t n = 0;                     /* overlappable launches issued so far (stream n & 1, events by n) */
+        uint64_t n = 0;                     /* overlappable launches issued so far (stream n mod AACG_PIPE_STREAMS, events by n) */
         uint64_t issued = 0;                /* every launch through the pipeline */
         hipStream_t joined_stream = nullptr; uint64_t joined_n = ~0ull;   /* the stream most recently put behind the pipeline, and at which launch count */
         bool open = false;                  /* launches issued since the last join that nobody outside is ordered behind yet */
-        bool concurrent = false;            /* the two streams were seen to run side by side (pipe_setup's probe) */
+        bool concurrent = false;            /* the streams were seen to run side by side, each pair of them (pipe_setup's probe) */
         bool serial = false;                /* the most recent launch was one that cannot overlap: on stream[0], behind its predecessor */
         aacg_plan* plan = nullptr;          /* the plan of launch n - 1 */
         unsigned long long epoch = 0;       /* rv epoch of launch n - 1 */
@@ -288,7 +288,7 @@ int launch_run(aacg_engine* e, const aacg_route& R, const aacg_dev_unit* d_units
         V.epoch = ++e->rv_epoch;
         if (xl.on) { V.xl_cells = e->d_xl_cells; V.xl_head = e->d_xl_head; V.epoch_in = xl.epoch_in; }
         if (epoch_out) *epoch_out = V.epoch;
-        if (e->d_trace) { P.ablate = e->ablate; P.spec_out = (float*)e->d_trace + (size_t)xl.set * (1u << 19); }   /* profiling builds: launches in flight side by side stamp different halves */
+        if (e->d_trace) { P.ablate = e->ablate; P.spec_out = (float*)e->d_trace + (size_t)xl.set * (1u << 18); }   /* profiling builds: launches in flight side by side stamp different quarters */
         return launch_kernel(e, aacg_find_run_kernel(R.run_key), (unsigned)n_runs, s, P, &V, stop);
     }
     P.runs = d_runs; P.n_runs = (int32_t)h.runs.size();
@@ -355,14 +355,14 @@ int pipe_join(aacg_engine* e, hipStream_t s)
     aacg_engine::pipe_t& pp = e->pipe;
     if (!pp.open) return AACG_OK;
     if (s && s == pp.joined_stream && pp.issued == pp.joined_n) return AACG_OK;   /* s is behind all of it already */
-    for (int k = 0; k < 2; k++) {
+    for (int k = 0; k < AACG_PIPE_STREAMS; k++) {
         if (s == pp.stream[k]) continue;                /* its own launches are in front of it anyway */
         if (s) {
             HIP_TRY(e, hipEventRecord(pp.tail[k], pp.stream[k]), AACG_ERR_NO_DEVICE);
             HIP_TRY(e, hipStreamWaitEvent(s, pp.tail[k], 0), AACG_ERR_NO_DEVICE);
         } else HIP_TRY(e, hipStreamSynchronize(pp.stream[k]), AACG_ERR_NO_DEVICE);
     }
-    if (!s) pp.open = false;                           /* the host has seen both streams drained: nothing in flight any more */
+    if (!s) pp.open = false;                           /* the host has seen the streams drained: nothing in flight any more */
     pp.joined_stream = s; pp.joined_n = pp.issued;
     return AACG_OK;
 }
@@ -420,6 +420,16 @@ int aacg_debug_route(int input_kind, int output_kind, int debug_route, int plan_
     if (t.size() + 1 > n) return AACG_ERR_INVALID_ARG;
     std::memcpy(dst, t.c_str(), t.size() + 1);
     return AACG_OK;
+}
+
+int aacg_debug_pipeline_order(unsigned long long n, int* stream, long long* sync_round, int* marked, long long* complete_upto)
+{
+    const aacg_pipe_order o = aacg_pipeline_order(n);
+    if (stream) *stream = o.stream;
+    if (sync_round) *sync_round = o.sync_round;
+    if (marked) *marked = o.marked ? 1 : 0;
+    if (complete_upto) *complete_upto = o.complete_upto;
+    return AACG_OV_BUFFERS;
 }
 
 /* The registered run kernels: `index`-th symbol into dst; returns its switches (AACG_RK_*), or < 0 past the end.  Every
@@ -521,7 +531,7 @@ void aacg_destroy(aacg_engine* e)
     if (e->d_pns) (void)hipFree(e->d_pns);
     if (e->d_xl_cells) (void)hipFree(e->d_xl_cells);
     if (e->d_xl_head) (void)hipFree(e->d_xl_head);
-    for (hipEvent_t ev : e->pipe.done) if (ev) (void)hipEventDestroy(ev);
+    for (auto& round : e->pipe.mark) for (hipEvent_t ev : round) if (ev) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : e->pipe.tail) if (ev) (void)hipEventDestroy(ev);
     if (e->pipe.fork) (void)hipEventDestroy(e->pipe.fork);
     for (hipStream_t st : e->pipe.stream) if (st) (void)hipStreamDestroy(st);
@@ -658,11 +668,11 @@ int aacg_plan_create_ex(aacg_engine* e, const aacg_unit_desc* units, uint32_t n_
               hip_ok(e, hipEventCreateWithFlags(&p->uploaded, hipEventDisableTiming), "hipEventCreate") &&
               hip_ok(e, hipEventCreateWithFlags(&p->last_use, hipEventDisableTiming), "hipEventCreate");
     /* the rendezvous cut of the chains, for plans that can take it (serially: long chains; through the pipeline: every plain
-     * batch): run table, links, and TWO sets of in-launch cells — overlapping launches of the plan must not share one */
+     * batch): run table, links, and a set of in-launch cells per pipeline stream — overlapping launches of the plan must not share one */
     const bool rvp = route_of(e, p->h, true).rv;
     const size_t rvs[4] = {rvp ? sizeof(aacg_run) * p->h.runs_rv.size() : 0, rvp ? sizeof(aacg_rv_link) * p->h.links_rv.size() : 0,
-                           rvp ? 2u * sizeof(unsigned long long) * AACG_RV_STATE_WORDS * (size_t)p->h.n_links_rv : 0,
-                           rvp ? 2u * sizeof(float) * AACG_RV_DATA_FLOATS * (size_t)p->h.n_links_rv : 0};
+                           rvp ? (size_t)AACG_PIPE_STREAMS * sizeof(unsigned long long) * AACG_RV_STATE_WORDS * (size_t)p->h.n_links_rv : 0,
+                           rvp ? (size_t)AACG_PIPE_STREAMS * sizeof(float) * AACG_RV_DATA_FLOATS * (size_t)p->h.n_links_rv : 0};
     const size_t want[AACG_PLAN_BUFFERS] = {ub, rb, tb, sb, xb, cb[0], cb[1], cb[2], cb[3], rvs[0], rvs[1], rvs[2], rvs[3]};
     void** const slot[AACG_PLAN_BUFFERS] = {(void**)&p->d_units, (void**)&p->d_runs, (void**)&p->d_tns, (void**)&p->d_scratch, (void**)&p->d_spec,
                              &p->d_cce[0], &p->d_cce[1], &p->d_cce[2], &p->d_cce[3], &p->d_rv[0], &p->d_rv[1], &p->d_rv[2], &p->d_rv[3]};
@@ -796,26 +806,29 @@ static int pipe_setup(aacg_engine* e)
 {
     aacg_engine::pipe_t& pp = e->pipe;
     if (pp.stream[0]) return AACG_OK;
-    /* Two streams that really run side by side.  Streams of the highest priority are dealt their hardware queues apart from the
-     * crowd of ordinary streams a host process may have made (PyTorch: 32 at once); the pair is then PROBED, and further
-     * candidates are tried if it shares a queue after all.  A pair that never overlaps still decodes correctly — serially. */
+    /* Streams that really run side by side.  Streams of the highest priority are dealt their hardware queues apart from the
+     * crowd of ordinary streams a host process may have made (PyTorch: 32 at once); every candidate is PROBED against the
+     * streams already chosen, and further candidates are tried if it shares a queue with one of them after all.  Streams that
+     * never overlap still decode correctly — serially. */
     int least = 0, greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
     unsigned* d_probe = nullptr;
     HIP_TRY(e, hipMalloc((void**)&d_probe, 8), AACG_ERR_OUT_OF_MEMORY);
     HIP_TRY(e, hipStreamCreateWithPriority(&pp.stream[0], hipStreamNonBlocking, greatest), AACG_ERR_NO_DEVICE);
-    hipStream_t spare[6]; int n_spare = 0;
-    for (int attempt = 0; attempt < 6 && !pp.concurrent; attempt++) {
+    hipStream_t spare[8]; int n_spare = 0, have = 1;
+    for (int attempt = 0; attempt < 8 && have < AACG_PIPE_STREAMS; attempt++) {
         hipStream_t cand = nullptr;
-        HIP_TRY(e, hipStreamCreateWithPriority(&cand, hipStreamNonBlocking, attempt < 4 ? greatest : 0), AACG_ERR_NO_DEVICE);
-        if (streams_overlap(e, pp.stream[0], cand, d_probe)) { pp.stream[1] = cand; pp.concurrent = true; }
-        else spare[n_spare++] = cand;
+        HIP_TRY(e, hipStreamCreateWithPriority(&cand, hipStreamNonBlocking, attempt < 6 ? greatest : 0), AACG_ERR_NO_DEVICE);
+        bool apart = true;
+        for (int k = 0; k < have && apart; k++) apart = streams_overlap(e, pp.stream[k], cand, d_probe);
+        if (apart) pp.stream[have++] = cand; else spare[n_spare++] = cand;
     }
-    if (!pp.stream[1]) pp.stream[1] = spare[--n_spare];
+    pp.concurrent = have == AACG_PIPE_STREAMS;
+    while (have < AACG_PIPE_STREAMS) pp.stream[have++] = spare[--n_spare];
     for (int i = 0; i < n_spare; i++) (void)hipStreamDestroy(spare[i]);
     (void)hipFree(d_probe);
     /* events that order and nothing else: no time stamps, no system-scope fence at the record */
-    for (hipEvent_t& ev : pp.done) HIP_TRY(e, hipEventCreateWithFlags(&ev, hipEventDisableTiming | hipEventDisableSystemFence), AACG_ERR_NO_DEVICE);
+    for (auto& round : pp.mark) for (hipEvent_t& ev : round) HIP_TRY(e, hipEventCreateWithFlags(&ev, hipEventDisableTiming | hipEventDisableSystemFence), AACG_ERR_NO_DEVICE);
     for (hipEvent_t& ev : pp.tail) HIP_TRY(e, hipEventCreateWithFlags(&ev, hipEventDisableTiming | hipEventDisableSystemFence), AACG_ERR_NO_DEVICE);
     HIP_TRY(e, hipEventCreateWithFlags(&pp.fork, hipEventDisableTiming | hipEventDisableSystemFence), AACG_ERR_NO_DEVICE);
     return AACG_OK;
@@ -839,17 +852,21 @@ int aacg_decode_pipelined_timed(aacg_engine* e, aacg_plan* p, const void* d_coef
     aacg_engine::pipe_t& pp = e->pipe;
     /* a route whose launches cannot overlap (optional stages, coupling, int16 PCM: no rendezvous build) runs on the pipeline's
      * first stream, launch behind launch: the stream orders them, no event is needed between two of them */
-    hipStream_t s = R.overlappable ? pp.stream[pp.n & 1u] : pp.stream[0];
+    const aacg_pipe_order ord = aacg_pipeline_order(pp.n);
+    hipStream_t s = R.overlappable ? pp.stream[ord.stream] : pp.stream[0];
     const bool follows = !R.overlappable && pp.open && pp.serial && pp.plan == p && p->last_pipelined && p->seen_epoch == e->epoch;
     /* Does this launch continue the one before it — same plan, nothing in between, a route whose chains meet in cells?  Then
      * the two may overlap: its input state arrives through the cross-launch cells, tagged with that launch's epoch.  Its
-     * stream puts it behind launch n - 2; every q-th launch of a stream also waits for the launch three before it (the other
-     * stream): together every launch is behind launch n - AACG_OV_BUFFERS, whose buffers and cells it reuses (aacg_device.h).
-     * Otherwise it starts behind everything in flight, from complete state. */
+     * stream puts it behind launch n - AACG_PIPE_STREAMS; the event waits of aacg_pipeline_order (aacg_routes.cpp) do the rest:
+     * together every launch is behind every launch up to n - AACG_OV_BUFFERS + 1, whose buffers and cells it reuses
+     * (aacg_device.h).  Otherwise it starts behind everything in flight, from complete state. */
     const bool continues = R.overlappable && pp.open && !pp.serial && pp.plan == p && p->last_pipelined && p->seen_epoch == e->epoch;
-    const uint64_t q = (uint64_t)pp.q;
     if (continues) {
-        if (pp.n >= 3 && q && ((pp.n >> 1) % q) == 0) HIP_TRY(e, hipStreamWaitEvent(s, pp.done[(pp.n - 3) & 3u], 0), AACG_ERR_NO_DEVICE);
+        /* back-pressure instead of cross-stream waits: the HOST waits until the round AACG_PIPE_DEPTH back is complete — no
+         * barrier packet enters a GPU queue (one per two launches cost the three-stream pipeline all it had gained), and the
+         * queues still hold a round of launches when the host comes back */
+        if (ord.sync_round >= 0)
+            for (hipEvent_t ev : pp.mark[((uint64_t)ord.sync_round / AACG_PIPE_MARK) % AACG_PIPE_RING]) HIP_TRY(e, hipEventSynchronize(ev), AACG_ERR_NO_DEVICE);
     } else if (!follows) {
         if ((rc = pipe_join(e, s))) return rc;
         if (p->used && !p->last_pipelined) {
@@ -861,16 +878,17 @@ int aacg_decode_pipelined_timed(aacg_engine* e, aacg_plan* p, const void* d_coef
     if (!p->used) HIP_TRY(e, hipStreamWaitEvent(s, p->uploaded, 0), AACG_ERR_NO_DEVICE);
     const cce_bufs cb = {(const aacg_run*)p->d_cce[0], (const aacg_couple_job*)p->d_cce[1], (const float*)p->d_cce[2], (float*)p->d_cce[3]};
     const rv_bufs rvb = {(const aacg_run*)p->d_rv[0], (const aacg_rv_link*)p->d_rv[1], (unsigned long long*)p->d_rv[2], (float*)p->d_rv[3]};
-    const xl_args xl = {R.overlappable, continues ? pp.epoch : 0ull, (int)(pp.n & 1u)};
+    const xl_args xl = {R.overlappable, continues ? pp.epoch : 0ull, ord.stream};
     unsigned long long epoch = 0;
-    /* the launch three on may wait for this one: its event rides on the dispatch itself where the route is a single launch
+    /* the host will wait for this one: its event rides on the dispatch itself where the route is a single launch
      * (no marker packet between this launch and the next of its stream), else it is recorded behind the route's last launch */
-    const bool ordered = R.overlappable && q && (((pp.n + 3) >> 1) % q) == 0;
-    hipEvent_t bound = R.rv ? (stop_mark ? (hipEvent_t)stop_mark : (ordered ? pp.done[pp.n & 3u] : nullptr)) : nullptr;
+    const bool ordered = R.overlappable && ord.marked;
+    hipEvent_t const mine = pp.mark[(pp.n / AACG_PIPE_STREAMS / AACG_PIPE_MARK) % AACG_PIPE_RING][ord.stream];
+    hipEvent_t bound = R.rv ? (stop_mark ? (hipEvent_t)stop_mark : (ordered ? mine : nullptr)) : nullptr;
     rc = launch_run(e, R, p->d_units, p->d_runs, p->d_tns, p->d_scratch, p->d_spec, cb, rvb, p->h, d_coeffs, d_meta, d_pcm,
                     (int)(p->launches % AACG_OV_BUFFERS), s, xl, &epoch, bound);
     if (rc) return rc;
-    if (ordered && bound != pp.done[pp.n & 3u]) HIP_TRY(e, hipEventRecord(pp.done[pp.n & 3u], s), AACG_ERR_NO_DEVICE);
+    if (ordered && bound != mine) HIP_TRY(e, hipEventRecord(mine, s), AACG_ERR_NO_DEVICE);
     if (stop_mark && bound != (hipEvent_t)stop_mark) HIP_TRY(e, hipEventRecord((hipEvent_t)stop_mark, s), AACG_ERR_NO_DEVICE);
     if (continues) pp.chained++;
     if (R.overlappable) pp.n++;
@@ -947,6 +965,10 @@ int aacg_plan_refresh_units(aacg_engine* e, aacg_plan* p, const aacg_unit_desc* 
     /* pageable source: the runtime stages it before returning, so the host copy may change again right away; in stream
      * order behind the launches that read the previous records */
     HIP_TRY(e, hipMemcpyAsync(p->d_units, p->h.units.data(), sizeof(aacg_dev_unit) * p->h.units.size(), hipMemcpyHostToDevice, s), AACG_ERR_NO_DEVICE);
+    if (p->h.runs_moved) {                                  /* the batch's blocks lie elsewhere: the run tables' copies of the offsets with them */
+        if (p->d_runs) HIP_TRY(e, hipMemcpyAsync(p->d_runs, p->h.runs.data(), sizeof(aacg_run) * p->h.runs.size(), hipMemcpyHostToDevice, s), AACG_ERR_NO_DEVICE);
+        if (p->d_rv[0]) HIP_TRY(e, hipMemcpyAsync(p->d_rv[0], p->h.runs_rv.data(), sizeof(aacg_run) * p->h.runs_rv.size(), hipMemcpyHostToDevice, s), AACG_ERR_NO_DEVICE);
+    }
     p->last_stream = s;
     p->used = true;
     p->last_pipelined = false;

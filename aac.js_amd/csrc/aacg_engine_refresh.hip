@@ -21,14 +21,16 @@ void aacg_units_refresh(aacg_dev_unit* units, const aacg_unit_desc* parsed, cons
     const aacg_unit_desc p = parsed[i];
     const aacg_parse_result r = results[i / max_units];
     const uint32_t e = i % max_units;
-    bool ok = r.status == AACG_PARSE_OK && e < r.n_units && p.n_ch == u.d.n_ch && p.channel == u.d.channel;
+    /* (the blocks: the plan's run tables carry copies of the offsets, aacg_run.wave_coef — a frame the parser put elsewhere is not
+     * the frame the plan was made for) */
+    bool ok = r.status == AACG_PARSE_OK && e < r.n_units && p.n_ch == u.d.n_ch && p.channel == u.d.channel &&
+              p.coef_offset == u.d.coef_offset && p.meta_offset == u.d.meta_offset;
     if (ok && refuse_pns && (p.flags & AACG_UNIT_HAS_PNS)) ok = false;      /* AACG_PNS_REFERENCE engines do not decode noise bands */
     /* A refused frame's record (and the slots e >= n_units) is unspecified: nothing is taken from it.  Its unit keeps
      * the offsets the planner validated — a silent unit still loads its blocks (quant_load reads unconditionally). */
     u.d.tns_offset = 0;
     u.gmap[0] = u.gmap[1] = 0;
     if (ok) {
-        u.d.coef_offset = p.coef_offset; u.d.meta_offset = p.meta_offset;
         u.d.flags = p.flags;
         for (int c = 0; c < 2; c++) {
             u.d.ch[c] = p.ch[c];

@@ -42,6 +42,7 @@ struct aacg_plan_host {
      * by a rendezvous cell instead of a recomputed frame.  The route of plain batches with a chain longer than a run
      * (long_chains) and of every plain batch launched through aacg_decode_pipelined */
     bool     long_chains = false;
+    bool     runs_moved = false;        /* aacg_plan_refresh_host: the batch's block offsets differ from the ones the run tables carried — they were rewritten */
     std::vector<aacg_run>     runs_rv;
     std::vector<aacg_rv_link> links_rv;     /* one per run, same order */
     uint32_t n_links_rv = 0;
@@ -85,6 +86,7 @@ int aacg_plan_build(const aacg_unit_desc* units, uint32_t n_units, int sample_in
 
 /* A kept plan's unit records rewritten from the next batch's (same structure: streams, frames, elements, PCM positions);
  * AACG_ERR_LAYOUT_CHANGE if the structure differs, in which case nothing has been touched. */
+void aacg_plan_fill_run_waves(aacg_plan_host* h);
 int aacg_plan_refresh_host(aacg_plan_host* h, const aacg_unit_desc* units, uint32_t n_units, int sample_index, bool tns_spec, std::string* err);
 
 /* tns.js:111-152: per-filter sample range and LPC coefficients of one channel (float32 stores as in the

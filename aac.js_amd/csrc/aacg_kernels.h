@@ -890,11 +890,11 @@ struct quant_regs { dpi4 ql[2], qr[2]; unsigned mw[2][2]; };
 
 /* the unit's quantised spectra (16 bytes per lane per load) and raw band words, issued early */
 template <bool NTL = false>                             /* NTL: non-temporal loads (dp_load_nt) */
-DP_DEVICE void quant_load(const aacg_kparams& P, const unit_view& u, int n_ch, quant_regs& r)
+DP_DEVICE void quant_load(const aacg_kparams& P, uint32_t coef_block, uint32_t meta_block, int n_ch, quant_regs& r)
 {
     const int lane = dp_lane();
-    const int16_t* q0 = (const int16_t*)P.coeffs + (size_t)u.coef_offset * 1024u;
-    const aacg_band_meta* meta = P.meta + u.meta_offset;
+    const int16_t* q0 = (const int16_t*)P.coeffs + (size_t)coef_block * 1024u;
+    const aacg_band_meta* meta = P.meta + meta_block;
     /* unconditional loads (a single channel reads its own block twice): no per-load branches, so the
      * compiler keeps all of them in flight together */
     const int16_t* q1 = q0 + (n_ch == 2 ? 1024 : 0);
@@ -1985,44 +1985,51 @@ DP_DEVICE void imdct_run_body(const aacg_kparams& P, const aacg_rv_args* V = nul
     int* flags = (int*)(slots + AACG_WG_WAVES * AACG_SLOT_FLOATS);
     float* xch = EX ? (float*)(flags + AACG_WG_WAVES) + wave * AACG_RUN_XCH_FLOATS : nullptr;
 
-    /* the table loads go first: everything behind them in the vector-memory queue may stay in flight
-     * while the tables are copied to LDS */
+    /* The start of a run is dependent memory round trips and nothing else (aacg_run, aacg_device.h): behind the kernel
+     * arguments ONE batch — the run record's header, the link record, the three words of the record that belong to this wave
+     * (its unit, where that unit's spectra and band words lie), and the table loads, which stay in flight across the wait —
+     * then the spectra's requests and, beside them, the unit record.  Spelled out (dp_sload / dp_swait): left to itself hipcc
+     * makes a chain of five round trips out of the same reads. */
+    dp_su8 rh = dp_sload8(run, P.tab);                 /* (the table pointer with the first batch of kernel arguments) */
+    dp_su4 lkw = dp_sload4(RV ? (const void*)(V->links + dp_block()) : (const void*)run);
+    unsigned w_unit = dp_sload1(run, (int)__builtin_offsetof(aacg_run, wave_unit) + 4 * wave);
+    unsigned w_coef = dp_sload1(run, (int)__builtin_offsetof(aacg_run, wave_coef) + 4 * wave);
+    unsigned w_meta = dp_sload1(run, (int)__builtin_offsetof(aacg_run, wave_meta) + 4 * wave);
     dpf4 tr0, tr1;
     stage_tables_load(P.tab, TAB_FLOATS, tr0, tr1);
+    dp_swait(rh, lkw, w_unit, w_coef, w_meta);
 
-    const int n_units = run->n_units;
-    const bool has_pred = !RV && run->pred_unit >= 0;
+    const int pred_unit = (int)rh[0], n_units = (int)rh[1];
+    const bool run_is_last = rh[2] != 0;
+    const int w_nch = (int)((rh[3] >> (2 * wave)) & 3u);
+    const int run_ov0[2] = {(int)rh[4], (int)rh[5]}, run_rot[2] = {(int)rh[6], (int)rh[7]};
+    const bool has_pred = !RV && pred_unit >= 0;
     aacg_rv_link lk; lk.link_in = lk.link_out = lk.succ_unit = -1; lk.reserved = 0;
-    if (RV) lk = V->links[dp_block()];
+    if (RV) { lk.link_in = (int)lkw[0]; lk.link_out = (int)lkw[1]; lk.succ_unit = (int)lkw[2]; }
     /* pipelined launches (aacg_decode_pipelined): the two ends of a chain meet the plan's neighbouring LAUNCHES in cross-launch
      * cells (aacg_xl_cell) exactly as its runs meet each other in the in-launch ones */
     const bool xl = RV && V->xl_cells != nullptr;
     /* the frame another workgroup may be waiting for: a run's last, when its chain goes on — in this launch or in the next */
     const bool hands_over = RV && wave == n_units - 1 && (lk.link_out >= 0 || xl);
-#ifdef AACG_EXP_XL_NOEARLY                               /* experiment: only the in-launch hand-overs run ahead of their group */
-    const bool hurry = RV && wave == n_units - 1 && lk.link_out >= 0;
-#else
     const bool hurry = hands_over;
-#endif
     /* this launch's overlap buffers of the run's channels (float offsets in the pool), evaluated where a chain's first or last wave needs them */
-#define AACG_OV_IN(c)  (run->ov0[c] + 1024 * ov_buffer(run->rot[c], P.flip))
-#define AACG_OV_OUT(c) (run->ov0[c] + 1024 * ov_buffer(run->rot[c], P.flip + 1))
+#define AACG_OV_IN(c)  (run_ov0[c] + 1024 * ov_buffer(run_rot[c], P.flip))
+#define AACG_OV_OUT(c) (run_ov0[c] + 1024 * ov_buffer(run_rot[c], P.flip + 1))
     /* A later run of a chain starts from the tail of the frame before it, which another workgroup owns, so it
      * recomputes that frame's IMDCT.  With up to 15 frames wave 0 does only that (waves 1.. own the frames);
      * a full run of 16 frames gives wave 0 double duty: first the predecessor (its tail goes to a scratch
-     * area in global memory), then its own frame, which takes its overlap from that scratch area. */
+     * area in global memory), then its own frame, which takes its overlap from that scratch area.
+     * (aacg_run_wave_unit is the same rule on the planner's side: wave_unit / wave_coef / wave_meta are per WAVE.) */
     const bool dd = DD && has_pred && n_units == AACG_WG_WAVES;
-    int ui = -1;
-    if (has_pred && !dd) { if (wave == 0) ui = run->pred_unit; else if (wave - 1 < n_units) ui = run->unit[wave - 1]; }
-    else                 { if (wave < n_units) ui = run->unit[wave]; }
-    ui = dp_uniform(ui);
     const bool is_pred_wave = has_pred && !dd && wave == 0;
+    const bool active = (has_pred && !dd) ? (wave == 0 || wave - 1 < n_units) : wave < n_units;     /* this wave has a frame */
     const int n_pass = (DD && dd && wave == 0) ? 2 : 1;
     float* scratch = DD ? P.scratch + (size_t)dp_block() * AACG_SLOT_FLOATS : nullptr;
 
     float hx0[8], hy0[8], hx1[8], hy1[8];
-    /* scalar loads: nothing that may clobber memory (stores, clock reads) precedes them */
-    unit_view u = load_unit(P.units + (n_pass == 2 ? run->pred_unit : (ui >= 0 ? ui : 0)));
+    /* the unit record (a wave without a frame reads unit 0's and ignores it): scalar loads — nothing that may clobber memory
+     * (stores, clock reads) precedes them — requested here, first used behind the table barrier */
+    unit_view u = load_unit(P.units + dp_uniform((int)w_unit));
     /* Earlier frames get the higher issue priority: they finish first and their PCM stores overlap
      * the later waves' arithmetic.  A wave only ever waits for the wave before it, whose priority is
      * never lower, so a spinning consumer cannot starve its producer. */
@@ -2033,10 +2040,6 @@ DP_DEVICE void imdct_run_body(const aacg_kparams& P, const aacg_rv_args* V = nul
     /* (the coupling builds carry their side buffer in spec_out, aacg_set_cpl: never a trace there) */
     unsigned long long* trace = (!CPL && AACG_ABL(P, 16)) ? (unsigned long long*)P.spec_out + ((size_t)dp_block() * AACG_WG_WAVES + wave) * 8 : nullptr;
     if (trace && lane == 0) trace[0] = t_start;
-    int n_ch = ui >= 0 ? u.n_ch : 0;
-    int cls0 = u.seq[0] == AACG_EIGHT_SHORT_SEQUENCE;
-    int cls1 = u.seq[1] == AACG_EIGHT_SHORT_SEQUENCE;
-    bool pair_path = n_ch == 2 && u.seq[0] == u.seq[1] && u.shape[0] == u.shape[1] && u.shape_prev[0] == u.shape_prev[1];
 
     /* This wave's spectrum: only the tables are waited for before the barrier.  All loads are
      * unconditional (an idle wave of a short run re-reads unit 0 and ignores it; a single channel reads
@@ -2044,11 +2047,13 @@ DP_DEVICE void imdct_run_body(const aacg_kparams& P, const aacg_rv_args* V = nul
      * serialise the HBM round trips. */
     quant_regs qreg;
     dpf4 xa[4], xb[4];
-    auto issue_loads = [&]() {
-        if (KIND == AACG_INPUT_QUANT_I16) quant_load<NTL>(P, u, u.n_ch, qreg);
+    int n_ch = 0, cls0 = 0, cls1 = 0;                  /* from the unit record, whose first use is behind the table barrier */
+    bool pair_path = false;
+    auto issue_loads = [&](uint32_t coef_block, uint32_t meta_block, int nch) {
+        if (KIND == AACG_INPUT_QUANT_I16) quant_load<NTL>(P, coef_block, meta_block, nch, qreg);
         else {
-            const float* xsrc = (const float*)P.coeffs + (size_t)u.coef_offset * 1024u;
-            const float* xsrc1 = xsrc + (u.n_ch == 2 ? 1024 : 0);
+            const float* xsrc = (const float*)P.coeffs + (size_t)coef_block * 1024u;
+            const float* xsrc1 = xsrc + (nch == 2 ? 1024 : 0);
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 if (NTL) { xa[i] = dp_load_nt((const dpf4*)(xsrc + 4 * lane + 256 * i)); xb[i] = dp_load_nt((const dpf4*)(xsrc1 + 4 * lane + 256 * i)); }
@@ -2081,12 +2086,16 @@ DP_DEVICE void imdct_run_body(const aacg_kparams& P, const aacg_rv_args* V = nul
      * its data after ~1.7 us instead of queueing behind the whole chip's 33 MB, and the later groups' data
      * arrives while the SIMD is still busy with the earlier ones. */
     const bool early = wave < (KIND == AACG_INPUT_QUANT_I16 ? 2 : 4) || hurry || AACG_ABL(P, 128);
-    if (early) issue_loads();
+    if (early) issue_loads(w_coef, w_meta, w_nch);
     stage_tables_store(lds, TAB_FLOATS, tr0, tr1);
     if (lane == 0) flags[wave] = 0;
     dp_block_sync_lds();                               /* tables and flags are in LDS */
-    if (!early) issue_loads();
+    if (!early) issue_loads(w_coef, w_meta, w_nch);
     if (trace && lane == 0) trace[1] = dp_clock();
+    n_ch = active ? u.n_ch : 0;
+    cls0 = u.seq[0] == AACG_EIGHT_SHORT_SEQUENCE;
+    cls1 = u.seq[1] == AACG_EIGHT_SHORT_SEQUENCE;
+    pair_path = n_ch == 2 && u.seq[0] == u.seq[1] && u.shape[0] == u.shape[1] && u.shape_prev[0] == u.shape_prev[1];
 
     /* dequantise / stage this wave's loaded spectrum and run the filterbank on it: tails into the slot, the
      * windowed first half into hx / hy */
@@ -2164,19 +2173,19 @@ DP_DEVICE void imdct_run_body(const aacg_kparams& P, const aacg_rv_args* V = nul
         filter_unit<AACG_VM_KIND(KIND)>(tab, u, n_ch, pair_path, want_head, slot, hx0, hy0, hx1, hy1);
     };
 
-    if (ui >= 0) front(!is_pred_wave && n_pass == 1);
+    if (active) front(!is_pred_wave && n_pass == 1);
     if (DD && n_pass == 2) {
         /* double duty (cold: only the first wave of a full later run): park the predecessor's tails, then fetch
          * and process this wave's own frame with a second copy of the code above */
         dp_keep_branch();
         dp_wave_sync();
         save_tails(scratch, scratch + 1024);
-        u = load_unit(P.units + ui);
+        u = load_unit(P.units + dp_uniform(run->unit[0]));
         n_ch = u.n_ch;
         cls0 = u.seq[0] == AACG_EIGHT_SHORT_SEQUENCE;
         cls1 = u.seq[1] == AACG_EIGHT_SHORT_SEQUENCE;
         pair_path = n_ch == 2 && u.seq[0] == u.seq[1] && u.shape[0] == u.shape[1] && u.shape_prev[0] == u.shape_prev[1];
-        issue_loads();
+        issue_loads(u.coef_offset, u.meta_offset, u.n_ch);
         dp_wave_sync();                                /* the slot is free again */
         front(true);
     }
@@ -2188,13 +2197,13 @@ DP_DEVICE void imdct_run_body(const aacg_kparams& P, const aacg_rv_args* V = nul
 
     typedef typename pcm_elem<OUT>::type pcm_t;
     const unsigned long long rv_tag = RV ? V->epoch << 2 : 0ull;
-    if (RV && hands_over && ui >= 0) {
+    if (RV && hands_over && active) {
         /* the chain goes on in another workgroup: publish this frame's tails — or, if that workgroup was here first and left
          * its windowed first half, finish its frame (nobody waits for anybody: no dispatch order is assumed).  `cross`: the
          * other workgroup belongs to the plan's NEXT launch; the tails then land in the out overlap buffer itself */
         dp_keep_branch();
         const bool cross = lk.link_out < 0;
-        aacg_xl_cell* cell = cross ? V->xl_cells + ((run->ov0[0] >> 10) + ov_buffer(run->rot[0], P.flip + 1)) : nullptr;
+        aacg_xl_cell* cell = cross ? V->xl_cells + ((run_ov0[0] >> 10) + ov_buffer(run_rot[0], P.flip + 1)) : nullptr;
         float* data = cross ? nullptr : V->data + (size_t)lk.link_out * AACG_RV_DATA_FLOATS;
         unsigned long long* st = cross ? &cell->state : V->state + (size_t)lk.link_out * AACG_RV_STATE_WORDS;
         float* t0 = cross ? P.overlap + AACG_OV_OUT(0) : data;
@@ -2225,13 +2234,13 @@ DP_DEVICE void imdct_run_body(const aacg_kparams& P, const aacg_rv_args* V = nul
         }
     }
 
-    if (ui >= 0 && !is_pred_wave && AACG_ABL(P, 2)) {
+    if (active && !is_pred_wave && AACG_ABL(P, 2)) {
         /* profiling: keep the values live without storing 8 KiB of PCM */
         float acc = 0.0f;
 #pragma unroll
         for (int m = 0; m < 8; m++) acc += hx0[m] + hy0[m] + hx1[m] + hy1[m];
         if (acc == 123456.789f) P.pcm[0] = acc;
-    } else if (ui >= 0 && !is_pred_wave) {
+    } else if (active && !is_pred_wave) {
         /* the long paths of the int16 seam deal their columns out by long_col (filter_unit<VM>) */
         const int lcol = AACG_VM_KIND(KIND) ? long_col(lane) : lane;
         if (wave == 0) {
@@ -2247,7 +2256,7 @@ DP_DEVICE void imdct_run_body(const aacg_kparams& P, const aacg_rv_args* V = nul
                 /* the tails the run before it published — or, if they are not there yet, leave the windowed first half for that
                  * run (and, across launches, where the finished samples go) and go */
                 dp_keep_branch();
-                aacg_xl_cell* cell = cross ? V->xl_cells + ((run->ov0[0] >> 10) + ov_buffer(run->rot[0], P.flip)) : nullptr;
+                aacg_xl_cell* cell = cross ? V->xl_cells + ((run_ov0[0] >> 10) + ov_buffer(run_rot[0], P.flip)) : nullptr;
                 float* data = cross ? nullptr : V->data + (size_t)lk.link_in * AACG_RV_DATA_FLOATS;
                 unsigned long long* st = cross ? &cell->state : V->state + (size_t)lk.link_in * AACG_RV_STATE_WORDS;
                 const float* t0 = cross ? P.overlap + AACG_OV_IN(0) : data;
@@ -2282,8 +2291,12 @@ DP_DEVICE void imdct_run_body(const aacg_kparams& P, const aacg_rv_args* V = nul
         if (trace && lane == 0) trace[5] = dp_clock();     /* PCM stores issued */
         /* the chain's last frame in this launch: its tail is the new overlap state (planar in HBM) */
         const int last_wave = (has_pred && !dd) ? n_units : n_units - 1;
-        if (wave == last_wave && run->is_last && !xl)      /* (pipelined: the hand-over above has put it there, or the next launch has taken it) */
+        if (wave == last_wave && run_is_last && !xl)      /* (pipelined: the hand-over above has put it there, or the next launch has taken it) */
             save_tails(P.overlap + AACG_OV_OUT(0), P.overlap + AACG_OV_OUT(1));
+    }
+    if (trace) {                                           /* profiling: when this wave's stores were acknowledged (a wave ends no earlier), and on which CU it ran */
+        dp_vm_drain();
+        if (lane == 0) trace[7] = ((unsigned long long)dp_cu_id() << 52) | (dp_clock() & 0xfffffffffffffull);
     }
 }
 
@@ -2320,7 +2333,7 @@ DP_DEVICE void spectral_ex_body(const aacg_kparams& P, int n_units)
     float xl[16], xr[16];
     if (KIND == AACG_INPUT_QUANT_I16) {
         quant_regs qreg;
-        quant_load(P, u, n_ch, qreg);
+        quant_load(P, u.coef_offset, u.meta_offset, n_ch, qreg);
         spectral_quant<true>(P, tab, u, n_ch, qreg, slot, xl, xr);
     } else {
         const float* x0 = (const float*)P.coeffs + (size_t)u.coef_offset * 1024u;
@@ -2434,7 +2447,7 @@ DP_DEVICE void spectral_body(const aacg_kparams& P, int n_units)
     const int n_ch = u.n_ch;
     float xl[16], xr[16];
     quant_regs qreg;
-    quant_load(P, u, n_ch, qreg);
+    quant_load(P, u.coef_offset, u.meta_offset, n_ch, qreg);
     spectral_quant(P, tab, u, n_ch, qreg, bt, xl, xr);
     float* out = P.spec_out + (size_t)u.coef_offset * 1024u;
 #pragma unroll

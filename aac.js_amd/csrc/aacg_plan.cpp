@@ -135,6 +135,25 @@ static uint32_t group_map(const aacg_chan_info& ci)
     return gmap;
 }
 
+
+/* Every run table's per-wave copies of where its units' spectra lie (aacg_run.wave_*): after the tables are made, and again
+ * whenever unit records are rewritten with other block offsets. */
+void aacg_plan_fill_run_waves(aacg_plan_host* h)
+{
+    for (std::vector<aacg_run>* tab : {&h->runs, &h->runs_rv, &h->cce_runs})
+        for (aacg_run& r : *tab) {
+            r.wave_nch = 0;
+            for (int w = 0; w < AACG_RUN_W; w++) {
+                const int32_t ui = aacg_run_wave_unit(r, w);
+                const aacg_unit_desc& d = h->units[ui >= 0 ? (size_t)ui : 0].d;
+                r.wave_unit[w] = ui >= 0 ? ui : 0;
+                r.wave_coef[w] = d.coef_offset;
+                r.wave_meta[w] = d.meta_offset;
+                r.wave_nch |= (uint32_t)(d.n_ch & 3) << (2 * w);
+            }
+        }
+}
+
 /* A kept plan takes the next batch's unit records: same streams, frames, elements and PCM positions (that is what the run
  * tables were built from), new window info, flags and block offsets.  What the host pays per batch is this loop and a
  * copy of the records instead of aacg_plan_build (27 ns per unit) — for callers that keep spectra on the device and
@@ -165,8 +184,10 @@ int aacg_plan_refresh_host(aacg_plan_host* h, const aacg_unit_desc* units, uint3
         coef_blocks = std::max(coef_blocks, u.coef_offset + u.n_ch);
         meta_blocks = std::max(meta_blocks, u.meta_offset + u.n_ch);
     }
+    bool moved = false;
     for (uint32_t i = 0; i < n_units; i++) {               /* nothing is touched before the whole batch has passed */
         aacg_dev_unit& du = h->units[i];
+        moved = moved || du.d.coef_offset != units[i].coef_offset || du.d.meta_offset != units[i].meta_offset;
         du.d = units[i];
         for (int c = 0; c < 2; c++) {
             du.gmap[c] = c < du.d.n_ch ? group_map(du.d.ch[c]) : 0;
@@ -174,6 +195,9 @@ int aacg_plan_refresh_host(aacg_plan_host* h, const aacg_unit_desc* units, uint3
         }
     }
     h->coef_blocks = coef_blocks; h->meta_blocks = meta_blocks;
+    /* the run tables carry copies of the block offsets (aacg_run.wave_coef / wave_meta): a batch laid out otherwise takes new ones */
+    h->runs_moved = moved;
+    if (moved) aacg_plan_fill_run_waves(h);
     return AACG_OK;
 }
 
@@ -397,7 +421,6 @@ int aacg_plan_build(const aacg_unit_desc* units, uint32_t n_units, int sample_in
             if (pos && r.n_units == AACG_RUN_W) out->needs_scratch = true;
             pos += (size_t)r.n_units;
             r.is_last = pos >= n ? 1 : 0;
-            r.reserved = 0;
             (oc.is_cce ? cce_gen : gen).push_back(r);
         }
         ch.n_runs = oc.is_cce ? 0 : (uint32_t)gen.size() - ch.first_run;
@@ -418,7 +441,6 @@ int aacg_plan_build(const aacg_unit_desc* units, uint32_t n_units, int sample_in
                 }
                 const bool more = pos + AACG_RUN_W < n;
                 r.is_last = more ? 0 : 1;
-                r.reserved = 0;
                 aacg_rv_link lk;
                 lk.link_in = link;
                 link = more ? (int32_t)out->n_links_rv++ : -1;
@@ -486,6 +508,7 @@ int aacg_plan_build(const aacg_unit_desc* units, uint32_t n_units, int sample_in
         }
     }
     out->cce_runs = cce_gen;
+    aacg_plan_fill_run_waves(out);
     /* chain.first_run refers to generation order; the engine only needs counts, keep as is */
     return AACG_OK;
 }

@@ -82,3 +82,19 @@ std::string aacg_route_names(const aacg_route& r, bool any_tns)
     if (r.couple_pcm) add("aacg_couple_pcm");
     return s;
 }
+
+aacg_pipe_order aacg_pipeline_order(uint64_t n)
+{
+    static_assert(AACG_PIPE_DEPTH % AACG_PIPE_MARK == 0 && AACG_PIPE_RING > AACG_PIPE_DEPTH / AACG_PIPE_MARK, "the round waited for is a marked one whose events are still kept");
+    /* the last launch enqueued before the next wait is AACG_PIPE_STREAMS * (check + AACG_PIPE_MARK) - 1 and knows everything up to
+     * AACG_PIPE_STREAMS * (check - AACG_PIPE_DEPTH) + AACG_PIPE_STREAMS - 1 complete: the distance must stay below the buffers */
+    static_assert(AACG_PIPE_STREAMS * (AACG_PIPE_MARK + AACG_PIPE_DEPTH) - AACG_PIPE_STREAMS <= AACG_OV_BUFFERS - 1, "a launch could start before one whose overlap buffers it reuses has finished");
+    aacg_pipe_order o;
+    const uint64_t round = n / AACG_PIPE_STREAMS, pos = n % AACG_PIPE_STREAMS;
+    o.stream = (int)pos;
+    o.marked = round % AACG_PIPE_MARK == 0;
+    const uint64_t check = round - round % AACG_PIPE_MARK;            /* the most recent round that began with a wait */
+    o.sync_round = (pos == 0 && round == check && check >= AACG_PIPE_DEPTH) ? (int64_t)(check - AACG_PIPE_DEPTH) : -1;
+    o.complete_upto = check >= AACG_PIPE_DEPTH ? (int64_t)((check - AACG_PIPE_DEPTH) * AACG_PIPE_STREAMS + AACG_PIPE_STREAMS - 1) : -1;
+    return o;
+}

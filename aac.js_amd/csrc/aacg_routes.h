@@ -62,6 +62,24 @@ aacg_route aacg_pick_route(int input_kind, int output_kind, int debug_route, boo
 std::string aacg_run_kernel_name(unsigned key);
 /* the launches of a route by kernel name, " + " between them: what a rocprofv3 kernel trace of the batch shows */
 std::string aacg_route_names(const aacg_route& r, bool any_tns);
+
+/* How the n-th launch of a pipelined sequence (aacg_decode_pipelined) is ordered against the ones before it: the ONE place the
+ * rule lives — the engine issues by it, the lane emulator schedules workgroups by it, tests/test_routes.py walks it and checks
+ * that it keeps every launch behind all launches up to n - AACG_OV_BUFFERS + 1 (aacg_device.h).
+ * Launches go to AACG_PIPE_STREAMS streams in turn (a ROUND = one launch per stream).  The launches of every AACG_PIPE_MARK-th
+ * round carry a completion event; before the host enqueues the first launch of such a round it WAITS (host side, no packet in
+ * any GPU queue) for the events of the round AACG_PIPE_DEPTH rounds back — a stream's launch complete means its earlier ones are,
+ * so everything up to that round's end is complete before anything of this round and the next AACG_PIPE_MARK - 1 exists. */
+#define AACG_PIPE_MARK  2
+#define AACG_PIPE_DEPTH 4
+struct aacg_pipe_order {
+    int     stream;                   /* which of the AACG_PIPE_STREAMS internal streams: in-order behind its earlier launches */
+    int64_t sync_round;               /* the host waits for this round's events before enqueuing launch n, or -1 */
+    bool    marked;                   /* its completion gets an event (slot: round / AACG_PIPE_MARK mod AACG_PIPE_RING, stream) */
+    int64_t complete_upto;            /* every launch up to this one is KNOWN complete when launch n is enqueued, or -1 */
+};
+#define AACG_PIPE_RING  4             /* marked rounds whose events are kept: > AACG_PIPE_DEPTH / AACG_PIPE_MARK */
+aacg_pipe_order aacg_pipeline_order(uint64_t n);
 #endif
 
 #endif

@@ -266,6 +266,35 @@ DP_DEVICE dp_u64 dp_first_u64(dp_u64 v)
     return ((dp_u64)hi << 32) | lo;
 }
 
+/* which CU of the chip this wave runs on (profiling): XCC_ID[3:0] above HW_ID's SE_ID / SH_ID / CU_ID fields (bits 14:8) */
+DP_DEVICE unsigned dp_cu_id()
+{
+    unsigned hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    return ((xcc & 15u) << 7) | ((hw >> 8) & 0x7fu);
+}
+/* Scalar loads issued where the SOURCE says, and waited for where the source says.  hipcc turns uniform reads of read-only
+ * memory into s_load by itself, but it decides the order: a prologue's loads come out as a chain — load, wait, use, next load —
+ * even where they are independent (every result's first use gets its own s_waitcnt lgkmcnt(0), and loads are not hoisted above
+ * it).  A run kernel's start is nothing BUT dependent round trips (aacg_run, aacg_device.h), so there the batch is spelled
+ * out: dp_sload*() issue, dp_swait() is the one wait, and its in/out operands keep every use of the results behind it.
+ * No memory clobber anywhere: that would turn the compiler's own later uniform reads into vector loads. */
+typedef unsigned dp_su2 __attribute__((ext_vector_type(2)));
+typedef unsigned dp_su4 __attribute__((ext_vector_type(4)));
+typedef unsigned dp_su8 __attribute__((ext_vector_type(8)));
+/* (not `volatile`, which would count as a clobber of memory — see above; their outputs feed dp_swait, which keeps them in place) */
+DP_DEVICE unsigned dp_sload1(const void* p, int byte_off) { unsigned r; asm("s_load_dword %0, %1, %2" : "=s"(r) : "s"(p), "s"(byte_off)); return r; }
+DP_DEVICE dp_su4 dp_sload4(const void* p) { dp_su4 r; asm("s_load_dwordx4 %0, %1, 0x0" : "=s"(r) : "s"(p)); return r; }
+DP_DEVICE dp_su8 dp_sload8(const void* p) { dp_su8 r; asm("s_load_dwordx8 %0, %1, 0x0" : "=s"(r) : "s"(p)); return r; }
+DP_DEVICE void dp_swait(dp_su8& a, dp_su4& b, unsigned& c, unsigned& d, unsigned& e)
+{
+    asm("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b), "+s"(c), "+s"(d), "+s"(e));
+}
+/* `also`: a pointer the batch does not read but that must have ARRIVED by now — the compiler fetches kernel arguments lazily,
+ * one first used behind a batch would be fetched behind it, a round trip later */
+DP_DEVICE dp_su8 dp_sload8(const void* p, const void* also) { dp_su8 r; asm("s_load_dwordx8 %0, %1, 0x0" : "=s"(r) : "s"(p), "s"(also)); return r; }
+
 /* true in every lane if the predicate holds in any lane of the wave */
 /* LDS bump allocation: returns the old value */
 DP_DEVICE int dp_lds_atomic_add(int* p, int v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }

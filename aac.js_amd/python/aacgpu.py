@@ -31,7 +31,8 @@ ABI_SYMBOLS = ["aacg_create", "aacg_destroy", "aacg_last_error", "aacg_abi_versi
                "aacg_pipeline_create", "aacg_pipeline_destroy", "aacg_pipeline_last_error", "aacg_pipeline_reset_stream", "aacg_pipeline_decode"]
 # ... and include/aacgpu_tools.h (measurement and diagnostics: bench.py, tools/, tests)
 TOOLS_SYMBOLS = ["aacg_calib_copy", "aacg_timer_create", "aacg_timer_record", "aacg_timer_elapsed_ms", "aacg_timer_destroy",
-                 "aacg_pipeline_chained", "aacg_pipeline_concurrent", "aacg_decode_pipelined_timed", "aacg_debug_transform", "aacg_debug_set_route", "aacg_debug_route", "aacg_debug_run_kernel"]
+                 "aacg_pipeline_chained", "aacg_pipeline_concurrent", "aacg_decode_pipelined_timed", "aacg_debug_transform", "aacg_debug_set_route", "aacg_debug_route", "aacg_debug_run_kernel",
+                 "aacg_debug_pipeline_order"]
 # aacg_debug_set_route / aacg_debug_route flags
 DEBUG_ROUTE_UNFUSED_COUPLING, DEBUG_ROUTE_RECOMPUTE = 1, 8
 ROUTE_PLAN_TNS, ROUTE_PLAN_PNS, ROUTE_PLAN_LONG_CHAINS, ROUTE_PLAN_FULL_LATER_RUNS = 1, 2, 4, 8
@@ -262,6 +263,20 @@ def run_kernels():
             return out
         out[buf.value.decode()] = key
         i += 1
+
+
+PIPE_STREAMS = 3        # AACG_PIPE_STREAMS: launches of a pipelined sequence that may be in flight side by side (aacg_device.h)
+
+
+def pipeline_order(n):
+    """How launch n of a pipelined sequence is ordered (aacg_pipeline_order, aacg_routes.cpp): (stream, the round whose completion
+    events the host waits for before enqueuing it or -1, whether its own completion gets an event, the launch up to which
+    everything is known complete when it is enqueued or -1, number of rotating overlap buffers the rule has to cover)."""
+    lib = load_library()
+    lib.aacg_debug_pipeline_order.argtypes = [C.c_ulonglong, C.POINTER(C.c_int), C.POINTER(C.c_longlong), C.POINTER(C.c_int), C.POINTER(C.c_longlong)]
+    st, w, m, u = C.c_int(), C.c_longlong(), C.c_int(), C.c_longlong()
+    k = lib.aacg_debug_pipeline_order(n, C.byref(st), C.byref(w), C.byref(m), C.byref(u))
+    return st.value, w.value, bool(m.value), u.value, k
 
 
 def calib_copy(d_dst, d_src, n_bytes, stream=0):

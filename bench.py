@@ -348,12 +348,12 @@ def main():
             return self.ev.elapsed_time(later.ev) if args.default_events else self.ev.elapsed_ms(later.ev)
     evs = [_Mark() for _ in range(R + 1)]
     issued = [0.0]
-    # Pipelined launches: a repeat ends when its last launch AND the one before it (which runs beside it on the other stream) are
+    # Pipelined launches: a repeat ends when its last launch AND the ones that run beside it on the other streams are
     # complete.  Their marks are bound to the dispatches themselves (aacg_decode_pipelined_timed: the time stamp is the
     # dispatch's end, no marker packet enters a queue, nothing is joined inside the timed region); the opening mark is an
     # ordinary one on the timing stream, joined behind the warm-up steps.
     bound = pipelined and not args.default_events
-    tails = [[aacgpu.TimerMark() for _ in range(min(2, args.steps))] for _ in range(R)] if bound else None
+    tails = [[aacgpu.TimerMark() for _ in range(min(aacgpu.PIPE_STREAMS, args.steps))] for _ in range(R)] if bound else None
 
     def timed_steps():
         t0 = time.perf_counter()
@@ -361,7 +361,7 @@ def main():
         evs[0].record()
         for r in range(R):
             for i in range(args.steps):
-                k = args.steps - 1 - i                   # 0 for the repeat's last launch, 1 for the one before it
+                k = args.steps - 1 - i                   # 0 for the repeat's last launch, 1 for the one before it, ...
                 step(n_pre + args.warmup + r * args.steps + i, tails[r][k] if bound and k < len(tails[r]) else None)
             if not bound:
                 join()                                   # a mark's time stamp is the completion of every launch before it
@@ -435,8 +435,8 @@ def main():
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "timing": dict(stats, events=("torch.cuda.Event (default HIP events: a system-scope fence per record)" if args.default_events else
                                       "hipEventDisableSystemFence (timing-only HIP events, aacg_timer_*)"),
-                       method=("the K timed steps are run R times back to back; a repeat ends when its last two launches (which run side by "
-                               "side on the engine's two streams) are both complete — HIP events bound to those dispatches' completion "
+                       method=("the K timed steps are run R times back to back; a repeat ends when its last three launches (which run side by "
+                               "side on the engine's three streams) are all complete — HIP events bound to those dispatches' completion "
                                "(hipExtLaunchKernel stopEvent), the opening event on the timing stream behind the warm-up steps" if bound else
                                "the K timed steps are run R times back to back, each repeat between its own HIP events on the launch stream") +
                               " (MAX over ranks per repeat); value and ms_per_step: the MEDIAN repeat; wall_*: host clock between "
@@ -452,9 +452,9 @@ def main():
                    "output": "float32 PCM as the reference returns it" if args.output == "f32" else "int16 PCM (AACG_OUTPUT_I16)",
                    "streams_per_gpu": n_streams, "frames_per_stream_per_step": n_frames, "buffers_rotated": args.nbuf,
                    "realtime_multiple": value / 46.875, "sharding": "streams over ranks, no data-path collective", "pipelines": args.pipelines,
-                   "launches": ("aacg_decode_pipelined: ONE plan, the same %d streams continued launch after launch on the engine's two internal HIP "
+                   "launches": ("aacg_decode_pipelined: ONE plan, the same %d streams continued launch after launch on the engine's three internal HIP "
                                 "streams taken in turn; consecutive launches overlap, their chains meet in rendezvous cells (nobody waits); %d of the %d "
-                                "launches of this process continued the launch before them; the two streams were %s" % (n_streams, eng.pipeline_chained(), n_pre + args.warmup + R * args.steps + (0 if args.no_parity else 1),
+                                "launches of this process continued the launch before them; the streams were %s" % (n_streams, eng.pipeline_chained(), n_pre + args.warmup + R * args.steps + (0 if args.no_parity else 1),
                                    "seen to run side by side when the pipeline was set up" if eng.pipeline_concurrent() else "NOT seen to run side by side (one hardware queue): the launches serialise"))
                                if pipelined else "aacg_decode_device: every launch behind the one before it on one HIP stream",
                    "preconditioning": "%d untimed steps (%.0f ms of load) before the warm-up steps: steady GPU clocks" % (n_pre, args.precondition_ms),

@@ -474,11 +474,12 @@ const char* aacg_parse_kernel_name(void);
 
 /* Parser -> transform without the host in between.  A plan's run tables depend on which streams bring how many frames
  * of which element layout, not on what the frames contain; batch after batch of the same streams can therefore keep
- * ONE plan (built once from unit records that carry the structure: stream, pcm_offset, channel, n_out_ch, n_ch) and
- * have its device unit records rewritten from aacg_parse_device's output: window info, flags and the coef / meta
- * offsets come from d_parsed_units (plan unit i <- parsed record i, so the plan's units must be listed frame by frame
+ * ONE plan (built once from unit records that carry the structure: stream, pcm_offset, channel, n_out_ch, n_ch and the
+ * coef / meta block offsets aacg_parse_device will use: block = frame * max_channels + channel) and
+ * have its device unit records rewritten from aacg_parse_device's output: window info and flags
+ * come from d_parsed_units (plan unit i <- parsed record i, so the plan's units must be listed frame by frame
  * with max_units per frame), the rest stays.  A frame the parser refused, an element that is not the one the plan
- * expects, or a unit with noise bands (their stage is chosen when a plan is built) becomes a silent unit and is counted in *d_refused (device
+ * expects (other channels, other blocks), or a unit with noise bands (their stage is chosen when a plan is built) becomes a silent unit and is counted in *d_refused (device
  * counter, caller zeroes it).  Asynchronous on hip_stream; follow with aacg_decode_device on the same stream.
  * QUANT_I16 engines with AACG_TNS_REFERENCE only (TNS records are prepared on the host).                      */
 int aacg_plan_refresh_from_parse(aacg_engine* e, aacg_plan* p, const aacg_unit_desc* d_parsed_units,

@@ -339,8 +339,8 @@ int emu_decode_pipelined(int input_kind, int sample_index, int max_streams, int 
     if (!R.overlappable) { g_err = "not a plain batch"; return AACG_ERR_UNSUPPORTED; }
     static unsigned long long epoch = 5000;
     const size_t cells = (size_t)ph.n_links_rv;
-    std::vector<unsigned long long> rv_state(2 * cells * AACG_RV_STATE_WORDS + 1, 0x5a5a5a5a5a5a5a5aull);
-    std::vector<float> rv_data(2 * cells * AACG_RV_DATA_FLOATS + 1, std::numeric_limits<float>::quiet_NaN());
+    std::vector<unsigned long long> rv_state(AACG_PIPE_STREAMS * cells * AACG_RV_STATE_WORDS + 1, 0x5a5a5a5a5a5a5a5aull);
+    std::vector<float> rv_data(AACG_PIPE_STREAMS * cells * AACG_RV_DATA_FLOATS + 1, std::numeric_limits<float>::quiet_NaN());
     std::vector<aacg_kparams> P((size_t)n_launches);
     std::vector<aacg_rv_args> V((size_t)n_launches);
     for (int j = 0; j < n_launches; j++) {
@@ -352,8 +352,9 @@ int emu_decode_pipelined(int input_kind, int sample_index, int max_streams, int 
         aacg_rv_args& v = V[(size_t)j];
         std::memset(&v, 0, sizeof v);
         v.links = ph.links_rv.data();
-        v.state = rv_state.data() + (size_t)(j & 1) * cells * AACG_RV_STATE_WORDS;
-        v.data = rv_data.data() + (size_t)(j & 1) * cells * AACG_RV_DATA_FLOATS;
+        const size_t set = (size_t)aacg_pipeline_order((uint64_t)j).stream;      /* launches in flight together never share a set of in-launch cells */
+        v.state = rv_state.data() + set * cells * AACG_RV_STATE_WORDS;
+        v.data = rv_data.data() + set * cells * AACG_RV_DATA_FLOATS;
         v.epoch = ++epoch;
         v.xl_cells = (aacg_xl_cell*)xl_cells; v.xl_head = xl_head;
         v.epoch_in = j ? V[(size_t)j - 1].epoch : first_epoch_in;
@@ -363,17 +364,17 @@ int emu_decode_pipelined(int input_kind, int sample_index, int max_streams, int 
     if (order == 0) {
         for (int j = 0; j < n_launches; j++) for (int b = 0; b < B; b++) sched.emplace_back(j, b);
     } else if (order == 1) {
-        for (int j = 0; j < n_launches; j += 2) {
-            if (j + 1 < n_launches) for (int b = 0; b < B; b++) sched.emplace_back(j + 1, b);
-            for (int b = 0; b < B; b++) sched.emplace_back(j, b);
-        }
+        /* as late as the streams allow: of every AACG_PIPE_STREAMS consecutive launches the last one first */
+        for (int j = 0; j < n_launches; j += AACG_PIPE_STREAMS)
+            for (int k = AACG_PIPE_STREAMS - 1; k >= 0; k--)
+                if (j + k < n_launches) for (int b = 0; b < B; b++) sched.emplace_back(j + k, b);
     } else {
-        /* the engine's ordering rules, exactly (aacg_decode_pipelined): launch j goes to stream j & 1, so it starts after launch
-         * j - 2 is complete; every q-th launch of a stream also waits for launch j - 3, q = (AACG_OV_BUFFERS - 1) / 2.  Among the
-         * launches those rules allow to run, the next workgroup is drawn at random, in each launch's own shuffled block order */
+        /* the engine's ordering rules, exactly (aacg_pipeline_order, aacg_routes.cpp): launch j goes to stream j mod
+         * AACG_PIPE_STREAMS, so it starts after the launch AACG_PIPE_STREAMS before it is complete, and it does not exist before
+         * the launches the host waits for are complete.  Among the launches those rules allow to run, the next workgroup is drawn at random, in each launch's
+         * own shuffled block order */
         uint32_t rng = (uint32_t)order * 2654435761u + 12345u;
         auto next = [&]() { rng ^= rng << 13; rng ^= rng >> 17; rng ^= rng << 5; return rng; };
-        const int q = (AACG_OV_BUFFERS - 1) / 2;
         std::vector<std::vector<int>> left((size_t)n_launches);
         for (int j = 0; j < n_launches; j++) {
             for (int b = 0; b < B; b++) left[(size_t)j].push_back(b);
@@ -384,8 +385,11 @@ int emu_decode_pipelined(int input_kind, int sample_index, int max_streams, int 
         while (remaining) {
             std::vector<int> ready;
             for (int j = 0; j < n_launches; j++) {
-                if (left[(size_t)j].empty() || !done(j - 2)) continue;
-                if (j >= 3 && ((j >> 1) % q) == 0 && !done(j - 3)) continue;
+                const aacg_pipe_order o = aacg_pipeline_order((uint64_t)j);
+                if (left[(size_t)j].empty() || !done(j - AACG_PIPE_STREAMS)) continue;
+                bool known = true;                          /* the host enqueues it only after everything up to complete_upto is complete */
+                for (int m = 0; m <= (int)o.complete_upto && known; m++) known = done(m);
+                if (!known) continue;
                 ready.push_back(j);
             }
             const int j = ready[next() % (uint32_t)ready.size()];

@@ -9,11 +9,12 @@ import numpy as np
 import orc
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-RUN_DTYPE = np.dtype([("pred_unit", "<i4"), ("n_units", "<i4"), ("unit", "<i4", (16,)),
-                      ("ov0", "<i4", (2,)), ("rot", "<i4", (2,)), ("is_last", "<i4"), ("reserved", "<i4")])
+RUN_DTYPE = np.dtype([("pred_unit", "<i4"), ("n_units", "<i4"), ("is_last", "<i4"), ("wave_nch", "<u4"),
+                      ("ov0", "<i4", (2,)), ("rot", "<i4", (2,)), ("unit", "<i4", (16,)),
+                      ("wave_unit", "<i4", (16,)), ("wave_coef", "<u4", (16,)), ("wave_meta", "<u4", (16,))])     # aacg_run, aacg_device.h
 
 
-OV_BUFFERS = 5          # AACG_OV_BUFFERS: rotating overlap buffers per channel (aacg_device.h)
+OV_BUFFERS = 16         # AACG_OV_BUFFERS: rotating overlap buffers per channel (aacg_device.h)
 
 
 def new_pool(streams, channels):

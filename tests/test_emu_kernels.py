@@ -148,6 +148,12 @@ def test_planner_runs(emu):
         assert (r["pred_unit"] == -1) == first and (first or r["pred_unit"] == ids[0] - 1)
         assert r["n_units"] <= (16 if first else 15)           # wave 0 of a later run recomputes the predecessor
         assert r["is_last"] == (ids[-1] % T == T - 1)
+        # what every WAVE of the run loads first (a later run's wave 0: the predecessor) rides in the record itself
+        waves = ([] if first else [r["pred_unit"]]) + list(ids)
+        for w in range(16):
+            ui = waves[w] if w < len(waves) else 0
+            assert r["wave_unit"][w] == ui and r["wave_coef"][w] == wl["units"][ui]["coef_offset"] and r["wave_meta"][w] == wl["units"][ui]["meta_offset"]
+            assert (r["wave_nch"] >> (2 * w)) & 3 == wl["units"][ui]["n_ch"]
     assert (seen == 1).all()
     # consecutive runs of one chain sit a multiple of 8 blocks apart (same XCD under the observed b % 8 dispatch)
     pos = {int(r["unit"][0]): i for i, r in enumerate(runs)}

@@ -88,3 +88,33 @@ def test_every_combination_of_flags_has_a_registered_kernel(engine_lib):
                 assert piped == serial
             n += 1
     assert n > 1000
+
+
+def test_pipelined_launches_stay_behind_the_launches_whose_buffers_they_reuse():
+    """aacg_pipeline_order (aacg_routes.cpp) is the one place the ordering of pipelined launches lives: the engine issues by it,
+    the emulator schedules by it.  Launch n reads overlap buffer n mod K and writes n + 1 mod K (K = AACG_OV_BUFFERS), so it
+    shares buffers and cells with launches n - K + 1, n - K, n - K - 1 (and their multiples): it has to START BEHIND every
+    launch up to n - K + 1 — through its stream (in order behind its own earlier launches) and through what the host has seen
+    complete before it enqueued it (the events of a marked round: a stream's launch complete means its earlier ones are)."""
+    N = 240
+    order = [A.pipeline_order(n) for n in range(N)]
+    K = order[0][4]
+    S = A.PIPE_STREAMS
+    assert K >= 3 and all(o[4] == K for o in order)
+    assert {o[0] for o in order} == set(range(S))
+    known = -1                                              # everything up to this launch is complete, as far as the host knows
+    for n, (st, sync_round, marked, upto, _) in enumerate(order):
+        assert st == n % S
+        if sync_round >= 0:
+            waited = [m for m in range(sync_round * S, sync_round * S + S)]
+            assert all(order[m][2] for m in waited), "the host waits for round %d, whose launches carry no events" % sync_round
+            assert {order[m][0] for m in waited} == set(range(S)) and max(waited) < n
+            known = max(waited)                             # one launch per stream complete: everything before them too
+        assert upto == known, "launch %d: the rule says everything up to %d is complete, the waits so far give %d" % (n, upto, known)
+        behind = max(known, n - S if n >= S else -1)        # plus its own stream's earlier launches, which do not help with the others
+        assert known >= n - (K - 1), "launch %d may start before launch %d is complete, whose buffers it shares (K = %d)" % (n, n - K + 1, K)
+        assert behind < n - 1 or n < 2, "a launch must be able to run beside the one before it"
+    # the streams are worth having: a launch never has to wait for the S - 1 launches before it
+    assert all(order[n][3] < n - (S - 1) for n in range(S, N))
+    # and the GPU's queues never run dry when the host comes back from a wait: at least a round is enqueued beyond what it waited for
+    assert all(n - (order[n][1] * S + S - 1) > S for n in range(N) if order[n][1] >= 0)

@@ -50,7 +50,8 @@ def _batches(S, T, layout, n, seam, oracle, seed):
 
 
 @pytest.mark.parametrize("layout,S,T,n,seam", [(("cpe",), 3, 16, 7, "q"), (("cpe",), 2, 7, 6, "f"), (("sce",), 2, 16, 4, "q"),
-                                                (("cpe",), 1, 37, 4, "q"), (("cpe", "cpe", "cpe", "sce"), 1, 5, 6, "q"), (("sce", "cpe"), 1, 18, 3, "f")])
+                                                (("cpe",), 1, 37, 4, "q"), (("cpe", "cpe", "cpe", "sce"), 1, 5, 6, "q"), (("sce", "cpe"), 1, 18, 3, "f"),
+                                                (("cpe",), 2, 3, 2 * emu_lib.OV_BUFFERS + 3, "q")])       # the rotating buffers and cells come round twice
 def test_overlapped_launches_equal_the_serialised_route_bit_for_bit(emu, oracle, layout, S, T, n, seam):
     base, C, coeffs, metas, refs, ov = _batches(S, T, layout, n, seam, oracle, 71)
     # the serialised route: one launch after the other, each from the complete state the one before left

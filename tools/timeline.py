@@ -30,7 +30,7 @@ eng.synchronize()
 raw = np.zeros(1 << 20, np.float32)
 eng._check(eng.lib.aacg_get_table(eng.handle, 100, raw.ctypes.data, raw.size))
 if PIPE:                                                                # the last launch stamped half (N - 1) & 1 of the buffer, the one before it the other
-    last, prev = raw[((N_LAUNCH - 1) & 1) << 19:][: 1 << 19], raw[((N_LAUNCH - 2) & 1) << 19:][: 1 << 19]
+    last, prev = raw[((N_LAUNCH - 1) % 3) << 18:][: 1 << 18], raw[((N_LAUNCH - 2) % 3) << 18:][: 1 << 18]     # launch n stamps part n mod AACG_PIPE_STREAMS
     tp = prev.view(np.uint64)[: 256 * 16 * 8].reshape(256, 16, 8).astype(np.float64) * 0.01
     raw = last
 NW = int(os.environ.get("TL_WAVES", str(min(16, T))))                  # waves of a workgroup that carry a frame (T / 2 for a folded chain)
@@ -51,6 +51,22 @@ if PIPE:
     print("pipelined: this launch's workgroup starts, sorted, against the previous launch's workgroup ends (stores issued), sorted: median lag %.2f us, p10 %.2f, p90 %.2f" % tuple(
         np.percentile(np.sort(sl) - np.sort(ep), q) for q in (50, 10, 90)))
     print("pipelined: start-to-start of the two launches (median workgroup): %.2f us; workgroup life (start -> last stores issued) median %.2f us" % (np.median(sl) - np.median(sp), np.median(el - sl)))
+    # the same CU, workgroup after workgroup: slot 7 = (CU id << 52) | clock when the wave's stores were acknowledged
+    rawp, rawl = prev.view(np.uint64)[: 256 * 16 * 8].reshape(256, 16, 8), last.view(np.uint64)[: 256 * 16 * 8].reshape(256, 16, 8)
+    M = (1 << 52) - 1
+    cu_p, cu_l = (rawp[:NBp, 0, 7] >> np.uint64(52)).astype(int), (rawl[:NB, 0, 7] >> np.uint64(52)).astype(int)
+    ack_p = ((rawp[:NBp, :NW, 7] & np.uint64(M)).astype(np.float64) * 0.01).max(axis=1)
+    ack_l = ((rawl[:NB, :NW, 7] & np.uint64(M)).astype(np.float64) * 0.01).max(axis=1)
+    by_cu = {int(c): i for i, c in enumerate(cu_p)}
+    rows = [(ep[by_cu[c]], ack_p[by_cu[c]], sl[i]) for i, c in enumerate(cu_l) if int(c) in by_cu]
+    if rows and len(set(cu_p.tolist())) > 1:
+        r = np.array(rows)
+        ok = r[:, 2] > r[:, 0]                          # this launch's workgroup came after the previous launch's on that CU
+        r = r[ok]
+        print("pipelined, CU by CU (%d CUs seen, %d pairs where this launch's workgroup followed the previous launch's on its CU):" % (len(set(cu_p.tolist())), len(r)))
+        print("   last stores issued -> acknowledged: median %.2f us (p10 %.2f, p90 %.2f);  acknowledged -> next workgroup's first wave: median %.2f (p10 %.2f, p90 %.2f);  together %.2f" % (
+            *(np.percentile(r[:, 1] - r[:, 0], q) for q in (50, 10, 90)), *(np.percentile(r[:, 2] - r[:, 1], q) for q in (50, 10, 90)), np.median(r[:, 2] - r[:, 0])))
+    print("this launch: last stores issued -> acknowledged, per workgroup: median %.2f us, p90 %.2f" % tuple(np.percentile(ack_l - el, q) for q in (50, 90)))
 
 # distribution over workgroups: where do the stragglers come from?
 end = t[:, :, 5].max(axis=1) - t0                     # last stores issued per workgroup
