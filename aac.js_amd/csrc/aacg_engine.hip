@@ -81,14 +81,15 @@ struct aacg_engine {
      * CUs the launches before it have left while those are still finishing, and a CU that is done with launch n + 1's workgroup
      * finds one of launch n + 2 waiting.  The chains of consecutive launches meet in cross-launch cells (aacg_xl_cell); how far
      * a launch may run ahead of the ones whose overlap buffers and cells it reuses is bounded by the HOST: it does not enqueue
-     * a round of launches before the round AACG_PIPE_DEPTH back is complete (aacg_pipeline_order, aacg_routes.cpp, is the rule in
+     * a round of launches before the round AACG_PIPE_DEPTH(streams) back is complete (aacg_pipeline_order, aacg_routes.cpp, is the rule in
      * one place; aacg_device.h has the arithmetic). */
     struct pipe_t {
         hipStream_t stream[AACG_PIPE_STREAMS] = {};
         hipEvent_t mark[AACG_PIPE_RING][AACG_PIPE_STREAMS] = {};   /* completion events of the marked rounds' launches (aacg_pipeline_order) */
         hipEvent_t tail[AACG_PIPE_STREAMS] = {};   /* joins: everything on stream k so far */
         hipEvent_t fork = nullptr;
-        uint64_t n = 0;                     /* overlappable launches issued so far (stream n mod AACG_PIPE_STREAMS, events by n) */
+        uint64_t n = 0;                     /* overlappable launches of the current sequence so far (aacg_pipeline_order(n, streams)) */
+        int streams = AACG_PIPE_STREAMS;    /* of the current sequence (aacg_pipeline_streams) */
         uint64_t issued = 0;                /* every launch through the pipeline */
         hipStream_t joined_stream = nullptr; uint64_t joined_n = ~0ull;   /* the stream most recently put behind the pipeline, and at which launch count */
         bool open = false;                  /* launches issued since the last join that nobody outside is ordered behind yet */
@@ -422,9 +423,9 @@ int aacg_debug_route(int input_kind, int output_kind, int debug_route, int plan_
     return AACG_OK;
 }
 
-int aacg_debug_pipeline_order(unsigned long long n, int* stream, long long* sync_round, int* marked, long long* complete_upto)
+int aacg_debug_pipeline_order(unsigned long long n, int streams, int* stream, long long* sync_round, int* marked, long long* complete_upto)
 {
-    const aacg_pipe_order o = aacg_pipeline_order(n);
+    const aacg_pipe_order o = aacg_pipeline_order(n, streams);
     if (stream) *stream = o.stream;
     if (sync_round) *sync_round = o.sync_round;
     if (marked) *marked = o.marked ? 1 : 0;
@@ -852,8 +853,6 @@ int aacg_decode_pipelined_timed(aacg_engine* e, aacg_plan* p, const void* d_coef
     aacg_engine::pipe_t& pp = e->pipe;
     /* a route whose launches cannot overlap (optional stages, coupling, int16 PCM: no rendezvous build) runs on the pipeline's
      * first stream, launch behind launch: the stream orders them, no event is needed between two of them */
-    const aacg_pipe_order ord = aacg_pipeline_order(pp.n);
-    hipStream_t s = R.overlappable ? pp.stream[ord.stream] : pp.stream[0];
     const bool follows = !R.overlappable && pp.open && pp.serial && pp.plan == p && p->last_pipelined && p->seen_epoch == e->epoch;
     /* Does this launch continue the one before it — same plan, nothing in between, a route whose chains meet in cells?  Then
      * the two may overlap: its input state arrives through the cross-launch cells, tagged with that launch's epoch.  Its
@@ -861,8 +860,11 @@ int aacg_decode_pipelined_timed(aacg_engine* e, aacg_plan* p, const void* d_coef
      * together every launch is behind every launch up to n - AACG_OV_BUFFERS + 1, whose buffers and cells it reuses
      * (aacg_device.h).  Otherwise it starts behind everything in flight, from complete state. */
     const bool continues = R.overlappable && pp.open && !pp.serial && pp.plan == p && p->last_pipelined && p->seen_epoch == e->epoch;
+    if (!continues) { pp.n = 0; pp.streams = aacg_pipeline_streams(p->h); }      /* a new sequence */
+    const aacg_pipe_order ord = aacg_pipeline_order(pp.n, pp.streams);
+    hipStream_t s = R.overlappable ? pp.stream[ord.stream] : pp.stream[0];
     if (continues) {
-        /* back-pressure instead of cross-stream waits: the HOST waits until the round AACG_PIPE_DEPTH back is complete — no
+        /* back-pressure instead of cross-stream waits: the HOST waits until the round AACG_PIPE_DEPTH(streams) back is complete — no
          * barrier packet enters a GPU queue (one per two launches cost the three-stream pipeline all it had gained), and the
          * queues still hold a round of launches when the host comes back */
         if (ord.sync_round >= 0)
@@ -883,7 +885,7 @@ int aacg_decode_pipelined_timed(aacg_engine* e, aacg_plan* p, const void* d_coef
     /* the host will wait for this one: its event rides on the dispatch itself where the route is a single launch
      * (no marker packet between this launch and the next of its stream), else it is recorded behind the route's last launch */
     const bool ordered = R.overlappable && ord.marked;
-    hipEvent_t const mine = pp.mark[(pp.n / AACG_PIPE_STREAMS / AACG_PIPE_MARK) % AACG_PIPE_RING][ord.stream];
+    hipEvent_t const mine = pp.mark[(pp.n / (uint64_t)pp.streams / AACG_PIPE_MARK) % AACG_PIPE_RING][ord.stream];
     hipEvent_t bound = R.rv ? (stop_mark ? (hipEvent_t)stop_mark : (ordered ? mine : nullptr)) : nullptr;
     rc = launch_run(e, R, p->d_units, p->d_runs, p->d_tns, p->d_scratch, p->d_spec, cb, rvb, p->h, d_coeffs, d_meta, d_pcm,
                     (int)(p->launches % AACG_OV_BUFFERS), s, xl, &epoch, bound);

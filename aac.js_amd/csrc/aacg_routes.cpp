@@ -83,18 +83,25 @@ std::string aacg_route_names(const aacg_route& r, bool any_tns)
     return s;
 }
 
-aacg_pipe_order aacg_pipeline_order(uint64_t n)
+aacg_pipe_order aacg_pipeline_order(uint64_t n, int streams)
 {
-    static_assert(AACG_PIPE_DEPTH % AACG_PIPE_MARK == 0 && AACG_PIPE_RING > AACG_PIPE_DEPTH / AACG_PIPE_MARK, "the round waited for is a marked one whose events are still kept");
-    /* the last launch enqueued before the next wait is AACG_PIPE_STREAMS * (check + AACG_PIPE_MARK) - 1 and knows everything up to
-     * AACG_PIPE_STREAMS * (check - AACG_PIPE_DEPTH) + AACG_PIPE_STREAMS - 1 complete: the distance must stay below the buffers */
-    static_assert(AACG_PIPE_STREAMS * (AACG_PIPE_MARK + AACG_PIPE_DEPTH) - AACG_PIPE_STREAMS <= AACG_OV_BUFFERS - 1, "a launch could start before one whose overlap buffers it reuses has finished");
+    const uint64_t S = (uint64_t)(streams < 1 ? 1 : (streams > AACG_PIPE_STREAMS ? AACG_PIPE_STREAMS : streams));
+    const uint64_t depth = AACG_PIPE_DEPTH(S);
+    static_assert(AACG_PIPE_DEPTH(1) / AACG_PIPE_MARK < AACG_PIPE_RING && AACG_PIPE_DEPTH(AACG_PIPE_STREAMS) >= AACG_PIPE_MARK, "the round waited for is a marked one whose events are still kept");
+    static_assert(AACG_PIPE_STREAMS * (AACG_PIPE_MARK + AACG_PIPE_DEPTH(AACG_PIPE_STREAMS)) - AACG_PIPE_STREAMS <= AACG_OV_BUFFERS - 1 &&
+                  2 * (AACG_PIPE_MARK + AACG_PIPE_DEPTH(2)) - 2 <= AACG_OV_BUFFERS - 1 && (AACG_PIPE_MARK + AACG_PIPE_DEPTH(1)) - 1 <= AACG_OV_BUFFERS - 1,
+                  "a launch could start before one whose overlap buffers it reuses has finished");
     aacg_pipe_order o;
-    const uint64_t round = n / AACG_PIPE_STREAMS, pos = n % AACG_PIPE_STREAMS;
+    const uint64_t round = n / S, pos = n % S;
     o.stream = (int)pos;
     o.marked = round % AACG_PIPE_MARK == 0;
     const uint64_t check = round - round % AACG_PIPE_MARK;            /* the most recent round that began with a wait */
-    o.sync_round = (pos == 0 && round == check && check >= AACG_PIPE_DEPTH) ? (int64_t)(check - AACG_PIPE_DEPTH) : -1;
-    o.complete_upto = check >= AACG_PIPE_DEPTH ? (int64_t)((check - AACG_PIPE_DEPTH) * AACG_PIPE_STREAMS + AACG_PIPE_STREAMS - 1) : -1;
+    o.sync_round = (pos == 0 && round == check && check >= depth) ? (int64_t)(check - depth) : -1;
+    o.complete_upto = check >= depth ? (int64_t)((check - depth) * S + S - 1) : -1;
     return o;
+}
+
+int aacg_pipeline_streams(const aacg_plan_host& h)
+{
+    return h.runs_rv.size() > 512 ? 2 : AACG_PIPE_STREAMS;
 }

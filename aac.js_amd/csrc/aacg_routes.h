@@ -66,20 +66,30 @@ std::string aacg_route_names(const aacg_route& r, bool any_tns);
 /* How the n-th launch of a pipelined sequence (aacg_decode_pipelined) is ordered against the ones before it: the ONE place the
  * rule lives — the engine issues by it, the lane emulator schedules workgroups by it, tests/test_routes.py walks it and checks
  * that it keeps every launch behind all launches up to n - AACG_OV_BUFFERS + 1 (aacg_device.h).
- * Launches go to AACG_PIPE_STREAMS streams in turn (a ROUND = one launch per stream).  The launches of every AACG_PIPE_MARK-th
+ * Launches go to `streams` streams in turn (a ROUND = one launch per stream; aacg_pipeline_streams picks 2 or AACG_PIPE_STREAMS for a
+ * sequence).  The launches of every AACG_PIPE_MARK-th
  * round carry a completion event; before the host enqueues the first launch of such a round it WAITS (host side, no packet in
- * any GPU queue) for the events of the round AACG_PIPE_DEPTH rounds back — a stream's launch complete means its earlier ones are,
+ * any GPU queue) for the events of the round AACG_PIPE_DEPTH(streams) rounds back — a stream's launch complete means its earlier ones are,
  * so everything up to that round's end is complete before anything of this round and the next AACG_PIPE_MARK - 1 exists. */
 #define AACG_PIPE_MARK  2
-#define AACG_PIPE_DEPTH 4
+/* rounds between the one the host waits for and the one it is about to enqueue: as many as the buffers allow (the deeper, the
+ * longer the host may be away before a queue runs dry) — the last launch enqueued before the next wait is
+ * S (check + AACG_PIPE_MARK) - 1, everything up to S (check - depth) + S - 1 is known complete, and the distance must stay
+ * below AACG_OV_BUFFERS: S (AACG_PIPE_MARK + depth) - S <= AACG_OV_BUFFERS - 1; even, so that the round is a marked one */
+#define AACG_PIPE_DEPTH(S) ((((AACG_OV_BUFFERS - 1 + (S)) / (S) - AACG_PIPE_MARK) / AACG_PIPE_MARK) * AACG_PIPE_MARK)
 struct aacg_pipe_order {
-    int     stream;                   /* which of the AACG_PIPE_STREAMS internal streams: in-order behind its earlier launches */
+    int     stream;                   /* which of the internal streams: in-order behind its earlier launches */
     int64_t sync_round;               /* the host waits for this round's events before enqueuing launch n, or -1 */
     bool    marked;                   /* its completion gets an event (slot: round / AACG_PIPE_MARK mod AACG_PIPE_RING, stream) */
     int64_t complete_upto;            /* every launch up to this one is KNOWN complete when launch n is enqueued, or -1 */
 };
-#define AACG_PIPE_RING  4             /* marked rounds whose events are kept: > AACG_PIPE_DEPTH / AACG_PIPE_MARK */
-aacg_pipe_order aacg_pipeline_order(uint64_t n);
+#define AACG_PIPE_RING  8             /* marked rounds whose events are kept: > AACG_PIPE_DEPTH(1) / AACG_PIPE_MARK */
+aacg_pipe_order aacg_pipeline_order(uint64_t n, int streams);
+/* How many streams a pipelined sequence of this plan's launches takes in turn.  Three where a launch is about one workgroup per
+ * CU: a CU that is done with launch n + 1's workgroup then finds one of launch n + 2 waiting (BASELINE config 2: 11.7 -> 11.3 us;
+ * config 4 shape 11.6 -> 11.4).  Two where a launch is several rounds of workgroups anyway: a third launch in flight only
+ * scatters the elements of a stream over more of the L2s (config 5 shape: 58.9 us with two, 63.5 with three, same box). */
+int aacg_pipeline_streams(const aacg_plan_host& h);
 #endif
 
 #endif

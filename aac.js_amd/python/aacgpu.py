@@ -268,14 +268,14 @@ def run_kernels():
 PIPE_STREAMS = 3        # AACG_PIPE_STREAMS: launches of a pipelined sequence that may be in flight side by side (aacg_device.h)
 
 
-def pipeline_order(n):
-    """How launch n of a pipelined sequence is ordered (aacg_pipeline_order, aacg_routes.cpp): (stream, the round whose completion
+def pipeline_order(n, streams=PIPE_STREAMS):
+    """How launch n of a pipelined sequence on `streams` streams is ordered (aacg_pipeline_order, aacg_routes.cpp): (stream, the round whose completion
     events the host waits for before enqueuing it or -1, whether its own completion gets an event, the launch up to which
     everything is known complete when it is enqueued or -1, number of rotating overlap buffers the rule has to cover)."""
     lib = load_library()
-    lib.aacg_debug_pipeline_order.argtypes = [C.c_ulonglong, C.POINTER(C.c_int), C.POINTER(C.c_longlong), C.POINTER(C.c_int), C.POINTER(C.c_longlong)]
+    lib.aacg_debug_pipeline_order.argtypes = [C.c_ulonglong, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_longlong), C.POINTER(C.c_int), C.POINTER(C.c_longlong)]
     st, w, m, u = C.c_int(), C.c_longlong(), C.c_int(), C.c_longlong()
-    k = lib.aacg_debug_pipeline_order(n, C.byref(st), C.byref(w), C.byref(m), C.byref(u))
+    k = lib.aacg_debug_pipeline_order(n, streams, C.byref(st), C.byref(w), C.byref(m), C.byref(u))
     return st.value, w.value, bool(m.value), u.value, k
 
 

@@ -68,11 +68,11 @@ int aacg_debug_set_route(aacg_engine* e, int flags);
 int aacg_debug_route(int input_kind, int output_kind, int debug_route, int plan_flags, int pipelined, char* dst, size_t n);
 /* The registered run kernels: the index-th symbol into dst, returns its switches (the key launch_run looks it up by), < 0 past the end. */
 int aacg_debug_run_kernel(int index, char* dst, size_t n);
-/* The ordering rule of pipelined launches (aacg_pipeline_order, aacg_routes.cpp): stream of launch n; the round (one launch per
+/* The ordering rule of pipelined launches (aacg_pipeline_order, aacg_routes.cpp) for a sequence on `streams` streams: stream of launch n; the round (one launch per
  * stream) whose completion events the host waits for before enqueuing it (-1: none); whether its own completion gets an event;
  * the launch up to which everything is known complete when it is enqueued (-1: nothing).  Returns the number of rotating
  * overlap buffers the rule must cover. */
-int aacg_debug_pipeline_order(unsigned long long n, int* stream, long long* sync_round, int* marked, long long* complete_upto);
+int aacg_debug_pipeline_order(unsigned long long n, int streams, int* stream, long long* sync_round, int* marked, long long* complete_upto);
 
 #ifdef __cplusplus
 }

@@ -328,7 +328,7 @@ int emu_decode_cce(int input_kind, int sample_index, int max_streams, int max_ch
 int emu_decode_pipelined(int input_kind, int sample_index, int max_streams, int max_channels,
                          const aacg_unit_desc* units, uint32_t n_units, int n_launches, const void* const* coeffs, const aacg_band_meta* const* meta,
                          float* const* pcm, size_t n_pcm_floats, float* overlap_pool, uint8_t* parity,
-                         void* xl_cells, float* xl_head, int order, unsigned long long first_epoch_in, unsigned long long* last_epoch)
+                         void* xl_cells, float* xl_head, int order, unsigned long long first_epoch_in, unsigned long long* last_epoch, int streams)
 {
     if (g_tab_index != sample_index) { int rc = aacg_build_tables(sample_index, &g_tab, nullptr); if (rc) return rc; g_tab_index = sample_index; }
     aacg_plan_host ph;
@@ -338,6 +338,7 @@ int emu_decode_pipelined(int input_kind, int sample_index, int max_streams, int 
     const aacg_route R = aacg_pick_route(input_kind, AACG_OUTPUT_F32, 0, false, ph, true);
     if (!R.overlappable) { g_err = "not a plain batch"; return AACG_ERR_UNSUPPORTED; }
     static unsigned long long epoch = 5000;
+    const int NS = streams > 0 ? streams : aacg_pipeline_streams(ph);          /* streams the sequence takes in turn (0: the engine's choice) */
     const size_t cells = (size_t)ph.n_links_rv;
     std::vector<unsigned long long> rv_state(AACG_PIPE_STREAMS * cells * AACG_RV_STATE_WORDS + 1, 0x5a5a5a5a5a5a5a5aull);
     std::vector<float> rv_data(AACG_PIPE_STREAMS * cells * AACG_RV_DATA_FLOATS + 1, std::numeric_limits<float>::quiet_NaN());
@@ -352,7 +353,7 @@ int emu_decode_pipelined(int input_kind, int sample_index, int max_streams, int 
         aacg_rv_args& v = V[(size_t)j];
         std::memset(&v, 0, sizeof v);
         v.links = ph.links_rv.data();
-        const size_t set = (size_t)aacg_pipeline_order((uint64_t)j).stream;      /* launches in flight together never share a set of in-launch cells */
+        const size_t set = (size_t)aacg_pipeline_order((uint64_t)j, NS).stream;      /* launches in flight together never share a set of in-launch cells */
         v.state = rv_state.data() + set * cells * AACG_RV_STATE_WORDS;
         v.data = rv_data.data() + set * cells * AACG_RV_DATA_FLOATS;
         v.epoch = ++epoch;
@@ -364,13 +365,13 @@ int emu_decode_pipelined(int input_kind, int sample_index, int max_streams, int 
     if (order == 0) {
         for (int j = 0; j < n_launches; j++) for (int b = 0; b < B; b++) sched.emplace_back(j, b);
     } else if (order == 1) {
-        /* as late as the streams allow: of every AACG_PIPE_STREAMS consecutive launches the last one first */
-        for (int j = 0; j < n_launches; j += AACG_PIPE_STREAMS)
-            for (int k = AACG_PIPE_STREAMS - 1; k >= 0; k--)
+        /* as late as the streams allow: of every NS consecutive launches the last one first */
+        for (int j = 0; j < n_launches; j += NS)
+            for (int k = NS - 1; k >= 0; k--)
                 if (j + k < n_launches) for (int b = 0; b < B; b++) sched.emplace_back(j + k, b);
     } else {
         /* the engine's ordering rules, exactly (aacg_pipeline_order, aacg_routes.cpp): launch j goes to stream j mod
-         * AACG_PIPE_STREAMS, so it starts after the launch AACG_PIPE_STREAMS before it is complete, and it does not exist before
+         * NS, so it starts after the launch NS before it is complete, and it does not exist before
          * the launches the host waits for are complete.  Among the launches those rules allow to run, the next workgroup is drawn at random, in each launch's
          * own shuffled block order */
         uint32_t rng = (uint32_t)order * 2654435761u + 12345u;
@@ -385,8 +386,8 @@ int emu_decode_pipelined(int input_kind, int sample_index, int max_streams, int 
         while (remaining) {
             std::vector<int> ready;
             for (int j = 0; j < n_launches; j++) {
-                const aacg_pipe_order o = aacg_pipeline_order((uint64_t)j);
-                if (left[(size_t)j].empty() || !done(j - AACG_PIPE_STREAMS)) continue;
+                const aacg_pipe_order o = aacg_pipeline_order((uint64_t)j, NS);
+                if (left[(size_t)j].empty() || !done(j - NS)) continue;
                 bool known = true;                          /* the host enqueues it only after everything up to complete_upto is complete */
                 for (int m = 0; m <= (int)o.complete_upto && known; m++) known = done(m);
                 if (!known) continue;

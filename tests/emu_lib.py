@@ -39,7 +39,7 @@ class Emu:
         L.emu_plan.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
         L.emu_plan_refresh.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int]
         L.emu_decode_pipelined.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
-                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_uint64, C.c_void_p]
+                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_uint64, C.c_void_p, C.c_int]
         L.emu_get_windows.argtypes = [C.c_int, C.c_void_p]
         L.emu_get_iq_sf.argtypes = [C.c_void_p, C.c_void_p]
 
@@ -89,10 +89,10 @@ class Emu:
         assert len(first) == len(nxt)
         return self.lib.emu_plan_refresh(first.ctypes.data, nxt.ctypes.data, len(first), sample_index, max_streams, max_channels, 1 if tns_spec else 0)
 
-    def decode_pipelined(self, units, coeffs_list, meta_list, n_pcm, pool, parity, cells, heads, order=0, epoch_in=0, sample_index=3):
+    def decode_pipelined(self, units, coeffs_list, meta_list, n_pcm, pool, parity, cells, heads, order=0, epoch_in=0, sample_index=3, streams=0):
         """aacg_decode_pipelined for len(coeffs_list) consecutive launches of ONE plan, workgroup by workgroup in an order the
-        engine's rules allow (order: 0 launch after launch, 1 the later launch of every pair first, >= 2 random interleaving with
-        that seed).  cells: uint64 [S][C][OV_BUFFERS][4] (aacg_xl_cell), heads: like pool.  Returns (list of PCM arrays, epoch of the
+        engine's rules allow (order: 0 launch after launch, 1 the last launch of every round of streams first, >= 2 random interleaving
+        with that seed; streams: how many the sequence takes in turn, 0 = the engine's choice for the plan).  cells: uint64 [S][C][OV_BUFFERS][4] (aacg_xl_cell), heads: like pool.  Returns (list of PCM arrays, epoch of the
         last launch: pass it as epoch_in to continue the sequence with the last launch 'still in flight')."""
         units = np.ascontiguousarray(units)
         n = len(coeffs_list)
@@ -105,7 +105,7 @@ class Emu:
         pp = (C.c_void_p * n)(*[x.ctypes.data for x in pcm])
         last = C.c_uint64(0)
         rc = self.lib.emu_decode_pipelined(kind, sample_index, pool.shape[0], pool.shape[1], units.ctypes.data, len(units), n, cp, mp, pp, n_pcm,
-                                           pool.ctypes.data, parity.ctypes.data, cells.ctypes.data, heads.ctypes.data, order, epoch_in, C.byref(last))
+                                           pool.ctypes.data, parity.ctypes.data, cells.ctypes.data, heads.ctypes.data, order, epoch_in, C.byref(last), streams)
         if rc:
             raise RuntimeError("emu_decode_pipelined rc=%d: %s" % (rc, self.error()))
         return pcm, last.value

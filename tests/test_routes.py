@@ -5,6 +5,8 @@ executes the descriptor that function returns and aacg_plan_kernels prints the s
 reference src/decoder.js:218-248 + src/filter_bank.js:88-204."""
 import itertools
 
+import pytest
+
 import aacgpu as A
 
 Q, F = A.INPUT_QUANT_I16, A.INPUT_SPEC_F32
@@ -90,16 +92,17 @@ def test_every_combination_of_flags_has_a_registered_kernel(engine_lib):
     assert n > 1000
 
 
-def test_pipelined_launches_stay_behind_the_launches_whose_buffers_they_reuse():
+@pytest.mark.parametrize("S", [2, 3])
+def test_pipelined_launches_stay_behind_the_launches_whose_buffers_they_reuse(S):
     """aacg_pipeline_order (aacg_routes.cpp) is the one place the ordering of pipelined launches lives: the engine issues by it,
     the emulator schedules by it.  Launch n reads overlap buffer n mod K and writes n + 1 mod K (K = AACG_OV_BUFFERS), so it
     shares buffers and cells with launches n - K + 1, n - K, n - K - 1 (and their multiples): it has to START BEHIND every
     launch up to n - K + 1 — through its stream (in order behind its own earlier launches) and through what the host has seen
     complete before it enqueued it (the events of a marked round: a stream's launch complete means its earlier ones are)."""
     N = 240
-    order = [A.pipeline_order(n) for n in range(N)]
+    order = [A.pipeline_order(n, S) for n in range(N)]
     K = order[0][4]
-    S = A.PIPE_STREAMS
+    assert S <= A.PIPE_STREAMS
     assert K >= 3 and all(o[4] == K for o in order)
     assert {o[0] for o in order} == set(range(S))
     known = -1                                              # everything up to this launch is complete, as far as the host knows

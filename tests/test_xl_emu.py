@@ -62,10 +62,10 @@ def test_overlapped_launches_equal_the_serialised_route_bit_for_bit(emu, oracle,
         d = serial[j].astype(np.float64) - refs[j]
         assert float(np.sqrt(np.mean(d * d))) < 1e-5 and not np.isnan(serial[j]).any()
     assert np.abs(serial_state - ov).max() <= 1e-5 * max(1.0, float(np.abs(ov).max()))
-    for order in (0, 1, 2, 3, 11):
+    for order, streams in ((0, 0), (1, 0), (2, 0), (3, 0), (11, 0), (1, 2), (5, 2)):        # streams 0: the engine's choice for the plan (three here)
         pool, par = emu_lib.new_pool(S, C)
         cells, heads = _cells(S, C)
-        got, _ = emu.decode_pipelined(base["units"], coeffs, metas, base["n_pcm"], pool, par, cells, heads, order=order)
+        got, _ = emu.decode_pipelined(base["units"], coeffs, metas, base["n_pcm"], pool, par, cells, heads, order=order, streams=streams)
         for j in range(n):
             assert np.array_equal(got[j].view(np.uint32), serial[j].view(np.uint32)), (order, j)
         assert np.array_equal(emu_lib.pool_current(pool, par).view(np.uint32), serial_state.view(np.uint32)), order
