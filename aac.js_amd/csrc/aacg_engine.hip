@@ -265,7 +265,7 @@ int launch_kernel(aacg_engine* e, const aacg_run_kernel* k, unsigned blocks, hip
 
 /* what a pipelined launch adds to the rendezvous arguments: the cross-launch cells, the epoch its input state carries, and
  * which of the plan's two sets of in-launch cells it uses (overlapping launches must not share one) */
-struct xl_args { bool on; unsigned long long epoch_in; int set; };
+struct xl_args { bool on; unsigned long long epoch_in; int set; int trace_part = 0; };   /* trace_part: which quarter of the profiling buffer this launch stamps */
 
 /* enqueue the launches of route R for a planned batch (device pointers) */
 int launch_run(aacg_engine* e, const aacg_route& R, const aacg_dev_unit* d_units, const aacg_run* d_runs, const aacg_dev_tns* d_tns,
@@ -289,7 +289,7 @@ int launch_run(aacg_engine* e, const aacg_route& R, const aacg_dev_unit* d_units
         V.epoch = ++e->rv_epoch;
         if (xl.on) { V.xl_cells = e->d_xl_cells; V.xl_head = e->d_xl_head; V.epoch_in = xl.epoch_in; }
         if (epoch_out) *epoch_out = V.epoch;
-        if (e->d_trace) { P.ablate = e->ablate; P.spec_out = (float*)e->d_trace + (size_t)xl.set * (1u << 18); }   /* profiling builds: launches in flight side by side stamp different quarters */
+        if (e->d_trace) { P.ablate = e->ablate; P.spec_out = (float*)e->d_trace + (size_t)xl.trace_part * (1u << 18); }   /* profiling builds: the last four launches keep their stamps */
         return launch_kernel(e, aacg_find_run_kernel(R.run_key), (unsigned)n_runs, s, P, &V, stop);
     }
     P.runs = d_runs; P.n_runs = (int32_t)h.runs.size();
@@ -880,7 +880,7 @@ int aacg_decode_pipelined_timed(aacg_engine* e, aacg_plan* p, const void* d_coef
     if (!p->used) HIP_TRY(e, hipStreamWaitEvent(s, p->uploaded, 0), AACG_ERR_NO_DEVICE);
     const cce_bufs cb = {(const aacg_run*)p->d_cce[0], (const aacg_couple_job*)p->d_cce[1], (const float*)p->d_cce[2], (float*)p->d_cce[3]};
     const rv_bufs rvb = {(const aacg_run*)p->d_rv[0], (const aacg_rv_link*)p->d_rv[1], (unsigned long long*)p->d_rv[2], (float*)p->d_rv[3]};
-    const xl_args xl = {R.overlappable, continues ? pp.epoch : 0ull, ord.stream};
+    const xl_args xl = {R.overlappable, continues ? pp.epoch : 0ull, ord.stream, (int)(pp.n & 3u)};
     unsigned long long epoch = 0;
     /* the host will wait for this one: its event rides on the dispatch itself where the route is a single launch
      * (no marker packet between this launch and the next of its stream), else it is recorded behind the route's last launch */

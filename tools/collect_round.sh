@@ -52,6 +52,6 @@ done
 # per-wave phase timelines (profile build): launch after launch, and pipelined steady state
 if [ -f aac.js_amd/csrc/variants/profile.so ]; then
   ( echo "== serial launches (aacg_decode_device): one launch, every CU starts together"; AACGPU_LIB=aac.js_amd/csrc/variants/profile.so AACG_ABLATE=16 timeout 120 python3 tools/timeline.py quant 2>/dev/null
-    echo; echo "== pipelined launches (aacg_decode_pipelined): the last of 41 launches, the one before it still running beside it"; AACGPU_LIB=aac.js_amd/csrc/variants/profile.so AACG_ABLATE=16 TL_PIPE=1 timeout 120 python3 tools/timeline.py quant 2>/dev/null ) > $OUT/timeline.txt
+    echo; echo "== pipelined launches (aacg_decode_pipelined): the fourth launch from the end of 3001, its neighbours running beside it"; AACGPU_LIB=aac.js_amd/csrc/variants/profile.so AACG_ABLATE=16 TL_PIPE=1 timeout 120 python3 tools/timeline.py quant 2>/dev/null ) > $OUT/timeline.txt
 fi
 ls -la $OUT

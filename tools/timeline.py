@@ -19,7 +19,7 @@ else:
 d_out = torch.empty(wl["n_pcm"], dtype=torch.float32, device="cuda")
 torch.cuda.synchronize()
 PIPE = bool(os.environ.get("TL_PIPE"))                                  # TL_PIPE=1: launches through aacg_decode_pipelined (steady state: two in flight)
-N_LAUNCH = int(os.environ.get("TL_LAUNCHES", "41" if PIPE else "5"))
+N_LAUNCH = int(os.environ.get("TL_LAUNCHES", "3001" if PIPE else "5"))    # pipelined: long enough for the host to be ahead of the GPU (steady state)
 outs = [torch.empty(wl["n_pcm"], dtype=torch.float32, device="cuda") for _ in range(4)]
 for i in range(N_LAUNCH):
     if PIPE:
@@ -29,8 +29,11 @@ for i in range(N_LAUNCH):
 eng.synchronize()
 raw = np.zeros(1 << 20, np.float32)
 eng._check(eng.lib.aacg_get_table(eng.handle, 100, raw.ctypes.data, raw.size))
-if PIPE:                                                                # the last launch stamped half (N - 1) & 1 of the buffer, the one before it the other
-    last, prev = raw[((N_LAUNCH - 1) % 3) << 18:][: 1 << 18], raw[((N_LAUNCH - 2) % 3) << 18:][: 1 << 18]     # launch n stamps part n mod AACG_PIPE_STREAMS
+if PIPE:                                                                # launch n stamps quarter n mod 4 of the buffer: the last four launches are there
+    # "this" launch = the fourth from the end, so that it has successors in flight like any launch of a long sequence; "previous" = the one before it
+    parts = [raw[k << 18:][: 1 << 18] for k in range(4)]
+    parts.sort(key=lambda a: float(np.median(a.view(np.uint64)[: 256 * 16 * 8].reshape(256, 16, 8)[:, 0, 0])))     # oldest first
+    last, prev = parts[1], parts[0]
     tp = prev.view(np.uint64)[: 256 * 16 * 8].reshape(256, 16, 8).astype(np.float64) * 0.01
     raw = last
 NW = int(os.environ.get("TL_WAVES", str(min(16, T))))                  # waves of a workgroup that carry a frame (T / 2 for a folded chain)
