@@ -503,7 +503,7 @@ class Engine:
         self._check(self.lib.aacg_decode_device(self.handle, plan.handle, d_coeffs, d_meta, d_pcm, stream))
 
     def decode_pipelined(self, plan, d_coeffs, d_meta, d_pcm, mark=None):
-        """aacg_decode_pipelined: the next launch of `plan` on the engine's two internal streams taken in turn; it may overlap the
+        """aacg_decode_pipelined: the next launch of `plan` on the engine's internal streams taken in turn; it may overlap the
         launch before it (their chains meet in rendezvous cells).  Results: after pipeline_join / synchronize.
         mark: a TimerMark bound to the launch's completion (aacg_decode_pipelined_timed; measurement only)."""
         if mark is not None:
@@ -524,7 +524,7 @@ class Engine:
         return int(self.lib.aacg_pipeline_chained(self.handle))
 
     def pipeline_concurrent(self):
-        """True if the engine's two internal streams were seen to run side by side (else pipelined launches serialise: correct, not faster)."""
+        """True if the engine's internal streams were seen to run side by side (else pipelined launches serialise: correct, not faster)."""
         return bool(self.lib.aacg_pipeline_concurrent(self.handle))
 
     def plan_refresh_from_parse(self, plan, d_parsed_units, d_results, max_units, d_refused, stream=0):

@@ -338,8 +338,10 @@ int aacg_synchronize(aacg_engine* e, void* hip_stream);
  * aacg_decode_device puts every launch of a plan behind the one before it: the next batch's first frame needs the last
  * frame's tail (filter_bank.js:38-41, the only state the path carries; filter_bank.js:105-118 is the hand-over).  But that
  * dependency is per (stream, element) chain, not per launch: chain c of launch k + 1 needs chain c's tail of launch k and
- * nothing else.  aacg_decode_pipelined launches on two engine-owned HIP streams taken in turn, so that launch k + 1 starts
- * on the compute units launch k has already left; the two launches' chains meet in rendezvous cells in global memory —
+ * nothing else.  aacg_decode_pipelined launches on engine-owned HIP streams taken in turn (three, or two for plans whose
+ * launches are several rounds of workgroups anyway), so that launch k + 1 starts on the compute units launch k has already
+ * left and a unit that is done with launch k + 1 finds work of launch k + 2; consecutive launches' chains meet in rendezvous
+ * cells in global memory —
  * whichever side of a chain arrives first publishes what it has (launch k: the windowed tail = the new overlap state;
  * launch k + 1: its windowed first half and where the finished samples go) and leaves, the second finishes the frame.
  * Nobody waits for another workgroup, no dispatch order is assumed, and both arrival orders add the same two rounded
@@ -351,6 +353,11 @@ int aacg_synchronize(aacg_engine* e, void* hip_stream);
  *     for the host after aacg_pipeline_join(e, NULL) / aacg_synchronize.
  *   - Launches through other entry points (aacg_decode_device, aacg_submit*, another plan) are ordered behind the
  *     pipeline's by the engine; mixing costs the overlap, never the result.
+ *   - BACK-PRESSURE: at most fifteen launches of a sequence are in flight.  A launch reuses the overlap buffers and cells of
+ *     the launch sixteen before it, and instead of ordering that on the GPU (a wait in a queue costs what the overlap gains)
+ *     the call itself waits — on the host, every second round of launches — until the round four (three streams) or six (two)
+ *     rounds back is complete.  A caller that enqueues faster than the GPU decodes is slowed to the GPU's pace; nothing else
+ *     changes (aacg_pipeline_order in aacg_routes.cpp is the rule, tests/test_routes.py walks it).
  * Replaces: one `readChunk()` worth of process() + interleave (decoder.js:201-215) per stream and frame, batch after batch. */
 int aacg_decode_pipelined(aacg_engine* e, aacg_plan* p, const void* d_coeffs, const aacg_band_meta* d_meta, void* d_pcm);
 /* the pipeline's later launches start after everything enqueued on hip_stream so far (inputs produced there) */

@@ -28,8 +28,8 @@ int aacg_decode_pipelined_timed(aacg_engine* e, aacg_plan* p, const void* d_coef
 /* How many launches of aacg_decode_pipelined continued the launch before them through the cross-launch cells (and so were
  * allowed to overlap it) since the engine was made: tests assert that the route they mean to exercise was taken. */
 uint64_t aacg_pipeline_chained(const aacg_engine* e);
-/* 1 if the engine's two internal streams were seen to run side by side when the pipeline was set up (HIP multiplexes streams onto a
- * few hardware queues; two streams on one queue serialise): 0 = pipelined launches are correct but do not overlap. */
+/* 1 if the engine's internal streams were seen to run side by side, each pair of them, when the pipeline was set up (HIP multiplexes
+ * streams onto a few hardware queues; two streams on one queue serialise): 0 = pipelined launches are correct but do not overlap. */
 int aacg_pipeline_concurrent(const aacg_engine* e);
 
 /* Diagnostic: the IMDCT stage of the kernels on its own, for known-answer tests against the reference's MDCT.process
