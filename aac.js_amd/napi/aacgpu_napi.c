@@ -524,18 +524,67 @@ static napi_value js_pipeline_create(napi_env env, napi_callback_info info)
 /* Page-locked PCM buffers handed to JavaScript as external ArrayBuffers: the PCM of a batch comes down from the device
  * straight into the memory the Float32Array views — no staging copy, no zero-filled allocation of tens of megabytes per batch.
  * A buffer returns to the pool when the garbage collector has let go of the batch's last frame (the finalizer runs on the
- * JavaScript thread, like every call into this addon); the pool holds a few, the rest are freed. */
+ * JavaScript thread, like every call into this addon); the pool holds a few, the rest are freed.
+ * Finalizers do not run inside a synchronous loop, though, and that is how a host drains 256 streams: every flush would then
+ * page-lock a fresh 33 MB (2.3 ms — as long as the rest of the flush).  So a helper thread keeps the NEXT buffers ready: when
+ * one is taken, it makes another of that size while JavaScript slices the batch, and it does the freeing too. */
 #define PCM_POOL_MAX 8
+#define PCM_READY_MAX 2
 typedef struct { void* ptr; size_t bytes; } pcm_buf;
-static pcm_buf g_pool[PCM_POOL_MAX];
+static pcm_buf g_pool[PCM_POOL_MAX];               /* recycled by finalizers: JavaScript thread only */
 static int g_pool_n = 0;
+static pthread_mutex_t g_prep_lock = PTHREAD_MUTEX_INITIALIZER;
+static pthread_cond_t g_prep_wake = PTHREAD_COND_INITIALIZER;
+static pcm_buf g_ready[PCM_READY_MAX];             /* made ahead by the helper (under g_prep_lock) */
+static int g_ready_n = 0;
+static size_t g_want_bytes = 0;                    /* the size the helper keeps ready */
+static void* g_trash[64];                          /* buffers for the helper to free */
+static int g_trash_n = 0;
+static int g_prep_started = 0;
+
+static void* prep_main(void* arg)
+{
+    (void)arg;
+    pthread_mutex_lock(&g_prep_lock);
+    for (;;) {
+        if (g_trash_n) {
+            void* p = g_trash[--g_trash_n];
+            pthread_mutex_unlock(&g_prep_lock);
+            L.host_free(p);
+            pthread_mutex_lock(&g_prep_lock);
+            continue;
+        }
+        if (g_want_bytes && g_ready_n < PCM_READY_MAX) {
+            const size_t bytes = g_want_bytes;
+            pthread_mutex_unlock(&g_prep_lock);
+            void* p = L.host_alloc(bytes);
+            pthread_mutex_lock(&g_prep_lock);
+            if (p) {
+                if (g_ready_n < PCM_READY_MAX && bytes == g_want_bytes) { g_ready[g_ready_n].ptr = p; g_ready[g_ready_n].bytes = bytes; g_ready_n++; }
+                else if (g_trash_n < 64) g_trash[g_trash_n++] = p;
+            } else g_want_bytes = 0;                /* out of page-locked memory: the caller's own attempt will report it */
+            continue;
+        }
+        pthread_cond_wait(&g_prep_wake, &g_prep_lock);
+    }
+    return NULL;
+}
+
+static void pcm_discard(void* p)                   /* free off the JavaScript thread where possible */
+{
+    pthread_mutex_lock(&g_prep_lock);
+    const int queued = g_prep_started && g_trash_n < 64;
+    if (queued) { g_trash[g_trash_n++] = p; pthread_cond_signal(&g_prep_wake); }
+    pthread_mutex_unlock(&g_prep_lock);
+    if (!queued) L.host_free(p);
+}
 
 static void pcm_finalize(napi_env env, void* data, void* hint)
 {
     const size_t bytes = (size_t)hint;
     (void)env;
     if (g_pool_n < PCM_POOL_MAX) { g_pool[g_pool_n].ptr = data; g_pool[g_pool_n].bytes = bytes; g_pool_n++; }
-    else L.host_free(data);
+    else pcm_discard(data);
 }
 
 static void* pcm_take(size_t bytes, size_t* got)
@@ -546,8 +595,22 @@ static void* pcm_take(size_t bytes, size_t* got)
             g_pool[i] = g_pool[--g_pool_n];
             return p;
         }
+    void* p = NULL;
+    pthread_mutex_lock(&g_prep_lock);
+    if (!g_prep_started) {
+        pthread_t t;
+        if (pthread_create(&t, NULL, prep_main, NULL) == 0) { pthread_detach(t); g_prep_started = 1; }
+    }
+    for (int i = 0; i < g_ready_n && !p; i++)
+        if (g_ready[i].bytes == bytes) { p = g_ready[i].ptr; g_ready[i] = g_ready[--g_ready_n]; }
+    if (g_want_bytes != bytes) {                   /* another batch size: what was made ahead for the old one goes */
+        while (g_ready_n && g_trash_n < 64) g_trash[g_trash_n++] = g_ready[--g_ready_n].ptr;
+        g_want_bytes = bytes;
+    }
+    if (g_prep_started) pthread_cond_signal(&g_prep_wake);
+    pthread_mutex_unlock(&g_prep_lock);
     *got = bytes;
-    return L.host_alloc(bytes);
+    return p ? p : L.host_alloc(bytes);
 }
 
 /* pipelineDecode(pipeline, bytes:Uint8Array, frames:Uint32Array(2 * S * F) [offset, length]..., slots:Uint32Array(S), framesPerStream,
@@ -605,7 +668,7 @@ static napi_value js_pipeline_decode(napi_env env, napi_callback_info info)
     if (rc) snprintf(msg, sizeof msg, "aacgpu: aacg_pipeline_decode failed (%d): %.800s", rc, L.pipeline_last_error(p));
     pthread_mutex_unlock(&pb->lock);
     if (rc) {
-        if (slot < 0) { if (g_pool_n < PCM_POOL_MAX) { g_pool[g_pool_n].ptr = pcm; g_pool[g_pool_n].bytes = got; g_pool_n++; } else L.host_free(pcm); }
+        if (slot < 0) { if (g_pool_n < PCM_POOL_MAX) { g_pool[g_pool_n].ptr = pcm; g_pool[g_pool_n].bytes = got; g_pool_n++; } else pcm_discard(pcm); }
         napi_throw_error(env, NULL, msg);
         return NULL;
     }
