@@ -6,6 +6,8 @@
  * CPU fallback: every entry point either runs the HIP kernels or returns an error.
  */
 #include <hip/hip_runtime.h>
+
+#include <chrono>
 #include <hip/hip_ext.h>
 
 #include <cstdio>
@@ -867,8 +869,19 @@ int aacg_decode_pipelined_timed(aacg_engine* e, aacg_plan* p, const void* d_coef
         /* back-pressure instead of cross-stream waits: the HOST waits until the round AACG_PIPE_DEPTH(streams) back is complete — no
          * barrier packet enters a GPU queue (one per two launches cost the three-stream pipeline all it had gained), and the
          * queues still hold a round of launches when the host comes back */
-        if (ord.sync_round >= 0)
-            for (hipEvent_t ev : pp.mark[((uint64_t)ord.sync_round / AACG_PIPE_MARK) % AACG_PIPE_RING]) HIP_TRY(e, hipEventSynchronize(ev), AACG_ERR_NO_DEVICE);
+        if (ord.sync_round >= 0) {
+            /* (bounded: if an event has not completed after two seconds — a stalled device, a driver that lost a signal — the
+             * ordering moves to the GPU for this round, which is always correct, instead of leaving the caller in a wait) */
+            const auto deadline = std::chrono::steady_clock::now() + std::chrono::seconds(2);
+            for (hipEvent_t ev : pp.mark[((uint64_t)ord.sync_round / AACG_PIPE_MARK) % AACG_PIPE_RING]) {
+                hipError_t st;
+                while ((st = hipEventQuery(ev)) == hipErrorNotReady && std::chrono::steady_clock::now() < deadline) {}
+                if (st == hipErrorNotReady) {
+                    (void)hipGetLastError();
+                    for (hipStream_t ps : pp.stream) HIP_TRY(e, hipStreamWaitEvent(ps, ev, 0), AACG_ERR_NO_DEVICE);
+                } else HIP_TRY(e, st, AACG_ERR_NO_DEVICE);
+            }
+        }
     } else if (!follows) {
         if ((rc = pipe_join(e, s))) return rc;
         if (p->used && !p->last_pipelined) {

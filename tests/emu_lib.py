@@ -24,7 +24,10 @@ def new_pool(streams, channels):
 
 class Emu:
     def __init__(self, target="libaacg_emu.so"):
-        subprocess.run(["make", "-C", os.path.join(HERE, "emu"), target], check=True, stdout=subprocess.DEVNULL)
+        import fcntl
+        with open(os.path.join(HERE, "emu", ".build.lock"), "w") as lock:      # one make at a time (pytest-xdist workers)
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            subprocess.run(["make", "-C", os.path.join(HERE, "emu"), target], check=True, stdout=subprocess.DEVNULL)
         self.lib = L = C.CDLL(os.path.join(HERE, "emu", target))
         L.emu_last_error.restype = C.c_char_p
         L.emu_decode.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,

@@ -28,7 +28,11 @@ assert CCE_DTYPE.itemsize == 7716
 
 
 def build(target="liboracle.so"):
-    subprocess.run(["make", "-C", ORACLE_DIR, target], check=True, stdout=subprocess.DEVNULL)
+    # one make at a time: pytest-xdist workers (and bench.py's ranks) all come here, and two makes writing one .so is a torn file
+    import fcntl
+    with open(os.path.join(ORACLE_DIR, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        subprocess.run(["make", "-C", ORACLE_DIR, target], check=True, stdout=subprocess.DEVNULL)
     return os.path.join(ORACLE_DIR, target)
 
 
