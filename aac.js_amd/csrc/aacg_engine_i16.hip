@@ -23,7 +23,21 @@ void aacg_imdct_run_quant_i16_nt(const aacg_kparams P) { imdct_run_body<AACG_INP
 extern "C" __global__ __launch_bounds__(AACG_WG_THREADS)
 void aacg_imdct_run_f32_i16_nt(const aacg_kparams P) { imdct_run_body<AACG_INPUT_SPEC_F32, AACG_OUTPUT_I16, false, false, false, false, true>(P); }
 
+/* chains that meet in rendezvous cells — between the runs of a launch and between consecutive launches (aacg_engine_rv.hip) */
+extern "C" __global__ __launch_bounds__(AACG_WG_THREADS)
+void aacg_imdct_run_quant_rv_i16(const aacg_kparams P, const aacg_rv_args V) { imdct_run_body<AACG_INPUT_QUANT_I16, AACG_OUTPUT_I16, false, false, false, true>(P, &V); }
+extern "C" __global__ __launch_bounds__(AACG_WG_THREADS)
+void aacg_imdct_run_f32_rv_i16(const aacg_kparams P, const aacg_rv_args V) { imdct_run_body<AACG_INPUT_SPEC_F32, AACG_OUTPUT_I16, false, false, false, true>(P, &V); }
+extern "C" __global__ __launch_bounds__(AACG_WG_THREADS)
+void aacg_imdct_run_quant_rv_i16_nt(const aacg_kparams P, const aacg_rv_args V) { imdct_run_body<AACG_INPUT_QUANT_I16, AACG_OUTPUT_I16, false, false, false, true, true>(P, &V); }
+extern "C" __global__ __launch_bounds__(AACG_WG_THREADS)
+void aacg_imdct_run_f32_rv_i16_nt(const aacg_kparams P, const aacg_rv_args V) { imdct_run_body<AACG_INPUT_SPEC_F32, AACG_OUTPUT_I16, false, false, false, true, true>(P, &V); }
+
 const aacg_run_kernel aacg_run_kernels_i16[] = {
+    {AACG_RK_RV | AACG_RK_I16 | AACG_RK_QUANT, "aacg_imdct_run_quant_rv_i16", (const void*)aacg_imdct_run_quant_rv_i16},
+    {AACG_RK_RV | AACG_RK_I16, "aacg_imdct_run_f32_rv_i16", (const void*)aacg_imdct_run_f32_rv_i16},
+    {AACG_RK_RV | AACG_RK_I16 | AACG_RK_NT | AACG_RK_QUANT, "aacg_imdct_run_quant_rv_i16_nt", (const void*)aacg_imdct_run_quant_rv_i16_nt},
+    {AACG_RK_RV | AACG_RK_I16 | AACG_RK_NT, "aacg_imdct_run_f32_rv_i16_nt", (const void*)aacg_imdct_run_f32_rv_i16_nt},
     {AACG_RK_I16 | AACG_RK_QUANT, "aacg_imdct_run_quant_i16", (const void*)aacg_imdct_run_quant_i16},
     {AACG_RK_I16, "aacg_imdct_run_f32_i16", (const void*)aacg_imdct_run_f32_i16},
     {AACG_RK_I16 | AACG_RK_DD | AACG_RK_QUANT, "aacg_imdct_run_quant_dd_i16", (const void*)aacg_imdct_run_quant_dd_i16},
@@ -31,4 +45,4 @@ const aacg_run_kernel aacg_run_kernels_i16[] = {
     {AACG_RK_I16 | AACG_RK_NT | AACG_RK_QUANT, "aacg_imdct_run_quant_i16_nt", (const void*)aacg_imdct_run_quant_i16_nt},
     {AACG_RK_I16 | AACG_RK_NT, "aacg_imdct_run_f32_i16_nt", (const void*)aacg_imdct_run_f32_i16_nt}
 };
-const int aacg_run_kernels_i16_n = 6;
+const int aacg_run_kernels_i16_n = 10;

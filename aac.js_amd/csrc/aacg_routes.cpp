@@ -16,12 +16,12 @@ aacg_route aacg_pick_route(int input_kind, int output_kind, int debug_route, boo
     bool quant = input_kind == AACG_INPUT_QUANT_I16;
     const bool stages = h.any_tns || (quant && h.any_pns);
     const unsigned nt = (h.wide_frames && !tracing) ? AACG_RK_NT : 0u;     /* batches of multichannel frames: non-temporal loads of the spectra */
-    /* plain batches — f32 PCM, no optional stage, no coupling element: with a chain longer than a run, or launched through the
+    /* plain batches — no optional stage, no coupling element: with a chain longer than a run, or launched through the
      * pipeline, they take the rendezvous cut of their chains (AACG_DEBUG_ROUTE_RECOMPUTE: long chains the old way; serial launches only) */
-    const bool plain = !i16 && !h.any_cce && !stages && !h.runs_rv.empty();
+    const bool plain = !h.any_cce && !stages && !h.runs_rv.empty();
     if (plain && (pipelined || (h.long_chains && !(debug_route & AACG_DEBUG_ROUTE_RECOMPUTE)))) {
         r.has_run = true;
-        r.run_key = AACG_RK_RV | nt | (quant ? AACG_RK_QUANT : 0u);
+        r.run_key = AACG_RK_RV | nt | (i16 ? AACG_RK_I16 : 0u) | (quant ? AACG_RK_QUANT : 0u);
         r.rv = true;
         r.overlappable = true;
         return r;

@@ -346,7 +346,7 @@ int aacg_synchronize(aacg_engine* e, void* hip_stream);
  * launch k + 1: its windowed first half and where the finished samples go) and leaves, the second finishes the frame.
  * Nobody waits for another workgroup, no dispatch order is assumed, and both arrival orders add the same two rounded
  * numbers: the PCM is bit-identical to aacg_decode_device's.
- *   - Plain batches (float PCM, no AACG_TNS_SPEC / AACG_PNS_SPEC stage, no coupling element) overlap; every other plan
+ *   - Plain batches (float or int16 PCM, no AACG_TNS_SPEC / AACG_PNS_SPEC stage, no coupling element) overlap; every other plan
  *     is accepted and runs behind the launch before it, as aacg_decode_device would run it.
  *   - Inputs must be complete when the call is made, or be produced on a stream the pipeline has been forked from
  *     (aacg_pipeline_fork) since; outputs are complete for work on hip_stream after aacg_pipeline_join(e, hip_stream) and

@@ -49,6 +49,8 @@ void run_kernel(unsigned key, const aacg_kparams& P, const aacg_rv_args* V)
     case AACG_RK_CPL | AACG_RK_QUANT:               imdct_run_body<Q, O32, false, false, true>(P); break;
     case AACG_RK_RV:                                imdct_run_body<F, O32, false, false, false, true>(P, V); break;
     case AACG_RK_RV | AACG_RK_QUANT:                imdct_run_body<Q, O32, false, false, false, true>(P, V); break;
+    case AACG_RK_RV | AACG_RK_I16:                  imdct_run_body<F, O16, false, false, false, true>(P, V); break;
+    case AACG_RK_RV | AACG_RK_I16 | AACG_RK_QUANT:  imdct_run_body<Q, O16, false, false, false, true>(P, V); break;
     default: std::abort();                          /* a route without a kernel */
     }
 }

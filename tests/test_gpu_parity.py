@@ -959,6 +959,47 @@ def test_pipelined_launches_equal_the_serialised_route_bit_for_bit(oracle, layou
             assert rms(serial[j], oracle.decode_batch(base["units"], host[j], base["meta"], base["n_pcm"], ov)) < RMS_TOL
 
 
+@pytest.mark.parametrize("layout,S,T", [(("cpe",), 256, 16), (("cpe", "cpe", "cpe", "sce"), 40, 24)])
+def test_pipelined_int16_pcm_equals_the_serialised_route(oracle, layout, S, T):
+    """AACG_OUTPUT_I16 engines through the pipeline (aacg_imdct_run_*_rv_i16): 64 overlapped launches against the same launches
+    one behind the other — the same int16 samples and the same overlap state; the first launch against the oracle's PCM rounded
+    the same way."""
+    torch = _torch()
+    n = 64
+    base = aacgpu_workload.make_batch(n_streams=S, n_frames=T, layout=layout, mix=True, intensity=True, seed=7500)
+    C = base["C"]
+    ins, host = _device_batches(torch, base, n, "q", oracle, 9)
+    d_meta = torch.from_numpy(base["meta"].view(np.int16)).cuda()
+    results = []
+    for pipelined in (False, True):
+        eng = aacgpu.Engine(aacgpu.INPUT_QUANT_I16, max_streams=S, max_channels=C, output_kind=aacgpu.OUTPUT_I16)
+        plan = eng.plan(base["units"])
+        name = eng.plan_kernels(plan, pipelined=pipelined)
+        wide = "_nt" if C > 2 else ""
+        assert name == ("aacg_imdct_run_quant_rv_i16" + wide if pipelined or T > 16 else "aacg_imdct_run_quant_i16" + wide)
+        outs = [torch.full((base["n_pcm"],), -1, dtype=torch.int16, device="cuda") for _ in range(n)]
+        torch.cuda.synchronize()
+        for j in range(n):
+            if pipelined:
+                eng.decode_pipelined(plan, ins[j].data_ptr(), d_meta.data_ptr(), outs[j].data_ptr())
+            else:
+                eng.decode_device(plan, ins[j].data_ptr(), d_meta.data_ptr(), outs[j].data_ptr(), 0)
+        eng.synchronize()
+        torch.cuda.synchronize()
+        if pipelined:
+            assert eng.pipeline_chained() == n - 1
+        results.append(([o.cpu().numpy() for o in outs], overlaps(eng, S, C)))
+        plan.destroy()
+        eng.close()
+    (serial, s_state), (piped, p_state) = results
+    for j in range(n):
+        assert np.array_equal(piped[j], serial[j]), "launch %d differs from the serialised route" % j
+    assert np.array_equal(p_state.view(np.uint32), s_state.view(np.uint32))
+    ov = np.zeros((S, C, 1024), np.float32)
+    d = serial[0].astype(np.int32) - _pcm16(oracle.decode_batch(base["units"], host[0], base["meta"], base["n_pcm"], ov))
+    assert np.abs(d).max() <= 1 and np.count_nonzero(d) <= 1e-2 * d.size
+
+
 def test_pipelined_launches_mixed_with_everything_else(oracle):
     """The pipeline next to the other entry points on the same streams — aacg_decode_device of the same plan, another plan, the
     host-buffer path, aacg_get_overlap, a fork from and a join onto a caller's stream: mixing costs the overlap, never the

@@ -27,6 +27,7 @@ b cfg3_tns_spec_quant --workload cfg3 --tns spec --steps 1000 --warmup 200 --no-
 b cfg3_tns_spec_f32 --workload cfg3 --tns spec --input spec --steps 1000 --warmup 200 --no-cpu-baseline
 b cfg5_cce_spec --workload cfg5 --cce spec --steps 500 --warmup 100 --no-cpu-baseline
 b quant_i16out --output i16 --no-cpu-baseline
+b quant_i16out_serial --output i16 --serial --no-cpu-baseline
 b quant_pipelines2 --pipelines 2 --no-cpu-baseline
 b quant_2ranks_shared_gpu --gpus 2 --dist-backend gloo --share-gpu --steps 1000 --warmup 200
 # the driver's launch line with one rank: RCCL carries the barrier and the 8-byte reductions

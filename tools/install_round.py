@@ -96,7 +96,8 @@ def main():
             ("config 5 shape (7 channels per frame), int16 in, overlapped", "cfg5", ("%s; %.1f M L2 write requests" % (x_("cfg5_quant", "cfg5"), T["cfg5_quant"].get("TCP_TCC_WRITE_REQ", 0) / 1e6)) if "cfg5_quant" in T else ""),
             ("config 5 shape, `--serial`", "cfg5_serial", ""),
             ("config 5 shape, f32 in, overlapped", "cfg5_spec", ""),
-            ("int16 in → **int16 PCM**, config 2 (no rendezvous build: launch behind launch)", "quant_i16out", ""),
+            ("int16 in → **int16 PCM**, config 2, overlapped (`aacg_imdct_run_quant_rv_i16`)", "quant_i16out", ""),
+            ("int16 PCM, `--serial`", "quant_i16out_serial", ""),
             ("config 3 + `AACG_TNS_SPEC`, a filter on every channel-frame (one launch, not overlapped)", "cfg3_tns_spec_quant", x_("cfg3_tns_quant_ex", "cfg3_tns_spec_quant")),
             ("the same, f32 seam", "cfg3_tns_spec_f32", ""),
             ("config 5 + `AACG_CCE_SPEC`, one independent CCE per frame (two launches, not overlapped)", "cfg5_cce_spec", ""),
