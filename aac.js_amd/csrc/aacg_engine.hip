@@ -290,6 +290,7 @@ int launch_run(aacg_engine* e, const aacg_route& R, const aacg_dev_unit* d_units
         V.data = rvb.data ? rvb.data + (size_t)xl.set * AACG_RV_DATA_FLOATS * n_links : nullptr;
         V.epoch = ++e->rv_epoch;
         if (xl.on) { V.xl_cells = e->d_xl_cells; V.xl_head = e->d_xl_head; V.epoch_in = xl.epoch_in; }
+        if (R.run_key & AACG_RK_EX) { P.tns = h.any_tns ? d_tns : nullptr; P.pns = e->d_pns; }    /* optional stages inside the run kernel */
         if (epoch_out) *epoch_out = V.epoch;
         if (e->d_trace) { P.ablate = e->ablate; P.spec_out = (float*)e->d_trace + (size_t)xl.trace_part * (1u << 18); }   /* profiling builds: the last four launches keep their stamps */
         return launch_kernel(e, aacg_find_run_kernel(R.run_key), (unsigned)n_runs, s, P, &V, stop);

@@ -18,10 +18,20 @@ void aacg_imdct_run_quant_ex(const aacg_kparams P) { imdct_run_body<AACG_INPUT_Q
 extern "C" __global__ __launch_bounds__(AACG_WG_THREADS)
 void aacg_imdct_run_f32_ex(const aacg_kparams P) { imdct_run_body<AACG_INPUT_SPEC_F32, AACG_OUTPUT_F32, false, true>(P); }
 
+/* the same with chains that meet in rendezvous cells (aacg_engine_rv.hip): chains longer than a run without a staged route, and
+ * launches through the pipeline that overlap */
+extern "C" __global__ __launch_bounds__(AACG_WG_THREADS)
+void aacg_imdct_run_quant_ex_rv(const aacg_kparams P, const aacg_rv_args V) { imdct_run_body<AACG_INPUT_QUANT_I16, AACG_OUTPUT_F32, false, true, false, true>(P, &V); }
+
+extern "C" __global__ __launch_bounds__(AACG_WG_THREADS)
+void aacg_imdct_run_f32_ex_rv(const aacg_kparams P, const aacg_rv_args V) { imdct_run_body<AACG_INPUT_SPEC_F32, AACG_OUTPUT_F32, false, true, false, true>(P, &V); }
+
 static_assert(AACG_LDS_BYTES_QUANT_EX <= 160 * 1024, "the TNS exchange areas must fit beside the slots");
 
 const aacg_run_kernel aacg_run_kernels_exrun[] = {
     {AACG_RK_EX | AACG_RK_QUANT, "aacg_imdct_run_quant_ex", (const void*)aacg_imdct_run_quant_ex},
-    {AACG_RK_EX, "aacg_imdct_run_f32_ex", (const void*)aacg_imdct_run_f32_ex}
+    {AACG_RK_EX, "aacg_imdct_run_f32_ex", (const void*)aacg_imdct_run_f32_ex},
+    {AACG_RK_EX | AACG_RK_RV | AACG_RK_QUANT, "aacg_imdct_run_quant_ex_rv", (const void*)aacg_imdct_run_quant_ex_rv},
+    {AACG_RK_EX | AACG_RK_RV, "aacg_imdct_run_f32_ex_rv", (const void*)aacg_imdct_run_f32_ex_rv}
 };
-const int aacg_run_kernels_exrun_n = 2;
+const int aacg_run_kernels_exrun_n = 4;

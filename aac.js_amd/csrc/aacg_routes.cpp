@@ -26,6 +26,15 @@ aacg_route aacg_pick_route(int input_kind, int output_kind, int debug_route, boo
         r.overlappable = true;
         return r;
     }
+    /* the optional stages inside the run kernel, same cut: one launch where a chain longer than a run took a staged route, and
+     * launches through the pipeline overlap */
+    if (stages && !i16 && !h.any_cce && !h.runs_rv.empty() && (pipelined || (h.long_chains && !(debug_route & AACG_DEBUG_ROUTE_RECOMPUTE)))) {
+        r.has_run = true;
+        r.run_key = AACG_RK_EX | AACG_RK_RV | (quant ? AACG_RK_QUANT : 0u);
+        r.rv = true;
+        r.overlappable = true;
+        return r;
+    }
     unsigned key = 0;
     if (h.any_cce_dependent) {
         /* coupling in the spectral domain: every unit's spectrum as f32 first, the coupling passes and the TNS filters on that */

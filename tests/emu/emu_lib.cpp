@@ -49,6 +49,8 @@ void run_kernel(unsigned key, const aacg_kparams& P, const aacg_rv_args* V)
     case AACG_RK_CPL | AACG_RK_QUANT:               imdct_run_body<Q, O32, false, false, true>(P); break;
     case AACG_RK_RV:                                imdct_run_body<F, O32, false, false, false, true>(P, V); break;
     case AACG_RK_RV | AACG_RK_QUANT:                imdct_run_body<Q, O32, false, false, false, true>(P, V); break;
+    case AACG_RK_RV | AACG_RK_EX:                   imdct_run_body<F, O32, false, true, false, true>(P, V); break;
+    case AACG_RK_RV | AACG_RK_EX | AACG_RK_QUANT:   imdct_run_body<Q, O32, false, true, false, true>(P, V); break;
     case AACG_RK_RV | AACG_RK_I16:                  imdct_run_body<F, O16, false, false, false, true>(P, V); break;
     case AACG_RK_RV | AACG_RK_I16 | AACG_RK_QUANT:  imdct_run_body<Q, O16, false, false, false, true>(P, V); break;
     default: std::abort();                          /* a route without a kernel */
@@ -240,7 +242,7 @@ int emu_decode_cce(int input_kind, int sample_index, int max_streams, int max_ch
     aacg_route R = aacg_pick_route(input_kind, g_out_kind, (g_unfused ? AACG_DEBUG_ROUTE_UNFUSED_COUPLING : 0) | (g_rv ? 0 : AACG_DEBUG_ROUTE_RECOMPUTE), false, ph, false);
     if (g_staged && R.has_run && (R.run_key & AACG_RK_EX)) {     /* test switch: the optional stages as a launch of their own even where the engine runs them inside */
         R.stage = AACG_STAGE_SPECTRAL_EX; R.stage_quant = input_kind == AACG_INPUT_QUANT_I16;
-        R.run_key = 0;
+        R.run_key = ph.needs_scratch ? AACG_RK_DD : 0; R.rv = false;
     }
     aacg_kparams P;
     std::memset(&P, 0, sizeof P);
@@ -275,6 +277,7 @@ int emu_decode_cce(int input_kind, int sample_index, int max_streams, int max_ch
         if (g_rv == 2) { std::reverse(runs.begin(), runs.end()); std::reverse(links.begin(), links.end()); }
         aacg_kparams K = P;
         K.runs = runs.data(); K.n_runs = (int32_t)runs.size(); K.scratch = nullptr;
+        if (R.run_key & AACG_RK_EX) K.pns = &pns_tab;      /* optional stages inside the run kernel */
         aacg_rv_args V;
         std::memset(&V, 0, sizeof V);
         V.links = links.data(); V.state = rv_state.data(); V.data = rv_data.data(); V.epoch = ++epoch;

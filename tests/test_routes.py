@@ -24,11 +24,11 @@ def compose(key):
 
 def test_every_registered_kernel_carries_the_symbol_its_switches_compose(engine_lib):
     reg = A.run_kernels()
-    assert len(reg) == 26 and len(set(reg.values())) == 26          # one kernel per set of switches
+    assert len(reg) == 28 and len(set(reg.values())) == 28          # one kernel per set of switches
     for name, key in reg.items():
         assert name == compose(key), (name, key)
     both = {n.replace("_quant", "_X").replace("_f32", "_X") for n in reg}
-    assert len(both) == 13                                          # every variant exists for both seams
+    assert len(both) == 14                                          # every variant exists for both seams
 
 
 def test_named_variants_are_the_routes_of_the_batches_they_were_built_for(engine_lib):
@@ -54,8 +54,9 @@ def test_named_variants_are_the_routes_of_the_batches_they_were_built_for(engine
     assert r(Q, O32, T) == "aacg_imdct_run_quant_ex" and r(F, O32, T | W) == "aacg_imdct_run_f32_ex" and r(Q, O32, P) == "aacg_imdct_run_quant_ex"
     assert r(F, O32, P) == "aacg_imdct_run_f32"                                   # noise bands are a matter of the quantised seam
     assert r(Q, O16, T) == "aacg_spectral_ex_quant + aacg_imdct_run_f32_i16"
-    assert r(Q, O32, T | L | FULL) == "aacg_spectral_ex_quant + aacg_imdct_run_f32_dd"
-    assert r(Q, O32, T, pipelined=True) == "aacg_imdct_run_quant_ex"
+    assert r(Q, O32, T | L | FULL) == "aacg_imdct_run_quant_ex_rv"                 # a chain longer than a run: the rendezvous cut, one launch
+    assert r(Q, O32, T | L | FULL, debug_flags=A.DEBUG_ROUTE_RECOMPUTE) == "aacg_spectral_ex_quant + aacg_imdct_run_f32_dd"
+    assert r(Q, O32, T, pipelined=True) == "aacg_imdct_run_quant_ex_rv" and r(F, O32, T | W, pipelined=True) == "aacg_imdct_run_f32_ex_rv"
     # coupling
     assert r(Q, O32, CI) == "aacg_imdct_run_quant (coupling elements) + aacg_imdct_run_quant_cpl"
     assert r(Q, O32, CI | W) == "aacg_imdct_run_quant (coupling elements) + aacg_imdct_run_quant_cpl_nt"
@@ -85,7 +86,7 @@ def test_every_combination_of_flags_has_a_registered_kernel(engine_lib):
                         continue                                    # nothing to launch
                     assert k in reg or k in ("copy", "aacg_couple_spec", "aacg_couple_pcm", "aacg_spectral_ex_quant", "aacg_spectral_ex_f32"), route
             stages = pf & A.ROUTE_PLAN_TNS or (kin == Q and pf & A.ROUTE_PLAN_PNS)
-            plain = not stages and not pf & (A.ROUTE_PLAN_CCE_INDEPENDENT | A.ROUTE_PLAN_CCE_DEPENDENT | A.ROUTE_PLAN_NO_RUNS)
+            plain = (not stages or kout == O32) and not pf & (A.ROUTE_PLAN_CCE_INDEPENDENT | A.ROUTE_PLAN_CCE_DEPENDENT | A.ROUTE_PLAN_NO_RUNS)
             assert ("_rv" in piped) == bool(plain), (kin, kout, pf, piped)
             if not plain:
                 assert piped == serial

@@ -439,3 +439,54 @@ def test_config3_tns_workload(emu, oracle):
     par = np.zeros(4, np.uint8)
     pcm = emu.decode(units, wl["q"], wl["meta"], wl["n_pcm"], pool, par, tns=tns)
     assert _rel(pcm, ref) < KERNEL_REL_TOL
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seam,S,T", [("q", 128, 16), ("f", 48, 40)])
+def test_gpu_tns_launches_overlapped_equal_launch_behind_launch(oracle, seam, S, T):
+    """AACG_TNS_SPEC batches through aacg_decode_pipelined (aacg_imdct_run_*_ex_rv: the filters inside the run kernel, chains that
+    meet in rendezvous cells — between the runs of a chain longer than 16 frames and between consecutive launches): 40 overlapped
+    launches of one plan against the same launches one behind the other, np.array_equal on the bits, and the overlap state; the
+    first launch against the oracle."""
+    import aacgpu
+    import torch
+    n = 40
+    wl = W.make_batch(n_streams=S, n_frames=T, layout=("cpe",), mix=True, intensity=True, seed=88)
+    C = wl["C"]
+    units, tns = W.add_tns(wl, seed=8, p_channel=0.7)
+    ov = np.zeros((S, C, 1024), np.float32)
+    _, spec = oracle.decode_batch(wl["units"], wl["q"], wl["meta"], wl["n_pcm"], ov, want_spec=True)      # spectra before TNS
+    ov[:] = 0
+    ref = oracle.decode_batch(units, wl["q"], wl["meta"], wl["n_pcm"], ov, tns=tns)
+    kind = aacgpu.INPUT_QUANT_I16 if seam == "q" else aacgpu.INPUT_SPEC_F32
+    host = wl["q"] if seam == "q" else spec.astype(np.float32)
+    ins = [torch.from_numpy(np.ascontiguousarray(np.roll(host, 97 * j, axis=0))).cuda() for j in range(n)]
+    dm = torch.from_numpy(wl["meta"].view(np.int16)).cuda() if seam == "q" else None
+    mp = dm.data_ptr() if dm is not None else None
+    results = []
+    for pipelined in (False, True):
+        eng = aacgpu.Engine(kind, S, C, tns_mode=aacgpu.TNS_SPEC)
+        plan = eng.plan(units, tns=tns)
+        name = eng.plan_kernels(plan, pipelined=pipelined)
+        which = "quant" if seam == "q" else "f32"
+        assert name == ("aacg_imdct_run_%s_ex_rv" % which if pipelined or T > 16 else "aacg_imdct_run_%s_ex" % which)
+        outs = [torch.full((wl["n_pcm"],), float("nan"), dtype=torch.float32, device="cuda") for _ in range(n)]
+        torch.cuda.synchronize()
+        for j in range(n):
+            if pipelined:
+                eng.decode_pipelined(plan, ins[j].data_ptr(), mp, outs[j].data_ptr())
+            else:
+                eng.decode_device(plan, ins[j].data_ptr(), mp, outs[j].data_ptr(), 0)
+        eng.synchronize()
+        torch.cuda.synchronize()
+        if pipelined:
+            assert eng.pipeline_chained() == n - 1
+        results.append(([o.cpu().numpy() for o in outs], _gpu_overlaps(eng, S, C)))
+        plan.destroy()
+        eng.close()
+    (serial, s_state), (piped, p_state) = results
+    assert _rel(serial[0], ref) < KERNEL_REL_TOL
+    for j in range(n):
+        assert not np.isnan(piped[j]).any(), j
+        assert np.array_equal(piped[j].view(np.uint32), serial[j].view(np.uint32)), "launch %d differs from the serialised route" % j
+    assert np.array_equal(p_state.view(np.uint32), s_state.view(np.uint32))

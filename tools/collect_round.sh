@@ -25,6 +25,7 @@ b cfg5_serial --workload cfg5 --serial --steps 1000 --warmup 200 --no-cpu-baseli
 b cfg5_spec --workload cfg5 --input spec --steps 1000 --warmup 200 --no-cpu-baseline
 b cfg3_tns_spec_quant --workload cfg3 --tns spec --steps 1000 --warmup 200 --no-cpu-baseline
 b cfg3_tns_spec_f32 --workload cfg3 --tns spec --input spec --steps 1000 --warmup 200 --no-cpu-baseline
+b cfg3_tns_spec_quant_serial --workload cfg3 --tns spec --serial --steps 1000 --warmup 200 --no-cpu-baseline
 b cfg5_cce_spec --workload cfg5 --cce spec --steps 500 --warmup 100 --no-cpu-baseline
 b quant_i16out --output i16 --no-cpu-baseline
 b quant_i16out_serial --output i16 --serial --no-cpu-baseline

@@ -42,7 +42,7 @@ def main():
     prof = os.path.join(ROOT, "profiles")
     profiled = {"quant": ("prof_quant", "aacg_imdct_run_quant_rv", "cfg2"), "quant_serial": ("prof_quant_serial", "aacg_imdct_run_quant", "cfg2"),
                 "spec": ("prof_spec", "aacg_imdct_run_f32_rv", "cfg2"), "cfg5_quant": ("prof_cfg5", "aacg_imdct_run_quant_rv_nt", "cfg5"),
-                "cfg3_tns_quant_ex": ("prof_cfg3_tns", "aacg_imdct_run_quant_ex", "cfg3")}
+                "cfg3_tns_quant_ex": ("prof_cfg3_tns", "aacg_imdct_run_quant_ex_rv", "cfg3")}
     for p_ in sorted(set(v[0] for v in profiled.values())):
         for suffix in ("summary.txt", "kernel_stats.csv", "intervals.txt"):
             f = os.path.join(src, "%s_%s" % (p_, suffix))
@@ -98,8 +98,9 @@ def main():
             ("config 5 shape, f32 in, overlapped", "cfg5_spec", ""),
             ("int16 in → **int16 PCM**, config 2, overlapped (`aacg_imdct_run_quant_rv_i16`)", "quant_i16out", ""),
             ("int16 PCM, `--serial`", "quant_i16out_serial", ""),
-            ("config 3 + `AACG_TNS_SPEC`, a filter on every channel-frame (one launch, not overlapped)", "cfg3_tns_spec_quant", x_("cfg3_tns_quant_ex", "cfg3_tns_spec_quant")),
+            ("config 3 + `AACG_TNS_SPEC`, a filter on every channel-frame, overlapped (`aacg_imdct_run_quant_ex_rv`)", "cfg3_tns_spec_quant", x_("cfg3_tns_quant_ex", "cfg3_tns_spec_quant")),
             ("the same, f32 seam", "cfg3_tns_spec_f32", ""),
+            ("config 3 + `AACG_TNS_SPEC`, `--serial`", "cfg3_tns_spec_quant_serial", ""),
             ("config 5 + `AACG_CCE_SPEC`, one independent CCE per frame (two launches, not overlapped)", "cfg5_cce_spec", ""),
             ("two disjoint stream sets on two HIP streams, plain kernel (`--pipelines 2`, supplementary: what overlap is worth without a rendezvous)", "quant_pipelines2", ""),
             ("driver's `torch.distributed.run` line, one rank over RCCL", "quant_torchrun_rccl_1rank", "")]
