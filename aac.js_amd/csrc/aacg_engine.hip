@@ -863,7 +863,7 @@ int aacg_decode_pipelined_timed(aacg_engine* e, aacg_plan* p, const void* d_coef
      * together every launch is behind every launch up to n - AACG_OV_BUFFERS + 1, whose buffers and cells it reuses
      * (aacg_device.h).  Otherwise it starts behind everything in flight, from complete state. */
     const bool continues = R.overlappable && pp.open && !pp.serial && pp.plan == p && p->last_pipelined && p->seen_epoch == e->epoch;
-    if (!continues) { pp.n = 0; pp.streams = aacg_pipeline_streams(p->h); }      /* a new sequence */
+    if (!continues) { pp.n = 0; pp.streams = aacg_pipeline_streams(p->h, R.run_key); }      /* a new sequence */
     const aacg_pipe_order ord = aacg_pipeline_order(pp.n, pp.streams);
     hipStream_t s = R.overlappable ? pp.stream[ord.stream] : pp.stream[0];
     if (continues) {

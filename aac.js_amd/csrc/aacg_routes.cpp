@@ -110,7 +110,10 @@ aacg_pipe_order aacg_pipeline_order(uint64_t n, int streams)
     return o;
 }
 
-int aacg_pipeline_streams(const aacg_plan_host& h)
+int aacg_pipeline_streams(const aacg_plan_host& h, unsigned run_key)
 {
-    return h.runs_rv.size() > 512 ? 2 : AACG_PIPE_STREAMS;
+    if (h.runs_rv.size() > 512) return 2;                                   /* several rounds of workgroups per launch */
+    if (run_key & AACG_RK_I16) return 2;                                    /* int16 PCM */
+    if ((run_key & AACG_RK_EX) && (run_key & AACG_RK_QUANT)) return 2;      /* optional stages on the int16 seam */
+    return AACG_PIPE_STREAMS;
 }

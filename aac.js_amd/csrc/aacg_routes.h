@@ -85,11 +85,16 @@ struct aacg_pipe_order {
 };
 #define AACG_PIPE_RING  8             /* marked rounds whose events are kept: > AACG_PIPE_DEPTH(1) / AACG_PIPE_MARK */
 aacg_pipe_order aacg_pipeline_order(uint64_t n, int streams);
-/* How many streams a pipelined sequence of this plan's launches takes in turn.  Three where a launch is about one workgroup per
- * CU: a CU that is done with launch n + 1's workgroup then finds one of launch n + 2 waiting (BASELINE config 2: 11.7 -> 11.3 us;
- * config 4 shape 11.6 -> 11.4).  Two where a launch is several rounds of workgroups anyway: a third launch in flight only
- * scatters the elements of a stream over more of the L2s (config 5 shape: 58.9 us with two, 63.5 with three, same box). */
-int aacg_pipeline_streams(const aacg_plan_host& h);
+/* How many streams a pipelined sequence of this plan's launches takes in turn — measured, route by route (same box, interleaved,
+ * tools/ab.sh; us per launch with two / three streams):
+ *   plain kernels, f32 PCM, a launch = one round of workgroups   config 2: 11.6-11.8 / 11.3;  config 4 shape: 11.6 / 11.4;  f32 seam: - / 12.2
+ *   the same with int16 PCM                                       10.0 / 10.9
+ *   optional stages inside the run kernel (TNS on config 3)       int16 seam 23.7-23.9 / 24.0;  f32 seam 25.5 / 25.0-25.2
+ *   a launch of several rounds of workgroups (config 5 shape)     58.8-59.3 / 63.4-64.2 (a third launch in flight scatters a stream's
+ *                                                                 elements over more of the L2s)
+ * Three where a CU that is done with launch n + 1's workgroup would otherwise find nothing of launch n + 2 to run; two where the
+ * launches in flight already contend for the write path more than that wait costs. */
+int aacg_pipeline_streams(const aacg_plan_host& h, unsigned run_key);
 #endif
 
 #endif

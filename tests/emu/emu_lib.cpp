@@ -343,7 +343,7 @@ int emu_decode_pipelined(int input_kind, int sample_index, int max_streams, int 
     const aacg_route R = aacg_pick_route(input_kind, AACG_OUTPUT_F32, 0, false, ph, true);
     if (!R.overlappable) { g_err = "not a plain batch"; return AACG_ERR_UNSUPPORTED; }
     static unsigned long long epoch = 5000;
-    const int NS = streams > 0 ? streams : aacg_pipeline_streams(ph);          /* streams the sequence takes in turn (0: the engine's choice) */
+    const int NS = streams > 0 ? streams : aacg_pipeline_streams(ph, R.run_key);          /* streams the sequence takes in turn (0: the engine's choice) */
     const size_t cells = (size_t)ph.n_links_rv;
     std::vector<unsigned long long> rv_state(AACG_PIPE_STREAMS * cells * AACG_RV_STATE_WORDS + 1, 0x5a5a5a5a5a5a5a5aull);
     std::vector<float> rv_data(AACG_PIPE_STREAMS * cells * AACG_RV_DATA_FLOATS + 1, std::numeric_limits<float>::quiet_NaN());
