@@ -306,13 +306,26 @@ def main():
 
     pipelined = not args.serial and args.pipelines == 1
 
+    # The enqueue loop is host work per launch, and with the pipeline's back-pressure the host is part of the loop: the C ABI is
+    # called with arguments converted once (ctypes objects per buffer set), not through the convenience wrappers of aacgpu.py.
+    import ctypes
+    _vp = ctypes.c_void_p
+    _ptrs = [(_vp(d_in.data_ptr()), _vp(d_out.data_ptr())) for d_in, d_out in bufs]
+    _meta = _vp(meta_ptr) if meta_ptr is not None else None
+    _h, _lib, _nbuf = _vp(eng.handle.value if hasattr(eng.handle, "value") else eng.handle), eng.lib, args.nbuf
+    _plan_h = [_vp(p.handle.value if hasattr(p.handle, "value") else p.handle) for p in plans]
+    _piped, _piped_timed, _serial = _lib.aacg_decode_pipelined, _lib.aacg_decode_pipelined_timed, _lib.aacg_decode_device
+    _streams = [_vp(t.cuda_stream) for t in tstreams]
+
     def step(i, mark=None):
-        d_in, d_out = bufs[i % args.nbuf]
-        if pipelined:                                  # the engine's two internal streams in turn: launch i may overlap launch i - 1
-            eng.decode_pipelined(plans[0], d_in.data_ptr(), meta_ptr, d_out.data_ptr(), mark)
-            return
-        pl = i % args.pipelines
-        eng.decode_device(plans[pl], d_in.data_ptr(), meta_ptr, d_out.data_ptr(), tstreams[pl].cuda_stream)
+        a, o = _ptrs[i % _nbuf]
+        if pipelined:                                  # the engine's internal streams in turn: launch i may overlap launch i - 1
+            rc = _piped(_h, _plan_h[0], a, _meta, o) if mark is None else _piped_timed(_h, _plan_h[0], a, _meta, o, mark.h)
+        else:
+            pl = i % args.pipelines
+            rc = _serial(_h, _plan_h[pl], a, _meta, o, _streams[pl])
+        if rc:
+            eng._check(rc)
 
     def join():                                        # the timing stream behind everything launched so far
         if pipelined:
