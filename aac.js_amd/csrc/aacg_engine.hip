@@ -88,6 +88,8 @@ struct aacg_engine {
     struct pipe_t {
         hipStream_t stream[AACG_PIPE_STREAMS] = {};
         hipEvent_t mark[AACG_PIPE_RING][AACG_PIPE_STREAMS] = {};   /* completion events of the marked rounds' launches (aacg_pipeline_order) */
+        hipEvent_t seen[AACG_PIPE_RING][AACG_PIPE_STREAMS] = {};   /* the event that stands for each of them: the engine's own, or a caller's timing
+                                                                       mark bound to that launch (aacg_decode_pipelined_timed) — one event per dispatch */
         hipEvent_t tail[AACG_PIPE_STREAMS] = {};   /* joins: everything on stream k so far */
         hipEvent_t fork = nullptr;
         uint64_t n = 0;                     /* overlappable launches of the current sequence so far (aacg_pipeline_order(n, streams)) */
@@ -863,7 +865,7 @@ int aacg_decode_pipelined_timed(aacg_engine* e, aacg_plan* p, const void* d_coef
      * together every launch is behind every launch up to n - AACG_OV_BUFFERS + 1, whose buffers and cells it reuses
      * (aacg_device.h).  Otherwise it starts behind everything in flight, from complete state. */
     const bool continues = R.overlappable && pp.open && !pp.serial && pp.plan == p && p->last_pipelined && p->seen_epoch == e->epoch;
-    if (!continues) { pp.n = 0; pp.streams = aacg_pipeline_streams(p->h, R.run_key); }      /* a new sequence */
+    if (!continues) { pp.n = 0; pp.streams = aacg_pipeline_streams(p->h, R.run_key); std::memset(pp.seen, 0, sizeof pp.seen); }      /* a new sequence */
     const aacg_pipe_order ord = aacg_pipeline_order(pp.n, pp.streams);
     hipStream_t s = R.overlappable ? pp.stream[ord.stream] : pp.stream[0];
     if (continues) {
@@ -874,7 +876,8 @@ int aacg_decode_pipelined_timed(aacg_engine* e, aacg_plan* p, const void* d_coef
             /* (bounded: if an event has not completed after two seconds — a stalled device, a driver that lost a signal — the
              * ordering moves to the GPU for this round, which is always correct, instead of leaving the caller in a wait) */
             const auto deadline = std::chrono::steady_clock::now() + std::chrono::seconds(2);
-            for (hipEvent_t ev : pp.mark[((uint64_t)ord.sync_round / AACG_PIPE_MARK) % AACG_PIPE_RING]) {
+            for (hipEvent_t ev : pp.seen[((uint64_t)ord.sync_round / AACG_PIPE_MARK) % AACG_PIPE_RING]) {
+                if (!ev) continue;
                 hipError_t st;
                 while ((st = hipEventQuery(ev)) == hipErrorNotReady && std::chrono::steady_clock::now() < deadline) {}
                 if (st == hipErrorNotReady) {
@@ -899,7 +902,11 @@ int aacg_decode_pipelined_timed(aacg_engine* e, aacg_plan* p, const void* d_coef
     /* the host will wait for this one: its event rides on the dispatch itself where the route is a single launch
      * (no marker packet between this launch and the next of its stream), else it is recorded behind the route's last launch */
     const bool ordered = R.overlappable && ord.marked;
-    hipEvent_t const mine = pp.mark[(pp.n / (uint64_t)pp.streams / AACG_PIPE_MARK) % AACG_PIPE_RING][ord.stream];
+    const size_t slot = (size_t)((pp.n / (uint64_t)pp.streams / AACG_PIPE_MARK) % AACG_PIPE_RING);
+    /* a caller's timing mark bound to this launch stands for the engine's own event (it must stay alive until the pipeline
+     * has been joined: aacgpu_tools.h) — a second event would be a marker packet in the queue behind the dispatch */
+    hipEvent_t const mine = (stop_mark && R.rv) ? (hipEvent_t)stop_mark : pp.mark[slot][ord.stream];
+    if (ordered) pp.seen[slot][ord.stream] = mine;
     hipEvent_t bound = R.rv ? (stop_mark ? (hipEvent_t)stop_mark : (ordered ? mine : nullptr)) : nullptr;
     rc = launch_run(e, R, p->d_units, p->d_runs, p->d_tns, p->d_scratch, p->d_spec, cb, rvb, p->h, d_coeffs, d_meta, d_pcm,
                     (int)(p->launches % AACG_OV_BUFFERS), s, xl, &epoch, bound);

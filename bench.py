@@ -346,7 +346,11 @@ def main():
         torch.cuda.synchronize()
     for i in range(args.warmup):
         step(n_pre + i)
-    R = max(1, args.repeats)
+    # R repeats of the K-step region.  With overlapped launches a repeat's end is the completion of launches that run side by
+    # side with the next repeat's first ones, so short regions scatter by a launch or so either way around the same mean
+    # (K = 20: 9.2-12.8 us per step over 25 repeats, mean 11.43 both times, medians 11.22 and 11.89 in two runs): short
+    # regions are repeated more often, until about 2000 launches are timed — the median settles, the run stays short.
+    R = max(1, args.repeats, min(200, -(-2000 // max(1, args.steps))) if args.repeats == 25 else args.repeats)
     # Timing marks: HIP events that only measure time (hipEventDisableSystemFence, aacg_timer_*).  A default event's record is
     # a system-scope fence — cache write-back and invalidation — and the launch behind it starts on cold caches: at the
     # driver's K = 20 that is one fence per 240 us of launches (12.45 against 12.13 us per step at K = 2000 on one box).

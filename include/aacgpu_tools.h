@@ -23,7 +23,9 @@ int aacg_timer_record(void* mark, void* hip_stream);
 int aacg_timer_elapsed_ms(void* first, void* second, float* ms);
 void aacg_timer_destroy(void* mark);
 /* aacg_decode_pipelined with a timing mark bound to the launch's completion (its time stamp is the end of that dispatch; no marker
- * packet enters the queue): bench.py brackets its timed regions with the marks of the launches at their ends. */
+ * packet enters the queue): bench.py brackets its timed regions with the marks of the launches at their ends.  The mark also stands
+ * for the engine's own completion event of that launch (one event per dispatch), so it must stay alive until the pipeline has
+ * been joined (aacg_pipeline_join / aacg_synchronize) or a new sequence has begun. */
 int aacg_decode_pipelined_timed(aacg_engine* e, aacg_plan* p, const void* d_coeffs, const aacg_band_meta* d_meta, void* d_pcm, void* stop_mark);
 /* How many launches of aacg_decode_pipelined continued the launch before them through the cross-launch cells (and so were
  * allowed to overlap it) since the engine was made: tests assert that the route they mean to exercise was taken. */
