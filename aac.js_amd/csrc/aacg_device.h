@@ -199,6 +199,9 @@ struct aacg_kparams {
  * ride in fields those kernels have no other use for — no double duty (scratch), no optional stages (pns), no spectral
  * output (spec_out) — so that the kernel arguments of every other launch stay as they are (a longer argument block costs the
  * headline kernel its measured 0.05 us, and the layout of that block has cost it 0.35 us before: DESIGN.md 6). */
+/* AACG_TNS_SPEC launches (the run kernels with the stages inside, the staged spectral kernel) take the plan's transition
+ * matrices (tns_matrix_row, aacg_kernels.h) the same way: in `scratch`, which those launches have no other use for. */
+static inline void aacg_set_tns_m(aacg_kparams* P, const double* m) { P->scratch = (float*)(void*)m; }
 static inline void aacg_set_cpl(aacg_kparams* P, const aacg_couple_job* jobs, const float* gains, const float* side)
 {
     P->scratch = (float*)(void*)jobs; P->pns = (const aacg_pns_tables*)(const void*)gains; P->spec_out = (float*)side;

@@ -45,6 +45,7 @@ void aacg_refresh_launch(aacg_dev_unit* units, const aacg_unit_desc* parsed, con
 /* aacg_engine_spectral.hip: the optional stages (AACG_PNS_SPEC noise bands, AACG_TNS_SPEC filters) -> f32 spectra */
 int aacg_spectral_ex_set_lds_limits(void);
 void aacg_spectral_ex_launch(bool quant, int n_units, hipStream_t s, const aacg_kparams& P);
+void aacg_tns_matrices_launch(const aacg_dev_tns* d_recs, double* d_m, uint32_t n_records, hipStream_t s);
 /* aacg_engine_couple.hip: AACG_CCE_SPEC */
 void aacg_couple_launch(bool pcm, hipStream_t s, const aacg_couple_params& Q);
 struct cce_bufs { const aacg_run* runs; const aacg_couple_job* jobs; const float* gains; float* side; };
@@ -267,6 +268,12 @@ int launch_kernel(aacg_engine* e, const aacg_run_kernel* k, unsigned blocks, hip
     return AACG_OK;
 }
 
+/* A plan's TNS records and, behind them in the same buffer, their transition matrices (tns_matrix_row, aacg_kernels.h: made on
+ * the device by aacg_tns_matrices when the records are uploaded, read by every launch that runs filters). */
+static size_t tns_record_bytes(size_t n) { return (sizeof(aacg_dev_tns) * n + 255u) & ~(size_t)255u; }
+static size_t tns_buffer_bytes(size_t n) { return n ? tns_record_bytes(n) + sizeof(double) * AACG_TNS_M_DOUBLES * n : 0; }
+static double* tns_matrices_of(const aacg_dev_tns* d_tns, size_t n) { return (double*)((char*)const_cast<aacg_dev_tns*>(d_tns) + tns_record_bytes(n)); }
+
 /* what a pipelined launch adds to the rendezvous arguments: the cross-launch cells, the epoch its input state carries, and
  * which of the plan's two sets of in-launch cells it uses (overlapping launches must not share one) */
 struct xl_args { bool on; unsigned long long epoch_in; int set; int trace_part = 0; };   /* trace_part: which quarter of the profiling buffer this launch stamps */
@@ -292,7 +299,10 @@ int launch_run(aacg_engine* e, const aacg_route& R, const aacg_dev_unit* d_units
         V.data = rvb.data ? rvb.data + (size_t)xl.set * AACG_RV_DATA_FLOATS * n_links : nullptr;
         V.epoch = ++e->rv_epoch;
         if (xl.on) { V.xl_cells = e->d_xl_cells; V.xl_head = e->d_xl_head; V.epoch_in = xl.epoch_in; }
-        if (R.run_key & AACG_RK_EX) { P.tns = h.any_tns ? d_tns : nullptr; P.pns = e->d_pns; }    /* optional stages inside the run kernel */
+        if (R.run_key & AACG_RK_EX) {                    /* optional stages inside the run kernel */
+            P.tns = h.any_tns ? d_tns : nullptr; P.pns = e->d_pns;
+            if (h.any_tns) aacg_set_tns_m(&P, tns_matrices_of(d_tns, h.tns.size()));
+        }
         if (epoch_out) *epoch_out = V.epoch;
         if (e->d_trace) { P.ablate = e->ablate; P.spec_out = (float*)e->d_trace + (size_t)xl.trace_part * (1u << 18); }   /* profiling builds: the last four launches keep their stamps */
         return launch_kernel(e, aacg_find_run_kernel(R.run_key), (unsigned)n_runs, s, P, &V, stop);
@@ -323,7 +333,7 @@ int launch_run(aacg_engine* e, const aacg_route& R, const aacg_dev_unit* d_units
         couple(AACG_CCE_BEFORE_TNS);
         if (h.any_tns) {
             P.coeffs = d_spec; P.meta = nullptr; P.tns = d_tns;
-            aacg_spectral_ex_launch(false, (int)h.units.size(), s, P);
+            { aacg_kparams Q = P; aacg_set_tns_m(&Q, tns_matrices_of(d_tns, h.tns.size())); aacg_spectral_ex_launch(false, (int)h.units.size(), s, Q); }
         }
         couple(AACG_CCE_AFTER_TNS);
         P.spec_out = trace_or_null; P.coeffs = d_spec; P.meta = nullptr; P.tns = nullptr;
@@ -331,10 +341,11 @@ int launch_run(aacg_engine* e, const aacg_route& R, const aacg_dev_unit* d_units
         /* the optional stages first, as a launch of their own that leaves f32 spectra, which the f32 run kernel takes from there */
         float* trace_or_null = P.spec_out;
         P.spec_out = d_spec; P.pns = e->d_pns;
-        aacg_spectral_ex_launch(R.stage_quant, (int)h.units.size(), s, P);
+        { aacg_kparams Q = P; if (h.any_tns) aacg_set_tns_m(&Q, tns_matrices_of(d_tns, h.tns.size())); aacg_spectral_ex_launch(R.stage_quant, (int)h.units.size(), s, Q); }
         P.spec_out = trace_or_null; P.coeffs = d_spec; P.meta = nullptr; P.tns = nullptr;
     } else if (R.has_run && (R.run_key & AACG_RK_EX)) {
         P.pns = e->d_pns;                                /* optional stages (noise bands, TNS filters) inside the run kernel: one launch */
+        if (h.any_tns) aacg_set_tns_m(&P, tns_matrices_of(d_tns, h.tns.size()));
     }
     int rc = AACG_OK;
     auto side_pass = [&]() {                            /* the independently switched coupling elements' own filterbank pass */
@@ -666,7 +677,7 @@ int aacg_plan_create_ex(aacg_engine* e, const aacg_unit_desc* units, uint32_t n_
     }
     const size_t ub = sizeof(aacg_dev_unit) * n_units, rb = sizeof(aacg_run) * p->h.runs.size();
     const size_t xb = needs_spec_buffer(e, p->h) ? (size_t)p->h.coef_blocks * 1024u * sizeof(float) : 0;
-    const size_t tb = sizeof(aacg_dev_tns) * p->h.tns.size();
+    const size_t tb = tns_buffer_bytes(p->h.tns.size());
     const size_t sb = p->h.needs_scratch ? p->h.runs.size() * AACG_SLOT_FLOATS * sizeof(float) : 0;
     const size_t cb[4] = {sizeof(aacg_run) * p->h.cce_runs.size(), sizeof(aacg_couple_job) * p->h.couple_jobs.size(),
                           sizeof(float) * p->h.gains.size(), (size_t)p->h.side_blocks * 4096u};
@@ -689,7 +700,8 @@ int aacg_plan_create_ex(aacg_engine* e, const aacg_unit_desc* units, uint32_t n_
         if (!want[i]) continue;
         *slot[i] = pool_take(e, want[i], &p->bytes[i]);
         ok = *slot[i] != nullptr &&
-             (!src[i] || hip_ok(e, hipMemcpyAsync(*slot[i], src[i], want[i], hipMemcpyHostToDevice, e->stream), "upload plan tables"));
+             (!src[i] || hip_ok(e, hipMemcpyAsync(*slot[i], src[i], i == 2 ? sizeof(aacg_dev_tns) * p->h.tns.size() : want[i], hipMemcpyHostToDevice, e->stream), "upload plan tables"));
+        if (ok && i == 2) aacg_tns_matrices_launch(p->d_tns, tns_matrices_of(p->d_tns, p->h.tns.size()), (uint32_t)p->h.tns.size(), e->stream);   /* behind the records, once */
         /* rendezvous state words count only with a launch's epoch in them; a recycled or fresh buffer starts from zero all the same */
         if (ok && i == 11) ok = hip_ok(e, hipMemsetAsync(*slot[i], 0, want[i], e->stream), "zero rendezvous state");
     }
@@ -1125,7 +1137,7 @@ int aacg_submit_ex(aacg_engine* e, const aacg_batch* batch, uint64_t* ticket)
     }
 
     const size_t ub = sizeof(aacg_dev_unit) * h.units.size(), rb = sizeof(aacg_run) * h.runs.size();
-    const size_t tb = sizeof(aacg_dev_tns) * h.tns.size();
+    const size_t tb = tns_buffer_bytes(h.tns.size());
     const size_t sb = h.needs_scratch ? h.runs.size() * AACG_SLOT_FLOATS * sizeof(float) : 0;
     const size_t xb = needs_spec_buffer(e, h) ? (size_t)n_coef_blocks * 1024u * sizeof(float) : 0;
     const size_t ccb[4] = {sizeof(aacg_run) * h.cce_runs.size(), sizeof(aacg_couple_job) * h.couple_jobs.size(),
@@ -1177,7 +1189,10 @@ int aacg_submit_ex(aacg_engine* e, const aacg_batch* batch, uint64_t* ticket)
     if (rb) HIP_TRY(e, hipMemcpyAsync(sl.d_runs, h.runs.data(), rb, hipMemcpyHostToDevice, s), AACG_ERR_NO_DEVICE);
     if (rvs[0]) HIP_TRY(e, hipMemcpyAsync(sl.d_rv[0], h.runs_rv.data(), rvs[0], hipMemcpyHostToDevice, s), AACG_ERR_NO_DEVICE);
     if (rvs[1]) HIP_TRY(e, hipMemcpyAsync(sl.d_rv[1], h.links_rv.data(), rvs[1], hipMemcpyHostToDevice, s), AACG_ERR_NO_DEVICE);
-    if (tb) HIP_TRY(e, hipMemcpyAsync(sl.d_tns, h.tns.data(), tb, hipMemcpyHostToDevice, s), AACG_ERR_NO_DEVICE);
+    if (tb) {
+        HIP_TRY(e, hipMemcpyAsync(sl.d_tns, h.tns.data(), sizeof(aacg_dev_tns) * h.tns.size(), hipMemcpyHostToDevice, s), AACG_ERR_NO_DEVICE);
+        aacg_tns_matrices_launch((const aacg_dev_tns*)sl.d_tns, tns_matrices_of((const aacg_dev_tns*)sl.d_tns, h.tns.size()), (uint32_t)h.tns.size(), s);
+    }
     for (int i = 0; i < 3; i++) if (ccb[i]) HIP_TRY(e, hipMemcpyAsync(sl.d_cce[i], cce_src[i], ccb[i], hipMemcpyHostToDevice, s), AACG_ERR_NO_DEVICE);
     HIP_TRY(e, hipMemcpyAsync(sl.d_coeffs, src_coeffs, cb, hipMemcpyHostToDevice, s), AACG_ERR_NO_DEVICE);
     if (quant) HIP_TRY(e, hipMemcpyAsync(sl.d_meta, src_meta, mb, hipMemcpyHostToDevice, s), AACG_ERR_NO_DEVICE);

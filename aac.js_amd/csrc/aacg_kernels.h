@@ -1335,9 +1335,51 @@ DP_DEVICE void tns_run(float* blk, int inc, int chunks, int n_valid, const float
     }
 }
 
-/* one long-window filter of each channel (slot f of the records; order 0 / null record = nothing to do in that half) */
+/* Row r of M = A^BL, the transition of a block of BL samples (A: the filter's companion matrix — first row -lpc, ones below
+ * the diagonal): w <- w A, BL times, from e_r, in double precision (in float32 the transitions of a near-unstable filter lose
+ * the state: 2e-3 of the signal against 2e-6).  It depends on the filter only, not on the data: 768 of a wave's ~7000 issue
+ * slots per pass when every wave derived it for itself, so it is made ONCE per plan by a kernel of its own
+ * (aacg_tns_matrices, aacg_engine_spectral.hip: one lane per row, this very function) and read back by the row lanes —
+ * 96 bytes per lane, requested before the block's zero-state pass and in the registers after it. */
+#define AACG_TNS_M_DOUBLES (3 * AACG_TNS_MAX_ORDER * AACG_TNS_MAX_ORDER)      /* per channel record: [filter slot 0..2][row][column] */
+/* where they ride in the kernel arguments of the launches that run filters (aacg_set_tns_m, aacg_device.h) */
+DP_DEVICE const double* aacg_tns_m(const aacg_kparams& P) { return (const double*)(const void*)P.scratch; }
+DP_DEVICE void tns_matrix_row(const float (&lpc)[AACG_TNS_MAX_ORDER], int r, double (&row)[AACG_TNS_MAX_ORDER])
+{
+    constexpr int P = AACG_TNS_MAX_ORDER, BL = 32;
+#pragma unroll
+    for (int k = 0; k < P; k++) row[k] = (k == r) ? 1.0 : 0.0;
+#pragma unroll 2
+    for (int step = 0; step < BL; step++) {
+        const double w0 = row[0];
+#pragma unroll
+        for (int k = 0; k < P - 1; k++) row[k] = dp_fma(-w0, (double)lpc[k], row[k + 1]);
+        row[P - 1] = -w0 * (double)lpc[P - 1];
+    }
+}
+/* the matrices of one channel record's long-window filter slots: lane = 16 f + r of the record's 64 */
+DP_DEVICE void tns_matrices_body(const aacg_dev_tns* recs, double* M, uint32_t n_records)
+{
+    constexpr int P = AACG_TNS_MAX_ORDER;
+    const uint32_t rec = (uint32_t)dp_block() * AACG_WG_WAVES + (uint32_t)dp_wave();
+    const int lane = dp_lane(), f = lane >> 4, r = lane & 15;
+    if (rec >= n_records || f >= 3 || r >= P) return;
+    const aacg_dev_tns* t = recs + rec;
+    const int order = t->order[f];
+    float lpc[P];
+#pragma unroll
+    for (int k = 0; k < P; k++) lpc[k] = (k < order) ? t->lpc[f][k] : 0.0f;
+    double row[P];
+    tns_matrix_row(lpc, r, row);
+    double* dst = M + (size_t)rec * AACG_TNS_M_DOUBLES + (size_t)(f * P + r) * P;
+#pragma unroll
+    for (int k = 0; k < P; k++) dst[k] = row[k];
+}
+
+/* one long-window filter of each channel (slot f of the records; order 0 / null record = nothing to do in that half).
+ * mA / mB: the records' transition matrices (AACG_TNS_M_DOUBLES each; null where the record is) */
 template <int R>
-DP_DEVICE void tns_long_pass(float* slot, float* xch, const aacg_dev_tns* recA, const aacg_dev_tns* recB, int f)
+DP_DEVICE void tns_long_pass(float* slot, float* xch, const aacg_dev_tns* recA, const aacg_dev_tns* recB, int f, const double* mA, const double* mB)
 {
     constexpr int P = AACG_TNS_MAX_ORDER, BL = AACG_TNS_BLOCK;
     const int lane = dp_lane(), half = lane >> 5, b = lane & 31;
@@ -1360,25 +1402,25 @@ DP_DEVICE void tns_long_pass(float* slot, float* xch, const aacg_dev_tns* recA, 
     const int n_valid = order > 0 ? (size - m0 < 0 ? 0 : (size - m0 > BL ? BL : size - m0)) : 0;
     float* blk = area + (inc > 0 ? start + m0 : start - m0 - 3);
 
+    /* 2 (its loads first). row r of M = A^BL (tns_matrix_row).  Every row of sixteen lanes holds the twelve rows (lane r of
+     * the row: row r): the carry below then never leaves a lane row.  Lanes r16 >= P and halves without a filter: zeros,
+     * they ride along. */
+    const int r16 = lane & 15;
+    double row[P];
+    const double* mrec = half ? mB : mA;
+    {
+        const bool have = mrec != nullptr && order > 0 && r16 < P;
+        const double* src = have ? mrec + (size_t)(f * P + r16) * P : (mA ? mA : mB);     /* (always a readable address: one of the two is a record's) */
+#pragma unroll
+        for (int k = 0; k < P; k += 2) { const dpd2 t = *(const dpd2*)(src + k); row[k] = have ? t.x : 0.0; row[k + 1] = have ? t.y : 0.0; }
+    }
+
     /* 1. zero-state response; the state it leaves is the block's own contribution c_b to the state behind it */
     float c_own[P];
 #pragma unroll
     for (int k = 0; k < P; k++) c_own[k] = 0.0f;
     tns_run<P, false>(blk, inc, BL / 4, n_valid, lpc, c_own);
 
-    /* 2. row r of M = A^BL: w <- w A, BL times, from e_r (A: first row -lpc, ones below the diagonal).  Every row of
-     * sixteen lanes holds the twelve rows (lane r of the row: row r): the carry below then never leaves a lane row */
-    const int r16 = lane & 15;
-    double row[P];                                       /* lanes r16 >= P: zeros, they ride along */
-#pragma unroll
-    for (int k = 0; k < P; k++) row[k] = (k == r16) ? 1.0 : 0.0;
-#pragma unroll 2
-    for (int step = 0; step < BL; step++) {
-        const double w0 = row[0];
-#pragma unroll
-        for (int k = 0; k < P - 1; k++) row[k] = dp_fma(-w0, (double)lpc[k], row[k + 1]);
-        row[P - 1] = -w0 * (double)lpc[P - 1];
-    }
 
     /* 3. serial carry: v_0 = c_0; v_s = M v_(s-1) + c_s.  s_in = this block's incoming state (y[-1-k]).
      * What this loop costs is LDS time, one pipe for the CU's 16 waves (a wave-wide 16-byte store takes 13 cycles to
@@ -1460,12 +1502,16 @@ DP_DEVICE void tns_short_pass(float* slot, const aacg_dev_tns* recA, const aacg_
 /* All TNS filters of a unit, in place on its spectra in the slot (channel c at slot + 1024 c, ICStream.data order).
  * rec0 / rec1: the channels' records, null where a channel has none. */
 template <int R>
-DP_DEVICE void tns_unit(float* slot, float* xch, const aacg_dev_tns* rec0, const aacg_dev_tns* rec1, bool short0, bool short1)
+DP_DEVICE void tns_unit(float* slot, float* xch, const aacg_dev_tns* rec0, const aacg_dev_tns* rec1, bool short0, bool short1,
+                        const aacg_dev_tns* recs = nullptr, const double* M = nullptr)
 {
     const aacg_dev_tns* l0 = short0 ? nullptr : rec0;
     const aacg_dev_tns* l1 = short1 ? nullptr : rec1;
+    /* the records' transition matrices: same index as the record */
+    const double* m0 = (M && l0) ? M + (size_t)(l0 - recs) * AACG_TNS_M_DOUBLES : nullptr;
+    const double* m1 = (M && l1) ? M + (size_t)(l1 - recs) * AACG_TNS_M_DOUBLES : nullptr;
     if (l0 || l1)
-        for (int f = 0; f < 3; f++) tns_long_pass<R>(slot, xch, l0, l1, f);   /* up to three filters, disjoint band ranges (tns.js:119-124) */
+        for (int f = 0; f < 3; f++) tns_long_pass<R>(slot, xch, l0, l1, f, m0, m1);   /* up to three filters, disjoint band ranges (tns.js:119-124) */
     if ((short0 && rec0) || (short1 && rec1)) tns_short_pass(slot, rec0, rec1, short0, short1);
 }
 
@@ -2128,7 +2174,7 @@ DP_DEVICE void imdct_run_body(const aacg_kparams& P, const aacg_rv_args* V = nul
                 if (n_ch == 2) stage_nat8(xr, slot + 1024);
                 dp_wave_sync();
                 tns_unit<AACG_RUN_TNS_ROUND>(slot, xch, u.tns[0] ? P.tns + u.tns_offset : nullptr, (n_ch == 2 && u.tns[1]) ? P.tns + u.tns_offset + 1 : nullptr,
-                                             u.seq[0] == AACG_EIGHT_SHORT_SEQUENCE, u.seq[1] == AACG_EIGHT_SHORT_SEQUENCE);
+                                             u.seq[0] == AACG_EIGHT_SHORT_SEQUENCE, u.seq[1] == AACG_EIGHT_SHORT_SEQUENCE, P.tns, aacg_tns_m(P));
 #pragma unroll
                 for (int i = 0; i < 2; i++) {
                     const dpf4 a = *(const dpf4*)(slot + 8 * lane + 512 * i), b = *(const dpf4*)(slot + 8 * lane + 512 * i + 4);
@@ -2154,7 +2200,7 @@ DP_DEVICE void imdct_run_body(const aacg_kparams& P, const aacg_rv_args* V = nul
                 }
                 dp_wave_sync();
                 tns_unit<AACG_RUN_TNS_ROUND>(slot, xch, u.tns[0] ? P.tns + u.tns_offset : nullptr, (n_ch == 2 && u.tns[1]) ? P.tns + u.tns_offset + 1 : nullptr,
-                                             u.seq[0] == AACG_EIGHT_SHORT_SEQUENCE, u.seq[1] == AACG_EIGHT_SHORT_SEQUENCE);
+                                             u.seq[0] == AACG_EIGHT_SHORT_SEQUENCE, u.seq[1] == AACG_EIGHT_SHORT_SEQUENCE, P.tns, aacg_tns_m(P));
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
                     xa[i] = *(const dpf4*)(slot + 4 * lane + 256 * i);
@@ -2358,7 +2404,7 @@ DP_DEVICE void spectral_ex_body(const aacg_kparams& P, int n_units)
         if (n_ch == 2) stage_nat8(xr, slot + 1024);
         dp_wave_sync();
         tns_unit<AACG_SPX_TNS_ROUND>(slot, xch, tns0 ? P.tns + u.tns_offset : nullptr, tns1 ? P.tns + u.tns_offset + 1 : nullptr,
-                 u.seq[0] == AACG_EIGHT_SHORT_SEQUENCE, u.seq[1] == AACG_EIGHT_SHORT_SEQUENCE);
+                 u.seq[0] == AACG_EIGHT_SHORT_SEQUENCE, u.seq[1] == AACG_EIGHT_SHORT_SEQUENCE, P.tns, aacg_tns_m(P));
 #pragma unroll
         for (int i = 0; i < 2; i++) {
             const dpf4 a = *(const dpf4*)(slot + 8 * lane + 512 * i), b = *(const dpf4*)(slot + 8 * lane + 512 * i + 4);

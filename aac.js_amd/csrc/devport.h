@@ -24,6 +24,7 @@
 
 typedef float2 dpf2;
 typedef float4 dpf4;
+typedef double2 dpd2;
 typedef int4   dpi4;
 typedef uint2  dpu2;
 /* (left, right) channel pair: every arithmetic op on it is one v_pk_*_f32 */

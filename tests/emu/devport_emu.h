@@ -23,6 +23,7 @@
 #define DP_KERNEL(a, b)
 
 struct alignas(8)  dpf2 { float x, y; };
+struct alignas(16) dpd2 { double x, y; };
 struct alignas(16) dpf4 { float x, y, z, w; };
 struct alignas(16) dpi4 { int x, y, z, w; };
 struct alignas(8)  dpu2 { uint32_t x, y; };

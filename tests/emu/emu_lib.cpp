@@ -67,6 +67,7 @@ void* lane_main(void* p)
     else if (a->kind == 9) couple_pcm_body(*a->Q, 4);
     else if (a->kind == 3) spectral_ex_body<AACG_INPUT_QUANT_I16>(*a->P, a->n_units);
     else if (a->kind == 4) spectral_ex_body<AACG_INPUT_SPEC_F32>(*a->P, a->n_units);
+    else if (a->kind == 10) tns_matrices_body(a->P->tns, (double*)(void*)a->P->scratch, (uint32_t)a->n_units);
     else                   spectral_body(*a->P, a->n_units);
     return nullptr;
 }
@@ -251,6 +252,14 @@ int emu_decode_cce(int input_kind, int sample_index, int max_streams, int max_ch
     P.tns = ph.any_tns ? ph.tns.data() : nullptr;
     std::vector<float> scratch(ph.needs_scratch ? ph.runs.size() * AACG_SLOT_FLOATS : 1, 0.0f);
     P.scratch = ph.needs_scratch ? scratch.data() : nullptr;
+    /* the plan's TNS transition matrices, made once by a kernel of their own (aacg_tns_matrices): what the engine does when it
+     * creates the plan; they ride in `scratch` for the launches that run filters (aacg_set_tns_m) */
+    std::vector<double> tns_m(ph.any_tns ? ph.tns.size() * AACG_TNS_M_DOUBLES : 1, std::numeric_limits<double>::quiet_NaN());
+    if (ph.any_tns) {
+        aacg_kparams T = P;
+        aacg_set_tns_m(&T, tns_m.data());
+        launch(T, 10, 0, (int)((ph.tns.size() + AACG_WG_WAVES - 1) / AACG_WG_WAVES), AACG_WG_WAVES, 64, (int)ph.tns.size());
+    }
     std::vector<float> spec;
     static aacg_pns_tables pns_tab;
     aacg_build_pns_tables(sample_index, &pns_tab);
@@ -277,7 +286,7 @@ int emu_decode_cce(int input_kind, int sample_index, int max_streams, int max_ch
         if (g_rv == 2) { std::reverse(runs.begin(), runs.end()); std::reverse(links.begin(), links.end()); }
         aacg_kparams K = P;
         K.runs = runs.data(); K.n_runs = (int32_t)runs.size(); K.scratch = nullptr;
-        if (R.run_key & AACG_RK_EX) K.pns = &pns_tab;      /* optional stages inside the run kernel */
+        if (R.run_key & AACG_RK_EX) { K.pns = &pns_tab; if (ph.any_tns) aacg_set_tns_m(&K, tns_m.data()); }      /* optional stages inside the run kernel */
         aacg_rv_args V;
         std::memset(&V, 0, sizeof V);
         V.links = links.data(); V.state = rv_state.data(); V.data = rv_data.data(); V.epoch = ++epoch;
@@ -291,7 +300,7 @@ int emu_decode_cce(int input_kind, int sample_index, int max_streams, int max_ch
             else std::memcpy(spec.data(), coeffs, spec.size() * sizeof(float));
             couple(AACG_CCE_BEFORE_TNS);
             if (ph.any_tns) {
-                Q.coeffs = spec.data(); Q.meta = nullptr; Q.tns = ph.tns.data();
+                Q.coeffs = spec.data(); Q.meta = nullptr; Q.tns = ph.tns.data(); aacg_set_tns_m(&Q, tns_m.data());
                 launch(Q, 4, 0, unit_blocks, AACG_WG_WAVES, AACG_WG_WAVES * AACG_SPX_WAVE_FLOATS * 4, (int)n_units);
             }
             couple(AACG_CCE_AFTER_TNS);
@@ -299,10 +308,10 @@ int emu_decode_cce(int input_kind, int sample_index, int max_streams, int max_ch
         } else if (R.stage == AACG_STAGE_SPECTRAL_EX) {
             spec.assign((size_t)ph.coef_blocks * 1024u, 0.0f);
             aacg_kparams Q = P;
-            Q.spec_out = spec.data(); Q.pns = &pns_tab;
+            Q.spec_out = spec.data(); Q.pns = &pns_tab; if (ph.any_tns) aacg_set_tns_m(&Q, tns_m.data());
             launch(Q, R.stage_quant ? 3 : 4, 0, unit_blocks, AACG_WG_WAVES, ((R.stage_quant ? AACG_SPX_TAB_FLOATS : 0) + AACG_WG_WAVES * AACG_SPX_WAVE_FLOATS) * 4, (int)n_units);
             P.coeffs = spec.data(); P.meta = nullptr; P.tns = nullptr;
-        } else if (R.has_run && (R.run_key & AACG_RK_EX)) P.pns = &pns_tab;
+        } else if (R.has_run && (R.run_key & AACG_RK_EX)) { P.pns = &pns_tab; if (ph.any_tns) aacg_set_tns_m(&P, tns_m.data()); }
         auto side_pass = [&]() {
             aacg_kparams C = P;
             C.runs = ph.cce_runs.data(); C.n_runs = (int32_t)ph.cce_runs.size(); C.pcm = side.data(); C.scratch = nullptr;
