@@ -2136,9 +2136,6 @@ DP_DEVICE void imdct_run_body(const aacg_kparams& P, const aacg_rv_args* V = nul
     stage_tables_store(lds, TAB_FLOATS, tr0, tr1);
     if (lane == 0) flags[wave] = 0;
     dp_block_sync_lds();                               /* tables and flags are in LDS */
-#ifdef AACG_EXP_JIT
-    if (!early && wave >= AACG_EXP_JIT) dp_flag_wait(&flags[wave - 8], 1);     /* experiment: requests just in time */
-#endif
     if (!early) issue_loads(w_coef, w_meta, w_nch);
     if (trace && lane == 0) trace[1] = dp_clock();
     n_ch = active ? u.n_ch : 0;

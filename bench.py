@@ -10,15 +10,17 @@ buffer sets so that no step is served from the 256 MiB Infinity Cache.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--input quant|spec] [--workload cfg2|cfg3|cfg4|cfg5] [--tns reference|spec]
 
-Launches: consecutive steps go through aacg_decode_pipelined — the engine's two internal HIP streams taken in turn, so that
+Launches: consecutive steps go through aacg_decode_pipelined — the engine's internal HIP streams taken in turn, so that
 step k + 1 starts on the compute units step k has already left; the chains of the two launches meet in rendezvous cells
 (include/aacgpu.h; --serial: aacg_decode_device on one stream, every launch behind the one before it, the method of rounds
 1-4).  ONE plan, ONE set of 256 streams continued launch after launch either way (`config.pipelines` 1).
 
-Timing: W untimed warm-up steps, then the timed region of exactly K steps — R times back to back (--repeats, default 25),
-every repeat bracketed by its own HIP events on the timing stream, which the engine joins behind the pipeline's launches in
-front of every mark (aacg_pipeline_join: a mark's time stamp is the completion of the launches before it), the whole set
-between barrier + synchronize on both sides.  `ms_per_step` = MEDIAN over the R repeats of (MAX over ranks of the repeat's event time) / K (SURVEY.md 8d asks
+Timing: W untimed warm-up steps, then the timed region of exactly K steps — R times back to back (--repeats, default 25;
+regions shorter than 80 steps are repeated until about 2000 launches are timed).  A repeat ends when its last launches —
+one per pipeline stream: they run side by side — are complete: HIP events bound to those dispatches' completion
+(aacg_decode_pipelined_timed; no marker packet enters a queue, nothing is joined inside the timed region); the opening mark is
+recorded on the timing stream joined behind the warm-up steps; the whole set between barrier + synchronize on both sides
+(--serial: every repeat between its own events on the launch stream).  `ms_per_step` = MEDIAN over the R repeats of (MAX over ranks of the repeat's event time) / K (SURVEY.md 8d asks
 for a median; one 0.25 ms window says nothing about its own spread), `timing` carries min / max / first / R, and
 `value` = frames of all ranks per step / that median.  The host's clock between the barriers is reported beside it
 (`wall_ms_per_step`, `value_wall`: adds the launch latency of the first step and the wake-up after the last one).

@@ -912,7 +912,7 @@ def _device_batches(torch, base, n, seam, oracle, seed):
                                                     (("cpe",), 32, 128, 64, "q", True), (("cpe", "cpe", "cpe", "sce"), 64, 16, 64, "q", True),
                                                     (("sce",), 700, 3, 64, "q", True)])
 def test_pipelined_launches_equal_the_serialised_route_bit_for_bit(oracle, layout, S, T, n, seam, mix):
-    """>= 64 back-to-back launches of ONE plan through aacg_decode_pipelined (two internal streams taken in turn; the chains of
+    """>= 64 back-to-back launches of ONE plan through aacg_decode_pipelined (the engine's internal streams taken in turn; the chains of
     neighbouring launches meet in cross-launch cells, nobody waits) against the same launches through aacg_decode_device on one
     stream (the plain kernels, every launch behind the one before it): np.array_equal on uint32 views, every launch's PCM and
     the final overlap state — BASELINE config 2 / 3 / 4 / 5 shapes, a grid larger than the chip (both arrival orders occur),
