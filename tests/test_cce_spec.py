@@ -339,3 +339,45 @@ def test_js_host_coupling_gpu(oracle, tmp_path):
     ref = oracle.decode_batch(units, q, meta, n * 1024 * C, np.zeros((1, H, 1024), np.float32), cce=cce)
     pcm = np.fromfile(os.path.join(out, "coupling.pcm"), np.float32)
     assert pcm.size == ref.size and rel(pcm, ref) < RMS_REL
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("layout,points,T,S", [(("cpe", "cpe", "cpe", "sce"), (2,), 16, 64), (("sce", "cpe"), (2, 2), 9, 40)])
+def test_gpu_coupling_through_the_pipeline_equals_launch_behind_launch(oracle, layout, points, T, S):
+    """Batches with fused independent coupling through aacg_decode_pipelined (no rendezvous build: launch behind launch on the
+    pipeline's first stream): 24 launches of one plan that way against the same launches through aacg_decode_device — the same
+    bits, PCM and overlap state; the first launch against the oracle.  (Round 5 also ran the coupling elements' pass of launch
+    n + 1 beside the main launch n, on a stream and a side buffer of its own: the same bits, 90.8 us against 87.3 — the two
+    kernels contend for the chip and the two event waits per step cost more than the pass's ramp and drain; not kept.)"""
+    import torch
+    n = 24
+    wl = aacgpu_workload.make_batch(n_streams=S, n_frames=T, layout=layout, mix=True, seed=31)
+    H = wl["C"] + len(points)
+    units, q, meta, cce = aacgpu_workload.add_cce(wl, points=points, seed=500)
+    ins = [torch.from_numpy(np.ascontiguousarray(np.roll(q, 53 * j, axis=0))).cuda() for j in range(n)]
+    dm = torch.from_numpy(meta.view(np.int16)).cuda()
+    results = []
+    for pipelined in (False, True):
+        eng = aacgpu.Engine(aacgpu.INPUT_QUANT_I16, max_streams=S, max_channels=H, cce_mode=aacgpu.CCE_SPEC)
+        plan = eng.plan(units, cce=cce)
+        assert "_cpl" in eng.plan_kernels(plan, pipelined=pipelined)
+        outs = [torch.full((wl["n_pcm"],), float("nan"), dtype=torch.float32, device="cuda") for _ in range(n)]
+        torch.cuda.synchronize()
+        for j in range(n):
+            if pipelined:
+                eng.decode_pipelined(plan, ins[j].data_ptr(), dm.data_ptr(), outs[j].data_ptr())
+            else:
+                eng.decode_device(plan, ins[j].data_ptr(), dm.data_ptr(), outs[j].data_ptr(), 0)
+        eng.synchronize()
+        torch.cuda.synchronize()
+        state = np.stack([[eng.get_overlap(s, c) for c in range(H)] for s in range(S)])
+        results.append(([o.cpu().numpy() for o in outs], state))
+        plan.destroy()
+        eng.close()
+    (serial, s_state), (piped, p_state) = results
+    ov = np.zeros((S, H, 1024), np.float32)
+    assert rel(serial[0], oracle.decode_batch(units, q, meta, wl["n_pcm"], ov, cce=cce)) < RMS_REL
+    for j in range(n):
+        assert not np.isnan(piped[j]).any(), j
+        assert np.array_equal(piped[j].view(np.uint32), serial[j].view(np.uint32)), "launch %d differs from the serialised route" % j
+    assert np.array_equal(p_state.view(np.uint32), s_state.view(np.uint32))
