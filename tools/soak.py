@@ -6,12 +6,12 @@ Usage: python tools/soak.py [seconds]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "aac.js_amd", "python")); sys.path.insert(0, os.path.join(ROOT, "tests"))
-import numpy as np, aacgpu, aacgpu_workload as W, orc
+import numpy as np, torch, aacgpu, aacgpu_workload as W, orc
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 o = orc.load()
 rng = np.random.default_rng(20261001)
-t0 = time.time(); n_batches = n_frames = n_narrow = 0; worst = 0.0
+t0 = time.time(); n_batches = n_frames = n_narrow = n_piped = 0; worst = 0.0
 while time.time() - t0 < budget:
     seed = int(rng.integers(1, 1 << 30))
     if rng.random() < 0.5:
@@ -57,5 +57,28 @@ while time.time() - t0 < budget:
         # a single tail (the last frame only) is noisier than the batch average: 5e-6 is seen once in ~50 k batches
         assert ov_err < (1e-4 if use_tns else 2e-5), (seed, rep, mode, "overlap", ov_err)
         n_batches += 1; n_frames += len(wl["units"])
+    # a third of the time: the same batch as a PLAN, launched 3..14 times in a row through aacg_decode_pipelined (launches
+    # overlap, their chains meet in rendezvous cells; TNS / PNS batches take the in-run stage kernels' rendezvous builds),
+    # every launch against the oracle continued from launch to launch
+    if rng.random() < 0.34:
+        engp = aacgpu.Engine(aacgpu.INPUT_QUANT_I16, S, C, tns_mode=int(use_tns), pns_mode=int(use_pns))
+        plan = engp.plan(units, tns=tns)
+        n = int(rng.integers(3, 15))
+        dq = torch.from_numpy(np.ascontiguousarray(wl["q"])).cuda(); dm = torch.from_numpy(np.ascontiguousarray(meta).view(np.int16)).cuda()
+        outs = [torch.full((wl["n_pcm"],), float("nan"), dtype=torch.float32, device="cuda") for _ in range(n)]
+        torch.cuda.synchronize()
+        for j in range(n):
+            engp.decode_pipelined(plan, dq.data_ptr(), dm.data_ptr(), outs[j].data_ptr())
+        engp.synchronize(); torch.cuda.synchronize()
+        ovp = np.zeros((S, C, 1024), np.float32)
+        for j in range(n):
+            ref = o.decode_batch(units, wl["q"], meta, wl["n_pcm"], ovp, tns=tns, pns=use_pns)
+            pcm = outs[j].cpu().numpy()
+            sig = float(np.sqrt(np.mean(ref.astype(np.float64) ** 2))) + 1e-12
+            err = float(np.sqrt(np.mean((pcm.astype(np.float64) - ref) ** 2))) / sig
+            worst = max(worst, err)
+            assert np.array_equal(np.isnan(pcm), np.isnan(ref)) and err < (2e-5 if use_tns else 5e-6), (seed, "pipelined", j, mode, err)
+        plan.destroy(); engp.close()
+        n_piped += n
     eng.close(); engf.close()
-print("soak ok: %d batches, %d units, worst relative rms error %.2e, %.0f s; %d engine pairs on the one-channel-per-wave route" % (n_batches, n_frames, worst, time.time() - t0, n_narrow))
+print("soak ok: %d batches, %d units, worst relative rms error %.2e, %.0f s; %d engine pairs on the recompute route for long chains; %d launches through the pipeline" % (n_batches, n_frames, worst, time.time() - t0, n_narrow, n_piped))
