@@ -24,7 +24,10 @@
  *                  `processPair`, decoder.js:285)
  *   stream         one decoder instance's worth of state: the reference keeps
  *                  `FilterBank.overlaps[ch]` (filter_bank.js:38-41) per decoder; the
- *                  engine keeps it per (stream slot, channel) in HBM.
+ *                  engine keeps it per (stream slot, channel) in HBM — in sixteen rotating buffers
+ *                  (a launch reads one and writes the next, so that consecutive launches can overlap:
+ *                  aacg_decode_pipelined), plus as much again for the hand-over between launches:
+ *                  128 KB per (stream slot, channel) in all.
  */
 #ifndef AACGPU_H
 #define AACGPU_H
