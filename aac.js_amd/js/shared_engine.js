@@ -41,6 +41,11 @@ function SharedEngine(opts) {
      * page-locked buffers made once and used in turn: a frame is valid until its SharedEngine has flushed K more times, i.e. for
      * at least (K - 1) x lookahead further frames of its stream; a consumer that keeps frames longer copies them (frame.slice()) */
     this.pcmRing = opts.pcmRing | 0;
+    /* resident: decode the NEXT flush's batch while the caller consumes this one (addon.pipelineSubmit / pipelineCollect: the
+     * native call runs on a thread of its own).  A flush then collects the batch submitted by the flush before and submits the
+     * one after; streams are read one flush (lookahead frames) further ahead than they are consumed, and with pcmRing a frame
+     * is valid for one flush less. */
+    this.overlap = !!opts.overlap;
     this.stats = { batches: 0, frames: 0, units: 0, engineNs: 0n, retries: 0 };
 }
 
@@ -119,19 +124,19 @@ function scanFrames(b, at, max, lens) {
 }
 
 /* resident flush: the next frames of every stream that has run dry or has room, ONE native call, views of its PCM handed out */
-SharedEngine.prototype.flushResident = function (g) {
-    const L = this.lookahead, C = g.channels;
+SharedEngine.prototype.prepareResident = function (g, room) {
+    const L = this.lookahead;
     const part = [];
     let F = L;
     for (const dec of g.decoders) {
-        if (dec.queue.length >= L) continue;               // a slow reader's queue does not grow with every flush of its peers
+        if (dec.queue.length >= room) continue;            // a slow reader's queue does not grow with every flush of its peers
         if (!dec.rlens) dec.rlens = new Uint32Array(L);
         const n = scanFrames(dec.rbuf, dec.rpos, L, dec.rlens);
         if (n < 0) { if (!dec.badHeader) { dec.badHeader = true; dec.queue.push(new Error('Invalid ADTS header.')); } continue; }
         if (n === 0) continue;
         part.push(dec); F = Math.min(F, n);
     }
-    if (!part.length) return;
+    if (!part.length) return null;
     const S = part.length, frames = new Uint32Array(2 * S * F), slots = new Uint32Array(S), starts = new Uint32Array(S + 1);
     let total = 0;
     for (let s = 0; s < S; s++) {
@@ -146,15 +151,15 @@ SharedEngine.prototype.flushResident = function (g) {
         bytes.set(dec.rbuf.subarray(dec.rpos, dec.rpos + len), starts[s]);
         dec.rpos += len;
     }
-    const results = new Uint8Array(8 * S * F);
-    const t0 = process.hrtime.bigint();
-    let out = null, failed = null;
-    try { out = g.addon.pipelineDecode(g.pipeline, bytes, frames, slots, F, results, C, this.pcmRing, this.pcmRing ? this.maxStreams * L * 1024 * C : 0); } catch (err) { failed = err instanceof Error ? err : new Error(String(err)); }
-    this.stats.engineNs += process.hrtime.bigint() - t0;
+    return { part: part, S: S, F: F, frames: frames, slots: slots, bytes: bytes, results: new Uint8Array(8 * S * F) };
+};
+
+/* the batch's PCM: one array on page-locked memory the device wrote into; a frame is a view of it (the memory returns to the
+ * addon's pool when the last of the batch's frames has been collected) */
+SharedEngine.prototype.deliverResident = function (g, b, out, failed) {
+    const C = g.channels, part = b.part, S = b.S, F = b.F, results = b.results;
     this.stats.batches++; this.stats.units += S * F;
     if (failed) { for (const dec of part) dec.queue.push(failed); return; }
-    /* the batch's PCM: one array on page-locked memory the device wrote into; a frame is a view of it (the memory returns to the
-     * addon's pool when the last of the batch's frames has been collected) */
     const pcm = out.pcm, refused = out.refused, per = 1024 * C;
     for (let s = 0; s < S; s++) {
         const q = part[s].queue;
@@ -167,6 +172,30 @@ SharedEngine.prototype.flushResident = function (g) {
         }
     }
     this.stats.frames += S * F;
+};
+
+SharedEngine.prototype.flushResident = function (g) {
+    const L = this.lookahead, C = g.channels, ringElems = this.pcmRing ? this.maxStreams * L * 1024 * C : 0;
+    const args = (b) => [g.pipeline, b.bytes, b.frames, b.slots, b.F, b.results, C, this.pcmRing, ringElems];
+    const t0 = process.hrtime.bigint();
+    let b = null, out = null, failed = null;
+    if (this.overlap && g.pending) {                       // the batch the flush before this one submitted
+        b = g.pending; g.pending = null;
+        try { out = g.addon.pipelineCollect(g.pipeline); } catch (err) { failed = err instanceof Error ? err : new Error(String(err)); }
+    } else {
+        b = this.prepareResident(g, L);
+        if (!b) return;
+        try { out = g.addon.pipelineDecode.apply(null, args(b)); } catch (err) { failed = err instanceof Error ? err : new Error(String(err)); }
+    }
+    this.stats.engineNs += process.hrtime.bigint() - t0;
+    this.deliverResident(g, b, out, failed);
+    if (this.overlap && !failed) {                         // ... and the one after it: decoded while the caller reads this one
+        const nb = this.prepareResident(g, 2 * L);
+        if (nb) {
+            try { g.addon.pipelineSubmit.apply(null, args(nb)); g.pending = nb; }
+            catch (err) { this.deliverResident(g, nb, null, err instanceof Error ? err : new Error(String(err))); }
+        }
+    }
 };
 
 /* every registered decoder parses ahead what it has buffered; one batch per engine */

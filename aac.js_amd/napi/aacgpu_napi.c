@@ -105,7 +105,8 @@ static int get_i32(napi_env env, napi_value obj, const char* key, int32_t dflt)
 #define PCM_RING_MAX 16
 typedef struct { uint32_t kind; void* ptr; pthread_mutex_t lock; int out_i16; /* engine / pipeline: AACG_OUTPUT_I16 */
                  /* pipeline, { pcmRing: K }: K page-locked PCM buffers made once and handed out in turn (pipelineDecode) */
-                 napi_ref ring_ab[PCM_RING_MAX]; void* ring_ptr[PCM_RING_MAX]; size_t ring_bytes; int ring_n; unsigned ring_next; } handle_box;
+                 napi_ref ring_ab[PCM_RING_MAX]; void* ring_ptr[PCM_RING_MAX]; size_t ring_bytes; int ring_n; unsigned ring_next;
+                 void* job; /* pipeline: the batch submitted and not yet collected (pipelineSubmit / pipelineCollect) */ } handle_box;
 
 static handle_box* box_new(uint32_t kind, void* ptr)
 {
@@ -471,11 +472,13 @@ static napi_value js_parse_batch(napi_env env, napi_callback_info info)
 /* ---- bytes in, PCM out (aacg_pipeline_*): the resident route behind SharedEngine({ resident: true }) ------------------- */
 static void ring_finalize(napi_env env, void* data, void* hint) { (void)env; (void)hint; if (data && L.host_free) L.host_free(data); }
 
+static void pipe_abandon(napi_env env, void* job);    /* a submitted batch nobody collected: wait for it, drop it */
 static void pipeline_finalize(napi_env env, void* data, void* hint)
 {
     (void)hint;
     handle_box* b = (handle_box*)data;
     if (!b) return;
+    if (b->job) { pipe_abandon(env, b->job); b->job = NULL; }
     if (b->ptr && L.pipeline_destroy) L.pipeline_destroy((aacg_pipeline*)b->ptr);
     for (int i = 0; i < b->ring_n; i++) if (b->ring_ab[i]) napi_delete_reference(env, b->ring_ab[i]);   /* (the buffers go with their ArrayBuffers: ring_finalize) */
     b->kind = 0;
@@ -619,15 +622,27 @@ static void* pcm_take(size_t bytes, size_t* got)
  * ring = 0 / absent: the PCM array's memory is the caller's for as long as any view of it lives (a buffer per call, recycled by
  * the garbage collector's finalizer).  ring = K: the pipeline's K buffers of ringElems elements, made at the first call, are
  * handed out in turn — what a call returns is overwritten by the K-th call after it. */
-static napi_value js_pipeline_decode(napi_env env, napi_callback_info info)
+typedef struct {
+    handle_box* pb;
+    const uint8_t* db; size_t nb; const aacg_parse_frame* df; const uint32_t* ds; size_t ns; uint32_t F; aacg_parse_result* dr;
+    void* pcm; size_t got, elems; int slot;
+    napi_ref keep[4];                                  /* the four argument arrays: theirs is the memory the native call reads and writes */
+    int n_keep;
+    pthread_t thread; int threaded;
+    int rc; uint32_t refused; char msg[1024];
+} pipe_job;
+
+/* argument checking and the PCM buffer: everything that needs the JavaScript thread before the native call */
+static pipe_job* pipe_prepare(napi_env env, napi_callback_info info, int keep_args)
 {
-    size_t argc = 9; napi_value argv[9], out, v, ab;
-    CHECK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    size_t argc = 9; napi_value argv[9];
+    if (napi_get_cb_info(env, info, &argc, argv, NULL, NULL) != napi_ok) return NULL;
     if (argc < 7) { napi_throw_error(env, NULL, "aacgpu: pipelineDecode takes at least 7 arguments"); return NULL; }
     uint32_t ring = 0, ring_elems = 0;
     if (argc >= 9) { napi_get_value_uint32(env, argv[7], &ring); napi_get_value_uint32(env, argv[8], &ring_elems); }
     handle_box* pb = box_of(env, argv[0], BOX_PIPELINE, "aacgpu: bad pipeline handle");
     if (!pb) return NULL;
+    if (pb->job) { napi_throw_error(env, NULL, "aacgpu: a submitted batch has not been collected yet (pipelineCollect)"); return NULL; }
     napi_typedarray_type t; size_t nb, nf, ns, nr; void *db, *df, *ds, *dr; uint32_t F = 0, C = 0;
     napi_get_value_uint32(env, argv[4], &F);
     napi_get_value_uint32(env, argv[6], &C);
@@ -660,18 +675,43 @@ static napi_value js_pipeline_decode(napi_env env, napi_callback_info info)
         pcm = pcm_take(bytes, &got);
         if (!pcm) { napi_throw_error(env, NULL, "aacgpu: out of page-locked memory"); return NULL; }
     }
-    uint32_t refused = 0;
-    pthread_mutex_lock(&pb->lock);
-    aacg_pipeline* p = (aacg_pipeline*)pb->ptr;
-    int rc = L.pipeline_decode(p, (const uint8_t*)db, nb, (const aacg_parse_frame*)df, (const uint32_t*)ds, (uint32_t)ns, F, pcm, (aacg_parse_result*)dr, &refused);
-    char msg[1024];
-    if (rc) snprintf(msg, sizeof msg, "aacgpu: aacg_pipeline_decode failed (%d): %.800s", rc, L.pipeline_last_error(p));
-    pthread_mutex_unlock(&pb->lock);
-    if (rc) {
-        if (slot < 0) { if (g_pool_n < PCM_POOL_MAX) { g_pool[g_pool_n].ptr = pcm; g_pool[g_pool_n].bytes = got; g_pool_n++; } else pcm_discard(pcm); }
-        napi_throw_error(env, NULL, msg);
+    pipe_job* j = (pipe_job*)calloc(1, sizeof *j);
+    if (!j) { napi_throw_error(env, NULL, "aacgpu: out of memory"); return NULL; }
+    j->pb = pb; j->db = (const uint8_t*)db; j->nb = nb; j->df = (const aacg_parse_frame*)df; j->ds = (const uint32_t*)ds; j->ns = ns; j->F = F;
+    j->dr = (aacg_parse_result*)dr; j->pcm = pcm; j->got = got; j->elems = elems; j->slot = slot;
+    if (keep_args) {
+        const int which[4] = {1, 2, 3, 5};
+        for (int k = 0; k < 4; k++)
+            if (napi_create_reference(env, argv[which[k]], 1, &j->keep[j->n_keep]) == napi_ok) j->n_keep++;
+    }
+    return j;
+}
+
+static void* pipe_run(void* arg)
+{
+    pipe_job* j = (pipe_job*)arg;
+    pthread_mutex_lock(&j->pb->lock);
+    aacg_pipeline* p = (aacg_pipeline*)j->pb->ptr;
+    j->rc = L.pipeline_decode(p, j->db, j->nb, j->df, j->ds, (uint32_t)j->ns, j->F, j->pcm, j->dr, &j->refused);
+    if (j->rc) snprintf(j->msg, sizeof j->msg, "aacgpu: aacg_pipeline_decode failed (%d): %.800s", j->rc, L.pipeline_last_error(p));
+    pthread_mutex_unlock(&j->pb->lock);
+    return NULL;
+}
+
+/* back on the JavaScript thread: { pcm, refused } or the error; the job is freed */
+static napi_value pipe_finish(napi_env env, pipe_job* j)
+{
+    napi_value out = NULL, v, ab;
+    handle_box* pb = j->pb;
+    for (int k = 0; k < j->n_keep; k++) napi_delete_reference(env, j->keep[k]);
+    if (j->rc) {
+        if (j->slot < 0) { if (g_pool_n < PCM_POOL_MAX) { g_pool[g_pool_n].ptr = j->pcm; g_pool[g_pool_n].bytes = j->got; g_pool_n++; } else pcm_discard(j->pcm); }
+        napi_throw_error(env, NULL, j->msg);
+        free(j);
         return NULL;
     }
+    const size_t elems = j->elems, got = j->got; void* pcm = j->pcm; const int slot = j->slot; const uint32_t refused = j->refused;
+    free(j);
     if (slot >= 0) CHECK(env, napi_get_reference_value(env, pb->ring_ab[slot], &ab));
     else
     /* (the engine is not told about the buffer's size with napi_adjust_external_memory: it answers 33 MB of external memory
@@ -683,6 +723,49 @@ static napi_value js_pipeline_decode(napi_env env, napi_callback_info info)
     CHECK(env, napi_create_uint32(env, refused, &v));
     CHECK(env, napi_set_named_property(env, out, "refused", v));
     return out;
+}
+
+static void pipe_abandon(napi_env env, void* job)
+{
+    pipe_job* j = (pipe_job*)job;
+    if (j->threaded) pthread_join(j->thread, NULL);
+    for (int k = 0; k < j->n_keep; k++) napi_delete_reference(env, j->keep[k]);
+    if (j->slot < 0) pcm_discard(j->pcm);
+    free(j);
+}
+
+static napi_value js_pipeline_decode(napi_env env, napi_callback_info info)
+{
+    pipe_job* j = pipe_prepare(env, info, 0);
+    if (!j) return NULL;
+    pipe_run(j);
+    return pipe_finish(env, j);
+}
+
+/* pipelineSubmit(same arguments as pipelineDecode): the native call runs on a thread of its own while JavaScript goes on — slicing
+ * the batch before, say; the four argument arrays must not be touched until pipelineCollect(pipeline) -> { pcm, refused } has
+ * returned (it waits for the call).  One batch in flight per pipeline. */
+static napi_value js_pipeline_submit(napi_env env, napi_callback_info info)
+{
+    pipe_job* j = pipe_prepare(env, info, 1);
+    if (!j) return NULL;
+    if (pthread_create(&j->thread, NULL, pipe_run, j) == 0) j->threaded = 1;
+    else pipe_run(j);                                   /* no thread to be had: the call is made here and now */
+    j->pb->job = j;
+    return NULL;
+}
+
+static napi_value js_pipeline_collect(napi_env env, napi_callback_info info)
+{
+    size_t argc = 1; napi_value argv[1];
+    CHECK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    handle_box* pb = box_of(env, argv[0], BOX_PIPELINE, "aacgpu: bad pipeline handle");
+    if (!pb) return NULL;
+    pipe_job* j = (pipe_job*)pb->job;
+    if (!j) { napi_throw_error(env, NULL, "aacgpu: pipelineCollect: nothing has been submitted"); return NULL; }
+    pb->job = NULL;
+    if (j->threaded) pthread_join(j->thread, NULL);
+    return pipe_finish(env, j);
 }
 
 static napi_value js_pipeline_reset_stream(napi_env env, napi_callback_info info)
@@ -725,6 +808,8 @@ static napi_value init(napi_env env, napi_value exports)
         {"parseStatusString", NULL, js_parse_status_string, NULL, NULL, NULL, napi_default, NULL},
         {"pipelineCreate", NULL, js_pipeline_create, NULL, NULL, NULL, napi_default, NULL},
         {"pipelineDecode", NULL, js_pipeline_decode, NULL, NULL, NULL, napi_default, NULL},
+        {"pipelineSubmit", NULL, js_pipeline_submit, NULL, NULL, NULL, napi_default, NULL},
+        {"pipelineCollect", NULL, js_pipeline_collect, NULL, NULL, NULL, napi_default, NULL},
         {"pipelineResetStream", NULL, js_pipeline_reset_stream, NULL, NULL, NULL, napi_default, NULL},
     };
     napi_define_properties(env, exports, sizeof props / sizeof props[0], props);

@@ -171,6 +171,41 @@ if (mode === 'cpu') {
     assert.strictEqual(copies.length, ref0.length);
     copies.forEach(function (p, t) { assert.deepStrictEqual(Buffer.from(p.buffer), Buffer.from(ref0[t].buffer, ref0[t].byteOffset, ref0[t].byteLength), 'ring frame ' + t); });
     assert.notDeepStrictEqual(Buffer.from(views[0].buffer, views[0].byteOffset, views[0].byteLength), Buffer.from(copies[0].buffer), 'frame 0 of flush 0 was not overwritten by flush 3');
-    console.log('resident shared engine: ' + res.stats.frames + ' frames in ' + res.stats.batches + ' native calls; piecewise feed and a corrupt frame ok');
+    /* { overlap: true }: the next flush's batch is decoded (a native thread) while the caller reads this one.  The same eight
+     * streams round robin, a stream fed in pieces, and the corrupt frame: the same frames, the same bits, the error where it belongs */
+    const ro = new host.SharedEngine({ maxStreams: 16, maxChannels: 8, resident: true, lookahead: 4, overlap: true });
+    const odecs = names.map(function (n) { return open(n, { shared: ro }); });
+    const ogot = drainRoundRobin(odecs);
+    names.forEach(function (n, i) {
+        const c = manifest.find(function (m) { return m.name === n; });
+        assert.strictEqual(ogot[i].length, c.frames, n + ' (resident, overlapped): frames delivered');
+        ogot[i].forEach(function (p, t) {
+            assert.deepStrictEqual(Buffer.from(p.buffer, p.byteOffset, p.byteLength), Buffer.from(alone[i][t].buffer, alone[i][t].byteOffset, alone[i][t].byteLength), n + ' (resident, overlapped) frame ' + t);
+        });
+    });
+    const r4 = new host.SharedEngine({ maxStreams: 4, maxChannels: 2, resident: true, lookahead: 3, overlap: true });
+    const pw = new host.GpuAACDecoder({ shared: r4 }); pw.init();
+    const dm4 = new host.adts.AdtsDemuxer(function (event, payload) {
+        if (event === 'format') Object.assign(pw.format, payload); else if (event === 'cookie') pw.setCookie(payload); else if (event === 'data') pw.feed(payload);
+    });
+    const got4 = [];
+    for (let at = 0; at < whole.length; at += 1501) {
+        dm4.push(whole.subarray(at, Math.min(whole.length, at + 1501)));
+        for (let p; (p = pw.readChunk());) got4.push(p);
+    }
+    assert.strictEqual(got4.length, ref0.length, 'piecewise feed, overlapped: frames delivered');
+    got4.forEach(function (p, t) { assert.deepStrictEqual(Buffer.from(p.buffer, p.byteOffset, p.byteLength), Buffer.from(ref0[t].buffer, ref0[t].byteOffset, ref0[t].byteLength), 'piecewise overlapped frame ' + t); });
+    const broken4 = new host.GpuAACDecoder({ shared: r4 }); broken4.init();
+    const dm5 = new host.adts.AdtsDemuxer(function (event, payload) {
+        if (event === 'format') Object.assign(broken4.format, payload); else if (event === 'cookie') broken4.setCookie(payload); else if (event === 'data') broken4.feed(payload);
+    });
+    dm5.push(bad);
+    let threw4 = 0, delivered4 = 0;
+    for (let t = 0; t < list.length; t++) {
+        try { const p = broken4.readChunk(); if (p) { delivered4++; if (t < 5) assert.deepStrictEqual(Buffer.from(p.buffer, p.byteOffset, p.byteLength), Buffer.from(ref0[t].buffer, ref0[t].byteOffset, ref0[t].byteLength)); } }
+        catch (e) { threw4++; assert.strictEqual(t, 5, 'the error belongs to frame 5: ' + e.message); }
+    }
+    assert.strictEqual(threw4, 1); assert.strictEqual(delivered4, list.length - 1);
+    console.log('resident shared engine: ' + res.stats.frames + ' frames in ' + res.stats.batches + ' native calls; piecewise feed and a corrupt frame ok; overlapped flushes ok (' + ro.stats.batches + ' native calls)');
 }
 console.log('shared ' + mode + ' tests ok');

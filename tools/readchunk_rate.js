@@ -44,7 +44,7 @@ function ours(gpuParse) {
 /* N concurrent streams: the same bytes into N decoders, read round robin as N players would; `shared`: one SharedEngine
  * (one batch per flush for all of them) or an engine per decoder (one batch per decoder: what N independent plugin instances
  * do).  Engine time = wall time inside engine.decodeBatch (upload, kernels, download), on this one JavaScript thread. */
-function many(shared, lookahead, pcmRing) {
+function many(shared, lookahead, pcmRing, overlap) {
     const resident = shared === 'resident';
     try {
         let engineNs = 0n, batches = 0;
@@ -53,7 +53,7 @@ function many(shared, lookahead, pcmRing) {
             eng.decodeBatch = function () { const t = process.hrtime.bigint(); try { return inner.apply(null, arguments); } finally { engineNs += process.hrtime.bigint() - t; batches++; } };
             return eng;
         };
-        const sh = shared ? new host.SharedEngine({ maxStreams: nStreams, maxChannels: 2, resident: resident, lookahead: lookahead, pcmRing: pcmRing | 0 }) : null;
+        const sh = shared ? new host.SharedEngine({ maxStreams: nStreams, maxChannels: 2, resident: resident, lookahead: lookahead, pcmRing: pcmRing | 0, overlap: !!overlap }) : null;
         const decs = [];
         for (let i = 0; i < nStreams; i++) {
             const dec = new host.GpuAACDecoder({ frontend: resident ? null : new host.FrontEnd(), lookahead: lookahead, shared: sh });
@@ -86,7 +86,9 @@ if (nStreams) {
     out.shared_engine = many(true, 16);
     out.shared_engine_resident = many('resident', 16);        // bytes -> PCM in one native call per flush: JavaScript finds frame boundaries and slices PCM
     out.shared_engine_resident_ring8 = many('resident', 16, 8);   // the same with the PCM in a ring of 8 page-locked buffers (a frame stays valid for 7 more flushes)
-    if (out.shared_engine_resident.checksum !== undefined) out.resident_same_checksum = out.shared_engine_resident.checksum === out.independent_decoders.checksum && out.shared_engine_resident_ring8.checksum === out.independent_decoders.checksum;
+    out.shared_engine_resident_overlap = many('resident', 16, 0, true);   // ... and with the next flush's batch decoded while this one is read
+    out.shared_engine_resident_ring8_overlap = many('resident', 16, 8, true);
+    if (out.shared_engine_resident.checksum !== undefined) out.resident_same_checksum = out.shared_engine_resident.checksum === out.independent_decoders.checksum && out.shared_engine_resident_ring8.checksum === out.independent_decoders.checksum && out.shared_engine_resident_overlap.checksum === out.independent_decoders.checksum && out.shared_engine_resident_ring8_overlap.checksum === out.independent_decoders.checksum;
     if (out.independent_decoders.frames_per_engine_second && out.shared_engine.frames_per_engine_second) {
         out.engine_time_ratio = +(out.shared_engine.frames_per_engine_second / out.independent_decoders.frames_per_engine_second).toFixed(2);
         out.same_checksum = out.shared_engine.checksum === out.independent_decoders.checksum;
