@@ -48,6 +48,18 @@ def main():
             f = os.path.join(src, "%s_%s" % (p_, suffix))
             if os.path.exists(f):
                 shutil.copy(f, os.path.join(prof, "%s_%s_%s" % (rnd, p_[5:], suffix)))
+        # overlapped launches: a trace row's duration includes its wait for CUs and the launches running beside it; what a launch
+        # COSTS is the spacing of the rows — say so at the top of the summary, with the figures of the same trace
+        summ, iv = os.path.join(prof, "%s_%s_summary.txt" % (rnd, p_[5:])), os.path.join(src, "%s_intervals.txt" % p_)
+        if os.path.exists(summ) and os.path.exists(iv):
+            lines = [l for l in open(iv).read().splitlines() if l.startswith(("kernel:", "dispatch duration", "overlap with", "time per launch"))]
+            over = any(l.startswith("overlap with") and "median 0.00" not in l for l in lines)
+            if over:
+                note = ["NOTE  launches of this route OVERLAP (aacg_decode_pipelined, DESIGN.md 3d): avg_ns below is the length of a trace row (begin -> end,",
+                        "NOTE  including the row's wait for CUs), not what a launch costs; the same trace's row spacing (tools/kernel_intervals.py, %s_%s_intervals.txt):" % (rnd, p_[5:])]
+                body = open(summ).read()
+                if not body.startswith("NOTE"):
+                    open(summ, "w").write("\n".join(note + ["NOTE  " + l for l in lines]) + "\n" + body)
     for f, dst in (("readchunk_256streams.json", "readchunk_256streams.json"), ("micro.txt", "micro.txt"), ("timeline.txt", "timeline.txt")):
         if os.path.exists(os.path.join(src, f)):
             shutil.copy(os.path.join(src, f), os.path.join(prof, "%s_%s" % (rnd, dst)))
