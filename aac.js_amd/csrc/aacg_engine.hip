@@ -824,6 +824,7 @@ static int pipe_setup(aacg_engine* e)
 {
     aacg_engine::pipe_t& pp = e->pipe;
     if (pp.stream[0]) return AACG_OK;
+    HIP_TRY(e, hipSetDevice(e->cfg.device_ordinal), AACG_ERR_NO_DEVICE);     /* the streams belong to the engine's device, whatever the caller's current one is */
     /* Streams that really run side by side.  Streams of the highest priority are dealt their hardware queues apart from the
      * crowd of ordinary streams a host process may have made (PyTorch: 32 at once); every candidate is PROBED against the
      * streams already chosen, and further candidates are tried if it shares a queue with one of them after all.  Streams that
