@@ -16,7 +16,8 @@ step k + 1 starts on the compute units step k has already left; the chains of th
 1-4).  ONE plan, ONE set of 256 streams continued launch after launch either way (`config.pipelines` 1).
 
 Timing: W untimed warm-up steps, then the timed region of exactly K steps — R times back to back (--repeats, default 25;
-regions shorter than 80 steps are repeated until about 2000 launches are timed).  A repeat ends when its last launches —
+regions shorter than 80 steps are repeated until about 2000 launches are timed, and the median is then taken over runs of
+consecutive repeats of at least 100 launches: region_stats says why).  A repeat ends when its last launches —
 one per pipeline stream: they run side by side — are complete: HIP events bound to those dispatches' completion
 (aacg_decode_pipelined_timed; no marker packet enters a queue, nothing is joined inside the timed region); the opening mark is
 recorded on the timing stream joined behind the warm-up steps; the whole set between barrier + synchronize on both sides
@@ -60,13 +61,25 @@ def workload_shape(workload):
     return mix, n_streams, n_frames, layout, (7 if workload == "cfg5" else 2)
 
 
-def region_stats(region_ms, steps):
-    """Per-step time of the R timed repeats (each K steps): median (the figure quoted), min, max, first."""
-    per = sorted(float(t) / steps for t in region_ms)
-    n = len(per)
-    med = per[n // 2] if n % 2 else 0.5 * (per[n // 2 - 1] + per[n // 2])
-    return {"repeats": n, "ms_per_step_median": med, "ms_per_step_min": per[0], "ms_per_step_max": per[-1],
-            "ms_per_step_first": float(region_ms[0]) / steps, "ms_per_step_each": [float(t) / steps for t in region_ms]}
+def region_stats(region_ms, steps, group=1):
+    """Per-step time of the R timed repeats (each K steps): median (the figure quoted), min, max, first.
+    group > 1: the median is taken over runs of `group` consecutive repeats.  With overlapped launches a repeat ends at the
+    completion of launches that run beside the next repeat's first ones: its end is a maximum over those launches, a short
+    repeat's time scatters by a launch either way and skews (at K = 20: 8.9-13.8 us per step around a mean of 11.6, median 0.1
+    above it); the sum over consecutive repeats telescopes, so longer runs of repeats have the same mean and a fraction of the
+    scatter.  min / max / each stay per repeat."""
+    each = [float(t) / steps for t in region_ms]
+    n = len(each)
+    g = max(1, min(int(group), n))
+    runs = [sum(each[i:i + g]) / g for i in range(0, n - g + 1, g)] if g > 1 else list(each)
+    per = sorted(runs)
+    m = len(per)
+    med = per[m // 2] if m % 2 else 0.5 * (per[m // 2 - 1] + per[m // 2])
+    out = {"repeats": n, "ms_per_step_median": med, "ms_per_step_min": min(each), "ms_per_step_max": max(each),
+           "ms_per_step_first": each[0], "ms_per_step_each": each, "ms_per_step_mean": sum(each) / n}
+    if g > 1:
+        out["median_over"] = "%d runs of %d consecutive repeats (%d launches each)" % (m, g, g * steps)
+    return out
 
 
 def whole_job_value(world, frames_per_step, ms_per_step):
@@ -395,8 +408,9 @@ def main():
     else:
         mine_ms = [evs[r].elapsed_time(evs[r + 1]) for r in range(R)]                 # this rank's R repeats of K steps, on the launch stream
     region_ms = aacgpu_shard.reduce_max_list(dist, mine_ms, dev)                      # MAX over ranks, repeat by repeat
-    stats = region_stats(region_ms, args.steps)
-    kernel_ms = region_stats(mine_ms, args.steps)["ms_per_step_median"]               # rank 0's own launches, for its roofline
+    group = -(-100 // args.steps) if (bound and args.steps < 100) else 1              # overlapped launches: regions of at least 100 launches under the median
+    stats = region_stats(region_ms, args.steps, group)
+    kernel_ms = region_stats(mine_ms, args.steps, group)["ms_per_step_median"]        # rank 0's own launches, for its roofline
 
     # Same process, same box, same clocks, right behind the timed region (untimed itself): what this box's memory system
     # gives a float4 copy launch of the step's byte volume (half read, half written; buffers rotated past the Infinity
