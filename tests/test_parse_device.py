@@ -299,8 +299,8 @@ def _silent(units):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name,layout", [("stereo600", [(2, 0)]), ("fuzz", [(1, 0), (2, 1)])])
-def test_gpu_plan_refresh_from_parse(standard, oracle, name, layout):
+@pytest.mark.parametrize("name,layout,moved", [("stereo600", [(2, 0)], False), ("fuzz", [(1, 0), (2, 1)], False), ("stereo600", [(2, 0)], True)])
+def test_gpu_plan_refresh_from_parse(standard, oracle, name, layout, moved):
     """Parser -> transform without the host in between: a plan built once from the streams' structure, its device unit
     records rewritten from aacg_parse_device's output (aacg_plan_refresh_from_parse), equals parsing to the host and
     planning there — including the frames that become silent (refused by the parser, wrong element, noise bands)."""
@@ -328,12 +328,18 @@ def test_gpu_plan_refresh_from_parse(standard, oracle, name, layout):
     skel["n_ch"] = np.tile(np.array([k for k, _ in layout], np.uint8), n)
     skel["channel"] = np.tile(np.array([c for _, c in layout], np.uint16), n)
     skel["coef_offset"] = skel["meta_offset"] = f * Ch + skel["channel"]
+    if moved:
+        # the plan's run tables carry copies of the block offsets (aacg_run.wave_coef): a frame the plan expects in OTHER blocks
+        # than the parser's (frame * max_channels + channel) is not the frame the plan was made for — refused, silent, counted
+        sel = (f % 7) == 3
+        skel["coef_offset"][sel] = skel["meta_offset"][sel] = n * Ch + (f[sel] % 5) * Ch
     # host reference: the parsed records where they fit the skeleton, silent units elsewhere (the rule of the refresh kernel)
     ref_units = skel.copy()
     got = host["units"]
     res = np.repeat(host["results"], U)
     e = np.tile(np.arange(U), n)
     ok = (res["status"] == 0) & (e < res["n_units"]) & (got["n_ch"] == skel["n_ch"]) & (got["channel"] == skel["channel"]) & ((got["flags"] & 4) == 0)
+    ok &= (got["coef_offset"] == skel["coef_offset"]) & (got["meta_offset"] == skel["meta_offset"])
     ref_units["flags"][ok] = got["flags"][ok]
     ch = got["ch"][ok].copy()
     ch["flags"] = 0
@@ -341,18 +347,22 @@ def test_gpu_plan_refresh_from_parse(standard, oracle, name, layout):
     ref_units["coef_offset"] = got["coef_offset"]
     ref_units["meta_offset"] = got["meta_offset"]
     bad = ~ok
+    qh, mh = host["q"], host["meta"]
+    if moved:                                                  # (the oracle reads the silent units' blocks too: give it the extra ones)
+        qh = np.concatenate([qh, np.zeros((5 * Ch, 1024), qh.dtype)])
+        mh = np.concatenate([mh, np.zeros((5 * Ch,) + mh.shape[1:], mh.dtype)])
     ref_units["coef_offset"][bad] = skel["coef_offset"][bad]     # a refused frame keeps the planner's offsets: the silent unit still loads its blocks
     ref_units["meta_offset"][bad] = skel["meta_offset"][bad]
     ov = np.zeros((S, C, 1024), np.float32)
-    ref = oracle.decode_batch(ref_units, host["q"], host["meta"], n * 1024 * C, ov, sample_index=case["sampleIndex"])
+    ref = oracle.decode_batch(ref_units, qh, mh, n * 1024 * C, ov, sample_index=case["sampleIndex"])
     # device path
     dev = torch.device("cuda:0")
     t = lambda arr: torch.from_numpy(np.ascontiguousarray(arr).view(np.uint8).reshape(-1)).to(dev)
     pad = np.concatenate([data, np.zeros((-len(data)) % 16 + 32, np.uint8)])
     d_bytes, d_frames = t(pad), t(frames)
     d_units = torch.full((n * U * 64,), 0xFF, dtype=torch.uint8, device=dev)      # stale memory: a refused frame's record must not be trusted
-    d_q = torch.zeros(n * Ch * 1024, dtype=torch.int16, device=dev)
-    d_meta = torch.zeros(n * Ch * 120, dtype=torch.int16, device=dev)
+    d_q = torch.zeros((n + 5) * Ch * 1024, dtype=torch.int16, device=dev)
+    d_meta = torch.zeros((n + 5) * Ch * 120, dtype=torch.int16, device=dev)
     d_res = torch.zeros(n * 8, dtype=torch.uint8, device=dev)
     d_pcm = torch.zeros(n * 1024 * C, dtype=torch.float32, device=dev)
     d_refused = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -368,7 +378,7 @@ def test_gpu_plan_refresh_from_parse(standard, oracle, name, layout):
     eng.decode_device(plan, d_q.data_ptr(), d_meta.data_ptr(), d_pcm.data_ptr(), side.cuda_stream)
     side.synchronize()
     assert int(d_refused.cpu()[0]) == int(bad.sum())
-    if name == "stereo600":
+    if name == "stereo600" and not moved:
         assert not bad.any()
     else:
         assert bad.any() and ok.any()
