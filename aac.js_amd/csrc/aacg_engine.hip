@@ -908,6 +908,13 @@ int aacg_decode_pipelined_timed(aacg_engine* e, aacg_plan* p, const void* d_coef
         if (e->last_kernel) HIP_TRY(e, hipStreamWaitEvent(s, e->last_kernel, 0), AACG_ERR_NO_DEVICE);   /* the host-buffer path's batches */
     }
     if (!p->used) HIP_TRY(e, hipStreamWaitEvent(s, p->uploaded, 0), AACG_ERR_NO_DEVICE);
+    if (!continues && R.overlappable) {
+        /* a new sequence: its next launches go to the other streams and are not behind this one — but they must be behind
+         * everything this one is behind (an earlier sequence's launches on a third stream may share overlap buffers with them:
+         * the back-pressure bookkeeping starts anew with the sequence) */
+        HIP_TRY(e, hipEventRecord(pp.fork, s), AACG_ERR_NO_DEVICE);
+        for (hipStream_t ps : pp.stream) if (ps != s) HIP_TRY(e, hipStreamWaitEvent(ps, pp.fork, 0), AACG_ERR_NO_DEVICE);
+    }
     const cce_bufs cb = {(const aacg_run*)p->d_cce[0], (const aacg_couple_job*)p->d_cce[1], (const float*)p->d_cce[2], (float*)p->d_cce[3]};
     const rv_bufs rvb = {(const aacg_run*)p->d_rv[0], (const aacg_rv_link*)p->d_rv[1], (unsigned long long*)p->d_rv[2], (float*)p->d_rv[3]};
     const xl_args xl = {R.overlappable, continues ? pp.epoch : 0ull, ord.stream, (int)(pp.n & 3u)};
