@@ -965,6 +965,7 @@ int aacg_pipeline_join(aacg_engine* e, void* hip_stream)
 
 uint64_t aacg_pipeline_chained(const aacg_engine* e) { return e ? e->pipe.chained : 0; }
 int aacg_pipeline_concurrent(const aacg_engine* e) { return e && e->pipe.concurrent ? 1 : 0; }
+int aacg_pipeline_streams_used(const aacg_engine* e) { return e && e->pipe.stream[0] ? e->pipe.streams : 0; }
 
 /* The plan's device unit records take what the parser found (device to device); the run tables stay. */
 int aacg_plan_refresh_from_parse(aacg_engine* e, aacg_plan* p, const aacg_unit_desc* d_parsed_units,

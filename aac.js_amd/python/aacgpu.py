@@ -32,7 +32,7 @@ ABI_SYMBOLS = ["aacg_create", "aacg_destroy", "aacg_last_error", "aacg_abi_versi
 # ... and include/aacgpu_tools.h (measurement and diagnostics: bench.py, tools/, tests)
 TOOLS_SYMBOLS = ["aacg_calib_copy", "aacg_timer_create", "aacg_timer_record", "aacg_timer_elapsed_ms", "aacg_timer_destroy",
                  "aacg_pipeline_chained", "aacg_pipeline_concurrent", "aacg_decode_pipelined_timed", "aacg_debug_transform", "aacg_debug_set_route", "aacg_debug_route", "aacg_debug_run_kernel",
-                 "aacg_debug_pipeline_order"]
+                 "aacg_debug_pipeline_order", "aacg_pipeline_streams_used"]
 # aacg_debug_set_route / aacg_debug_route flags
 DEBUG_ROUTE_UNFUSED_COUPLING, DEBUG_ROUTE_RECOMPUTE = 1, 8
 ROUTE_PLAN_TNS, ROUTE_PLAN_PNS, ROUTE_PLAN_LONG_CHAINS, ROUTE_PLAN_FULL_LATER_RUNS = 1, 2, 4, 8
@@ -129,6 +129,7 @@ def load_library(path=LIB_PATH):
     L.aacg_pipeline_chained.argtypes = [C.c_void_p]
     L.aacg_pipeline_chained.restype = C.c_uint64
     L.aacg_pipeline_concurrent.argtypes = [C.c_void_p]
+    L.aacg_pipeline_streams_used.argtypes = [C.c_void_p]
     L.aacg_debug_route.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_size_t]
     L.aacg_debug_run_kernel.argtypes = [C.c_int, C.c_char_p, C.c_size_t]
     L.aacg_plan_refresh_units.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
@@ -522,6 +523,10 @@ class Engine:
     def pipeline_chained(self):
         """Launches of decode_pipelined that continued (and were allowed to overlap) the launch before them."""
         return int(self.lib.aacg_pipeline_chained(self.handle))
+
+    def pipeline_streams_used(self):
+        """How many of the engine's internal streams the current pipelined sequence takes in turn (0 before the first launch)."""
+        return int(self.lib.aacg_pipeline_streams_used(self.handle))
 
     def pipeline_concurrent(self):
         """True if the engine's internal streams were seen to run side by side (else pipelined launches serialise: correct, not faster)."""

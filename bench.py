@@ -468,8 +468,8 @@ def main():
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "timing": dict(stats, events=("torch.cuda.Event (default HIP events: a system-scope fence per record)" if args.default_events else
                                       "hipEventDisableSystemFence (timing-only HIP events, aacg_timer_*)"),
-                       method=("the K timed steps are run R times back to back; a repeat ends when its last three launches (which run side by "
-                               "side on the engine's three streams) are all complete — HIP events bound to those dispatches' completion "
+                       method=("the K timed steps are run R times back to back; a repeat ends when its last launches (one per pipeline stream: they "
+                               "run side by side) are all complete — HIP events bound to those dispatches' completion "
                                "(hipExtLaunchKernel stopEvent), the opening event on the timing stream behind the warm-up steps" if bound else
                                "the K timed steps are run R times back to back, each repeat between its own HIP events on the launch stream") +
                               " (MAX over ranks per repeat); value and ms_per_step: the MEDIAN repeat; wall_*: host clock between "
@@ -485,9 +485,9 @@ def main():
                    "output": "float32 PCM as the reference returns it" if args.output == "f32" else "int16 PCM (AACG_OUTPUT_I16)",
                    "streams_per_gpu": n_streams, "frames_per_stream_per_step": n_frames, "buffers_rotated": args.nbuf,
                    "realtime_multiple": value / 46.875, "sharding": "streams over ranks, no data-path collective", "pipelines": args.pipelines,
-                   "launches": ("aacg_decode_pipelined: ONE plan, the same %d streams continued launch after launch on the engine's three internal HIP "
+                   "launches": ("aacg_decode_pipelined: ONE plan, the same %d streams continued launch after launch on %d of the engine's internal HIP "
                                 "streams taken in turn; consecutive launches overlap, their chains meet in rendezvous cells (nobody waits); %d of the %d "
-                                "launches of this process continued the launch before them; the streams were %s" % (n_streams, eng.pipeline_chained(), n_pre + args.warmup + R * args.steps + (0 if args.no_parity else 1),
+                                "launches of this process continued the launch before them; the streams were %s" % (n_streams, eng.pipeline_streams_used(), eng.pipeline_chained(), n_pre + args.warmup + R * args.steps + (0 if args.no_parity else 1),
                                    "seen to run side by side when the pipeline was set up" if eng.pipeline_concurrent() else "NOT seen to run side by side (one hardware queue): the launches serialise"))
                                if pipelined else "aacg_decode_device: every launch behind the one before it on one HIP stream",
                    "preconditioning": "%d untimed steps (%.0f ms of load) before the warm-up steps: steady GPU clocks" % (n_pre, args.precondition_ms),

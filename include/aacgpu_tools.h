@@ -33,6 +33,8 @@ uint64_t aacg_pipeline_chained(const aacg_engine* e);
 /* 1 if the engine's internal streams were seen to run side by side, each pair of them, when the pipeline was set up (HIP multiplexes
  * streams onto a few hardware queues; two streams on one queue serialise): 0 = pipelined launches are correct but do not overlap. */
 int aacg_pipeline_concurrent(const aacg_engine* e);
+/* how many of the engine's streams the current pipelined sequence takes in turn (aacg_pipeline_streams, aacg_routes.h); 0 before the first */
+int aacg_pipeline_streams_used(const aacg_engine* e);
 
 /* Diagnostic: the IMDCT stage of the kernels on its own, for known-answer tests against the reference's MDCT.process
  * (mdct.js:62-115) and FFT.process (fft.js:105-192) vectors.  One spectrum in (1024 floats: one long window, or eight
