@@ -35,6 +35,7 @@ struct aacg_plan_host {
     std::vector<aacg_dev_tns>  tns;     /* device form of the TNS side info (AACG_TNS_SPEC), same indexing as the input */
     bool     any_tns = false;         /* some channel has AACG_CHAN_TNS_PRESENT and TNS records were given */
     bool     any_pns = false;         /* some unit carries AACG_UNIT_HAS_PNS */
+    uint32_t short_units = 0;         /* units with an EIGHT_SHORT_SEQUENCE channel, as planned (or last refreshed from the host) */
     bool     needs_scratch = false;   /* some later run holds 16 frames: its first wave parks the predecessor's tails */
     bool     wide_frames = false;     /* at least half of the units belong to frames of more than two channels: the multichannel kernel variants (aacg_engine_nt.hip) */
     std::vector<aacg_run>   runs;     /* in launch (block) order, XCD-aware */

@@ -185,8 +185,10 @@ int aacg_plan_refresh_host(aacg_plan_host* h, const aacg_unit_desc* units, uint3
         meta_blocks = std::max(meta_blocks, u.meta_offset + u.n_ch);
     }
     bool moved = false;
+    h->short_units = 0;
     for (uint32_t i = 0; i < n_units; i++) {               /* nothing is touched before the whole batch has passed */
         aacg_dev_unit& du = h->units[i];
+        if (units[i].ch[0].window_sequence == AACG_EIGHT_SHORT_SEQUENCE || (units[i].n_ch == 2 && units[i].ch[1].window_sequence == AACG_EIGHT_SHORT_SEQUENCE)) h->short_units++;
         moved = moved || du.d.coef_offset != units[i].coef_offset || du.d.meta_offset != units[i].meta_offset;
         du.d = units[i];
         for (int c = 0; c < 2; c++) {
@@ -227,6 +229,7 @@ int aacg_plan_build(const aacg_unit_desc* units, uint32_t n_units, int sample_in
         const aacg_unit_desc& u = units[i];
         if (u.flags & AACG_UNIT_HAS_PNS) out->any_pns = true;
         if (u.n_out_ch > 2) n_wide++;
+        if (u.ch[0].window_sequence == AACG_EIGHT_SHORT_SEQUENCE || (u.n_ch == 2 && u.ch[1].window_sequence == AACG_EIGHT_SHORT_SEQUENCE)) out->short_units++;
         if (u.n_ch < 1 || u.n_ch > 2) return fail(err, AACG_ERR_INVALID_ARG, "unit %ld: n_ch %ld", i, u.n_ch);
         if ((int)u.stream >= max_streams) return fail(err, AACG_ERR_CAPACITY, "unit %ld: stream %ld >= max_streams", i, u.stream);
         const bool is_cce = (u.flags & AACG_UNIT_CCE) != 0;

@@ -115,5 +115,6 @@ int aacg_pipeline_streams(const aacg_plan_host& h, unsigned run_key)
     if (h.runs_rv.size() > 512) return 2;                                   /* several rounds of workgroups per launch */
     if (run_key & AACG_RK_I16) return 2;                                    /* int16 PCM */
     if ((run_key & AACG_RK_EX) && (run_key & AACG_RK_QUANT)) return 2;      /* optional stages on the int16 seam */
+    if (2u * h.short_units > h.units.size()) return 2;                      /* mostly frames of eight short windows */
     return AACG_PIPE_STREAMS;
 }

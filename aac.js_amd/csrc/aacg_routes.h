@@ -90,6 +90,7 @@ aacg_pipe_order aacg_pipeline_order(uint64_t n, int streams);
  *   plain kernels, f32 PCM, a launch = one round of workgroups   config 2: 11.6-11.8 / 11.3;  config 4 shape: 11.6 / 11.4;  f32 seam: - / 12.2
  *   the same with int16 PCM                                       10.0 / 10.9
  *   optional stages inside the run kernel (TNS on config 3)       int16 seam 23.7-23.9 / 24.0;  f32 seam 25.5 / 25.0-25.2
+ *   plain kernels on frames of eight short windows only             11.4 / 12.0  (frames of long windows: 11.5 / 11.1; config 3's mix, one in four: 11.4 / 11.4)
  *   a launch of several rounds of workgroups (config 5 shape)     58.8-59.3 / 63.4-64.2 (a third launch in flight scatters a stream's
  *                                                                 elements over more of the L2s)
  * Three where a CU that is done with launch n + 1's workgroup would otherwise find nothing of launch n + 2 to run; two where the
