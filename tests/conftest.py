@@ -18,6 +18,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """A GPU test that has not returned after ten minutes never will (the whole suite takes one): fail it with the stacks on
+    stderr (pytest-timeout, where installed) instead of sitting there until whoever started the run gives up."""
+    if not config.pluginmanager.hasplugin("timeout"):
+        return
+    for item in items:
+        if item.get_closest_marker("gpu") and not item.get_closest_marker("timeout"):
+            item.add_marker(pytest.mark.timeout(600))
+
+
 @pytest.fixture(scope="session")
 def golden():
     from golden_io import load_golden
