@@ -21,6 +21,7 @@
 #include "aacg_kernels.h"
 #include "aacg_host.h"
 #include "aacg_routes.h"
+#include "aacg_wait.h"
 
 /* ---- kernels ----------------------------------------------------------------------- */
 /* 1024 threads = 16 waves, one workgroup per CU: 4 waves per SIMD -> 128 VGPRs per lane */
@@ -40,7 +41,7 @@ const aacg_run_kernel aacg_run_kernels_plain[] = {
 const int aacg_run_kernels_plain_n = 2;
 
 /* aacg_engine_refresh.hip: a kept plan's unit records from the device parser's output */
-void aacg_refresh_launch(aacg_dev_unit* units, const aacg_unit_desc* parsed, const aacg_parse_result* results, uint32_t n_units,
+void aacg_refresh_launch(aacg_dev_unit* units, const aacg_unit_desc* parsed, aacg_parse_result* results, const aacg_refresh_map* map, uint32_t n_units,
                          uint32_t max_units, int refuse_pns, uint32_t* refused, hipStream_t s);
 /* aacg_engine_spectral.hip: the optional stages (AACG_PNS_SPEC noise bands, AACG_TNS_SPEC filters) -> f32 spectra */
 int aacg_spectral_ex_set_lds_limits(void);
@@ -137,6 +138,14 @@ struct aacg_engine {
     void* d_trace = nullptr;                /* profiling: per-wave phase timestamps when (ablate & 16) */
     int debug_route = 0;                    /* aacg_debug_set_route: diagnostic route choices for parity tests (0 in production) */
     int ablate = 0;                         /* -DAACG_PROFILE builds: env AACG_ABLATE (aacg_kernels.h); always 0 in the shipped library */
+    /* host waits (aacg_wait.h): bounded by wait.limit_s, AACG_ERR_TIMEOUT + a dump of what was in flight when it passes */
+    aacg_wait_policy wait;
+    std::vector<hipStream_t> foreign;       /* callers' streams this engine has enqueued work on (aacg_decode_device & co.): what "everything of this engine" must cover */
+    float* h_ov = nullptr;                  /* page-locked 4 KB: aacg_get_overlap / aacg_set_overlap staging (an asynchronous copy the wait can bound) */
+    bool wedged = false;                    /* a wait has timed out: destruction leaks instead of waiting again */
+    hipStream_t dump_stream = nullptr;      /* in_flight(): the cells are read by a copy on a stream of its own, into page-locked memory made at aacg_create */
+    aacg_xl_cell* h_dump = nullptr;         /* (nothing is allocated or freed while a device may be hung: hipHostFree / hipStreamDestroy wait for it) */
+    std::string pipe_note;                  /* what pipe_setup found (one hardware queue, ...): told once through aacg_last_error */
     std::string err;
 };
 
@@ -156,6 +165,8 @@ struct aacg_plan {
     hipEvent_t uploaded = nullptr;          /* the tables are on the device */
     hipEvent_t last_use = nullptr;          /* recorded at destruction on last_stream: everything launched with this plan */
     hipStream_t last_stream = nullptr;      /* stream of the most recent launch (no per-launch event: it costs 3 us per step) */
+    uint32_t unit_sets = 1, cur_set = 0;    /* aacg_plan_set_unit_sets: d_units holds unit_sets copies of the records; launches read cur_set */
+    const aacg_dev_unit* units_now() const { return d_units + (size_t)cur_set * n_units; }
     bool used = false;
     bool last_pipelined = false;            /* its most recent launch went through aacg_decode_pipelined */
     uint64_t seen_epoch = ~0ull;            /* engine epoch right after this plan's last launch */
@@ -225,6 +236,106 @@ bool is_pinned(const void* p)
     hipPointerAttribute_t a;
     if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
     return a.type == hipMemoryTypeHost;
+}
+
+/* ---- bounded host waits (aacg_wait.h) ------------------------------------------------------------------------------ */
+#define AACG_DUMP_CELLS 4096u
+const char* event_state(hipEvent_t ev)
+{
+    if (!ev) return "-";
+    const hipError_t st = hipEventQuery(ev);
+    (void)hipGetLastError();
+    return st == hipSuccess ? "done" : st == hipErrorNotReady ? "PENDING" : "error";
+}
+const char* stream_state(hipStream_t s)
+{
+    const hipError_t st = hipStreamQuery(s);
+    (void)hipGetLastError();
+    return st == hipSuccess ? "idle" : st == hipErrorNotReady ? "BUSY" : "error";
+}
+
+/* What was in flight, for the text of an AACG_ERR_TIMEOUT: the pipeline's counters, every stream's and completion event's state,
+ * and the rendezvous cells' state words (read by a copy on a stream of its own, itself bounded: a hung kernel does not stop the
+ * copy engines). */
+std::string in_flight(aacg_engine* e)
+{
+    char b[512];
+    std::string o;
+    const aacg_engine::pipe_t& pp = e->pipe;
+    std::snprintf(b, sizeof b, "pipeline: %llu launches issued, %llu in the current sequence on %d streams, %llu chained, open %d serial %d concurrent %d, rv epoch %llu; ",
+                  (unsigned long long)pp.issued, (unsigned long long)pp.n, pp.streams, (unsigned long long)pp.chained, (int)pp.open, (int)pp.serial, (int)pp.concurrent, e->rv_epoch);
+    o += b;
+    o += std::string("engine stream ") + stream_state(e->stream);
+    for (int k = 0; k < AACG_PIPE_STREAMS; k++) if (pp.stream[k]) { std::snprintf(b, sizeof b, ", pipe stream %d %s", k, stream_state(pp.stream[k])); o += b; }
+    for (int k = 0; k < 2; k++) if (e->slot[k].stream) { std::snprintf(b, sizeof b, ", batch slot %d %s (busy %d, kernel %s, copy-back %s)", k, stream_state(e->slot[k].stream), (int)e->slot[k].busy, event_state(e->slot[k].kernel_done), event_state(e->slot[k].done)); o += b; }
+    for (size_t k = 0; k < e->foreign.size(); k++) { std::snprintf(b, sizeof b, ", caller stream %p %s", (void*)e->foreign[k], stream_state(e->foreign[k])); o += b; }
+    if (pp.stream[0]) {
+        o += "; completion events [ring slot: per stream]";
+        for (int r = 0; r < AACG_PIPE_RING; r++) {
+            std::snprintf(b, sizeof b, " %d:", r); o += b;
+            for (int k = 0; k < AACG_PIPE_STREAMS; k++) { o += k ? "/" : ""; o += event_state(pp.seen[r][k] ? pp.seen[r][k] : nullptr); }
+        }
+    }
+    /* the cross-launch cells' state words by kind and epoch */
+    const size_t n_cells = (size_t)e->cfg.max_streams * (size_t)e->cfg.max_channels * (size_t)AACG_OV_BUFFERS;
+    const size_t take = n_cells < AACG_DUMP_CELLS ? n_cells : AACG_DUMP_CELLS;
+    /* the stream is made at the first dump, not with the engine: one more stream at set-up shifts the runtime's stream -> hardware
+     * queue assignment under the pipeline's streams (the comment at aacg_engine::pool); it is destroyed with the engine */
+    if (!e->dump_stream && hipStreamCreateWithFlags(&e->dump_stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); e->dump_stream = nullptr; }
+    hipStream_t ds = e->dump_stream;
+    aacg_xl_cell* h = e->h_dump;
+    if (e->d_xl_cells && ds && h && hipMemcpyAsync(h, e->d_xl_cells, take * sizeof(aacg_xl_cell), hipMemcpyDeviceToHost, ds) == hipSuccess) {
+        aacg_wait_policy quick; quick.limit_s = 0.25;
+        if (aacg_wait_stream(ds, quick) == hipSuccess) {
+            unsigned long long n_tail = 0, n_head = 0, lo = ~0ull, hi = 0;
+            std::string heads;
+            for (size_t i = 0; i < take; i++) {
+                const unsigned long long w = h[i].state, ep = w >> 2;
+                if (!w) continue;
+                if ((w & 3) == AACG_RV_TAIL) n_tail++;
+                if ((w & 3) == AACG_RV_HEAD) { n_head++; if (n_head <= 4) { std::snprintf(b, sizeof b, " cell %zu epoch %llu", i, ep); heads += b; } }
+                lo = ep < lo ? ep : lo; hi = ep > hi ? ep : hi;
+            }
+            std::snprintf(b, sizeof b, "; cross-launch cells (first %zu of %zu): %llu TAIL, %llu HEAD (a HEAD nobody finished = a consumer whose producer never came:%s), epochs %llu..%llu",
+                          take, n_cells, n_tail, n_head, heads.empty() ? " none" : heads.c_str(), lo == ~0ull ? 0ull : lo, hi);
+            o += b;
+        } else o += "; cross-launch cells unreadable: a device-to-host copy on a fresh stream did not complete in 250 ms either";
+    } else { (void)hipGetLastError(); o += "; cross-launch cells not read"; }
+    return o;
+}
+
+int timed_out(aacg_engine* e, const char* what)
+{
+    char b[160];
+    std::snprintf(b, sizeof b, "%s: the GPU did not answer within %.1f s (aacg_set_wait_limit_ms). In flight: ", what, e->wait.limit_s);
+    e->err = std::string(b) + in_flight(e);
+    e->wedged = true;
+    return AACG_ERR_TIMEOUT;
+}
+int wait_stream(aacg_engine* e, hipStream_t s, const char* what)
+{
+    const hipError_t st = aacg_wait_stream(s, e->wait);
+    if (st == hipSuccess) return AACG_OK;
+    if (st == hipErrorNotReady) return timed_out(e, what);
+    e->err = std::string(what) + ": " + hipGetErrorString(st);
+    return AACG_ERR_NO_DEVICE;
+}
+int wait_event(aacg_engine* e, hipEvent_t ev, const char* what)
+{
+    const hipError_t st = aacg_wait_event(ev, e->wait);
+    if (st == hipSuccess) return AACG_OK;
+    if (st == hipErrorNotReady) return timed_out(e, what);
+    e->err = std::string(what) + ": " + hipGetErrorString(st);
+    return AACG_ERR_NO_DEVICE;
+}
+/* a caller's stream the engine has put work on */
+void note_stream(aacg_engine* e, hipStream_t s)
+{
+    if (!s || s == e->stream) return;
+    for (hipStream_t k : e->pipe.stream) if (k == s) return;
+    for (hipStream_t k : e->foreign) if (k == s) return;
+    if (e->foreign.size() >= 32) e->foreign.erase(e->foreign.begin());
+    e->foreign.push_back(s);
 }
 
 }  // namespace
@@ -377,10 +488,33 @@ int pipe_join(aacg_engine* e, hipStream_t s)
         if (s) {
             HIP_TRY(e, hipEventRecord(pp.tail[k], pp.stream[k]), AACG_ERR_NO_DEVICE);
             HIP_TRY(e, hipStreamWaitEvent(s, pp.tail[k], 0), AACG_ERR_NO_DEVICE);
-        } else HIP_TRY(e, hipStreamSynchronize(pp.stream[k]), AACG_ERR_NO_DEVICE);
+        } else { const int wrc = wait_stream(e, pp.stream[k], "waiting for the pipelined launches"); if (wrc) return wrc; }
     }
     if (!s) pp.open = false;                           /* the host has seen the streams drained: nothing in flight any more */
     pp.joined_stream = s; pp.joined_n = pp.issued;
+    return AACG_OK;
+}
+
+/* Everything this engine has enqueued anywhere is complete: its own stream, the pipeline's, the host-buffer path's two, and
+ * every caller's stream it was asked to launch on (what hipDeviceSynchronize stood for until round 5 — without waiting for
+ * streams the engine never touched, and bounded). */
+int quiesce(aacg_engine* e, const char* what)
+{
+    int rc = wait_stream(e, e->stream, what);
+    if (rc) return rc;
+    if (e->pipe.stream[0]) {
+        for (hipStream_t ps : e->pipe.stream) if (ps && (rc = wait_stream(e, ps, what))) return rc;
+        e->pipe.open = false;
+        e->pipe.joined_stream = nullptr; e->pipe.joined_n = e->pipe.issued;
+    }
+    for (auto& sl : e->slot) if (sl.stream && (rc = wait_stream(e, sl.stream, what))) return rc;
+    for (size_t k = 0; k < e->foreign.size();) {
+        const hipError_t st = aacg_wait_stream(e->foreign[k], e->wait);
+        if (st == hipErrorNotReady) return timed_out(e, what);
+        if (st != hipSuccess) { (void)hipGetLastError(); e->foreign.erase(e->foreign.begin() + (long)k); continue; }   /* the caller has destroyed it: nothing left on it */
+        k++;
+    }
+    e->wedged = false;                                  /* everything has answered */
     return AACG_OK;
 }
 
@@ -534,8 +668,50 @@ int aacg_create(const aacg_config* cfg, aacg_engine** out)
     if ((e->ablate & 16) && hipMalloc(&e->d_trace, 1u << 22) == hipSuccess) (void)hipMemset(e->d_trace, 0, 1u << 22);
 #endif
     /* the uploads and memsets above went to the null stream; the engine's streams are non-blocking and would not wait for it */
-    if (!hip_ok(e, hipDeviceSynchronize(), "synchronize after setup")) { aacg_destroy(e); return AACG_ERR_NO_DEVICE; }
+    if (!hip_ok(e, hipHostMalloc((void**)&e->h_ov, 4096, hipHostMallocDefault), "hipHostMalloc (overlap staging)") ||
+        !hip_ok(e, hipHostMalloc((void**)&e->h_dump, AACG_DUMP_CELLS * sizeof(aacg_xl_cell), hipHostMallocDefault), "hipHostMalloc (dump staging)")) { aacg_destroy(e); return AACG_ERR_OUT_OF_MEMORY; }
+    { const int wrc = wait_stream(e, nullptr, "aacg_create: waiting for the table uploads"); if (wrc) { std::fprintf(stderr, "aacgpu: %s\n", e->err.c_str()); aacg_destroy(e); return wrc; } }
     *out = e;
+    return AACG_OK;
+}
+
+int aacg_set_wait_limit_ms(aacg_engine* e, uint32_t ms)
+{
+    if (!e || !ms) return AACG_ERR_INVALID_ARG;
+    e->wait.limit_s = ms * 1e-3;
+    return AACG_OK;
+}
+int aacg_debug_in_flight(aacg_engine* e, char* dst, size_t n)
+{
+    if (!e || !dst || !n) return AACG_ERR_INVALID_ARG;
+    (void)hipSetDevice(e->cfg.device_ordinal);
+    const std::string t = in_flight(e);
+    std::snprintf(dst, n, "%s", t.c_str());
+    return (int)t.size();
+}
+static int pipe_setup(aacg_engine* e);
+/* tests only (aacgpu_tools.h): keeps one of the engine's streams busy for `ms` milliseconds (a single wave polling a word nobody
+ * sets, bounded by the device clock), so that the bounded waits and their dump can be exercised without a broken device */
+int aacg_debug_stall(aacg_engine* e, int which, uint32_t ms)
+{
+    if (!e || which < 0 || which > AACG_PIPE_STREAMS || ms > 5000) return AACG_ERR_INVALID_ARG;
+    HIP_TRY(e, hipSetDevice(e->cfg.device_ordinal), AACG_ERR_NO_DEVICE);
+    if (which) { const int rc = pipe_setup(e); if (rc) return rc; }
+    hipStream_t s = which ? e->pipe.stream[which - 1] : e->stream;
+    /* the cross-launch cells' pool is zeroed memory nobody writes a 1 into at word 2 of a cell (the PCM address of a HEAD is 8-byte aligned and never 1) */
+    static unsigned* d_flag = nullptr;
+    if (!d_flag) { HIP_TRY(e, hipMalloc((void**)&d_flag, 8), AACG_ERR_OUT_OF_MEMORY); HIP_TRY(e, hipMemset(d_flag, 0, 8), AACG_ERR_NO_DEVICE); }
+    hipLaunchKernelGGL(aacg_probe_wait, dim3(1), dim3(1), 0, s, d_flag, d_flag + 1, (long long)ms * 100000LL);      /* 100 MHz clock */
+    HIP_TRY(e, hipGetLastError(), AACG_ERR_NO_DEVICE);
+    if (which) { e->pipe.open = true; e->pipe.issued++; }     /* something of the pipeline is in flight */
+    return AACG_OK;
+}
+/* measurement only (aacgpu_tools.h): how the host waits once a wait has lasted spin_us */
+int aacg_debug_set_wait_mode(aacg_engine* e, int mode, double spin_us)
+{
+    if (!e || mode < AACG_WAIT_SPIN || mode > AACG_WAIT_BLOCK || e->pipe.stream[0]) return AACG_ERR_INVALID_ARG;   /* before the first pipelined launch: the events' flags depend on it */
+    e->wait.mode = mode;
+    if (spin_us >= 0) e->wait.spin_us = spin_us;
     return AACG_OK;
 }
 
@@ -543,7 +719,17 @@ void aacg_destroy(aacg_engine* e)
 {
     if (!e) return;
     (void)hipSetDevice(e->cfg.device_ordinal);
-    (void)hipDeviceSynchronize();
+    /* a device that has stopped answering is not waited for again, and nothing of it is freed (hipFree waits for the device):
+     * the memory stays with the process, the caller gets its thread back */
+    if (e->wedged) { e->wait.limit_s = e->wait.limit_s < 0.25 ? e->wait.limit_s : 0.25; e->wedged = false; }   /* it did not answer once: one short look whether it does now */
+    if (quiesce(e, "aacg_destroy") != AACG_OK) {
+        std::fprintf(stderr, "aacgpu: aacg_destroy: %s — device memory of this engine is left allocated\n", e->err.c_str());
+        delete e;
+        return;
+    }
+    if (e->h_ov) (void)hipHostFree(e->h_ov);
+    if (e->h_dump) (void)hipHostFree(e->h_dump);
+    if (e->dump_stream) (void)hipStreamDestroy(e->dump_stream);
     if (e->d_tab) (void)hipFree(e->d_tab);
     if (e->d_pns) (void)hipFree(e->d_pns);
     if (e->d_xl_cells) (void)hipFree(e->d_xl_cells);
@@ -578,7 +764,8 @@ static int ov_check(aacg_engine* e, uint32_t stream, uint32_t channel)
         return AACG_ERR_INVALID_ARG;
     }
     HIP_TRY(e, hipSetDevice(e->cfg.device_ordinal), AACG_ERR_NO_DEVICE);
-    HIP_TRY(e, hipDeviceSynchronize(), AACG_ERR_NO_DEVICE);
+    const int rc = quiesce(e, "overlap state: waiting for the launches that advance it");
+    if (rc) return rc;
     e->pipe.open = false;                               /* nothing in flight any more: the next pipelined launch starts from complete state */
     return AACG_OK;
 }
@@ -594,9 +781,8 @@ int aacg_reset_stream(aacg_engine* e, uint32_t stream)
     int rc = ov_check(e, stream, 0);
     if (rc) return rc;
     for (int c = 0; c < e->cfg.max_channels; c++)
-        HIP_TRY(e, hipMemset(ov_ptr(e, stream, (uint32_t)c), 0, 4096), AACG_ERR_NO_DEVICE);
-    HIP_TRY(e, hipDeviceSynchronize(), AACG_ERR_NO_DEVICE);       /* null-stream memsets: a launch on a non-blocking stream must not overtake them */
-    return AACG_OK;
+        HIP_TRY(e, hipMemsetAsync(ov_ptr(e, stream, (uint32_t)c), 0, 4096, e->stream), AACG_ERR_NO_DEVICE);
+    return wait_stream(e, e->stream, "aacg_reset_stream");      /* complete before any later launch, whatever stream it takes */
 }
 
 int aacg_get_overlap(aacg_engine* e, uint32_t stream, uint32_t channel, float* dst)
@@ -604,7 +790,9 @@ int aacg_get_overlap(aacg_engine* e, uint32_t stream, uint32_t channel, float* d
     int rc = ov_check(e, stream, channel);
     if (rc) return rc;
     if (!dst) return AACG_ERR_INVALID_ARG;
-    HIP_TRY(e, hipMemcpy(dst, ov_ptr(e, stream, channel), 4096, hipMemcpyDeviceToHost), AACG_ERR_NO_DEVICE);
+    HIP_TRY(e, hipMemcpyAsync(e->h_ov, ov_ptr(e, stream, channel), 4096, hipMemcpyDeviceToHost, e->stream), AACG_ERR_NO_DEVICE);
+    if ((rc = wait_stream(e, e->stream, "aacg_get_overlap"))) return rc;
+    std::memcpy(dst, e->h_ov, 4096);
     /* the pool holds the state PCM-scaled (AACG_PCM_SCALE in the windows); the ABI speaks the reference's scale
      * (FilterBank.overlaps, filter_bank.js:38-41): a power of two, exact both ways */
     for (int i = 0; i < 1024; i++) dst[i] *= 32768.0f;
@@ -616,10 +804,9 @@ int aacg_set_overlap(aacg_engine* e, uint32_t stream, uint32_t channel, const fl
     int rc = ov_check(e, stream, channel);
     if (rc) return rc;
     if (!src) return AACG_ERR_INVALID_ARG;
-    float scaled[1024];
-    for (int i = 0; i < 1024; i++) scaled[i] = src[i] * AACG_PCM_SCALE;
-    HIP_TRY(e, hipMemcpy(ov_ptr(e, stream, channel), scaled, 4096, hipMemcpyHostToDevice), AACG_ERR_NO_DEVICE);
-    return AACG_OK;
+    for (int i = 0; i < 1024; i++) e->h_ov[i] = src[i] * AACG_PCM_SCALE;
+    HIP_TRY(e, hipMemcpyAsync(ov_ptr(e, stream, channel), e->h_ov, 4096, hipMemcpyHostToDevice, e->stream), AACG_ERR_NO_DEVICE);
+    return wait_stream(e, e->stream, "aacg_set_overlap");
 }
 
 int aacg_get_table(aacg_engine* e, int which, float* dst, size_t n)
@@ -721,14 +908,20 @@ void aacg_plan_destroy(aacg_plan* p)
     (void)hipSetDevice(e->cfg.device_ordinal);
     /* the buffers go back to the free list: wait for the copies into them and for the last kernel that reads them
      * (two events, not the whole device) */
-    if (p->uploaded) { (void)hipEventSynchronize(p->uploaded); (void)hipEventDestroy(p->uploaded); }
-    if (p->last_pipelined) (void)pipe_join(e, nullptr);       /* its launches on both internal streams */
+    bool idle = !e->wedged;
+    if (p->uploaded) { idle = idle && wait_event(e, p->uploaded, "aacg_plan_destroy: the plan's uploads") == AACG_OK; (void)hipEventDestroy(p->uploaded); }
+    if (p->last_pipelined) idle = idle && pipe_join(e, nullptr) == AACG_OK;       /* its launches on the internal streams */
     if (p->last_use) {
-        if (p->used) {
-            if (hipEventRecord(p->last_use, p->last_stream) == hipSuccess) (void)hipEventSynchronize(p->last_use);
-            else { (void)hipGetLastError(); (void)hipDeviceSynchronize(); }        /* the stream is gone: wait for everything */
+        if (p->used && idle) {
+            if (hipEventRecord(p->last_use, p->last_stream) == hipSuccess) idle = wait_event(e, p->last_use, "aacg_plan_destroy: the plan's last launch") == AACG_OK;
+            else { (void)hipGetLastError(); idle = quiesce(e, "aacg_plan_destroy") == AACG_OK; }        /* the stream is gone: wait for everything of the engine */
         }
         (void)hipEventDestroy(p->last_use);
+    }
+    if (!idle) {                                        /* a launch that may still be running reads these buffers: they are not recycled */
+        if (e->pipe.plan == p) e->pipe.plan = nullptr;
+        delete p;
+        return;
     }
     void* const ptr[AACG_PLAN_BUFFERS] = {p->d_units, p->d_runs, p->d_tns, p->d_scratch, p->d_spec, p->d_cce[0], p->d_cce[1], p->d_cce[2], p->d_cce[3],
                            p->d_rv[0], p->d_rv[1], p->d_rv[2], p->d_rv[3]};
@@ -783,6 +976,7 @@ int aacg_decode_device(aacg_engine* e, aacg_plan* p, const void* d_coeffs, const
     const aacg_route R = route_of(e, p->h, false);
     if ((rc = plan_check_route(e, p, R))) return rc;
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : e->stream;
+    note_stream(e, s);
     if (!p->used) HIP_TRY(e, hipStreamWaitEvent(s, p->uploaded, 0), AACG_ERR_NO_DEVICE);
     /* pipelined launches in flight (of this plan or of another: the caller orders PLANS, the engine its own streams) first */
     if ((rc = pipe_join(e, s))) return rc;
@@ -796,7 +990,7 @@ int aacg_decode_device(aacg_engine* e, aacg_plan* p, const void* d_coeffs, const
     const cce_bufs cb = {(const aacg_run*)p->d_cce[0], (const aacg_couple_job*)p->d_cce[1], (const float*)p->d_cce[2], (float*)p->d_cce[3]};
     const rv_bufs rvb = {(const aacg_run*)p->d_rv[0], (const aacg_rv_link*)p->d_rv[1], (unsigned long long*)p->d_rv[2], (float*)p->d_rv[3]};
     const xl_args serial = {false, 0ull, 0};
-    rc = launch_run(e, R, p->d_units, p->d_runs, p->d_tns, p->d_scratch, p->d_spec, cb, rvb, p->h, d_coeffs, d_meta, d_pcm,
+    rc = launch_run(e, R, p->units_now(), p->d_runs, p->d_tns, p->d_scratch, p->d_spec, cb, rvb, p->h, d_coeffs, d_meta, d_pcm,
                     (int)(p->launches % AACG_OV_BUFFERS), s, serial, nullptr);
     if (rc) return rc;
     p->last_stream = s;
@@ -808,18 +1002,21 @@ int aacg_decode_device(aacg_engine* e, aacg_plan* p, const void* d_coeffs, const
 
 /* ---- pipelined launches ---------------------------------------------------------------- */
 /* true if a kernel on b runs while one on a is running (both idle before) */
-static bool streams_overlap(aacg_engine* e, hipStream_t a, hipStream_t b, unsigned* d_probe)
+static bool streams_overlap(aacg_engine* e, hipStream_t a, hipStream_t b, unsigned* d_probe, unsigned* h_seen)
 {
-    if (hipMemsetAsync(d_probe, 0, 8, a) != hipSuccess || hipStreamSynchronize(a) != hipSuccess) return false;
+    aacg_wait_policy quick = e->wait; quick.limit_s = quick.limit_s < 2.0 ? quick.limit_s : 2.0;
+    if (hipMemsetAsync(d_probe, 0, 8, a) != hipSuccess || aacg_wait_stream(a, quick) != hipSuccess) { (void)hipGetLastError(); return false; }
     hipLaunchKernelGGL(aacg_probe_wait, dim3(1), dim3(1), 0, a, d_probe, d_probe + 1, 50000LL);      /* at most 0.5 ms (100 MHz clock) */
     hipLaunchKernelGGL(aacg_probe_set, dim3(1), dim3(1), 0, b, d_probe);
-    unsigned seen = 0;
-    if (hipStreamSynchronize(a) != hipSuccess || hipStreamSynchronize(b) != hipSuccess ||
-        hipMemcpy(&seen, d_probe + 1, 4, hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); return false; }
-    (void)e;
-    return seen != 0;
+    *h_seen = 0;
+    if (aacg_wait_stream(b, quick) != hipSuccess || hipMemcpyAsync(h_seen, d_probe + 1, 4, hipMemcpyDeviceToHost, a) != hipSuccess ||
+        aacg_wait_stream(a, quick) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return *h_seen != 0;
 }
 
+/* The pipeline's streams and events, made in locals and committed to the engine only when ALL of them exist: a failure half-way
+ * destroys what was made and leaves e->pipe untouched, so that the next call tries again (the first stream used
+ * to be the "ready" flag, and a later failure left null streams and events behind it). */
 static int pipe_setup(aacg_engine* e)
 {
     aacg_engine::pipe_t& pp = e->pipe;
@@ -828,28 +1025,56 @@ static int pipe_setup(aacg_engine* e)
     /* Streams that really run side by side.  Streams of the highest priority are dealt their hardware queues apart from the
      * crowd of ordinary streams a host process may have made (PyTorch: 32 at once); every candidate is PROBED against the
      * streams already chosen, and further candidates are tried if it shares a queue with one of them after all.  Streams that
-     * never overlap still decode correctly — serially. */
+     * never overlap still decode correctly — serially.  (Highest priority also means: ahead of the host process's own
+     * ordinary streams when both have work; the pipeline's launches are 11 us each, nothing starves.) */
     int least = 0, greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-    unsigned* d_probe = nullptr;
-    HIP_TRY(e, hipMalloc((void**)&d_probe, 8), AACG_ERR_OUT_OF_MEMORY);
-    HIP_TRY(e, hipStreamCreateWithPriority(&pp.stream[0], hipStreamNonBlocking, greatest), AACG_ERR_NO_DEVICE);
-    hipStream_t spare[8]; int n_spare = 0, have = 1;
+    struct made_t {
+        hipStream_t stream[AACG_PIPE_STREAMS] = {};
+        hipStream_t spare[8] = {}; int n_spare = 0;
+        hipEvent_t mark[AACG_PIPE_RING][AACG_PIPE_STREAMS] = {}, tail[AACG_PIPE_STREAMS] = {}, fork = nullptr;
+        unsigned* d_probe = nullptr; unsigned* h_seen = nullptr;
+        void release(bool keep) {
+            for (int i = 0; i < n_spare; i++) if (spare[i]) (void)hipStreamDestroy(spare[i]);
+            if (d_probe) (void)hipFree(d_probe);
+            if (h_seen) (void)hipHostFree(h_seen);
+            if (keep) return;
+            for (auto& round : mark) for (hipEvent_t ev : round) if (ev) (void)hipEventDestroy(ev);
+            for (hipEvent_t ev : tail) if (ev) (void)hipEventDestroy(ev);
+            if (fork) (void)hipEventDestroy(fork);
+            for (hipStream_t st : stream) if (st) (void)hipStreamDestroy(st);
+        }
+    } m;
+#define PIPE_TRY(call, code) do { if (!hip_ok(e, (call), #call)) { m.release(false); return (code); } } while (0)
+    PIPE_TRY(hipMalloc((void**)&m.d_probe, 8), AACG_ERR_OUT_OF_MEMORY);
+    PIPE_TRY(hipHostMalloc((void**)&m.h_seen, 4, hipHostMallocDefault), AACG_ERR_OUT_OF_MEMORY);
+    PIPE_TRY(hipStreamCreateWithPriority(&m.stream[0], hipStreamNonBlocking, greatest), AACG_ERR_NO_DEVICE);
+    int have = 1;
     for (int attempt = 0; attempt < 8 && have < AACG_PIPE_STREAMS; attempt++) {
         hipStream_t cand = nullptr;
-        HIP_TRY(e, hipStreamCreateWithPriority(&cand, hipStreamNonBlocking, attempt < 6 ? greatest : 0), AACG_ERR_NO_DEVICE);
+        PIPE_TRY(hipStreamCreateWithPriority(&cand, hipStreamNonBlocking, attempt < 6 ? greatest : 0), AACG_ERR_NO_DEVICE);
         bool apart = true;
-        for (int k = 0; k < have && apart; k++) apart = streams_overlap(e, pp.stream[k], cand, d_probe);
-        if (apart) pp.stream[have++] = cand; else spare[n_spare++] = cand;
+        for (int k = 0; k < have && apart; k++) apart = streams_overlap(e, m.stream[k], cand, m.d_probe, m.h_seen);
+        if (apart) m.stream[have++] = cand; else m.spare[m.n_spare++] = cand;
     }
-    pp.concurrent = have == AACG_PIPE_STREAMS;
-    while (have < AACG_PIPE_STREAMS) pp.stream[have++] = spare[--n_spare];
-    for (int i = 0; i < n_spare; i++) (void)hipStreamDestroy(spare[i]);
-    (void)hipFree(d_probe);
-    /* events that order and nothing else: no time stamps, no system-scope fence at the record */
-    for (auto& round : pp.mark) for (hipEvent_t& ev : round) HIP_TRY(e, hipEventCreateWithFlags(&ev, hipEventDisableTiming | hipEventDisableSystemFence), AACG_ERR_NO_DEVICE);
-    for (hipEvent_t& ev : pp.tail) HIP_TRY(e, hipEventCreateWithFlags(&ev, hipEventDisableTiming | hipEventDisableSystemFence), AACG_ERR_NO_DEVICE);
-    HIP_TRY(e, hipEventCreateWithFlags(&pp.fork, hipEventDisableTiming | hipEventDisableSystemFence), AACG_ERR_NO_DEVICE);
+    const bool concurrent = have == AACG_PIPE_STREAMS;
+    while (have < AACG_PIPE_STREAMS) { m.stream[have++] = m.spare[--m.n_spare]; m.spare[m.n_spare] = nullptr; }
+    /* events that order and nothing else: no time stamps, no system-scope fence at the record (AACG_WAIT_BLOCK, a measurement
+     * mode: interrupt-driven waits) */
+    const unsigned flags = hipEventDisableTiming | hipEventDisableSystemFence | (e->wait.mode == AACG_WAIT_BLOCK ? hipEventBlockingSync : 0u);
+    for (auto& round : m.mark) for (hipEvent_t& ev : round) PIPE_TRY(hipEventCreateWithFlags(&ev, flags), AACG_ERR_NO_DEVICE);
+    for (hipEvent_t& ev : m.tail) PIPE_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming | hipEventDisableSystemFence), AACG_ERR_NO_DEVICE);
+    PIPE_TRY(hipEventCreateWithFlags(&m.fork, hipEventDisableTiming | hipEventDisableSystemFence), AACG_ERR_NO_DEVICE);
+#undef PIPE_TRY
+    m.release(true);
+    std::memcpy(pp.mark, m.mark, sizeof pp.mark);
+    std::memcpy(pp.tail, m.tail, sizeof pp.tail);
+    pp.fork = m.fork;
+    pp.concurrent = concurrent;
+    std::memcpy(pp.stream, m.stream, sizeof pp.stream);      /* last: stream[0] is what says "set up" */
+    if (!concurrent)
+        e->pipe_note = "aacg_decode_pipelined: the engine's internal HIP streams were NOT seen to run side by side when the pipeline was set up "
+                       "(the runtime put them on one hardware queue): pipelined launches are correct and run one behind the other (aacg_pipeline_info)";
     return AACG_OK;
 }
 
@@ -888,13 +1113,13 @@ int aacg_decode_pipelined_timed(aacg_engine* e, aacg_plan* p, const void* d_coef
         if (ord.sync_round >= 0) {
             /* (bounded: if an event has not completed after two seconds — a stalled device, a driver that lost a signal — the
              * ordering moves to the GPU for this round, which is always correct, instead of leaving the caller in a wait) */
-            const auto deadline = std::chrono::steady_clock::now() + std::chrono::seconds(2);
+            aacg_wait_policy bp = e->wait; bp.limit_s = bp.limit_s < 2.0 ? bp.limit_s : 2.0;
             for (hipEvent_t ev : pp.seen[((uint64_t)ord.sync_round / AACG_PIPE_MARK) % AACG_PIPE_RING]) {
                 if (!ev) continue;
-                hipError_t st;
-                while ((st = hipEventQuery(ev)) == hipErrorNotReady && std::chrono::steady_clock::now() < deadline) {}
+                /* aacg_wait.h: a few microseconds of polling (the GPU is seldom more than a launch behind), then the caller's core
+                 * is given back between polls — round 5 spun here without pause */
+                const hipError_t st = aacg_wait_event(ev, bp);
                 if (st == hipErrorNotReady) {
-                    (void)hipGetLastError();
                     for (hipStream_t ps : pp.stream) HIP_TRY(e, hipStreamWaitEvent(ps, ev, 0), AACG_ERR_NO_DEVICE);
                 } else HIP_TRY(e, st, AACG_ERR_NO_DEVICE);
             }
@@ -928,7 +1153,7 @@ int aacg_decode_pipelined_timed(aacg_engine* e, aacg_plan* p, const void* d_coef
     hipEvent_t const mine = (stop_mark && R.rv) ? (hipEvent_t)stop_mark : pp.mark[slot][ord.stream];
     if (ordered) pp.seen[slot][ord.stream] = mine;
     hipEvent_t bound = R.rv ? (stop_mark ? (hipEvent_t)stop_mark : (ordered ? mine : nullptr)) : nullptr;
-    rc = launch_run(e, R, p->d_units, p->d_runs, p->d_tns, p->d_scratch, p->d_spec, cb, rvb, p->h, d_coeffs, d_meta, d_pcm,
+    rc = launch_run(e, R, p->units_now(), p->d_runs, p->d_tns, p->d_scratch, p->d_spec, cb, rvb, p->h, d_coeffs, d_meta, d_pcm,
                     (int)(p->launches % AACG_OV_BUFFERS), s, xl, &epoch, bound);
     if (rc) return rc;
     if (ordered && bound != mine) HIP_TRY(e, hipEventRecord(mine, s), AACG_ERR_NO_DEVICE);
@@ -944,6 +1169,7 @@ int aacg_decode_pipelined_timed(aacg_engine* e, aacg_plan* p, const void* d_coef
     p->used = true;
     p->last_pipelined = true;
     plan_advance(e, p);
+    if (!e->pipe_note.empty()) { e->err = e->pipe_note; e->pipe_note.clear(); }   /* once: aacg_last_error after a successful call */
     return AACG_OK;
 }
 
@@ -966,25 +1192,69 @@ int aacg_pipeline_join(aacg_engine* e, void* hip_stream)
 uint64_t aacg_pipeline_chained(const aacg_engine* e) { return e ? e->pipe.chained : 0; }
 int aacg_pipeline_concurrent(const aacg_engine* e) { return e && e->pipe.concurrent ? 1 : 0; }
 int aacg_pipeline_streams_used(const aacg_engine* e) { return e && e->pipe.stream[0] ? e->pipe.streams : 0; }
+int aacg_pipeline_info(const aacg_engine* e, int* streams_used, int* concurrent)
+{
+    if (!e) return AACG_ERR_INVALID_ARG;
+    if (streams_used) *streams_used = e->pipe.stream[0] ? e->pipe.streams : 0;
+    if (concurrent) *concurrent = e->pipe.stream[0] ? (e->pipe.concurrent ? 1 : 0) : -1;
+    return AACG_OK;
+}
 
 /* The plan's device unit records take what the parser found (device to device); the run tables stay. */
 int aacg_plan_refresh_from_parse(aacg_engine* e, aacg_plan* p, const aacg_unit_desc* d_parsed_units,
                                  const aacg_parse_result* d_results, uint32_t max_units, uint32_t* d_refused, void* hip_stream)
 {
-    if (!e || !p || p->e != e || !d_parsed_units || !d_results || !max_units || !d_refused) return AACG_ERR_INVALID_ARG;
+    /* (without a map the kernel only reads the results) */
+    return aacg_plan_refresh_from_parse_ex(e, p, d_parsed_units, const_cast<aacg_parse_result*>(d_results), max_units, nullptr, p ? p->cur_set : 0, d_refused, hip_stream);
+}
+
+/* More sets of unit records for a plan that is refreshed while its earlier launches are in flight: the buffer is made anew
+ * (n_sets copies of the planner's records), before the plan's first launch. */
+int aacg_plan_set_unit_sets(aacg_engine* e, aacg_plan* p, uint32_t n_sets)
+{
+    if (!e || !p || p->e != e || n_sets < 1 || n_sets > 8) return AACG_ERR_INVALID_ARG;
+    if (p->used || p->launches) { e->err = "aacg_plan_set_unit_sets: before the plan's first launch"; return AACG_ERR_INVALID_ARG; }
+    if (n_sets == p->unit_sets) return AACG_OK;
+    HIP_TRY(e, hipSetDevice(e->cfg.device_ordinal), AACG_ERR_NO_DEVICE);
+    const size_t ub = sizeof(aacg_dev_unit) * p->n_units;
+    size_t got = 0;
+    void* fresh = pool_take(e, ub * n_sets, &got);
+    if (!fresh) return AACG_ERR_OUT_OF_MEMORY;
+    for (uint32_t k = 0; k < n_sets; k++)
+        if (!hip_ok(e, hipMemcpyAsync((char*)fresh + ub * k, p->h.units.data(), ub, hipMemcpyHostToDevice, e->stream), "upload plan unit sets")) { pool_give(e, fresh, got); return AACG_ERR_NO_DEVICE; }
+    pool_give(e, p->d_units, p->bytes[0]);               /* its upload is in front of whatever takes it next on the same stream */
+    p->d_units = (aacg_dev_unit*)fresh; p->bytes[0] = got;
+    p->unit_sets = n_sets; p->cur_set = 0;
+    HIP_TRY(e, hipEventRecord(p->uploaded, e->stream), AACG_ERR_NO_DEVICE);
+    return AACG_OK;
+}
+
+int aacg_plan_refresh_from_parse_ex(aacg_engine* e, aacg_plan* p, const aacg_unit_desc* d_parsed_units, aacg_parse_result* d_results,
+                                    uint32_t max_units, const aacg_refresh_map* d_map, uint32_t set, uint32_t* d_refused, void* hip_stream)
+{
+    if (!e || !p || p->e != e || !d_parsed_units || !d_results || !max_units || !d_refused || set >= p->unit_sets) return AACG_ERR_INVALID_ARG;
     if (e->cfg.input_kind != AACG_INPUT_QUANT_I16) { e->err = "aacg_plan_refresh_from_parse needs a QUANT_I16 engine"; return AACG_ERR_INVALID_ARG; }
     if (p->h.any_tns || p->h.any_pns || e->cfg.tns_mode == AACG_TNS_SPEC) {
         e->err = "aacg_plan_refresh_from_parse: TNS records / noise tables are prepared on the host, such plans are rebuilt per batch";
         return AACG_ERR_UNSUPPORTED;
     }
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : e->stream;
+    note_stream(e, s);
     HIP_TRY(e, hipStreamWaitEvent(s, p->uploaded, 0), AACG_ERR_NO_DEVICE);
+    if (p->unit_sets > 1) {
+        /* a set of its own: nothing in flight reads it (the caller's word), so neither the pipeline is joined nor the plan's
+         * sequence of overlapped launches ended; the next launch reads this set */
+        aacg_refresh_launch(p->d_units + (size_t)set * p->n_units, d_parsed_units, d_results, d_map, p->n_units, max_units, 1, d_refused, s);
+        HIP_TRY(e, hipGetLastError(), AACG_ERR_NO_DEVICE);
+        p->cur_set = set;
+        return AACG_OK;
+    }
     if (p->last_pipelined) { int jrc = pipe_join(e, s); if (jrc) return jrc; }
     if (p->used && p->last_stream != s && !p->last_pipelined) {              /* the records' readers on the plan's previous stream first */
         HIP_TRY(e, hipEventRecord(p->last_use, p->last_stream), AACG_ERR_NO_DEVICE);
         HIP_TRY(e, hipStreamWaitEvent(s, p->last_use, 0), AACG_ERR_NO_DEVICE);
     }
-    aacg_refresh_launch(p->d_units, d_parsed_units, d_results, p->n_units, max_units, 1, d_refused, s);
+    aacg_refresh_launch(p->d_units, d_parsed_units, d_results, d_map, p->n_units, max_units, 1, d_refused, s);
     HIP_TRY(e, hipGetLastError(), AACG_ERR_NO_DEVICE);
     p->last_stream = s;
     p->used = true;
@@ -999,6 +1269,7 @@ int aacg_plan_refresh_units(aacg_engine* e, aacg_plan* p, const aacg_unit_desc* 
     int rc = aacg_plan_refresh_host(&p->h, units, n_units, e->cfg.sample_index, e->cfg.tns_mode == AACG_TNS_SPEC, &e->err);
     if (rc) return rc;
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : e->stream;
+    note_stream(e, s);
     HIP_TRY(e, hipStreamWaitEvent(s, p->uploaded, 0), AACG_ERR_NO_DEVICE);
     /* the plan's previous launch on ANOTHER stream may still be reading the records this copy overwrites: order behind it */
     if (p->last_pipelined) { int jrc = pipe_join(e, s); if (jrc) return jrc; }
@@ -1025,9 +1296,10 @@ int aacg_spectral_device(aacg_engine* e, aacg_plan* p, const void* d_coeffs, con
     if (!e || !p || p->e != e || !d_coeffs || !d_meta || !d_spec_out) return AACG_ERR_INVALID_ARG;
     if (e->cfg.input_kind != AACG_INPUT_QUANT_I16) { e->err = "spectral stage needs a QUANT_I16 engine"; return AACG_ERR_INVALID_ARG; }
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : e->stream;
+    note_stream(e, s);
     aacg_kparams P;
     std::memset(&P, 0, sizeof P);
-    P.units = p->d_units; P.coeffs = d_coeffs; P.meta = d_meta; P.spec_out = d_spec_out; P.tab = e->d_tab;
+    P.units = p->units_now(); P.coeffs = d_coeffs; P.meta = d_meta; P.spec_out = d_spec_out; P.tab = e->d_tab;
     HIP_TRY(e, hipStreamWaitEvent(s, p->uploaded, 0), AACG_ERR_NO_DEVICE);
     hipLaunchKernelGGL(aacg_spectral, dim3((p->n_units + AACG_WG_WAVES - 1) / AACG_WG_WAVES), dim3(AACG_WG_THREADS),
                        AACG_LDS_BYTES_SPECTRAL, s, P, (int)p->n_units);
@@ -1040,7 +1312,9 @@ int aacg_spectral_device(aacg_engine* e, aacg_plan* p, const void* d_coeffs, con
 int aacg_synchronize(aacg_engine* e, void* hip_stream)
 {
     if (!e) return AACG_ERR_INVALID_ARG;
-    HIP_TRY(e, hipStreamSynchronize(hip_stream ? (hipStream_t)hip_stream : e->stream), AACG_ERR_NO_DEVICE);
+    HIP_TRY(e, hipSetDevice(e->cfg.device_ordinal), AACG_ERR_NO_DEVICE);
+    const int rc = wait_stream(e, hip_stream ? (hipStream_t)hip_stream : e->stream, "aacg_synchronize");
+    if (rc) return rc;
     return pipe_join(e, nullptr);                       /* and whatever aacg_decode_pipelined has in flight */
 }
 
@@ -1057,7 +1331,8 @@ int aacg_wait(aacg_engine* e, uint64_t ticket)
     if (!e || ticket == 0 || ticket > e->submitted) return AACG_ERR_INVALID_ARG;
     aacg_engine::slot_t& sl = e->slot[(ticket - 1) & 1];
     if (sl.busy) {
-        HIP_TRY(e, hipEventSynchronize(sl.done), AACG_ERR_NO_DEVICE);
+        const int rc = wait_event(e, sl.done, "aacg_wait");
+        if (rc) return rc;
         sl.busy = false;
         if (sl.user_pcm) { std::memcpy(sl.user_pcm, sl.h_pcm, sl.user_pcm_bytes); sl.user_pcm = nullptr; }
     }

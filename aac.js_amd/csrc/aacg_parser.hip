@@ -5,6 +5,7 @@
  */
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -12,6 +13,7 @@
 
 #include "aacg_parse.h"
 #include "aacg_host.h"
+#include "aacg_wait.h"
 
 extern "C" DP_KERNEL(AACG_PARSE_WG_LARGE, 1)
 void aacg_parse_frames(const aacg_parse_params P) { aacg_parse::parse_body(P); }
@@ -83,6 +85,7 @@ struct aacg_parser {
     hipStream_t last_stream = nullptr;
     void* d_buf[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     size_t cap[7] = {0, 0, 0, 0, 0, 0, 0};
+    aacg_wait_policy wait;            /* aacg_parse_batch's host waits are bounded (aacg_wait.h): AACG_ERR_TIMEOUT */
     std::string err;
 };
 
@@ -162,7 +165,8 @@ const char* aacg_parse_status_string(int status)
         "Pulse tool not allowed in eight short sequence.", "Pulse SWB or offset out of range", "TODO: add pulse data",
         "TNS filter out of range", "Prediction not implemented.", "TODO: decode gain control/SSR", "TODO: PCE_ELEMENT",
         "maxSFB out of range", "Reserved ms mask type: 3", "Huffman: escape sequence too long",
-        "more elements or channels in the frame than allowed for" };
+        "more elements or channels in the frame than allowed for",
+        "the frame's elements are not the ones its stream began with" };
     return status >= 0 && status < (int)(sizeof text / sizeof *text) ? text[status] : "unknown status";
 }
 
@@ -196,7 +200,14 @@ void aacg_parser_destroy(aacg_parser* p)
 {
     if (!p) return;
     (void)hipSetDevice(p->device);
-    (void)hipDeviceSynchronize();
+    /* its own stream and the last caller's stream it launched on, bounded; a device that does not answer keeps the memory */
+    if ((p->stream && aacg_wait_stream(p->stream, p->wait) == hipErrorNotReady) ||
+        (p->last_stream && p->last_stream != p->stream && aacg_wait_stream(p->last_stream, p->wait) == hipErrorNotReady)) {
+        std::fprintf(stderr, "aacgpu: aacg_parser_destroy: the GPU did not answer within the wait limit — device memory of this parser is left allocated\n");
+        delete p;
+        return;
+    }
+    (void)hipGetLastError();
     if (p->order_free) (void)hipEventDestroy(p->order_free);
     if (p->d_order) (void)hipFree(p->d_order);
     for (int i = 0; i < 7; i++) if (p->d_buf[i]) (void)hipFree(p->d_buf[i]);
@@ -249,12 +260,26 @@ int aacg_parse_batch(aacg_parser* p, const uint8_t* bytes, size_t n_bytes, const
     P.n_frames = n_frames; P.max_units = max_units; P.max_channels = max_channels; P.options = options & ~AACG_PARSE_SKIP_ZERO_FILL;
     int rc = launch(p, P, s);
     if (rc) return rc;
+    /* the kernel first, bounded: the copies into the caller's (pageable) memory below wait inside the runtime, and a device that
+     * has just answered will carry them out */
+    { const hipError_t st = aacg_wait_stream(s, p->wait);
+      if (st == hipErrorNotReady) return fail(p, AACG_ERR_TIMEOUT, "aacg_parse_batch: the parse kernel did not complete within the wait limit (" + std::to_string(n_frames) + " frames, workgroups of " + std::to_string(P.wg_threads) + ")");
+      HIPCHECK(st); }
     HIPCHECK(hipMemcpyAsync(units, p->d_buf[2], sizes[2], hipMemcpyDeviceToHost, s));
     HIPCHECK(hipMemcpyAsync(q, p->d_buf[3], sizes[3], hipMemcpyDeviceToHost, s));
     HIPCHECK(hipMemcpyAsync(meta, p->d_buf[4], sizes[4], hipMemcpyDeviceToHost, s));
     if (tns) HIPCHECK(hipMemcpyAsync(tns, p->d_buf[5], sizes[5], hipMemcpyDeviceToHost, s));
     HIPCHECK(hipMemcpyAsync(results, p->d_buf[6], sizes[6], hipMemcpyDeviceToHost, s));
-    HIPCHECK(hipStreamSynchronize(s));
+    { const hipError_t st = aacg_wait_stream(s, p->wait);
+      if (st == hipErrorNotReady) return fail(p, AACG_ERR_TIMEOUT, "aacg_parse_batch: the copies back did not complete within the wait limit");
+      HIPCHECK(st); }
+    return AACG_OK;
+}
+
+int aacg_parser_set_wait_limit_ms(aacg_parser* p, uint32_t ms)
+{
+    if (!p || !ms) return AACG_ERR_INVALID_ARG;
+    p->wait.limit_s = ms * 1e-3;
     return AACG_OK;
 }
 

@@ -20,9 +20,11 @@
  * demuxer fed it; a flush finds the next frames' boundaries (the 13-bit ADTS frame_length: six byte reads per frame), hands the
  * bytes of ALL streams to ONE native call (aacg_pipeline_decode: bit streams up, parse kernel, kept plan refreshed on the device,
  * transform kernel, PCM down) and slices what comes back.  JavaScript touches no coefficient and no unit record; what
- * readChunk() returns are views of the batch's PCM array.  For streams whose frames are one SCE or one CPE
- * (channel_configuration 1 / 2), as the reference executes them (TNS identity, no PNS / coupling modes); decoders of other
- * layouts on a resident SharedEngine take the parsing route above, on an engine of their own sample rate.
+ * readChunk() returns are views of the batch's PCM array.  For ADTS byte streams of any channel configuration 1..8 (one
+ * pipeline per sample rate and channel count; a stream's element layout — SCE + CPE + CPE + LFE, say — is learnt on the device
+ * from its first frame, coupling elements are parsed and dropped), as the reference executes them (TNS identity, no PNS /
+ * coupling modes).  MP4 samples ('mp4a': packets without ADTS headers, several to a buffer, whose boundaries only a parse
+ * finds) and decoders with spec modes take the parsing route above on the same SharedEngine.
  * Replaces, per batch, what src/decoder.js:125-216 does per frame.
  */
 'use strict';
@@ -62,7 +64,10 @@ SharedEngine.prototype.attach = function (dec) {
     const cfg = dec.config;
     if (cfg.chanConfig + dec.maxCoupling > this.maxChannels) throw new Error('SharedEngine: ' + cfg.chanConfig + ' channels exceed maxChannels ' + this.maxChannels);
     if (dec.group) this.detach(dec);                       // a new cookie: a new stream
-    if (this.resident && cfg.profile === 2 && (cfg.chanConfig === 1 || cfg.chanConfig === 2) && !dec.tnsMode && !dec.pnsMode && !dec.cceMode && !dec.carryWindowShape)
+    /* the resident route reads ADTS frame lengths itself: an 'mp4a' track's samples have none (aurora.js feeds them through
+     * feedPacket, which the device route never sees — ADVICE round 5: such a decoder used to deliver nothing, without an error) */
+    const adts = !dec.format || dec.format.formatID === undefined || dec.format.formatID === 'aac ';
+    if (this.resident && adts && cfg.profile === 2 && cfg.chanConfig >= 1 && cfg.chanConfig <= 8 && !dec.tnsMode && !dec.pnsMode && !dec.cceMode && !dec.carryWindowShape)
         return this.attachResident(dec);
     let g = this.groups.get(cfg.sampleIndex);
     if (!g) {
@@ -111,13 +116,15 @@ SharedEngine.prototype.detach = function (dec) {
 };
 
 /* how many complete ADTS frames (at most `max`) start at byte `at` of `b`: their lengths into `lens`; -1 where the bytes at a
- * frame boundary are not an ADTS header (the reference's 'Invalid ADTS header.', adts_demuxer.js:29) */
+ * frame boundary are not an ADTS header (the reference's 'Invalid ADTS header.', adts_demuxer.js:29) — or are one whose
+ * frame_length is shorter than the header itself: a corrupt length field must not stall the stream silently (ADVICE round 5) */
 function scanFrames(b, at, max, lens) {
     let n = 0;
     while (n < max && at + 7 <= b.length) {
         if (b[at] !== 0xff || (b[at + 1] & 0xf0) !== 0xf0) return n ? n : -1;
         const len = ((b[at + 3] & 3) << 11) | (b[at + 4] << 3) | (b[at + 5] >> 5);
-        if (len < 7 || at + len > b.length) break;
+        if (len < 7) return n ? n : -1;
+        if (at + len > b.length) break;
         lens[n++] = len; at += len;
     }
     return n;
@@ -165,9 +172,9 @@ SharedEngine.prototype.deliverResident = function (g, b, out, failed) {
         const q = part[s].queue;
         for (let f = 0, i = s * F; f < F; f++, i++) {
             /* a frame the device refused: the reference's message for its status where the frame is reached (it was decoded as
-             * silence: the stream goes on); a frame whose elements are not the stream's channel configuration likewise */
+             * silence: the stream goes on); a frame whose elements are not the ones its stream began with has a status of its own
+             * (AACG_PARSE_LAYOUT, set where the plan's records are refreshed) */
             if (refused && results[8 * i]) q.push(new Error(g.addon.parseStatusString(results[8 * i])));
-            else if (refused && (results[8 * i + 1] !== 1 || results[8 * i + 2] !== C)) q.push(new Error('aacgpu: the frame\'s elements are not the stream\'s channel configuration'));
             else q.push(pcm.subarray(i * per, (i + 1) * per));
         }
     }

@@ -48,6 +48,9 @@ static struct {
     int  (*pipeline_reset_stream)(aacg_pipeline*, uint32_t);
     int  (*pipeline_decode)(aacg_pipeline*, const uint8_t*, size_t, const aacg_parse_frame*, const uint32_t*, uint32_t, uint32_t,
                             void*, aacg_parse_result*, uint32_t*);
+    int  (*pipeline_submit)(aacg_pipeline*, const uint8_t*, size_t, const aacg_parse_frame*, const uint32_t*, uint32_t, uint32_t,
+                            void*, aacg_parse_result*, uint32_t*, uint64_t*);
+    int  (*pipeline_collect)(aacg_pipeline*, uint64_t);
     void* (*host_alloc)(size_t);
     void (*host_free)(void*);
 } L;
@@ -82,6 +85,7 @@ static int load_lib(napi_env env, const char* path)
     SYM(parse_status_string, "aacg_parse_status_string"); SYM(parse_batch, "aacg_parse_batch");
     SYM(pipeline_create, "aacg_pipeline_create"); SYM(pipeline_destroy, "aacg_pipeline_destroy"); SYM(pipeline_last_error, "aacg_pipeline_last_error");
     SYM(pipeline_reset_stream, "aacg_pipeline_reset_stream"); SYM(pipeline_decode, "aacg_pipeline_decode");
+    SYM(pipeline_submit, "aacg_pipeline_submit"); SYM(pipeline_collect, "aacg_pipeline_collect");
     SYM(host_alloc, "aacg_host_alloc"); SYM(host_free, "aacg_host_free");
 #undef SYM
     return 1;
@@ -106,7 +110,8 @@ static int get_i32(napi_env env, napi_value obj, const char* key, int32_t dflt)
 typedef struct { uint32_t kind; void* ptr; pthread_mutex_t lock; int out_i16; /* engine / pipeline: AACG_OUTPUT_I16 */
                  /* pipeline, { pcmRing: K }: K page-locked PCM buffers made once and handed out in turn (pipelineDecode) */
                  napi_ref ring_ab[PCM_RING_MAX]; void* ring_ptr[PCM_RING_MAX]; size_t ring_bytes; int ring_n; unsigned ring_next;
-                 void* job; /* pipeline: the batch submitted and not yet collected (pipelineSubmit / pipelineCollect) */ } handle_box;
+                 /* pipeline: the batches submitted and not yet collected, oldest first (pipelineSubmit / pipelineCollect) */
+                 void* jobs[4]; int n_jobs; } handle_box;
 
 static handle_box* box_new(uint32_t kind, void* ptr)
 {
@@ -478,7 +483,8 @@ static void pipeline_finalize(napi_env env, void* data, void* hint)
     (void)hint;
     handle_box* b = (handle_box*)data;
     if (!b) return;
-    if (b->job) { pipe_abandon(env, b->job); b->job = NULL; }
+    for (int i = 0; i < b->n_jobs; i++) pipe_abandon(env, b->jobs[i]);
+    b->n_jobs = 0;
     if (b->ptr && L.pipeline_destroy) L.pipeline_destroy((aacg_pipeline*)b->ptr);
     for (int i = 0; i < b->ring_n; i++) if (b->ring_ab[i]) napi_delete_reference(env, b->ring_ab[i]);   /* (the buffers go with their ArrayBuffers: ring_finalize) */
     b->kind = 0;
@@ -509,6 +515,7 @@ static napi_value js_pipeline_create(napi_env env, napi_callback_info info)
     cfg.max_frames = get_i32(env, argv[0], "maxFrames", 16);
     cfg.output_kind = get_i32(env, argv[0], "outputKind", AACG_OUTPUT_F32);
     cfg.parse_options = get_i32(env, argv[0], "parseOptions", AACG_PARSE_REFERENCE_QUIRKS);
+    cfg.lanes = get_i32(env, argv[0], "lanes", 0);
     aacg_pipeline* p = NULL;
     int rc = L.pipeline_create(&cfg, (const aacg_code_entry*)de, (const uint32_t*)dc, &p);
     if (rc) {
@@ -534,8 +541,18 @@ static napi_value js_pipeline_create(napi_env env, napi_callback_info info)
 #define PCM_POOL_MAX 8
 #define PCM_READY_MAX 2
 typedef struct { void* ptr; size_t bytes; } pcm_buf;
-static pcm_buf g_pool[PCM_POOL_MAX];               /* recycled by finalizers: JavaScript thread only */
+static pcm_buf g_pool[PCM_POOL_MAX];               /* recycled by finalizers (the JavaScript thread of whichever environment — main or a
+                                                      worker — let go of the buffer: under g_pool_lock) */
 static int g_pool_n = 0;
+static pthread_mutex_t g_pool_lock = PTHREAD_MUTEX_INITIALIZER;
+static int pool_put(void* p, size_t bytes)          /* 1: kept for the next batch of that size */
+{
+    int kept = 0;
+    pthread_mutex_lock(&g_pool_lock);
+    if (g_pool_n < PCM_POOL_MAX) { g_pool[g_pool_n].ptr = p; g_pool[g_pool_n].bytes = bytes; g_pool_n++; kept = 1; }
+    pthread_mutex_unlock(&g_pool_lock);
+    return kept;
+}
 static pthread_mutex_t g_prep_lock = PTHREAD_MUTEX_INITIALIZER;
 static pthread_cond_t g_prep_wake = PTHREAD_COND_INITIALIZER;
 static pcm_buf g_ready[PCM_READY_MAX];             /* made ahead by the helper (under g_prep_lock) */
@@ -586,18 +603,20 @@ static void pcm_finalize(napi_env env, void* data, void* hint)
 {
     const size_t bytes = (size_t)hint;
     (void)env;
-    if (g_pool_n < PCM_POOL_MAX) { g_pool[g_pool_n].ptr = data; g_pool[g_pool_n].bytes = bytes; g_pool_n++; }
-    else pcm_discard(data);
+    if (!pool_put(data, bytes)) pcm_discard(data);
 }
 
 static void* pcm_take(size_t bytes, size_t* got)
 {
+    pthread_mutex_lock(&g_pool_lock);
     for (int i = 0; i < g_pool_n; i++)
         if (g_pool[i].bytes >= bytes && g_pool[i].bytes <= 2 * bytes + 4096) {
             void* p = g_pool[i].ptr; *got = g_pool[i].bytes;
             g_pool[i] = g_pool[--g_pool_n];
+            pthread_mutex_unlock(&g_pool_lock);
             return p;
         }
+    pthread_mutex_unlock(&g_pool_lock);
     void* p = NULL;
     pthread_mutex_lock(&g_prep_lock);
     if (!g_prep_started) {
@@ -628,7 +647,7 @@ typedef struct {
     void* pcm; size_t got, elems; int slot;
     napi_ref keep[4];                                  /* the four argument arrays: theirs is the memory the native call reads and writes */
     int n_keep;
-    pthread_t thread; int threaded;
+    uint64_t ticket; int submitted;                    /* pipelineSubmit: aacg_pipeline_submit's ticket */
     int rc; uint32_t refused; char msg[1024];
 } pipe_job;
 
@@ -642,12 +661,13 @@ static pipe_job* pipe_prepare(napi_env env, napi_callback_info info, int keep_ar
     if (argc >= 9) { napi_get_value_uint32(env, argv[7], &ring); napi_get_value_uint32(env, argv[8], &ring_elems); }
     handle_box* pb = box_of(env, argv[0], BOX_PIPELINE, "aacgpu: bad pipeline handle");
     if (!pb) return NULL;
-    if (pb->job) { napi_throw_error(env, NULL, "aacgpu: a submitted batch has not been collected yet (pipelineCollect)"); return NULL; }
+    if (pb->n_jobs && !keep_args) { napi_throw_error(env, NULL, "aacgpu: submitted batches have not been collected yet (pipelineCollect)"); return NULL; }
+    if (pb->n_jobs >= 3) { napi_throw_error(env, NULL, "aacgpu: pipelineSubmit: three batches are in flight already (pipelineCollect)"); return NULL; }
     napi_typedarray_type t; size_t nb, nf, ns, nr; void *db, *df, *ds, *dr; uint32_t F = 0, C = 0;
     napi_get_value_uint32(env, argv[4], &F);
     napi_get_value_uint32(env, argv[6], &C);
     if (!typed(env, argv[1], &t, &nb, &db) || t != napi_uint8_array || !typed(env, argv[2], &t, &nf, &df) || t != napi_uint32_array ||
-        !typed(env, argv[3], &t, &ns, &ds) || t != napi_uint32_array || !F || nf != 2 * ns * F || (C != 1 && C != 2) ||
+        !typed(env, argv[3], &t, &ns, &ds) || t != napi_uint32_array || !F || nf != 2 * ns * F || C < 1 || C > AACG_MAX_CHANNELS ||
         !typed(env, argv[5], &t, &nr, &dr) || t != napi_uint8_array || nr != ns * F * sizeof(aacg_parse_result)) {
         napi_throw_type_error(env, NULL, "pipelineDecode(pipeline, Uint8Array bytes, Uint32Array frames (2 per frame), Uint32Array slots, framesPerStream, Uint8Array results (8 per frame), channels)");
         return NULL;
@@ -660,13 +680,22 @@ static pipe_job* pipe_prepare(napi_env env, napi_callback_info info, int keep_ar
         if (ring > PCM_RING_MAX || ring_elems < elems) { napi_throw_range_error(env, NULL, "aacgpu: pipelineDecode: ring of at most 16 buffers, each at least one batch long"); return NULL; }
         if (!pb->ring_n) {                                 /* the pipeline's ring: made once, kept alive by references until the pipeline goes */
             pb->ring_bytes = (size_t)ring_elems * (pb->out_i16 ? 2u : 4u);
-            for (uint32_t i = 0; i < ring; i++) {
+            uint32_t made = 0;
+            for (; made < ring; made++) {
                 void* m = L.host_alloc(pb->ring_bytes);
                 napi_value rab;
-                if (!m || napi_create_external_arraybuffer(env, m, pb->ring_bytes, ring_finalize, NULL, &rab) != napi_ok ||
-                    napi_create_reference(env, rab, 1, &pb->ring_ab[i]) != napi_ok) { if (m) L.host_free(m); napi_throw_error(env, NULL, "aacgpu: out of page-locked memory"); return NULL; }
-                pb->ring_ptr[i] = m; pb->ring_n = (int)i + 1;
+                if (!m) break;
+                /* once the ArrayBuffer exists the memory is ITS (ring_finalize frees it when the buffer is collected); before, ours */
+                if (napi_create_external_arraybuffer(env, m, pb->ring_bytes, ring_finalize, NULL, &rab) != napi_ok) { L.host_free(m); break; }
+                if (napi_create_reference(env, rab, 1, &pb->ring_ab[made]) != napi_ok) break;
+                pb->ring_ptr[made] = m;
             }
+            if (made < ring) {                             /* all K or none: a shorter ring would overwrite frames earlier than the caller was told */
+                for (uint32_t i = 0; i < made; i++) { napi_delete_reference(env, pb->ring_ab[i]); pb->ring_ab[i] = NULL; pb->ring_ptr[i] = NULL; }
+                napi_throw_error(env, NULL, "aacgpu: out of page-locked memory (pcmRing)");
+                return NULL;
+            }
+            pb->ring_n = (int)ring;
         }
         if (bytes > pb->ring_bytes) { napi_throw_range_error(env, NULL, "aacgpu: pipelineDecode: batch larger than the ring's buffers"); return NULL; }
         slot = (int)(pb->ring_next++ % (unsigned)pb->ring_n);
@@ -676,7 +705,7 @@ static pipe_job* pipe_prepare(napi_env env, napi_callback_info info, int keep_ar
         if (!pcm) { napi_throw_error(env, NULL, "aacgpu: out of page-locked memory"); return NULL; }
     }
     pipe_job* j = (pipe_job*)calloc(1, sizeof *j);
-    if (!j) { napi_throw_error(env, NULL, "aacgpu: out of memory"); return NULL; }
+    if (!j) { if (slot < 0 && !pool_put(pcm, got)) pcm_discard(pcm); napi_throw_error(env, NULL, "aacgpu: out of memory"); return NULL; }
     j->pb = pb; j->db = (const uint8_t*)db; j->nb = nb; j->df = (const aacg_parse_frame*)df; j->ds = (const uint32_t*)ds; j->ns = ns; j->F = F;
     j->dr = (aacg_parse_result*)dr; j->pcm = pcm; j->got = got; j->elems = elems; j->slot = slot;
     if (keep_args) {
@@ -687,15 +716,28 @@ static pipe_job* pipe_prepare(napi_env env, napi_callback_info info, int keep_ar
     return j;
 }
 
-static void* pipe_run(void* arg)
+/* the synchronous call (pipelineDecode), or the enqueue half of the asynchronous pair (pipelineSubmit: aacg_pipeline_submit
+ * stages the bytes and returns when the batch is on its lane — no thread of the addon's is involved, round 5's was) */
+static void pipe_run(pipe_job* j, int submit_only)
 {
-    pipe_job* j = (pipe_job*)arg;
     pthread_mutex_lock(&j->pb->lock);
     aacg_pipeline* p = (aacg_pipeline*)j->pb->ptr;
-    j->rc = L.pipeline_decode(p, j->db, j->nb, j->df, j->ds, (uint32_t)j->ns, j->F, j->pcm, j->dr, &j->refused);
-    if (j->rc) snprintf(j->msg, sizeof j->msg, "aacgpu: aacg_pipeline_decode failed (%d): %.800s", j->rc, L.pipeline_last_error(p));
+    if (submit_only) {
+        j->rc = L.pipeline_submit(p, j->db, j->nb, j->df, j->ds, (uint32_t)j->ns, j->F, j->pcm, j->dr, &j->refused, &j->ticket);
+        j->submitted = j->rc == 0;
+    } else j->rc = L.pipeline_decode(p, j->db, j->nb, j->df, j->ds, (uint32_t)j->ns, j->F, j->pcm, j->dr, &j->refused);
+    if (j->rc) snprintf(j->msg, sizeof j->msg, "aacgpu: %s failed (%d): %.800s", submit_only ? "aacg_pipeline_submit" : "aacg_pipeline_decode", j->rc, L.pipeline_last_error(p));
     pthread_mutex_unlock(&j->pb->lock);
-    return NULL;
+}
+static void pipe_wait(pipe_job* j)
+{
+    if (!j->submitted) return;
+    pthread_mutex_lock(&j->pb->lock);
+    aacg_pipeline* p = (aacg_pipeline*)j->pb->ptr;
+    j->rc = L.pipeline_collect(p, j->ticket);
+    if (j->rc) snprintf(j->msg, sizeof j->msg, "aacgpu: aacg_pipeline_collect failed (%d): %.800s", j->rc, L.pipeline_last_error(p));
+    j->submitted = 0;
+    pthread_mutex_unlock(&j->pb->lock);
 }
 
 /* back on the JavaScript thread: { pcm, refused } or the error; the job is freed */
@@ -705,7 +747,7 @@ static napi_value pipe_finish(napi_env env, pipe_job* j)
     handle_box* pb = j->pb;
     for (int k = 0; k < j->n_keep; k++) napi_delete_reference(env, j->keep[k]);
     if (j->rc) {
-        if (j->slot < 0) { if (g_pool_n < PCM_POOL_MAX) { g_pool[g_pool_n].ptr = j->pcm; g_pool[g_pool_n].bytes = j->got; g_pool_n++; } else pcm_discard(j->pcm); }
+        if (j->slot < 0 && !pool_put(j->pcm, j->got)) pcm_discard(j->pcm);
         napi_throw_error(env, NULL, j->msg);
         free(j);
         return NULL;
@@ -728,7 +770,7 @@ static napi_value pipe_finish(napi_env env, pipe_job* j)
 static void pipe_abandon(napi_env env, void* job)
 {
     pipe_job* j = (pipe_job*)job;
-    if (j->threaded) pthread_join(j->thread, NULL);
+    pipe_wait(j);                                       /* the device writes into j->pcm and the results array until then */
     for (int k = 0; k < j->n_keep; k++) napi_delete_reference(env, j->keep[k]);
     if (j->slot < 0) pcm_discard(j->pcm);
     free(j);
@@ -738,20 +780,21 @@ static napi_value js_pipeline_decode(napi_env env, napi_callback_info info)
 {
     pipe_job* j = pipe_prepare(env, info, 0);
     if (!j) return NULL;
-    pipe_run(j);
+    pipe_run(j, 0);
     return pipe_finish(env, j);
 }
 
-/* pipelineSubmit(same arguments as pipelineDecode): the native call runs on a thread of its own while JavaScript goes on — slicing
- * the batch before, say; the four argument arrays must not be touched until pipelineCollect(pipeline) -> { pcm, refused } has
- * returned (it waits for the call).  One batch in flight per pipeline. */
+/* pipelineSubmit(same arguments as pipelineDecode): the batch is staged and enqueued (aacg_pipeline_submit) and the call returns
+ * while the device works — JavaScript slices the batch before, say.  The bytes / frames / slots arrays may be reused at once; the
+ * results array belongs to the batch until pipelineCollect(pipeline) -> { pcm, refused } has returned the OLDEST submitted batch
+ * (it waits for it, bounded).  Up to three batches in flight per pipeline. */
 static napi_value js_pipeline_submit(napi_env env, napi_callback_info info)
 {
     pipe_job* j = pipe_prepare(env, info, 1);
     if (!j) return NULL;
-    if (pthread_create(&j->thread, NULL, pipe_run, j) == 0) j->threaded = 1;
-    else pipe_run(j);                                   /* no thread to be had: the call is made here and now */
-    j->pb->job = j;
+    pipe_run(j, 1);
+    if (j->rc) return pipe_finish(env, j);              /* refused at once: thrown here, nothing to collect */
+    j->pb->jobs[j->pb->n_jobs++] = j;
     return NULL;
 }
 
@@ -761,10 +804,11 @@ static napi_value js_pipeline_collect(napi_env env, napi_callback_info info)
     CHECK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
     handle_box* pb = box_of(env, argv[0], BOX_PIPELINE, "aacgpu: bad pipeline handle");
     if (!pb) return NULL;
-    pipe_job* j = (pipe_job*)pb->job;
-    if (!j) { napi_throw_error(env, NULL, "aacgpu: pipelineCollect: nothing has been submitted"); return NULL; }
-    pb->job = NULL;
-    if (j->threaded) pthread_join(j->thread, NULL);
+    if (!pb->n_jobs) { napi_throw_error(env, NULL, "aacgpu: pipelineCollect: nothing has been submitted"); return NULL; }
+    pipe_job* j = (pipe_job*)pb->jobs[0];
+    for (int i = 1; i < pb->n_jobs; i++) pb->jobs[i - 1] = pb->jobs[i];
+    pb->n_jobs--;
+    pipe_wait(j);
     return pipe_finish(env, j);
 }
 

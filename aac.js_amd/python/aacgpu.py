@@ -16,7 +16,8 @@ LIB_PATH = os.environ.get("AACGPU_LIB") or os.path.join(ROOT, "aac.js_amd", "csr
 INPUT_SPEC_F32, INPUT_QUANT_I16 = 0, 1
 OUTPUT_F32, OUTPUT_I16 = 0, 1
 ERR_NAMES = {0: "OK", -1: "INVALID_ARG", -2: "NO_DEVICE", -3: "OUT_OF_MEMORY", -4: "CAPACITY",
-             -5: "UNSUPPORTED", -6: "LAYOUT_CHANGE", -7: "STALE_PLAN"}
+             -5: "UNSUPPORTED", -6: "LAYOUT_CHANGE", -7: "STALE_PLAN", -8: "TIMEOUT"}
+ERR_TIMEOUT = -8
 
 # every symbol include/aacgpu.h declares
 ABI_SYMBOLS = ["aacg_create", "aacg_destroy", "aacg_last_error", "aacg_abi_version", "aacg_reset_stream",
@@ -28,11 +29,15 @@ ABI_SYMBOLS = ["aacg_create", "aacg_destroy", "aacg_last_error", "aacg_abi_versi
                "aacg_parse_batch", "aacg_parse_device", "aacg_parse_kernel_name", "aacg_plan_refresh_from_parse", "aacg_standard_codebooks",
                "aacg_decode_batch_ex", "aacg_submit_ex", "aacg_plan_create_ex", "aacg_plan_kernels", "aacg_plan_kernels_ex", "aacg_plan_refresh_units",
                "aacg_decode_pipelined", "aacg_pipeline_fork", "aacg_pipeline_join",
-               "aacg_pipeline_create", "aacg_pipeline_destroy", "aacg_pipeline_last_error", "aacg_pipeline_reset_stream", "aacg_pipeline_decode"]
+               "aacg_pipeline_create", "aacg_pipeline_destroy", "aacg_pipeline_last_error", "aacg_pipeline_reset_stream", "aacg_pipeline_decode",
+               "aacg_pipeline_submit", "aacg_pipeline_collect", "aacg_pipeline_set_wait_limit_ms", "aacg_pipeline_stream_layout",
+               "aacg_set_wait_limit_ms", "aacg_parser_set_wait_limit_ms", "aacg_pipeline_info",
+               "aacg_plan_set_unit_sets", "aacg_plan_refresh_from_parse_ex"]
 # ... and include/aacgpu_tools.h (measurement and diagnostics: bench.py, tools/, tests)
 TOOLS_SYMBOLS = ["aacg_calib_copy", "aacg_timer_create", "aacg_timer_record", "aacg_timer_elapsed_ms", "aacg_timer_destroy",
                  "aacg_pipeline_chained", "aacg_pipeline_concurrent", "aacg_decode_pipelined_timed", "aacg_debug_transform", "aacg_debug_set_route", "aacg_debug_route", "aacg_debug_run_kernel",
-                 "aacg_debug_pipeline_order", "aacg_pipeline_streams_used"]
+                 "aacg_debug_pipeline_order", "aacg_pipeline_streams_used", "aacg_debug_set_wait_mode", "aacg_debug_in_flight", "aacg_debug_stall"]
+WAIT_SPIN, WAIT_YIELD, WAIT_SLEEP, WAIT_BLOCK = 0, 1, 2, 3
 # aacg_debug_set_route / aacg_debug_route flags
 DEBUG_ROUTE_UNFUSED_COUPLING, DEBUG_ROUTE_RECOMPUTE = 1, 8
 ROUTE_PLAN_TNS, ROUTE_PLAN_PNS, ROUTE_PLAN_LONG_CHAINS, ROUTE_PLAN_FULL_LATER_RUNS = 1, 2, 4, 8
@@ -71,6 +76,12 @@ class Config(C.Structure):
     _fields_ = [("abi_version", C.c_int32), ("device_ordinal", C.c_int32), ("sample_index", C.c_int32),
                 ("max_streams", C.c_int32), ("max_channels", C.c_int32), ("max_batch_units", C.c_int32),
                 ("input_kind", C.c_int32), ("tns_mode", C.c_int32), ("pns_mode", C.c_int32), ("output_kind", C.c_int32), ("cce_mode", C.c_int32)]
+
+
+class PipelineConfig(C.Structure):
+    _fields_ = [("abi_version", C.c_int32), ("device_ordinal", C.c_int32), ("sample_index", C.c_int32), ("max_streams", C.c_int32),
+                ("channels", C.c_int32), ("max_frames", C.c_int32), ("output_kind", C.c_int32), ("parse_options", C.c_int32),
+                ("lanes", C.c_int32), ("reserved", C.c_int32 * 3)]
 
 
 class Batch(C.Structure):
@@ -189,6 +200,24 @@ def load_library(path=LIB_PATH):
     L.aacg_plan_create_ex.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]
     L.aacg_debug_transform.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     L.aacg_standard_codebooks.restype = C.c_uint32
+    L.aacg_set_wait_limit_ms.argtypes = [C.c_void_p, C.c_uint32]
+    L.aacg_parser_set_wait_limit_ms.argtypes = [C.c_void_p, C.c_uint32]
+    L.aacg_pipeline_info.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.aacg_debug_set_wait_mode.argtypes = [C.c_void_p, C.c_int, C.c_double]
+    L.aacg_debug_in_flight.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+    L.aacg_plan_set_unit_sets.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+    L.aacg_plan_refresh_from_parse_ex.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+    L.aacg_pipeline_create.argtypes = [C.POINTER(PipelineConfig), C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]
+    L.aacg_pipeline_destroy.argtypes = [C.c_void_p]
+    L.aacg_pipeline_destroy.restype = None
+    L.aacg_pipeline_last_error.argtypes = [C.c_void_p]
+    L.aacg_pipeline_last_error.restype = C.c_char_p
+    L.aacg_pipeline_reset_stream.argtypes = [C.c_void_p, C.c_uint32]
+    L.aacg_pipeline_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.aacg_pipeline_submit.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64)]
+    L.aacg_pipeline_collect.argtypes = [C.c_void_p, C.c_uint64]
+    L.aacg_pipeline_set_wait_limit_ms.argtypes = [C.c_void_p, C.c_uint32]
+    L.aacg_pipeline_stream_layout.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(C.c_uint32)]
     _lib = L
     return L
 
@@ -352,6 +381,103 @@ class Parser:
 
     def status_string(self, status):
         return self.lib.aacg_parse_status_string(int(status)).decode()
+
+
+REFRESH_MAP_DTYPE = np.dtype([("parsed_index", "<u4"), ("frame_units", "<u4")])
+PARSE_LAYOUT = 16          # AACG_PARSE_LAYOUT: a frame whose elements are not its stream's
+
+
+class Pipeline:
+    """aacg_pipeline: bytes in, PCM out — device front end and transform behind one call per batch, `lanes` batches in flight
+    (include/aacgpu.h).  channels = the streams' chanConfig (1..8)."""
+
+    def __init__(self, channels=2, max_streams=1, max_frames=16, sample_index=3, device=0, output_kind=OUTPUT_F32,
+                 parse_options=PARSE_REFERENCE_QUIRKS, lanes=0, entries=None, counts=None):
+        self.lib = load_library()
+        if entries is None:
+            entries, counts = standard_codebooks()
+        entries, counts = np.ascontiguousarray(entries), np.ascontiguousarray(counts, np.uint32)
+        cfg = PipelineConfig(self.lib.aacg_abi_version(), device, sample_index, max_streams, channels, max_frames, output_kind, parse_options, lanes)
+        h = C.c_void_p()
+        rc = self.lib.aacg_pipeline_create(C.byref(cfg), entries.ctypes.data, counts.ctypes.data, C.byref(h))
+        if rc != 0:
+            raise AacgError(rc, "aacg_pipeline_create failed (no GPU?)")
+        self.handle, self.channels, self.i16 = h, channels, output_kind == OUTPUT_I16
+        self._keep = {}
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.aacg_pipeline_destroy(self.handle)
+            self.handle = None
+            for p in getattr(self, "_pinned", []):
+                self.lib.aacg_host_free(p)
+            self._pinned = []
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise AacgError(rc, self.lib.aacg_pipeline_last_error(self.handle).decode())
+
+    def pinned(self, shape, dtype):
+        """numpy array over page-locked host memory (aacg_host_alloc): the PCM comes straight down from the device into it."""
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p = self.lib.aacg_host_alloc(n)
+        if not p:
+            raise AacgError(-3, "aacg_host_alloc failed")
+        self._pinned = getattr(self, "_pinned", [])
+        self._pinned.append(p)
+        return np.frombuffer((C.c_char * n).from_address(p), dtype=dtype).reshape(shape)
+
+    def set_wait_limit_ms(self, ms):
+        self._check(self.lib.aacg_pipeline_set_wait_limit_ms(self.handle, int(ms)))
+
+    def reset_stream(self, slot):
+        self._check(self.lib.aacg_pipeline_reset_stream(self.handle, slot))
+
+    def stream_layout(self, slot):
+        """(channels of every element of the slot's frames, how many of the elements are decoded); ([], 0) before it is learnt."""
+        ch, kept = np.zeros(8, np.uint8), C.c_uint32()
+        n = self.lib.aacg_pipeline_stream_layout(self.handle, slot, ch.ctypes.data, C.byref(kept))
+        if n < 0:
+            raise AacgError(n, "aacg_pipeline_stream_layout")
+        return [int(c) for c in ch[:n]], int(kept.value)
+
+    def _args(self, data, frames, slots, frames_per_stream, pcm):
+        data = np.ascontiguousarray(data, np.uint8)
+        frames = np.ascontiguousarray(frames)
+        slots = np.ascontiguousarray(slots, np.uint32)
+        assert frames.dtype == PARSE_FRAME_DTYPE and len(frames) == len(slots) * frames_per_stream
+        n = len(frames)
+        if pcm is None:
+            pcm = np.zeros(n * 1024 * self.channels, np.int16 if self.i16 else np.float32)
+        assert pcm.size >= n * 1024 * self.channels
+        return data, frames, slots, pcm, np.zeros(n, PARSE_RESULT_DTYPE), C.c_uint32(0)
+
+    def decode(self, data, frames, slots, frames_per_stream, pcm=None):
+        """Synchronous: (pcm, results, n_refused).  frames[s * F + f] = frame f of stream s in `data`."""
+        data, frames, slots, pcm, res, refused = self._args(data, frames, slots, frames_per_stream, pcm)
+        self._check(self.lib.aacg_pipeline_decode(self.handle, data.ctypes.data, data.size, frames.ctypes.data, slots.ctypes.data, len(slots),
+                                                  frames_per_stream, pcm.ctypes.data, res.ctypes.data, C.byref(refused)))
+        return pcm, res, int(refused.value)
+
+    def submit(self, data, frames, slots, frames_per_stream, pcm=None):
+        """Asynchronous: returns a ticket; collect(ticket) -> (pcm, results, n_refused)."""
+        data, frames, slots, pcm, res, refused = self._args(data, frames, slots, frames_per_stream, pcm)
+        t = C.c_uint64()
+        self._check(self.lib.aacg_pipeline_submit(self.handle, data.ctypes.data, data.size, frames.ctypes.data, slots.ctypes.data, len(slots),
+                                                  frames_per_stream, pcm.ctypes.data, res.ctypes.data, C.byref(refused), C.byref(t)))
+        self._keep[t.value] = (pcm, res, refused)
+        return t.value
+
+    def collect(self, ticket):
+        self._check(self.lib.aacg_pipeline_collect(self.handle, ticket))
+        pcm, res, refused = self._keep.pop(ticket)
+        return pcm, res, int(refused.value)
 
 
 class Plan:
@@ -527,6 +653,28 @@ class Engine:
     def pipeline_streams_used(self):
         """How many of the engine's internal streams the current pipelined sequence takes in turn (0 before the first launch)."""
         return int(self.lib.aacg_pipeline_streams_used(self.handle))
+
+    def pipeline_info(self):
+        """(streams the current pipelined sequence takes in turn, whether they were seen to run side by side: 1 / 0 / -1 before set-up)."""
+        a, b = C.c_int(), C.c_int()
+        self._check(self.lib.aacg_pipeline_info(self.handle, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def set_wait_limit_ms(self, ms):
+        self._check(self.lib.aacg_set_wait_limit_ms(self.handle, int(ms)))
+
+    def debug_set_wait_mode(self, mode, spin_us=-1.0):
+        self._check(self.lib.aacg_debug_set_wait_mode(self.handle, mode, float(spin_us)))
+
+    def debug_stall(self, which, ms):
+        """One of the engine's streams (0: its own, 1..3: the pipeline's) busy for `ms` milliseconds: tests of the bounded waits."""
+        self.lib.aacg_debug_stall.argtypes = [C.c_void_p, C.c_int, C.c_uint32]
+        self._check(self.lib.aacg_debug_stall(self.handle, which, ms))
+
+    def in_flight(self):
+        buf = C.create_string_buffer(4096)
+        self.lib.aacg_debug_in_flight(self.handle, buf, 4096)
+        return buf.value.decode()
 
     def pipeline_concurrent(self):
         """True if the engine's internal streams were seen to run side by side (else pipelined launches serialise: correct, not faster)."""

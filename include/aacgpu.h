@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define AACG_ABI_VERSION 5
+#define AACG_ABI_VERSION 6
 
 #define AACG_FRAME_LEN      1024   /* decoder.js:86 frameLength                       */
 #define AACG_MAX_SECTIONS   120    /* ics.js:49 MAX_SECTIONS (bandTypes/scaleFactors) */
@@ -55,7 +55,12 @@ enum {
     AACG_ERR_CAPACITY       = -4,   /* batch larger than the engine was created for    */
     AACG_ERR_UNSUPPORTED    = -5,   /* reference throws here too (pulse, gain, PNS...) */
     AACG_ERR_LAYOUT_CHANGE  = -6,   /* element layout of a stream changes inside one batch */
-    AACG_ERR_STALE_PLAN     = -7    /* plan does not match the engine's overlap parity */
+    AACG_ERR_STALE_PLAN     = -7,   /* plan does not match the engine's overlap parity */
+    AACG_ERR_TIMEOUT        = -8    /* a host wait for the GPU passed the engine's wait limit (aacg_set_wait_limit_ms): the call
+                                       returns instead of hanging, aacg_last_error says what was in flight (launch counts, every
+                                       stream's and completion event's state, the rendezvous cells' state words).  The work may
+                                       still complete later; the engine's state is then undefined — destroy it (aacg_destroy does
+                                       not wait again and leaves the engine's device memory allocated)                        */
 };
 
 /* ---- window sequences, ics.js:44-47 ------------------------------------------- */
@@ -249,6 +254,11 @@ int  aacg_create(const aacg_config* cfg, aacg_engine** out);
 void aacg_destroy(aacg_engine* e);
 const char* aacg_last_error(const aacg_engine* e);   /* text of the last failure            */
 int  aacg_abi_version(void);
+/* Every wait of the host for the GPU behind this ABI — aacg_synchronize, aacg_wait, aacg_get/set_overlap, aacg_reset_stream,
+ * aacg_plan_destroy, the back-pressure of aacg_decode_pipelined, aacg_decode_batch* — is bounded: after `ms` milliseconds
+ * (default 30 000) it returns AACG_ERR_TIMEOUT.  A wait polls for a few microseconds and then sleeps between polls: it does not
+ * hold the caller's core.  (`readChunk()` in the reference returns or throws, decoder.js:125-216; it never blocks.)        */
+int  aacg_set_wait_limit_ms(aacg_engine* e, uint32_t ms);
 
 /* ---- overlap state (filter_bank.js:38-41) ------------------------------------------ */
 int aacg_reset_stream(aacg_engine* e, uint32_t stream);                       /* zero = new FilterBank */
@@ -367,6 +377,12 @@ int aacg_decode_pipelined(aacg_engine* e, aacg_plan* p, const void* d_coeffs, co
 int aacg_pipeline_fork(aacg_engine* e, void* hip_stream);
 /* work enqueued on hip_stream from now on starts after the pipeline's launches so far; NULL: the host waits for them */
 int aacg_pipeline_join(aacg_engine* e, void* hip_stream);
+/* What a caller of aacg_decode_pipelined should know about the engine's internal streams: *streams_used = how many of them the
+ * current sequence of launches takes in turn (0 before the first pipelined launch); *concurrent = 1 if they were seen to run
+ * side by side when the pipeline was set up, 0 if the runtime put them on one hardware queue — pipelined launches are then
+ * correct but run one behind the other (the first successful aacg_decode_pipelined also leaves a note in aacg_last_error) —
+ * -1 before the pipeline has been set up.  Either pointer may be NULL. */
+int aacg_pipeline_info(const aacg_engine* e, int* streams_used, int* concurrent);
 
 /* ---- introspection ---------------------------------------------------------------------------------------------- */
 /* Copies the engine's host-built tables (what the device kernels read) for table KATs.
@@ -431,7 +447,10 @@ enum {                         /* aacg_parse_result.status; the reference's mess
                                           outside its offset table)                                     */
     AACG_PARSE_MS_MASK = 13,           /* cpe.js:66  'Reserved ms mask type: 3'                         */
     AACG_PARSE_ESCAPE = 14,            /* escape sequence longer than the standard's 13 bits            */
-    AACG_PARSE_CAPACITY = 15           /* more elements / channels in the frame than the caller allowed */
+    AACG_PARSE_CAPACITY = 15,          /* more elements / channels in the frame than the caller allowed */
+    AACG_PARSE_LAYOUT = 16             /* never written by the parser: aacg_plan_refresh_from_parse_ex marks a frame that parsed
+                                          well but does not have the elements its stream's plan was made for (the reference decodes
+                                          whatever elements a frame brings, decoder.js:233-247; a kept plan cannot)              */
 };
 #define AACG_PARSE_APPLY_PULSES      0x1u   /* add pulse data to the spectrum (ISO/IEC 14496-3 4.6.3.3) instead
                                                of failing the frame as the reference does              */
@@ -459,6 +478,9 @@ int aacg_parser_create(int device_ordinal, int sample_index, const aacg_code_ent
 void aacg_parser_destroy(aacg_parser* p);
 const char* aacg_parser_last_error(const aacg_parser* p);
 const char* aacg_parse_status_string(int status);
+/* aacg_parse_batch's waits for the GPU are bounded like the engine's (aacg_set_wait_limit_ms): AACG_ERR_TIMEOUT after `ms`
+ * milliseconds, default 30 000. */
+int aacg_parser_set_wait_limit_ms(aacg_parser* p, uint32_t ms);
 
 /* Frame f's element e lands in units[f * max_units + e]; its channels in q / meta / tns block
  * f * max_channels + (running channel index), which is what the record's coef_offset / meta_offset /
@@ -495,6 +517,27 @@ const char* aacg_parse_kernel_name(void);
 int aacg_plan_refresh_from_parse(aacg_engine* e, aacg_plan* p, const aacg_unit_desc* d_parsed_units,
                                  const aacg_parse_result* d_results, uint32_t max_units, uint32_t* d_refused,
                                  void* hip_stream);
+/* The same for plans that (a) list only the elements their streams have and (b) are refreshed while earlier launches of theirs
+ * are still in flight — what a host does that keeps several batches of the same streams between bytes and PCM at a time.
+ *   d_map (device, one per plan unit, or NULL = plan unit i <- parsed record i): where the parser put the unit's element
+ *     (frame * max_units + element) and how many elements its frame must have.  The units of a frame must be listed next to
+ *     each other in the frame's order.  A frame is then taken or refused AS A WHOLE: wrong element count, an element of other
+ *     channels or blocks, a parse error -> every unit of it silent, *d_refused += 1 per frame, and d_results[frame].status
+ *     becomes AACG_PARSE_LAYOUT where the parser had said OK (d_results is written).
+ *   set: which of the plan's sets of unit records to rewrite (aacg_plan_set_unit_sets); the plan's next launch reads that set.
+ *     With more than one set the call does not wait for the plan's launches in flight — the CALLER guarantees that no launch
+ *     still reads `set` (e.g. its previous user's output has been waited for on hip_stream) — and a sequence of
+ *     aacg_decode_pipelined launches is not interrupted by it: consecutive batches still overlap through the rendezvous cells. */
+typedef struct aacg_refresh_map {
+    uint32_t parsed_index;     /* frame * max_units + element                                                     */
+    uint32_t frame_units;      /* bits 0..7: elements (SCE / CPE / LFE) the frame must have; 0: not checked, refusal per unit.
+                                  bits 8..15: how many of them (the first ones) the plan lists, 0 = all — the reference drops
+                                  the elements beyond chanConfig channels (decoder.js:233)                               */
+} aacg_refresh_map;
+int aacg_plan_set_unit_sets(aacg_engine* e, aacg_plan* p, uint32_t n_sets);     /* 1..8, before the plan's first launch */
+int aacg_plan_refresh_from_parse_ex(aacg_engine* e, aacg_plan* p, const aacg_unit_desc* d_parsed_units,
+                                    aacg_parse_result* d_results, uint32_t max_units, const aacg_refresh_map* d_map,
+                                    uint32_t set, uint32_t* d_refused, void* hip_stream);
 
 /* The host's counterpart of aacg_plan_refresh_from_parse, for callers that parse on the CPU (the JavaScript front end) but
  * keep spectra and PCM on the device: batch after batch of the same streams keeps ONE plan, and the next batch's unit
@@ -505,13 +548,19 @@ int aacg_plan_refresh_from_parse(aacg_engine* e, aacg_plan* p, const aacg_unit_d
  * (AACG_ERR_UNSUPPORTED).  Replaces decoder.js:138-198's per-frame `new ICStream` bookkeeping for a whole batch. */
 int aacg_plan_refresh_units(aacg_engine* e, aacg_plan* p, const aacg_unit_desc* units, uint32_t n_units, void* hip_stream);
 
-/* ---- bytes in, PCM out: front end and transform resident, ONE call per batch ---------------------------------------
+/* ---- bytes in, PCM out: front end and transform resident, ONE call per batch, several batches in flight ---------------
  * What a host of the reference does per stream and per frame in readChunk() (decoder.js:125-216: parse the raw_data_block,
  * process(elements), interleave) for a batch of streams at once: the frames' bytes go up, aacg_parse_device writes the
- * records in HBM, aacg_plan_refresh_from_parse turns them into a kept plan's unit records, aacg_decode_device runs the
- * transform, the PCM comes down — three kernels and three copies on one HIP stream behind this call; nothing but the frame
- * boundaries (ADTS frame_length) and the stream slots is the host's.  For streams whose every frame is one SCE (channels 1)
- * or one CPE (channels 2) — channel_configuration 1 / 2; other layouts take the aacg_parse_* / aacg_plan_* calls above.
+ * records in HBM, aacg_plan_refresh_from_parse_ex turns them into a kept plan's unit records, aacg_decode_pipelined runs the
+ * transform, the PCM comes down; nothing but the frame boundaries (ADTS frame_length) and the stream slots is the host's.
+ * A batch takes one of `lanes` sets of device buffers and a HIP stream of its own: batch k's PCM is on its way down PCIe
+ * while batch k + 1's bytes go up and are parsed, and the transform launches of consecutive batches of one shape are
+ * consecutive launches of ONE plan through aacg_decode_pipelined (they overlap through the rendezvous cells).
+ * channels 1 / 2: every frame one SCE / one CPE (channel_configuration 1 / 2; any other frame is refused).  channels 3..8: the
+ * reference's chanConfig (decoder.js:77,219: the number of output channels); a stream's element layout — the SCE / CPE / LFE
+ * elements of a frame in order, channels dealt out in element order, elements beyond `channels` dropped (decoder.js:233-247) —
+ * is learnt from the first frame it submits after aacg_pipeline_reset_stream, and a later frame with other elements is
+ * refused as a whole (AACG_PARSE_LAYOUT).  Coupling channel elements are parsed and dropped, as the reference executes them.
  * A pipeline owns an engine (AACG_INPUT_QUANT_I16, AACG_TNS_REFERENCE) and a parser; it is not re-entrant. */
 typedef struct aacg_pipeline aacg_pipeline;
 typedef struct aacg_pipeline_config {
@@ -519,10 +568,12 @@ typedef struct aacg_pipeline_config {
     int32_t device_ordinal;
     int32_t sample_index;      /* config.sampleIndex (decoder.js:63)                                        */
     int32_t max_streams;       /* stream slots with overlap state                                           */
-    int32_t channels;          /* 1 or 2: every frame one SCE / one CPE                                     */
+    int32_t channels;          /* 1..8: channels of a frame's PCM (the reference's chanConfig)               */
     int32_t max_frames;        /* frames per stream in one batch, at most                                   */
     int32_t output_kind;       /* AACG_OUTPUT_*                                                             */
     int32_t parse_options;     /* AACG_PARSE_* (AACG_PARSE_REFERENCE_QUIRKS for what aac.js reads)          */
+    int32_t lanes;             /* batches in flight at most, 1..4; 0 = 3 (ABI version 6)                     */
+    int32_t reserved[3];       /* zero                                                                      */
 } aacg_pipeline_config;
 int  aacg_pipeline_create(const aacg_pipeline_config* cfg, const aacg_code_entry* entries, const uint32_t counts[12], aacg_pipeline** out);
 void aacg_pipeline_destroy(aacg_pipeline* p);
@@ -539,6 +590,22 @@ int  aacg_pipeline_reset_stream(aacg_pipeline* p, uint32_t slot);               
 int  aacg_pipeline_decode(aacg_pipeline* p, const uint8_t* bytes, size_t n_bytes, const aacg_parse_frame* frames,
                           const uint32_t* slots, uint32_t n_streams, uint32_t frames_per_stream,
                           void* pcm_out, aacg_parse_result* results, uint32_t* n_refused);
+/* The asynchronous pair of the same call.  aacg_pipeline_submit stages the bytes (they may be reused when it returns),
+ * enqueues the batch on the next lane and returns a ticket; pcm_out / results / n_refused are written by the time
+ * aacg_pipeline_collect(ticket) returns and must stay valid until then.  Batches decode in submission order (consecutive
+ * batches of a stream chain through its overlap state); up to `lanes` may be in flight — submitting one more first finishes
+ * the oldest (its outputs are then complete, collecting it later returns at once).  Tickets count from 1.
+ * aacg_pipeline_collect waits at most the wait limit (aacg_pipeline_set_wait_limit_ms, default 30 s): AACG_ERR_TIMEOUT, with
+ * the lanes' and the engine's state in aacg_pipeline_last_error.  Replaces decoder.js:125-216 for a batch, without the
+ * caller's thread waiting for PCIe. */
+int  aacg_pipeline_submit(aacg_pipeline* p, const uint8_t* bytes, size_t n_bytes, const aacg_parse_frame* frames,
+                          const uint32_t* slots, uint32_t n_streams, uint32_t frames_per_stream,
+                          void* pcm_out, aacg_parse_result* results, uint32_t* n_refused, uint64_t* ticket);
+int  aacg_pipeline_collect(aacg_pipeline* p, uint64_t ticket);
+int  aacg_pipeline_set_wait_limit_ms(aacg_pipeline* p, uint32_t ms);
+/* The element layout learnt for a stream slot: returns the number of SCE / CPE / LFE elements of its frames (0: not learnt
+ * yet), their channel counts in element_channels[0..7] and how many of them (the first ones) fit `channels` in *kept. */
+int  aacg_pipeline_stream_layout(aacg_pipeline* p, uint32_t slot, uint8_t element_channels[8], uint32_t* kept);
 
 #ifdef __cplusplus
 }

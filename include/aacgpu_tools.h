@@ -35,6 +35,16 @@ uint64_t aacg_pipeline_chained(const aacg_engine* e);
 int aacg_pipeline_concurrent(const aacg_engine* e);
 /* how many of the engine's streams the current pipelined sequence takes in turn (aacg_pipeline_streams, aacg_routes.h); 0 before the first */
 int aacg_pipeline_streams_used(const aacg_engine* e);
+/* How the host waits once a wait has lasted spin_us microseconds of polling (aacg_wait.h): 0 keep polling (round 5), 1 sched_yield
+ * between polls, 2 sleep between polls (the default), 3 hipEventSynchronize on a blocking-sync event (UNBOUNDED: measurement only).
+ * Before the first pipelined launch; spin_us < 0 keeps the default (20).  tools/micro/pipe_drive --wait-mode. */
+int aacg_debug_set_wait_mode(aacg_engine* e, int mode, double spin_us);
+/* What is in flight on the engine right now, as text (what an AACG_ERR_TIMEOUT's aacg_last_error carries): launch counts, every
+ * stream's and completion event's state, the cross-launch rendezvous cells' state words.  Returns the text's length. */
+int aacg_debug_in_flight(aacg_engine* e, char* dst, size_t n);
+/* Tests of the bounded waits: one of the engine's streams (0: its own, 1..3: the pipeline's) busy for `ms` milliseconds (<= 5000)
+ * with a one-wave kernel that polls a word nobody sets.  Nothing on the decode path calls this. */
+int aacg_debug_stall(aacg_engine* e, int which, uint32_t ms);
 
 /* Diagnostic: the IMDCT stage of the kernels on its own, for known-answer tests against the reference's MDCT.process
  * (mdct.js:62-115) and FFT.process (fft.js:105-192) vectors.  One spectrum in (1024 floats: one long window, or eight

@@ -27,7 +27,7 @@ def test_header_and_binding_agree():
 def test_library_exports_every_declared_symbol(engine_lib):
     for name in declared_symbols() + declared_symbols("aacgpu_tools.h"):
         assert hasattr(engine_lib, name), "libaacgpu.so does not export " + name
-    assert engine_lib.aacg_abi_version() == 5
+    assert engine_lib.aacg_abi_version() == 6
     assert engine_lib.aacg_kernel_name().decode().startswith("aacg_imdct_run")
 
 
