@@ -39,11 +39,30 @@
 
 #define AACG_PIPELINE_MAX_LANES 4
 
+/* The batch's bytes up (and its few kilobytes of results down) are moved by THIS kernel, not by hipMemcpyAsync: page-locked host
+ * memory is mapped into the device's address space, and a few workgroups of 16-byte loads and stores move 1.4 MB in 30 us.  The
+ * runtime's copies go through the two SDMA engines whatever their direction: in round 6's first build a lane's bytes waited up
+ * to 0.6 ms behind another lane's PCM on its way down (kernel + copy trace, profiles/r06_resident_budget.txt), and the lanes ran
+ * in lockstep pairs with the link idle a third of the time — 0.89-0.93 ms per batch.  A kernel on the lane's own stream waits
+ * for nothing but its predecessor on that stream.  The PCM itself stays with the SDMA engines, ONE copy per batch: 0.64 ms per
+ * batch (52 GB/s).  Measured against it: the PCM through this kernel too — 0.89, its PCIe-bound stores hold up the other
+ * kernels' stores (the parse kernel then takes 1.0-1.4 ms instead of 0.55) — and the PCM as two SDMA halves on two streams —
+ * 0.84-0.88, the halves of one batch take both engines and the next lane's copy waits behind them. */
+extern "C" __global__ __launch_bounds__(256)
+void aacg_pipe_copy(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16)
+{
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+    const v4u* s = (const v4u*)src;
+    v4u* d = (v4u*)dst;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x)
+        __builtin_nontemporal_store(__builtin_nontemporal_load(&s[i]), &d[i]);
+}
+
 struct aacg_pipeline {
     aacg_pipeline_config cfg;
     aacg_engine* engine = nullptr;
     aacg_parser* parser = nullptr;      /* layouts of new streams (synchronous, host pointers) */
-    int n_lanes = 3;
+    int n_lanes = 4;
     uint32_t C = 2;                     /* channels of a frame's PCM (chanConfig) */
     uint32_t Cp = 2, U = 1;             /* what the parser is allowed per frame: channels (block stride), elements */
     bool learn = false;                 /* C > 2: layouts are learnt; C <= 2: every frame one SCE / one CPE */
@@ -73,6 +92,7 @@ struct aacg_pipeline {
         std::vector<uint32_t> unlearnt;   /* streams of the batch (by position) whose layout was not known: nothing of them was decoded */
     } lane[AACG_PIPELINE_MAX_LANES];
     uint64_t submitted = 0;
+    size_t res_cap16 = 0;               /* a lane's h_res: results of up to max_streams x max_frames frames, then (16-byte aligned) the refusal count */
     aacg_wait_policy wait;
     std::string err;
 };
@@ -95,6 +115,15 @@ bool is_pinned(const void* ptr)
     hipPointerAttribute_t a;
     if (hipPointerGetAttributes(&a, ptr) != hipSuccess) { (void)hipGetLastError(); return false; }
     return a.type == hipMemoryTypeHost;
+}
+
+/* bytes (a multiple of 16, both ends 16-byte aligned) between device memory and mapped page-locked host memory, on stream s */
+void pipe_copy(const void* src, void* dst, size_t bytes, hipStream_t s)
+{
+    const size_t n16 = bytes / 16;
+    if (!n16) return;
+    const unsigned blocks = (unsigned)((n16 + 255) / 256 < 64 ? (n16 + 255) / 256 : 64);      /* 64 x 256 lanes x 16 bytes in flight: the link, not the chip */
+    hipLaunchKernelGGL(aacg_pipe_copy, dim3(blocks), dim3(256), 0, s, (const uint4*)src, (uint4*)dst, n16);
 }
 
 void drop_plan(aacg_pipeline* p, size_t i)
@@ -192,7 +221,7 @@ int finish_lane(aacg_pipeline* p, aacg_pipeline::lane_t& L)
     if (!L.direct) std::memcpy(L.user_pcm, L.h_pcm, L.pcm_bytes);
     /* a stream whose first frame did not parse has no layout yet: every frame of it in this batch came out silent and says so */
     aacg_parse_result* res = (aacg_parse_result*)L.h_res;
-    uint32_t* refused = (uint32_t*)((char*)L.h_res + (size_t)L.n * sizeof(aacg_parse_result));
+    uint32_t* refused = (uint32_t*)((char*)L.h_res + p->res_cap16);
     for (uint32_t s : L.unlearnt)
         for (uint32_t f = 0; f < L.F; f++) { aacg_parse_result& r = res[(size_t)s * L.F + f]; if (r.status == AACG_PARSE_OK) r.status = AACG_PARSE_LAYOUT; (*refused)++; }
     if (L.user_results) std::memcpy(L.user_results, res, (size_t)L.n * sizeof(aacg_parse_result));
@@ -266,7 +295,7 @@ void aacg_pipeline_destroy(aacg_pipeline* p)
     }
     drop_plans(p);
     for (auto& L : p->lane) {
-        for (void* d : {L.d_bytes, L.d_frames, L.d_units, L.d_q, L.d_meta, L.d_res, L.d_pcm, L.d_refused}) if (d) (void)hipFree(d);
+        for (void* d : {L.d_bytes, L.d_units, L.d_q, L.d_meta, L.d_res, L.d_pcm, L.d_refused}) if (d) (void)hipFree(d);      /* (d_frames lies in d_bytes) */
         for (void* h : {L.h_in, L.h_pcm, L.h_res}) if (h) (void)hipHostFree(h);
         if (L.done) (void)hipEventDestroy(L.done);
         if (L.parser) aacg_parser_destroy(L.parser);
@@ -288,7 +317,7 @@ int aacg_pipeline_create(const aacg_pipeline_config* cfg, const aacg_code_entry*
     aacg_pipeline* p = new (std::nothrow) aacg_pipeline();
     if (!p) return AACG_ERR_OUT_OF_MEMORY;
     p->cfg = *cfg;
-    p->n_lanes = cfg->lanes ? cfg->lanes : 3;
+    p->n_lanes = cfg->lanes ? cfg->lanes : 4;
     p->C = (uint32_t)cfg->channels;
     p->learn = p->C > 2;
     p->Cp = p->learn ? AACG_MAX_CHANNELS : p->C;
@@ -303,20 +332,27 @@ int aacg_pipeline_create(const aacg_pipeline_config* cfg, const aacg_code_entry*
     if (rc == AACG_OK) rc = aacg_parser_create(cfg->device_ordinal, cfg->sample_index, entries, counts, &p->parser);
     if (rc) { aacg_pipeline_destroy(p); return rc; }
     const size_t n = (size_t)cfg->max_streams * (size_t)cfg->max_frames, C = p->C, Cp = p->Cp, U = p->U;
+    p->res_cap16 = (n * sizeof(aacg_parse_result) + 15) & ~(size_t)15;
     bool good = ok(p, hipSetDevice(cfg->device_ordinal), "hipSetDevice");
+    /* The lanes' streams take the LOWEST priority: the runtime deals streams of one priority onto a handful of hardware queues
+     * of their own, and two streams on one queue run one behind the other — a lane's parse behind another lane's copy down.
+     * At the ordinary priority the lanes shared two queues with whatever else the process had made (kernel trace of round 6's first
+     * build); at the lowest they are by themselves, and what competes with them for compute units — the transform launches on
+     * the engine's highest-priority streams — is what should win. */
+    int least = 0, greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
     for (int k = 0; k < p->n_lanes && good; k++) {
         auto& L = p->lane[k];
         if (aacg_parser_create(cfg->device_ordinal, cfg->sample_index, entries, counts, &L.parser) != AACG_OK) { p->err = "aacg_parser_create (lane)"; good = false; break; }
-        good = ok(p, hipStreamCreateWithFlags(&L.st, hipStreamNonBlocking), "hipStreamCreate") &&
+        good = ok(p, hipStreamCreateWithPriority(&L.st, hipStreamNonBlocking, least), "hipStreamCreate") &&
                ok(p, hipEventCreateWithFlags(&L.done, hipEventDisableTiming), "hipEventCreate") &&
-               ok(p, hipMalloc(&L.d_frames, n * sizeof(aacg_parse_frame)), "hipMalloc") &&
                ok(p, hipMalloc(&L.d_units, n * U * sizeof(aacg_unit_desc)), "hipMalloc") &&
                ok(p, hipMalloc(&L.d_q, n * Cp * 2048), "hipMalloc") && ok(p, hipMemsetAsync(L.d_q, 0, n * Cp * 2048, L.st), "hipMemset") &&
                ok(p, hipMalloc(&L.d_meta, n * Cp * sizeof(aacg_band_meta)), "hipMalloc") &&
-               ok(p, hipMalloc(&L.d_res, n * sizeof(aacg_parse_result)), "hipMalloc") &&
+               ok(p, hipMalloc(&L.d_res, p->res_cap16), "hipMalloc") &&
                ok(p, hipMalloc(&L.d_pcm, n * C * 1024 * pcm_elem(p)), "hipMalloc") &&
                ok(p, hipMalloc(&L.d_refused, 16), "hipMalloc") &&
-               ok(p, hipHostMalloc(&L.h_res, n * sizeof(aacg_parse_result) + 16, hipHostMallocDefault), "hipHostMalloc") &&
+               ok(p, hipHostMalloc(&L.h_res, p->res_cap16 + 16, hipHostMallocDefault), "hipHostMalloc") &&
                aacg_wait_stream(L.st, p->wait) == hipSuccess;
     }
     if (!good) { if (p->err.empty()) p->err = "the pipeline's set-up did not complete"; std::fprintf(stderr, "aacgpu: %s\n", p->err.c_str()); aacg_pipeline_destroy(p); return AACG_ERR_OUT_OF_MEMORY; }
@@ -370,21 +406,22 @@ int aacg_pipeline_submit(aacg_pipeline* p, const uint8_t* bytes, size_t n_bytes,
     if (rc) return rc;
     if (p->learn && (rc = learn_layouts(p, bytes, n_bytes, frames, slots, n_streams, frames_per_stream))) return rc;
     /* staging: the bytes (16-byte aligned, AACG_PARSE_PAD readable bytes behind them) and the frame table in one page-locked block */
-    const size_t padded = ((n_bytes + 15) & ~(size_t)15) + 64, table = (size_t)n * sizeof(aacg_parse_frame);
-    if (padded + table > L.h_in_cap) {
+    const size_t padded = ((n_bytes + 15) & ~(size_t)15) + 64, table = (size_t)n * sizeof(aacg_parse_frame), up = padded + ((table + 15) & ~(size_t)15);
+    if (up > L.h_in_cap) {
         if (L.h_in) (void)hipHostFree(L.h_in);
         L.h_in = nullptr; L.h_in_cap = 0;
-        const size_t want = (padded + table) * 3 / 2 + 4096;
+        const size_t want = up * 3 / 2 + 4096;
         P_TRY(p, hipHostMalloc(&L.h_in, want, hipHostMallocDefault), AACG_ERR_OUT_OF_MEMORY);
         L.h_in_cap = want;
     }
-    if (padded > L.bytes_cap) {
+    if (up > L.bytes_cap) {                              /* bytes and frame table travel as one block: the table lies behind the bytes on the device too */
         if (L.d_bytes) (void)hipFree(L.d_bytes);
         L.d_bytes = nullptr; L.bytes_cap = 0;
-        const size_t want = padded * 3 / 2 + 4096;
+        const size_t want = up * 3 / 2 + 4096;
         P_TRY(p, hipMalloc(&L.d_bytes, want), AACG_ERR_OUT_OF_MEMORY);
         L.bytes_cap = want;
     }
+    L.d_frames = (char*)L.d_bytes + padded;
     std::memcpy(L.h_in, bytes, n_bytes);
     std::memset((char*)L.h_in + n_bytes, 0, padded - n_bytes);
     std::memcpy((char*)L.h_in + padded, frames, table);
@@ -400,9 +437,8 @@ int aacg_pipeline_submit(aacg_pipeline* p, const uint8_t* bytes, size_t n_bytes,
     L.unlearnt.clear();
     if (p->learn) for (uint32_t s = 0; s < n_streams; s++) if (!p->layout[slots[s]].kept) L.unlearnt.push_back(s);
     if (!L.unlearnt.empty()) P_TRY(p, hipMemsetAsync(L.d_pcm, 0, pcm_bytes, st), AACG_ERR_NO_DEVICE);      /* no unit writes their frames */
-    P_TRY(p, hipMemcpyAsync(L.d_bytes, L.h_in, padded, hipMemcpyHostToDevice, st), AACG_ERR_NO_DEVICE);
-    P_TRY(p, hipMemcpyAsync(L.d_frames, (char*)L.h_in + padded, table, hipMemcpyHostToDevice, st), AACG_ERR_NO_DEVICE);
-    P_TRY(p, hipMemsetAsync(L.d_refused, 0, 4, st), AACG_ERR_NO_DEVICE);
+    pipe_copy(L.h_in, L.d_bytes, up, st);                 /* aacg_pipe_copy: not the SDMA engines, where it would queue behind other lanes' PCM */
+    P_TRY(p, hipMemsetAsync(L.d_refused, 0, 16, st), AACG_ERR_NO_DEVICE);
     /* the spectra of a refused frame and the positions outside the coded bands are never read by the transform (a refused frame
      * becomes a silent unit), so the parser need not clear 8 KB per frame first */
     rc = aacg_parse_device(L.parser, L.d_bytes, (const aacg_parse_frame*)L.d_frames, n, U, Cp, (uint32_t)p->cfg.parse_options | AACG_PARSE_SKIP_ZERO_FILL,
@@ -424,9 +460,14 @@ int aacg_pipeline_submit(aacg_pipeline* p, const uint8_t* bytes, size_t n_bytes,
     }
     if (rc == AACG_OK && kp) rc = aacg_pipeline_join(p->engine, st);
     if (rc) { p->err = std::string("transform: ") + aacg_last_error(p->engine); return rc; }
-    P_TRY(p, hipMemcpyAsync(direct ? pcm_out : L.h_pcm, L.d_pcm, pcm_bytes, hipMemcpyDeviceToHost, st), AACG_ERR_NO_DEVICE);
-    P_TRY(p, hipMemcpyAsync(L.h_res, L.d_res, (size_t)n * sizeof(aacg_parse_result), hipMemcpyDeviceToHost, st), AACG_ERR_NO_DEVICE);
-    P_TRY(p, hipMemcpyAsync((char*)L.h_res + (size_t)n * sizeof(aacg_parse_result), L.d_refused, 4, hipMemcpyDeviceToHost, st), AACG_ERR_NO_DEVICE);
+    {
+        char* dst = (char*)(direct ? pcm_out : L.h_pcm);
+        P_TRY(p, hipMemcpyAsync(dst, L.d_pcm, pcm_bytes, hipMemcpyDeviceToHost, st), AACG_ERR_NO_DEVICE);      /* one SDMA copy per batch (see aacg_pipe_copy) */
+    }
+    /* the results and, behind where the largest batch's would end, the refusal count */
+    pipe_copy(L.d_res, L.h_res, ((size_t)n * sizeof(aacg_parse_result) + 15) & ~(size_t)15, st);
+    pipe_copy(L.d_refused, (char*)L.h_res + p->res_cap16, 16, st);
+    P_TRY(p, hipGetLastError(), AACG_ERR_NO_DEVICE);
     P_TRY(p, hipEventRecord(L.done, st), AACG_ERR_NO_DEVICE);
     L.busy = true; L.ticket = ++p->submitted; L.user_pcm = pcm_out; L.direct = direct; L.pcm_bytes = pcm_bytes;
     L.user_results = results; L.user_refused = n_refused; L.n = n; L.F = frames_per_stream;

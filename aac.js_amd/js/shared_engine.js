@@ -43,11 +43,12 @@ function SharedEngine(opts) {
      * page-locked buffers made once and used in turn: a frame is valid until its SharedEngine has flushed K more times, i.e. for
      * at least (K - 1) x lookahead further frames of its stream; a consumer that keeps frames longer copies them (frame.slice()) */
     this.pcmRing = opts.pcmRing | 0;
-    /* resident: decode the NEXT flush's batch while the caller consumes this one (addon.pipelineSubmit / pipelineCollect: the
-     * native call runs on a thread of its own).  A flush then collects the batch submitted by the flush before and submits the
-     * one after; streams are read one flush (lookahead frames) further ahead than they are consumed, and with pcmRing a frame
-     * is valid for one flush less. */
-    this.overlap = !!opts.overlap;
+    /* resident: decode the NEXT flush's batch while the caller consumes this one (addon.pipelineSubmit / pipelineCollect:
+     * aacg_pipeline_submit enqueues the batch on one of the pipeline's lanes and returns; no thread of the addon's is involved).
+     * A flush then collects the batch submitted by the flush before and submits the one after; streams are read one flush
+     * (lookahead frames) further ahead than they are consumed, and with pcmRing a frame is valid for one flush less.  On by
+     * default since round 6 ({ overlap: false } for a flush that decodes what it returns). */
+    this.overlap = opts.overlap === undefined ? this.resident : !!opts.overlap;
     this.stats = { batches: 0, frames: 0, units: 0, engineNs: 0n, retries: 0 };
 }
 

@@ -44,7 +44,10 @@ function ours(gpuParse) {
 /* N concurrent streams: the same bytes into N decoders, read round robin as N players would; `shared`: one SharedEngine
  * (one batch per flush for all of them) or an engine per decoder (one batch per decoder: what N independent plugin instances
  * do).  Engine time = wall time inside engine.decodeBatch (upload, kernels, download), on this one JavaScript thread. */
-function many(shared, lookahead, pcmRing, overlap) {
+/* yieldEvery > 0 (manyAsync): the same drain, but back to the event loop after every yieldEvery round-robin passes — what an
+ * event-driven host (Aurora decodes from timers and 'data' events) does anyway, and what lets the garbage collector's finalizers
+ * return a flush's page-locked PCM buffer to the addon's pool instead of a fresh 33 MB being page-locked per flush */
+function many(shared, lookahead, pcmRing, overlap, yieldEvery, done) {
     const resident = shared === 'resident';
     try {
         let engineNs = 0n, batches = 0;
@@ -54,6 +57,12 @@ function many(shared, lookahead, pcmRing, overlap) {
             return eng;
         };
         const sh = shared ? new host.SharedEngine({ maxStreams: nStreams, maxChannels: 2, resident: resident, lookahead: lookahead, pcmRing: pcmRing | 0, overlap: !!overlap }) : null;
+        const finish = function (t0, n, sum) {
+            if (resident) { engineNs = sh.stats.engineNs; batches = sh.stats.batches; }       // wall time inside the one native call per flush
+            const s = Number(process.hrtime.bigint() - t0) / 1e9, es = Number(engineNs) / 1e9;
+            return { streams: nStreams, lookahead: lookahead, frames: n, seconds: +s.toFixed(3), frames_per_s: Math.round(n / s), batches: batches,
+                     frames_per_batch: +(n / batches).toFixed(1), engine_seconds: +es.toFixed(3), frames_per_engine_second: Math.round(n / es), checksum: sum };
+        };
         const decs = [];
         for (let i = 0; i < nStreams; i++) {
             const dec = new host.GpuAACDecoder({ frontend: resident ? null : new host.FrontEnd(), lookahead: lookahead, shared: sh });
@@ -69,26 +78,41 @@ function many(shared, lookahead, pcmRing, overlap) {
         }
         if (shared && !resident) for (const g of sh.groups.values()) timed(g.engine);
         const t0 = process.hrtime.bigint();
-        let n = 0, sum = 0;
-        for (let live = nStreams; live;) {
-            live = 0;
+        let n = 0, sum = 0, passes = 0;
+        const pass = function () {
+            let live = 0;
             for (const d of decs) { const pcm = d.readChunk(); if (pcm) { n++; sum += pcm[17]; live++; } }
+            return live;
+        };
+        if (yieldEvery) {
+            const turn = function () {
+                try {
+                    for (let k = 0; k < yieldEvery; k++) if (!pass()) return done(Object.assign(finish(t0, n, sum), { event_loop_turn_every_passes: yieldEvery }));
+                    setImmediate(turn);
+                } catch (e) { done({ error: String(e.message || e).slice(0, 200) }); }
+            };
+            return turn();
         }
-        if (resident) { engineNs = sh.stats.engineNs; batches = sh.stats.batches; }       // wall time inside the one native call per flush
-        const s = Number(process.hrtime.bigint() - t0) / 1e9, es = Number(engineNs) / 1e9;
-        return { streams: nStreams, lookahead: lookahead, frames: n, seconds: +s.toFixed(3), frames_per_s: Math.round(n / s), batches: batches,
-                 frames_per_batch: +(n / batches).toFixed(1), engine_seconds: +es.toFixed(3), frames_per_engine_second: Math.round(n / es), checksum: sum };
-    } catch (e) { return { error: String(e.message || e).slice(0, 200) }; }
+        while (pass()) passes++;
+        return finish(t0, n, sum);
+    } catch (e) { const r = { error: String(e.message || e).slice(0, 200) }; if (done) done(r); return r; }
 }
-if (nStreams) {
+if (nStreams && process.env.READCHUNK_ONLY === 'event_loop') {
+    many('resident', 16, process.env.READCHUNK_RING | 0, true, parseInt(process.env.READCHUNK_YIELD || '16', 10), function (r) { console.log(JSON.stringify(r)); process.exit(0); });
+} else if (nStreams) {
     out.stream = 'stereo48.aac x ' + repeats + ' x ' + nStreams + ' streams';
     out.independent_decoders = many(false, 16);
     out.shared_engine = many(true, 16);
-    out.shared_engine_resident = many('resident', 16);        // bytes -> PCM in one native call per flush: JavaScript finds frame boundaries and slices PCM
-    out.shared_engine_resident_ring8 = many('resident', 16, 8);   // the same with the PCM in a ring of 8 page-locked buffers (a frame stays valid for 7 more flushes)
-    out.shared_engine_resident_overlap = many('resident', 16, 0, true);   // ... and with the next flush's batch decoded while this one is read
-    out.shared_engine_resident_ring8_overlap = many('resident', 16, 8, true);
-    if (out.shared_engine_resident.checksum !== undefined) out.resident_same_checksum = out.shared_engine_resident.checksum === out.independent_decoders.checksum && out.shared_engine_resident_ring8.checksum === out.independent_decoders.checksum && out.shared_engine_resident_overlap.checksum === out.independent_decoders.checksum && out.shared_engine_resident_ring8_overlap.checksum === out.independent_decoders.checksum;
+    out.shared_engine_resident_no_overlap = many('resident', 16, 0, false);   // bytes -> PCM in one native call per flush, the flush waits for what it returns (round 5's default)
+    out.shared_engine_resident = many('resident', 16, 0, true);   // the default since round 6: the next flush's batch is decoded while this one is read
+    out.shared_engine_resident_ring8_no_overlap = many('resident', 16, 8, false);   // the PCM in a ring of 8 page-locked buffers (a frame stays valid for 7 more flushes)
+    out.shared_engine_resident_ring8 = many('resident', 16, 8, true);
+    /* (READCHUNK_ONLY=event_loop runs the default from a host that returns to the event loop every READCHUNK_YIELD passes, in a
+     * process of its own: behind the synchronous drains above, the first turn of the event loop finalizes every page-locked
+     * buffer those left behind — a few hundred hipHostFree calls that have nothing to do with the variant being timed) */
+    const same = function (k) { return out[k] && out[k].checksum === out.independent_decoders.checksum; };
+    if (out.shared_engine_resident.checksum !== undefined)
+        out.resident_same_checksum = ['shared_engine_resident_no_overlap', 'shared_engine_resident', 'shared_engine_resident_ring8_no_overlap', 'shared_engine_resident_ring8'].every(same);
     if (out.independent_decoders.frames_per_engine_second && out.shared_engine.frames_per_engine_second) {
         out.engine_time_ratio = +(out.shared_engine.frames_per_engine_second / out.independent_decoders.frames_per_engine_second).toFixed(2);
         out.same_checksum = out.shared_engine.checksum === out.independent_decoders.checksum;
