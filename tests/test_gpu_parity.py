@@ -959,6 +959,42 @@ def test_pipelined_launches_equal_the_serialised_route_bit_for_bit(oracle, layou
             assert rms(serial[j], oracle.decode_batch(base["units"], host[j], base["meta"], base["n_pcm"], ov)) < RMS_TOL
 
 
+@pytest.mark.parametrize("layout,S,T,seam", [(("cpe",), 24, 7, "q"), (("cpe", "sce"), 20, 19, "q"), (("cpe",), 16, 5, "f")])
+def test_pipelined_launches_every_launch_against_the_oracle(oracle, layout, S, T, seam):
+    """The soak's pipelined leg as a test the driver runs: 208 back-to-back launches of ONE plan through
+    aacg_decode_pipelined — every window sequence, intensity, chains shorter and longer than a run (19 frames: the run-to-run AND
+    the launch-to-launch rendezvous), new coefficients every launch — and EVERY launch's PCM against the oracle, which carries
+    the same streams' overlap state from launch to launch; the final overlap state too.  A fault common to the pipelined and
+    the serialised route behind the first launches would show here and nowhere else in the suite."""
+    torch = _torch()
+    n = 208
+    base = aacgpu_workload.make_batch(n_streams=S, n_frames=T, layout=layout, mix=True, intensity=True, seed=7700)
+    C = base["C"]
+    kind = aacgpu.INPUT_QUANT_I16 if seam == "q" else aacgpu.INPUT_SPEC_F32
+    ins, host = _device_batches(torch, base, n, seam, oracle, 11)
+    d_meta = torch.from_numpy(base["meta"].view(np.int16)).cuda() if seam == "q" else None
+    mp = d_meta.data_ptr() if d_meta is not None else None
+    eng = aacgpu.Engine(kind, max_streams=S, max_channels=C)
+    plan = eng.plan(base["units"])
+    outs = [torch.full((base["n_pcm"],), float("nan"), dtype=torch.float32, device="cuda") for _ in range(n)]
+    torch.cuda.synchronize()
+    for j in range(n):
+        eng.decode_pipelined(plan, ins[j].data_ptr(), mp, outs[j].data_ptr())
+    eng.synchronize()
+    assert eng.pipeline_chained() == n - 1
+    ov = np.zeros((S, C, 1024), np.float32)
+    worst = 0.0
+    for j in range(n):
+        got = outs[j].cpu().numpy()
+        assert not np.isnan(got).any(), j
+        worst = max(worst, rms(got, oracle.decode_batch(base["units"], host[j], base["meta"] if seam == "q" else None, base["n_pcm"], ov)))
+    assert worst < RMS_TOL
+    state = overlaps(eng, S, C)
+    assert np.allclose(state, ov, rtol=0, atol=1e-4 * max(1.0, float(np.abs(ov).max())))
+    plan.destroy()
+    eng.close()
+
+
 @pytest.mark.parametrize("layout,S,T", [(("cpe",), 256, 16), (("cpe", "cpe", "cpe", "sce"), 40, 24)])
 def test_pipelined_int16_pcm_equals_the_serialised_route(oracle, layout, S, T):
     """AACG_OUTPUT_I16 engines through the pipeline (aacg_imdct_run_*_rv_i16): 64 overlapped launches against the same launches
