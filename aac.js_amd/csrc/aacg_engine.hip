@@ -371,8 +371,10 @@ int launch_kernel(aacg_engine* e, const aacg_run_kernel* k, unsigned blocks, hip
     if (!k) { e->err = "no run kernel for this route"; return AACG_ERR_UNSUPPORTED; }
     aacg_kparams p = P;
     aacg_rv_args v;
-    void* args[2] = {&p, nullptr};
+    void* args[8] = {&p, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     if (k->key & AACG_RK_RV) { v = *V; args[1] = &v; }
+    const void *a_runs = p.runs, *a_tab = p.tab, *a_links = V ? V->links : nullptr, *a_units = p.units, *a_coeffs = p.coeffs, *a_meta = p.meta;
+    if (k->preloaded) { args[0] = &a_runs; args[1] = &a_tab; args[2] = &a_links; args[3] = &a_units; args[4] = &a_coeffs; args[5] = &a_meta; args[6] = &p; args[7] = &v; }   /* AACG_RUN_KERNEL_PRE (aacg_routes.h) */
     const dim3 block(AACG_WG_THREADS);
     if (stop) HIP_TRY(e, hipExtLaunchKernel(k->fn, dim3(blocks), block, args, 0, s, nullptr, stop, 0), AACG_ERR_NO_DEVICE);
     else      HIP_TRY(e, hipLaunchKernel(k->fn, dim3(blocks), block, args, 0, s), AACG_ERR_NO_DEVICE);

@@ -8,23 +8,17 @@
 #include "aacg_kernels.h"
 #include "aacg_routes.h"
 
-extern "C" __global__ __launch_bounds__(AACG_WG_THREADS)
-void aacg_imdct_run_quant_rv(const aacg_kparams P, const aacg_rv_args V) { imdct_run_body<AACG_INPUT_QUANT_I16, AACG_OUTPUT_F32, false, false, false, true>(P, &V); }
-
-extern "C" __global__ __launch_bounds__(AACG_WG_THREADS)
-void aacg_imdct_run_f32_rv(const aacg_kparams P, const aacg_rv_args V) { imdct_run_body<AACG_INPUT_SPEC_F32, AACG_OUTPUT_F32, false, false, false, true>(P, &V); }
-
+/* (imdct_run_body<KIND, OUT, DD, EX, CPL, RV, NTL, PRE>) */
+AACG_RUN_KERNEL_PRE(aacg_imdct_run_quant_rv, AACG_INPUT_QUANT_I16, AACG_OUTPUT_F32, false, false, false, true, false)
+AACG_RUN_KERNEL_PRE(aacg_imdct_run_f32_rv, AACG_INPUT_SPEC_F32, AACG_OUTPUT_F32, false, false, false, true, false)
 /* the same for batches of multichannel frames: non-temporal loads of the spectra (aacg_engine_nt.hip says why) */
-extern "C" __global__ __launch_bounds__(AACG_WG_THREADS)
-void aacg_imdct_run_quant_rv_nt(const aacg_kparams P, const aacg_rv_args V) { imdct_run_body<AACG_INPUT_QUANT_I16, AACG_OUTPUT_F32, false, false, false, true, true>(P, &V); }
-
-extern "C" __global__ __launch_bounds__(AACG_WG_THREADS)
-void aacg_imdct_run_f32_rv_nt(const aacg_kparams P, const aacg_rv_args V) { imdct_run_body<AACG_INPUT_SPEC_F32, AACG_OUTPUT_F32, false, false, false, true, true>(P, &V); }
+AACG_RUN_KERNEL_PRE(aacg_imdct_run_quant_rv_nt, AACG_INPUT_QUANT_I16, AACG_OUTPUT_F32, false, false, false, true, true)
+AACG_RUN_KERNEL_PRE(aacg_imdct_run_f32_rv_nt, AACG_INPUT_SPEC_F32, AACG_OUTPUT_F32, false, false, false, true, true)
 
 const aacg_run_kernel aacg_run_kernels_rv[] = {
-    {AACG_RK_RV | AACG_RK_QUANT, "aacg_imdct_run_quant_rv", (const void*)aacg_imdct_run_quant_rv},
-    {AACG_RK_RV, "aacg_imdct_run_f32_rv", (const void*)aacg_imdct_run_f32_rv},
-    {AACG_RK_RV | AACG_RK_NT | AACG_RK_QUANT, "aacg_imdct_run_quant_rv_nt", (const void*)aacg_imdct_run_quant_rv_nt},
-    {AACG_RK_RV | AACG_RK_NT, "aacg_imdct_run_f32_rv_nt", (const void*)aacg_imdct_run_f32_rv_nt}
+    {AACG_RK_RV | AACG_RK_QUANT, "aacg_imdct_run_quant_rv", (const void*)aacg_imdct_run_quant_rv, true},
+    {AACG_RK_RV, "aacg_imdct_run_f32_rv", (const void*)aacg_imdct_run_f32_rv, true},
+    {AACG_RK_RV | AACG_RK_NT | AACG_RK_QUANT, "aacg_imdct_run_quant_rv_nt", (const void*)aacg_imdct_run_quant_rv_nt, true},
+    {AACG_RK_RV | AACG_RK_NT, "aacg_imdct_run_f32_rv_nt", (const void*)aacg_imdct_run_f32_rv_nt, true}
 };
 const int aacg_run_kernels_rv_n = 4;

@@ -890,11 +890,11 @@ struct quant_regs { dpi4 ql[2], qr[2]; unsigned mw[2][2]; };
 
 /* the unit's quantised spectra (16 bytes per lane per load) and raw band words, issued early */
 template <bool NTL = false>                             /* NTL: non-temporal loads (dp_load_nt) */
-DP_DEVICE void quant_load(const aacg_kparams& P, uint32_t coef_block, uint32_t meta_block, int n_ch, quant_regs& r)
+DP_DEVICE void quant_load(const void* coeffs, const aacg_band_meta* metas, uint32_t coef_block, uint32_t meta_block, int n_ch, quant_regs& r)
 {
     const int lane = dp_lane();
-    const int16_t* q0 = (const int16_t*)P.coeffs + (size_t)coef_block * 1024u;
-    const aacg_band_meta* meta = P.meta + meta_block;
+    const int16_t* q0 = (const int16_t*)coeffs + (size_t)coef_block * 1024u;
+    const aacg_band_meta* meta = metas + meta_block;
     /* unconditional loads (a single channel reads its own block twice): no per-load branches, so the
      * compiler keeps all of them in flight together */
     const int16_t* q1 = q0 + (n_ch == 2 ? 1024 : 0);
@@ -2018,12 +2018,18 @@ DP_DEVICE int ov_buffer(int rot, int add) { int r = rot + add; r = r >= AACG_OV_
 #define AACG_LDS_BYTES_QUANT_EX (AACG_LDS_BYTES_QUANT + 4 * AACG_WG_WAVES * AACG_RUN_XCH_FLOATS)
 /* RV = true builds (aacg_engine_rv.hip): chains longer than a run without a recomputed frame — the plan's runs all start from
  * what the run before them hands over through a rendezvous cell (aacg_rv_args), never from a recomputed predecessor. */
-template <int KIND, int OUT = AACG_OUTPUT_F32, bool DD = false, bool EX = false, bool CPL = false, bool RV = false, bool NTL = false>
-DP_DEVICE void imdct_run_body(const aacg_kparams& P, const aacg_rv_args* V = nullptr)
+template <int KIND, int OUT = AACG_OUTPUT_F32, bool DD = false, bool EX = false, bool CPL = false, bool RV = false, bool NTL = false, bool PRE = false>
+DP_DEVICE void imdct_run_body(const aacg_kparams& P, const aacg_rv_args* V = nullptr, const aacg_run* runs_pre = nullptr, const aacg_tables* tab_pre = nullptr, const aacg_rv_link* links_pre = nullptr,
+                              const aacg_dev_unit* units_pre = nullptr, const void* coeffs_pre = nullptr, const aacg_band_meta* meta_pre = nullptr)
 {
+    const aacg_run* const k_runs = PRE ? runs_pre : P.runs;
+    const aacg_tables* const k_tab = PRE ? tab_pre : P.tab;
+    const aacg_dev_unit* const k_units = PRE ? units_pre : P.units;
+    const void* const k_coeffs = PRE ? coeffs_pre : P.coeffs;
+    const aacg_band_meta* const k_meta = PRE ? meta_pre : P.meta;
     const int TAB_FLOATS = (KIND == AACG_INPUT_QUANT_I16) ? AACG_TAB_QUANT_FLOATS : AACG_TAB_F32_FLOATS;
     const int lane = dp_lane(), wave = dp_wave();
-    const aacg_run* run = P.runs + dp_block();
+    const aacg_run* run = k_runs + dp_block();
     float* lds = (float*)dp_lds_fixed<4 * AACG_LDS_FLOATS(TAB_FLOATS) + (EX ? 4 * AACG_WG_WAVES * AACG_RUN_XCH_FLOATS : 0)>();
     const float* tab = lds;
     float* slots = lds + AACG_TAB_SLOT_BASE(TAB_FLOATS);
@@ -2036,13 +2042,13 @@ DP_DEVICE void imdct_run_body(const aacg_kparams& P, const aacg_rv_args* V = nul
      * (its unit, where that unit's spectra and band words lie), and the table loads, which stay in flight across the wait —
      * then the spectra's requests and, beside them, the unit record.  Spelled out (dp_sload / dp_swait): left to itself hipcc
      * makes a chain of five round trips out of the same reads. */
-    dp_su8 rh = dp_sload8(run, P.tab);                 /* (the table pointer with the first batch of kernel arguments) */
-    dp_su4 lkw = dp_sload4(RV ? (const void*)(V->links + dp_block()) : (const void*)run);
+    dp_su8 rh = dp_sload8(run, k_tab);                 /* (the table pointer with the first batch of kernel arguments) */
+    dp_su4 lkw = dp_sload4(RV ? (const void*)((PRE ? links_pre : V->links) + dp_block()) : (const void*)run);
     unsigned w_unit = dp_sload1(run, (int)__builtin_offsetof(aacg_run, wave_unit) + 4 * wave);
     unsigned w_coef = dp_sload1(run, (int)__builtin_offsetof(aacg_run, wave_coef) + 4 * wave);
     unsigned w_meta = dp_sload1(run, (int)__builtin_offsetof(aacg_run, wave_meta) + 4 * wave);
     dpf4 tr0, tr1;
-    stage_tables_load(P.tab, TAB_FLOATS, tr0, tr1);
+    stage_tables_load(k_tab, TAB_FLOATS, tr0, tr1);
     dp_swait(rh, lkw, w_unit, w_coef, w_meta);
 
     const int pred_unit = (int)rh[0], n_units = (int)rh[1];
@@ -2075,7 +2081,7 @@ DP_DEVICE void imdct_run_body(const aacg_kparams& P, const aacg_rv_args* V = nul
     float hx0[8], hy0[8], hx1[8], hy1[8];
     /* the unit record (a wave without a frame reads unit 0's and ignores it): scalar loads — nothing that may clobber memory
      * (stores, clock reads) precedes them — requested here, first used behind the table barrier */
-    unit_view u = load_unit(P.units + dp_uniform((int)w_unit));
+    unit_view u = load_unit(k_units + dp_uniform((int)w_unit));
     /* Earlier frames get the higher issue priority: they finish first and their PCM stores overlap
      * the later waves' arithmetic.  A wave only ever waits for the wave before it, whose priority is
      * never lower, so a spinning consumer cannot starve its producer. */
@@ -2096,9 +2102,9 @@ DP_DEVICE void imdct_run_body(const aacg_kparams& P, const aacg_rv_args* V = nul
     int n_ch = 0, cls0 = 0, cls1 = 0;                  /* from the unit record, whose first use is behind the table barrier */
     bool pair_path = false;
     auto issue_loads = [&](uint32_t coef_block, uint32_t meta_block, int nch) {
-        if (KIND == AACG_INPUT_QUANT_I16) quant_load<NTL>(P, coef_block, meta_block, nch, qreg);
+        if (KIND == AACG_INPUT_QUANT_I16) quant_load<NTL>(k_coeffs, k_meta, coef_block, meta_block, nch, qreg);
         else {
-            const float* xsrc = (const float*)P.coeffs + (size_t)coef_block * 1024u;
+            const float* xsrc = (const float*)k_coeffs + (size_t)coef_block * 1024u;
             const float* xsrc1 = xsrc + (nch == 2 ? 1024 : 0);
 #pragma unroll
             for (int i = 0; i < 4; i++) {
@@ -2379,7 +2385,7 @@ DP_DEVICE void spectral_ex_body(const aacg_kparams& P, int n_units)
     float xl[16], xr[16];
     if (KIND == AACG_INPUT_QUANT_I16) {
         quant_regs qreg;
-        quant_load(P, u.coef_offset, u.meta_offset, n_ch, qreg);
+        quant_load(P.coeffs, P.meta, u.coef_offset, u.meta_offset, n_ch, qreg);
         spectral_quant<true>(P, tab, u, n_ch, qreg, slot, xl, xr);
     } else {
         const float* x0 = (const float*)P.coeffs + (size_t)u.coef_offset * 1024u;
@@ -2493,7 +2499,7 @@ DP_DEVICE void spectral_body(const aacg_kparams& P, int n_units)
     const int n_ch = u.n_ch;
     float xl[16], xr[16];
     quant_regs qreg;
-    quant_load(P, u.coef_offset, u.meta_offset, n_ch, qreg);
+    quant_load(P.coeffs, P.meta, u.coef_offset, u.meta_offset, n_ch, qreg);
     spectral_quant(P, tab, u, n_ch, qreg, bt, xl, xr);
     float* out = P.spec_out + (size_t)u.coef_offset * 1024u;
 #pragma unroll

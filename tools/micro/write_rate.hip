@@ -29,6 +29,21 @@ __global__ __launch_bounds__(1024) void cp(v4f* dst, const v4f* src, size_t n4)
 // four elements of a stream on one XCD, co-scheduled).  Nothing but the stores: what the CU write path + L2 + HBM take for this layout.
 //   mode 0: element-major (the run kernels' epilogue);  mode 1: the same bytes, every wave a contiguous 28-byte-per-sample-frame stretch
 //   (what a frame-major workgroup could store if its elements' samples met in LDS first)
+//   mode 2 (round 6): TWO elements per workgroup — CPE0 + CPE1: a 16-byte piece of every 28, CPE2 + LFE: a
+//   12-byte piece — half the workgroups (2 per frame), half the chains; what the write path takes for that pattern alone
+__global__ __launch_bounds__(1024) void wr7b(float* pcm, int n_streams, int nt)
+{
+    const int R = 2 * n_streams, b = blockIdx.x, x = b & 7, per = R >> 3;
+    const int i = x * per + (b >> 3), s = i >> 1, half = i & 1;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    float* base = pcm + ((size_t)s * 16 + w) * 7168 + 4 * half;
+    for (int j = 0; j < 16; j++) {
+        const int n = lane + 64 * j;
+        float* p = base + (size_t)n * 7;
+        if (!half) { typedef float f4u __attribute__((ext_vector_type(4), aligned(4))); f4u v = {1.0f, (float)n, 2.0f, 3.0f}; if (nt) __builtin_nontemporal_store(v, (f4u*)p); else *(f4u*)p = v; }
+        else { typedef float f2u __attribute__((ext_vector_type(2), aligned(4))); f2u v = {1.0f, (float)n}; if (nt) { __builtin_nontemporal_store(v, (f2u*)p); __builtin_nontemporal_store(3.0f, p + 2); } else { *(f2u*)p = v; p[2] = 3.0f; } }
+    }
+}
 __global__ __launch_bounds__(1024) void wr7(float* pcm, int n_streams, int mode, int nt)
 {
     const int R = 4 * n_streams, b = blockIdx.x, x = b & 7, per = R >> 3;
@@ -95,7 +110,17 @@ int main()
             float ms; hipEventElapsedTime(&ms, e0, e1);
             return ms * 1e3 / reps;
         };
-        const double a = time7(0, 0), an = time7(0, 1), c = time7(1, 0), cn = time7(1, 1);
+        auto time7b = [&](int nt) {
+            for (int pass = 0; pass < 2; pass++) {
+                if (pass) hipEventRecord(e0);
+                for (int i = 0; i < reps; i++) hipLaunchKernelGGL(wr7b, dim3(2 * S), dim3(1024), 0, 0, (float*)(buf + (size_t)(i % 8) * set), S, nt);
+            }
+            hipEventRecord(e1); hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1);
+            return ms * 1e3 / reps;
+        };
+        const double a = time7(0, 0), an = time7(0, 1), c = time7(1, 0), cn = time7(1, 1), p2 = time7b(0), p2n = time7b(1);
+        printf("config-5 PCM stores alone, two elements per workgroup (512 workgroups: 16-byte and 12-byte pieces of every 28): %.2f us plain, %.2f us nt (%.2f TB/s)\n", p2, p2n, bytes / p2n / 1e6);
         printf("config-5 PCM stores alone (%.1f MB, 1024 workgroups): element-major 8/4 bytes of every 28: %.2f us plain (%.2f TB/s), %.2f us nt | "
                "the same bytes as contiguous 16-byte stores: %.2f us plain, %.2f us nt (%.2f TB/s)\n", bytes / 1e6, a, bytes / a / 1e6, an, c, cn, bytes / cn / 1e6);
         /* config 5's algorithmic bytes (197.7 MB) as a copy, half read and half written: 4 sets of 128 MB on either side */
