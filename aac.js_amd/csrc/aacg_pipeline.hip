@@ -295,7 +295,7 @@ void aacg_pipeline_destroy(aacg_pipeline* p)
     }
     drop_plans(p);
     for (auto& L : p->lane) {
-        for (void* d : {L.d_bytes, L.d_units, L.d_q, L.d_meta, L.d_res, L.d_pcm, L.d_refused}) if (d) (void)hipFree(d);      /* (d_frames lies in d_bytes) */
+        for (void* d : {L.d_bytes, L.d_units, L.d_q, L.d_meta, L.d_res, L.d_pcm}) if (d) (void)hipFree(d);      /* (d_frames lies in d_bytes, d_refused in d_res) */
         for (void* h : {L.h_in, L.h_pcm, L.h_res}) if (h) (void)hipHostFree(h);
         if (L.done) (void)hipEventDestroy(L.done);
         if (L.parser) aacg_parser_destroy(L.parser);
@@ -349,11 +349,11 @@ int aacg_pipeline_create(const aacg_pipeline_config* cfg, const aacg_code_entry*
                ok(p, hipMalloc(&L.d_units, n * U * sizeof(aacg_unit_desc)), "hipMalloc") &&
                ok(p, hipMalloc(&L.d_q, n * Cp * 2048), "hipMalloc") && ok(p, hipMemsetAsync(L.d_q, 0, n * Cp * 2048, L.st), "hipMemset") &&
                ok(p, hipMalloc(&L.d_meta, n * Cp * sizeof(aacg_band_meta)), "hipMalloc") &&
-               ok(p, hipMalloc(&L.d_res, p->res_cap16), "hipMalloc") &&
+               ok(p, hipMalloc(&L.d_res, p->res_cap16 + 16), "hipMalloc") &&      /* the refusal count lies behind the results: one copy brings both down */
                ok(p, hipMalloc(&L.d_pcm, n * C * 1024 * pcm_elem(p)), "hipMalloc") &&
-               ok(p, hipMalloc(&L.d_refused, 16), "hipMalloc") &&
                ok(p, hipHostMalloc(&L.h_res, p->res_cap16 + 16, hipHostMallocDefault), "hipHostMalloc") &&
                aacg_wait_stream(L.st, p->wait) == hipSuccess;
+        if (good) L.d_refused = (char*)L.d_res + p->res_cap16;
     }
     if (!good) { if (p->err.empty()) p->err = "the pipeline's set-up did not complete"; std::fprintf(stderr, "aacgpu: %s\n", p->err.c_str()); aacg_pipeline_destroy(p); return AACG_ERR_OUT_OF_MEMORY; }
     *out = p;
@@ -464,9 +464,9 @@ int aacg_pipeline_submit(aacg_pipeline* p, const uint8_t* bytes, size_t n_bytes,
         char* dst = (char*)(direct ? pcm_out : L.h_pcm);
         P_TRY(p, hipMemcpyAsync(dst, L.d_pcm, pcm_bytes, hipMemcpyDeviceToHost, st), AACG_ERR_NO_DEVICE);      /* one SDMA copy per batch (see aacg_pipe_copy) */
     }
-    /* the results and, behind where the largest batch's would end, the refusal count */
-    pipe_copy(L.d_res, L.h_res, ((size_t)n * sizeof(aacg_parse_result) + 15) & ~(size_t)15, st);
-    pipe_copy(L.d_refused, (char*)L.h_res + p->res_cap16, 16, st);
+    /* the results and, behind where the largest batch's would end, the refusal count: one small launch (a launch that writes to
+     * host memory costs 50 us of the lane's time whatever it carries) */
+    pipe_copy(L.d_res, L.h_res, p->res_cap16 + 16, st);
     P_TRY(p, hipGetLastError(), AACG_ERR_NO_DEVICE);
     P_TRY(p, hipEventRecord(L.done, st), AACG_ERR_NO_DEVICE);
     L.busy = true; L.ticket = ++p->submitted; L.user_pcm = pcm_out; L.direct = direct; L.pcm_bytes = pcm_bytes;

@@ -16,8 +16,9 @@ step k + 1 starts on the compute units step k has already left; the chains of th
 1-4).  ONE plan, ONE set of 256 streams continued launch after launch either way (`config.pipelines` 1).
 
 Timing: W untimed warm-up steps, then the timed region of exactly K steps — R times back to back (--repeats, default 25;
-regions shorter than 80 steps are repeated until about 2000 launches are timed, and the median is then taken over runs of
-consecutive repeats of at least 100 launches: region_stats says why).  A repeat ends when its last launches —
+regions shorter than 80 steps are repeated until about 2000 launches are timed, and timed in runs of consecutive repeats of at
+least 100 launches — the marks go behind every G-th repeat, G x K >= 100: region_stats says why the median wants such runs, and
+marks as dense as three per twenty launches cost the overlapped route up to 1.5 us per launch).  A timed run ends when its last launches —
 one per pipeline stream: they run side by side — are complete: HIP events bound to those dispatches' completion
 (aacg_decode_pipelined_timed; no marker packet enters a queue, nothing is joined inside the timed region); the opening mark is
 recorded on the timing stream joined behind the warm-up steps; the whole set between barrier + synchronize on both sides
@@ -235,6 +236,9 @@ def main():
                          "of aacg_decode_pipelined")
     ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
                     help="collective backend of the harness (barrier + MAX only); gloo for ranks that share a GPU")
+    ap.add_argument("--wait-mode", type=int, default=-1, choices=[-1, 0, 1, 2, 3],
+                    help="measurement only (aacg_debug_set_wait_mode): how the engine's host waits wait — 0 poll without pause (round 5), 1 yield, 2 the shipped "
+                         "policy spelled out, 3 blocking events; -1 (default): whatever the library ships")
     ap.add_argument("--share-gpu", action="store_true",
                     help="testing on a box with fewer GPUs than ranks: rank r uses device r mod device_count (use with --dist-backend gloo)")
     args = ap.parse_args()
@@ -282,6 +286,8 @@ def main():
                         tns_mode=aacgpu.TNS_SPEC if args.tns == "spec" else aacgpu.TNS_REFERENCE,
                         output_kind=aacgpu.OUTPUT_I16 if args.output == "i16" else aacgpu.OUTPUT_F32)
 
+    if args.wait_mode >= 0:
+        eng.debug_set_wait_mode(args.wait_mode)
     # rank r owns its own streams: independent data per rank, same shape
     base = aacgpu_workload.make_batch(n_streams=n_streams, n_frames=n_frames, mix=mix, layout=layout,
                                       seed=aacgpu_shard.rank_seed(0xAAC00002, rank))
@@ -385,16 +391,29 @@ def main():
     # dispatch's end, no marker packet enters a queue, nothing is joined inside the timed region); the opening mark is an
     # ordinary one on the timing stream, joined behind the warm-up steps.
     bound = pipelined and not args.default_events
-    tails = [[aacgpu.TimerMark() for _ in range(min(aacgpu.PIPE_STREAMS, args.steps))] for _ in range(R)] if bound else None
+    # Regions shorter than 100 launches: the marks go behind every G-th repeat (G x K >= 100 launches), not behind every one.  The median
+    # was taken over such runs of consecutive repeats anyway (region_stats says why: a 20-launch repeat's end scatters by a launch
+    # either way); what round 6 found is that the marks themselves are not free when they are dense — three timing events bound to
+    # every twenty launches cost the overlapped route 1.1-1.5 us per launch on a box whose default line reads 11.0 (12.2-12.6 at the
+    # driver's K = 20; with K = 100, three marks per hundred launches: 10.9-11.0; `--default-events`: 11.3): the same K-step region,
+    # the same R x K launches back to back, fewer time stamps taken inside them.
+    group = -(-100 // args.steps) if (bound and args.steps < 100) else 1
+    if group > 1:
+        R = -(-R // group) * group
+    n_marked = R // group
+    tails = [[aacgpu.TimerMark() for _ in range(min(aacgpu.PIPE_STREAMS, args.steps))] for _ in range(n_marked)] if bound else None
 
     def timed_steps():
         t0 = time.perf_counter()
         join()                                           # the opening mark: the warm-up steps are complete
         evs[0].record()
+        K = args.steps
         for r in range(R):
-            for i in range(args.steps):
-                k = args.steps - 1 - i                   # 0 for the repeat's last launch, 1 for the one before it, ...
-                step(n_pre + args.warmup + r * args.steps + i, tails[r][k] if bound and k < len(tails[r]) else None)
+            marks = tails[r // group] if (bound and r % group == group - 1) else None      # the repeat that closes a timed run
+            base_i = n_pre + args.warmup + r * K
+            for i in range(K):
+                k = K - 1 - i                            # 0 for the repeat's last launch, 1 for the one before it, ...
+                step(base_i + i, marks[k] if marks is not None and k < len(marks) else None)
             if not bound:
                 join()                                   # a mark's time stamp is the completion of every launch before it
                 evs[r + 1].record()
@@ -403,14 +422,16 @@ def main():
     dev = torch.device("cuda", device)
     _, wall = aacgpu_shard.timed(dist, torch.cuda.synchronize, timed_steps, dev)      # barrier + synchronize on both sides, MAX over ranks
     if bound:
-        ends = [0.0] + [max(evs[0].ev.elapsed_ms(m) for m in tails[r]) for r in range(R)]      # ms since the opening mark
-        mine_ms = [ends[r + 1] - ends[r] for r in range(R)]
+        ends = [0.0] + [max(evs[0].ev.elapsed_ms(m) for m in tails[g]) for g in range(n_marked)]      # ms since the opening mark
+        mine_ms = [ends[g + 1] - ends[g] for g in range(n_marked)]                   # runs of `group` consecutive repeats of K steps
     else:
         mine_ms = [evs[r].elapsed_time(evs[r + 1]) for r in range(R)]                 # this rank's R repeats of K steps, on the launch stream
-    region_ms = aacgpu_shard.reduce_max_list(dist, mine_ms, dev)                      # MAX over ranks, repeat by repeat
-    group = -(-100 // args.steps) if (bound and args.steps < 100) else 1              # overlapped launches: regions of at least 100 launches under the median
-    stats = region_stats(region_ms, args.steps, group)
-    kernel_ms = region_stats(mine_ms, args.steps, group)["ms_per_step_median"]        # rank 0's own launches, for its roofline
+    region_ms = aacgpu_shard.reduce_max_list(dist, mine_ms, dev)                      # MAX over ranks, timed run by timed run
+    stats = region_stats(region_ms, args.steps * group, 1)
+    if group > 1:
+        stats["median_over"] = "%d timed runs of %d consecutive repeats of the %d-step region (%d launches each): marks behind every %d-th repeat" % (n_marked, group, args.steps, group * args.steps, group)
+        stats["repeats_of_the_k_step_region"] = R
+    kernel_ms = region_stats(mine_ms, args.steps * group, 1)["ms_per_step_median"]    # rank 0's own launches, for its roofline
 
     # Same process, same box, same clocks, right behind the timed region (untimed itself): what this box's memory system
     # gives a float4 copy launch of the step's byte volume (half read, half written; buffers rotated past the Infinity
@@ -468,7 +489,8 @@ def main():
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "timing": dict(stats, events=("torch.cuda.Event (default HIP events: a system-scope fence per record)" if args.default_events else
                                       "hipEventDisableSystemFence (timing-only HIP events, aacg_timer_*)"),
-                       method=("the K timed steps are run R times back to back; a repeat ends when its last launches (one per pipeline stream: they "
+                       method=("the K timed steps are run R times back to back" + (" and timed in runs of %d consecutive repeats (%d launches)" % (group, group * args.steps) if group > 1 else "") +
+                               "; a timed run ends when its last launches (one per pipeline stream: they "
                                "run side by side) are all complete — HIP events bound to those dispatches' completion "
                                "(hipExtLaunchKernel stopEvent), the opening event on the timing stream behind the warm-up steps" if bound else
                                "the K timed steps are run R times back to back, each repeat between its own HIP events on the launch stream") +

@@ -34,12 +34,27 @@ b quant_2ranks_shared_gpu --gpus 2 --dist-backend gloo --share-gpu --steps 1000 
 # the driver's launch line with one rank: RCCL carries the barrier and the 8-byte reductions
 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29541 bench.py --gpus 1 --steps 1000 --warmup 200 --no-cpu-baseline \
   > $OUT/bench_quant_torchrun_rccl_1rank.json 2> $OUT/bench_quant_torchrun_rccl_1rank.err || echo "bench torchrun failed" >> $OUT/failures.txt
-# the plugin surface: 256 streams through readChunk() on one JavaScript thread (independent decoders, SharedEngine, resident SharedEngine)
-node tools/readchunk_rate.js --streams 256 24 > $OUT/readchunk_256streams.json 2> $OUT/readchunk_256streams.err || echo "readchunk failed" >> $OUT/failures.txt
+# the plugin surface: 256 streams through readChunk() on one JavaScript thread (independent decoders, SharedEngine, resident SharedEngine);
+# and the same with 5.1 streams (SCE + CPE + CPE + LFE: config 5's shape behind the plugin surface)
+node tools/readchunk_rate.js --streams 256 100 > $OUT/readchunk_256streams.json 2> $OUT/readchunk_256streams.err || echo "readchunk failed" >> $OUT/failures.txt
+node tools/readchunk_rate.js --file surround48 --streams 256 100 > $OUT/readchunk_256streams_surround.json 2> $OUT/readchunk_256streams_surround.err || echo "readchunk surround failed" >> $OUT/failures.txt
+# bytes -> PCM through the C ABI (aacg_pipeline_*): one batch at a time, and with batches in flight
+( A=tests/golden/streams/stereo48.aac
+  tools/micro/resident_drive $A --sync; tools/micro/resident_drive $A --lanes 2; tools/micro/resident_drive $A --lanes 3; tools/micro/resident_drive $A --lanes 4
+  tools/micro/resident_drive $A --sync --i16; tools/micro/resident_drive $A --lanes 4 --i16; tools/micro/resident_drive $A --lanes 4 --pageable --batches 50
+  tools/micro/resident_drive tests/golden/streams/surround48.aac --lanes 4 --streams 256; tools/micro/resident_drive tests/golden/streams/mono22.aac --lanes 4 ) > $OUT/resident.jsonl 2> $OUT/resident.err
+# the headline route from a tight C loop, how the host waits (aacg_wait.h), and an event on every launch
+( for m in 0 1 2 3; do echo "wait mode $m: $(tools/micro/pipe_drive --wait-mode $m --repeats 3 2>/dev/null)"; done
+  echo "default policy: $(tools/micro/pipe_drive --repeats 3 2>/dev/null)"
+  echo "an event bound to every launch: $(tools/micro/pipe_drive --mark-all --repeats 3 2>/dev/null)"
+  echo "launch behind launch: $(tools/micro/pipe_drive --serial --repeats 3 2>/dev/null)" ) > $OUT/wait_modes.txt 2>&1
 # microbenchmarks behind the pipeline's design choices
 ( for m in launch_cost queue_map stop_event; do echo "== tools/micro/$m"; timeout 120 tools/micro/$m 2>&1; done ) > $OUT/micro.txt
 # rocprofv3: kernel trace + PMC passes (tools/prof.sh); pipelined launches overlap, so the trace's row spacing is printed beside the stats
 bash tools/prof.sh $TAG/prof_quant > $OUT/prof_quant.log 2>&1
+# the headline's kernel trace from the C driver (tools/micro/pipe_drive: no interpreter between two launches), beside bench.py's own
+bash tools/prof_pipe.sh $TAG/prof_pipe > $OUT/prof_pipe.log 2>&1
+cat $OUT/prof_pipe/pipe_drive.json $OUT/prof_pipe/pipe_drive_traced.json > $OUT/pipe_drive.jsonl 2>/dev/null
 bash tools/prof.sh $TAG/prof_quant_serial --serial > $OUT/prof_quant_serial.log 2>&1
 bash tools/prof.sh $TAG/prof_spec --input spec > $OUT/prof_spec.log 2>&1
 bash tools/prof.sh $TAG/prof_cfg5 --workload cfg5 > $OUT/prof_cfg5.log 2>&1
@@ -51,6 +66,25 @@ for p in prof_quant prof_quant_serial prof_spec prof_cfg5 prof_cfg3_tns; do
   find $OUT/$p/trace -name "*kernel_stats.csv" -exec cp {} $OUT/${p}_kernel_stats.csv \; 2>/dev/null
   rm -rf $OUT/$p
 done
+# the headline's intervals and kernel stats: the C driver's trace (bench.py's stay beside them)
+if [ -s $OUT/prof_pipe/intervals.txt ]; then
+  mv $OUT/prof_quant_intervals.txt $OUT/prof_quant_bench_intervals.txt; mv $OUT/prof_quant_kernel_stats.csv $OUT/prof_quant_bench_kernel_stats.csv
+  ( cat $OUT/prof_pipe/intervals.txt
+    python3 - <<PY
+import json
+u = json.loads(open("$OUT/prof_pipe/pipe_drive.json").read().strip().splitlines()[-1]); t = json.loads(open("$OUT/prof_pipe/pipe_drive_traced.json").read().strip().splitlines()[-1])
+print("driver: tools/micro/pipe_drive (C, aacg_decode_pipelined in a tight loop); the same binary untraced: %.2f us per launch by its dispatches' events (%.2f by the host's clock); under the tracer it measures %.2f itself" % (u["us_per_launch_events"], u["us_per_launch_host_clock"], t["us_per_launch_events"]))
+for n in ("default", "20steps"):
+    try:
+        d = json.loads(open("$OUT/prof_pipe/bench_%s.json" % n).read().strip().splitlines()[-1])
+        print("driver: bench.py (%s) on the same box, untraced: %.2f us per launch" % (n, d["ms_per_step"] * 1e3))
+    except Exception as e:
+        pass
+PY
+  ) > $OUT/prof_quant_intervals.txt
+  cp $OUT/prof_pipe/kernel_stats.csv $OUT/prof_quant_kernel_stats.csv
+fi
+rm -rf $OUT/prof_pipe/trace
 # per-wave phase timelines (profile build): launch after launch, and pipelined steady state
 if [ -f aac.js_amd/csrc/variants/profile.so ]; then
   ( echo "== serial launches (aacg_decode_device): one launch, every CU starts together"; AACGPU_LIB=aac.js_amd/csrc/variants/profile.so AACG_ABLATE=16 timeout 120 python3 tools/timeline.py quant 2>/dev/null

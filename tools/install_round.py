@@ -52,7 +52,7 @@ def main():
         # COSTS is the spacing of the rows — say so at the top of the summary, with the figures of the same trace
         summ, iv = os.path.join(prof, "%s_%s_summary.txt" % (rnd, p_[5:])), os.path.join(src, "%s_intervals.txt" % p_)
         if os.path.exists(summ) and os.path.exists(iv):
-            lines = [l for l in open(iv).read().splitlines() if l.startswith(("kernel:", "dispatch duration", "overlap with", "time per launch"))]
+            lines = [l for l in open(iv).read().splitlines() if l.startswith(("kernel:", "dispatch duration", "overlap with", "time per launch", "NOTE in flight", "driver:"))]
             over = any(l.startswith("overlap with") and "median 0.00" not in l for l in lines)
             if over:
                 note = ["NOTE  launches of this route OVERLAP (aacg_decode_pipelined, DESIGN.md 3d): avg_ns below is the length of a trace row (begin -> end,",
@@ -60,7 +60,9 @@ def main():
                 body = open(summ).read()
                 if not body.startswith("NOTE"):
                     open(summ, "w").write("\n".join(note + ["NOTE  " + l for l in lines]) + "\n" + body)
-    for f, dst in (("readchunk_256streams.json", "readchunk_256streams.json"), ("micro.txt", "micro.txt"), ("timeline.txt", "timeline.txt")):
+    for f, dst in (("readchunk_256streams.json", "readchunk_256streams.json"), ("readchunk_256streams_surround.json", "readchunk_256streams_surround.json"), ("micro.txt", "micro.txt"),
+                   ("timeline.txt", "timeline.txt"), ("pipe_drive.jsonl", "pipe_drive.jsonl"), ("resident.jsonl", "resident_drive.jsonl"), ("wait_modes.txt", "wait_modes.txt"),
+                   ("prof_quant_bench_intervals.txt", "quant_bench_intervals.txt"), ("prof_quant_bench_kernel_stats.csv", "quant_bench_kernel_stats.csv")):
         if os.path.exists(os.path.join(src, f)):
             shutil.copy(os.path.join(src, f), os.path.join(prof, "%s_%s" % (rnd, dst)))
     T = {"note": "HBM traffic per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (KiB; separate passes, tools/prof.sh, profiles/%s_*_summary.txt). gfx950 correction per "

@@ -83,6 +83,8 @@ def regions(rows):
     print("dispatch duration (begin -> end)  median %.2f us  min %.2f  max %.2f  mean %.2f" % (med(dur) / 1e3, min(dur) / 1e3, max(dur) / 1e3, sum(dur) / len(dur) / 1e3))
     print("start -> next start               median %.2f us  mean %.2f" % (med(s2s) / 1e3, sum(s2s) / len(s2s) / 1e3))
     print("end   -> next end                 median %.2f us  mean %.2f" % (med(e2e) / 1e3, sum(e2e) / len(e2e) / 1e3))
+    ov = [max(0, c[i][1] - c[i + 1][0]) for c in keep for i in range(len(c) - 1)]
+    print("overlap with the next dispatch    median %.2f us  mean %.2f   (0 = serialised)" % (med(ov) / 1e3, sum(ov) / len(ov) / 1e3))
     print("time per launch, region by region: %s us" % " ".join("%.2f" % (t / 1e3) for t in per_region))
     print("time per launch over the steady part: %.2f us  [(last end - first end) / (launches - 1), all kept regions]" % (per_launch / 1e3))
     print("NOTE in flight: %.2f dispatches on average (mean duration / time per launch = %.2f / %.2f), %.2f counted at the dispatches' starts (median %d);"

@@ -14,14 +14,18 @@
 const fs = require('fs'), path = require('path');
 const root = path.join(__dirname, '..');
 const host = require(path.join(root, 'aac.js_amd', 'js'));
-const argv = process.argv.slice(2);
+const argv0 = process.argv.slice(2);
+/* --file NAME: another of the committed streams (tests/golden/streams/NAME.aac; surround48 = SCE + CPE + CPE + LFE, six channels) */
+const fileAt = argv0.indexOf('--file'), fileName = fileAt >= 0 ? argv0[fileAt + 1] : 'stereo48';
+const argv = argv0.filter(function (a, i) { return fileAt < 0 || (i !== fileAt && i !== fileAt + 1); });
 const nStreams = argv[0] === '--streams' ? parseInt(argv[1], 10) : 0;
 const repeats = parseInt((nStreams ? argv[2] : argv[0]) || (nStreams ? '4' : '400'), 10);
-const one = new Uint8Array(fs.readFileSync(path.join(root, 'tests', 'golden', 'streams', 'stereo48.aac')));
+const one = new Uint8Array(fs.readFileSync(path.join(root, 'tests', 'golden', 'streams', fileName + '.aac')));
+const nChannels = host.adts.frames(one)[0].header.chanConfig;
 const perFile = host.adts.frames(one).length;
 const bytes = new Uint8Array(one.length * repeats);
 for (let i = 0; i < repeats; i++) bytes.set(one, i * one.length);
-const out = { stream: 'stereo48.aac x ' + repeats, frames: perFile * repeats, bytes: bytes.length };
+const out = { stream: fileName + '.aac x ' + repeats, channels: nChannels, frames: perFile * repeats, bytes: bytes.length };
 
 function ours(gpuParse) {
     try {
@@ -56,7 +60,7 @@ function many(shared, lookahead, pcmRing, overlap, yieldEvery, done) {
             eng.decodeBatch = function () { const t = process.hrtime.bigint(); try { return inner.apply(null, arguments); } finally { engineNs += process.hrtime.bigint() - t; batches++; } };
             return eng;
         };
-        const sh = shared ? new host.SharedEngine({ maxStreams: nStreams, maxChannels: 2, resident: resident, lookahead: lookahead, pcmRing: pcmRing | 0, overlap: !!overlap }) : null;
+        const sh = shared ? new host.SharedEngine({ maxStreams: nStreams, maxChannels: Math.max(2, nChannels), resident: resident, lookahead: lookahead, pcmRing: pcmRing | 0, overlap: !!overlap }) : null;
         const finish = function (t0, n, sum) {
             if (resident) { engineNs = sh.stats.engineNs; batches = sh.stats.batches; }       // wall time inside the one native call per flush
             const s = Number(process.hrtime.bigint() - t0) / 1e9, es = Number(engineNs) / 1e9;
@@ -100,7 +104,7 @@ function many(shared, lookahead, pcmRing, overlap, yieldEvery, done) {
 if (nStreams && process.env.READCHUNK_ONLY === 'event_loop') {
     many('resident', 16, process.env.READCHUNK_RING | 0, true, parseInt(process.env.READCHUNK_YIELD || '16', 10), function (r) { console.log(JSON.stringify(r)); process.exit(0); });
 } else if (nStreams) {
-    out.stream = 'stereo48.aac x ' + repeats + ' x ' + nStreams + ' streams';
+    out.stream = fileName + '.aac x ' + repeats + ' x ' + nStreams + ' streams';
     out.independent_decoders = many(false, 16);
     out.shared_engine = many(true, 16);
     out.shared_engine_resident_no_overlap = many('resident', 16, 0, false);   // bytes -> PCM in one native call per flush, the flush waits for what it returns (round 5's default)
