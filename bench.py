@@ -358,15 +358,6 @@ def main():
     # so a few hundred warm-up steps are over before the clocks have ramped (measured: 15.9 us per step after 40
     # warm-up steps, 14.2 us after 4000).  Untimed preconditioning, reported in the JSON line; then the W warm-up
     # steps of the contract; the timed region is exactly K steps.
-    n_pre = 0
-    t_pre = time.perf_counter()
-    while (time.perf_counter() - t_pre) * 1e3 < args.precondition_ms:
-        for _ in range(256):
-            step(n_pre)
-            n_pre += 1
-        torch.cuda.synchronize()
-    for i in range(args.warmup):
-        step(n_pre + i)
     # R repeats of the K-step region.  With overlapped launches a repeat's end is the completion of launches that run side by
     # side with the next repeat's first ones, so short regions scatter by a launch or so either way around the same mean
     # (K = 20: 9.2-12.8 us per step over 25 repeats, mean 11.43 both times, medians 11.22 and 11.89 in two runs): short
@@ -402,7 +393,19 @@ def main():
         R = -(-R // group) * group
     n_marked = R // group
     tails = [[aacgpu.TimerMark() for _ in range(min(aacgpu.PIPE_STREAMS, args.steps))] for _ in range(n_marked)] if bound else None
+    flat_marks = [m for t in tails for m in t] if bound else []
 
+    n_pre = 0
+    t_pre = time.perf_counter()
+    while (time.perf_counter() - t_pre) * 1e3 < args.precondition_ms:
+        for _ in range(256):
+            # (every timing mark is bound once here, untimed: a mark's FIRST binding to a dispatch costs the host more than its
+            # later ones — tools: 11.13 us per launch with three fresh marks per twenty launches, 10.97 with the same marks again)
+            step(n_pre, flat_marks[n_pre] if n_pre < len(flat_marks) else None)
+            n_pre += 1
+        torch.cuda.synchronize()
+    for i in range(args.warmup):
+        step(n_pre + i)
     def timed_steps():
         t0 = time.perf_counter()
         join()                                           # the opening mark: the warm-up steps are complete
