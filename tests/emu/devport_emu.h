@@ -128,8 +128,8 @@ DP_DEVICE unsigned dp_g_load_u32(const unsigned* p) { return __atomic_load_n(p, 
 DP_DEVICE void dp_g_store_u32(unsigned* p, unsigned v) { __atomic_store_n(p, v, __ATOMIC_RELAXED); }
 DP_DEVICE unsigned dp_cu_id() { return 0; }
 /* scalar loads in a spelled-out batch (devport.h): here plain reads */
-struct dp_su4 { unsigned v[4]; unsigned operator[](int i) const { return v[i]; } };
-struct dp_su8 { unsigned v[8]; unsigned operator[](int i) const { return v[i]; } };
+struct dp_su4 { unsigned v[4]; unsigned operator[](int i) const { return v[i]; } unsigned& operator[](int i) { return v[i]; } };
+struct dp_su8 { unsigned v[8]; unsigned operator[](int i) const { return v[i]; } unsigned& operator[](int i) { return v[i]; } };
 DP_DEVICE unsigned dp_sload1(const void* p, int byte_off) { unsigned r; memcpy(&r, (const char*)p + byte_off, 4); return r; }
 DP_DEVICE dp_su4 dp_sload4(const void* p) { dp_su4 r; memcpy(r.v, p, 16); return r; }
 DP_DEVICE dp_su8 dp_sload8(const void* p) { dp_su8 r; memcpy(r.v, p, 32); return r; }
