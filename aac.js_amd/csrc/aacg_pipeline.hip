@@ -37,7 +37,7 @@
 #include "../../include/aacgpu_tools.h"
 #include "aacg_wait.h"
 
-#define AACG_PIPELINE_MAX_LANES 4
+#define AACG_PIPELINE_MAX_LANES 8
 
 /* The batch's bytes up (and its few kilobytes of results down) are moved by THIS kernel, not by hipMemcpyAsync: page-locked host
  * memory is mapped into the device's address space, and a few workgroups of 16-byte loads and stores move 1.4 MB in 30 us.  The

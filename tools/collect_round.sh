@@ -43,6 +43,13 @@ node tools/readchunk_rate.js --file surround48 --streams 256 100 > $OUT/readchun
   tools/micro/resident_drive $A --sync; tools/micro/resident_drive $A --lanes 2; tools/micro/resident_drive $A --lanes 3; tools/micro/resident_drive $A --lanes 4
   tools/micro/resident_drive $A --sync --i16; tools/micro/resident_drive $A --lanes 4 --i16; tools/micro/resident_drive $A --lanes 4 --pageable --batches 50
   tools/micro/resident_drive tests/golden/streams/surround48.aac --lanes 4 --streams 256; tools/micro/resident_drive tests/golden/streams/mono22.aac --lanes 4 ) > $OUT/resident.jsonl 2> $OUT/resident.err
+# where a resident batch's time goes: kernel + copy trace of the same driver (f32 and int16 PCM), tools/resident_budget.py
+( for v in "" "--i16"; do
+    rm -rf $OUT/prof_resident; rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $OUT/prof_resident -o resident -- tools/micro/resident_drive tests/golden/streams/stereo48.aac --lanes 4 --batches 50 $v > $OUT/prof_resident.json 2> $OUT/prof_resident.err
+    python3 tools/resident_budget.py $(find $OUT/prof_resident -name "resident_kernel_trace.csv") $(find $OUT/prof_resident -name "resident_memory_copy_trace.csv") "4 lanes, ${v:-f32} PCM, traced: $(python3 -c "import json,sys; print('%.3f ms per batch by the driver' % json.loads(open('$OUT/prof_resident.json').read().strip().splitlines()[-1])['ms_per_batch_median'])")"
+  done; rm -rf $OUT/prof_resident ) > $OUT/resident_budget.txt 2>&1
+# what the headline's launch would cost if the dequantisation (or the PCM stores) were free: the profile build's skipping switches
+bash tools/floor.sh 2 > $OUT/dequant_floor.txt 2>&1
 # the headline route from a tight C loop, how the host waits (aacg_wait.h), and an event on every launch
 ( for m in 0 1 2 3; do echo "wait mode $m: $(tools/micro/pipe_drive --wait-mode $m --repeats 3 2>/dev/null)"; done
   echo "default policy: $(tools/micro/pipe_drive --repeats 3 2>/dev/null)"

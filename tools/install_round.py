@@ -61,7 +61,7 @@ def main():
                 if not body.startswith("NOTE"):
                     open(summ, "w").write("\n".join(note + ["NOTE  " + l for l in lines]) + "\n" + body)
     for f, dst in (("readchunk_256streams.json", "readchunk_256streams.json"), ("readchunk_256streams_surround.json", "readchunk_256streams_surround.json"), ("micro.txt", "micro.txt"),
-                   ("timeline.txt", "timeline.txt"), ("pipe_drive.jsonl", "pipe_drive.jsonl"), ("resident.jsonl", "resident_drive.jsonl"), ("wait_modes.txt", "wait_modes.txt"),
+                   ("timeline.txt", "timeline.txt"), ("pipe_drive.jsonl", "pipe_drive.jsonl"), ("resident.jsonl", "resident_drive.jsonl"), ("wait_modes.txt", "wait_modes.txt"), ("resident_budget.txt", "resident_budget.txt"), ("dequant_floor.txt", "dequant_floor.txt"),
                    ("prof_quant_bench_intervals.txt", "quant_bench_intervals.txt"), ("prof_quant_bench_kernel_stats.csv", "quant_bench_kernel_stats.csv")):
         if os.path.exists(os.path.join(src, f)):
             shutil.copy(os.path.join(src, f), os.path.join(prof, "%s_%s" % (rnd, dst)))
