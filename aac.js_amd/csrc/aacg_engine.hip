@@ -417,7 +417,8 @@ int launch_run(aacg_engine* e, const aacg_route& R, const aacg_dev_unit* d_units
             if (h.any_tns) aacg_set_tns_m(&P, tns_matrices_of(d_tns, h.tns.size()));
         }
         if (epoch_out) *epoch_out = V.epoch;
-        if (e->d_trace) { P.ablate = e->ablate; P.spec_out = (float*)e->d_trace + (size_t)xl.trace_part * (1u << 18); }   /* profiling builds: the last four launches keep their stamps */
+        P.ablate = e->d_trace ? e->ablate : (e->ablate & ~16);                                       /* profiling builds only (0 in the library that ships) */
+        if (e->d_trace) P.spec_out = (float*)e->d_trace + (size_t)xl.trace_part * (1u << 18);       /* ... the last four launches keep their stamps */
         return launch_kernel(e, aacg_find_run_kernel(R.run_key), (unsigned)n_runs, s, P, &V, stop);
     }
     P.runs = d_runs; P.n_runs = (int32_t)h.runs.size();

@@ -71,6 +71,52 @@ void aacg_parse_order_fill(const aacg_parse_frame* frames, uint32_t n, uint32_t*
     }
 }
 
+/* Small batches (a resident pipeline's 4096 frames): everything in front of the parse kernel in ONE launch.  On a stream that
+ * carries a batch through a dozen small steps every step costs its launch gap (5-10 us, and up to 60 when a transform launch of
+ * the highest priority holds the dispatcher: profiles/r06_resident_budget.txt), and five of them were memsets, three the
+ * counting sort.  Block 0 sorts (count, scan, place: the three kernels above in one workgroup's LDS); the other blocks clear
+ * the regions the parser promises zeroed.  Regions are multiples of 16 bytes. */
+#define AACG_PARSE_PREPARE_MAX 16384u
+struct aacg_clear_regions { void* at[4]; unsigned long long n16[4]; };
+extern "C" __global__ __launch_bounds__(1024)
+void aacg_parse_prepare(const aacg_clear_regions C, const aacg_parse_frame* frames, uint32_t n, uint32_t* order, uint32_t lanes, uint32_t n_wg, uint32_t waves_per_wg)
+{
+    const uint32_t t = threadIdx.x;
+    if (order && blockIdx.x == 0) {
+        __shared__ uint32_t cnt[AACG_PARSE_BUCKETS], sum[AACG_PARSE_BUCKETS];
+        for (uint32_t i = t; i < lanes; i += 1024u) order[i] = 0xffffffffu;        /* idle lanes */
+        cnt[t] = 0;
+        __syncthreads();
+        for (uint32_t i = t; i < n; i += 1024u) atomicAdd(&cnt[length_bucket(frames[i].byte_length)], 1u);
+        __syncthreads();
+        const uint32_t mine = cnt[t];
+        sum[t] = mine;
+        __syncthreads();
+        for (uint32_t d = 1; d < AACG_PARSE_BUCKETS; d <<= 1) {
+            const uint32_t add = t >= d ? sum[t - d] : 0u;
+            __syncthreads();
+            sum[t] += add;
+            __syncthreads();
+        }
+        cnt[t] = sum[t] - mine;                                                      /* where the bucket starts */
+        __syncthreads();
+        for (uint32_t i = t; i < n; i += 1024u) {
+            const uint32_t pos = atomicAdd(&cnt[length_bucket(frames[i].byte_length)], 1u), piece = pos >> 6;
+            order[((piece % n_wg) * waves_per_wg + piece / n_wg) * 64u + (pos & 63u)] = i;
+        }
+        return;
+    }
+    const uint32_t first = order ? 1u : 0u, blocks = gridDim.x - first;
+    if (!blocks) return;
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+    const v4u zero = {0u, 0u, 0u, 0u};
+    for (int r = 0; r < 4; r++) {
+        v4u* d = (v4u*)C.at[r];
+        const size_t n16 = (size_t)C.n16[r];
+        for (size_t i = (size_t)(blockIdx.x - first) * 1024u + t; i < n16; i += (size_t)blocks * 1024u) d[i] = zero;
+    }
+}
+
 struct aacg_parser {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -114,35 +160,53 @@ int launch(aacg_parser* p, aacg_parse_params& P, hipStream_t s)
     if (P.wg_threads != AACG_PARSE_WG_SMALL && P.wg_threads != 512 && P.wg_threads != AACG_PARSE_WG_LARGE) return fail(p, AACG_ERR_INVALID_ARG, "AACG_PARSE_WG must be 256, 512 or 1024");
     while (AACG_PARSE_LDS_FIXED(p->lut_words, P.wg_threads) > p->lds_bytes) P.wg_threads /= 2;      /* very large tables */
     P.arena_bytes = (uint32_t)(p->lds_bytes - AACG_PARSE_LDS_FIXED(p->lut_words, P.wg_threads));
-    if (!(P.options & AACG_PARSE_SKIP_ZERO_FILL)) HIPCHECK(hipMemsetAsync(P.q, 0, (size_t)P.n_frames * P.max_channels * 1024u * sizeof(int16_t), s));
-    HIPCHECK(hipMemsetAsync(P.meta, 0, (size_t)P.n_frames * P.max_channels * sizeof(aacg_band_meta), s));
-    if (P.tns) HIPCHECK(hipMemsetAsync(P.tns, 0, (size_t)P.n_frames * P.max_channels * sizeof(aacg_tns_info), s));
-    /* unit records of refused frames and of element slots beyond a frame's count stay zero (never stale memory) */
-    HIPCHECK(hipMemsetAsync(P.units, 0, (size_t)P.n_frames * P.max_units * sizeof(aacg_unit_desc), s));
-    /* The lane-order scratch belongs to the parser, not to the launch: a launch on another stream first waits for the
-     * previous launch's kernels (same stream: ordered anyway).  Two streams may therefore alternate on one parser. */
-    if (p->last_stream && p->last_stream != s) HIPCHECK(hipStreamWaitEvent(s, p->order_free, 0));
+    const unsigned grid = (P.n_frames + P.wg_threads - 1) / P.wg_threads;
     /* Frames of similar length into the same wave, and long and short waves onto every CU alike (AACG_PARSE_SORT=0: table
      * order).  Measured with frame lengths spread 44..1186 bytes: 16 k frames 1.40 -> 0.89 ms, 64 k 1.36 -> 0.94. */
     static const bool sort_enabled = [] { const char* v = std::getenv("AACG_PARSE_SORT"); return !(v && v[0] == '0'); }();
-    const unsigned grid = (P.n_frames + P.wg_threads - 1) / P.wg_threads;
-    P.order = nullptr;
-    if (sort_enabled && P.n_frames > 64u) {
-        const size_t lanes = (size_t)grid * P.wg_threads, need = lanes + AACG_PARSE_BUCKETS;
+    const bool sorted = sort_enabled && P.n_frames > 64u;
+    const size_t lanes = (size_t)grid * P.wg_threads;
+    if (sorted) {
+        const size_t need = lanes + AACG_PARSE_BUCKETS;
         if (need > p->order_cap) {
             if (p->d_order) (void)hipFree(p->d_order);
             p->d_order = nullptr; p->order_cap = 0;
             if (hipMalloc((void**)&p->d_order, need * sizeof(uint32_t)) != hipSuccess) return fail(p, AACG_ERR_OUT_OF_MEMORY, "hipMalloc failed");
             p->order_cap = need;
         }
-        uint32_t* hist = p->d_order + lanes;
-        const unsigned blocks = (P.n_frames + 255u) / 256u;
-        HIPCHECK(hipMemsetAsync(p->d_order, 0xff, lanes * sizeof(uint32_t), s));
-        HIPCHECK(hipMemsetAsync(hist, 0, AACG_PARSE_BUCKETS * sizeof(uint32_t), s));
-        hipLaunchKernelGGL(aacg_parse_order_count, dim3(blocks), dim3(256), 0, s, P.frames, P.n_frames, hist);
-        hipLaunchKernelGGL(aacg_parse_order_scan, dim3(1), dim3(AACG_PARSE_BUCKETS), 0, s, hist);
-        hipLaunchKernelGGL(aacg_parse_order_fill, dim3(blocks), dim3(256), 0, s, P.frames, P.n_frames, hist, p->d_order, grid, P.wg_threads / 64u);
-        P.order = p->d_order;
+    }
+    /* what the parser promises zeroed: the spectra (positions outside the coded bands), the band words (only the coded ones are
+     * written), TNS records, and the unit records of refused frames and of element slots beyond a frame's count (never stale memory) */
+    struct region { void* at; size_t bytes; };
+    const region regions[4] = {
+        { (P.options & AACG_PARSE_SKIP_ZERO_FILL) ? nullptr : (void*)P.q, (size_t)P.n_frames * P.max_channels * 1024u * sizeof(int16_t) },
+        { (void*)P.meta, (size_t)P.n_frames * P.max_channels * sizeof(aacg_band_meta) },
+        { (void*)P.tns, (size_t)P.n_frames * P.max_channels * sizeof(aacg_tns_info) },
+        { (void*)P.units, (size_t)P.n_frames * P.max_units * sizeof(aacg_unit_desc) } };
+    /* The lane-order scratch belongs to the parser, not to the launch: a launch on another stream first waits for the
+     * previous launch's kernels (same stream: ordered anyway).  Two streams may therefore alternate on one parser. */
+    if (p->last_stream && p->last_stream != s) HIPCHECK(hipStreamWaitEvent(s, p->order_free, 0));
+    P.order = sorted ? p->d_order : nullptr;
+    bool fused = P.n_frames <= AACG_PARSE_PREPARE_MAX;
+    for (const region& r : regions) if (r.at && (((uintptr_t)r.at | r.bytes) & 15u)) fused = false;
+    if (fused) {                                         /* one launch in front of the parse kernel (aacg_parse_prepare) */
+        aacg_clear_regions C;
+        size_t total16 = 0;
+        for (int i = 0; i < 4; i++) { C.at[i] = regions[i].at; C.n16[i] = regions[i].at ? regions[i].bytes / 16u : 0u; total16 += (size_t)C.n16[i]; }
+        unsigned blocks = (unsigned)((total16 + 4095u) / 4096u);                    /* four 16-byte stores per thread */
+        blocks = (blocks < 1u ? 1u : blocks > 512u ? 512u : blocks) + (sorted ? 1u : 0u);
+        hipLaunchKernelGGL(aacg_parse_prepare, dim3(blocks), dim3(1024), 0, s, C, P.frames, P.n_frames, sorted ? p->d_order : nullptr, (uint32_t)lanes, grid, P.wg_threads / 64u);
+    } else {
+        for (const region& r : regions) if (r.at) HIPCHECK(hipMemsetAsync(r.at, 0, r.bytes, s));
+        if (sorted) {
+            uint32_t* hist = p->d_order + lanes;
+            const unsigned blocks = (P.n_frames + 255u) / 256u;
+            HIPCHECK(hipMemsetAsync(p->d_order, 0xff, lanes * sizeof(uint32_t), s));
+            HIPCHECK(hipMemsetAsync(hist, 0, AACG_PARSE_BUCKETS * sizeof(uint32_t), s));
+            hipLaunchKernelGGL(aacg_parse_order_count, dim3(blocks), dim3(256), 0, s, P.frames, P.n_frames, hist);
+            hipLaunchKernelGGL(aacg_parse_order_scan, dim3(1), dim3(AACG_PARSE_BUCKETS), 0, s, hist);
+            hipLaunchKernelGGL(aacg_parse_order_fill, dim3(blocks), dim3(256), 0, s, P.frames, P.n_frames, hist, p->d_order, grid, P.wg_threads / 64u);
+        }
     }
     hipLaunchKernelGGL(aacg_parse_frames, dim3(grid), dim3(P.wg_threads), p->lds_bytes, s, P);
     HIPCHECK(hipGetLastError());

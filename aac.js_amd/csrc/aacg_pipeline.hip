@@ -49,13 +49,17 @@
  * kernels' stores (the parse kernel then takes 1.0-1.4 ms instead of 0.55) — and the PCM as two SDMA halves on two streams —
  * 0.84-0.88, the halves of one batch take both engines and the next lane's copy waits behind them. */
 extern "C" __global__ __launch_bounds__(256)
-void aacg_pipe_copy(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16)
+void aacg_pipe_copy(const uint4* src, uint4* dst, size_t n16, int clear_last)
 {
     typedef unsigned v4u __attribute__((ext_vector_type(4)));
     const v4u* s = (const v4u*)src;
     v4u* d = (v4u*)dst;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x)
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) {
         __builtin_nontemporal_store(__builtin_nontemporal_load(&s[i]), &d[i]);
+        /* the results' copy: its last 16 bytes are the batch's refusal count, cleared for the lane's next batch by the lane that has
+         * just read them (one launch less on the lane's stream than a memset in front of every batch) */
+        if (clear_last && i == n16 - 1) { const v4u zero = {0u, 0u, 0u, 0u}; ((v4u*)src)[i] = zero; }
+    }
 }
 
 struct aacg_pipeline {
@@ -85,7 +89,7 @@ struct aacg_pipeline {
         void *h_in = nullptr, *h_pcm = nullptr, *h_res = nullptr;
         size_t bytes_cap = 0, h_in_cap = 0;
         /* the batch in flight */
-        bool busy = false;
+        bool busy = false, count_stale = false;
         uint64_t ticket = 0;
         void* user_pcm = nullptr; bool direct = false; size_t pcm_bytes = 0;
         aacg_parse_result* user_results = nullptr; uint32_t* user_refused = nullptr; uint32_t n = 0, F = 0;
@@ -118,12 +122,12 @@ bool is_pinned(const void* ptr)
 }
 
 /* bytes (a multiple of 16, both ends 16-byte aligned) between device memory and mapped page-locked host memory, on stream s */
-void pipe_copy(const void* src, void* dst, size_t bytes, hipStream_t s)
+void pipe_copy(const void* src, void* dst, size_t bytes, hipStream_t s, bool clear_last = false)
 {
     const size_t n16 = bytes / 16;
     if (!n16) return;
     const unsigned blocks = (unsigned)((n16 + 255) / 256 < 64 ? (n16 + 255) / 256 : 64);      /* 64 x 256 lanes x 16 bytes in flight: the link, not the chip */
-    hipLaunchKernelGGL(aacg_pipe_copy, dim3(blocks), dim3(256), 0, s, (const uint4*)src, (uint4*)dst, n16);
+    hipLaunchKernelGGL(aacg_pipe_copy, dim3(blocks), dim3(256), 0, s, (const uint4*)src, (uint4*)dst, n16, clear_last ? 1 : 0);
 }
 
 void drop_plan(aacg_pipeline* p, size_t i)
@@ -350,6 +354,7 @@ int aacg_pipeline_create(const aacg_pipeline_config* cfg, const aacg_code_entry*
                ok(p, hipMalloc(&L.d_q, n * Cp * 2048), "hipMalloc") && ok(p, hipMemsetAsync(L.d_q, 0, n * Cp * 2048, L.st), "hipMemset") &&
                ok(p, hipMalloc(&L.d_meta, n * Cp * sizeof(aacg_band_meta)), "hipMalloc") &&
                ok(p, hipMalloc(&L.d_res, p->res_cap16 + 16), "hipMalloc") &&      /* the refusal count lies behind the results: one copy brings both down */
+               ok(p, hipMemsetAsync(L.d_res, 0, p->res_cap16 + 16, L.st), "hipMemset") &&
                ok(p, hipMalloc(&L.d_pcm, n * C * 1024 * pcm_elem(p)), "hipMalloc") &&
                ok(p, hipHostMalloc(&L.h_res, p->res_cap16 + 16, hipHostMallocDefault), "hipHostMalloc") &&
                aacg_wait_stream(L.st, p->wait) == hipSuccess;
@@ -438,7 +443,8 @@ int aacg_pipeline_submit(aacg_pipeline* p, const uint8_t* bytes, size_t n_bytes,
     if (p->learn) for (uint32_t s = 0; s < n_streams; s++) if (!p->layout[slots[s]].kept) L.unlearnt.push_back(s);
     if (!L.unlearnt.empty()) P_TRY(p, hipMemsetAsync(L.d_pcm, 0, pcm_bytes, st), AACG_ERR_NO_DEVICE);      /* no unit writes their frames */
     pipe_copy(L.h_in, L.d_bytes, up, st);                 /* aacg_pipe_copy: not the SDMA engines, where it would queue behind other lanes' PCM */
-    P_TRY(p, hipMemsetAsync(L.d_refused, 0, 16, st), AACG_ERR_NO_DEVICE);
+    if (L.count_stale) P_TRY(p, hipMemsetAsync(L.d_refused, 0, 16, st), AACG_ERR_NO_DEVICE);      /* a submission that failed half-way left its count behind */
+    L.count_stale = true;
     /* the spectra of a refused frame and the positions outside the coded bands are never read by the transform (a refused frame
      * becomes a silent unit), so the parser need not clear 8 KB per frame first */
     rc = aacg_parse_device(L.parser, L.d_bytes, (const aacg_parse_frame*)L.d_frames, n, U, Cp, (uint32_t)p->cfg.parse_options | AACG_PARSE_SKIP_ZERO_FILL,
@@ -466,7 +472,8 @@ int aacg_pipeline_submit(aacg_pipeline* p, const uint8_t* bytes, size_t n_bytes,
     }
     /* the results and, behind where the largest batch's would end, the refusal count: one small launch (a launch that writes to
      * host memory costs 50 us of the lane's time whatever it carries) */
-    pipe_copy(L.d_res, L.h_res, p->res_cap16 + 16, st);
+    L.count_stale = false;
+    pipe_copy(L.d_res, L.h_res, p->res_cap16 + 16, st, true);           /* ... and the count is cleared for the lane's next batch (set to zero at create) */
     P_TRY(p, hipGetLastError(), AACG_ERR_NO_DEVICE);
     P_TRY(p, hipEventRecord(L.done, st), AACG_ERR_NO_DEVICE);
     L.busy = true; L.ticket = ++p->submitted; L.user_pcm = pcm_out; L.direct = direct; L.pcm_bytes = pcm_bytes;

@@ -1,0 +1,81 @@
+// Microbenchmark (profiling aid, not product code): what does a launch of the run kernels' SHAPE cost when the kernel does nothing?
+// The headline launch is 256 workgroups x 16 waves, ~152 KB of static LDS (one workgroup per CU), 120 VGPRs, three launches in
+// flight on three streams.  tools/floor.sh found that skipping the dequantisation or the PCM stores shortens a launch behind a
+// launch by 1.0 / 1.5 us and the overlapped route by nothing: something that does not depend on the kernel's work sets the period.
+// Here every wave just lives for `life` microseconds (s_sleep on the constant 100 MHz clock), and launches go round three
+// streams like aacg_decode_pipelined's: cost per launch against life, waves per workgroup, LDS per workgroup, streams.
+//   hipcc --offload-arch=gfx950 -O2 -o dispatch_rate dispatch_rate.hip && ./dispatch_rate
+#include <hip/hip_runtime.h>
+#include <chrono>
+#include <cstdio>
+#include <vector>
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+
+template <int LDS_BYTES, int THREADS>
+__global__ __launch_bounds__(THREADS) void shape(unsigned* sink, int life_ticks, int jitter, int launch)
+{
+    // jitter: 1 = one workgroup in a hundred lives 4 us longer, 2 = one in ten 1 us longer, 3 = every workgroup 0..1 us longer (hashed)
+    const unsigned h = (blockIdx.x * 2654435761u + (unsigned)launch * 40503u) >> 7;
+    if (jitter == 1 && h % 100u == 0) life_ticks += 400;
+    if (jitter == 2 && h % 10u == 0) life_ticks += 100;
+    if (jitter == 3) life_ticks += (int)(h % 100u);
+    __shared__ unsigned lds[LDS_BYTES / 4];
+    const unsigned long long t0 = wall_clock64();
+    lds[threadIdx.x] = threadIdx.x;                                  // the allocation is real
+    asm volatile("v_mov_b32 v119, 0" ::: "v119");                    // 120 VGPRs like the run kernels
+    while ((long long)(wall_clock64() - t0) < (long long)life_ticks) __builtin_amdgcn_s_sleep(1);
+    if (lds[(threadIdx.x + 1) % THREADS] == 0xffffffffu) sink[0] = 1;
+}
+
+template <int LDS_BYTES, int THREADS>
+static double run(int n_streams, hipStream_t* st, unsigned* sink, int grid, double life_us, int launches, int jitter = 0)
+{
+    const int ticks = (int)(life_us * 100.0);
+    for (int i = 0; i < 300; i++) hipLaunchKernelGGL((shape<LDS_BYTES, THREADS>), dim3(grid), dim3(THREADS), 0, st[i % n_streams], sink, ticks, jitter, i);
+    (void)hipDeviceSynchronize();
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int i = 0; i < launches; i++)                               // no back-pressure: the queues hold the launches
+        hipLaunchKernelGGL((shape<LDS_BYTES, THREADS>), dim3(grid), dim3(THREADS), 0, st[i % n_streams], sink, ticks, jitter, i);
+    (void)hipDeviceSynchronize();
+    const auto t1 = std::chrono::steady_clock::now();
+    return std::chrono::duration<double, std::micro>(t1 - t0).count() / launches;
+}
+
+int main()
+{
+    int lo = 0, hi = 0;
+    CK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    hipStream_t st[4];
+    for (auto& s : st) CK(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, hi));
+    unsigned* sink = nullptr;
+    CK(hipMalloc(&sink, 64));
+    const int N = 3000;
+    const double lives[] = {0.0, 2.0, 4.0, 6.0, 8.0, 9.0, 10.0, 12.0};
+    std::printf("cost of a launch that does nothing but live (us per launch; 256 workgroups unless said; %d launches, streams taken in turn)\n", N);
+    std::printf("%-64s", "life of a wave, us:");
+    for (double l : lives) std::printf(" %6.1f", l);
+    std::printf("\n");
+    auto row = [&](const char* name, auto fn) {
+        std::printf("%-64s", name);
+        for (double l : lives) std::printf(" %6.2f", fn(l));
+        std::printf("\n");
+        std::fflush(stdout);
+    };
+    row("16 waves, 152 KB LDS (the run kernels' shape), 3 streams", [&](double l) { return run<152 * 1024, 1024>(3, st, sink, 256, l, N); });
+    row("16 waves, 152 KB LDS, 2 streams", [&](double l) { return run<152 * 1024, 1024>(2, st, sink, 256, l, N); });
+    row("16 waves, 152 KB LDS, 1 stream", [&](double l) { return run<152 * 1024, 1024>(1, st, sink, 256, l, N); });
+    row("16 waves, 152 KB LDS, 4 streams", [&](double l) { return run<152 * 1024, 1024>(4, st, sink, 256, l, N); });
+    row("16 waves, 76 KB LDS (two workgroups fit a CU), 3 streams", [&](double l) { return run<76 * 1024, 1024>(3, st, sink, 256, l, N); });
+    row("16 waves, 4 KB LDS, 3 streams", [&](double l) { return run<4 * 1024, 1024>(3, st, sink, 256, l, N); });
+    row("8 waves, 152 KB LDS, 3 streams", [&](double l) { return run<152 * 1024, 512>(3, st, sink, 256, l, N); });
+    row("8 waves, 76 KB LDS, 512 workgroups, 3 streams", [&](double l) { return run<76 * 1024, 512>(3, st, sink, 512, l, N); });
+    row("4 waves, 152 KB LDS, 3 streams", [&](double l) { return run<152 * 1024, 256>(3, st, sink, 256, l, N); });
+    row("16 waves, 152 KB LDS, 128 workgroups, 3 streams", [&](double l) { return run<152 * 1024, 1024>(3, st, sink, 128, l, N); });
+    row("16 waves, 152 KB LDS, 512 workgroups (two rounds), 3 streams", [&](double l) { return run<152 * 1024, 1024>(3, st, sink, 512, l, N); });
+    row("the run kernels' shape, 3 streams, one workgroup in 100 lives 4 us longer", [&](double l) { return run<152 * 1024, 1024>(3, st, sink, 256, l, N, 1); });
+    row("the run kernels' shape, 3 streams, one workgroup in 10 lives 1 us longer", [&](double l) { return run<152 * 1024, 1024>(3, st, sink, 256, l, N, 2); });
+    row("the run kernels' shape, 3 streams, every workgroup 0..1 us longer", [&](double l) { return run<152 * 1024, 1024>(3, st, sink, 256, l, N, 3); });
+    row("the run kernels' shape, 4 streams, one workgroup in 100 lives 4 us longer", [&](double l) { return run<152 * 1024, 1024>(4, st, sink, 256, l, N, 1); });
+    row("the run kernels' shape, 2 streams, one workgroup in 100 lives 4 us longer", [&](double l) { return run<152 * 1024, 1024>(2, st, sink, 256, l, N, 1); });
+    return 0;
+}
