@@ -17,6 +17,10 @@
 #include <string>
 #include <algorithm>
 #include <vector>
+#include <mutex>
+#include <thread>
+#include <unordered_map>
+#include <sys/mman.h>
 
 #include "aacg_kernels.h"
 #include "aacg_host.h"
@@ -1322,12 +1326,62 @@ int aacg_synchronize(aacg_engine* e, void* hip_stream)
 }
 
 /* ---- host-buffer path: process(elements) + interleave for a batch ------------------- */
+/* Page-locked memory for a caller's buffers.  Small blocks: hipHostMalloc.  Large ones (a batch's PCM: 32 MiB and more, FRESH for
+ * every flush of a host that keeps what readChunk() returned) are what round 6 measured (tools/micro/pinned_alloc.hip,
+ * profiles/r06_pinned_alloc.txt): hipHostMalloc of 32 MiB 3.5-6 ms, two threads at it together 11 ms for both — of which the
+ * runtime's own part is small: the kernel zeroing and mapping 8192 fresh pages one fault at a time is 3.1 ms.  The same bytes as
+ * sixteen 2 MiB pages (MADV_HUGEPAGE), faulted in by four threads at once, 0.5 ms; hipHostRegister of pages that are there 0.07 ms;
+ * a copy down into it runs at the rate of hipHostMalloc memory (0.60 ms per 32 MiB) and hipPointerGetAttributes calls it host
+ * memory like the other. */
+namespace {
+struct host_block { void* base; size_t mapped; };
+std::mutex g_host_lock;
+std::unordered_map<void*, host_block> g_host_blocks;
+const size_t HOST_HUGE = (size_t)2u << 20, HOST_LARGE = (size_t)8u << 20;
+}
 void* aacg_host_alloc(size_t bytes)
 {
+    if (bytes >= HOST_LARGE) {
+        const size_t len = (bytes + HOST_HUGE - 1) & ~(HOST_HUGE - 1);
+        void* base = mmap(nullptr, len + HOST_HUGE, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+        if (base != MAP_FAILED) {
+            char* q = (char*)(((uintptr_t)base + HOST_HUGE - 1) & ~(uintptr_t)(HOST_HUGE - 1));
+            (void)madvise(q, len, MADV_HUGEPAGE);
+            const unsigned hw = std::thread::hardware_concurrency(), T = hw >= 8 ? 4u : hw >= 2 ? 2u : 1u;
+            auto touch = [q, len, T](unsigned k) {
+                const size_t pieces = len / HOST_HUGE, a = pieces * k / T * HOST_HUGE, b = pieces * (k + 1) / T * HOST_HUGE;
+                for (size_t i = a; i < b; i += 4096) ((volatile char*)q)[i] = 0;          /* (4 KiB steps: where huge pages are off, every page still gets its fault here) */
+            };
+            std::vector<std::thread> helpers;
+            bool spawned = true;
+            try { for (unsigned k = 1; k < T; k++) helpers.emplace_back(touch, k); } catch (...) { spawned = false; }
+            touch(0);
+            for (auto& h : helpers) h.join();
+            if (!spawned) for (unsigned k = (unsigned)helpers.size() + 1; k < T; k++) touch(k);
+            if (hipHostRegister(q, len, hipHostRegisterDefault) == hipSuccess) {
+                std::lock_guard<std::mutex> g(g_host_lock);
+                g_host_blocks[q] = host_block{base, len + HOST_HUGE};
+                return q;
+            }
+            (void)hipGetLastError();
+            (void)munmap(base, len + HOST_HUGE);
+        }
+    }
     void* p = nullptr;
     return hipHostMalloc(&p, bytes, hipHostMallocDefault) == hipSuccess ? p : nullptr;
 }
-void aacg_host_free(void* p) { if (p) (void)hipHostFree(p); }
+void aacg_host_free(void* p)
+{
+    if (!p) return;
+    host_block b{nullptr, 0};
+    {
+        std::lock_guard<std::mutex> g(g_host_lock);
+        auto it = g_host_blocks.find(p);
+        if (it != g_host_blocks.end()) { b = it->second; g_host_blocks.erase(it); }
+    }
+    if (b.base) { (void)hipHostUnregister(p); (void)munmap(b.base, b.mapped); }
+    else (void)hipHostFree(p);
+}
 
 int aacg_wait(aacg_engine* e, uint64_t ticket)
 {

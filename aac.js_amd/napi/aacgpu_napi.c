@@ -14,6 +14,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include "../../include/aacgpu.h"
 
@@ -536,10 +537,10 @@ static napi_value js_pipeline_create(napi_env env, napi_callback_info info)
  * A buffer returns to the pool when the garbage collector has let go of the batch's last frame (the finalizer runs on the
  * JavaScript thread, like every call into this addon); the pool holds a few, the rest are freed.
  * Finalizers do not run inside a synchronous loop, though, and that is how a host drains 256 streams: every flush would then
- * page-lock a fresh 33 MB (2.3 ms — as long as the rest of the flush).  So a helper thread keeps the NEXT buffers ready: when
+ * page-lock a fresh 33 MB (3.5-6 ms with hipHostMalloc; 0.6 since round 6: aacg_host_alloc).  So a helper thread keeps the NEXT buffers ready: when
  * one is taken, it makes another of that size while JavaScript slices the batch, and it does the freeing too. */
 #define PCM_POOL_MAX 8
-#define PCM_READY_MAX 2
+#define PCM_READY_MAX 3
 typedef struct { void* ptr; size_t bytes; } pcm_buf;
 static pcm_buf g_pool[PCM_POOL_MAX];               /* recycled by finalizers (the JavaScript thread of whichever environment — main or a
                                                       worker — let go of the buffer: under g_pool_lock) */
@@ -555,6 +556,7 @@ static int pool_put(void* p, size_t bytes)          /* 1: kept for the next batc
 }
 static pthread_mutex_t g_prep_lock = PTHREAD_MUTEX_INITIALIZER;
 static pthread_cond_t g_prep_wake = PTHREAD_COND_INITIALIZER;
+static pthread_cond_t g_ready_wake = PTHREAD_COND_INITIALIZER;   /* the helper has put a buffer into g_ready */
 static pcm_buf g_ready[PCM_READY_MAX];             /* made ahead by the helper (under g_prep_lock) */
 static int g_ready_n = 0;
 static size_t g_want_bytes = 0;                    /* the size the helper keeps ready */
@@ -580,9 +582,9 @@ static void* prep_main(void* arg)
             void* p = L.host_alloc(bytes);
             pthread_mutex_lock(&g_prep_lock);
             if (p) {
-                if (g_ready_n < PCM_READY_MAX && bytes == g_want_bytes) { g_ready[g_ready_n].ptr = p; g_ready[g_ready_n].bytes = bytes; g_ready_n++; }
+                if (g_ready_n < PCM_READY_MAX && bytes == g_want_bytes) { g_ready[g_ready_n].ptr = p; g_ready[g_ready_n].bytes = bytes; g_ready_n++; pthread_cond_broadcast(&g_ready_wake); }
                 else if (g_trash_n < 64) g_trash[g_trash_n++] = p;
-            } else g_want_bytes = 0;                /* out of page-locked memory: the caller's own attempt will report it */
+            } else { g_want_bytes = 0; pthread_cond_broadcast(&g_ready_wake); }      /* out of page-locked memory: the caller's own attempt will report it */
             continue;
         }
         pthread_cond_wait(&g_prep_wake, &g_prep_lock);
@@ -625,11 +627,26 @@ static void* pcm_take(size_t bytes, size_t* got)
     }
     for (int i = 0; i < g_ready_n && !p; i++)
         if (g_ready[i].bytes == bytes) { p = g_ready[i].ptr; g_ready[i] = g_ready[--g_ready_n]; }
-    if (g_want_bytes != bytes) {                   /* another batch size: what was made ahead for the old one goes */
+    const int same_size = g_want_bytes == bytes;
+    if (!same_size) {                              /* another batch size: what was made ahead for the old one goes */
         while (g_ready_n && g_trash_n < 64) g_trash[g_trash_n++] = g_ready[--g_ready_n].ptr;
         g_want_bytes = bytes;
     }
     if (g_prep_started) pthread_cond_signal(&g_prep_wake);
+    /* none ready, but the helper is at one of this size: wait for that one rather than allocate beside it (two threads
+     * page-locking 32 MiB at the same time take longer than one after the other: tools/micro/pinned_alloc.hip) */
+    if (!p && g_prep_started && same_size) {
+        struct timespec until;
+        clock_gettime(CLOCK_REALTIME, &until);
+        until.tv_nsec += 20 * 1000 * 1000;
+        if (until.tv_nsec >= 1000000000L) { until.tv_sec++; until.tv_nsec -= 1000000000L; }
+        while (!p && g_want_bytes == bytes) {
+            for (int i = 0; i < g_ready_n && !p; i++)
+                if (g_ready[i].bytes == bytes) { p = g_ready[i].ptr; g_ready[i] = g_ready[--g_ready_n]; }
+            if (p) { pthread_cond_signal(&g_prep_wake); break; }
+            if (pthread_cond_timedwait(&g_ready_wake, &g_prep_lock, &until) != 0) break;
+        }
+    }
     pthread_mutex_unlock(&g_prep_lock);
     *got = bytes;
     return p ? p : L.host_alloc(bytes);

@@ -95,6 +95,36 @@ def test_pipeline_batches_in_flight_equal_batches_one_at_a_time():
     o.close()
 
 
+def test_large_page_locked_blocks_take_the_pcm_like_small_ones():
+    """aacg_host_alloc: blocks of 8 MiB and more are fresh huge pages faulted in by a few threads and registered (round 6: 0.6 ms
+    per 32 MiB instead of 3.5-6); the PCM that comes down into one equals the PCM that comes down into pageable memory, the block
+    is zero when handed out, and freeing both kinds works in any order."""
+    case = CASES[0]
+    data, table, refpcm = load(case)
+    S, F = 640, 2                                            # 640 x 2 x 2048 floats = 10 MiB of PCM: a large block
+    n = case["frames"]
+    starts = [s % (n - F + 1) for s in range(S)]
+    frames = np.concatenate([table[starts[s]: starts[s] + F] for s in range(S)])
+    p = aacgpu.Pipeline(channels=2, max_streams=S, max_frames=F, lanes=2)
+    big = p.pinned(S * F * 2048, np.float32)
+    assert big.nbytes >= 8 << 20 and not big.any()
+    big[::4099] = 7.0                                        # writable from the host, every page of it
+    small = p.pinned(1024, np.float32)
+    small[:] = 1.0
+    got, res, refused = p.collect(p.submit(data, frames, np.arange(S), F, pcm=big))
+    assert refused == 0 and not res["status"].any()
+    for s in range(S):
+        p.reset_stream(s)
+    want, _, _ = p.decode(data, frames, np.arange(S), F)     # into a numpy array of the binding's: pageable memory
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    close_to(got.reshape(S, F * 2048)[0], refpcm[:F * 2048])
+    lib = p.lib
+    for ptr in list(p._pinned):                              # the large one first, then the small one
+        lib.aacg_host_free(ptr)
+    p._pinned = []
+    p.close()
+
+
 def test_pipeline_refuses_a_frame_of_another_layout_as_a_whole():
     """A 5.1 stream whose third frame is replaced by a stereo frame: that frame is refused as a whole (AACG_PARSE_LAYOUT), the
     stream's state moves on through a silent frame, the frames before it are the reference's."""

@@ -4,7 +4,7 @@
 # (tools/micro/pipe_drive), interleaved with the shipped library on the same box.  The PCM of a skipping run is wrong on purpose.
 #   8  the dequantisation's arithmetic skipped: the spectra are the quantised integers converted to float (the loads of spectra
 #      and band words, the staging stores and everything behind them stay)
-#   2  the PCM stores skipped
+#   2  the epilogue skipped: the wait for the predecessor's tail, the overlap-add and the PCM stores
 # usage: tools/floor.sh [rounds, default 2]  > profiles/rNN_dequant_floor.txt
 set -u
 N=${1:-2}
@@ -20,7 +20,7 @@ one() { # label, library dir or "", AACG_ABLATE, extra args
   python3 -c "
 import json,sys
 d=json.loads(sys.argv[1])
-print('  %-78s %6.2f us per launch   (%s)' % (sys.argv[2], d['us_per_launch_events'] or d['us_per_launch_host_clock'], d['kernel']))" "$out" "$1"
+print('  %-92s %6.2f us per launch   (%s)' % (sys.argv[2], d['us_per_launch_events'] or d['us_per_launch_host_clock'], d['kernel']))" "$out" "$1"
 }
 echo "tools/floor.sh: config 2 (4096 stereo frames per launch, int16 seam -> f32 PCM), 3 x 30 000 launches per line, $N rounds interleaved, one box"
 for r in $(seq 1 $N); do
@@ -28,12 +28,12 @@ for r in $(seq 1 $N); do
   one "the library that ships" "" 0 ""
   one "profile build, nothing skipped" $D 0 ""
   one "profile build, dequantisation arithmetic skipped (AACG_ABLATE=8)" $D 8 ""
-  one "profile build, PCM stores skipped (AACG_ABLATE=2)" $D 2 ""
+  one "profile build, epilogue skipped: tail wait, overlap-add, PCM stores (AACG_ABLATE=2)" $D 2 ""
   one "profile build, both skipped (AACG_ABLATE=10)" $D 10 ""
   echo "round $r, launch behind launch (aacg_decode_device):"
   one "the library that ships" "" 0 "--serial"
   one "profile build, nothing skipped" $D 0 "--serial"
   one "profile build, dequantisation arithmetic skipped (AACG_ABLATE=8)" $D 8 "--serial"
-  one "profile build, PCM stores skipped (AACG_ABLATE=2)" $D 2 "--serial"
+  one "profile build, epilogue skipped: tail wait, overlap-add, PCM stores (AACG_ABLATE=2)" $D 2 "--serial"
 done
 rm -rf $D
