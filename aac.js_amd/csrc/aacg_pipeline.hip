@@ -453,6 +453,7 @@ int aacg_pipeline_submit(aacg_pipeline* p, const uint8_t* bytes, size_t n_bytes,
     for (int attempt = 0; kp; attempt++) {
         /* this lane's set of the plan's unit records: the launch that read it last was this lane's previous batch, whose PCM has
          * come down on this stream since */
+        if (attempt) P_TRY(p, hipMemsetAsync(L.d_refused, 0, 16, st), AACG_ERR_NO_DEVICE);      /* the stale plan's refresh has counted this batch's refusals already */
         rc = aacg_plan_refresh_from_parse_ex(p->engine, kp->plan, (const aacg_unit_desc*)L.d_units, (aacg_parse_result*)L.d_res, U,
                                              (const aacg_refresh_map*)kp->d_map, set, (uint32_t*)L.d_refused, st);
         /* the transform: behind this lane's parse and refresh (fork), in front of its copy down (join); consecutive batches of

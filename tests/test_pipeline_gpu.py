@@ -125,6 +125,23 @@ def test_large_page_locked_blocks_take_the_pcm_like_small_ones():
     p.close()
 
 
+def test_refusals_are_counted_once_when_a_kept_plan_has_gone_stale():
+    """A pipeline keeps a plan per batch shape; when another shape's plan has advanced the streams since, the kept one is stale, the
+    submission makes a new one and refreshes again — and must not count the batch's refused frames twice (found by
+    tools/soak_resident.py in round 6)."""
+    data, table, _ = load(CASES[0])
+    data = data.copy()
+    off, length = int(table[3]["byte_offset"]), int(table[3]["byte_length"])
+    data[off + 7: off + length] = 0xFF                      # frame 3: a raw_data_block that ends at once (no CPE in it)
+    p = aacgpu.Pipeline(channels=2, max_streams=1, max_frames=2, lanes=2)
+    for a, F in ((0, 1), (1, 2)):                            # shape (1 frame), then shape (2 frames): the first shape's plan is stale now
+        _, res, refused = p.decode(data, table[a:a + F].copy(), np.arange(1), F)
+        assert refused == 0 and not res["status"].any()
+    _, res, refused = p.decode(data, table[3:4].copy(), np.arange(1), 1)
+    assert refused == 1, refused
+    p.close()
+
+
 def test_pipeline_refuses_a_frame_of_another_layout_as_a_whole():
     """A 5.1 stream whose third frame is replaced by a stereo frame: that frame is refused as a whole (AACG_PARSE_LAYOUT), the
     stream's state moves on through a silent frame, the frames before it are the reference's."""

@@ -16,14 +16,29 @@ __global__ __launch_bounds__(THREADS) void shape(unsigned* sink, int life_ticks,
 {
     // jitter: 1 = one workgroup in a hundred lives 4 us longer, 2 = one in ten 1 us longer, 3 = every workgroup 0..1 us longer (hashed)
     const unsigned h = (blockIdx.x * 2654435761u + (unsigned)launch * 40503u) >> 7;
-    if (jitter == 1 && h % 100u == 0) life_ticks += 400;
-    if (jitter == 2 && h % 10u == 0) life_ticks += 100;
-    if (jitter == 3) life_ticks += (int)(h % 100u);
+    if ((jitter & 15) == 1 && h % 100u == 0) life_ticks += 400;
+    if ((jitter & 15) == 2 && h % 10u == 0) life_ticks += 100;
+    if ((jitter & 15) == 3) life_ticks += (int)(h % 100u);
     __shared__ unsigned lds[LDS_BYTES / 4];
     const unsigned long long t0 = wall_clock64();
     lds[threadIdx.x] = threadIdx.x;                                  // the allocation is real
     asm volatile("v_mov_b32 v119, 0" ::: "v119");                    // 120 VGPRs like the run kernels
+    // jitter bits 4..: what a run kernel does at its two ends.  16: copy 24 KB of tables from global memory into LDS and meet at a
+    // barrier before anything else; 32: every wave ends with 8 KB of non-temporal 16-byte stores (its PCM); 64: ... and waits for them
+    if (jitter & 16) {
+        const uint4* tab = (const uint4*)(sink + 1024);
+        for (int i = threadIdx.x; i < 1536; i += THREADS) ((uint4*)lds)[i + 64] = tab[i];
+        __syncthreads();
+    }
     while ((long long)(wall_clock64() - t0) < (long long)life_ticks) __builtin_amdgcn_s_sleep(1);
+    if (jitter & 32) {
+        typedef unsigned v4u __attribute__((ext_vector_type(4)));
+        v4u* out = (v4u*)(sink + 65536) + ((size_t)(launch & 7) * gridDim.x * (THREADS / 64) + (size_t)blockIdx.x * (THREADS / 64) + threadIdx.x / 64) * 512 + (threadIdx.x & 63);
+        const v4u v = {threadIdx.x, (unsigned)launch, 0u, 0u};
+#pragma unroll
+        for (int k = 0; k < 8; k++) __builtin_nontemporal_store(v, out + 64 * k);
+        if (jitter & 64) __builtin_amdgcn_s_waitcnt(0);
+    }
     if (lds[(threadIdx.x + 1) % THREADS] == 0xffffffffu) sink[0] = 1;
 }
 
@@ -48,7 +63,8 @@ int main()
     hipStream_t st[4];
     for (auto& s : st) CK(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, hi));
     unsigned* sink = nullptr;
-    CK(hipMalloc(&sink, 64));
+    CK(hipMalloc(&sink, (size_t)320 << 20));              // tables at +4 KB, eight launches' worth of PCM at +256 KB
+    CK(hipMemset(sink, 0, (size_t)320 << 20));
     const int N = 3000;
     const double lives[] = {0.0, 2.0, 4.0, 6.0, 8.0, 9.0, 10.0, 12.0};
     std::printf("cost of a launch that does nothing but live (us per launch; 256 workgroups unless said; %d launches, streams taken in turn)\n", N);
@@ -72,6 +88,10 @@ int main()
     row("4 waves, 152 KB LDS, 3 streams", [&](double l) { return run<152 * 1024, 256>(3, st, sink, 256, l, N); });
     row("16 waves, 152 KB LDS, 128 workgroups, 3 streams", [&](double l) { return run<152 * 1024, 1024>(3, st, sink, 128, l, N); });
     row("16 waves, 152 KB LDS, 512 workgroups (two rounds), 3 streams", [&](double l) { return run<152 * 1024, 1024>(3, st, sink, 512, l, N); });
+    row("the run kernels' shape, 3 streams, 24 KB of tables copied to LDS + a barrier first", [&](double l) { return run<152 * 1024, 1024>(3, st, sink, 256, l, N, 16); });
+    row("the run kernels' shape, 3 streams, every wave ends with 8 KB of nt stores", [&](double l) { return run<152 * 1024, 1024>(3, st, sink, 256, l, N, 32); });
+    row("the run kernels' shape, 3 streams, ... and waits for them", [&](double l) { return run<152 * 1024, 1024>(3, st, sink, 256, l, N, 32 + 64); });
+    row("the run kernels' shape, 3 streams, tables first and stores last", [&](double l) { return run<152 * 1024, 1024>(3, st, sink, 256, l, N, 16 + 32); });
     row("the run kernels' shape, 3 streams, one workgroup in 100 lives 4 us longer", [&](double l) { return run<152 * 1024, 1024>(3, st, sink, 256, l, N, 1); });
     row("the run kernels' shape, 3 streams, one workgroup in 10 lives 1 us longer", [&](double l) { return run<152 * 1024, 1024>(3, st, sink, 256, l, N, 2); });
     row("the run kernels' shape, 3 streams, every workgroup 0..1 us longer", [&](double l) { return run<152 * 1024, 1024>(3, st, sink, 256, l, N, 3); });
