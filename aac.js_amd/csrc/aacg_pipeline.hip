@@ -66,7 +66,7 @@ struct aacg_pipeline {
     aacg_pipeline_config cfg;
     aacg_engine* engine = nullptr;
     aacg_parser* parser = nullptr;      /* layouts of new streams (synchronous, host pointers) */
-    int n_lanes = 4;
+    int n_lanes = 5;
     uint32_t C = 2;                     /* channels of a frame's PCM (chanConfig) */
     uint32_t Cp = 2, U = 1;             /* what the parser is allowed per frame: channels (block stride), elements */
     bool learn = false;                 /* C > 2: layouts are learnt; C <= 2: every frame one SCE / one CPE */
@@ -321,7 +321,7 @@ int aacg_pipeline_create(const aacg_pipeline_config* cfg, const aacg_code_entry*
     aacg_pipeline* p = new (std::nothrow) aacg_pipeline();
     if (!p) return AACG_ERR_OUT_OF_MEMORY;
     p->cfg = *cfg;
-    p->n_lanes = cfg->lanes ? cfg->lanes : 4;
+    p->n_lanes = cfg->lanes ? cfg->lanes : 5;      /* four of the lowest priority and one of the level above: int16 PCM 0.37 -> 0.33 ms per batch, the link's rate; six and more share queues again */
     p->C = (uint32_t)cfg->channels;
     p->learn = p->C > 2;
     p->Cp = p->learn ? AACG_MAX_CHANNELS : p->C;
@@ -348,7 +348,10 @@ int aacg_pipeline_create(const aacg_pipeline_config* cfg, const aacg_code_entry*
     for (int k = 0; k < p->n_lanes && good; k++) {
         auto& L = p->lane[k];
         if (aacg_parser_create(cfg->device_ordinal, cfg->sample_index, entries, counts, &L.parser) != AACG_OK) { p->err = "aacg_parser_create (lane)"; good = false; break; }
-        good = ok(p, hipStreamCreateWithPriority(&L.st, hipStreamNonBlocking, least), "hipStreamCreate") &&
+        /* lanes 0..3 at the lowest priority, a level nobody else uses (four hardware queues); further lanes at the level between
+         * that and the engine's pipeline streams: other queues again, so that a fifth lane does not wait behind the first */
+        const int prio = k < 4 ? least : (least + greatest) / 2;
+        good = ok(p, hipStreamCreateWithPriority(&L.st, hipStreamNonBlocking, prio), "hipStreamCreate") &&
                ok(p, hipEventCreateWithFlags(&L.done, hipEventDisableTiming), "hipEventCreate") &&
                ok(p, hipMalloc(&L.d_units, n * U * sizeof(aacg_unit_desc)), "hipMalloc") &&
                ok(p, hipMalloc(&L.d_q, n * Cp * 2048), "hipMalloc") && ok(p, hipMemsetAsync(L.d_q, 0, n * Cp * 2048, L.st), "hipMemset") &&

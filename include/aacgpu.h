@@ -575,7 +575,7 @@ typedef struct aacg_pipeline_config {
     int32_t max_frames;        /* frames per stream in one batch, at most                                   */
     int32_t output_kind;       /* AACG_OUTPUT_*                                                             */
     int32_t parse_options;     /* AACG_PARSE_* (AACG_PARSE_REFERENCE_QUIRKS for what aac.js reads)          */
-    int32_t lanes;             /* batches in flight at most, 1..8; 0 = 4 (ABI version 6)                     */
+    int32_t lanes;             /* batches in flight at most, 1..8; 0 = 5 (ABI version 6)                     */
     int32_t reserved[3];       /* zero                                                                      */
 } aacg_pipeline_config;
 int  aacg_pipeline_create(const aacg_pipeline_config* cfg, const aacg_code_entry* entries, const uint32_t counts[12], aacg_pipeline** out);

@@ -40,13 +40,13 @@ node tools/readchunk_rate.js --streams 256 100 > $OUT/readchunk_256streams.json 
 node tools/readchunk_rate.js --file surround48 --streams 256 100 > $OUT/readchunk_256streams_surround.json 2> $OUT/readchunk_256streams_surround.err || echo "readchunk surround failed" >> $OUT/failures.txt
 # bytes -> PCM through the C ABI (aacg_pipeline_*): one batch at a time, and with batches in flight
 ( A=tests/golden/streams/stereo48.aac
-  tools/micro/resident_drive $A --sync; tools/micro/resident_drive $A --lanes 2; tools/micro/resident_drive $A --lanes 3; tools/micro/resident_drive $A --lanes 4
-  tools/micro/resident_drive $A --sync --i16; tools/micro/resident_drive $A --lanes 4 --i16; tools/micro/resident_drive $A --lanes 4 --pageable --batches 50
-  tools/micro/resident_drive tests/golden/streams/surround48.aac --lanes 4 --streams 256; tools/micro/resident_drive tests/golden/streams/mono22.aac --lanes 4 ) > $OUT/resident.jsonl 2> $OUT/resident.err
+  tools/micro/resident_drive $A --sync; for l in 2 3 4 5 6 8; do tools/micro/resident_drive $A --lanes $l; done
+  tools/micro/resident_drive $A --sync --i16; for l in 4 5 6 8; do tools/micro/resident_drive $A --lanes $l --i16; done; tools/micro/resident_drive $A --lanes 5 --pageable --batches 50
+  tools/micro/resident_drive tests/golden/streams/surround48.aac --lanes 5 --streams 256; tools/micro/resident_drive tests/golden/streams/mono22.aac --lanes 5 ) > $OUT/resident.jsonl 2> $OUT/resident.err
 # where a resident batch's time goes: kernel + copy trace of the same driver (f32 and int16 PCM), tools/resident_budget.py
 ( for v in "" "--i16"; do
-    rm -rf $OUT/prof_resident; rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $OUT/prof_resident -o resident -- tools/micro/resident_drive tests/golden/streams/stereo48.aac --lanes 4 --batches 50 $v > $OUT/prof_resident.json 2> $OUT/prof_resident.err
-    python3 tools/resident_budget.py $(find $OUT/prof_resident -name "resident_kernel_trace.csv") $(find $OUT/prof_resident -name "resident_memory_copy_trace.csv") "4 lanes, ${v:-f32} PCM, traced: $(python3 -c "import json,sys; print('%.3f ms per batch by the driver' % json.loads(open('$OUT/prof_resident.json').read().strip().splitlines()[-1])['ms_per_batch_median'])")"
+    rm -rf $OUT/prof_resident; rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $OUT/prof_resident -o resident -- tools/micro/resident_drive tests/golden/streams/stereo48.aac --lanes 5 --batches 50 $v > $OUT/prof_resident.json 2> $OUT/prof_resident.err
+    python3 tools/resident_budget.py $(find $OUT/prof_resident -name "resident_kernel_trace.csv") $(find $OUT/prof_resident -name "resident_memory_copy_trace.csv") "5 lanes, ${v:-f32} PCM, traced: $(python3 -c "import json,sys; print('%.3f ms per batch by the driver' % json.loads(open('$OUT/prof_resident.json').read().strip().splitlines()[-1])['ms_per_batch_median'])")"
   done; rm -rf $OUT/prof_resident ) > $OUT/resident_budget.txt 2>&1
 # what the headline's launch would cost if the dequantisation (or the PCM stores) were free: the profile build's skipping switches
 bash tools/floor.sh 2 > $OUT/dequant_floor.txt 2>&1

@@ -61,7 +61,7 @@ while time.time() - t0 < budget:
     chosen = [members[i] for i in rng.permutation(len(members))[:S]]
     # a malformed stream stays in only up to (and including) its bad frame: what comes after a frame the reference threw on is ours to define
     Fmax = int(rng.integers(1, 5))
-    lanes = int(rng.integers(1, 5))
+    lanes = int(rng.integers(1, 7))
     i16 = bool(rng.integers(0, 3) == 0)
     pipe = aacgpu.Pipeline(channels=C, max_streams=S, max_frames=Fmax, sample_index=si, lanes=lanes,
                            output_kind=aacgpu.OUTPUT_I16 if i16 else aacgpu.OUTPUT_F32)
