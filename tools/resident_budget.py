@@ -43,7 +43,7 @@ def main():
     h2d = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in cop if r["Direction"].endswith("HOST_TO_DEVICE") and t0 <= int(r["Start_Timestamp"]) <= t1]
     if len(h2d) > len(keep) // 2:
         print("  runtime copies UP in the window: %d, %.1f us median — the bytes go through the SDMA engines in this build" % (len(h2d), med([e - s for s, e in h2d]) / 1e3))
-    steps = ["aacg_pipe_copy", "__amd_rocclr_fillBufferAligned", "aacg_parse_order_count", "aacg_parse_order_scan", "aacg_parse_order_fill", "aacg_parse_frames", "aacg_units_refresh", "aacg_imdct_run"]
+    steps = ["aacg_pipe_copy", "__amd_rocclr_fillBufferAligned", "aacg_parse_prepare", "aacg_parse_order_count", "aacg_parse_order_scan", "aacg_parse_order_fill", "aacg_parse_frames", "aacg_units_refresh", "aacg_imdct_run"]
     inwin = [r for r in kern if t0 <= int(r["Start_Timestamp"]) <= t1]
     print("  kernels of a batch (median begin -> end; a row includes its wait for CUs while other lanes' kernels run):")
     for s in steps:
@@ -54,19 +54,8 @@ def main():
         per = len(rs) / len(keep)
         name = rs[0]["Kernel_Name"] if s == "aacg_imdct_run" else s
         print("    %-34s %5.1f per batch   %8.1f us median   %8.1f max" % (name[:34], per, med(d) / 1e3, max(d) / 1e3))
-    # how many batches are inside the device at once: from a batch's first kernel (its bytes' copy) to the end of its PCM copy
-    ups = sorted(int(r["Start_Timestamp"]) for r in inwin if r["Kernel_Name"].startswith("aacg_parse_order_count"))
-    if ups:
-        lat = []
-        ends = [e for _, e in keep]
-        for u in ups:
-            later = [e for e in ends if e > u]
-            if later:
-                lat.append(later[0] - u)
-        # a batch's PCM copy is the n_lanes-th end after its parse began at the latest; the nearest end is a lower bound of nothing: print the spacing instead
-        q = sorted((int(r["Queue_Id"]) for r in inwin if r["Kernel_Name"].startswith("aacg_parse_frames")))
-        print("  hardware queues the parse kernels ran on: %s" % sorted(set(q)))
     par = [r for r in inwin if r["Kernel_Name"].startswith("aacg_parse_frames")]
+    print("  hardware queues the parse kernels ran on: %s" % sorted(set(int(r["Queue_Id"]) for r in par)))
     ev = sorted([(int(r["Start_Timestamp"]), 1) for r in par] + [(int(r["End_Timestamp"]), -1) for r in par])
     cur, last, acc = 0, t0, {}
     for t, d in ev:
