@@ -69,17 +69,18 @@ def test_pipeline_decodes_the_reference_streams(case, split):
     p.close()
 
 
-def test_pipeline_batches_in_flight_equal_batches_one_at_a_time():
-    """64 streams (the stereo stream at 64 different starting frames) x 3 batches of 5 frames: three lanes with every batch
-    submitted before the first is collected, against one lane and synchronous calls — bit for bit; and the streams that start
-    at frame 0 equal the reference."""
+@pytest.mark.parametrize("lanes,F", [(3, 5), (6, 2)], ids=["3 lanes", "6 lanes (two priority levels)"])
+def test_pipeline_batches_in_flight_equal_batches_one_at_a_time(lanes, F):
+    """64 streams (the stereo stream at 64 different starting frames) x as many batches as lanes: every batch submitted before the
+    first is collected, against one lane and synchronous calls — bit for bit; and the streams that start at frame 0 equal the
+    reference.  Lanes beyond the fourth ride streams of another priority level (other hardware queues)."""
     case = CASES[0]
     data, table, refpcm = load(case)
-    n, S, F, B = case["frames"], 64, 5, 3
+    n, S, B = case["frames"], 64, lanes
     starts = [s % (n - F * B + 1) for s in range(S)]
     def batch(b):
         return np.concatenate([table[starts[s] + b * F: starts[s] + (b + 1) * F] for s in range(S)])
-    a = aacgpu.Pipeline(channels=2, max_streams=S, max_frames=F, lanes=3)
+    a = aacgpu.Pipeline(channels=2, max_streams=S, max_frames=F, lanes=lanes)
     o = aacgpu.Pipeline(channels=2, max_streams=S, max_frames=F, lanes=1)
     pinned = [a.pinned(S * F * 2048, np.float32) for _ in range(B)]
     tickets = [a.submit(data, batch(b), np.arange(S), F, pcm=pinned[b]) for b in range(B)]
