@@ -91,7 +91,8 @@ def test_pipeline_batches_in_flight_equal_batches_one_at_a_time(lanes, F):
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), b
         for s in range(S):
             if starts[s] == 0:
-                close_to(got.reshape(S, F * 2048)[s], refpcm[b * F * 2048:(b + 1) * F * 2048])
+                ref = refpcm[b * F * 2048:(b + 1) * F * 2048]          # (a batch of two frames may be a quiet stretch: per sample, not by rms)
+                assert np.abs(got.reshape(S, F * 2048)[s].astype(np.float64) - ref).max() <= 1e-5 * max(1.0, 4.0 * float(np.sqrt(np.mean(ref.astype(np.float64) ** 2))))
     a.close()
     o.close()
 
