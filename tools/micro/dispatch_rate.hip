@@ -30,7 +30,27 @@ __global__ __launch_bounds__(THREADS) void shape(unsigned* sink, int life_ticks,
         for (int i = threadIdx.x; i < 1536; i += THREADS) ((uint4*)lds)[i + 64] = tab[i];
         __syncthreads();
     }
-    while ((long long)(wall_clock64() - t0) < (long long)life_ticks) __builtin_amdgcn_s_sleep(1);
+    if (!(jitter & 256)) while ((long long)(wall_clock64() - t0) < (long long)life_ticks) __builtin_amdgcn_s_sleep(1);
+    if (jitter & 128) {           // 128: ONE 16-byte store per lane at the very end (does a wave's end wait for its last store's way out?)
+        typedef unsigned v4u __attribute__((ext_vector_type(4)));
+        v4u* out = (v4u*)(sink + 65536) + ((size_t)(launch & 7) * gridDim.x * (THREADS / 64) + (size_t)blockIdx.x * (THREADS / 64) + threadIdx.x / 64) * 512 + (threadIdx.x & 63);
+        const v4u v = {threadIdx.x, (unsigned)launch, 0u, 0u};
+        if (jitter & 512) *out = v; else __builtin_nontemporal_store(v, out);
+    }
+    if (jitter & 256) {           // 256: the run kernels' rhythm — the four groups of waves end a quarter of the life apart, each with its 8 KB of stores
+        const int group = (threadIdx.x / 64) / 4;
+        const long long until = (long long)life_ticks * (group + 1) / 4;
+        while ((long long)(wall_clock64() - t0) < until) __builtin_amdgcn_s_sleep(1);
+        typedef unsigned v4u __attribute__((ext_vector_type(4)));
+        v4u* out = (v4u*)(sink + 65536) + ((size_t)(launch & 7) * gridDim.x * (THREADS / 64) + (size_t)blockIdx.x * (THREADS / 64) + threadIdx.x / 64) * 512 + (threadIdx.x & 63);
+        const v4u v = {threadIdx.x, (unsigned)launch, 0u, 0u};
+        // 1024: only the LAST group's stores are plain ones
+        const bool plain = (jitter & 512) || ((jitter & 1024) && group == 3);
+#pragma unroll
+        for (int k = 0; k < 8; k++) { if (plain) out[64 * k] = v; else __builtin_nontemporal_store(v, out + 64 * k); }
+        if (lds[(threadIdx.x + 1) % THREADS] == 0xffffffffu) sink[0] = 1;
+        return;
+    }
     if (jitter & 32) {
         typedef unsigned v4u __attribute__((ext_vector_type(4)));
         v4u* out = (v4u*)(sink + 65536) + ((size_t)(launch & 7) * gridDim.x * (THREADS / 64) + (size_t)blockIdx.x * (THREADS / 64) + threadIdx.x / 64) * 512 + (threadIdx.x & 63);
@@ -92,6 +112,11 @@ int main()
     row("the run kernels' shape, 3 streams, every wave ends with 8 KB of nt stores", [&](double l) { return run<152 * 1024, 1024>(3, st, sink, 256, l, N, 32); });
     row("the run kernels' shape, 3 streams, ... and waits for them", [&](double l) { return run<152 * 1024, 1024>(3, st, sink, 256, l, N, 32 + 64); });
     row("the run kernels' shape, 3 streams, tables first and stores last", [&](double l) { return run<152 * 1024, 1024>(3, st, sink, 256, l, N, 16 + 32); });
+    row("the run kernels' shape, 3 streams, every wave ends with ONE 16-byte store per lane", [&](double l) { return run<152 * 1024, 1024>(3, st, sink, 256, l, N, 128); });
+    row("the run kernels' shape, 3 streams, groups of 4 waves end a quarter-life apart, 8 KB each", [&](double l) { return run<152 * 1024, 1024>(3, st, sink, 256, l, N, 256); });
+    row("... ONE 16-byte store per lane at the end, a plain (cached) store", [&](double l) { return run<152 * 1024, 1024>(3, st, sink, 256, l, N, 128 + 512); });
+    row("... groups a quarter-life apart, 8 KB each, plain stores", [&](double l) { return run<152 * 1024, 1024>(3, st, sink, 256, l, N, 256 + 512); });
+    row("... groups a quarter-life apart, 8 KB each, nt but the last group's plain", [&](double l) { return run<152 * 1024, 1024>(3, st, sink, 256, l, N, 256 + 1024); });
     row("the run kernels' shape, 3 streams, one workgroup in 100 lives 4 us longer", [&](double l) { return run<152 * 1024, 1024>(3, st, sink, 256, l, N, 1); });
     row("the run kernels' shape, 3 streams, one workgroup in 10 lives 1 us longer", [&](double l) { return run<152 * 1024, 1024>(3, st, sink, 256, l, N, 2); });
     row("the run kernels' shape, 3 streams, every workgroup 0..1 us longer", [&](double l) { return run<152 * 1024, 1024>(3, st, sink, 256, l, N, 3); });
