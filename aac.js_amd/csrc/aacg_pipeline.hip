@@ -405,6 +405,10 @@ int aacg_pipeline_submit(aacg_pipeline* p, const uint8_t* bytes, size_t n_bytes,
     if ((int)n_streams > p->cfg.max_streams || (int)frames_per_stream > p->cfg.max_frames) { p->err = "batch larger than the pipeline was created for"; return AACG_ERR_CAPACITY; }
     const uint32_t n = n_streams * frames_per_stream, C = p->C, Cp = p->Cp, U = p->U;
     for (uint32_t s = 0; s < n_streams; s++) if ((int)slots[s] >= p->cfg.max_streams) { p->err = "stream slot out of range"; return AACG_ERR_CAPACITY; }
+    {   /* a slot is one stream's overlap state: a batch brings each at most once (its frames are consecutive ones of that stream) */
+        std::vector<bool> seen((size_t)p->cfg.max_streams, false);
+        for (uint32_t s = 0; s < n_streams; s++) { if (seen[slots[s]]) { p->err = "a stream slot is listed twice in one batch"; return AACG_ERR_INVALID_ARG; } seen[slots[s]] = true; }
+    }
     for (uint32_t i = 0; i < n; i++)
         if ((size_t)frames[i].byte_offset + frames[i].byte_length > n_bytes) { p->err = "a frame points outside the byte buffer"; return AACG_ERR_INVALID_ARG; }
     P_TRY(p, hipSetDevice(p->cfg.device_ordinal), AACG_ERR_NO_DEVICE);

@@ -582,7 +582,8 @@ int  aacg_pipeline_create(const aacg_pipeline_config* cfg, const aacg_code_entry
 void aacg_pipeline_destroy(aacg_pipeline* p);
 const char* aacg_pipeline_last_error(const aacg_pipeline* p);
 int  aacg_pipeline_reset_stream(aacg_pipeline* p, uint32_t slot);                 /* new FilterBank for that slot */
-/* One batch, synchronous: n_streams streams (slots[s]: the stream slot that owns stream s's overlap state), the next
+/* One batch, synchronous: n_streams streams (slots[s]: the stream slot that owns stream s's overlap state; each slot at most
+ * once per batch: AACG_ERR_INVALID_ARG otherwise), the next
  * frames_per_stream frames of each; frames[s * frames_per_stream + f] = frame f of stream s in `bytes` (an ADTS frame,
  * header included, or a bare raw_data_block).  pcm_out: [stream][frame][1024][channels] (float, or int16 for
  * AACG_OUTPUT_I16 pipelines), any host memory — page-locked memory (aacg_host_alloc) receives the PCM straight from the

@@ -127,6 +127,16 @@ def test_large_page_locked_blocks_take_the_pcm_like_small_ones():
     p.close()
 
 
+def test_a_slot_listed_twice_in_a_batch_is_an_error():
+    data, table, _ = load(CASES[0])
+    p = aacgpu.Pipeline(channels=2, max_streams=4, max_frames=1)
+    with pytest.raises(aacgpu.AacgError):
+        p.decode(data, table[0:2].copy(), np.array([1, 1]), 1)
+    pcm, res, refused = p.decode(data, table[0:2].copy(), np.array([1, 2]), 1)      # the pipeline is usable afterwards
+    assert refused == 0 and not res["status"].any()
+    p.close()
+
+
 def test_refusals_are_counted_once_when_a_kept_plan_has_gone_stale():
     """A pipeline keeps a plan per batch shape; when another shape's plan has advanced the streams since, the kept one is stale, the
     submission makes a new one and refreshes again — and must not count the batch's refused frames twice (found by
