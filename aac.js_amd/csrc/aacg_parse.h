@@ -450,6 +450,7 @@ DP_DEVICE void parse_frame(const lane_ctx& c, uint32_t frame)
             n_units++; channel += n_ch;
         } else if (type == 2) {
             parse_cce(r, c);
+            any |= AACG_PARSE_HAS_CCE;             /* the element's bits were consumed and nothing of it kept (decoder.js:406-433 never applies it) */
         } else if (type == 4) {
             const int align = (int)br_read(r, 1);
             int count = (int)br_read(r, 8);

@@ -323,6 +323,7 @@ FrontEnd.prototype.cce = function (bits, config, keep) {
 /* ---- raw_data_block (decoder.js:138-200) ------------------------------------------------------------ */
 FrontEnd.prototype.parseRawDataBlock = function (bits, config) {
     const elements = [], parts = [];
+    let hadCoupling = false;
     for (;;) {
         const type = bits.read(3);
         if (type === END) break;
@@ -342,6 +343,7 @@ FrontEnd.prototype.parseRawDataBlock = function (bits, config) {
         }
         case CCE: {
             const e = this.cce(bits, config, this.keepCoupling);
+            hadCoupling = true;
             if (e) { e.id = id; elements.push(e); parts.push([e.q, e.meta]); }
             break;
         }
@@ -367,7 +369,7 @@ FrontEnd.prototype.parseRawDataBlock = function (bits, config) {
     const q = new Int16Array(n), meta = new Uint16Array(n / FRAME * META_WORDS);
     n = 0;
     for (const p of parts) { q.set(p[0], n); meta.set(p[1], n / FRAME * META_WORDS); n += p[0].length; }
-    return { elements: elements, q: q, meta: meta, bitsUsed: bits.pos };     // bitsUsed: from the start of the frame's bytes, byte-aligned
+    return { elements: elements, q: q, meta: meta, bitsUsed: bits.pos, hadCoupling: hadCoupling };     // bitsUsed: from the start of the frame's bytes, byte-aligned
 };
 
 /* next complete frame, or null.  `decoder.config` supplies sampleIndex (set by setCookie). */

@@ -465,6 +465,8 @@ enum {                         /* aacg_parse_result.status; the reference's mess
                                                NOISE / INTENSITY and bands beyond max_sfb are not taken from the spectrum) */
 #define AACG_PARSE_HAS_PNS 0x1
 #define AACG_PARSE_HAS_TNS 0x2
+#define AACG_PARSE_HAS_CCE 0x4   /* the frame held a coupling channel element: parsed and dropped (what aac.js executes); a host that
+                                    applies coupling (AACG_CCE_SPEC) takes such a frame's records from a front end that keeps them */
 typedef struct aacg_parse_result {
     uint8_t  status;           /* AACG_PARSE_*; a failed frame's output records are unspecified
                                   (partially written; never uninitialised memory)                  */

@@ -87,6 +87,7 @@ function emit(name, frames, o) {
                          maskPresent: e.maskPresent, hasPns: e.hasPns, ch: e.ch, tnsOffset: anyTns ? block : 0, tag: (TYPE_CODE[e.type] << 4) | e.id });
             channel += e.ch.length;
         });
+        if (frame.hadCoupling) flags |= 4;                        // AACG_PARSE_HAS_CCE
         const packed = host.packUnits(units);
         units.forEach(function (u, i) { packed[i * host.UNIT_BYTES + 14] = u.tag; });            // reserved0: (element type << 4) | id
         unitBytes.set(packed, f * o.maxUnits * host.UNIT_BYTES);

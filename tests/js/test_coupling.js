@@ -100,8 +100,8 @@ const captured = { units: [], q: [], meta: [], cce: [] };
 const recorder = { resetStream: function () {}, decodeBatch: function (units, q, meta, pcm, tns, cce) {
     captured.units.push(Buffer.from(units)); captured.q.push(Buffer.from(q.buffer, q.byteOffset, q.byteLength));
     captured.meta.push(Buffer.from(meta.buffer, meta.byteOffset, meta.byteLength)); captured.cce.push(Buffer.from(cce)); } };
-function decode(engine) {
-    const dec = new host.GpuAACDecoder({ engine: engine, frontend: new FrontEnd({ codebooks: cb, coupling: true, referenceQuirks: false }),
+function decode(engine, frontend) {
+    const dec = new host.GpuAACDecoder({ engine: engine, frontend: frontend || new FrontEnd({ codebooks: cb, coupling: true, referenceQuirks: false }),
                                          lookahead: FRAMES, cceMode: host.CCE_SPEC, maxCoupling: 2 });
     dec.init();
     dec.setCookie(new Uint8Array([(2 << 3) | (SI >> 1), ((SI & 1) << 7) | (C << 3)]));
@@ -145,5 +145,22 @@ if (mode === 'gpu') {
     const pcm = decode(null);                                     // a real engine, created by setCookie
     assert.strictEqual(pcm.length, FRAMES);
     fs.writeFileSync(path.join(outdir, 'coupling.pcm'), Buffer.concat(pcm.map(function (p) { return Buffer.from(p.buffer, p.byteOffset, p.byteLength); })));
+    /* the same through the device front end (round 6): a frame that holds a coupling element is flagged by the device parser and
+     * its records come from the JavaScript front end; bit for bit the same PCM.  Every frame of this stream has coupling elements;
+     * a stream without them stays on the device */
+    const gfe = new host.GpuFrontEnd({ codebooks: cb, coupling: true, referenceQuirks: false });
+    const viaDevice = decode(null, gfe);
+    assert.strictEqual(viaDevice.length, FRAMES);
+    viaDevice.forEach(function (p, t) { assert.deepStrictEqual(Buffer.from(p.buffer, p.byteOffset, p.byteLength), Buffer.from(pcm[t].buffer, pcm[t].byteOffset, pcm[t].byteLength), 'frame ' + t); });
+    assert.deepStrictEqual(gfe.stats, { deviceFrames: 0, cpuFrames: FRAMES });
+    const plainFrames = [];
+    for (let t = 0; t < 4; t++) plainFrames.push(wr.adtsFrame(randomFrame(wr, rng, ['cpe', 'sce'], function () { return PATTERN[t % PATTERN.length]; }, { quirks: false }), C, {}));
+    const gfe2 = new host.GpuFrontEnd({ codebooks: cb, coupling: true, referenceQuirks: false }), ref2 = new FrontEnd({ codebooks: cb, coupling: true, referenceQuirks: false });
+    for (const f of plainFrames) { gfe2.push(f); ref2.push(f); }
+    for (let t = 0; t < 4; t++) {
+        const a = gfe2.parseFrame({ config: { sampleIndex: SI } }), b = ref2.parseFrame({ config: { sampleIndex: SI } });
+        assert.deepStrictEqual(Array.from(a.q), Array.from(b.q)); assert.deepStrictEqual(Array.from(a.meta), Array.from(b.meta));
+    }
+    assert.deepStrictEqual(gfe2.stats, { deviceFrames: 4, cpuFrames: 0 });
 }
 console.log('coupling ' + mode + ' tests ok');
