@@ -97,6 +97,25 @@ def test_pipeline_batches_in_flight_equal_batches_one_at_a_time(lanes, F):
     o.close()
 
 
+def test_pipeline_at_the_benchmarked_batch_size_equals_the_reference_on_every_stream():
+    """256 streams x 16 frames per batch (BASELINE config 2's batch: 4096 stereo frames), the next batch (the stream's last two
+    frames) in flight behind it, into page-locked memory: every one of the 256 streams equals what the reference decoded."""
+    case = CASES[0]
+    data, table, refpcm = load(case)
+    n, S = case["frames"], 256
+    p = aacgpu.Pipeline(channels=2, max_streams=S, max_frames=16)
+    shapes = [(0, 16), (16, n - 16)]
+    bufs = [p.pinned(S * F * 2048, np.float32) for _, F in shapes]
+    tickets = [p.submit(data, np.tile(table[a:a + F], S), np.arange(S), F, pcm=bufs[i]) for i, (a, F) in enumerate(shapes)]
+    for (a, F), t in zip(shapes, tickets):
+        pcm, res, refused = p.collect(t)
+        assert refused == 0 and not res["status"].any()
+        pcm = pcm.reshape(S, F * 2048)
+        assert np.array_equal(pcm.view(np.uint32), np.tile(pcm[:1].view(np.uint32), (S, 1)))      # 256 slots, one stream: one result
+        close_to(pcm[0], refpcm[a * 2048:(a + F) * 2048])
+    p.close()
+
+
 def test_large_page_locked_blocks_take_the_pcm_like_small_ones():
     """aacg_host_alloc: blocks of 8 MiB and more are fresh huge pages faulted in by a few threads and registered (round 6: 0.6 ms
     per 32 MiB instead of 3.5-6); the PCM that comes down into one equals the PCM that comes down into pageable memory, the block
