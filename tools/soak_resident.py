@@ -69,7 +69,6 @@ while time.time() - t0 < budget:
     data = np.concatenate([m["data"] for m in chosen])
     usable = [m["e"]["decoded"] + (1 if m["e"]["error"] else 0) for m in chosen]      # frames of each stream that go in
     pos = [0] * S                                   # next frame of each stream
-    state_from = [0] * S                            # the frame the stream's overlap state started from (0, or where it was reset to 0)
     pending = []
     def submit():
         F = int(rng.integers(1, Fmax + 1))
@@ -80,13 +79,13 @@ while time.time() - t0 < budget:
         for s in range(S):
             fr[s * F:(s + 1) * F] = chosen[s]["table"][pos[s]:pos[s] + F]
             fr["byte_offset"][s * F:(s + 1) * F] += base[s]
-        pending.append((pipe.submit(data, fr, np.arange(S), F), F, list(pos), list(state_from)))
+        pending.append((pipe.submit(data, fr, np.arange(S), F), F, list(pos)))
         for s in range(S):
             pos[s] += F
         return True
     def collect():
         global batches, frames, refused_frames, worst
-        t, F, at, started = pending.pop(0)
+        t, F, at = pending.pop(0)
         pcm, res, refused = pipe.collect(t)
         pcm = pcm.reshape(S, F, 1024 * C)
         n_bad = 0
@@ -102,8 +101,6 @@ while time.time() - t0 < budget:
                     n_bad += 1
                     continue
                 assert st == 0, (m["e"]["name"], k, st)
-                if started[s] != 0:
-                    continue                                                # after a reset mid-stream the oracle's frames do not apply
                 want = m["ref"][k]
                 got = pcm[s, f].astype(np.float64) / (32768.0 if i16 else 1.0)
                 if i16:
@@ -131,8 +128,7 @@ while time.time() - t0 < budget:
         if alive and not pending and rng.random() < 0.05:                   # nothing in flight: a stream starts over
             s = int(rng.integers(0, S))
             pipe.reset_stream(s)
-            pos[s] = 0
-            state_from[s] = 0
+            pos[s] = 0                                                      # (a reset stream starts over at its frame 0: the oracle's frames apply again)
             resets += 1
     pipe.close()
     rounds += 1
